@@ -1,0 +1,397 @@
+"""bitmagic_amd -- MI355X-native bm::bvector<> / bm::aggregator<> hot path.
+
+Python mirror of the reference's operator interface for this path (same names,
+argument meaning and error behaviour), layered on the C-ABI of include/bmx.h:
+
+    reference (C++)                                this package
+    ---------------------------------------------  -------------------------------------------
+    bm::bvector<>                  src/bm.h:113     bvector
+      bit_and/bit_or/bit_xor/bit_sub(a, b, opt)     bvector.bit_and(a, b, opt) ...  (static, 3-operand)
+      count()                       :2431           bvector.count()
+      build_rs_index(&rs)           :2531           bvector.build_rs_index() -> rs_index
+      count_to / rank(n, rs)        :3120,1449      bvector.count_to(n, rs) / rank(n, rs)
+      select(rank, pos, rs)         :5350           bvector.select(rank, rs) -> (found, pos)
+    bm::bit_import_u32             src/bmbvimport.h bit_import_u32(ctx, words, optimize)
+    bm::count_and/or/xor/sub       src/bmalgo.h     count_and(a, b) ...
+    bm::aggregator<bvector<>>      src/bmaggregator.h:120
+      add / reset / combine_or / combine_and /      aggregator.add / reset / combine_or /
+      combine_and_sub                               combine_and / combine_and_sub
+      pipeline<agg_opt_only_counts> :222            aggregator.pipeline (add().add(bv, grp), complete())
+      combine_and_sub(pipe)         :1292           aggregator.combine_and_sub(pipe)
+
+The data path is the HIP library only; there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Iterable, Sequence
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import BmxError, check, lib  # noqa: F401
+from .sharding import shard_range, allreduce_counts  # noqa: F401
+
+NULL, FULL, BIT, GAP = 0, 1, 2, 3
+AND, OR, XOR, SUB = 0, 1, 2, 3
+BLOCK_WORDS, BLOCK_BITS = 2048, 65536
+opt_none, opt_compress = 0, 3        # bvector::optmode (src/bm.h:129-135)
+ID_MAX = 0xFFFFFFFF                  # bm::id_max (src/bmconst.h:109)
+
+__all__ = ["context", "bvector", "aggregator", "rs_index", "bit_import_u32", "count_and", "count_or",
+           "count_xor", "count_sub", "BmxError", "simd_version", "device_count"]
+
+
+def simd_version() -> int:
+    return lib().bmx_simd_version()
+
+
+def device_count() -> int:
+    n = C.c_int()
+    check(lib().bmx_device_count(C.byref(n)))
+    return n.value
+
+
+def _ptr(a: np.ndarray | None):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class context:
+    """One device + one HIP stream (bmx_ctx).  `stream` may be a raw hipStream_t
+    (e.g. torch.cuda.current_stream().cuda_stream) so torch events see the kernels."""
+
+    def __init__(self, device: int = 0, stream: int | None = None):
+        self._h = C.c_void_p()
+        check(lib().bmx_ctx_create(device, C.c_void_p(stream) if stream else None, C.byref(self._h)))
+        self.device = device
+
+    def close(self):
+        if self._h:
+            lib().bmx_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        check(lib().bmx_ctx_synchronize(self._h))
+
+    def mem_used(self) -> int:
+        b = C.c_uint64()
+        check(lib().bmx_ctx_mem_used(self._h, C.byref(b)))
+        return b.value
+
+    def timer_start(self):
+        check(lib().bmx_timer_start(self._h))
+
+    def timer_stop_ms(self) -> float:
+        ms = C.c_float()
+        check(lib().bmx_timer_stop_ms(self._h, C.byref(ms)))
+        return ms.value
+
+
+class bvector:
+    """Device-resident, immutable bit-vector (block table + slabs in HBM)."""
+
+    def __init__(self, ctx: context, handle: C.c_void_p):
+        self.ctx, self._h = ctx, handle
+
+    def __del__(self):
+        try:
+            if self._h and self.ctx._h:
+                lib().bmx_vec_free(self.ctx._h, self._h)
+            self._h = None
+        except Exception:
+            pass
+
+    # ---- construction -----------------------------------------------------
+    @staticmethod
+    def from_block_table(ctx: context, nbits: int, kinds, offs, bit_slab, gap_slab) -> "bvector":
+        """bmx_vec_upload: the flattened walk of blocks_manager::top_blocks_root()."""
+        kinds = np.ascontiguousarray(kinds, np.uint8)
+        offs = np.ascontiguousarray(offs, np.uint32)
+        bit_slab = np.ascontiguousarray(bit_slab, np.uint32)
+        gap_slab = np.ascontiguousarray(gap_slab, np.uint16)
+        h = C.c_void_p()
+        check(lib().bmx_vec_upload(ctx._h, nbits, kinds.size, _ptr(kinds), _ptr(offs),
+                                   _ptr(bit_slab) if bit_slab.size else None, bit_slab.size // BLOCK_WORDS,
+                                   _ptr(gap_slab) if gap_slab.size else None, gap_slab.size, C.byref(h)))
+        return bvector(ctx, h)
+
+    @staticmethod
+    def generate(ctx: context, seed: int, vec_id: int, density_q16: int, nbits: int,
+                 with_common: bool = False, optimize: bool = True) -> "bvector":
+        h = C.c_void_p()
+        check(lib().bmx_vec_generate(ctx._h, seed, vec_id, int(with_common), density_q16, nbits,
+                                     int(optimize), C.byref(h)))
+        return bvector(ctx, h)
+
+    # ---- inspection -------------------------------------------------------
+    def info(self):
+        nbits, nblocks, slab, gw = C.c_uint64(), C.c_uint32(), C.c_uint32(), C.c_uint64()
+        counts = (C.c_uint32 * 4)()
+        check(lib().bmx_vec_info(self._h, C.byref(nbits), C.byref(nblocks), counts, C.byref(slab), C.byref(gw)))
+        return {"nbits": nbits.value, "nblocks": nblocks.value, "counts": list(counts),
+                "bit_slab_blocks": slab.value, "gap_words": gw.value}
+
+    def size(self) -> int:
+        return self.info()["nbits"]
+
+    def calc_stat(self):
+        """bvector::calc_stat (src/bm.h:4010): bit_blocks / gap_blocks."""
+        i = self.info()
+        return {"bit_blocks": i["counts"][BIT], "gap_blocks": i["counts"][GAP],
+                "full_blocks": i["counts"][FULL], "null_blocks": i["counts"][NULL]}
+
+    def block_table(self):
+        """-> kinds, offs, bit_slab, gap_slab (bmx_vec_download)"""
+        i = self.info()
+        kinds = np.zeros(i["nblocks"], np.uint8)
+        offs = np.zeros(i["nblocks"], np.uint32)
+        bit_slab = np.zeros(i["bit_slab_blocks"] * BLOCK_WORDS, np.uint32)
+        gap_slab = np.zeros(i["gap_words"], np.uint16)
+        check(lib().bmx_vec_download(self.ctx._h, self._h, _ptr(kinds), _ptr(offs),
+                                     _ptr(bit_slab) if bit_slab.size else None,
+                                     _ptr(gap_slab) if gap_slab.size else None))
+        return kinds, offs, bit_slab, gap_slab
+
+    def to_words(self, nwords: int | None = None) -> np.ndarray:
+        if nwords is None:
+            nwords = self.info()["nblocks"] * BLOCK_WORDS
+        out = np.zeros(nwords, np.uint32)
+        if nwords:
+            check(lib().bmx_vec_to_words(self.ctx._h, self._h, _ptr(out), nwords))
+        return out
+
+    # ---- set algebra (3-operand forms, src/bm.h:6185,5973,6072,6403) -------
+    @staticmethod
+    def _op2(op, a: "bvector", b: "bvector", opt_mode: int) -> "bvector":
+        h = C.c_void_p()
+        check(lib().bmx_op2(a.ctx._h, op, a._h, b._h, int(opt_mode == opt_compress), C.byref(h)))
+        return bvector(a.ctx, h)
+
+    @staticmethod
+    def bit_and(a, b, opt_mode=opt_none):
+        return bvector._op2(AND, a, b, opt_mode)
+
+    @staticmethod
+    def bit_or(a, b, opt_mode=opt_none):
+        return bvector._op2(OR, a, b, opt_mode)
+
+    @staticmethod
+    def bit_xor(a, b, opt_mode=opt_none):
+        return bvector._op2(XOR, a, b, opt_mode)
+
+    @staticmethod
+    def bit_sub(a, b, opt_mode=opt_none):
+        return bvector._op2(SUB, a, b, opt_mode)
+
+    def count(self) -> int:
+        c = C.c_uint64()
+        check(lib().bmx_count(self.ctx._h, self._h, C.byref(c)))
+        return c.value
+
+    # ---- rank / select ----------------------------------------------------
+    def build_rs_index(self) -> "rs_index":
+        h = C.c_void_p()
+        check(lib().bmx_rs_build(self.ctx._h, self._h, C.byref(h)))
+        return rs_index(self, h)
+
+    def count_to(self, n, rs: "rs_index"):
+        """ones in [0..n] inclusive; scalar or array of positions"""
+        arr = np.ascontiguousarray(np.atleast_1d(n), np.uint64)
+        out = np.zeros(arr.shape, np.uint64)
+        if arr.size:
+            check(lib().bmx_rank_batch(self.ctx._h, self._h, rs._h, _ptr(arr), arr.size, _ptr(out)))
+        return int(out[0]) if np.isscalar(n) else out
+
+    rank = count_to
+
+    def select(self, rank, rs: "rs_index"):
+        """-> (found, pos); rank is 1-based (src/bm.h:5350)"""
+        arr = np.ascontiguousarray(np.atleast_1d(rank), np.uint64)
+        pos = np.zeros(arr.shape, np.uint64)
+        found = np.zeros(arr.shape, np.uint8)
+        if arr.size:
+            check(lib().bmx_select_batch(self.ctx._h, self._h, rs._h, _ptr(arr), arr.size, _ptr(pos), _ptr(found)))
+        if np.isscalar(rank):
+            return bool(found[0]), int(pos[0])
+        return found.astype(bool), pos
+
+
+class rs_index:
+    """bm::rs_index (src/bmrs.h:39): built on the device, exportable in the reference's layout."""
+
+    def __init__(self, bv: bvector, handle):
+        self.bv, self.ctx, self._h = bv, bv.ctx, handle
+
+    def __del__(self):
+        try:
+            if self._h and self.ctx._h:
+                lib().bmx_rs_free(self.ctx._h, self._h)
+            self._h = None
+        except Exception:
+            pass
+
+    def count(self) -> int:
+        c = C.c_uint64()
+        check(lib().bmx_rs_count(self._h, C.byref(c)))
+        return c.value
+
+    def export(self):
+        """-> bcount[nb], sub_count[nb] (first | second<<16 | aux0<<32 | aux1<<48)"""
+        n = self.bv.info()["nblocks"]
+        bc = np.zeros(n, np.uint32)
+        sub = np.zeros(n, np.uint64)
+        if n:
+            check(lib().bmx_rs_export(self.ctx._h, self._h, _ptr(bc), _ptr(sub)))
+        return bc, sub
+
+
+def bit_import_u32(ctx: context, words, optimize: bool = True) -> bvector:
+    """bm::bit_import_u32(bv, words, nwords, optimize)  src/bmbvimport.h:46"""
+    words = np.ascontiguousarray(words, np.uint32)
+    h = C.c_void_p()
+    check(lib().bmx_vec_import_bits(ctx._h, _ptr(words) if words.size else None, words.size, int(optimize), C.byref(h)))
+    return bvector(ctx, h)
+
+
+def _count_op2(op, a: bvector, b: bvector) -> int:
+    c = C.c_uint64()
+    check(lib().bmx_count_op2(a.ctx._h, op, a._h, b._h, C.byref(c)))
+    return c.value
+
+
+def count_and(a, b): return _count_op2(AND, a, b)      # src/bmalgo.h:49
+def count_or(a, b): return _count_op2(OR, a, b)        # :149
+def count_xor(a, b): return _count_op2(XOR, a, b)      # :81
+def count_sub(a, b): return _count_op2(SUB, a, b)      # :115
+
+
+def _handles(vecs: Sequence[bvector]):
+    arr = (C.c_void_p * max(len(vecs), 1))()
+    for i, v in enumerate(vecs):
+        arr[i] = v._h
+    return arr
+
+
+class arg_groups:
+    """aggregator::arg_groups (src/bmaggregator.h:2925): group 0 = AND, group 1 = SUB."""
+
+    def __init__(self):
+        self.arg_bv0: list[bvector] = []
+        self.arg_bv1: list[bvector] = []
+
+    def add(self, bv: bvector | None, agr_group: int = 0) -> int:
+        if agr_group > 1:
+            raise BmxError(_ffi.ERR_RANGE, "BMX-03: Incorrect range or index", "agr_group > 1")   # BM_ERR_RANGE :2934
+        if bv is None:                       # ignored, :2939-2947
+            return 0
+        (self.arg_bv1 if agr_group else self.arg_bv0).append(bv)
+        return len(self.arg_bv1 if agr_group else self.arg_bv0)
+
+    def reset(self):
+        self.arg_bv0.clear()
+        self.arg_bv1.clear()
+
+
+class pipeline:
+    """aggregator::pipeline<agg_opt_only_counts> (src/bmaggregator.h:222-341)."""
+
+    def __init__(self, ctx: context):
+        self.ctx = ctx
+        self.groups: list[arg_groups] = []
+        self._h = None
+        self._counts: np.ndarray | None = None
+
+    def add(self) -> arg_groups:
+        if self._h:
+            raise RuntimeError("pipeline already complete()")
+        g = arg_groups()
+        self.groups.append(g)
+        return g
+
+    def size(self) -> int:
+        return len(self.groups)
+
+    def complete(self):
+        and_list = [v for g in self.groups for v in g.arg_bv0]
+        sub_list = [v for g in self.groups for v in g.arg_bv1]
+        and_n = (C.c_uint32 * max(len(self.groups), 1))(*[len(g.arg_bv0) for g in self.groups])
+        sub_n = (C.c_uint32 * max(len(self.groups), 1))(*[len(g.arg_bv1) for g in self.groups])
+        h = C.c_void_p()
+        check(lib().bmx_pipeline_create(self.ctx._h, _handles(and_list), and_n, _handles(sub_list), sub_n,
+                                        len(self.groups), C.byref(h)))
+        self._h = h
+
+    def is_complete(self) -> bool:
+        return self._h is not None
+
+    def get_bv_count_vector(self) -> np.ndarray:
+        return self._counts
+
+    def operand_bytes(self, nb_from: int = 0, nb_to: int = ID_MAX) -> int:
+        b = C.c_uint64()
+        check(lib().bmx_pipeline_operand_bytes(self.ctx._h, self._h, nb_from, nb_to, C.byref(b)))
+        return b.value
+
+    def __del__(self):
+        try:
+            if self._h and self.ctx._h:
+                lib().bmx_pipeline_destroy(self.ctx._h, self._h)
+            self._h = None
+        except Exception:
+            pass
+
+
+class aggregator:
+    """bm::aggregator<bvector<>> (src/bmaggregator.h:120)."""
+
+    pipeline = pipeline
+
+    def __init__(self, ctx: context):
+        self.ctx = ctx
+        self.ag = arg_groups()
+
+    def add(self, bv: bvector | None, agr_group: int = 0) -> int:       # :1013
+        return self.ag.add(bv, agr_group)
+
+    def reset(self):                                                     # :941
+        self.ag.reset()
+
+    def combine_or(self, bv_src: Iterable[bvector] | None = None) -> bvector:         # :1021 / :1101
+        src = list(bv_src) if bv_src is not None else self.ag.arg_bv0
+        h = C.c_void_p()
+        check(lib().bmx_agg_or(self.ctx._h, _handles(src), len(src), C.byref(h)))
+        return bvector(self.ctx, h)
+
+    def combine_and(self, bv_src: Iterable[bvector] | None = None) -> bvector:        # :1030 == combine_and_sub w/o SUB
+        src = list(bv_src) if bv_src is not None else self.ag.arg_bv0
+        return self.combine_and_sub(src, [])[0]
+
+    def combine_and_sub(self, bv_src_and=None, bv_src_sub=None):                         # :1044 / :1162 / :1292
+        """-> (target, any)  |  with a pipeline argument: runs it, counts in pipe.get_bv_count_vector()"""
+        if isinstance(bv_src_and, pipeline):
+            return self._run_pipeline(bv_src_and)
+        a = list(bv_src_and) if bv_src_and is not None else self.ag.arg_bv0
+        s = list(bv_src_sub) if bv_src_sub is not None else self.ag.arg_bv1
+        h = C.c_void_p()
+        any_ = C.c_int()
+        check(lib().bmx_agg_and_sub(self.ctx._h, _handles(a), len(a), _handles(s), len(s), C.byref(h), C.byref(any_)))
+        return bvector(self.ctx, h), bool(any_.value)
+
+    def _run_pipeline(self, pipe: pipeline, nb_from: int = 0, nb_to: int = ID_MAX):
+        if not pipe.is_complete():
+            raise RuntimeError("pipeline is not complete()")
+        out = np.zeros(max(pipe.size(), 1), np.uint64)
+        check(lib().bmx_pipeline_run_counts(self.ctx._h, pipe._h, nb_from, nb_to,
+                                            out.ctypes.data_as(C.POINTER(C.c_uint64))))
+        pipe._counts = out[:pipe.size()]
+        return pipe._counts
+
+    def run_counts_dev(self, pipe: pipeline, d_counts_ptr: int, nb_from: int = 0, nb_to: int = ID_MAX):
+        """asynchronous run; counts land in device memory (e.g. a torch tensor's data_ptr())"""
+        check(lib().bmx_pipeline_run_counts_dev(self.ctx._h, pipe._h, nb_from, nb_to, C.c_void_p(d_counts_ptr)))

@@ -1,0 +1,837 @@
+// bmx.hip -- C-ABI (include/bmx.h) of the MI355X-native bit-vector engine.
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared bmx.hip -o libbmx.so
+#include "../../include/bmx.h"
+#include "bmx_kernels2.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+// ---------------------------------------------------------------------------
+// error plumbing: no exception crosses the ABI (lang-maps/libbm conventions)
+// ---------------------------------------------------------------------------
+static thread_local std::string g_last_error;
+
+static int fail_hip(hipError_t e, const char* what, int line)
+{
+    char buf[512];
+    snprintf(buf, sizeof(buf), "%s failed at bmx.hip:%d: %s", what, line, hipGetErrorString(e));
+    g_last_error = buf;
+    return e == hipErrorOutOfMemory ? BMX_ERR_BADALLOC : BMX_ERR_DEVICE;
+}
+#define HIPCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail_hip(e_, #call, __LINE__); } while (0)
+#define ARGCHK(cond) do { if (!(cond)) { g_last_error = "bad argument: " #cond; return BMX_ERR_BADARG; } } while (0)
+#define KCHK() HIPCHK(hipGetLastError())
+
+struct bmx_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    uint64_t mem_used = 0;
+    // grow-only scratch
+    void* scratch = nullptr; size_t scratch_bytes = 0;      // raw block slab for import/generate
+    void* aux = nullptr; size_t aux_bytes = 0;              // stats / offsets / totals
+    u64* d_small = nullptr;                                 // 64 x u64 result words
+    u64* h_small = nullptr;                                 // pinned mirror
+    int pipe_unroll = 2;
+    int xcd_swz = 1;
+};
+
+struct bmx_vec {
+    bmx_ctx* ctx;
+    uint64_t nbits; uint32_t nblocks;
+    uint32_t counts[4]; uint64_t gap_words; uint32_t n_bit;
+    u64* d_desc; uint4* d_bits; u16* d_gaps;
+    size_t bytes;
+};
+
+struct bmx_pipeline {
+    bmx_ctx* ctx;
+    uint32_t ngroups, ncols, col_stride, n_ops;
+    bool has_gap;
+    u64* d_dmat;
+    u32* d_meta;       // row_off | and_n | sub_n | and_off | sub_off (ngroups each) | nblocks (n_ops)
+    const u64** d_descs;
+    size_t bytes;
+};
+
+struct bmx_rs {
+    bmx_ctx* ctx;
+    uint32_t nblocks; uint64_t count;
+    u32* d_bcount; u64* d_sub; u64* d_rcount; u16* d_cum;
+    size_t bytes;
+};
+
+static int set_dev(const bmx_ctx* ctx) { HIPCHK(hipSetDevice(ctx->device)); return BMX_OK; }
+
+static int dmalloc(bmx_ctx* ctx, void** p, size_t bytes)
+{
+    *p = nullptr;
+    if (!bytes) bytes = 16;
+    HIPCHK(hipMalloc(p, bytes));
+    ctx->mem_used += bytes;
+    return BMX_OK;
+}
+static void dfree(bmx_ctx* ctx, void* p, size_t bytes) { if (p) { (void)hipFree(p); ctx->mem_used -= std::min<uint64_t>(ctx->mem_used, bytes ? bytes : 16); } }
+
+static int ensure(bmx_ctx* ctx, void** buf, size_t* cur, size_t need)
+{
+    if (*cur >= need) return BMX_OK;
+    if (*buf) { HIPCHK(hipStreamSynchronize(ctx->stream)); (void)hipFree(*buf); *buf = nullptr; *cur = 0; }
+    HIPCHK(hipMalloc(buf, need));
+    *cur = need;
+    return BMX_OK;
+}
+
+extern "C" {
+
+const char* bmx_error_msg(int status)
+{
+    switch (status) {
+    case BMX_OK: return "BMX-00: All correct";
+    case BMX_ERR_BADALLOC: return "BMX-01: Allocation error (HBM or host)";
+    case BMX_ERR_BADARG: return "BMX-02: Invalid or missing function argument";
+    case BMX_ERR_RANGE: return "BMX-03: Incorrect range or index";
+    case BMX_ERR_DEVICE: return "BMX-04: No usable gfx950 device or HIP runtime failure";
+    default: return "BMX-XX: Unknown error";
+    }
+}
+const char* bmx_last_error(void) { return g_last_error.c_str(); }
+int bmx_simd_version(void) { return 950; }
+
+int bmx_device_count(int* n)
+{
+    ARGCHK(n);
+    *n = 0;
+    HIPCHK(hipGetDeviceCount(n));
+    return BMX_OK;
+}
+
+int bmx_ctx_create(int device, void* stream, bmx_ctx** out)
+{
+    ARGCHK(out);
+    *out = nullptr;
+    int n = 0;
+    HIPCHK(hipGetDeviceCount(&n));
+    if (device < 0 || device >= n) { g_last_error = "device index out of range"; return BMX_ERR_RANGE; }
+    HIPCHK(hipSetDevice(device));
+    bmx_ctx* ctx = new (std::nothrow) bmx_ctx();
+    if (!ctx) return BMX_ERR_BADALLOC;
+    ctx->device = device;
+    if (stream) ctx->stream = (hipStream_t)stream;
+    else { HIPCHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)); ctx->own_stream = true; }
+    HIPCHK(hipEventCreate(&ctx->ev0));
+    HIPCHK(hipEventCreate(&ctx->ev1));
+    HIPCHK(hipMalloc((void**)&ctx->d_small, 64 * sizeof(u64)));
+    HIPCHK(hipHostMalloc((void**)&ctx->h_small, 64 * sizeof(u64)));
+    if (const char* e = getenv("BMX_PIPE_UNROLL")) ctx->pipe_unroll = atoi(e);
+    if (const char* e = getenv("BMX_XCD_SWIZZLE")) ctx->xcd_swz = atoi(e);
+    *out = ctx;
+    return BMX_OK;
+}
+
+int bmx_ctx_destroy(bmx_ctx* ctx)
+{
+    if (!ctx) return BMX_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->scratch) (void)hipFree(ctx->scratch);
+    if (ctx->aux) (void)hipFree(ctx->aux);
+    if (ctx->d_small) (void)hipFree(ctx->d_small);
+    if (ctx->h_small) (void)hipHostFree(ctx->h_small);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return BMX_OK;
+}
+
+int bmx_ctx_synchronize(bmx_ctx* ctx)
+{
+    ARGCHK(ctx);
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return BMX_OK;
+}
+
+int bmx_ctx_mem_used(const bmx_ctx* ctx, uint64_t* bytes)
+{
+    ARGCHK(ctx && bytes);
+    *bytes = ctx->mem_used;
+    return BMX_OK;
+}
+
+int bmx_timer_start(bmx_ctx* ctx) { ARGCHK(ctx); HIPCHK(hipEventRecord(ctx->ev0, ctx->stream)); return BMX_OK; }
+int bmx_timer_stop_ms(bmx_ctx* ctx, float* ms)
+{
+    ARGCHK(ctx && ms);
+    HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
+    HIPCHK(hipEventSynchronize(ctx->ev1));
+    HIPCHK(hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
+    return BMX_OK;
+}
+
+// ---------------------------------------------------------------------------
+// vectors
+// ---------------------------------------------------------------------------
+static bmx_vec* vec_alloc_host(bmx_ctx* ctx, uint64_t nbits, uint32_t nblocks)
+{
+    bmx_vec* v = new (std::nothrow) bmx_vec();
+    if (!v) return nullptr;
+    memset(v, 0, sizeof(*v));
+    v->ctx = ctx; v->nbits = nbits; v->nblocks = nblocks;
+    return v;
+}
+
+static int vec_alloc_device(bmx_vec* v, uint32_t n_bit, uint64_t gap_words)
+{
+    bmx_ctx* ctx = v->ctx;
+    int rc;
+    v->n_bit = n_bit; v->gap_words = gap_words;
+    size_t b_desc = (size_t)std::max<uint32_t>(v->nblocks, 1) * 8, b_bits = (size_t)n_bit * 8192, b_gaps = (size_t)gap_words * 2;
+    if ((rc = dmalloc(ctx, (void**)&v->d_desc, b_desc))) return rc;
+    if ((rc = dmalloc(ctx, (void**)&v->d_bits, b_bits))) return rc;
+    if ((rc = dmalloc(ctx, (void**)&v->d_gaps, b_gaps))) return rc;
+    v->bytes = std::max<size_t>(b_desc, 16) + std::max<size_t>(b_bits, 16) + std::max<size_t>(b_gaps, 16);
+    return BMX_OK;
+}
+
+int bmx_vec_free(bmx_ctx* ctx, bmx_vec* v)
+{
+    if (!v) return BMX_OK;
+    ARGCHK(ctx && v->ctx == ctx);
+    int rc = set_dev(ctx); if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (v->d_desc) (void)hipFree(v->d_desc);
+    if (v->d_bits) (void)hipFree(v->d_bits);
+    if (v->d_gaps) (void)hipFree(v->d_gaps);
+    ctx->mem_used -= std::min<uint64_t>(ctx->mem_used, v->bytes);
+    delete v;
+    return BMX_OK;
+}
+
+int bmx_vec_upload(bmx_ctx* ctx, uint64_t nbits, uint32_t nblocks,
+                   const uint8_t* kinds, const uint32_t* offs,
+                   const uint32_t* bit_slab, uint32_t n_bit_blocks,
+                   const uint16_t* gap_slab, uint64_t gap_words, bmx_vec** out)
+{
+    ARGCHK(ctx && out && (nblocks == 0 || (kinds && offs)));
+    ARGCHK(n_bit_blocks == 0 || bit_slab);
+    ARGCHK(gap_words == 0 || gap_slab);
+    *out = nullptr;
+    int rc = set_dev(ctx); if (rc) return rc;
+    bmx_vec* v = vec_alloc_host(ctx, nbits, nblocks);
+    if (!v) return BMX_ERR_BADALLOC;
+    if ((rc = vec_alloc_device(v, n_bit_blocks, gap_words))) { bmx_vec_free(ctx, v); return rc; }
+    std::vector<u64> desc(std::max<uint32_t>(nblocks, 1), 0);
+    for (uint32_t nb = 0; nb < nblocks; ++nb) {
+        uint8_t k = kinds[nb];
+        if (k > BMX_GAP) { bmx_vec_free(ctx, v); g_last_error = "bad block kind"; return BMX_ERR_BADARG; }
+        v->counts[k]++;
+        if (k == BMX_BIT) {
+            if (offs[nb] >= n_bit_blocks) { bmx_vec_free(ctx, v); return BMX_ERR_RANGE; }
+            desc[nb] = DESC_MAKE(v->d_bits + (size_t)offs[nb] * 512u, K_BIT);
+        } else if (k == BMX_GAP) {
+            uint64_t o = offs[nb];
+            if (o >= gap_words || o + (gap_slab[o] >> 3) + 1u > gap_words) { bmx_vec_free(ctx, v); return BMX_ERR_RANGE; }
+            desc[nb] = DESC_MAKE(v->d_gaps + o, K_GAP);
+        } else desc[nb] = DESC_MAKE(0, k);
+    }
+    HIPCHK(hipMemcpyAsync(v->d_desc, desc.data(), (size_t)nblocks * 8, hipMemcpyHostToDevice, ctx->stream));
+    if (n_bit_blocks) HIPCHK(hipMemcpyAsync(v->d_bits, bit_slab, (size_t)n_bit_blocks * 8192, hipMemcpyHostToDevice, ctx->stream));
+    if (gap_words) HIPCHK(hipMemcpyAsync(v->d_gaps, gap_slab, (size_t)gap_words * 2, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    *out = v;
+    return BMX_OK;
+}
+
+// raw block slab (in ctx->scratch, nblocks x 8 KiB) -> classified / compressed vector
+static int vec_from_raw(bmx_ctx* ctx, uint64_t nbits, uint32_t nblocks, int optimize, bmx_vec** out)
+{
+    int rc;
+    size_t aux_need = (size_t)nblocks * (sizeof(BlockStat) + 4) + 64;
+    if ((rc = ensure(ctx, &ctx->aux, &ctx->aux_bytes, aux_need))) return rc;
+    BlockStat* st = (BlockStat*)ctx->aux;
+    u32* offs = (u32*)((char*)ctx->aux + (size_t)nblocks * sizeof(BlockStat));
+    const uint4* raw = (const uint4*)ctx->scratch;
+    bmx_vec* v = vec_alloc_host(ctx, nbits, nblocks);
+    if (!v) return BMX_ERR_BADALLOC;
+    if (nblocks) {
+        hipLaunchKernelGGL(k_block_stats, dim3((nblocks + 3) / 4), dim3(256), 0, ctx->stream, raw, nblocks, optimize, st);
+        KCHK();
+        hipLaunchKernelGGL(k_scan_layout, dim3(1), dim3(1024), 0, ctx->stream, st, nblocks, offs, ctx->d_small);
+        KCHK();
+        HIPCHK(hipMemcpyAsync(ctx->h_small, ctx->d_small, 6 * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+    } else memset(ctx->h_small, 0, 6 * sizeof(u64));
+    uint32_t n_bit = (uint32_t)ctx->h_small[0]; uint64_t gap_words = ctx->h_small[1];
+    for (int k = 0; k < 4; ++k) v->counts[k] = (uint32_t)ctx->h_small[2 + k];
+    if ((rc = vec_alloc_device(v, n_bit, gap_words))) { bmx_vec_free(ctx, v); return rc; }
+    if (nblocks) {
+        hipLaunchKernelGGL(k_emit_blocks, dim3((nblocks + 3) / 4), dim3(256), 0, ctx->stream,
+                           raw, nblocks, st, offs, v->d_bits, v->d_gaps, v->d_desc);
+        KCHK();
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
+    *out = v;
+    return BMX_OK;
+}
+
+int bmx_vec_import_bits(bmx_ctx* ctx, const uint32_t* words, uint64_t nwords, int optimize, bmx_vec** out)
+{
+    ARGCHK(ctx && out && (nwords == 0 || words));
+    *out = nullptr;
+    int rc = set_dev(ctx); if (rc) return rc;
+    uint64_t nblocks64 = (nwords + BMX_BLOCK_WORDS - 1) / BMX_BLOCK_WORDS;
+    if (nblocks64 > 65536ull * 16) { g_last_error = "vector too long"; return BMX_ERR_RANGE; }
+    uint32_t nblocks = (uint32_t)nblocks64;
+    size_t raw_bytes = (size_t)nblocks * 8192;
+    if ((rc = ensure(ctx, &ctx->scratch, &ctx->scratch_bytes, std::max<size_t>(raw_bytes, 8192)))) return rc;
+    if (nwords) HIPCHK(hipMemcpyAsync(ctx->scratch, words, nwords * 4, hipMemcpyHostToDevice, ctx->stream));
+    if (raw_bytes > nwords * 4)
+        HIPCHK(hipMemsetAsync((char*)ctx->scratch + nwords * 4, 0, raw_bytes - nwords * 4, ctx->stream));
+    return vec_from_raw(ctx, nwords * 32ull, nblocks, optimize, out);
+}
+
+int bmx_vec_generate(bmx_ctx* ctx, uint64_t seed, uint32_t vec_id, int with_common,
+                     uint32_t density_q16, uint64_t nbits, int optimize, bmx_vec** out)
+{
+    ARGCHK(ctx && out && density_q16 <= 65536u);
+    *out = nullptr;
+    int rc = set_dev(ctx); if (rc) return rc;
+    uint64_t nblocks64 = (nbits + BMX_BLOCK_BITS - 1) / BMX_BLOCK_BITS;
+    if (nblocks64 > 65536ull * 16) { g_last_error = "vector too long"; return BMX_ERR_RANGE; }
+    uint32_t nblocks = (uint32_t)nblocks64;
+    size_t raw_bytes = (size_t)nblocks * 8192;
+    if ((rc = ensure(ctx, &ctx->scratch, &ctx->scratch_bytes, std::max<size_t>(raw_bytes, 8192)))) return rc;
+    u64 nwords64 = (u64)nblocks * 1024u;
+    if (nwords64) {
+        u32 grid = (u32)std::min<u64>((nwords64 + 255) / 256, 256u * 32u);
+        hipLaunchKernelGGL(k_generate, dim3(grid), dim3(256), 0, ctx->stream, seed, vec_id, with_common,
+                           density_q16, nbits, (u64*)ctx->scratch, nwords64);
+        KCHK();
+    }
+    return vec_from_raw(ctx, nbits, nblocks, optimize, out);
+}
+
+int bmx_vec_info(const bmx_vec* v, uint64_t* nbits, uint32_t* nblocks, uint32_t counts[4],
+                 uint32_t* bit_slab_blocks, uint64_t* gap_words)
+{
+    ARGCHK(v);
+    if (nbits) *nbits = v->nbits;
+    if (nblocks) *nblocks = v->nblocks;
+    if (counts) memcpy(counts, v->counts, sizeof(v->counts));
+    if (bit_slab_blocks) *bit_slab_blocks = v->n_bit;
+    if (gap_words) *gap_words = v->gap_words;
+    return BMX_OK;
+}
+
+int bmx_vec_download(bmx_ctx* ctx, const bmx_vec* v, uint8_t* kinds, uint32_t* offs,
+                     uint32_t* bit_slab, uint16_t* gap_slab)
+{
+    ARGCHK(ctx && v && v->ctx == ctx);
+    int rc = set_dev(ctx); if (rc) return rc;
+    if (kinds || offs) {
+        std::vector<u64> desc(std::max<uint32_t>(v->nblocks, 1));
+        HIPCHK(hipMemcpyAsync(desc.data(), v->d_desc, (size_t)v->nblocks * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        for (uint32_t nb = 0; nb < v->nblocks; ++nb) {
+            u32 k = DESC_K(desc[nb]);
+            if (kinds) kinds[nb] = (uint8_t)k;
+            if (offs) {
+                if (k == K_BIT) offs[nb] = (uint32_t)((DESC_P(desc[nb]) - (u64)(uintptr_t)v->d_bits) / 8192u);
+                else if (k == K_GAP) offs[nb] = (uint32_t)((DESC_P(desc[nb]) - (u64)(uintptr_t)v->d_gaps) / 2u);
+                else offs[nb] = 0;
+            }
+        }
+    }
+    if (bit_slab && v->n_bit) HIPCHK(hipMemcpyAsync(bit_slab, v->d_bits, (size_t)v->n_bit * 8192, hipMemcpyDeviceToHost, ctx->stream));
+    if (gap_slab && v->gap_words) HIPCHK(hipMemcpyAsync(gap_slab, v->d_gaps, (size_t)v->gap_words * 2, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return BMX_OK;
+}
+
+int bmx_vec_to_words(bmx_ctx* ctx, const bmx_vec* v, uint32_t* words, uint64_t nwords)
+{
+    ARGCHK(ctx && v && v->ctx == ctx && (nwords == 0 || words));
+    int rc = set_dev(ctx); if (rc) return rc;
+    if (!nwords) return BMX_OK;
+    uint32_t nb_out = (uint32_t)((nwords + BMX_BLOCK_WORDS - 1) / BMX_BLOCK_WORDS);
+    if ((rc = ensure(ctx, &ctx->scratch, &ctx->scratch_bytes, (size_t)nb_out * 8192))) return rc;
+    hipLaunchKernelGGL(k_vec_expand, dim3((nb_out + 3) / 4), dim3(256), 0, ctx->stream,
+                       v->d_desc, v->nblocks, nb_out, (uint4*)ctx->scratch);
+    KCHK();
+    HIPCHK(hipMemcpyAsync(words, ctx->scratch, nwords * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return BMX_OK;
+}
+
+int bmx_count(bmx_ctx* ctx, const bmx_vec* a, uint64_t* count)
+{
+    ARGCHK(ctx && a && count && a->ctx == ctx);
+    int rc = set_dev(ctx); if (rc) return rc;
+    HIPCHK(hipMemsetAsync(ctx->d_small, 0, 8, ctx->stream));
+    if (a->nblocks) {
+        hipLaunchKernelGGL(k_vec_count, dim3((a->nblocks + 3) / 4), dim3(256), 0, ctx->stream, a->d_desc, a->nblocks, ctx->d_small);
+        KCHK();
+    }
+    HIPCHK(hipMemcpyAsync(ctx->h_small, ctx->d_small, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    *count = ctx->h_small[0];
+    return BMX_OK;
+}
+
+// ---------------------------------------------------------------------------
+// pipeline
+// ---------------------------------------------------------------------------
+int bmx_pipeline_create(bmx_ctx* ctx, const bmx_vec* const* and_list, const uint32_t* and_n,
+                        const bmx_vec* const* sub_list, const uint32_t* sub_n,
+                        size_t ngroups, bmx_pipeline** out)
+{
+    ARGCHK(ctx && out && ngroups > 0 && ngroups < (1u << 20) && and_n && sub_n);
+    *out = nullptr;
+    int rc = set_dev(ctx); if (rc) return rc;
+    size_t tot_and = 0, tot_sub = 0;
+    for (size_t g = 0; g < ngroups; ++g) {
+        if (and_n[g] > 65535u || sub_n[g] > 65535u) { g_last_error = "more than 65535 operands in one arg-group"; return BMX_ERR_RANGE; }
+        tot_and += and_n[g]; tot_sub += sub_n[g];
+    }
+    ARGCHK(tot_and == 0 || and_list);
+    ARGCHK(tot_sub == 0 || sub_list);
+    size_t n_ops = tot_and + tot_sub;
+    std::vector<const u64*> descs(std::max<size_t>(n_ops, 1), nullptr);
+    std::vector<u32> meta(5 * ngroups + std::max<size_t>(n_ops, 1), 0);
+    u32* row_off = meta.data(); u32* m_and_n = row_off + ngroups; u32* m_sub_n = m_and_n + ngroups;
+    u32* and_off = m_sub_n + ngroups; u32* sub_off = and_off + ngroups; u32* nblk = sub_off + ngroups;
+    uint32_t ncols = 0, col_stride = 0; bool has_gap = false;
+    size_t ia = 0, is = 0;
+    for (size_t g = 0; g < ngroups; ++g) {
+        row_off[g] = col_stride; col_stride += 2 + and_n[g] + sub_n[g];
+        m_and_n[g] = and_n[g]; m_sub_n[g] = sub_n[g];
+        and_off[g] = (u32)ia; sub_off[g] = (u32)(tot_and + is);
+        for (uint32_t k = 0; k < and_n[g]; ++k, ++ia) {
+            const bmx_vec* v = and_list[ia];
+            if (!v || v->ctx != ctx) { g_last_error = "operand is null or belongs to another context"; return BMX_ERR_BADARG; }
+            descs[ia] = v->d_desc; nblk[ia] = v->nblocks; ncols = std::max(ncols, v->nblocks); has_gap |= v->counts[BMX_GAP] != 0;
+        }
+        for (uint32_t k = 0; k < sub_n[g]; ++k, ++is) {
+            const bmx_vec* v = sub_list[is];
+            if (!v || v->ctx != ctx) { g_last_error = "operand is null or belongs to another context"; return BMX_ERR_BADARG; }
+            descs[tot_and + is] = v->d_desc; nblk[tot_and + is] = v->nblocks; ncols = std::max(ncols, v->nblocks); has_gap |= v->counts[BMX_GAP] != 0;
+        }
+    }
+    bmx_pipeline* p = new (std::nothrow) bmx_pipeline();
+    if (!p) return BMX_ERR_BADALLOC;
+    memset(p, 0, sizeof(*p));
+    p->ctx = ctx; p->ngroups = (uint32_t)ngroups; p->ncols = ncols; p->col_stride = col_stride; p->n_ops = (uint32_t)n_ops; p->has_gap = has_gap;
+    size_t b_dmat = (size_t)std::max<uint32_t>(ncols, 1) * col_stride * 8, b_meta = meta.size() * 4, b_descs = descs.size() * 8;
+    if ((rc = dmalloc(ctx, (void**)&p->d_dmat, b_dmat)) || (rc = dmalloc(ctx, (void**)&p->d_meta, b_meta)) ||
+        (rc = dmalloc(ctx, (void**)&p->d_descs, b_descs))) { bmx_pipeline_destroy(ctx, p); return rc; }
+    p->bytes = b_dmat + b_meta + b_descs;
+    HIPCHK(hipMemcpyAsync(p->d_meta, meta.data(), b_meta, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(p->d_descs, descs.data(), b_descs, hipMemcpyHostToDevice, ctx->stream));
+    if (ncols) {
+        PipeOperands po;
+        po.desc = (const u64* const*)p->d_descs;
+        po.nblocks = p->d_meta + 5 * ngroups;
+        po.row_off = p->d_meta; po.and_n = p->d_meta + ngroups; po.sub_n = p->d_meta + 2 * ngroups;
+        po.and_off = p->d_meta + 3 * ngroups; po.sub_off = p->d_meta + 4 * ngroups;
+        u64 nthreads = (u64)ncols * ngroups;
+        hipLaunchKernelGGL(k_pipe_sort, dim3((u32)((nthreads + 255) / 256)), dim3(256), 0, ctx->stream,
+                           po, (u32)ngroups, ncols, col_stride, p->d_dmat);
+        KCHK();
+    }
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    *out = p;
+    return BMX_OK;
+}
+
+int bmx_pipeline_destroy(bmx_ctx* ctx, bmx_pipeline* p)
+{
+    if (!p) return BMX_OK;
+    ARGCHK(ctx && p->ctx == ctx);
+    int rc = set_dev(ctx); if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (p->d_dmat) (void)hipFree(p->d_dmat);
+    if (p->d_meta) (void)hipFree(p->d_meta);
+    if (p->d_descs) (void)hipFree((void*)p->d_descs);
+    ctx->mem_used -= std::min<uint64_t>(ctx->mem_used, p->bytes);
+    delete p;
+    return BMX_OK;
+}
+
+static int pipe_range(const bmx_pipeline* p, uint32_t& nb_from, uint32_t& nb_to)
+{
+    if (nb_to > p->ncols) nb_to = p->ncols;
+    if (nb_from > nb_to) { g_last_error = "nb_from > nb_to"; return BMX_ERR_RANGE; }
+    return BMX_OK;
+}
+
+int bmx_pipeline_run_counts_dev(bmx_ctx* ctx, bmx_pipeline* p, uint32_t nb_from, uint32_t nb_to, uint64_t* d_counts)
+{
+    ARGCHK(ctx && p && p->ctx == ctx && d_counts);
+    int rc = set_dev(ctx); if (rc) return rc;
+    if ((rc = pipe_range(p, nb_from, nb_to))) return rc;
+    HIPCHK(hipMemsetAsync(d_counts, 0, (size_t)p->ngroups * 8, ctx->stream));
+    u64 nitems64 = (u64)(nb_to - nb_from) * p->ngroups;
+    if (!nitems64) return BMX_OK;
+    if (nitems64 > 0xFFFFFFF0ull) { g_last_error = "too many (column, group) items in one run"; return BMX_ERR_RANGE; }
+    u32 nitems = (u32)nitems64;
+    u32 grid = (nitems + 3) / 4;
+    size_t lds = p->has_gap ? 4 * 2048 * 4 : 0;
+    const u32* row_off = p->d_meta; const u32* and_n = p->d_meta + p->ngroups; const u32* sub_n = p->d_meta + 2 * p->ngroups;
+#define LAUNCH_PIPE(U) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pipe_counts<U>), dim3(grid), dim3(256), lds, ctx->stream, \
+        p->d_dmat, row_off, and_n, sub_n, p->col_stride, p->ngroups, nb_from, nitems, ctx->xcd_swz, (u64*)d_counts)
+    switch (ctx->pipe_unroll) {
+    case 1: LAUNCH_PIPE(1); break;
+    case 4: LAUNCH_PIPE(4); break;
+    case 3: LAUNCH_PIPE(3); break;
+    default: LAUNCH_PIPE(2); break;
+    }
+#undef LAUNCH_PIPE
+    KCHK();
+    return BMX_OK;
+}
+
+int bmx_pipeline_run_counts(bmx_ctx* ctx, bmx_pipeline* p, uint32_t nb_from, uint32_t nb_to, uint64_t* counts_out)
+{
+    ARGCHK(ctx && p && p->ctx == ctx && counts_out);
+    int rc = set_dev(ctx); if (rc) return rc;
+    u64* d_counts = nullptr;
+    size_t bytes = (size_t)p->ngroups * 8;
+    if (p->ngroups <= 64) d_counts = ctx->d_small;
+    else HIPCHK(hipMalloc((void**)&d_counts, bytes));
+    rc = bmx_pipeline_run_counts_dev(ctx, p, nb_from, nb_to, d_counts);
+    if (!rc) {
+        hipError_t e = hipMemcpyAsync(counts_out, d_counts, bytes, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) rc = fail_hip(e, "counts readback", __LINE__);
+    }
+    if (p->ngroups > 64) (void)hipFree(d_counts);
+    return rc;
+}
+
+int bmx_pipeline_operand_bytes(bmx_ctx* ctx, bmx_pipeline* p, uint32_t nb_from, uint32_t nb_to, uint64_t* bytes)
+{
+    ARGCHK(ctx && p && p->ctx == ctx && bytes);
+    int rc = set_dev(ctx); if (rc) return rc;
+    if ((rc = pipe_range(p, nb_from, nb_to))) return rc;
+    *bytes = 0;
+    u64 nitems64 = (u64)(nb_to - nb_from) * p->ngroups;
+    if (!nitems64) return BMX_OK;
+    HIPCHK(hipMemsetAsync(ctx->d_small, 0, 8, ctx->stream));
+    hipLaunchKernelGGL(k_pipe_bytes, dim3((u32)((nitems64 + 255) / 256)), dim3(256), 0, ctx->stream,
+                       p->d_dmat, p->d_meta, p->d_meta + p->ngroups, p->d_meta + 2 * p->ngroups,
+                       p->col_stride, p->ngroups, nb_from, (u32)nitems64, ctx->d_small);
+    KCHK();
+    HIPCHK(hipMemcpyAsync(ctx->h_small, ctx->d_small, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    *bytes = ctx->h_small[0];
+    return BMX_OK;
+}
+
+} // extern "C"
+
+// ---------------------------------------------------------------------------
+// materialised results: full-size slab (one slot per block column), see
+// store_result() in bmx_kernels2.h
+// ---------------------------------------------------------------------------
+static int result_begin(bmx_ctx* ctx, uint64_t nbits, uint32_t nblocks, bmx_vec** out, BlockStat** st, u32** offs)
+{
+    int rc;
+    size_t aux_need = (size_t)nblocks * (sizeof(BlockStat) + 4) + 64;
+    if ((rc = ensure(ctx, &ctx->aux, &ctx->aux_bytes, aux_need))) return rc;
+    *st = (BlockStat*)ctx->aux;
+    *offs = (u32*)((char*)ctx->aux + (size_t)nblocks * sizeof(BlockStat));
+    bmx_vec* v = vec_alloc_host(ctx, nbits, nblocks);
+    if (!v) return BMX_ERR_BADALLOC;
+    size_t b_desc = (size_t)std::max<uint32_t>(nblocks, 1) * 8, b_bits = (size_t)nblocks * 8192;
+    if ((rc = dmalloc(ctx, (void**)&v->d_desc, b_desc)) || (rc = dmalloc(ctx, (void**)&v->d_bits, b_bits))) { bmx_vec_free(ctx, v); return rc; }
+    v->n_bit = nblocks;
+    v->bytes = std::max<size_t>(b_desc, 16) + std::max<size_t>(b_bits, 16);
+    *out = v;
+    return BMX_OK;
+}
+
+static int result_finish(bmx_ctx* ctx, bmx_vec* v, BlockStat* st, u32* offs)
+{
+    int rc;
+    uint32_t nblocks = v->nblocks;
+    if (!nblocks) return BMX_OK;
+    hipLaunchKernelGGL(k_scan_layout, dim3(1), dim3(1024), 0, ctx->stream, st, nblocks, offs, ctx->d_small);
+    KCHK();
+    HIPCHK(hipMemcpyAsync(ctx->h_small, ctx->d_small, 6 * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    uint64_t gap_words = ctx->h_small[1];
+    for (int k = 0; k < 4; ++k) v->counts[k] = (uint32_t)ctx->h_small[2 + k];
+    if (gap_words) {
+        size_t b_gaps = (size_t)gap_words * 2;
+        if ((rc = dmalloc(ctx, (void**)&v->d_gaps, b_gaps))) return rc;
+        v->bytes += std::max<size_t>(b_gaps, 16);
+        v->gap_words = gap_words;
+        hipLaunchKernelGGL(k_emit_gaps, dim3((nblocks + 3) / 4), dim3(256), 0, ctx->stream,
+                           v->d_bits, nblocks, st, offs, v->d_gaps, v->d_desc);
+        KCHK();
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
+    if (v->counts[BMX_BIT] == 0) {            // nothing lives in the slab: give it back
+        size_t b_bits = std::max<size_t>((size_t)v->n_bit * 8192, 16);
+        (void)hipFree(v->d_bits); v->d_bits = nullptr;
+        ctx->mem_used -= std::min<uint64_t>(ctx->mem_used, b_bits); v->bytes -= b_bits; v->n_bit = 0;
+    }
+    return BMX_OK;
+}
+
+extern "C" {
+
+int bmx_op2(bmx_ctx* ctx, int op, const bmx_vec* a, const bmx_vec* b, int opt_compress, bmx_vec** result)
+{
+    ARGCHK(ctx && a && b && result && a->ctx == ctx && b->ctx == ctx && op >= BMX_AND && op <= BMX_SUB);
+    *result = nullptr;
+    int rc = set_dev(ctx); if (rc) return rc;
+    uint32_t nblocks = std::max(a->nblocks, b->nblocks);
+    uint64_t nbits = std::max(a->nbits, b->nbits);                  // src/bm.h:6219-6221
+    bmx_vec* v; BlockStat* st; u32* offs;
+    if ((rc = result_begin(ctx, nbits, nblocks, &v, &st, &offs))) return rc;
+    if (nblocks) {
+        hipLaunchKernelGGL(k_op2, dim3((nblocks + 3) / 4), dim3(256), 0, ctx->stream, op,
+                           a->d_desc, a->nblocks, b->d_desc, b->nblocks, nblocks, opt_compress,
+                           v->d_bits, v->d_desc, st);
+        KCHK();
+    }
+    if ((rc = result_finish(ctx, v, st, offs))) { bmx_vec_free(ctx, v); return rc; }
+    *result = v;
+    return BMX_OK;
+}
+
+int bmx_count_op2(bmx_ctx* ctx, int op, const bmx_vec* a, const bmx_vec* b, uint64_t* count)
+{
+    ARGCHK(ctx && a && b && count && a->ctx == ctx && b->ctx == ctx && op >= BMX_AND && op <= BMX_SUB);
+    int rc = set_dev(ctx); if (rc) return rc;
+    uint32_t nblocks = std::max(a->nblocks, b->nblocks);
+    HIPCHK(hipMemsetAsync(ctx->d_small, 0, 8, ctx->stream));
+    if (nblocks) {
+        hipLaunchKernelGGL(k_count_op2, dim3((nblocks + 3) / 4), dim3(256), 0, ctx->stream, op,
+                           a->d_desc, a->nblocks, b->d_desc, b->nblocks, nblocks, ctx->d_small);
+        KCHK();
+    }
+    HIPCHK(hipMemcpyAsync(ctx->h_small, ctx->d_small, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    *count = ctx->h_small[0];
+    return BMX_OK;
+}
+
+int bmx_agg_or(bmx_ctx* ctx, const bmx_vec* const* src, size_t n, bmx_vec** result)
+{
+    ARGCHK(ctx && result && (n == 0 || src) && n <= 65535);
+    *result = nullptr;
+    int rc = set_dev(ctx); if (rc) return rc;
+    uint32_t ncols = 0; uint64_t nbits = 0; bool has_gap = false;
+    std::vector<const u64*> descs(std::max<size_t>(n, 1), nullptr);
+    std::vector<u32> nblk(std::max<size_t>(n, 1), 0);
+    for (size_t i = 0; i < n; ++i) {
+        if (!src[i] || src[i]->ctx != ctx) { g_last_error = "operand is null or belongs to another context"; return BMX_ERR_BADARG; }
+        descs[i] = src[i]->d_desc; nblk[i] = src[i]->nblocks;
+        ncols = std::max(ncols, src[i]->nblocks); nbits = std::max(nbits, src[i]->nbits);
+        has_gap |= src[i]->counts[BMX_GAP] != 0;
+    }
+    bmx_vec* v; BlockStat* st; u32* offs;
+    if ((rc = result_begin(ctx, nbits, ncols, &v, &st, &offs))) return rc;      // empty list => cleared target (:1105)
+    if (n && ncols) {
+        void* d_descs = nullptr; void* d_nblk = nullptr; void* d_dmat = nullptr;
+        size_t b_dmat = (size_t)ncols * (n + 2) * 8;
+        hipError_t e = hipMalloc(&d_descs, n * 8);
+        if (e == hipSuccess) e = hipMalloc(&d_nblk, n * 4);
+        if (e == hipSuccess) e = hipMalloc(&d_dmat, b_dmat);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_descs, descs.data(), n * 8, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_nblk, nblk.data(), n * 4, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_or_sort, dim3((ncols + 255) / 256), dim3(256), 0, ctx->stream,
+                               (const u64* const*)d_descs, (const u32*)d_nblk, (u32)n, ncols, (u64*)d_dmat);
+            size_t lds = has_gap ? 4 * 2048 * 4 : 0;
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_agg_or<2>), dim3((ncols + 3) / 4), dim3(256), lds, ctx->stream,
+                               (const u64*)d_dmat, (u32)n, ncols, 0 /* opt_mode_ = opt_none, :917 */, ctx->xcd_swz,
+                               v->d_bits, v->d_desc, st);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) rc = result_finish(ctx, v, st, offs);
+        else rc = fail_hip(e, "bmx_agg_or", __LINE__);
+        (void)hipStreamSynchronize(ctx->stream);
+        if (d_descs) (void)hipFree(d_descs);
+        if (d_nblk) (void)hipFree(d_nblk);
+        if (d_dmat) (void)hipFree(d_dmat);
+        if (rc) { bmx_vec_free(ctx, v); return rc; }
+    } else if (ncols) {
+        HIPCHK(hipMemsetAsync(v->d_desc, 0, (size_t)ncols * 8, ctx->stream));
+        v->counts[BMX_NULL] = ncols;
+    }
+    *result = v;
+    return BMX_OK;
+}
+
+int bmx_agg_and_sub(bmx_ctx* ctx, const bmx_vec* const* src_and, size_t n_and,
+                    const bmx_vec* const* src_sub, size_t n_sub, bmx_vec** result, int* any)
+{
+    ARGCHK(ctx && result && (n_and == 0 || src_and) && (n_sub == 0 || src_sub));
+    *result = nullptr;
+    if (any) *any = 0;
+    int rc = set_dev(ctx); if (rc) return rc;
+    uint64_t nbits = 0; uint32_t ncols = 0;
+    for (size_t i = 0; i < n_and; ++i) { ARGCHK(src_and[i]); nbits = std::max(nbits, src_and[i]->nbits); ncols = std::max(ncols, src_and[i]->nblocks); }
+    for (size_t i = 0; i < n_sub; ++i) { ARGCHK(src_sub[i]); nbits = std::max(nbits, src_sub[i]->nbits); ncols = std::max(ncols, src_sub[i]->nblocks); }
+    bmx_vec* v; BlockStat* st; u32* offs;
+    if (!n_and) {                                               // empty AND group => cleared target (:1170-1174)
+        if ((rc = result_begin(ctx, nbits, ncols, &v, &st, &offs))) return rc;
+        if (ncols) HIPCHK(hipMemsetAsync(v->d_desc, 0, (size_t)ncols * 8, ctx->stream));
+        v->counts[BMX_NULL] = ncols;
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        *result = v;
+        return BMX_OK;
+    }
+    uint32_t an = (uint32_t)n_and, sn = (uint32_t)n_sub;
+    bmx_pipeline* p = nullptr;
+    if ((rc = bmx_pipeline_create(ctx, src_and, &an, src_sub, &sn, 1, &p))) return rc;
+    if ((rc = result_begin(ctx, nbits, ncols, &v, &st, &offs))) { bmx_pipeline_destroy(ctx, p); return rc; }
+    if (ncols) {
+        size_t lds = p->has_gap ? 4 * 2048 * 4 : 0;
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_agg_and_sub<2>), dim3((ncols + 3) / 4), dim3(256), lds, ctx->stream,
+                           p->d_dmat, p->d_meta + 1, p->d_meta + 2, p->col_stride, ncols,
+                           1 /* combine_and_sub always stores with opt_compress, :1210 */, ctx->xcd_swz,
+                           v->d_bits, v->d_desc, st);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) rc = fail_hip(e, "k_agg_and_sub", __LINE__);
+    }
+    if (!rc) rc = result_finish(ctx, v, st, offs);
+    bmx_pipeline_destroy(ctx, p);
+    if (rc) { bmx_vec_free(ctx, v); return rc; }
+    if (any) *any = (v->counts[BMX_FULL] + v->counts[BMX_BIT] + v->counts[BMX_GAP]) != 0;
+    *result = v;
+    return BMX_OK;
+}
+
+// ---------------------------------------------------------------------------
+// rank / select
+// ---------------------------------------------------------------------------
+int bmx_rs_build(bmx_ctx* ctx, const bmx_vec* v, bmx_rs** out)
+{
+    ARGCHK(ctx && v && out && v->ctx == ctx);
+    *out = nullptr;
+    int rc = set_dev(ctx); if (rc) return rc;
+    bmx_rs* rs = new (std::nothrow) bmx_rs();
+    if (!rs) return BMX_ERR_BADALLOC;
+    memset(rs, 0, sizeof(*rs));
+    rs->ctx = ctx; rs->nblocks = v->nblocks;
+    uint32_t n = std::max<uint32_t>(v->nblocks, 1);
+    size_t b1 = (size_t)n * 4, b2 = (size_t)n * 8, b3 = (size_t)n * 8, b4 = (size_t)n * 128;
+    if ((rc = dmalloc(ctx, (void**)&rs->d_bcount, b1)) || (rc = dmalloc(ctx, (void**)&rs->d_sub, b2)) ||
+        (rc = dmalloc(ctx, (void**)&rs->d_rcount, b3)) || (rc = dmalloc(ctx, (void**)&rs->d_cum, b4))) { bmx_rs_free(ctx, rs); return rc; }
+    rs->bytes = b1 + b2 + b3 + b4;
+    if (v->nblocks) {
+        hipLaunchKernelGGL(k_rs_build, dim3((v->nblocks + 3) / 4), dim3(256), 0, ctx->stream,
+                           v->d_desc, v->nblocks, rs->d_bcount, rs->d_sub, rs->d_cum);
+        KCHK();
+        hipLaunchKernelGGL(k_rs_scan, dim3(1), dim3(1024), 0, ctx->stream, rs->d_bcount, v->nblocks, rs->d_rcount, ctx->d_small);
+        KCHK();
+        HIPCHK(hipMemcpyAsync(ctx->h_small, ctx->d_small, 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        rs->count = ctx->h_small[0];
+    }
+    *out = rs;
+    return BMX_OK;
+}
+
+int bmx_rs_free(bmx_ctx* ctx, bmx_rs* rs)
+{
+    if (!rs) return BMX_OK;
+    ARGCHK(ctx && rs->ctx == ctx);
+    int rc = set_dev(ctx); if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (rs->d_bcount) (void)hipFree(rs->d_bcount);
+    if (rs->d_sub) (void)hipFree(rs->d_sub);
+    if (rs->d_rcount) (void)hipFree(rs->d_rcount);
+    if (rs->d_cum) (void)hipFree(rs->d_cum);
+    ctx->mem_used -= std::min<uint64_t>(ctx->mem_used, rs->bytes);
+    delete rs;
+    return BMX_OK;
+}
+
+int bmx_rs_count(const bmx_rs* rs, uint64_t* count) { ARGCHK(rs && count); *count = rs->count; return BMX_OK; }
+
+int bmx_rs_export(bmx_ctx* ctx, const bmx_rs* rs, uint32_t* bcount, uint64_t* sub_count)
+{
+    ARGCHK(ctx && rs && rs->ctx == ctx);
+    int rc = set_dev(ctx); if (rc) return rc;
+    if (bcount && rs->nblocks) HIPCHK(hipMemcpyAsync(bcount, rs->d_bcount, (size_t)rs->nblocks * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (sub_count && rs->nblocks) HIPCHK(hipMemcpyAsync(sub_count, rs->d_sub, (size_t)rs->nblocks * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return BMX_OK;
+}
+
+static u32 query_grid(size_t q) { return (u32)std::min<size_t>((q * 8 + 255) / 256, 256u * 16u); }
+
+int bmx_rank_batch_dev(bmx_ctx* ctx, const bmx_vec* v, const bmx_rs* rs, const uint64_t* d_n, size_t q, uint64_t* d_out)
+{
+    ARGCHK(ctx && v && rs && v->ctx == ctx && rs->ctx == ctx && rs->nblocks == v->nblocks && (q == 0 || (d_n && d_out)));
+    int rc = set_dev(ctx); if (rc) return rc;
+    if (!q) return BMX_OK;
+    hipLaunchKernelGGL(k_rank, dim3(query_grid(q)), dim3(256), 0, ctx->stream, v->d_desc, v->nblocks,
+                       rs->d_rcount, rs->d_cum, rs->count, (const u64*)d_n, (u64)q, (u64*)d_out);
+    KCHK();
+    return BMX_OK;
+}
+
+int bmx_select_batch_dev(bmx_ctx* ctx, const bmx_vec* v, const bmx_rs* rs, const uint64_t* d_rank, size_t q,
+                         uint64_t* d_pos, uint8_t* d_found)
+{
+    ARGCHK(ctx && v && rs && v->ctx == ctx && rs->ctx == ctx && rs->nblocks == v->nblocks && (q == 0 || (d_rank && d_pos && d_found)));
+    int rc = set_dev(ctx); if (rc) return rc;
+    if (!q) return BMX_OK;
+    hipLaunchKernelGGL(k_select, dim3(query_grid(q)), dim3(256), 0, ctx->stream, v->d_desc, v->nblocks,
+                       rs->d_rcount, rs->d_cum, rs->count, (const u64*)d_rank, (u64)q, (u64*)d_pos, (u8*)d_found);
+    KCHK();
+    return BMX_OK;
+}
+
+int bmx_rank_batch(bmx_ctx* ctx, const bmx_vec* v, const bmx_rs* rs, const uint64_t* n, size_t q, uint64_t* out)
+{
+    ARGCHK(ctx && (q == 0 || (n && out)));
+    int rc = set_dev(ctx); if (rc) return rc;
+    if (!q) return BMX_OK;
+    u64* d = nullptr;
+    HIPCHK(hipMalloc((void**)&d, q * 16));
+    hipError_t e = hipMemcpyAsync(d, n, q * 8, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+        rc = bmx_rank_batch_dev(ctx, v, rs, d, q, d + q);
+        if (!rc) e = hipMemcpyAsync(out, d + q, q * 8, hipMemcpyDeviceToHost, ctx->stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail_hip(e, "bmx_rank_batch", __LINE__);
+    return rc;
+}
+
+int bmx_select_batch(bmx_ctx* ctx, const bmx_vec* v, const bmx_rs* rs, const uint64_t* rank, size_t q,
+                     uint64_t* pos, uint8_t* found)
+{
+    ARGCHK(ctx && (q == 0 || (rank && pos && found)));
+    int rc = set_dev(ctx); if (rc) return rc;
+    if (!q) return BMX_OK;
+    u64* d = nullptr;
+    HIPCHK(hipMalloc((void**)&d, q * 17));
+    hipError_t e = hipMemcpyAsync(d, rank, q * 8, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+        rc = bmx_select_batch_dev(ctx, v, rs, d, q, d + q, (uint8_t*)(d + 2 * q));
+        if (!rc) e = hipMemcpyAsync(pos, d + q, q * 8, hipMemcpyDeviceToHost, ctx->stream);
+        if (!rc && e == hipSuccess) e = hipMemcpyAsync(found, d + 2 * q, q, hipMemcpyDeviceToHost, ctx->stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail_hip(e, "bmx_select_batch", __LINE__);
+    return rc;
+}
+
+} // extern "C"

@@ -1,0 +1,253 @@
+// bmx_device.h -- wave64 device primitives for 64 Kbit bit-blocks and GAP blocks (gfx950).
+//
+// Register image of a bit-block ("Blk"): one wavefront holds one whole block,
+// lane l keeps r[i] = the 16 bytes at byte offset i*1024 + l*16 (i = 0..7).
+// Every HBM access of a block is therefore 8 fully coalesced 1 KiB wave loads
+// (global_load_dwordx4 with a wave-uniform SGPR base).  32-bit word w of the
+// block (src/bmconst.h:55: 2048 words) lives at (i, l, j) with w = i*256 + l*4 + j.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint8_t  u8;
+typedef uint16_t u16;
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+#define BMX_DESC_KIND(d) ((u32)((d) & 3ull))
+#define BMX_DESC_PTR(d)  ((d) & ~3ull)
+
+// plain clang vector (not HIP's uint4 class) so it can live behind an
+// address_space(1) pointer: loads become global_load_dwordx4 with an SGPR base
+// instead of flat_load (flat also ties up lgkmcnt and blocks load/ALU overlap).
+typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(1))) u32x4* gcptr4;
+typedef __attribute__((address_space(1))) u32x4* gptr4;
+typedef const __attribute__((address_space(1))) u16* gcptr16;
+
+struct Blk { u32x4 r[8]; };
+
+__device__ __forceinline__ gcptr4 as_gc4(u64 addr) { return (gcptr4)(uintptr_t)addr; }
+__device__ __forceinline__ gcptr4 as_gc4(const void* p) { return (gcptr4)(uintptr_t)p; }
+__device__ __forceinline__ gptr4 as_g4(void* p) { return (gptr4)(uintptr_t)p; }
+__device__ __forceinline__ gcptr16 as_gc16(u64 addr) { return (gcptr16)(uintptr_t)addr; }
+
+__device__ __forceinline__ u32 lane_id() { return threadIdx.x & 63u; }
+
+__device__ __forceinline__ u64 uniform64(u64 v)
+{
+    u32 lo = __builtin_amdgcn_readfirstlane((u32)v);
+    u32 hi = __builtin_amdgcn_readfirstlane((u32)(v >> 32));
+    return ((u64)hi << 32) | lo;
+}
+__device__ __forceinline__ u32 uniform32(u32 v) { return __builtin_amdgcn_readfirstlane(v); }
+
+__device__ __forceinline__ u32 wave_sum(u32 v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// inclusive prefix sum across the 64 lanes
+__device__ __forceinline__ u32 wave_scan_incl(u32 v, u32 lane)
+{
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        u32 n = __shfl_up(v, o, 64);
+        if (lane >= (u32)o) v += n;
+    }
+    return v;
+}
+
+__device__ __forceinline__ void blk_load(Blk& b, gcptr4 p, u32 lane)
+{
+#pragma unroll
+    for (int i = 0; i < 8; ++i) b.r[i] = p[i * 64 + lane];
+}
+__device__ __forceinline__ void blk_store(const Blk& b, gptr4 p, u32 lane)
+{
+#pragma unroll
+    for (int i = 0; i < 8; ++i) p[i * 64 + lane] = b.r[i];
+}
+__device__ __forceinline__ void blk_fill(Blk& b, u32 v)
+{
+#pragma unroll
+    for (int i = 0; i < 8; ++i) b.r[i] = (u32x4)(v);
+}
+__device__ __forceinline__ void blk_and(Blk& a, const Blk& b)
+{
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a.r[i] &= b.r[i];
+}
+__device__ __forceinline__ void blk_andn(Blk& a, const Blk& b)   // a &= ~b
+{
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a.r[i] &= ~b.r[i];
+}
+__device__ __forceinline__ void blk_or(Blk& a, const Blk& b)
+{
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a.r[i] |= b.r[i];
+}
+__device__ __forceinline__ void blk_xor(Blk& a, const Blk& b)
+{
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a.r[i] ^= b.r[i];
+}
+__device__ __forceinline__ void blk_op(int op, Blk& a, const Blk& b)
+{
+    switch (op) { case 0: blk_and(a, b); break; case 1: blk_or(a, b); break;
+                  case 2: blk_xor(a, b); break; default: blk_andn(a, b); break; }
+}
+// lane-local OR of all words (non-zero iff this lane holds any set bit)
+__device__ __forceinline__ u32 blk_lane_or(const Blk& b)
+{
+    u32 v = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v |= b.r[i].x | b.r[i].y | b.r[i].z | b.r[i].w;
+    return v;
+}
+__device__ __forceinline__ u32 blk_lane_and(const Blk& b)
+{
+    u32 v = ~0u;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v &= b.r[i].x & b.r[i].y & b.r[i].z & b.r[i].w;
+    return v;
+}
+// wave-uniform tests (bit_is_all_zero src/bmfunc.h:1669, is_bits_one :6838)
+__device__ __forceinline__ bool blk_is_zero(const Blk& b) { return __ballot(blk_lane_or(b) != 0u) == 0ull; }
+__device__ __forceinline__ bool blk_is_ones(const Blk& b) { return __ballot(blk_lane_and(b) != ~0u) == 0ull; }
+
+// lane-local popcount (bit_block_count src/bmfunc.h:5808); caller wave_sum()s it
+__device__ __forceinline__ u32 blk_lane_popcount(const Blk& b)
+{
+    u32 c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        c += __popcll(((u64)b.r[i].y << 32) | b.r[i].x);
+        c += __popcll(((u64)b.r[i].w << 32) | b.r[i].z);
+    }
+    return c;
+}
+
+// ---------------------------------------------------------------------------
+// Transition masks: bit k of t(word) is set iff bit k differs from its
+// predecessor in linear bit order (bit_block_calc_change src/bmfunc.h:6040).
+// Bit 0 of word 0 has no predecessor.  Returns the lane-local transition count
+// and leaves the masks in t.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ u32 blk_transitions(const Blk& b, Blk& t, u32 lane)
+{
+    u32 cnt = 0;
+    u32 prev_row_last = 0;          // MSB of word (i-1, 63, 3), wave-uniform
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        u32 w0 = b.r[i].x, w1 = b.r[i].y, w2 = b.r[i].z, w3 = b.r[i].w;
+        u32 up = __shfl_up(w3, 1, 64) >> 31;                  // MSB of lane-1's last word
+        u32 p0 = lane ? up : (i ? prev_row_last : (w0 & 1u)); // block start: no transition
+        t.r[i].x = w0 ^ ((w0 << 1) | p0);
+        t.r[i].y = w1 ^ ((w1 << 1) | (w0 >> 31));
+        t.r[i].z = w2 ^ ((w2 << 1) | (w1 >> 31));
+        t.r[i].w = w3 ^ ((w3 << 1) | (w2 >> 31));
+        cnt += __popc(t.r[i].x) + __popc(t.r[i].y) + __popc(t.r[i].z) + __popc(t.r[i].w);
+        prev_row_last = __shfl(w3, 63, 64) >> 31;
+    }
+    return cnt;
+}
+
+// ---------------------------------------------------------------------------
+// GAP decode (normative rule: SURVEY.md Appendix B; reference
+// gap_convert_to_bitset src/bmfunc.h:5232 / gap_add_to_bitset :4796).
+// Data-parallel form: scatter a toggle bit at e[k]+1 for k = 1..len-1 (plus
+// position 0 when the block starts with a 1-run) into a per-wave 8 KiB LDS
+// bitmap, then take the inclusive prefix-XOR over the 65,536 positions:
+// in-word by shift/xor doubling, across words by ballot + mbcnt parity.
+// lds: 2048 u32 private to this wave.  All 64 lanes must call.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ u32 prefix_xor32(u32 x)
+{
+    x ^= x << 1; x ^= x << 2; x ^= x << 4; x ^= x << 8; x ^= x << 16;
+    return x;
+}
+
+__device__ __forceinline__ void gap_decode(gcptr16 g, u32* lds, Blk& out, u32 lane)
+{
+    u32x4* l4 = reinterpret_cast<u32x4*>(lds);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) l4[i * 64 + lane] = (u32x4)(0u);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    u32 hdr = g[0];
+    u32 len = hdr >> 3;
+    if ((hdr & 1u) && lane == 0) atomicXor(&lds[0], 1u);
+    for (u32 k = 1 + lane; k < len; k += 64) {
+        u32 p = (u32)g[k] + 1u;
+        atomicXor(&lds[p >> 5], 1u << (p & 31u));
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    u32 carry = 0;                      // value of the bit preceding the current row (wave-uniform)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        u32x4 t = l4[i * 64 + lane];
+        u32 x0 = prefix_xor32(t.x), x1 = prefix_xor32(t.y), x2 = prefix_xor32(t.z), x3 = prefix_xor32(t.w);
+        // MSB of the in-word prefix = parity of the word's toggles
+        u64 b0 = __ballot((int)(x0 >> 31)), b1 = __ballot((int)(x1 >> 31));
+        u64 b2 = __ballot((int)(x2 >> 31)), b3 = __ballot((int)(x3 >> 31));
+        // toggles in lower lanes of this row (all four words of each lower lane)
+        u32 below = __builtin_amdgcn_mbcnt_hi((u32)(b0 >> 32), __builtin_amdgcn_mbcnt_lo((u32)b0, 0));
+        below = __builtin_amdgcn_mbcnt_hi((u32)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((u32)b1, below));
+        below = __builtin_amdgcn_mbcnt_hi((u32)(b2 >> 32), __builtin_amdgcn_mbcnt_lo((u32)b2, below));
+        below = __builtin_amdgcn_mbcnt_hi((u32)(b3 >> 32), __builtin_amdgcn_mbcnt_lo((u32)b3, below));
+        u32 c0 = (carry ^ below) & 1u;
+        u32 c1 = c0 ^ (x0 >> 31), c2 = c1 ^ (x1 >> 31), c3 = c2 ^ (x2 >> 31);
+        out.r[i].x = x0 ^ (0u - c0);
+        out.r[i].y = x1 ^ (0u - c1);
+        out.r[i].z = x2 ^ (0u - c2);
+        out.r[i].w = x3 ^ (0u - c3);
+        carry ^= (u32)(__popcll(b0) + __popcll(b1) + __popcll(b2) + __popcll(b3)) & 1u;
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+// popcount of a GAP block without expanding it (gap_bit_count_unr src/bmfunc.h:3107).
+// Returns the lane-local partial; caller wave_sum()s.
+__device__ __forceinline__ u32 gap_lane_popcount(gcptr16 g, u32 lane)
+{
+    u32 hdr = g[0];
+    u32 len = hdr >> 3, s = hdr & 1u;
+    u32 c = 0;
+    // run k (1-based) covers (e[k-1], e[k]] and has value s ^ ((k-1)&1)
+    for (u32 k = 1 + lane; k <= len; k += 64) {
+        if ((s ^ ((k - 1u) & 1u)) != 0u) {
+            u32 e = g[k];
+            u32 pe = (k == 1u) ? 0xFFFFFFFFu : (u32)g[k - 1];
+            c += e - pe;            // k==1: e - (-1) = e + 1
+        }
+    }
+    return c;
+}
+
+// ---------------------------------------------------------------------------
+// synthetic generator: normative arithmetic in oracle/bmx_oracle.c bmo_gen_word64
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ u64 mix64(u64 x)
+{
+    x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
+    x ^= x >> 27; x *= 0x94D049BB133111EBull;
+    x ^= x >> 31;
+    return x;
+}
+__device__ __forceinline__ u64 gen_word64(u64 seed, u32 vec_id, u64 w64, u32 d)
+{
+    if (d >= 65536u) return ~0ull;
+    u64 base = seed ^ ((u64)vec_id * 0x9E3779B97F4A7C15ull);
+    u64 acc = 0;
+#pragma unroll
+    for (u32 k = 0; k < 16; ++k) {
+        u64 r = mix64(base + (w64 * 16u + k) * 0xD6E8FEB86659FD93ull);
+        acc = ((d >> k) & 1u) ? (acc | r) : (acc & r);
+    }
+    return acc;
+}

@@ -1,0 +1,372 @@
+// bmx_kernels.h -- HIP kernels of the bvector/aggregator hot path (gfx950, wave64).
+// One wavefront owns one 64 Kbit block (see bmx_device.h).  No MFMA: the work is
+// bitwise and HBM-bound; what matters is coalesced 16 B/lane loads, enough
+// independent loads in flight, and never reading an operand twice.
+#pragma once
+#include "bmx_device.h"
+
+// descriptor: device pointer in the low 48 bits, kind in bits 62..63
+#define DESC_MAKE(ptr, kind) ((u64)(uintptr_t)(ptr) | ((u64)(kind) << 62))
+#define DESC_K(d) ((u32)((d) >> 62))
+#define DESC_P(d) ((d) & 0x0000FFFFFFFFFFFFull)
+enum { K_NULL = 0, K_FULL = 1, K_BIT = 2, K_GAP = 3 };
+
+// pipeline row flags
+#define ROW_EMPTY 1ull
+#define ROW_FULL  2ull
+#define ROW_ONES  4ull    // accumulator starts as all-ones (no bit-block AND operand)
+
+struct BlockStat { u32 pop; u32 runs; u32 first; u32 kind; };
+
+// ---------------------------------------------------------------------------
+// synthetic data: out = nblocks * 1024 64-bit words, bits >= nbits are zero
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256)
+void k_generate(u64 seed, u32 vec_id, int with_common, u32 d, u64 nbits, u64* __restrict__ out, u64 nwords64)
+{
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    u64 stride = (u64)gridDim.x * blockDim.x;
+    for (; i < nwords64; i += stride) {
+        u64 v = gen_word64(seed, vec_id, i, d);
+        if (with_common) v |= gen_word64(seed, 0xFFFFFFFFu, i, d);
+        u64 bit0 = i * 64u;
+        if (bit0 >= nbits) v = 0;
+        else if (nbits - bit0 < 64u) v &= (~0ull) >> (64u - (nbits - bit0));
+        out[i] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// import, step 1: per raw block popcount / run count / first bit and the storage
+// decision of blocks_manager::optimize_bit_block (src/bmblocks.h:1412-1436):
+//   runs == 1 -> NULL or FULL;  optimize && runs < 1276 -> GAP;  else BIT.
+// One wave per block, 4 blocks per workgroup.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256)
+void k_block_stats(const uint4* __restrict__ raw, u32 nblocks, int optimize, BlockStat* __restrict__ st)
+{
+    u32 lane = lane_id();
+    u32 nb = uniform32(blockIdx.x * 4u + (threadIdx.x >> 6));
+    if (nb >= nblocks) return;
+    Blk b, t;
+    blk_load(b, as_gc4(raw + (size_t)nb * 512u), lane);
+    u32 pop = wave_sum(blk_lane_popcount(b));
+    u32 runs = 1u + wave_sum(blk_transitions(b, t, lane));
+    u32 first = __shfl(b.r[0].x, 0, 64) & 1u;
+    if (lane == 0) {
+        u32 kind = (runs == 1u) ? (first ? K_FULL : K_NULL)
+                 : ((optimize && runs < 1276u) ? K_GAP : K_BIT);
+        st[nb] = BlockStat{pop, runs, first, kind};
+    }
+}
+
+// step 2: exclusive scan of storage sizes (single workgroup; nblocks <= 2^20)
+// offs[nb] = bit-block ordinal or GAP u16-word offset; totals[0]=n_bit, [1]=gap_words,
+// totals[2..5] = blocks per kind
+__global__ __launch_bounds__(1024)
+void k_scan_layout(const BlockStat* __restrict__ st, u32 nblocks, u32* __restrict__ offs, u64* __restrict__ totals)
+{
+    __shared__ u32 s_bit[1024], s_gap[1024];
+    __shared__ u32 carry_bit, carry_gap;
+    __shared__ u32 kcnt[4];
+    u32 tid = threadIdx.x;
+    if (tid == 0) { carry_bit = 0; carry_gap = 0; }
+    if (tid < 4) kcnt[tid] = 0;
+    __syncthreads();
+    for (u32 base = 0; base < nblocks; base += 1024u) {
+        u32 nb = base + tid;
+        u32 vb = 0, vg = 0, kind = K_NULL;
+        if (nb < nblocks) {
+            kind = st[nb].kind;
+            vb = kind == K_BIT;
+            vg = kind == K_GAP ? st[nb].runs + 1u : 0u;
+            atomicAdd(&kcnt[kind], 1u);
+        }
+        s_bit[tid] = vb; s_gap[tid] = vg;
+        __syncthreads();
+        for (u32 o = 1; o < 1024u; o <<= 1) {
+            u32 a = 0, g = 0;
+            if (tid >= o) { a = s_bit[tid - o]; g = s_gap[tid - o]; }
+            __syncthreads();
+            s_bit[tid] += a; s_gap[tid] += g;
+            __syncthreads();
+        }
+        if (nb < nblocks) offs[nb] = (kind == K_BIT) ? carry_bit + s_bit[tid] - vb
+                                  : (kind == K_GAP) ? carry_gap + s_gap[tid] - vg : 0u;
+        __syncthreads();
+        if (tid == 1023u) { carry_bit += s_bit[1023]; carry_gap += s_gap[1023]; }
+        __syncthreads();
+    }
+    if (tid == 0) { totals[0] = carry_bit; totals[1] = carry_gap; }
+    if (tid < 4) totals[2 + tid] = kcnt[tid];
+}
+
+// step 3: write each block in its final form + the descriptor table.
+// GAP conversion = bit_block_to_gap (src/bmfunc.h:5542): run k ends just before
+// the k-th transition; index of a transition = 1 + number of earlier transitions.
+__global__ __launch_bounds__(256)
+void k_emit_blocks(const uint4* __restrict__ raw, u32 nblocks, const BlockStat* __restrict__ st,
+                   const u32* __restrict__ offs, uint4* __restrict__ bit_slab, u16* __restrict__ gap_slab,
+                   u64* __restrict__ desc)
+{
+    u32 lane = lane_id();
+    u32 nb = uniform32(blockIdx.x * 4u + (threadIdx.x >> 6));
+    if (nb >= nblocks) return;
+    u32 kind = uniform32(st[nb].kind);
+    if (kind == K_NULL || kind == K_FULL) { if (lane == 0) desc[nb] = DESC_MAKE(0, kind); return; }
+    Blk b;
+    blk_load(b, as_gc4(raw + (size_t)nb * 512u), lane);
+    if (kind == K_BIT) {
+        uint4* dst = bit_slab + (size_t)offs[nb] * 512u;
+        blk_store(b, as_g4(dst), lane);
+        if (lane == 0) desc[nb] = DESC_MAKE(dst, K_BIT);
+        return;
+    }
+    // GAP
+    u16* g = gap_slab + offs[nb];
+    Blk t;
+    (void)blk_transitions(b, t, lane);
+    u32 len = uniform32(st[nb].runs);
+    u32 idx_base = 1u;                  // first run-end slot
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        u32 c = __popc(t.r[i].x) + __popc(t.r[i].y) + __popc(t.r[i].z) + __popc(t.r[i].w);
+        u32 incl = wave_scan_incl(c, lane);
+        u32 idx = idx_base + incl - c;
+        u32 wbase = (u32)i * 256u + lane * 4u;
+        u32 tw[4] = {t.r[i].x, t.r[i].y, t.r[i].z, t.r[i].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            u32 m = tw[j];
+            while (m) {
+                u32 k = __builtin_ctz(m); m &= m - 1u;
+                g[idx++] = (u16)((wbase + j) * 32u + k - 1u);
+            }
+        }
+        idx_base += __shfl(incl, 63, 64);
+    }
+    if (lane == 0) {
+        u32 level = len <= 124u ? 0u : len <= 252u ? 1u : len <= 508u ? 2u : 3u;   // gap_calc_level src/bmfunc.h:5418
+        g[0] = (u16)((len << 3) | (level << 1) | st[nb].first);
+        g[len] = 65535u;
+        desc[nb] = DESC_MAKE(g, K_GAP);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// load any block kind into registers (NULL -> zeros, FULL -> ones, GAP decoded)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void blk_from_desc(u64 d, Blk& b, u32* lds, u32 lane)
+{
+    u32 k = DESC_K(d);
+    if (k == K_BIT) blk_load(b, as_gc4(DESC_P(d)), lane);
+    else if (k == K_GAP) gap_decode(as_gc16(DESC_P(d)), lds, b, lane);
+    else blk_fill(b, k == K_FULL ? ~0u : 0u);
+}
+
+// bvector::count()  src/bm.h:2431 -> block_bitcount src/bmblocks.h:1710
+__global__ __launch_bounds__(256)
+void k_vec_count(const u64* __restrict__ desc, u32 nblocks, u64* __restrict__ total)
+{
+    u32 lane = lane_id();
+    u32 nb = uniform32(blockIdx.x * 4u + (threadIdx.x >> 6));
+    if (nb >= nblocks) return;
+    u64 d = uniform64(desc[nb]);
+    u32 k = DESC_K(d);
+    u32 c = 0;
+    if (k == K_NULL) return;
+    if (k == K_FULL) c = 65536u;
+    else if (k == K_BIT) { Blk b; blk_load(b, as_gc4(DESC_P(d)), lane); c = wave_sum(blk_lane_popcount(b)); }
+    else c = wave_sum(gap_lane_popcount(as_gc16(DESC_P(d)), lane));
+    if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(total), (unsigned long long)c);
+}
+
+// expand a vector into raw words (nblocks_out blocks; blocks past the table are zero)
+__global__ __launch_bounds__(256)
+void k_vec_expand(const u64* __restrict__ desc, u32 nblocks, u32 nblocks_out, uint4* __restrict__ out)
+{
+    __shared__ u32 lds[4 * 2048];
+    u32 lane = lane_id(), wave = threadIdx.x >> 6;
+    u32 nb = uniform32(blockIdx.x * 4u + wave);
+    if (nb >= nblocks_out) return;
+    u64 d = nb < nblocks ? uniform64(desc[nb]) : 0ull;
+    Blk b;
+    blk_from_desc(d, b, lds + wave * 2048u, lane);
+    blk_store(b, as_g4(out + (size_t)nb * 512u), lane);
+}
+
+// ---------------------------------------------------------------------------
+// Pipeline "complete()": for every block column and arg-group, classify the
+// operands once (aggregator::sort_input_blocks_and / _or, src/bmaggregator.h:
+// 2315,2278) into a row  [hdr, flags, AND region (n_and), SUB region (n_sub)]:
+// bit-block pointers are packed from the front of a region, GAP pointers from
+// its back.  hdr = nbit_and | ngap_and<<16 | nbit_sub<<32 | ngap_sub<<48.
+// One thread per (column, group).
+// ---------------------------------------------------------------------------
+struct PipeOperands {
+    const u64* const* desc;     // per operand: descriptor table
+    const u32* nblocks;         // per operand: table length
+    const u32* and_off; const u32* and_n;   // per group: slice of the operand arrays (AND)
+    const u32* sub_off; const u32* sub_n;   // per group: (SUB)
+    const u32* row_off;         // per group: offset of its row inside a column record
+};
+
+__global__ __launch_bounds__(256)
+void k_pipe_sort(PipeOperands po, u32 ngroups, u32 ncols, u32 col_stride, u64* __restrict__ dmat)
+{
+    u64 tid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= (u64)ncols * ngroups) return;
+    u32 c = (u32)(tid / ngroups), g = (u32)(tid - (u64)c * ngroups);
+    u64* row = dmat + (size_t)c * col_stride + po.row_off[g];
+    u32 na = po.and_n[g], ns = po.sub_n[g];
+    u32 ao = po.and_off[g], so = po.sub_off[g];
+    u64* ra = row + 2; u64* rs = row + 2 + na;
+    u32 nbit = 0, ngap = 0; bool has_full = false, empty = (na == 0);
+    for (u32 k = 0; k < na; ++k) {
+        u32 op = ao + k;
+        u64 d = c < po.nblocks[op] ? po.desc[op][c] : 0ull;
+        u32 kd = DESC_K(d);
+        if (kd == K_NULL) { empty = true; break; }           // any NULL => empty column (:2327)
+        if (kd == K_FULL) has_full = true;                   // FULL operands are dropped (:2346)
+        else if (kd == K_BIT) ra[nbit++] = DESC_P(d);
+        else ra[na - 1u - ngap++] = DESC_P(d);
+    }
+    u32 sbit = 0, sgap = 0;
+    if (!empty) {
+        for (u32 k = 0; k < ns; ++k) {
+            u32 op = so + k;
+            u64 d = c < po.nblocks[op] ? po.desc[op][c] : 0ull;
+            u32 kd = DESC_K(d);
+            if (kd == K_NULL) continue;
+            if (kd == K_FULL) { empty = true; break; }       // FULL in the SUB group => empty (:1746)
+            if (kd == K_BIT) rs[sbit++] = DESC_P(d);
+            else rs[ns - 1u - sgap++] = DESC_P(d);
+        }
+    }
+    u64 flags = 0;
+    if (empty) flags = ROW_EMPTY;
+    else if (!nbit && !ngap) { if (!sbit && !sgap) flags = ROW_FULL; else flags = ROW_ONES; }  // all FULL (:1751)
+    else if (!nbit) flags = ROW_ONES;                        // GAP-only AND group (:2033)
+    (void)has_full;
+    row[0] = (u64)nbit | ((u64)ngap << 16) | ((u64)sbit << 32) | ((u64)sgap << 48);
+    row[1] = flags;
+}
+
+// XCD-aware workgroup remap (bijective for any grid size): hardware places
+// workgroup b on XCD b % 8; give every XCD one contiguous slice of the work so
+// neighbouring block columns (same 2 MiB pages of every operand slab) stay on
+// one XCD's L2/TLB.
+__device__ __forceinline__ u32 xcd_remap(u32 b, u32 nwg)
+{
+    u32 q = nwg >> 3, rem = nwg & 7u;
+    u32 x = b & 7u, i = b >> 3;
+    return x * q + (x < rem ? x : rem) + i;
+}
+
+// ---------------------------------------------------------------------------
+// THE hot kernel: fused N-way AND(-SUB) + COUNT, counts only
+// (aggregator::combine_and_sub(pipe) with agg_opt_only_counts,
+//  src/bmaggregator.h:1292-1399; per column :1720; bit-block chain :1994,2125;
+//  GAP operands :1820,1854;  count[g] += is_full ? 65536 : popcount(result)).
+// One wave = one (column, group) work item; accumulator = 32 VGPRs; U operand
+// blocks (U x 8 KiB) are in flight per wave; the running result is tested for
+// all-zero after every batch (the reference's digest==0 early exit, :2052).
+// ---------------------------------------------------------------------------
+template <int U>
+__global__ __launch_bounds__(256)
+void k_pipe_counts(const u64* __restrict__ dmat, const u32* __restrict__ row_off,
+                   const u32* __restrict__ and_n, const u32* __restrict__ sub_n, u32 col_stride,
+                   u32 ngroups, u32 col_from, u32 nitems, int xcd_swz, u64* __restrict__ counts)
+{
+    extern __shared__ u32 lds_dyn[];
+    u32 lane = lane_id(), wave = threadIdx.x >> 6;
+    u32 bid = xcd_swz ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
+    u32 item = uniform32(bid * 4u + wave);
+    if (item >= nitems) return;
+    u32 c = item / ngroups, g = item - c * ngroups;
+    const u64* row = dmat + (size_t)(col_from + c) * col_stride + row_off[g];
+    u64 hdr = uniform64(row[0]), flags = uniform64(row[1]);
+    if (flags & ROW_EMPTY) return;
+    if (flags & ROW_FULL) { if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(&counts[g]), 65536ull); return; }
+    u32 nba = (u32)(hdr & 0xFFFFu), nga = (u32)((hdr >> 16) & 0xFFFFu);
+    u32 nbs = (u32)((hdr >> 32) & 0xFFFFu), ngs = (u32)(hdr >> 48);
+    u32 na = uniform32(and_n[g]), ns = uniform32(sub_n[g]);
+    const u64* pa = row + 2;
+    const u64* ps = pa + na;
+    u32* lds = lds_dyn + wave * 2048u;
+
+    Blk acc;
+    u32 k = 0;
+    if (flags & ROW_ONES) blk_fill(acc, ~0u);
+    else { blk_load(acc, as_gc4(uniform64(pa[0])), lane); k = 1; }
+
+    // AND bit-block operands, U at a time
+    for (; k + U <= nba; k += U) {
+        Blk t[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) blk_load(t[u], as_gc4(uniform64(pa[k + u])), lane);
+#pragma unroll
+        for (int u = 0; u < U; ++u) blk_and(acc, t[u]);
+        if (blk_is_zero(acc)) return;
+    }
+    for (; k < nba; ++k) {
+        Blk t; blk_load(t, as_gc4(uniform64(pa[k])), lane);
+        blk_and(acc, t);
+    }
+    if (blk_is_zero(acc)) return;
+    // SUB bit-block operands
+    k = 0;
+    for (; k + U <= nbs; k += U) {
+        Blk t[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) blk_load(t[u], as_gc4(uniform64(ps[k + u])), lane);
+#pragma unroll
+        for (int u = 0; u < U; ++u) blk_andn(acc, t[u]);
+        if (blk_is_zero(acc)) return;
+    }
+    for (; k < nbs; ++k) {
+        Blk t; blk_load(t, as_gc4(uniform64(ps[k])), lane);
+        blk_andn(acc, t);
+    }
+    // GAP operands (packed from the back of each region)
+    for (u32 i = 0; i < nga; ++i) {
+        Blk t; gap_decode(as_gc16(uniform64(pa[na - 1u - i])), lds, t, lane);
+        blk_and(acc, t);
+        if (blk_is_zero(acc)) return;
+    }
+    for (u32 i = 0; i < ngs; ++i) {
+        Blk t; gap_decode(as_gc16(uniform64(ps[ns - 1u - i])), lds, t, lane);
+        blk_andn(acc, t);
+        if (blk_is_zero(acc)) return;
+    }
+    u32 cnt = wave_sum(blk_lane_popcount(acc));
+    if (lane == 0 && cnt) atomicAdd(reinterpret_cast<unsigned long long*>(&counts[g]), (unsigned long long)cnt);
+}
+
+// algorithmic operand bytes of the rows in [col_from, col_from+ncols)
+__global__ __launch_bounds__(256)
+void k_pipe_bytes(const u64* __restrict__ dmat, const u32* __restrict__ row_off, const u32* __restrict__ and_n,
+                  const u32* __restrict__ sub_n, u32 col_stride, u32 ngroups, u32 col_from, u32 nitems,
+                  u64* __restrict__ total)
+{
+    u64 tid = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    u64 bytes = 0;
+    if (tid < nitems) {
+        u32 c = (u32)(tid / ngroups), g = (u32)(tid - (u64)c * ngroups);
+        const u64* row = dmat + (size_t)(col_from + c) * col_stride + row_off[g];
+        u64 hdr = row[0], flags = row[1];
+        if (!(flags & (ROW_EMPTY | ROW_FULL))) {
+            u32 nba = (u32)(hdr & 0xFFFFu), nga = (u32)((hdr >> 16) & 0xFFFFu);
+            u32 nbs = (u32)((hdr >> 32) & 0xFFFFu), ngs = (u32)(hdr >> 48);
+            bytes = (u64)(nba + nbs) * 8192ull;
+            const u64* pa = row + 2; const u64* ps = pa + and_n[g];
+            for (u32 i = 0; i < nga; ++i) bytes += 2ull * ((as_gc16(pa[and_n[g] - 1u - i])[0] >> 3) + 1u);
+            for (u32 i = 0; i < ngs; ++i) bytes += 2ull * ((as_gc16(ps[sub_n[g] - 1u - i])[0] >> 3) + 1u);
+        }
+    }
+    // block reduce
+    __shared__ u64 s[256];
+    s[threadIdx.x] = bytes; __syncthreads();
+    for (u32 o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) s[threadIdx.x] += s[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0 && s[0]) atomicAdd(reinterpret_cast<unsigned long long*>(total), (unsigned long long)s[0]);
+}

@@ -1,0 +1,556 @@
+// bmx_kernels2.h -- pairwise set algebra, aggregator with materialised results,
+// rank/select.  Same wave-per-block register image as bmx_kernels.h.
+#pragma once
+#include "bmx_kernels.h"
+
+// ---------------------------------------------------------------------------
+// Result store.  A materialised result vector owns a full-size slab (one 8 KiB
+// slot per block column: HBM is plentiful, no compaction pass, no second read);
+// the block rule of blocks_manager::opt_copy_bit_block (src/bmblocks.h:1355):
+//   runs == 1 -> NULL / FULL (nothing stored)
+//   opt_compress && runs < 1276 -> GAP candidate: raw bits parked in the slot,
+//                                  converted by k_emit_gaps afterwards
+//   else BIT in its slot.
+// All 64 lanes call; st[nb] and desc[nb] are written by lane 0.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void store_result(const Blk& acc, u32 nb, int opt_compress,
+                                             uint4* __restrict__ slab, u64* __restrict__ desc,
+                                             BlockStat* __restrict__ st, u32 lane)
+{
+    Blk t;
+    u32 pop = wave_sum(blk_lane_popcount(acc));
+    u32 runs = 1u + wave_sum(blk_transitions(acc, t, lane));
+    u32 first = __shfl(acc.r[0].x, 0, 64) & 1u;
+    u32 kind = (runs == 1u) ? (first ? K_FULL : K_NULL)
+             : ((opt_compress && runs < 1276u) ? K_GAP : K_BIT);
+    uint4* slot = slab + (size_t)nb * 512u;
+    if (kind == K_BIT || kind == K_GAP) blk_store(acc, as_g4(slot), lane);
+    if (lane == 0) {
+        st[nb] = BlockStat{pop, runs, first, kind};
+        desc[nb] = (kind == K_BIT) ? DESC_MAKE(slot, K_BIT) : DESC_MAKE(0, kind == K_GAP ? K_NULL : kind);
+    }
+}
+
+__device__ __forceinline__ void store_trivial(u32 kind, u32 nb, u64* __restrict__ desc,
+                                              BlockStat* __restrict__ st, u32 lane)
+{
+    if (lane == 0) {
+        st[nb] = BlockStat{kind == K_FULL ? 65536u : 0u, 1u, kind == K_FULL ? 1u : 0u, kind};
+        desc[nb] = DESC_MAKE(0, kind);
+    }
+}
+
+// GAP conversion of the parked candidates (bit_block_to_gap src/bmfunc.h:5542)
+__global__ __launch_bounds__(256)
+void k_emit_gaps(const uint4* __restrict__ slab, u32 nblocks, const BlockStat* __restrict__ st,
+                 const u32* __restrict__ offs, u16* __restrict__ gap_slab, u64* __restrict__ desc)
+{
+    u32 lane = lane_id();
+    u32 nb = uniform32(blockIdx.x * 4u + (threadIdx.x >> 6));
+    if (nb >= nblocks) return;
+    if (uniform32(st[nb].kind) != K_GAP) return;
+    Blk b, t;
+    blk_load(b, as_gc4(slab + (size_t)nb * 512u), lane);
+    (void)blk_transitions(b, t, lane);
+    u16* g = gap_slab + offs[nb];
+    u32 len = uniform32(st[nb].runs);
+    u32 idx_base = 1u;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        u32 c = __popc(t.r[i].x) + __popc(t.r[i].y) + __popc(t.r[i].z) + __popc(t.r[i].w);
+        u32 incl = wave_scan_incl(c, lane);
+        u32 idx = idx_base + incl - c;
+        u32 wbase = (u32)i * 256u + lane * 4u;
+        u32 tw[4] = {t.r[i].x, t.r[i].y, t.r[i].z, t.r[i].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            u32 m = tw[j];
+            while (m) {
+                u32 k = __builtin_ctz(m); m &= m - 1u;
+                g[idx++] = (u16)((wbase + j) * 32u + k - 1u);
+            }
+        }
+        idx_base += __shfl(incl, 63, 64);
+    }
+    if (lane == 0) {
+        u32 level = len <= 124u ? 0u : len <= 252u ? 1u : len <= 508u ? 2u : 3u;
+        g[0] = (u16)((len << 3) | (level << 1) | st[nb].first);
+        g[len] = 65535u;
+        desc[nb] = DESC_MAKE(g, K_GAP);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Pairwise ops.  bvector::bit_and/or/xor/sub(bv1, bv2)  src/bm.h:6185,5973,6072,6403
+// per block: combine_operation_block_* (:7100,6945,7018,7285); NULL/FULL
+// shortcuts of SURVEY Appendix A.1 never touch block data.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ u64 desc_at(const u64* __restrict__ d, u32 n, u32 nb)
+{
+    return nb < n ? uniform64(d[nb]) : 0ull;
+}
+
+__global__ __launch_bounds__(256)
+void k_op2(int op, const u64* __restrict__ da, u32 na, const u64* __restrict__ db, u32 nbk,
+           u32 nblocks, int opt_compress, uint4* __restrict__ slab, u64* __restrict__ desc,
+           BlockStat* __restrict__ st)
+{
+    __shared__ u32 lds[4 * 2048];
+    u32 lane = lane_id(), wave = threadIdx.x >> 6;
+    u32 nb = uniform32(blockIdx.x * 4u + wave);
+    if (nb >= nblocks) return;
+    u64 a = desc_at(da, na, nb), b = desc_at(db, nbk, nb);
+    u32 ka = DESC_K(a), kb = DESC_K(b);
+    // shortcuts that produce NULL / FULL without reading anything
+    if (op == BMX_AND) {
+        if (ka == K_NULL || kb == K_NULL) { store_trivial(K_NULL, nb, desc, st, lane); return; }
+        if (ka == K_FULL && kb == K_FULL) { store_trivial(K_FULL, nb, desc, st, lane); return; }
+    } else if (op == BMX_OR) {
+        if (ka == K_FULL || kb == K_FULL) { store_trivial(K_FULL, nb, desc, st, lane); return; }
+        if (ka == K_NULL && kb == K_NULL) { store_trivial(K_NULL, nb, desc, st, lane); return; }
+    } else if (op == BMX_XOR) {
+        if ((ka == K_NULL && kb == K_NULL) || (ka == K_FULL && kb == K_FULL)) { store_trivial(K_NULL, nb, desc, st, lane); return; }
+        if ((ka == K_NULL && kb == K_FULL) || (ka == K_FULL && kb == K_NULL)) { store_trivial(K_FULL, nb, desc, st, lane); return; }
+    } else {
+        if (ka == K_NULL || kb == K_FULL) { store_trivial(K_NULL, nb, desc, st, lane); return; }
+        if (ka == K_FULL && kb == K_NULL) { store_trivial(K_FULL, nb, desc, st, lane); return; }
+    }
+    Blk x, y;
+    u32* l = lds + wave * 2048u;
+    blk_from_desc(a, x, l, lane);
+    blk_from_desc(b, y, l, lane);
+    blk_op(op, x, y);
+    store_result(x, nb, opt_compress, slab, desc, st, lane);
+}
+
+// bm::count_and/or/xor/sub  src/bmalgo.h:49,149,81,115 (distance_operation,
+// src/bmalgo_impl.h:766,853): popcount(a OP b) without materialising.
+__global__ __launch_bounds__(256)
+void k_count_op2(int op, const u64* __restrict__ da, u32 na, const u64* __restrict__ db, u32 nbk,
+                 u32 nblocks, u64* __restrict__ total)
+{
+    __shared__ u32 lds[4 * 2048];
+    u32 lane = lane_id(), wave = threadIdx.x >> 6;
+    u32 nb = uniform32(blockIdx.x * 4u + wave);
+    if (nb >= nblocks) return;
+    u64 a = desc_at(da, na, nb), b = desc_at(db, nbk, nb);
+    u32 ka = DESC_K(a), kb = DESC_K(b);
+    if (ka == K_NULL && kb == K_NULL) return;
+    if (op == BMX_AND && (ka == K_NULL || kb == K_NULL)) return;
+    if (op == BMX_SUB && (ka == K_NULL || kb == K_FULL)) return;
+    Blk x, y;
+    u32* l = lds + wave * 2048u;
+    blk_from_desc(a, x, l, lane);
+    blk_from_desc(b, y, l, lane);
+    blk_op(op, x, y);
+    u32 c = wave_sum(blk_lane_popcount(x));
+    if (lane == 0 && c) atomicAdd(reinterpret_cast<unsigned long long*>(total), (unsigned long long)c);
+}
+
+// ---------------------------------------------------------------------------
+// OR-group classification (aggregator::sort_input_blocks_or src/bmaggregator.h:2278):
+// row = [hdr, flags, region(n)]; hdr = nbit | ngap<<16; any FULL => ROW_FULL;
+// nothing => ROW_EMPTY.  One thread per column.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256)
+void k_or_sort(const u64* const* __restrict__ descs, const u32* __restrict__ nblk, u32 n, u32 ncols,
+               u64* __restrict__ dmat)
+{
+    u32 c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ncols) return;
+    u64* row = dmat + (size_t)c * (n + 2u);
+    u64* r = row + 2;
+    u32 nbit = 0, ngap = 0; bool full = false;
+    for (u32 k = 0; k < n; ++k) {
+        u64 d = c < nblk[k] ? descs[k][c] : 0ull;
+        u32 kd = DESC_K(d);
+        if (kd == K_NULL) continue;
+        if (kd == K_FULL) { full = true; break; }
+        if (kd == K_BIT) r[nbit++] = DESC_P(d);
+        else r[n - 1u - ngap++] = DESC_P(d);
+    }
+    row[0] = (u64)nbit | ((u64)ngap << 16);
+    row[1] = full ? ROW_FULL : ((nbit | ngap) ? 0ull : ROW_EMPTY);
+}
+
+// aggregator::combine_or(i, j, ...)  src/bmaggregator.h:1626; bit-block chain
+// process_bit_blocks_or :1924 (saturation to all-ones => FULL, :1951);
+// GAP operands process_gap_blocks_or :1808.
+template <int U>
+__global__ __launch_bounds__(256)
+void k_agg_or(const u64* __restrict__ dmat, u32 n, u32 ncols, int opt_compress, int xcd_swz,
+              uint4* __restrict__ slab, u64* __restrict__ desc, BlockStat* __restrict__ st)
+{
+    extern __shared__ u32 lds_dyn[];
+    u32 lane = lane_id(), wave = threadIdx.x >> 6;
+    u32 bid = xcd_swz ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
+    u32 c = uniform32(bid * 4u + wave);
+    if (c >= ncols) return;
+    const u64* row = dmat + (size_t)c * (n + 2u);
+    u64 hdr = uniform64(row[0]), flags = uniform64(row[1]);
+    if (flags & ROW_EMPTY) { store_trivial(K_NULL, c, desc, st, lane); return; }
+    if (flags & ROW_FULL) { store_trivial(K_FULL, c, desc, st, lane); return; }
+    u32 nbit = (u32)(hdr & 0xFFFFu), ngap = (u32)((hdr >> 16) & 0xFFFFu);
+    const u64* p = row + 2;
+    Blk acc;
+    u32 k = 0;
+    if (nbit) { blk_load(acc, as_gc4(uniform64(p[0])), lane); k = 1; }
+    else blk_fill(acc, 0u);
+    for (; k + U <= nbit; k += U) {
+        Blk t[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) blk_load(t[u], as_gc4(uniform64(p[k + u])), lane);
+#pragma unroll
+        for (int u = 0; u < U; ++u) blk_or(acc, t[u]);
+        if (blk_is_ones(acc)) { store_trivial(K_FULL, c, desc, st, lane); return; }
+    }
+    for (; k < nbit; ++k) {
+        Blk t; blk_load(t, as_gc4(uniform64(p[k])), lane);
+        blk_or(acc, t);
+    }
+    u32* lds = lds_dyn + wave * 2048u;
+    for (u32 i = 0; i < ngap; ++i) {
+        Blk t; gap_decode(as_gc16(uniform64(p[n - 1u - i])), lds, t, lane);
+        blk_or(acc, t);
+    }
+    store_result(acc, c, opt_compress, slab, desc, st, lane);
+}
+
+// aggregator::combine_and_sub(target, ...)  src/bmaggregator.h:1162 with result
+// blocks (always stored with opt_compress, :1210-1211).  Shares the row format
+// and evaluation order of k_pipe_counts (single group).
+template <int U>
+__global__ __launch_bounds__(256)
+void k_agg_and_sub(const u64* __restrict__ dmat, const u32* __restrict__ and_n_p, const u32* __restrict__ sub_n_p,
+                   u32 col_stride, u32 ncols, int opt_compress, int xcd_swz,
+                   uint4* __restrict__ slab, u64* __restrict__ desc, BlockStat* __restrict__ st)
+{
+    extern __shared__ u32 lds_dyn[];
+    u32 lane = lane_id(), wave = threadIdx.x >> 6;
+    u32 bid = xcd_swz ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
+    u32 c = uniform32(bid * 4u + wave);
+    if (c >= ncols) return;
+    const u64* row = dmat + (size_t)c * col_stride;
+    u64 hdr = uniform64(row[0]), flags = uniform64(row[1]);
+    if (flags & ROW_EMPTY) { store_trivial(K_NULL, c, desc, st, lane); return; }
+    if (flags & ROW_FULL) { store_trivial(K_FULL, c, desc, st, lane); return; }
+    u32 nba = (u32)(hdr & 0xFFFFu), nga = (u32)((hdr >> 16) & 0xFFFFu);
+    u32 nbs = (u32)((hdr >> 32) & 0xFFFFu), ngs = (u32)(hdr >> 48);
+    u32 na = uniform32(and_n_p[0]), ns = uniform32(sub_n_p[0]);
+    const u64* pa = row + 2;
+    const u64* ps = pa + na;
+    u32* lds = lds_dyn + wave * 2048u;
+    Blk acc;
+    u32 k = 0;
+    bool zero = false;
+    if (flags & ROW_ONES) blk_fill(acc, ~0u);
+    else { blk_load(acc, as_gc4(uniform64(pa[0])), lane); k = 1; }
+    for (; k + U <= nba && !zero; k += U) {
+        Blk t[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) blk_load(t[u], as_gc4(uniform64(pa[k + u])), lane);
+#pragma unroll
+        for (int u = 0; u < U; ++u) blk_and(acc, t[u]);
+        zero = blk_is_zero(acc);
+    }
+    for (; k < nba && !zero; ++k) { Blk t; blk_load(t, as_gc4(uniform64(pa[k])), lane); blk_and(acc, t); }
+    for (k = 0; k < nbs && !zero; ++k) {
+        Blk t; blk_load(t, as_gc4(uniform64(ps[k])), lane); blk_andn(acc, t);
+        if ((k & 3u) == 3u) zero = blk_is_zero(acc);
+    }
+    for (u32 i = 0; i < nga && !zero; ++i) {
+        Blk t; gap_decode(as_gc16(uniform64(pa[na - 1u - i])), lds, t, lane);
+        blk_and(acc, t); zero = blk_is_zero(acc);
+    }
+    for (u32 i = 0; i < ngs && !zero; ++i) {
+        Blk t; gap_decode(as_gc16(uniform64(ps[ns - 1u - i])), lds, t, lane);
+        blk_andn(acc, t); zero = blk_is_zero(acc);
+    }
+    if (zero) { store_trivial(K_NULL, c, desc, st, lane); return; }
+    store_result(acc, c, opt_compress, slab, desc, st, lane);
+}
+
+// ---------------------------------------------------------------------------
+// Rank / select.
+// Device index (MI355X-first, sized for HBM not for a CPU cache): per block
+//   rcount[nb]  u64  ones in blocks [0..nb]              (rs_index::rcount, src/bmrs.h:361)
+//   cum[nb][64] u16  ones before each 1024-bit wave      (one 128 B line per block)
+// so rank(n) = rcount[nb-1] + cum[nb][w] + popcount of <= 128 B: three
+// INDEPENDENT loads whose addresses all follow from n (no pointer chase).
+// The reference-compatible bcount / sub_count words (src/bm.h:2646-2656) are
+// produced alongside so a host rs_index can be filled (bmx_rs_export).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ u32 word_count_to(u32 w, u32 widx, u32 R)
+{
+    // ones of word `widx` that lie at block positions <= R
+    u32 lo = widx * 32u;
+    if (lo > R) return 0u;
+    u32 n = R - lo;                      // last included bit index, may be >= 31
+    u32 m = n >= 31u ? ~0u : ((2u << n) - 1u);
+    return __popc(w & m);
+}
+
+__device__ __forceinline__ u32 blk_lane_count_to(const Blk& b, u32 R, u32 lane)
+{
+    u32 c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        u32 w0 = (u32)i * 256u + lane * 4u;
+        c += word_count_to(b.r[i].x, w0, R) + word_count_to(b.r[i].y, w0 + 1u, R)
+           + word_count_to(b.r[i].z, w0 + 2u, R) + word_count_to(b.r[i].w, w0 + 3u, R);
+    }
+    return c;
+}
+
+// ones of a GAP block at positions <= R (gap_bit_count_to src/bmfunc.h:3499), lane partial
+__device__ __forceinline__ u32 gap_lane_count_to(gcptr16 g, u32 R, u32 lane)
+{
+    u32 hdr = g[0]; u32 len = hdr >> 3, s = hdr & 1u; u32 c = 0;
+    for (u32 k = 1 + lane; k <= len; k += 64) {
+        if ((s ^ ((k - 1u) & 1u)) != 0u) {
+            u32 e = g[k];
+            u32 start = (k == 1u) ? 0u : (u32)g[k - 1] + 1u;
+            if (start <= R) c += (e < R ? e : R) - start + 1u;
+        }
+    }
+    return c;
+}
+// gap_bfind (src/bmfunc.h:1844): smallest k with g[k] >= pos, lane partial = #{k: g[k] < pos}
+__device__ __forceinline__ u32 gap_lane_below(gcptr16 g, u32 pos, u32 lane)
+{
+    u32 len = (u32)g[0] >> 3; u32 c = 0;
+    for (u32 k = 1 + lane; k <= len; k += 64) c += ((u32)g[k] < pos);
+    return c;
+}
+
+// bvector::build_rs_index  src/bm.h:2531, one wave per block
+__global__ __launch_bounds__(256)
+void k_rs_build(const u64* __restrict__ desc, u32 nblocks, u32* __restrict__ bcount, u64* __restrict__ sub,
+                u16* __restrict__ cum)
+{
+    __shared__ u32 lds[4 * 2048];
+    u32 lane = lane_id(), wave = threadIdx.x >> 6;
+    u32 nb = uniform32(blockIdx.x * 4u + wave);
+    if (nb >= nblocks) return;
+    u64 d = uniform64(desc[nb]);
+    u32 k = DESC_K(d);
+    u16* crow = cum + (size_t)nb * 64u;
+    if (k == K_NULL) { crow[lane] = 0; if (lane == 0) { bcount[nb] = 0; sub[nb] = 0; } return; }
+    if (k == K_FULL) {
+        crow[lane] = (u16)(lane * 1024u);
+        if (lane == 0) { bcount[nb] = 65536u; sub[nb] = 21825ull | (21824ull << 16) | (32737ull << 32) | (54561ull << 48); }
+        return;
+    }
+    u32 c0, c1, total; u64 aux0, aux1;
+    Blk b;
+    if (k == K_BIT) {
+        blk_load(b, as_gc4(DESC_P(d)), lane);
+        aux0 = wave_sum(blk_lane_count_to(b, 21824u + 10912u, lane));
+        aux1 = wave_sum(blk_lane_count_to(b, 43648u + 10912u, lane));
+    } else {
+        gcptr16 g = as_gc16(DESC_P(d));
+        gap_decode(g, lds + wave * 2048u, b, lane);
+        u32 s = (u32)g[0] & 1u;
+        u32 i0 = 1u + wave_sum(gap_lane_below(g, 21825u, lane));
+        u32 i1 = 1u + wave_sum(gap_lane_below(g, 43649u, lane));
+        aux0 = ((u64)i0 << 1) | (s ^ ((i0 - 1u) & 1u));
+        aux1 = ((u64)i1 << 1) | (s ^ ((i1 - 1u) & 1u));
+    }
+    c0 = wave_sum(blk_lane_count_to(b, 21824u, lane));
+    c1 = wave_sum(blk_lane_count_to(b, 43648u, lane));
+    // per-1024-bit wave counts: 1024 bits = 32 words = 8 lanes x 4 words of one register row
+    u32 mine = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        u32 pc = __popc(b.r[i].x) + __popc(b.r[i].y) + __popc(b.r[i].z) + __popc(b.r[i].w);
+        pc += __shfl_xor(pc, 1, 64); pc += __shfl_xor(pc, 2, 64); pc += __shfl_xor(pc, 4, 64);
+        // lanes 8q..8q+7 now hold the count of digest wave (i*8 + q); hand it to lane i*8+q
+        u32 v = __shfl(pc, (lane & 7u) * 8u, 64);
+        if ((lane >> 3) == (u32)i) mine = v;
+    }
+    u32 incl = wave_scan_incl(mine, lane);
+    crow[lane] = (u16)(incl - mine);
+    total = __shfl(incl, 63, 64);
+    if (lane == 0) {
+        bcount[nb] = total;
+        sub[nb] = (u64)(c0 | ((c1 - c0) << 16)) | ((aux0 & 0xFFFFull) << 32) | ((aux1 & 0xFFFFull) << 48);
+    }
+}
+
+// inclusive running count over blocks (single workgroup)
+__global__ __launch_bounds__(1024)
+void k_rs_scan(const u32* __restrict__ bcount, u32 nblocks, u64* __restrict__ rcount, u64* __restrict__ total)
+{
+    __shared__ u64 s[1024];
+    __shared__ u64 carry;
+    u32 tid = threadIdx.x;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (u32 base = 0; base < nblocks; base += 1024u) {
+        u32 nb = base + tid;
+        u64 v = nb < nblocks ? bcount[nb] : 0u;
+        s[tid] = v; __syncthreads();
+        for (u32 o = 1; o < 1024u; o <<= 1) {
+            u64 a = tid >= o ? s[tid - o] : 0ull;
+            __syncthreads();
+            s[tid] += a;
+            __syncthreads();
+        }
+        if (nb < nblocks) rcount[nb] = carry + s[tid];
+        __syncthreads();
+        if (tid == 1023u) carry += s[1023];
+        __syncthreads();
+    }
+    if (tid == 0) *total = carry;
+}
+
+// 8 lanes cooperate on one query (8 queries per wave step): each lane owns 16 B
+// of the 128 B line that holds the query's 1024-bit wave.
+__device__ __forceinline__ u32 group_sum8(u32 v)
+{
+    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
+    return v;
+}
+
+// ones of GAP block g at positions in [from..to] (to inclusive), summed over a group of 8 lanes
+__device__ __forceinline__ u32 gap_group_count_range(gcptr16 g, u32 from, u32 to, u32 sub)
+{
+    u32 hdr = g[0]; u32 len = hdr >> 3, s = hdr & 1u;
+    // first run that reaches `from`: smallest k with g[k] >= from (binary search, all lanes alike)
+    u32 lo = 1, hi = len;
+    while (lo < hi) { u32 mid = (lo + hi) >> 1; if ((u32)g[mid] < from) lo = mid + 1; else hi = mid; }
+    u32 c = 0;
+    for (u32 k = lo + sub; k <= len; k += 8) {
+        u32 start = (k == 1u) ? 0u : (u32)g[k - 1] + 1u;
+        if (start > to) break;
+        if ((s ^ ((k - 1u) & 1u)) != 0u) {
+            u32 e = g[k];
+            u32 a = start > from ? start : from, b = e < to ? e : to;
+            c += b - a + 1u;
+        }
+    }
+    return c;
+}
+
+// bvector::count_to / rank(n, rs)  src/bm.h:3120 -- ones in [0..n]
+__global__ __launch_bounds__(256)
+void k_rank(const u64* __restrict__ desc, u32 nblocks, const u64* __restrict__ rcount, const u16* __restrict__ cum,
+            u64 total, const u64* __restrict__ q, u64 nq, u64* __restrict__ out)
+{
+    u32 sub = threadIdx.x & 7u;
+    u64 qi = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 3;
+    u64 stride = ((u64)gridDim.x * blockDim.x) >> 3;
+    u64 nq_round = (nq + 7ull) & ~7ull;
+    for (; qi < nq_round; qi += stride) {          // whole groups stay converged
+        bool live = qi < nq;
+        u64 n = live ? q[qi] : 0ull;
+        u64 nb64 = n >> 16; u32 nbit = (u32)(n & 0xFFFFu);
+        u64 res = 0;
+        u32 part = 0;
+        if (nb64 >= nblocks) res = total;           // rs.get_total() rule, src/bm.h:3133
+        else {
+            u32 nb = (u32)nb64;
+            u64 d = desc[nb];
+            u32 kd = DESC_K(d);
+            res = nb ? rcount[nb - 1] : 0ull;
+            u32 w = nbit >> 10;                     // digest wave
+            if (kd == K_FULL) res += (u64)nbit + 1u;
+            else if (kd == K_BIT) {
+                res += cum[(size_t)nb * 64u + w];
+                u32x4 v = as_gc4(DESC_P(d))[w * 8u + sub];
+                u32 base = w * 32u + sub * 4u;      // word index of v.x
+                part = word_count_to(v.x, base, nbit) + word_count_to(v.y, base + 1u, nbit)
+                     + word_count_to(v.z, base + 2u, nbit) + word_count_to(v.w, base + 3u, nbit);
+            } else if (kd == K_GAP) {
+                res += cum[(size_t)nb * 64u + w];
+                part = gap_group_count_range(as_gc16(DESC_P(d)), w << 10, nbit, sub);
+            }
+        }
+        part = group_sum8(part);
+        if (live && sub == 0) out[qi] = res + part;
+    }
+}
+
+// bvector::select(rank, pos, rs)  src/bm.h:5350: position of the rank-th (1-based) set bit
+__global__ __launch_bounds__(256)
+void k_select(const u64* __restrict__ desc, u32 nblocks, const u64* __restrict__ rcount, const u16* __restrict__ cum,
+              u64 total, const u64* __restrict__ q, u64 nq, u64* __restrict__ pos, u8* __restrict__ found)
+{
+    u32 lane = lane_id();
+    u32 sub = lane & 7u;
+    u64 qi = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 3;
+    u64 stride = ((u64)gridDim.x * blockDim.x) >> 3;
+    u64 nq_round = (nq + 7ull) & ~7ull;
+    for (; qi < nq_round; qi += stride) {
+        bool live = qi < nq;
+        u64 r = live ? q[qi] : 0ull;
+        bool ok = live && r != 0ull && r <= total && nblocks != 0u;
+        u64 result = 0;
+        u32 kd = K_NULL, w = 0, rr = 0, nb = 0; u64 d = 0;
+        if (ok) {
+            // rs_index::find (src/bmrs.h:492): first block whose running count reaches r
+            u32 lo = 0, hi = nblocks - 1u;
+            while (lo < hi) { u32 mid = lo + ((hi - lo) >> 1); if (rcount[mid] < r) lo = mid + 1u; else hi = mid; }
+            nb = lo;
+            rr = (u32)(r - (nb ? rcount[nb - 1] : 0ull));       // 1..65536 inside the block
+            d = desc[nb]; kd = DESC_K(d);
+            if (kd == K_FULL) result = ((u64)nb << 16) + rr - 1u;
+            else {
+                // digest wave: last w with cum[w] < rr
+                const u16* crow = cum + (size_t)nb * 64u;
+                u32 l2 = 0, h2 = 63;
+                while (l2 < h2) { u32 mid = (l2 + h2 + 1u) >> 1; if ((u32)crow[mid] < rr) l2 = mid; else h2 = mid - 1u; }
+                w = l2; rr -= crow[w];                          // 1..1024 inside the wave
+            }
+        }
+        // bit-blocks: 8 lanes x 16 B = the wave's 128 B line (block_find_rank src/bmfunc.h:9754)
+        u32x4 v = (u32x4)(0u);
+        if (ok && kd == K_BIT) v = as_gc4(DESC_P(d))[w * 8u + sub];
+        u32 p0 = __popc(v.x), p1 = __popc(v.y), p2 = __popc(v.z), p3 = __popc(v.w);
+        u32 mine = p0 + p1 + p2 + p3;
+        // exclusive prefix inside the group of 8
+        u32 incl = mine;
+        { u32 t;
+          t = __shfl_up(incl, 1, 64); if (sub >= 1u) incl += t;
+          t = __shfl_up(incl, 2, 64); if (sub >= 2u) incl += t;
+          t = __shfl_up(incl, 4, 64); if (sub >= 4u) incl += t; }
+        u32 excl = incl - mine;
+        bool hit = ok && kd == K_BIT && rr > excl && rr <= incl;
+        if (hit) {
+            u32 need = rr - excl;                               // 1..mine within my 4 words
+            u32 word, wi;
+            if (need <= p0) { word = v.x; wi = 0; }
+            else if (need <= p0 + p1) { word = v.y; wi = 1; need -= p0; }
+            else if (need <= p0 + p1 + p2) { word = v.z; wi = 2; need -= p0 + p1; }
+            else { word = v.w; wi = 3; need -= p0 + p1 + p2; }
+            for (u32 s = 1; s < need; ++s) word &= word - 1u;   // word_select (src/bmfunc.h:1084)
+            u32 bit = (w * 32u + sub * 4u + wi) * 32u + (u32)__builtin_ctz(word);
+            pos[qi] = ((u64)nb << 16) + bit;
+        }
+        if (ok && kd == K_GAP) {
+            // gap_find_rank (src/bmfunc.h:3457) restricted to the wave: walk runs from the wave start
+            gcptr16 g = as_gc16(DESC_P(d));
+            u32 hdr = g[0]; u32 len = hdr >> 3, s0 = hdr & 1u;
+            u32 from = w << 10;
+            u32 lo = 1, hi = len;
+            while (lo < hi) { u32 mid = (lo + hi) >> 1; if ((u32)g[mid] < from) lo = mid + 1; else hi = mid; }
+            if (sub == 0) {
+                u32 need = rr;
+                for (u32 k = lo; k <= len; ++k) {
+                    if ((s0 ^ ((k - 1u) & 1u)) != 0u) {
+                        u32 start = (k == 1u) ? 0u : (u32)g[k - 1] + 1u;
+                        if (start < from) start = from;
+                        u32 cnt = (u32)g[k] - start + 1u;
+                        if (need <= cnt) { result = ((u64)nb << 16) + start + need - 1u; break; }
+                        need -= cnt;
+                    }
+                }
+            }
+        }
+        if (live && sub == 0) {
+            found[qi] = ok ? 1 : 0;
+            if (!ok) pos[qi] = 0;
+            else if (kd != K_BIT) pos[qi] = result;
+        }
+    }
+}

@@ -1,0 +1,183 @@
+/*
+ * bmx.h -- C-ABI of the MI355X-native bit-vector set-algebra engine (libbmx.so).
+ *
+ * This is the drop-in boundary for the bm::bvector<> / bm::aggregator<> hot path
+ * of BitMagic (reference = /root/reference, v9.2.1).  The reference has no
+ * run-time FFI for this path: its only seam is the compile-time VECT_* macro
+ * table (src/bmavx2.h:3432-3587, selected by src/bmsimd.h:24-65), whose calls
+ * cover one 8 KiB block each -- three orders of magnitude too fine for a GPU
+ * launch.  The boundary therefore sits one level up, at the per-vector loops
+ * that walk the (i,j) block tree; each entry point below names the reference
+ * interface it replaces.  Conventions follow the reference's own C wrapper
+ * (lang-maps/libbm/include/libbm.h:28-35,74-76,123-140): opaque handles, every
+ * function returns an int status, outputs through pointer arguments, no C++
+ * exceptions or STL types cross the ABI, plain pointers and sizes only.
+ *
+ * Data model handed across the boundary: a vector is a
+ * flat BLOCK TABLE -- kinds[nb] in {NULL, FULL, BIT, GAP} plus one contiguous
+ * slab of 8 KiB bit-blocks and one slab of GAP blocks (uint16 run-end lists) --
+ * obtained by walking blocks_manager::top_blocks_root() (src/bmblocks.h:595)
+ * exactly like bvector::count() does (src/bm.h:2436-2474).
+ *
+ * Threading: one bmx_ctx = one HIP stream; calls on a ctx are serialised by the
+ * caller (the reference aggregator is not thread-safe either,
+ * src/bmaggregator.h:824-853); distinct contexts may run concurrently.
+ * Vectors are immutable once created and may be shared by any number of
+ * operations on the context that owns them.
+ */
+#ifndef BMX_H
+#define BMX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* status codes: numeric values of libbm.h:28-35 where a twin exists */
+#define BMX_OK            0
+#define BMX_ERR_BADALLOC  1   /* BM_ERR_BADALLOC */
+#define BMX_ERR_BADARG    2   /* BM_ERR_BADARG   */
+#define BMX_ERR_RANGE     3   /* BM_ERR_RANGE    */
+#define BMX_ERR_DEVICE    4   /* BM_ERR_CPU twin: no usable gfx950 device / HIP failure */
+
+/* block kinds of the flat block table (tagged pointers of src/bmdef.h:165-199) */
+#define BMX_NULL 0
+#define BMX_FULL 1
+#define BMX_BIT  2
+#define BMX_GAP  3
+
+/* set operations (src/bmconst.h set_operation: set_AND, set_OR, set_XOR, set_SUB) */
+#define BMX_AND 0
+#define BMX_OR  1
+#define BMX_XOR 2
+#define BMX_SUB 3
+
+/* geometry (src/bmconst.h:55-87) */
+#define BMX_BLOCK_WORDS 2048u
+#define BMX_BLOCK_BITS  65536u
+
+typedef struct bmx_ctx      bmx_ctx;
+typedef struct bmx_vec      bmx_vec;
+typedef struct bmx_pipeline bmx_pipeline;
+typedef struct bmx_rs       bmx_rs;
+
+/* ---- library / context (BM_init, BM_error_msg, BM_simd_version: libbm.h:123-140) ---- */
+const char* bmx_error_msg(int status);
+/* last HIP/driver error text recorded on this thread ("" if none) */
+const char* bmx_last_error(void);
+/* 950 for gfx950: the analogue of bm::simd_version() (src/bmsimd.h:67-90) */
+int bmx_simd_version(void);
+int bmx_device_count(int* n);
+/* stream: a hipStream_t owned by the caller, or NULL to let the context create its own */
+int bmx_ctx_create(int device, void* stream, bmx_ctx** out);
+int bmx_ctx_destroy(bmx_ctx* ctx);
+int bmx_ctx_synchronize(bmx_ctx* ctx);
+/* bytes of HBM currently held by vectors/pipelines of this context */
+int bmx_ctx_mem_used(const bmx_ctx* ctx, uint64_t* bytes);
+
+/* ---- vectors ---- */
+/* Upload a flattened block table (walk of top_blocks_root()).
+ * offs[nb]: BIT -> ordinal of the block inside bit_slab; GAP -> uint16 word offset
+ * of the block inside gap_slab.  The engine copies; the host keeps its blocks. */
+int bmx_vec_upload(bmx_ctx* ctx, uint64_t nbits, uint32_t nblocks,
+                   const uint8_t* kinds, const uint32_t* offs,
+                   const uint32_t* bit_slab, uint32_t n_bit_blocks,
+                   const uint16_t* gap_slab, uint64_t gap_words,
+                   bmx_vec** out);
+/* bm::bit_import_u32(bv, words, nwords, optimize)  src/bmbvimport.h:46.
+ * Raw bits go to the device; classification into NULL/FULL/BIT and, with
+ * optimize, GAP compression (optimize_bit_block, src/bmblocks.h:1412) run there. */
+int bmx_vec_import_bits(bmx_ctx* ctx, const uint32_t* words, uint64_t nwords,
+                        int optimize, bmx_vec** out);
+/* Synthetic vector generated on the device with the counter-based generator of
+ * SURVEY.md section 8(d) (normative arithmetic: oracle/bmx_oracle.c bmo_gen_word64):
+ * per-bit Bernoulli(density_q16 / 65536); with_common ORs in the shared vector
+ * (correlated data set, tests/perf/perf.cpp:234-267); then as bmx_vec_import_bits. */
+int bmx_vec_generate(bmx_ctx* ctx, uint64_t seed, uint32_t vec_id, int with_common,
+                     uint32_t density_q16, uint64_t nbits, int optimize, bmx_vec** out);
+int bmx_vec_free(bmx_ctx* ctx, bmx_vec* v);
+/* bvector::calc_stat (src/bm.h:4010): counts[kind]; bit_slab_blocks / gap_words =
+ * sizes (8 KiB blocks / uint16 words) of the two slabs bmx_vec_download fills.
+ * Result vectors keep one slab slot per block column, so bit_slab_blocks may
+ * exceed counts[BMX_BIT]; offs[] always indexes the slab that is downloaded. */
+int bmx_vec_info(const bmx_vec* v, uint64_t* nbits, uint32_t* nblocks,
+                 uint32_t counts[4], uint32_t* bit_slab_blocks, uint64_t* gap_words);
+/* Download the block table (feeds blocks_manager on the host, src/bmblocks.h:1355).
+ * Array sizes come from bmx_vec_info; any pointer may be NULL to skip that part. */
+int bmx_vec_download(bmx_ctx* ctx, const bmx_vec* v, uint8_t* kinds, uint32_t* offs,
+                     uint32_t* bit_slab, uint16_t* gap_slab);
+/* expand to raw words (export twin of bit_import_u32) */
+int bmx_vec_to_words(bmx_ctx* ctx, const bmx_vec* v, uint32_t* words, uint64_t nwords);
+
+/* ---- pairwise set algebra ---- */
+/* bvector::count()  src/bm.h:2431 */
+int bmx_count(bmx_ctx* ctx, const bmx_vec* a, uint64_t* count);
+/* bvector::bit_and/bit_or/bit_xor/bit_sub(bv1, bv2, opt_mode)  src/bm.h:6185,5973,6072,6403
+ * opt_compress != 0 re-compresses produced blocks (opt_compress, src/bm.h:6263). */
+int bmx_op2(bmx_ctx* ctx, int op, const bmx_vec* a, const bmx_vec* b, int opt_compress,
+            bmx_vec** result);
+/* bm::count_and/count_or/count_xor/count_sub  src/bmalgo.h:49,149,81,115 */
+int bmx_count_op2(bmx_ctx* ctx, int op, const bmx_vec* a, const bmx_vec* b, uint64_t* count);
+
+/* ---- aggregator ---- */
+/* aggregator::combine_or(target, src, n)  src/bmaggregator.h:1101 */
+int bmx_agg_or(bmx_ctx* ctx, const bmx_vec* const* src, size_t n, bmx_vec** result);
+/* aggregator::combine_and_sub(target, and, n_and, sub, n_sub, false)  src/bmaggregator.h:1162
+ * (combine_and(target) == n_sub 0, :1030-1039).  *any = result is non-empty. */
+int bmx_agg_and_sub(bmx_ctx* ctx, const bmx_vec* const* src_and, size_t n_and,
+                    const bmx_vec* const* src_sub, size_t n_sub,
+                    bmx_vec** result, int* any);
+/* aggregator::pipeline<agg_opt_only_counts>  src/bmaggregator.h:62-103,222-341:
+ * arg-groups are given as concatenated operand lists, and_n[g] / sub_n[g] per
+ * group (pipeline::add() + arg_groups::add(bv, 0|1) + complete(), :2784-2931). */
+int bmx_pipeline_create(bmx_ctx* ctx,
+                        const bmx_vec* const* and_list, const uint32_t* and_n,
+                        const bmx_vec* const* sub_list, const uint32_t* sub_n,
+                        size_t ngroups, bmx_pipeline** out);
+int bmx_pipeline_destroy(bmx_ctx* ctx, bmx_pipeline* p);
+/* aggregator::combine_and_sub(pipe)  src/bmaggregator.h:1292 with counts only
+ * (:1392-1399): counts_out[g] = popcount of group g's AND-SUB result restricted
+ * to block columns [nb_from, nb_to) (nb_to = UINT32_MAX: all).  Synchronous. */
+int bmx_pipeline_run_counts(bmx_ctx* ctx, bmx_pipeline* p, uint32_t nb_from, uint32_t nb_to,
+                            uint64_t* counts_out);
+/* Same, asynchronous on the context's stream; d_counts is DEVICE memory
+ * (ngroups x uint64) -- e.g. the buffer a following RCCL all-reduce sums. */
+int bmx_pipeline_run_counts_dev(bmx_ctx* ctx, bmx_pipeline* p, uint32_t nb_from, uint32_t nb_to,
+                                uint64_t* d_counts);
+/* algorithmic operand bytes one run over [nb_from, nb_to) must read
+ * (8192 B per bit-block operand, 2*(len+1) B per GAP operand; NULL/FULL: 0) */
+int bmx_pipeline_operand_bytes(bmx_ctx* ctx, bmx_pipeline* p, uint32_t nb_from, uint32_t nb_to,
+                               uint64_t* bytes);
+
+/* ---- rank / select ---- */
+/* bvector::build_rs_index  src/bm.h:2531 */
+int bmx_rs_build(bmx_ctx* ctx, const bmx_vec* v, bmx_rs** out);
+int bmx_rs_free(bmx_ctx* ctx, bmx_rs* rs);
+/* rs_index::count()  src/bmrs.h:340 */
+int bmx_rs_count(const bmx_rs* rs, uint64_t* count);
+/* reference-compatible per-block arrays so a host rs_index can be filled:
+ * bcount[nb] (rs_index::count(nb)) and sub_count[nb] packed as
+ * first | second<<16 | aux0<<32 | aux1<<48 (src/bm.h:2646-2656, src/bmrs.h:688) */
+int bmx_rs_export(bmx_ctx* ctx, const bmx_rs* rs, uint32_t* bcount, uint64_t* sub_count);
+/* bvector::count_to / rank(n, rs): ones in [0..n] inclusive  src/bm.h:3120,1449 (batched) */
+int bmx_rank_batch(bmx_ctx* ctx, const bmx_vec* v, const bmx_rs* rs,
+                   const uint64_t* n, size_t q, uint64_t* out);
+/* bvector::select(rank, pos, rs): rank is 1-based  src/bm.h:5350 (batched) */
+int bmx_select_batch(bmx_ctx* ctx, const bmx_vec* v, const bmx_rs* rs,
+                     const uint64_t* rank, size_t q, uint64_t* pos, uint8_t* found);
+/* device-resident query/answer buffers (no PCIe in the timed region) */
+int bmx_rank_batch_dev(bmx_ctx* ctx, const bmx_vec* v, const bmx_rs* rs,
+                       const uint64_t* d_n, size_t q, uint64_t* d_out);
+int bmx_select_batch_dev(bmx_ctx* ctx, const bmx_vec* v, const bmx_rs* rs,
+                         const uint64_t* d_rank, size_t q, uint64_t* d_pos, uint8_t* d_found);
+
+/* ---- timing helper: HIP events on the context's stream ---- */
+int bmx_timer_start(bmx_ctx* ctx);
+int bmx_timer_stop_ms(bmx_ctx* ctx, float* ms);   /* synchronises on the stop event */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BMX_H */

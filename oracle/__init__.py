@@ -203,6 +203,8 @@ class Oracle:
             L.bmo_vec_from_table.restype = vp
             L.bmo_vec_from_table.argtypes = [C.c_uint64, C.c_uint32, C.POINTER(C.c_uint8), C.POINTER(C.c_uint32),
                                              C.POINTER(C.c_uint32), C.POINTER(C.c_uint16)]
+            L.bmo_gen_word64.restype = C.c_uint64
+            L.bmo_gen_word64.argtypes = [C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32]
             L.bmo_gen_words.restype = None
             L.bmo_gen_words.argtypes = [C.c_uint64, C.c_uint32, C.c_int, C.c_uint32, C.c_uint64, C.c_uint64,
                                         C.c_uint64, C.POINTER(C.c_uint32)]

@@ -44,6 +44,7 @@ inline int block_kind(const bm::word_t* p)
 
 } // namespace
 
+#pragma GCC visibility push(default)
 extern "C" {
 
 int ref_simd_version() { return bm::simd_version(); }
@@ -253,3 +254,4 @@ void ref_gap_convert_to_bitset(uint32_t* dest, const uint16_t* gap) { bm::gap_co
 uint32_t ref_gap_bit_count(const uint16_t* gap) { return bm::gap_bit_count_unr(gap); }
 
 } // extern "C"
+#pragma GCC visibility pop

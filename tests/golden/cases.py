@@ -1,0 +1,93 @@
+"""Deterministic input construction shared by make_golden.py (runs against the
+reference in the build container) and the tests (run anywhere).  Inputs are
+rebuilt from the normative counter-based generator (oracle/bmx_oracle.c
+bmo_gen_word64); the fixtures pin them with a SHA-256 so a generator drift is caught."""
+from __future__ import annotations
+
+import hashlib
+
+import numpy as np
+
+SEED = 0xB17A61C
+BLOCK_WORDS = 2048
+
+# name -> (nbits, n_vectors, density_q16, common_density_q16 or None, structured)
+CASES = {
+    "gap_sparse":   (3 * 65536 + 4321, 6, 66, None, True),      # 0.1 %  -> all GAP
+    "gap_half":     (3 * 65536 + 4321, 6, 328, None, True),     # 0.5 %  -> all GAP, long run lists
+    "mixed_1pct":   (4 * 65536 + 77, 6, 655, 655, True),        # 1 %    -> bit/GAP mix
+    "bit_10pct":    (3 * 65536 + 4321, 6, 6554, 6554, True),    # 10 %   -> bit-blocks, correlated (config 3A)
+    "bit_10pct_ind": (3 * 65536 + 1, 6, 6554, None, False),     # 10 %   independent (config 3B: AND empties)
+    "bit_50pct":    (2 * 65536 + 40000, 6, 32768, None, True),  # 50 %
+    "dense_gap":    (3 * 65536 + 4321, 6, 65470, None, True),   # 99.9 % -> GAP with long 1-runs
+    "one_block":    (1000, 6, 6554, None, False),               # config 1 scale: a single partial block
+}
+
+
+def structure(words: np.ndarray, case: str, v: int) -> np.ndarray:
+    """Plant NULL / FULL blocks and long runs so every block kind and every
+    pairwise kind combination occurs (mirrors FillSetsRandomMethod's mixing,
+    tests/stress/t.cpp:917)."""
+    nblocks = (words.size + BLOCK_WORDS - 1) // BLOCK_WORDS
+    h = int(hashlib.sha256(f"{case}:{v}".encode()).hexdigest(), 16)
+    for nb in range(nblocks):
+        r = (h >> (4 * nb)) & 15
+        lo, hi = nb * BLOCK_WORDS, min((nb + 1) * BLOCK_WORDS, words.size)
+        if r == 0:
+            words[lo:hi] = 0
+        elif r == 1:
+            words[lo:hi] = 0xFFFFFFFF
+        elif r == 2:                       # a long run of ones inside the block
+            words[lo + (hi - lo) // 4: lo + (hi - lo) // 2] = 0xFFFFFFFF
+        elif r == 3:                       # a long hole
+            words[lo + (hi - lo) // 3: lo + 2 * (hi - lo) // 3] = 0
+    return words
+
+
+def make_inputs(port, case: str):
+    """-> list of uint32 word arrays (one per vector), nbits"""
+    nbits, n, dq, cdq, structured = CASES[case]
+    out = []
+    for v in range(n):
+        w = port.gen_words(SEED, v, dq, nbits)
+        if cdq:
+            w |= port.gen_words(SEED, 0xFFFFFFFF, cdq, nbits)
+        if structured:
+            w = structure(w, case, v)
+            # keep bits >= nbits zero
+            tail = nbits % 32
+            nw = (nbits + 31) // 32
+            w[nw:] = 0
+            if tail:
+                w[nw - 1] &= (1 << tail) - 1
+        out.append(w)
+    return out, nbits
+
+
+def sha(a: np.ndarray) -> str:
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+# operand selections exercised per case: (AND indices, SUB indices)
+AGG_GROUPS = [([0, 1], []), ([0, 1, 2], []), ([0, 1, 2, 3, 4, 5], []), ([0, 1], [2]), ([0], [1, 2, 3]),
+              ([0, 1, 2], [3, 4, 5]), ([3], []), ([1, 0, 5, 2], [4])]
+OR_SETS = [[0, 1], [0, 1, 2, 3, 4, 5], [2], [5, 3, 1]]
+PAIRS = [(0, 1), (1, 0), (2, 3), (4, 5), (0, 0)]
+
+
+def rank_queries(nbits: int) -> np.ndarray:
+    rng = np.random.default_rng(12345)
+    q = rng.integers(0, nbits, size=512).astype(np.uint64)
+    fixed = [0, 1, 31, 32, 1023, 1024, 21823, 21824, 21825, 32736, 32737, 43647, 43648, 43649, 54560, 54561,
+             65534, 65535, 65536, 65537, nbits - 1]
+    fixed = [f for f in fixed if f < nbits]
+    return np.concatenate([q, np.array(fixed, np.uint64)])
+
+
+def select_queries(count: int) -> np.ndarray:
+    rng = np.random.default_rng(54321)
+    base = [0, 1, 2, count, count + 1, count + 1000]
+    if count > 0:
+        q = rng.integers(1, count + 1, size=512).astype(np.uint64)
+        return np.concatenate([q, np.array(base, np.uint64)])
+    return np.array(base, np.uint64)

@@ -1,0 +1,103 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.json from the REFERENCE ITSELF (BitMagic 9.2.1,
+/root/reference/src compiled by oracle/Makefile into oracle/_ref/).  Runs only in
+the build container; the outputs are committed so every other machine can check
+the oracle (and through it the HIP path) without the reference present.
+
+    python tests/golden/make_golden.py            # writes golden_avx2.json (+ checks scalar agrees)
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+sys.path.insert(0, HERE)
+
+import oracle  # noqa: E402
+from cases import (AGG_GROUPS, CASES, OR_SETS, PAIRS, SEED, make_inputs, rank_queries, select_queries, sha)  # noqa: E402
+
+
+def gap_slab_masked(kinds, offs, gaps):
+    g = gaps.copy()
+    for k, o in zip(kinds, offs):
+        if k == oracle.GAP:
+            g[o] &= 0xFFF9          # capacity level bits are an allocator detail
+    return g
+
+
+def run(R, P):
+    out = {"reference": R.name, "simd_version": int(R.lib.ref_simd_version()), "seed": SEED, "cases": {}}
+    # generator known answers (pins bmo_gen_word64; the HIP generator is checked against the same)
+    out["generator_kat"] = [
+        {"vec": v, "w64": w, "dq": d, "word": int(P.lib.bmo_gen_word64(SEED, v, w, d))}
+        for v, w, d in [(0, 0, 6554), (1, 12345, 655), (0xFFFFFFFF, 7, 32768), (255, 15625000 - 1, 6554), (3, 1 << 33, 1)]]
+    for case in CASES:
+        words, nbits = make_inputs(P, case)
+        vecs = [R.import_words(w, True, nbits) for w in words]
+        c = {"nbits": nbits, "input_sha": [sha(w) for w in words]}
+        flat = [v.flatten() for v in vecs]
+        c["kinds"] = [f[0].tolist() for f in flat]
+        c["gap_sha"] = [sha(gap_slab_masked(f[0], f[1], f[3])) for f in flat]
+        c["gap_words"] = [int(f[3].size) for f in flat]
+        c["count"] = [v.count() for v in vecs]
+        # pairwise
+        c["op2"] = {}
+        for (i, j) in PAIRS:
+            for op in range(4):
+                t = R.op2(op, vecs[i], vecs[j], False)
+                tc = R.op2(op, vecs[i], vecs[j], True)
+                assert (t.to_words() == tc.to_words()).all()
+                c["op2"][f"{op}:{i}:{j}"] = {"sha": sha(t.to_words()), "count": t.count(),
+                                             "count_op": R.count_op2(op, vecs[i], vecs[j]),
+                                             "kinds_opt": tc.flatten()[0].tolist()}
+        # aggregator
+        c["agg_and_sub"] = []
+        for (a, s) in AGG_GROUPS:
+            t = R.agg_and_sub([vecs[i] for i in a], [vecs[i] for i in s])
+            c["agg_and_sub"].append({"and": a, "sub": s, "sha": sha(t.to_words()), "count": t.count(),
+                                     "kinds": t.flatten()[0].tolist()})
+        c["agg_or"] = []
+        for o in OR_SETS:
+            t = R.agg_or([vecs[i] for i in o])
+            c["agg_or"].append({"src": o, "sha": sha(t.to_words()), "count": t.count()})
+        cnt = R.pipeline_counts([([vecs[i] for i in a], [vecs[i] for i in s]) for (a, s) in AGG_GROUPS])
+        c["pipeline_counts"] = [int(x) for x in cnt]
+        assert c["pipeline_counts"] == [g["count"] for g in c["agg_and_sub"]]
+        # rank / select
+        c["rs"] = []
+        for vi in (0, 1, 2):
+            v = vecs[vi]
+            rs = R.rs_build(v)
+            bc, sub = rs.export(v.nblocks)
+            rq = rank_queries(nbits)
+            sq = select_queries(v.count())
+            pos, found = rs.select(sq)
+            c["rs"].append({"vec": vi, "count": rs.count(), "bcount": bc.tolist(), "sub_count": [int(x) for x in sub],
+                            "rank": [int(x) for x in rs.rank(rq)],
+                            "select_found": found.astype(int).tolist(),
+                            "select_pos": [int(p) if f else 0 for p, f in zip(pos, found)]})
+        out["cases"][case] = c
+        print("case", case, "done", file=sys.stderr)
+    return out
+
+
+def main():
+    oracle.build()
+    P = oracle.port()
+    g = {fl: run(oracle.reference(fl), P) for fl in ("avx2", "scalar")}
+    a, s = g["avx2"], g["scalar"]
+    assert a["cases"] == s["cases"], "AVX2 and scalar reference builds disagree"
+    assert a["simd_version"] == 5 and s["simd_version"] == 0
+    a["also_verified_with"] = s["reference"]
+    with open(os.path.join(HERE, "golden_ref.json"), "w") as f:
+        json.dump(a, f, separators=(",", ":"))
+    print("wrote golden_ref.json", os.path.getsize(os.path.join(HERE, "golden_ref.json")), "bytes")
+
+
+if __name__ == "__main__":
+    main()

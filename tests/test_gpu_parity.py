@@ -1,0 +1,303 @@
+"""GPU parity tests: the HIP path, driven through the C-ABI (ctypes binding of
+include/bmx.h), against (1) the golden vectors the reference generated, (2) the CPU
+oracle on seeded inputs, (3) size-independent properties at BASELINE.json sizes.
+Bit-exact everywhere: all arithmetic is integer / bitwise."""
+import numpy as np
+import pytest
+
+import oracle
+from cases import (AGG_GROUPS, CASES, OR_SETS, PAIRS, SEED, make_inputs, rank_queries, select_queries, sha)
+
+pytestmark = pytest.mark.gpu
+
+import bitmagic_amd as bm  # noqa: E402
+
+
+def _gap_masked(kinds, offs, gaps):
+    g = gaps.copy()
+    for k, o in zip(kinds, offs):
+        if k == bm.GAP:
+            g[o] &= 0xFFF9
+    return g
+
+
+def _compact_gaps(kinds, offs, gaps):
+    """GAP blocks concatenated in block order (layout-independent view of the slab)"""
+    out = []
+    for k, o in zip(kinds, offs):
+        if k == bm.GAP:
+            n = (int(gaps[o]) >> 3) + 1
+            blk = gaps[o:o + n].copy(); blk[0] &= 0xFFF9
+            out.append(blk)
+    return np.concatenate(out) if out else np.zeros(0, np.uint16)
+
+
+def test_library_is_the_hip_one(ctx):
+    assert bm.simd_version() == 950 and bm.device_count() >= 1
+
+
+def test_generator_matches_oracle(ctx, port, golden):
+    for dq, common, nbits in [(6554, False, 3 * 65536 + 17), (655, True, 2 * 65536), (66, False, 65536 + 5),
+                              (32768, True, 70000), (65536, False, 1000), (0, False, 65536)]:
+        v = bm.bvector.generate(ctx, SEED, 5, dq, nbits, with_common=common, optimize=False)
+        exp = port.gen_words(SEED, 5, dq, nbits, with_common=common)
+        got = v.to_words(exp.size)
+        assert (got == exp).all(), (dq, common)
+    # the normative known answers the reference-side fixture pins
+    for k in golden["generator_kat"]:
+        if k["w64"] < (1 << 20):
+            nbits = (k["w64"] + 1) * 64
+            v = bm.bvector.generate(ctx, SEED, k["vec"], k["dq"], nbits, optimize=False)
+            w = v.to_words(nbits // 32)
+            assert (int(w[-1]) << 32 | int(w[-2])) == k["word"]
+
+
+@pytest.mark.parametrize("case", list(CASES))
+def test_golden_case(ctx, port, golden, case):
+    g = golden["cases"][case]
+    words, nbits = make_inputs(port, case)
+    assert [sha(w) for w in words] == g["input_sha"]
+    # (a) bit_import_u32 twin: classification + GAP conversion on the device
+    vecs = [bm.bit_import_u32(ctx, w, True) for w in words]
+    for v, w, kinds, gsha, cnt in zip(vecs, words, g["kinds"], g["gap_sha"], g["count"]):
+        k, o, bits, gaps = v.block_table()
+        assert k.tolist() == kinds
+        assert sha(_compact_gaps(k, o, gaps)) == gsha or not gaps.size and gsha == sha(np.zeros(0, np.uint16))
+        assert v.count() == cnt
+        assert (v.to_words(w.size) == w).all()
+    # (b) upload of a host block table (the oracle's flatten == walk of top_blocks_root())
+    up = []
+    for w in words:
+        pv = port.import_words(w, True, nbits)
+        k, o, bits, gaps = pv.flatten()
+        u = bm.bvector.from_block_table(ctx, nbits, k, o, bits, gaps)
+        assert (u.to_words(w.size) == w).all()
+        up.append(u)
+    nw = words[0].size
+    nwb = ((nbits + 65535) // 65536) * 2048
+    for (i, j) in PAIRS:
+        for op, f, cf in [(0, bm.bvector.bit_and, bm.count_and), (1, bm.bvector.bit_or, bm.count_or),
+                          (2, bm.bvector.bit_xor, bm.count_xor), (3, bm.bvector.bit_sub, bm.count_sub)]:
+            e = g["op2"][f"{op}:{i}:{j}"]
+            t = f(vecs[i], vecs[j])
+            assert sha(t.to_words(nwb)) == e["sha"], (op, i, j)
+            assert t.count() == e["count"]
+            assert cf(vecs[i], up[j]) == e["count_op"]
+            tc = f(up[i], vecs[j], bm.opt_compress)
+            assert sha(tc.to_words(nwb)) == e["sha"]
+            kk = tc.block_table()[0].tolist()
+            # representation: identical to the reference except that a GAP x GAP result that is
+            # all-ones stays a 1-run GAP block there (clone_gap_block) and is FULL here
+            assert all(a == b or (a == bm.FULL and b == bm.GAP) for a, b in zip(kk, e["kinds_opt"])), (kk, e["kinds_opt"])
+    agg = bm.aggregator(ctx)
+    for e in g["agg_and_sub"]:
+        t, any_ = agg.combine_and_sub([vecs[i] for i in e["and"]], [up[i] for i in e["sub"]])
+        assert sha(t.to_words(nwb)) == e["sha"] and t.count() == e["count"]
+        assert any_ == (e["count"] > 0)
+        assert t.block_table()[0].tolist() == e["kinds"]
+    for e in g["agg_or"]:
+        t = agg.combine_or([vecs[i] for i in e["src"]])
+        assert sha(t.to_words(nwb)) == e["sha"] and t.count() == e["count"]
+    pipe = bm.aggregator.pipeline(ctx)
+    for (a, s) in AGG_GROUPS:
+        ag = pipe.add()
+        for i in a: ag.add(vecs[i], 0)
+        for i in s: ag.add(vecs[i], 1)
+    pipe.complete()
+    cnt = agg.combine_and_sub(pipe)
+    assert [int(x) for x in cnt] == g["pipeline_counts"]
+    assert [int(x) for x in pipe.get_bv_count_vector()] == g["pipeline_counts"]
+    # block-range shards add up (multi-GPU premise)
+    nb = vecs[0].info()["nblocks"]
+    parts = sum(agg._run_pipeline(pipe, a, b).astype(np.int64) for a, b in [(0, 1), (1, nb)])
+    assert parts.tolist() == g["pipeline_counts"]
+    for e in g["rs"]:
+        v = vecs[e["vec"]]
+        rs = v.build_rs_index()
+        assert rs.count() == e["count"]
+        bc, sub = rs.export()
+        assert bc.tolist() == e["bcount"][:len(bc)]
+        assert [int(x) for x in sub] == e["sub_count"][:len(sub)]
+        assert [int(x) for x in v.count_to(rank_queries(nbits), rs)] == e["rank"]
+        found, pos = v.select(select_queries(e["count"]), rs)
+        assert found.astype(int).tolist() == e["select_found"]
+        assert [int(p) if f else 0 for p, f in zip(pos, found)] == e["select_pos"]
+
+
+@pytest.mark.parametrize("dq,cdq,nvec", [(40, None, 9), (655, 655, 12), (6554, 6554, 40), (6554, None, 17),
+                                         (32768, 20000, 33), (65500, None, 8)])
+def test_differential_vs_oracle(ctx, port, dq, cdq, nvec):
+    """seeded random vectors incl. NULL/FULL blocks and ragged lengths; aggregator ladders over operand
+    prefixes / suffixes as in StressTestAggregatorAND/OR (tests/stress/t.cpp:10811-11164)"""
+    rng = np.random.default_rng(dq * 131 + nvec)
+    nbits_max = 37 * 65536 + 1234
+    pv, gv = [], []
+    for v in range(nvec):
+        nbits = nbits_max if v % 5 else nbits_max - 7 * 65536 - 99       # ragged
+        w = port.gen_words(4242, v, dq, nbits)
+        if cdq:
+            w |= port.gen_words(4242, 0xFFFFFFFF, cdq, nbits)
+            nw = (nbits + 31) // 32
+            if nbits % 32: w[nw - 1] &= (1 << (nbits % 32)) - 1
+            w[nw:] = 0
+        for nb in range((w.size + 2047) // 2048):
+            r = rng.integers(0, 24)
+            if r == 0: w[nb * 2048:(nb + 1) * 2048] = 0
+            elif r == 1 and (nb + 1) * 2048 <= (nbits // 32): w[nb * 2048:(nb + 1) * 2048] = 0xFFFFFFFF
+        pv.append(port.import_words(w, True, w.size * 32))
+        gv.append(bm.bit_import_u32(ctx, w, True))
+        assert gv[-1].block_table()[0].tolist() == pv[-1].flatten()[0].tolist()
+        assert gv[-1].count() == pv[-1].count()
+    nwb = ((nbits_max + 65535) // 65536) * 2048
+    agg = bm.aggregator(ctx)
+    ladders = sorted(set([1, 2, 3, 5, 6, 7, 8, 9, nvec - 1, nvec]))
+    groups = []
+    for n in ladders:
+        if n < 1 or n > nvec: continue
+        groups.append((list(range(n)), []))
+        groups.append((list(range(nvec - n, nvec)), list(range(0, max(0, nvec - n - 2), 3))))
+    pipe = bm.aggregator.pipeline(ctx)
+    for a, s in groups:
+        ag = pipe.add()
+        for i in a: ag.add(gv[i], 0)
+        for i in s: ag.add(gv[i], 1)
+    pipe.complete()
+    got = agg.combine_and_sub(pipe)
+    exp = port.pipeline_counts([([pv[i] for i in a], [pv[i] for i in s]) for a, s in groups])
+    assert (got == exp).all(), (got, exp)
+    for a, s in groups[::3]:
+        t, _ = agg.combine_and_sub([gv[i] for i in a], [gv[i] for i in s])
+        e = port.agg_and_sub([pv[i] for i in a], [pv[i] for i in s])
+        assert (t.to_words(nwb) == e.to_words(nwb)).all()
+        assert t.block_table()[0].tolist() == (e.flatten()[0].tolist() + [0] * 64)[:t.info()["nblocks"]]
+        o = agg.combine_or([gv[i] for i in a + s])
+        eo = port.agg_or([pv[i] for i in a + s])
+        assert (o.to_words(nwb) == eo.to_words(nwb)).all()
+    for i, j in [(0, 1), (1, 5), (2, nvec - 1)]:
+        for op in range(4):
+            t = bm.bvector._op2(op, gv[i], gv[j], bm.opt_none)
+            assert (t.to_words(nwb) == port.op2(op, pv[i], pv[j]).to_words(nwb)).all()
+            assert bm._count_op2(op, gv[i], gv[j]) == port.count_op2(op, pv[i], pv[j])
+    # rank / select against the oracle on a mixed vector
+    v, p = gv[1], pv[1]
+    rs, prs = v.build_rs_index(), port.rs_build(p)
+    q = rng.integers(0, nbits_max, size=5000).astype(np.uint64)
+    assert (v.rank(q, rs) == prs.rank(q)).all()
+    c = p.count()
+    if c:
+        r = np.concatenate([rng.integers(1, c + 1, size=5000).astype(np.uint64), np.array([1, c, 0, c + 1], np.uint64)])
+        found, pos = v.select(r, rs)
+        ppos, pfound = prs.select(r)
+        assert (found == pfound).all() and (pos[found] == ppos[pfound]).all()
+
+
+def test_kats_from_reference_tests(ctx, port):
+    """AggregatorTest known answers (tests/stress/t.cpp:10100-10152, 10318-10373) through the HIP path"""
+    def mk(bits, n=3 * 65536, ranges=()):
+        p = port.new(n)
+        for b in bits: p.set_bit(b)
+        for l, r in ranges: p.set_range(l, r)
+        k, o, bs, gs = p.flatten()
+        return bm.bvector.from_block_table(ctx, n, k, o, bs, gs)
+    agg = bm.aggregator(ctx)
+    a, b = mk([1, 2, 3]), mk([0, 4, 5])
+    agg.add(a); agg.add(b)
+    t = agg.combine_or()
+    assert t.count() == 6 and (t.to_words(1)[0] == 0b111111)
+    assert agg.combine_and().count() == 0
+    agg.reset()
+    c = mk([1, 2, 3, 4, 5, 70000])
+    t, any_ = agg.combine_and_sub([c], [a])
+    assert any_ and t.count() == 3
+    f1, f2 = mk([], ranges=[(0, 65535)]), mk([], ranges=[(0, 2 * 65536 - 1)])
+    assert agg.combine_or([f1, f2]).block_table()[0].tolist() == [bm.FULL, bm.FULL, bm.NULL]
+    t, _ = agg.combine_and_sub([f1, f2], [])
+    assert t.block_table()[0].tolist() == [bm.FULL, bm.NULL, bm.NULL] and t.count() == 65536
+    # empty AND group => cleared target, any == false (src/bmaggregator.h:1170-1174)
+    t, any_ = agg.combine_and_sub([], [a])
+    assert not any_ and t.count() == 0
+    # rank/select round trip on an all-ones vector (t.cpp:5005-5032)
+    n = 4 * 65536
+    ones = mk([], n=n, ranges=[(0, n - 1)])
+    rs = ones.build_rs_index()
+    q = np.arange(0, n, 997, dtype=np.uint64)
+    assert (ones.rank(q, rs) == q + 1).all()
+    found, pos = ones.select(q + 1, rs)
+    assert found.all() and (pos == q).all()
+
+
+def test_edge_cases(ctx):
+    e = bm.bit_import_u32(ctx, np.zeros(0, np.uint32))
+    assert e.count() == 0 and e.info()["nblocks"] == 0
+    one = bm.bit_import_u32(ctx, np.array([1], np.uint32))
+    assert one.count() == 1 and bm.count_and(one, e) == 0 and bm.count_or(one, e) == 1
+    assert bm.bvector.bit_or(e, one).count() == 1 and bm.bvector.bit_sub(one, one).count() == 0
+    agg = bm.aggregator(ctx)
+    assert agg.combine_or([]).count() == 0
+    other = bm.context(0)
+    foreign = bm.bit_import_u32(other, np.array([1], np.uint32))
+    with pytest.raises(bm.BmxError) as ei:
+        bm.count_and(one, foreign)
+    assert ei.value.status == 2
+    del foreign
+    other.close()
+
+
+def test_full_size_pairwise_properties(ctx, port):
+    """BASELINE config 2 size: two 1e9-bit vectors.  Size-independent identities + sampled blocks vs oracle."""
+    nbits = 1_000_000_000
+    for dq in (655, 6554, 32768):
+        a = bm.bvector.generate(ctx, SEED, 1, dq, nbits)
+        b = bm.bvector.generate(ctx, SEED, 2, dq, nbits)
+        ca, cb = a.count(), b.count()
+        c_and, c_or, c_xor, c_sub = bm.count_and(a, b), bm.count_or(a, b), bm.count_xor(a, b), bm.count_sub(a, b)
+        assert c_and + c_sub == ca and c_or == ca + cb - c_and and c_xor == c_or - c_and
+        p = dq / 65536
+        assert abs(ca - p * nbits) < 8 * np.sqrt(nbits * p * (1 - p))
+        t = bm.bvector.bit_and(a, b)
+        assert t.count() == c_and
+        x = bm.bvector.bit_xor(a, b, bm.opt_compress)
+        assert x.count() == c_xor
+        # idempotence / complement round trip:  (a XOR b) XOR b == a
+        back = bm.bvector.bit_xor(x, b)
+        assert bm.count_xor(back, a) == 0
+        # sampled blocks against the oracle's generator + import
+        for nb0 in (0, 7777, 15258):
+            nw = min(2048, (nbits + 31) // 32 - nb0 * 2048)
+            wa = port.gen_words(SEED, 1, dq, nbits, word_off=nb0 * 2048, nwords=nw)
+            got = a.to_words((nb0 + 1) * 2048)[nb0 * 2048: nb0 * 2048 + nw]
+            assert (got == wa).all()
+        del t, x, back
+
+
+def test_full_size_256way_and_count(ctx, port):
+    """BASELINE config 3: aggregator AND + COUNT over 256 x 1e9-bit vectors (correlated data set A).
+    Checks: shard sums == total; sampled block columns equal the oracle run on the same
+    generated inputs; monotonicity over operand prefixes."""
+    nbits, nvec, dq = 1_000_000_000, 256, 6554
+    vecs = [bm.bvector.generate(ctx, SEED, v, dq, nbits, with_common=True) for v in range(nvec)]
+    agg = bm.aggregator(ctx)
+    pipe = bm.aggregator.pipeline(ctx)
+    for n in (256, 128, 2):
+        ag = pipe.add()
+        for v in vecs[:n]: ag.add(v, 0)
+    pipe.complete()
+    total = agg.combine_and_sub(pipe).astype(np.int64)
+    assert total[0] <= total[1] <= total[2] and total[0] > 0
+    nb = vecs[0].info()["nblocks"]
+    assert nb == 15259
+    cuts = [0, 1, 4000, 9999, nb]
+    parts = sum(agg._run_pipeline(pipe, a, b).astype(np.int64) for a, b in zip(cuts[:-1], cuts[1:]))
+    assert (parts == total).all()
+    assert pipe.operand_bytes() == (256 + 128 + 2) * nb * 8192
+    # sampled columns vs oracle
+    for nb0 in (3, 15258):
+        nw = min(2048, (nbits + 31) // 32 - nb0 * 2048)
+        pvs = []
+        for v in range(nvec):
+            w = np.zeros((nb0 + 1) * 2048, np.uint32)
+            w[nb0 * 2048: nb0 * 2048 + nw] = port.gen_words(SEED, v, dq, nbits, with_common=True, word_off=nb0 * 2048, nwords=nw)
+            pvs.append(port.import_words(w, True))
+        exp = port.pipeline_counts([(pvs[:256], []), (pvs[:128], []), (pvs[:2], [])], nb0, nb0 + 1)
+        got = agg._run_pipeline(pipe, nb0, nb0 + 1)
+        assert (got == exp).all(), (nb0, got, exp)
