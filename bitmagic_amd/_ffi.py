@@ -49,6 +49,7 @@ def lib() -> C.CDLL:
         "bmx_ctx_create": (i32, [i32, vp, P(vp)]),
         "bmx_ctx_destroy": (i32, [vp]),
         "bmx_ctx_synchronize": (i32, [vp]),
+        "bmx_ctx_set_tuning": (i32, [vp, C.c_char_p, i32]),
         "bmx_ctx_mem_used": (i32, [vp, P(u64)]),
         "bmx_vec_upload": (i32, [vp, u64, u32, vp, vp, vp, u32, vp, u64, P(vp)]),
         "bmx_vec_import_bits": (i32, [vp, vp, u64, i32, P(vp)]),

@@ -38,7 +38,10 @@ struct bmx_ctx {
     void* aux = nullptr; size_t aux_bytes = 0;              // stats / offsets / totals
     u64* d_small = nullptr;                                 // 64 x u64 result words
     u64* h_small = nullptr;                                 // pinned mirror
-    int pipe_unroll = 2;
+    int pipe_unroll = 2;       // operand blocks in flight per wave
+    int pipe_rows = 8;         // register rows per work item (8 = whole block, 4/2/1 = slices)
+    int pipe_nt = 1;           // non-temporal operand loads (+4.5 % on the streamed-once headline case)
+    int pipe_wg = 256;         // workgroup size of the counts kernel
     int xcd_swz = 1;
 };
 
@@ -130,6 +133,9 @@ int bmx_ctx_create(int device, void* stream, bmx_ctx** out)
     HIPCHK(hipMalloc((void**)&ctx->d_small, 64 * sizeof(u64)));
     HIPCHK(hipHostMalloc((void**)&ctx->h_small, 64 * sizeof(u64)));
     if (const char* e = getenv("BMX_PIPE_UNROLL")) ctx->pipe_unroll = atoi(e);
+    if (const char* e = getenv("BMX_PIPE_ROWS")) ctx->pipe_rows = atoi(e);
+    if (const char* e = getenv("BMX_PIPE_NT")) ctx->pipe_nt = atoi(e);
+    if (const char* e = getenv("BMX_PIPE_WG")) ctx->pipe_wg = atoi(e);
     if (const char* e = getenv("BMX_XCD_SWIZZLE")) ctx->xcd_swz = atoi(e);
     *out = ctx;
     return BMX_OK;
@@ -148,6 +154,19 @@ int bmx_ctx_destroy(bmx_ctx* ctx)
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
+    return BMX_OK;
+}
+
+int bmx_ctx_set_tuning(bmx_ctx* ctx, const char* key, int value)
+{
+    ARGCHK(ctx && key);
+    std::string k(key);
+    if (k == "pipe_unroll") { ARGCHK(value == 1 || value == 2 || value == 4); ctx->pipe_unroll = value; }
+    else if (k == "pipe_rows") { ARGCHK(value == 8 || value == 4 || value == 2 || value == 1); ctx->pipe_rows = value; }
+    else if (k == "pipe_nt") ctx->pipe_nt = value != 0;
+    else if (k == "pipe_wg") { ARGCHK(value == 64 || value == 128 || value == 256); ctx->pipe_wg = value; }
+    else if (k == "xcd_swizzle") ctx->xcd_swz = value != 0;
+    else { g_last_error = "unknown tuning key"; return BMX_ERR_BADARG; }
     return BMX_OK;
 }
 
@@ -479,17 +498,35 @@ int bmx_pipeline_run_counts_dev(bmx_ctx* ctx, bmx_pipeline* p, uint32_t nb_from,
     HIPCHK(hipMemsetAsync(d_counts, 0, (size_t)p->ngroups * 8, ctx->stream));
     u64 nitems64 = (u64)(nb_to - nb_from) * p->ngroups;
     if (!nitems64) return BMX_OK;
+    const u32* row_off = p->d_meta; const u32* and_n = p->d_meta + p->ngroups; const u32* sub_n = p->d_meta + 2 * p->ngroups;
+    if (!p->has_gap) {
+        // bit-block-only fast path: (column, group, slice) items
+        u32 rows = (u32)ctx->pipe_rows, parts = 8u / rows;
+        u64 n64 = nitems64 * parts;
+        if (n64 > 0xFFFFFFF0ull) { g_last_error = "too many work items in one run"; return BMX_ERR_RANGE; }
+        u32 nitems = (u32)n64, wpb = (u32)ctx->pipe_wg / 64u, grid = (nitems + wpb - 1) / wpb;
+#define LAUNCH_BITS(U, R, NT) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pipe_counts_bits<U, R, NT>), dim3(grid), dim3(ctx->pipe_wg), 0, ctx->stream, \
+        p->d_dmat, row_off, and_n, p->col_stride, p->ngroups, nb_from, nitems, ctx->xcd_swz, (u64*)d_counts)
+#define LAUNCH_BITS_R(U, NT) switch (rows) { case 1: LAUNCH_BITS(U, 1, NT); break; case 2: LAUNCH_BITS(U, 2, NT); break; \
+        case 4: LAUNCH_BITS(U, 4, NT); break; default: LAUNCH_BITS(U, 8, NT); break; }
+#define LAUNCH_BITS_U(NT) switch (ctx->pipe_unroll) { case 1: LAUNCH_BITS_R(1, NT); break; case 4: LAUNCH_BITS_R(4, NT); break; \
+        default: LAUNCH_BITS_R(2, NT); break; }
+        if (ctx->pipe_nt) { LAUNCH_BITS_U(true); } else { LAUNCH_BITS_U(false); }
+#undef LAUNCH_BITS_U
+#undef LAUNCH_BITS_R
+#undef LAUNCH_BITS
+        KCHK();
+        return BMX_OK;
+    }
     if (nitems64 > 0xFFFFFFF0ull) { g_last_error = "too many (column, group) items in one run"; return BMX_ERR_RANGE; }
     u32 nitems = (u32)nitems64;
     u32 grid = (nitems + 3) / 4;
-    size_t lds = p->has_gap ? 4 * 2048 * 4 : 0;
-    const u32* row_off = p->d_meta; const u32* and_n = p->d_meta + p->ngroups; const u32* sub_n = p->d_meta + 2 * p->ngroups;
+    size_t lds = 4 * 2048 * 4;
 #define LAUNCH_PIPE(U) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pipe_counts<U>), dim3(grid), dim3(256), lds, ctx->stream, \
         p->d_dmat, row_off, and_n, sub_n, p->col_stride, p->ngroups, nb_from, nitems, ctx->xcd_swz, (u64*)d_counts)
     switch (ctx->pipe_unroll) {
     case 1: LAUNCH_PIPE(1); break;
     case 4: LAUNCH_PIPE(4); break;
-    case 3: LAUNCH_PIPE(3); break;
     default: LAUNCH_PIPE(2); break;
     }
 #undef LAUNCH_PIPE

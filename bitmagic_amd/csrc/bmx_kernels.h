@@ -343,6 +343,105 @@ void k_pipe_counts(const u64* __restrict__ dmat, const u32* __restrict__ row_off
     if (lane == 0 && cnt) atomicAdd(reinterpret_cast<unsigned long long*>(&counts[g]), (unsigned long long)cnt);
 }
 
+// ---------------------------------------------------------------------------
+// Bit-block-only fast path of the same computation (pipelines whose operands
+// contain no GAP block: the headline case).  A work item is one ROWS/8 slice
+// of a (column, group): ROWS register rows = ROWS KiB of every operand block.
+// Smaller items = more independent waves, shorter ramp-up and drain tail;
+// the early-exit test becomes per slice (finer than the reference's digest).
+// NT selects non-temporal loads (streamed-once data).
+// ---------------------------------------------------------------------------
+template <int ROWS> struct Part { u32x4 r[ROWS]; };
+
+template <int ROWS, bool NT>
+__device__ __forceinline__ void part_load(Part<ROWS>& b, gcptr4 p, u32 lane)
+{
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) {
+        if constexpr (NT) b.r[i] = __builtin_nontemporal_load(p + i * 64 + lane);
+        else b.r[i] = p[i * 64 + lane];
+    }
+}
+template <int ROWS>
+__device__ __forceinline__ bool part_is_zero(const Part<ROWS>& b)
+{
+    u32 v = 0;
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) v |= b.r[i].x | b.r[i].y | b.r[i].z | b.r[i].w;
+    return __ballot(v != 0u) == 0ull;
+}
+
+template <int U, int ROWS, bool NT>
+__global__ __launch_bounds__(256)
+void k_pipe_counts_bits(const u64* __restrict__ dmat, const u32* __restrict__ row_off,
+                        const u32* __restrict__ and_n, u32 col_stride,
+                        u32 ngroups, u32 col_from, u32 nitems, int xcd_swz, u64* __restrict__ counts)
+{
+    constexpr u32 PARTS = 8 / ROWS;
+    u32 lane = lane_id(), wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+    u32 bid = xcd_swz ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
+    u32 item = uniform32(bid * wpb + wave);
+    if (item >= nitems) return;
+    u32 part = item % PARTS, cg = item / PARTS;
+    u32 c = cg / ngroups, g = cg - c * ngroups;
+    const u64* row = dmat + (size_t)(col_from + c) * col_stride + row_off[g];
+    u64 hdr = uniform64(row[0]), flags = uniform64(row[1]);
+    if (flags & ROW_EMPTY) return;
+    if (flags & ROW_FULL) { if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(&counts[g]), (unsigned long long)(65536u / PARTS)); return; }
+    u32 nba = (u32)(hdr & 0xFFFFu), nbs = (u32)((hdr >> 32) & 0xFFFFu);
+    u32 na = uniform32(and_n[g]);
+    const u64* pa = row + 2;
+    const u64* ps = pa + na;
+    const u32 poff = part * ROWS * 64u;          // in 16-byte units
+
+    Part<ROWS> acc;
+    u32 k = 0;
+    if (flags & ROW_ONES) {
+#pragma unroll
+        for (int i = 0; i < ROWS; ++i) acc.r[i] = (u32x4)(~0u);
+    } else { part_load<ROWS, NT>(acc, as_gc4(uniform64(pa[0])) + poff, lane); k = 1; }
+    for (; k + U <= nba; k += U) {
+        Part<ROWS> t[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) part_load<ROWS, NT>(t[u], as_gc4(uniform64(pa[k + u])) + poff, lane);
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int i = 0; i < ROWS; ++i) acc.r[i] &= t[u].r[i];
+        if (part_is_zero<ROWS>(acc)) return;
+    }
+    for (; k < nba; ++k) {
+        Part<ROWS> t; part_load<ROWS, NT>(t, as_gc4(uniform64(pa[k])) + poff, lane);
+#pragma unroll
+        for (int i = 0; i < ROWS; ++i) acc.r[i] &= t.r[i];
+    }
+    if (part_is_zero<ROWS>(acc)) return;
+    k = 0;
+    for (; k + U <= nbs; k += U) {
+        Part<ROWS> t[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) part_load<ROWS, NT>(t[u], as_gc4(uniform64(ps[k + u])) + poff, lane);
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int i = 0; i < ROWS; ++i) acc.r[i] &= ~t[u].r[i];
+        if (part_is_zero<ROWS>(acc)) return;
+    }
+    for (; k < nbs; ++k) {
+        Part<ROWS> t; part_load<ROWS, NT>(t, as_gc4(uniform64(ps[k])) + poff, lane);
+#pragma unroll
+        for (int i = 0; i < ROWS; ++i) acc.r[i] &= ~t.r[i];
+    }
+    u32 cnt = 0;
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) {
+        cnt += __popcll(((u64)acc.r[i].y << 32) | acc.r[i].x);
+        cnt += __popcll(((u64)acc.r[i].w << 32) | acc.r[i].z);
+    }
+    cnt = wave_sum(cnt);
+    if (lane == 0 && cnt) atomicAdd(reinterpret_cast<unsigned long long*>(&counts[g]), (unsigned long long)cnt);
+}
+
 // algorithmic operand bytes of the rows in [col_from, col_from+ncols)
 __global__ __launch_bounds__(256)
 void k_pipe_bytes(const u64* __restrict__ dmat, const u32* __restrict__ row_off, const u32* __restrict__ and_n,

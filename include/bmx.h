@@ -74,6 +74,9 @@ int bmx_device_count(int* n);
 int bmx_ctx_create(int device, void* stream, bmx_ctx** out);
 int bmx_ctx_destroy(bmx_ctx* ctx);
 int bmx_ctx_synchronize(bmx_ctx* ctx);
+/* launch-shape knobs of the counts pipeline (results never depend on them):
+ * "pipe_unroll" 1|2|4, "pipe_rows" 8|4|2|1, "pipe_nt" 0|1, "pipe_wg" 64|128|256, "xcd_swizzle" 0|1 */
+int bmx_ctx_set_tuning(bmx_ctx* ctx, const char* key, int value);
 /* bytes of HBM currently held by vectors/pipelines of this context */
 int bmx_ctx_mem_used(const bmx_ctx* ctx, uint64_t* bytes);
 

@@ -1,0 +1,121 @@
+// bmx/bm_adapter.hpp -- bridge between a host bm::bvector<> (the real BitMagic
+// container) and a device-resident bmx::bvector.  Include AFTER "bm.h".
+//
+// This is the code a BitMagic maintainer adds to route the vector-level loops of
+// the hot path to the GPU: it walks blocks_manager exactly like
+// bvector<>::count() does (src/bm.h:2436-2474), hands the
+// flattened block table to bmx_vec_upload, and turns a downloaded result back
+// into host blocks through the reference's own blocks_manager, so ownership and
+// allocator rules of bm::bvector<> are untouched.
+#pragma once
+
+#include <cstring>
+#include <vector>
+
+#include "bvector.hpp"
+
+namespace bmx {
+
+struct block_table {
+    uint64_t nbits = 0;
+    std::vector<uint8_t> kinds;
+    std::vector<uint32_t> offs;
+    std::vector<uint32_t> bit_slab;     // n_bit * 2048 words
+    std::vector<uint16_t> gap_slab;
+};
+
+/// flatten a bm::bvector<> (any allocator) into a block table of `nblocks` blocks
+template <class BMBV>
+void flatten(const BMBV& bv, uint32_t nblocks, block_table& t)
+{
+    const typename BMBV::blocks_manager_type& bman = bv.get_blocks_manager();
+    t.nbits = bv.size();
+    t.kinds.assign(nblocks, BMX_NULL); t.offs.assign(nblocks, 0);
+    t.bit_slab.clear(); t.gap_slab.clear();
+    if (!bman.is_init()) return;
+    uint32_t n_bit = 0;
+    for (uint32_t nb = 0; nb < nblocks; ++nb) {
+        unsigned i = nb >> bm::set_array_shift, j = nb & bm::set_array_mask;
+        if (i >= bman.top_block_size()) break;
+        const bm::word_t* p = bman.get_block_ptr(i, j);
+        if (!p) continue;
+        if (p == FULL_BLOCK_FAKE_ADDR || p == FULL_BLOCK_REAL_ADDR) { t.kinds[nb] = BMX_FULL; continue; }
+        if (BM_IS_GAP(p)) {
+            const bm::gap_word_t* g = BMGAP_PTR(p);
+            unsigned n = (unsigned)(g[0] >> 3) + 1u;
+            t.kinds[nb] = BMX_GAP; t.offs[nb] = (uint32_t)t.gap_slab.size();
+            t.gap_slab.insert(t.gap_slab.end(), g, g + n);
+        } else {
+            t.kinds[nb] = BMX_BIT; t.offs[nb] = n_bit++;
+            t.bit_slab.insert(t.bit_slab.end(), p, p + bm::set_block_size);
+        }
+    }
+}
+
+/// number of blocks needed to cover every stored block of bv
+template <class BMBV>
+uint32_t effective_blocks(const BMBV& bv)
+{
+    typename BMBV::size_type last = 0;
+    if (!bv.find_reverse(last)) return 0;
+    return (uint32_t)(last >> bm::set_block_shift) + 1u;
+}
+
+/// host bm::bvector<>  ->  device bmx::bvector
+template <class BMBV>
+void upload(const BMBV& src, bvector& dst, uint32_t nblocks = 0)
+{
+    if (!nblocks) nblocks = effective_blocks(src);
+    block_table t;
+    flatten(src, nblocks, t);
+    uint64_t nbits = (uint64_t)nblocks * BMX_BLOCK_BITS;
+    dst.assign_block_table(nbits, nblocks, t.kinds.data(), t.offs.data(), t.bit_slab.data(),
+                           (uint32_t)(t.bit_slab.size() / BMX_BLOCK_WORDS), t.gap_slab.data(), t.gap_slab.size());
+}
+
+/// install a block table into a host bm::bvector<> through the reference's own
+/// blocks_manager (FULL sentinel / clone_gap_block src/bmblocks.h:865 / copy_bit_block :1340)
+template <class BMBV>
+void install(BMBV& dst, uint32_t nblocks, const uint8_t* kinds, const uint32_t* offs,
+             const uint32_t* bit_slab, const uint16_t* gap_slab)
+{
+    dst.clear(true);
+    dst.init();
+    typename BMBV::blocks_manager_type& bman = dst.get_blocks_manager();
+    BM_DECLARE_TEMP_BLOCK(tb)          // SIMD builds stream-copy from an aligned source (src/bmfunc.h:7573)
+    for (uint32_t nb = 0; nb < nblocks; ++nb) {
+        unsigned i = nb >> bm::set_array_shift, j = nb & bm::set_array_mask;
+        if (kinds[nb] == BMX_NULL) continue;
+        bman.reserve_top_blocks(i + 1);
+        bman.check_alloc_top_subblock(i);
+        switch (kinds[nb]) {
+        case BMX_FULL:
+            bman.set_block_ptr(i, j, FULL_BLOCK_FAKE_ADDR);
+            break;
+        case BMX_BIT:
+            std::memcpy(tb.begin(), bit_slab + (size_t)offs[nb] * BMX_BLOCK_WORDS, BMX_BLOCK_WORDS * 4);
+            bman.copy_bit_block(i, j, tb.begin());
+            break;
+        default: {
+            const bm::gap_word_t* g = gap_slab + offs[nb];
+            bman.clone_gap_block(i, j, g, (unsigned)(g[0] >> 3));
+            break; }
+        }
+    }
+}
+
+/// device bmx::bvector  ->  host bm::bvector<>
+template <class BMBV>
+void download(const bvector& src, BMBV& dst)
+{
+    if (src.empty_handle()) { dst.clear(true); return; }
+    uint64_t nbits = 0, gap_words = 0; uint32_t nblocks = 0, slab_blocks = 0; uint32_t counts[4];
+    check(bmx_vec_info(src.handle(), &nbits, &nblocks, counts, &slab_blocks, &gap_words));
+    std::vector<uint8_t> kinds(nblocks ? nblocks : 1); std::vector<uint32_t> offs(nblocks ? nblocks : 1);
+    std::vector<uint32_t> bits((size_t)slab_blocks * BMX_BLOCK_WORDS); std::vector<uint16_t> gaps(gap_words);
+    check(bmx_vec_download(src.get_context().handle(), src.handle(), kinds.data(), offs.data(),
+                           bits.empty() ? nullptr : bits.data(), gaps.empty() ? nullptr : gaps.data()));
+    install(dst, nblocks, kinds.data(), offs.data(), bits.data(), gaps.data());
+}
+
+} // namespace bmx

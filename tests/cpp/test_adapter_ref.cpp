@@ -1,0 +1,98 @@
+// End-to-end drop-in check with the REAL reference container: build bm::bvector<>s with
+// BitMagic, upload through bmx/bm_adapter.hpp, run the path on the GPU, download into
+// bm::bvector<> and compare with BitMagic's own result (compare() == 0).
+// Compiled ONLY where /root/reference exists (tests/cpp/Makefile -> oracle/_ref/, git-ignored);
+// the binary travels to the GPU box and is run by tests/test_cpp_facade.py (-m gpu).
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "bm.h"
+#include "bmaggregator.h"
+#include "bmalgo.h"
+#include "bmbvimport.h"
+
+#include "bmx/bm_adapter.hpp"
+extern "C" {
+#include "../../oracle/bmx_oracle.h"     // only for the deterministic input generator
+}
+
+#define REQUIRE(c) do { if (!(c)) { std::fprintf(stderr, "FAILED %s:%d: %s\n", __FILE__, __LINE__, #c); std::exit(1); } } while (0)
+
+typedef bm::bvector<> bvect;
+
+int main()
+{
+    bmx::context ctx(0);
+    const uint64_t nbits = 9 * 65536 + 123;
+    const unsigned NV = 8;
+    const uint32_t NB = 10;
+    std::vector<bvect> hv(NV);
+    std::vector<bmx::bvector> gv;
+    for (unsigned v = 0; v < NV; ++v) {
+        uint32_t dq = v < 3 ? 6554u : (v < 6 ? 655u : 100u);
+        uint64_t nw = ((nbits + 63) / 64) * 2;
+        std::vector<uint32_t> w(nw);
+        bmo_gen_words(0xB17A61C, v, v < 3, dq, nbits, 0, nw, w.data());
+        bm::bit_import_u32(hv[v], w.data(), bvect::size_type(nw), true);
+        if (v == 2) hv[v].set_range(65536 * 3, 65536 * 5 - 1);          // FULL blocks
+        if (v == 4) hv[v].set_range(65536 * 6, 65536 * 7 - 1, false);   // a NULL block
+        gv.emplace_back(ctx);
+        bmx::upload(hv[v], gv[v], NB);
+        REQUIRE(gv[v].count() == hv[v].count());
+        bvect back; bmx::download(gv[v], back);
+        REQUIRE(back.compare(hv[v]) == 0);
+    }
+    // pairwise ops vs the reference's own results
+    for (int op = 0; op < 4; ++op) {
+        for (unsigned i = 0; i + 1 < NV; i += 2) {
+            bvect ref; bmx::bvector t(ctx);
+            switch (op) {
+            case 0: ref.bit_and(hv[i], hv[i + 1]); t.bit_and(gv[i], gv[i + 1], bmx::bvector::opt_compress); REQUIRE(bmx::count_and(gv[i], gv[i + 1]) == bm::count_and(hv[i], hv[i + 1])); break;
+            case 1: ref.bit_or(hv[i], hv[i + 1]); t.bit_or(gv[i], gv[i + 1]); REQUIRE(bmx::count_or(gv[i], gv[i + 1]) == bm::count_or(hv[i], hv[i + 1])); break;
+            case 2: ref.bit_xor(hv[i], hv[i + 1]); t.bit_xor(gv[i], gv[i + 1], bmx::bvector::opt_compress); REQUIRE(bmx::count_xor(gv[i], gv[i + 1]) == bm::count_xor(hv[i], hv[i + 1])); break;
+            default: ref.bit_sub(hv[i], hv[i + 1]); t.bit_sub(gv[i], gv[i + 1]); REQUIRE(bmx::count_sub(gv[i], gv[i + 1]) == bm::count_sub(hv[i], hv[i + 1])); break;
+            }
+            bvect got; bmx::download(t, got);
+            REQUIRE(got.compare(ref) == 0);
+        }
+    }
+    // aggregator vs bm::aggregator
+    {
+        bm::aggregator<bvect> ragg; bmx::aggregator<bmx::bvector> gagg(ctx);
+        for (unsigned v = 0; v < 5; ++v) { ragg.add(&hv[v]); gagg.add(&gv[v]); }
+        ragg.add(&hv[6], 1); gagg.add(&gv[6], 1);
+        bvect r1, r2, g1, g2; bmx::bvector t(ctx);
+        ragg.combine_and_sub(r1); bool any = gagg.combine_and_sub(t); bmx::download(t, g1);
+        REQUIRE(g1.compare(r1) == 0 && any == r1.any());
+        ragg.combine_or(r2); gagg.combine_or(t); bmx::download(t, g2);
+        REQUIRE(g2.compare(r2) == 0);
+        // counts-only pipeline vs the reference pipeline
+        bm::aggregator<bvect>::pipeline<bm::agg_opt_only_counts> rp;
+        bmx::aggregator<bmx::bvector>::pipeline<bmx::agg_opt_only_counts> gp(ctx);
+        for (unsigned g = 0; g < 3; ++g) {
+            auto* ra = rp.add(); auto* ga = gp.add();
+            for (unsigned v = g; v < NV; v += (g + 1)) { ra->add(&hv[v], 0); ga->add(&gv[v], 0); }
+            if (g) { ra->add(&hv[7], 1); ga->add(&gv[7], 1); }
+        }
+        rp.complete(); gp.complete();
+        ragg.combine_and_sub(rp); gagg.combine_and_sub(gp);
+        for (unsigned g = 0; g < 3; ++g) REQUIRE(gp.get_bv_count_vector()[g] == rp.get_bv_count_vector()[g]);
+    }
+    // rank / select vs bvector<>::count_to / select with the reference rs_index
+    {
+        bvect::rs_index_type rrs; hv[3].build_rs_index(&rrs);
+        bmx::rs_index grs; gv[3].build_rs_index(&grs);
+        REQUIRE(grs.count() == rrs.count());
+        for (uint64_t n = 0; n < nbits; n += 7919) REQUIRE(gv[3].count_to(n, grs) == hv[3].count_to(bvect::size_type(n), rrs));
+        for (uint64_t r = 1; r <= grs.count(); r += 1 + grs.count() / 131) {
+            uint64_t p = 0; bvect::size_type q = 0;
+            REQUIRE(gv[3].select(r, p, grs) && hv[3].select(bvect::size_type(r), q, rrs) && p == q);
+        }
+        std::vector<uint32_t> bc; std::vector<uint64_t> sub;
+        grs.export_blocks(bc, sub, NB);
+        for (uint32_t nb = 0; nb < NB; ++nb) REQUIRE(bc[nb] == rrs.count(nb) && sub[nb] == rrs.sub_count(nb));
+    }
+    std::printf("test_adapter_ref ok (simd_version %d)\n", bm::simd_version());
+    return 0;
+}

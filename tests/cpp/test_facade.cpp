@@ -1,0 +1,104 @@
+// GPU test of the header-only C++ facade (include/bmx/bvector.hpp) against the C oracle.
+// Built by tests/cpp/Makefile, run by tests/test_cpp_facade.py (-m gpu).
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "bmx/bvector.hpp"
+extern "C" {
+#include "../../oracle/bmx_oracle.h"
+}
+
+#define REQUIRE(c) do { if (!(c)) { std::fprintf(stderr, "FAILED %s:%d: %s\n", __FILE__, __LINE__, #c); std::exit(1); } } while (0)
+
+static const uint64_t SEED = 0xB17A61C;
+
+int main()
+{
+    bmx::context ctx(0);
+    const uint64_t nbits = 11 * 65536 + 777;
+    const unsigned NV = 10;
+    std::vector<std::vector<uint32_t>> words(NV);
+    std::vector<bmo_vec*> pv(NV);
+    std::vector<bmx::bvector> gv;
+    for (unsigned v = 0; v < NV; ++v) {
+        uint32_t dq = v < 4 ? 6554u : (v < 7 ? 655u : 120u);          // bit, mixed, GAP operands
+        uint64_t nw = ((nbits + 63) / 64) * 2;
+        words[v].resize(nw);
+        bmo_gen_words(SEED, v, v < 4, dq, nbits, 0, nw, words[v].data());
+        pv[v] = bmo_vec_import(words[v].data(), nw, 1);
+        gv.emplace_back(ctx);
+        bmx::bit_import_u32(gv[v], words[v].data(), nw, true);
+        REQUIRE(gv[v].count() == bmo_vec_count(pv[v]));
+        bmx::bvector::statistics st; gv[v].calc_stat(&st);
+        uint32_t c[4]; uint64_t gw; bmo_vec_stat(pv[v], c, &gw);
+        REQUIRE(st.bit_blocks == c[BMO_BIT] && st.gap_blocks == c[BMO_GAP]);
+    }
+    // pairwise, 3-operand and 2-operand forms
+    for (int op = 0; op < 4; ++op) {
+        bmx::bvector t(ctx), u(ctx);
+        bmo_vec* e = bmo_op2(op, pv[1], pv[5], 0);
+        switch (op) {
+        case 0: t.bit_and(gv[1], gv[5]); REQUIRE(bmx::count_and(gv[1], gv[5]) == bmo_vec_count(e)); break;
+        case 1: t.bit_or(gv[1], gv[5], bmx::bvector::opt_compress); REQUIRE(bmx::count_or(gv[1], gv[5]) == bmo_vec_count(e)); break;
+        case 2: t.bit_xor(gv[1], gv[5]); REQUIRE(bmx::count_xor(gv[1], gv[5]) == bmo_vec_count(e)); break;
+        default: t.bit_sub(gv[1], gv[5]); REQUIRE(bmx::count_sub(gv[1], gv[5]) == bmo_vec_count(e)); break;
+        }
+        REQUIRE(t.count() == bmo_vec_count(e));
+        std::vector<uint32_t> w1(12 * 2048), w2(12 * 2048);
+        t.export_words(w1.data(), w1.size()); bmo_vec_to_words(e, w2.data(), w2.size());
+        REQUIRE(w1 == w2);
+        // in-place form must give the same vector
+        bmx::bit_import_u32(u, words[1].data(), words[1].size(), true);
+        switch (op) { case 0: u &= gv[5]; break; case 1: u |= gv[5]; break; case 2: u ^= gv[5]; break; default: u -= gv[5]; break; }
+        REQUIRE(u.equal(t));
+        bmo_vec_free(e);
+    }
+    // aggregator, member API
+    bmx::aggregator<bmx::bvector> agg(ctx);
+    for (unsigned v = 0; v < 4; ++v) agg.add(&gv[v]);
+    agg.add(nullptr);                                   // ignored
+    bool threw = false;
+    try { agg.add(&gv[0], 2); } catch (const bmx::error& e) { threw = e.status() == BMX_ERR_RANGE; }
+    REQUIRE(threw);
+    agg.add(&gv[8], 1);
+    bmx::bvector t(ctx);
+    bool any = agg.combine_and_sub(t);
+    const bmo_vec* a4[4] = {pv[0], pv[1], pv[2], pv[3]}; const bmo_vec* s1[1] = {pv[8]};
+    bmo_vec* e = bmo_agg_and_sub(a4, 4, s1, 1);
+    REQUIRE(t.count() == bmo_vec_count(e) && any == (bmo_vec_count(e) != 0));
+    agg.combine_or(t);
+    bmo_vec* eo = bmo_agg_or(a4, 4);
+    REQUIRE(t.count() == bmo_vec_count(eo));
+    bmo_vec_free(e); bmo_vec_free(eo);
+    // counts-only pipeline
+    bmx::aggregator<bmx::bvector>::pipeline<bmx::agg_opt_only_counts> pipe(ctx);
+    {
+        auto* g0 = pipe.add(); for (unsigned v = 0; v < NV; ++v) g0->add(&gv[v], 0);
+        auto* g1 = pipe.add(); g1->add(&gv[0], 0); g1->add(&gv[1], 0); g1->add(&gv[9], 1);
+        auto* g2 = pipe.add(); g2->add(&gv[4], 0); g2->add(&gv[7], 0);
+    }
+    pipe.complete();
+    agg.combine_and_sub(pipe);
+    const bmo_vec* al[14]; for (unsigned v = 0; v < NV; ++v) al[v] = pv[v];
+    al[10] = pv[0]; al[11] = pv[1]; al[12] = pv[4]; al[13] = pv[7];
+    const bmo_vec* sl[1] = {pv[9]};
+    uint32_t an[3] = {NV, 2, 2}, sn[3] = {0, 1, 0}; uint64_t exp[3];
+    bmo_agg_pipeline_counts(al, an, sl, sn, 3, 0, 12, exp);
+    for (int g = 0; g < 3; ++g) REQUIRE(pipe.get_bv_count_vector()[g] == exp[g]);
+    // rank / select
+    bmx::rs_index rs; gv[5].build_rs_index(&rs);
+    bmo_rs* prs = bmo_rs_build(pv[5]);
+    REQUIRE(rs.count() == bmo_rs_count(prs));
+    for (uint64_t n = 0; n < nbits; n += 9973) REQUIRE(gv[5].count_to(n, rs) == bmo_rank(pv[5], prs, n));
+    for (uint64_t r = 1; r <= rs.count(); r += 1 + rs.count() / 97) {
+        uint64_t p1 = 0, p2 = 0;
+        REQUIRE(gv[5].select(r, p1, rs) && bmo_select(pv[5], prs, r, &p2) && p1 == p2);
+    }
+    uint64_t dummy;
+    REQUIRE(!gv[5].select(0, dummy, rs) && !gv[5].select(rs.count() + 1, dummy, rs));
+    bmo_rs_free(prs);
+    for (unsigned v = 0; v < NV; ++v) bmo_vec_free(pv[v]);
+    std::printf("test_facade ok\n");
+    return 0;
+}
