@@ -76,6 +76,7 @@ def lib() -> C.CDLL:
         "bmx_select_batch": (i32, [vp, vp, vp, vp, C.c_size_t, vp, vp]),
         "bmx_rank_batch_dev": (i32, [vp, vp, vp, vp, C.c_size_t, vp]),
         "bmx_select_batch_dev": (i32, [vp, vp, vp, vp, C.c_size_t, vp, vp]),
+        "bmx_diag_stream_read": (i32, [vp, u64, i32, u32, i32, i32, P(C.c_float)]),
         "bmx_timer_start": (i32, [vp]),
         "bmx_timer_stop_ms": (i32, [vp, P(C.c_float)]),
     }

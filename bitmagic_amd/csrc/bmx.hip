@@ -38,10 +38,11 @@ struct bmx_ctx {
     void* aux = nullptr; size_t aux_bytes = 0;              // stats / offsets / totals
     u64* d_small = nullptr;                                 // 64 x u64 result words
     u64* h_small = nullptr;                                 // pinned mirror
-    int pipe_unroll = 2;       // operand blocks in flight per wave
+    int pipe_unroll = 4;       // operand blocks per batch (two batches in flight in the v2 kernel)
     int pipe_rows = 8;         // register rows per work item (8 = whole block, 4/2/1 = slices)
     int pipe_nt = 1;           // non-temporal operand loads (+4.5 % on the streamed-once headline case)
     int pipe_wg = 256;         // workgroup size of the counts kernel
+    int pipe_ver = 2;          // 1 = k_pipe_counts_bits, 2 = software-pipelined k_pipe_counts_bits2
     int xcd_swz = 1;
 };
 
@@ -135,6 +136,7 @@ int bmx_ctx_create(int device, void* stream, bmx_ctx** out)
     if (const char* e = getenv("BMX_PIPE_UNROLL")) ctx->pipe_unroll = atoi(e);
     if (const char* e = getenv("BMX_PIPE_ROWS")) ctx->pipe_rows = atoi(e);
     if (const char* e = getenv("BMX_PIPE_NT")) ctx->pipe_nt = atoi(e);
+    if (const char* e = getenv("BMX_PIPE_VER")) ctx->pipe_ver = atoi(e);
     if (const char* e = getenv("BMX_PIPE_WG")) ctx->pipe_wg = atoi(e);
     if (const char* e = getenv("BMX_XCD_SWIZZLE")) ctx->xcd_swz = atoi(e);
     *out = ctx;
@@ -164,9 +166,35 @@ int bmx_ctx_set_tuning(bmx_ctx* ctx, const char* key, int value)
     if (k == "pipe_unroll") { ARGCHK(value == 1 || value == 2 || value == 4); ctx->pipe_unroll = value; }
     else if (k == "pipe_rows") { ARGCHK(value == 8 || value == 4 || value == 2 || value == 1); ctx->pipe_rows = value; }
     else if (k == "pipe_nt") ctx->pipe_nt = value != 0;
+    else if (k == "pipe_ver") { ARGCHK(value == 1 || value == 2); ctx->pipe_ver = value; }
     else if (k == "pipe_wg") { ARGCHK(value == 64 || value == 128 || value == 256); ctx->pipe_wg = value; }
     else if (k == "xcd_swizzle") ctx->xcd_swz = value != 0;
     else { g_last_error = "unknown tuning key"; return BMX_ERR_BADARG; }
+    return BMX_OK;
+}
+
+int bmx_diag_stream_read(bmx_ctx* ctx, uint64_t bytes, int nt, uint32_t blocks_per_wave, int pattern, int iters, float* ms_per_pass)
+{
+    ARGCHK(ctx && ms_per_pass && bytes >= 8192 && blocks_per_wave >= 1 && iters >= 1);
+    int rc = set_dev(ctx); if (rc) return rc;
+    void* buf = nullptr;
+    u64 nblk = bytes / 8192;
+    HIPCHK(hipMalloc(&buf, nblk * 8192));
+    hipError_t e = hipMemsetAsync(buf, 0x5A, nblk * 8192, ctx->stream);
+    u64 waves = (nblk + blocks_per_wave - 1) / blocks_per_wave;
+    u32 grid = (u32)((waves + 3) / 4);
+    for (int it = -1; it < iters && e == hipSuccess; ++it) {
+        if (it == 0) e = hipEventRecord(ctx->ev0, ctx->stream);
+        if (nt) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_diag_stream_read<true>), dim3(grid), dim3(256), 0, ctx->stream, (const uint4*)buf, nblk, blocks_per_wave, pattern, ctx->xcd_swz, ctx->d_small);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_diag_stream_read<false>), dim3(grid), dim3(256), 0, ctx->stream, (const uint4*)buf, nblk, blocks_per_wave, pattern, ctx->xcd_swz, ctx->d_small);
+    }
+    if (e == hipSuccess) e = hipEventRecord(ctx->ev1, ctx->stream);
+    if (e == hipSuccess) e = hipEventSynchronize(ctx->ev1);
+    float ms = 0;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
+    (void)hipFree(buf);
+    if (e != hipSuccess) return fail_hip(e, "bmx_diag_stream_read", __LINE__);
+    *ms_per_pass = ms / iters;
     return BMX_OK;
 }
 
@@ -504,6 +532,16 @@ int bmx_pipeline_run_counts_dev(bmx_ctx* ctx, bmx_pipeline* p, uint32_t nb_from,
         u32 rows = (u32)ctx->pipe_rows, parts = 8u / rows;
         u64 n64 = nitems64 * parts;
         if (n64 > 0xFFFFFFF0ull) { g_last_error = "too many work items in one run"; return BMX_ERR_RANGE; }
+        if (ctx->pipe_ver == 2) {
+            u32 nitems = (u32)nitems64, wpb = (u32)ctx->pipe_wg / 64u, grid = (nitems + wpb - 1) / wpb;
+#define LAUNCH_B2(U, NT) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pipe_counts_bits2<U, NT>), dim3(grid), dim3(ctx->pipe_wg), 0, ctx->stream, \
+        p->d_dmat, row_off, and_n, p->col_stride, p->ngroups, nb_from, nitems, ctx->xcd_swz, (u64*)d_counts)
+            if (ctx->pipe_nt) { switch (ctx->pipe_unroll) { case 1: LAUNCH_B2(1, true); break; case 4: LAUNCH_B2(4, true); break; default: LAUNCH_B2(2, true); break; } }
+            else { switch (ctx->pipe_unroll) { case 1: LAUNCH_B2(1, false); break; case 4: LAUNCH_B2(4, false); break; default: LAUNCH_B2(2, false); break; } }
+#undef LAUNCH_B2
+            KCHK();
+            return BMX_OK;
+        }
         u32 nitems = (u32)n64, wpb = (u32)ctx->pipe_wg / 64u, grid = (nitems + wpb - 1) / wpb;
 #define LAUNCH_BITS(U, R, NT) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pipe_counts_bits<U, R, NT>), dim3(grid), dim3(ctx->pipe_wg), 0, ctx->stream, \
         p->d_dmat, row_off, and_n, p->col_stride, p->ngroups, nb_from, nitems, ctx->xcd_swz, (u64*)d_counts)

@@ -442,6 +442,108 @@ void k_pipe_counts_bits(const u64* __restrict__ dmat, const u32* __restrict__ ro
     if (lane == 0 && cnt) atomicAdd(reinterpret_cast<unsigned long long*>(&counts[g]), (unsigned long long)cnt);
 }
 
+// ---------------------------------------------------------------------------
+// v2 of the bit-block-only fast path: software-pipelined.
+//  * operand pointers are fetched 64 at a time with ONE coalesced vector load
+//    (lane l keeps pointer 64*c + l) and handed out with v_readlane -- no scalar
+//    memory latency inside the operand loop;
+//  * two register buffers: the loads of batch n+1 are issued before batch n is
+//    consumed, so a wave always has U..2U blocks in flight;
+//  * the tail batch re-uses its last operand (AND / AND-NOT are idempotent), so
+//    there is no remainder loop.
+// Whole blocks per wave (ROWS = 8) only: measured best (tools/tune_pipe.py).
+// Measured alternatives that did NOT win on MI355X (same box, interleaved A/B, 256 x 1e9 bits):
+//   slices of 4/2/1 KiB per wave (-3..-8 %), occupancy pinned to 8 waves/SIMD with a
+//   one-block-in-flight loop (-7 %), hand-placed asm loads with counted vmcnt (-5 %, and hipcc
+//   may copy an asm-loaded register before the wait), dropping the early-exit test (-2 %).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ u64 readlane64(u64 v, u32 l)
+{
+    u32 lo = __builtin_amdgcn_readlane((u32)v, l);
+    u32 hi = __builtin_amdgcn_readlane((u32)(v >> 32), l);
+    return ((u64)hi << 32) | lo;
+}
+
+template <int U, bool NT, bool SUBOP>
+__device__ __forceinline__ bool pipe_chain(Part<8>& acc, const u64* __restrict__ plist, u32 n, u32 lane)
+{
+    // ANDs (or AND-NOTs) operands 0 .. n-1 of plist into acc; returns true when acc became all-zero.
+    // plist is wave-uniform, so plist[i] is a scalar (SMEM) load: it counts on lgkmcnt, not vmcnt,
+    // and is issued one batch ahead -- the vector-memory pipeline never waits for a pointer.
+    if (n == 0) return false;
+    u64 pn[U];                                               // pointers of the batch to issue next
+    auto fetch = [&](u32 k) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) pn[u] = plist[k + u < n ? k + u : n - 1u];   // tail: repeat the last operand
+    };
+    auto issue = [&](Part<8>* buf) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) part_load<8, NT>(buf[u], as_gc4(uniform64(pn[u])), lane);
+    };
+    auto consume = [&](Part<8>* buf) {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { if (SUBOP) acc.r[i] &= ~buf[u].r[i]; else acc.r[i] &= buf[u].r[i]; }
+        return part_is_zero<8>(acc);
+    };
+    // The loop body is ONE basic block that issues batch j+1 before consuming batch j and batch
+    // j+2 before consuming batch j+1; the only branch is the back-edge.  (With an early-exit branch
+    // between issue and consume, LLVM sinks the loads below the branch -- or, for a guarded issue,
+    // merges the wait counters to vmcnt(0) at the join -- and the two buffers serialise.)
+    // Early exit therefore has a granularity of 2U operands.  Past the end the clamped index
+    // re-loads the last operand (idempotent; <= 2U L2-resident blocks per column).
+    Part<8> A[U], B[U];
+    u32 k = U;                      // first operand of the batch to issue next
+    fetch(0);
+    issue(A);
+    fetch(k);
+    bool zero;
+    do {
+        issue(B); fetch(k + U);
+        bool z1 = consume(A);
+        issue(A); fetch(k + 2 * U);
+        bool z2 = consume(B);
+        zero = z1 | z2;
+        k += 2 * U;
+    } while (!zero && k < n + U);   // batch starting at k-U has been issued into A: consume it next time
+    return zero;
+}
+
+template <int U, bool NT>
+__global__ __launch_bounds__(256)
+void k_pipe_counts_bits2(const u64* __restrict__ dmat, const u32* __restrict__ row_off,
+                         const u32* __restrict__ and_n, u32 col_stride,
+                         u32 ngroups, u32 col_from, u32 nitems, int xcd_swz, u64* __restrict__ counts)
+{
+    u32 lane = lane_id(), wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+    u32 bid = xcd_swz ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
+    u32 item = uniform32(bid * wpb + wave);
+    if (item >= nitems) return;
+    u32 c = item / ngroups, g = item - c * ngroups;
+    const u64* row = dmat + (size_t)(col_from + c) * col_stride + row_off[g];
+    u64 hdr = uniform64(row[0]), flags = uniform64(row[1]);
+    if (flags & ROW_EMPTY) return;
+    if (flags & ROW_FULL) { if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(&counts[g]), 65536ull); return; }
+    u32 nba = (u32)(hdr & 0xFFFFu), nbs = (u32)((hdr >> 32) & 0xFFFFu);
+    u32 na = uniform32(and_n[g]);
+    const u64* pa = row + 2;
+    const u64* ps = pa + na;
+    Part<8> acc;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc.r[i] = (u32x4)(~0u);
+    if (pipe_chain<U, NT, false>(acc, pa, nba, lane)) return;
+    if (pipe_chain<U, NT, true>(acc, ps, nbs, lane)) return;
+    u32 cnt = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        cnt += __popcll(((u64)acc.r[i].y << 32) | acc.r[i].x);
+        cnt += __popcll(((u64)acc.r[i].w << 32) | acc.r[i].z);
+    }
+    cnt = wave_sum(cnt);
+    if (lane == 0 && cnt) atomicAdd(reinterpret_cast<unsigned long long*>(&counts[g]), (unsigned long long)cnt);
+}
+
 // algorithmic operand bytes of the rows in [col_from, col_from+ncols)
 __global__ __launch_bounds__(256)
 void k_pipe_bytes(const u64* __restrict__ dmat, const u32* __restrict__ row_off, const u32* __restrict__ and_n,
@@ -468,4 +570,33 @@ void k_pipe_bytes(const u64* __restrict__ dmat, const u32* __restrict__ row_off,
     s[threadIdx.x] = bytes; __syncthreads();
     for (u32 o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) s[threadIdx.x] += s[threadIdx.x + o]; __syncthreads(); }
     if (threadIdx.x == 0 && s[0]) atomicAdd(reinterpret_cast<unsigned long long*>(total), (unsigned long long)s[0]);
+}
+
+// ---------------------------------------------------------------------------
+// diagnostics: plain streaming read of a large buffer (practical HBM ceiling of
+// the box, measured next to the product kernels by tools/tune_pipe.py)
+// mode 0: one wave per contiguous CHUNK (8 KiB x chunk_blocks), plain loads
+// mode 1: same with non-temporal loads
+// ---------------------------------------------------------------------------
+// pattern 0: wave w reads blocks [w*bpw, (w+1)*bpw) (contiguous); pattern 1: wave w reads block
+// j*nwaves + w for j < bpw (the access pattern of an N-way aggregation over N separate vectors)
+template <bool NT>
+__global__ __launch_bounds__(256)
+void k_diag_stream_read(const uint4* __restrict__ buf, u64 nblocks8k, u32 blocks_per_wave, int pattern, int xcd_swz, u64* __restrict__ sink)
+{
+    u32 lane = lane_id();
+    u32 bid = xcd_swz ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
+    u64 w = (u64)bid * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    u64 nwaves = nblocks8k / blocks_per_wave;
+    if (w >= nwaves) return;
+    u64 b0 = pattern ? w : w * blocks_per_wave;
+    u64 step = pattern ? nwaves : 1;
+    u32x4 acc = (u32x4)(0u);
+    for (u32 j = 0; j < blocks_per_wave; ++j) {
+        Part<8> t;
+        part_load<8, NT>(t, as_gc4(buf + (b0 + j * step) * 512u), lane);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc |= t.r[i];
+    }
+    if ((acc.x | acc.y | acc.z | acc.w) == 0x12345678u) sink[0] = 1;   // never true for the memset pattern; defeats DCE
 }

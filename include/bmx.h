@@ -75,7 +75,7 @@ int bmx_ctx_create(int device, void* stream, bmx_ctx** out);
 int bmx_ctx_destroy(bmx_ctx* ctx);
 int bmx_ctx_synchronize(bmx_ctx* ctx);
 /* launch-shape knobs of the counts pipeline (results never depend on them):
- * "pipe_unroll" 1|2|4, "pipe_rows" 8|4|2|1, "pipe_nt" 0|1, "pipe_wg" 64|128|256, "xcd_swizzle" 0|1 */
+ * "pipe_unroll" 1|2|4, "pipe_rows" 8|4|2|1, "pipe_nt" 0|1, "pipe_wg" 64|128|256, "pipe_ver" 1|2, "xcd_swizzle" 0|1 */
 int bmx_ctx_set_tuning(bmx_ctx* ctx, const char* key, int value);
 /* bytes of HBM currently held by vectors/pipelines of this context */
 int bmx_ctx_mem_used(const bmx_ctx* ctx, uint64_t* bytes);
@@ -175,6 +175,13 @@ int bmx_rank_batch_dev(bmx_ctx* ctx, const bmx_vec* v, const bmx_rs* rs,
                        const uint64_t* d_n, size_t q, uint64_t* d_out);
 int bmx_select_batch_dev(bmx_ctx* ctx, const bmx_vec* v, const bmx_rs* rs,
                          const uint64_t* d_rank, size_t q, uint64_t* d_pos, uint8_t* d_found);
+
+/* ---- diagnostics ---- */
+/* plain streaming read of a scratch buffer: the practical HBM read ceiling of this box,
+ * to put next to the product kernels (tools/tune_pipe.py).  ms_per_pass = avg of iters passes. */
+int bmx_diag_stream_read(bmx_ctx* ctx, uint64_t bytes, int nontemporal, uint32_t blocks_per_wave,
+                         int pattern /* 0 contiguous per wave, 1 strided like an N-way aggregation */,
+                         int iters, float* ms_per_pass);
 
 /* ---- timing helper: HIP events on the context's stream ---- */
 int bmx_timer_start(bmx_ctx* ctx);

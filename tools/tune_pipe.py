@@ -24,15 +24,15 @@ counts = torch.zeros(1, dtype=torch.int64, device="cuda")
 ob = pipe.operand_bytes()
 if a.variants:
     variants = [tuple(int(x) for x in v.split(":")) for v in a.variants.split(",")]
+    variants = [v if len(v) == 6 else v + (1,) for v in variants]
 else:
-    variants = [(u, r, nt, wg, sw) for u in (1, 2, 4) for r in (8, 4, 2) for nt in (0, 1) for wg in (256,) for sw in (1,)]
-    variants += [(1, 8, 0, 64, 1), (1, 8, 0, 128, 1), (2, 4, 0, 64, 1), (1, 8, 0, 256, 0), (2, 4, 0, 256, 0), (1, 1, 0, 256, 1), (4, 1, 0, 256, 1)]
+    variants = [(u, 8, nt, 256, 1, ver) for u in (1, 2, 4) for nt in (0, 1) for ver in (1, 2)] + [(2, 4, 1, 256, 1, 1), (4, 8, 1, 256, 0, 2)]
 res = {v: [] for v in variants}
 ref = None
 for rnd in range(a.rounds):
     for v in variants:
-        u, r, nt, wg, sw = v
-        for k, x in (("pipe_unroll", u), ("pipe_rows", r), ("pipe_nt", nt), ("pipe_wg", wg), ("xcd_swizzle", sw)):
+        u, r, nt, wg, sw, ver = v
+        for k, x in (("pipe_unroll", u), ("pipe_rows", r), ("pipe_nt", nt), ("pipe_wg", wg), ("xcd_swizzle", sw), ("pipe_ver", ver)):
             ctx.set_tuning(k, x)
         agg.run_counts_dev(pipe, counts.data_ptr())
         torch.cuda.synchronize()
@@ -42,6 +42,15 @@ for rnd in range(a.rounds):
         ctx.timer_start()
         for _ in range(a.iters): agg.run_counts_dev(pipe, counts.data_ptr())
         res[v].append(ctx.timer_stop_ms() / a.iters)
+import ctypes as C
+from bitmagic_amd import _ffi
+for swz in (1, 0):
+  ctx.set_tuning("xcd_swizzle", swz)
+  for pattern in (0, 1):
+    for bpw in (1, 16, 256):
+        ms = C.c_float()
+        _ffi.check(_ffi.lib().bmx_diag_stream_read(ctx._h, 16 << 30, 1, bpw, pattern, 5, C.byref(ms)))
+        print(f"stream_read 16 GiB nt=1 swz={swz} pattern={pattern} blocks_per_wave={bpw}: {ms.value:.4f} ms  {(16 << 30) / ms.value / 1e6:.0f} GB/s  frac {(16 << 30) / ms.value / 1e6 / 8000:.3f}")
 rows = []
 for v, t in res.items():
     t = np.array(t)
@@ -49,4 +58,4 @@ for v, t in res.items():
 rows.sort()
 print("count", ref, "operand GB", ob / 1e9)
 for med, mn, v in rows:
-    print(f"U={v[0]} rows={v[1]} nt={v[2]} wg={v[3]} swz={v[4]}  median {med:.4f} ms  min {mn:.4f} ms  {ob/med/1e6:.0f} GB/s  frac {ob/med/1e6/8000:.3f}")
+    print(f"ver={v[5]} U={v[0]} rows={v[1]} nt={v[2]} wg={v[3]} swz={v[4]}  median {med:.4f} ms  min {mn:.4f} ms  {ob/med/1e6:.0f} GB/s  frac {ob/med/1e6/8000:.3f}")
