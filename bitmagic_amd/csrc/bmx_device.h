@@ -25,7 +25,9 @@ typedef const __attribute__((address_space(1))) u32x4* gcptr4;
 typedef __attribute__((address_space(1))) u32x4* gptr4;
 typedef const __attribute__((address_space(1))) u16* gcptr16;
 
-struct Blk { u32x4 r[8]; };
+// ROWS register rows of a block (ROWS KiB); a whole block is Part<8>
+template <int ROWS> struct Part { u32x4 r[ROWS]; };
+typedef Part<8> Blk;
 
 __device__ __forceinline__ gcptr4 as_gc4(u64 addr) { return (gcptr4)(uintptr_t)addr; }
 __device__ __forceinline__ gcptr4 as_gc4(const void* p) { return (gcptr4)(uintptr_t)p; }
@@ -58,6 +60,32 @@ __device__ __forceinline__ u32 wave_scan_incl(u32 v, u32 lane)
         if (lane >= (u32)o) v += n;
     }
     return v;
+}
+
+template <int ROWS, bool NT>
+__device__ __forceinline__ void part_load(Part<ROWS>& b, gcptr4 p, u32 lane)
+{
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) {
+        if constexpr (NT) b.r[i] = __builtin_nontemporal_load(p + i * 64 + lane);
+        else b.r[i] = p[i * 64 + lane];
+    }
+}
+template <int ROWS>
+__device__ __forceinline__ bool part_is_zero(const Part<ROWS>& b)
+{
+    u32 v = 0;
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) v |= b.r[i].x | b.r[i].y | b.r[i].z | b.r[i].w;
+    return __ballot(v != 0u) == 0ull;
+}
+template <int ROWS>
+__device__ __forceinline__ bool part_is_ones(const Part<ROWS>& b)
+{
+    u32 v = ~0u;
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) v &= b.r[i].x & b.r[i].y & b.r[i].z & b.r[i].w;
+    return __ballot(v != ~0u) == 0ull;
 }
 
 __device__ __forceinline__ void blk_load(Blk& b, gcptr4 p, u32 lane)
@@ -251,3 +279,65 @@ __device__ __forceinline__ u64 gen_word64(u64 seed, u32 vec_id, u64 w64, u32 d)
     }
     return acc;
 }
+
+// ---------------------------------------------------------------------------
+// software-pipelined fold of a list of bit-block operands (see k_pipe_counts_bits2)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ u64 readlane64(u64 v, u32 l)
+{
+    u32 lo = __builtin_amdgcn_readlane((u32)v, l);
+    u32 hi = __builtin_amdgcn_readlane((u32)(v >> 32), l);
+    return ((u64)hi << 32) | lo;
+}
+
+template <int U, bool NT, int OPK>
+__device__ __forceinline__ bool pipe_chain(Part<8>& acc, const u64* __restrict__ plist, u32 n, u32 lane)
+{
+    // Folds operands 0 .. n-1 of plist into acc: OPK 0 = AND, 1 = AND-NOT, 2 = OR.  Returns true when
+    // acc saturated (all-zero for AND / AND-NOT, all-ones for OR) so the caller can stop early.
+    // plist is wave-uniform, so plist[i] is a scalar (SMEM) load: it counts on lgkmcnt, not vmcnt,
+    // and is issued one batch ahead -- the vector-memory pipeline never waits for a pointer.
+    if (n == 0) return false;
+    u64 pn[U];                                               // pointers of the batch to issue next
+    auto fetch = [&](u32 k) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) pn[u] = plist[k + u < n ? k + u : n - 1u];   // tail: repeat the last operand
+    };
+    auto issue = [&](Part<8>* buf) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) part_load<8, NT>(buf[u], as_gc4(uniform64(pn[u])), lane);
+    };
+    auto consume = [&](Part<8>* buf) {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if constexpr (OPK == 0) acc.r[i] &= buf[u].r[i];
+                else if constexpr (OPK == 1) acc.r[i] &= ~buf[u].r[i];
+                else acc.r[i] |= buf[u].r[i];
+            }
+        if constexpr (OPK == 2) return part_is_ones<8>(acc); else return part_is_zero<8>(acc);
+    };
+    // The loop body is ONE basic block that issues batch j+1 before consuming batch j and batch
+    // j+2 before consuming batch j+1; the only branch is the back-edge.  (With an early-exit branch
+    // between issue and consume, LLVM sinks the loads below the branch -- or, for a guarded issue,
+    // merges the wait counters to vmcnt(0) at the join -- and the two buffers serialise.)
+    // Early exit therefore has a granularity of 2U operands.  Past the end the clamped index
+    // re-loads the last operand (idempotent; <= 2U L2-resident blocks per column).
+    Part<8> A[U], B[U];
+    u32 k = U;                      // first operand of the batch to issue next
+    fetch(0);
+    issue(A);
+    fetch(k);
+    bool zero;
+    do {
+        issue(B); fetch(k + U);
+        bool z1 = consume(A);
+        issue(A); fetch(k + 2 * U);
+        bool z2 = consume(B);
+        zero = z1 | z2;
+        k += 2 * U;
+    } while (!zero && k < n + U);   // batch starting at k-U has been issued into A: consume it next time
+    return zero;
+}
+

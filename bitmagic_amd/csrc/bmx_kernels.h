@@ -296,38 +296,10 @@ void k_pipe_counts(const u64* __restrict__ dmat, const u32* __restrict__ row_off
     u32* lds = lds_dyn + wave * 2048u;
 
     Blk acc;
-    u32 k = 0;
-    if (flags & ROW_ONES) blk_fill(acc, ~0u);
-    else { blk_load(acc, as_gc4(uniform64(pa[0])), lane); k = 1; }
-
-    // AND bit-block operands, U at a time
-    for (; k + U <= nba; k += U) {
-        Blk t[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) blk_load(t[u], as_gc4(uniform64(pa[k + u])), lane);
-#pragma unroll
-        for (int u = 0; u < U; ++u) blk_and(acc, t[u]);
-        if (blk_is_zero(acc)) return;
-    }
-    for (; k < nba; ++k) {
-        Blk t; blk_load(t, as_gc4(uniform64(pa[k])), lane);
-        blk_and(acc, t);
-    }
-    if (blk_is_zero(acc)) return;
-    // SUB bit-block operands
-    k = 0;
-    for (; k + U <= nbs; k += U) {
-        Blk t[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) blk_load(t[u], as_gc4(uniform64(ps[k + u])), lane);
-#pragma unroll
-        for (int u = 0; u < U; ++u) blk_andn(acc, t[u]);
-        if (blk_is_zero(acc)) return;
-    }
-    for (; k < nbs; ++k) {
-        Blk t; blk_load(t, as_gc4(uniform64(ps[k])), lane);
-        blk_andn(acc, t);
-    }
+    blk_fill(acc, ~0u);
+    // bit-block operands: software-pipelined fold (bmx_device.h pipe_chain), AND group then SUB group
+    if (pipe_chain<U, true, 0>(acc, pa, nba, lane)) return;
+    if (pipe_chain<U, true, 1>(acc, ps, nbs, lane)) return;
     // GAP operands (packed from the back of each region)
     for (u32 i = 0; i < nga; ++i) {
         Blk t; gap_decode(as_gc16(uniform64(pa[na - 1u - i])), lds, t, lane);
@@ -351,26 +323,6 @@ void k_pipe_counts(const u64* __restrict__ dmat, const u32* __restrict__ row_off
 // the early-exit test becomes per slice (finer than the reference's digest).
 // NT selects non-temporal loads (streamed-once data).
 // ---------------------------------------------------------------------------
-template <int ROWS> struct Part { u32x4 r[ROWS]; };
-
-template <int ROWS, bool NT>
-__device__ __forceinline__ void part_load(Part<ROWS>& b, gcptr4 p, u32 lane)
-{
-#pragma unroll
-    for (int i = 0; i < ROWS; ++i) {
-        if constexpr (NT) b.r[i] = __builtin_nontemporal_load(p + i * 64 + lane);
-        else b.r[i] = p[i * 64 + lane];
-    }
-}
-template <int ROWS>
-__device__ __forceinline__ bool part_is_zero(const Part<ROWS>& b)
-{
-    u32 v = 0;
-#pragma unroll
-    for (int i = 0; i < ROWS; ++i) v |= b.r[i].x | b.r[i].y | b.r[i].z | b.r[i].w;
-    return __ballot(v != 0u) == 0ull;
-}
-
 template <int U, int ROWS, bool NT>
 __global__ __launch_bounds__(256)
 void k_pipe_counts_bits(const u64* __restrict__ dmat, const u32* __restrict__ row_off,
@@ -457,59 +409,6 @@ void k_pipe_counts_bits(const u64* __restrict__ dmat, const u32* __restrict__ ro
 //   one-block-in-flight loop (-7 %), hand-placed asm loads with counted vmcnt (-5 %, and hipcc
 //   may copy an asm-loaded register before the wait), dropping the early-exit test (-2 %).
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ u64 readlane64(u64 v, u32 l)
-{
-    u32 lo = __builtin_amdgcn_readlane((u32)v, l);
-    u32 hi = __builtin_amdgcn_readlane((u32)(v >> 32), l);
-    return ((u64)hi << 32) | lo;
-}
-
-template <int U, bool NT, bool SUBOP>
-__device__ __forceinline__ bool pipe_chain(Part<8>& acc, const u64* __restrict__ plist, u32 n, u32 lane)
-{
-    // ANDs (or AND-NOTs) operands 0 .. n-1 of plist into acc; returns true when acc became all-zero.
-    // plist is wave-uniform, so plist[i] is a scalar (SMEM) load: it counts on lgkmcnt, not vmcnt,
-    // and is issued one batch ahead -- the vector-memory pipeline never waits for a pointer.
-    if (n == 0) return false;
-    u64 pn[U];                                               // pointers of the batch to issue next
-    auto fetch = [&](u32 k) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) pn[u] = plist[k + u < n ? k + u : n - 1u];   // tail: repeat the last operand
-    };
-    auto issue = [&](Part<8>* buf) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) part_load<8, NT>(buf[u], as_gc4(uniform64(pn[u])), lane);
-    };
-    auto consume = [&](Part<8>* buf) {
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-#pragma unroll
-            for (int i = 0; i < 8; ++i) { if (SUBOP) acc.r[i] &= ~buf[u].r[i]; else acc.r[i] &= buf[u].r[i]; }
-        return part_is_zero<8>(acc);
-    };
-    // The loop body is ONE basic block that issues batch j+1 before consuming batch j and batch
-    // j+2 before consuming batch j+1; the only branch is the back-edge.  (With an early-exit branch
-    // between issue and consume, LLVM sinks the loads below the branch -- or, for a guarded issue,
-    // merges the wait counters to vmcnt(0) at the join -- and the two buffers serialise.)
-    // Early exit therefore has a granularity of 2U operands.  Past the end the clamped index
-    // re-loads the last operand (idempotent; <= 2U L2-resident blocks per column).
-    Part<8> A[U], B[U];
-    u32 k = U;                      // first operand of the batch to issue next
-    fetch(0);
-    issue(A);
-    fetch(k);
-    bool zero;
-    do {
-        issue(B); fetch(k + U);
-        bool z1 = consume(A);
-        issue(A); fetch(k + 2 * U);
-        bool z2 = consume(B);
-        zero = z1 | z2;
-        k += 2 * U;
-    } while (!zero && k < n + U);   // batch starting at k-U has been issued into A: consume it next time
-    return zero;
-}
-
 template <int U, bool NT>
 __global__ __launch_bounds__(256)
 void k_pipe_counts_bits2(const u64* __restrict__ dmat, const u32* __restrict__ row_off,

@@ -193,21 +193,8 @@ void k_agg_or(const u64* __restrict__ dmat, u32 n, u32 ncols, int opt_compress, 
     u32 nbit = (u32)(hdr & 0xFFFFu), ngap = (u32)((hdr >> 16) & 0xFFFFu);
     const u64* p = row + 2;
     Blk acc;
-    u32 k = 0;
-    if (nbit) { blk_load(acc, as_gc4(uniform64(p[0])), lane); k = 1; }
-    else blk_fill(acc, 0u);
-    for (; k + U <= nbit; k += U) {
-        Blk t[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) blk_load(t[u], as_gc4(uniform64(p[k + u])), lane);
-#pragma unroll
-        for (int u = 0; u < U; ++u) blk_or(acc, t[u]);
-        if (blk_is_ones(acc)) { store_trivial(K_FULL, c, desc, st, lane); return; }
-    }
-    for (; k < nbit; ++k) {
-        Blk t; blk_load(t, as_gc4(uniform64(p[k])), lane);
-        blk_or(acc, t);
-    }
+    blk_fill(acc, 0u);
+    if (pipe_chain<U, true, 2>(acc, p, nbit, lane)) { store_trivial(K_FULL, c, desc, st, lane); return; }   // saturated (:1951)
     u32* lds = lds_dyn + wave * 2048u;
     for (u32 i = 0; i < ngap; ++i) {
         Blk t; gap_decode(as_gc16(uniform64(p[n - 1u - i])), lds, t, lane);
@@ -241,23 +228,9 @@ void k_agg_and_sub(const u64* __restrict__ dmat, const u32* __restrict__ and_n_p
     const u64* ps = pa + na;
     u32* lds = lds_dyn + wave * 2048u;
     Blk acc;
-    u32 k = 0;
-    bool zero = false;
-    if (flags & ROW_ONES) blk_fill(acc, ~0u);
-    else { blk_load(acc, as_gc4(uniform64(pa[0])), lane); k = 1; }
-    for (; k + U <= nba && !zero; k += U) {
-        Blk t[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) blk_load(t[u], as_gc4(uniform64(pa[k + u])), lane);
-#pragma unroll
-        for (int u = 0; u < U; ++u) blk_and(acc, t[u]);
-        zero = blk_is_zero(acc);
-    }
-    for (; k < nba && !zero; ++k) { Blk t; blk_load(t, as_gc4(uniform64(pa[k])), lane); blk_and(acc, t); }
-    for (k = 0; k < nbs && !zero; ++k) {
-        Blk t; blk_load(t, as_gc4(uniform64(ps[k])), lane); blk_andn(acc, t);
-        if ((k & 3u) == 3u) zero = blk_is_zero(acc);
-    }
+    blk_fill(acc, ~0u);
+    bool zero = pipe_chain<U, true, 0>(acc, pa, nba, lane);
+    if (!zero) zero = pipe_chain<U, true, 1>(acc, ps, nbs, lane);
     for (u32 i = 0; i < nga && !zero; ++i) {
         Blk t; gap_decode(as_gc16(uniform64(pa[na - 1u - i])), lds, t, lane);
         blk_and(acc, t); zero = blk_is_zero(acc);

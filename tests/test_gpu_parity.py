@@ -301,3 +301,51 @@ def test_full_size_256way_and_count(ctx, port):
         exp = port.pipeline_counts([(pvs[:256], []), (pvs[:128], []), (pvs[:2], [])], nb0, nb0 + 1)
         got = agg._run_pipeline(pipe, nb0, nb0 + 1)
         assert (got == exp).all(), (nb0, got, exp)
+
+
+def test_launch_shape_knobs_do_not_change_results(ctx, port):
+    """every tuning combination of the counts pipeline (kernel version, batch size, slice size, NT, workgroup
+    size, XCD swizzle) x every operand count 1..19 (pipeline tail handling) x AND / AND-SUB groups"""
+    nbits = 13 * 65536 + 5
+    nv = 19
+    words = []
+    for v in range(nv):
+        w = port.gen_words(777, v, 20000, nbits) | port.gen_words(777, 0xFFFFFFFF, 9000, nbits)
+        if v % 7 == 3: w[2048:4096] = 0xFFFFFFFF                       # FULL block
+        if v % 9 == 4: w[3 * 2048:4 * 2048] = 0                          # NULL block
+        nw = (nbits + 31) // 32
+        w[nw:] = 0; w[nw - 1] &= (1 << (nbits % 32)) - 1
+        words.append(w)
+    gv = [bm.bit_import_u32(ctx, w, True) for w in words]
+    pv = [port.import_words(w, True, w.size * 32) for w in words]
+    groups = [(list(range(n)), []) for n in range(1, nv + 1)]
+    groups += [(list(range(n)), list(range(n, min(nv, n + k)))) for n in (1, 2, 5, 8) for k in (1, 2, 3, 4, 5, 9)]
+    exp = port.pipeline_counts([([pv[i] for i in a], [pv[i] for i in s]) for a, s in groups])
+    pipe = bm.aggregator.pipeline(ctx)
+    for a, s in groups:
+        ag = pipe.add()
+        for i in a: ag.add(gv[i], 0)
+        for i in s: ag.add(gv[i], 1)
+    pipe.complete()
+    agg = bm.aggregator(ctx)
+    try:
+        for ver in (1, 2):
+            for u in (1, 2, 4):
+                for rows in ((8, 4, 2, 1) if ver == 1 else (8,)):
+                    for nt in (0, 1):
+                        for wg, swz in ((256, 1), (64, 0), (128, 1)):
+                            for k, x in (("pipe_ver", ver), ("pipe_unroll", u), ("pipe_rows", rows), ("pipe_nt", nt),
+                                         ("pipe_wg", wg), ("xcd_swizzle", swz)):
+                                ctx.set_tuning(k, x)
+                            got = agg.combine_and_sub(pipe)
+                            assert (got == exp).all(), (ver, u, rows, nt, wg, swz)
+    finally:
+        for k, x in (("pipe_ver", 2), ("pipe_unroll", 4), ("pipe_rows", 8), ("pipe_nt", 1), ("pipe_wg", 256), ("xcd_swizzle", 1)):
+            ctx.set_tuning(k, x)
+    # the materialising twins use the same fold: every prefix, AND-SUB and OR
+    for a, s in groups[::4]:
+        t, _ = agg.combine_and_sub([gv[i] for i in a], [gv[i] for i in s])
+        e = port.agg_and_sub([pv[i] for i in a], [pv[i] for i in s])
+        assert (t.to_words(14 * 2048) == e.to_words(14 * 2048)).all()
+        o = agg.combine_or([gv[i] for i in a + s])
+        assert (o.to_words(14 * 2048) == port.agg_or([pv[i] for i in a + s]).to_words(14 * 2048)).all()
