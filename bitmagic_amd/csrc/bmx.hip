@@ -239,7 +239,8 @@ static int vec_alloc_device(bmx_vec* v, uint32_t n_bit, uint64_t gap_words)
     bmx_ctx* ctx = v->ctx;
     int rc;
     v->n_bit = n_bit; v->gap_words = gap_words;
-    size_t b_desc = (size_t)std::max<uint32_t>(v->nblocks, 1) * 8, b_bits = (size_t)n_bit * 8192, b_gaps = (size_t)gap_words * 2;
+    // + 64-byte guard: gap_apply_lds_lane requests the first 64 B of a GAP block before it knows its length
+    size_t b_desc = (size_t)std::max<uint32_t>(v->nblocks, 1) * 8, b_bits = (size_t)n_bit * 8192, b_gaps = (size_t)gap_words * 2 + 64;
     if ((rc = dmalloc(ctx, (void**)&v->d_desc, b_desc))) return rc;
     if ((rc = dmalloc(ctx, (void**)&v->d_bits, b_bits))) return rc;
     if ((rc = dmalloc(ctx, (void**)&v->d_gaps, b_gaps))) return rc;
@@ -271,26 +272,35 @@ int bmx_vec_upload(bmx_ctx* ctx, uint64_t nbits, uint32_t nblocks,
     ARGCHK(gap_words == 0 || gap_slab);
     *out = nullptr;
     int rc = set_dev(ctx); if (rc) return rc;
+    // validate + re-pack the GAP slab so that every block starts 16-byte aligned on the device
+    std::vector<u16> gpad;
+    std::vector<u64> goff(std::max<uint32_t>(nblocks, 1), 0);
+    for (uint32_t nb = 0; nb < nblocks; ++nb) {
+        if (kinds[nb] > BMX_GAP) { g_last_error = "bad block kind"; return BMX_ERR_BADARG; }
+        if (kinds[nb] == BMX_BIT && offs[nb] >= n_bit_blocks) { g_last_error = "bit-block offset out of range"; return BMX_ERR_RANGE; }
+        if (kinds[nb] != BMX_GAP) continue;
+        uint64_t o = offs[nb];
+        if (o >= gap_words) { g_last_error = "GAP offset out of range"; return BMX_ERR_RANGE; }
+        uint32_t len = gap_slab[o] >> 3;
+        if (len == 0 || len > 1280u + 8u || o + len + 1u > gap_words || gap_slab[o + len] != 65535u) { g_last_error = "malformed GAP block"; return BMX_ERR_RANGE; }
+        goff[nb] = gpad.size();
+        gpad.insert(gpad.end(), gap_slab + o, gap_slab + o + len + 1u);
+        gpad.resize((gpad.size() + 7u) & ~(size_t)7u, 0);
+    }
     bmx_vec* v = vec_alloc_host(ctx, nbits, nblocks);
     if (!v) return BMX_ERR_BADALLOC;
-    if ((rc = vec_alloc_device(v, n_bit_blocks, gap_words))) { bmx_vec_free(ctx, v); return rc; }
+    if ((rc = vec_alloc_device(v, n_bit_blocks, gpad.size()))) { bmx_vec_free(ctx, v); return rc; }
     std::vector<u64> desc(std::max<uint32_t>(nblocks, 1), 0);
     for (uint32_t nb = 0; nb < nblocks; ++nb) {
         uint8_t k = kinds[nb];
-        if (k > BMX_GAP) { bmx_vec_free(ctx, v); g_last_error = "bad block kind"; return BMX_ERR_BADARG; }
         v->counts[k]++;
-        if (k == BMX_BIT) {
-            if (offs[nb] >= n_bit_blocks) { bmx_vec_free(ctx, v); return BMX_ERR_RANGE; }
-            desc[nb] = DESC_MAKE(v->d_bits + (size_t)offs[nb] * 512u, K_BIT);
-        } else if (k == BMX_GAP) {
-            uint64_t o = offs[nb];
-            if (o >= gap_words || o + (gap_slab[o] >> 3) + 1u > gap_words) { bmx_vec_free(ctx, v); return BMX_ERR_RANGE; }
-            desc[nb] = DESC_MAKE(v->d_gaps + o, K_GAP);
-        } else desc[nb] = DESC_MAKE(0, k);
+        if (k == BMX_BIT) desc[nb] = DESC_MAKE(v->d_bits + (size_t)offs[nb] * 512u, K_BIT);
+        else if (k == BMX_GAP) desc[nb] = DESC_MAKE(v->d_gaps + goff[nb], K_GAP);
+        else desc[nb] = DESC_MAKE(0, k);
     }
     HIPCHK(hipMemcpyAsync(v->d_desc, desc.data(), (size_t)nblocks * 8, hipMemcpyHostToDevice, ctx->stream));
     if (n_bit_blocks) HIPCHK(hipMemcpyAsync(v->d_bits, bit_slab, (size_t)n_bit_blocks * 8192, hipMemcpyHostToDevice, ctx->stream));
-    if (gap_words) HIPCHK(hipMemcpyAsync(v->d_gaps, gap_slab, (size_t)gap_words * 2, hipMemcpyHostToDevice, ctx->stream));
+    if (!gpad.empty()) HIPCHK(hipMemcpyAsync(v->d_gaps, gpad.data(), gpad.size() * 2, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     *out = v;
     return BMX_OK;
@@ -644,7 +654,7 @@ static int result_finish(bmx_ctx* ctx, bmx_vec* v, BlockStat* st, u32* offs)
     uint64_t gap_words = ctx->h_small[1];
     for (int k = 0; k < 4; ++k) v->counts[k] = (uint32_t)ctx->h_small[2 + k];
     if (gap_words) {
-        size_t b_gaps = (size_t)gap_words * 2;
+        size_t b_gaps = (size_t)gap_words * 2 + 64;      // + guard, see vec_alloc_device
         if ((rc = dmalloc(ctx, (void**)&v->d_gaps, b_gaps))) return rc;
         v->bytes += std::max<size_t>(b_gaps, 16);
         v->gap_words = gap_words;
@@ -705,7 +715,7 @@ int bmx_agg_or(bmx_ctx* ctx, const bmx_vec* const* src, size_t n, bmx_vec** resu
     ARGCHK(ctx && result && (n == 0 || src) && n <= 65535);
     *result = nullptr;
     int rc = set_dev(ctx); if (rc) return rc;
-    uint32_t ncols = 0; uint64_t nbits = 0; bool has_gap = false;
+    uint32_t ncols = 0; uint64_t nbits = 0; bool has_gap = false, has_bit = false;
     std::vector<const u64*> descs(std::max<size_t>(n, 1), nullptr);
     std::vector<u32> nblk(std::max<size_t>(n, 1), 0);
     for (size_t i = 0; i < n; ++i) {
@@ -713,10 +723,31 @@ int bmx_agg_or(bmx_ctx* ctx, const bmx_vec* const* src, size_t n, bmx_vec** resu
         descs[i] = src[i]->d_desc; nblk[i] = src[i]->nblocks;
         ncols = std::max(ncols, src[i]->nblocks); nbits = std::max(nbits, src[i]->nbits);
         has_gap |= src[i]->counts[BMX_GAP] != 0;
+        has_bit |= src[i]->counts[BMX_BIT] != 0;
     }
     bmx_vec* v; BlockStat* st; u32* offs;
     if ((rc = result_begin(ctx, nbits, ncols, &v, &st, &offs))) return rc;      // empty list => cleared target (:1105)
-    if (n && ncols) {
+    if (n >= 64 && ncols && has_gap && !has_bit) {
+        // many GAP-only operands: column-tile kernel straight from the descriptor tables (no sort pass)
+        void* d_descs = nullptr; void* d_nblk = nullptr;
+        hipError_t e = hipMalloc(&d_descs, n * 8);
+        if (e == hipSuccess) e = hipMalloc(&d_nblk, n * 4);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_descs, descs.data(), n * 8, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_nblk, nblk.data(), n * 4, hipMemcpyHostToDevice, ctx->stream);
+        size_t lds = (size_t)OR_TILE * 8192 + OR_TILE * 4;
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_agg_or_gap_tiled), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_agg_or_gap_tiled, dim3((ncols + OR_TILE - 1) / OR_TILE), dim3(1024), lds, ctx->stream,
+                               (const u64* const*)d_descs, (const u32*)d_nblk, (u32)n, ncols, 0, v->d_bits, v->d_desc, st);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) rc = result_finish(ctx, v, st, offs);
+        else rc = fail_hip(e, "bmx_agg_or (tiled)", __LINE__);
+        (void)hipStreamSynchronize(ctx->stream);
+        if (d_descs) (void)hipFree(d_descs);
+        if (d_nblk) (void)hipFree(d_nblk);
+        if (rc) { bmx_vec_free(ctx, v); return rc; }
+    } else if (n && ncols) {
         void* d_descs = nullptr; void* d_nblk = nullptr; void* d_dmat = nullptr;
         size_t b_dmat = (size_t)ncols * (n + 2) * 8;
         hipError_t e = hipMalloc(&d_descs, n * 8);

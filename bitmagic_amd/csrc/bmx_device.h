@@ -239,6 +239,145 @@ __device__ __forceinline__ void gap_decode(gcptr16 g, u32* lds, Blk& out, u32 la
     __builtin_amdgcn_wave_barrier();
 }
 
+// ---------------------------------------------------------------------------
+// Applying a GAP operand to an accumulator block held in LDS (2048 u32 per wave):
+// the run-parallel twin of gap_add_to_bitset / gap_and_to_bitset / gap_sub_to_bitset
+// (src/bmfunc.h:4796,4847,4669 with or_bit_block / sub_bit_block :4520,4568).
+//   GAP_OR : set the 1-runs        GAP_AND : clear the 0-runs      GAP_SUB : clear the 1-runs
+// First / last word of a run go through ds atomics (several lanes may touch one
+// word), whole words in between are plain stores (all writers store the same value).
+// Cost follows the run list (2 B per run end read, ~2 LDS ops per run) instead of the
+// fixed ~600 instructions of gap_decode -- what makes thousands of sparse GAP
+// operands per column (BASELINE configs[4]) affordable.
+// ---------------------------------------------------------------------------
+enum { GAP_OR = 0, GAP_AND = 1, GAP_SUB = 2 };
+
+template <int MODE>
+__device__ __forceinline__ void lds_apply_edge(u32* lds, u32 w, u32 mask)
+{
+    if constexpr (MODE == GAP_OR) atomicOr(&lds[w], mask); else atomicAnd(&lds[w], ~mask);
+}
+
+// one run [s, e] (inclusive bit positions); words strictly inside are returned for the caller to fill
+template <int MODE>
+__device__ __forceinline__ void lds_apply_run_edges(u32* lds, u32 s, u32 e)
+{
+    u32 wl = s >> 5, wr = e >> 5;
+    u32 ml = ~0u << (s & 31u), mr = ~0u >> (31u - (e & 31u));
+    if (wl == wr) lds_apply_edge<MODE>(lds, wl, ml & mr);
+    else { lds_apply_edge<MODE>(lds, wl, ml); lds_apply_edge<MODE>(lds, wr, mr); }
+}
+
+// wave-parallel over the runs of ONE operand: lane j takes every 64th run of the wanted polarity
+template <int MODE>
+__device__ __forceinline__ void gap_apply_lds_wave(gcptr16 g, u32* lds, u32 lane)
+{
+    const u32 fill = (MODE == GAP_OR) ? ~0u : 0u;
+    u32 hdr = g[0];
+    u32 len = hdr >> 3, sbit = hdr & 1u;
+    const u32 want = (MODE == GAP_AND) ? 0u : 1u;
+    u32 k0 = (sbit == want) ? 1u : 2u;                 // first run (1-based) with the wanted value
+    for (u32 kb = k0; kb <= len; kb += 128u) {         // 64 runs of one polarity per step
+        u32 k = kb + 2u * lane;
+        bool act = k <= len;
+        u32 s = 0, e = 0;
+        if (act) { e = g[k]; s = (k == 1u) ? 0u : (u32)g[k - 1] + 1u; lds_apply_run_edges<MODE>(lds, s, e); }
+        u32 wl = s >> 5, wr = e >> 5;
+        u32 inner = (act && wr > wl + 1u) ? wr - wl - 1u : 0u;
+        // short interiors: each lane fills its own; long ones (> 16 words): the whole wave helps
+        if (inner && inner <= 16u) for (u32 w = wl + 1u; w < wr; ++w) lds[w] = fill;
+        u64 longm = __ballot(inner > 16u);
+        while (longm) {
+            u32 l = (u32)__builtin_ctzll(longm); longm &= longm - 1ull;
+            u32 a = __builtin_amdgcn_readlane(wl, l) + 1u, b = __builtin_amdgcn_readlane(wr, l);
+            for (u32 w = a + lane; w < b; w += 64u) lds[w] = fill;
+        }
+    }
+}
+
+// one lane walks the wanted runs of its own operand (64 operands per wave step): for many short operands.
+// The block is fetched 16 B (8 run ends) at a time -- GAP blocks are 16-B aligned in the slab -- with the
+// next chunk requested before the current one is processed: one memory round trip per 8 run ends.
+// Only runs of the wanted polarity are visited: with x_i the i-th dword of the block (lo16 = word 2i,
+// hi16 = word 2i+1), run 2i+1 is [lo(x_i)+1, hi(x_i)] (run 1 starts at 0) and run 2i+2 is
+// [hi(x_i)+1, lo(x_i+1)].
+template <int MODE>
+__device__ __forceinline__ void gap_apply_chunk(u32* lds, const u32 x[5], u32 c, u32 len, bool odd_runs)
+{
+    const u32 fill = (MODE == GAP_OR) ? ~0u : 0u;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        u32 k, s, e;
+        if (odd_runs) { k = 8u * c + 2u * i + 1u; s = (k == 1u) ? 0u : (x[i] & 0xFFFFu) + 1u; e = x[i] >> 16; }
+        else          { k = 8u * c + 2u * i + 2u; s = (x[i] >> 16) + 1u; e = x[i + 1] & 0xFFFFu; }
+        if (k <= len) {
+            lds_apply_run_edges<MODE>(lds, s, e);
+            for (u32 w = (s >> 5) + 1u; w < (e >> 5); ++w) lds[w] = fill;
+        }
+    }
+}
+
+// The first 64 bytes (31 run ends: every block of a sparse vector) are requested in ONE go, before the
+// header is known -- GAP slabs carry a 64-byte guard at their end for this -- so a short block costs a
+// single memory round trip; longer blocks continue 16 B at a time with one chunk of run-ahead.
+template <int MODE>
+__device__ __forceinline__ void gap_apply_lds_lane(gcptr16 g, u32* lds)
+{
+    const u32 want = (MODE == GAP_AND) ? 0u : 1u;
+    gcptr4 g4 = (gcptr4)(uintptr_t)g;
+    u32x4 c0 = g4[0], c1 = g4[1], c2 = g4[2], c3 = g4[3];
+    u32 hdr = c0.x & 0xFFFFu;
+    u32 len = hdr >> 3;
+    bool odd_runs = (hdr & 1u) == want;     // wanted runs are 1,3,5,.. (else 2,4,6,..)
+    u32 nchunks = (len + 8u) >> 3;          // ceil((len + 1) / 8)
+    { u32 x[5] = {c0.x, c0.y, c0.z, c0.w, c1.x}; gap_apply_chunk<MODE>(lds, x, 0, len, odd_runs); }
+    if (nchunks > 1u) { u32 x[5] = {c1.x, c1.y, c1.z, c1.w, c2.x}; gap_apply_chunk<MODE>(lds, x, 1, len, odd_runs); }
+    if (nchunks > 2u) { u32 x[5] = {c2.x, c2.y, c2.z, c2.w, c3.x}; gap_apply_chunk<MODE>(lds, x, 2, len, odd_runs); }
+    if (nchunks > 3u) {
+        u32x4 cur = c3;
+        for (u32 c = 3; c < nchunks; ++c) {
+            u32x4 nxt = (c + 1u < nchunks) ? g4[c + 1u] : cur;
+            u32 x[5] = {cur.x, cur.y, cur.z, cur.w, nxt.x};
+            gap_apply_chunk<MODE>(lds, x, c, len, odd_runs);
+            cur = nxt;
+        }
+    }
+}
+
+// apply n GAP operands (pointer list walked BACKWARDS from plist_back: row regions pack GAP
+// pointers from their end) to the wave's LDS accumulator
+template <int MODE>
+__device__ __forceinline__ void gap_apply_list(const u64* __restrict__ plist_back, u32 n, u32* lds, u32 lane)
+{
+    if (n >= 32u) {                                    // many operands: lane-per-operand, pointers one step ahead
+        u64 p = lane < n ? *(plist_back - lane) : 0ull;
+        for (u32 i = lane; i < n; i += 64u) {
+            u64 pn = i + 64u < n ? *(plist_back - (i + 64u)) : 0ull;
+            gap_apply_lds_lane<MODE>(as_gc16(p), lds);
+            p = pn;
+        }
+    } else {
+        for (u32 i = 0; i < n; ++i) gap_apply_lds_wave<MODE>(as_gc16(uniform64(*(plist_back - i))), lds, lane);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ void blk_to_lds(const Blk& b, u32* lds, u32 lane)
+{
+    u32x4* l4 = reinterpret_cast<u32x4*>(lds);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) l4[i * 64 + lane] = b.r[i];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ void blk_from_lds(Blk& b, const u32* lds, u32 lane)
+{
+    const u32x4* l4 = reinterpret_cast<const u32x4*>(lds);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) b.r[i] = l4[i * 64 + lane];
+}
+
 // popcount of a GAP block without expanding it (gap_bit_count_unr src/bmfunc.h:3107).
 // Returns the lane-local partial; caller wave_sum()s.
 __device__ __forceinline__ u32 gap_lane_popcount(gcptr16 g, u32 lane)

@@ -61,7 +61,8 @@ void k_block_stats(const uint4* __restrict__ raw, u32 nblocks, int optimize, Blo
 }
 
 // step 2: exclusive scan of storage sizes (single workgroup; nblocks <= 2^20)
-// offs[nb] = bit-block ordinal or GAP u16-word offset; totals[0]=n_bit, [1]=gap_words,
+// offs[nb] = bit-block ordinal or GAP u16-word offset (multiple of 8: every GAP block starts on a
+// 16-byte boundary so a lane can fetch it with dwordx4 loads); totals[0]=n_bit, [1]=gap_words,
 // totals[2..5] = blocks per kind
 __global__ __launch_bounds__(1024)
 void k_scan_layout(const BlockStat* __restrict__ st, u32 nblocks, u32* __restrict__ offs, u64* __restrict__ totals)
@@ -79,7 +80,7 @@ void k_scan_layout(const BlockStat* __restrict__ st, u32 nblocks, u32* __restric
         if (nb < nblocks) {
             kind = st[nb].kind;
             vb = kind == K_BIT;
-            vg = kind == K_GAP ? st[nb].runs + 1u : 0u;
+            vg = kind == K_GAP ? ((st[nb].runs + 1u + 7u) & ~7u) : 0u;   // GAP blocks start 16-B aligned in the slab
             atomicAdd(&kcnt[kind], 1u);
         }
         s_bit[tid] = vb; s_gap[tid] = vg;
@@ -300,16 +301,12 @@ void k_pipe_counts(const u64* __restrict__ dmat, const u32* __restrict__ row_off
     // bit-block operands: software-pipelined fold (bmx_device.h pipe_chain), AND group then SUB group
     if (pipe_chain<U, true, 0>(acc, pa, nba, lane)) return;
     if (pipe_chain<U, true, 1>(acc, ps, nbs, lane)) return;
-    // GAP operands (packed from the back of each region)
-    for (u32 i = 0; i < nga; ++i) {
-        Blk t; gap_decode(as_gc16(uniform64(pa[na - 1u - i])), lds, t, lane);
-        blk_and(acc, t);
-        if (blk_is_zero(acc)) return;
-    }
-    for (u32 i = 0; i < ngs; ++i) {
-        Blk t; gap_decode(as_gc16(uniform64(ps[ns - 1u - i])), lds, t, lane);
-        blk_andn(acc, t);
-        if (blk_is_zero(acc)) return;
+    // GAP operands (packed from the back of each region): applied run-by-run to the accumulator in LDS
+    if (nga | ngs) {
+        blk_to_lds(acc, lds, lane);
+        if (nga) gap_apply_list<GAP_AND>(pa + na - 1u, nga, lds, lane);
+        if (ngs) gap_apply_list<GAP_SUB>(ps + ns - 1u, ngs, lds, lane);
+        blk_from_lds(acc, lds, lane);
     }
     u32 cnt = wave_sum(blk_lane_popcount(acc));
     if (lane == 0 && cnt) atomicAdd(reinterpret_cast<unsigned long long*>(&counts[g]), (unsigned long long)cnt);

@@ -195,12 +195,65 @@ void k_agg_or(const u64* __restrict__ dmat, u32 n, u32 ncols, int opt_compress, 
     Blk acc;
     blk_fill(acc, 0u);
     if (pipe_chain<U, true, 2>(acc, p, nbit, lane)) { store_trivial(K_FULL, c, desc, st, lane); return; }   // saturated (:1951)
-    u32* lds = lds_dyn + wave * 2048u;
-    for (u32 i = 0; i < ngap; ++i) {
-        Blk t; gap_decode(as_gc16(uniform64(p[n - 1u - i])), lds, t, lane);
-        blk_or(acc, t);
+    if (ngap) {                                          // process_gap_blocks_or (:1808), run-parallel in LDS
+        u32* lds = lds_dyn + wave * 2048u;
+        blk_to_lds(acc, lds, lane);
+        gap_apply_list<GAP_OR>(p + n - 1u, ngap, lds, lane);
+        blk_from_lds(acc, lds, lane);
     }
     store_result(acc, c, opt_compress, slab, desc, st, lane);
+}
+
+// ---------------------------------------------------------------------------
+// combine_or over MANY GAP-only operands (BASELINE configs[4]: thousands of sparse
+// vectors).  Profiling the column-per-wave kernel on 4096 x 4e9-bit vectors showed
+// 94 % UTCL1 (TLB) misses: 64 lanes of a wave touched 64 different vectors = 64
+// different pages per load.  Here a 1024-thread workgroup owns a TILE of 16
+// consecutive block columns with 16 accumulators in LDS (128 KiB), and 16 adjacent
+// lanes read the 16 consecutive GAP blocks of ONE operand (contiguous in its slab,
+// descriptors contiguous too): 4 pages per wave load instead of 64, full cache
+// lines.  Operands come straight from the vectors' descriptor tables (no sort pass).
+// Requires: no operand holds a bit-block (checked on the host; FULL/NULL are fine).
+// ---------------------------------------------------------------------------
+#define OR_TILE 16u
+__global__ __launch_bounds__(1024)
+void k_agg_or_gap_tiled(const u64* const* __restrict__ descs, const u32* __restrict__ nblk, u32 n, u32 ncols,
+                        int opt_compress, uint4* __restrict__ slab, u64* __restrict__ desc, BlockStat* __restrict__ st)
+{
+    extern __shared__ u32 lds_dyn[];                 // OR_TILE x 2048 u32 accumulators + OR_TILE flags
+    u32* full = lds_dyn + OR_TILE * 2048u;
+    u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    u32 c0 = blockIdx.x * OR_TILE;
+    // zero the accumulators: 1024 threads x 128 B
+    u32x4* l4 = reinterpret_cast<u32x4*>(lds_dyn);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) l4[i * 1024 + tid] = (u32x4)(0u);
+    if (tid < OR_TILE) full[tid] = 0u;
+    __syncthreads();
+    u32 t = lane & (OR_TILE - 1u), grp = lane / OR_TILE;          // 4 operands per wave
+    u32 col = c0 + t;
+    u32 ops_per_step = (blockDim.x >> 6) * (64u / OR_TILE);
+    u32* acc = lds_dyn + t * 2048u;
+    u32 op = wave * (64u / OR_TILE) + grp;
+    u64 d = (op < n && col < ncols && col < nblk[op]) ? descs[op][col] : 0ull;
+    for (; op < n; op += ops_per_step) {
+        u32 opn = op + ops_per_step;
+        u64 dn = (opn < n && col < ncols && col < nblk[opn]) ? descs[opn][col] : 0ull;   // one step ahead
+        u32 k = DESC_K(d);
+        if (k == K_GAP) gap_apply_lds_lane<GAP_OR>(as_gc16(DESC_P(d)), acc);
+        else if (k == K_FULL) full[t] = 1u;
+        d = dn;
+    }
+    __syncthreads();
+    // one wave per column of the tile: classify + store (opt_copy_bit_block rule)
+    for (u32 tc = wave; tc < OR_TILE; tc += (blockDim.x >> 6)) {
+        u32 c = c0 + tc;
+        if (c >= ncols) break;
+        if (full[tc]) { store_trivial(K_FULL, c, desc, st, lane); continue; }
+        Blk b;
+        blk_from_lds(b, lds_dyn + tc * 2048u, lane);
+        store_result(b, c, opt_compress, slab, desc, st, lane);
+    }
 }
 
 // aggregator::combine_and_sub(target, ...)  src/bmaggregator.h:1162 with result
@@ -231,13 +284,12 @@ void k_agg_and_sub(const u64* __restrict__ dmat, const u32* __restrict__ and_n_p
     blk_fill(acc, ~0u);
     bool zero = pipe_chain<U, true, 0>(acc, pa, nba, lane);
     if (!zero) zero = pipe_chain<U, true, 1>(acc, ps, nbs, lane);
-    for (u32 i = 0; i < nga && !zero; ++i) {
-        Blk t; gap_decode(as_gc16(uniform64(pa[na - 1u - i])), lds, t, lane);
-        blk_and(acc, t); zero = blk_is_zero(acc);
-    }
-    for (u32 i = 0; i < ngs && !zero; ++i) {
-        Blk t; gap_decode(as_gc16(uniform64(ps[ns - 1u - i])), lds, t, lane);
-        blk_andn(acc, t); zero = blk_is_zero(acc);
+    if (!zero && (nga | ngs)) {
+        blk_to_lds(acc, lds, lane);
+        if (nga) gap_apply_list<GAP_AND>(pa + na - 1u, nga, lds, lane);
+        if (ngs) gap_apply_list<GAP_SUB>(ps + ns - 1u, ngs, lds, lane);
+        blk_from_lds(acc, lds, lane);
+        zero = blk_is_zero(acc);
     }
     if (zero) { store_trivial(K_NULL, c, desc, st, lane); return; }
     store_result(acc, c, opt_compress, slab, desc, st, lane);

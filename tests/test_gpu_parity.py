@@ -349,3 +349,32 @@ def test_launch_shape_knobs_do_not_change_results(ctx, port):
         assert (t.to_words(14 * 2048) == e.to_words(14 * 2048)).all()
         o = agg.combine_or([gv[i] for i in a + s])
         assert (o.to_words(14 * 2048) == port.agg_or([pv[i] for i in a + s]).to_words(14 * 2048)).all()
+
+
+@pytest.mark.parametrize("dq,nvec", [(13, 200), (60, 96), (65500, 70), (300, 33)])
+def test_many_gap_operands(ctx, port, dq, nvec):
+    """BASELINE configs[4] shape at test scale: combine_or / combine_and_sub / counts pipeline over many GAP
+    operands per block column (lane-per-operand run scatter, >= 32 operands) incl. dense GAP (long 1-runs)"""
+    nbits = 5 * 65536 + 4000
+    words = [port.gen_words(31337, v, dq, nbits) for v in range(nvec)]
+    words[3][2048:4096] = 0                                   # NULL block in one operand
+    if dq > 60000:
+        words[5][0:2048] = 0xFFFFFFFF                         # FULL block
+    gv = [bm.bit_import_u32(ctx, w, True) for w in words]
+    pv = [port.import_words(w, True, w.size * 32) for w in words]
+    assert gv[0].calc_stat()["gap_blocks"] > 0
+    agg = bm.aggregator(ctx)
+    nwb = 6 * 2048
+    o = agg.combine_or(gv)
+    assert (o.to_words(nwb) == port.agg_or(pv).to_words(nwb)).all()
+    for a, s in [(list(range(nvec)), []), ([0, 1], list(range(2, nvec))), (list(range(0, nvec, 2)), list(range(1, nvec, 2))),
+                 ([5], list(range(6, min(nvec, 6 + 40))))]:
+        t, _ = agg.combine_and_sub([gv[i] for i in a], [gv[i] for i in s])
+        e = port.agg_and_sub([pv[i] for i in a], [pv[i] for i in s])
+        assert (t.to_words(nwb) == e.to_words(nwb)).all(), (len(a), len(s))
+        pipe = bm.aggregator.pipeline(ctx)
+        ag = pipe.add()
+        for i in a: ag.add(gv[i], 0)
+        for i in s: ag.add(gv[i], 1)
+        pipe.complete()
+        assert int(agg.combine_and_sub(pipe)[0]) == e.count()
