@@ -82,6 +82,9 @@ class context:
     def set_tuning(self, key: str, value: int):
         check(lib().bmx_ctx_set_tuning(self._h, key.encode(), int(value)))
 
+    def trim(self):
+        check(lib().bmx_ctx_trim(self._h))
+
     def mem_used(self) -> int:
         b = C.c_uint64()
         check(lib().bmx_ctx_mem_used(self._h, C.byref(b)))

@@ -51,6 +51,7 @@ def lib() -> C.CDLL:
         "bmx_ctx_synchronize": (i32, [vp]),
         "bmx_ctx_set_tuning": (i32, [vp, C.c_char_p, i32]),
         "bmx_ctx_mem_used": (i32, [vp, P(u64)]),
+        "bmx_ctx_trim": (i32, [vp]),
         "bmx_vec_upload": (i32, [vp, u64, u32, vp, vp, vp, u32, vp, u64, P(vp)]),
         "bmx_vec_import_bits": (i32, [vp, vp, u64, i32, P(vp)]),
         "bmx_vec_generate": (i32, [vp, u64, u32, i32, u32, u64, i32, P(vp)]),
@@ -61,6 +62,7 @@ def lib() -> C.CDLL:
         "bmx_count": (i32, [vp, vp, P(u64)]),
         "bmx_op2": (i32, [vp, i32, vp, vp, i32, P(vp)]),
         "bmx_count_op2": (i32, [vp, i32, vp, vp, P(u64)]),
+        "bmx_count_op2_dev": (i32, [vp, i32, vp, vp, vp]),
         "bmx_agg_or": (i32, [vp, P(vp), C.c_size_t, P(vp)]),
         "bmx_agg_and_sub": (i32, [vp, P(vp), C.c_size_t, P(vp), C.c_size_t, P(vp), P(i32)]),
         "bmx_pipeline_create": (i32, [vp, P(vp), P(u32), P(vp), P(u32), C.c_size_t, P(vp)]),

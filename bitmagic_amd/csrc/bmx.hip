@@ -8,7 +8,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <map>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 // ---------------------------------------------------------------------------
@@ -37,7 +39,13 @@ struct bmx_ctx {
     void* scratch = nullptr; size_t scratch_bytes = 0;      // raw block slab for import/generate
     void* aux = nullptr; size_t aux_bytes = 0;              // stats / offsets / totals
     u64* d_small = nullptr;                                 // 64 x u64 result words
+    u64* d_slots = nullptr;                                 // COUNT_SLOTS striped count accumulators (kept zero between launches)
     u64* h_small = nullptr;                                 // pinned mirror
+    // caching device allocator: results of same-shaped operations re-use their blocks instead of
+    // paying hipMalloc / hipFree (which synchronises the device) on every call
+    std::multimap<size_t, void*> pool_free;
+    std::unordered_map<void*, size_t> pool_live;
+    uint64_t pool_cached = 0, pool_cap = 16ull << 30;
     int pipe_unroll = 4;       // operand blocks per batch (two batches in flight in the v2 kernel)
     int pipe_rows = 8;         // register rows per work item (8 = whole block, 4/2/1 = slices)
     int pipe_nt = 1;           // non-temporal operand loads (+4.5 % on the streamed-once headline case)
@@ -73,15 +81,55 @@ struct bmx_rs {
 
 static int set_dev(const bmx_ctx* ctx) { HIPCHK(hipSetDevice(ctx->device)); return BMX_OK; }
 
+static size_t pool_round(size_t bytes)
+{
+    if (bytes < 256) bytes = 256;
+    size_t g = bytes >= (2u << 20) ? (2u << 20) : (bytes >= (64u << 10) ? (64u << 10) : 256u);
+    return (bytes + g - 1) / g * g;
+}
+
 static int dmalloc(bmx_ctx* ctx, void** p, size_t bytes)
 {
     *p = nullptr;
-    if (!bytes) bytes = 16;
-    HIPCHK(hipMalloc(p, bytes));
-    ctx->mem_used += bytes;
+    size_t sz = pool_round(bytes);
+    auto it = ctx->pool_free.lower_bound(sz);
+    if (it != ctx->pool_free.end() && it->first <= sz + sz / 4) {          // best fit within 25 % slack
+        *p = it->second; sz = it->first;
+        ctx->pool_cached -= sz;
+        ctx->pool_free.erase(it);
+    } else {
+        hipError_t e = hipMalloc(p, sz);
+        if (e == hipErrorOutOfMemory && !ctx->pool_free.empty()) {          // give the cache back and retry
+            (void)hipGetLastError();
+            for (auto& kv : ctx->pool_free) (void)hipFree(kv.second);
+            ctx->pool_free.clear(); ctx->pool_cached = 0;
+            e = hipMalloc(p, sz);
+        }
+        if (e != hipSuccess) return fail_hip(e, "hipMalloc", __LINE__);
+    }
+    ctx->pool_live[*p] = sz;
+    ctx->mem_used += sz;
     return BMX_OK;
 }
-static void dfree(bmx_ctx* ctx, void* p, size_t bytes) { if (p) { (void)hipFree(p); ctx->mem_used -= std::min<uint64_t>(ctx->mem_used, bytes ? bytes : 16); } }
+
+// the caller guarantees no kernel still uses p (handles are freed after a stream synchronise)
+static void dfree(bmx_ctx* ctx, void* p)
+{
+    if (!p) return;
+    auto it = ctx->pool_live.find(p);
+    if (it == ctx->pool_live.end()) { (void)hipFree(p); return; }
+    size_t sz = it->second;
+    ctx->pool_live.erase(it);
+    ctx->mem_used -= std::min<uint64_t>(ctx->mem_used, sz);
+    if (ctx->pool_cached + sz <= ctx->pool_cap) { ctx->pool_free.emplace(sz, p); ctx->pool_cached += sz; }
+    else (void)hipFree(p);
+}
+
+static void pool_trim(bmx_ctx* ctx)
+{
+    for (auto& kv : ctx->pool_free) (void)hipFree(kv.second);
+    ctx->pool_free.clear(); ctx->pool_cached = 0;
+}
 
 static int ensure(bmx_ctx* ctx, void** buf, size_t* cur, size_t need)
 {
@@ -133,6 +181,9 @@ int bmx_ctx_create(int device, void* stream, bmx_ctx** out)
     HIPCHK(hipEventCreate(&ctx->ev1));
     HIPCHK(hipMalloc((void**)&ctx->d_small, 64 * sizeof(u64)));
     HIPCHK(hipHostMalloc((void**)&ctx->h_small, 64 * sizeof(u64)));
+    HIPCHK(hipMalloc((void**)&ctx->d_slots, COUNT_SLOTS * COUNT_SLOT_STRIDE * sizeof(u64)));
+    HIPCHK(hipMemsetAsync(ctx->d_slots, 0, COUNT_SLOTS * COUNT_SLOT_STRIDE * sizeof(u64), ctx->stream));
+    if (const char* e = getenv("BMX_POOL_MAX_MB")) ctx->pool_cap = (uint64_t)atoll(e) << 20;
     if (const char* e = getenv("BMX_PIPE_UNROLL")) ctx->pipe_unroll = atoi(e);
     if (const char* e = getenv("BMX_PIPE_ROWS")) ctx->pipe_rows = atoi(e);
     if (const char* e = getenv("BMX_PIPE_NT")) ctx->pipe_nt = atoi(e);
@@ -148,9 +199,11 @@ int bmx_ctx_destroy(bmx_ctx* ctx)
     if (!ctx) return BMX_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    pool_trim(ctx);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->aux) (void)hipFree(ctx->aux);
     if (ctx->d_small) (void)hipFree(ctx->d_small);
+    if (ctx->d_slots) (void)hipFree(ctx->d_slots);
     if (ctx->h_small) (void)hipHostFree(ctx->h_small);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -205,6 +258,15 @@ int bmx_ctx_synchronize(bmx_ctx* ctx)
     return BMX_OK;
 }
 
+int bmx_ctx_trim(bmx_ctx* ctx)
+{
+    ARGCHK(ctx);
+    int rc = set_dev(ctx); if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    pool_trim(ctx);
+    return BMX_OK;
+}
+
 int bmx_ctx_mem_used(const bmx_ctx* ctx, uint64_t* bytes)
 {
     ARGCHK(ctx && bytes);
@@ -254,10 +316,7 @@ int bmx_vec_free(bmx_ctx* ctx, bmx_vec* v)
     ARGCHK(ctx && v->ctx == ctx);
     int rc = set_dev(ctx); if (rc) return rc;
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    if (v->d_desc) (void)hipFree(v->d_desc);
-    if (v->d_bits) (void)hipFree(v->d_bits);
-    if (v->d_gaps) (void)hipFree(v->d_gaps);
-    ctx->mem_used -= std::min<uint64_t>(ctx->mem_used, v->bytes);
+    dfree(ctx, v->d_desc); dfree(ctx, v->d_bits); dfree(ctx, v->d_gaps);
     delete v;
     return BMX_OK;
 }
@@ -431,11 +490,12 @@ int bmx_count(bmx_ctx* ctx, const bmx_vec* a, uint64_t* count)
 {
     ARGCHK(ctx && a && count && a->ctx == ctx);
     int rc = set_dev(ctx); if (rc) return rc;
-    HIPCHK(hipMemsetAsync(ctx->d_small, 0, 8, ctx->stream));
     if (a->nblocks) {
-        hipLaunchKernelGGL(k_vec_count, dim3((a->nblocks + 3) / 4), dim3(256), 0, ctx->stream, a->d_desc, a->nblocks, ctx->d_small);
+        hipLaunchKernelGGL(k_vec_count, dim3((a->nblocks + 3) / 4), dim3(256), 0, ctx->stream, a->d_desc, a->nblocks, ctx->d_slots);
         KCHK();
     }
+    hipLaunchKernelGGL(k_sum_slots, dim3(1), dim3(64), 0, ctx->stream, ctx->d_slots, ctx->d_small);
+    KCHK();
     HIPCHK(hipMemcpyAsync(ctx->h_small, ctx->d_small, 8, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     *count = ctx->h_small[0];
@@ -513,10 +573,7 @@ int bmx_pipeline_destroy(bmx_ctx* ctx, bmx_pipeline* p)
     ARGCHK(ctx && p->ctx == ctx);
     int rc = set_dev(ctx); if (rc) return rc;
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    if (p->d_dmat) (void)hipFree(p->d_dmat);
-    if (p->d_meta) (void)hipFree(p->d_meta);
-    if (p->d_descs) (void)hipFree((void*)p->d_descs);
-    ctx->mem_used -= std::min<uint64_t>(ctx->mem_used, p->bytes);
+    dfree(ctx, p->d_dmat); dfree(ctx, p->d_meta); dfree(ctx, (void*)p->d_descs);
     delete p;
     return BMX_OK;
 }
@@ -589,14 +646,14 @@ int bmx_pipeline_run_counts(bmx_ctx* ctx, bmx_pipeline* p, uint32_t nb_from, uin
     u64* d_counts = nullptr;
     size_t bytes = (size_t)p->ngroups * 8;
     if (p->ngroups <= 64) d_counts = ctx->d_small;
-    else HIPCHK(hipMalloc((void**)&d_counts, bytes));
+    else if ((rc = dmalloc(ctx, (void**)&d_counts, bytes))) return rc;
     rc = bmx_pipeline_run_counts_dev(ctx, p, nb_from, nb_to, d_counts);
     if (!rc) {
         hipError_t e = hipMemcpyAsync(counts_out, d_counts, bytes, hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) rc = fail_hip(e, "counts readback", __LINE__);
     }
-    if (p->ngroups > 64) (void)hipFree(d_counts);
+    if (p->ngroups > 64) dfree(ctx, d_counts);
     return rc;
 }
 
@@ -664,9 +721,7 @@ static int result_finish(bmx_ctx* ctx, bmx_vec* v, BlockStat* st, u32* offs)
         HIPCHK(hipStreamSynchronize(ctx->stream));
     }
     if (v->counts[BMX_BIT] == 0) {            // nothing lives in the slab: give it back
-        size_t b_bits = std::max<size_t>((size_t)v->n_bit * 8192, 16);
-        (void)hipFree(v->d_bits); v->d_bits = nullptr;
-        ctx->mem_used -= std::min<uint64_t>(ctx->mem_used, b_bits); v->bytes -= b_bits; v->n_bit = 0;
+        dfree(ctx, v->d_bits); v->d_bits = nullptr; v->n_bit = 0;
     }
     return BMX_OK;
 }
@@ -693,17 +748,26 @@ int bmx_op2(bmx_ctx* ctx, int op, const bmx_vec* a, const bmx_vec* b, int opt_co
     return BMX_OK;
 }
 
-int bmx_count_op2(bmx_ctx* ctx, int op, const bmx_vec* a, const bmx_vec* b, uint64_t* count)
+int bmx_count_op2_dev(bmx_ctx* ctx, int op, const bmx_vec* a, const bmx_vec* b, uint64_t* d_count)
 {
-    ARGCHK(ctx && a && b && count && a->ctx == ctx && b->ctx == ctx && op >= BMX_AND && op <= BMX_SUB);
+    ARGCHK(ctx && a && b && d_count && a->ctx == ctx && b->ctx == ctx && op >= BMX_AND && op <= BMX_SUB);
     int rc = set_dev(ctx); if (rc) return rc;
     uint32_t nblocks = std::max(a->nblocks, b->nblocks);
-    HIPCHK(hipMemsetAsync(ctx->d_small, 0, 8, ctx->stream));
     if (nblocks) {
         hipLaunchKernelGGL(k_count_op2, dim3((nblocks + 3) / 4), dim3(256), 0, ctx->stream, op,
-                           a->d_desc, a->nblocks, b->d_desc, b->nblocks, nblocks, ctx->d_small);
+                           a->d_desc, a->nblocks, b->d_desc, b->nblocks, nblocks, ctx->d_slots);
         KCHK();
     }
+    hipLaunchKernelGGL(k_sum_slots, dim3(1), dim3(64), 0, ctx->stream, ctx->d_slots, (u64*)d_count);
+    KCHK();
+    return BMX_OK;
+}
+
+int bmx_count_op2(bmx_ctx* ctx, int op, const bmx_vec* a, const bmx_vec* b, uint64_t* count)
+{
+    ARGCHK(ctx && count);
+    int rc = bmx_count_op2_dev(ctx, op, a, b, ctx->d_small);
+    if (rc) return rc;
     HIPCHK(hipMemcpyAsync(ctx->h_small, ctx->d_small, 8, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     *count = ctx->h_small[0];
@@ -730,9 +794,8 @@ int bmx_agg_or(bmx_ctx* ctx, const bmx_vec* const* src, size_t n, bmx_vec** resu
     if (n >= 64 && ncols && has_gap && !has_bit) {
         // many GAP-only operands: column-tile kernel straight from the descriptor tables (no sort pass)
         void* d_descs = nullptr; void* d_nblk = nullptr;
-        hipError_t e = hipMalloc(&d_descs, n * 8);
-        if (e == hipSuccess) e = hipMalloc(&d_nblk, n * 4);
-        if (e == hipSuccess) e = hipMemcpyAsync(d_descs, descs.data(), n * 8, hipMemcpyHostToDevice, ctx->stream);
+        if ((rc = dmalloc(ctx, &d_descs, n * 8)) || (rc = dmalloc(ctx, &d_nblk, n * 4))) { dfree(ctx, d_descs); bmx_vec_free(ctx, v); return rc; }
+        hipError_t e = hipMemcpyAsync(d_descs, descs.data(), n * 8, hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(d_nblk, nblk.data(), n * 4, hipMemcpyHostToDevice, ctx->stream);
         size_t lds = (size_t)OR_TILE * 8192 + OR_TILE * 4;
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_agg_or_gap_tiled), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -744,16 +807,15 @@ int bmx_agg_or(bmx_ctx* ctx, const bmx_vec* const* src, size_t n, bmx_vec** resu
         if (e == hipSuccess) rc = result_finish(ctx, v, st, offs);
         else rc = fail_hip(e, "bmx_agg_or (tiled)", __LINE__);
         (void)hipStreamSynchronize(ctx->stream);
-        if (d_descs) (void)hipFree(d_descs);
-        if (d_nblk) (void)hipFree(d_nblk);
+        dfree(ctx, d_descs); dfree(ctx, d_nblk);
         if (rc) { bmx_vec_free(ctx, v); return rc; }
     } else if (n && ncols) {
         void* d_descs = nullptr; void* d_nblk = nullptr; void* d_dmat = nullptr;
         size_t b_dmat = (size_t)ncols * (n + 2) * 8;
-        hipError_t e = hipMalloc(&d_descs, n * 8);
-        if (e == hipSuccess) e = hipMalloc(&d_nblk, n * 4);
-        if (e == hipSuccess) e = hipMalloc(&d_dmat, b_dmat);
-        if (e == hipSuccess) e = hipMemcpyAsync(d_descs, descs.data(), n * 8, hipMemcpyHostToDevice, ctx->stream);
+        if ((rc = dmalloc(ctx, &d_descs, n * 8)) || (rc = dmalloc(ctx, &d_nblk, n * 4)) || (rc = dmalloc(ctx, &d_dmat, b_dmat))) {
+            dfree(ctx, d_descs); dfree(ctx, d_nblk); bmx_vec_free(ctx, v); return rc;
+        }
+        hipError_t e = hipMemcpyAsync(d_descs, descs.data(), n * 8, hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(d_nblk, nblk.data(), n * 4, hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess) {
             hipLaunchKernelGGL(k_or_sort, dim3((ncols + 255) / 256), dim3(256), 0, ctx->stream,
@@ -767,9 +829,7 @@ int bmx_agg_or(bmx_ctx* ctx, const bmx_vec* const* src, size_t n, bmx_vec** resu
         if (e == hipSuccess) rc = result_finish(ctx, v, st, offs);
         else rc = fail_hip(e, "bmx_agg_or", __LINE__);
         (void)hipStreamSynchronize(ctx->stream);
-        if (d_descs) (void)hipFree(d_descs);
-        if (d_nblk) (void)hipFree(d_nblk);
-        if (d_dmat) (void)hipFree(d_dmat);
+        dfree(ctx, d_descs); dfree(ctx, d_nblk); dfree(ctx, d_dmat);
         if (rc) { bmx_vec_free(ctx, v); return rc; }
     } else if (ncols) {
         HIPCHK(hipMemsetAsync(v->d_desc, 0, (size_t)ncols * 8, ctx->stream));
@@ -856,11 +916,7 @@ int bmx_rs_free(bmx_ctx* ctx, bmx_rs* rs)
     ARGCHK(ctx && rs->ctx == ctx);
     int rc = set_dev(ctx); if (rc) return rc;
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    if (rs->d_bcount) (void)hipFree(rs->d_bcount);
-    if (rs->d_sub) (void)hipFree(rs->d_sub);
-    if (rs->d_rcount) (void)hipFree(rs->d_rcount);
-    if (rs->d_cum) (void)hipFree(rs->d_cum);
-    ctx->mem_used -= std::min<uint64_t>(ctx->mem_used, rs->bytes);
+    dfree(ctx, rs->d_bcount); dfree(ctx, rs->d_sub); dfree(ctx, rs->d_rcount); dfree(ctx, rs->d_cum);
     delete rs;
     return BMX_OK;
 }
@@ -908,14 +964,14 @@ int bmx_rank_batch(bmx_ctx* ctx, const bmx_vec* v, const bmx_rs* rs, const uint6
     int rc = set_dev(ctx); if (rc) return rc;
     if (!q) return BMX_OK;
     u64* d = nullptr;
-    HIPCHK(hipMalloc((void**)&d, q * 16));
+    if ((rc = dmalloc(ctx, (void**)&d, q * 16))) return rc;
     hipError_t e = hipMemcpyAsync(d, n, q * 8, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) {
         rc = bmx_rank_batch_dev(ctx, v, rs, d, q, d + q);
         if (!rc) e = hipMemcpyAsync(out, d + q, q * 8, hipMemcpyDeviceToHost, ctx->stream);
     }
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    (void)hipFree(d);
+    dfree(ctx, d);
     if (e != hipSuccess) return fail_hip(e, "bmx_rank_batch", __LINE__);
     return rc;
 }
@@ -927,7 +983,7 @@ int bmx_select_batch(bmx_ctx* ctx, const bmx_vec* v, const bmx_rs* rs, const uin
     int rc = set_dev(ctx); if (rc) return rc;
     if (!q) return BMX_OK;
     u64* d = nullptr;
-    HIPCHK(hipMalloc((void**)&d, q * 17));
+    if ((rc = dmalloc(ctx, (void**)&d, q * 17))) return rc;
     hipError_t e = hipMemcpyAsync(d, rank, q * 8, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) {
         rc = bmx_select_batch_dev(ctx, v, rs, d, q, d + q, (uint8_t*)(d + 2 * q));
@@ -935,7 +991,7 @@ int bmx_select_batch(bmx_ctx* ctx, const bmx_vec* v, const bmx_rs* rs, const uin
         if (!rc && e == hipSuccess) e = hipMemcpyAsync(found, d + 2 * q, q, hipMemcpyDeviceToHost, ctx->stream);
     }
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    (void)hipFree(d);
+    dfree(ctx, d);
     if (e != hipSuccess) return fail_hip(e, "bmx_select_batch", __LINE__);
     return rc;
 }

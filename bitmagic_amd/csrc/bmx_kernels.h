@@ -64,40 +64,65 @@ void k_block_stats(const uint4* __restrict__ raw, u32 nblocks, int optimize, Blo
 // offs[nb] = bit-block ordinal or GAP u16-word offset (multiple of 8: every GAP block starts on a
 // 16-byte boundary so a lane can fetch it with dwordx4 loads); totals[0]=n_bit, [1]=gap_words,
 // totals[2..5] = blocks per kind
+// Each thread owns SCAN_PER consecutive blocks (serial prefix in registers), the 1024 partials are
+// scanned with wave shuffles + one LDS hop: 16,384 blocks per pass and 2 barriers per pass.
+#define SCAN_PER 16u
+__device__ __forceinline__ void wg_scan2_excl(u32& a, u32& b, u32* sm /* 2 x 16 */, u32 tid, u32& tot_a, u32& tot_b)
+{
+    // exclusive scan of (a, b) over 1024 threads; tot_* = sums over the workgroup
+    u32 lane = tid & 63u, w = tid >> 6;
+    u32 ia = wave_scan_incl(a, lane), ib = wave_scan_incl(b, lane);
+    if (lane == 63u) { sm[w] = ia; sm[16 + w] = ib; }
+    __syncthreads();
+    u32 oa = 0, ob = 0, ta = 0, tb = 0;
+#pragma unroll
+    for (u32 i = 0; i < 16; ++i) { u32 x = sm[i], y = sm[16 + i]; if (i < w) { oa += x; ob += y; } ta += x; tb += y; }
+    __syncthreads();
+    a = oa + ia - a; b = ob + ib - b; tot_a = ta; tot_b = tb;
+}
+
 __global__ __launch_bounds__(1024)
 void k_scan_layout(const BlockStat* __restrict__ st, u32 nblocks, u32* __restrict__ offs, u64* __restrict__ totals)
 {
-    __shared__ u32 s_bit[1024], s_gap[1024];
-    __shared__ u32 carry_bit, carry_gap;
+    __shared__ u32 sm[32];
     __shared__ u32 kcnt[4];
     u32 tid = threadIdx.x;
-    if (tid == 0) { carry_bit = 0; carry_gap = 0; }
     if (tid < 4) kcnt[tid] = 0;
     __syncthreads();
-    for (u32 base = 0; base < nblocks; base += 1024u) {
-        u32 nb = base + tid;
-        u32 vb = 0, vg = 0, kind = K_NULL;
-        if (nb < nblocks) {
-            kind = st[nb].kind;
-            vb = kind == K_BIT;
-            vg = kind == K_GAP ? ((st[nb].runs + 1u + 7u) & ~7u) : 0u;   // GAP blocks start 16-B aligned in the slab
-            atomicAdd(&kcnt[kind], 1u);
+    u32 carry_bit = 0, carry_gap = 0;
+    u32 kc[4] = {0, 0, 0, 0};
+    for (u32 base = 0; base < nblocks; base += 1024u * SCAN_PER) {
+        u32 nb0 = base + tid * SCAN_PER;
+        u32 kind[SCAN_PER], vg[SCAN_PER];
+        u32 sb = 0, sg = 0;
+#pragma unroll
+        for (u32 i = 0; i < SCAN_PER; ++i) {
+            u32 nb = nb0 + i;
+            kind[i] = 0xFFu; vg[i] = 0;
+            if (nb < nblocks) {
+                BlockStat x = st[nb];
+                kind[i] = x.kind;
+                vg[i] = x.kind == K_GAP ? ((x.runs + 1u + 7u) & ~7u) : 0u;      // GAP blocks start 16-B aligned
+                sb += x.kind == K_BIT; sg += vg[i];
+                kc[x.kind & 3u]++;
+            }
         }
-        s_bit[tid] = vb; s_gap[tid] = vg;
-        __syncthreads();
-        for (u32 o = 1; o < 1024u; o <<= 1) {
-            u32 a = 0, g = 0;
-            if (tid >= o) { a = s_bit[tid - o]; g = s_gap[tid - o]; }
-            __syncthreads();
-            s_bit[tid] += a; s_gap[tid] += g;
-            __syncthreads();
+        u32 eb = sb, eg = sg, tb, tg;
+        wg_scan2_excl(eb, eg, sm, tid, tb, tg);
+        u32 ob = carry_bit + eb, og = carry_gap + eg;
+#pragma unroll
+        for (u32 i = 0; i < SCAN_PER; ++i) {
+            u32 nb = nb0 + i;
+            if (nb < nblocks) {
+                offs[nb] = kind[i] == K_BIT ? ob : (kind[i] == K_GAP ? og : 0u);
+                ob += kind[i] == K_BIT; og += vg[i];
+            }
         }
-        if (nb < nblocks) offs[nb] = (kind == K_BIT) ? carry_bit + s_bit[tid] - vb
-                                  : (kind == K_GAP) ? carry_gap + s_gap[tid] - vg : 0u;
-        __syncthreads();
-        if (tid == 1023u) { carry_bit += s_bit[1023]; carry_gap += s_gap[1023]; }
-        __syncthreads();
+        carry_bit += tb; carry_gap += tg;
     }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) if (kc[k]) atomicAdd(&kcnt[k], kc[k]);
+    __syncthreads();
     if (tid == 0) { totals[0] = carry_bit; totals[1] = carry_gap; }
     if (tid < 4) totals[2 + tid] = kcnt[tid];
 }
@@ -165,21 +190,49 @@ __device__ __forceinline__ void blk_from_desc(u64 d, Blk& b, u32* lds, u32 lane)
     else blk_fill(b, k == K_FULL ? ~0u : 0u);
 }
 
+// Count fan-in.  One device-scope atomic per wave on a single word serialises at ~12 ns each
+// (15,259 waves of a 1 Gbit vector = 0.18 ms, 4x the streaming time of the kernel itself), so short
+// counting kernels add into COUNT_SLOTS words, one 128-B line apart, picked by workgroup id, after a
+// workgroup-level LDS reduce; k_sum_slots folds them.  (Integer adds: order-independent, exact.)
+#define COUNT_SLOTS 64u
+#define COUNT_SLOT_STRIDE 16u      // u64 words = 128 B
+__device__ __forceinline__ void count_fanin(u32 wave_count, u64* __restrict__ slots, u32 lane, u32 wave)
+{
+    __shared__ u32 part[16];
+    u32 nw = blockDim.x >> 6;
+    if (lane == 0) part[wave] = wave_count;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u64 t = 0;
+        for (u32 i = 0; i < nw; ++i) t += part[i];
+        if (t) atomicAdd(reinterpret_cast<unsigned long long*>(slots + (blockIdx.x % COUNT_SLOTS) * COUNT_SLOT_STRIDE), (unsigned long long)t);
+    }
+}
+__global__ __launch_bounds__(64)
+void k_sum_slots(u64* __restrict__ slots, u64* __restrict__ out)
+{
+    u32 lane = threadIdx.x;
+    u64 v = slots[lane * COUNT_SLOT_STRIDE];
+    slots[lane * COUNT_SLOT_STRIDE] = 0;            // leave the slots clean for the next launch
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if (lane == 0) *out = v;
+}
+
 // bvector::count()  src/bm.h:2431 -> block_bitcount src/bmblocks.h:1710
 __global__ __launch_bounds__(256)
-void k_vec_count(const u64* __restrict__ desc, u32 nblocks, u64* __restrict__ total)
+void k_vec_count(const u64* __restrict__ desc, u32 nblocks, u64* __restrict__ slots)
 {
-    u32 lane = lane_id();
-    u32 nb = uniform32(blockIdx.x * 4u + (threadIdx.x >> 6));
-    if (nb >= nblocks) return;
-    u64 d = uniform64(desc[nb]);
-    u32 k = DESC_K(d);
+    u32 lane = lane_id(), wave = threadIdx.x >> 6;
+    u32 nb = uniform32(blockIdx.x * 4u + wave);
     u32 c = 0;
-    if (k == K_NULL) return;
-    if (k == K_FULL) c = 65536u;
-    else if (k == K_BIT) { Blk b; blk_load(b, as_gc4(DESC_P(d)), lane); c = wave_sum(blk_lane_popcount(b)); }
-    else c = wave_sum(gap_lane_popcount(as_gc16(DESC_P(d)), lane));
-    if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(total), (unsigned long long)c);
+    if (nb < nblocks) {
+        u64 d = uniform64(desc[nb]);
+        u32 k = DESC_K(d);
+        if (k == K_FULL) c = 65536u;
+        else if (k == K_BIT) { Blk b; blk_load(b, as_gc4(DESC_P(d)), lane); c = wave_sum(blk_lane_popcount(b)); }
+        else if (k == K_GAP) c = wave_sum(gap_lane_popcount(as_gc16(DESC_P(d)), lane));
+    }
+    count_fanin(c, slots, lane, wave);
 }
 
 // expand a vector into raw words (nblocks_out blocks; blocks past the table are zero)

@@ -127,24 +127,27 @@ void k_op2(int op, const u64* __restrict__ da, u32 na, const u64* __restrict__ d
 // src/bmalgo_impl.h:766,853): popcount(a OP b) without materialising.
 __global__ __launch_bounds__(256)
 void k_count_op2(int op, const u64* __restrict__ da, u32 na, const u64* __restrict__ db, u32 nbk,
-                 u32 nblocks, u64* __restrict__ total)
+                 u32 nblocks, u64* __restrict__ slots)
 {
     __shared__ u32 lds[4 * 2048];
     u32 lane = lane_id(), wave = threadIdx.x >> 6;
     u32 nb = uniform32(blockIdx.x * 4u + wave);
-    if (nb >= nblocks) return;
-    u64 a = desc_at(da, na, nb), b = desc_at(db, nbk, nb);
-    u32 ka = DESC_K(a), kb = DESC_K(b);
-    if (ka == K_NULL && kb == K_NULL) return;
-    if (op == BMX_AND && (ka == K_NULL || kb == K_NULL)) return;
-    if (op == BMX_SUB && (ka == K_NULL || kb == K_FULL)) return;
-    Blk x, y;
-    u32* l = lds + wave * 2048u;
-    blk_from_desc(a, x, l, lane);
-    blk_from_desc(b, y, l, lane);
-    blk_op(op, x, y);
-    u32 c = wave_sum(blk_lane_popcount(x));
-    if (lane == 0 && c) atomicAdd(reinterpret_cast<unsigned long long*>(total), (unsigned long long)c);
+    u32 c = 0;
+    if (nb < nblocks) {
+        u64 a = desc_at(da, na, nb), b = desc_at(db, nbk, nb);
+        u32 ka = DESC_K(a), kb = DESC_K(b);
+        bool skip = (ka == K_NULL && kb == K_NULL) || (op == BMX_AND && (ka == K_NULL || kb == K_NULL)) ||
+                    (op == BMX_SUB && (ka == K_NULL || kb == K_FULL));
+        if (!skip) {
+            Blk x, y;
+            u32* l = lds + wave * 2048u;
+            blk_from_desc(a, x, l, lane);
+            blk_from_desc(b, y, l, lane);
+            blk_op(op, x, y);
+            c = wave_sum(blk_lane_popcount(x));
+        }
+    }
+    count_fanin(c, slots, lane, wave);
 }
 
 // ---------------------------------------------------------------------------
@@ -402,29 +405,25 @@ void k_rs_build(const u64* __restrict__ desc, u32 nblocks, u32* __restrict__ bco
     }
 }
 
-// inclusive running count over blocks (single workgroup)
+// inclusive running count over blocks (single workgroup, SCAN_PER blocks per thread per pass)
 __global__ __launch_bounds__(1024)
 void k_rs_scan(const u32* __restrict__ bcount, u32 nblocks, u64* __restrict__ rcount, u64* __restrict__ total)
 {
-    __shared__ u64 s[1024];
-    __shared__ u64 carry;
+    __shared__ u32 sm[32];
     u32 tid = threadIdx.x;
-    if (tid == 0) carry = 0;
-    __syncthreads();
-    for (u32 base = 0; base < nblocks; base += 1024u) {
-        u32 nb = base + tid;
-        u64 v = nb < nblocks ? bcount[nb] : 0u;
-        s[tid] = v; __syncthreads();
-        for (u32 o = 1; o < 1024u; o <<= 1) {
-            u64 a = tid >= o ? s[tid - o] : 0ull;
-            __syncthreads();
-            s[tid] += a;
-            __syncthreads();
-        }
-        if (nb < nblocks) rcount[nb] = carry + s[tid];
-        __syncthreads();
-        if (tid == 1023u) carry += s[1023];
-        __syncthreads();
+    u64 carry = 0;
+    for (u32 base = 0; base < nblocks; base += 1024u * SCAN_PER) {
+        u32 nb0 = base + tid * SCAN_PER;
+        u32 v[SCAN_PER]; u32 sum = 0;
+#pragma unroll
+        for (u32 i = 0; i < SCAN_PER; ++i) { v[i] = nb0 + i < nblocks ? bcount[nb0 + i] : 0u; sum += v[i]; }
+        // one pass covers <= 16,384 blocks x 65,536 bits = 2^30 < 2^32: u32 partials are exact
+        u32 e = sum, dummy = 0, tot, td;
+        wg_scan2_excl(e, dummy, sm, tid, tot, td);
+        u64 run = carry + e;
+#pragma unroll
+        for (u32 i = 0; i < SCAN_PER; ++i) { run += v[i]; if (nb0 + i < nblocks) rcount[nb0 + i] = run; }
+        carry += tot;
     }
     if (tid == 0) *total = carry;
 }

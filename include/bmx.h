@@ -77,6 +77,10 @@ int bmx_ctx_synchronize(bmx_ctx* ctx);
 /* launch-shape knobs of the counts pipeline (results never depend on them):
  * "pipe_unroll" 1|2|4, "pipe_rows" 8|4|2|1, "pipe_nt" 0|1, "pipe_wg" 64|128|256, "pipe_ver" 1|2, "xcd_swizzle" 0|1 */
 int bmx_ctx_set_tuning(bmx_ctx* ctx, const char* key, int value);
+/* The context keeps freed device blocks in a size-keyed cache (results of same-shaped
+ * operations re-use them instead of paying hipMalloc/hipFree, which synchronises the
+ * device); bmx_ctx_trim gives the cache back to the driver.  BMX_POOL_MAX_MB caps it. */
+int bmx_ctx_trim(bmx_ctx* ctx);
 /* bytes of HBM currently held by vectors/pipelines of this context */
 int bmx_ctx_mem_used(const bmx_ctx* ctx, uint64_t* bytes);
 
@@ -123,6 +127,8 @@ int bmx_op2(bmx_ctx* ctx, int op, const bmx_vec* a, const bmx_vec* b, int opt_co
             bmx_vec** result);
 /* bm::count_and/count_or/count_xor/count_sub  src/bmalgo.h:49,149,81,115 */
 int bmx_count_op2(bmx_ctx* ctx, int op, const bmx_vec* a, const bmx_vec* b, uint64_t* count);
+/* same, asynchronous on the context's stream; d_count is DEVICE memory (one uint64) */
+int bmx_count_op2_dev(bmx_ctx* ctx, int op, const bmx_vec* a, const bmx_vec* b, uint64_t* d_count);
 
 /* ---- aggregator ---- */
 /* aggregator::combine_or(target, src, n)  src/bmaggregator.h:1101 */
