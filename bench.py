@@ -96,12 +96,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    # launched by torch.distributed.run (RANK set): always go through RCCL, also for a 1-rank job, so the
+    # collective path is exercised wherever the launcher is used
+    use_dist = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)
+    torch.cuda.set_device(local_rank)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(local_rank)
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for N > 1"
 
     import bitmagic_amd as bm
@@ -131,13 +132,13 @@ def main():
 
     def step():
         agg.run_counts_dev(pipe, counts.data_ptr())
-        if world > 1:
-            dist.all_reduce(counts)
+        if use_dist:
+            dist.all_reduce(counts)                      # RCCL: 8 bytes per arg-group, same stream as the kernel
 
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     ctx.timer_start()                                    # HIP events on the launch stream
@@ -146,12 +147,12 @@ def main():
         step()
     ev_ms = ctx.timer_stop_ms()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    if world > 1:
+    if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     total_count = int(counts.item())
@@ -199,7 +200,7 @@ def main():
             except Exception as e:  # the baseline is a reported number, never the product path
                 res["cpu_baseline"] = {"value": None, "unit": "Gbit/s", "cores": 1, "kind": "port", "sample": f"failed: {e}"}
         print(json.dumps(res))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -216,6 +216,44 @@ class bvector:
 
     rank = count_to
 
+    def _bit_and_rank(self, n, rs):
+        """(bit(n), rank(n)) for an array of positions: bit(n) = rank(n) - rank(n-1)"""
+        n = np.ascontiguousarray(np.atleast_1d(n), np.uint64)
+        prev = np.where(n > 0, n - np.uint64(1), np.uint64(0))
+        r = self.count_to(np.concatenate([n, prev]), rs)
+        rn, rp = r[:n.size], np.where(n > 0, r[n.size:], np.uint64(0))
+        return (rn - rp), rn
+
+    def rank_corrected(self, n, rs: "rs_index"):
+        """rank(n) - bit(n)  (src/bm.h:3229)"""
+        bit, rn = self._bit_and_rank(n, rs)
+        out = rn - bit
+        return int(out[0]) if np.isscalar(n) else out
+
+    def count_to_test(self, n, rs: "rs_index"):
+        """bit(n) ? rank(n) : 0  (src/bm.h:3173)"""
+        bit, rn = self._bit_and_rank(n, rs)
+        out = np.where(bit != 0, rn, np.uint64(0))
+        return int(out[0]) if np.isscalar(n) else out
+
+    def count_range(self, left, right, rs: "rs_index"):
+        """ones in [left..right]; arguments are swapped when left > right  (src/bm.h:3548)"""
+        l = np.ascontiguousarray(np.atleast_1d(left), np.uint64); r = np.ascontiguousarray(np.atleast_1d(right), np.uint64)
+        lo, hi = np.minimum(l, r), np.maximum(l, r)
+        prev = np.where(lo > 0, lo - np.uint64(1), np.uint64(0))
+        q = self.count_to(np.concatenate([hi, prev]), rs)
+        out = q[:hi.size] - np.where(lo > 0, q[hi.size:], np.uint64(0))
+        return int(out[0]) if np.isscalar(left) else out
+
+    def find_rank(self, rank, from_pos, rs: "rs_index"):
+        """position of the rank-th set bit at or after from_pos  (src/bm.h:5279) -> (found, pos)"""
+        rk = np.ascontiguousarray(np.atleast_1d(rank), np.uint64); fr = np.ascontiguousarray(np.atleast_1d(from_pos), np.uint64)
+        before = np.where(fr > 0, self.count_to(np.where(fr > 0, fr - np.uint64(1), np.uint64(0)), rs), np.uint64(0))
+        found, pos = self.select(np.where(rk > 0, rk + before, np.uint64(0)), rs)
+        if np.isscalar(rank):
+            return bool(found[0]), int(pos[0])
+        return found, pos
+
     def select(self, rank, rs: "rs_index"):
         """-> (found, pos); rank is 1-based (src/bm.h:5350)"""
         arr = np.ascontiguousarray(np.atleast_1d(rank), np.uint64)
@@ -388,6 +426,14 @@ class aggregator:
         any_ = C.c_int()
         check(lib().bmx_agg_and_sub(self.ctx._h, _handles(a), len(a), _handles(s), len(s), C.byref(h), C.byref(any_)))
         return bvector(self.ctx, h), bool(any_.value)
+
+    def find_first_and_sub(self, bv_src_and=None, bv_src_sub=None):                      # :1079 / :1458
+        """-> (found, idx): first set bit of AND(group 0) AND NOT OR(group 1)"""
+        a = list(bv_src_and) if bv_src_and is not None else self.ag.arg_bv0
+        s = list(bv_src_sub) if bv_src_sub is not None else self.ag.arg_bv1
+        found, idx = C.c_int(), C.c_uint64()
+        check(lib().bmx_find_first_and_sub(self.ctx._h, _handles(a), len(a), _handles(s), len(s), C.byref(found), C.byref(idx)))
+        return bool(found.value), int(idx.value)
 
     def _run_pipeline(self, pipe: pipeline, nb_from: int = 0, nb_to: int = ID_MAX):
         if not pipe.is_complete():

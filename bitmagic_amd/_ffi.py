@@ -65,6 +65,7 @@ def lib() -> C.CDLL:
         "bmx_count_op2_dev": (i32, [vp, i32, vp, vp, vp]),
         "bmx_agg_or": (i32, [vp, P(vp), C.c_size_t, P(vp)]),
         "bmx_agg_and_sub": (i32, [vp, P(vp), C.c_size_t, P(vp), C.c_size_t, P(vp), P(i32)]),
+        "bmx_find_first_and_sub": (i32, [vp, P(vp), C.c_size_t, P(vp), C.c_size_t, P(i32), P(u64)]),
         "bmx_pipeline_create": (i32, [vp, P(vp), P(u32), P(vp), P(u32), C.c_size_t, P(vp)]),
         "bmx_pipeline_destroy": (i32, [vp, vp]),
         "bmx_pipeline_run_counts": (i32, [vp, vp, u32, u32, P(u64)]),

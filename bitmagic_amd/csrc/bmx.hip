@@ -879,6 +879,31 @@ int bmx_agg_and_sub(bmx_ctx* ctx, const bmx_vec* const* src_and, size_t n_and,
     return BMX_OK;
 }
 
+int bmx_find_first_and_sub(bmx_ctx* ctx, const bmx_vec* const* src_and, size_t n_and,
+                           const bmx_vec* const* src_sub, size_t n_sub, int* found, uint64_t* idx)
+{
+    ARGCHK(ctx && found && idx && (n_and == 0 || src_and) && (n_sub == 0 || src_sub));
+    *found = 0; *idx = 0;
+    int rc = set_dev(ctx); if (rc) return rc;
+    if (!n_and) return BMX_OK;
+    uint32_t an = (uint32_t)n_and, sn = (uint32_t)n_sub;
+    bmx_pipeline* p = nullptr;
+    if ((rc = bmx_pipeline_create(ctx, src_and, &an, src_sub, &sn, 1, &p))) return rc;
+    hipError_t e = hipMemsetAsync(ctx->d_small, 0xFF, 8, ctx->stream);
+    if (e == hipSuccess && p->ncols) {
+        size_t lds = p->has_gap ? 4 * 2048 * 4 : 0;
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_find_first_and_sub<2>), dim3((p->ncols + 3) / 4), dim3(256), lds, ctx->stream,
+                           p->d_dmat, p->d_meta + 1, p->d_meta + 2, p->col_stride, p->ncols, ctx->d_small);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(ctx->h_small, ctx->d_small, 8, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    bmx_pipeline_destroy(ctx, p);
+    if (e != hipSuccess) return fail_hip(e, "bmx_find_first_and_sub", __LINE__);
+    if (ctx->h_small[0] != ~0ull) { *found = 1; *idx = ctx->h_small[0]; }
+    return BMX_OK;
+}
+
 // ---------------------------------------------------------------------------
 // rank / select
 // ---------------------------------------------------------------------------

@@ -298,6 +298,56 @@ void k_agg_and_sub(const u64* __restrict__ dmat, const u32* __restrict__ and_n_p
     store_result(acc, c, opt_compress, slab, desc, st, lane);
 }
 
+// aggregator::find_first_and_sub  src/bmaggregator.h:1458: index of the first set bit of
+// AND(group 0) AND NOT OR(group 1) without materialising the result.  Columns are visited in
+// ascending order by the dispatcher; a wave gives up as soon as an earlier column already has a hit
+// (*best holds the smallest global bit index found so far, ~0 = none).
+template <int U>
+__global__ __launch_bounds__(256)
+void k_find_first_and_sub(const u64* __restrict__ dmat, const u32* __restrict__ and_n_p, const u32* __restrict__ sub_n_p,
+                          u32 col_stride, u32 ncols, u64* __restrict__ best)
+{
+    extern __shared__ u32 lds_dyn[];
+    u32 lane = lane_id(), wave = threadIdx.x >> 6;
+    u32 c = uniform32(blockIdx.x * 4u + wave);
+    if (c >= ncols) return;
+    u64 cur = __hip_atomic_load(best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (((u64)c << 16) > cur) return;
+    const u64* row = dmat + (size_t)c * col_stride;
+    u64 hdr = uniform64(row[0]), flags = uniform64(row[1]);
+    if (flags & ROW_EMPTY) return;
+    if (flags & ROW_FULL) { if (lane == 0) atomicMin(reinterpret_cast<unsigned long long*>(best), (unsigned long long)c << 16); return; }
+    u32 nba = (u32)(hdr & 0xFFFFu), nga = (u32)((hdr >> 16) & 0xFFFFu);
+    u32 nbs = (u32)((hdr >> 32) & 0xFFFFu), ngs = (u32)(hdr >> 48);
+    u32 na = uniform32(and_n_p[0]), ns = uniform32(sub_n_p[0]);
+    const u64* pa = row + 2;
+    const u64* ps = pa + na;
+    u32* lds = lds_dyn + wave * 2048u;
+    Blk acc;
+    blk_fill(acc, ~0u);
+    if (pipe_chain<U, false, 0>(acc, pa, nba, lane)) return;
+    if (pipe_chain<U, false, 1>(acc, ps, nbs, lane)) return;
+    if (nga | ngs) {
+        blk_to_lds(acc, lds, lane);
+        if (nga) gap_apply_list<GAP_AND>(pa + na - 1u, nga, lds, lane);
+        if (ngs) gap_apply_list<GAP_SUB>(ps + ns - 1u, ngs, lds, lane);
+        blk_from_lds(acc, lds, lane);
+    }
+    // bit_find_first (src/bmfunc.h:9499): smallest linear bit index held by this lane, then wave min
+    u32 mine = 0xFFFFFFFFu;
+#pragma unroll
+    for (int i = 7; i >= 0; --i) {
+        u32 w[4] = {acc.r[i].x, acc.r[i].y, acc.r[i].z, acc.r[i].w};
+#pragma unroll
+        for (int j = 3; j >= 0; --j)
+            if (w[j]) mine = (((u32)i * 256u + lane * 4u + (u32)j) << 5) + (u32)__builtin_ctz(w[j]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { u32 t = __shfl_xor(mine, o, 64); mine = t < mine ? t : mine; }
+    if (lane == 0 && mine != 0xFFFFFFFFu)
+        atomicMin(reinterpret_cast<unsigned long long*>(best), ((unsigned long long)c << 16) + mine);
+}
+
 // ---------------------------------------------------------------------------
 // Rank / select.
 // Device index (MI355X-first, sized for HBM not for a CPU cache): per block

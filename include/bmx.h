@@ -138,6 +138,10 @@ int bmx_agg_or(bmx_ctx* ctx, const bmx_vec* const* src, size_t n, bmx_vec** resu
 int bmx_agg_and_sub(bmx_ctx* ctx, const bmx_vec* const* src_and, size_t n_and,
                     const bmx_vec* const* src_sub, size_t n_sub,
                     bmx_vec** result, int* any);
+/* aggregator::find_first_and_sub(idx, and, n_and, sub, n_sub)  src/bmaggregator.h:1458:
+ * index of the first set bit of the AND-SUB result, nothing materialised. */
+int bmx_find_first_and_sub(bmx_ctx* ctx, const bmx_vec* const* src_and, size_t n_and,
+                           const bmx_vec* const* src_sub, size_t n_sub, int* found, uint64_t* idx);
 /* aggregator::pipeline<agg_opt_only_counts>  src/bmaggregator.h:62-103,222-341:
  * arg-groups are given as concatenated operand lists, and_n[g] / sub_n[g] per
  * group (pipeline::add() + arg_groups::add(bv, 0|1) + complete(), :2784-2931). */

@@ -176,6 +176,25 @@ public:
         if (f) pos = p;
         return f != 0;
     }
+    /// rank_corrected(n) = rank(n) - bit(n)  src/bm.h:3229
+    size_type rank_corrected(size_type n, const rs_index& rs) const { size_type b, r; bit_and_rank(n, rs, b, r); return r - b; }
+    /// count_to_test(n) = bit(n) ? rank(n) : 0  src/bm.h:3173
+    size_type count_to_test(size_type n, const rs_index& rs) const { size_type b, r; bit_and_rank(n, rs, b, r); return b ? r : 0; }
+    /// count_range(left, right): ones in [left..right], arguments swapped when left > right  src/bm.h:3548
+    size_type count_range(size_type left, size_type right, const rs_index& rs) const
+    {
+        if (left > right) std::swap(left, right);
+        size_type q[2] = {right, left ? left - 1 : 0}, out[2];
+        count_to(q, 2, out, rs);
+        return out[0] - (left ? out[1] : 0);
+    }
+    /// find_rank(rank, from, pos, rs): rank-th set bit at or after `from`  src/bm.h:5279
+    bool find_rank(size_type rank_in, size_type from, size_type& pos, const rs_index& rs) const
+    {
+        if (!rank_in) return false;
+        size_type before = from ? count_to(from - 1, rs) : 0;
+        return select(rank_in + before, pos, rs);
+    }
     /// batched forms (one launch for q queries)
     void count_to(const size_type* n, size_t q, size_type* out, const rs_index& rs) const
     { require(); check(bmx_rank_batch(ctx_->handle(), h_, rs.h_, n, q, out)); }
@@ -191,6 +210,12 @@ public:
 
 private:
     void require() const { if (!h_) throw error(BMX_ERR_BADARG, "BMX-02: vector holds no device data"); }
+    void bit_and_rank(size_type n, const rs_index& rs, size_type& bit, size_type& rank_n) const
+    {
+        size_type q[2] = {n, n ? n - 1 : 0}, out[2];
+        count_to(q, 2, out, rs);
+        rank_n = out[0]; bit = out[0] - (n ? out[1] : 0);
+    }
     bvector& op3(int op, const bvector& a, const bvector& b, optmode opt)
     {
         a.require(); b.require();
@@ -322,6 +347,20 @@ public:
         check(bmx_agg_and_sub(ctx_->handle(), a.data(), src_and_size, s.data(), src_sub_size, &r, &any));
         bv_target.adopt(r);
         return any != 0;
+    }
+    /// find_first_and_sub(idx)  src/bmaggregator.h:1079 / C-style :1458
+    bool find_first_and_sub(size_type& idx)
+    { return find_first_and_sub(idx, ag_.arg_bv0.data(), ag_.arg_bv0.size(), ag_.arg_bv1.data(), ag_.arg_bv1.size()); }
+    bool find_first_and_sub(size_type& idx, const bvector_type_const_ptr* bv_src_and, size_t src_and_size,
+                            const bvector_type_const_ptr* bv_src_sub, size_t src_sub_size)
+    {
+        std::vector<const bmx_vec*> a(src_and_size), s(src_sub_size);
+        for (size_t i = 0; i < src_and_size; ++i) a[i] = bv_src_and[i]->handle();
+        for (size_t i = 0; i < src_sub_size; ++i) s[i] = bv_src_sub[i]->handle();
+        int found = 0; uint64_t p = 0;
+        check(bmx_find_first_and_sub(ctx_->handle(), a.data(), src_and_size, s.data(), src_sub_size, &found, &p));
+        if (found) idx = p;
+        return found != 0;
     }
     /// combine_and_sub(pipe)  src/bmaggregator.h:1292 (counts land in pipe.get_bv_count_vector())
     template <class TPipe>

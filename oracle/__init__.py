@@ -145,6 +145,20 @@ class RS:
             self.orc._f("rs_export")(self.h, _u32p(bc), _u64p(sub))
         return bc, sub
 
+    def count_range(self, l: int, r: int) -> int:
+        return int(self.orc._f("count_range")(self.vec.h, self.h, C.c_uint64(l), C.c_uint64(r)))
+
+    def rank_corrected(self, n: int) -> int:
+        return int(self.orc._f("rank_corrected")(self.vec.h, self.h, C.c_uint64(n)))
+
+    def count_to_test(self, n: int) -> int:
+        return int(self.orc._f("count_to_test")(self.vec.h, self.h, C.c_uint64(n)))
+
+    def find_rank(self, rank: int, frm: int):
+        pos = C.c_uint64()
+        f = self.orc._f("find_rank")(self.vec.h, self.h, C.c_uint64(rank), C.c_uint64(frm), C.byref(pos))
+        return bool(f), int(pos.value)
+
     def rank(self, n) -> np.ndarray:
         n = np.ascontiguousarray(n, np.uint64)
         out = np.zeros(n.shape, np.uint64)
@@ -186,6 +200,17 @@ class Oracle:
         getattr(L, prefix + "rank_batch").argtypes = [vp, vp, C.POINTER(C.c_uint64), C.c_size_t, C.POINTER(C.c_uint64)]
         getattr(L, prefix + "select_batch").argtypes = [vp, vp, C.POINTER(C.c_uint64), C.c_size_t,
                                                         C.POINTER(C.c_uint64), C.POINTER(C.c_uint8)]
+        for fn in ["count_range", "rank_corrected", "count_to_test"]:
+            getattr(L, prefix + fn).restype = C.c_uint64
+        getattr(L, prefix + "count_range").argtypes = [vp, vp, C.c_uint64, C.c_uint64]
+        getattr(L, prefix + "rank_corrected").argtypes = [vp, vp, C.c_uint64]
+        getattr(L, prefix + "count_to_test").argtypes = [vp, vp, C.c_uint64]
+        getattr(L, prefix + "find_rank").restype = C.c_int
+        getattr(L, prefix + "find_rank").argtypes = [vp, vp, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]
+        getattr(L, prefix + "vec_find_first").restype = C.c_int
+        getattr(L, prefix + "vec_find_first").argtypes = [vp, C.POINTER(C.c_uint64)]
+        getattr(L, prefix + "find_first_and_sub").restype = C.c_int
+        getattr(L, prefix + "find_first_and_sub").argtypes = [C.POINTER(vp), C.c_size_t, C.POINTER(vp), C.c_size_t, C.POINTER(C.c_uint64)]
         if self.is_ref:
             L.ref_vec_new.argtypes = []
             L.ref_vec_stat.argtypes = [vp, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
@@ -279,6 +304,16 @@ class Oracle:
         self._f("agg_pipeline_counts")(self._ptrs(and_list), _u32p(and_n), self._ptrs(sub_list), _u32p(sub_n),
                                        len(groups), C.c_uint32(nb_from), C.c_uint32(nb_to), _u64p(out))
         return out
+
+    def find_first(self, v: Vec):
+        pos = C.c_uint64()
+        f = self._f("vec_find_first")(v.h, C.byref(pos))
+        return bool(f), int(pos.value)
+
+    def find_first_and_sub(self, and_vecs, sub_vecs=()):
+        idx = C.c_uint64()
+        f = self._f("find_first_and_sub")(self._ptrs(and_vecs), len(and_vecs), self._ptrs(sub_vecs), len(sub_vecs), C.byref(idx))
+        return bool(f), int(idx.value)
 
     def rs_build(self, v: Vec) -> RS:
         return RS(self, self._f("rs_build")(v.h), v)

@@ -1108,6 +1108,47 @@ bmo_vec* bmo_agg_and_sub(const bmo_vec* const* src_and, size_t n_and,
     return t;
 }
 
+static int block_find_first(const uint32_t* b, uint32_t* bit)      /* src/bmfunc.h:9499 bit_find_first */
+{
+    for (unsigned i = 0; i < BMO_BLOCK_WORDS; ++i)
+        if (b[i]) { *bit = i * 32u + (uint32_t)__builtin_ctz(b[i]); return 1; }
+    return 0;
+}
+
+int bmo_vec_find_first(const bmo_vec* v, uint64_t* pos)
+{
+    uint32_t tmp[BMO_BLOCK_WORDS];
+    for (uint32_t nb = 0; nb < v->nblocks; ++nb) {
+        if (v->kind[nb] == BMO_NULL) continue;
+        uint32_t bit;
+        if (block_find_first(block_as_bits(v, nb, tmp), &bit)) { *pos = ((uint64_t)nb << 16) + bit; return 1; }
+    }
+    return 0;
+}
+
+/* aggregator::find_first_and_sub  src/bmaggregator.h:1458 (per column :1534-1547) */
+int bmo_find_first_and_sub(const bmo_vec* const* src_and, size_t n_and,
+                           const bmo_vec* const* src_sub, size_t n_sub, uint64_t* idx)
+{
+    uint64_t nbits;
+    uint32_t nblocks = max_blocks(src_and, n_and, &nbits);
+    if (!n_and) return 0;
+    arg_list A, S; arg_list_init(&A, n_and); arg_list_init(&S, n_sub);
+    uint32_t* tb1 = alloc_bit_block();
+    int found = 0;
+    for (uint32_t nb = 0; nb < nblocks && !found; ++nb) {
+        int is_full;
+        uint64_t digest = and_sub_column(nb, src_and, n_and, src_sub, n_sub, &A, &S, tb1, &is_full);
+        if (is_full) { *idx = (uint64_t)nb << 16; found = 1; break; }
+        if (!digest) continue;
+        zero_non_digest(tb1, digest);
+        uint32_t bit;
+        if (block_find_first(tb1, &bit)) { *idx = ((uint64_t)nb << 16) + bit; found = 1; }
+    }
+    free(tb1); arg_list_free(&A); arg_list_free(&S);
+    return found;
+}
+
 /* aggregator::combine_or  src/bmaggregator.h:1101, per column :1626;
  * result stored with opt_mode_ = opt_none (:917,1658) */
 bmo_vec* bmo_agg_or(const bmo_vec* const* src, size_t n)
@@ -1290,6 +1331,27 @@ int bmo_select(const bmo_vec* v, const bmo_rs* rs, uint64_t rank, uint64_t* pos)
     }
     *pos = ((uint64_t)nb << 16) + bit;
     return 1;
+}
+
+/* src/bm.h:3548: count_range(l, r) = rank(r) - rank(l-1); arguments are swapped when l > r (:3554) */
+uint64_t bmo_count_range(const bmo_vec* v, const bmo_rs* rs, uint64_t left, uint64_t right)
+{
+    if (left > right) { uint64_t t = left; left = right; right = t; }
+    if (left == right) return (uint64_t)bmo_vec_get_bit(v, left);
+    return bmo_rank(v, rs, right) - (left ? bmo_rank(v, rs, left - 1) : 0);
+}
+/* src/bm.h:3229: rank(n) - bit(n) */
+uint64_t bmo_rank_corrected(const bmo_vec* v, const bmo_rs* rs, uint64_t n)
+{ return bmo_rank(v, rs, n) - (uint64_t)bmo_vec_get_bit(v, n); }
+/* src/bm.h:3173: bit(n) ? rank(n) : 0 */
+uint64_t bmo_count_to_test(const bmo_vec* v, const bmo_rs* rs, uint64_t n)
+{ return bmo_vec_get_bit(v, n) ? bmo_rank(v, rs, n) : 0; }
+/* src/bm.h:5279 find_rank(rank, from, pos, rs): position of the rank-th set bit at or after `from` */
+int bmo_find_rank(const bmo_vec* v, const bmo_rs* rs, uint64_t rank, uint64_t from, uint64_t* pos)
+{
+    if (!rank) return 0;
+    uint64_t before = from ? bmo_rank(v, rs, from - 1) : 0;
+    return bmo_select(v, rs, rank + before, pos);
 }
 
 void bmo_rank_batch(const bmo_vec* v, const bmo_rs* rs, const uint64_t* n, size_t q, uint64_t* out)

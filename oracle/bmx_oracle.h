@@ -109,6 +109,13 @@ void     bmo_agg_pipeline_counts(const bmo_vec* const* and_list, const uint32_t*
                                  size_t ngroups, uint32_t nb_from, uint32_t nb_to,
                                  uint64_t* counts_out);
 
+/* first set bit of a vector (bvector::find) and of an AND-SUB aggregation without materialising
+ * (aggregator::find_first_and_sub, src/bmaggregator.h:1458).  Logical definition; the reference
+ * additionally narrows the searched sub-array range by the SUB group (its own ":1526 TODO"). */
+int      bmo_vec_find_first(const bmo_vec* v, uint64_t* pos);
+int      bmo_find_first_and_sub(const bmo_vec* const* src_and, size_t n_and,
+                                const bmo_vec* const* src_sub, size_t n_sub, uint64_t* idx);
+
 /* rank / select (src/bm.h:3120,5350 ; Appendix A.5) */
 typedef struct bmo_rs bmo_rs;
 bmo_rs*  bmo_rs_build(const bmo_vec* v);                    /* src/bm.h:2531 */
@@ -119,6 +126,11 @@ uint32_t bmo_rs_total_blocks(const bmo_rs* rs);
 void     bmo_rs_export(const bmo_rs* rs, uint32_t* bcount, uint64_t* sub_count);
 uint64_t bmo_rank(const bmo_vec* v, const bmo_rs* rs, uint64_t n);          /* count_to */
 int      bmo_select(const bmo_vec* v, const bmo_rs* rs, uint64_t rank, uint64_t* pos);
+/* src/bm.h:3548 count_range, :3229 rank_corrected, :3173 count_to_test, :5279 find_rank(rank, from) */
+uint64_t bmo_count_range(const bmo_vec* v, const bmo_rs* rs, uint64_t left, uint64_t right);
+uint64_t bmo_rank_corrected(const bmo_vec* v, const bmo_rs* rs, uint64_t n);
+uint64_t bmo_count_to_test(const bmo_vec* v, const bmo_rs* rs, uint64_t n);
+int      bmo_find_rank(const bmo_vec* v, const bmo_rs* rs, uint64_t rank, uint64_t from, uint64_t* pos);
 void     bmo_rank_batch(const bmo_vec* v, const bmo_rs* rs, const uint64_t* n, size_t q, uint64_t* out);
 void     bmo_select_batch(const bmo_vec* v, const bmo_rs* rs, const uint64_t* r, size_t q,
                           uint64_t* pos, uint8_t* found);

@@ -244,6 +244,32 @@ void ref_select_batch(void* v, void* r, const uint64_t* rk, size_t q, uint64_t* 
     }
 }
 
+// bvector::find (first set bit), aggregator::find_first_and_sub (bmaggregator.h:1458)
+int ref_vec_find_first(void* v, uint64_t* pos)
+{
+    bvect::size_type p = 0; bool f = static_cast<bvect*>(v)->find(p); *pos = p; return f;
+}
+int ref_find_first_and_sub(void* const* src_and, size_t n_and, void* const* src_sub, size_t n_sub, uint64_t* idx)
+{
+    agg_t agg; bvect::size_type i = 0;
+    bool f = agg.find_first_and_sub(i, reinterpret_cast<const bvect* const*>(src_and), n_and,
+                                    reinterpret_cast<const bvect* const*>(src_sub), n_sub);
+    *idx = i; return f;
+}
+// rank variants: bm.h:3548 count_range, :3229 rank_corrected, :3173 count_to_test, :5279 find_rank
+uint64_t ref_count_range(void* v, void* r, uint64_t left, uint64_t right)
+{ return static_cast<bvect*>(v)->count_range(bvect::size_type(left), bvect::size_type(right), static_cast<ref_rs*>(r)->rs); }
+uint64_t ref_rank_corrected(void* v, void* r, uint64_t n)
+{ return static_cast<bvect*>(v)->rank_corrected(bvect::size_type(n), static_cast<ref_rs*>(r)->rs); }
+uint64_t ref_count_to_test(void* v, void* r, uint64_t n)
+{ return static_cast<bvect*>(v)->count_to_test(bvect::size_type(n), static_cast<ref_rs*>(r)->rs); }
+int ref_find_rank(void* v, void* r, uint64_t rank, uint64_t from, uint64_t* pos)
+{
+    bvect::size_type p = 0;
+    bool f = static_cast<bvect*>(v)->find_rank(bvect::size_type(rank), bvect::size_type(from), p, static_cast<ref_rs*>(r)->rs);
+    *pos = p; return f;
+}
+
 // block-level known-answer helpers (bmfunc.h) used by the golden generator
 uint32_t ref_bit_block_count(const uint32_t* blk) { return bm::bit_block_count(blk); }
 uint64_t ref_calc_block_digest0(const uint32_t* blk) { return bm::calc_block_digest0(blk); }

@@ -70,6 +70,12 @@ int main()
     agg.combine_or(t);
     bmo_vec* eo = bmo_agg_or(a4, 4);
     REQUIRE(t.count() == bmo_vec_count(eo));
+    {
+        bmx::size_type idx = 0; uint64_t pidx = 0;
+        bool f = agg.find_first_and_sub(idx);
+        int pf = bmo_find_first_and_sub(a4, 4, s1, 1, &pidx);
+        REQUIRE(f == (pf != 0) && (!f || idx == pidx));
+    }
     bmo_vec_free(e); bmo_vec_free(eo);
     // counts-only pipeline
     bmx::aggregator<bmx::bvector>::pipeline<bmx::agg_opt_only_counts> pipe(ctx);
@@ -94,6 +100,15 @@ int main()
     for (uint64_t r = 1; r <= rs.count(); r += 1 + rs.count() / 97) {
         uint64_t p1 = 0, p2 = 0;
         REQUIRE(gv[5].select(r, p1, rs) && bmo_select(pv[5], prs, r, &p2) && p1 == p2);
+    }
+    for (uint64_t n = 3; n + 5000 < nbits; n += 77777) {
+        REQUIRE(gv[5].count_range(n, n + 5000, rs) == bmo_count_range(pv[5], prs, n, n + 5000));
+        REQUIRE(gv[5].count_range(n + 5000, n, rs) == bmo_count_range(pv[5], prs, n, n + 5000));
+        REQUIRE(gv[5].rank_corrected(n, rs) == bmo_rank_corrected(pv[5], prs, n));
+        REQUIRE(gv[5].count_to_test(n, rs) == bmo_count_to_test(pv[5], prs, n));
+        uint64_t p1 = 0, p2 = 0;
+        bool f1 = gv[5].find_rank(7, n, p1, rs); int f2 = bmo_find_rank(pv[5], prs, 7, n, &p2);
+        REQUIRE(f1 == (f2 != 0) && (!f1 || p1 == p2));
     }
     uint64_t dummy;
     REQUIRE(!gv[5].select(0, dummy, rs) && !gv[5].select(rs.count() + 1, dummy, rs));

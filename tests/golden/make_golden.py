@@ -61,6 +61,15 @@ def run(R, P):
             t = R.agg_and_sub([vecs[i] for i in a], [vecs[i] for i in s])
             c["agg_and_sub"].append({"and": a, "sub": s, "sha": sha(t.to_words()), "count": t.count(),
                                      "kinds": t.flatten()[0].tolist()})
+        # find_first_and_sub: the logical first bit of the reference's own combine_and_sub result; the
+        # reference call is recorded too (it may narrow the search range by the SUB group, :1526 TODO)
+        c["find_first"] = []
+        for (a, s_) in AGG_GROUPS:
+            t = R.agg_and_sub([vecs[i] for i in a], [vecs[i] for i in s_])
+            lf = R.find_first(t)
+            rf = R.find_first_and_sub([vecs[i] for i in a], [vecs[i] for i in s_])
+            c["find_first"].append({"and": a, "sub": s_, "found": bool(lf[0]), "idx": lf[1] if lf[0] else 0,
+                                    "reference_call_agrees": bool(rf == lf or (not rf[0] and not lf[0]))})
         c["agg_or"] = []
         for o in OR_SETS:
             t = R.agg_or([vecs[i] for i in o])
@@ -77,7 +86,14 @@ def run(R, P):
             rq = rank_queries(nbits)
             sq = select_queries(v.count())
             pos, found = rs.select(sq)
+            rq_l = rq[::7][:60]; rq_r = rq[3::7][:60]
+            fr_rank = sq[:40]; fr_from = rq[:40]
+            fr = [rs.find_rank(int(a_), int(b_)) for a_, b_ in zip(fr_rank, fr_from)]
             c["rs"].append({"vec": vi, "count": rs.count(), "bcount": bc.tolist(), "sub_count": [int(x) for x in sub],
+                            "count_range": [rs.count_range(int(a_), int(b_)) for a_, b_ in zip(rq_l, rq_r)],
+                            "rank_corrected": [rs.rank_corrected(int(a_)) for a_ in rq[:120]],
+                            "count_to_test": [rs.count_to_test(int(a_)) for a_ in rq[:120]],
+                            "find_rank_found": [int(f) for f, _ in fr], "find_rank_pos": [int(p_) if f else 0 for f, p_ in fr],
                             "rank": [int(x) for x in rs.rank(rq)],
                             "select_found": found.astype(int).tolist(),
                             "select_pos": [int(p) if f else 0 for p, f in zip(pos, found)]})

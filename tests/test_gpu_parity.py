@@ -98,6 +98,9 @@ def test_golden_case(ctx, port, golden, case):
     for e in g["agg_or"]:
         t = agg.combine_or([vecs[i] for i in e["src"]])
         assert sha(t.to_words(nwb)) == e["sha"] and t.count() == e["count"]
+    for e in g["find_first"]:
+        f, idx = agg.find_first_and_sub([vecs[i] for i in e["and"]], [up[i] for i in e["sub"]])
+        assert f == e["found"] and (not f or idx == e["idx"]), (e, f, idx)
     pipe = bm.aggregator.pipeline(ctx)
     for (a, s) in AGG_GROUPS:
         ag = pipe.add()
@@ -122,6 +125,13 @@ def test_golden_case(ctx, port, golden, case):
         found, pos = v.select(select_queries(e["count"]), rs)
         assert found.astype(int).tolist() == e["select_found"]
         assert [int(p) if f else 0 for p, f in zip(pos, found)] == e["select_pos"]
+        rq, sq = rank_queries(nbits), select_queries(e["count"])
+        assert [int(x) for x in v.count_range(rq[::7][:60], rq[3::7][:60], rs)] == e["count_range"]
+        assert [int(x) for x in v.rank_corrected(rq[:120], rs)] == e["rank_corrected"]
+        assert [int(x) for x in v.count_to_test(rq[:120], rs)] == e["count_to_test"]
+        ff, fp = v.find_rank(sq[:40], rq[:40], rs)
+        assert ff.astype(int).tolist() == e["find_rank_found"]
+        assert [int(p) if f else 0 for p, f in zip(fp, ff)] == e["find_rank_pos"]
 
 
 @pytest.mark.parametrize("dq,cdq,nvec", [(40, None, 9), (655, 655, 12), (6554, 6554, 40), (6554, None, 17),
