@@ -39,7 +39,8 @@ opt_none, opt_compress = 0, 3        # bvector::optmode (src/bm.h:129-135)
 ID_MAX = 0xFFFFFFFF                  # bm::id_max (src/bmconst.h:109)
 
 __all__ = ["context", "bvector", "aggregator", "rs_index", "bit_import_u32", "count_and", "count_or",
-           "count_xor", "count_sub", "BmxError", "simd_version", "device_count"]
+           "count_xor", "count_sub", "BmxError", "simd_version", "device_count", "agg_run_options",
+           "agg_opt_only_counts", "agg_opt_bvect_and_counts", "agg_opt_disable_bvects_and_counts"]
 
 
 def simd_version() -> int:
@@ -342,14 +343,51 @@ class arg_groups:
         self.arg_bv1.clear()
 
 
-class pipeline:
-    """aggregator::pipeline<agg_opt_only_counts> (src/bmaggregator.h:222-341)."""
+class agg_run_options:
+    """bm::agg_run_options<OBvects, OCounts> (src/bmaggregator.h:62-103)"""
 
-    def __init__(self, ctx: context):
+    def __init__(self, make_results: bool = True, compute_counts: bool = False):
+        self.make_results, self.compute_counts = make_results, compute_counts
+
+    def is_make_results(self): return self.make_results
+    def is_compute_counts(self): return self.compute_counts
+
+
+agg_opt_disable_bvects_and_counts = agg_run_options(False, False)    # :84
+agg_opt_only_counts = agg_run_options(False, True)                   # :92
+agg_opt_bvect_and_counts = agg_run_options(True, True)               # :100
+
+
+class pipeline:
+    """aggregator::pipeline<Opt> (src/bmaggregator.h:222-341); default Opt = agg_opt_only_counts here
+    (the headline path); pass agg_run_options() for the reference's default (result vectors, no counts)."""
+
+    def __init__(self, ctx: context, opt: agg_run_options = agg_opt_only_counts):
         self.ctx = ctx
+        self.opt = opt
         self.groups: list[arg_groups] = []
         self._h = None
         self._counts: np.ndarray | None = None
+        self._results: list = []
+        self._or_target: bvector | None = None
+        self._want_or_target = False
+        self.search_count_limit = ID_MAX
+
+    def set_or_target(self, bv_or: "bvector | None" = None):
+        """pipeline::set_or_target (:245): all group results are OR-ed into the target; the (immutable)
+        device vector passed here is the initial content, the updated one is returned by get_or_target()"""
+        self._want_or_target = True
+        self._or_target = bv_or
+
+    def get_or_target(self) -> "bvector | None":
+        return self._or_target
+
+    def set_search_count_limit(self, limit: int):
+        """(:255) approximate by contract -- "can find more, cannot find less" -- accepted and ignored"""
+        self.search_count_limit = limit
+
+    def get_bv_res_vector(self) -> list:
+        return self._results
 
     def add(self) -> arg_groups:
         if self._h:
@@ -407,7 +445,8 @@ class aggregator:
         self.ag.reset()
 
     def combine_or(self, bv_src: Iterable[bvector] | None = None) -> bvector:         # :1021 / :1101
-        src = list(bv_src) if bv_src is not None else self.ag.arg_bv0
+        src = list(bv_src) if bv_src is not None else list(self.ag.arg_bv0)
+        self.ag.reset()              # the reference clears the member arg-groups here (src/bmaggregator.h:1110)
         h = C.c_void_p()
         check(lib().bmx_agg_or(self.ctx._h, _handles(src), len(src), C.byref(h)))
         return bvector(self.ctx, h)
@@ -417,9 +456,15 @@ class aggregator:
         return self.combine_and_sub(src, [])[0]
 
     def combine_and_sub(self, bv_src_and=None, bv_src_sub=None):                         # :1044 / :1162 / :1292
-        """-> (target, any)  |  with a pipeline argument: runs it, counts in pipe.get_bv_count_vector()"""
+        """-> (target, any)  |  with a pipeline argument: runs it according to its options; results in
+        pipe.get_bv_res_vector() / get_bv_count_vector() / get_or_target()"""
         if isinstance(bv_src_and, pipeline):
-            return self._run_pipeline(bv_src_and)
+            pipe = bv_src_and
+            if pipe.opt.is_make_results() or pipe._want_or_target:
+                return self._run_pipeline_results(pipe)
+            if pipe.opt.is_compute_counts():
+                return self._run_pipeline(pipe)
+            return None
         a = list(bv_src_and) if bv_src_and is not None else self.ag.arg_bv0
         s = list(bv_src_sub) if bv_src_sub is not None else self.ag.arg_bv1
         h = C.c_void_p()
@@ -443,6 +488,27 @@ class aggregator:
                                             out.ctypes.data_as(C.POINTER(C.c_uint64))))
         pipe._counts = out[:pipe.size()]
         return pipe._counts
+
+    def _run_pipeline_results(self, pipe: pipeline):
+        if not pipe.is_complete():
+            raise RuntimeError("pipeline is not complete()")
+        n = pipe.size()
+        res = (C.c_void_p * max(n, 1))()
+        cnt = np.zeros(max(n, 1), np.uint64)
+        ort = C.c_void_p()
+        want_res = pipe.opt.is_make_results()
+        want_cnt = pipe.opt.is_compute_counts()
+        check(lib().bmx_pipeline_run_results(
+            self.ctx._h, pipe._h, res if want_res else None,
+            cnt.ctypes.data_as(C.POINTER(C.c_uint64)) if (want_cnt and want_res) else None,
+            pipe._or_target._h if (pipe._want_or_target and pipe._or_target is not None) else None,
+            C.byref(ort) if pipe._want_or_target else None))
+        pipe._results = [bvector(self.ctx, C.c_void_p(res[g])) if (want_res and res[g]) else None for g in range(n)]
+        if pipe._want_or_target:
+            pipe._or_target = bvector(self.ctx, ort)
+        if want_cnt:
+            pipe._counts = cnt[:n] if want_res else self._run_pipeline(pipe)
+        return pipe._results
 
     def run_counts_dev(self, pipe: pipeline, d_counts_ptr: int, nb_from: int = 0, nb_to: int = ID_MAX):
         """asynchronous run; counts land in device memory (e.g. a torch tensor's data_ptr())"""

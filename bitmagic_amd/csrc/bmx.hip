@@ -66,6 +66,9 @@ struct bmx_pipeline {
     bmx_ctx* ctx;
     uint32_t ngroups, ncols, col_stride, n_ops;
     bool has_gap;
+    uint64_t nbits;                       // max size of the operands
+    std::vector<u32>* h_row_off;          // host copy: row offset of each group inside a column record
+    std::vector<u32>* h_and_n;            // host copy: AND operands per group
     u64* d_dmat;
     u32* d_meta;       // row_off | and_n | sub_n | and_off | sub_off (ngroups each) | nblocks (n_ops)
     const u64** d_descs;
@@ -524,7 +527,7 @@ int bmx_pipeline_create(bmx_ctx* ctx, const bmx_vec* const* and_list, const uint
     std::vector<u32> meta(5 * ngroups + std::max<size_t>(n_ops, 1), 0);
     u32* row_off = meta.data(); u32* m_and_n = row_off + ngroups; u32* m_sub_n = m_and_n + ngroups;
     u32* and_off = m_sub_n + ngroups; u32* sub_off = and_off + ngroups; u32* nblk = sub_off + ngroups;
-    uint32_t ncols = 0, col_stride = 0; bool has_gap = false;
+    uint32_t ncols = 0, col_stride = 0; bool has_gap = false; uint64_t max_bits = 0;
     size_t ia = 0, is = 0;
     for (size_t g = 0; g < ngroups; ++g) {
         row_off[g] = col_stride; col_stride += 2 + and_n[g] + sub_n[g];
@@ -534,17 +537,22 @@ int bmx_pipeline_create(bmx_ctx* ctx, const bmx_vec* const* and_list, const uint
             const bmx_vec* v = and_list[ia];
             if (!v || v->ctx != ctx) { g_last_error = "operand is null or belongs to another context"; return BMX_ERR_BADARG; }
             descs[ia] = v->d_desc; nblk[ia] = v->nblocks; ncols = std::max(ncols, v->nblocks); has_gap |= v->counts[BMX_GAP] != 0;
+            max_bits = std::max(max_bits, v->nbits);
         }
         for (uint32_t k = 0; k < sub_n[g]; ++k, ++is) {
             const bmx_vec* v = sub_list[is];
             if (!v || v->ctx != ctx) { g_last_error = "operand is null or belongs to another context"; return BMX_ERR_BADARG; }
             descs[tot_and + is] = v->d_desc; nblk[tot_and + is] = v->nblocks; ncols = std::max(ncols, v->nblocks); has_gap |= v->counts[BMX_GAP] != 0;
+            max_bits = std::max(max_bits, v->nbits);
         }
     }
     bmx_pipeline* p = new (std::nothrow) bmx_pipeline();
     if (!p) return BMX_ERR_BADALLOC;
     memset(p, 0, sizeof(*p));
     p->ctx = ctx; p->ngroups = (uint32_t)ngroups; p->ncols = ncols; p->col_stride = col_stride; p->n_ops = (uint32_t)n_ops; p->has_gap = has_gap;
+    p->nbits = max_bits;
+    p->h_row_off = new std::vector<u32>(row_off, row_off + ngroups);
+    p->h_and_n = new std::vector<u32>(m_and_n, m_and_n + ngroups);
     size_t b_dmat = (size_t)std::max<uint32_t>(ncols, 1) * col_stride * 8, b_meta = meta.size() * 4, b_descs = descs.size() * 8;
     if ((rc = dmalloc(ctx, (void**)&p->d_dmat, b_dmat)) || (rc = dmalloc(ctx, (void**)&p->d_meta, b_meta)) ||
         (rc = dmalloc(ctx, (void**)&p->d_descs, b_descs))) { bmx_pipeline_destroy(ctx, p); return rc; }
@@ -574,6 +582,7 @@ int bmx_pipeline_destroy(bmx_ctx* ctx, bmx_pipeline* p)
     int rc = set_dev(ctx); if (rc) return rc;
     HIPCHK(hipStreamSynchronize(ctx->stream));
     dfree(ctx, p->d_dmat); dfree(ctx, p->d_meta); dfree(ctx, (void*)p->d_descs);
+    delete p->h_row_off; delete p->h_and_n;
     delete p;
     return BMX_OK;
 }
@@ -774,7 +783,14 @@ int bmx_count_op2(bmx_ctx* ctx, int op, const bmx_vec* a, const bmx_vec* b, uint
     return BMX_OK;
 }
 
+static int agg_or_impl(bmx_ctx* ctx, const bmx_vec* const* src, size_t n, int opt_compress, bmx_vec** result);
+
 int bmx_agg_or(bmx_ctx* ctx, const bmx_vec* const* src, size_t n, bmx_vec** result)
+{
+    return agg_or_impl(ctx, src, n, 0 /* opt_mode_ = opt_none, src/bmaggregator.h:917 */, result);
+}
+
+static int agg_or_impl(bmx_ctx* ctx, const bmx_vec* const* src, size_t n, int opt_compress, bmx_vec** result)
 {
     ARGCHK(ctx && result && (n == 0 || src) && n <= 65535);
     *result = nullptr;
@@ -801,7 +817,7 @@ int bmx_agg_or(bmx_ctx* ctx, const bmx_vec* const* src, size_t n, bmx_vec** resu
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_agg_or_gap_tiled), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e == hipSuccess) {
             hipLaunchKernelGGL(k_agg_or_gap_tiled, dim3((ncols + OR_TILE - 1) / OR_TILE), dim3(1024), lds, ctx->stream,
-                               (const u64* const*)d_descs, (const u32*)d_nblk, (u32)n, ncols, 0, v->d_bits, v->d_desc, st);
+                               (const u64* const*)d_descs, (const u32*)d_nblk, (u32)n, ncols, opt_compress, v->d_bits, v->d_desc, st);
             e = hipGetLastError();
         }
         if (e == hipSuccess) rc = result_finish(ctx, v, st, offs);
@@ -822,7 +838,7 @@ int bmx_agg_or(bmx_ctx* ctx, const bmx_vec* const* src, size_t n, bmx_vec** resu
                                (const u64* const*)d_descs, (const u32*)d_nblk, (u32)n, ncols, (u64*)d_dmat);
             size_t lds = has_gap ? 4 * 2048 * 4 : 0;
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_agg_or<2>), dim3((ncols + 3) / 4), dim3(256), lds, ctx->stream,
-                               (const u64*)d_dmat, (u32)n, ncols, 0 /* opt_mode_ = opt_none, :917 */, ctx->xcd_swz,
+                               (const u64*)d_dmat, (u32)n, ncols, opt_compress, ctx->xcd_swz,
                                v->d_bits, v->d_desc, st);
             e = hipGetLastError();
         }
@@ -876,6 +892,43 @@ int bmx_agg_and_sub(bmx_ctx* ctx, const bmx_vec* const* src_and, size_t n_and,
     if (rc) { bmx_vec_free(ctx, v); return rc; }
     if (any) *any = (v->counts[BMX_FULL] + v->counts[BMX_BIT] + v->counts[BMX_GAP]) != 0;
     *result = v;
+    return BMX_OK;
+}
+
+// combine_and_sub(pipe) with result vectors / counts / OR target (src/bmaggregator.h:1292-1449)
+int bmx_pipeline_run_results(bmx_ctx* ctx, bmx_pipeline* p, bmx_vec** results_out, uint64_t* counts_out,
+                             const bmx_vec* or_target_in, bmx_vec** or_target_out)
+{
+    ARGCHK(ctx && p && p->ctx == ctx && (results_out || or_target_out));
+    ARGCHK(!or_target_in || or_target_in->ctx == ctx);
+    int rc = set_dev(ctx); if (rc) return rc;
+    std::vector<bmx_vec*> res(p->ngroups, nullptr);
+    auto cleanup = [&]() { for (bmx_vec* r : res) if (r) bmx_vec_free(ctx, r); };
+    for (uint32_t g = 0; g < p->ngroups; ++g) {
+        if (counts_out) counts_out[g] = 0;
+        if (!(*p->h_and_n)[g] || !p->ncols) continue;                       // empty AND group: skipped (:1352)
+        bmx_vec* v; BlockStat* st; u32* offs;
+        if ((rc = result_begin(ctx, p->nbits, p->ncols, &v, &st, &offs))) { cleanup(); return rc; }
+        size_t lds = p->has_gap ? 4 * 2048 * 4 : 0;
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_agg_and_sub<2>), dim3((p->ncols + 3) / 4), dim3(256), lds, ctx->stream,
+                           p->d_dmat + (*p->h_row_off)[g], p->d_meta + p->ngroups + g, p->d_meta + 2 * p->ngroups + g,
+                           p->col_stride, p->ncols, 1 /* opt_compress, :1421 */, ctx->xcd_swz, v->d_bits, v->d_desc, st);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { bmx_vec_free(ctx, v); cleanup(); return fail_hip(e, "k_agg_and_sub", __LINE__); }
+        if ((rc = result_finish(ctx, v, st, offs))) { bmx_vec_free(ctx, v); cleanup(); return rc; }
+        if (v->counts[BMX_FULL] + v->counts[BMX_BIT] + v->counts[BMX_GAP] == 0) { bmx_vec_free(ctx, v); continue; }   // nothing found: stays NULL (:1406)
+        res[g] = v;
+        if (counts_out && (rc = bmx_count(ctx, v, &counts_out[g]))) { cleanup(); return rc; }
+    }
+    if (or_target_out) {
+        std::vector<const bmx_vec*> src;
+        if (or_target_in) src.push_back(or_target_in);
+        for (bmx_vec* r : res) if (r) src.push_back(r);
+        *or_target_out = nullptr;
+        if ((rc = agg_or_impl(ctx, src.data(), src.size(), 1 /* optimised at the end, :1440-1447 */, or_target_out))) { cleanup(); return rc; }
+    }
+    if (results_out) for (uint32_t g = 0; g < p->ngroups; ++g) results_out[g] = res[g];
+    else cleanup();
     return BMX_OK;
 }
 

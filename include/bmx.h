@@ -159,6 +159,15 @@ int bmx_pipeline_run_counts(bmx_ctx* ctx, bmx_pipeline* p, uint32_t nb_from, uin
  * (ngroups x uint64) -- e.g. the buffer a following RCCL all-reduce sums. */
 int bmx_pipeline_run_counts_dev(bmx_ctx* ctx, bmx_pipeline* p, uint32_t nb_from, uint32_t nb_to,
                                 uint64_t* d_counts);
+/* aggregator::combine_and_sub(pipe) for the other run options (src/bmaggregator.h:62-103):
+ *   results_out != NULL  -> Opt::is_make_results(): one vector per arg-group, NULL where the group found
+ *                           nothing (:1406-1415); blocks stored with opt_compress (:1421)
+ *   counts_out  != NULL  -> Opt::is_compute_counts()
+ *   or_target_out != NULL -> pipeline::set_or_target (:245): OR of or_target_in (may be NULL) and every
+ *                           group result, optimised (:1440-1447)
+ * set_search_count_limit (:255) is approximate by contract ("can find more"); it is accepted and ignored. */
+int bmx_pipeline_run_results(bmx_ctx* ctx, bmx_pipeline* p, bmx_vec** results_out, uint64_t* counts_out,
+                             const bmx_vec* or_target_in, bmx_vec** or_target_out);
 /* algorithmic operand bytes one run over [nb_from, nb_to) must read
  * (8192 B per bit-block operand, 2*(len+1) B per GAP operand; NULL/FULL: 0) */
 int bmx_pipeline_operand_bytes(bmx_ctx* ctx, bmx_pipeline* p, uint32_t nb_from, uint32_t nb_to,

@@ -262,8 +262,15 @@ inline size_type count_or(const bvector& a, const bvector& b) { return detail::c
 inline size_type count_xor(const bvector& a, const bvector& b) { return detail::count_op(BMX_XOR, a, b); }   // :81
 inline size_type count_sub(const bvector& a, const bvector& b) { return detail::count_op(BMX_SUB, a, b); }   // :115
 
-/// run options tag (src/bmaggregator.h:62-103): only the counts-only pipeline is on the path
-struct agg_opt_only_counts {};
+/// run options (src/bmaggregator.h:62-103)
+template <bool OBvects = true, bool OCounts = false>
+struct agg_run_options {
+    static constexpr bool is_make_results() noexcept { return OBvects; }
+    static constexpr bool is_compute_counts() noexcept { return OCounts; }
+};
+typedef agg_run_options<false, false> agg_opt_disable_bvects_and_counts;   // :84
+typedef agg_run_options<false, true> agg_opt_only_counts;                  // :92
+typedef agg_run_options<true, true> agg_opt_bvect_and_counts;              // :100
 
 /// bm::aggregator<BV> twin (src/bmaggregator.h:120)
 template <class BV = bvector>
@@ -286,12 +293,24 @@ public:
         }
     };
 
-    /// aggregator::pipeline<Opt> (src/bmaggregator.h:222-341), counts-only option
-    template <class Opt = agg_opt_only_counts>
+    /// aggregator::pipeline<Opt> (src/bmaggregator.h:222-341)
+    template <class Opt = agg_run_options<> >
     class pipeline {
     public:
+        typedef Opt options_type;
         explicit pipeline(context& ctx) : ctx_(&ctx) {}
-        ~pipeline() { if (h_) bmx_pipeline_destroy(ctx_->handle(), h_); for (size_t i = 0; i < groups_.size(); ++i) delete groups_[i]; }
+        ~pipeline()
+        {
+            if (h_) bmx_pipeline_destroy(ctx_->handle(), h_);
+            for (size_t i = 0; i < groups_.size(); ++i) delete groups_[i];
+            for (size_t i = 0; i < results_.size(); ++i) delete results_[i];
+        }
+        /// set_or_target (:245): group results are OR-ed into *bv_or (re-seated to the updated device vector)
+        void set_or_target(BV* bv_or) noexcept { or_target_ = bv_or; }
+        /// set_search_count_limit (:255): approximate by contract ("can find more"); accepted and ignored
+        void set_search_count_limit(size_type limit) noexcept { search_count_limit_ = limit; }
+        /// result vectors (nullptr where a group found nothing, :1406-1415); owned by the pipeline
+        std::vector<BV*>& get_bv_res_vector() noexcept { return results_; }
         pipeline(const pipeline&) = delete;
         pipeline& operator=(const pipeline&) = delete;
         arg_groups* add() { if (h_) throw error(BMX_ERR_BADARG, "pipeline already complete()"); groups_.push_back(new arg_groups()); return groups_.back(); }
@@ -315,6 +334,9 @@ public:
         context* ctx_;
         std::vector<arg_groups*> groups_;
         std::vector<size_type> counts_;
+        std::vector<BV*> results_;
+        BV* or_target_ = nullptr;
+        size_type search_count_limit_ = ~size_type(0);
         bmx_pipeline* h_ = nullptr;
     };
 
@@ -333,6 +355,7 @@ public:
     {
         std::vector<const bmx_vec*> h(src_size);
         for (size_t i = 0; i < src_size; ++i) h[i] = bv_src[i]->handle();
+        ag_.reset();                 // the reference clears the member arg-groups here (src/bmaggregator.h:1110)
         bmx_vec* r = nullptr;
         check(bmx_agg_or(ctx_->handle(), h.data(), src_size, &r));
         bv_target.adopt(r);
@@ -367,7 +390,25 @@ public:
     void combine_and_sub(TPipe& pipe)
     {
         if (!pipe.is_complete()) throw error(BMX_ERR_BADARG, "pipeline is not complete()");
-        if (pipe.size()) check(bmx_pipeline_run_counts(ctx_->handle(), pipe.h_, 0, 0xFFFFFFFFu, pipe.counts_.data()));
+        if (!pipe.size()) return;
+        typedef typename TPipe::options_type opt;
+        if (opt::is_make_results() || pipe.or_target_) {
+            std::vector<bmx_vec*> res(pipe.size(), nullptr);
+            bmx_vec* ort = nullptr;
+            const bmx_vec* ort_in = (pipe.or_target_ && !pipe.or_target_->empty_handle()) ? pipe.or_target_->handle() : nullptr;
+            check(bmx_pipeline_run_results(ctx_->handle(), pipe.h_, opt::is_make_results() ? res.data() : nullptr,
+                                           (opt::is_make_results() && opt::is_compute_counts()) ? pipe.counts_.data() : nullptr,
+                                           ort_in, pipe.or_target_ ? &ort : nullptr));
+            for (size_t i = 0; i < pipe.results_.size(); ++i) delete pipe.results_[i];
+            pipe.results_.assign(pipe.size(), nullptr);
+            for (size_t g = 0; g < res.size(); ++g)
+                if (res[g]) { pipe.results_[g] = new BV(*ctx_); pipe.results_[g]->adopt(res[g]); }
+            if (pipe.or_target_) pipe.or_target_->adopt(ort);
+            if (opt::is_compute_counts() && !opt::is_make_results())
+                check(bmx_pipeline_run_counts(ctx_->handle(), pipe.h_, 0, 0xFFFFFFFFu, pipe.counts_.data()));
+        } else if (opt::is_compute_counts()) {
+            check(bmx_pipeline_run_counts(ctx_->handle(), pipe.h_, 0, 0xFFFFFFFFu, pipe.counts_.data()));
+        }
     }
 
 private:

@@ -207,6 +207,10 @@ class Oracle:
         getattr(L, prefix + "count_to_test").argtypes = [vp, vp, C.c_uint64]
         getattr(L, prefix + "find_rank").restype = C.c_int
         getattr(L, prefix + "find_rank").argtypes = [vp, vp, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]
+        getattr(L, prefix + "agg_pipeline_results").restype = None
+        getattr(L, prefix + "agg_pipeline_results").argtypes = [
+            C.POINTER(vp), C.POINTER(C.c_uint32), C.POINTER(vp), C.POINTER(C.c_uint32), C.c_size_t,
+            C.POINTER(vp), C.POINTER(C.c_uint64), C.POINTER(vp)]
         getattr(L, prefix + "vec_find_first").restype = C.c_int
         getattr(L, prefix + "vec_find_first").argtypes = [vp, C.POINTER(C.c_uint64)]
         getattr(L, prefix + "find_first_and_sub").restype = C.c_int
@@ -304,6 +308,20 @@ class Oracle:
         self._f("agg_pipeline_counts")(self._ptrs(and_list), _u32p(and_n), self._ptrs(sub_list), _u32p(sub_n),
                                        len(groups), C.c_uint32(nb_from), C.c_uint32(nb_to), _u64p(out))
         return out
+
+    def pipeline_results(self, groups):
+        """-> (results: list[Vec|None], counts: np.ndarray, or_target: Vec)"""
+        and_list = [v for g in groups for v in g[0]]
+        sub_list = [v for g in groups for v in g[1]]
+        and_n = np.array([len(g[0]) for g in groups], np.uint32)
+        sub_n = np.array([len(g[1]) for g in groups], np.uint32)
+        nbits = max([v.nbits for v in and_list + sub_list], default=0)
+        res = (C.c_void_p * max(len(groups), 1))()
+        cnt = np.zeros(len(groups), np.uint64)
+        ort = C.c_void_p()
+        self._f("agg_pipeline_results")(self._ptrs(and_list), _u32p(and_n), self._ptrs(sub_list), _u32p(sub_n),
+                                        len(groups), res, _u64p(cnt), C.byref(ort))
+        return [Vec(self, res[g], nbits) if res[g] else None for g in range(len(groups))], cnt, Vec(self, ort, nbits)
 
     def find_first(self, v: Vec):
         pos = C.c_uint64()

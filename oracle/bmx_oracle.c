@@ -1108,6 +1108,30 @@ bmo_vec* bmo_agg_and_sub(const bmo_vec* const* src_and, size_t n_and,
     return t;
 }
 
+void bmo_agg_pipeline_results(const bmo_vec* const* and_list, const uint32_t* and_n,
+                              const bmo_vec* const* sub_list, const uint32_t* sub_n, size_t ngroups,
+                              bmo_vec** results_out, uint64_t* counts_out, bmo_vec** or_target_out)
+{
+    size_t ao = 0, so = 0;
+    uint64_t nbits = 0;
+    bmo_vec** tmp = (bmo_vec**)calloc(ngroups ? ngroups : 1, sizeof(*tmp));
+    size_t nres = 0;
+    for (size_t g = 0; g < ngroups; ao += and_n[g], so += sub_n[g], ++g) {
+        results_out[g] = NULL; counts_out[g] = 0;
+        if (!and_n[g]) continue;                                   /* :1352-1354 */
+        bmo_vec* t = bmo_agg_and_sub(and_list + ao, and_n[g], sub_list + so, sub_n[g]);
+        if (t->nbits > nbits) nbits = t->nbits;
+        uint64_t c = bmo_vec_count(t);
+        counts_out[g] = c;
+        if (c) { results_out[g] = t; tmp[nres++] = t; } else bmo_vec_free(t);   /* lazily created: NULL if nothing found */
+    }
+    bmo_vec* ort = bmo_agg_or((const bmo_vec* const*)tmp, nres);
+    if (ort->nbits < nbits) ort->nbits = nbits;
+    bmo_vec_optimize(ort);
+    *or_target_out = ort;
+    free(tmp);
+}
+
 static int block_find_first(const uint32_t* b, uint32_t* bit)      /* src/bmfunc.h:9499 bit_find_first */
 {
     for (unsigned i = 0; i < BMO_BLOCK_WORDS; ++i)

@@ -109,6 +109,13 @@ void     bmo_agg_pipeline_counts(const bmo_vec* const* and_list, const uint32_t*
                                  size_t ngroups, uint32_t nb_from, uint32_t nb_to,
                                  uint64_t* counts_out);
 
+/* pipeline<agg_opt_bvect_and_counts> + OR target (src/bmaggregator.h:1292-1449): per group a result
+ * vector (NULL when the group found nothing, :1406-1415), its count, and the OR of all results
+ * (optimised, :1440-1447) */
+void     bmo_agg_pipeline_results(const bmo_vec* const* and_list, const uint32_t* and_n,
+                                  const bmo_vec* const* sub_list, const uint32_t* sub_n, size_t ngroups,
+                                  bmo_vec** results_out, uint64_t* counts_out, bmo_vec** or_target_out);
+
 /* first set bit of a vector (bvector::find) and of an AND-SUB aggregation without materialising
  * (aggregator::find_first_and_sub, src/bmaggregator.h:1458).  Logical definition; the reference
  * additionally narrows the searched sub-array range by the SUB group (its own ":1526 TODO"). */

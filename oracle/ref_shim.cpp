@@ -205,6 +205,35 @@ void ref_agg_pipeline_counts(void* const* and_list, const uint32_t* and_n,
     for (size_t g = 0; g < ngroups; ++g) counts_out[g] = cnt[g];
 }
 
+// full pipeline: pipeline<agg_opt_bvect_and_counts> with an OR target (bmaggregator.h:62-103,222-341,1292-1449)
+// results_out[g] = new bvector (caller frees with ref_vec_free) or NULL when the group found nothing;
+// *or_target_out = new bvector holding the OR of all group results.
+void ref_agg_pipeline_results(void* const* and_list, const uint32_t* and_n,
+                              void* const* sub_list, const uint32_t* sub_n, size_t ngroups,
+                              void** results_out, uint64_t* counts_out, void** or_target_out)
+{
+    agg_t agg;
+    agg_t::pipeline<bm::agg_opt_bvect_and_counts> pipe;
+    bvect* ort = new bvect();
+    pipe.set_or_target(ort);
+    size_t ao = 0, so = 0;
+    for (size_t g = 0; g < ngroups; ++g) {
+        agg_t::arg_groups* ag = pipe.add();
+        for (uint32_t k = 0; k < and_n[g]; ++k) ag->add(static_cast<const bvect*>(and_list[ao + k]), 0);
+        for (uint32_t k = 0; k < sub_n[g]; ++k) ag->add(static_cast<const bvect*>(sub_list[so + k]), 1);
+        ao += and_n[g]; so += sub_n[g];
+    }
+    pipe.complete();
+    agg.combine_and_sub(pipe);
+    auto& res = pipe.get_bv_res_vector();
+    auto& cnt = pipe.get_bv_count_vector();
+    for (size_t g = 0; g < ngroups; ++g) {
+        counts_out[g] = cnt[g];
+        results_out[g] = res[g] ? new bvect(*res[g]) : nullptr;
+    }
+    *or_target_out = ort;
+}
+
 // rank / select: bm.h:2531 build_rs_index, :3120 count_to, :5350 select
 struct ref_rs { bvect::rs_index_type rs; };
 

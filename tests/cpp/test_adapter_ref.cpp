@@ -78,6 +78,32 @@ int main()
         rp.complete(); gp.complete();
         ragg.combine_and_sub(rp); gagg.combine_and_sub(gp);
         for (unsigned g = 0; g < 3; ++g) REQUIRE(gp.get_bv_count_vector()[g] == rp.get_bv_count_vector()[g]);
+        // results + counts + OR target vs the reference pipeline<agg_opt_bvect_and_counts>
+        bm::aggregator<bvect>::pipeline<bm::agg_opt_bvect_and_counts> rp2;
+        bmx::aggregator<bmx::bvector>::pipeline<bmx::agg_opt_bvect_and_counts> gp2(ctx);
+        bvect r_or; bmx::bvector g_or(ctx);
+        rp2.set_or_target(&r_or); gp2.set_or_target(&g_or);
+        for (unsigned g = 0; g < 4; ++g) {
+            auto* ra = rp2.add(); auto* ga = gp2.add();
+            for (unsigned v = g; v < NV; v += 2) { ra->add(&hv[v], 0); ga->add(&gv[v], 0); }
+            if (g & 1) { ra->add(&hv[0], 1); ga->add(&gv[0], 1); }
+        }
+        rp2.complete(); gp2.complete();
+        ragg.combine_and_sub(rp2); gagg.combine_and_sub(gp2);
+        for (unsigned g = 0; g < 4; ++g) {
+            REQUIRE(gp2.get_bv_count_vector()[g] == rp2.get_bv_count_vector()[g]);
+            const bvect* rr = rp2.get_bv_res_vector()[g]; bmx::bvector* gr = gp2.get_bv_res_vector()[g];
+            REQUIRE((rr == nullptr) == (gr == nullptr));
+            if (rr) { bvect got; bmx::download(*gr, got); REQUIRE(got.compare(*rr) == 0); }
+        }
+        bvect got_or; bmx::download(g_or, got_or);
+        REQUIRE(got_or.compare(r_or) == 0);
+        // find_first_and_sub vs the reference
+        bvect::size_type ri = 0; bmx::size_type gi = 0;
+        bool rf = ragg.find_first_and_sub(ri), gf = gagg.find_first_and_sub(gi);
+        if (!(rf == gf && (!rf || ri == gi))) std::fprintf(stderr, "find_first_and_sub: reference %d %llu, device %d %llu\n",
+                                                           (int)rf, (unsigned long long)ri, (int)gf, (unsigned long long)gi);
+        REQUIRE(rf == gf && (!rf || ri == gi));
     }
     // rank / select vs bvector<>::count_to / select with the reference rs_index
     {

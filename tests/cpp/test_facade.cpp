@@ -67,15 +67,16 @@ int main()
     const bmo_vec* a4[4] = {pv[0], pv[1], pv[2], pv[3]}; const bmo_vec* s1[1] = {pv[8]};
     bmo_vec* e = bmo_agg_and_sub(a4, 4, s1, 1);
     REQUIRE(t.count() == bmo_vec_count(e) && any == (bmo_vec_count(e) != 0));
-    agg.combine_or(t);
-    bmo_vec* eo = bmo_agg_or(a4, 4);
-    REQUIRE(t.count() == bmo_vec_count(eo));
     {
         bmx::size_type idx = 0; uint64_t pidx = 0;
         bool f = agg.find_first_and_sub(idx);
         int pf = bmo_find_first_and_sub(a4, 4, s1, 1, &pidx);
         REQUIRE(f == (pf != 0) && (!f || idx == pidx));
     }
+    agg.combine_or(t);                                  // also clears the arg-groups (reference :1110)
+    bmo_vec* eo = bmo_agg_or(a4, 4);
+    REQUIRE(t.count() == bmo_vec_count(eo));
+    { bmx::size_type idx = 0; REQUIRE(!agg.find_first_and_sub(idx)); }
     bmo_vec_free(e); bmo_vec_free(eo);
     // counts-only pipeline
     bmx::aggregator<bmx::bvector>::pipeline<bmx::agg_opt_only_counts> pipe(ctx);

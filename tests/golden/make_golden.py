@@ -77,6 +77,14 @@ def run(R, P):
         cnt = R.pipeline_counts([([vecs[i] for i in a], [vecs[i] for i in s]) for (a, s) in AGG_GROUPS])
         c["pipeline_counts"] = [int(x) for x in cnt]
         assert c["pipeline_counts"] == [g["count"] for g in c["agg_and_sub"]]
+        # full pipeline (agg_opt_bvect_and_counts + OR target), AggregatorTest t.cpp:10378-10580 shape
+        res, rc, ort = R.pipeline_results([([vecs[i] for i in a], [vecs[i] for i in s_]) for (a, s_) in AGG_GROUPS])
+        assert [int(x) for x in rc] == c["pipeline_counts"]
+        c["pipeline_results"] = {
+            "present": [r is not None for r in res],
+            "sha": [sha(r.to_words()) if r is not None else None for r in res],
+            "kinds": [r.flatten()[0].tolist() if r is not None else None for r in res],
+            "or_target_sha": sha(ort.to_words()), "or_target_kinds": ort.flatten()[0].tolist(), "or_target_count": ort.count()}
         # rank / select
         c["rs"] = []
         for vi in (0, 1, 2):

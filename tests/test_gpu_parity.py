@@ -114,6 +114,34 @@ def test_golden_case(ctx, port, golden, case):
     nb = vecs[0].info()["nblocks"]
     parts = sum(agg._run_pipeline(pipe, a, b).astype(np.int64) for a, b in [(0, 1), (1, nb)])
     assert parts.tolist() == g["pipeline_counts"]
+    # the other run options: result vectors + counts + OR target (pipeline<agg_opt_bvect_and_counts>)
+    pr = g["pipeline_results"]
+    for opt in (bm.agg_opt_bvect_and_counts, bm.agg_run_options(), bm.agg_opt_disable_bvects_and_counts):
+        p2 = bm.aggregator.pipeline(ctx, opt)
+        p2.set_or_target()
+        for (a, s) in AGG_GROUPS:
+            ag = p2.add()
+            for i in a: ag.add(vecs[i], 0)
+            for i in s: ag.add(up[i], 1)
+        p2.complete()
+        agg.combine_and_sub(p2)
+        ort = p2.get_or_target()
+        assert sha(ort.to_words(nwb)) == pr["or_target_sha"] and ort.count() == pr["or_target_count"]
+        assert ort.block_table()[0].tolist() == pr["or_target_kinds"]
+        if opt.is_make_results():
+            res = p2.get_bv_res_vector()
+            assert [r is not None for r in res] == pr["present"]
+            assert [sha(r.to_words(nwb)) if r is not None else None for r in res] == pr["sha"]
+            assert [r.block_table()[0].tolist() if r is not None else None for r in res] == pr["kinds"]
+        if opt.is_compute_counts():
+            assert [int(x) for x in p2.get_bv_count_vector()] == g["pipeline_counts"]
+    # an OR target that already holds bits keeps them (combine_operation_block_or into the target, :1378-1389)
+    p3 = bm.aggregator.pipeline(ctx, bm.agg_run_options())
+    p3.set_or_target(vecs[5])
+    ag = p3.add(); ag.add(vecs[0], 0); ag.add(vecs[1], 0)
+    p3.complete(); agg.combine_and_sub(p3)
+    exp = port.agg_or([port.import_words(words[5], True, nbits), port.agg_and_sub([port.import_words(words[0], True, nbits), port.import_words(words[1], True, nbits)])])
+    assert (p3.get_or_target().to_words(nwb) == exp.to_words(nwb)).all()
     for e in g["rs"]:
         v = vecs[e["vec"]]
         rs = v.build_rs_index()
@@ -212,9 +240,10 @@ def test_kats_from_reference_tests(ctx, port):
     agg = bm.aggregator(ctx)
     a, b = mk([1, 2, 3]), mk([0, 4, 5])
     agg.add(a); agg.add(b)
+    assert agg.combine_and().count() == 0
     t = agg.combine_or()
     assert t.count() == 6 and (t.to_words(1)[0] == 0b111111)
-    assert agg.combine_and().count() == 0
+    assert agg.ag.arg_bv0 == []           # combine_or clears the arg-groups like the reference (:1110)
     agg.reset()
     c = mk([1, 2, 3, 4, 5, 70000])
     t, any_ = agg.combine_and_sub([c], [a])
