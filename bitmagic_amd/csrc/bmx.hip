@@ -51,6 +51,8 @@ struct bmx_ctx {
     int pipe_nt = 1;           // non-temporal operand loads (+4.5 % on the streamed-once headline case)
     int pipe_wg = 256;         // workgroup size of the counts kernel
     int pipe_ver = 2;          // 1 = k_pipe_counts_bits, 2 = software-pipelined k_pipe_counts_bits2
+    int pipe_staged = -1;      // LDS-staged many-groups kernel: -1 auto, 0 never, 1 whenever possible
+    int pipe_slots = 16;       // plane blocks staged at a time (16: 1024-thread WG; 8: two 512-thread WGs per CU)
     int xcd_swz = 1;
 };
 
@@ -67,6 +69,9 @@ struct bmx_pipeline {
     uint32_t ngroups, ncols, col_stride, n_ops;
     bool has_gap;
     uint64_t nbits;                       // max size of the operands
+    // LDS-staged path (k_pipe_counts_staged): distinct vectors ("planes") + per-group plane masks
+    uint32_t nplanes, nchunks; bool staged_ok;
+    const u64** d_udesc; u32* d_unblk; u32* d_gmask; u32* d_gskip;
     std::vector<u32>* h_row_off;          // host copy: row offset of each group inside a column record
     std::vector<u32>* h_and_n;            // host copy: AND operands per group
     u64* d_dmat;
@@ -222,6 +227,8 @@ int bmx_ctx_set_tuning(bmx_ctx* ctx, const char* key, int value)
     if (k == "pipe_unroll") { ARGCHK(value == 1 || value == 2 || value == 4); ctx->pipe_unroll = value; }
     else if (k == "pipe_rows") { ARGCHK(value == 8 || value == 4 || value == 2 || value == 1); ctx->pipe_rows = value; }
     else if (k == "pipe_nt") ctx->pipe_nt = value != 0;
+    else if (k == "pipe_slots") { ARGCHK(value == 8 || value == 16); ctx->pipe_slots = value; }
+    else if (k == "pipe_staged") { ARGCHK(value >= -1 && value <= 1); ctx->pipe_staged = value; }
     else if (k == "pipe_ver") { ARGCHK(value == 1 || value == 2); ctx->pipe_ver = value; }
     else if (k == "pipe_wg") { ARGCHK(value == 64 || value == 128 || value == 256); ctx->pipe_wg = value; }
     else if (k == "xcd_swizzle") ctx->xcd_swz = value != 0;
@@ -553,6 +560,41 @@ int bmx_pipeline_create(bmx_ctx* ctx, const bmx_vec* const* and_list, const uint
     p->nbits = max_bits;
     p->h_row_off = new std::vector<u32>(row_off, row_off + ngroups);
     p->h_and_n = new std::vector<u32>(m_and_n, m_and_n + ngroups);
+    // distinct vectors of the pipeline (pipeline::unique_vectors(), src/bmaggregator.h:301) and the
+    // (AND | SUB << 16) plane masks of every group, 16 planes per chunk
+    {
+        std::unordered_map<const u64*, u32> plane_of;
+        std::vector<const u64*> udesc; std::vector<u32> unblk;
+        auto plane = [&](size_t op) {
+            auto it = plane_of.find(descs[op]);
+            if (it != plane_of.end()) return it->second;
+            u32 id = (u32)udesc.size(); plane_of.emplace(descs[op], id);
+            udesc.push_back(descs[op]); unblk.push_back(nblk[op]);
+            return id;
+        };
+        std::vector<u32> plane_id(std::max<size_t>(n_ops, 1));
+        for (size_t op = 0; op < n_ops; ++op) plane_id[op] = plane(op);
+        p->nplanes = (uint32_t)udesc.size();
+        p->nchunks = (p->nplanes + 15u) / 16u;
+        p->staged_ok = p->nplanes > 0 && (size_t)ngroups * p->nchunks < (1u << 28);
+        if (p->staged_ok) {
+            std::vector<u32> gmask((size_t)ngroups * std::max<u32>(p->nchunks, 1), 0), gskip(ngroups, 0);
+            size_t a0 = 0, s0 = 0;
+            for (size_t g = 0; g < ngroups; ++g) {
+                gskip[g] = and_n[g] == 0;
+                for (uint32_t k = 0; k < and_n[g]; ++k) { u32 pl = plane_id[a0 + k]; gmask[g * p->nchunks + pl / 16] |= 1u << (pl % 16); }
+                for (uint32_t k = 0; k < sub_n[g]; ++k) { u32 pl = plane_id[tot_and + s0 + k]; gmask[g * p->nchunks + pl / 16] |= 1u << (16 + pl % 16); }
+                a0 += and_n[g]; s0 += sub_n[g];
+            }
+            if ((rc = dmalloc(ctx, (void**)&p->d_udesc, udesc.size() * 8)) || (rc = dmalloc(ctx, (void**)&p->d_unblk, unblk.size() * 4)) ||
+                (rc = dmalloc(ctx, (void**)&p->d_gmask, gmask.size() * 4)) || (rc = dmalloc(ctx, (void**)&p->d_gskip, gskip.size() * 4))) { bmx_pipeline_destroy(ctx, p); return rc; }
+            HIPCHK(hipMemcpyAsync(p->d_udesc, udesc.data(), udesc.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+            HIPCHK(hipMemcpyAsync(p->d_unblk, unblk.data(), unblk.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+            HIPCHK(hipMemcpyAsync(p->d_gmask, gmask.data(), gmask.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+            HIPCHK(hipMemcpyAsync(p->d_gskip, gskip.data(), gskip.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+            HIPCHK(hipStreamSynchronize(ctx->stream));     // the host vectors die at the end of this scope
+        }
+    }
     size_t b_dmat = (size_t)std::max<uint32_t>(ncols, 1) * col_stride * 8, b_meta = meta.size() * 4, b_descs = descs.size() * 8;
     if ((rc = dmalloc(ctx, (void**)&p->d_dmat, b_dmat)) || (rc = dmalloc(ctx, (void**)&p->d_meta, b_meta)) ||
         (rc = dmalloc(ctx, (void**)&p->d_descs, b_descs))) { bmx_pipeline_destroy(ctx, p); return rc; }
@@ -582,6 +624,7 @@ int bmx_pipeline_destroy(bmx_ctx* ctx, bmx_pipeline* p)
     int rc = set_dev(ctx); if (rc) return rc;
     HIPCHK(hipStreamSynchronize(ctx->stream));
     dfree(ctx, p->d_dmat); dfree(ctx, p->d_meta); dfree(ctx, (void*)p->d_descs);
+    dfree(ctx, (void*)p->d_udesc); dfree(ctx, p->d_unblk); dfree(ctx, p->d_gmask); dfree(ctx, p->d_gskip);
     delete p->h_row_off; delete p->h_and_n;
     delete p;
     return BMX_OK;
@@ -603,6 +646,23 @@ int bmx_pipeline_run_counts_dev(bmx_ctx* ctx, bmx_pipeline* p, uint32_t nb_from,
     u64 nitems64 = (u64)(nb_to - nb_from) * p->ngroups;
     if (!nitems64) return BMX_OK;
     const u32* row_off = p->d_meta; const u32* and_n = p->d_meta + p->ngroups; const u32* sub_n = p->d_meta + 2 * p->ngroups;
+    {
+        // many groups over few distinct vectors: every plane block is re-used >= 8 times per column
+        bool reuse = p->ngroups >= 32 && (uint64_t)p->n_ops >= 8ull * p->nplanes;
+        bool use_staged = p->staged_ok && (ctx->pipe_staged == 1 || (ctx->pipe_staged < 0 && reuse));
+        if (use_staged) {
+            size_t lds = (size_t)ctx->pipe_slots * 8192;
+#define LAUNCH_STG(S) do { \
+            HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pipe_counts_staged<S>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pipe_counts_staged<S>), dim3(nb_to - nb_from), dim3(S * 64), lds, ctx->stream, \
+                               (const u64* const*)p->d_udesc, (const u32*)p->d_unblk, p->nplanes, (const u32*)p->d_gmask, (const u32*)p->d_gskip, \
+                               p->ngroups, nb_from, nb_to - nb_from, ctx->xcd_swz, (u64*)d_counts); } while (0)
+            if (ctx->pipe_slots == 8) LAUNCH_STG(8); else LAUNCH_STG(16);
+#undef LAUNCH_STG
+            KCHK();
+            return BMX_OK;
+        }
+    }
     if (!p->has_gap) {
         // bit-block-only fast path: (column, group, slice) items
         u32 rows = (u32)ctx->pipe_rows, parts = 8u / rows;

@@ -378,8 +378,17 @@ def test_launch_shape_knobs_do_not_change_results(ctx, port):
                                 ctx.set_tuning(k, x)
                             got = agg.combine_and_sub(pipe)
                             assert (got == exp).all(), (ver, u, rows, nt, wg, swz)
+        # LDS-staged many-groups kernel forced on (19 planes = 2 chunks, FULL / NULL planes, AND-SUB masks)
+        for swz, slots in ((0, 16), (1, 16), (1, 8)):
+            ctx.set_tuning("pipe_staged", 1); ctx.set_tuning("xcd_swizzle", swz); ctx.set_tuning("pipe_slots", slots)
+            got = agg.combine_and_sub(pipe)
+            assert (got == exp).all(), ("staged", swz, got, exp)
+            nb = gv[0].info()["nblocks"]
+            parts = sum(agg._run_pipeline(pipe, a, b).astype(np.int64) for a, b in [(0, 5), (5, nb)])
+            assert (parts == exp.astype(np.int64)).all()
     finally:
-        for k, x in (("pipe_ver", 2), ("pipe_unroll", 4), ("pipe_rows", 8), ("pipe_nt", 1), ("pipe_wg", 256), ("xcd_swizzle", 1)):
+        for k, x in (("pipe_ver", 2), ("pipe_unroll", 4), ("pipe_rows", 8), ("pipe_nt", 1), ("pipe_wg", 256), ("xcd_swizzle", 1),
+                     ("pipe_staged", -1), ("pipe_slots", 16)):
             ctx.set_tuning(k, x)
     # the materialising twins use the same fold: every prefix, AND-SUB and OR
     for a, s in groups[::4]:
@@ -417,3 +426,8 @@ def test_many_gap_operands(ctx, port, dq, nvec):
         for i in s: ag.add(gv[i], 1)
         pipe.complete()
         assert int(agg.combine_and_sub(pipe)[0]) == e.count()
+        ctx.set_tuning("pipe_staged", 1)               # GAP planes expanded into LDS by the staged kernel
+        try:
+            assert int(agg.combine_and_sub(pipe)[0]) == e.count()
+        finally:
+            ctx.set_tuning("pipe_staged", -1)
