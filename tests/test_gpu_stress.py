@@ -1,0 +1,147 @@
+"""GPU randomized differential stress test -- the analogue of StressTest / FillSetsRandomMethod
+(tests/stress/t.cpp:917,11439): random block tables (every block independently NULL / FULL / bit / GAP with
+random run structure, un-optimised representations included), random operations, compared with the oracle."""
+import numpy as np
+import pytest
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+import bitmagic_amd as bm  # noqa: E402
+
+
+def _random_block(rng, kind):
+    """-> 2048 uint32 words of one block of the requested flavour"""
+    if kind == "zero":
+        return np.zeros(2048, np.uint32)
+    if kind == "ones":
+        return np.full(2048, 0xFFFFFFFF, np.uint32)
+    if kind == "dense":
+        return rng.integers(0, 1 << 32, size=2048, dtype=np.uint64).astype(np.uint32)
+    if kind == "sparse":
+        w = np.zeros(2048, np.uint32)
+        for p in rng.integers(0, 65536, size=int(rng.integers(1, 200))):
+            w[p >> 5] |= np.uint32(1 << (int(p) & 31))
+        return w
+    if kind == "runs":                       # a few long runs: GAP with big interiors
+        bits = np.zeros(65536, np.uint8)
+        pos = np.sort(rng.integers(0, 65536, size=2 * int(rng.integers(1, 40))))
+        for a, b in zip(pos[::2], pos[1::2]):
+            bits[a:b + 1] = 1
+        return np.packbits(bits, bitorder="little").view(np.uint32).copy()
+    if kind == "antisparse":                 # almost all ones
+        w = np.full(2048, 0xFFFFFFFF, np.uint32)
+        for p in rng.integers(0, 65536, size=int(rng.integers(1, 100))):
+            w[p >> 5] &= np.uint32(~(1 << (int(p) & 31)) & 0xFFFFFFFF)
+        return w
+    if kind == "edge":                       # bits at block / word / wave borders
+        w = np.zeros(2048, np.uint32)
+        for p in (0, 31, 32, 1023, 1024, 21824, 21825, 43648, 65535):
+            if rng.integers(0, 2): w[p >> 5] |= np.uint32(1 << (p & 31))
+        return w
+    raise ValueError(kind)
+
+
+KINDS = ["zero", "ones", "dense", "sparse", "runs", "antisparse", "edge"]
+
+
+def _random_vector(rng, port, ctx, nblocks, optimize):
+    words = np.concatenate([_random_block(rng, KINDS[int(rng.integers(0, len(KINDS)))]) for _ in range(nblocks)])
+    pv = port.import_words(words, optimize, nblocks * 65536)
+    if rng.integers(0, 2):                  # half of the vectors go through the host block-table upload
+        k, o, b, g = pv.flatten()
+        gv = bm.bvector.from_block_table(ctx, nblocks * 65536, k, o, b, g)
+    else:
+        gv = bm.bit_import_u32(ctx, words, optimize)
+    return pv, gv
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_block_tables(ctx, port, seed):
+    rng = np.random.default_rng(1000 + seed)
+    nvec = int(rng.integers(3, 14))
+    vecs = [_random_vector(rng, port, ctx, int(rng.integers(1, 9)), bool(rng.integers(0, 2))) for _ in range(nvec)]
+    pv = [v[0] for v in vecs]; gv = [v[1] for v in vecs]
+    nwb = 9 * 2048
+    agg = bm.aggregator(ctx)
+    for v, g in zip(pv, gv):
+        assert g.count() == v.count()
+        assert (g.to_words(nwb) == v.to_words(nwb)).all()
+    for _ in range(12):
+        i, j = (int(x) for x in rng.integers(0, nvec, 2))
+        op = int(rng.integers(0, 4)); opt = bm.opt_compress if rng.integers(0, 2) else bm.opt_none
+        t = bm.bvector._op2(op, gv[i], gv[j], opt)
+        e = port.op2(op, pv[i], pv[j], opt == bm.opt_compress)
+        assert (t.to_words(nwb) == e.to_words(nwb)).all(), (seed, op, i, j)
+        assert bm._count_op2(op, gv[i], gv[j]) == port.count_op2(op, pv[i], pv[j]) == e.count()
+    groups = []
+    for _ in range(10):
+        na = int(rng.integers(1, nvec + 1)); ns = int(rng.integers(0, nvec))
+        a = [int(x) for x in rng.integers(0, nvec, na)]; s = [int(x) for x in rng.integers(0, nvec, ns)]
+        groups.append((a, s))
+        t, any_ = agg.combine_and_sub([gv[k] for k in a], [gv[k] for k in s])
+        e = port.agg_and_sub([pv[k] for k in a], [pv[k] for k in s])
+        assert (t.to_words(nwb) == e.to_words(nwb)).all(), (seed, a, s)
+        assert any_ == (e.count() > 0)
+        f, idx = agg.find_first_and_sub([gv[k] for k in a], [gv[k] for k in s])
+        pf, pidx = port.find_first_and_sub([pv[k] for k in a], [pv[k] for k in s])
+        assert f == pf and (not f or idx == pidx), (seed, a, s, f, idx, pf, pidx)
+        o = agg.combine_or([gv[k] for k in a + s])
+        assert (o.to_words(nwb) == port.agg_or([pv[k] for k in a + s]).to_words(nwb)).all()
+    exp = port.pipeline_counts([([pv[k] for k in a], [pv[k] for k in s]) for a, s in groups])
+    for staged in (0, 1):
+        ctx.set_tuning("pipe_staged", staged)
+        try:
+            pipe = bm.aggregator.pipeline(ctx)
+            for a, s in groups:
+                ag = pipe.add()
+                for k in a: ag.add(gv[k], 0)
+                for k in s: ag.add(gv[k], 1)
+            pipe.complete()
+            assert (agg.combine_and_sub(pipe) == exp).all(), (seed, staged)
+        finally:
+            ctx.set_tuning("pipe_staged", -1)
+    # rank / select on a random member
+    k = int(rng.integers(0, nvec))
+    rs, prs = gv[k].build_rs_index(), port.rs_build(pv[k])
+    nbits = pv[k].nbits
+    q = rng.integers(0, nbits, size=400).astype(np.uint64)
+    assert (gv[k].rank(q, rs) == prs.rank(q)).all()
+    c = pv[k].count()
+    r = rng.integers(0, c + 2, size=400).astype(np.uint64)
+    found, pos = gv[k].select(r, rs)
+    ppos, pfound = prs.select(r)
+    assert (found == pfound).all() and (pos[found] == ppos[pfound]).all()
+    bc, sub = rs.export(); pbc, psub = prs.export()
+    assert (bc == pbc).all() and (sub == psub).all()
+
+
+def test_error_behaviour(ctx):
+    """status codes follow libbm's (lang-maps/libbm/include/libbm.h:28-35): BADARG = 2, RANGE = 3"""
+    one = bm.bit_import_u32(ctx, np.array([5], np.uint32))
+    with pytest.raises(bm.BmxError) as e:
+        ctx.set_tuning("no_such_knob", 1)
+    assert e.value.status == 2
+    # malformed block tables are rejected, not trusted
+    with pytest.raises(bm.BmxError) as e:
+        bm.bvector.from_block_table(ctx, 65536, [bm.BIT], [3], np.zeros(2048, np.uint32), np.zeros(0, np.uint16))
+    assert e.value.status == 3
+    with pytest.raises(bm.BmxError) as e:                      # GAP block whose last run end is not 65535
+        bm.bvector.from_block_table(ctx, 65536, [bm.GAP], [0], np.zeros(0, np.uint32), np.array([2 << 3, 100, 200], np.uint16))
+    assert e.value.status == 3
+    with pytest.raises(bm.BmxError) as e:
+        bm.bvector.from_block_table(ctx, 65536, [7], [0], np.zeros(0, np.uint32), np.zeros(0, np.uint16))
+    assert e.value.status == 2
+    pipe = bm.aggregator.pipeline(ctx)
+    with pytest.raises(RuntimeError):
+        bm.aggregator(ctx).combine_and_sub(pipe)               # not complete()
+    ag = pipe.add(); ag.add(one, 0); pipe.complete()
+    with pytest.raises(RuntimeError):
+        pipe.add()                                             # no add() after complete()
+    with pytest.raises(bm.BmxError) as e:                      # block range upside down
+        bm.aggregator(ctx)._run_pipeline(pipe, 5, 2)
+    assert e.value.status == 3
+    # the allocator cache can be returned to the driver at any time
+    before = ctx.mem_used(); ctx.trim(); assert ctx.mem_used() == before
+    assert one.count() == 2
