@@ -49,9 +49,11 @@ struct bmx_ctx {
     int pipe_unroll = 4;       // operand blocks per batch (two batches in flight in the v2 kernel)
     int pipe_rows = 8;         // register rows per work item (8 = whole block, 4/2/1 = slices)
     int pipe_nt = 1;           // non-temporal operand loads (+4.5 % on the streamed-once headline case)
-    int pipe_wg = 256;         // workgroup size of the counts kernel
+    int pipe_wg = 384;         // workgroup size of the bit-only counts kernel: 6 adjacent columns per workgroup, 2 workgroups per CU
+                               // (+6 % over 256 in the A/B sweep: co-scheduled waves read one contiguous stretch of each operand)
     int pipe_ver = 2;          // 1 = k_pipe_counts_bits, 2 = software-pipelined k_pipe_counts_bits2
     int pipe_staged = -1;      // LDS-staged many-groups kernel: -1 auto, 0 never, 1 whenever possible
+    int pipe_lds = 0;          // experiment: dynamic LDS bytes requested by the bit-only counts kernel (occupancy throttle)
     int pipe_slots = 16;       // plane blocks staged at a time (16: 1024-thread WG; 8: two 512-thread WGs per CU)
     int xcd_swz = 1;
 };
@@ -227,10 +229,11 @@ int bmx_ctx_set_tuning(bmx_ctx* ctx, const char* key, int value)
     if (k == "pipe_unroll") { ARGCHK(value == 1 || value == 2 || value == 4); ctx->pipe_unroll = value; }
     else if (k == "pipe_rows") { ARGCHK(value == 8 || value == 4 || value == 2 || value == 1); ctx->pipe_rows = value; }
     else if (k == "pipe_nt") ctx->pipe_nt = value != 0;
+    else if (k == "pipe_lds") { ARGCHK(value >= 0 && value <= 160 * 1024); ctx->pipe_lds = value; }
     else if (k == "pipe_slots") { ARGCHK(value == 8 || value == 16); ctx->pipe_slots = value; }
     else if (k == "pipe_staged") { ARGCHK(value >= -1 && value <= 1); ctx->pipe_staged = value; }
     else if (k == "pipe_ver") { ARGCHK(value == 1 || value == 2); ctx->pipe_ver = value; }
-    else if (k == "pipe_wg") { ARGCHK(value == 64 || value == 128 || value == 256); ctx->pipe_wg = value; }
+    else if (k == "pipe_wg") { ARGCHK(value >= 64 && value <= 1024 && value % 64 == 0); ctx->pipe_wg = value; }
     else if (k == "xcd_swizzle") ctx->xcd_swz = value != 0;
     else { g_last_error = "unknown tuning key"; return BMX_ERR_BADARG; }
     return BMX_OK;
@@ -670,16 +673,30 @@ int bmx_pipeline_run_counts_dev(bmx_ctx* ctx, bmx_pipeline* p, uint32_t nb_from,
         if (n64 > 0xFFFFFFF0ull) { g_last_error = "too many work items in one run"; return BMX_ERR_RANGE; }
         if (ctx->pipe_ver == 2) {
             u32 nitems = (u32)nitems64, wpb = (u32)ctx->pipe_wg / 64u, grid = (nitems + wpb - 1) / wpb;
-#define LAUNCH_B2(U, NT) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pipe_counts_bits2<U, NT>), dim3(grid), dim3(ctx->pipe_wg), 0, ctx->stream, \
+#define LAUNCH_B2(U, NT, WG) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pipe_counts_bits2<U, NT, WG>), dim3(grid), dim3(ctx->pipe_wg), (size_t)ctx->pipe_lds, ctx->stream, \
         p->d_dmat, row_off, and_n, p->col_stride, p->ngroups, nb_from, nitems, ctx->xcd_swz, (u64*)d_counts)
-            if (ctx->pipe_nt) { switch (ctx->pipe_unroll) { case 1: LAUNCH_B2(1, true); break; case 4: LAUNCH_B2(4, true); break; default: LAUNCH_B2(2, true); break; } }
-            else { switch (ctx->pipe_unroll) { case 1: LAUNCH_B2(1, false); break; case 4: LAUNCH_B2(4, false); break; default: LAUNCH_B2(2, false); break; } }
+            if (ctx->pipe_wg == 1024) { if (ctx->pipe_nt) LAUNCH_B2(2, true, 1024); else LAUNCH_B2(2, false, 1024); }   // 128 VGPRs max
+            else if (ctx->pipe_wg == 768) { if (ctx->pipe_nt) LAUNCH_B2(4, true, 768); else LAUNCH_B2(4, false, 768); }
+            else if (ctx->pipe_wg == 640) { if (ctx->pipe_nt) LAUNCH_B2(4, true, 640); else LAUNCH_B2(4, false, 640); }
+            else if (ctx->pipe_wg == 576) { if (ctx->pipe_nt) LAUNCH_B2(4, true, 576); else LAUNCH_B2(4, false, 576); }
+            else if (ctx->pipe_wg == 448) { if (ctx->pipe_nt) LAUNCH_B2(4, true, 448); else LAUNCH_B2(4, false, 448); }
+            else if (ctx->pipe_wg == 384) { if (ctx->pipe_nt) LAUNCH_B2(4, true, 384); else LAUNCH_B2(4, false, 384); }
+            else if (ctx->pipe_wg == 320) { if (ctx->pipe_nt) LAUNCH_B2(4, true, 320); else LAUNCH_B2(4, false, 320); }
+            else if (ctx->pipe_wg == 192) { if (ctx->pipe_nt) LAUNCH_B2(4, true, 192); else LAUNCH_B2(4, false, 192); }
+            else if (ctx->pipe_wg == 512) {
+                if (ctx->pipe_nt) { switch (ctx->pipe_unroll) { case 1: LAUNCH_B2(1, true, 512); break; case 4: LAUNCH_B2(4, true, 512); break; default: LAUNCH_B2(2, true, 512); break; } }
+                else { switch (ctx->pipe_unroll) { case 1: LAUNCH_B2(1, false, 512); break; case 4: LAUNCH_B2(4, false, 512); break; default: LAUNCH_B2(2, false, 512); break; } }
+            }
+            else if (ctx->pipe_wg > 256) { g_last_error = "unsupported pipe_wg"; return BMX_ERR_BADARG; }
+            else if (ctx->pipe_nt) { switch (ctx->pipe_unroll) { case 1: LAUNCH_B2(1, true, 256); break; case 4: LAUNCH_B2(4, true, 256); break; default: LAUNCH_B2(2, true, 256); break; } }
+            else { switch (ctx->pipe_unroll) { case 1: LAUNCH_B2(1, false, 256); break; case 4: LAUNCH_B2(4, false, 256); break; default: LAUNCH_B2(2, false, 256); break; } }
 #undef LAUNCH_B2
             KCHK();
             return BMX_OK;
         }
-        u32 nitems = (u32)n64, wpb = (u32)ctx->pipe_wg / 64u, grid = (nitems + wpb - 1) / wpb;
-#define LAUNCH_BITS(U, R, NT) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pipe_counts_bits<U, R, NT>), dim3(grid), dim3(ctx->pipe_wg), 0, ctx->stream, \
+        u32 wg1 = ctx->pipe_wg > 256 ? 256u : (u32)ctx->pipe_wg;          // v1 kernels are compiled for <= 256 threads
+        u32 nitems = (u32)n64, wpb = wg1 / 64u, grid = (nitems + wpb - 1) / wpb;
+#define LAUNCH_BITS(U, R, NT) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pipe_counts_bits<U, R, NT>), dim3(grid), dim3(wg1), 0, ctx->stream, \
         p->d_dmat, row_off, and_n, p->col_stride, p->ngroups, nb_from, nitems, ctx->xcd_swz, (u64*)d_counts)
 #define LAUNCH_BITS_R(U, NT) switch (rows) { case 1: LAUNCH_BITS(U, 1, NT); break; case 2: LAUNCH_BITS(U, 2, NT); break; \
         case 4: LAUNCH_BITS(U, 4, NT); break; default: LAUNCH_BITS(U, 8, NT); break; }

@@ -459,12 +459,13 @@ void k_pipe_counts_bits(const u64* __restrict__ dmat, const u32* __restrict__ ro
 //   one-block-in-flight loop (-7 %), hand-placed asm loads with counted vmcnt (-5 %, and hipcc
 //   may copy an asm-loaded register before the wait), dropping the early-exit test (-2 %).
 // ---------------------------------------------------------------------------
-template <int U, bool NT>
-__global__ __launch_bounds__(256)
+template <int U, bool NT, int WG = 256>
+__global__ __launch_bounds__(WG)
 void k_pipe_counts_bits2(const u64* __restrict__ dmat, const u32* __restrict__ row_off,
                          const u32* __restrict__ and_n, u32 col_stride,
                          u32 ngroups, u32 col_from, u32 nitems, int xcd_swz, u64* __restrict__ counts)
 {
+    extern __shared__ u32 lds_unused[];          // only an occupancy throttle for experiments ("pipe_lds")
     u32 lane = lane_id(), wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
     u32 bid = xcd_swz ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
     u32 item = uniform32(bid * wpb + wave);

@@ -75,7 +75,7 @@ int bmx_ctx_create(int device, void* stream, bmx_ctx** out);
 int bmx_ctx_destroy(bmx_ctx* ctx);
 int bmx_ctx_synchronize(bmx_ctx* ctx);
 /* launch-shape knobs of the counts pipeline (results never depend on them):
- * "pipe_unroll" 1|2|4, "pipe_rows" 8|4|2|1, "pipe_nt" 0|1, "pipe_wg" 64|128|256, "pipe_ver" 1|2, "pipe_staged" -1|0|1, "pipe_slots" 8|16, "xcd_swizzle" 0|1 */
+ * "pipe_unroll" 1|2|4, "pipe_rows" 8|4|2|1, "pipe_nt" 0|1, "pipe_wg" 64..768 (multiples of 64), "pipe_ver" 1|2, "pipe_staged" -1|0|1, "pipe_slots" 8|16, "xcd_swizzle" 0|1 */
 int bmx_ctx_set_tuning(bmx_ctx* ctx, const char* key, int value);
 /* The context keeps freed device blocks in a size-keyed cache (results of same-shaped
  * operations re-use them instead of paying hipMalloc/hipFree, which synchronises the

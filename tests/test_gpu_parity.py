@@ -372,7 +372,7 @@ def test_launch_shape_knobs_do_not_change_results(ctx, port):
             for u in (1, 2, 4):
                 for rows in ((8, 4, 2, 1) if ver == 1 else (8,)):
                     for nt in (0, 1):
-                        for wg, swz in ((256, 1), (64, 0), (128, 1)):
+                        for wg, swz in ((256, 1), (64, 0), (128, 1)) + (((384, 1), (512, 0), (768, 1)) if (ver == 2 and u == 4) else ()):
                             for k, x in (("pipe_ver", ver), ("pipe_unroll", u), ("pipe_rows", rows), ("pipe_nt", nt),
                                          ("pipe_wg", wg), ("xcd_swizzle", swz)):
                                 ctx.set_tuning(k, x)
@@ -387,7 +387,7 @@ def test_launch_shape_knobs_do_not_change_results(ctx, port):
             parts = sum(agg._run_pipeline(pipe, a, b).astype(np.int64) for a, b in [(0, 5), (5, nb)])
             assert (parts == exp.astype(np.int64)).all()
     finally:
-        for k, x in (("pipe_ver", 2), ("pipe_unroll", 4), ("pipe_rows", 8), ("pipe_nt", 1), ("pipe_wg", 256), ("xcd_swizzle", 1),
+        for k, x in (("pipe_ver", 2), ("pipe_unroll", 4), ("pipe_rows", 8), ("pipe_nt", 1), ("pipe_wg", 384), ("xcd_swizzle", 1),
                      ("pipe_staged", -1), ("pipe_slots", 16)):
             ctx.set_tuning(k, x)
     # the materialising twins use the same fold: every prefix, AND-SUB and OR

@@ -24,15 +24,17 @@ counts = torch.zeros(1, dtype=torch.int64, device="cuda")
 ob = pipe.operand_bytes()
 if a.variants:
     variants = [tuple(int(x) for x in v.split(":")) for v in a.variants.split(",")]
-    variants = [v if len(v) == 6 else v + (1,) for v in variants]
+    variants = [v if len(v) >= 6 else v + (1,) for v in variants]
+    variants = [v if len(v) == 7 else v + (0,) for v in variants]
 else:
-    variants = [(u, 8, nt, 256, 1, ver) for u in (1, 2, 4) for nt in (0, 1) for ver in (1, 2)] + [(2, 4, 1, 256, 1, 1), (4, 8, 1, 256, 0, 2)]
+    variants = [(u, 8, nt, 256, 1, ver, 0) for u in (1, 2, 4) for nt in (0, 1) for ver in (1, 2)] + [(2, 4, 1, 256, 1, 1, 0), (4, 8, 1, 256, 0, 2, 0)]
+    variants += [(4, 8, 1, wg, 1, 2, 0) for wg in (192, 320, 384, 448, 512, 640, 768)]
 res = {v: [] for v in variants}
 ref = None
 for rnd in range(a.rounds):
     for v in variants:
-        u, r, nt, wg, sw, ver = v
-        for k, x in (("pipe_unroll", u), ("pipe_rows", r), ("pipe_nt", nt), ("pipe_wg", wg), ("xcd_swizzle", sw), ("pipe_ver", ver)):
+        u, r, nt, wg, sw, ver, ldsb = v
+        for k, x in (("pipe_unroll", u), ("pipe_rows", r), ("pipe_nt", nt), ("pipe_wg", wg), ("xcd_swizzle", sw), ("pipe_ver", ver), ("pipe_lds", ldsb)):
             ctx.set_tuning(k, x)
         agg.run_counts_dev(pipe, counts.data_ptr())
         torch.cuda.synchronize()
@@ -58,4 +60,4 @@ for v, t in res.items():
 rows.sort()
 print("count", ref, "operand GB", ob / 1e9)
 for med, mn, v in rows:
-    print(f"ver={v[5]} U={v[0]} rows={v[1]} nt={v[2]} wg={v[3]} swz={v[4]}  median {med:.4f} ms  min {mn:.4f} ms  {ob/med/1e6:.0f} GB/s  frac {ob/med/1e6/8000:.3f}")
+    print(f"ver={v[5]} U={v[0]} rows={v[1]} nt={v[2]} wg={v[3]} swz={v[4]} lds={v[6]}  median {med:.4f} ms  min {mn:.4f} ms  {ob/med/1e6:.0f} GB/s  frac {ob/med/1e6/8000:.3f}")
