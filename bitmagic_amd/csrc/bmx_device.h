@@ -344,23 +344,51 @@ __device__ __forceinline__ void gap_apply_lds_lane(gcptr16 g, u32* lds)
     }
 }
 
-// apply n GAP operands (pointer list walked BACKWARDS from plist_back: row regions pack GAP
-// pointers from their end) to the wave's LDS accumulator
-template <int MODE>
-__device__ __forceinline__ void gap_apply_list(const u64* __restrict__ plist_back, u32 n, u32* lds, u32 lane)
+__device__ __forceinline__ bool lds_blk_is_zero(const u32* lds, u32 lane)
 {
-    if (n >= 32u) {                                    // many operands: lane-per-operand, pointers one step ahead
-        u64 p = lane < n ? *(plist_back - lane) : 0ull;
-        for (u32 i = lane; i < n; i += 64u) {
-            u64 pn = i + 64u < n ? *(plist_back - (i + 64u)) : 0ull;
-            gap_apply_lds_lane<MODE>(as_gc16(p), lds);
-            p = pn;
+    const u32x4* l4 = reinterpret_cast<const u32x4*>(lds);
+    u32 v = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { u32x4 t = l4[i * 64 + lane]; v |= t.x | t.y | t.z | t.w; }
+    return __ballot(v != 0u) == 0ull;
+}
+
+// Apply n GAP operands (pointer list walked BACKWARDS from plist_back: row regions pack GAP pointers
+// from their end) to the wave's LDS accumulator.  Returns true when an AND / SUB accumulator became
+// all-zero (the caller stops: the reference's digest == 0 exit in process_gap_blocks_and/sub,
+// src/bmaggregator.h:1820,1854).  Few operands: one at a time, runs spread over the lanes, test after
+// each.  Many (>= 32): the first 8 that way (sparse intersections die within a few operands), the rest
+// one operand per lane, 64 at a time, with a test per step.
+template <int MODE>
+__device__ __forceinline__ bool gap_apply_list(const u64* __restrict__ plist_back, u32 n, u32* lds, u32 lane)
+{
+    const bool CHECK = MODE != GAP_OR;
+    u32 head = n >= 32u ? 8u : n;
+    u32 i = 0;
+    for (; i < head; ++i) {
+        gap_apply_lds_wave<MODE>(as_gc16(uniform64(*(plist_back - i))), lds, lane);
+        if (CHECK) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (lds_blk_is_zero(lds, lane)) return true;
         }
-    } else {
-        for (u32 i = 0; i < n; ++i) gap_apply_lds_wave<MODE>(as_gc16(uniform64(*(plist_back - i))), lds, lane);
+    }
+    if (i < n) {                                       // many operands: lane-per-operand, pointers one step ahead
+        u64 p = i + lane < n ? *(plist_back - (i + lane)) : 0ull;
+        for (; i < n; i += 64u) {
+            u64 pn = i + 64u + lane < n ? *(plist_back - (i + 64u + lane)) : 0ull;
+            if (i + lane < n) gap_apply_lds_lane<MODE>(as_gc16(p), lds);
+            p = pn;
+            if (CHECK) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                if (lds_blk_is_zero(lds, lane)) return true;
+            }
+        }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    return false;
 }
 
 __device__ __forceinline__ void blk_to_lds(const Blk& b, u32* lds, u32 lane)

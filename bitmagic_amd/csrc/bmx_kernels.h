@@ -357,8 +357,8 @@ void k_pipe_counts(const u64* __restrict__ dmat, const u32* __restrict__ row_off
     // GAP operands (packed from the back of each region): applied run-by-run to the accumulator in LDS
     if (nga | ngs) {
         blk_to_lds(acc, lds, lane);
-        if (nga) gap_apply_list<GAP_AND>(pa + na - 1u, nga, lds, lane);
-        if (ngs) gap_apply_list<GAP_SUB>(ps + ns - 1u, ngs, lds, lane);
+        if (nga && gap_apply_list<GAP_AND>(pa + na - 1u, nga, lds, lane)) return;
+        if (ngs && gap_apply_list<GAP_SUB>(ps + ns - 1u, ngs, lds, lane)) return;
         blk_from_lds(acc, lds, lane);
     }
     u32 cnt = wave_sum(blk_lane_popcount(acc));

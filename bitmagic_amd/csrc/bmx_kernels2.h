@@ -201,7 +201,7 @@ void k_agg_or(const u64* __restrict__ dmat, u32 n, u32 ncols, int opt_compress, 
     if (ngap) {                                          // process_gap_blocks_or (:1808), run-parallel in LDS
         u32* lds = lds_dyn + wave * 2048u;
         blk_to_lds(acc, lds, lane);
-        gap_apply_list<GAP_OR>(p + n - 1u, ngap, lds, lane);
+        (void)gap_apply_list<GAP_OR>(p + n - 1u, ngap, lds, lane);
         blk_from_lds(acc, lds, lane);
     }
     store_result(acc, c, opt_compress, slab, desc, st, lane);
@@ -289,10 +289,9 @@ void k_agg_and_sub(const u64* __restrict__ dmat, const u32* __restrict__ and_n_p
     if (!zero) zero = pipe_chain<U, true, 1>(acc, ps, nbs, lane);
     if (!zero && (nga | ngs)) {
         blk_to_lds(acc, lds, lane);
-        if (nga) gap_apply_list<GAP_AND>(pa + na - 1u, nga, lds, lane);
-        if (ngs) gap_apply_list<GAP_SUB>(ps + ns - 1u, ngs, lds, lane);
-        blk_from_lds(acc, lds, lane);
-        zero = blk_is_zero(acc);
+        zero = nga && gap_apply_list<GAP_AND>(pa + na - 1u, nga, lds, lane);
+        if (!zero) zero = ngs && gap_apply_list<GAP_SUB>(ps + ns - 1u, ngs, lds, lane);
+        if (!zero) { blk_from_lds(acc, lds, lane); zero = blk_is_zero(acc); }
     }
     if (zero) { store_trivial(K_NULL, c, desc, st, lane); return; }
     store_result(acc, c, opt_compress, slab, desc, st, lane);
@@ -403,8 +402,8 @@ void k_find_first_and_sub(const u64* __restrict__ dmat, const u32* __restrict__ 
     if (pipe_chain<U, false, 1>(acc, ps, nbs, lane)) return;
     if (nga | ngs) {
         blk_to_lds(acc, lds, lane);
-        if (nga) gap_apply_list<GAP_AND>(pa + na - 1u, nga, lds, lane);
-        if (ngs) gap_apply_list<GAP_SUB>(ps + ns - 1u, ngs, lds, lane);
+        if (nga && gap_apply_list<GAP_AND>(pa + na - 1u, nga, lds, lane)) return;
+        if (ngs && gap_apply_list<GAP_SUB>(ps + ns - 1u, ngs, lds, lane)) return;
         blk_from_lds(acc, lds, lane);
     }
     // bit_find_first (src/bmfunc.h:9499): smallest linear bit index held by this lane, then wave min
