@@ -185,14 +185,16 @@ int bmx_ctx_create(int device, void* stream, bmx_ctx** out)
     bmx_ctx* ctx = new (std::nothrow) bmx_ctx();
     if (!ctx) return BMX_ERR_BADALLOC;
     ctx->device = device;
+#define CTXCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { int r_ = fail_hip(e_, #call, __LINE__); bmx_ctx_destroy(ctx); return r_; } } while (0)
     if (stream) ctx->stream = (hipStream_t)stream;
-    else { HIPCHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)); ctx->own_stream = true; }
-    HIPCHK(hipEventCreate(&ctx->ev0));
-    HIPCHK(hipEventCreate(&ctx->ev1));
-    HIPCHK(hipMalloc((void**)&ctx->d_small, 64 * sizeof(u64)));
-    HIPCHK(hipHostMalloc((void**)&ctx->h_small, 64 * sizeof(u64)));
-    HIPCHK(hipMalloc((void**)&ctx->d_slots, COUNT_SLOTS * COUNT_SLOT_STRIDE * sizeof(u64)));
-    HIPCHK(hipMemsetAsync(ctx->d_slots, 0, COUNT_SLOTS * COUNT_SLOT_STRIDE * sizeof(u64), ctx->stream));
+    else { CTXCHK(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)); ctx->own_stream = true; }
+    CTXCHK(hipEventCreate(&ctx->ev0));
+    CTXCHK(hipEventCreate(&ctx->ev1));
+    CTXCHK(hipMalloc((void**)&ctx->d_small, 64 * sizeof(u64)));
+    CTXCHK(hipHostMalloc((void**)&ctx->h_small, 64 * sizeof(u64)));
+    CTXCHK(hipMalloc((void**)&ctx->d_slots, COUNT_SLOTS * COUNT_SLOT_STRIDE * sizeof(u64)));
+    CTXCHK(hipMemsetAsync(ctx->d_slots, 0, COUNT_SLOTS * COUNT_SLOT_STRIDE * sizeof(u64), ctx->stream));
+#undef CTXCHK
     if (const char* e = getenv("BMX_POOL_MAX_MB")) ctx->pool_cap = (uint64_t)atoll(e) << 20;
     if (const char* e = getenv("BMX_PIPE_UNROLL")) ctx->pipe_unroll = atoi(e);
     if (const char* e = getenv("BMX_PIPE_ROWS")) ctx->pipe_rows = atoi(e);
@@ -208,7 +210,7 @@ int bmx_ctx_destroy(bmx_ctx* ctx)
 {
     if (!ctx) return BMX_OK;
     (void)hipSetDevice(ctx->device);
-    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     pool_trim(ctx);
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->aux) (void)hipFree(ctx->aux);
@@ -217,7 +219,7 @@ int bmx_ctx_destroy(bmx_ctx* ctx)
     if (ctx->h_small) (void)hipHostFree(ctx->h_small);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
-    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return BMX_OK;
 }
@@ -556,6 +558,7 @@ int bmx_pipeline_create(bmx_ctx* ctx, const bmx_vec* const* and_list, const uint
             max_bits = std::max(max_bits, v->nbits);
         }
     }
+#define PIPECHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { int r_ = fail_hip(e_, #call, __LINE__); bmx_pipeline_destroy(ctx, p); return r_; } } while (0)
     bmx_pipeline* p = new (std::nothrow) bmx_pipeline();
     if (!p) return BMX_ERR_BADALLOC;
     memset(p, 0, sizeof(*p));
@@ -591,19 +594,19 @@ int bmx_pipeline_create(bmx_ctx* ctx, const bmx_vec* const* and_list, const uint
             }
             if ((rc = dmalloc(ctx, (void**)&p->d_udesc, udesc.size() * 8)) || (rc = dmalloc(ctx, (void**)&p->d_unblk, unblk.size() * 4)) ||
                 (rc = dmalloc(ctx, (void**)&p->d_gmask, gmask.size() * 4)) || (rc = dmalloc(ctx, (void**)&p->d_gskip, gskip.size() * 4))) { bmx_pipeline_destroy(ctx, p); return rc; }
-            HIPCHK(hipMemcpyAsync(p->d_udesc, udesc.data(), udesc.size() * 8, hipMemcpyHostToDevice, ctx->stream));
-            HIPCHK(hipMemcpyAsync(p->d_unblk, unblk.data(), unblk.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-            HIPCHK(hipMemcpyAsync(p->d_gmask, gmask.data(), gmask.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-            HIPCHK(hipMemcpyAsync(p->d_gskip, gskip.data(), gskip.size() * 4, hipMemcpyHostToDevice, ctx->stream));
-            HIPCHK(hipStreamSynchronize(ctx->stream));     // the host vectors die at the end of this scope
+            PIPECHK(hipMemcpyAsync(p->d_udesc, udesc.data(), udesc.size() * 8, hipMemcpyHostToDevice, ctx->stream));
+            PIPECHK(hipMemcpyAsync(p->d_unblk, unblk.data(), unblk.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+            PIPECHK(hipMemcpyAsync(p->d_gmask, gmask.data(), gmask.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+            PIPECHK(hipMemcpyAsync(p->d_gskip, gskip.data(), gskip.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+            PIPECHK(hipStreamSynchronize(ctx->stream));     // the host vectors die at the end of this scope
         }
     }
     size_t b_dmat = (size_t)std::max<uint32_t>(ncols, 1) * col_stride * 8, b_meta = meta.size() * 4, b_descs = descs.size() * 8;
     if ((rc = dmalloc(ctx, (void**)&p->d_dmat, b_dmat)) || (rc = dmalloc(ctx, (void**)&p->d_meta, b_meta)) ||
         (rc = dmalloc(ctx, (void**)&p->d_descs, b_descs))) { bmx_pipeline_destroy(ctx, p); return rc; }
     p->bytes = b_dmat + b_meta + b_descs;
-    HIPCHK(hipMemcpyAsync(p->d_meta, meta.data(), b_meta, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(p->d_descs, descs.data(), b_descs, hipMemcpyHostToDevice, ctx->stream));
+    PIPECHK(hipMemcpyAsync(p->d_meta, meta.data(), b_meta, hipMemcpyHostToDevice, ctx->stream));
+    PIPECHK(hipMemcpyAsync(p->d_descs, descs.data(), b_descs, hipMemcpyHostToDevice, ctx->stream));
     if (ncols) {
         PipeOperands po;
         po.desc = (const u64* const*)p->d_descs;
@@ -613,11 +616,12 @@ int bmx_pipeline_create(bmx_ctx* ctx, const bmx_vec* const* and_list, const uint
         u64 nthreads = (u64)ncols * ngroups;
         hipLaunchKernelGGL(k_pipe_sort, dim3((u32)((nthreads + 255) / 256)), dim3(256), 0, ctx->stream,
                            po, (u32)ngroups, ncols, col_stride, p->d_dmat);
-        KCHK();
+        PIPECHK(hipGetLastError());
     }
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    PIPECHK(hipStreamSynchronize(ctx->stream));
     *out = p;
     return BMX_OK;
+#undef PIPECHK
 }
 
 int bmx_pipeline_destroy(bmx_ctx* ctx, bmx_pipeline* p)
