@@ -145,3 +145,75 @@ def test_error_behaviour(ctx):
     # the allocator cache can be returned to the driver at any time
     before = ctx.mem_used(); ctx.trim(); assert ctx.mem_used() == before
     assert one.count() == 2
+
+
+def test_degenerate_gap_blocks_and_unoptimized_tables(ctx, port):
+    """vectors as an un-optimised reference container can hold them: GAP blocks that are
+    all-zero / all-one (len 1), bit-blocks that are all-zero / all-one; treated by content, not by kind"""
+    G0 = np.array([(1 << 3) | 0, 65535], np.uint16)              # all-zero GAP block
+    G1 = np.array([(1 << 3) | 1, 65535], np.uint16)              # all-one GAP block
+    G2 = np.array([(3 << 3) | 0, 99, 199, 65535], np.uint16)     # bits 100..199
+    G3 = np.array([(2 << 3) | 1, 0, 65535], np.uint16)           # only bit 0
+    gaps = np.concatenate([G0, G1, G2, G3])
+    kinds = [bm.GAP, bm.GAP, bm.GAP, bm.GAP, bm.BIT, bm.BIT, bm.NULL, bm.FULL]
+    offs = [0, 2, 4, 8, 0, 1, 0, 0]
+    bits = np.concatenate([np.zeros(2048, np.uint32), np.full(2048, 0xFFFFFFFF, np.uint32)])
+    nbits = 8 * 65536
+    a = bm.bvector.from_block_table(ctx, nbits, kinds, offs, bits, gaps)
+    pa = port.from_table(nbits, kinds, offs, bits, gaps)
+    assert a.count() == pa.count() == 65536 + 100 + 1 + 65536 + 65536
+    assert (a.to_words() == pa.to_words()).all()
+    rng = np.random.default_rng(9)
+    w = rng.integers(0, 1 << 32, size=8 * 2048, dtype=np.uint64).astype(np.uint32)
+    b = bm.bit_import_u32(ctx, w, True); pb = port.import_words(w, True)
+    agg = bm.aggregator(ctx)
+    for op in range(4):
+        for x, y, px, py in ((a, b, pa, pb), (b, a, pb, pa), (a, a, pa, pa)):
+            for opt in (bm.opt_none, bm.opt_compress):
+                t = bm.bvector._op2(op, x, y, opt)
+                assert (t.to_words() == port.op2(op, px, py, opt == bm.opt_compress).to_words()).all(), (op, opt)
+            assert bm._count_op2(op, x, y) == port.count_op2(op, px, py)
+    t, _ = agg.combine_and_sub([a, b], [])
+    assert (t.to_words() == port.agg_and_sub([pa, pb], []).to_words()).all()
+    t, _ = agg.combine_and_sub([b], [a])
+    assert (t.to_words() == port.agg_and_sub([pb], [pa]).to_words()).all()
+    assert (agg.combine_or([a, b]).to_words() == port.agg_or([pa, pb]).to_words()).all()
+    rs, prs = a.build_rs_index(), port.rs_build(pa)
+    q = np.arange(0, nbits, 1237, dtype=np.uint64)
+    assert (a.rank(q, rs) == prs.rank(q)).all()
+    r = np.arange(1, pa.count() + 1, 997, dtype=np.uint64)
+    f, p = a.select(r, rs); pp, pf = prs.select(r)
+    assert f.all() and (p == pp).all()
+
+
+def test_two_contexts_from_two_threads(port):
+    """distinct contexts (one HIP stream each) may be driven concurrently from different host threads"""
+    import threading
+    nbits = 40 * 65536
+    words = [port.gen_words(5150, v, 6554, nbits, with_common=True) for v in range(12)]
+    exp = int(port.pipeline_counts([([port.import_words(w, True, nbits) for w in words], [])])[0])
+    errors = []
+
+    def work(tid):
+        try:
+            c = bm.context(0)
+            vecs = [bm.bit_import_u32(c, w, True) for w in words]
+            agg = bm.aggregator(c)
+            for _ in range(20):
+                pipe = bm.aggregator.pipeline(c)
+                ag = pipe.add()
+                for v in vecs: ag.add(v, 0)
+                pipe.complete()
+                got = int(agg.combine_and_sub(pipe)[0])
+                t, _ = agg.combine_and_sub(vecs, [])
+                if got != exp or t.count() != exp:
+                    errors.append((tid, got, exp))
+            del vecs
+            c.close()
+        except Exception as e:  # pragma: no cover
+            errors.append((tid, repr(e)))
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(3)]
+    for t in th: t.start()
+    for t in th: t.join()
+    assert not errors, errors
