@@ -86,6 +86,7 @@ struct bmx_rs {
     bmx_ctx* ctx;
     uint32_t nblocks; uint64_t count;
     u32* d_bcount; u64* d_sub; u64* d_rcount; u16* d_cum;
+    u64* d_sample; uint32_t nsamples, sample_shift;       // top level of the select search (<= 2048 entries)
     size_t bytes;
 };
 
@@ -1061,6 +1062,13 @@ int bmx_rs_build(bmx_ctx* ctx, const bmx_vec* v, bmx_rs** out)
         KCHK();
         hipLaunchKernelGGL(k_rs_scan, dim3(1), dim3(1024), 0, ctx->stream, rs->d_bcount, v->nblocks, rs->d_rcount, ctx->d_small);
         KCHK();
+        uint32_t shift = 0;
+        while (((v->nblocks + (1u << shift) - 1u) >> shift) > 2048u) ++shift;
+        rs->sample_shift = shift; rs->nsamples = (v->nblocks + (1u << shift) - 1u) >> shift;
+        if ((rc = dmalloc(ctx, (void**)&rs->d_sample, (size_t)rs->nsamples * 8))) { bmx_rs_free(ctx, rs); return rc; }
+        hipLaunchKernelGGL(k_rs_sample, dim3((rs->nsamples + 255) / 256), dim3(256), 0, ctx->stream,
+                           rs->d_rcount, v->nblocks, shift, rs->nsamples, rs->d_sample);
+        KCHK();
         HIPCHK(hipMemcpyAsync(ctx->h_small, ctx->d_small, 8, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipStreamSynchronize(ctx->stream));
         rs->count = ctx->h_small[0];
@@ -1075,7 +1083,7 @@ int bmx_rs_free(bmx_ctx* ctx, bmx_rs* rs)
     ARGCHK(ctx && rs->ctx == ctx);
     int rc = set_dev(ctx); if (rc) return rc;
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    dfree(ctx, rs->d_bcount); dfree(ctx, rs->d_sub); dfree(ctx, rs->d_rcount); dfree(ctx, rs->d_cum);
+    dfree(ctx, rs->d_bcount); dfree(ctx, rs->d_sub); dfree(ctx, rs->d_rcount); dfree(ctx, rs->d_cum); dfree(ctx, rs->d_sample);
     delete rs;
     return BMX_OK;
 }
@@ -1112,7 +1120,8 @@ int bmx_select_batch_dev(bmx_ctx* ctx, const bmx_vec* v, const bmx_rs* rs, const
     int rc = set_dev(ctx); if (rc) return rc;
     if (!q) return BMX_OK;
     hipLaunchKernelGGL(k_select, dim3(query_grid(q)), dim3(256), 0, ctx->stream, v->d_desc, v->nblocks,
-                       rs->d_rcount, rs->d_cum, rs->count, (const u64*)d_rank, (u64)q, (u64*)d_pos, (u8*)d_found);
+                       rs->d_rcount, rs->d_cum, rs->d_sample, rs->nsamples, rs->sample_shift, rs->count,
+                       (const u64*)d_rank, (u64)q, (u64*)d_pos, (u8*)d_found);
     KCHK();
     return BMX_OK;
 }

@@ -551,6 +551,16 @@ void k_rs_scan(const u32* __restrict__ bcount, u32 nblocks, u64* __restrict__ rc
     if (tid == 0) *total = carry;
 }
 
+// top level of the select search: every (1 << shift)-th inclusive running count, small enough for LDS
+__global__ __launch_bounds__(256)
+void k_rs_sample(const u64* __restrict__ rcount, u32 nblocks, u32 shift, u32 nsamples, u64* __restrict__ sample)
+{
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nsamples) return;
+    u64 last = (((u64)i + 1ull) << shift) - 1ull;
+    sample[i] = rcount[last < nblocks ? last : nblocks - 1u];
+}
+
 // 8 lanes cooperate on one query (8 queries per wave step): each lane owns 16 B
 // of the 128 B line that holds the query's 1024-bit wave.
 __device__ __forceinline__ u32 group_sum8(u32 v)
@@ -621,8 +631,14 @@ void k_rank(const u64* __restrict__ desc, u32 nblocks, const u64* __restrict__ r
 // bvector::select(rank, pos, rs)  src/bm.h:5350: position of the rank-th (1-based) set bit
 __global__ __launch_bounds__(256)
 void k_select(const u64* __restrict__ desc, u32 nblocks, const u64* __restrict__ rcount, const u16* __restrict__ cum,
+              const u64* __restrict__ sample, u32 nsamples, u32 shift,
               u64 total, const u64* __restrict__ q, u64 nq, u64* __restrict__ pos, u8* __restrict__ found)
 {
+    // top level of rs_index::find in LDS (<= 2048 samples = 16 KiB): 11 LDS probes replace as many dependent
+    // global loads; the bottom level searches one group of (1 << shift) blocks in global memory
+    __shared__ u64 s_sample[2048];
+    for (u32 i = threadIdx.x; i < nsamples; i += blockDim.x) s_sample[i] = sample[i];
+    __syncthreads();
     u32 lane = lane_id();
     u32 sub = lane & 7u;
     u64 qi = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 3;
@@ -636,7 +652,10 @@ void k_select(const u64* __restrict__ desc, u32 nblocks, const u64* __restrict__
         u32 kd = K_NULL, w = 0, rr = 0, nb = 0; u64 d = 0;
         if (ok) {
             // rs_index::find (src/bmrs.h:492): first block whose running count reaches r
-            u32 lo = 0, hi = nblocks - 1u;
+            u32 glo = 0, ghi = nsamples - 1u;
+            while (glo < ghi) { u32 mid = glo + ((ghi - glo) >> 1); if (s_sample[mid] < r) glo = mid + 1u; else ghi = mid; }
+            u32 lo = glo << shift, hi = ((glo + 1u) << shift) - 1u;
+            if (hi > nblocks - 1u) hi = nblocks - 1u;
             while (lo < hi) { u32 mid = lo + ((hi - lo) >> 1); if (rcount[mid] < r) lo = mid + 1u; else hi = mid; }
             nb = lo;
             rr = (u32)(r - (nb ? rcount[nb - 1] : 0ull));       // 1..65536 inside the block
