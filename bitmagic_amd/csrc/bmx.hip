@@ -86,6 +86,7 @@ struct bmx_rs {
     bmx_ctx* ctx;
     uint32_t nblocks; uint64_t count;
     u32* d_bcount; u64* d_sub; u64* d_rcount; u16* d_cum;
+    u16* d_gidx;                                          // GAP blocks: first run reaching each 1024-bit wave
     u64* d_sample; uint32_t nsamples, sample_shift;       // top level of the select search (<= 2048 entries)
     size_t bytes;
 };
@@ -1054,11 +1055,12 @@ int bmx_rs_build(bmx_ctx* ctx, const bmx_vec* v, bmx_rs** out)
     uint32_t n = std::max<uint32_t>(v->nblocks, 1);
     size_t b1 = (size_t)n * 4, b2 = (size_t)n * 8, b3 = (size_t)n * 8, b4 = (size_t)n * 128;
     if ((rc = dmalloc(ctx, (void**)&rs->d_bcount, b1)) || (rc = dmalloc(ctx, (void**)&rs->d_sub, b2)) ||
-        (rc = dmalloc(ctx, (void**)&rs->d_rcount, b3)) || (rc = dmalloc(ctx, (void**)&rs->d_cum, b4))) { bmx_rs_free(ctx, rs); return rc; }
+        (rc = dmalloc(ctx, (void**)&rs->d_rcount, b3)) || (rc = dmalloc(ctx, (void**)&rs->d_cum, b4)) ||
+        (rc = dmalloc(ctx, (void**)&rs->d_gidx, b4))) { bmx_rs_free(ctx, rs); return rc; }
     rs->bytes = b1 + b2 + b3 + b4;
     if (v->nblocks) {
         hipLaunchKernelGGL(k_rs_build, dim3((v->nblocks + 3) / 4), dim3(256), 0, ctx->stream,
-                           v->d_desc, v->nblocks, rs->d_bcount, rs->d_sub, rs->d_cum);
+                           v->d_desc, v->nblocks, rs->d_bcount, rs->d_sub, rs->d_cum, rs->d_gidx);
         KCHK();
         hipLaunchKernelGGL(k_rs_scan, dim3(1), dim3(1024), 0, ctx->stream, rs->d_bcount, v->nblocks, rs->d_rcount, ctx->d_small);
         KCHK();
@@ -1083,7 +1085,7 @@ int bmx_rs_free(bmx_ctx* ctx, bmx_rs* rs)
     ARGCHK(ctx && rs->ctx == ctx);
     int rc = set_dev(ctx); if (rc) return rc;
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    dfree(ctx, rs->d_bcount); dfree(ctx, rs->d_sub); dfree(ctx, rs->d_rcount); dfree(ctx, rs->d_cum); dfree(ctx, rs->d_sample);
+    dfree(ctx, rs->d_bcount); dfree(ctx, rs->d_sub); dfree(ctx, rs->d_rcount); dfree(ctx, rs->d_cum); dfree(ctx, rs->d_gidx); dfree(ctx, rs->d_sample);
     delete rs;
     return BMX_OK;
 }
@@ -1108,7 +1110,7 @@ int bmx_rank_batch_dev(bmx_ctx* ctx, const bmx_vec* v, const bmx_rs* rs, const u
     int rc = set_dev(ctx); if (rc) return rc;
     if (!q) return BMX_OK;
     hipLaunchKernelGGL(k_rank, dim3(query_grid(q)), dim3(256), 0, ctx->stream, v->d_desc, v->nblocks,
-                       rs->d_rcount, rs->d_cum, rs->count, (const u64*)d_n, (u64)q, (u64*)d_out);
+                       rs->d_rcount, rs->d_cum, rs->d_gidx, rs->count, (const u64*)d_n, (u64)q, (u64*)d_out);
     KCHK();
     return BMX_OK;
 }
@@ -1120,7 +1122,7 @@ int bmx_select_batch_dev(bmx_ctx* ctx, const bmx_vec* v, const bmx_rs* rs, const
     int rc = set_dev(ctx); if (rc) return rc;
     if (!q) return BMX_OK;
     hipLaunchKernelGGL(k_select, dim3(query_grid(q)), dim3(256), 0, ctx->stream, v->d_desc, v->nblocks,
-                       rs->d_rcount, rs->d_cum, rs->d_sample, rs->nsamples, rs->sample_shift, rs->count,
+                       rs->d_rcount, rs->d_cum, rs->d_gidx, rs->d_sample, rs->nsamples, rs->sample_shift, rs->count,
                        (const u64*)d_rank, (u64)q, (u64*)d_pos, (u8*)d_found);
     KCHK();
     return BMX_OK;

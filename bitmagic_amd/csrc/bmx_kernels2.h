@@ -477,7 +477,7 @@ __device__ __forceinline__ u32 gap_lane_below(gcptr16 g, u32 pos, u32 lane)
 // bvector::build_rs_index  src/bm.h:2531, one wave per block
 __global__ __launch_bounds__(256)
 void k_rs_build(const u64* __restrict__ desc, u32 nblocks, u32* __restrict__ bcount, u64* __restrict__ sub,
-                u16* __restrict__ cum)
+                u16* __restrict__ cum, u16* __restrict__ gidx)
 {
     __shared__ u32 lds[4 * 2048];
     u32 lane = lane_id(), wave = threadIdx.x >> 6;
@@ -502,6 +502,11 @@ void k_rs_build(const u64* __restrict__ desc, u32 nblocks, u32* __restrict__ bco
         gcptr16 g = as_gc16(DESC_P(d));
         gap_decode(g, lds + wave * 2048u, b, lane);
         u32 s = (u32)g[0] & 1u;
+        {   // gidx[w] = first run that reaches bit w*1024 (gap_bfind, src/bmfunc.h:1844), one wave of 1024 bits per lane
+            u32 glen = (u32)g[0] >> 3, from = lane << 10, lo = 1, hi = glen;
+            while (lo < hi) { u32 mid = (lo + hi) >> 1; if ((u32)g[mid] < from) lo = mid + 1; else hi = mid; }
+            gidx[(size_t)nb * 64u + lane] = (u16)lo;
+        }
         u32 i0 = 1u + wave_sum(gap_lane_below(g, 21825u, lane));
         u32 i1 = 1u + wave_sum(gap_lane_below(g, 43649u, lane));
         aux0 = ((u64)i0 << 1) | (s ^ ((i0 - 1u) & 1u));
@@ -570,12 +575,10 @@ __device__ __forceinline__ u32 group_sum8(u32 v)
 }
 
 // ones of GAP block g at positions in [from..to] (to inclusive), summed over a group of 8 lanes
-__device__ __forceinline__ u32 gap_group_count_range(gcptr16 g, u32 from, u32 to, u32 sub)
+__device__ __forceinline__ u32 gap_group_count_range(gcptr16 g, u32 lo, u32 from, u32 to, u32 sub)
 {
+    // lo = index of the first run that reaches `from` (from the rs-index: gidx[nb][wave])
     u32 hdr = g[0]; u32 len = hdr >> 3, s = hdr & 1u;
-    // first run that reaches `from`: smallest k with g[k] >= from (binary search, all lanes alike)
-    u32 lo = 1, hi = len;
-    while (lo < hi) { u32 mid = (lo + hi) >> 1; if ((u32)g[mid] < from) lo = mid + 1; else hi = mid; }
     u32 c = 0;
     for (u32 k = lo + sub; k <= len; k += 8) {
         u32 start = (k == 1u) ? 0u : (u32)g[k - 1] + 1u;
@@ -592,7 +595,7 @@ __device__ __forceinline__ u32 gap_group_count_range(gcptr16 g, u32 from, u32 to
 // bvector::count_to / rank(n, rs)  src/bm.h:3120 -- ones in [0..n]
 __global__ __launch_bounds__(256)
 void k_rank(const u64* __restrict__ desc, u32 nblocks, const u64* __restrict__ rcount, const u16* __restrict__ cum,
-            u64 total, const u64* __restrict__ q, u64 nq, u64* __restrict__ out)
+            const u16* __restrict__ gidx, u64 total, const u64* __restrict__ q, u64 nq, u64* __restrict__ out)
 {
     u32 sub = threadIdx.x & 7u;
     u64 qi = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 3;
@@ -620,7 +623,7 @@ void k_rank(const u64* __restrict__ desc, u32 nblocks, const u64* __restrict__ r
                      + word_count_to(v.z, base + 2u, nbit) + word_count_to(v.w, base + 3u, nbit);
             } else if (kd == K_GAP) {
                 res += cum[(size_t)nb * 64u + w];
-                part = gap_group_count_range(as_gc16(DESC_P(d)), w << 10, nbit, sub);
+                part = gap_group_count_range(as_gc16(DESC_P(d)), gidx[(size_t)nb * 64u + w], w << 10, nbit, sub);
             }
         }
         part = group_sum8(part);
@@ -631,7 +634,7 @@ void k_rank(const u64* __restrict__ desc, u32 nblocks, const u64* __restrict__ r
 // bvector::select(rank, pos, rs)  src/bm.h:5350: position of the rank-th (1-based) set bit
 __global__ __launch_bounds__(256)
 void k_select(const u64* __restrict__ desc, u32 nblocks, const u64* __restrict__ rcount, const u16* __restrict__ cum,
-              const u64* __restrict__ sample, u32 nsamples, u32 shift,
+              const u16* __restrict__ gidx, const u64* __restrict__ sample, u32 nsamples, u32 shift,
               u64 total, const u64* __restrict__ q, u64 nq, u64* __restrict__ pos, u8* __restrict__ found)
 {
     // top level of rs_index::find in LDS (<= 2048 samples = 16 KiB): 11 LDS probes replace as many dependent
@@ -698,8 +701,7 @@ void k_select(const u64* __restrict__ desc, u32 nblocks, const u64* __restrict__
             gcptr16 g = as_gc16(DESC_P(d));
             u32 hdr = g[0]; u32 len = hdr >> 3, s0 = hdr & 1u;
             u32 from = w << 10;
-            u32 lo = 1, hi = len;
-            while (lo < hi) { u32 mid = (lo + hi) >> 1; if ((u32)g[mid] < from) lo = mid + 1; else hi = mid; }
+            u32 lo = gidx[(size_t)nb * 64u + w];
             if (sub == 0) {
                 u32 need = rr;
                 for (u32 k = lo; k <= len; ++k) {
