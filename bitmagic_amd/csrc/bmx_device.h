@@ -209,9 +209,16 @@ __device__ __forceinline__ void gap_decode(gcptr16 g, u32* lds, Blk& out, u32 la
     u32 hdr = g[0];
     u32 len = hdr >> 3;
     if ((hdr & 1u) && lane == 0) atomicXor(&lds[0], 1u);
-    for (u32 k = 1 + lane; k < len; k += 64) {
-        u32 p = (u32)g[k] + 1u;
-        atomicXor(&lds[p >> 5], 1u << (p & 31u));
+    // run ends are fetched 8 wave-loads at a time (independent, issued together) before the LDS atomics
+    // that consume them: one memory round trip per 512 runs instead of one per 64
+    for (u32 kb = 1; kb < len; kb += 512u) {
+        u32 e[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { u32 k = kb + (u32)j * 64u + lane; e[j] = k < len ? (u32)g[k] : 0xFFFFFFFFu; }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (e[j] != 0xFFFFFFFFu) { u32 p = e[j] + 1u; atomicXor(&lds[p >> 5], 1u << (p & 31u)); }
+        }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -277,20 +284,32 @@ __device__ __forceinline__ void gap_apply_lds_wave(gcptr16 g, u32* lds, u32 lane
     u32 len = hdr >> 3, sbit = hdr & 1u;
     const u32 want = (MODE == GAP_AND) ? 0u : 1u;
     u32 k0 = (sbit == want) ? 1u : 2u;                 // first run (1-based) with the wanted value
-    for (u32 kb = k0; kb <= len; kb += 128u) {         // 64 runs of one polarity per step
-        u32 k = kb + 2u * lane;
-        bool act = k <= len;
-        u32 s = 0, e = 0;
-        if (act) { e = g[k]; s = (k == 1u) ? 0u : (u32)g[k - 1] + 1u; lds_apply_run_edges<MODE>(lds, s, e); }
-        u32 wl = s >> 5, wr = e >> 5;
-        u32 inner = (act && wr > wl + 1u) ? wr - wl - 1u : 0u;
-        // short interiors: each lane fills its own; long ones (> 16 words): the whole wave helps
-        if (inner && inner <= 16u) for (u32 w = wl + 1u; w < wr; ++w) lds[w] = fill;
-        u64 longm = __ballot(inner > 16u);
-        while (longm) {
-            u32 l = (u32)__builtin_ctzll(longm); longm &= longm - 1ull;
-            u32 a = __builtin_amdgcn_readlane(wl, l) + 1u, b = __builtin_amdgcn_readlane(wr, l);
-            for (u32 w = a + lane; w < b; w += 64u) lds[w] = fill;
+    // 4 steps of 64 runs per batch: the 8 run-end loads of a batch are issued together, then applied
+    for (u32 kb = k0; kb <= len; kb += 512u) {
+        u32 ee[4], ss[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            u32 k = kb + (u32)j * 128u + 2u * lane;
+            bool act = k <= len;
+            ee[j] = act ? (u32)g[k] : 0xFFFFFFFFu;
+            ss[j] = act ? ((k == 1u) ? 0u : (u32)g[k - 1] + 1u) : 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (kb + (u32)j * 128u > len) break;           // wave-uniform
+            bool act = ee[j] != 0xFFFFFFFFu;
+            u32 s = ss[j], e = act ? ee[j] : 0u;
+            if (act) lds_apply_run_edges<MODE>(lds, s, e);
+            u32 wl = s >> 5, wr = e >> 5;
+            u32 inner = (act && wr > wl + 1u) ? wr - wl - 1u : 0u;
+            // short interiors: each lane fills its own; long ones (> 16 words): the whole wave helps
+            if (inner && inner <= 16u) for (u32 w = wl + 1u; w < wr; ++w) lds[w] = fill;
+            u64 longm = __ballot(inner > 16u);
+            while (longm) {
+                u32 l = (u32)__builtin_ctzll(longm); longm &= longm - 1ull;
+                u32 a = __builtin_amdgcn_readlane(wl, l) + 1u, b = __builtin_amdgcn_readlane(wr, l);
+                for (u32 w = a + lane; w < b; w += 64u) lds[w] = fill;
+            }
         }
     }
 }
