@@ -372,44 +372,6 @@ __device__ __forceinline__ bool lds_blk_is_zero(const u32* lds, u32 lane)
     return __ballot(v != 0u) == 0ull;
 }
 
-// Apply n GAP operands (pointer list walked BACKWARDS from plist_back: row regions pack GAP pointers
-// from their end) to the wave's LDS accumulator.  Returns true when an AND / SUB accumulator became
-// all-zero (the caller stops: the reference's digest == 0 exit in process_gap_blocks_and/sub,
-// src/bmaggregator.h:1820,1854).  Few operands: one at a time, runs spread over the lanes, test after
-// each.  Many (>= 32): the first 8 that way (sparse intersections die within a few operands), the rest
-// one operand per lane, 64 at a time, with a test per step.
-template <int MODE>
-__device__ __forceinline__ bool gap_apply_list(const u64* __restrict__ plist_back, u32 n, u32* lds, u32 lane)
-{
-    const bool CHECK = MODE != GAP_OR;
-    u32 head = n >= 32u ? 8u : n;
-    u32 i = 0;
-    for (; i < head; ++i) {
-        gap_apply_lds_wave<MODE>(as_gc16(uniform64(*(plist_back - i))), lds, lane);
-        if (CHECK) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            if (lds_blk_is_zero(lds, lane)) return true;
-        }
-    }
-    if (i < n) {                                       // many operands: lane-per-operand, pointers one step ahead
-        u64 p = i + lane < n ? *(plist_back - (i + lane)) : 0ull;
-        for (; i < n; i += 64u) {
-            u64 pn = i + 64u + lane < n ? *(plist_back - (i + 64u + lane)) : 0ull;
-            if (i + lane < n) gap_apply_lds_lane<MODE>(as_gc16(p), lds);
-            p = pn;
-            if (CHECK) {
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                if (lds_blk_is_zero(lds, lane)) return true;
-            }
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    return false;
-}
-
 __device__ __forceinline__ void blk_to_lds(const Blk& b, u32* lds, u32 lane)
 {
     u32x4* l4 = reinterpret_cast<u32x4*>(lds);
@@ -423,6 +385,223 @@ __device__ __forceinline__ void blk_from_lds(Blk& b, const u32* lds, u32 lane)
     const u32x4* l4 = reinterpret_cast<const u32x4*>(lds);
 #pragma unroll
     for (int i = 0; i < 8; ++i) b.r[i] = l4[i * 64 + lane];
+}
+
+__device__ __forceinline__ u32 lds_blk_popcount(const u32* lds, u32 lane)
+{
+    const u32x4* l4 = reinterpret_cast<const u32x4*>(lds);
+    u32 c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        u32x4 t = l4[i * 64 + lane];
+        c += (u32)__popc(t.x) + (u32)__popc(t.y) + (u32)__popc(t.z) + (u32)__popc(t.w);
+    }
+    return uniform32(wave_sum(c));
+}
+
+// ---------------------------------------------------------------------------
+// Sparse state of an AND / SUB accumulator.  Once the running result holds at most
+// SPARSE_CAP set bits it is kept as a list of bit positions (<= 16 per lane, in
+// registers) and every further GAP operand is a membership test of those positions:
+// the operand's run ends are staged in LDS with coalesced 16-byte reads (one request
+// per 512 runs, requested one operand ahead, header two ahead) and each candidate is
+// located by a branch-free binary search (gap_bfind / gap_test, src/bmfunc.h:1721,1803).
+// This is the wave64 counterpart of the reference's digest narrowing
+// (gap_and_to_bitset(dest, gap, digest) src/bmfunc.h:4893): work follows the number
+// of surviving bits, not the number of runs of the operand.  Results are identical:
+// acc & gap (or acc & ~gap) restricted to the set bits of acc.
+// LDS use inside the wave's 8 KiB block: run ends in words [0, 640), candidate list in
+// [640, 1152); the block itself is rebuilt from the survivors at the end.
+// ---------------------------------------------------------------------------
+#define SPARSE_CAP 1024u
+#define SPARSE_NONE 0xFFFFFFFFu
+
+struct GapStage { u32x4 d[3]; };
+
+__device__ __forceinline__ void gap_stage_load(GapStage& s, gcptr16 g, u32 hdr, u32 lane)
+{
+    gcptr4 g4 = (gcptr4)(uintptr_t)g;
+    u32 nch = ((hdr >> 3) + 8u) >> 3;                  // 16-byte chunks holding words 0..len
+    const u32x4 z = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { u32 c = lane + 64u * (u32)j; s.d[j] = c < nch ? g4[c] : z; }
+}
+__device__ __forceinline__ void gap_stage_store(const GapStage& s, u32* lds, u32 hdr, u32 lane)
+{
+    u32x4* l4 = reinterpret_cast<u32x4*>(lds);
+    u32 nch = ((hdr >> 3) + 8u) >> 3;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { u32 c = lane + 64u * (u32)j; if (c < nch) l4[c] = s.d[j]; }
+}
+
+template <int MODE, int NJ>
+__device__ __forceinline__ void sparse_test(u32 (&cand)[16], const u16* G, u32 hdr)
+{
+    u32 len = hdr >> 3, sbit = hdr & 1u;
+    u32 k[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) k[j] = 0u;
+    // k = number of run ends below the position  =>  the position lies in run k+1, value sbit ^ (k & 1)
+    for (u32 step = 1u << (31 - __builtin_clz(len)); step; step >>= 1) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            u32 t = k[j] + step; t = t < len ? t : len;       // G[len] = 65535 never compares below
+            u32 v = G[t];
+            k[j] = v < cand[j] ? t : k[j];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        u32 bitv = (sbit ^ k[j]) & 1u;
+        bool keep = (MODE == GAP_AND) ? (bitv != 0u) : (bitv == 0u);
+        if (!keep) cand[j] = SPARSE_NONE;
+    }
+}
+
+// acc (in LDS, <= SPARSE_CAP bits) op= operands i0..n-1 of the list; true when nothing survives,
+// else the block is rebuilt in LDS.
+template <int MODE>
+__device__ __forceinline__ bool gap_apply_sparse(const u64* __restrict__ plist_back, u32 i0, u32 n, u32* lds, u32 lane)
+{
+    u16* list = reinterpret_cast<u16*>(lds + 640);
+    u32 cand[16];
+    u32 total, nj;
+    {   // set bits -> position list (lane-contiguous via a wave scan of the lane popcounts)
+        Blk b; blk_from_lds(b, lds, lane);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        u32 cnt = blk_lane_popcount(b);
+        u32 incl = wave_scan_incl(cnt, lane);
+        total = uniform32(__shfl(incl, 63, 64));
+        u32 off = incl - cnt;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            u32 ws[4] = {b.r[i].x, b.r[i].y, b.r[i].z, b.r[i].w};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                u32 w = ws[c];
+                u32 base = ((u32)i * 256u + lane * 4u + (u32)c) << 5;
+                while (w) { u32 bit = (u32)__builtin_ctz(w); w &= w - 1u; list[off++] = (u16)(base + bit); }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        nj = (total + 63u) >> 6;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            u32 idx = (u32)j * 64u + lane;
+            cand[j] = idx < total ? (u32)list[idx] : SPARSE_NONE;
+        }
+    }
+    const u16* G = reinterpret_cast<const u16*>(lds);
+    u32 i = i0;
+    gcptr16 g0 = as_gc16(uniform64(*(plist_back - i)));
+    u32 h0 = uniform32((u32)g0[0]);
+    GapStage cur; gap_stage_load(cur, g0, h0, lane);
+    gcptr16 g1 = as_gc16(uniform64(*(plist_back - (i + 1u < n ? i + 1u : n - 1u))));
+    u32 h1v = (u32)g1[0];
+    for (; i < n; ++i) {
+        u32 h1 = uniform32(h1v);
+        GapStage nxt; gap_stage_load(nxt, g1, h1, lane);             // operand i+1 (re-read of the last at the end)
+        u32 i2 = i + 2u < n ? i + 2u : n - 1u;
+        gcptr16 g2 = as_gc16(uniform64(*(plist_back - i2)));
+        u32 h2v = (u32)g2[0];
+        gap_stage_store(cur, lds, h0, lane);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (nj <= 1u) sparse_test<MODE, 1>(cand, G, h0);
+        else if (nj <= 2u) sparse_test<MODE, 2>(cand, G, h0);
+        else if (nj <= 4u) sparse_test<MODE, 4>(cand, G, h0);
+        else if (nj <= 8u) sparse_test<MODE, 8>(cand, G, h0);
+        else sparse_test<MODE, 16>(cand, G, h0);
+        u32 mine = 0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) mine += cand[j] != SPARSE_NONE ? 1u : 0u;
+        u32 incl = wave_scan_incl(mine, lane);
+        u32 alive = uniform32(__shfl(incl, 63, 64));
+        if (alive == 0u) return true;
+        if (((alive + 63u) >> 6) < nj) {                              // fewer slots suffice: compact through the list
+            u32 off = incl - mine;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) if (cand[j] != SPARSE_NONE) list[off++] = (u16)cand[j];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            nj = (alive + 63u) >> 6;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                u32 idx = (u32)j * 64u + lane;
+                cand[j] = idx < alive ? (u32)list[idx] : SPARSE_NONE;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        cur = nxt; g0 = g1; h0 = h1; g1 = g2; h1v = h2v;
+    }
+    {   // survivors -> block image
+        u32x4* l4 = reinterpret_cast<u32x4*>(lds);
+        const u32x4 z = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int r = 0; r < 8; ++r) l4[r * 64 + lane] = z;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            if (cand[j] != SPARSE_NONE) atomicOr(&lds[cand[j] >> 5], 1u << (cand[j] & 31u));
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    return false;
+}
+
+// Apply n GAP operands (pointer list walked BACKWARDS from plist_back: row regions pack GAP pointers
+// from their end) to the wave's LDS accumulator.  Returns true when an AND / SUB accumulator became
+// all-zero (the caller stops: the reference's digest == 0 exit in process_gap_blocks_and/sub,
+// src/bmaggregator.h:1820,1854).  Few operands: one at a time, runs spread over the lanes.  Many
+// (>= 32): the first 8 that way, the rest one operand per lane, 64 at a time.  AND / SUB test the
+// accumulator's population after every step: zero ends the column, <= SPARSE_CAP bits with at least
+// two operands left switches to the sparse state above.
+template <int MODE>
+__device__ __forceinline__ bool gap_apply_list(const u64* __restrict__ plist_back, u32 n, u32* lds, u32 lane)
+{
+    const bool CHECK = MODE != GAP_OR;
+    u32 head = n >= 32u ? 8u : n;
+    u32 i = 0;
+    if constexpr (CHECK) {
+        if (n >= 2u) {
+            u32 pop = lds_blk_popcount(lds, lane);
+            if (pop == 0u) return true;
+            if (pop <= SPARSE_CAP) return gap_apply_sparse<MODE>(plist_back, 0u, n, lds, lane);
+        }
+    }
+    for (; i < head; ++i) {
+        gap_apply_lds_wave<MODE>(as_gc16(uniform64(*(plist_back - i))), lds, lane);
+        if constexpr (CHECK) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            u32 pop = lds_blk_popcount(lds, lane);
+            if (pop == 0u) return true;
+            if (pop <= SPARSE_CAP && i + 2u < n) return gap_apply_sparse<MODE>(plist_back, i + 1u, n, lds, lane);
+        }
+    }
+    if (i < n) {                                       // many operands: lane-per-operand, pointers one step ahead
+        u64 p = i + lane < n ? *(plist_back - (i + lane)) : 0ull;
+        for (; i < n; i += 64u) {
+            u64 pn = i + 64u + lane < n ? *(plist_back - (i + 64u + lane)) : 0ull;
+            if (i + lane < n) gap_apply_lds_lane<MODE>(as_gc16(p), lds);
+            p = pn;
+            if constexpr (CHECK) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                u32 pop = lds_blk_popcount(lds, lane);
+                if (pop == 0u) return true;
+                if (pop <= SPARSE_CAP && i + 64u + 2u <= n)
+                    return gap_apply_sparse<MODE>(plist_back, i + 64u, n, lds, lane);
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    return false;
 }
 
 // popcount of a GAP block without expanding it (gap_bit_count_unr src/bmfunc.h:3107).
