@@ -435,7 +435,7 @@ __device__ __forceinline__ void gap_stage_store(const GapStage& s, u32* lds, u32
 }
 
 template <int MODE, int NJ>
-__device__ __forceinline__ void sparse_test(u32 (&cand)[16], const u16* G, u32 hdr)
+__device__ __forceinline__ u32 sparse_test(u32 (&cand)[16], const u16* G, u32 hdr)
 {
     u32 len = hdr >> 3, sbit = hdr & 1u;
     u32 k[NJ];
@@ -456,6 +456,10 @@ __device__ __forceinline__ void sparse_test(u32 (&cand)[16], const u16* G, u32 h
         bool keep = (MODE == GAP_AND) ? (bitv != 0u) : (bitv == 0u);
         if (!keep) cand[j] = SPARSE_NONE;
     }
+    u32 alive = 0;                                                    // scalar: ballots, no cross-lane traffic
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) alive += (u32)__popcll(__ballot(cand[j] != SPARSE_NONE));
+    return alive;
 }
 
 // acc (in LDS, <= SPARSE_CAP bits) op= operands i0..n-1 of the list; true when nothing survives,
@@ -509,19 +513,18 @@ __device__ __forceinline__ bool gap_apply_sparse(const u64* __restrict__ plist_b
         gap_stage_store(cur, lds, h0, lane);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        if (nj <= 1u) sparse_test<MODE, 1>(cand, G, h0);
-        else if (nj <= 2u) sparse_test<MODE, 2>(cand, G, h0);
-        else if (nj <= 4u) sparse_test<MODE, 4>(cand, G, h0);
-        else if (nj <= 8u) sparse_test<MODE, 8>(cand, G, h0);
-        else sparse_test<MODE, 16>(cand, G, h0);
-        u32 mine = 0;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) mine += cand[j] != SPARSE_NONE ? 1u : 0u;
-        u32 incl = wave_scan_incl(mine, lane);
-        u32 alive = uniform32(__shfl(incl, 63, 64));
+        u32 alive;
+        if (nj <= 1u) alive = sparse_test<MODE, 1>(cand, G, h0);
+        else if (nj <= 2u) alive = sparse_test<MODE, 2>(cand, G, h0);
+        else if (nj <= 4u) alive = sparse_test<MODE, 4>(cand, G, h0);
+        else if (nj <= 8u) alive = sparse_test<MODE, 8>(cand, G, h0);
+        else alive = sparse_test<MODE, 16>(cand, G, h0);
         if (alive == 0u) return true;
         if (((alive + 63u) >> 6) < nj) {                              // fewer slots suffice: compact through the list
-            u32 off = incl - mine;
+            u32 mine = 0;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) mine += cand[j] != SPARSE_NONE ? 1u : 0u;
+            u32 off = wave_scan_incl(mine, lane) - mine;
 #pragma unroll
             for (int j = 0; j < 16; ++j) if (cand[j] != SPARSE_NONE) list[off++] = (u16)cand[j];
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");

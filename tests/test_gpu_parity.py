@@ -431,3 +431,50 @@ def test_many_gap_operands(ctx, port, dq, nvec):
             assert int(agg.combine_and_sub(pipe)[0]) == e.count()
         finally:
             ctx.set_tuning("pipe_staged", -1)
+
+
+@pytest.mark.parametrize("common_bits,own_dq,nvec", [(1, 30, 40), (40, 100, 70), (400, 100, 90), (520, 40, 36),
+                                                     (700, 200, 50)])
+def test_sparse_state_of_gap_lists(ctx, port, common_bits, own_dq, nvec):
+    """AND / SUB lists of GAP operands whose intersection SURVIVES (a shared component): the accumulator turns
+    into a candidate list (<= 1024 bits) after the first operands and every further operand is a membership
+    test (bmx_device.h gap_apply_sparse) -- entry at list start, after the wave-mode head, after a lane-mode
+    step; compaction as candidates die; GAP blocks longer than 1024 runs; block rebuilt for combine_and_sub."""
+    nblk = 4
+    nbits = nblk * 65536
+    rng = np.random.default_rng(common_bits * 7 + nvec)
+    common = np.zeros(nbits // 32, np.uint32)
+    for b in range(nblk):                                              # block 3 gets no shared bits (dies)
+        if b == 3: continue
+        pos = rng.choice(65536, size=common_bits, replace=False) + b * 65536
+        np.bitwise_or.at(common, pos >> 5, (np.uint32(1) << (pos & 31).astype(np.uint32)))
+    words = []
+    for v in range(nvec):
+        w = port.gen_words(4242, v, own_dq, nbits) | common
+        if v % 7 == 3:                                                 # a long GAP block (~1100 runs) among them
+            extra = rng.choice(65536, size=450, replace=False) + 65536
+            np.bitwise_or.at(w, extra >> 5, (np.uint32(1) << (extra & 31).astype(np.uint32)))
+        words.append(w)
+    subs = [port.gen_words(999, 100 + v, 2000, nbits) for v in range(nvec // 2)]   # ~3 %: each kills few candidates
+    gv = [bm.bit_import_u32(ctx, w, True) for w in words]
+    pv = [port.import_words(w, True, nbits) for w in words]
+    gs = [bm.bit_import_u32(ctx, w, True) for w in subs]
+    ps = [port.import_words(w, True, nbits) for w in subs]
+    if common_bits + own_dq < 600:                                     # (the last case mixes BIT and GAP blocks)
+        assert gv[0].calc_stat()["gap_blocks"] >= 3
+    agg = bm.aggregator(ctx)
+    nwb = nblk * 2048
+    for na, ns in [(nvec, 0), (nvec, len(subs)), (3, len(subs)), (nvec // 2, 1), (2, 2), (34, 0)]:
+        a, s = gv[:na], gs[:ns]
+        e = port.agg_and_sub(pv[:na], ps[:ns])
+        t, _ = agg.combine_and_sub(a, s)
+        assert (t.to_words(nwb) == e.to_words(nwb)).all(), (na, ns)
+        pipe = bm.aggregator.pipeline(ctx)
+        ag = pipe.add()
+        for x in a: ag.add(x, 0)
+        for x in s: ag.add(x, 1)
+        pipe.complete()
+        assert int(agg.combine_and_sub(pipe)[0]) == e.count(), (na, ns)
+        found, pos = agg.find_first_and_sub(a, s)
+        ef, epos = port.find_first_and_sub(pv[:na], ps[:ns])
+        assert found == ef and (not found or pos == epos)
