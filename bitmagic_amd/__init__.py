@@ -437,6 +437,19 @@ class aggregator:
     def __init__(self, ctx: context):
         self.ctx = ctx
         self.ag = arg_groups()
+        self.opt_mode = False            # opt_none, :917
+        self.compute_count = False
+        self._count = 0
+
+    def set_optimization(self, opt: bool = True):                        # :359
+        self.opt_mode = bool(opt)
+
+    def set_compute_count(self, count_mode: bool):                       # :363
+        self.compute_count = bool(count_mode)
+        self._count = 0
+
+    def count(self) -> int:                                              # :488
+        return self._count
 
     def add(self, bv: bvector | None, agr_group: int = 0) -> int:       # :1013
         return self.ag.add(bv, agr_group)
@@ -471,6 +484,22 @@ class aggregator:
         any_ = C.c_int()
         check(lib().bmx_agg_and_sub(self.ctx._h, _handles(a), len(a), _handles(s), len(s), C.byref(h), C.byref(any_)))
         return bvector(self.ctx, h), bool(any_.value)
+
+    def combine_shift_right_and(self, bv_src_and=None, any: bool = False):               # :473,1089 / :552,2494
+        """-> (target, found).  T_0 = src[0], T_k = (T_{k-1} >> 1) & src[k]; target stored with the
+        aggregator's optimisation mode.  Under set_compute_count(True) nothing is stored (:2593):
+        -> (None, found) and count() holds the population."""
+        src = list(bv_src_and) if bv_src_and is not None else self.ag.arg_bv0
+        self._count = 0
+        if self.compute_count:
+            c = C.c_uint64()
+            check(lib().bmx_agg_shift_right_and_count(self.ctx._h, _handles(src), len(src), C.byref(c)))
+            self._count = int(c.value)
+            return None, self._count != 0
+        h, found = C.c_void_p(), C.c_int()
+        check(lib().bmx_agg_shift_right_and(self.ctx._h, _handles(src), len(src), int(self.opt_mode), int(any),
+                                            C.byref(h), C.byref(found)))
+        return bvector(self.ctx, h), bool(found.value)
 
     def find_first_and_sub(self, bv_src_and=None, bv_src_sub=None):                      # :1079 / :1458
         """-> (found, idx): first set bit of AND(group 0) AND NOT OR(group 1)"""

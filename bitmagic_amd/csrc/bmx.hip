@@ -2,6 +2,7 @@
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared bmx.hip -o libbmx.so
 #include "../../include/bmx.h"
 #include "bmx_kernels2.h"
+#include "bmx_kernels3.h"
 
 #include <algorithm>
 #include <cstdio>
@@ -1038,6 +1039,84 @@ int bmx_find_first_and_sub(bmx_ctx* ctx, const bmx_vec* const* src_and, size_t n
     if (e != hipSuccess) return fail_hip(e, "bmx_find_first_and_sub", __LINE__);
     if (ctx->h_small[0] != ~0ull) { *found = 1; *idx = ctx->h_small[0]; }
     return BMX_OK;
+}
+
+// aggregator::combine_shift_right_and  src/bmaggregator.h:552,2494 (count form: set_compute_count, :363,2595)
+static int shift_right_and_impl(bmx_ctx* ctx, const bmx_vec* const* src, size_t n, int opt_compress, int any,
+                                bmx_vec** result, int* found, uint64_t* count)
+{
+    ARGCHK(ctx && (n == 0 || src) && (result || count));
+    if (result) *result = nullptr;
+    if (found) *found = 0;
+    if (count) *count = 0;
+    int rc = set_dev(ctx); if (rc) return rc;
+    uint32_t ncols = 0; uint64_t nbits = 0;
+    std::vector<const u64*> descs(std::max<size_t>(n, 1), nullptr);
+    std::vector<u32> nblk(std::max<size_t>(n, 1), 0);
+    for (size_t i = 0; i < n; ++i) {
+        if (!src[i] || src[i]->ctx != ctx) { g_last_error = "operand is null or belongs to another context"; return BMX_ERR_BADARG; }
+        descs[i] = src[i]->d_desc; nblk[i] = src[i]->nblocks;
+        ncols = std::max(ncols, src[i]->nblocks); nbits = std::max(nbits, src[i]->nbits);
+    }
+    bmx_vec* v = nullptr; BlockStat* st = nullptr; u32* offs = nullptr;
+    if (result && (rc = result_begin(ctx, nbits, ncols, &v, &st, &offs))) return rc;   // empty list => cleared target (:2499)
+    if (!n || !ncols) {
+        if (v && ncols) {
+            hipError_t e = hipMemsetAsync(v->d_desc, 0, (size_t)ncols * 8, ctx->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+            if (e != hipSuccess) { bmx_vec_free(ctx, v); return fail_hip(e, "bmx_agg_shift_right_and", __LINE__); }
+            v->counts[BMX_NULL] = ncols;
+        }
+        if (result) *result = v;
+        return BMX_OK;
+    }
+    void* d_descs = nullptr; void* d_nblk = nullptr;
+    if ((rc = dmalloc(ctx, &d_descs, n * 8)) || (rc = dmalloc(ctx, &d_nblk, n * 4))) { dfree(ctx, d_descs); if (v) bmx_vec_free(ctx, v); return rc; }
+    hipError_t e = hipMemcpyAsync(d_descs, descs.data(), n * 8, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_nblk, nblk.data(), n * 4, hipMemcpyHostToDevice, ctx->stream);
+    size_t lds = 4 * 4096 * 4;
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_shift_right_and, dim3((ncols + 3) / 4), dim3(256), lds, ctx->stream,
+                           (const u64* const*)d_descs, (const u32*)d_nblk, (u32)n, ncols, opt_compress, result ? 0 : 1,
+                           ctx->xcd_swz, v ? v->d_bits : nullptr, v ? v->d_desc : nullptr, st, ctx->d_slots);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess && result && any) {
+        hipLaunchKernelGGL(k_keep_first_block, dim3(1), dim3(1024), 0, ctx->stream, st, v->d_desc, ncols);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess && !result) {
+        hipLaunchKernelGGL(k_sum_slots, dim3(1), dim3(64), 0, ctx->stream, ctx->d_slots, ctx->d_small);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(ctx->h_small, ctx->d_small, 8, hipMemcpyDeviceToHost, ctx->stream);
+    }
+    if (e == hipSuccess && result) rc = result_finish(ctx, v, st, offs);
+    else if (e != hipSuccess) rc = fail_hip(e, "bmx_agg_shift_right_and", __LINE__);
+    hipError_t e2 = hipStreamSynchronize(ctx->stream);
+    if (!rc && e2 != hipSuccess) rc = fail_hip(e2, "bmx_agg_shift_right_and", __LINE__);
+    dfree(ctx, d_descs); dfree(ctx, d_nblk);
+    if (rc) { if (v) bmx_vec_free(ctx, v); return rc; }
+    if (result) {
+        if (found) *found = (v->counts[BMX_FULL] + v->counts[BMX_BIT] + v->counts[BMX_GAP]) != 0;
+        *result = v;
+    } else {
+        *count = ctx->h_small[0];
+        if (found) *found = *count != 0;
+    }
+    return BMX_OK;
+}
+
+int bmx_agg_shift_right_and(bmx_ctx* ctx, const bmx_vec* const* src, size_t n, int opt_compress, int any,
+                            bmx_vec** result, int* found)
+{
+    ARGCHK(result);
+    return shift_right_and_impl(ctx, src, n, opt_compress, any, result, found, nullptr);
+}
+
+int bmx_agg_shift_right_and_count(bmx_ctx* ctx, const bmx_vec* const* src, size_t n, uint64_t* count)
+{
+    ARGCHK(count);
+    return shift_right_and_impl(ctx, src, n, 0, 0, nullptr, nullptr, count);
 }
 
 // ---------------------------------------------------------------------------

@@ -15,7 +15,7 @@
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ void store_result(const Blk& acc, u32 nb, int opt_compress,
                                              uint4* __restrict__ slab, u64* __restrict__ desc,
-                                             BlockStat* __restrict__ st, u32 lane)
+                                             BlockStat* __restrict__ st, u32 lane, bool full_as_bit = false)
 {
     Blk t;
     u32 pop = wave_sum(blk_lane_popcount(acc));
@@ -23,6 +23,7 @@ __device__ __forceinline__ void store_result(const Blk& acc, u32 nb, int opt_com
     u32 first = __shfl(acc.r[0].x, 0, 64) & 1u;
     u32 kind = (runs == 1u) ? (first ? K_FULL : K_NULL)
              : ((opt_compress && runs < 1276u) ? K_GAP : K_BIT);
+    if (full_as_bit && kind == K_FULL) kind = K_BIT;         // copy_bit_block (src/bmblocks.h:1340) keeps all-ones as bits
     uint4* slot = slab + (size_t)nb * 512u;
     if (kind == K_BIT || kind == K_GAP) blk_store(acc, as_g4(slot), lane);
     if (lane == 0) {

@@ -142,6 +142,16 @@ int bmx_agg_and_sub(bmx_ctx* ctx, const bmx_vec* const* src_and, size_t n_and,
  * index of the first set bit of the AND-SUB result, nothing materialised. */
 int bmx_find_first_and_sub(bmx_ctx* ctx, const bmx_vec* const* src_and, size_t n_and,
                            const bmx_vec* const* src_sub, size_t n_sub, int* found, uint64_t* idx);
+/* aggregator::combine_shift_right_and(bv_target, src, n, any)  src/bmaggregator.h:552,2494 (member form
+ * :473,1089): T_0 = src[0], T_k = (T_{k-1} >> 1) & src[k] with ">>" moving bit p to p+1 across block
+ * borders (process_shift_right_and :2618) -- result bit p is set iff src[k] has bit p-(n-1-k) for every k
+ * (sequence search).  Stored with the aggregator's optimisation mode (opt_none by default, :917,2600).
+ * any != 0: stop at the first block column that produced a result (:2519) -- the target then holds that one
+ * block.  *found = target is non-empty.  Empty list => cleared target, found = 0 (:2499-2503). */
+int bmx_agg_shift_right_and(bmx_ctx* ctx, const bmx_vec* const* src, size_t n, int opt_compress, int any,
+                            bmx_vec** result, int* found);
+/* same under set_compute_count(true) (src/bmaggregator.h:363,2595): no target, *count = aggregator::count(). */
+int bmx_agg_shift_right_and_count(bmx_ctx* ctx, const bmx_vec* const* src, size_t n, uint64_t* count);
 /* aggregator::pipeline<agg_opt_only_counts>  src/bmaggregator.h:62-103,222-341:
  * arg-groups are given as concatenated operand lists, and_n[g] / sub_n[g] per
  * group (pipeline::add() + arg_groups::add(bv, 0|1) + complete(), :2784-2931). */

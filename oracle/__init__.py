@@ -211,6 +211,10 @@ class Oracle:
         getattr(L, prefix + "agg_pipeline_results").argtypes = [
             C.POINTER(vp), C.POINTER(C.c_uint32), C.POINTER(vp), C.POINTER(C.c_uint32), C.c_size_t,
             C.POINTER(vp), C.POINTER(C.c_uint64), C.POINTER(vp)]
+        getattr(L, prefix + "agg_shift_right_and").restype = vp
+        getattr(L, prefix + "agg_shift_right_and").argtypes = [C.POINTER(vp), C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_int)]
+        getattr(L, prefix + "agg_shift_right_and_count").restype = C.c_uint64
+        getattr(L, prefix + "agg_shift_right_and_count").argtypes = [C.POINTER(vp), C.c_size_t]
         getattr(L, prefix + "vec_find_first").restype = C.c_int
         getattr(L, prefix + "vec_find_first").argtypes = [vp, C.POINTER(C.c_uint64)]
         getattr(L, prefix + "find_first_and_sub").restype = C.c_int
@@ -289,6 +293,15 @@ class Oracle:
     def agg_and_sub(self, and_vecs, sub_vecs=()) -> Vec:
         h = self._f("agg_and_sub")(self._ptrs(and_vecs), len(and_vecs), self._ptrs(sub_vecs), len(sub_vecs))
         return Vec(self, h, max([v.nbits for v in list(and_vecs) + list(sub_vecs)], default=0))
+
+    def agg_shift_right_and(self, vecs, opt_compress: bool = False, any: bool = False):
+        """-> (target Vec, found)  aggregator::combine_shift_right_and  src/bmaggregator.h:2494"""
+        f = C.c_int()
+        h = self._f("agg_shift_right_and")(self._ptrs(vecs), len(vecs), int(opt_compress), int(any), C.byref(f))
+        return Vec(self, h, max([v.nbits for v in vecs], default=0)), bool(f.value)
+
+    def agg_shift_right_and_count(self, vecs) -> int:
+        return int(self._f("agg_shift_right_and_count")(self._ptrs(vecs), len(vecs)))
 
     def agg_member(self, kind: str, vecs) -> Vec:
         """reference only: add()+combine_and()/combine_or() member API"""

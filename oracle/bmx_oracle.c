@@ -1215,6 +1215,84 @@ bmo_vec* bmo_agg_or(const bmo_vec* const* src, size_t n)
     return t;
 }
 
+/* aggregator::combine_shift_right_and  src/bmaggregator.h:2494-2529 (outer loop with the per-operand
+ * carry_overs[] array, :2479-2489), one block column :2534-2606, one stage process_shift_right_and
+ * :2611-2669 (fused shift+AND bit_block_shift_r1_and_unr; NULL argument: carry out, block zeroed :2655-2663;
+ * GAP argument: shift against the all-ones block then gap_and_to_bitset :2622-2640).
+ * Restated without the digest bookkeeping (the digest only skips work on waves that are already zero;
+ * the ":2579 0 into 00000 block" skip is kept because it also leaves carry_overs[k] untouched).
+ * count != NULL mirrors set_compute_count(true) (:363,2593-2597): nothing is stored, *count = count().
+ * any: return at the first column that produced a block (:2519). */
+static int shift_right_and_run(const bmo_vec* const* src, size_t n, int opt_compress, int any,
+                               bmo_vec* t, uint64_t* count)
+{
+    uint64_t nbits;
+    uint32_t nblocks = max_blocks(src, n, &nbits);
+    unsigned char* carry_overs = (unsigned char*)calloc(n ? n : 1, 1);
+    uint32_t* blk = alloc_bit_block();
+    uint32_t* arg = alloc_bit_block();
+    int found_any = 0;
+    for (uint32_t nb = 0; nb < nblocks; ++nb) {
+        /* first operand: plain copy (:2546-2570) */
+        int blk_zero = 0;
+        switch (kind_at(src[0], nb)) {
+        case BMO_NULL: memset(blk, 0, BMO_BLOCK_WORDS * 4); blk_zero = 1; break;
+        case BMO_FULL: memset(blk, 0xFF, BMO_BLOCK_WORDS * 4); break;
+        case BMO_GAP:  bmo_gap_convert_to_bitset(blk, (const uint16_t*)src[0]->blk[nb]); break;
+        default:       memcpy(blk, src[0]->blk[nb], BMO_BLOCK_WORDS * 4); break;
+        }
+        carry_overs[0] = 0;
+        for (size_t k = 1; k < n; ++k) {
+            unsigned co = carry_overs[k];
+            if (blk_zero && !co) continue;                                  /* :2579 */
+            /* shift right by one (bit p -> p+1), carry in at bit 0, carry out from bit 65535 */
+            unsigned co_out = blk[BMO_BLOCK_WORDS - 1] >> 31;
+            for (uint32_t w = BMO_BLOCK_WORDS - 1; w > 0; --w) blk[w] = (blk[w] << 1) | (blk[w - 1] >> 31);
+            blk[0] = (blk[0] << 1) | co;
+            switch (kind_at(src[k], nb)) {
+            case BMO_NULL: memset(blk, 0, BMO_BLOCK_WORDS * 4); break;     /* :2655-2663 */
+            case BMO_FULL: break;                                          /* get_block() hands out the real all-ones block */
+            case BMO_GAP:
+                bmo_gap_convert_to_bitset(arg, (const uint16_t*)src[k]->blk[nb]);
+                for (uint32_t w = 0; w < BMO_BLOCK_WORDS; ++w) blk[w] &= arg[w];
+                break;
+            default: {
+                const uint32_t* a = (const uint32_t*)src[k]->blk[nb];
+                for (uint32_t w = 0; w < BMO_BLOCK_WORDS; ++w) blk[w] &= a[w];
+                break; }
+            }
+            carry_overs[k] = (unsigned char)co_out;
+            blk_zero = 1;
+            for (uint32_t w = 0; w < BMO_BLOCK_WORDS; ++w) if (blk[w]) { blk_zero = 0; break; }
+        }
+        if (!blk_zero) {                                                    /* :2590-2604 */
+            if (count) *count += bmo_bit_block_count(blk);
+            else store_bit_block(t, nb, blk, opt_compress);
+            found_any = 1;
+            if (any) break;
+        }
+    }
+    free(blk); free(arg); free(carry_overs);
+    return found_any;
+}
+
+bmo_vec* bmo_agg_shift_right_and(const bmo_vec* const* src, size_t n, int opt_compress, int any, int* found)
+{
+    uint64_t nbits;
+    (void)max_blocks(src, n, &nbits);
+    bmo_vec* t = bmo_vec_new(nbits);
+    int f = n ? shift_right_and_run(src, n, opt_compress, any, t, NULL) : 0;   /* empty list: cleared target (:2499) */
+    if (found) *found = f;
+    return t;
+}
+
+uint64_t bmo_agg_shift_right_and_count(const bmo_vec* const* src, size_t n)
+{
+    uint64_t c = 0;
+    if (n) (void)shift_right_and_run(src, n, 0, 0, NULL, &c);
+    return c;
+}
+
 /* counts-only pipeline: src/bmaggregator.h:1292-1399
  *   count[p] += is_full ? 65536 : bit_block_count(tb1, digest) */
 void bmo_agg_pipeline_counts(const bmo_vec* const* and_list, const uint32_t* and_n,

@@ -101,6 +101,12 @@ uint64_t bmo_count_op2(int op, const bmo_vec* a, const bmo_vec* b);
 bmo_vec* bmo_agg_or(const bmo_vec* const* src, size_t n);
 bmo_vec* bmo_agg_and_sub(const bmo_vec* const* src_and, size_t n_and,
                          const bmo_vec* const* src_sub, size_t n_sub);
+/* aggregator::combine_shift_right_and (src/bmaggregator.h:2494-2669): T_0 = src[0],
+ * T_k = shift_right_1(T_{k-1}) & src[k] with the carry crossing block borders; stored with opt mode
+ * opt_compress (0 = opt_none, the aggregator default); any: stop at the first result block.
+ * _count: set_compute_count(true) form (:363,2593). */
+bmo_vec* bmo_agg_shift_right_and(const bmo_vec* const* src, size_t n, int opt_compress, int any, int* found);
+uint64_t bmo_agg_shift_right_and_count(const bmo_vec* const* src, size_t n);
 /* counts-only pipeline (src/bmaggregator.h:1292-1399): groups given as
  * concatenated pointer lists; and_n[g]/sub_n[g] operands per group.
  * block range [nb_from, nb_to) restricts the columns visited (shard support). */

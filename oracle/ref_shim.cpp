@@ -172,6 +172,26 @@ void* ref_agg_and_sub(void* const* src_and, size_t n_and, void* const* src_sub, 
     return t;
 }
 
+// aggregator::combine_shift_right_and (bmaggregator.h:552,2494); count form via set_compute_count (:363)
+void* ref_agg_shift_right_and(void* const* src, size_t n, int opt_compress, int any, int* found)
+{
+    bvect* t = new bvect();
+    agg_t agg;
+    agg.set_optimization(opt_compress ? bvect::opt_compress : bvect::opt_none);
+    bool f = agg.combine_shift_right_and(*t, reinterpret_cast<const bvect* const*>(src), n, any != 0);
+    if (found) *found = f ? 1 : 0;
+    return t;
+}
+
+uint64_t ref_agg_shift_right_and_count(void* const* src, size_t n)
+{
+    bvect t;
+    agg_t agg;
+    agg.set_compute_count(true);
+    (void)agg.combine_shift_right_and(t, reinterpret_cast<const bvect* const*>(src), n, false);
+    return agg.count();
+}
+
 // member-style API: add() + combine_and / combine_or  (bmaggregator.h:1013,1021,1030)
 void* ref_agg_member(int kind, void* const* src, size_t n)
 {

@@ -73,6 +73,9 @@ AGG_GROUPS = [([0, 1], []), ([0, 1, 2], []), ([0, 1, 2, 3, 4, 5], []), ([0, 1], 
               ([0, 1, 2], [3, 4, 5]), ([3], []), ([1, 0, 5, 2], [4])]
 OR_SETS = [[0, 1], [0, 1, 2, 3, 4, 5], [2], [5, 3, 1]]
 PAIRS = [(0, 1), (1, 0), (2, 3), (4, 5), (0, 0)]
+# combine_shift_right_and operand sequences (src[0] is shifted n-1 times): short patterns (register path,
+# shifts < 32), 40 and 70 operands (shifts across words), one operand (plain copy)
+SHIFT_SETS = [[0, 1], [1, 0], [0, 1, 2], [5, 4, 3, 2, 1, 0], [2], [0, 1] * 20, [3, 4, 5, 0, 1, 2, 2] * 10]
 
 
 def rank_queries(nbits: int) -> np.ndarray:

@@ -19,7 +19,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 sys.path.insert(0, HERE)
 
 import oracle  # noqa: E402
-from cases import (AGG_GROUPS, CASES, OR_SETS, PAIRS, SEED, make_inputs, rank_queries, select_queries, sha)  # noqa: E402
+from cases import (AGG_GROUPS, CASES, OR_SETS, PAIRS, SEED, SHIFT_SETS, make_inputs, rank_queries, select_queries, sha)  # noqa: E402
 
 
 def gap_slab_masked(kinds, offs, gaps):
@@ -74,6 +74,19 @@ def run(R, P):
         for o in OR_SETS:
             t = R.agg_or([vecs[i] for i in o])
             c["agg_or"].append({"src": o, "sha": sha(t.to_words()), "count": t.count()})
+        # combine_shift_right_and (bmaggregator.h:2494): default opt_none target, opt_compress kinds,
+        # the `any` form (first result block only) and the set_compute_count form
+        c["shift_right_and"] = []
+        for o in SHIFT_SETS:
+            src = [vecs[i] for i in o]
+            t, f = R.agg_shift_right_and(src, False, False)
+            tc, fc = R.agg_shift_right_and(src, True, False)
+            ta, fa = R.agg_shift_right_and(src, False, True)
+            assert (t.to_words() == tc.to_words()).all() and f == fc == fa
+            c["shift_right_and"].append({"src": o, "sha": sha(t.to_words()), "count": t.count(), "found": bool(f),
+                                         "kinds": t.flatten()[0].tolist(), "kinds_opt": tc.flatten()[0].tolist(),
+                                         "any_sha": sha(ta.to_words()), "any_count": ta.count(),
+                                         "count_mode": R.agg_shift_right_and_count(src)})
         cnt = R.pipeline_counts([([vecs[i] for i in a], [vecs[i] for i in s]) for (a, s) in AGG_GROUPS])
         c["pipeline_counts"] = [int(x) for x in cnt]
         assert c["pipeline_counts"] == [g["count"] for g in c["agg_and_sub"]]

@@ -98,6 +98,21 @@ def test_golden_case(ctx, port, golden, case):
     for e in g["agg_or"]:
         t = agg.combine_or([vecs[i] for i in e["src"]])
         assert sha(t.to_words(nwb)) == e["sha"] and t.count() == e["count"]
+    for e in g["shift_right_and"]:
+        src = [(vecs if k % 2 else up)[i] for k, i in enumerate(e["src"])]
+        agg.set_optimization(False)
+        t, f = agg.combine_shift_right_and(src)
+        assert sha(t.to_words(nwb)) == e["sha"] and t.count() == e["count"] and f == e["found"], e["src"]
+        assert t.block_table()[0].tolist() == e["kinds"]
+        agg.set_optimization(True)
+        assert agg.combine_shift_right_and(src)[0].block_table()[0].tolist() == e["kinds_opt"]
+        agg.set_optimization(False)
+        ta, fa = agg.combine_shift_right_and(src, any=True)
+        assert sha(ta.to_words(nwb)) == e["any_sha"] and ta.count() == e["any_count"] and fa == e["found"]
+        agg.set_compute_count(True)
+        none, fc = agg.combine_shift_right_and(src)
+        assert none is None and agg.count() == e["count_mode"] and fc == e["found"]
+        agg.set_compute_count(False)
     for e in g["find_first"]:
         f, idx = agg.find_first_and_sub([vecs[i] for i in e["and"]], [up[i] for i in e["sub"]])
         assert f == e["found"] and (not f or idx == e["idx"]), (e, f, idx)
@@ -478,3 +493,65 @@ def test_sparse_state_of_gap_lists(ctx, port, common_bits, own_dq, nvec):
         found, pos = agg.find_first_and_sub(a, s)
         ef, epos = port.find_first_and_sub(pv[:na], ps[:ns])
         assert found == ef and (not found or pos == epos)
+
+
+def test_shift_right_and(ctx, port):
+    """aggregator::combine_shift_right_and (src/bmaggregator.h:2494): the reference's own known answers
+    (tests/stress/t.cpp:10640-10800, table in test_oracle_golden.shift_right_and_kats) and seeded dense /
+    mixed operands vs the oracle -- pattern lengths 2..33 (register path, carries across block borders),
+    40 and 100 operands (shifts across words through the LDS window), GAP / FULL / NULL neighbours."""
+    from test_oracle_golden import shift_right_and_kats
+    agg = bm.aggregator(ctx)
+    for a, b, exp in shift_right_and_kats():
+        gv, pv = [], []
+        for spec in (a, b):
+            nbits = 0xFFFFFFFF if spec.get("range", (0, 0))[1] > (1 << 30) else 5 * 65536
+            v = port.new(nbits)
+            for i in spec.get("bits", []): v.set_bit(i)
+            if "range" in spec: v.set_range(*spec["range"])
+            v.optimize()
+            pv.append(v)
+            gv.append(bm.bvector.from_block_table(ctx, nbits, *v.flatten()))
+        agg.set_optimization(True)
+        t, f = agg.combine_shift_right_and(gv)
+        e, ef = port.agg_shift_right_and(pv, True, False)
+        assert t.count() == exp["count"] == e.count() and f == ef == (exp["count"] > 0)
+        k = t.block_table()[0].tolist()
+        assert k == e.flatten()[0].tolist()
+        if "blocks" in exp:
+            assert k.count(bm.BIT) + k.count(bm.GAP) == exp["blocks"]
+        nw = min(t.info()["nblocks"], 8) * 2048
+        assert (t.to_words(nw) == e.to_words(nw)).all()
+        agg.set_optimization(False)
+    nbits = 6 * 65536 + 1234
+    nw = 7 * 2048
+    rng = np.random.default_rng(2024)
+    for dq, n in [(64000, 2), (64000, 9), (65300, 33), (65400, 40), (65500, 100), (60000, 5), (32768, 3), (655, 2)]:
+        ws = []
+        for v in range(min(n, 12)):
+            w = port.gen_words(777 + dq, v, dq, nbits)
+            r = int(rng.integers(0, 6))
+            if r == 0: w[2048 * 2:2048 * 3] = 0xFFFFFFFF                 # FULL block (and a FULL lower neighbour)
+            if r == 1: w[2048 * 4:2048 * 5] = 0                          # NULL block
+            if r == 2: w[2048:2048 * 2] = 0xFFFFFFFF; w[2048 + 5] = 0x7FFFFFFF   # dense GAP block
+            ws.append(w)
+        sel = [i % len(ws) for i in range(n)]
+        gv = [bm.bit_import_u32(ctx, w, True) for w in ws]
+        pv = [port.import_words(w, True, nbits) for w in ws]
+        for opt in (False, True):
+            agg.set_optimization(opt)
+            t, f = agg.combine_shift_right_and([gv[i] for i in sel])
+            e, ef = port.agg_shift_right_and([pv[i] for i in sel], opt, False)
+            assert f == ef and (t.to_words(nw) == e.to_words(nw)).all(), (dq, n, opt)
+            assert t.block_table()[0].tolist() == e.flatten()[0].tolist()
+        agg.set_optimization(False)
+        ta, fa = agg.combine_shift_right_and([gv[i] for i in sel], any=True)
+        ea, efa = port.agg_shift_right_and([pv[i] for i in sel], False, True)
+        assert fa == efa and (ta.to_words(nw) == ea.to_words(nw)).all()
+        agg.set_compute_count(True)
+        agg.combine_shift_right_and([gv[i] for i in sel])
+        assert agg.count() == port.agg_shift_right_and_count([pv[i] for i in sel])
+        agg.set_compute_count(False)
+    # member form: add() + combine_shift_right_and(); empty list => cleared target (:2499)
+    t, f = agg.combine_shift_right_and([])
+    assert not f and t.count() == 0
