@@ -33,6 +33,17 @@ void flatten(const BMBV& bv, uint32_t nblocks, block_table& t)
     t.kinds.assign(nblocks, BMX_NULL); t.offs.assign(nblocks, 0);
     t.bit_slab.clear(); t.gap_slab.clear();
     if (!bman.is_init()) return;
+    {   // size the staging slabs once (a growing std::vector would re-copy them ~log2(n) times)
+        size_t nbit = 0, ngapw = 0;
+        for (uint32_t nb = 0; nb < nblocks; ++nb) {
+            unsigned i = nb >> bm::set_array_shift, j = nb & bm::set_array_mask;
+            if (i >= bman.top_block_size()) break;
+            const bm::word_t* p = bman.get_block_ptr(i, j);
+            if (!p || p == FULL_BLOCK_FAKE_ADDR || p == FULL_BLOCK_REAL_ADDR) continue;
+            if (BM_IS_GAP(p)) ngapw += (size_t)(BMGAP_PTR(p)[0] >> 3) + 1u; else ++nbit;
+        }
+        t.bit_slab.reserve(nbit * bm::set_block_size); t.gap_slab.reserve(ngapw);
+    }
     uint32_t n_bit = 0;
     for (uint32_t nb = 0; nb < nblocks; ++nb) {
         unsigned i = nb >> bm::set_array_shift, j = nb & bm::set_array_mask;
@@ -61,16 +72,58 @@ uint32_t effective_blocks(const BMBV& bv)
     return (uint32_t)(last >> bm::set_block_shift) + 1u;
 }
 
-/// host bm::bvector<>  ->  device bmx::bvector
+/// View of a vector whose blocks already lie back to back in memory -- what freeze() / optimize_freeze()
+/// produce (blocks_manager::alloc_arena + copy_to_arena, src/bmblocks.h:2614-2655,2692-2770: every
+/// bit-block in block order, then the top/sub pointer arrays, then every GAP block in block order).
+/// Fills kinds / offs only and points at the arena memory; false when the blocks are scattered.
 template <class BMBV>
-void upload(const BMBV& src, bvector& dst, uint32_t nblocks = 0)
+bool flatten_view(const BMBV& bv, uint32_t nblocks, block_table& t,
+                  const uint32_t*& bit_base, uint32_t& n_bit, const uint16_t*& gap_base, uint64_t& gap_words)
+{
+    const typename BMBV::blocks_manager_type& bman = bv.get_blocks_manager();
+    t.nbits = bv.size();
+    t.kinds.assign(nblocks, BMX_NULL); t.offs.assign(nblocks, 0);
+    t.bit_slab.clear(); t.gap_slab.clear();
+    bit_base = nullptr; gap_base = nullptr; n_bit = 0; gap_words = 0;
+    if (!bman.is_init()) return true;
+    for (uint32_t nb = 0; nb < nblocks; ++nb) {
+        unsigned i = nb >> bm::set_array_shift, j = nb & bm::set_array_mask;
+        if (i >= bman.top_block_size()) break;
+        const bm::word_t* p = bman.get_block_ptr(i, j);
+        if (!p) continue;
+        if (p == FULL_BLOCK_FAKE_ADDR || p == FULL_BLOCK_REAL_ADDR) { t.kinds[nb] = BMX_FULL; continue; }
+        if (BM_IS_GAP(p)) {
+            const bm::gap_word_t* g = BMGAP_PTR(p);
+            if (!gap_base) gap_base = g;
+            if (g != gap_base + gap_words) return false;
+            t.kinds[nb] = BMX_GAP; t.offs[nb] = (uint32_t)gap_words;
+            gap_words += (uint64_t)(g[0] >> 3) + 1u;
+        } else {
+            if (!bit_base) bit_base = p;
+            if (p != bit_base + (size_t)n_bit * bm::set_block_size) return false;
+            t.kinds[nb] = BMX_BIT; t.offs[nb] = n_bit++;
+        }
+    }
+    return true;
+}
+
+/// host bm::bvector<>  ->  device bmx::bvector.  A frozen (read-only, arena-backed) vector is uploaded
+/// straight from its arena -- no host-side gather; returns true when that path was taken.
+template <class BMBV>
+bool upload(const BMBV& src, bvector& dst, uint32_t nblocks = 0)
 {
     if (!nblocks) nblocks = effective_blocks(src);
-    block_table t;
-    flatten(src, nblocks, t);
     uint64_t nbits = (uint64_t)nblocks * BMX_BLOCK_BITS;
+    block_table t;
+    const uint32_t* bit_base; const uint16_t* gap_base; uint32_t n_bit; uint64_t gap_words;
+    if (src.is_ro() && flatten_view(src, nblocks, t, bit_base, n_bit, gap_base, gap_words)) {
+        dst.assign_block_table(nbits, nblocks, t.kinds.data(), t.offs.data(), bit_base, n_bit, gap_base, gap_words);
+        return true;
+    }
+    flatten(src, nblocks, t);
     dst.assign_block_table(nbits, nblocks, t.kinds.data(), t.offs.data(), t.bit_slab.data(),
                            (uint32_t)(t.bit_slab.size() / BMX_BLOCK_WORDS), t.gap_slab.data(), t.gap_slab.size());
+    return false;
 }
 
 /// install a block table into a host bm::bvector<> through the reference's own

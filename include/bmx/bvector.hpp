@@ -371,6 +371,35 @@ public:
         bv_target.adopt(r);
         return any != 0;
     }
+    /// set_optimization :359, set_compute_count :363, count() :488
+    void set_optimization(bool opt_compress = true) { opt_compress_ = opt_compress; }
+    void set_compute_count(bool count_mode) { compute_count_ = count_mode; count_ = 0; }
+    size_type count() const { return count_; }
+
+    /// combine_shift_right_and  src/bmaggregator.h:473,1089 (member form) / :552,2494 (C-style):
+    /// T_0 = src[0], T_k = (T_{k-1} >> 1) & src[k]; stored with the aggregator's optimisation mode.
+    /// Under set_compute_count(true) the target is left untouched and count() holds the population (:2593).
+    void combine_shift_right_and(BV& bv_target)
+    {
+        count_ = 0;
+        (void)combine_shift_right_and(bv_target, ag_.arg_bv0.data(), ag_.arg_bv0.size(), false);
+    }
+    bool combine_shift_right_and(BV& bv_target, const bvector_type_const_ptr* bv_src_and, size_t src_and_size, bool any)
+    {
+        std::vector<const bmx_vec*> h(src_and_size);
+        for (size_t i = 0; i < src_and_size; ++i) h[i] = bv_src_and[i]->handle();
+        if (compute_count_) {
+            uint64_t c = 0;
+            check(bmx_agg_shift_right_and_count(ctx_->handle(), h.data(), src_and_size, &c));
+            count_ += (size_type)c;
+            return count_ != 0;
+        }
+        bmx_vec* r = nullptr; int found = 0;
+        check(bmx_agg_shift_right_and(ctx_->handle(), h.data(), src_and_size, opt_compress_ ? 1 : 0, any ? 1 : 0, &r, &found));
+        bv_target.adopt(r);
+        return found != 0;
+    }
+
     /// find_first_and_sub(idx)  src/bmaggregator.h:1079 / C-style :1458
     bool find_first_and_sub(size_type& idx)
     { return find_first_and_sub(idx, ag_.arg_bv0.data(), ag_.arg_bv0.size(), ag_.arg_bv1.data(), ag_.arg_bv1.size()); }
@@ -414,6 +443,9 @@ public:
 private:
     context* ctx_;
     arg_groups ag_;
+    bool opt_compress_ = false;          // opt_mode_ = opt_none, src/bmaggregator.h:917
+    bool compute_count_ = false;
+    size_type count_ = 0;
 };
 
 } // namespace bmx

@@ -105,6 +105,45 @@ int main()
                                                            (int)rf, (unsigned long long)ri, (int)gf, (unsigned long long)gi);
         REQUIRE(rf == gf && (!rf || ri == gi));
     }
+    // frozen vectors (freeze() arena, src/bmblocks.h:2572-2770) upload straight from the arena
+    {
+        for (unsigned v = 0; v < NV; v += 3) {
+            bvect fz(hv[v]);
+            fz.freeze();
+            REQUIRE(fz.is_ro());
+            bmx::bvector g(ctx);
+            bool zero_copy = bmx::upload(fz, g, NB);
+            REQUIRE(zero_copy);
+            REQUIRE(g.count() == hv[v].count() && g.equal(gv[v]));
+            bvect back; bmx::download(g, back);
+            REQUIRE(back.compare(hv[v]) == 0);
+        }
+        bmx::bvector g2(ctx);
+        REQUIRE(!bmx::upload(hv[1], g2, NB));           // mutable vector: gathered copy
+    }
+    // combine_shift_right_and vs the reference (dense operands so that the chain survives), member form,
+    // opt_compress and count-only modes
+    {
+        std::vector<bvect> dv(6); std::vector<bmx::bvector> dg; dg.reserve(6);
+        for (unsigned v = 0; v < 6; ++v) {
+            dv[v].set_range(10, bvect::size_type(nbits - 20));
+            for (bvect::size_type k = 100 + v; k < nbits - 20; k += 997 + 131 * v) dv[v].clear_bit(k);
+            if (v & 1) dv[v].optimize();
+            dg.emplace_back(ctx); bmx::upload(dv[v], dg.back(), NB);
+        }
+        bm::aggregator<bvect> ragg; bmx::aggregator<bmx::bvector> gagg(ctx);
+        for (unsigned v = 0; v < 6; ++v) { ragg.add(&dv[v]); gagg.add(&dg[v]); }
+        for (int opt = 0; opt < 2; ++opt) {
+            bvect r; bmx::bvector t(ctx); bvect g;
+            if (opt) { ragg.set_optimization(); gagg.set_optimization(); }
+            ragg.combine_shift_right_and(r); gagg.combine_shift_right_and(t); bmx::download(t, g);
+            REQUIRE(r.any() && g.compare(r) == 0);
+        }
+        ragg.set_compute_count(true); gagg.set_compute_count(true);
+        bvect r; bmx::bvector t(ctx);
+        ragg.combine_shift_right_and(r); gagg.combine_shift_right_and(t);
+        REQUIRE(ragg.count() == gagg.count() && gagg.count() != 0);
+    }
     // rank / select vs bvector<>::count_to / select with the reference rs_index
     {
         bvect::rs_index_type rrs; hv[3].build_rs_index(&rrs);

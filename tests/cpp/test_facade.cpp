@@ -78,6 +78,24 @@ int main()
     REQUIRE(t.count() == bmo_vec_count(eo));
     { bmx::size_type idx = 0; REQUIRE(!agg.find_first_and_sub(idx)); }
     bmo_vec_free(e); bmo_vec_free(eo);
+    // combine_shift_right_and (member form on a fresh group, then the count-only mode)
+    {
+        bmx::aggregator<bmx::bvector> sagg(ctx);
+        const bmo_vec* s3[3] = {pv[0], pv[1], pv[2]};
+        for (unsigned v = 0; v < 3; ++v) sagg.add(&gv[v]);
+        bmx::bvector st(ctx);
+        sagg.combine_shift_right_and(st);
+        int pf = 0;
+        bmo_vec* es = bmo_agg_shift_right_and(s3, 3, 0, 0, &pf);
+        REQUIRE(st.count() == bmo_vec_count(es));
+        std::vector<uint32_t> w1(12 * 2048), w2(12 * 2048);
+        st.export_words(w1.data(), w1.size()); bmo_vec_to_words(es, w2.data(), w2.size());
+        REQUIRE(w1 == w2);
+        sagg.set_compute_count(true);
+        sagg.combine_shift_right_and(st);
+        REQUIRE(sagg.count() == bmo_agg_shift_right_and_count(s3, 3));
+        bmo_vec_free(es);
+    }
     // counts-only pipeline
     bmx::aggregator<bmx::bvector>::pipeline<bmx::agg_opt_only_counts> pipe(ctx);
     {
