@@ -363,6 +363,62 @@ __device__ __forceinline__ void gap_apply_lds_lane(gcptr16 g, u32* lds)
     }
 }
 
+// ---- OR of MANY sparse GAP operands (column-tile kernel): branch-light lane mode -----------------
+// The 64-byte head of the next operand's block is fetched while the current one is applied (GapHead),
+// and a run is applied without control flow in the common case: runs of a sparse vector sit inside one
+// word, so the first-word mask is OR-ed unconditionally (an inactive slot ORs 0) and only a run that
+// crosses words takes the branch.  ~20 VALU per run instead of ~45 (the kernel is VALU-bound: 16 waves
+// per CU each issuing ~16 runs per operand).
+struct GapHead { u32x4 c[4]; };
+
+__device__ __forceinline__ void gap_head_fetch(GapHead& h, u64 gaddr, bool is_gap)
+{
+    const u32x4 z = {0u, 0u, 0u, 0u};
+    gcptr4 g4 = (gcptr4)(uintptr_t)gaddr;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) h.c[j] = is_gap ? g4[j] : z;         // header 0 = length 0: nothing is applied
+}
+
+__device__ __forceinline__ void gap_or_chunk_fast(u32* lds, const u32 x[5], u32 c, u32 len, bool odd_runs)
+{
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        u32 k, s, e;
+        if (odd_runs) { k = 8u * c + 2u * i + 1u; s = (k == 1u) ? 0u : (x[i] & 0xFFFFu) + 1u; e = x[i] >> 16; }
+        else          { k = 8u * c + 2u * i + 2u; s = (x[i] >> 16) + 1u; e = x[i + 1] & 0xFFFFu; }
+        bool act = k <= len;
+        u32 wl = (s >> 5) & 2047u, wr = e >> 5;
+        u32 ml = ~0u << (s & 31u), mr = ~0u >> (31u - (e & 31u));
+        u32 m1 = (wl == wr) ? (ml & mr) : ml;
+        atomicOr(&lds[wl], act ? m1 : 0u);
+        if (act && wr > wl) {                                           // rare for sparse operands
+            atomicOr(&lds[wr], mr);
+            for (u32 w = wl + 1u; w < wr; ++w) lds[w] = ~0u;
+        }
+    }
+}
+
+__device__ __forceinline__ void gap_or_lane_fast(const GapHead& h, u64 gaddr, u32* lds)
+{
+    u32 hdr = h.c[0].x & 0xFFFFu;
+    u32 len = hdr >> 3;
+    bool odd_runs = (hdr & 1u) != 0u;                                  // 1-runs are runs 1,3,5,.. (else 2,4,..)
+    u32 nchunks = (len + 8u) >> 3;
+    { u32 x[5] = {h.c[0].x, h.c[0].y, h.c[0].z, h.c[0].w, h.c[1].x}; gap_or_chunk_fast(lds, x, 0, len, odd_runs); }
+    if (nchunks > 1u) { u32 x[5] = {h.c[1].x, h.c[1].y, h.c[1].z, h.c[1].w, h.c[2].x}; gap_or_chunk_fast(lds, x, 1, len, odd_runs); }
+    if (nchunks > 2u) { u32 x[5] = {h.c[2].x, h.c[2].y, h.c[2].z, h.c[2].w, h.c[3].x}; gap_or_chunk_fast(lds, x, 2, len, odd_runs); }
+    if (nchunks > 3u) {
+        gcptr4 g4 = (gcptr4)(uintptr_t)gaddr;
+        u32x4 cur = h.c[3];
+        for (u32 c = 3; c < nchunks; ++c) {
+            u32x4 nxt = (c + 1u < nchunks) ? g4[c + 1u] : cur;
+            u32 x[5] = {cur.x, cur.y, cur.z, cur.w, nxt.x};
+            gap_or_chunk_fast(lds, x, c, len, odd_runs);
+            cur = nxt;
+        }
+    }
+}
+
 __device__ __forceinline__ bool lds_blk_is_zero(const u32* lds, u32 lane)
 {
     const u32x4* l4 = reinterpret_cast<const u32x4*>(lds);

@@ -239,15 +239,40 @@ void k_agg_or_gap_tiled(const u64* const* __restrict__ descs, const u32* __restr
     u32 ops_per_step = (blockDim.x >> 6) * (64u / OR_TILE);
     u32* acc = lds_dyn + t * 2048u;
     u32 op = wave * (64u / OR_TILE) + grp;
-    u64 d = (op < n && col < ncols && col < nblk[op]) ? descs[op][col] : 0ull;
-    for (; op < n; op += ops_per_step) {
-        u32 opn = op + ops_per_step;
-        u64 dn = (opn < n && col < ncols && col < nblk[opn]) ? descs[opn][col] : 0ull;   // one step ahead
-        u32 k = DESC_K(d);
-        if (k == K_GAP) gap_apply_lds_lane<GAP_OR>(as_gc16(DESC_P(d)), acc);
-        else if (k == K_FULL) full[t] = 1u;
-        d = dn;
+    // Three dependent reads per operand (table pointer + length -> descriptor -> block head) are spread
+    // over three loop iterations, each issued unconditionally (indices clamped, results masked), so that
+    // no iteration waits for a load it issued itself: stage A runs 3 steps ahead, B 2, C 1.
+    typedef const __attribute__((address_space(1))) u64* gcptr64;
+    typedef const __attribute__((address_space(1))) u32* gcptr32_;
+    gcptr64 g_descs = (gcptr64)(uintptr_t)descs;
+    gcptr32_ g_nblk = (gcptr32_)(uintptr_t)nblk;
+    const u32 nm1 = n - 1u;
+    bool colok = col < ncols;
+#define TILE_STAGE_A(OP, PA, NB) { u32 oc_ = (OP) < n ? (OP) : nm1; PA = g_descs[oc_]; NB = ((OP) < n && colok) ? g_nblk[oc_] : 0u; }
+#define TILE_STAGE_B(PA, NB, D)  { u32 cc_ = col < (NB) ? col : 0u; u64 v_ = ((gcptr64)(uintptr_t)(PA))[cc_]; D = col < (NB) ? v_ : 0ull; }
+    u64 pa1, pa2, pa3; u32 nb1, nb2, nb3;
+    u64 d0, d1, d2;
+    GapHead h0, h1;
+    {   // prologue: fill the pipeline
+        u64 pa0; u32 nb0;
+        TILE_STAGE_A(op, pa0, nb0);
+        TILE_STAGE_A(op + ops_per_step, pa1, nb1);
+        TILE_STAGE_A(op + 2u * ops_per_step, pa2, nb2);
+        TILE_STAGE_B(pa0, nb0, d0);
+        TILE_STAGE_B(pa1, nb1, d1);
+        gap_head_fetch(h0, DESC_P(d0), DESC_K(d0) == K_GAP);
     }
+    for (; op < n; op += ops_per_step) {
+        TILE_STAGE_A(op + 3u * ops_per_step, pa3, nb3);
+        TILE_STAGE_B(pa2, nb2, d2);
+        gap_head_fetch(h1, DESC_P(d1), DESC_K(d1) == K_GAP);
+        gap_or_lane_fast(h0, DESC_P(d0), acc);
+        if (DESC_K(d0) == K_FULL) full[t] = 1u;
+        d0 = d1; d1 = d2; h0 = h1;
+        pa2 = pa3; nb2 = nb3;
+    }
+#undef TILE_STAGE_A
+#undef TILE_STAGE_B
     __syncthreads();
     // one wave per column of the tile: classify + store (opt_copy_bit_block rule)
     for (u32 tc = wave; tc < OR_TILE; tc += (blockDim.x >> 6)) {
