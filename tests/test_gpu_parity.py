@@ -552,6 +552,16 @@ def test_shift_right_and(ctx, port):
         agg.combine_shift_right_and([gv[i] for i in sel])
         assert agg.count() == port.agg_shift_right_and_count([pv[i] for i in sel])
         agg.set_compute_count(False)
+    # more operands than bits in a block: the window of src[0] starts one whole block (and 463 bits) lower
+    pl = port.new(3 * 65536)
+    pl.set_range(5, 3 * 65536 - 1)
+    pl.optimize()
+    gl = bm.bvector.from_block_table(ctx, 3 * 65536, *pl.flatten())
+    n_long = 66000
+    t, f = agg.combine_shift_right_and([gl] * n_long)
+    e, ef = port.agg_shift_right_and([pl] * n_long, False, False)
+    assert f == ef and t.count() == e.count() == 3 * 65536 - 5 - (n_long - 1)
+    assert (t.to_words(3 * 2048) == e.to_words(3 * 2048)).all()
     # member form: add() + combine_shift_right_and(); empty list => cleared target (:2499)
     t, f = agg.combine_shift_right_and([])
     assert not f and t.count() == 0
