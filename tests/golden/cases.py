@@ -94,3 +94,29 @@ def select_queries(count: int) -> np.ndarray:
         q = rng.integers(1, count + 1, size=512).astype(np.uint64)
         return np.concatenate([q, np.array(base, np.uint64)])
     return np.array(base, np.uint64)
+
+
+# ---- vectors longer than 2^32 bits (the reference's BM64ADDR build) ----------
+BM64_NBITS = 6_500_000_000            # 99,183 blocks; block 65,536 starts at bit 2^32
+BM64_NVEC = 4
+
+
+def bm64_build(o, seed: int):
+    """one test vector, built bit by bit through the oracle / reference API (same calls on both)"""
+    rng = np.random.default_rng(1000 + seed)
+    v = o.new(BM64_NBITS)
+    pos = np.concatenate([rng.integers(0, BM64_NBITS, size=3000), rng.integers(1 << 32, (1 << 32) + 200000, size=20000),
+                          np.array([0, (1 << 32) - 1, 1 << 32, BM64_NBITS - 1])])
+    for p in pos:
+        v.set_bit(int(p))
+    v.set_range((1 << 32) - 70000, (1 << 32) + 70000)                  # FULL block right below bit 2^32, runs across it
+    v.set_range(6_000_000_000 + seed * 1000, 6_000_200_000)
+    v.optimize()
+    return v
+
+
+def bm64_queries(count: int):
+    rank_q = np.array([0, (1 << 32) - 1, 1 << 32, (1 << 32) + 5, (1 << 32) + 65536, 5_000_000_000, 6_000_100_000,
+                       BM64_NBITS - 1], np.uint64)
+    sel_q = np.array([1, 2, 100, max(count // 2, 1), max(count - 1, 1), count, count + 1], np.uint64)
+    return rank_q, sel_q

@@ -19,7 +19,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 sys.path.insert(0, HERE)
 
 import oracle  # noqa: E402
-from cases import (AGG_GROUPS, CASES, OR_SETS, PAIRS, SEED, SHIFT_SETS, make_inputs, rank_queries, select_queries, sha)  # noqa: E402
+from cases import (AGG_GROUPS, BM64_NVEC, CASES, OR_SETS, PAIRS, SEED, SHIFT_SETS, bm64_build, bm64_queries, make_inputs, rank_queries, select_queries, sha)  # noqa: E402
 
 
 def gap_slab_masked(kinds, offs, gaps):
@@ -123,6 +123,32 @@ def run(R, P):
     return out
 
 
+def kinds_sha(v):
+    return sha(np.asarray(v.flatten()[0], np.uint8))
+
+
+def run_bm64(R):
+    """vectors above 2^32 bits through the reference compiled with -DBM64ADDR"""
+    vecs = [bm64_build(R, s_) for s_ in range(BM64_NVEC)]
+    out = {"reference": R.name, "count": [v.count() for v in vecs], "kinds_sha": [kinds_sha(v) for v in vecs], "op2": {}}
+    for op in range(4):
+        t = R.op2(op, vecs[0], vecs[1], True)
+        out["op2"][str(op)] = {"count": t.count(), "count_op": R.count_op2(op, vecs[0], vecs[1]), "kinds_sha": kinds_sha(t)}
+    t = R.agg_and_sub(vecs[:3], vecs[3:])
+    out["agg_and_sub"] = {"count": t.count(), "kinds_sha": kinds_sha(t), "find_first": list(R.find_first(t))}
+    t = R.agg_or(vecs)
+    out["agg_or"] = {"count": t.count()}
+    t, f = R.agg_shift_right_and(vecs[:3], True, False)
+    out["shift_right_and"] = {"count": t.count(), "found": bool(f), "kinds_sha": kinds_sha(t)}
+    out["pipeline_counts"] = [int(x) for x in R.pipeline_counts([(vecs[:2], []), (vecs[:3], vecs[3:]), (vecs[1:], [])])]
+    rs = R.rs_build(vecs[0])
+    rq, sq = bm64_queries(vecs[0].count())
+    pos, found = rs.select(sq)
+    out["rs"] = {"count": rs.count(), "rank": [int(x) for x in rs.rank(rq)], "select_found": found.astype(int).tolist(),
+                 "select_pos": [int(p_) if f_ else 0 for p_, f_ in zip(pos, found)]}
+    return out
+
+
 def main():
     oracle.build()
     P = oracle.port()
@@ -131,6 +157,7 @@ def main():
     assert a["cases"] == s["cases"], "AVX2 and scalar reference builds disagree"
     assert a["simd_version"] == 5 and s["simd_version"] == 0
     a["also_verified_with"] = s["reference"]
+    a["bm64"] = run_bm64(oracle.reference("avx2_64"))
     with open(os.path.join(HERE, "golden_ref.json"), "w") as f:
         json.dump(a, f, separators=(",", ":"))
     print("wrote golden_ref.json", os.path.getsize(os.path.join(HERE, "golden_ref.json")), "bytes")

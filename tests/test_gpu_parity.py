@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 import oracle
-from cases import (AGG_GROUPS, CASES, OR_SETS, PAIRS, SEED, make_inputs, rank_queries, select_queries, sha)
+from cases import (BM64_NVEC, bm64_build, bm64_queries, AGG_GROUPS, CASES, OR_SETS, PAIRS, SEED, make_inputs, rank_queries, select_queries, sha)
 
 pytestmark = pytest.mark.gpu
 
@@ -565,3 +565,45 @@ def test_shift_right_and(ctx, port):
     # member form: add() + combine_shift_right_and(); empty list => cleared target (:2499)
     t, f = agg.combine_shift_right_and([])
     assert not f and t.count() == 0
+
+
+def test_bm64_vectors(ctx, port, golden):
+    """vectors above 2^32 bits (bit positions are 64-bit through the whole ABI; 99,183 blocks) vs the fixtures the
+    reference generated in its BM64ADDR build: pairwise ops, aggregator, shift-right-and, pipeline, rank / select
+    with positions beyond 2^32"""
+    g = golden["bm64"]
+    ksha = lambda v: sha(np.asarray(v.block_table()[0], np.uint8))
+    pv = [bm64_build(port, s_) for s_ in range(BM64_NVEC)]
+    from cases import BM64_NBITS
+    vecs = [bm.bvector.from_block_table(ctx, BM64_NBITS, *p.flatten()) for p in pv]
+    assert [v.count() for v in vecs] == g["count"]
+    ops = [bm.bvector.bit_and, bm.bvector.bit_or, bm.bvector.bit_xor, bm.bvector.bit_sub]
+    cnts = [bm.count_and, bm.count_or, bm.count_xor, bm.count_sub]
+    for op in range(4):
+        e = g["op2"][str(op)]
+        t = ops[op](vecs[0], vecs[1], bm.opt_compress)
+        kk, ek = t.block_table()[0], port.op2(op, pv[0], pv[1], True).flatten()[0]
+        assert t.count() == e["count"] == cnts[op](vecs[0], vecs[1])
+        assert all(a == b or (a == bm.FULL and b == bm.GAP) for a, b in zip(kk.tolist(), ek.tolist()))   # DESIGN section 4 note
+    agg = bm.aggregator(ctx)
+    t, any_ = agg.combine_and_sub(vecs[:3], vecs[3:])
+    assert t.count() == g["agg_and_sub"]["count"] and ksha(t) == g["agg_and_sub"]["kinds_sha"] and any_
+    f, idx = agg.find_first_and_sub(vecs[:3], vecs[3:])
+    assert [f, idx] == [bool(g["agg_and_sub"]["find_first"][0]), g["agg_and_sub"]["find_first"][1]]
+    assert agg.combine_or(vecs).count() == g["agg_or"]["count"]
+    agg.set_optimization(True)
+    t, f = agg.combine_shift_right_and(vecs[:3])
+    assert t.count() == g["shift_right_and"]["count"] and f == g["shift_right_and"]["found"] and ksha(t) == g["shift_right_and"]["kinds_sha"]
+    pipe = bm.aggregator.pipeline(ctx)
+    for a, s_ in [(vecs[:2], []), (vecs[:3], vecs[3:]), (vecs[1:], [])]:
+        ag = pipe.add()
+        for x in a: ag.add(x, 0)
+        for x in s_: ag.add(x, 1)
+    pipe.complete()
+    assert [int(x) for x in agg.combine_and_sub(pipe)] == g["pipeline_counts"]
+    rs = vecs[0].build_rs_index()
+    rq, sq = bm64_queries(g["count"][0])
+    assert rs.count() == g["rs"]["count"] and [int(x) for x in vecs[0].rank(rq, rs)] == g["rs"]["rank"]
+    found, pos = vecs[0].select(sq, rs)
+    assert found.astype(int).tolist() == g["rs"]["select_found"]
+    assert [int(p_) if f_ else 0 for p_, f_ in zip(pos, found)] == g["rs"]["select_pos"]
