@@ -373,26 +373,32 @@ struct GapHead { u32x4 c[4]; };
 
 __device__ __forceinline__ void gap_head_fetch(GapHead& h, u64 gaddr, bool is_gap)
 {
-    const u32x4 z = {0u, 0u, 0u, 0u};
     gcptr4 g4 = (gcptr4)(uintptr_t)gaddr;
+    if (is_gap) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) h.c[j] = is_gap ? g4[j] : z;         // header 0 = length 0: nothing is applied
+        for (int j = 0; j < 4; ++j) h.c[j] = g4[j];
+    } else h.c[0].x = 0u;                                              // header 0 = length 0: nothing is applied (the rest is don't-care)
 }
 
-__device__ __forceinline__ void gap_or_chunk_fast(u32* lds, const u32 x[5], u32 c, u32 len, bool odd_runs)
+// x[0..4] = dwords 4c..4c+4 of the block; lim = len - (odd_runs ? 1 : 2): wanted run i of the chunk is
+// active iff 8c + 2i <= lim (signed: lim is -1 / -2 for an empty header).  Even start: the u16 stream is
+// re-paired with one v_alignbit per run so both polarities share the code below.
+__device__ __forceinline__ void gap_or_chunk_fast(u32* lds, const u32 x[5], u32 c, int lim, bool odd_runs)
 {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        u32 k, s, e;
-        if (odd_runs) { k = 8u * c + 2u * i + 1u; s = (k == 1u) ? 0u : (x[i] & 0xFFFFu) + 1u; e = x[i] >> 16; }
-        else          { k = 8u * c + 2u * i + 2u; s = (x[i] >> 16) + 1u; e = x[i + 1] & 0xFFFFu; }
-        bool act = k <= len;
-        u32 wl = (s >> 5) & 2047u, wr = e >> 5;
-        u32 ml = ~0u << (s & 31u), mr = ~0u >> (31u - (e & 31u));
-        u32 m1 = (wl == wr) ? (ml & mr) : ml;
-        atomicOr(&lds[wl], act ? m1 : 0u);
-        if (act && wr > wl) {                                           // rare for sparse operands
-            atomicOr(&lds[wr], mr);
+        u32 y = odd_runs ? x[i] : __builtin_amdgcn_alignbit(x[i + 1], x[i], 16);   // lo16 = end of the 0-run, hi16 = end of the 1-run
+        u32 s = (y & 0xFFFFu) + 1u;
+        if (c == 0u && i == 0) s = odd_runs ? 0u : s;                  // run 1 starts at bit 0 (lo16 is the header)
+        u32 e = y >> 16;
+        bool act = (int)(8u * c + 2u * (u32)i) <= lim;
+        u32 wl = s >> 5, wr = e >> 5;
+        u32 lo = 1u << (s & 31u), hi2 = 2u << (e & 31u);
+        bool same = wl == wr;
+        u32 m = (same ? hi2 : 0u) - lo;                                // bits s..e of the word, or s..31
+        atomicOr(&lds[wl], act ? m : 0u);                              // inactive slot: ORs 0 (wl <= 2048: inside the tile)
+        if (act && !same) {                                            // rare for sparse operands
+            atomicOr(&lds[wr], hi2 - 1u);
             for (u32 w = wl + 1u; w < wr; ++w) lds[w] = ~0u;
         }
     }
@@ -403,17 +409,18 @@ __device__ __forceinline__ void gap_or_lane_fast(const GapHead& h, u64 gaddr, u3
     u32 hdr = h.c[0].x & 0xFFFFu;
     u32 len = hdr >> 3;
     bool odd_runs = (hdr & 1u) != 0u;                                  // 1-runs are runs 1,3,5,.. (else 2,4,..)
+    int lim = (int)len - (odd_runs ? 1 : 2);
     u32 nchunks = (len + 8u) >> 3;
-    { u32 x[5] = {h.c[0].x, h.c[0].y, h.c[0].z, h.c[0].w, h.c[1].x}; gap_or_chunk_fast(lds, x, 0, len, odd_runs); }
-    if (nchunks > 1u) { u32 x[5] = {h.c[1].x, h.c[1].y, h.c[1].z, h.c[1].w, h.c[2].x}; gap_or_chunk_fast(lds, x, 1, len, odd_runs); }
-    if (nchunks > 2u) { u32 x[5] = {h.c[2].x, h.c[2].y, h.c[2].z, h.c[2].w, h.c[3].x}; gap_or_chunk_fast(lds, x, 2, len, odd_runs); }
+    { u32 x[5] = {h.c[0].x, h.c[0].y, h.c[0].z, h.c[0].w, h.c[1].x}; gap_or_chunk_fast(lds, x, 0, lim, odd_runs); }
+    if (nchunks > 1u) { u32 x[5] = {h.c[1].x, h.c[1].y, h.c[1].z, h.c[1].w, h.c[2].x}; gap_or_chunk_fast(lds, x, 1, lim, odd_runs); }
+    if (nchunks > 2u) { u32 x[5] = {h.c[2].x, h.c[2].y, h.c[2].z, h.c[2].w, h.c[3].x}; gap_or_chunk_fast(lds, x, 2, lim, odd_runs); }
     if (nchunks > 3u) {
         gcptr4 g4 = (gcptr4)(uintptr_t)gaddr;
         u32x4 cur = h.c[3];
         for (u32 c = 3; c < nchunks; ++c) {
             u32x4 nxt = (c + 1u < nchunks) ? g4[c + 1u] : cur;
             u32 x[5] = {cur.x, cur.y, cur.z, cur.w, nxt.x};
-            gap_or_chunk_fast(lds, x, c, len, odd_runs);
+            gap_or_chunk_fast(lds, x, c, lim, odd_runs);
             cur = nxt;
         }
     }

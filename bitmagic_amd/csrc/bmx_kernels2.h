@@ -252,7 +252,7 @@ void k_agg_or_gap_tiled(const u64* const* __restrict__ descs, const u32* __restr
 #define TILE_STAGE_B(PA, NB, D)  { u32 cc_ = col < (NB) ? col : 0u; u64 v_ = ((gcptr64)(uintptr_t)(PA))[cc_]; D = col < (NB) ? v_ : 0ull; }
     u64 pa1, pa2, pa3; u32 nb1, nb2, nb3;
     u64 d0, d1, d2;
-    GapHead h0, h1;
+    GapHead h0 = {}, h1 = {};
     {   // prologue: fill the pipeline
         u64 pa0; u32 nb0;
         TILE_STAGE_A(op, pa0, nb0);
