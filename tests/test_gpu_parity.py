@@ -607,3 +607,65 @@ def test_bm64_vectors(ctx, port, golden):
     found, pos = vecs[0].select(sq, rs)
     assert found.astype(int).tolist() == g["rs"]["select_found"]
     assert [int(p_) if f_ else 0 for p_, f_ in zip(pos, found)] == g["rs"]["select_pos"]
+
+
+def test_full_size_rank_select(ctx, port):
+    """BASELINE configs[3]: rs-index + rank / select on a 4e9-bit vector (10 % and the mixed 1 % case).
+    Size-independent properties: rank(select(r)) == r and select(rank(n)) <= n with bit(n) deciding equality,
+    rank(N-1) == count, rank is monotone with unit steps, count_range additivity; sampled blocks vs the oracle
+    on identically generated words."""
+    nbits = 4_000_000_000
+    rng = np.random.default_rng(99)
+    for dq in (6554, 655):
+        v = bm.bvector.generate(ctx, SEED, 42, dq, nbits)
+        rs = v.build_rs_index()
+        cnt = v.count()
+        assert rs.count() == cnt and v.rank(np.array([nbits - 1], np.uint64), rs)[0] == cnt
+        r = rng.integers(1, cnt + 1, size=200_000).astype(np.uint64)
+        found, pos = v.select(r, rs)
+        assert found.all() and (v.rank(pos, rs) == r).all()
+        assert (v.rank(pos - np.uint64(1), rs)[pos > 0] == (r - np.uint64(1))[pos > 0]).all()     # pos is a set bit
+        f2, _ = v.select(np.array([0, cnt + 1], np.uint64), rs)
+        assert not f2.any()
+        n = np.sort(rng.integers(0, nbits, size=200_000).astype(np.uint64))
+        rk = v.rank(n, rs)
+        assert (np.diff(rk.astype(np.int64)) >= 0).all() and (np.diff(rk.astype(np.int64)) <= np.diff(n.astype(np.int64))).all()
+        mid = (n[:-1] + n[1:]) // np.uint64(2)
+        cr = v.count_range(n[:-1], n[1:], rs)
+        left = v.count_range(n[:-1], mid, rs); right = v.count_range(mid + np.uint64(1), n[1:], rs)
+        ok = mid < n[1:]
+        assert (cr[ok] == (left + right)[ok]).all()
+        for nb0 in (0, 30517, 61035):                     # rank inside sampled blocks vs popcounts of the oracle's words
+            nw = min(2048, (nbits + 31) // 32 - nb0 * 2048)
+            w = port.gen_words(SEED, 42, dq, nbits, word_off=nb0 * 2048, nwords=nw)
+            bits = np.unpackbits(w.view(np.uint8), bitorder="little")
+            q = np.sort(rng.integers(0, nw * 32, size=300)).astype(np.uint64)
+            base = v.rank(np.array([nb0 * 65536 - 1], np.uint64), rs)[0] if nb0 else np.uint64(0)
+            got = v.rank(q + np.uint64(nb0 * 65536), rs) - base
+            assert (got == np.cumsum(bits)[q.astype(np.int64)]).all()
+        del rs, v
+
+
+def test_full_size_or_of_4096_sparse_vectors(ctx, port):
+    """BASELINE configs[4]: combine_or over 4096 sparse 4e9-bit vectors (0.02 %, every block GAP; the column-tile
+    kernel).  Properties: OR(all) == OR(OR(first half), OR(second half)); |OR| <= sum of counts; sampled block
+    columns equal the OR of the oracle's identically generated words."""
+    nbits, nvec, dq = 4_000_000_000, 4096, 13
+    vecs = [bm.bvector.generate(ctx, SEED, 10000 + i, dq, nbits) for i in range(nvec)]
+    assert vecs[0].calc_stat()["bit_blocks"] == 0
+    agg = bm.aggregator(ctx)
+    t = agg.combine_or(vecs)
+    tc = t.count()
+    h1, h2 = agg.combine_or(vecs[:2048]), agg.combine_or(vecs[2048:])
+    t2 = agg.combine_or([h1, h2])
+    assert t2.count() == tc and bm.count_xor(t, t2) == 0
+    assert bm.count_and(t, h1) == h1.count() and tc <= sum(v.count() for v in vecs[::512]) * 512 * 1.2
+    p = 1.0 - (1.0 - dq / 65536) ** nvec
+    assert abs(tc - p * nbits) < 1e-3 * nbits
+    for nb0 in (5, 61035):
+        nw = min(2048, (nbits + 31) // 32 - nb0 * 2048)
+        acc = np.zeros(nw, np.uint32)
+        for i in range(nvec):
+            acc |= port.gen_words(SEED, 10000 + i, dq, nbits, word_off=nb0 * 2048, nwords=nw)
+        got = t.to_words((nb0 + 1) * 2048)[nb0 * 2048: nb0 * 2048 + nw]
+        assert (got == acc).all()
