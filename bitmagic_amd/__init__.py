@@ -38,7 +38,7 @@ BLOCK_WORDS, BLOCK_BITS = 2048, 65536
 opt_none, opt_compress = 0, 3        # bvector::optmode (src/bm.h:129-135)
 ID_MAX = 0xFFFFFFFF                  # bm::id_max (src/bmconst.h:109)
 
-__all__ = ["context", "bvector", "aggregator", "rs_index", "bit_import_u32", "count_and", "count_or",
+__all__ = ["context", "bvector", "aggregator", "slice_scanner", "rs_index", "bit_import_u32", "count_and", "count_or",
            "count_xor", "count_sub", "BmxError", "simd_version", "device_count", "agg_run_options",
            "agg_opt_only_counts", "agg_opt_bvect_and_counts", "agg_opt_disable_bvects_and_counts"]
 
@@ -542,3 +542,58 @@ class aggregator:
     def run_counts_dev(self, pipe: pipeline, d_counts_ptr: int, nb_from: int = 0, nb_to: int = ID_MAX):
         """asynchronous run; counts land in device memory (e.g. a torch tensor's data_ptr())"""
         check(lib().bmx_pipeline_run_counts_dev(self.ctx._h, pipe._h, nb_from, nb_to, C.c_void_p(d_counts_ptr)))
+
+
+class slice_scanner:
+    """Bit-sliced equality search over device-resident slices: the aggregator call pattern of
+    bm::sparse_vector_scanner<SV>::find_eq (src/bmsparsevec_algo.h:1083,2387; group rule
+    prepare_and_sub_aggregator :2593-2640).  slices[i] holds bit i of every element (None = plane absent);
+    len(slices) plays effective_slices().  A batch of searches is one counts-only pipeline launch."""
+
+    def __init__(self, ctx: context, slices: Sequence[bvector | None]):
+        self.ctx, self.slices = ctx, list(slices)
+        self.agg = aggregator(ctx)
+
+    def _groups(self, value: int):
+        if value <= 0:
+            raise BmxError(_ffi.ERR_BADARG, "Invalid argument", "value 0 is find_zero() in the reference (not on this path)")
+        a = []
+        for bit in range(value.bit_length() - 1, -1, -1):               # backward order (:2614)
+            if (value >> bit) & 1:
+                if bit >= len(self.slices) or self.slices[bit] is None:
+                    return None                                          # a set bit without a plane: nothing matches (:2621)
+                a.append(self.slices[bit])
+        s = [p for i, p in enumerate(self.slices) if p is not None and not (value >> i) & 1]
+        return a, s
+
+    def find_eq(self, value: int):
+        """-> (bv_out or None, found)"""
+        g = self._groups(int(value))
+        if g is None:
+            return None, False
+        return self.agg.combine_and_sub(g[0], g[1])
+
+    def find_first_eq(self, value: int):
+        g = self._groups(int(value))
+        if g is None:
+            return False, 0
+        return self.agg.find_first_and_sub(g[0], g[1])
+
+    def find_eq_counts(self, values) -> np.ndarray:
+        out = np.zeros(len(values), np.uint64)
+        pipe = pipeline(self.ctx)
+        slot = []
+        for v in values:
+            g = self._groups(int(v))
+            if g is None:
+                slot.append(-1); continue
+            ag = pipe.add()
+            for x in g[0]: ag.add(x, 0)
+            for x in g[1]: ag.add(x, 1)
+            slot.append(pipe.size() - 1)
+        if pipe.size():
+            pipe.complete()
+            cnt = self.agg.combine_and_sub(pipe)
+            for q, sl in enumerate(slot):
+                if sl >= 0: out[q] = cnt[sl]
+        return out

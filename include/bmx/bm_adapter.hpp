@@ -126,6 +126,28 @@ bool upload(const BMBV& src, bvector& dst, uint32_t nblocks = 0)
     return false;
 }
 
+/// slices of a bit-sliced container (bm::sparse_vector<>: get_slice(i), effective_slices(),
+/// src/bmbmatrix.h:739,756) -> device vectors for bmx::slice_scanner (bmx/scanner.hpp).  `store` owns the
+/// device vectors; slices[i] is nullptr where the host plane does not exist.  All slices are uploaded
+/// with the same block count (the container's size) so that NULL tails behave as in the reference.
+template <class SV>
+void upload_slices(const SV& sv, context& ctx, std::vector<bvector>& store, std::vector<const bvector*>& slices)
+{
+    unsigned planes = sv.effective_slices();
+    uint32_t nblocks = (uint32_t)(((uint64_t)sv.size() + BMX_BLOCK_BITS - 1) / BMX_BLOCK_BITS);
+    store.clear(); store.reserve(planes);
+    std::vector<int> slot(planes, -1);
+    for (unsigned i = 0; i < planes; ++i) {
+        if (const typename SV::bvector_type* bv = sv.get_slice(i)) {
+            store.emplace_back(ctx);
+            upload(*bv, store.back(), nblocks ? nblocks : 1);
+            slot[i] = (int)store.size() - 1;
+        }
+    }
+    slices.assign(planes, nullptr);
+    for (unsigned i = 0; i < planes; ++i) if (slot[i] >= 0) slices[i] = &store[(size_t)slot[i]];
+}
+
 /// install a block table into a host bm::bvector<> through the reference's own
 /// blocks_manager (FULL sentinel / clone_gap_block src/bmblocks.h:865 / copy_bit_block :1340)
 template <class BMBV>

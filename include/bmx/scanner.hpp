@@ -1,0 +1,94 @@
+// bmx/scanner.hpp -- bit-sliced equality search over device-resident slices: the aggregator call
+// pattern of bm::sparse_vector_scanner<SV>, header-only over bmx.h.
+//
+//   reference                                                     here
+//   ------------------------------------------------------------  ----------------------------------
+//   sparse_vector_scanner::find_eq(sv, value, bv_out)             slice_scanner::find_eq(value, bv_out)
+//        src/bmsparsevec_algo.h:1083,4356 -> find_eq_with_nulls :2387-2412
+//   sparse_vector_scanner::find_eq(sv, value, pos) :1111,4434     slice_scanner::find_first_eq(value, idx)
+//        -> find_first_eq :2417
+//   prepare_and_sub_aggregator(sv, value) :2593-2640              slice_scanner::add_groups()
+//        AND group = slices of the set bits of the value (high bit first),
+//        SUB group = every other existing slice below effective_slices(); a set bit
+//        without a slice => nothing can match
+//   pipeline of many searches (batch of arg-groups, :3236,3408)   slice_scanner::find_eq_counts(values, n, counts)
+//
+// The slices stay resident in HBM; a batch of searches is ONE counts-only pipeline launch (the
+// LDS-staged kernel when many groups share the slices).  The container
+// (bm::sparse_vector<>) stays on the host: bmx::upload_slices (bm_adapter.hpp) uploads its slices.
+#pragma once
+
+#include <vector>
+
+#include "bvector.hpp"
+
+namespace bmx {
+
+class slice_scanner {
+public:
+    explicit slice_scanner(context& ctx) : ctx_(&ctx), agg_(ctx) {}
+
+    /// slice i holds bit i of every element; nullptr = the plane does not exist (sv.get_slice(i) == 0).
+    /// slices.size() plays effective_slices().
+    void bind(const std::vector<const bvector*>& slices) { slices_ = slices; }
+    size_t effective_slices() const noexcept { return slices_.size(); }
+
+    /// rows equal to `value` (value != 0) -> bv_out; false when nothing was found
+    bool find_eq(uint64_t value, bvector& bv_out)
+    {
+        if (!value) throw error(BMX_ERR_BADARG, "slice_scanner: value 0 is find_zero() in the reference (not on this path)");
+        aggregator<bvector>::arg_groups g;
+        if (!add_groups(value, g)) { bv_out.clear(); return false; }
+        return agg_.combine_and_sub(bv_out, g.arg_bv0.data(), g.arg_bv0.size(), g.arg_bv1.data(), g.arg_bv1.size(), false);
+    }
+
+    /// index of the first row equal to `value`
+    bool find_first_eq(uint64_t value, size_type& idx)
+    {
+        if (!value) return false;                                        // :2428
+        aggregator<bvector>::arg_groups g;
+        if (!add_groups(value, g)) return false;
+        return agg_.find_first_and_sub(idx, g.arg_bv0.data(), g.arg_bv0.size(), g.arg_bv1.data(), g.arg_bv1.size());
+    }
+
+    /// counts[q] = number of rows equal to values[q] (every value != 0): one pipeline, one launch
+    void find_eq_counts(const uint64_t* values, size_t n, uint64_t* counts)
+    {
+        typedef aggregator<bvector>::pipeline<agg_opt_only_counts> pipe_t;
+        pipe_t pipe(*ctx_);
+        std::vector<size_t> slot(n, ~size_t(0));
+        for (size_t q = 0; q < n; ++q) {
+            counts[q] = 0;
+            if (!values[q]) throw error(BMX_ERR_BADARG, "slice_scanner: value 0 is find_zero() in the reference (not on this path)");
+            aggregator<bvector>::arg_groups g;
+            if (!add_groups(values[q], g)) continue;                     // impossible value: count 0
+            aggregator<bvector>::arg_groups* pg = pipe.add();
+            *pg = g;
+            slot[q] = pipe.size() - 1;
+        }
+        if (!pipe.size()) return;
+        pipe.complete();
+        agg_.combine_and_sub(pipe);
+        for (size_t q = 0; q < n; ++q) if (slot[q] != ~size_t(0)) counts[q] = pipe.get_bv_count_vector()[slot[q]];
+    }
+
+private:
+    // prepare_and_sub_aggregator (src/bmsparsevec_algo.h:2593-2640)
+    bool add_groups(uint64_t value, aggregator<bvector>::arg_groups& g) const
+    {
+        for (int bit = 63; bit >= 0; --bit) {                            // backward order (:2614)
+            if (!((value >> bit) & 1u)) continue;
+            if ((size_t)bit >= slices_.size() || !slices_[(size_t)bit]) return false;      // :2621
+            g.add(slices_[(size_t)bit], 0);
+        }
+        for (size_t i = 0; i < slices_.size(); ++i)
+            if (slices_[i] && (i >= 64 || !((value >> i) & 1u))) g.add(slices_[i], 1);  // :2626-2631
+        return true;
+    }
+
+    context* ctx_;
+    aggregator<bvector> agg_;
+    std::vector<const bvector*> slices_;
+};
+
+} // namespace bmx

@@ -11,8 +11,11 @@
 #include "bmaggregator.h"
 #include "bmalgo.h"
 #include "bmbvimport.h"
+#include "bmsparsevec.h"
+#include "bmsparsevec_algo.h"
 
 #include "bmx/bm_adapter.hpp"
+#include "bmx/scanner.hpp"
 extern "C" {
 #include "../../oracle/bmx_oracle.h"     // only for the deterministic input generator
 }
@@ -143,6 +146,47 @@ int main()
         bvect r; bmx::bvector t(ctx);
         ragg.combine_shift_right_and(r); gagg.combine_shift_right_and(t);
         REQUIRE(ragg.count() == gagg.count() && gagg.count() != 0);
+    }
+    // bit-sliced search: bm::sparse_vector_scanner::find_eq / find_first_eq vs bmx::slice_scanner on the
+    // uploaded slices (group rule src/bmsparsevec_algo.h:2593-2640)
+    {
+        typedef bm::sparse_vector<unsigned, bvect> svect;
+        svect sv;
+        const unsigned N = 300000;
+        uint64_t x = 88172645463325252ull;
+        {
+            svect::back_insert_iterator bi = sv.get_back_inserter();
+            for (unsigned i = 0; i < N; ++i) {
+                x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+                unsigned v = (unsigned)(x % 97u);                    // 7 slices, value 0 occurs too
+                if (i % 1000 == 0) v = 70000u + (i % 7u);            // rare wide values: sparse high slices
+                bi = v;
+            }
+            bi.flush();
+        }
+        sv.optimize();
+        std::vector<bmx::bvector> store; std::vector<const bmx::bvector*> slices;
+        bmx::upload_slices(sv, ctx, store, slices);
+        REQUIRE(slices.size() == sv.effective_slices());
+        bmx::slice_scanner gs(ctx);
+        gs.bind(slices);
+        bm::sparse_vector_scanner<svect> rs;
+        std::vector<uint64_t> vals, ref_counts, got;
+        for (unsigned v : {1u, 2u, 17u, 64u, 96u, 97u, 120u, 70000u, 70003u, 70006u, 131072u, 5000000u}) {
+            bvect r; bmx::bvector g(ctx); bvect gh;
+            rs.find_eq(sv, v, r);                                    // :1083 -> find_eq_with_nulls :2387
+            bool rf = r.any();
+            bool gf = gs.find_eq(v, g);
+            if (!g.empty_handle()) bmx::download(g, gh);
+            REQUIRE(rf == gf && gh.compare(r) == 0);
+            bvect::size_type ri = 0; bmx::size_type gi = 0;
+            bool rff = rs.find_eq(sv, v, ri), gff = gs.find_first_eq(v, gi);       // :1111 -> find_first_eq :2417
+            REQUIRE(rff == gff && (!rff || ri == gi));
+            vals.push_back(v); ref_counts.push_back(r.count());
+        }
+        got.resize(vals.size());
+        gs.find_eq_counts(vals.data(), vals.size(), got.data());
+        REQUIRE(got == ref_counts);
     }
     // rank / select vs bvector<>::count_to / select with the reference rs_index
     {

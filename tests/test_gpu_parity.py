@@ -669,3 +669,37 @@ def test_full_size_or_of_4096_sparse_vectors(ctx, port):
             acc |= port.gen_words(SEED, 10000 + i, dq, nbits, word_off=nb0 * 2048, nwords=nw)
         got = t.to_words((nb0 + 1) * 2048)[nb0 * 2048: nb0 * 2048 + nw]
         assert (got == acc).all()
+
+
+def test_slice_scanner_vs_numpy(ctx):
+    """bit-sliced equality search (the sparse_vector_scanner call pattern) against a plain numpy
+    column: counts of a batch, result vectors, first positions; a value with a bit above every plane and a
+    value whose plane is absent must find nothing (src/bmsparsevec_algo.h:2621)"""
+    rng = np.random.default_rng(8)
+    n = 3 * 65536 + 999
+    col = rng.integers(0, 200, size=n).astype(np.uint32)
+    col[::5000] = 3000 + (np.arange(0, n, 5000) % 5).astype(np.uint32)          # rare wide values
+    nplanes = 12
+    slices = []
+    for b in range(nplanes):
+        bits = ((col >> b) & 1).astype(np.uint8)
+        if not bits.any():
+            slices.append(None); continue
+        w = np.packbits(np.concatenate([bits, np.zeros((-n) % 32, np.uint8)]), bitorder="little").view(np.uint32)
+        slices.append(bm.bit_import_u32(ctx, w, True))
+    assert any(s is None for s in slices)
+    sc = bm.slice_scanner(ctx, slices)
+    vals = [1, 7, 100, 199, 200, 255, 3000, 3004, 3005, 4095, 1 << 11, 1 << 20]
+    cnt = sc.find_eq_counts(vals)
+    assert cnt.tolist() == [int((col == v).sum()) for v in vals]
+    for v in vals:
+        t, found = sc.find_eq(v)
+        idx = np.flatnonzero(col == v)
+        assert found == (idx.size > 0)
+        if found:
+            got = np.flatnonzero(np.unpackbits(t.to_words((n + 31) // 32).view(np.uint8), bitorder="little")[:n])
+            assert (got == idx).all()
+        f, pos = sc.find_first_eq(v)
+        assert f == (idx.size > 0) and (not f or pos == idx[0])
+    with pytest.raises(bm.BmxError):
+        sc.find_eq(0)
