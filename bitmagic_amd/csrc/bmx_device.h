@@ -51,14 +51,17 @@ __device__ __forceinline__ u32 wave_sum(u32 v)
     return v;
 }
 
-// inclusive prefix sum across the 64 lanes
-__device__ __forceinline__ u32 wave_scan_incl(u32 v, u32 lane)
+// inclusive prefix sum across the 64 lanes: six v_add with a DPP operand (row_shr 1/2/4/8 inside the
+// rows of 16 lanes, then row_bcast:15 / row_bcast:31 to carry the row totals), no LDS crossbar traffic.
+// update_dpp(old = 0, ...) yields 0 in lanes without a source, i.e. the identity of the addition.
+__device__ __forceinline__ u32 wave_scan_incl(u32 v, u32 /*lane*/)
 {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        u32 n = __shfl_up(v, o, 64);
-        if (lane >= (u32)o) v += n;
-    }
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);     // row_shr:1
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);     // row_shr:2
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);     // row_shr:4
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);     // row_shr:8
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);     // row_bcast:15 -> rows 1, 3
+    v += (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);     // row_bcast:31 -> rows 2, 3
     return v;
 }
 

@@ -64,64 +64,60 @@ void k_block_stats(const uint4* __restrict__ raw, u32 nblocks, int optimize, Blo
 // offs[nb] = bit-block ordinal or GAP u16-word offset (multiple of 8: every GAP block starts on a
 // 16-byte boundary so a lane can fetch it with dwordx4 loads); totals[0]=n_bit, [1]=gap_words,
 // totals[2..5] = blocks per kind
-// Each thread owns SCAN_PER consecutive blocks (serial prefix in registers), the 1024 partials are
-// scanned with wave shuffles + one LDS hop: 16,384 blocks per pass and 2 barriers per pass.
+// 16,384 blocks per pass (SCAN_PER per thread), 2 barriers per pass.
 #define SCAN_PER 16u
-__device__ __forceinline__ void wg_scan2_excl(u32& a, u32& b, u32* sm /* 2 x 16 */, u32 tid, u32& tot_a, u32& tot_b)
-{
-    // exclusive scan of (a, b) over 1024 threads; tot_* = sums over the workgroup
-    u32 lane = tid & 63u, w = tid >> 6;
-    u32 ia = wave_scan_incl(a, lane), ib = wave_scan_incl(b, lane);
-    if (lane == 63u) { sm[w] = ia; sm[16 + w] = ib; }
-    __syncthreads();
-    u32 oa = 0, ob = 0, ta = 0, tb = 0;
-#pragma unroll
-    for (u32 i = 0; i < 16; ++i) { u32 x = sm[i], y = sm[16 + i]; if (i < w) { oa += x; ob += y; } ta += x; tb += y; }
-    __syncthreads();
-    a = oa + ia - a; b = ob + ib - b; tot_a = ta; tot_b = tb;
-}
-
+// Wave w of the workgroup owns blocks [base + w*1024, +1024) of a pass and walks them 64 at a time
+// (lane = consecutive block: every load / store instruction is one contiguous 1 KiB / 256 B piece),
+// carrying its running sums across the 16 steps; wave totals meet in LDS once per pass.
 __global__ __launch_bounds__(1024)
 void k_scan_layout(const BlockStat* __restrict__ st, u32 nblocks, u32* __restrict__ offs, u64* __restrict__ totals)
 {
     __shared__ u32 sm[32];
     __shared__ u32 kcnt[4];
-    u32 tid = threadIdx.x;
+    u32 tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
     if (tid < 4) kcnt[tid] = 0;
     __syncthreads();
     u32 carry_bit = 0, carry_gap = 0;
     u32 kc[4] = {0, 0, 0, 0};
+    const uint4* st4 = reinterpret_cast<const uint4*>(st);
     for (u32 base = 0; base < nblocks; base += 1024u * SCAN_PER) {
-        u32 nb0 = base + tid * SCAN_PER;
-        u32 kind[SCAN_PER], vg[SCAN_PER];
-        u32 sb = 0, sg = 0;
+        u32 nb0 = base + w * (64u * SCAN_PER) + lane;
+        u32 kind[SCAN_PER], vg[SCAN_PER], eb[SCAN_PER], eg[SCAN_PER];
+        uint4 x[SCAN_PER];
 #pragma unroll
         for (u32 i = 0; i < SCAN_PER; ++i) {
-            u32 nb = nb0 + i;
-            kind[i] = 0xFFu; vg[i] = 0;
-            if (nb < nblocks) {
-                BlockStat x = st[nb];
-                kind[i] = x.kind;
-                vg[i] = x.kind == K_GAP ? ((x.runs + 1u + 7u) & ~7u) : 0u;      // GAP blocks start 16-B aligned
-                sb += x.kind == K_BIT; sg += vg[i];
-                kc[x.kind & 3u]++;
-            }
+            u32 nb = nb0 + i * 64u;
+            x[i] = nb < nblocks ? st4[nb] : make_uint4(0u, 0u, 0u, 0xFFu);      // {pop, runs, first, kind}
         }
-        u32 eb = sb, eg = sg, tb, tg;
-        wg_scan2_excl(eb, eg, sm, tid, tb, tg);
-        u32 ob = carry_bit + eb, og = carry_gap + eg;
+        u32 run_b = 0, run_g = 0;                         // wave-local running sums over the steps
 #pragma unroll
         for (u32 i = 0; i < SCAN_PER; ++i) {
-            u32 nb = nb0 + i;
-            if (nb < nblocks) {
-                offs[nb] = kind[i] == K_BIT ? ob : (kind[i] == K_GAP ? og : 0u);
-                ob += kind[i] == K_BIT; og += vg[i];
-            }
+            kind[i] = x[i].w;
+            vg[i] = kind[i] == K_GAP ? ((x[i].y + 1u + 7u) & ~7u) : 0u;          // GAP blocks start 16-B aligned
+            u32 isb = kind[i] == K_BIT ? 1u : 0u;
+            if (kind[i] < 4u) kc[kind[i]]++;
+            u32 ib = wave_scan_incl(isb, lane), ig = wave_scan_incl(vg[i], lane);
+            eb[i] = run_b + ib - isb; eg[i] = run_g + ig - vg[i];
+            run_b += __shfl(ib, 63, 64); run_g += __shfl(ig, 63, 64);
+        }
+        if (lane == 0) { sm[w] = run_b; sm[16 + w] = run_g; }
+        __syncthreads();
+        u32 ob = carry_bit, og = carry_gap, tb = 0, tg = 0;
+#pragma unroll
+        for (u32 i = 0; i < 16; ++i) { u32 a = sm[i], b = sm[16 + i]; if (i < w) { ob += a; og += b; } tb += a; tg += b; }
+        __syncthreads();
+#pragma unroll
+        for (u32 i = 0; i < SCAN_PER; ++i) {
+            u32 nb = nb0 + i * 64u;
+            if (nb < nblocks) offs[nb] = kind[i] == K_BIT ? ob + eb[i] : (kind[i] == K_GAP ? og + eg[i] : 0u);
         }
         carry_bit += tb; carry_gap += tg;
     }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) if (kc[k]) atomicAdd(&kcnt[k], kc[k]);
+    for (int k = 0; k < 4; ++k) {                        // one LDS atomic per wave, not per thread
+        u32 t = wave_sum(kc[k]);
+        if (lane == 0 && t) atomicAdd(&kcnt[k], t);
+    }
     __syncthreads();
     if (tid == 0) { totals[0] = carry_bit; totals[1] = carry_gap; }
     if (tid < 4) totals[2 + tid] = kcnt[tid];

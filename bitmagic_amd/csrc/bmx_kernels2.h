@@ -563,20 +563,30 @@ void k_rs_build(const u64* __restrict__ desc, u32 nblocks, u32* __restrict__ bco
 __global__ __launch_bounds__(1024)
 void k_rs_scan(const u32* __restrict__ bcount, u32 nblocks, u64* __restrict__ rcount, u64* __restrict__ total)
 {
-    __shared__ u32 sm[32];
-    u32 tid = threadIdx.x;
+    __shared__ u32 sm[16];
+    u32 tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
     u64 carry = 0;
     for (u32 base = 0; base < nblocks; base += 1024u * SCAN_PER) {
-        u32 nb0 = base + tid * SCAN_PER;
-        u32 v[SCAN_PER]; u32 sum = 0;
+        u32 nb0 = base + w * (64u * SCAN_PER) + lane;             // lane = consecutive block: coalesced loads / stores
+        u32 v[SCAN_PER], inc[SCAN_PER];
 #pragma unroll
-        for (u32 i = 0; i < SCAN_PER; ++i) { v[i] = nb0 + i < nblocks ? bcount[nb0 + i] : 0u; sum += v[i]; }
+        for (u32 i = 0; i < SCAN_PER; ++i) { u32 nb = nb0 + i * 64u; v[i] = nb < nblocks ? bcount[nb] : 0u; }
         // one pass covers <= 16,384 blocks x 65,536 bits = 2^30 < 2^32: u32 partials are exact
-        u32 e = sum, dummy = 0, tot, td;
-        wg_scan2_excl(e, dummy, sm, tid, tot, td);
-        u64 run = carry + e;
+        u32 run = 0;
 #pragma unroll
-        for (u32 i = 0; i < SCAN_PER; ++i) { run += v[i]; if (nb0 + i < nblocks) rcount[nb0 + i] = run; }
+        for (u32 i = 0; i < SCAN_PER; ++i) {
+            u32 iv = wave_scan_incl(v[i], lane);
+            inc[i] = run + iv;
+            run += __shfl(iv, 63, 64);
+        }
+        if (lane == 0) sm[w] = run;
+        __syncthreads();
+        u32 off = 0, tot = 0;
+#pragma unroll
+        for (u32 i = 0; i < 16; ++i) { u32 a = sm[i]; if (i < w) off += a; tot += a; }
+        __syncthreads();
+#pragma unroll
+        for (u32 i = 0; i < SCAN_PER; ++i) { u32 nb = nb0 + i * 64u; if (nb < nblocks) rcount[nb] = carry + off + inc[i]; }
         carry += tot;
     }
     if (tid == 0) *total = carry;
