@@ -688,25 +688,46 @@ void k_select(const u64* __restrict__ desc, u32 nblocks, const u64* __restrict__
         u64 r = live ? q[qi] : 0ull;
         bool ok = live && r != 0ull && r <= total && nblocks != 0u;
         u64 result = 0;
-        u32 kd = K_NULL, w = 0, rr = 0, nb = 0; u64 d = 0;
+        u32 kd = K_NULL, w = 0, rr = 0, nb = 0, sr_lo = 0, sr_hi = 0; u64 d = 0;
         if (ok) {
             // rs_index::find (src/bmrs.h:492): first block whose running count reaches r
             u32 glo = 0, ghi = nsamples - 1u;
             while (glo < ghi) { u32 mid = glo + ((ghi - glo) >> 1); if (s_sample[mid] < r) glo = mid + 1u; else ghi = mid; }
             u32 lo = glo << shift, hi = ((glo + 1u) << shift) - 1u;
             if (hi > nblocks - 1u) hi = nblocks - 1u;
-            while (lo < hi) { u32 mid = lo + ((hi - lo) >> 1); if (rcount[mid] < r) lo = mid + 1u; else hi = mid; }
-            nb = lo;
-            rr = (u32)(r - (nb ? rcount[nb - 1] : 0ull));       // 1..65536 inside the block
-            d = desc[nb]; kd = DESC_K(d);
-            if (kd == K_FULL) result = ((u64)nb << 16) + rr - 1u;
-            else {
-                // digest wave: last w with cum[w] < rr
-                const u16* crow = cum + (size_t)nb * 64u;
-                u32 l2 = 0, h2 = 63;
-                while (l2 < h2) { u32 mid = (l2 + h2 + 1u) >> 1; if ((u32)crow[mid] < rr) l2 = mid; else h2 = mid - 1u; }
-                w = l2; rr -= crow[w];                          // 1..1024 inside the wave
+            while (hi - lo >= 32u) { u32 mid = lo + ((hi - lo) >> 1); if (rcount[mid] < r) lo = mid + 1u; else hi = mid; }
+            sr_lo = lo; sr_hi = hi;
+        }
+        // The last <= 32 running counts are read by the 8 lanes of the query's group in ONE round trip (4 each)
+        // and the block index is the number of entries below r; the 64-entry cumulative row of the block is
+        // searched the same way (8 x 16 B = its 128-byte line).  Three dependent memory round trips per query
+        // (running counts -> descriptor + row -> bit line) instead of ~13 for two scalar binary searches.
+        {
+            u32 below = 0;
+#pragma unroll
+            for (u32 j = 0; j < 4; ++j) {
+                u32 idx = sr_lo + sub * 4u + j;
+                if (ok && idx <= sr_hi) below += rcount[idx] < r ? 1u : 0u;
             }
+            below = group_sum8(below);
+            if (ok) {
+                nb = sr_lo + below;
+                rr = (u32)(r - (nb ? rcount[nb - 1] : 0ull));       // 1..65536 inside the block
+                d = desc[nb]; kd = DESC_K(d);
+                if (kd == K_FULL) result = ((u64)nb << 16) + rr - 1u;
+            }
+            // digest wave: last w with cum[w] < rr  (cum[0] = 0 < rr always; the row is non-decreasing)
+            bool need_row = ok && kd != K_FULL;
+            u32x4 cv = (u32x4)(0u);
+            if (need_row) cv = as_gc4(cum + (size_t)nb * 64u)[sub];
+            u32 c16[8] = {cv.x & 0xFFFFu, cv.x >> 16, cv.y & 0xFFFFu, cv.y >> 16, cv.z & 0xFFFFu, cv.z >> 16, cv.w & 0xFFFFu, cv.w >> 16};
+            u32 nlt = 0, best = 0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { bool lt = c16[j] < rr; nlt += lt ? 1u : 0u; best = (lt && c16[j] > best) ? c16[j] : best; }
+            nlt = group_sum8(nlt);
+            { u32 t; t = __shfl_xor(best, 1, 64); best = t > best ? t : best; t = __shfl_xor(best, 2, 64); best = t > best ? t : best;
+              t = __shfl_xor(best, 4, 64); best = t > best ? t : best; }
+            if (need_row) { w = nlt - 1u; rr -= best; }             // 1..1024 inside the wave
         }
         // bit-blocks: 8 lanes x 16 B = the wave's 128 B line (block_find_rank src/bmfunc.h:9754)
         u32x4 v = (u32x4)(0u);
