@@ -454,6 +454,7 @@ void k_pipe_counts_bits(const u64* __restrict__ dmat, const u32* __restrict__ ro
 //   slices of 4/2/1 KiB per wave (-3..-8 %), occupancy pinned to 8 waves/SIMD with a
 //   one-block-in-flight loop (-7 %), hand-placed asm loads with counted vmcnt (-5 %, and hipcc
 //   may copy an asm-loaded register before the wait), dropping the early-exit test (-2 %).
+//   a persistent grid drawing columns from per-XCD ticket counters (+-0.5 %: turnover and tail are not the gap).
 // ---------------------------------------------------------------------------
 template <int U, bool NT, int WG = 256>
 __global__ __launch_bounds__(WG)
