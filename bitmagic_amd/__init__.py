@@ -461,7 +461,7 @@ class aggregator:
         src = list(bv_src) if bv_src is not None else list(self.ag.arg_bv0)
         self.ag.reset()              # the reference clears the member arg-groups here (src/bmaggregator.h:1110)
         h = C.c_void_p()
-        check(lib().bmx_agg_or(self.ctx._h, _handles(src), len(src), C.byref(h)))
+        check(lib().bmx_agg_or_opt(self.ctx._h, _handles(src), len(src), int(self.opt_mode), C.byref(h)))
         return bvector(self.ctx, h)
 
     def combine_and(self, bv_src: Iterable[bvector] | None = None) -> bvector:        # :1030 == combine_and_sub w/o SUB

@@ -64,6 +64,7 @@ def lib() -> C.CDLL:
         "bmx_count_op2": (i32, [vp, i32, vp, vp, P(u64)]),
         "bmx_count_op2_dev": (i32, [vp, i32, vp, vp, vp]),
         "bmx_agg_or": (i32, [vp, P(vp), C.c_size_t, P(vp)]),
+        "bmx_agg_or_opt": (i32, [vp, P(vp), C.c_size_t, i32, P(vp)]),
         "bmx_agg_and_sub": (i32, [vp, P(vp), C.c_size_t, P(vp), C.c_size_t, P(vp), P(i32)]),
         "bmx_find_first_and_sub": (i32, [vp, P(vp), C.c_size_t, P(vp), C.c_size_t, P(i32), P(u64)]),
         "bmx_agg_shift_right_and": (i32, [vp, P(vp), C.c_size_t, i32, i32, P(vp), P(i32)]),

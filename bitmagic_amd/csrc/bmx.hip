@@ -874,6 +874,11 @@ int bmx_agg_or(bmx_ctx* ctx, const bmx_vec* const* src, size_t n, bmx_vec** resu
     return agg_or_impl(ctx, src, n, 0 /* opt_mode_ = opt_none, src/bmaggregator.h:917 */, result);
 }
 
+int bmx_agg_or_opt(bmx_ctx* ctx, const bmx_vec* const* src, size_t n, int opt_compress, bmx_vec** result)
+{
+    return agg_or_impl(ctx, src, n, opt_compress ? 1 : 0, result);
+}
+
 static int agg_or_impl(bmx_ctx* ctx, const bmx_vec* const* src, size_t n, int opt_compress, bmx_vec** result)
 {
     ARGCHK(ctx && result && (n == 0 || src) && n <= 65535);

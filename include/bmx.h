@@ -133,6 +133,9 @@ int bmx_count_op2_dev(bmx_ctx* ctx, int op, const bmx_vec* a, const bmx_vec* b, 
 /* ---- aggregator ---- */
 /* aggregator::combine_or(target, src, n)  src/bmaggregator.h:1101 */
 int bmx_agg_or(bmx_ctx* ctx, const bmx_vec* const* src, size_t n, bmx_vec** result);
+/* same after aggregator::set_optimization(opt) (src/bmaggregator.h:359): result blocks pass through
+ * opt_copy_bit_block(.., opt_mode_, ..) (:1658) */
+int bmx_agg_or_opt(bmx_ctx* ctx, const bmx_vec* const* src, size_t n, int opt_compress, bmx_vec** result);
 /* aggregator::combine_and_sub(target, and, n_and, sub, n_sub, false)  src/bmaggregator.h:1162
  * (combine_and(target) == n_sub 0, :1030-1039).  *any = result is non-empty. */
 int bmx_agg_and_sub(bmx_ctx* ctx, const bmx_vec* const* src_and, size_t n_and,

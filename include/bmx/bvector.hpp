@@ -357,7 +357,7 @@ public:
         for (size_t i = 0; i < src_size; ++i) h[i] = bv_src[i]->handle();
         ag_.reset();                 // the reference clears the member arg-groups here (src/bmaggregator.h:1110)
         bmx_vec* r = nullptr;
-        check(bmx_agg_or(ctx_->handle(), h.data(), src_size, &r));
+        check(bmx_agg_or_opt(ctx_->handle(), h.data(), src_size, opt_compress_ ? 1 : 0, &r));
         bv_target.adopt(r);
     }
     bool combine_and_sub(BV& bv_target, const bvector_type_const_ptr* bv_src_and, size_t src_and_size,

@@ -211,6 +211,8 @@ class Oracle:
         getattr(L, prefix + "agg_pipeline_results").argtypes = [
             C.POINTER(vp), C.POINTER(C.c_uint32), C.POINTER(vp), C.POINTER(C.c_uint32), C.c_size_t,
             C.POINTER(vp), C.POINTER(C.c_uint64), C.POINTER(vp)]
+        getattr(L, prefix + "agg_or_opt").restype = vp
+        getattr(L, prefix + "agg_or_opt").argtypes = [C.POINTER(vp), C.c_size_t, C.c_int]
         getattr(L, prefix + "agg_shift_right_and").restype = vp
         getattr(L, prefix + "agg_shift_right_and").argtypes = [C.POINTER(vp), C.c_size_t, C.c_int, C.c_int, C.POINTER(C.c_int)]
         getattr(L, prefix + "agg_shift_right_and_count").restype = C.c_uint64
@@ -286,8 +288,8 @@ class Oracle:
             arr[i] = v.h
         return arr
 
-    def agg_or(self, vecs) -> Vec:
-        h = self._f("agg_or")(self._ptrs(vecs), len(vecs))
+    def agg_or(self, vecs, opt_compress: bool = False) -> Vec:
+        h = self._f("agg_or_opt")(self._ptrs(vecs), len(vecs), int(opt_compress))
         return Vec(self, h, max([v.nbits for v in vecs], default=0))
 
     def agg_and_sub(self, and_vecs, sub_vecs=()) -> Vec:

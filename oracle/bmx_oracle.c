@@ -1175,7 +1175,11 @@ int bmo_find_first_and_sub(const bmo_vec* const* src_and, size_t n_and,
 
 /* aggregator::combine_or  src/bmaggregator.h:1101, per column :1626;
  * result stored with opt_mode_ = opt_none (:917,1658) */
-bmo_vec* bmo_agg_or(const bmo_vec* const* src, size_t n)
+bmo_vec* bmo_agg_or(const bmo_vec* const* src, size_t n) { return bmo_agg_or_opt(src, n, 0); }
+
+/* opt_compress != 0: aggregator::set_optimization() (:359) before combine_or -- blocks go through
+ * opt_copy_bit_block(.., opt_mode_, ..) (:1658, src/bmblocks.h:1355) */
+bmo_vec* bmo_agg_or_opt(const bmo_vec* const* src, size_t n, int opt_compress)
 {
     uint64_t nbits;
     uint32_t nblocks = max_blocks(src, n, &nbits);
@@ -1209,7 +1213,7 @@ bmo_vec* bmo_agg_or(const bmo_vec* const* src, size_t n)
         if (all_one) { t->kind[nb] = BMO_FULL; continue; }
         /* process_gap_blocks_or (:1808) */
         for (k = 0; k < L.ngap; ++k) gap_add_to_bitset(tb1, L.gap[k]);
-        store_bit_block(t, nb, tb1, 0);          /* opt_none: plain copy, even if empty */
+        store_bit_block(t, nb, tb1, opt_compress);   /* opt_none: plain copy, even if empty */
     }
     free(tb1); arg_list_free(&L);
     return t;

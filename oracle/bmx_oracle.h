@@ -98,7 +98,8 @@ bmo_vec* bmo_op2(int op, const bmo_vec* a, const bmo_vec* b, int opt_compress);
 uint64_t bmo_count_op2(int op, const bmo_vec* a, const bmo_vec* b);
 
 /* aggregator (src/bmaggregator.h:1101,1162 ; Appendix A.3) */
-bmo_vec* bmo_agg_or(const bmo_vec* const* src, size_t n);
+bmo_vec* bmo_agg_or(const bmo_vec* const* src, size_t n);                      /* opt_mode_ = opt_none (:917) */
+bmo_vec* bmo_agg_or_opt(const bmo_vec* const* src, size_t n, int opt_compress);  /* after set_optimization (:359) */
 bmo_vec* bmo_agg_and_sub(const bmo_vec* const* src_and, size_t n_and,
                          const bmo_vec* const* src_sub, size_t n_sub);
 /* aggregator::combine_shift_right_and (src/bmaggregator.h:2494-2669): T_0 = src[0],

@@ -163,6 +163,15 @@ void* ref_agg_or(void* const* src, size_t n)
     return t;
 }
 
+void* ref_agg_or_opt(void* const* src, size_t n, int opt_compress)
+{
+    bvect* t = new bvect();
+    agg_t agg;
+    agg.set_optimization(opt_compress ? bvect::opt_compress : bvect::opt_none);
+    agg.combine_or(*t, reinterpret_cast<const bvect* const*>(src), n);
+    return t;
+}
+
 void* ref_agg_and_sub(void* const* src_and, size_t n_and, void* const* src_sub, size_t n_sub)
 {
     bvect* t = new bvect();

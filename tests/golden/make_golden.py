@@ -73,7 +73,8 @@ def run(R, P):
         c["agg_or"] = []
         for o in OR_SETS:
             t = R.agg_or([vecs[i] for i in o])
-            c["agg_or"].append({"src": o, "sha": sha(t.to_words()), "count": t.count()})
+            c["agg_or"].append({"src": o, "sha": sha(t.to_words()), "count": t.count(), "kinds": t.flatten()[0].tolist(),
+                                "kinds_opt": R.agg_or([vecs[i] for i in o], True).flatten()[0].tolist()})
         # combine_shift_right_and (bmaggregator.h:2494): default opt_none target, opt_compress kinds,
         # the `any` form (first result block only) and the set_compute_count form
         c["shift_right_and"] = []

@@ -98,6 +98,9 @@ def test_golden_case(ctx, port, golden, case):
     for e in g["agg_or"]:
         t = agg.combine_or([vecs[i] for i in e["src"]])
         assert sha(t.to_words(nwb)) == e["sha"] and t.count() == e["count"]
+        agg.set_optimization(True)
+        assert agg.combine_or([vecs[i] for i in e["src"]]).block_table()[0].tolist() == e["kinds_opt"]
+        agg.set_optimization(False)
     for e in g["shift_right_and"]:
         src = [(vecs if k % 2 else up)[i] for k, i in enumerate(e["src"])]
         agg.set_optimization(False)
