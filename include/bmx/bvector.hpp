@@ -360,6 +360,14 @@ public:
         check(bmx_agg_or_opt(ctx_->handle(), h.data(), src_size, opt_compress_ ? 1 : 0, &r));
         bv_target.adopt(r);
     }
+    /// combine_and(target, src, n)  src/bmaggregator.h:1127 (the older C-style path; it also resets the member
+    /// arg-groups, :1143).  Same content as the AND-SUB path without a SUB group; blocks are stored compressed
+    /// here where the reference stores them with opt_mode_ (representation only).
+    void combine_and(BV& bv_target, const bvector_type_const_ptr* bv_src, size_t src_size)
+    {
+        if (src_size > 1) ag_.reset();
+        (void)combine_and_sub(bv_target, bv_src, src_size, nullptr, 0, false);
+    }
     bool combine_and_sub(BV& bv_target, const bvector_type_const_ptr* bv_src_and, size_t src_and_size,
                          const bvector_type_const_ptr* bv_src_sub, size_t src_sub_size, bool /*any*/)
     {
