@@ -130,10 +130,12 @@ class bvector:
 
     @staticmethod
     def generate(ctx: context, seed: int, vec_id: int, density_q16: int, nbits: int,
-                 with_common: bool = False, optimize: bool = True) -> "bvector":
+                 with_common: bool = False, optimize: bool = True, block_range=None) -> "bvector":
+        """block_range=(nb_from, nb_to): only that block range of the logical vector (a multi-GPU shard)"""
         h = C.c_void_p()
-        check(lib().bmx_vec_generate(ctx._h, seed, vec_id, int(with_common), density_q16, nbits,
-                                     int(optimize), C.byref(h)))
+        nb_from, nb_to = block_range if block_range is not None else (0, ID_MAX)
+        check(lib().bmx_vec_generate_shard(ctx._h, seed, vec_id, int(with_common), density_q16, nbits,
+                                           nb_from, nb_to, int(optimize), C.byref(h)))
         return bvector(ctx, h)
 
     # ---- inspection -------------------------------------------------------

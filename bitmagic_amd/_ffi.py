@@ -55,6 +55,7 @@ def lib() -> C.CDLL:
         "bmx_vec_upload": (i32, [vp, u64, u32, vp, vp, vp, u32, vp, u64, P(vp)]),
         "bmx_vec_import_bits": (i32, [vp, vp, u64, i32, P(vp)]),
         "bmx_vec_generate": (i32, [vp, u64, u32, i32, u32, u64, i32, P(vp)]),
+        "bmx_vec_generate_shard": (i32, [vp, u64, u32, i32, u32, u64, u32, u32, i32, P(vp)]),
         "bmx_vec_free": (i32, [vp, vp]),
         "bmx_vec_info": (i32, [vp, P(u64), P(u32), P(u32), P(u32), P(u64)]),
         "bmx_vec_download": (i32, [vp, vp, vp, vp, vp, vp]),

@@ -431,25 +431,36 @@ int bmx_vec_import_bits(bmx_ctx* ctx, const uint32_t* words, uint64_t nwords, in
     return vec_from_raw(ctx, nwords * 32ull, nblocks, optimize, out);
 }
 
-int bmx_vec_generate(bmx_ctx* ctx, uint64_t seed, uint32_t vec_id, int with_common,
-                     uint32_t density_q16, uint64_t nbits, int optimize, bmx_vec** out)
+int bmx_vec_generate_shard(bmx_ctx* ctx, uint64_t seed, uint32_t vec_id, int with_common,
+                           uint32_t density_q16, uint64_t nbits, uint32_t nb_from, uint32_t nb_to,
+                           int optimize, bmx_vec** out)
 {
     ARGCHK(ctx && out && density_q16 <= 65536u);
     *out = nullptr;
     int rc = set_dev(ctx); if (rc) return rc;
     uint64_t nblocks64 = (nbits + BMX_BLOCK_BITS - 1) / BMX_BLOCK_BITS;
     if (nblocks64 > 65536ull * 16) { g_last_error = "vector too long"; return BMX_ERR_RANGE; }
-    uint32_t nblocks = (uint32_t)nblocks64;
+    if (nb_to > nblocks64) nb_to = (uint32_t)nblocks64;
+    if (nb_from > nb_to) { g_last_error = "nb_from > nb_to"; return BMX_ERR_RANGE; }
+    uint32_t nblocks = nb_to - nb_from;
+    uint64_t lo = (uint64_t)nb_from * BMX_BLOCK_BITS, hi = std::min<uint64_t>(nbits, (uint64_t)nb_to * BMX_BLOCK_BITS);
+    uint64_t shard_bits = hi > lo ? hi - lo : 0;
     size_t raw_bytes = (size_t)nblocks * 8192;
     if ((rc = ensure(ctx, &ctx->scratch, &ctx->scratch_bytes, std::max<size_t>(raw_bytes, 8192)))) return rc;
     u64 nwords64 = (u64)nblocks * 1024u;
     if (nwords64) {
         u32 grid = (u32)std::min<u64>((nwords64 + 255) / 256, 256u * 32u);
         hipLaunchKernelGGL(k_generate, dim3(grid), dim3(256), 0, ctx->stream, seed, vec_id, with_common,
-                           density_q16, nbits, (u64*)ctx->scratch, nwords64);
+                           density_q16, nbits, (u64*)ctx->scratch, nwords64, (u64)nb_from * 1024u);
         KCHK();
     }
-    return vec_from_raw(ctx, nbits, nblocks, optimize, out);
+    return vec_from_raw(ctx, shard_bits, nblocks, optimize, out);
+}
+
+int bmx_vec_generate(bmx_ctx* ctx, uint64_t seed, uint32_t vec_id, int with_common,
+                     uint32_t density_q16, uint64_t nbits, int optimize, bmx_vec** out)
+{
+    return bmx_vec_generate_shard(ctx, seed, vec_id, with_common, density_q16, nbits, 0u, 0xFFFFFFFFu, optimize, out);
 }
 
 int bmx_vec_info(const bmx_vec* v, uint64_t* nbits, uint32_t* nblocks, uint32_t counts[4],

@@ -22,14 +22,16 @@ struct BlockStat { u32 pop; u32 runs; u32 first; u32 kind; };
 // synthetic data: out = nblocks * 1024 64-bit words, bits >= nbits are zero
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256)
-void k_generate(u64 seed, u32 vec_id, int with_common, u32 d, u64 nbits, u64* __restrict__ out, u64 nwords64)
+void k_generate(u64 seed, u32 vec_id, int with_common, u32 d, u64 nbits, u64* __restrict__ out, u64 nwords64, u64 word0)
 {
+    // out[i] = 64-bit word (word0 + i) of the logical vector: word0 != 0 generates a block-range shard
     u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     u64 stride = (u64)gridDim.x * blockDim.x;
     for (; i < nwords64; i += stride) {
-        u64 v = gen_word64(seed, vec_id, i, d);
-        if (with_common) v |= gen_word64(seed, 0xFFFFFFFFu, i, d);
-        u64 bit0 = i * 64u;
+        u64 w = word0 + i;
+        u64 v = gen_word64(seed, vec_id, w, d);
+        if (with_common) v |= gen_word64(seed, 0xFFFFFFFFu, w, d);
+        u64 bit0 = w * 64u;
         if (bit0 >= nbits) v = 0;
         else if (nbits - bit0 < 64u) v &= (~0ull) >> (64u - (nbits - bit0));
         out[i] = v;

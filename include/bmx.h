@@ -104,6 +104,12 @@ int bmx_vec_import_bits(bmx_ctx* ctx, const uint32_t* words, uint64_t nwords,
  * (correlated data set, tests/perf/perf.cpp:234-267); then as bmx_vec_import_bits. */
 int bmx_vec_generate(bmx_ctx* ctx, uint64_t seed, uint32_t vec_id, int with_common,
                      uint32_t density_q16, uint64_t nbits, int optimize, bmx_vec** out);
+/* Block-range shard of the same logical vector: blocks [nb_from, nb_to) only, as a vector of nb_to - nb_from
+ * blocks (every GPU holds only its block range of every operand; the per-column loops
+ * src/bmaggregator.h:1113-1121,1184-1218 are independent, so shard results add up / concatenate). */
+int bmx_vec_generate_shard(bmx_ctx* ctx, uint64_t seed, uint32_t vec_id, int with_common,
+                           uint32_t density_q16, uint64_t nbits, uint32_t nb_from, uint32_t nb_to,
+                           int optimize, bmx_vec** out);
 int bmx_vec_free(bmx_ctx* ctx, bmx_vec* v);
 /* bvector::calc_stat (src/bm.h:4010): counts[kind]; bit_slab_blocks / gap_words =
  * sizes (8 KiB blocks / uint16 words) of the two slabs bmx_vec_download fills.

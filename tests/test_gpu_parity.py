@@ -706,3 +706,31 @@ def test_slice_scanner_vs_numpy(ctx):
         assert f == (idx.size > 0) and (not f or pos == idx[0])
     with pytest.raises(bm.BmxError):
         sc.find_eq(0)
+
+
+def test_block_range_shards_add_up(ctx, port):
+    """a GPU holds only its block range of every operand.  Shards of the same logical vectors
+    (bmx_vec_generate_shard) give partial results whose popcounts add up to the whole-vector result, for the
+    OR of sparse GAP vectors (configs[4]) and the AND+COUNT pipeline (configs[2]); shard content equals the
+    oracle's words at the shard's offset."""
+    nbits, nvec = 40 * 65536 + 12345, 70
+    nblocks = 41
+    whole = [bm.bvector.generate(ctx, SEED, 300 + i, 40, nbits) for i in range(nvec)]
+    agg = bm.aggregator(ctx)
+    total_or = agg.combine_or(whole).count()
+    dense = [bm.bvector.generate(ctx, SEED, 500 + i, 30000, nbits, with_common=True) for i in range(6)]
+    total_and = agg.combine_and_sub(dense[:5], dense[5:])[0].count()
+    for world in (1, 2, 3, 8):
+        s_or = s_and = 0
+        for r in range(world):
+            lo, hi = bm.shard_range(nblocks, r, world)
+            sh = [bm.bvector.generate(ctx, SEED, 300 + i, 40, nbits, block_range=(lo, hi)) for i in range(nvec)]
+            assert sh[0].info()["nblocks"] == hi - lo
+            s_or += agg.combine_or(sh).count()
+            dsh = [bm.bvector.generate(ctx, SEED, 500 + i, 30000, nbits, with_common=True, block_range=(lo, hi)) for i in range(6)]
+            s_and += agg.combine_and_sub(dsh[:5], dsh[5:])[0].count()
+            if hi > lo:
+                nw = min((hi - lo) * 2048, (nbits + 31) // 32 - lo * 2048)
+                w = port.gen_words(SEED, 300, 40, nbits, word_off=lo * 2048, nwords=nw + (nw & 1))[:nw]
+                assert (sh[0].to_words(nw) == w).all()
+        assert s_or == total_or and s_and == total_and, world
