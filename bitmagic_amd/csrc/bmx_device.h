@@ -291,11 +291,17 @@ __device__ __forceinline__ void gap_apply_lds_wave(gcptr16 g, u32* lds, u32 lane
     for (u32 kb = k0; kb <= len; kb += 512u) {
         u32 ee[4], ss[4];
 #pragma unroll
+        for (int j = 0; j < 4; ++j) {                      // unconditional reads (index clamped), selected afterwards:
+            u32 k = kb + (u32)j * 128u + 2u * lane;        // a predicated read whose value is used inside the predicate
+            u32 kk = k <= len ? k : len;                   // makes hipcc wait for every single one
+            ee[j] = (u32)g[kk]; ss[j] = (u32)g[kk - 1u];
+        }
+#pragma unroll
         for (int j = 0; j < 4; ++j) {
             u32 k = kb + (u32)j * 128u + 2u * lane;
             bool act = k <= len;
-            ee[j] = act ? (u32)g[k] : 0xFFFFFFFFu;
-            ss[j] = act ? ((k == 1u) ? 0u : (u32)g[k - 1] + 1u) : 0u;
+            ee[j] = act ? ee[j] : 0xFFFFFFFFu;
+            ss[j] = act ? ((k == 1u) ? 0u : ss[j] + 1u) : 0u;
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
