@@ -701,25 +701,34 @@ void k_select(const u64* __restrict__ desc, u32 nblocks, const u64* __restrict__
         // The last <= 32 running counts are read by the 8 lanes of the query's group in ONE round trip (4 each)
         // and the block index is the number of entries below r; the 64-entry cumulative row of the block is
         // searched the same way (8 x 16 B = its 128-byte line).  Three dependent memory round trips per query
-        // (running counts -> descriptor + row -> bit line) instead of ~13 for two scalar binary searches.
+        // (running counts -> previous count + descriptor + row -> bit line) instead of ~13 for two scalar binary searches.
         {
             u32 below = 0;
+            u64 rc[4];
+#pragma unroll
+            for (u32 j = 0; j < 4; ++j) {                               // unconditional reads (index clamped), counted afterwards
+                u32 idx = sr_lo + sub * 4u + j;
+                rc[j] = rcount[idx <= sr_hi ? idx : sr_hi];
+            }
 #pragma unroll
             for (u32 j = 0; j < 4; ++j) {
                 u32 idx = sr_lo + sub * 4u + j;
-                if (ok && idx <= sr_hi) below += rcount[idx] < r ? 1u : 0u;
+                below += (ok && idx <= sr_hi && rc[j] < r) ? 1u : 0u;
             }
             below = group_sum8(below);
+            // previous running count, descriptor and the 64-entry row of block nb: three independent reads, issued
+            // together and unconditionally (nb = 0 for a dead query: every table has at least one entry)
+            nb = ok ? sr_lo + below : 0u;
+            u64 prev = rcount[nb ? nb - 1u : 0u];
+            d = desc[nb];
+            u32x4 cv = as_gc4(cum + (size_t)nb * 64u)[sub];
+            kd = ok ? DESC_K(d) : K_NULL;
             if (ok) {
-                nb = sr_lo + below;
-                rr = (u32)(r - (nb ? rcount[nb - 1] : 0ull));       // 1..65536 inside the block
-                d = desc[nb]; kd = DESC_K(d);
+                rr = (u32)(r - (nb ? prev : 0ull));                   // 1..65536 inside the block
                 if (kd == K_FULL) result = ((u64)nb << 16) + rr - 1u;
             }
             // digest wave: last w with cum[w] < rr  (cum[0] = 0 < rr always; the row is non-decreasing)
             bool need_row = ok && kd != K_FULL;
-            u32x4 cv = (u32x4)(0u);
-            if (need_row) cv = as_gc4(cum + (size_t)nb * 64u)[sub];
             u32 c16[8] = {cv.x & 0xFFFFu, cv.x >> 16, cv.y & 0xFFFFu, cv.y >> 16, cv.z & 0xFFFFu, cv.z >> 16, cv.w & 0xFFFFu, cv.w >> 16};
             u32 nlt = 0, best = 0;
 #pragma unroll
