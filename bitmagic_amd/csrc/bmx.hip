@@ -627,8 +627,8 @@ int bmx_pipeline_create(bmx_ctx* ctx, const bmx_vec* const* and_list, const uint
         po.nblocks = p->d_meta + 5 * ngroups;
         po.row_off = p->d_meta; po.and_n = p->d_meta + ngroups; po.sub_n = p->d_meta + 2 * ngroups;
         po.and_off = p->d_meta + 3 * ngroups; po.sub_off = p->d_meta + 4 * ngroups;
-        u64 nthreads = (u64)ncols * ngroups;
-        hipLaunchKernelGGL(k_pipe_sort, dim3((u32)((nthreads + 255) / 256)), dim3(256), 0, ctx->stream,
+        u64 nrows = (u64)ncols * ngroups;                  // one wave per (column, group) row
+        hipLaunchKernelGGL(k_pipe_sort, dim3((u32)((nrows + 3) / 4)), dim3(256), 0, ctx->stream,
                            po, (u32)ngroups, ncols, col_stride, p->d_dmat);
         PIPECHK(hipGetLastError());
     }
@@ -934,7 +934,7 @@ static int agg_or_impl(bmx_ctx* ctx, const bmx_vec* const* src, size_t n, int op
         hipError_t e = hipMemcpyAsync(d_descs, descs.data(), n * 8, hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(d_nblk, nblk.data(), n * 4, hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess) {
-            hipLaunchKernelGGL(k_or_sort, dim3((ncols + 255) / 256), dim3(256), 0, ctx->stream,
+            hipLaunchKernelGGL(k_or_sort, dim3((ncols + 3) / 4), dim3(256), 0, ctx->stream,
                                (const u64* const*)d_descs, (const u32*)d_nblk, (u32)n, ncols, (u64*)d_dmat);
             size_t lds = has_gap ? 4 * 2048 * 4 : 0;
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_agg_or<2>), dim3((ncols + 3) / 4), dim3(256), lds, ctx->stream,

@@ -154,27 +154,22 @@ void k_count_op2(int op, const u64* __restrict__ da, u32 na, const u64* __restri
 // ---------------------------------------------------------------------------
 // OR-group classification (aggregator::sort_input_blocks_or src/bmaggregator.h:2278):
 // row = [hdr, flags, region(n)]; hdr = nbit | ngap<<16; any FULL => ROW_FULL;
-// nothing => ROW_EMPTY.  One thread per column.
+// nothing => ROW_EMPTY.  One wave per column.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256)
 void k_or_sort(const u64* const* __restrict__ descs, const u32* __restrict__ nblk, u32 n, u32 ncols,
                u64* __restrict__ dmat)
 {
-    u32 c = blockIdx.x * blockDim.x + threadIdx.x;
+    u32 lane = lane_id();
+    u32 c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);     // one wave per column (sort_operands, bmx_kernels.h)
     if (c >= ncols) return;
     u64* row = dmat + (size_t)c * (n + 2u);
-    u64* r = row + 2;
-    u32 nbit = 0, ngap = 0; bool full = false;
-    for (u32 k = 0; k < n; ++k) {
-        u64 d = c < nblk[k] ? descs[k][c] : 0ull;
-        u32 kd = DESC_K(d);
-        if (kd == K_NULL) continue;
-        if (kd == K_FULL) { full = true; break; }
-        if (kd == K_BIT) r[nbit++] = DESC_P(d);
-        else r[n - 1u - ngap++] = DESC_P(d);
+    u32 nbit = 0, ngap = 0;
+    bool full = sort_operands(descs, nblk, 0u, n, c, K_FULL, row + 2, nbit, ngap, lane);
+    if (lane == 0) {
+        row[0] = (u64)nbit | ((u64)ngap << 16);
+        row[1] = full ? ROW_FULL : ((nbit | ngap) ? 0ull : ROW_EMPTY);
     }
-    row[0] = (u64)nbit | ((u64)ngap << 16);
-    row[1] = full ? ROW_FULL : ((nbit | ngap) ? 0ull : ROW_EMPTY);
 }
 
 // aggregator::combine_or(i, j, ...)  src/bmaggregator.h:1626; bit-block chain

@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Latency of whole host calls on SMALL collections (BASELINE configs[0] scale: 1 Mbit vectors), where launch
+and row-building latency dominate: combine_and_sub / combine_or / find_first_and_sub over 256 vectors, pairwise ops."""
+import json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import bitmagic_amd as bm
+s = torch.cuda.Stream(); torch.cuda.set_stream(s)
+ctx = bm.context(0, s.cuda_stream)
+def t(fn, reps=30, warm=5):
+    for _ in range(warm): fn()
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter(); fn(); ts.append((time.perf_counter() - t0) * 1e3)
+    return round(float(np.median(ts)), 4)
+for nbits in (1_000_000, 100_000_000):
+    vecs = [bm.bvector.generate(ctx, 0xB17A61C, v, 6554, nbits, with_common=True) for v in range(256)]
+    agg = bm.aggregator(ctx)
+    out = {"nbits": nbits, "nvec": 256}
+    out["combine_and_ms"] = t(lambda: agg.combine_and_sub(vecs, []))
+    out["combine_or_ms"] = t(lambda: agg.combine_or(vecs))
+    out["find_first_ms"] = t(lambda: agg.find_first_and_sub(vecs, []))
+    def mk():
+        p = bm.aggregator.pipeline(ctx); g = p.add()
+        for v in vecs: g.add(v, 0)
+        p.complete(); return p
+    out["pipeline_complete_ms"] = t(mk, reps=10, warm=2)
+    out["bit_and_ms"] = t(lambda: bm.bvector.bit_and(vecs[0], vecs[1]))
+    out["count_and_ms"] = t(lambda: bm.count_and(vecs[0], vecs[1]))
+    print(json.dumps(out))
