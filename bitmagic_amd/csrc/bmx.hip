@@ -596,7 +596,9 @@ int bmx_pipeline_create(bmx_ctx* ctx, const bmx_vec* const* and_list, const uint
         for (size_t op = 0; op < n_ops; ++op) plane_id[op] = plane(op);
         p->nplanes = (uint32_t)udesc.size();
         p->nchunks = (p->nplanes + 15u) / 16u;
-        p->staged_ok = p->nplanes > 0 && (size_t)ngroups * p->nchunks < (1u << 28);
+        // plane tables are only built where the staged kernel can be chosen (>= 32 groups, or forced by the knob):
+        // a single-group combine_and_sub should not pay four uploads and a sync for them
+        p->staged_ok = p->nplanes > 0 && (size_t)ngroups * p->nchunks < (1u << 28) && (ngroups >= 32 || ctx->pipe_staged == 1);
         if (p->staged_ok) {
             std::vector<u32> gmask((size_t)ngroups * std::max<u32>(p->nchunks, 1), 0), gskip(ngroups, 0);
             size_t a0 = 0, s0 = 0;

@@ -445,8 +445,13 @@ def test_many_gap_operands(ctx, port, dq, nvec):
         pipe.complete()
         assert int(agg.combine_and_sub(pipe)[0]) == e.count()
         ctx.set_tuning("pipe_staged", 1)               # GAP planes expanded into LDS by the staged kernel
-        try:
-            assert int(agg.combine_and_sub(pipe)[0]) == e.count()
+        try:                                           # (plane tables are built at complete() when the knob forces them)
+            pipe2 = bm.aggregator.pipeline(ctx)
+            ag2 = pipe2.add()
+            for i in a: ag2.add(gv[i], 0)
+            for i in s: ag2.add(gv[i], 1)
+            pipe2.complete()
+            assert int(agg.combine_and_sub(pipe2)[0]) == e.count()
         finally:
             ctx.set_tuning("pipe_staged", -1)
 
