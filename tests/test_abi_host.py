@@ -65,3 +65,33 @@ def test_no_device_fails_loudly():
         pytest.skip("GPU present")
     with pytest.raises(bm.BmxError):
         bm.context(0)
+
+
+def test_slice_scanner_group_rule():
+    """prepare_and_sub_aggregator (src/bmsparsevec_algo.h:2593-2640) as mirrored by slice_scanner: AND group =
+    planes of the set bits, high bit first; SUB group = every other existing plane; a set bit without a plane
+    (absent or beyond effective_slices) means nothing can match; value 0 is find_zero() and is refused"""
+    import bitmagic_amd as bm
+
+    class fake_ctx:            # group construction is host logic: no device call
+        _h = None
+    planes = ["p0", "p1", None, "p3", "p4"]            # plane 2 does not exist
+    sc = bm.slice_scanner(fake_ctx(), planes)
+    assert sc._groups(0b11011) == (["p4", "p3", "p1", "p0"], [])
+    assert sc._groups(0b01001) == (["p3", "p0"], ["p1", "p4"])
+    assert sc._groups(0b00100) is None                  # needs the absent plane
+    assert sc._groups(1 << 5) is None                   # bit above every plane
+    with pytest.raises(bm.BmxError) as e:
+        sc._groups(0)
+    assert e.value.status == 2
+
+
+def test_shard_ranges_cover_every_block_once():
+    from bitmagic_amd import shard_range
+    for nblocks in (0, 1, 7, 15259, 61036):
+        for world in (1, 2, 3, 8):
+            r = [shard_range(nblocks, k, world) for k in range(world)]
+            assert r[0][0] == 0 and r[-1][1] == nblocks
+            assert all(a[1] == b[0] for a, b in zip(r, r[1:]))
+            sizes = [hi - lo for lo, hi in r]
+            assert max(sizes) - min(sizes) <= 1
