@@ -612,10 +612,10 @@ __device__ __forceinline__ u32 gap_group_count_range(gcptr16 g, u32 lo, u32 from
     u32 hdr = g[0]; u32 len = hdr >> 3, s = hdr & 1u;
     u32 c = 0;
     for (u32 k = lo + sub; k <= len; k += 8) {
-        u32 start = (k == 1u) ? 0u : (u32)g[k - 1] + 1u;
+        u32 prev = g[k - 1], e = g[k];                      // both ends up front (a read inside the branch would be waited for alone)
+        u32 start = (k == 1u) ? 0u : prev + 1u;
         if (start > to) break;
         if ((s ^ ((k - 1u) & 1u)) != 0u) {
-            u32 e = g[k];
             u32 a = start > from ? start : from, b = e < to ? e : to;
             c += b - a + 1u;
         }
@@ -757,29 +757,44 @@ void k_select(const u64* __restrict__ desc, u32 nblocks, const u64* __restrict__
             u32 bit = (w * 32u + sub * 4u + wi) * 32u + (u32)__builtin_ctz(word);
             pos[qi] = ((u64)nb << 16) + bit;
         }
-        if (ok && kd == K_GAP) {
-            // gap_find_rank (src/bmfunc.h:3457) restricted to the wave: walk runs from the wave start
-            gcptr16 g = as_gc16(DESC_P(d));
-            u32 hdr = g[0]; u32 len = hdr >> 3, s0 = hdr & 1u;
-            u32 from = w << 10;
-            u32 lo = gidx[(size_t)nb * 64u + w];
-            if (sub == 0) {
-                u32 need = rr;
-                for (u32 k = lo; k <= len; ++k) {
-                    if ((s0 ^ ((k - 1u) & 1u)) != 0u) {
-                        u32 start = (k == 1u) ? 0u : (u32)g[k - 1] + 1u;
-                        if (start < from) start = from;
-                        u32 cnt = (u32)g[k] - start + 1u;
-                        if (need <= cnt) { result = ((u64)nb << 16) + start + need - 1u; break; }
-                        need -= cnt;
-                    }
+        {
+            // gap_find_rank (src/bmfunc.h:3457) restricted to the digest wave: the 8 lanes of the query take 8
+            // consecutive runs per round (run ends read unconditionally, index clamped), a prefix sum over the
+            // group finds the run that holds the rr-th bit.  All lanes of the wave walk the loop together
+            // (a group without a GAP query idles through it with gq = false).
+            bool gq = ok && kd == K_GAP;
+            gcptr16 g = gq ? as_gc16(DESC_P(d)) : (gcptr16)(uintptr_t)cum;       // idle lanes read a valid dummy
+            u32 len = 0, s0 = 0, lo = 1, from = w << 10, need = rr;
+            if (gq) { u32 hdr = g[0]; len = hdr >> 3; s0 = hdr & 1u; lo = gidx[(size_t)nb * 64u + w]; }
+            bool searching = gq;
+            for (u32 k0 = lo; __ballot(searching && k0 <= len) != 0ull; k0 += 8u) {
+                u32 k = k0 + sub;
+                bool act = searching && k <= len;
+                u32 kk = act ? k : 1u;
+                u32 prev = (u32)g[kk - 1u], e = (u32)g[kk];
+                u32 cnt = 0, start = 0;
+                if (act && (s0 ^ ((k - 1u) & 1u)) != 0u) {                // a 1-run
+                    start = (k == 1u) ? 0u : prev + 1u;
+                    if (start < from) start = from;
+                    cnt = e - start + 1u;
                 }
+                u32 incl = cnt;
+                { u32 t;
+                  t = __shfl_up(incl, 1, 64); if (sub >= 1u) incl += t;
+                  t = __shfl_up(incl, 2, 64); if (sub >= 2u) incl += t;
+                  t = __shfl_up(incl, 4, 64); if (sub >= 4u) incl += t; }
+                u32 total = __shfl(incl, (lane_id() & ~7u) + 7u, 64);
+                u32 excl = incl - cnt;
+                bool hit = searching && cnt != 0u && need > excl && need <= incl;
+                if (hit) pos[qi] = ((u64)nb << 16) + start + (need - excl) - 1u;
+                if (searching && need <= total) searching = false;       // some lane of the group had the hit
+                else need -= total;
             }
         }
         if (live && sub == 0) {
             found[qi] = ok ? 1 : 0;
             if (!ok) pos[qi] = 0;
-            else if (kd != K_BIT) pos[qi] = result;
+            else if (kd != K_BIT && kd != K_GAP) pos[qi] = result;
         }
     }
 }
