@@ -588,8 +588,11 @@ __device__ __forceinline__ bool gap_apply_sparse(const u64* __restrict__ plist_b
         u32 alive;
         if (nj <= 1u) alive = sparse_test<MODE, 1>(cand, G, h0);
         else if (nj <= 2u) alive = sparse_test<MODE, 2>(cand, G, h0);
+        else if (nj <= 3u) alive = sparse_test<MODE, 3>(cand, G, h0);
         else if (nj <= 4u) alive = sparse_test<MODE, 4>(cand, G, h0);
+        else if (nj <= 6u) alive = sparse_test<MODE, 6>(cand, G, h0);
         else if (nj <= 8u) alive = sparse_test<MODE, 8>(cand, G, h0);
+        else if (nj <= 12u) alive = sparse_test<MODE, 12>(cand, G, h0);
         else alive = sparse_test<MODE, 16>(cand, G, h0);
         if (alive == 0u) return true;
         if (((alive + 63u) >> 6) < nj) {                              // fewer slots suffice: compact through the list
