@@ -33,6 +33,22 @@ def test_adapter_compiles_against_reference(tmp_path):
     subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-I", REF, "-I", os.path.join(ROOT, "include"), str(src)], check=True)
 
 
+def test_c_header_is_plain_c99(tmp_path):
+    """CPU: include/bmx.h is a C header (a cgo / JNI / ctypes binding needs exactly that): the C client compiles
+    with -std=c99 -pedantic and links against libbmx.so"""
+    out = tmp_path / "c_abi_demo"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "examples", "c_abi_demo.c"), "-L", os.path.join(ROOT, "bitmagic_amd", "lib"), "-lbmx",
+                    "-Wl,-rpath," + os.path.join(ROOT, "bitmagic_amd", "lib"), "-Wl,-rpath,/opt/rocm/lib", "-o", str(out)], check=True)
+
+
+@pytest.mark.gpu
+def test_c_client_on_gpu():
+    subprocess.run(["make", "-s", "-C", CPP, "_bin/c_abi_demo"], check=True)
+    r = subprocess.run([os.path.join(CPP, "_bin", "c_abi_demo")], env=_env(), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "c_abi_demo ok" in r.stdout, r.stdout + r.stderr
+
+
 @pytest.mark.gpu
 def test_cpp_facade_on_gpu():
     subprocess.run(["make", "-s", "-C", CPP, "_bin/test_facade"], check=True)
