@@ -203,6 +203,15 @@ class bvector:
         check(lib().bmx_count(self.ctx._h, self._h, C.byref(c)))
         return c.value
 
+    def find(self):
+        """-> (found, pos) of the first set bit  (bvector::find, src/bm.h:1593)"""
+        found, idx = C.c_int(), C.c_uint64()
+        check(lib().bmx_find_first_and_sub(self.ctx._h, _handles([self]), 1, None, 0, C.byref(found), C.byref(idx)))
+        return bool(found.value), int(idx.value)
+
+    def any(self) -> bool:
+        return self.find()[0]
+
     # ---- rank / select ----------------------------------------------------
     def build_rs_index(self) -> "rs_index":
         h = C.c_void_p()

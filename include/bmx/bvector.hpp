@@ -130,6 +130,17 @@ public:
 
     /// bvector<>::count()  src/bm.h:2431
     size_type count() const { uint64_t c = 0; if (h_) check(bmx_count(ctx_->handle(), h_, &c)); return c; }
+    /// bvector<>::any() / find(pos) (src/bm.h:1593): first set bit = find_first_and_sub over the one-vector AND group
+    bool find(size_type& pos) const
+    {
+        if (!h_) return false;
+        const bmx_vec* one[1] = {h_};
+        int found = 0; uint64_t p = 0;
+        check(bmx_find_first_and_sub(ctx_->handle(), one, 1, nullptr, 0, &found, &p));
+        if (found) pos = p;
+        return found != 0;
+    }
+    bool any() const { size_type p; return find(p); }
 
     // ---- 3-operand set algebra: *this = bv1 OP bv2   (src/bm.h:6185,5973,6072,6403) ----
     bvector& bit_and(const bvector& bv1, const bvector& bv2, optmode opt = opt_none) { return op3(BMX_AND, bv1, bv2, opt); }

@@ -286,6 +286,10 @@ def test_kats_from_reference_tests(ctx, port):
 def test_edge_cases(ctx):
     e = bm.bit_import_u32(ctx, np.zeros(0, np.uint32))
     assert e.count() == 0 and e.info()["nblocks"] == 0
+    assert e.find() == (False, 0) and not e.any()
+    w = np.zeros(3 * 2048, np.uint32); w[2 * 2048 + 17] = 1 << 9
+    f = bm.bit_import_u32(ctx, w)
+    assert f.find() == (True, 2 * 65536 + 17 * 32 + 9) and f.any()
     one = bm.bit_import_u32(ctx, np.array([1], np.uint32))
     assert one.count() == 1 and bm.count_and(one, e) == 0 and bm.count_or(one, e) == 1
     assert bm.bvector.bit_or(e, one).count() == 1 and bm.bvector.bit_sub(one, one).count() == 0
