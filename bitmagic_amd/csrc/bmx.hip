@@ -372,7 +372,7 @@ int bmx_vec_upload(bmx_ctx* ctx, uint64_t nbits, uint32_t nblocks,
         uint8_t k = kinds[nb];
         v->counts[k]++;
         if (k == BMX_BIT) desc[nb] = DESC_MAKE(v->d_bits + (size_t)offs[nb] * 512u, K_BIT);
-        else if (k == BMX_GAP) desc[nb] = DESC_MAKE(v->d_gaps + goff[nb], K_GAP);
+        else if (k == BMX_GAP) desc[nb] = DESC_MAKE_GAP(v->d_gaps + goff[nb], gpad[goff[nb]] >> 3, gpad[goff[nb]] & 1u);
         else desc[nb] = DESC_MAKE(0, k);
     }
     HIPCHK(hipMemcpyAsync(v->d_desc, desc.data(), (size_t)nblocks * 8, hipMemcpyHostToDevice, ctx->stream));

@@ -14,6 +14,9 @@ typedef uint16_t u16;
 typedef uint32_t u32;
 typedef uint64_t u64;
 
+// (len << 1 | start bit) of a GAP block, carried in bits 48..60 of its descriptor
+#define GMETA(e) ((u32)((e) >> 48) & 0x1FFFu)
+#define GMETA_NONE 0xFFFFFFFFu
 #define BMX_DESC_KIND(d) ((u32)((d) & 3ull))
 #define BMX_DESC_PTR(d)  ((d) & ~3ull)
 
@@ -202,16 +205,19 @@ __device__ __forceinline__ u32 prefix_xor32(u32 x)
     return x;
 }
 
-__device__ __forceinline__ void gap_decode(gcptr16 g, u32* lds, Blk& out, u32 lane)
+// meta = GMETA of the block's descriptor when the caller has it: the run ends are then requested at once,
+// without a round trip for the header word.
+__device__ __forceinline__ void gap_decode(gcptr16 g, u32* lds, Blk& out, u32 lane, u32 meta = GMETA_NONE)
 {
+    u32 len, sbit;
+    if (meta != GMETA_NONE) { len = meta >> 1; sbit = meta & 1u; }
+    else { u32 hdr = g[0]; len = hdr >> 3; sbit = hdr & 1u; }
     u32x4* l4 = reinterpret_cast<u32x4*>(lds);
 #pragma unroll
     for (int i = 0; i < 8; ++i) l4[i * 64 + lane] = (u32x4)(0u);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    u32 hdr = g[0];
-    u32 len = hdr >> 3;
-    if ((hdr & 1u) && lane == 0) atomicXor(&lds[0], 1u);
+    if (sbit && lane == 0) atomicXor(&lds[0], 1u);
     // run ends are fetched 8 wave-loads at a time (independent, issued together) before the LDS atomics
     // that consume them: one memory round trip per 512 runs instead of one per 64
     for (u32 kb = 1; kb < len; kb += 512u) {
@@ -684,18 +690,17 @@ __device__ __forceinline__ bool gap_apply_list(const u64* __restrict__ plist_bac
 
 // popcount of a GAP block without expanding it (gap_bit_count_unr src/bmfunc.h:3107).
 // Returns the lane-local partial; caller wave_sum()s.
-__device__ __forceinline__ u32 gap_lane_popcount(gcptr16 g, u32 lane)
+__device__ __forceinline__ u32 gap_lane_popcount(gcptr16 g, u32 lane, u32 meta = GMETA_NONE)
 {
-    u32 hdr = g[0];
-    u32 len = hdr >> 3, s = hdr & 1u;
+    u32 len, s;
+    if (meta != GMETA_NONE) { len = meta >> 1; s = meta & 1u; }
+    else { u32 hdr = g[0]; len = hdr >> 3; s = hdr & 1u; }
     u32 c = 0;
-    // run k (1-based) covers (e[k-1], e[k]] and has value s ^ ((k-1)&1)
+    // run k (1-based) covers (e[k-1], e[k]] and has value s ^ ((k-1)&1); both ends are read unconditionally
     for (u32 k = 1 + lane; k <= len; k += 64) {
-        if ((s ^ ((k - 1u) & 1u)) != 0u) {
-            u32 e = g[k];
-            u32 pe = (k == 1u) ? 0xFFFFFFFFu : (u32)g[k - 1];
-            c += e - pe;            // k==1: e - (-1) = e + 1
-        }
+        u32 e = g[k], pe = g[k - 1];                   // k == 1: pe is the header word, unused
+        bool one = (s ^ ((k - 1u) & 1u)) != 0u;
+        c += one ? ((k == 1u) ? e + 1u : e - pe) : 0u;
     }
     return c;
 }

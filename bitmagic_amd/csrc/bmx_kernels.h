@@ -9,6 +9,9 @@
 #define DESC_MAKE(ptr, kind) ((u64)(uintptr_t)(ptr) | ((u64)(kind) << 62))
 #define DESC_K(d) ((u32)((d) >> 62))
 #define DESC_P(d) ((d) & 0x0000FFFFFFFFFFFFull)
+// GAP descriptors also carry (len << 1 | start bit) of the block in bits 48..60 (GMETA, bmx_device.h): the
+// run ends of a block can be requested without first waiting for its header word
+#define DESC_MAKE_GAP(ptr, len, sbit) (DESC_MAKE(ptr, K_GAP) | ((u64)((((u32)(len)) << 1) | ((u32)(sbit) & 1u)) << 48))
 enum { K_NULL = 0, K_FULL = 1, K_BIT = 2, K_GAP = 3 };
 
 // pipeline row flags
@@ -173,7 +176,7 @@ void k_emit_blocks(const uint4* __restrict__ raw, u32 nblocks, const BlockStat* 
         u32 level = len <= 124u ? 0u : len <= 252u ? 1u : len <= 508u ? 2u : 3u;   // gap_calc_level src/bmfunc.h:5418
         g[0] = (u16)((len << 3) | (level << 1) | st[nb].first);
         g[len] = 65535u;
-        desc[nb] = DESC_MAKE(g, K_GAP);
+        desc[nb] = DESC_MAKE_GAP(g, len, st[nb].first);
     }
 }
 
@@ -184,7 +187,7 @@ __device__ __forceinline__ void blk_from_desc(u64 d, Blk& b, u32* lds, u32 lane)
 {
     u32 k = DESC_K(d);
     if (k == K_BIT) blk_load(b, as_gc4(DESC_P(d)), lane);
-    else if (k == K_GAP) gap_decode(as_gc16(DESC_P(d)), lds, b, lane);
+    else if (k == K_GAP) gap_decode(as_gc16(DESC_P(d)), lds, b, lane, GMETA(d));
     else blk_fill(b, k == K_FULL ? ~0u : 0u);
 }
 
@@ -228,7 +231,7 @@ void k_vec_count(const u64* __restrict__ desc, u32 nblocks, u64* __restrict__ sl
         u32 k = DESC_K(d);
         if (k == K_FULL) c = 65536u;
         else if (k == K_BIT) { Blk b; blk_load(b, as_gc4(DESC_P(d)), lane); c = wave_sum(blk_lane_popcount(b)); }
-        else if (k == K_GAP) c = wave_sum(gap_lane_popcount(as_gc16(DESC_P(d)), lane));
+        else if (k == K_GAP) c = wave_sum(gap_lane_popcount(as_gc16(DESC_P(d)), lane, GMETA(d)));
     }
     count_fanin(c, slots, lane, wave);
 }

@@ -77,7 +77,7 @@ void k_emit_gaps(const uint4* __restrict__ slab, u32 nblocks, const BlockStat* _
         u32 level = len <= 124u ? 0u : len <= 252u ? 1u : len <= 508u ? 2u : 3u;
         g[0] = (u16)((len << 3) | (level << 1) | st[nb].first);
         g[len] = 65535u;
-        desc[nb] = DESC_MAKE(g, K_GAP);
+        desc[nb] = DESC_MAKE_GAP(g, len, st[nb].first);
     }
 }
 
@@ -521,10 +521,10 @@ void k_rs_build(const u64* __restrict__ desc, u32 nblocks, u32* __restrict__ bco
         aux1 = wave_sum(blk_lane_count_to(b, 43648u + 10912u, lane));
     } else {
         gcptr16 g = as_gc16(DESC_P(d));
-        gap_decode(g, lds + wave * 2048u, b, lane);
-        u32 s = (u32)g[0] & 1u;
+        gap_decode(g, lds + wave * 2048u, b, lane, GMETA(d));
+        u32 s = GMETA(d) & 1u;
         {   // gidx[w] = first run that reaches bit w*1024 (gap_bfind, src/bmfunc.h:1844), one wave of 1024 bits per lane
-            u32 glen = (u32)g[0] >> 3, from = lane << 10, lo = 1, hi = glen;
+            u32 glen = GMETA(d) >> 1, from = lane << 10, lo = 1, hi = glen;
             while (lo < hi) { u32 mid = (lo + hi) >> 1; if ((u32)g[mid] < from) lo = mid + 1; else hi = mid; }
             gidx[(size_t)nb * 64u + lane] = (u16)lo;
         }

@@ -64,7 +64,7 @@ __device__ __forceinline__ bool shifted_window(const u64* __restrict__ d, u32 nd
         return true;
     }
     // general: stage [tail of the lower block | upper block] in LDS
-    if (kp == K_GAP) { Blk t; gap_decode(as_gc16(DESC_P(dp)), W, t, lane); blk_to_lds(t, W, lane); }
+    if (kp == K_GAP) { Blk t; gap_decode(as_gc16(DESC_P(dp)), W, t, lane, GMETA(dp)); blk_to_lds(t, W, lane); }
     else if (kp == K_BIT) {
         gcptr32 p = (gcptr32)(uintptr_t)DESC_P(dp);
         for (u32 t = lane; t <= wq; t += 64u) W[2047u - wq + t] = p[2047u - wq + t];
