@@ -606,10 +606,10 @@ __device__ __forceinline__ u32 group_sum8(u32 v)
 }
 
 // ones of GAP block g at positions in [from..to] (to inclusive), summed over a group of 8 lanes
-__device__ __forceinline__ u32 gap_group_count_range(gcptr16 g, u32 lo, u32 from, u32 to, u32 sub)
+__device__ __forceinline__ u32 gap_group_count_range(gcptr16 g, u32 meta, u32 lo, u32 from, u32 to, u32 sub)
 {
-    // lo = index of the first run that reaches `from` (from the rs-index: gidx[nb][wave])
-    u32 hdr = g[0]; u32 len = hdr >> 3, s = hdr & 1u;
+    // lo = index of the first run that reaches `from` (from the rs-index: gidx[nb][wave]); meta = GMETA of the descriptor
+    u32 len = meta >> 1, s = meta & 1u;
     u32 c = 0;
     for (u32 k = lo + sub; k <= len; k += 8) {
         u32 prev = g[k - 1], e = g[k];                      // both ends up front (a read inside the branch would be waited for alone)
@@ -654,7 +654,7 @@ void k_rank(const u64* __restrict__ desc, u32 nblocks, const u64* __restrict__ r
                      + word_count_to(v.z, base + 2u, nbit) + word_count_to(v.w, base + 3u, nbit);
             } else if (kd == K_GAP) {
                 res += cum[(size_t)nb * 64u + w];
-                part = gap_group_count_range(as_gc16(DESC_P(d)), gidx[(size_t)nb * 64u + w], w << 10, nbit, sub);
+                part = gap_group_count_range(as_gc16(DESC_P(d)), GMETA(d), gidx[(size_t)nb * 64u + w], w << 10, nbit, sub);
             }
         }
         part = group_sum8(part);
@@ -765,7 +765,7 @@ void k_select(const u64* __restrict__ desc, u32 nblocks, const u64* __restrict__
             bool gq = ok && kd == K_GAP;
             gcptr16 g = gq ? as_gc16(DESC_P(d)) : (gcptr16)(uintptr_t)cum;       // idle lanes read a valid dummy
             u32 len = 0, s0 = 0, lo = 1, from = w << 10, need = rr;
-            if (gq) { u32 hdr = g[0]; len = hdr >> 3; s0 = hdr & 1u; lo = gidx[(size_t)nb * 64u + w]; }
+            if (gq) { len = GMETA(d) >> 1; s0 = GMETA(d) & 1u; lo = gidx[(size_t)nb * 64u + w]; }
             bool searching = gq;
             for (u32 k0 = lo; __ballot(searching && k0 <= len) != 0ull; k0 += 8u) {
                 u32 k = k0 + sub;
