@@ -608,16 +608,24 @@ __device__ __forceinline__ u32 group_sum8(u32 v)
 // ones of GAP block g at positions in [from..to] (to inclusive), summed over a group of 8 lanes
 __device__ __forceinline__ u32 gap_group_count_range(gcptr16 g, u32 meta, u32 lo, u32 from, u32 to, u32 sub)
 {
-    // lo = index of the first run that reaches `from` (from the rs-index: gidx[nb][wave]); meta = GMETA of the descriptor
+    // lo = index of the first run that reaches `from` (from the rs-index: gidx[nb][wave]); meta = GMETA of the descriptor.
+    // Each lane takes FOUR consecutive runs per round (five run ends read together, unconditionally, index clamped):
+    // the 8 lanes cover 32 runs, more than a 1024-bit wave of a sparse block holds, so one memory round trip
+    // usually answers the query (a lane walking every 8th run needed one round trip per 8 runs).
     u32 len = meta >> 1, s = meta & 1u;
     u32 c = 0;
-    for (u32 k = lo + sub; k <= len; k += 8) {
-        u32 prev = g[k - 1], e = g[k];                      // both ends up front (a read inside the branch would be waited for alone)
-        u32 start = (k == 1u) ? 0u : prev + 1u;
-        if (start > to) break;
-        if ((s ^ ((k - 1u) & 1u)) != 0u) {
-            u32 a = start > from ? start : from, b = e < to ? e : to;
-            c += b - a + 1u;
+    for (u32 k0 = lo + sub * 4u; k0 <= len; k0 += 32u) {
+        u32 ev[5];
+#pragma unroll
+        for (u32 j = 0; j < 5; ++j) { u32 kk = k0 - 1u + j; ev[j] = (u32)g[kk <= len ? kk : len]; }
+        if (((k0 == 1u) ? 0u : ev[0] + 1u) > to) break;
+#pragma unroll
+        for (u32 j = 0; j < 4; ++j) {
+            u32 k = k0 + j;
+            u32 start = (k == 1u) ? 0u : ev[j] + 1u;
+            bool one = k <= len && start <= to && (s ^ ((k - 1u) & 1u)) != 0u;
+            u32 a = start > from ? start : from, b = ev[j + 1u] < to ? ev[j + 1u] : to;
+            c += one ? b - a + 1u : 0u;
         }
     }
     return c;
