@@ -775,26 +775,38 @@ void k_select(const u64* __restrict__ desc, u32 nblocks, const u64* __restrict__
             u32 len = 0, s0 = 0, lo = 1, from = w << 10, need = rr;
             if (gq) { len = GMETA(d) >> 1; s0 = GMETA(d) & 1u; lo = gidx[(size_t)nb * 64u + w]; }
             bool searching = gq;
-            for (u32 k0 = lo; __ballot(searching && k0 <= len) != 0ull; k0 += 8u) {
-                u32 k = k0 + sub;
-                bool act = searching && k <= len;
-                u32 kk = act ? k : 1u;
-                u32 prev = (u32)g[kk - 1u], e = (u32)g[kk];
-                u32 cnt = 0, start = 0;
-                if (act && (s0 ^ ((k - 1u) & 1u)) != 0u) {                // a 1-run
-                    start = (k == 1u) ? 0u : prev + 1u;
+            for (u32 k0 = lo; __ballot(searching && k0 <= len) != 0ull; k0 += 32u) {
+                // four consecutive runs per lane: five run ends read together (unconditionally, index clamped)
+                u32 kf = k0 + sub * 4u;
+                u32 ev[5];
+#pragma unroll
+                for (u32 j = 0; j < 5; ++j) { u32 kk = kf - 1u + j; ev[j] = (u32)g[(searching && kk <= len) ? kk : 1u]; }
+                u32 cnt[4], st[4], mine = 0;
+#pragma unroll
+                for (u32 j = 0; j < 4; ++j) {
+                    u32 k = kf + j;
+                    bool one = searching && k <= len && (s0 ^ ((k - 1u) & 1u)) != 0u;
+                    u32 start = (k == 1u) ? 0u : ev[j] + 1u;
                     if (start < from) start = from;
-                    cnt = e - start + 1u;
+                    st[j] = start;
+                    cnt[j] = one ? ev[j + 1u] - start + 1u : 0u;
+                    mine += cnt[j];
                 }
-                u32 incl = cnt;
+                u32 incl = mine;
                 { u32 t;
                   t = __shfl_up(incl, 1, 64); if (sub >= 1u) incl += t;
                   t = __shfl_up(incl, 2, 64); if (sub >= 2u) incl += t;
                   t = __shfl_up(incl, 4, 64); if (sub >= 4u) incl += t; }
                 u32 total = __shfl(incl, (lane_id() & ~7u) + 7u, 64);
-                u32 excl = incl - cnt;
-                bool hit = searching && cnt != 0u && need > excl && need <= incl;
-                if (hit) pos[qi] = ((u64)nb << 16) + start + (need - excl) - 1u;
+                u32 excl = incl - mine;
+                if (searching && mine != 0u && need > excl && need <= incl) {
+                    u32 rem = need - excl;                                  // 1..mine inside this lane's four runs
+#pragma unroll
+                    for (u32 j = 0; j < 4; ++j) {
+                        if (rem != 0u && rem <= cnt[j]) { pos[qi] = ((u64)nb << 16) + st[j] + rem - 1u; rem = 0u; }
+                        else if (rem != 0u) rem -= cnt[j];
+                    }
+                }
                 if (searching && need <= total) searching = false;       // some lane of the group had the hit
                 else need -= total;
             }
