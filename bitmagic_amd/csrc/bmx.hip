@@ -256,7 +256,12 @@ int bmx_diag_stream_read(bmx_ctx* ctx, uint64_t bytes, int nt, uint32_t blocks_p
     u32 grid = (u32)((waves + 3) / 4);
     for (int it = -1; it < iters && e == hipSuccess; ++it) {
         if (it == 0) e = hipEventRecord(ctx->ev0, ctx->stream);
-        if (nt) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_diag_stream_read<true>), dim3(grid), dim3(256), 0, ctx->stream, (const uint4*)buf, nblk, blocks_per_wave, pattern, ctx->xcd_swz, ctx->d_small);
+#define DIAG_BUF(AUX) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_diag_stream_read_buf<AUX>), dim3(grid), dim3(256), 0, ctx->stream, (const uint4*)buf, nblk, blocks_per_wave, pattern, ctx->xcd_swz, ctx->d_small)
+        if (nt >= 100) {                         // 100 + cache-policy bits of a raw buffer load (1 = sc0, 2 = nt, 16 = sc1)
+            switch (nt - 100) { case 0: DIAG_BUF(0); break; case 1: DIAG_BUF(1); break; case 2: DIAG_BUF(2); break; case 3: DIAG_BUF(3); break;
+                                case 16: DIAG_BUF(16); break; case 17: DIAG_BUF(17); break; case 18: DIAG_BUF(18); break; default: DIAG_BUF(19); break; }
+        }
+        else if (nt) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_diag_stream_read<true>), dim3(grid), dim3(256), 0, ctx->stream, (const uint4*)buf, nblk, blocks_per_wave, pattern, ctx->xcd_swz, ctx->d_small);
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_diag_stream_read<false>), dim3(grid), dim3(256), 0, ctx->stream, (const uint4*)buf, nblk, blocks_per_wave, pattern, ctx->xcd_swz, ctx->d_small);
     }
     if (e == hipSuccess) e = hipEventRecord(ctx->ev1, ctx->stream);

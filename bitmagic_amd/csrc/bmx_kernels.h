@@ -510,6 +510,29 @@ void k_pipe_counts_bits2(const u64* __restrict__ dmat, const u32* __restrict__ r
     if (lane == 0 && cnt) atomicAdd(reinterpret_cast<unsigned long long*>(&counts[g]), (unsigned long long)cnt);
 }
 
+// same read pattern through raw buffer loads with an explicit cache policy (AUX: 1 = sc0, 2 = nt, 16 = sc1):
+// measures what the memory system does with each policy for a pure stream
+template <int AUX>
+__global__ __launch_bounds__(256)
+void k_diag_stream_read_buf(const uint4* __restrict__ buf, u64 nblocks8k, u32 blocks_per_wave, int pattern, int xcd_swz, u64* __restrict__ sink)
+{
+    u32 lane = lane_id();
+    u32 bid = xcd_swz ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
+    u64 w = (u64)bid * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    u64 nwaves = nblocks8k / blocks_per_wave;
+    if (w >= nwaves) return;
+    u64 b0 = pattern ? w : w * blocks_per_wave;
+    u64 step = pattern ? nwaves : 1;
+    u32x4 acc = (u32x4)(0u);
+    for (u32 j = 0; j < blocks_per_wave; ++j) {
+        u64 addr = uniform64((u64)(uintptr_t)(buf + (b0 + j * step) * 512u));
+        __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)(uintptr_t)addr, 0, 8192, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc |= __builtin_amdgcn_raw_buffer_load_b128(r, (int)(i * 1024 + lane * 16), 0, AUX);
+    }
+    if ((acc.x | acc.y | acc.z | acc.w) == 0x12345678u) sink[0] = 1;
+}
+
 // algorithmic operand bytes of the rows in [col_from, col_from+ncols)
 __global__ __launch_bounds__(256)
 void k_pipe_bytes(const u64* __restrict__ dmat, const u32* __restrict__ row_off, const u32* __restrict__ and_n,
