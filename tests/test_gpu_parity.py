@@ -743,3 +743,39 @@ def test_block_range_shards_add_up(ctx, port):
                 w = port.gen_words(SEED, 300, 40, nbits, word_off=lo * 2048, nwords=nw + (nw & 1))[:nw]
                 assert (sh[0].to_words(nw) == w).all()
         assert s_or == total_or and s_and == total_and, world
+
+
+def test_full_size_shift_right_and_properties(ctx, port):
+    """combine_shift_right_and on 1e9-bit vectors through size-independent identities: a single operand is a copy;
+    shifting against all-ones operands only moves the bits (the count drops by the bits pushed past the end);
+    [a, b] equals the AND of b with a moved by one, checked on sampled blocks against the oracle's words."""
+    nbits = 1_000_000_000
+    a = bm.bvector.generate(ctx, SEED, 77, 20000, nbits)
+    b = bm.bvector.generate(ctx, SEED, 78, 40000, nbits)
+    ones = bm.bvector.generate(ctx, SEED, 79, 65536, nbits)
+    assert ones.count() == nbits
+    agg = bm.aggregator(ctx)
+    t, f = agg.combine_shift_right_and([a])
+    assert f and bm.count_xor(t, a) == 0
+    ca = a.count()
+    tail = a.to_words((nbits + 31) // 32)[-1]
+    for k in (1, 2, 40):
+        t, f = agg.combine_shift_right_and([a] + [ones] * k)
+        lost = sum((int(tail) >> ((nbits - 1 - j) % 32)) & 1 for j in range(k))       # bits within k of the end
+        assert f and t.count() == ca - lost, k
+    t, f = agg.combine_shift_right_and([a, b])
+    agg.set_compute_count(True)
+    agg.combine_shift_right_and([a, b])
+    assert agg.count() == t.count()
+    agg.set_compute_count(False)
+    for nb0 in (0, 9000, 15258):
+        nw = min(2048, (nbits + 31) // 32 - nb0 * 2048)
+        lo = max(nb0 * 2048 - 2, 0)
+        wa = port.gen_words(SEED, 77, 20000, nbits, word_off=lo, nwords=nb0 * 2048 - lo + nw)
+        wb = port.gen_words(SEED, 78, 40000, nbits, word_off=nb0 * 2048, nwords=nw)
+        bits_a = np.unpackbits(wa.view(np.uint8), bitorder="little")
+        off = (nb0 * 2048 - lo) * 32
+        shifted = bits_a[off - 1: off - 1 + nw * 32] if off else np.concatenate([[0], bits_a[: nw * 32 - 1]]).astype(np.uint8)
+        exp = np.packbits(shifted, bitorder="little").view(np.uint32) & wb
+        got = t.to_words((nb0 + 1) * 2048)[nb0 * 2048: nb0 * 2048 + nw]
+        assert (got == exp).all(), nb0
