@@ -17,6 +17,22 @@ for args in [(2, 50, 45), (17, 80, 64), (90, 60, 33), (333, 150, 70), (600, 20, 
 for dq, nv in [(7, 130), (100, 64), (65400, 40), (2000, 35)]:
     try: P.test_many_gap_operands(ctx, port, dq, nv)
     except AssertionError as e: bad += 1; print("FAIL many", dq, nv, str(e)[:200])
+import numpy as np
+agg = bm.aggregator(ctx)
+for seed in range(400):
+    rng = np.random.default_rng(50000 + seed)
+    nblk = int(rng.integers(1, 7))
+    vecs = [S._random_vector(rng, port, ctx, nblk, True) for _ in range(int(rng.integers(1, 6)))]
+    n = int(rng.integers(1, 45))
+    sel = [int(x) for x in rng.integers(0, len(vecs), n)]
+    opt, any_ = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+    agg.set_optimization(opt)
+    t, f = agg.combine_shift_right_and([vecs[i][1] for i in sel], any=any_)
+    e, ef = port.agg_shift_right_and([vecs[i][0] for i in sel], opt, any_)
+    nw = nblk * 2048
+    ok = f == ef and (t.to_words(nw) == e.to_words(nw)).all() and t.block_table()[0].tolist()[:nblk] == e.flatten()[0].tolist()[:nblk]
+    if not ok: bad += 1; print("FAIL shift seed", seed, n, opt, any_)
+agg.set_optimization(False)
 print("soak done, failures:", bad)
 PY
 timeout 1200 python /tmp/soak.py > gpurun_out/soak.log 2>&1; tail -6 gpurun_out/soak.log
