@@ -839,6 +839,33 @@ static int result_finish(bmx_ctx* ctx, bmx_vec* v, BlockStat* st, u32* offs)
 
 extern "C" {
 
+// block-for-block copy of a device vector (bvector::operator=): same kinds, own slabs
+static int vec_clone(bmx_ctx* ctx, const bmx_vec* a, bmx_vec** out)
+{
+    bmx_vec* v = vec_alloc_host(ctx, a->nbits, a->nblocks);
+    if (!v) return BMX_ERR_BADALLOC;
+    int rc;
+    size_t b_bits = a->d_bits ? (size_t)a->n_bit * 8192 : 0, b_gaps = a->d_gaps ? (size_t)a->gap_words * 2 + 64 : 0;
+    size_t b_desc = (size_t)std::max<uint32_t>(a->nblocks, 1) * 8;
+    if ((rc = dmalloc(ctx, (void**)&v->d_desc, b_desc)) || (b_bits && (rc = dmalloc(ctx, (void**)&v->d_bits, b_bits))) ||
+        (b_gaps && (rc = dmalloc(ctx, (void**)&v->d_gaps, b_gaps)))) { bmx_vec_free(ctx, v); return rc; }
+    v->n_bit = a->d_bits ? a->n_bit : 0; v->gap_words = a->d_gaps ? a->gap_words : 0;
+    memcpy(v->counts, a->counts, sizeof(v->counts));
+    v->bytes = std::max<size_t>(b_desc, 16) + std::max<size_t>(b_bits, 16) + std::max<size_t>(b_gaps, 16);
+    hipError_t e = hipSuccess;
+    if (b_bits) e = hipMemcpyAsync(v->d_bits, a->d_bits, b_bits, hipMemcpyDeviceToDevice, ctx->stream);
+    if (e == hipSuccess && b_gaps) e = hipMemcpyAsync(v->d_gaps, a->d_gaps, b_gaps, hipMemcpyDeviceToDevice, ctx->stream);
+    if (e == hipSuccess && a->nblocks) {
+        hipLaunchKernelGGL(k_rebase_desc, dim3((a->nblocks + 255) / 256), dim3(256), 0, ctx->stream, a->d_desc, v->d_desc, a->nblocks,
+                           (u64)(uintptr_t)a->d_bits, (u64)(uintptr_t)v->d_bits, (u64)(uintptr_t)a->d_gaps, (u64)(uintptr_t)v->d_gaps);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { bmx_vec_free(ctx, v); return fail_hip(e, "vec_clone", __LINE__); }
+    *out = v;
+    return BMX_OK;
+}
+
 int bmx_op2(bmx_ctx* ctx, int op, const bmx_vec* a, const bmx_vec* b, int opt_compress, bmx_vec** result)
 {
     ARGCHK(ctx && a && b && result && a->ctx == ctx && b->ctx == ctx && op >= BMX_AND && op <= BMX_SUB);
@@ -846,6 +873,22 @@ int bmx_op2(bmx_ctx* ctx, int op, const bmx_vec* a, const bmx_vec* b, int opt_co
     int rc = set_dev(ctx); if (rc) return rc;
     uint32_t nblocks = std::max(a->nblocks, b->nblocks);
     uint64_t nbits = std::max(a->nbits, b->nbits);                  // src/bm.h:6219-6221
+    if (a == b) {
+        // aliasing as the reference handles it up front: AND / OR of a vector with itself is a block-for-block copy
+        // (src/bm.h:6191-6195, 5984-5988), XOR / SUB are empty (:6081, 6412); nothing is re-optimised
+        if (op == BMX_AND || op == BMX_OR) return vec_clone(ctx, a, result);
+        bmx_vec* v; BlockStat* st; u32* offs;
+        if ((rc = result_begin(ctx, nbits, nblocks, &v, &st, &offs))) return rc;
+        if (nblocks) {
+            hipError_t e = hipMemsetAsync(v->d_desc, 0, (size_t)nblocks * 8, ctx->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+            if (e != hipSuccess) { bmx_vec_free(ctx, v); return fail_hip(e, "bmx_op2", __LINE__); }
+        }
+        v->counts[BMX_NULL] = nblocks;
+        dfree(ctx, v->d_bits); v->d_bits = nullptr; v->n_bit = 0;
+        *result = v;
+        return BMX_OK;
+    }
     bmx_vec* v; BlockStat* st; u32* offs;
     if ((rc = result_begin(ctx, nbits, nblocks, &v, &st, &offs))) return rc;
     if (nblocks) {

@@ -81,6 +81,19 @@ void k_emit_gaps(const uint4* __restrict__ slab, u32 nblocks, const BlockStat* _
     }
 }
 
+// descriptors of a cloned vector: same kinds, pointers moved into the clone's slabs
+__global__ __launch_bounds__(256)
+void k_rebase_desc(const u64* __restrict__ in, u64* __restrict__ out, u32 n, u64 old_bits, u64 new_bits, u64 old_gaps, u64 new_gaps)
+{
+    u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u64 d = in[i];
+    u32 k = DESC_K(d);
+    if (k == K_BIT) d = (d & ~0x0000FFFFFFFFFFFFull) | (DESC_P(d) - old_bits + new_bits);
+    else if (k == K_GAP) d = (d & ~0x0000FFFFFFFFFFFFull) | (DESC_P(d) - old_gaps + new_gaps);
+    out[i] = d;
+}
+
 // ---------------------------------------------------------------------------
 // Pairwise ops.  bvector::bit_and/or/xor/sub(bv1, bv2)  src/bm.h:6185,5973,6072,6403
 // per block: combine_operation_block_* (:7100,6945,7018,7285); NULL/FULL

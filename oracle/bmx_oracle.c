@@ -929,6 +929,15 @@ bmo_vec* bmo_op2(int op, const bmo_vec* a, const bmo_vec* b, int opt_compress)
 {
     uint64_t nbits = a->nbits > b->nbits ? a->nbits : b->nbits;   /* src/bm.h:6219-6221 */
     bmo_vec* t = bmo_vec_new(nbits);
+    if (a == b) {
+        /* aliasing, handled up front by the reference: bit_and(bv, bv) is a plain copy (src/bm.h:6191-6195),
+         * bit_or(bv, bv) ORs bv into the emptied target = copies every block as it is (:5984-5988 with the
+         * "0,x -> copy x" rule), bit_xor / bit_sub of a vector with itself are empty (:6081-6082, 6412-6413).
+         * No block is re-optimised on these paths whatever opt_mode says. */
+        if (op == BMO_AND || op == BMO_OR)
+            for (uint32_t nb = 0; nb < t->nblocks; ++nb) clone_block(t, nb, a, 0);
+        return t;
+    }
     for (uint32_t nb = 0; nb < t->nblocks; ++nb) {
         int need_opt = op2_block(op, t, nb, a, b);
         if (need_opt && opt_compress && t->kind[nb] == BMO_BIT) {   /* optimize_bit_block, src/bmblocks.h:1412 */

@@ -287,6 +287,18 @@ def test_edge_cases(ctx):
     e = bm.bit_import_u32(ctx, np.zeros(0, np.uint32))
     assert e.count() == 0 and e.info()["nblocks"] == 0
     assert e.find() == (False, 0) and not e.any()
+    # aliasing (src/bm.h:6191-6195, 5984-5988, 6081, 6412): AND / OR of a vector with itself copy it block for block
+    # (an un-optimised all-zero bit-block stays a bit-block), XOR / SUB are empty
+    raw = np.zeros(4 * 2048, np.uint32); raw[2048:4096] = 0xFFFFFFFF; raw[3 * 2048 + 5] = 77
+    u = bm.bit_import_u32(ctx, raw, False)
+    ku = u.block_table()[0].tolist()
+    for fn in (bm.bvector.bit_and, bm.bvector.bit_or):
+        for opt in (bm.opt_none, bm.opt_compress):
+            c = fn(u, u, opt)
+            assert c.block_table()[0].tolist() == ku and (c.to_words(raw.size) == raw).all() and c.count() == u.count()
+    for fn in (bm.bvector.bit_xor, bm.bvector.bit_sub):
+        z = fn(u, u)
+        assert z.count() == 0 and set(z.block_table()[0].tolist()) == {bm.NULL} and z.info()["nblocks"] == 4
     w = np.zeros(3 * 2048, np.uint32); w[2 * 2048 + 17] = 1 << 9
     f = bm.bit_import_u32(ctx, w)
     assert f.find() == (True, 2 * 65536 + 17 * 32 + 9) and f.any()

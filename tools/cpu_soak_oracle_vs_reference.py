@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Build container only: randomized differential of the oracle restatement against the live reference (oracle/_ref):
+import kinds, pairwise ops (incl. aliased operands), aggregator AND-SUB / OR in both opt modes, shift-right-and,
+rank / select.  300 seeds, 0 mismatches."""
+import sys, numpy as np
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import oracle
+P = oracle.port(); R = oracle.reference("avx2")
+KINDS = ["null", "full", "sparse", "mid", "dense", "runs", "half"]
+def block(rng, kind):
+    w = np.zeros(2048, np.uint32)
+    if kind == "full": w[:] = 0xFFFFFFFF
+    elif kind == "sparse":
+        pos = rng.choice(65536, size=int(rng.integers(1, 400)), replace=False); np.bitwise_or.at(w, pos >> 5, (np.uint32(1) << (pos & 31).astype(np.uint32)))
+    elif kind == "mid": w[:] = rng.integers(0, 1 << 32, 2048, dtype=np.uint64).astype(np.uint32)
+    elif kind == "dense":
+        w[:] = 0xFFFFFFFF; pos = rng.choice(65536, size=int(rng.integers(1, 300)), replace=False); np.bitwise_and.at(w, pos >> 5, ~(np.uint32(1) << (pos & 31).astype(np.uint32)))
+    elif kind == "runs":
+        a = 0
+        while a < 2048:
+            l = int(rng.integers(1, 200)); w[a:a + l] = 0xFFFFFFFF if rng.integers(0, 2) else 0; a += l
+    elif kind == "half": w[:1024] = 0xFFFFFFFF
+    return w
+bad = 0
+for seed in range(300):
+    rng = np.random.default_rng(90000 + seed)
+    nblk = int(rng.integers(1, 6)); nv = int(rng.integers(2, 7))
+    ws = [np.concatenate([block(rng, KINDS[int(rng.integers(0, len(KINDS)))]) for _ in range(nblk)]) for _ in range(nv)]
+    opt = bool(rng.integers(0, 2))
+    pv = [P.import_words(w, opt, nblk * 65536) for w in ws]; rv = [R.import_words(w, opt, nblk * 65536) for w in ws]
+    try:
+        for p, r in zip(pv, rv): assert p.flatten()[0].tolist() == r.flatten()[0].tolist() and p.count() == r.count()
+        for op in range(4):
+            i, j = (int(x) for x in rng.integers(0, nv, 2)); oc = bool(rng.integers(0, 2))
+            a, b = P.op2(op, pv[i], pv[j], oc), R.op2(op, rv[i], rv[j], oc)
+            assert (a.to_words() == b.to_words()).all() and a.flatten()[0].tolist() == b.flatten()[0].tolist()
+            assert P.count_op2(op, pv[i], pv[j]) == R.count_op2(op, rv[i], rv[j])
+        na = int(rng.integers(1, nv + 1))
+        assert (P.agg_and_sub(pv[:na], pv[na:]).to_words() == R.agg_and_sub(rv[:na], rv[na:]).to_words()).all()
+        assert P.agg_and_sub(pv[:na], pv[na:]).flatten()[0].tolist() == R.agg_and_sub(rv[:na], rv[na:]).flatten()[0].tolist()
+        for oc in (False, True):
+            assert P.agg_or(pv, oc).flatten()[0].tolist() == R.agg_or(rv, oc).flatten()[0].tolist()
+        sel = [int(x) for x in rng.integers(0, nv, int(rng.integers(1, 40)))]
+        oc, an = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+        tp, fp = P.agg_shift_right_and([pv[i] for i in sel], oc, an); tr, fr = R.agg_shift_right_and([rv[i] for i in sel], oc, an)
+        assert fp == fr and (tp.to_words() == tr.to_words()).all() and tp.flatten()[0].tolist() == tr.flatten()[0].tolist()
+        rsp, rsr = P.rs_build(pv[0]), R.rs_build(rv[0])
+        q = rng.integers(0, nblk * 65536, 50).astype(np.uint64)
+        assert (rsp.rank(q) == rsr.rank(q)).all()
+        c = pv[0].count()
+        if c:
+            r = rng.integers(1, c + 1, 50).astype(np.uint64)
+            a, b = rsp.select(r), rsr.select(r)
+            assert (a[0] == b[0]).all() and (a[1] == b[1]).all()
+    except AssertionError as e:
+        bad += 1; print("FAIL seed", seed)
+print("cpu soak failures:", bad)
