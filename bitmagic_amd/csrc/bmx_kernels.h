@@ -44,7 +44,7 @@ void k_generate(u64 seed, u32 vec_id, int with_common, u32 d, u64 nbits, u64* __
 // ---------------------------------------------------------------------------
 // import, step 1: per raw block popcount / run count / first bit and the storage
 // decision of blocks_manager::optimize_bit_block (src/bmblocks.h:1412-1436):
-//   runs == 1 -> NULL or FULL;  optimize && runs < 1276 -> GAP;  else BIT.
+//   optimize: runs == 1 -> NULL or FULL;  runs < 1276 -> GAP;  else BIT.   no optimize: BIT.
 // One wave per block, 4 blocks per workgroup.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256)
@@ -59,8 +59,11 @@ void k_block_stats(const uint4* __restrict__ raw, u32 nblocks, int optimize, Blo
     u32 runs = 1u + wave_sum(blk_transitions(b, t, lane));
     u32 first = __shfl(b.r[0].x, 0, 64) & 1u;
     if (lane == 0) {
-        u32 kind = (runs == 1u) ? (first ? K_FULL : K_NULL)
-                 : ((optimize && runs < 1276u) ? K_GAP : K_BIT);
+        // without optimize every block is stored as a bit-block, an all-zero / all-ones one too (copy_bit_block,
+        // src/bmbvimport.h:46 + src/bmblocks.h:1340); optimize_bit_block (:1412) is what turns them into NULL / FULL / GAP
+        u32 kind = !optimize ? K_BIT
+                 : (runs == 1u) ? (first ? K_FULL : K_NULL)
+                 : (runs < 1276u ? K_GAP : K_BIT);
         st[nb] = BlockStat{pop, runs, first, kind};
     }
 }

@@ -13,10 +13,47 @@
 //   else BIT in its slot.
 // All 64 lanes call; st[nb] and desc[nb] are written by lane 0.
 // ---------------------------------------------------------------------------
+// How a produced block is classified.  ST_OPT: the opt_copy_bit_block rule above.  The 3-operand ops of the
+// reference do NOT treat every block alike (combine_operation_block_*, src/bm.h:7100-7340, Appendix A.1):
+//   ST_FORCE_BIT   a bit-block that is only copied (x op NULL, x AND FULL, ~x for XOR FULL) stays a bit-block,
+//                  whatever it holds and whatever opt_mode says (clone_assign_block, src/bmblocks.h:894)
+//   ST_FORCE_GAP   a copied GAP block and a GAP x GAP result stay GAP in either mode (clone_gap_block :865:
+//                  all-zero -> NULL, too long -> bit-block)
+//   ST_TEST_ZERO / ST_TEST_ONE   without opt_compress a computed block is stored as a bit-block unless the
+//                  operation itself tests it: all-zero -> NULL (B x B except OR, any AND, GAP - B), all-ones -> FULL (B OR B)
+enum { ST_OPT = 1, ST_FORCE_BIT = 2, ST_TEST_ZERO = 4, ST_TEST_ONE = 8, ST_FORCE_GAP = 16 };
+
+__device__ __forceinline__ void store_result_mode(const Blk& acc, u32 nb, u32 mode,
+                                                  uint4* __restrict__ slab, u64* __restrict__ desc,
+                                                  BlockStat* __restrict__ st, u32 lane)
+{
+    Blk t;
+    u32 pop = wave_sum(blk_lane_popcount(acc));
+    u32 runs = 1u + wave_sum(blk_transitions(acc, t, lane));
+    u32 first = __shfl(acc.r[0].x, 0, 64) & 1u;
+    u32 kind;
+    if (mode & ST_FORCE_BIT) kind = K_BIT;
+    else if (mode & (ST_FORCE_GAP | ST_OPT))
+        kind = (runs == 1u) ? (first ? K_FULL : K_NULL) : (runs < 1276u ? K_GAP : K_BIT);
+    else {
+        kind = K_BIT;
+        if ((mode & ST_TEST_ZERO) && runs == 1u && !first) kind = K_NULL;
+        if ((mode & ST_TEST_ONE) && runs == 1u && first) kind = K_FULL;
+    }
+    uint4* slot = slab + (size_t)nb * 512u;
+    if (kind == K_BIT || kind == K_GAP) blk_store(acc, as_g4(slot), lane);
+    if (lane == 0) {
+        st[nb] = BlockStat{pop, runs, first, kind};
+        desc[nb] = (kind == K_BIT) ? DESC_MAKE(slot, K_BIT) : DESC_MAKE(0, kind == K_GAP ? K_NULL : kind);
+    }
+}
+
 __device__ __forceinline__ void store_result(const Blk& acc, u32 nb, int opt_compress,
                                              uint4* __restrict__ slab, u64* __restrict__ desc,
                                              BlockStat* __restrict__ st, u32 lane, bool full_as_bit = false)
 {
+    // aggregator results: opt_copy_bit_block(.., opt_mode, ..); without opt_compress a block is stored as it is
+    // except that an empty / full one carries no storage here (full_as_bit: copy_bit_block keeps all-ones as bits)
     Blk t;
     u32 pop = wave_sum(blk_lane_popcount(acc));
     u32 runs = 1u + wave_sum(blk_transitions(acc, t, lane));
@@ -134,7 +171,23 @@ void k_op2(int op, const u64* __restrict__ da, u32 na, const u64* __restrict__ d
     blk_from_desc(a, x, l, lane);
     blk_from_desc(b, y, l, lane);
     blk_op(op, x, y);
-    store_result(x, nb, opt_compress, slab, desc, st, lane);
+    // classification of the produced block follows the reference case by case (see ST_* above)
+    u32 mode;
+    u32 copy_of = 4u;                                        // kind of the operand that is merely copied (4 = none)
+    if (op == BMX_AND) { if (ka == K_FULL) copy_of = kb; else if (kb == K_FULL) copy_of = ka; }
+    else if (op == BMX_OR) { if (ka == K_NULL) copy_of = kb; else if (kb == K_NULL) copy_of = ka; }
+    else if (op == BMX_XOR) { if (ka == K_NULL || ka == K_FULL) copy_of = kb; else if (kb == K_NULL || kb == K_FULL) copy_of = ka; }
+    else { if (kb == K_NULL) copy_of = ka; }
+    if (copy_of == K_BIT) mode = ST_FORCE_BIT;
+    else if (copy_of == K_GAP || (ka == K_GAP && kb == K_GAP)) mode = ST_FORCE_GAP;
+    else if (opt_compress) mode = ST_OPT;
+    else {
+        bool bb = ka != K_GAP && kb != K_GAP;                 // bit x bit (FULL in SUB counts as a real all-ones block)
+        mode = 0u;
+        if ((bb && op != BMX_OR) || op == BMX_AND || (ka == K_GAP && op == BMX_SUB)) mode |= ST_TEST_ZERO;
+        if (bb && op == BMX_OR) mode |= ST_TEST_ONE;
+    }
+    store_result_mode(x, nb, mode, slab, desc, st, lane);
 }
 
 // bm::count_and/or/xor/sub  src/bmalgo.h:49,149,81,115 (distance_operation,

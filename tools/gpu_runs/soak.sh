@@ -33,6 +33,26 @@ for seed in range(400):
     ok = f == ef and (t.to_words(nw) == e.to_words(nw)).all() and t.block_table()[0].tolist()[:nblk] == e.flatten()[0].tolist()[:nblk]
     if not ok: bad += 1; print("FAIL shift seed", seed, n, opt, any_)
 agg.set_optimization(False)
+# block kinds (representation) of compressed results vs the oracle
+for seed in range(400):
+    rng = np.random.default_rng(70000 + seed)
+    nblk = int(rng.integers(1, 7)); nv = int(rng.integers(2, 7))
+    vecs = [S._random_vector(rng, port, ctx, nblk, bool(rng.integers(0, 2))) for _ in range(nv)]
+    pv = [v[0] for v in vecs]; gv = [v[1] for v in vecs]
+    for op in range(4):
+        i, j = (int(x) for x in rng.integers(0, nv, 2))
+        for oc in (True, False):
+            kk = bm.bvector._op2(op, gv[i], gv[j], bm.opt_compress if oc else bm.opt_none).block_table()[0].tolist()
+            ek = port.op2(op, pv[i], pv[j], oc).flatten()[0].tolist()
+            if not all(a == b or (a == bm.FULL and b == bm.GAP) for a, b in zip(kk, ek)):
+                bad += 1; print("FAIL kinds op2", seed, op, oc, i, j, kk, ek, pv[i].flatten()[0].tolist(), pv[j].flatten()[0].tolist())
+    na = int(rng.integers(1, nv + 1))
+    t, _ = agg.combine_and_sub(gv[:na], gv[na:])
+    e = port.agg_and_sub(pv[:na], pv[na:])
+    if t.block_table()[0].tolist() != e.flatten()[0].tolist(): bad += 1; print("FAIL kinds and_sub", seed)
+    agg.set_optimization(True)
+    if agg.combine_or(gv).block_table()[0].tolist() != port.agg_or(pv, True).flatten()[0].tolist(): bad += 1; print("FAIL kinds or", seed)
+    agg.set_optimization(False)
 print("soak done, failures:", bad)
 PY
 timeout 1200 python /tmp/soak.py > gpurun_out/soak.log 2>&1; tail -6 gpurun_out/soak.log
