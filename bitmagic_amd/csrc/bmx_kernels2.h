@@ -259,14 +259,16 @@ void k_agg_or(const u64* __restrict__ dmat, u32 n, u32 ncols, int opt_compress, 
     const u64* p = row + 2;
     Blk acc;
     blk_fill(acc, 0u);
-    if (pipe_chain<U, true, 2>(acc, p, nbit, lane)) { store_trivial(K_FULL, c, desc, st, lane); return; }   // saturated (:1951)
+    // saturated (:1951) -- tested by the reference after every OR step, i.e. never when a single bit-block is just copied (:1936)
+    if (pipe_chain<U, true, 2>(acc, p, nbit, lane) && nbit >= 2u) { store_trivial(K_FULL, c, desc, st, lane); return; }
     if (ngap) {                                          // process_gap_blocks_or (:1808), run-parallel in LDS
         u32* lds = lds_dyn + wave * 2048u;
         blk_to_lds(acc, lds, lane);
         (void)gap_apply_list<GAP_OR>(p + n - 1u, ngap, lds, lane);
         blk_from_lds(acc, lds, lane);
     }
-    store_result(acc, c, opt_compress, slab, desc, st, lane);
+    // opt_copy_bit_block(.., opt_mode_, ..) (:1658): without opt_compress the block is copied as it is, empty or not
+    store_result_mode(acc, c, opt_compress ? ST_OPT : ST_FORCE_BIT, slab, desc, st, lane);
 }
 
 // ---------------------------------------------------------------------------
@@ -342,7 +344,7 @@ void k_agg_or_gap_tiled(const u64* const* __restrict__ descs, const u32* __restr
         if (full[tc]) { store_trivial(K_FULL, c, desc, st, lane); continue; }
         Blk b;
         blk_from_lds(b, lds_dyn + tc * 2048u, lane);
-        store_result(b, c, opt_compress, slab, desc, st, lane);
+        store_result_mode(b, c, opt_compress ? ST_OPT : ST_FORCE_BIT, slab, desc, st, lane);
     }
 }
 

@@ -50,8 +50,9 @@ for seed in range(400):
     t, _ = agg.combine_and_sub(gv[:na], gv[na:])
     e = port.agg_and_sub(pv[:na], pv[na:])
     if t.block_table()[0].tolist() != e.flatten()[0].tolist(): bad += 1; print("FAIL kinds and_sub", seed)
-    agg.set_optimization(True)
-    if agg.combine_or(gv).block_table()[0].tolist() != port.agg_or(pv, True).flatten()[0].tolist(): bad += 1; print("FAIL kinds or", seed)
+    for oc in (True, False):
+        agg.set_optimization(oc)
+        if agg.combine_or(gv).block_table()[0].tolist() != port.agg_or(pv, oc).flatten()[0].tolist(): bad += 1; print("FAIL kinds or", seed, oc)
     agg.set_optimization(False)
 print("soak done, failures:", bad)
 PY
