@@ -54,6 +54,32 @@ for seed in range(400):
         agg.set_optimization(oc)
         if agg.combine_or(gv).block_table()[0].tolist() != port.agg_or(pv, oc).flatten()[0].tolist(): bad += 1; print("FAIL kinds or", seed, oc)
     agg.set_optimization(False)
+    # pipeline with result vectors, counts and an OR target: presence, kinds and content of every result
+    groups = []
+    for _ in range(int(rng.integers(1, 5))):
+        a = [int(x) for x in rng.integers(0, nv, int(rng.integers(0, nv + 1)))]
+        s_ = [int(x) for x in rng.integers(0, nv, int(rng.integers(0, nv)))]
+        groups.append((a, s_))
+    pipe = bm.aggregator.pipeline(ctx, bm.agg_opt_bvect_and_counts)
+    pipe.set_or_target(None)
+    for a, s_ in groups:
+        ag = pipe.add()
+        for k in a: ag.add(gv[k], 0)
+        for k in s_: ag.add(gv[k], 1)
+    pipe.complete()
+    agg.combine_and_sub(pipe)
+    pres, pcnt, port_or = port.pipeline_results([([pv[k] for k in a], [pv[k] for k in s_]) for a, s_ in groups])
+    res = pipe.get_bv_res_vector()
+    nw = nblk * 2048
+    okp = [r is None for r in res] == [r is None for r in pres] and [int(x) for x in pipe.get_bv_count_vector()] == [int(x) for x in pcnt]
+    for r, e in zip(res, pres):
+        if r is not None and e is not None:
+            okp = okp and (r.to_words(nw) == e.to_words(nw)).all() and r.block_table()[0].tolist()[:nblk] == e.flatten()[0].tolist()[:nblk]
+    go = pipe.get_or_target()
+    gk = go.block_table()[0].tolist()[:nblk]; gk += [0] * (nblk - len(gk))     # (an untouched OR target has no blocks at all)
+    pk = port_or.flatten()[0].tolist()[:nblk]; pk += [0] * (nblk - len(pk))
+    okp = okp and (go.to_words(nw) == port_or.to_words(nw)).all() and gk == pk
+    if not okp: bad += 1; print("FAIL pipeline results", seed, groups)
 print("soak done, failures:", bad)
 PY
 timeout 1200 python /tmp/soak.py > gpurun_out/soak.log 2>&1; tail -6 gpurun_out/soak.log
