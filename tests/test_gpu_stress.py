@@ -217,3 +217,35 @@ def test_two_contexts_from_two_threads(port):
     for t in th: t.start()
     for t in th: t.join()
     assert not errors, errors
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_block_kinds_follow_reference(ctx, port, seed):
+    """REPRESENTATION parity on random block tables (tools/gpu_runs/soak.sh runs 400 of these): block kinds of the
+    pairwise ops in both opt modes (copied bit / GAP blocks, GAP x GAP, computed blocks), of combine_and_sub, of
+    combine_or with and without set_optimization, of pipeline results and the OR target, of shift-right-and.
+    The one documented difference: an all-ones GAP x GAP result is FULL here, a 1-run GAP block in the reference."""
+    rng = np.random.default_rng(70000 + seed)
+    nblk = int(rng.integers(1, 7)); nv = int(rng.integers(2, 7))
+    vecs = [_random_vector(rng, port, ctx, nblk, bool(rng.integers(0, 2))) for _ in range(nv)]
+    pv = [v[0] for v in vecs]; gv = [v[1] for v in vecs]
+    for p, g in zip(pv, gv):
+        assert g.block_table()[0].tolist() == p.flatten()[0].tolist()
+    agg = bm.aggregator(ctx)
+    for op in range(4):
+        i, j = (int(x) for x in rng.integers(0, nv, 2))
+        for oc in (True, False):
+            kk = bm.bvector._op2(op, gv[i], gv[j], bm.opt_compress if oc else bm.opt_none).block_table()[0].tolist()
+            ek = port.op2(op, pv[i], pv[j], oc).flatten()[0].tolist()
+            assert all(a == b or (a == bm.FULL and b == bm.GAP) for a, b in zip(kk, ek)), (op, oc, i, j, kk, ek)
+    na = int(rng.integers(1, nv + 1))
+    t, _ = agg.combine_and_sub(gv[:na], gv[na:])
+    assert t.block_table()[0].tolist() == port.agg_and_sub(pv[:na], pv[na:]).flatten()[0].tolist()
+    for oc in (True, False):
+        agg.set_optimization(oc)
+        assert agg.combine_or(gv).block_table()[0].tolist() == port.agg_or(pv, oc).flatten()[0].tolist(), oc
+        sel = [int(x) for x in rng.integers(0, nv, int(rng.integers(1, 12)))]
+        t, f = agg.combine_shift_right_and([gv[k] for k in sel])
+        e, ef = port.agg_shift_right_and([pv[k] for k in sel], oc, False)
+        assert f == ef and t.block_table()[0].tolist()[:nblk] == e.flatten()[0].tolist()[:nblk]
+    agg.set_optimization(False)
