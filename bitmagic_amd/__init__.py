@@ -38,7 +38,7 @@ BLOCK_WORDS, BLOCK_BITS = 2048, 65536
 opt_none, opt_compress = 0, 3        # bvector::optmode (src/bm.h:129-135)
 ID_MAX = 0xFFFFFFFF                  # bm::id_max (src/bmconst.h:109)
 
-__all__ = ["context", "bvector", "aggregator", "slice_scanner", "rs_index", "bit_import_u32", "count_and", "count_or",
+__all__ = ["context", "bvector", "aggregator", "slice_scanner", "rs_index", "group", "gbvector", "gaggregator", "gpipeline", "bit_import_u32", "count_and", "count_or",
            "count_xor", "count_sub", "BmxError", "simd_version", "device_count", "agg_run_options",
            "agg_opt_only_counts", "agg_opt_bvect_and_counts", "agg_opt_disable_bvects_and_counts"]
 
@@ -608,3 +608,216 @@ class slice_scanner:
             for q, sl in enumerate(slot):
                 if sl >= 0: out[q] = cnt[sl]
         return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# multi-GPU: device groups (include/bmx.h "device groups")
+# ---------------------------------------------------------------------------------------------------
+GROUP_HOST_SUM, GROUP_RCCL = 0, 1
+
+
+class group:
+    """n devices driven by one host thread (bmx_group): every vector is sharded by block range over the
+    members (column independence, src/bmaggregator.h:1184-1218), counts are summed on the host or by an
+    in-library RCCL all-reduce (flags=GROUP_RCCL).  A device may be listed several times."""
+
+    def __init__(self, devices: Sequence[int], flags: int = GROUP_HOST_SUM):
+        self._h = C.c_void_p()
+        arr = (C.c_int * len(devices))(*devices)
+        check(lib().bmx_group_create(arr, len(devices), flags, C.byref(self._h)))
+        self.devices = list(devices)
+
+    def close(self):
+        if self._h:
+            lib().bmx_group_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def size(self) -> int:
+        n = C.c_int()
+        check(lib().bmx_group_size(self._h, C.byref(n)))
+        return n.value
+
+    def shard_range(self, nblocks: int, member: int) -> tuple[int, int]:
+        lo, hi = C.c_uint32(), C.c_uint32()
+        check(lib().bmx_group_shard_range(self._h, nblocks, member, C.byref(lo), C.byref(hi)))
+        return lo.value, hi.value
+
+    def set_tuning(self, key: str, value: int):
+        for m in range(self.size()):
+            c = C.c_void_p()
+            check(lib().bmx_group_ctx(self._h, m, C.byref(c)))
+            check(lib().bmx_ctx_set_tuning(c, key.encode(), int(value)))
+
+
+class gbvector:
+    """bit-vector sharded by block range over the members of a group (bmx_gvec)"""
+
+    def __init__(self, grp: group, handle):
+        self.grp, self._h = grp, handle
+
+    def __del__(self):
+        try:
+            if self._h and self.grp._h:
+                lib().bmx_gvec_free(self.grp._h, self._h)
+            self._h = None
+        except Exception:
+            pass
+
+    @staticmethod
+    def from_block_table(grp: group, nbits: int, kinds, offs, bit_slab, gap_slab) -> "gbvector":
+        kinds = np.ascontiguousarray(kinds, np.uint8); offs = np.ascontiguousarray(offs, np.uint32)
+        bit_slab = np.ascontiguousarray(bit_slab, np.uint32); gap_slab = np.ascontiguousarray(gap_slab, np.uint16)
+        h = C.c_void_p()
+        check(lib().bmx_gvec_upload(grp._h, nbits, kinds.size, _ptr(kinds), _ptr(offs),
+                                    _ptr(bit_slab) if bit_slab.size else None, bit_slab.size // BLOCK_WORDS,
+                                    _ptr(gap_slab) if gap_slab.size else None, gap_slab.size, C.byref(h)))
+        return gbvector(grp, h)
+
+    @staticmethod
+    def generate(grp: group, seed: int, vec_id: int, density_q16: int, nbits: int,
+                 with_common: bool = False, optimize: bool = True) -> "gbvector":
+        h = C.c_void_p()
+        check(lib().bmx_gvec_generate(grp._h, seed, vec_id, int(with_common), density_q16, nbits, int(optimize), C.byref(h)))
+        return gbvector(grp, h)
+
+    def info(self):
+        nbits, nblocks, slab, gw = C.c_uint64(), C.c_uint32(), C.c_uint32(), C.c_uint64()
+        counts = (C.c_uint32 * 4)()
+        check(lib().bmx_gvec_info(self._h, C.byref(nbits), C.byref(nblocks), counts, C.byref(slab), C.byref(gw)))
+        return {"nbits": nbits.value, "nblocks": nblocks.value, "counts": list(counts),
+                "bit_slab_blocks": slab.value, "gap_words": gw.value}
+
+    def block_table(self):
+        i = self.info()
+        kinds = np.zeros(i["nblocks"], np.uint8); offs = np.zeros(i["nblocks"], np.uint32)
+        bit_slab = np.zeros(i["bit_slab_blocks"] * BLOCK_WORDS, np.uint32); gap_slab = np.zeros(i["gap_words"], np.uint16)
+        check(lib().bmx_gvec_download(self.grp._h, self._h, _ptr(kinds), _ptr(offs),
+                                      _ptr(bit_slab) if bit_slab.size else None, _ptr(gap_slab) if gap_slab.size else None))
+        return kinds, offs, bit_slab, gap_slab
+
+    def count(self) -> int:
+        c = C.c_uint64()
+        check(lib().bmx_gvec_count(self.grp._h, self._h, C.byref(c)))
+        return c.value
+
+    @staticmethod
+    def _op2(op, a: "gbvector", b: "gbvector", opt_mode: int = opt_none) -> "gbvector":
+        h = C.c_void_p()
+        check(lib().bmx_gvec_op2(a.grp._h, op, a._h, b._h, int(opt_mode == opt_compress), C.byref(h)))
+        return gbvector(a.grp, h)
+
+    @staticmethod
+    def bit_and(a, b, opt_mode=opt_none): return gbvector._op2(AND, a, b, opt_mode)
+    @staticmethod
+    def bit_or(a, b, opt_mode=opt_none): return gbvector._op2(OR, a, b, opt_mode)
+    @staticmethod
+    def bit_xor(a, b, opt_mode=opt_none): return gbvector._op2(XOR, a, b, opt_mode)
+    @staticmethod
+    def bit_sub(a, b, opt_mode=opt_none): return gbvector._op2(SUB, a, b, opt_mode)
+
+    @staticmethod
+    def count_op2(op, a: "gbvector", b: "gbvector") -> int:
+        c = C.c_uint64()
+        check(lib().bmx_gvec_count_op2(a.grp._h, op, a._h, b._h, C.byref(c)))
+        return c.value
+
+
+class gpipeline:
+    """aggregator::pipeline<agg_opt_only_counts> over sharded vectors (bmx_gpipeline)"""
+
+    def __init__(self, grp: group):
+        self.grp = grp
+        self.groups: list[arg_groups] = []
+        self._h = None
+        self._counts = None
+
+    def add(self) -> arg_groups:
+        if self._h:
+            raise RuntimeError("pipeline already complete()")
+        g = arg_groups()
+        self.groups.append(g)
+        return g
+
+    def size(self) -> int:
+        return len(self.groups)
+
+    def complete(self):
+        and_list = [v for g in self.groups for v in g.arg_bv0]
+        sub_list = [v for g in self.groups for v in g.arg_bv1]
+        and_n = (C.c_uint32 * max(len(self.groups), 1))(*[len(g.arg_bv0) for g in self.groups])
+        sub_n = (C.c_uint32 * max(len(self.groups), 1))(*[len(g.arg_bv1) for g in self.groups])
+        h = C.c_void_p()
+        check(lib().bmx_gpipeline_create(self.grp._h, _handles(and_list), and_n, _handles(sub_list), sub_n,
+                                         len(self.groups), C.byref(h)))
+        self._h = h
+
+    def is_complete(self) -> bool:
+        return self._h is not None
+
+    def get_bv_count_vector(self):
+        return self._counts
+
+    def last_ms(self) -> list:
+        ms = (C.c_float * self.grp.size())()
+        check(lib().bmx_gpipeline_last_ms(self.grp._h, self._h, ms))
+        return list(ms)
+
+    def __del__(self):
+        try:
+            if self._h and self.grp._h:
+                lib().bmx_gpipeline_destroy(self.grp._h, self._h)
+            self._h = None
+        except Exception:
+            pass
+
+
+class gaggregator:
+    """bm::aggregator over the sharded vectors of a group: same calls, n GPUs"""
+
+    pipeline = gpipeline
+
+    def __init__(self, grp: group):
+        self.grp = grp
+        self.ag = arg_groups()
+        self.opt_mode = False
+
+    def set_optimization(self, opt: bool = True):
+        self.opt_mode = bool(opt)
+
+    def add(self, bv: gbvector | None, agr_group: int = 0) -> int:
+        return self.ag.add(bv, agr_group)
+
+    def reset(self):
+        self.ag.reset()
+
+    def combine_or(self, bv_src=None) -> gbvector:
+        src = list(bv_src) if bv_src is not None else list(self.ag.arg_bv0)
+        self.ag.reset()
+        h = C.c_void_p()
+        check(lib().bmx_gagg_or(self.grp._h, _handles(src), len(src), int(self.opt_mode), C.byref(h)))
+        return gbvector(self.grp, h)
+
+    def combine_and(self, bv_src=None) -> gbvector:
+        src = list(bv_src) if bv_src is not None else self.ag.arg_bv0
+        return self.combine_and_sub(src, [])[0]
+
+    def combine_and_sub(self, bv_src_and=None, bv_src_sub=None):
+        if isinstance(bv_src_and, gpipeline):
+            pipe = bv_src_and
+            if not pipe.is_complete():
+                raise RuntimeError("pipeline is not complete()")
+            out = np.zeros(max(pipe.size(), 1), np.uint64)
+            check(lib().bmx_gpipeline_run_counts(self.grp._h, pipe._h, out.ctypes.data_as(C.POINTER(C.c_uint64))))
+            pipe._counts = out[:pipe.size()]
+            return pipe._counts
+        a = list(bv_src_and) if bv_src_and is not None else self.ag.arg_bv0
+        s = list(bv_src_sub) if bv_src_sub is not None else self.ag.arg_bv1
+        h, any_ = C.c_void_p(), C.c_int()
+        check(lib().bmx_gagg_and_sub(self.grp._h, _handles(a), len(a), _handles(s), len(s), C.byref(h), C.byref(any_)))
+        return gbvector(self.grp, h), bool(any_.value)

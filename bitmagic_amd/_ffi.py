@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libbmx.so")
+# BMX_LIB selects another build of the same ABI (the tuning build lib/libbmx_tune.so: extra launch shapes + diagnostics)
+LIB_PATH = os.environ.get("BMX_LIB") or os.path.join(_HERE, "lib", "libbmx.so")
 
 OK, ERR_BADALLOC, ERR_BADARG, ERR_RANGE, ERR_DEVICE = 0, 1, 2, 3, 4
 
@@ -84,7 +85,26 @@ def lib() -> C.CDLL:
         "bmx_select_batch": (i32, [vp, vp, vp, vp, C.c_size_t, vp, vp]),
         "bmx_rank_batch_dev": (i32, [vp, vp, vp, vp, C.c_size_t, vp]),
         "bmx_select_batch_dev": (i32, [vp, vp, vp, vp, C.c_size_t, vp, vp]),
-        "bmx_diag_stream_read": (i32, [vp, u64, i32, u32, i32, i32, P(C.c_float)]),
+        "bmx_group_create": (i32, [P(i32), i32, i32, P(vp)]),
+        "bmx_group_destroy": (i32, [vp]),
+        "bmx_group_size": (i32, [vp, P(i32)]),
+        "bmx_group_ctx": (i32, [vp, i32, P(vp)]),
+        "bmx_group_shard_range": (i32, [vp, u32, i32, P(u32), P(u32)]),
+        "bmx_gvec_upload": (i32, [vp, u64, u32, vp, vp, vp, u32, vp, u64, P(vp)]),
+        "bmx_gvec_generate": (i32, [vp, u64, u32, i32, u32, u64, i32, P(vp)]),
+        "bmx_gvec_free": (i32, [vp, vp]),
+        "bmx_gvec_info": (i32, [vp, P(u64), P(u32), P(u32), P(u32), P(u64)]),
+        "bmx_gvec_shard": (i32, [vp, i32, P(vp)]),
+        "bmx_gvec_download": (i32, [vp, vp, vp, vp, vp, vp]),
+        "bmx_gvec_count": (i32, [vp, vp, P(u64)]),
+        "bmx_gvec_count_op2": (i32, [vp, i32, vp, vp, P(u64)]),
+        "bmx_gvec_op2": (i32, [vp, i32, vp, vp, i32, P(vp)]),
+        "bmx_gagg_or": (i32, [vp, P(vp), C.c_size_t, i32, P(vp)]),
+        "bmx_gagg_and_sub": (i32, [vp, P(vp), C.c_size_t, P(vp), C.c_size_t, P(vp), P(i32)]),
+        "bmx_gpipeline_create": (i32, [vp, P(vp), P(u32), P(vp), P(u32), C.c_size_t, P(vp)]),
+        "bmx_gpipeline_destroy": (i32, [vp, vp]),
+        "bmx_gpipeline_run_counts": (i32, [vp, vp, P(u64)]),
+        "bmx_gpipeline_last_ms": (i32, [vp, vp, P(C.c_float)]),
         "bmx_timer_start": (i32, [vp]),
         "bmx_timer_stop_ms": (i32, [vp, P(C.c_float)]),
     }
@@ -98,6 +118,9 @@ def lib() -> C.CDLL:
         fn.restype, fn.argtypes = res, args
     if missing:
         raise ImportError(f"libbmx.so does not export: {', '.join(missing)}")
+    if hasattr(L, "bmx_diag_stream_read"):        # tuning build only (bitmagic_amd/csrc/bmx_diag.h)
+        L.bmx_diag_stream_read.restype = i32
+        L.bmx_diag_stream_read.argtypes = [vp, u64, i32, u32, i32, i32, P(C.c_float)]
     _lib = L
     return L
 

@@ -1,6 +1,9 @@
 // bmx.hip -- C-ABI (include/bmx.h) of the MI355X-native bit-vector engine.
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared bmx.hip -o libbmx.so
-#include "../../include/bmx.h"
+#include "bmx_internal.h"
+#ifdef BMX_DIAG
+#include "bmx_diag.h"
+#endif
 #include "bmx_kernels2.h"
 #include "bmx_kernels3.h"
 
@@ -19,78 +22,16 @@
 // ---------------------------------------------------------------------------
 static thread_local std::string g_last_error;
 
-static int fail_hip(hipError_t e, const char* what, int line)
+int bmx_fail_hip(hipError_t e, const char* what, const char* file, int line)
 {
     char buf[512];
-    snprintf(buf, sizeof(buf), "%s failed at bmx.hip:%d: %s", what, line, hipGetErrorString(e));
+    const char* base = strrchr(file, '/');
+    snprintf(buf, sizeof(buf), "%s failed at %s:%d: %s", what, base ? base + 1 : file, line, hipGetErrorString(e));
     g_last_error = buf;
     return e == hipErrorOutOfMemory ? BMX_ERR_BADALLOC : BMX_ERR_DEVICE;
 }
-#define HIPCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail_hip(e_, #call, __LINE__); } while (0)
-#define ARGCHK(cond) do { if (!(cond)) { g_last_error = "bad argument: " #cond; return BMX_ERR_BADARG; } } while (0)
-#define KCHK() HIPCHK(hipGetLastError())
-
-struct bmx_ctx {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    bool own_stream = false;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    uint64_t mem_used = 0;
-    // grow-only scratch
-    void* scratch = nullptr; size_t scratch_bytes = 0;      // raw block slab for import/generate
-    void* aux = nullptr; size_t aux_bytes = 0;              // stats / offsets / totals
-    u64* d_small = nullptr;                                 // 64 x u64 result words
-    u64* d_slots = nullptr;                                 // COUNT_SLOTS striped count accumulators (kept zero between launches)
-    u64* h_small = nullptr;                                 // pinned mirror
-    // caching device allocator: results of same-shaped operations re-use their blocks instead of
-    // paying hipMalloc / hipFree (which synchronises the device) on every call
-    std::multimap<size_t, void*> pool_free;
-    std::unordered_map<void*, size_t> pool_live;
-    uint64_t pool_cached = 0, pool_cap = 16ull << 30;
-    int pipe_unroll = 4;       // operand blocks per batch (two batches in flight in the v2 kernel)
-    int pipe_rows = 8;         // register rows per work item (8 = whole block, 4/2/1 = slices)
-    int pipe_nt = 1;           // non-temporal operand loads (+4.5 % on the streamed-once headline case)
-    int pipe_wg = 384;         // workgroup size of the bit-only counts kernel: 6 adjacent columns per workgroup, 2 workgroups per CU
-                               // (+6 % over 256 in the A/B sweep: co-scheduled waves read one contiguous stretch of each operand)
-    int pipe_ver = 2;          // 1 = k_pipe_counts_bits, 2 = software-pipelined k_pipe_counts_bits2
-    int pipe_staged = -1;      // LDS-staged many-groups kernel: -1 auto, 0 never, 1 whenever possible
-    int pipe_lds = 0;          // experiment: dynamic LDS bytes requested by the bit-only counts kernel (occupancy throttle)
-    int pipe_slots = 16;       // plane blocks staged at a time (16: 1024-thread WG; 8: two 512-thread WGs per CU)
-    int xcd_swz = 1;
-};
-
-struct bmx_vec {
-    bmx_ctx* ctx;
-    uint64_t nbits; uint32_t nblocks;
-    uint32_t counts[4]; uint64_t gap_words; uint32_t n_bit;
-    u64* d_desc; uint4* d_bits; u16* d_gaps;
-    size_t bytes;
-};
-
-struct bmx_pipeline {
-    bmx_ctx* ctx;
-    uint32_t ngroups, ncols, col_stride, n_ops;
-    bool has_gap;
-    uint64_t nbits;                       // max size of the operands
-    // LDS-staged path (k_pipe_counts_staged): distinct vectors ("planes") + per-group plane masks
-    uint32_t nplanes, nchunks; bool staged_ok;
-    const u64** d_udesc; u32* d_unblk; u32* d_gmask; u32* d_gskip;
-    std::vector<u32>* h_row_off;          // host copy: row offset of each group inside a column record
-    std::vector<u32>* h_and_n;            // host copy: AND operands per group
-    u64* d_dmat;
-    u32* d_meta;       // row_off | and_n | sub_n | and_off | sub_off (ngroups each) | nblocks (n_ops)
-    const u64** d_descs;
-    size_t bytes;
-};
-
-struct bmx_rs {
-    bmx_ctx* ctx;
-    uint32_t nblocks; uint64_t count;
-    u32* d_bcount; u64* d_sub; u64* d_rcount; u16* d_cum;
-    u16* d_gidx;                                          // GAP blocks: first run reaching each 1024-bit wave
-    u64* d_sample; uint32_t nsamples, sample_shift;       // top level of the select search (<= 2048 entries)
-    size_t bytes;
-};
+void bmx_set_last_error(const char* msg) { g_last_error = msg ? msg : ""; }
+static int fail_hip(hipError_t e, const char* what, int line) { return bmx_fail_hip(e, what, "bmx.hip", line); }
 
 static int set_dev(const bmx_ctx* ctx) { HIPCHK(hipSetDevice(ctx->device)); return BMX_OK; }
 
@@ -153,6 +94,59 @@ static int ensure(bmx_ctx* ctx, void** buf, size_t* cur, size_t need)
     return BMX_OK;
 }
 
+// ---- launch shapes of the bit-only counts kernel --------------------------------------------------
+typedef void (*pipe_bits_fn)(const u64*, const u32*, const u32*, u32, u32, u32, u32, int, u64*);
+
+// Slice size by the number of (column, group) items of the run: whole blocks when the chip already gets
+// >= ~12 k waves (the 15,259-column headline), smaller slices for a block-range shard of a multi-GPU job or a
+// short collection, so that every run has >= ~12 k independent waves to hide the HBM latency with.
+static u32 pipe_rows_auto(u64 nitems)
+{
+    if (nitems >= 12000u) return 8u;
+    if (nitems >= 6000u) return 4u;
+    if (nitems >= 3000u) return 2u;
+    return 1u;
+}
+static u32 pipe_unroll_default(u32 rows) { return rows == 8u ? 4u : rows == 4u ? 4u : 8u; }
+
+template <int ROWS>
+static pipe_bits_fn pipe_bits_rows(u32 unroll, bool nt, u32 wg)
+{
+#define B2(U, NT, WG) (pipe_bits_fn)k_pipe_counts_bits2<U, NT, WG, ROWS>
+    if (wg == 384 && nt) {
+        if (unroll == 4) return B2(4, true, 384);
+        if constexpr (ROWS <= 4) { if (unroll == 8) return B2(8, true, 384); }
+        if constexpr (ROWS <= 2) { if (unroll == 16) return B2(16, true, 384); }
+    }
+    if (wg == 384 && !nt && unroll == 4) return B2(4, false, 384);
+    if (wg == 256 && nt) {
+        if (unroll == 4) return B2(4, true, 256);
+        if constexpr (ROWS <= 4) { if (unroll == 8) return B2(8, true, 256); }
+    }
+#ifdef BMX_TUNE   // shapes of the tuning sweeps (tools/tune_pipe.py): make -C bitmagic_amd/csrc tune
+    if constexpr (ROWS == 8) {
+        if (nt && unroll == 4) switch (wg) { case 192: return B2(4, true, 192); case 320: return B2(4, true, 320); case 448: return B2(4, true, 448);
+                                             case 512: return B2(4, true, 512); case 576: return B2(4, true, 576); case 640: return B2(4, true, 640);
+                                             case 768: return B2(4, true, 768); default: break; }
+        if (nt && unroll == 2) switch (wg) { case 256: return B2(2, true, 256); case 384: return B2(2, true, 384); case 1024: return B2(2, true, 1024); default: break; }
+        if (nt && unroll == 1 && wg == 256) return B2(1, true, 256);
+        if (!nt && unroll == 4 && wg == 256) return B2(4, false, 256);
+    }
+#endif
+#undef B2
+    return nullptr;
+}
+static pipe_bits_fn pipe_bits_kernel(u32 rows, u32 unroll, bool nt, u32 wg)
+{
+    switch (rows) {
+    case 8: return pipe_bits_rows<8>(unroll, nt, wg);
+    case 4: return pipe_bits_rows<4>(unroll, nt, wg);
+    case 2: return pipe_bits_rows<2>(unroll, nt, wg);
+    case 1: return pipe_bits_rows<1>(unroll, nt, wg);
+    default: return nullptr;
+    }
+}
+
 extern "C" {
 
 const char* bmx_error_msg(int status)
@@ -198,13 +192,15 @@ int bmx_ctx_create(int device, void* stream, bmx_ctx** out)
     CTXCHK(hipMalloc((void**)&ctx->d_slots, COUNT_SLOTS * COUNT_SLOT_STRIDE * sizeof(u64)));
     CTXCHK(hipMemsetAsync(ctx->d_slots, 0, COUNT_SLOTS * COUNT_SLOT_STRIDE * sizeof(u64), ctx->stream));
 #undef CTXCHK
-    if (const char* e = getenv("BMX_POOL_MAX_MB")) ctx->pool_cap = (uint64_t)atoll(e) << 20;
-    if (const char* e = getenv("BMX_PIPE_UNROLL")) ctx->pipe_unroll = atoi(e);
-    if (const char* e = getenv("BMX_PIPE_ROWS")) ctx->pipe_rows = atoi(e);
-    if (const char* e = getenv("BMX_PIPE_NT")) ctx->pipe_nt = atoi(e);
-    if (const char* e = getenv("BMX_PIPE_VER")) ctx->pipe_ver = atoi(e);
-    if (const char* e = getenv("BMX_PIPE_WG")) ctx->pipe_wg = atoi(e);
-    if (const char* e = getenv("BMX_XCD_SWIZZLE")) ctx->xcd_swz = atoi(e);
+    if (const char* e = getenv("BMX_POOL_MAX_MB")) { long long mb = atoll(e); if (mb >= 0) ctx->pool_cap = (uint64_t)mb << 20; }
+    // launch-shape knobs from the environment go through the same validation as bmx_ctx_set_tuning;
+    // an invalid value is ignored (the default stays)
+    static const char* const env_keys[][2] = {
+        {"BMX_PIPE_UNROLL", "pipe_unroll"}, {"BMX_PIPE_ROWS", "pipe_rows"}, {"BMX_PIPE_NT", "pipe_nt"},
+        {"BMX_PIPE_WG", "pipe_wg"}, {"BMX_PIPE_SPLIT", "pipe_split"}, {"BMX_OR_TILE", "or_tile"}, {"BMX_XCD_SWIZZLE", "xcd_swizzle"}};
+    for (auto& kv : env_keys)
+        if (const char* e = getenv(kv[0])) (void)bmx_ctx_set_tuning(ctx, kv[1], atoi(e));
+    g_last_error.clear();
     *out = ctx;
     return BMX_OK;
 }
@@ -215,6 +211,9 @@ int bmx_ctx_destroy(bmx_ctx* ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     pool_trim(ctx);
+    // vectors / pipelines the caller never freed: their handles die with the context, the device memory must not leak
+    for (auto& kv : ctx->pool_live) (void)hipFree(kv.first);
+    ctx->pool_live.clear();
     if (ctx->scratch) (void)hipFree(ctx->scratch);
     if (ctx->aux) (void)hipFree(ctx->aux);
     if (ctx->d_small) (void)hipFree(ctx->d_small);
@@ -231,19 +230,21 @@ int bmx_ctx_set_tuning(bmx_ctx* ctx, const char* key, int value)
 {
     ARGCHK(ctx && key);
     std::string k(key);
-    if (k == "pipe_unroll") { ARGCHK(value == 1 || value == 2 || value == 4); ctx->pipe_unroll = value; }
-    else if (k == "pipe_rows") { ARGCHK(value == 8 || value == 4 || value == 2 || value == 1); ctx->pipe_rows = value; }
+    if (k == "pipe_unroll") { ARGCHK(value == 0 || value == 1 || value == 2 || value == 4 || value == 8 || value == 16); ctx->pipe_unroll = value; }
+    else if (k == "pipe_rows") { ARGCHK(value == 0 || value == 8 || value == 4 || value == 2 || value == 1); ctx->pipe_rows = value; }
     else if (k == "pipe_nt") ctx->pipe_nt = value != 0;
     else if (k == "pipe_lds") { ARGCHK(value >= 0 && value <= 160 * 1024); ctx->pipe_lds = value; }
     else if (k == "pipe_slots") { ARGCHK(value == 8 || value == 16); ctx->pipe_slots = value; }
     else if (k == "pipe_staged") { ARGCHK(value >= -1 && value <= 1); ctx->pipe_staged = value; }
-    else if (k == "pipe_ver") { ARGCHK(value == 1 || value == 2); ctx->pipe_ver = value; }
+    else if (k == "pipe_split") { ARGCHK(value >= -1 && value <= 1); ctx->pipe_split = value; }
+    else if (k == "or_tile") { ARGCHK(value >= 0 && value <= 3); ctx->or_tile = value; }
     else if (k == "pipe_wg") { ARGCHK(value >= 64 && value <= 1024 && value % 64 == 0); ctx->pipe_wg = value; }
     else if (k == "xcd_swizzle") ctx->xcd_swz = value != 0;
     else { g_last_error = "unknown tuning key"; return BMX_ERR_BADARG; }
     return BMX_OK;
 }
 
+#ifdef BMX_DIAG
 int bmx_diag_stream_read(bmx_ctx* ctx, uint64_t bytes, int nt, uint32_t blocks_per_wave, int pattern, int iters, float* ms_per_pass)
 {
     ARGCHK(ctx && ms_per_pass && bytes >= 8192 && blocks_per_wave >= 1 && iters >= 1);
@@ -273,6 +274,8 @@ int bmx_diag_stream_read(bmx_ctx* ctx, uint64_t bytes, int nt, uint32_t blocks_p
     *ms_per_pass = ms / iters;
     return BMX_OK;
 }
+
+#endif  // BMX_DIAG
 
 int bmx_ctx_synchronize(bmx_ctx* ctx)
 {
@@ -339,7 +342,7 @@ int bmx_vec_free(bmx_ctx* ctx, bmx_vec* v)
     ARGCHK(ctx && v->ctx == ctx);
     int rc = set_dev(ctx); if (rc) return rc;
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    dfree(ctx, v->d_desc); dfree(ctx, v->d_bits); dfree(ctx, v->d_gaps);
+    dfree(ctx, v->d_desc); dfree(ctx, v->d_bits); dfree(ctx, v->d_gaps); dfree(ctx, v->d_ord);
     delete v;
     return BMX_OK;
 }
@@ -354,36 +357,62 @@ int bmx_vec_upload(bmx_ctx* ctx, uint64_t nbits, uint32_t nblocks,
     ARGCHK(gap_words == 0 || gap_slab);
     *out = nullptr;
     int rc = set_dev(ctx); if (rc) return rc;
-    // validate + re-pack the GAP slab so that every block starts 16-byte aligned on the device
-    std::vector<u16> gpad;
-    std::vector<u64> goff(std::max<uint32_t>(nblocks, 1), 0);
+    // Host work is O(nblocks): kinds / offsets / GAP headers.  The two slabs are handed to the copy engine as
+    // they are (for a freeze()d vector that is the arena memory itself: no per-block host copy of bit OR GAP
+    // blocks); GAP blocks are re-packed onto 16-byte boundaries and validated (terminator, strictly ascending
+    // run ends) by k_gap_repack on the device.
+    std::vector<u64> desc(std::max<uint32_t>(nblocks, 1), 0);
+    std::vector<u32> gsrc;                                     // per block: source word offset of a GAP block (others: 0)
+    uint32_t counts[4] = {0, 0, 0, 0};
+    uint64_t gpad_words = 0; bool any_gap = false;
     for (uint32_t nb = 0; nb < nblocks; ++nb) {
-        if (kinds[nb] > BMX_GAP) { g_last_error = "bad block kind"; return BMX_ERR_BADARG; }
-        if (kinds[nb] == BMX_BIT && offs[nb] >= n_bit_blocks) { g_last_error = "bit-block offset out of range"; return BMX_ERR_RANGE; }
-        if (kinds[nb] != BMX_GAP) continue;
+        uint8_t k = kinds[nb];
+        if (k > BMX_GAP) { g_last_error = "bad block kind"; return BMX_ERR_BADARG; }
+        counts[k]++;
+        if (k == BMX_BIT && offs[nb] >= n_bit_blocks) { g_last_error = "bit-block offset out of range"; return BMX_ERR_RANGE; }
+        if (k != BMX_GAP) continue;
         uint64_t o = offs[nb];
         if (o >= gap_words) { g_last_error = "GAP offset out of range"; return BMX_ERR_RANGE; }
         uint32_t len = gap_slab[o] >> 3;
-        if (len == 0 || len > 1280u + 8u || o + len + 1u > gap_words || gap_slab[o + len] != 65535u) { g_last_error = "malformed GAP block"; return BMX_ERR_RANGE; }
-        goff[nb] = gpad.size();
-        gpad.insert(gpad.end(), gap_slab + o, gap_slab + o + len + 1u);
-        gpad.resize((gpad.size() + 7u) & ~(size_t)7u, 0);
+        // len <= 1279 = capacity of the top GAP level (glen(3) = 1280 words incl. the header, src/bmconst.h:81-87)
+        if (len == 0 || len > 1279u || o + len + 1u > gap_words) { g_last_error = "malformed GAP block (length)"; return BMX_ERR_RANGE; }
+        if (!any_gap) { gsrc.assign(nblocks, 0); any_gap = true; }
+        gsrc[nb] = (u32)o;
+        desc[nb] = gpad_words;                                 // destination word offset, turned into a descriptor below
+        gpad_words += ((uint64_t)len + 1u + 7u) & ~7ull;
     }
     bmx_vec* v = vec_alloc_host(ctx, nbits, nblocks);
     if (!v) return BMX_ERR_BADALLOC;
-    if ((rc = vec_alloc_device(v, n_bit_blocks, gpad.size()))) { bmx_vec_free(ctx, v); return rc; }
-    std::vector<u64> desc(std::max<uint32_t>(nblocks, 1), 0);
+#define UPCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { int r_ = fail_hip(e_, #call, __LINE__); bmx_vec_free(ctx, v); return r_; } } while (0)
+    if ((rc = vec_alloc_device(v, n_bit_blocks, gpad_words))) { bmx_vec_free(ctx, v); return rc; }
+    memcpy(v->counts, counts, sizeof(counts));
     for (uint32_t nb = 0; nb < nblocks; ++nb) {
         uint8_t k = kinds[nb];
-        v->counts[k]++;
         if (k == BMX_BIT) desc[nb] = DESC_MAKE(v->d_bits + (size_t)offs[nb] * 512u, K_BIT);
-        else if (k == BMX_GAP) desc[nb] = DESC_MAKE_GAP(v->d_gaps + goff[nb], gpad[goff[nb]] >> 3, gpad[goff[nb]] & 1u);
+        else if (k == BMX_GAP) { u16 h = gap_slab[offs[nb]]; desc[nb] = DESC_MAKE_GAP(v->d_gaps + desc[nb], h >> 3, h & 1u); }
         else desc[nb] = DESC_MAKE(0, k);
     }
-    HIPCHK(hipMemcpyAsync(v->d_desc, desc.data(), (size_t)nblocks * 8, hipMemcpyHostToDevice, ctx->stream));
-    if (n_bit_blocks) HIPCHK(hipMemcpyAsync(v->d_bits, bit_slab, (size_t)n_bit_blocks * 8192, hipMemcpyHostToDevice, ctx->stream));
-    if (!gpad.empty()) HIPCHK(hipMemcpyAsync(v->d_gaps, gpad.data(), gpad.size() * 2, hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (nblocks) UPCHK(hipMemcpyAsync(v->d_desc, desc.data(), (size_t)nblocks * 8, hipMemcpyHostToDevice, ctx->stream));
+    if (n_bit_blocks) UPCHK(hipMemcpyAsync(v->d_bits, bit_slab, (size_t)n_bit_blocks * 8192, hipMemcpyHostToDevice, ctx->stream));
+    if (any_gap) {
+        size_t raw_bytes = ((size_t)gap_words * 2 + 15u) & ~(size_t)15u, src_bytes = (size_t)nblocks * 4;
+        if ((rc = ensure(ctx, &ctx->scratch, &ctx->scratch_bytes, raw_bytes + src_bytes))) { bmx_vec_free(ctx, v); return rc; }
+        u16* d_raw = (u16*)ctx->scratch; u32* d_src = (u32*)((char*)ctx->scratch + raw_bytes);
+        UPCHK(hipMemcpyAsync(d_raw, gap_slab, (size_t)gap_words * 2, hipMemcpyHostToDevice, ctx->stream));
+        UPCHK(hipMemcpyAsync(d_src, gsrc.data(), src_bytes, hipMemcpyHostToDevice, ctx->stream));
+        UPCHK(hipMemsetAsync(ctx->d_small, 0, 8, ctx->stream));
+        hipLaunchKernelGGL(k_gap_repack, dim3((nblocks + 3) / 4), dim3(256), 0, ctx->stream,
+                           (const u16*)d_raw, (const u32*)d_src, (const u64*)v->d_desc, nblocks, ctx->d_small);
+        UPCHK(hipGetLastError());
+        UPCHK(hipMemcpyAsync(ctx->h_small, ctx->d_small, 8, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    UPCHK(hipStreamSynchronize(ctx->stream));
+#undef UPCHK
+    if (any_gap && ctx->h_small[0]) {
+        bmx_vec_free(ctx, v);
+        g_last_error = "malformed GAP block (terminator / run ends not strictly ascending)";
+        return BMX_ERR_RANGE;
+    }
     *out = v;
     return BMX_OK;
 }
@@ -399,13 +428,14 @@ static int vec_from_raw(bmx_ctx* ctx, uint64_t nbits, uint32_t nblocks, int opti
     const uint4* raw = (const uint4*)ctx->scratch;
     bmx_vec* v = vec_alloc_host(ctx, nbits, nblocks);
     if (!v) return BMX_ERR_BADALLOC;
+#define RAWCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { int r_ = fail_hip(e_, #call, __LINE__); bmx_vec_free(ctx, v); return r_; } } while (0)
     if (nblocks) {
         hipLaunchKernelGGL(k_block_stats, dim3((nblocks + 3) / 4), dim3(256), 0, ctx->stream, raw, nblocks, optimize, st);
-        KCHK();
+        RAWCHK(hipGetLastError());
         hipLaunchKernelGGL(k_scan_layout, dim3(1), dim3(1024), 0, ctx->stream, st, nblocks, offs, ctx->d_small);
-        KCHK();
-        HIPCHK(hipMemcpyAsync(ctx->h_small, ctx->d_small, 6 * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(hipStreamSynchronize(ctx->stream));
+        RAWCHK(hipGetLastError());
+        RAWCHK(hipMemcpyAsync(ctx->h_small, ctx->d_small, 6 * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
+        RAWCHK(hipStreamSynchronize(ctx->stream));
     } else memset(ctx->h_small, 0, 6 * sizeof(u64));
     uint32_t n_bit = (uint32_t)ctx->h_small[0]; uint64_t gap_words = ctx->h_small[1];
     for (int k = 0; k < 4; ++k) v->counts[k] = (uint32_t)ctx->h_small[2 + k];
@@ -413,9 +443,10 @@ static int vec_from_raw(bmx_ctx* ctx, uint64_t nbits, uint32_t nblocks, int opti
     if (nblocks) {
         hipLaunchKernelGGL(k_emit_blocks, dim3((nblocks + 3) / 4), dim3(256), 0, ctx->stream,
                            raw, nblocks, st, offs, v->d_bits, v->d_gaps, v->d_desc);
-        KCHK();
-        HIPCHK(hipStreamSynchronize(ctx->stream));
+        RAWCHK(hipGetLastError());
+        RAWCHK(hipStreamSynchronize(ctx->stream));
     }
+#undef RAWCHK
     *out = v;
     return BMX_OK;
 }
@@ -475,7 +506,7 @@ int bmx_vec_info(const bmx_vec* v, uint64_t* nbits, uint32_t* nblocks, uint32_t 
     if (nbits) *nbits = v->nbits;
     if (nblocks) *nblocks = v->nblocks;
     if (counts) memcpy(counts, v->counts, sizeof(v->counts));
-    if (bit_slab_blocks) *bit_slab_blocks = v->n_bit;
+    if (bit_slab_blocks) *bit_slab_blocks = v->d_ord ? v->counts[BMX_BIT] : v->n_bit;   // a slab with unused slots is gathered on download
     if (gap_words) *gap_words = v->gap_words;
     return BMX_OK;
 }
@@ -487,19 +518,33 @@ int bmx_vec_download(bmx_ctx* ctx, const bmx_vec* v, uint8_t* kinds, uint32_t* o
     int rc = set_dev(ctx); if (rc) return rc;
     if (kinds || offs) {
         std::vector<u64> desc(std::max<uint32_t>(v->nblocks, 1));
+        std::vector<u32> ord;
         HIPCHK(hipMemcpyAsync(desc.data(), v->d_desc, (size_t)v->nblocks * 8, hipMemcpyDeviceToHost, ctx->stream));
+        if (offs && v->d_ord && v->nblocks) {
+            ord.resize(v->nblocks);
+            HIPCHK(hipMemcpyAsync(ord.data(), v->d_ord, (size_t)v->nblocks * 4, hipMemcpyDeviceToHost, ctx->stream));
+        }
         HIPCHK(hipStreamSynchronize(ctx->stream));
         for (uint32_t nb = 0; nb < v->nblocks; ++nb) {
             u32 k = DESC_K(desc[nb]);
             if (kinds) kinds[nb] = (uint8_t)k;
             if (offs) {
-                if (k == K_BIT) offs[nb] = (uint32_t)((DESC_P(desc[nb]) - (u64)(uintptr_t)v->d_bits) / 8192u);
+                if (k == K_BIT) offs[nb] = v->d_ord ? ord[nb] : (uint32_t)((DESC_P(desc[nb]) - (u64)(uintptr_t)v->d_bits) / 8192u);
                 else if (k == K_GAP) offs[nb] = (uint32_t)((DESC_P(desc[nb]) - (u64)(uintptr_t)v->d_gaps) / 2u);
                 else offs[nb] = 0;
             }
         }
     }
-    if (bit_slab && v->n_bit) HIPCHK(hipMemcpyAsync(bit_slab, v->d_bits, (size_t)v->n_bit * 8192, hipMemcpyDeviceToHost, ctx->stream));
+    if (bit_slab && v->d_ord && v->counts[BMX_BIT]) {
+        // result slab with unused slots: only the live blocks cross PCIe, gathered into their ordinals first
+        size_t bytes = (size_t)v->counts[BMX_BIT] * 8192;
+        if ((rc = ensure(ctx, &ctx->scratch, &ctx->scratch_bytes, bytes))) return rc;
+        hipLaunchKernelGGL(k_gather_bits, dim3((v->nblocks + 3) / 4), dim3(256), 0, ctx->stream,
+                           (const u64*)v->d_desc, (const u32*)v->d_ord, v->nblocks, (uint4*)ctx->scratch);
+        KCHK();
+        HIPCHK(hipMemcpyAsync(bit_slab, ctx->scratch, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    } else if (bit_slab && v->n_bit && v->d_bits)
+        HIPCHK(hipMemcpyAsync(bit_slab, v->d_bits, (size_t)v->n_bit * 8192, hipMemcpyDeviceToHost, ctx->stream));
     if (gap_slab && v->gap_words) HIPCHK(hipMemcpyAsync(gap_slab, v->d_gaps, (size_t)v->gap_words * 2, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return BMX_OK;
@@ -520,17 +565,28 @@ int bmx_vec_to_words(bmx_ctx* ctx, const bmx_vec* v, uint32_t* words, uint64_t n
     return BMX_OK;
 }
 
-int bmx_count(bmx_ctx* ctx, const bmx_vec* a, uint64_t* count)
+} // extern "C"
+
+int bmx_i_count_async(bmx_ctx* ctx, const bmx_vec* a, int slot)
 {
-    ARGCHK(ctx && a && count && a->ctx == ctx);
+    ARGCHK(ctx && a && a->ctx == ctx && slot >= 0 && slot < 64);
     int rc = set_dev(ctx); if (rc) return rc;
     if (a->nblocks) {
         hipLaunchKernelGGL(k_vec_count, dim3((a->nblocks + 3) / 4), dim3(256), 0, ctx->stream, a->d_desc, a->nblocks, ctx->d_slots);
         KCHK();
     }
-    hipLaunchKernelGGL(k_sum_slots, dim3(1), dim3(64), 0, ctx->stream, ctx->d_slots, ctx->d_small);
+    hipLaunchKernelGGL(k_sum_slots, dim3(1), dim3(64), 0, ctx->stream, ctx->d_slots, ctx->d_small + slot);
     KCHK();
-    HIPCHK(hipMemcpyAsync(ctx->h_small, ctx->d_small, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipMemcpyAsync(ctx->h_small + slot, ctx->d_small + slot, 8, hipMemcpyDeviceToHost, ctx->stream));
+    return BMX_OK;
+}
+
+extern "C" {
+
+int bmx_count(bmx_ctx* ctx, const bmx_vec* a, uint64_t* count)
+{
+    ARGCHK(ctx && a && count && a->ctx == ctx);
+    int rc = bmx_i_count_async(ctx, a, 0); if (rc) return rc;
     HIPCHK(hipStreamSynchronize(ctx->stream));
     *count = ctx->h_small[0];
     return BMX_OK;
@@ -558,6 +614,8 @@ int bmx_pipeline_create(bmx_ctx* ctx, const bmx_vec* const* and_list, const uint
     std::vector<u32> meta(5 * ngroups + std::max<size_t>(n_ops, 1), 0);
     u32* row_off = meta.data(); u32* m_and_n = row_off + ngroups; u32* m_sub_n = m_and_n + ngroups;
     u32* and_off = m_sub_n + ngroups; u32* sub_off = and_off + ngroups; u32* nblk = sub_off + ngroups;
+    // row offsets / operand offsets are 32-bit on the device: refuse what does not fit instead of wrapping
+    if (n_ops > 0xFFFFFFF0ull || 2ull * ngroups + n_ops > 0xFFFFFFF0ull) { g_last_error = "pipeline too large: operand count exceeds 32 bits"; return BMX_ERR_RANGE; }
     uint32_t ncols = 0, col_stride = 0; bool has_gap = false; uint64_t max_bits = 0;
     size_t ia = 0, is = 0;
     for (size_t g = 0; g < ngroups; ++g) {
@@ -693,44 +751,18 @@ int bmx_pipeline_run_counts_dev(bmx_ctx* ctx, bmx_pipeline* p, uint32_t nb_from,
     }
     if (!p->has_gap) {
         // bit-block-only fast path: (column, group, slice) items
-        u32 rows = (u32)ctx->pipe_rows, parts = 8u / rows;
+        u32 rows = (u32)ctx->pipe_rows;
+        if (!rows) rows = pipe_rows_auto(nitems64);
+        u32 parts = 8u / rows;
         u64 n64 = nitems64 * parts;
         if (n64 > 0xFFFFFFF0ull) { g_last_error = "too many work items in one run"; return BMX_ERR_RANGE; }
-        if (ctx->pipe_ver == 2) {
-            u32 nitems = (u32)nitems64, wpb = (u32)ctx->pipe_wg / 64u, grid = (nitems + wpb - 1) / wpb;
-#define LAUNCH_B2(U, NT, WG) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pipe_counts_bits2<U, NT, WG>), dim3(grid), dim3(ctx->pipe_wg), (size_t)ctx->pipe_lds, ctx->stream, \
-        p->d_dmat, row_off, and_n, p->col_stride, p->ngroups, nb_from, nitems, ctx->xcd_swz, (u64*)d_counts)
-            if (ctx->pipe_wg == 1024) { if (ctx->pipe_nt) LAUNCH_B2(2, true, 1024); else LAUNCH_B2(2, false, 1024); }   // 128 VGPRs max
-            else if (ctx->pipe_wg == 768) { if (ctx->pipe_nt) LAUNCH_B2(4, true, 768); else LAUNCH_B2(4, false, 768); }
-            else if (ctx->pipe_wg == 640) { if (ctx->pipe_nt) LAUNCH_B2(4, true, 640); else LAUNCH_B2(4, false, 640); }
-            else if (ctx->pipe_wg == 576) { if (ctx->pipe_nt) LAUNCH_B2(4, true, 576); else LAUNCH_B2(4, false, 576); }
-            else if (ctx->pipe_wg == 448) { if (ctx->pipe_nt) LAUNCH_B2(4, true, 448); else LAUNCH_B2(4, false, 448); }
-            else if (ctx->pipe_wg == 384) { if (ctx->pipe_nt) LAUNCH_B2(4, true, 384); else LAUNCH_B2(4, false, 384); }
-            else if (ctx->pipe_wg == 320) { if (ctx->pipe_nt) LAUNCH_B2(4, true, 320); else LAUNCH_B2(4, false, 320); }
-            else if (ctx->pipe_wg == 192) { if (ctx->pipe_nt) LAUNCH_B2(4, true, 192); else LAUNCH_B2(4, false, 192); }
-            else if (ctx->pipe_wg == 512) {
-                if (ctx->pipe_nt) { switch (ctx->pipe_unroll) { case 1: LAUNCH_B2(1, true, 512); break; case 4: LAUNCH_B2(4, true, 512); break; default: LAUNCH_B2(2, true, 512); break; } }
-                else { switch (ctx->pipe_unroll) { case 1: LAUNCH_B2(1, false, 512); break; case 4: LAUNCH_B2(4, false, 512); break; default: LAUNCH_B2(2, false, 512); break; } }
-            }
-            else if (ctx->pipe_wg > 256) { g_last_error = "unsupported pipe_wg"; return BMX_ERR_BADARG; }
-            else if (ctx->pipe_nt) { switch (ctx->pipe_unroll) { case 1: LAUNCH_B2(1, true, 256); break; case 4: LAUNCH_B2(4, true, 256); break; default: LAUNCH_B2(2, true, 256); break; } }
-            else { switch (ctx->pipe_unroll) { case 1: LAUNCH_B2(1, false, 256); break; case 4: LAUNCH_B2(4, false, 256); break; default: LAUNCH_B2(2, false, 256); break; } }
-#undef LAUNCH_B2
-            KCHK();
-            return BMX_OK;
-        }
-        u32 wg1 = ctx->pipe_wg > 256 ? 256u : (u32)ctx->pipe_wg;          // v1 kernels are compiled for <= 256 threads
-        u32 nitems = (u32)n64, wpb = wg1 / 64u, grid = (nitems + wpb - 1) / wpb;
-#define LAUNCH_BITS(U, R, NT) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pipe_counts_bits<U, R, NT>), dim3(grid), dim3(wg1), 0, ctx->stream, \
-        p->d_dmat, row_off, and_n, p->col_stride, p->ngroups, nb_from, nitems, ctx->xcd_swz, (u64*)d_counts)
-#define LAUNCH_BITS_R(U, NT) switch (rows) { case 1: LAUNCH_BITS(U, 1, NT); break; case 2: LAUNCH_BITS(U, 2, NT); break; \
-        case 4: LAUNCH_BITS(U, 4, NT); break; default: LAUNCH_BITS(U, 8, NT); break; }
-#define LAUNCH_BITS_U(NT) switch (ctx->pipe_unroll) { case 1: LAUNCH_BITS_R(1, NT); break; case 4: LAUNCH_BITS_R(4, NT); break; \
-        default: LAUNCH_BITS_R(2, NT); break; }
-        if (ctx->pipe_nt) { LAUNCH_BITS_U(true); } else { LAUNCH_BITS_U(false); }
-#undef LAUNCH_BITS_U
-#undef LAUNCH_BITS_R
-#undef LAUNCH_BITS
+        u32 nitems = (u32)n64;
+        u32 unroll = ctx->pipe_unroll ? (u32)ctx->pipe_unroll : pipe_unroll_default(rows);
+        pipe_bits_fn fn = pipe_bits_kernel(rows, unroll, ctx->pipe_nt != 0, (u32)ctx->pipe_wg);
+        if (!fn) { g_last_error = "this (pipe_rows, pipe_unroll, pipe_nt, pipe_wg) shape is not compiled into the library"; return BMX_ERR_BADARG; }
+        u32 wpb = (u32)ctx->pipe_wg / 64u, grid = (nitems + wpb - 1) / wpb;
+        hipLaunchKernelGGL(fn, dim3(grid), dim3(ctx->pipe_wg), (size_t)ctx->pipe_lds, ctx->stream,
+                           (const u64*)p->d_dmat, row_off, and_n, p->col_stride, p->ngroups, nb_from, nitems, ctx->xcd_swz, (u64*)d_counts);
         KCHK();
         return BMX_OK;
     }
@@ -810,6 +842,12 @@ static int result_begin(bmx_ctx* ctx, uint64_t nbits, uint32_t nblocks, bmx_vec*
     return BMX_OK;
 }
 
+// Memory of a result: the full-size slab lives only while the result is being produced.  When fewer than 7/8 of
+// its slots hold a bit-block the survivors are moved into a right-sized slab (k_compact_bits; the ordinals come
+// from the layout scan) and the big one goes back to the pool: a sparse result of a 1e9-bit operation costs what
+// it holds, not 125 MB, and bmx_pipeline_run_results over G groups needs (sum of the live blocks) + ONE transient
+// slab.  A nearly full slab is kept as it is (no second pass over the blocks); its ordinals are kept in d_ord so
+// that bmx_vec_download moves only live blocks.
 static int result_finish(bmx_ctx* ctx, bmx_vec* v, BlockStat* st, u32* offs)
 {
     int rc;
@@ -821,6 +859,7 @@ static int result_finish(bmx_ctx* ctx, bmx_vec* v, BlockStat* st, u32* offs)
     HIPCHK(hipStreamSynchronize(ctx->stream));
     uint64_t gap_words = ctx->h_small[1];
     for (int k = 0; k < 4; ++k) v->counts[k] = (uint32_t)ctx->h_small[2 + k];
+    bool pending = false;
     if (gap_words) {
         size_t b_gaps = (size_t)gap_words * 2 + 64;      // + guard, see vec_alloc_device
         if ((rc = dmalloc(ctx, (void**)&v->d_gaps, b_gaps))) return rc;
@@ -829,9 +868,27 @@ static int result_finish(bmx_ctx* ctx, bmx_vec* v, BlockStat* st, u32* offs)
         hipLaunchKernelGGL(k_emit_gaps, dim3((nblocks + 3) / 4), dim3(256), 0, ctx->stream,
                            v->d_bits, nblocks, st, offs, v->d_gaps, v->d_desc);
         KCHK();
-        HIPCHK(hipStreamSynchronize(ctx->stream));
+        pending = true;
     }
-    if (v->counts[BMX_BIT] == 0) {            // nothing lives in the slab: give it back
+    uint32_t live = v->counts[BMX_BIT];
+    uint4* old_slab = nullptr;
+    if (live && (uint64_t)live * 8u < (uint64_t)nblocks * 7u) {
+        uint4* packed = nullptr;
+        if ((rc = dmalloc(ctx, (void**)&packed, (size_t)live * 8192))) return rc;
+        hipLaunchKernelGGL(k_compact_bits, dim3((nblocks + 3) / 4), dim3(256), 0, ctx->stream,
+                           (const uint4*)v->d_bits, nblocks, (const BlockStat*)st, (const u32*)offs, packed, v->d_desc);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { dfree(ctx, packed); return fail_hip(e, "k_compact_bits", __LINE__); }
+        old_slab = v->d_bits; v->d_bits = packed; v->n_bit = live;
+        pending = true;
+    } else if (live && live < nblocks) {
+        if ((rc = dmalloc(ctx, (void**)&v->d_ord, (size_t)nblocks * 4))) return rc;
+        HIPCHK(hipMemcpyAsync(v->d_ord, offs, (size_t)nblocks * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        pending = true;
+    }
+    if (pending) HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (old_slab) dfree(ctx, old_slab);
+    if (live == 0) {                          // nothing lives in the slab: give it back
         dfree(ctx, v->d_bits); v->d_bits = nullptr; v->n_bit = 0;
     }
     return BMX_OK;
@@ -855,6 +912,10 @@ static int vec_clone(bmx_ctx* ctx, const bmx_vec* a, bmx_vec** out)
     hipError_t e = hipSuccess;
     if (b_bits) e = hipMemcpyAsync(v->d_bits, a->d_bits, b_bits, hipMemcpyDeviceToDevice, ctx->stream);
     if (e == hipSuccess && b_gaps) e = hipMemcpyAsync(v->d_gaps, a->d_gaps, b_gaps, hipMemcpyDeviceToDevice, ctx->stream);
+    if (e == hipSuccess && a->d_ord && a->nblocks) {
+        if ((rc = dmalloc(ctx, (void**)&v->d_ord, (size_t)a->nblocks * 4))) { bmx_vec_free(ctx, v); return rc; }
+        e = hipMemcpyAsync(v->d_ord, a->d_ord, (size_t)a->nblocks * 4, hipMemcpyDeviceToDevice, ctx->stream);
+    }
     if (e == hipSuccess && a->nblocks) {
         hipLaunchKernelGGL(k_rebase_desc, dim3((a->nblocks + 255) / 256), dim3(256), 0, ctx->stream, a->d_desc, v->d_desc, a->nblocks,
                            (u64)(uintptr_t)a->d_bits, (u64)(uintptr_t)v->d_bits, (u64)(uintptr_t)a->d_gaps, (u64)(uintptr_t)v->d_gaps);
@@ -917,12 +978,24 @@ int bmx_count_op2_dev(bmx_ctx* ctx, int op, const bmx_vec* a, const bmx_vec* b, 
     return BMX_OK;
 }
 
+} // extern "C"
+
+int bmx_i_count_op2_async(bmx_ctx* ctx, int op, const bmx_vec* a, const bmx_vec* b, int slot)
+{
+    ARGCHK(ctx && slot >= 0 && slot < 64);
+    int rc = bmx_count_op2_dev(ctx, op, a, b, ctx->d_small + slot);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(ctx->h_small + slot, ctx->d_small + slot, 8, hipMemcpyDeviceToHost, ctx->stream));
+    return BMX_OK;
+}
+
+extern "C" {
+
 int bmx_count_op2(bmx_ctx* ctx, int op, const bmx_vec* a, const bmx_vec* b, uint64_t* count)
 {
     ARGCHK(ctx && count);
-    int rc = bmx_count_op2_dev(ctx, op, a, b, ctx->d_small);
+    int rc = bmx_i_count_op2_async(ctx, op, a, b, 0);
     if (rc) return rc;
-    HIPCHK(hipMemcpyAsync(ctx->h_small, ctx->d_small, 8, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     *count = ctx->h_small[0];
     return BMX_OK;
@@ -1204,20 +1277,22 @@ int bmx_rs_build(bmx_ctx* ctx, const bmx_vec* v, bmx_rs** out)
         (rc = dmalloc(ctx, (void**)&rs->d_gidx, b4))) { bmx_rs_free(ctx, rs); return rc; }
     rs->bytes = b1 + b2 + b3 + b4;
     if (v->nblocks) {
+#define RSCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { int r_ = fail_hip(e_, #call, __LINE__); bmx_rs_free(ctx, rs); return r_; } } while (0)
         hipLaunchKernelGGL(k_rs_build, dim3((v->nblocks + 3) / 4), dim3(256), 0, ctx->stream,
                            v->d_desc, v->nblocks, rs->d_bcount, rs->d_sub, rs->d_cum, rs->d_gidx);
-        KCHK();
+        RSCHK(hipGetLastError());
         hipLaunchKernelGGL(k_rs_scan, dim3(1), dim3(1024), 0, ctx->stream, rs->d_bcount, v->nblocks, rs->d_rcount, ctx->d_small);
-        KCHK();
+        RSCHK(hipGetLastError());
         uint32_t shift = 0;
         while (((v->nblocks + (1u << shift) - 1u) >> shift) > 2048u) ++shift;
         rs->sample_shift = shift; rs->nsamples = (v->nblocks + (1u << shift) - 1u) >> shift;
         if ((rc = dmalloc(ctx, (void**)&rs->d_sample, (size_t)rs->nsamples * 8))) { bmx_rs_free(ctx, rs); return rc; }
         hipLaunchKernelGGL(k_rs_sample, dim3((rs->nsamples + 255) / 256), dim3(256), 0, ctx->stream,
                            rs->d_rcount, v->nblocks, shift, rs->nsamples, rs->d_sample);
-        KCHK();
-        HIPCHK(hipMemcpyAsync(ctx->h_small, ctx->d_small, 8, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(hipStreamSynchronize(ctx->stream));
+        RSCHK(hipGetLastError());
+        RSCHK(hipMemcpyAsync(ctx->h_small, ctx->d_small, 8, hipMemcpyDeviceToHost, ctx->stream));
+        RSCHK(hipStreamSynchronize(ctx->stream));
+#undef RSCHK
         rs->count = ctx->h_small[0];
     }
     *out = rs;

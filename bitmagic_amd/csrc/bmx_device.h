@@ -738,11 +738,13 @@ __device__ __forceinline__ u64 readlane64(u64 v, u32 l)
     return ((u64)hi << 32) | lo;
 }
 
-template <int U, bool NT, int OPK>
-__device__ __forceinline__ bool pipe_chain(Part<8>& acc, const u64* __restrict__ plist, u32 n, u32 lane)
+template <int U, bool NT, int OPK, int ROWS = 8>
+__device__ __forceinline__ bool pipe_chain(Part<ROWS>& acc, const u64* __restrict__ plist, u32 n, u32 lane, u32 poff = 0u)
 {
     // Folds operands 0 .. n-1 of plist into acc: OPK 0 = AND, 1 = AND-NOT, 2 = OR.  Returns true when
     // acc saturated (all-zero for AND / AND-NOT, all-ones for OR) so the caller can stop early.
+    // ROWS < 8: acc is the ROWS KiB slice of the block that starts poff 16-byte units into it (thin
+    // shards: more, smaller work items per block column).
     // plist is wave-uniform, so plist[i] is a scalar (SMEM) load: it counts on lgkmcnt, not vmcnt,
     // and is issued one batch ahead -- the vector-memory pipeline never waits for a pointer.
     if (n == 0) return false;
@@ -751,20 +753,20 @@ __device__ __forceinline__ bool pipe_chain(Part<8>& acc, const u64* __restrict__
 #pragma unroll
         for (int u = 0; u < U; ++u) pn[u] = plist[k + u < n ? k + u : n - 1u];   // tail: repeat the last operand
     };
-    auto issue = [&](Part<8>* buf) {
+    auto issue = [&](Part<ROWS>* buf) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) part_load<8, NT>(buf[u], as_gc4(uniform64(pn[u])), lane);
+        for (int u = 0; u < U; ++u) part_load<ROWS, NT>(buf[u], as_gc4(uniform64(pn[u])) + poff, lane);
     };
-    auto consume = [&](Part<8>* buf) {
+    auto consume = [&](Part<ROWS>* buf) {
 #pragma unroll
         for (int u = 0; u < U; ++u)
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
+            for (int i = 0; i < ROWS; ++i) {
                 if constexpr (OPK == 0) acc.r[i] &= buf[u].r[i];
                 else if constexpr (OPK == 1) acc.r[i] &= ~buf[u].r[i];
                 else acc.r[i] |= buf[u].r[i];
             }
-        if constexpr (OPK == 2) return part_is_ones<8>(acc); else return part_is_zero<8>(acc);
+        if constexpr (OPK == 2) return part_is_ones<ROWS>(acc); else return part_is_zero<ROWS>(acc);
     };
     // The loop body is ONE basic block that issues batch j+1 before consuming batch j and batch
     // j+2 before consuming batch j+1; the only branch is the back-edge.  (With an early-exit branch
@@ -772,7 +774,7 @@ __device__ __forceinline__ bool pipe_chain(Part<8>& acc, const u64* __restrict__
     // merges the wait counters to vmcnt(0) at the join -- and the two buffers serialise.)
     // Early exit therefore has a granularity of 2U operands.  Past the end the clamped index
     // re-loads the last operand (idempotent; <= 2U L2-resident blocks per column).
-    Part<8> A[U], B[U];
+    Part<ROWS> A[U], B[U];
     u32 k = U;                      // first operand of the batch to issue next
     fetch(0);
     issue(A);
@@ -788,4 +790,3 @@ __device__ __forceinline__ bool pipe_chain(Part<8>& acc, const u64* __restrict__
     } while (!zero && k < n + U);   // batch starting at k-U has been issued into A: consume it next time
     return zero;
 }
-

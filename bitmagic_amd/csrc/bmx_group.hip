@@ -1,0 +1,506 @@
+// bmx_group.hip -- multi-GPU group layer of libbmx.so (include/bmx.h "device groups").
+//
+// Reference: there is none to translate -- bm::aggregator is single-threaded (src/bmaggregator.h:824-853).
+// What the layer relies on is the column independence of the reference's loops (combine_or :1113-1121,
+// combine_and_sub :1184-1218, bit_and src/bm.h:6226-6271): result block (i,j) depends on operand blocks (i,j)
+// only, so the linear block range is cut into one contiguous shard per device, every member runs the
+// single-device engine (bmx.hip) over its shard, and the only exchange is the sum of the popcounts.
+//
+// Host-only code: it composes the C-ABI of bmx.hip plus the two asynchronous internals of bmx_internal.h.
+#include "bmx_internal.h"
+
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <thread>
+
+struct bmx_group {
+    int n = 0, flags = 0;
+    std::vector<bmx_ctx*> ctx;
+    // RCCL (optional, loaded on demand: the library has no link-time dependency on librccl)
+    void* rccl = nullptr;
+    std::vector<void*> comm;
+    int (*p_allreduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*p_group_start)() = nullptr;
+    int (*p_group_end)() = nullptr;
+    int (*p_comm_destroy)(void*) = nullptr;
+    const char* (*p_errstr)(int) = nullptr;
+};
+
+struct bmx_gvec {
+    bmx_group* g;
+    uint64_t nbits; uint32_t nblocks;
+    std::vector<bmx_vec*> shard;          // shard[m] lives on g->ctx[m], blocks shard_range(nblocks, m)
+};
+
+struct bmx_gpipeline {
+    bmx_group* g;
+    uint32_t ngroups;
+    std::vector<bmx_pipeline*> pipe;
+    std::vector<u64*> d_counts;           // per member: ngroups x u64 on the device
+    u64* h_counts = nullptr;              // pinned, n x ngroups
+    std::vector<hipEvent_t> ev0, ev1;
+    std::vector<float> last_ms;
+};
+
+static void shard_range(uint32_t nblocks, int m, int n, uint32_t* lo, uint32_t* hi)
+{
+    uint32_t q = nblocks / (uint32_t)n, r = nblocks % (uint32_t)n, mm = (uint32_t)m;
+    *lo = mm * q + std::min(mm, r);
+    *hi = *lo + q + (mm < r ? 1u : 0u);
+}
+
+// run fn(m) for every member on its own host thread (the single-device entry points are synchronous);
+// returns the first non-zero status and carries that thread's error text over to the caller's
+template <class F>
+static int for_each_member(bmx_group* g, F fn)
+{
+    std::vector<int> rc((size_t)g->n, BMX_OK);
+    std::vector<std::string> msg((size_t)g->n);
+    auto body = [&](int m) { rc[(size_t)m] = fn(m); if (rc[(size_t)m]) msg[(size_t)m] = bmx_last_error(); };
+    if (g->n == 1) body(0);
+    else {
+        std::vector<std::thread> th;
+        th.reserve((size_t)g->n);
+        for (int m = 0; m < g->n; ++m) th.emplace_back(body, m);
+        for (auto& t : th) t.join();
+    }
+    for (int m = 0; m < g->n; ++m)
+        if (rc[(size_t)m]) { bmx_set_last_error(msg[(size_t)m].c_str()); return rc[(size_t)m]; }
+    return BMX_OK;
+}
+
+static int sync_all(bmx_group* g)
+{
+    int rc = BMX_OK;
+    for (int m = 0; m < g->n; ++m) { int r = bmx_ctx_synchronize(g->ctx[(size_t)m]); if (r && !rc) rc = r; }
+    return rc;
+}
+
+static int load_rccl(bmx_group* g, const int* devices)
+{
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    for (const char* nm : names) { g->rccl = dlopen(nm, RTLD_NOW | RTLD_GLOBAL); if (g->rccl) break; }
+    if (!g->rccl) { bmx_set_last_error("BMX_GROUP_RCCL: librccl.so could not be loaded"); return BMX_ERR_DEVICE; }
+    auto p_init_all = (int (*)(void**, int, const int*))dlsym(g->rccl, "ncclCommInitAll");
+    g->p_allreduce = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(g->rccl, "ncclAllReduce");
+    g->p_group_start = (int (*)())dlsym(g->rccl, "ncclGroupStart");
+    g->p_group_end = (int (*)())dlsym(g->rccl, "ncclGroupEnd");
+    g->p_comm_destroy = (int (*)(void*))dlsym(g->rccl, "ncclCommDestroy");
+    g->p_errstr = (const char* (*)(int))dlsym(g->rccl, "ncclGetErrorString");
+    if (!p_init_all || !g->p_allreduce || !g->p_group_start || !g->p_group_end || !g->p_comm_destroy) {
+        bmx_set_last_error("BMX_GROUP_RCCL: librccl.so lacks the expected entry points"); return BMX_ERR_DEVICE;
+    }
+    g->comm.assign((size_t)g->n, nullptr);
+    int r = p_init_all(g->comm.data(), g->n, devices);
+    if (r != 0) {
+        std::string m = "ncclCommInitAll failed: "; m += g->p_errstr ? g->p_errstr(r) : "?";
+        bmx_set_last_error(m.c_str()); g->comm.clear(); return BMX_ERR_DEVICE;
+    }
+    return BMX_OK;
+}
+
+extern "C" {
+
+int bmx_group_create(const int* devices, int n, int flags, bmx_group** out)
+{
+    ARGCHK(out && devices && n >= 1 && n <= 64 && (flags & ~BMX_GROUP_RCCL) == 0);
+    *out = nullptr;
+    if (flags & BMX_GROUP_RCCL)
+        for (int a = 0; a < n; ++a) for (int b = a + 1; b < n; ++b)
+            if (devices[a] == devices[b]) { bmx_set_last_error("BMX_GROUP_RCCL needs distinct devices"); return BMX_ERR_BADARG; }
+    bmx_group* g = new (std::nothrow) bmx_group();
+    if (!g) return BMX_ERR_BADALLOC;
+    g->n = n; g->flags = flags;
+    for (int m = 0; m < n; ++m) {
+        bmx_ctx* c = nullptr;
+        int rc = bmx_ctx_create(devices[m], nullptr, &c);
+        if (rc) { bmx_group_destroy(g); return rc; }
+        g->ctx.push_back(c);
+    }
+    if (flags & BMX_GROUP_RCCL) { int rc = load_rccl(g, devices); if (rc) { bmx_group_destroy(g); return rc; } }
+    *out = g;
+    return BMX_OK;
+}
+
+int bmx_group_destroy(bmx_group* g)
+{
+    if (!g) return BMX_OK;
+    for (size_t m = 0; m < g->comm.size(); ++m) if (g->comm[m] && g->p_comm_destroy) (void)g->p_comm_destroy(g->comm[m]);
+    for (bmx_ctx* c : g->ctx) bmx_ctx_destroy(c);
+    // librccl stays loaded: unloading a library that registered HIP fat binaries is not safe
+    delete g;
+    return BMX_OK;
+}
+
+int bmx_group_size(const bmx_group* g, int* n) { ARGCHK(g && n); *n = g->n; return BMX_OK; }
+
+int bmx_group_ctx(const bmx_group* g, int member, bmx_ctx** ctx)
+{
+    ARGCHK(g && ctx);
+    if (member < 0 || member >= g->n) { bmx_set_last_error("member index out of range"); return BMX_ERR_RANGE; }
+    *ctx = g->ctx[(size_t)member];
+    return BMX_OK;
+}
+
+int bmx_group_shard_range(const bmx_group* g, uint32_t nblocks, int member, uint32_t* nb_from, uint32_t* nb_to)
+{
+    ARGCHK(g && nb_from && nb_to);
+    if (member < 0 || member >= g->n) { bmx_set_last_error("member index out of range"); return BMX_ERR_RANGE; }
+    shard_range(nblocks, member, g->n, nb_from, nb_to);
+    return BMX_OK;
+}
+
+static bmx_gvec* gvec_new(bmx_group* g, uint64_t nbits, uint32_t nblocks)
+{
+    bmx_gvec* v = new (std::nothrow) bmx_gvec();
+    if (!v) return nullptr;
+    v->g = g; v->nbits = nbits; v->nblocks = nblocks;
+    v->shard.assign((size_t)g->n, nullptr);
+    return v;
+}
+
+int bmx_gvec_free(bmx_group* g, bmx_gvec* v)
+{
+    if (!v) return BMX_OK;
+    ARGCHK(g && v->g == g);
+    int rc = BMX_OK;
+    for (int m = 0; m < g->n; ++m) { int r = bmx_vec_free(g->ctx[(size_t)m], v->shard[(size_t)m]); if (r && !rc) rc = r; }
+    delete v;
+    return rc;
+}
+
+static uint64_t shard_bits(uint64_t nbits, uint32_t lo, uint32_t hi)
+{
+    uint64_t b0 = (uint64_t)lo * BMX_BLOCK_BITS, b1 = std::min<uint64_t>(nbits, (uint64_t)hi * BMX_BLOCK_BITS);
+    return b1 > b0 ? b1 - b0 : 0;
+}
+
+int bmx_gvec_upload(bmx_group* g, uint64_t nbits, uint32_t nblocks, const uint8_t* kinds, const uint32_t* offs,
+                    const uint32_t* bit_slab, uint32_t n_bit_blocks, const uint16_t* gap_slab, uint64_t gap_words,
+                    bmx_gvec** out)
+{
+    ARGCHK(g && out && (nblocks == 0 || (kinds && offs)));
+    *out = nullptr;
+    bmx_gvec* v = gvec_new(g, nbits, nblocks);
+    if (!v) return BMX_ERR_BADALLOC;
+    int rc = for_each_member(g, [&](int m) -> int {
+        uint32_t lo, hi; shard_range(nblocks, m, g->n, &lo, &hi);
+        // the piece of each slab this shard references: [min offset, max end) -- exact for tables in block
+        // order (what a tree walk or a frozen arena yields), still correct for any other order
+        uint32_t bmin = 0xFFFFFFFFu, bmax = 0; uint64_t gmin = ~0ull, gmax = 0;
+        for (uint32_t nb = lo; nb < hi; ++nb) {
+            if (kinds[nb] == BMX_BIT) { bmin = std::min(bmin, offs[nb]); bmax = std::max(bmax, offs[nb] + 1u); }
+            else if (kinds[nb] == BMX_GAP) {
+                uint64_t o = offs[nb];
+                if (!gap_slab || o >= gap_words) { bmx_set_last_error("GAP offset out of range"); return BMX_ERR_RANGE; }
+                gmin = std::min(gmin, o); gmax = std::max(gmax, o + (uint64_t)(gap_slab[o] >> 3) + 1u);
+            } else if (kinds[nb] > BMX_GAP) { bmx_set_last_error("bad block kind"); return BMX_ERR_BADARG; }
+        }
+        if (bmax > n_bit_blocks) { bmx_set_last_error("bit-block offset out of range"); return BMX_ERR_RANGE; }
+        if (gmax > gap_words) { bmx_set_last_error("malformed GAP block (length)"); return BMX_ERR_RANGE; }
+        if (bmin == 0xFFFFFFFFu) { bmin = 0; bmax = 0; }
+        if (gmin == ~0ull) { gmin = 0; gmax = 0; }
+        std::vector<uint32_t> so(std::max<uint32_t>(hi - lo, 1u), 0);
+        for (uint32_t nb = lo; nb < hi; ++nb)
+            so[nb - lo] = kinds[nb] == BMX_BIT ? offs[nb] - bmin : (kinds[nb] == BMX_GAP ? (uint32_t)(offs[nb] - gmin) : 0u);
+        return bmx_vec_upload(g->ctx[(size_t)m], shard_bits(nbits, lo, hi), hi - lo, kinds + lo, so.data(),
+                              bmax > bmin ? bit_slab + (size_t)bmin * BMX_BLOCK_WORDS : nullptr, bmax - bmin,
+                              gmax > gmin ? gap_slab + gmin : nullptr, gmax - gmin, &v->shard[(size_t)m]);
+    });
+    if (rc) { std::string keep = bmx_last_error(); bmx_gvec_free(g, v); bmx_set_last_error(keep.c_str()); return rc; }
+    *out = v;
+    return BMX_OK;
+}
+
+int bmx_gvec_generate(bmx_group* g, uint64_t seed, uint32_t vec_id, int with_common, uint32_t density_q16,
+                      uint64_t nbits, int optimize, bmx_gvec** out)
+{
+    ARGCHK(g && out);
+    *out = nullptr;
+    uint64_t nblocks64 = (nbits + BMX_BLOCK_BITS - 1) / BMX_BLOCK_BITS;
+    if (nblocks64 > 65536ull * 16) { bmx_set_last_error("vector too long"); return BMX_ERR_RANGE; }
+    bmx_gvec* v = gvec_new(g, nbits, (uint32_t)nblocks64);
+    if (!v) return BMX_ERR_BADALLOC;
+    int rc = for_each_member(g, [&](int m) -> int {
+        uint32_t lo, hi; shard_range(v->nblocks, m, g->n, &lo, &hi);
+        return bmx_vec_generate_shard(g->ctx[(size_t)m], seed, vec_id, with_common, density_q16, nbits, lo, hi, optimize,
+                                      &v->shard[(size_t)m]);
+    });
+    if (rc) { std::string keep = bmx_last_error(); bmx_gvec_free(g, v); bmx_set_last_error(keep.c_str()); return rc; }
+    *out = v;
+    return BMX_OK;
+}
+
+int bmx_gvec_info(const bmx_gvec* v, uint64_t* nbits, uint32_t* nblocks, uint32_t counts[4],
+                  uint32_t* bit_slab_blocks, uint64_t* gap_words)
+{
+    ARGCHK(v);
+    uint32_t c[4] = {0, 0, 0, 0}; uint32_t slab = 0; uint64_t gw = 0;
+    for (bmx_vec* s : v->shard) {
+        uint32_t sc[4], sb; uint64_t sg;
+        int rc = bmx_vec_info(s, nullptr, nullptr, sc, &sb, &sg); if (rc) return rc;
+        for (int k = 0; k < 4; ++k) c[k] += sc[k];
+        slab += sb; gw += sg;
+    }
+    if (nbits) *nbits = v->nbits;
+    if (nblocks) *nblocks = v->nblocks;
+    if (counts) memcpy(counts, c, sizeof(c));
+    if (bit_slab_blocks) *bit_slab_blocks = slab;
+    if (gap_words) *gap_words = gw;
+    return BMX_OK;
+}
+
+int bmx_gvec_shard(const bmx_gvec* v, int member, const bmx_vec** shard)
+{
+    ARGCHK(v && shard);
+    if (member < 0 || member >= (int)v->shard.size()) { bmx_set_last_error("member index out of range"); return BMX_ERR_RANGE; }
+    *shard = v->shard[(size_t)member];
+    return BMX_OK;
+}
+
+int bmx_gvec_download(bmx_group* g, const bmx_gvec* v, uint8_t* kinds, uint32_t* offs, uint32_t* bit_slab, uint16_t* gap_slab)
+{
+    ARGCHK(g && v && v->g == g);
+    uint32_t bbase = 0; uint64_t gbase = 0;
+    for (int m = 0; m < g->n; ++m) {
+        uint32_t lo, hi; shard_range(v->nblocks, m, g->n, &lo, &hi);
+        const bmx_vec* s = v->shard[(size_t)m];
+        uint32_t sb; uint64_t sg;
+        int rc = bmx_vec_info(s, nullptr, nullptr, nullptr, &sb, &sg); if (rc) return rc;
+        std::vector<uint8_t> kk;
+        uint8_t* kdst = kinds ? kinds + lo : nullptr;
+        if (offs && !kinds) { kk.resize(std::max<uint32_t>(hi - lo, 1u)); kdst = kk.data(); }
+        rc = bmx_vec_download(g->ctx[(size_t)m], s, kdst, offs ? offs + lo : nullptr,
+                              bit_slab ? bit_slab + (size_t)bbase * BMX_BLOCK_WORDS : nullptr,
+                              gap_slab ? gap_slab + gbase : nullptr);
+        if (rc) return rc;
+        if (offs) for (uint32_t nb = lo; nb < hi; ++nb) {
+            if (kdst[nb - lo] == BMX_BIT) offs[nb] += bbase;
+            else if (kdst[nb - lo] == BMX_GAP) {
+                if (gbase + offs[nb] > 0xFFFFFFFFull) { bmx_set_last_error("gathered GAP slab exceeds 32-bit word offsets"); return BMX_ERR_RANGE; }
+                offs[nb] += (uint32_t)gbase;
+            }
+        }
+        bbase += sb; gbase += sg;
+    }
+    return BMX_OK;
+}
+
+int bmx_gvec_count(bmx_group* g, const bmx_gvec* a, uint64_t* count)
+{
+    ARGCHK(g && a && count && a->g == g);
+    for (int m = 0; m < g->n; ++m) { int rc = bmx_i_count_async(g->ctx[(size_t)m], a->shard[(size_t)m], 0); if (rc) { (void)sync_all(g); return rc; } }
+    int rc = sync_all(g); if (rc) return rc;
+    uint64_t t = 0;
+    for (int m = 0; m < g->n; ++m) t += g->ctx[(size_t)m]->h_small[0];
+    *count = t;
+    return BMX_OK;
+}
+
+int bmx_gvec_count_op2(bmx_group* g, int op, const bmx_gvec* a, const bmx_gvec* b, uint64_t* count)
+{
+    ARGCHK(g && a && b && count && a->g == g && b->g == g);
+    if (a->nblocks != b->nblocks) { bmx_set_last_error("sharded operands must cover the same block range (upload them with the same nblocks)"); return BMX_ERR_BADARG; }
+    for (int m = 0; m < g->n; ++m) {
+        int rc = bmx_i_count_op2_async(g->ctx[(size_t)m], op, a->shard[(size_t)m], b->shard[(size_t)m], 0);
+        if (rc) { (void)sync_all(g); return rc; }
+    }
+    int rc = sync_all(g); if (rc) return rc;
+    uint64_t t = 0;
+    for (int m = 0; m < g->n; ++m) t += g->ctx[(size_t)m]->h_small[0];
+    *count = t;
+    return BMX_OK;
+}
+
+int bmx_gvec_op2(bmx_group* g, int op, const bmx_gvec* a, const bmx_gvec* b, int opt_compress, bmx_gvec** result)
+{
+    ARGCHK(g && a && b && result && a->g == g && b->g == g);
+    *result = nullptr;
+    if (a->nblocks != b->nblocks) { bmx_set_last_error("sharded operands must cover the same block range (upload them with the same nblocks)"); return BMX_ERR_BADARG; }
+    bmx_gvec* v = gvec_new(g, std::max(a->nbits, b->nbits), a->nblocks);
+    if (!v) return BMX_ERR_BADALLOC;
+    int rc = for_each_member(g, [&](int m) -> int {
+        return bmx_op2(g->ctx[(size_t)m], op, a->shard[(size_t)m], b->shard[(size_t)m], opt_compress, &v->shard[(size_t)m]);
+    });
+    if (rc) { std::string keep = bmx_last_error(); bmx_gvec_free(g, v); bmx_set_last_error(keep.c_str()); return rc; }
+    *result = v;
+    return BMX_OK;
+}
+
+static int same_range(bmx_group* g, const bmx_gvec* const* src, size_t n, uint32_t* nblocks, uint64_t* nbits)
+{
+    for (size_t i = 0; i < n; ++i) {
+        if (!src[i] || src[i]->g != g) { bmx_set_last_error("operand is null or belongs to another group"); return BMX_ERR_BADARG; }
+        if (*nblocks == 0xFFFFFFFFu) *nblocks = src[i]->nblocks;
+        else if (src[i]->nblocks != *nblocks) { bmx_set_last_error("sharded operands must cover the same block range (upload them with the same nblocks)"); return BMX_ERR_BADARG; }
+        *nbits = std::max(*nbits, src[i]->nbits);
+    }
+    return BMX_OK;
+}
+
+int bmx_gagg_or(bmx_group* g, const bmx_gvec* const* src, size_t n, int opt_compress, bmx_gvec** result)
+{
+    ARGCHK(g && result && (n == 0 || src));
+    *result = nullptr;
+    uint32_t nblocks = 0xFFFFFFFFu; uint64_t nbits = 0;
+    int rc = same_range(g, src, n, &nblocks, &nbits); if (rc) return rc;
+    if (nblocks == 0xFFFFFFFFu) nblocks = 0;
+    bmx_gvec* v = gvec_new(g, nbits, nblocks);
+    if (!v) return BMX_ERR_BADALLOC;
+    rc = for_each_member(g, [&](int m) -> int {
+        std::vector<const bmx_vec*> h(std::max<size_t>(n, 1));
+        for (size_t i = 0; i < n; ++i) h[i] = src[i]->shard[(size_t)m];
+        return bmx_agg_or_opt(g->ctx[(size_t)m], h.data(), n, opt_compress, &v->shard[(size_t)m]);
+    });
+    if (rc) { std::string keep = bmx_last_error(); bmx_gvec_free(g, v); bmx_set_last_error(keep.c_str()); return rc; }
+    *result = v;
+    return BMX_OK;
+}
+
+int bmx_gagg_and_sub(bmx_group* g, const bmx_gvec* const* src_and, size_t n_and,
+                     const bmx_gvec* const* src_sub, size_t n_sub, bmx_gvec** result, int* any)
+{
+    ARGCHK(g && result && (n_and == 0 || src_and) && (n_sub == 0 || src_sub));
+    *result = nullptr;
+    if (any) *any = 0;
+    uint32_t nblocks = 0xFFFFFFFFu; uint64_t nbits = 0;
+    int rc = same_range(g, src_and, n_and, &nblocks, &nbits); if (rc) return rc;
+    rc = same_range(g, src_sub, n_sub, &nblocks, &nbits); if (rc) return rc;
+    if (nblocks == 0xFFFFFFFFu) nblocks = 0;
+    bmx_gvec* v = gvec_new(g, nbits, nblocks);
+    if (!v) return BMX_ERR_BADALLOC;
+    std::vector<int> many((size_t)g->n, 0);
+    rc = for_each_member(g, [&](int m) -> int {
+        std::vector<const bmx_vec*> a(std::max<size_t>(n_and, 1)), s(std::max<size_t>(n_sub, 1));
+        for (size_t i = 0; i < n_and; ++i) a[i] = src_and[i]->shard[(size_t)m];
+        for (size_t i = 0; i < n_sub; ++i) s[i] = src_sub[i]->shard[(size_t)m];
+        return bmx_agg_and_sub(g->ctx[(size_t)m], a.data(), n_and, s.data(), n_sub, &v->shard[(size_t)m], &many[(size_t)m]);
+    });
+    if (rc) { std::string keep = bmx_last_error(); bmx_gvec_free(g, v); bmx_set_last_error(keep.c_str()); return rc; }
+    if (any) for (int m = 0; m < g->n; ++m) *any |= many[(size_t)m];
+    *result = v;
+    return BMX_OK;
+}
+
+int bmx_gpipeline_destroy(bmx_group* g, bmx_gpipeline* p)
+{
+    if (!p) return BMX_OK;
+    ARGCHK(g && p->g == g);
+    for (int m = 0; m < g->n; ++m) {
+        bmx_ctx* c = g->ctx[(size_t)m];
+        (void)hipSetDevice(c->device);
+        (void)hipStreamSynchronize(c->stream);
+        if ((size_t)m < p->pipe.size()) bmx_pipeline_destroy(c, p->pipe[(size_t)m]);
+        if ((size_t)m < p->d_counts.size() && p->d_counts[(size_t)m]) (void)hipFree(p->d_counts[(size_t)m]);
+        if ((size_t)m < p->ev0.size() && p->ev0[(size_t)m]) (void)hipEventDestroy(p->ev0[(size_t)m]);
+        if ((size_t)m < p->ev1.size() && p->ev1[(size_t)m]) (void)hipEventDestroy(p->ev1[(size_t)m]);
+    }
+    if (p->h_counts) (void)hipHostFree(p->h_counts);
+    delete p;
+    return BMX_OK;
+}
+
+int bmx_gpipeline_create(bmx_group* g, const bmx_gvec* const* and_list, const uint32_t* and_n,
+                         const bmx_gvec* const* sub_list, const uint32_t* sub_n, size_t ngroups, bmx_gpipeline** out)
+{
+    ARGCHK(g && out && ngroups > 0 && ngroups < (1u << 20) && and_n && sub_n);
+    *out = nullptr;
+    size_t tot_and = 0, tot_sub = 0;
+    for (size_t k = 0; k < ngroups; ++k) { tot_and += and_n[k]; tot_sub += sub_n[k]; }
+    ARGCHK(tot_and == 0 || and_list);
+    ARGCHK(tot_sub == 0 || sub_list);
+    uint32_t nblocks = 0xFFFFFFFFu; uint64_t nbits = 0;
+    int rc = same_range(g, and_list, tot_and, &nblocks, &nbits); if (rc) return rc;
+    rc = same_range(g, sub_list, tot_sub, &nblocks, &nbits); if (rc) return rc;
+    bmx_gpipeline* p = new (std::nothrow) bmx_gpipeline();
+    if (!p) return BMX_ERR_BADALLOC;
+    p->g = g; p->ngroups = (uint32_t)ngroups;
+    p->pipe.assign((size_t)g->n, nullptr); p->d_counts.assign((size_t)g->n, nullptr);
+    p->ev0.assign((size_t)g->n, nullptr); p->ev1.assign((size_t)g->n, nullptr); p->last_ms.assign((size_t)g->n, 0.f);
+    rc = for_each_member(g, [&](int m) -> int {
+        bmx_ctx* c = g->ctx[(size_t)m];
+        std::vector<const bmx_vec*> a(std::max<size_t>(tot_and, 1)), s(std::max<size_t>(tot_sub, 1));
+        for (size_t i = 0; i < tot_and; ++i) a[i] = and_list[i]->shard[(size_t)m];
+        for (size_t i = 0; i < tot_sub; ++i) s[i] = sub_list[i]->shard[(size_t)m];
+        int r = bmx_pipeline_create(c, a.data(), and_n, s.data(), sub_n, ngroups, &p->pipe[(size_t)m]);
+        if (r) return r;
+        HIPCHK(hipSetDevice(c->device));
+        HIPCHK(hipMalloc((void**)&p->d_counts[(size_t)m], ngroups * 8));
+        HIPCHK(hipEventCreate(&p->ev0[(size_t)m]));
+        HIPCHK(hipEventCreate(&p->ev1[(size_t)m]));
+        return BMX_OK;
+    });
+    if (!rc) {
+        hipError_t e = hipHostMalloc((void**)&p->h_counts, (size_t)g->n * ngroups * 8);
+        if (e != hipSuccess) rc = bmx_fail_hip(e, "hipHostMalloc", __FILE__, __LINE__);
+    }
+    if (rc) { std::string keep = bmx_last_error(); bmx_gpipeline_destroy(g, p); bmx_set_last_error(keep.c_str()); return rc; }
+    *out = p;
+    return BMX_OK;
+}
+
+int bmx_gpipeline_run_counts(bmx_group* g, bmx_gpipeline* p, uint64_t* counts_out)
+{
+    ARGCHK(g && p && p->g == g && counts_out);
+    const size_t ng = p->ngroups;
+    // 1. enqueue the counts kernel on every member (asynchronous: all devices start before any is waited for)
+    for (int m = 0; m < g->n; ++m) {
+        bmx_ctx* c = g->ctx[(size_t)m];
+        HIPCHK(hipSetDevice(c->device));
+        HIPCHK(hipEventRecord(p->ev0[(size_t)m], c->stream));
+        int rc = bmx_pipeline_run_counts_dev(c, p->pipe[(size_t)m], 0u, 0xFFFFFFFFu, p->d_counts[(size_t)m]);
+        if (rc) { (void)sync_all(g); return rc; }
+        HIPCHK(hipEventRecord(p->ev1[(size_t)m], c->stream));
+    }
+    // 2. the only exchange: the popcounts (8 B per arg-group)
+    const bool rccl = (g->flags & BMX_GROUP_RCCL) && !g->comm.empty();
+    if (rccl) {
+        int r = g->p_group_start();
+        for (int m = 0; m < g->n && r == 0; ++m) {
+            bmx_ctx* c = g->ctx[(size_t)m];
+            HIPCHK(hipSetDevice(c->device));
+            r = g->p_allreduce(p->d_counts[(size_t)m], p->d_counts[(size_t)m], ng, 5 /* ncclUint64 */, 0 /* ncclSum */,
+                               g->comm[(size_t)m], c->stream);
+        }
+        int r2 = g->p_group_end();
+        if (r || r2) {
+            std::string msg = "RCCL all-reduce failed: "; msg += g->p_errstr ? g->p_errstr(r ? r : r2) : "?";
+            (void)sync_all(g); bmx_set_last_error(msg.c_str()); return BMX_ERR_DEVICE;
+        }
+        bmx_ctx* c0 = g->ctx[0];
+        HIPCHK(hipSetDevice(c0->device));
+        HIPCHK(hipMemcpyAsync(p->h_counts, p->d_counts[0], ng * 8, hipMemcpyDeviceToHost, c0->stream));
+    } else {
+        for (int m = 0; m < g->n; ++m) {
+            bmx_ctx* c = g->ctx[(size_t)m];
+            HIPCHK(hipSetDevice(c->device));
+            HIPCHK(hipMemcpyAsync(p->h_counts + (size_t)m * ng, p->d_counts[(size_t)m], ng * 8, hipMemcpyDeviceToHost, c->stream));
+        }
+    }
+    int rc = sync_all(g); if (rc) return rc;
+    for (size_t k = 0; k < ng; ++k) {
+        uint64_t t = p->h_counts[k];
+        if (!rccl) for (int m = 1; m < g->n; ++m) t += p->h_counts[(size_t)m * ng + k];
+        counts_out[k] = t;
+    }
+    for (int m = 0; m < g->n; ++m) {
+        float ms = 0.f;
+        (void)hipSetDevice(g->ctx[(size_t)m]->device);
+        if (hipEventElapsedTime(&ms, p->ev0[(size_t)m], p->ev1[(size_t)m]) != hipSuccess) { (void)hipGetLastError(); ms = 0.f; }
+        p->last_ms[(size_t)m] = ms;
+    }
+    return BMX_OK;
+}
+
+int bmx_gpipeline_last_ms(bmx_group* g, const bmx_gpipeline* p, float* ms)
+{
+    ARGCHK(g && p && p->g == g && ms);
+    for (int m = 0; m < g->n; ++m) ms[m] = p->last_ms[(size_t)m];
+    return BMX_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,93 @@
+// bmx_internal.h -- host-side structures shared by the translation units of libbmx.so
+// (bmx.hip: single-device engine + kernels; bmx_group.hip: multi-device group layer).
+// Not part of the ABI: include/bmx.h is.
+#pragma once
+#include "../../include/bmx.h"
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <map>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+typedef uint8_t  u8;
+typedef uint16_t u16;
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+// error plumbing: no exception crosses the ABI (lang-maps/libbm conventions)
+int bmx_fail_hip(hipError_t e, const char* what, const char* file, int line);
+void bmx_set_last_error(const char* msg);
+#define HIPCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return bmx_fail_hip(e_, #call, __FILE__, __LINE__); } while (0)
+#define ARGCHK(cond) do { if (!(cond)) { bmx_set_last_error("bad argument: " #cond); return BMX_ERR_BADARG; } } while (0)
+#define KCHK() HIPCHK(hipGetLastError())
+
+struct bmx_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    uint64_t mem_used = 0;
+    // grow-only scratch
+    void* scratch = nullptr; size_t scratch_bytes = 0;      // raw block slab for import/generate/upload/download staging
+    void* aux = nullptr; size_t aux_bytes = 0;              // stats / offsets / totals
+    u64* d_small = nullptr;                                 // 64 x u64 result words
+    u64* d_slots = nullptr;                                 // COUNT_SLOTS striped count accumulators (kept zero between launches)
+    u64* h_small = nullptr;                                 // pinned mirror
+    // caching device allocator: results of same-shaped operations re-use their blocks instead of
+    // paying hipMalloc / hipFree (which synchronises the device) on every call
+    std::multimap<size_t, void*> pool_free;
+    std::unordered_map<void*, size_t> pool_live;
+    uint64_t pool_cached = 0, pool_cap = 16ull << 30;
+    int pipe_unroll = 0;       // operand slices per batch (two batches in flight); 0 = the measured best for the slice size
+    int pipe_rows = 0;         // register rows (KiB of a block) per work item: 8 = whole block, 4/2/1 = slices, 0 = auto by item count
+    int pipe_nt = 1;           // non-temporal operand loads (+4.5 % on the streamed-once headline case)
+    int pipe_wg = 384;         // workgroup size of the bit-only counts kernel: 6 adjacent items per workgroup, 2 workgroups per CU
+                               // (+6 % over 256 in the A/B sweep: co-scheduled waves read one contiguous stretch of each operand)
+    int pipe_staged = -1;      // LDS-staged many-groups kernel: -1 auto, 0 never, 1 whenever possible
+    int pipe_lds = 0;          // experiment: dynamic LDS bytes requested by the bit-only counts kernel (occupancy throttle)
+    int pipe_slots = 16;       // plane blocks staged at a time (16: 1024-thread WG; 8: two 512-thread WGs per CU)
+    int pipe_split = -1;       // few columns: waves of a workgroup share one column's operand list: -1 auto, 0 never, 1 always
+    int or_tile = 0;           // k_agg_or_gap_tiled variant (0 = default)
+    int xcd_swz = 1;
+};
+
+struct bmx_vec {
+    bmx_ctx* ctx;
+    uint64_t nbits; uint32_t nblocks;
+    uint32_t counts[4]; uint64_t gap_words; uint32_t n_bit;   // n_bit = slots of d_bits
+    u64* d_desc; uint4* d_bits; u16* d_gaps;
+    u32* d_ord;        // result vectors whose slab has unused slots: ordinal of every bit-block (download gathers), else null
+    size_t bytes;
+};
+
+struct bmx_pipeline {
+    bmx_ctx* ctx;
+    uint32_t ngroups, ncols, col_stride, n_ops;
+    bool has_gap;
+    uint64_t nbits;                       // max size of the operands
+    // LDS-staged path (k_pipe_counts_staged): distinct vectors ("planes") + per-group plane masks
+    uint32_t nplanes, nchunks; bool staged_ok;
+    const u64** d_udesc; u32* d_unblk; u32* d_gmask; u32* d_gskip;
+    std::vector<u32>* h_row_off;          // host copy: row offset of each group inside a column record
+    std::vector<u32>* h_and_n;            // host copy: AND operands per group
+    u64* d_dmat;
+    u32* d_meta;       // row_off | and_n | sub_n | and_off | sub_off (ngroups each) | nblocks (n_ops)
+    const u64** d_descs;
+    size_t bytes;
+};
+
+struct bmx_rs {
+    bmx_ctx* ctx;
+    uint32_t nblocks; uint64_t count;
+    u32* d_bcount; u64* d_sub; u64* d_rcount; u16* d_cum;
+    u16* d_gidx;                                          // GAP blocks: first run reaching each 1024-bit wave
+    u64* d_sample; uint32_t nsamples, sample_shift;       // top level of the select search (<= 2048 entries)
+    size_t bytes;
+};
+
+// asynchronous building blocks the group layer composes (bmx.hip): everything is enqueued on ctx->stream,
+// the 8-byte results land in ctx->h_small[slot] (pinned) after the stream has been synchronised
+int bmx_i_count_async(bmx_ctx* ctx, const bmx_vec* a, int slot);
+int bmx_i_count_op2_async(bmx_ctx* ctx, int op, const bmx_vec* a, const bmx_vec* b, int slot);

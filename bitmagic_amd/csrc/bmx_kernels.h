@@ -184,6 +184,36 @@ void k_emit_blocks(const uint4* __restrict__ raw, u32 nblocks, const BlockStat* 
 }
 
 // ---------------------------------------------------------------------------
+// upload: GAP blocks of the host slab (raw, back to back as in a freeze()d arena,
+// src/bmblocks.h:2614-2655) -> 16-byte aligned blocks of the device slab, validated
+// on the way (the kernels index LDS with the run ends, so a malformed block must never
+// get in): word[len] == 65535 (gap_max_bits - 1) and run ends strictly ascending
+// (gap block invariant, src/bmfunc.h:1844-1896).  One wave per block; *err |= 1 on a violation.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256)
+void k_gap_repack(const u16* __restrict__ raw, const u32* __restrict__ src_off, const u64* __restrict__ desc,
+                  u32 nblocks, u64* __restrict__ err)
+{
+    u32 lane = lane_id();
+    u32 nb = uniform32(blockIdx.x * 4u + (threadIdx.x >> 6));
+    if (nb >= nblocks) return;
+    u64 d = uniform64(desc[nb]);
+    if (DESC_K(d) != K_GAP) return;
+    const u16* src = raw + src_off[nb];
+    u16* dst = (u16*)(uintptr_t)DESC_P(d);
+    u32 len = GMETA(d) >> 1;
+    u32 padded = (len + 1u + 7u) & ~7u;
+    bool bad = false;
+    for (u32 k = lane; k < padded; k += 64u) {
+        u32 cur = k <= len ? (u32)src[k] : 0u;
+        if (k >= 2u && k <= len && (u32)src[k - 1u] >= cur) bad = true;
+        if (k == len && cur != 65535u) bad = true;
+        dst[k] = (u16)cur;
+    }
+    if (__ballot(bad) != 0ull && lane == 0) atomicOr(reinterpret_cast<unsigned long long*>(err), 1ull);
+}
+
+// ---------------------------------------------------------------------------
 // load any block kind into registers (NULL -> zeros, FULL -> ones, GAP decoded)
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ void blk_from_desc(u64 d, Blk& b, u32* lds, u32 lane)
@@ -385,17 +415,30 @@ void k_pipe_counts(const u64* __restrict__ dmat, const u32* __restrict__ row_off
 
 // ---------------------------------------------------------------------------
 // Bit-block-only fast path of the same computation (pipelines whose operands
-// contain no GAP block: the headline case).  A work item is one ROWS/8 slice
-// of a (column, group): ROWS register rows = ROWS KiB of every operand block.
-// Smaller items = more independent waves, shorter ramp-up and drain tail;
-// the early-exit test becomes per slice (finer than the reference's digest).
-// NT selects non-temporal loads (streamed-once data).
+// contain no GAP block: the headline case), software-pipelined (pipe_chain):
+//  * operand pointers are wave-uniform and read with scalar loads one batch ahead;
+//  * two register buffers: the loads of batch n+1 are issued before batch n is
+//    consumed, so a wave always has U..2U slices in flight;
+//  * the tail batch re-uses its last operand (AND / AND-NOT are idempotent), so
+//    there is no remainder loop.
+// A work item is one ROWS/8 slice of a (column, group): ROWS register rows = ROWS KiB of
+// every operand block, slices of one column adjacent in the item order (the waves of a
+// workgroup read one contiguous stretch of every operand).  ROWS = 8 (whole blocks) is the
+// measured best when there are >= ~12 k columns (tools/tune_pipe.py); a block-range shard
+// of a multi-GPU job (1,907 columns per GPU for 1e9 bits on 8 GPUs) is cut into smaller
+// slices so that the chip still sees thousands of independent waves (bmx.hip pipe_rows_auto);
+// the early-exit test is then per slice (finer than the reference's digest, same result).
+// Measured alternatives that did NOT win on MI355X at full size (same box, interleaved A/B,
+// 256 x 1e9 bits): occupancy pinned to 8 waves/SIMD with a one-block-in-flight loop (-7 %),
+// hand-placed asm loads with counted vmcnt (-5 %, and hipcc may copy an asm-loaded register
+// before the wait), dropping the early-exit test (-2 %), a persistent grid drawing columns
+// from per-XCD ticket counters (+-0.5 %: turnover and tail are not the gap).
 // ---------------------------------------------------------------------------
-template <int U, int ROWS, bool NT>
-__global__ __launch_bounds__(256)
-void k_pipe_counts_bits(const u64* __restrict__ dmat, const u32* __restrict__ row_off,
-                        const u32* __restrict__ and_n, u32 col_stride,
-                        u32 ngroups, u32 col_from, u32 nitems, int xcd_swz, u64* __restrict__ counts)
+template <int U, bool NT, int WG = 256, int ROWS = 8>
+__global__ __launch_bounds__(WG)
+void k_pipe_counts_bits2(const u64* __restrict__ dmat, const u32* __restrict__ row_off,
+                         const u32* __restrict__ and_n, u32 col_stride,
+                         u32 ngroups, u32 col_from, u32 nitems, int xcd_swz, u64* __restrict__ counts)
 {
     constexpr u32 PARTS = 8 / ROWS;
     u32 lane = lane_id(), wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
@@ -413,45 +456,11 @@ void k_pipe_counts_bits(const u64* __restrict__ dmat, const u32* __restrict__ ro
     const u64* pa = row + 2;
     const u64* ps = pa + na;
     const u32 poff = part * ROWS * 64u;          // in 16-byte units
-
     Part<ROWS> acc;
-    u32 k = 0;
-    if (flags & ROW_ONES) {
 #pragma unroll
-        for (int i = 0; i < ROWS; ++i) acc.r[i] = (u32x4)(~0u);
-    } else { part_load<ROWS, NT>(acc, as_gc4(uniform64(pa[0])) + poff, lane); k = 1; }
-    for (; k + U <= nba; k += U) {
-        Part<ROWS> t[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) part_load<ROWS, NT>(t[u], as_gc4(uniform64(pa[k + u])) + poff, lane);
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-#pragma unroll
-            for (int i = 0; i < ROWS; ++i) acc.r[i] &= t[u].r[i];
-        if (part_is_zero<ROWS>(acc)) return;
-    }
-    for (; k < nba; ++k) {
-        Part<ROWS> t; part_load<ROWS, NT>(t, as_gc4(uniform64(pa[k])) + poff, lane);
-#pragma unroll
-        for (int i = 0; i < ROWS; ++i) acc.r[i] &= t.r[i];
-    }
-    if (part_is_zero<ROWS>(acc)) return;
-    k = 0;
-    for (; k + U <= nbs; k += U) {
-        Part<ROWS> t[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) part_load<ROWS, NT>(t[u], as_gc4(uniform64(ps[k + u])) + poff, lane);
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-#pragma unroll
-            for (int i = 0; i < ROWS; ++i) acc.r[i] &= ~t[u].r[i];
-        if (part_is_zero<ROWS>(acc)) return;
-    }
-    for (; k < nbs; ++k) {
-        Part<ROWS> t; part_load<ROWS, NT>(t, as_gc4(uniform64(ps[k])) + poff, lane);
-#pragma unroll
-        for (int i = 0; i < ROWS; ++i) acc.r[i] &= ~t.r[i];
-    }
+    for (int i = 0; i < ROWS; ++i) acc.r[i] = (u32x4)(~0u);
+    if (pipe_chain<U, NT, 0, ROWS>(acc, pa, nba, lane, poff)) return;
+    if (pipe_chain<U, NT, 1, ROWS>(acc, ps, nbs, lane, poff)) return;
     u32 cnt = 0;
 #pragma unroll
     for (int i = 0; i < ROWS; ++i) {
@@ -462,57 +471,7 @@ void k_pipe_counts_bits(const u64* __restrict__ dmat, const u32* __restrict__ ro
     if (lane == 0 && cnt) atomicAdd(reinterpret_cast<unsigned long long*>(&counts[g]), (unsigned long long)cnt);
 }
 
-// ---------------------------------------------------------------------------
-// v2 of the bit-block-only fast path: software-pipelined.
-//  * operand pointers are fetched 64 at a time with ONE coalesced vector load
-//    (lane l keeps pointer 64*c + l) and handed out with v_readlane -- no scalar
-//    memory latency inside the operand loop;
-//  * two register buffers: the loads of batch n+1 are issued before batch n is
-//    consumed, so a wave always has U..2U blocks in flight;
-//  * the tail batch re-uses its last operand (AND / AND-NOT are idempotent), so
-//    there is no remainder loop.
-// Whole blocks per wave (ROWS = 8) only: measured best (tools/tune_pipe.py).
-// Measured alternatives that did NOT win on MI355X (same box, interleaved A/B, 256 x 1e9 bits):
-//   slices of 4/2/1 KiB per wave (-3..-8 %), occupancy pinned to 8 waves/SIMD with a
-//   one-block-in-flight loop (-7 %), hand-placed asm loads with counted vmcnt (-5 %, and hipcc
-//   may copy an asm-loaded register before the wait), dropping the early-exit test (-2 %).
-//   a persistent grid drawing columns from per-XCD ticket counters (+-0.5 %: turnover and tail are not the gap).
-// ---------------------------------------------------------------------------
-template <int U, bool NT, int WG = 256>
-__global__ __launch_bounds__(WG)
-void k_pipe_counts_bits2(const u64* __restrict__ dmat, const u32* __restrict__ row_off,
-                         const u32* __restrict__ and_n, u32 col_stride,
-                         u32 ngroups, u32 col_from, u32 nitems, int xcd_swz, u64* __restrict__ counts)
-{
-    extern __shared__ u32 lds_unused[];          // only an occupancy throttle for experiments ("pipe_lds")
-    u32 lane = lane_id(), wave = threadIdx.x >> 6, wpb = blockDim.x >> 6;
-    u32 bid = xcd_swz ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
-    u32 item = uniform32(bid * wpb + wave);
-    if (item >= nitems) return;
-    u32 c = item / ngroups, g = item - c * ngroups;
-    const u64* row = dmat + (size_t)(col_from + c) * col_stride + row_off[g];
-    u64 hdr = uniform64(row[0]), flags = uniform64(row[1]);
-    if (flags & ROW_EMPTY) return;
-    if (flags & ROW_FULL) { if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(&counts[g]), 65536ull); return; }
-    u32 nba = (u32)(hdr & 0xFFFFu), nbs = (u32)((hdr >> 32) & 0xFFFFu);
-    u32 na = uniform32(and_n[g]);
-    const u64* pa = row + 2;
-    const u64* ps = pa + na;
-    Part<8> acc;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) acc.r[i] = (u32x4)(~0u);
-    if (pipe_chain<U, NT, false>(acc, pa, nba, lane)) return;
-    if (pipe_chain<U, NT, true>(acc, ps, nbs, lane)) return;
-    u32 cnt = 0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        cnt += __popcll(((u64)acc.r[i].y << 32) | acc.r[i].x);
-        cnt += __popcll(((u64)acc.r[i].w << 32) | acc.r[i].z);
-    }
-    cnt = wave_sum(cnt);
-    if (lane == 0 && cnt) atomicAdd(reinterpret_cast<unsigned long long*>(&counts[g]), (unsigned long long)cnt);
-}
-
+#ifdef BMX_DIAG
 // same read pattern through raw buffer loads with an explicit cache policy (AUX: 1 = sc0, 2 = nt, 16 = sc1):
 // measures what the memory system does with each policy for a pure stream
 template <int AUX>
@@ -535,6 +494,8 @@ void k_diag_stream_read_buf(const uint4* __restrict__ buf, u64 nblocks8k, u32 bl
     }
     if ((acc.x | acc.y | acc.z | acc.w) == 0x12345678u) sink[0] = 1;
 }
+
+#endif  // BMX_DIAG
 
 // algorithmic operand bytes of the rows in [col_from, col_from+ncols)
 __global__ __launch_bounds__(256)
@@ -564,6 +525,7 @@ void k_pipe_bytes(const u64* __restrict__ dmat, const u32* __restrict__ row_off,
     if (threadIdx.x == 0 && s[0]) atomicAdd(reinterpret_cast<unsigned long long*>(total), (unsigned long long)s[0]);
 }
 
+#ifdef BMX_DIAG
 // ---------------------------------------------------------------------------
 // diagnostics: plain streaming read of a large buffer (practical HBM ceiling of
 // the box, measured next to the product kernels by tools/tune_pipe.py)
@@ -592,3 +554,4 @@ void k_diag_stream_read(const uint4* __restrict__ buf, u64 nblocks8k, u32 blocks
     }
     if ((acc.x | acc.y | acc.z | acc.w) == 0x12345678u) sink[0] = 1;   // never true for the memset pattern; defeats DCE
 }
+#endif  // BMX_DIAG

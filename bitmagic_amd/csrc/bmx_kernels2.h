@@ -21,7 +21,10 @@
 //                  all-zero -> NULL, too long -> bit-block)
 //   ST_TEST_ZERO / ST_TEST_ONE   without opt_compress a computed block is stored as a bit-block unless the
 //                  operation itself tests it: all-zero -> NULL (B x B except OR, any AND, GAP - B), all-ones -> FULL (B OR B)
-enum { ST_OPT = 1, ST_FORCE_BIT = 2, ST_TEST_ZERO = 4, ST_TEST_ONE = 8, ST_FORCE_GAP = 16 };
+//   ST_GAP_RESULT  a GAP x GAP result goes through clone_gap_block(i, j, tmp_buf, len) (src/bmblocks.h:865-889,
+//                  called from combine_operation_block_* src/bm.h:7133,6975,7050,7319): only an all-ZERO level-0
+//                  result is dropped; an all-ones result stays a GAP block of ONE run (it does not become FULL)
+enum { ST_OPT = 1, ST_FORCE_BIT = 2, ST_TEST_ZERO = 4, ST_TEST_ONE = 8, ST_FORCE_GAP = 16, ST_GAP_RESULT = 32 };
 
 __device__ __forceinline__ void store_result_mode(const Blk& acc, u32 nb, u32 mode,
                                                   uint4* __restrict__ slab, u64* __restrict__ desc,
@@ -33,9 +36,10 @@ __device__ __forceinline__ void store_result_mode(const Blk& acc, u32 nb, u32 mo
     u32 first = __shfl(acc.r[0].x, 0, 64) & 1u;
     u32 kind;
     if (mode & ST_FORCE_BIT) kind = K_BIT;
-    else if (mode & (ST_FORCE_GAP | ST_OPT))
+    else if (mode & (ST_FORCE_GAP | ST_OPT)) {
         kind = (runs == 1u) ? (first ? K_FULL : K_NULL) : (runs < 1276u ? K_GAP : K_BIT);
-    else {
+        if ((mode & ST_GAP_RESULT) && runs == 1u && first) kind = K_GAP;      // 1-run GAP block [hdr, 65535]
+    } else {
         kind = K_BIT;
         if ((mode & ST_TEST_ZERO) && runs == 1u && !first) kind = K_NULL;
         if ((mode & ST_TEST_ONE) && runs == 1u && first) kind = K_FULL;
@@ -118,6 +122,37 @@ void k_emit_gaps(const uint4* __restrict__ slab, u32 nblocks, const BlockStat* _
     }
 }
 
+// result slab -> right-sized slab: bit-block nb moves to ordinal offs[nb] (from k_scan_layout) and its
+// descriptor follows.  One wave per block column.
+__global__ __launch_bounds__(256)
+void k_compact_bits(const uint4* __restrict__ slab, u32 nblocks, const BlockStat* __restrict__ st,
+                    const u32* __restrict__ offs, uint4* __restrict__ packed, u64* __restrict__ desc)
+{
+    u32 lane = lane_id();
+    u32 nb = uniform32(blockIdx.x * 4u + (threadIdx.x >> 6));
+    if (nb >= nblocks) return;
+    if (uniform32(st[nb].kind) != K_BIT) return;
+    Blk b;
+    blk_load(b, as_gc4(slab + (size_t)nb * 512u), lane);
+    uint4* dst = packed + (size_t)uniform32(offs[nb]) * 512u;
+    blk_store(b, as_g4(dst), lane);
+    if (lane == 0) desc[nb] = DESC_MAKE(dst, K_BIT);
+}
+
+// download of a slab with unused slots: bit-block nb -> out[ord[nb]]
+__global__ __launch_bounds__(256)
+void k_gather_bits(const u64* __restrict__ desc, const u32* __restrict__ ord, u32 nblocks, uint4* __restrict__ out)
+{
+    u32 lane = lane_id();
+    u32 nb = uniform32(blockIdx.x * 4u + (threadIdx.x >> 6));
+    if (nb >= nblocks) return;
+    u64 d = uniform64(desc[nb]);
+    if (DESC_K(d) != K_BIT) return;
+    Blk b;
+    blk_load(b, as_gc4(DESC_P(d)), lane);
+    blk_store(b, as_g4(out + (size_t)uniform32(ord[nb]) * 512u), lane);
+}
+
 // descriptors of a cloned vector: same kinds, pointers moved into the clone's slabs
 __global__ __launch_bounds__(256)
 void k_rebase_desc(const u64* __restrict__ in, u64* __restrict__ out, u32 n, u64 old_bits, u64 new_bits, u64 old_gaps, u64 new_gaps)
@@ -179,7 +214,8 @@ void k_op2(int op, const u64* __restrict__ da, u32 na, const u64* __restrict__ d
     else if (op == BMX_XOR) { if (ka == K_NULL || ka == K_FULL) copy_of = kb; else if (kb == K_NULL || kb == K_FULL) copy_of = ka; }
     else { if (kb == K_NULL) copy_of = ka; }
     if (copy_of == K_BIT) mode = ST_FORCE_BIT;
-    else if (copy_of == K_GAP || (ka == K_GAP && kb == K_GAP)) mode = ST_FORCE_GAP;
+    else if (copy_of == K_GAP) mode = ST_FORCE_GAP;
+    else if (ka == K_GAP && kb == K_GAP) mode = ST_FORCE_GAP | ST_GAP_RESULT;
     else if (opt_compress) mode = ST_OPT;
     else {
         bool bb = ka != K_GAP && kb != K_GAP;                 // bit x bit (FULL in SUB counts as a real all-ones block)

@@ -74,8 +74,10 @@ int bmx_device_count(int* n);
 int bmx_ctx_create(int device, void* stream, bmx_ctx** out);
 int bmx_ctx_destroy(bmx_ctx* ctx);
 int bmx_ctx_synchronize(bmx_ctx* ctx);
-/* launch-shape knobs of the counts pipeline (results never depend on them):
- * "pipe_unroll" 1|2|4, "pipe_rows" 8|4|2|1, "pipe_nt" 0|1, "pipe_wg" 64..768 (multiples of 64), "pipe_ver" 1|2, "pipe_staged" -1|0|1, "pipe_slots" 8|16, "xcd_swizzle" 0|1 */
+/* launch-shape knobs of the counts pipeline (results never depend on them; 0 / -1 = automatic):
+ * "pipe_rows" 0|8|4|2|1 (KiB of a block per work item), "pipe_unroll" 0|1|2|4|8|16, "pipe_nt" 0|1,
+ * "pipe_wg" 64..1024 (multiples of 64; the default build carries 256 and 384), "pipe_staged" -1|0|1, "pipe_slots" 8|16,
+ * "pipe_split" -1|0|1, "or_tile" 0..3, "xcd_swizzle" 0|1.  Environment twins (BMX_PIPE_ROWS, ...) pass the same checks. */
 int bmx_ctx_set_tuning(bmx_ctx* ctx, const char* key, int value);
 /* The context keeps freed device blocks in a size-keyed cache (results of same-shaped
  * operations re-use them instead of paying hipMalloc/hipFree, which synchronises the
@@ -163,7 +165,10 @@ int bmx_agg_shift_right_and(bmx_ctx* ctx, const bmx_vec* const* src, size_t n, i
 int bmx_agg_shift_right_and_count(bmx_ctx* ctx, const bmx_vec* const* src, size_t n, uint64_t* count);
 /* aggregator::pipeline<agg_opt_only_counts>  src/bmaggregator.h:62-103,222-341:
  * arg-groups are given as concatenated operand lists, and_n[g] / sub_n[g] per
- * group (pipeline::add() + arg_groups::add(bv, 0|1) + complete(), :2784-2931). */
+ * group (pipeline::add() + arg_groups::add(bv, 0|1) + complete(), :2784-2931).
+ * Lifetime: like the reference's pipeline, which stores bvector POINTERS (:2939), the object references its
+ * operand vectors: they must stay alive (not bmx_vec_free'd) until bmx_pipeline_destroy.
+ * Limits: < 2^20 groups, <= 65535 operands per list, total operands + 2 x groups < 2^32 (else BMX_ERR_RANGE). */
 int bmx_pipeline_create(bmx_ctx* ctx,
                         const bmx_vec* const* and_list, const uint32_t* and_n,
                         const bmx_vec* const* sub_list, const uint32_t* sub_n,
@@ -214,12 +219,63 @@ int bmx_rank_batch_dev(bmx_ctx* ctx, const bmx_vec* v, const bmx_rs* rs,
 int bmx_select_batch_dev(bmx_ctx* ctx, const bmx_vec* v, const bmx_rs* rs,
                          const uint64_t* d_rank, size_t q, uint64_t* d_pos, uint8_t* d_found);
 
-/* ---- diagnostics ---- */
-/* plain streaming read of a scratch buffer: the practical HBM read ceiling of this box,
- * to put next to the product kernels (tools/tune_pipe.py).  ms_per_pass = avg of iters passes. */
-int bmx_diag_stream_read(bmx_ctx* ctx, uint64_t bytes, int nontemporal, uint32_t blocks_per_wave,
-                         int pattern /* 0 contiguous per wave, 1 strided like an N-way aggregation */,
-                         int iters, float* ms_per_pass);
+/* ---- multi-GPU: device groups (SURVEY.md section 8(b) "init with a device list", section 8(e)) ----
+ * Every block column (i,j) is independent for AND/OR/XOR/SUB/COUNT (src/bmaggregator.h:1113-1121,1184-1218,
+ * src/bm.h:6226-6271), so a group of n devices shards the linear block range [0, nblocks) into n contiguous
+ * pieces: member m holds blocks bmx_group_shard_range(nblocks, m) of EVERY vector (a "sharded vector",
+ * bmx_gvec); operand bits never cross xGMI.  One host thread drives all members: kernels are enqueued on every
+ * member's stream before the first one is waited for; the only exchange is the sum of the per-member popcounts
+ * (8 B per arg-group), done on the host (default) or by an RCCL all-reduce over xGMI (BMX_GROUP_RCCL; librccl is
+ * loaded on demand, devices must be distinct).  Materialised results stay sharded; bmx_gvec_download gathers.
+ * A device may appear several times in `devices` (several streams on one GPU; what the 1-GPU tests use). */
+typedef struct bmx_group     bmx_group;
+typedef struct bmx_gvec      bmx_gvec;
+typedef struct bmx_gpipeline bmx_gpipeline;
+#define BMX_GROUP_HOST_SUM 0
+#define BMX_GROUP_RCCL     1
+int bmx_group_create(const int* devices, int n, int flags, bmx_group** out);
+int bmx_group_destroy(bmx_group* g);
+int bmx_group_size(const bmx_group* g, int* n);
+/* member m's context (owned by the group): e.g. to set tuning knobs or upload private vectors */
+int bmx_group_ctx(const bmx_group* g, int member, bmx_ctx** ctx);
+/* contiguous, exhaustive, balanced to within one block */
+int bmx_group_shard_range(const bmx_group* g, uint32_t nblocks, int member, uint32_t* nb_from, uint32_t* nb_to);
+/* bmx_vec_upload for a group: the block table is cut at the shard borders, every member receives its piece */
+int bmx_gvec_upload(bmx_group* g, uint64_t nbits, uint32_t nblocks,
+                    const uint8_t* kinds, const uint32_t* offs,
+                    const uint32_t* bit_slab, uint32_t n_bit_blocks,
+                    const uint16_t* gap_slab, uint64_t gap_words, bmx_gvec** out);
+/* bmx_vec_generate for a group: every member generates its own block range (bmx_vec_generate_shard) */
+int bmx_gvec_generate(bmx_group* g, uint64_t seed, uint32_t vec_id, int with_common,
+                      uint32_t density_q16, uint64_t nbits, int optimize, bmx_gvec** out);
+int bmx_gvec_free(bmx_group* g, bmx_gvec* v);
+/* totals over the shards; bit_slab_blocks / gap_words size the buffers of bmx_gvec_download */
+int bmx_gvec_info(const bmx_gvec* v, uint64_t* nbits, uint32_t* nblocks, uint32_t counts[4],
+                  uint32_t* bit_slab_blocks, uint64_t* gap_words);
+/* member m's shard (owned by the gvec; lives on bmx_group_ctx(g, m)) */
+int bmx_gvec_shard(const bmx_gvec* v, int member, const bmx_vec** shard);
+/* gathers the shards into ONE block table (same layout as bmx_vec_download) */
+int bmx_gvec_download(bmx_group* g, const bmx_gvec* v, uint8_t* kinds, uint32_t* offs,
+                      uint32_t* bit_slab, uint16_t* gap_slab);
+/* bvector::count() / bm::count_* over all shards: n kernels in flight at once, one sum */
+int bmx_gvec_count(bmx_group* g, const bmx_gvec* a, uint64_t* count);
+int bmx_gvec_count_op2(bmx_group* g, int op, const bmx_gvec* a, const bmx_gvec* b, uint64_t* count);
+/* bvector::bit_and/or/xor/sub (3-operand), result sharded like the operands */
+int bmx_gvec_op2(bmx_group* g, int op, const bmx_gvec* a, const bmx_gvec* b, int opt_compress, bmx_gvec** result);
+/* aggregator::combine_or / combine_and_sub over sharded vectors (src/bmaggregator.h:1101,1162) */
+int bmx_gagg_or(bmx_group* g, const bmx_gvec* const* src, size_t n, int opt_compress, bmx_gvec** result);
+int bmx_gagg_and_sub(bmx_group* g, const bmx_gvec* const* src_and, size_t n_and,
+                     const bmx_gvec* const* src_sub, size_t n_sub, bmx_gvec** result, int* any);
+/* aggregator::pipeline + combine_and_sub(pipe), counts only (src/bmaggregator.h:1292-1399): member m runs the
+ * pipeline over its shard of every operand, counts_out[g] = sum over the members */
+int bmx_gpipeline_create(bmx_group* g,
+                         const bmx_gvec* const* and_list, const uint32_t* and_n,
+                         const bmx_gvec* const* sub_list, const uint32_t* sub_n,
+                         size_t ngroups, bmx_gpipeline** out);
+int bmx_gpipeline_destroy(bmx_group* g, bmx_gpipeline* p);
+int bmx_gpipeline_run_counts(bmx_group* g, bmx_gpipeline* p, uint64_t* counts_out);
+/* per-member device time of the last bmx_gpipeline_run_counts (HIP events on the member streams), ms[n] */
+int bmx_gpipeline_last_ms(bmx_group* g, const bmx_gpipeline* p, float* ms);
 
 /* ---- timing helper: HIP events on the context's stream ---- */
 int bmx_timer_start(bmx_ctx* ctx);

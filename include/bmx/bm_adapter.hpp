@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "bvector.hpp"
+#include "group.hpp"
 
 namespace bmx {
 
@@ -109,8 +110,9 @@ bool flatten_view(const BMBV& bv, uint32_t nblocks, block_table& t,
 
 /// host bm::bvector<>  ->  device bmx::bvector.  A frozen (read-only, arena-backed) vector is uploaded
 /// straight from its arena -- no host-side gather; returns true when that path was taken.
-template <class BMBV>
-bool upload(const BMBV& src, bvector& dst, uint32_t nblocks = 0)
+/// DST = bmx::bvector (one GPU) or bmx::gbvector (block-range shards over a device group).
+template <class BMBV, class DST>
+bool upload(const BMBV& src, DST& dst, uint32_t nblocks = 0)
 {
     if (!nblocks) nblocks = effective_blocks(src);
     uint64_t nbits = (uint64_t)nblocks * BMX_BLOCK_BITS;
@@ -190,6 +192,20 @@ void download(const bvector& src, BMBV& dst)
     std::vector<uint32_t> bits((size_t)slab_blocks * BMX_BLOCK_WORDS); std::vector<uint16_t> gaps(gap_words);
     check(bmx_vec_download(src.get_context().handle(), src.handle(), kinds.data(), offs.data(),
                            bits.empty() ? nullptr : bits.data(), gaps.empty() ? nullptr : gaps.data()));
+    install(dst, nblocks, kinds.data(), offs.data(), bits.data(), gaps.data());
+}
+
+/// sharded device vector (device group)  ->  host bm::bvector<>: the shards are gathered into one block table
+template <class BMBV>
+void download(const gbvector& src, BMBV& dst)
+{
+    if (src.empty_handle()) { dst.clear(true); return; }
+    uint64_t nbits = 0, gap_words = 0; uint32_t nblocks = 0, slab_blocks = 0; uint32_t counts[4];
+    check(bmx_gvec_info(src.handle(), &nbits, &nblocks, counts, &slab_blocks, &gap_words));
+    std::vector<uint8_t> kinds(nblocks ? nblocks : 1); std::vector<uint32_t> offs(nblocks ? nblocks : 1);
+    std::vector<uint32_t> bits((size_t)slab_blocks * BMX_BLOCK_WORDS); std::vector<uint16_t> gaps(gap_words);
+    check(bmx_gvec_download(src.get_group().handle(), src.handle(), kinds.data(), offs.data(),
+                            bits.empty() ? nullptr : bits.data(), gaps.empty() ? nullptr : gaps.data()));
     install(dst, nblocks, kinds.data(), offs.data(), bits.data(), gaps.data());
 }
 

@@ -1,0 +1,128 @@
+"""GPU: the multi-device group layer of the C-ABI (include/bmx.h "device groups") on ONE MI355X -- a group may
+list a device several times, so the 1-GPU box runs 3- and 8-member groups (one stream per member).  Everything a
+group computes must equal what a single context computes and what the oracle says: block columns are independent
+(src/bmaggregator.h:1184-1218), so block-range shards add up / concatenate exactly."""
+import numpy as np
+import pytest
+
+import bitmagic_amd as bm
+
+pytestmark = pytest.mark.gpu
+
+SEED = 0xB17A61C
+
+
+def _vectors(port, nvec, nbits, dens, seed0=0, common=False):
+    words = [port.gen_words(SEED + 17, seed0 + v, dens[v % len(dens)], nbits, with_common=common) for v in range(nvec)]
+    return words, [port.import_words(w, True, nbits) for w in words]
+
+
+@pytest.mark.parametrize("members", [1, 3, 8])
+def test_group_matches_single_context_and_oracle(ctx, port, members):
+    nbits = 37 * 65536 + 4321                     # 38 blocks: uneven shards for 3 and 8 members
+    words, pv = _vectors(port, 9, nbits, [6554, 300, 30000, 2, 655])     # bit, GAP, dense, nearly empty, mixed
+    grp = bm.group([0] * members)
+    assert grp.size() == members
+    r = [grp.shard_range(38, m) for m in range(members)]
+    assert r[0][0] == 0 and r[-1][1] == 38 and all(a[1] == b[0] for a, b in zip(r, r[1:]))
+    gv = [bm.gbvector.from_block_table(grp, nbits, *p.flatten()) for p in pv]
+    sv = [bm.bvector.from_block_table(ctx, nbits, *p.flatten()) for p in pv]
+    for g, s, p in zip(gv, sv, pv):
+        assert g.count() == s.count() == p.count()
+        assert g.info()["counts"] == s.info()["counts"]
+        k, o, b, gp = g.block_table()
+        ek, eo, eb, egp = p.flatten()
+        assert k.tolist() == ek.tolist()
+        # content: install the gathered table into a single-context vector and compare words
+        back = bm.bvector.from_block_table(ctx, nbits, k, o, b, gp)
+        assert (back.to_words() == p.to_words()).all()
+    for op in range(4):
+        for i, j in ((0, 1), (1, 2), (4, 0), (3, 3 - 1)):
+            assert bm.gbvector.count_op2(op, gv[i], gv[j]) == port.count_op2(op, pv[i], pv[j])
+            for oc in (bm.opt_none, bm.opt_compress):
+                t = bm.gbvector._op2(op, gv[i], gv[j], oc)
+                e = port.op2(op, pv[i], pv[j], oc == bm.opt_compress)
+                assert t.count() == e.count()
+                assert t.block_table()[0].tolist() == e.flatten()[0].tolist(), (op, i, j, oc)
+    agg = bm.gaggregator(grp)
+    t, any_ = agg.combine_and_sub([gv[0], gv[2]], [gv[1], gv[4]])
+    e = port.agg_and_sub([pv[0], pv[2]], [pv[1], pv[4]])
+    assert t.count() == e.count() and any_ == (e.count() > 0)
+    assert t.block_table()[0].tolist() == e.flatten()[0].tolist()
+    for oc in (False, True):
+        agg.set_optimization(oc)
+        o = agg.combine_or(gv)
+        eo = port.agg_or(pv, oc)
+        assert o.count() == eo.count() and o.block_table()[0].tolist() == eo.flatten()[0].tolist()
+    groups = [(list(range(3)), []), ([0, 2], [1, 4]), ([0], []), ([2, 0], [3])]
+    pipe = bm.gaggregator.pipeline(grp)
+    for a, s in groups:
+        ag = pipe.add()
+        for i in a: ag.add(gv[i], 0)
+        for i in s: ag.add(gv[i], 1)
+    pipe.complete()
+    got = agg.combine_and_sub(pipe)
+    exp = port.pipeline_counts([([pv[i] for i in a], [pv[i] for i in s]) for a, s in groups])
+    assert (got == exp).all(), (got, exp)
+    ms = pipe.last_ms()
+    assert len(ms) == members and all(x >= 0 for x in ms)
+    grp.close()
+
+
+def test_group_generate_equals_single_generate(ctx, port):
+    """bmx_gvec_generate: every member generates its own block range of the SAME logical vector"""
+    nbits = 100 * 65536 + 99
+    grp = bm.group([0, 0, 0, 0])
+    for vid, dq, common in ((1, 6554, True), (2, 200, False)):
+        g = bm.gbvector.generate(grp, SEED, vid, dq, nbits, with_common=common)
+        s = bm.bvector.generate(ctx, SEED, vid, dq, nbits, with_common=common)
+        assert g.count() == s.count()
+        assert g.block_table()[0].tolist() == s.block_table()[0].tolist()
+    grp.close()
+
+
+def test_group_rccl_single_member(ctx, port):
+    """BMX_GROUP_RCCL on the one device of this box: librccl is loaded on demand, ncclCommInitAll(1), the counts
+    go through ncclAllReduce (a 1-rank all-reduce) -- the code path the 8-GPU job takes"""
+    nbits = 20 * 65536
+    words, pv = _vectors(port, 4, nbits, [6554, 20000])
+    try:
+        grp = bm.group([0], bm.GROUP_RCCL)
+    except bm.BmxError as e:
+        pytest.fail(f"RCCL group could not be created: {e}")
+    gv = [bm.gbvector.from_block_table(grp, nbits, *p.flatten()) for p in pv]
+    agg = bm.gaggregator(grp)
+    pipe = bm.gaggregator.pipeline(grp)
+    for a, s in (([0, 1, 2], []), ([0], [3])):
+        ag = pipe.add()
+        for i in a: ag.add(gv[i], 0)
+        for i in s: ag.add(gv[i], 1)
+    pipe.complete()
+    got = agg.combine_and_sub(pipe)
+    exp = port.pipeline_counts([([pv[0], pv[1], pv[2]], []), ([pv[0]], [pv[3]])])
+    assert (got == exp).all()
+    with pytest.raises(bm.BmxError):
+        bm.group([0, 0], bm.GROUP_RCCL)          # RCCL needs distinct devices
+    grp.close()
+
+
+def test_group_full_size_headline_shards(ctx):
+    """BASELINE configs[2] shape through the group API at reduced width: 32 x 1e9-bit vectors, 8 members on one
+    GPU; the sharded count equals the single-context count (size-independent property: shard sums = total)"""
+    nbits, nvec = 1_000_000_000, 32
+    grp = bm.group([0] * 8)
+    gv = [bm.gbvector.generate(grp, SEED, v, 6554, nbits, with_common=True) for v in range(nvec)]
+    agg = bm.gaggregator(grp)
+    pipe = bm.gaggregator.pipeline(grp)
+    ag = pipe.add()
+    for v in gv: ag.add(v, 0)
+    pipe.complete()
+    got = int(agg.combine_and_sub(pipe)[0])
+    del pipe, gv
+    grp.close()
+    sv = [bm.bvector.generate(ctx, SEED, v, 6554, nbits, with_common=True) for v in range(nvec)]
+    a = bm.aggregator(ctx); p = bm.aggregator.pipeline(ctx); g = p.add()
+    for v in sv: g.add(v, 0)
+    p.complete()
+    exp = int(a.combine_and_sub(p)[0])
+    assert got == exp and got > 90_000_000

@@ -86,9 +86,9 @@ def test_golden_case(ctx, port, golden, case):
             tc = f(up[i], vecs[j], bm.opt_compress)
             assert sha(tc.to_words(nwb)) == e["sha"]
             kk = tc.block_table()[0].tolist()
-            # representation: identical to the reference except that a GAP x GAP result that is
-            # all-ones stays a 1-run GAP block there (clone_gap_block) and is FULL here
-            assert all(a == b or (a == bm.FULL and b == bm.GAP) for a, b in zip(kk, e["kinds_opt"])), (kk, e["kinds_opt"])
+            # representation: identical to the reference, including the all-ones GAP x GAP result that
+            # stays a 1-run GAP block (clone_gap_block, src/bmblocks.h:865-889)
+            assert kk == e["kinds_opt"], (op, i, j, kk, e["kinds_opt"])
     agg = bm.aggregator(ctx)
     for e in g["agg_and_sub"]:
         t, any_ = agg.combine_and_sub([vecs[i] for i in e["and"]], [up[i] for i in e["sub"]])
@@ -402,16 +402,24 @@ def test_launch_shape_knobs_do_not_change_results(ctx, port):
     pipe.complete()
     agg = bm.aggregator(ctx)
     try:
-        for ver in (1, 2):
-            for u in (1, 2, 4):
-                for rows in ((8, 4, 2, 1) if ver == 1 else (8,)):
-                    for nt in (0, 1):
-                        for wg, swz in ((256, 1), (64, 0), (128, 1)) + (((384, 1), (512, 0), (768, 1)) if (ver == 2 and u == 4) else ()):
-                            for k, x in (("pipe_ver", ver), ("pipe_unroll", u), ("pipe_rows", rows), ("pipe_nt", nt),
-                                         ("pipe_wg", wg), ("xcd_swizzle", swz)):
-                                ctx.set_tuning(k, x)
-                            got = agg.combine_and_sub(pipe)
-                            assert (got == exp).all(), (ver, u, rows, nt, wg, swz)
+        # every launch shape the default build carries: slice sizes 8/4/2/1 KiB x unroll x nt x workgroup size
+        shapes = [(rows, u, 1, wg) for rows in (8, 4, 2, 1) for wg in (384, 256)
+                  for u in ((4,) if rows == 8 else (4, 8) if (rows == 4 or wg == 256) else (4, 8, 16))]
+        shapes += [(rows, 4, 0, 384) for rows in (8, 4, 2, 1)] + [(0, 0, 1, 384)]
+        for rows, u, nt, wg in shapes:
+            for swz in (1, 0):
+                for k, x in (("pipe_unroll", u), ("pipe_rows", rows), ("pipe_nt", nt), ("pipe_wg", wg), ("xcd_swizzle", swz)):
+                    ctx.set_tuning(k, x)
+                got = agg.combine_and_sub(pipe)
+                assert (got == exp).all(), (rows, u, nt, wg, swz)
+                nb = gv[0].info()["nblocks"]
+                parts = sum(agg._run_pipeline(pipe, a, b).astype(np.int64) for a, b in [(0, 3), (3, 4), (4, nb)])
+                assert (parts == exp.astype(np.int64)).all(), (rows, u, nt, wg, swz)
+        ctx.set_tuning("pipe_wg", 192)                          # a shape only the tuning build carries: refused, not mis-launched
+        with pytest.raises(bm.BmxError):
+            agg.combine_and_sub(pipe)
+        for k, x in (("pipe_unroll", 0), ("pipe_rows", 0), ("pipe_nt", 1), ("pipe_wg", 384), ("xcd_swizzle", 1)):
+            ctx.set_tuning(k, x)
         # LDS-staged many-groups kernel forced on (19 planes = 2 chunks, FULL / NULL planes, AND-SUB masks)
         for swz, slots in ((0, 16), (1, 16), (1, 8)):
             ctx.set_tuning("pipe_staged", 1); ctx.set_tuning("xcd_swizzle", swz); ctx.set_tuning("pipe_slots", slots)
@@ -421,7 +429,7 @@ def test_launch_shape_knobs_do_not_change_results(ctx, port):
             parts = sum(agg._run_pipeline(pipe, a, b).astype(np.int64) for a, b in [(0, 5), (5, nb)])
             assert (parts == exp.astype(np.int64)).all()
     finally:
-        for k, x in (("pipe_ver", 2), ("pipe_unroll", 4), ("pipe_rows", 8), ("pipe_nt", 1), ("pipe_wg", 384), ("xcd_swizzle", 1),
+        for k, x in (("pipe_unroll", 0), ("pipe_rows", 0), ("pipe_nt", 1), ("pipe_wg", 384), ("xcd_swizzle", 1),
                      ("pipe_staged", -1), ("pipe_slots", 16)):
             ctx.set_tuning(k, x)
     # the materialising twins use the same fold: every prefix, AND-SUB and OR
@@ -608,7 +616,7 @@ def test_bm64_vectors(ctx, port, golden):
         t = ops[op](vecs[0], vecs[1], bm.opt_compress)
         kk, ek = t.block_table()[0], port.op2(op, pv[0], pv[1], True).flatten()[0]
         assert t.count() == e["count"] == cnts[op](vecs[0], vecs[1])
-        assert all(a == b or (a == bm.FULL and b == bm.GAP) for a, b in zip(kk.tolist(), ek.tolist()))   # DESIGN section 4 note
+        assert kk.tolist() == ek.tolist()
     agg = bm.aggregator(ctx)
     t, any_ = agg.combine_and_sub(vecs[:3], vecs[3:])
     assert t.count() == g["agg_and_sub"]["count"] and ksha(t) == g["agg_and_sub"]["kinds_sha"] and any_

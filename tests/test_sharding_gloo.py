@@ -42,7 +42,17 @@ def _worker(rank, world, port_no, q):
     t = torch.from_numpy(local.astype(np.int64))
     allreduce_counts(t)
     full = P.pipeline_counts(groups)
-    q.put((rank, t.tolist(), [int(x) for x in full]))
+    # strong-scaling bench layout: every rank BUILDS only its block range of every vector (bmx_vec_generate_shard /
+    # gen_words with a word offset) -- the shard of a generated vector equals the generated shard
+    gbits, nv = 21 * 65536 + 777, 5
+    glo, ghi = shard_range(22, rank, world)
+    sh = [P.import_words(P.gen_words(0xB17A61C, v, 6554, gbits, with_common=True, word_off=glo * 2048, nwords=(ghi - glo) * 2048),
+                         True, max(min(gbits, ghi * 65536) - glo * 65536, 0)) for v in range(nv)]
+    t2 = torch.from_numpy(P.pipeline_counts([(sh, [])]).astype(np.int64))
+    allreduce_counts(t2)
+    whole = [P.import_words(P.gen_words(0xB17A61C, v, 6554, gbits, with_common=True), True, gbits) for v in range(nv)]
+    full2 = P.pipeline_counts([(whole, [])])
+    q.put((rank, t.tolist() + t2.tolist(), [int(x) for x in full] + [int(x) for x in full2]))
     dist.destroy_process_group()
 
 
@@ -56,3 +66,22 @@ def test_two_rank_sharded_counts_match_unsharded():
     for p in procs: p.join(60)
     for rank, got, full in res:
         assert got == full, (rank, got, full)
+
+
+def test_bench_allcores_cpu_baseline_protocol():
+    """bench.py's all-cores CPU leg (one block-range replica per worker process, READY/go protocol): the fanned-out
+    full count equals the single-process count of the same workload"""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    import oracle
+    nvec, dq, nbits = 6, 6554, 11 * 65536 + 5
+    out = bench.cpu_baseline_allcores(nvec, dq, nbits, cores=3, reps=2)
+    P = oracle.port()
+    vecs = [P.import_words(P.gen_words(bench.SEED, v, dq, nbits, with_common=True), True, nbits) for v in range(nvec)]
+    assert out["full_count"] == int(P.pipeline_counts([(vecs, [])])[0])
+    assert out["cores_used"] == 3 and out["allcores_gbit_s"] > 0
+    one = bench.cpu_baseline_1core(nvec, dq, nbits, 4, None)
+    sub = [P.import_words(P.gen_words(bench.SEED, v, dq, nbits, with_common=True, word_off=0, nwords=4 * 2048), True, 4 * 65536) for v in range(nvec)]
+    assert one["count"] == int(P.pipeline_counts([(sub, [])])[0]) and one["cores"] == 1
