@@ -302,7 +302,7 @@ def run_headline(args):
         if use_dist:
             ar_us = event_avg_ms(lambda: dist.all_reduce(counts), 20, ctx) * 1e3
         r = {"dt": dt, "ev_ms": ev_ms, "count": total, "op_bytes": op_bytes, "k_ms": k_ms, "ar_us": ar_us,
-             "build_s": t_build, "blocks": hi - lo, "stat0": vecs[0].calc_stat(), "mem": ctx.mem_used(),
+             "build_s": t_build, "blocks": hi - lo, "plan": pipe.describe(), "stat0": vecs[0].calc_stat(), "mem": ctx.mem_used(),
              "pipe": pipe, "vecs": vecs}
         return r
 
@@ -316,7 +316,7 @@ def run_headline(args):
         pipe = main["pipe"]
         t_sh = event_avg_ms(lambda: agg.run_counts_dev(pipe, counts.data_ptr(), lo, hi), 20, ctx)
         b_sh = pipe.operand_bytes(lo, hi)
-        shard_eff = {"blocks": hi - lo, "ms": round(t_sh, 4), "GBps": round(b_sh / t_sh / 1e6, 1),
+        shard_eff = {"blocks": hi - lo, "kernel": pipe.describe(lo, hi), "ms": round(t_sh, 4), "GBps": round(b_sh / t_sh / 1e6, 1),
                      "rate_vs_full": round((b_sh / t_sh) / (main["op_bytes"] / main["k_ms"]), 4),
                      "note": "block columns [0, 1907) of the resident collection = what one of 8 GPUs runs under --scaling strong"}
     gpu_sample = None
@@ -336,8 +336,6 @@ def run_headline(args):
         value = bits_per_step * args.steps / main["dt"] / 1e9
         achieved = main["op_bytes"] / (main["k_ms"] * 1e-3) / 1e9
         traffic, tsrc = traffic_note(f"agg_and_count_{args.nvec}x{args.nbits}")
-        rows = 8 if main["blocks"] >= 12000 else 4 if main["blocks"] >= 6000 else 2 if main["blocks"] >= 3000 else 1   # pipe_rows_auto (bmx.hip)
-        unroll = 4 if rows >= 4 else 8
         res = {
             "metric": METRIC, "value": round(value, 2), "unit": "Gbit/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(main["dt"] / args.steps * 1e3, 4), "higher_is_better": True,
@@ -356,7 +354,7 @@ def run_headline(args):
                        "build_seconds": round(main["build_s"], 2), "hbm_resident_bytes": main["mem"]},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": tsrc,
-                         "kernel": f"k_pipe_counts_bits2<{unroll}, true, 384, {rows}>" if not main["stat0"]["gap_blocks"] else "k_pipe_counts<4>",
+                         "kernel": main["plan"],
                          "algorithmic_bytes_per_launch": main["op_bytes"],
                          "avg_launch_ms": round(main["k_ms"], 4), "scope": "rank 0's GPU",
                          "timing": "hipEvent pair on the launch stream around back-to-back launches of the kernel alone"},

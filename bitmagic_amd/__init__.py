@@ -431,6 +431,12 @@ class pipeline:
         check(lib().bmx_pipeline_operand_bytes(self.ctx._h, self._h, nb_from, nb_to, C.byref(b)))
         return b.value
 
+    def describe(self, nb_from: int = 0, nb_to: int = ID_MAX) -> str:
+        """kernel + launch plan a counts run over the block range takes"""
+        buf = C.create_string_buffer(256)
+        check(lib().bmx_pipeline_describe(self.ctx._h, self._h, nb_from, nb_to, buf, 256))
+        return buf.value.decode()
+
     def __del__(self):
         try:
             if self._h and self.ctx._h:

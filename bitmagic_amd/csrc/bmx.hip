@@ -97,40 +97,73 @@ static int ensure(bmx_ctx* ctx, void** buf, size_t* cur, size_t need)
 // ---- launch shapes of the bit-only counts kernel --------------------------------------------------
 typedef void (*pipe_bits_fn)(const u64*, const u32*, const u32*, u32, u32, u32, u32, int, u64*);
 
-// Slice size by the number of (column, group) items of the run: whole blocks when the chip already gets
-// >= ~12 k waves (the 15,259-column headline), smaller slices for a block-range shard of a multi-GPU job or a
-// short collection, so that every run has >= ~12 k independent waves to hide the HBM latency with.
-static u32 pipe_rows_auto(u64 nitems)
+// Launch plan of the bit-only counts kernel for a run of nitems (column, group) items of whole blocks.
+// One WINDOW = one machine-load of waves: 256 CUs x the waves one CU holds at this workgroup size.  Measured on
+// the headline (tools/tune_pipe.py, profiles/r02): one workgroup of 8-12 waves per CU, windows cut evenly --
+//   wg 640 / window 2560: 86.2 %, wg 576: 86.2 %, wg 512 / 2048: 85.7 %, wg 768 / 3072: 85.3 %, wg 256 / 2048: 84.9 %
+//   of the HBM peak, against 79.1 % for the single launch (wg 384) on the same box.
+// The shape is picked by how evenly the run fills its windows (a 1,908-column shard of an 8-GPU job fills 93 %
+// of a 2,048-wave window and runs at 84 %; 3,815 columns -> 2 x 1,908 at 85.7 %).  Runs much shorter than a
+// window are cut into smaller slices (rows < 8) so the chip still sees >= ~1.4 k waves.
+// Explicit knobs override: pipe_rows, pipe_wg, pipe_unroll, pipe_window (-1 = single launch).
+static u32 pipe_window_cap(u32 wg)
 {
-    if (nitems >= 12000u) return 8u;
-    if (nitems >= 6000u) return 4u;
-    if (nitems >= 3000u) return 2u;
-    return 1u;
+    u32 wpb = wg / 64u;
+    u32 per_cu = wpb >= 7u ? 1u : 12u / wpb;                          // 147 VGPRs: 12 waves per CU
+    return 256u * per_cu * wpb;
 }
-static u32 pipe_unroll_default(u32 rows) { return rows == 8u ? 4u : rows == 4u ? 4u : 8u; }
+static void pipe_plan(const bmx_ctx* ctx, u64 nitems, u32 ngroups, u32& rows, u32& wg, u32& unroll, u32& window)
+{
+    rows = (u32)ctx->pipe_rows;
+    if (!rows) rows = nitems >= 1400u ? 8u : nitems >= 700u ? 4u : nitems >= 350u ? 2u : 1u;
+    unroll = ctx->pipe_unroll ? (u32)ctx->pipe_unroll : (rows >= 4u ? 4u : 8u);
+    u64 n = nitems * (8u / rows);
+    wg = (u32)ctx->pipe_wg;
+    if (!wg) {
+        wg = 256u;
+        if (rows == 8u) {
+            static const u32 cand[3] = {640u, 768u, 512u};               // preference order on equal fill
+            double best = -1.0;
+            for (u32 c : cand) {
+                u64 cap = pipe_window_cap(c), nwin = (n + cap - 1) / cap, per = (n + nwin - 1) / nwin;
+                double fill = (double)per / (double)cap;
+                if (fill > best + 0.02) { best = fill; wg = c; }
+            }
+        }
+    }
+    if (ctx->pipe_window < 0 || (ctx->pipe_window == 0 && ngroups > 4u)) window = 0u;     // many groups: operand re-use in L2 is what matters
+    else if (ctx->pipe_window > 0) window = (u32)ctx->pipe_window;
+    else window = (u32)std::max<u64>(pipe_window_cap(wg) / ((u64)ngroups * (8u / rows)), 1u);
+}
 
 template <int ROWS>
 static pipe_bits_fn pipe_bits_rows(u32 unroll, bool nt, u32 wg)
 {
 #define B2(U, NT, WG) (pipe_bits_fn)k_pipe_counts_bits2<U, NT, WG, ROWS>
-    if (wg == 384 && nt) {
-        if (unroll == 4) return B2(4, true, 384);
-        if constexpr (ROWS <= 4) { if (unroll == 8) return B2(8, true, 384); }
-        if constexpr (ROWS <= 2) { if (unroll == 16) return B2(16, true, 384); }
-    }
-    if (wg == 384 && !nt && unroll == 4) return B2(4, false, 384);
     if (wg == 256 && nt) {
         if (unroll == 4) return B2(4, true, 256);
         if constexpr (ROWS <= 4) { if (unroll == 8) return B2(8, true, 256); }
     }
+    if (wg == 256 && !nt && unroll == 4) return B2(4, false, 256);
+    if constexpr (ROWS == 8) {
+        if (unroll == 4 && nt) switch (wg) { case 384: return B2(4, true, 384); case 512: return B2(4, true, 512);
+                                             case 640: return B2(4, true, 640); case 768: return B2(4, true, 768); default: break; }
+        if (unroll == 4 && !nt && wg == 640) return B2(4, false, 640);
+    }
 #ifdef BMX_TUNE   // shapes of the tuning sweeps (tools/tune_pipe.py): make -C bitmagic_amd/csrc tune
     if constexpr (ROWS == 8) {
         if (nt && unroll == 4) switch (wg) { case 192: return B2(4, true, 192); case 320: return B2(4, true, 320); case 448: return B2(4, true, 448);
-                                             case 512: return B2(4, true, 512); case 576: return B2(4, true, 576); case 640: return B2(4, true, 640);
-                                             case 768: return B2(4, true, 768); default: break; }
-        if (nt && unroll == 2) switch (wg) { case 256: return B2(2, true, 256); case 384: return B2(2, true, 384); case 1024: return B2(2, true, 1024); default: break; }
+                                             case 576: return B2(4, true, 576); default: break; }
+        if (nt && unroll == 2) switch (wg) { case 256: return B2(2, true, 256); case 384: return B2(2, true, 384); case 640: return B2(2, true, 640);
+                                             case 1024: return B2(2, true, 1024); default: break; }
         if (nt && unroll == 1 && wg == 256) return B2(1, true, 256);
-        if (!nt && unroll == 4 && wg == 256) return B2(4, false, 256);
+    } else {
+        if (nt && wg == 384) {
+            if (unroll == 4) return B2(4, true, 384);
+            if constexpr (ROWS <= 4) { if (unroll == 8) return B2(8, true, 384); }
+            if constexpr (ROWS <= 2) { if (unroll == 16) return B2(16, true, 384); }
+        }
+        if (nt && wg == 512 && unroll == 4) return B2(4, true, 512);
     }
 #endif
 #undef B2
@@ -197,7 +230,7 @@ int bmx_ctx_create(int device, void* stream, bmx_ctx** out)
     // an invalid value is ignored (the default stays)
     static const char* const env_keys[][2] = {
         {"BMX_PIPE_UNROLL", "pipe_unroll"}, {"BMX_PIPE_ROWS", "pipe_rows"}, {"BMX_PIPE_NT", "pipe_nt"},
-        {"BMX_PIPE_WG", "pipe_wg"}, {"BMX_PIPE_SPLIT", "pipe_split"}, {"BMX_OR_TILE", "or_tile"}, {"BMX_XCD_SWIZZLE", "xcd_swizzle"}};
+        {"BMX_PIPE_WG", "pipe_wg"}, {"BMX_PIPE_WINDOW", "pipe_window"}, {"BMX_PIPE_SPLIT", "pipe_split"}, {"BMX_OR_TILE", "or_tile"}, {"BMX_XCD_SWIZZLE", "xcd_swizzle"}};
     for (auto& kv : env_keys)
         if (const char* e = getenv(kv[0])) (void)bmx_ctx_set_tuning(ctx, kv[1], atoi(e));
     g_last_error.clear();
@@ -237,8 +270,9 @@ int bmx_ctx_set_tuning(bmx_ctx* ctx, const char* key, int value)
     else if (k == "pipe_slots") { ARGCHK(value == 8 || value == 16); ctx->pipe_slots = value; }
     else if (k == "pipe_staged") { ARGCHK(value >= -1 && value <= 1); ctx->pipe_staged = value; }
     else if (k == "pipe_split") { ARGCHK(value >= -1 && value <= 1); ctx->pipe_split = value; }
+    else if (k == "pipe_window") { ARGCHK(value >= -1); ctx->pipe_window = value; }
     else if (k == "or_tile") { ARGCHK(value >= 0 && value <= 3); ctx->or_tile = value; }
-    else if (k == "pipe_wg") { ARGCHK(value >= 64 && value <= 1024 && value % 64 == 0); ctx->pipe_wg = value; }
+    else if (k == "pipe_wg") { ARGCHK(value == 0 || (value >= 64 && value <= 1024 && value % 64 == 0)); ctx->pipe_wg = value; }
     else if (k == "xcd_swizzle") ctx->xcd_swz = value != 0;
     else { g_last_error = "unknown tuning key"; return BMX_ERR_BADARG; }
     return BMX_OK;
@@ -751,19 +785,29 @@ int bmx_pipeline_run_counts_dev(bmx_ctx* ctx, bmx_pipeline* p, uint32_t nb_from,
     }
     if (!p->has_gap) {
         // bit-block-only fast path: (column, group, slice) items
-        u32 rows = (u32)ctx->pipe_rows;
-        if (!rows) rows = pipe_rows_auto(nitems64);
+        // Launch plan (pipe_plan): the run is issued as a sequence of launches over column WINDOWS of at most one
+        // machine-load of waves each.  Inside a window every wave is in flight at once and the whole chip walks
+        // the operand list in step: at any moment HBM serves ONE contiguous stretch of one operand slab (open-page
+        // locality) instead of 256 unrelated streams, which is what a single launch over all columns degenerates
+        // into after its first round of workgroups (measured: +5 % on the headline, tools/chunk_probe.py; a
+        // 1,908-column shard = one window runs at a higher rate than the full-size steady state).
+        u32 rows, wg, unroll, window;
+        pipe_plan(ctx, nitems64, p->ngroups, rows, wg, unroll, window);
         u32 parts = 8u / rows;
-        u64 n64 = nitems64 * parts;
-        if (n64 > 0xFFFFFFF0ull) { g_last_error = "too many work items in one run"; return BMX_ERR_RANGE; }
-        u32 nitems = (u32)n64;
-        u32 unroll = ctx->pipe_unroll ? (u32)ctx->pipe_unroll : pipe_unroll_default(rows);
-        pipe_bits_fn fn = pipe_bits_kernel(rows, unroll, ctx->pipe_nt != 0, (u32)ctx->pipe_wg);
+        if (nitems64 * parts > 0xFFFFFFF0ull) { g_last_error = "too many work items in one run"; return BMX_ERR_RANGE; }
+        pipe_bits_fn fn = pipe_bits_kernel(rows, unroll, ctx->pipe_nt != 0, wg);
         if (!fn) { g_last_error = "this (pipe_rows, pipe_unroll, pipe_nt, pipe_wg) shape is not compiled into the library"; return BMX_ERR_BADARG; }
-        u32 wpb = (u32)ctx->pipe_wg / 64u, grid = (nitems + wpb - 1) / wpb;
-        hipLaunchKernelGGL(fn, dim3(grid), dim3(ctx->pipe_wg), (size_t)ctx->pipe_lds, ctx->stream,
-                           (const u64*)p->d_dmat, row_off, and_n, p->col_stride, p->ngroups, nb_from, nitems, ctx->xcd_swz, (u64*)d_counts);
-        KCHK();
+        u32 wpb = wg / 64u;
+        u32 ncols = nb_to - nb_from;
+        u32 nwin = window ? (ncols + window - 1u) / window : 1u;
+        u32 per = (ncols + nwin - 1u) / nwin;                      // even split: no short last window
+        for (u32 c0 = 0; c0 < ncols; c0 += per) {
+            u32 cols = std::min(per, ncols - c0);
+            u32 nitems = cols * p->ngroups * parts, grid = (nitems + wpb - 1) / wpb;
+            hipLaunchKernelGGL(fn, dim3(grid), dim3(wg), (size_t)ctx->pipe_lds, ctx->stream,
+                               (const u64*)p->d_dmat, row_off, and_n, p->col_stride, p->ngroups, nb_from + c0, nitems, ctx->xcd_swz, (u64*)d_counts);
+            KCHK();
+        }
         return BMX_OK;
     }
     if (nitems64 > 0xFFFFFFF0ull) { g_last_error = "too many (column, group) items in one run"; return BMX_ERR_RANGE; }
@@ -779,6 +823,27 @@ int bmx_pipeline_run_counts_dev(bmx_ctx* ctx, bmx_pipeline* p, uint32_t nb_from,
     }
 #undef LAUNCH_PIPE
     KCHK();
+    return BMX_OK;
+}
+
+int bmx_pipeline_describe(bmx_ctx* ctx, bmx_pipeline* p, uint32_t nb_from, uint32_t nb_to, char* buf, size_t buf_len)
+{
+    ARGCHK(ctx && p && p->ctx == ctx && buf && buf_len > 0);
+    int rc = pipe_range(p, nb_from, nb_to); if (rc) return rc;
+    u64 nitems64 = (u64)(nb_to - nb_from) * p->ngroups;
+    bool reuse = p->ngroups >= 32 && (uint64_t)p->n_ops >= 8ull * p->nplanes;
+    if (p->staged_ok && (ctx->pipe_staged == 1 || (ctx->pipe_staged < 0 && reuse)))
+        snprintf(buf, buf_len, "k_pipe_counts_staged<%d> x 1 launch, %u workgroups", ctx->pipe_slots, nb_to - nb_from);
+    else if (p->has_gap)
+        snprintf(buf, buf_len, "k_pipe_counts<%d> x 1 launch", ctx->pipe_unroll == 1 ? 1 : ctx->pipe_unroll == 2 ? 2 : 4);
+    else {
+        u32 rows, wg, unroll, window;
+        pipe_plan(ctx, nitems64, p->ngroups, rows, wg, unroll, window);
+        u32 ncols = nb_to - nb_from, nwin = (window && ncols) ? (ncols + window - 1u) / window : 1u;
+        u32 per = nwin ? (ncols + nwin - 1u) / nwin : 0u;
+        snprintf(buf, buf_len, "k_pipe_counts_bits2<%u,%s,%u,%u> x %u launch%s of <= %u columns", unroll, ctx->pipe_nt ? "true" : "false",
+                 wg, rows, nwin, nwin == 1 ? "" : "es", per);
+    }
     return BMX_OK;
 }
 

@@ -43,8 +43,8 @@ struct bmx_ctx {
     int pipe_unroll = 0;       // operand slices per batch (two batches in flight); 0 = the measured best for the slice size
     int pipe_rows = 0;         // register rows (KiB of a block) per work item: 8 = whole block, 4/2/1 = slices, 0 = auto by item count
     int pipe_nt = 1;           // non-temporal operand loads (+4.5 % on the streamed-once headline case)
-    int pipe_wg = 384;         // workgroup size of the bit-only counts kernel: 6 adjacent items per workgroup, 2 workgroups per CU
-                               // (+6 % over 256 in the A/B sweep: co-scheduled waves read one contiguous stretch of each operand)
+    int pipe_wg = 0;           // workgroup size of the bit-only counts kernel (0 = plan default, see pipe_plan in bmx.hip)
+    int pipe_window = 0;       // block columns per launch: 0 = one machine-load of waves (pipe_plan), -1 = a single launch, N = explicit
     int pipe_staged = -1;      // LDS-staged many-groups kernel: -1 auto, 0 never, 1 whenever possible
     int pipe_lds = 0;          // experiment: dynamic LDS bytes requested by the bit-only counts kernel (occupancy throttle)
     int pipe_slots = 16;       // plane blocks staged at a time (16: 1024-thread WG; 8: two 512-thread WGs per CU)

@@ -376,10 +376,13 @@ def test_full_size_256way_and_count(ctx, port):
         assert (got == exp).all(), (nb0, got, exp)
 
 
-def test_launch_shape_knobs_do_not_change_results(ctx, port):
-    """every tuning combination of the counts pipeline (kernel version, batch size, slice size, NT, workgroup
-    size, XCD swizzle) x every operand count 1..19 (pipeline tail handling) x AND / AND-SUB groups"""
-    nbits = 13 * 65536 + 5
+@pytest.mark.parametrize("tail_bits", [0, 5])
+def test_launch_shape_knobs_do_not_change_results(ctx, port, tail_bits):
+    """every tuning combination of the counts pipeline (slice size, batch size, NT, workgroup size, launch windows,
+    XCD swizzle) x every operand count 1..19 (pipeline tail handling) x AND / AND-SUB groups.
+    tail_bits 0: BIT / FULL / NULL blocks only -> the bit-only kernels k_pipe_counts_bits2<...> (the headline path);
+    tail_bits 5: the last block is a GAP block -> the general kernel k_pipe_counts (the shape knobs must be harmless)."""
+    nbits = 13 * 65536 + tail_bits
     nv = 19
     words = []
     for v in range(nv):
@@ -391,6 +394,9 @@ def test_launch_shape_knobs_do_not_change_results(ctx, port):
         words.append(w)
     gv = [bm.bit_import_u32(ctx, w, True) for w in words]
     pv = [port.import_words(w, True, w.size * 32) for w in words]
+    has_gap = any(g.calc_stat()["gap_blocks"] for g in gv)
+    assert has_gap == (tail_bits != 0)
+    assert sum(g.calc_stat()["full_blocks"] for g in gv) >= 2 and sum(g.calc_stat()["null_blocks"] for g in gv) >= 2
     groups = [(list(range(n)), []) for n in range(1, nv + 1)]
     groups += [(list(range(n)), list(range(n, min(nv, n + k)))) for n in (1, 2, 5, 8) for k in (1, 2, 3, 4, 5, 9)]
     exp = port.pipeline_counts([([pv[i] for i in a], [pv[i] for i in s]) for a, s in groups])
@@ -402,23 +408,28 @@ def test_launch_shape_knobs_do_not_change_results(ctx, port):
     pipe.complete()
     agg = bm.aggregator(ctx)
     try:
-        # every launch shape the default build carries: slice sizes 8/4/2/1 KiB x unroll x nt x workgroup size
-        shapes = [(rows, u, 1, wg) for rows in (8, 4, 2, 1) for wg in (384, 256)
-                  for u in ((4,) if rows == 8 else (4, 8) if (rows == 4 or wg == 256) else (4, 8, 16))]
-        shapes += [(rows, 4, 0, 384) for rows in (8, 4, 2, 1)] + [(0, 0, 1, 384)]
-        for rows, u, nt, wg in shapes:
+        # every launch shape the default build carries (slice size x unroll x nt x workgroup size) x launch windows
+        shapes = [(8, 4, 1, wg, win) for wg in (256, 384, 512, 640, 768) for win in (0, -1, 3)]
+        shapes += [(rows, u, 1, 256, win) for rows in (4, 2, 1) for u in (4, 8) for win in (0, -1)]
+        shapes += [(rows, 4, 0, 256, 0) for rows in (8, 4, 2, 1)] + [(8, 4, 0, 640, 0), (0, 0, 1, 0, 0), (0, 0, 1, 0, 2)]
+        ctx.set_tuning("pipe_staged", 0)                        # many groups over few vectors would pick the LDS-staged kernel
+        for rows, u, nt, wg, win in shapes:
             for swz in (1, 0):
-                for k, x in (("pipe_unroll", u), ("pipe_rows", rows), ("pipe_nt", nt), ("pipe_wg", wg), ("xcd_swizzle", swz)):
+                for k, x in (("pipe_unroll", u), ("pipe_rows", rows), ("pipe_nt", nt), ("pipe_wg", wg), ("pipe_window", win), ("xcd_swizzle", swz)):
                     ctx.set_tuning(k, x)
                 got = agg.combine_and_sub(pipe)
-                assert (got == exp).all(), (rows, u, nt, wg, swz)
+                assert (got == exp).all(), (rows, u, nt, wg, win, swz)
                 nb = gv[0].info()["nblocks"]
                 parts = sum(agg._run_pipeline(pipe, a, b).astype(np.int64) for a, b in [(0, 3), (3, 4), (4, nb)])
-                assert (parts == exp.astype(np.int64)).all(), (rows, u, nt, wg, swz)
+                assert (parts == exp.astype(np.int64)).all(), (rows, u, nt, wg, win, swz)
         ctx.set_tuning("pipe_wg", 192)                          # a shape only the tuning build carries: refused, not mis-launched
-        with pytest.raises(bm.BmxError):
-            agg.combine_and_sub(pipe)
-        for k, x in (("pipe_unroll", 0), ("pipe_rows", 0), ("pipe_nt", 1), ("pipe_wg", 384), ("xcd_swizzle", 1)):
+        if not has_gap:
+            assert "k_pipe_counts_bits2<" in pipe.describe()
+            with pytest.raises(bm.BmxError):
+                agg.combine_and_sub(pipe)
+        else:
+            assert "k_pipe_counts<" in pipe.describe()
+        for k, x in (("pipe_unroll", 0), ("pipe_rows", 0), ("pipe_nt", 1), ("pipe_wg", 0), ("pipe_window", 0), ("xcd_swizzle", 1)):
             ctx.set_tuning(k, x)
         # LDS-staged many-groups kernel forced on (19 planes = 2 chunks, FULL / NULL planes, AND-SUB masks)
         for swz, slots in ((0, 16), (1, 16), (1, 8)):
@@ -429,7 +440,7 @@ def test_launch_shape_knobs_do_not_change_results(ctx, port):
             parts = sum(agg._run_pipeline(pipe, a, b).astype(np.int64) for a, b in [(0, 5), (5, nb)])
             assert (parts == exp.astype(np.int64)).all()
     finally:
-        for k, x in (("pipe_unroll", 0), ("pipe_rows", 0), ("pipe_nt", 1), ("pipe_wg", 384), ("xcd_swizzle", 1),
+        for k, x in (("pipe_unroll", 0), ("pipe_rows", 0), ("pipe_nt", 1), ("pipe_wg", 0), ("pipe_window", 0), ("xcd_swizzle", 1),
                      ("pipe_staged", -1), ("pipe_slots", 16)):
             ctx.set_tuning(k, x)
     # the materialising twins use the same fold: every prefix, AND-SUB and OR

@@ -2,7 +2,7 @@
 """Within-process interleaved A/B of the counts-pipeline launch shapes (headline workload or a block range of it).
 Needs the tuning build for shapes outside the default set:  make -C bitmagic_amd/csrc tune;
   BMX_LIB=bitmagic_amd/lib/libbmx_tune.so python tools/tune_pipe.py [--nvec 256] [--rounds 7] [--shard 8]
-variant = rows:unroll:nt:wg:swz[:lds]   (rows/unroll 0 = auto)"""
+variant = rows:unroll:nt:wg:swz:window[:lds]   (rows/unroll/wg/window 0 = plan default, window -1 = single launch)"""
 import argparse, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -30,17 +30,18 @@ counts = torch.zeros(1, dtype=torch.int64, device="cuda")
 ob = pipe.operand_bytes(lo, hi)
 if a.variants:
     variants = [tuple(int(x) for x in v.split(":")) for v in a.variants.split(",")]
-    variants = [v if len(v) == 6 else v + (0,) for v in variants]
+    variants = [v if len(v) == 7 else v + (0,) for v in variants]
 else:
-    variants = [(8, 4, 1, 384, 1, 0), (8, 4, 1, 256, 1, 0), (4, 4, 1, 384, 1, 0), (4, 8, 1, 384, 1, 0), (2, 8, 1, 384, 1, 0),
-                (2, 16, 1, 384, 1, 0), (1, 8, 1, 384, 1, 0), (1, 16, 1, 384, 1, 0), (2, 4, 1, 384, 1, 0), (1, 4, 1, 384, 1, 0),
-                (4, 8, 1, 256, 1, 0), (2, 8, 1, 256, 1, 0), (1, 8, 1, 256, 1, 0), (0, 0, 1, 384, 1, 0)]
+    variants = [(0, 0, 1, 0, 1, 0, 0), (8, 4, 1, 384, 1, -1, 0), (8, 4, 1, 256, 1, -1, 0)]
+    variants += [(8, 4, 1, wg, 1, w, 0) for wg, ws in ((256, (1024, 2048, 3072)), (384, (1536, 3072)), (192, (1536, 2304, 3072)), (512, (2048,)), (320, (1280, 2560)))
+                 for w in ws]
+    variants += [(8, 2, 1, 256, 1, 2048, 0), (8, 2, 1, 384, 1, 3072, 0), (4, 4, 1, 256, 1, 1024, 0), (4, 8, 1, 256, 1, 1024, 0)]
 res = {v: [] for v in variants}
 ref = None
 for rnd in range(a.rounds):
     for v in variants:
-        r, u, nt, wg, sw, ldsb = v
-        for k, x in (("pipe_unroll", u), ("pipe_rows", r), ("pipe_nt", nt), ("pipe_wg", wg), ("xcd_swizzle", sw), ("pipe_lds", ldsb)):
+        r, u, nt, wg, sw, win, ldsb = v
+        for k, x in (("pipe_unroll", u), ("pipe_rows", r), ("pipe_nt", nt), ("pipe_wg", wg), ("xcd_swizzle", sw), ("pipe_window", win), ("pipe_lds", ldsb)):
             ctx.set_tuning(k, x)
         try:
             agg.run_counts_dev(pipe, counts.data_ptr(), lo, hi)
@@ -73,4 +74,4 @@ for v, t in res.items():
 rows.sort()
 print(f"blocks [{lo}, {hi}) of {nblocks}  count {ref}  operand GB {ob / 1e9:.3f}")
 for med, mn, v in rows:
-    print(f"rows={v[0]} U={v[1]} nt={v[2]} wg={v[3]} swz={v[4]} lds={v[5]}  median {med:.4f} ms  min {mn:.4f} ms  {ob/med/1e6:.0f} GB/s  frac {ob/med/1e6/8000:.3f}")
+    print(f"rows={v[0]} U={v[1]} nt={v[2]} wg={v[3]} swz={v[4]} window={v[5]} lds={v[6]}  median {med:.4f} ms  min {mn:.4f} ms  {ob/med/1e6:.0f} GB/s  frac {ob/med/1e6/8000:.3f}")
