@@ -234,7 +234,7 @@ def traffic_note(workload: str):
     try:
         tj = json.load(open(tpath))
         if tj.get("workload") == workload:
-            return tj.get("hbm_bytes_per_launch"), f"profiles/{tj.get('source', 'traffic_latest.json')} (PMC passes of a separate rocprofv3 run, not measured in this run)"
+            return tj.get("hbm_bytes_per_launch"), f"{tj.get('source', 'profiles/traffic_latest.json')} (PMC passes of a separate rocprofv3 run, not measured in this run)"
     except Exception:
         pass
     return None, None
@@ -302,7 +302,7 @@ def run_headline(args):
         if use_dist:
             ar_us = event_avg_ms(lambda: dist.all_reduce(counts), 20, ctx) * 1e3
         r = {"dt": dt, "ev_ms": ev_ms, "count": total, "op_bytes": op_bytes, "k_ms": k_ms, "ar_us": ar_us,
-             "build_s": t_build, "blocks": hi - lo, "plan": pipe.describe(), "stat0": vecs[0].calc_stat(), "mem": ctx.mem_used(),
+             "build_s": t_build, "blocks": hi - lo, "plan": pipe.describe(), "nlaunch": pipe.launches(), "stat0": vecs[0].calc_stat(), "mem": ctx.mem_used(),
              "pipe": pipe, "vecs": vecs}
         return r
 
@@ -354,10 +354,14 @@ def run_headline(args):
                        "build_seconds": round(main["build_s"], 2), "hbm_resident_bytes": main["mem"]},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": tsrc,
-                         "kernel": main["plan"],
-                         "algorithmic_bytes_per_launch": main["op_bytes"],
-                         "avg_launch_ms": round(main["k_ms"], 4), "scope": "rank 0's GPU",
-                         "timing": "hipEvent pair on the launch stream around back-to-back launches of the kernel alone"},
+                         "kernel": main["plan"], "launches_per_step": main["nlaunch"],
+                         "algorithmic_bytes_per_launch": main["op_bytes"] // main["nlaunch"],
+                         "avg_launch_ms": round(main["k_ms"] / main["nlaunch"], 4),
+                         "algorithmic_bytes_per_step": main["op_bytes"], "kernel_ms_per_step": round(main["k_ms"], 4),
+                         "scope": "rank 0's GPU",
+                         "timing": "hipEvent pair on the launch stream around back-to-back passes of the kernel alone (a pass = "
+                                   "launches_per_step launches over equal column windows); avg_launch_ms = pass time / launches, "
+                                   "inter-launch gaps included"},
             "per_rank": {"kernel_ms": [round(x, 4) for x in k_all],
                          "GBps": [round(b / (k * 1e-3) / 1e9, 1) for b, k in zip(bytes_all, k_all)],
                          "allreduce_us": None if main["ar_us"] is None else round(main["ar_us"], 1),

@@ -434,8 +434,13 @@ class pipeline:
     def describe(self, nb_from: int = 0, nb_to: int = ID_MAX) -> str:
         """kernel + launch plan a counts run over the block range takes"""
         buf = C.create_string_buffer(256)
-        check(lib().bmx_pipeline_describe(self.ctx._h, self._h, nb_from, nb_to, buf, 256))
+        check(lib().bmx_pipeline_describe(self.ctx._h, self._h, nb_from, nb_to, buf, 256, None))
         return buf.value.decode()
+
+    def launches(self, nb_from: int = 0, nb_to: int = ID_MAX) -> int:
+        buf = C.create_string_buffer(256); n = C.c_uint32()
+        check(lib().bmx_pipeline_describe(self.ctx._h, self._h, nb_from, nb_to, buf, 256, C.byref(n)))
+        return n.value
 
     def __del__(self):
         try:

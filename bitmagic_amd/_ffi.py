@@ -77,7 +77,7 @@ def lib() -> C.CDLL:
         "bmx_pipeline_run_counts_dev": (i32, [vp, vp, u32, u32, vp]),
         "bmx_pipeline_run_results": (i32, [vp, vp, P(vp), P(u64), vp, P(vp)]),
         "bmx_pipeline_operand_bytes": (i32, [vp, vp, u32, u32, P(u64)]),
-        "bmx_pipeline_describe": (i32, [vp, vp, u32, u32, C.c_char_p, C.c_size_t]),
+        "bmx_pipeline_describe": (i32, [vp, vp, u32, u32, C.c_char_p, C.c_size_t, P(u32)]),
         "bmx_rs_build": (i32, [vp, vp, P(vp)]),
         "bmx_rs_free": (i32, [vp, vp]),
         "bmx_rs_count": (i32, [vp, P(u64)]),

@@ -826,9 +826,10 @@ int bmx_pipeline_run_counts_dev(bmx_ctx* ctx, bmx_pipeline* p, uint32_t nb_from,
     return BMX_OK;
 }
 
-int bmx_pipeline_describe(bmx_ctx* ctx, bmx_pipeline* p, uint32_t nb_from, uint32_t nb_to, char* buf, size_t buf_len)
+int bmx_pipeline_describe(bmx_ctx* ctx, bmx_pipeline* p, uint32_t nb_from, uint32_t nb_to, char* buf, size_t buf_len, uint32_t* n_launches)
 {
     ARGCHK(ctx && p && p->ctx == ctx && buf && buf_len > 0);
+    if (n_launches) *n_launches = 1;
     int rc = pipe_range(p, nb_from, nb_to); if (rc) return rc;
     u64 nitems64 = (u64)(nb_to - nb_from) * p->ngroups;
     bool reuse = p->ngroups >= 32 && (uint64_t)p->n_ops >= 8ull * p->nplanes;
@@ -843,6 +844,7 @@ int bmx_pipeline_describe(bmx_ctx* ctx, bmx_pipeline* p, uint32_t nb_from, uint3
         u32 per = nwin ? (ncols + nwin - 1u) / nwin : 0u;
         snprintf(buf, buf_len, "k_pipe_counts_bits2<%u,%s,%u,%u> x %u launch%s of <= %u columns", unroll, ctx->pipe_nt ? "true" : "false",
                  wg, rows, nwin, nwin == 1 ? "" : "es", per);
+        if (n_launches) *n_launches = nwin;
     }
     return BMX_OK;
 }

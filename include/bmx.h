@@ -197,8 +197,10 @@ int bmx_pipeline_run_results(bmx_ctx* ctx, bmx_pipeline* p, bmx_vec** results_ou
 int bmx_pipeline_operand_bytes(bmx_ctx* ctx, bmx_pipeline* p, uint32_t nb_from, uint32_t nb_to,
                                uint64_t* bytes);
 
-/* which kernel and launch plan a counts run over [nb_from, nb_to) takes (for benchmark reports / profiles) */
-int bmx_pipeline_describe(bmx_ctx* ctx, bmx_pipeline* p, uint32_t nb_from, uint32_t nb_to, char* buf, size_t buf_len);
+/* which kernel and launch plan a counts run over [nb_from, nb_to) takes (for benchmark reports / profiles);
+ * n_launches (may be NULL) = kernel launches of one run */
+int bmx_pipeline_describe(bmx_ctx* ctx, bmx_pipeline* p, uint32_t nb_from, uint32_t nb_to, char* buf, size_t buf_len,
+                          uint32_t* n_launches);
 
 /* ---- rank / select ---- */
 /* bvector::build_rs_index  src/bm.h:2531 */
