@@ -566,19 +566,31 @@ class aggregator:
         check(lib().bmx_pipeline_run_counts_dev(self.ctx._h, pipe._h, nb_from, nb_to, C.c_void_p(d_counts_ptr)))
 
 
-class slice_scanner:
-    """Bit-sliced equality search over device-resident slices: the aggregator call pattern of
-    bm::sparse_vector_scanner<SV>::find_eq (src/bmsparsevec_algo.h:1083,2387; group rule
-    prepare_and_sub_aggregator :2593-2640).  slices[i] holds bit i of every element (None = plane absent);
-    len(slices) plays effective_slices().  A batch of searches is one counts-only pipeline launch."""
+CMP_GT, CMP_GE, CMP_LT, CMP_LE, CMP_RANGE, CMP_EQ, CMP_ZERO, CMP_NONZERO = range(8)
 
-    def __init__(self, ctx: context, slices: Sequence[bvector | None]):
+
+class slice_scanner:
+    """Bit-sliced search over device-resident slices: the aggregator call pattern of
+    bm::sparse_vector_scanner<SV> (src/bmsparsevec_algo.h): find_eq :1083,2387 (group rule
+    prepare_and_sub_aggregator :2593-2640), find_gt/ge/lt/le/find_range :1135-1174, find_zero :2290,
+    find_nonzero :4464.  slices[i] holds bit i of every element (None = plane absent); len(slices) plays
+    effective_slices(); size = sv.size() (rows; default: the longest slice); not_null = sv.get_null_bvector().
+    A batch of equality searches is one counts-only pipeline launch; a comparison search is one pass over the planes."""
+
+    def __init__(self, ctx: context, slices: Sequence[bvector | None], size: int | None = None, not_null: bvector | None = None):
         self.ctx, self.slices = ctx, list(slices)
         self.agg = aggregator(ctx)
+        self.not_null = not_null
+        self._size = size
+
+    def size(self) -> int:
+        if self._size is None:
+            self._size = max([p.size() for p in self.slices if p is not None], default=0)
+        return self._size
 
     def _groups(self, value: int):
         if value <= 0:
-            raise BmxError(_ffi.ERR_BADARG, "Invalid argument", "value 0 is find_zero() in the reference (not on this path)")
+            raise BmxError(_ffi.ERR_BADARG, "Invalid argument", "value 0 has no AND group: find_eq(0) goes through the comparison kernel")
         a = []
         for bit in range(value.bit_length() - 1, -1, -1):               # backward order (:2614)
             if (value >> bit) & 1:
@@ -588,8 +600,34 @@ class slice_scanner:
         s = [p for i, p in enumerate(self.slices) if p is not None and not (value >> i) & 1]
         return a, s
 
+    def _compare(self, pred: int, v0: int = 0, v1: int = 0, count_only: bool = False):
+        if v0 < 0 or v1 < 0 or v0 >= 1 << 64 or v1 >= 1 << 64:
+            raise BmxError(_ffi.ERR_RANGE, "Incorrect range or index", "unsigned 64-bit values only")
+        arr = (C.c_void_p * max(len(self.slices), 1))()
+        for i, p in enumerate(self.slices):
+            arr[i] = p._h if p is not None else None
+        h, cnt = C.c_void_p(), C.c_uint64()
+        check(lib().bmx_slice_compare(self.ctx._h, arr, len(self.slices), pred, v0, v1, self.size(),
+                                      self.not_null._h if self.not_null is not None else None,
+                                      None if count_only else C.byref(h), C.byref(cnt)))
+        return cnt.value if count_only else bvector(self.ctx, h)
+
+    def find_gt(self, value: int) -> bvector: return self._compare(CMP_GT, value)              # :2690
+    def find_ge(self, value: int) -> bvector: return self._compare(CMP_GE, value)              # :2717
+    def find_lt(self, value: int) -> bvector: return self._compare(CMP_LT, value)              # :2790
+    def find_le(self, value: int) -> bvector: return self._compare(CMP_LE, value)              # :2824
+    def find_range(self, lo: int, hi: int) -> bvector: return self._compare(CMP_RANGE, lo, hi) # :2862
+    def find_zero(self) -> bvector: return self._compare(CMP_ZERO)                             # :2290 (null_correct = true)
+    def find_nonzero(self) -> bvector: return self._compare(CMP_NONZERO)                       # :4464
+    def count(self, pred: int, v0: int = 0, v1: int = 0) -> int:
+        """popcount of a comparison search without materialising it"""
+        return self._compare(pred, v0, v1, count_only=True)
+
     def find_eq(self, value: int):
         """-> (bv_out or None, found)"""
+        if int(value) == 0:                                              # find_eq(sv, 0, ..) == find_zero (:4366)
+            t = self._compare(CMP_EQ, 0)
+            return t, t.any()
         g = self._groups(int(value))
         if g is None:
             return None, False
@@ -605,7 +643,9 @@ class slice_scanner:
         out = np.zeros(len(values), np.uint64)
         pipe = pipeline(self.ctx)
         slot = []
-        for v in values:
+        for q, v in enumerate(values):
+            if int(v) == 0:
+                out[q] = self.count(CMP_EQ, 0); slot.append(-1); continue
             g = self._groups(int(v))
             if g is None:
                 slot.append(-1); continue

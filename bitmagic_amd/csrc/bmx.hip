@@ -6,6 +6,7 @@
 #endif
 #include "bmx_kernels2.h"
 #include "bmx_kernels3.h"
+#include "bmx_kernels4.h"
 
 #include <algorithm>
 #include <cstdio>
@@ -1323,6 +1324,69 @@ int bmx_agg_shift_right_and_count(bmx_ctx* ctx, const bmx_vec* const* src, size_
 {
     ARGCHK(count);
     return shift_right_and_impl(ctx, src, n, 0, 0, nullptr, nullptr, count);
+}
+
+// sparse_vector_scanner<SV>::find_gt/ge/lt/le/range/eq/zero/nonzero over resident slices (bmx_kernels4.h)
+int bmx_slice_compare(bmx_ctx* ctx, const bmx_vec* const* slices, size_t nslices, int pred, uint64_t v0, uint64_t v1,
+                      uint64_t size, const bmx_vec* not_null, bmx_vec** result, uint64_t* count)
+{
+    ARGCHK(ctx && (nslices == 0 || slices) && nslices <= 64 && pred >= BMX_CMP_GT && pred <= BMX_CMP_NONZERO && (result || count));
+    ARGCHK(!not_null || not_null->ctx == ctx);
+    if (result) *result = nullptr;
+    if (count) *count = 0;
+    int rc = set_dev(ctx); if (rc) return rc;
+    if (pred == BMX_CMP_RANGE && v1 < v0) std::swap(v0, v1);              // bm::xor_swap(from, to), :2872
+    if (pred == BMX_CMP_ZERO || pred == BMX_CMP_NONZERO) v0 = 0;
+    uint64_t nblocks64 = (size + BMX_BLOCK_BITS - 1) / BMX_BLOCK_BITS;
+    if (nblocks64 > 65536ull * 16) { g_last_error = "vector too long"; return BMX_ERR_RANGE; }
+    uint32_t ncols = (uint32_t)nblocks64;
+    // which results can contain value 0 = where NULL elements hide (needs_null_correct_*, :1703-1735, unsigned)
+    int null_correct = 0;
+    switch (pred) {
+    case BMX_CMP_GE: case BMX_CMP_RANGE: null_correct = v0 == 0; break;
+    case BMX_CMP_LT: null_correct = v0 > 0; break;
+    case BMX_CMP_LE: case BMX_CMP_ZERO: null_correct = 1; break;
+    case BMX_CMP_EQ: null_correct = v0 == 0; break;
+    default: break;
+    }
+    std::vector<const u64*> descs(std::max<size_t>(nslices, 1), nullptr);
+    std::vector<u32> nblk(std::max<size_t>(nslices, 1), 0);
+    for (size_t i = 0; i < nslices; ++i) {
+        if (!slices[i]) continue;                                           // plane does not exist
+        if (slices[i]->ctx != ctx) { g_last_error = "slice belongs to another context"; return BMX_ERR_BADARG; }
+        descs[i] = slices[i]->d_desc; nblk[i] = slices[i]->nblocks;
+    }
+    bmx_vec* v = nullptr; BlockStat* st = nullptr; u32* offs = nullptr;
+    if (result && (rc = result_begin(ctx, size, ncols, &v, &st, &offs))) return rc;
+    if (!ncols) { if (result) *result = v; return BMX_OK; }
+    void* d_descs = nullptr; void* d_nblk = nullptr;
+    size_t nal = std::max<size_t>(nslices, 1);
+    if ((rc = dmalloc(ctx, &d_descs, nal * 8)) || (rc = dmalloc(ctx, &d_nblk, nal * 4))) { dfree(ctx, d_descs); if (v) bmx_vec_free(ctx, v); return rc; }
+    hipError_t e = hipMemcpyAsync(d_descs, descs.data(), nal * 8, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_nblk, nblk.data(), nal * 4, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_slice_compare, dim3((ncols + 3) / 4), dim3(256), 0, ctx->stream,
+                           (const u64* const*)d_descs, (const u32*)d_nblk, (u32)nslices, ncols, pred, v0, v1, size,
+                           not_null ? (const u64*)not_null->d_desc : nullptr, not_null ? not_null->nblocks : 0u, null_correct,
+                           result ? 0 : 1, ctx->xcd_swz, v ? v->d_bits : nullptr, v ? v->d_desc : nullptr, st, ctx->d_slots);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess && !result) {
+        hipLaunchKernelGGL(k_sum_slots, dim3(1), dim3(64), 0, ctx->stream, ctx->d_slots, ctx->d_small);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(ctx->h_small, ctx->d_small, 8, hipMemcpyDeviceToHost, ctx->stream);
+    }
+    if (e == hipSuccess && result) rc = result_finish(ctx, v, st, offs);
+    else if (e != hipSuccess) rc = fail_hip(e, "bmx_slice_compare", __LINE__);
+    hipError_t e2 = hipStreamSynchronize(ctx->stream);
+    if (!rc && e2 != hipSuccess) rc = fail_hip(e2, "bmx_slice_compare", __LINE__);
+    dfree(ctx, d_descs); dfree(ctx, d_nblk);
+    if (rc) { if (v) bmx_vec_free(ctx, v); return rc; }
+    if (result) {
+        *result = v;
+        if (count) { rc = bmx_count(ctx, v, count); if (rc) return rc; }
+    } else *count = ctx->h_small[0];
+    return BMX_OK;
 }
 
 // ---------------------------------------------------------------------------

@@ -163,6 +163,27 @@ int bmx_agg_shift_right_and(bmx_ctx* ctx, const bmx_vec* const* src, size_t n, i
                             bmx_vec** result, int* found);
 /* same under set_compute_count(true) (src/bmaggregator.h:363,2595): no target, *count = aggregator::count(). */
 int bmx_agg_shift_right_and_count(bmx_ctx* ctx, const bmx_vec* const* src, size_t n, uint64_t* count);
+/* ---- bit-sliced comparison search (the range-search half of bm::sparse_vector_scanner<SV>, unsigned values) ----
+ * slices[i] = device vector of bit-plane i (sv.get_slice(i)), NULL where the plane does not exist; nslices plays
+ * effective_slices(); size = sv.size() (rows); not_null = sv.get_null_bvector() or NULL.
+ *   BMX_CMP_GT/GE/LT/LE (v0)   find_gt / find_ge / find_lt / find_le      src/bmsparsevec_algo.h:2690,2717,2790,2824
+ *   BMX_CMP_RANGE [v0, v1]     find_range (closed, swapped when v1 < v0)   :2862
+ *   BMX_CMP_EQ (v0)            find_eq incl. value 0                       :4356,2387
+ *   BMX_CMP_ZERO / NONZERO     find_zero(null_correct = true) / find_nonzero :2290,4464
+ * NULL elements are stored as 0: where the predicate admits 0 the result is AND-ed with not_null
+ * (needs_null_correct_*, :1703-1735; correct_nulls :2376).  One pass over the planes (bmx_kernels4.h).
+ * result may be NULL (count only: nothing is materialised); count may be NULL. */
+#define BMX_CMP_GT 0
+#define BMX_CMP_GE 1
+#define BMX_CMP_LT 2
+#define BMX_CMP_LE 3
+#define BMX_CMP_RANGE 4
+#define BMX_CMP_EQ 5
+#define BMX_CMP_ZERO 6
+#define BMX_CMP_NONZERO 7
+int bmx_slice_compare(bmx_ctx* ctx, const bmx_vec* const* slices, size_t nslices, int pred, uint64_t v0, uint64_t v1,
+                      uint64_t size, const bmx_vec* not_null, bmx_vec** result, uint64_t* count);
+
 /* aggregator::pipeline<agg_opt_only_counts>  src/bmaggregator.h:62-103,222-341:
  * arg-groups are given as concatenated operand lists, and_n[g] / sub_n[g] per
  * group (pipeline::add() + arg_groups::add(bv, 0|1) + complete(), :2784-2931).

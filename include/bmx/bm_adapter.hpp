@@ -133,11 +133,12 @@ bool upload(const BMBV& src, DST& dst, uint32_t nblocks = 0)
 /// device vectors; slices[i] is nullptr where the host plane does not exist.  All slices are uploaded
 /// with the same block count (the container's size) so that NULL tails behave as in the reference.
 template <class SV>
-void upload_slices(const SV& sv, context& ctx, std::vector<bvector>& store, std::vector<const bvector*>& slices)
+void upload_slices(const SV& sv, context& ctx, std::vector<bvector>& store, std::vector<const bvector*>& slices,
+                   const bvector** not_null = nullptr)
 {
     unsigned planes = sv.effective_slices();
     uint32_t nblocks = (uint32_t)(((uint64_t)sv.size() + BMX_BLOCK_BITS - 1) / BMX_BLOCK_BITS);
-    store.clear(); store.reserve(planes);
+    store.clear(); store.reserve(planes + 1u);
     std::vector<int> slot(planes, -1);
     for (unsigned i = 0; i < planes; ++i) {
         if (const typename SV::bvector_type* bv = sv.get_slice(i)) {
@@ -146,8 +147,18 @@ void upload_slices(const SV& sv, context& ctx, std::vector<bvector>& store, std:
             slot[i] = (int)store.size() - 1;
         }
     }
+    int null_slot = -1;
+    if (not_null) {                                  // sv.get_null_bvector(): the NOT-NULL flags of a nullable container
+        *not_null = nullptr;
+        if (const typename SV::bvector_type* bn = sv.get_null_bvector()) {
+            store.emplace_back(ctx);
+            upload(*bn, store.back(), nblocks ? nblocks : 1);
+            null_slot = (int)store.size() - 1;
+        }
+    }
     slices.assign(planes, nullptr);
     for (unsigned i = 0; i < planes; ++i) if (slot[i] >= 0) slices[i] = &store[(size_t)slot[i]];
+    if (null_slot >= 0) *not_null = &store[(size_t)null_slot];
 }
 
 /// install a block table into a host bm::bvector<> through the reference's own

@@ -12,6 +12,9 @@
 //        SUB group = every other existing slice below effective_slices(); a set bit
 //        without a slice => nothing can match
 //   pipeline of many searches (batch of arg-groups, :3236,3408)   slice_scanner::find_eq_counts(values, n, counts)
+//   find_gt / find_ge / find_lt / find_le / find_range             slice_scanner::find_gt(value, bv_out) ...
+//        :1135-1174 -> :2690-2880, find_gt_horizontal_u :2914         ONE pass over the planes (bmx_slice_compare,
+//   find_zero :2290, find_nonzero :4464, find_eq(sv, 0, ..) :4366     bmx_kernels4.h) instead of a chain of vector ops
 //
 // The slices stay resident in HBM; a batch of searches is ONE counts-only pipeline launch (the
 // LDS-staged kernel when many groups share the slices).  The container
@@ -29,14 +32,31 @@ public:
     explicit slice_scanner(context& ctx) : ctx_(&ctx), agg_(ctx) {}
 
     /// slice i holds bit i of every element; nullptr = the plane does not exist (sv.get_slice(i) == 0).
-    /// slices.size() plays effective_slices().
-    void bind(const std::vector<const bvector*>& slices) { slices_ = slices; }
+    /// slices.size() plays effective_slices(); size = sv.size() (rows; 0 = the longest slice);
+    /// not_null = device copy of sv.get_null_bvector() (nullptr: the container has no NULLs).
+    void bind(const std::vector<const bvector*>& slices, size_type size = 0, const bvector* not_null = nullptr)
+    {
+        slices_ = slices; size_ = size; not_null_ = not_null;
+        if (!size_) for (size_t i = 0; i < slices_.size(); ++i) if (slices_[i] && slices_[i]->size() > size_) size_ = slices_[i]->size();
+    }
     size_t effective_slices() const noexcept { return slices_.size(); }
+    size_type size() const noexcept { return size_; }
 
-    /// rows equal to `value` (value != 0) -> bv_out; false when nothing was found
+    // ---- comparison searches (unsigned values): one pass over the planes ----
+    void find_gt(uint64_t value, bvector& bv_out) { compare(BMX_CMP_GT, value, 0, &bv_out); }            // :2690
+    void find_ge(uint64_t value, bvector& bv_out) { compare(BMX_CMP_GE, value, 0, &bv_out); }            // :2717
+    void find_lt(uint64_t value, bvector& bv_out) { compare(BMX_CMP_LT, value, 0, &bv_out); }            // :2790
+    void find_le(uint64_t value, bvector& bv_out) { compare(BMX_CMP_LE, value, 0, &bv_out); }            // :2824
+    void find_range(uint64_t from, uint64_t to, bvector& bv_out) { compare(BMX_CMP_RANGE, from, to, &bv_out); }   // :2862
+    void find_zero(bvector& bv_out) { compare(BMX_CMP_ZERO, 0, 0, &bv_out); }                            // :2290 (null_correct)
+    void find_nonzero(bvector& bv_out) { compare(BMX_CMP_NONZERO, 0, 0, &bv_out); }                      // :4464
+    /// popcount of a comparison search, nothing materialised (pred = BMX_CMP_*)
+    size_type count(int pred, uint64_t v0, uint64_t v1 = 0) { return compare(pred, v0, v1, nullptr); }
+
+    /// rows equal to `value` -> bv_out; false when nothing was found (value 0: find_zero, :4366)
     bool find_eq(uint64_t value, bvector& bv_out)
     {
-        if (!value) throw error(BMX_ERR_BADARG, "slice_scanner: value 0 is find_zero() in the reference (not on this path)");
+        if (!value) { compare(BMX_CMP_EQ, 0, 0, &bv_out); return bv_out.any(); }
         aggregator<bvector>::arg_groups g;
         if (!add_groups(value, g)) { bv_out.clear(); return false; }
         return agg_.combine_and_sub(bv_out, g.arg_bv0.data(), g.arg_bv0.size(), g.arg_bv1.data(), g.arg_bv1.size(), false);
@@ -59,7 +79,7 @@ public:
         std::vector<size_t> slot(n, ~size_t(0));
         for (size_t q = 0; q < n; ++q) {
             counts[q] = 0;
-            if (!values[q]) throw error(BMX_ERR_BADARG, "slice_scanner: value 0 is find_zero() in the reference (not on this path)");
+            if (!values[q]) { counts[q] = count(BMX_CMP_EQ, 0); continue; }
             aggregator<bvector>::arg_groups g;
             if (!add_groups(values[q], g)) continue;                     // impossible value: count 0
             aggregator<bvector>::arg_groups* pg = pipe.add();
@@ -73,6 +93,17 @@ public:
     }
 
 private:
+    size_type compare(int pred, uint64_t v0, uint64_t v1, bvector* out)
+    {
+        std::vector<const bmx_vec*> h(slices_.size() ? slices_.size() : 1, nullptr);
+        for (size_t i = 0; i < slices_.size(); ++i) h[i] = slices_[i] ? slices_[i]->handle() : nullptr;
+        bmx_vec* r = nullptr; uint64_t c = 0;
+        check(bmx_slice_compare(ctx_->handle(), h.data(), slices_.size(), pred, v0, v1, size_,
+                                (not_null_ && !not_null_->empty_handle()) ? not_null_->handle() : nullptr,
+                                out ? &r : nullptr, out ? nullptr : &c));
+        if (out) out->adopt(r);
+        return c;
+    }
     // prepare_and_sub_aggregator (src/bmsparsevec_algo.h:2593-2640)
     bool add_groups(uint64_t value, aggregator<bvector>::arg_groups& g) const
     {
@@ -89,6 +120,8 @@ private:
     context* ctx_;
     aggregator<bvector> agg_;
     std::vector<const bvector*> slices_;
+    size_type size_ = 0;
+    const bvector* not_null_ = nullptr;
 };
 
 } // namespace bmx

@@ -187,6 +187,38 @@ int main()
         got.resize(vals.size());
         gs.find_eq_counts(vals.data(), vals.size(), got.data());
         REQUIRE(got == ref_counts);
+        // range search: find_gt / find_ge / find_lt / find_le / find_range / find_zero / find_nonzero / find_eq(0)
+        // vs the real scanner (src/bmsparsevec_algo.h:1135-1174, 2290, 2690-2880, 4464), with and without NULLs
+        typedef bm::sparse_vector<unsigned, bvect> svect_t;
+        svect_t svn(bm::use_null);
+        for (unsigned i = 0; i < N; ++i) { unsigned v = sv.get(i); if (i % 11u == 3u) continue; svn.set(i, v); }   // gaps = NULL elements
+        svn.optimize();
+        for (int with_null = 0; with_null < 2; ++with_null) {
+            const svect_t& S = with_null ? svn : sv;
+            std::vector<bmx::bvector> st2; std::vector<const bmx::bvector*> sl2; const bmx::bvector* nn = nullptr;
+            bmx::upload_slices(S, ctx, st2, sl2, &nn);
+            REQUIRE((nn != nullptr) == (with_null != 0));
+            bmx::slice_scanner g2(ctx);
+            g2.bind(sl2, S.size(), nn);
+            bm::sparse_vector_scanner<svect_t> r2;
+            auto same = [&](bvect& r, bmx::bvector& g) { bvect gh; if (!g.empty_handle()) bmx::download(g, gh); return gh.compare(r) == 0; };
+            for (unsigned v : {0u, 1u, 2u, 50u, 95u, 96u, 97u, 128u, 69999u, 70000u, 70003u, 70006u, 70007u, 131071u, 131072u, 4000000u}) {
+                bvect r; bmx::bvector g(ctx);
+                r2.find_gt(S, v, r); g2.find_gt(v, g); REQUIRE(same(r, g));
+                r.clear(); r2.find_ge(S, v, r); g2.find_ge(v, g); REQUIRE(same(r, g));
+                r.clear(); r2.find_lt(S, v, r); g2.find_lt(v, g); REQUIRE(same(r, g));
+                r.clear(); r2.find_le(S, v, r); g2.find_le(v, g); REQUIRE(same(r, g));
+                REQUIRE(g2.count(BMX_CMP_LE, v) == r.count());
+            }
+            for (auto pr : {std::pair<unsigned, unsigned>{0u, 0u}, {0u, 5u}, {3u, 3u}, {90u, 10u}, {10u, 69999u}, {96u, 70003u}, {70001u, 70005u}, {1u, 4000000u}}) {
+                bvect r; bmx::bvector g(ctx);
+                r2.find_range(S, pr.first, pr.second, r); g2.find_range(pr.first, pr.second, g);
+                REQUIRE(same(r, g));
+            }
+            { bvect r; bmx::bvector g(ctx); r2.find_zero(S, r); g2.find_zero(g); REQUIRE(same(r, g)); }
+            { bvect r; bmx::bvector g(ctx); r2.find_nonzero(S, r); g2.find_nonzero(g); REQUIRE(same(r, g)); }
+            { bvect r; bmx::bvector g(ctx); r2.find_eq(S, 0u, r); bool gf = g2.find_eq(0, g); REQUIRE(r.any() == gf && same(r, g)); }
+        }
     }
     // rank / select vs bvector<>::count_to / select with the reference rs_index
     {

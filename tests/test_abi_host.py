@@ -70,7 +70,7 @@ def test_no_device_fails_loudly():
 def test_slice_scanner_group_rule():
     """prepare_and_sub_aggregator (src/bmsparsevec_algo.h:2593-2640) as mirrored by slice_scanner: AND group =
     planes of the set bits, high bit first; SUB group = every other existing plane; a set bit without a plane
-    (absent or beyond effective_slices) means nothing can match; value 0 is find_zero() and is refused"""
+    (absent or beyond effective_slices) means nothing can match; value 0 has no AND group (it goes through the comparison kernel)"""
     import bitmagic_amd as bm
 
     class fake_ctx:            # group construction is host logic: no device call

@@ -731,7 +731,7 @@ def test_slice_scanner_vs_numpy(ctx):
         w = np.packbits(np.concatenate([bits, np.zeros((-n) % 32, np.uint8)]), bitorder="little").view(np.uint32)
         slices.append(bm.bit_import_u32(ctx, w, True))
     assert any(s is None for s in slices)
-    sc = bm.slice_scanner(ctx, slices)
+    sc = bm.slice_scanner(ctx, slices, size=n)
     vals = [1, 7, 100, 199, 200, 255, 3000, 3004, 3005, 4095, 1 << 11, 1 << 20]
     cnt = sc.find_eq_counts(vals)
     assert cnt.tolist() == [int((col == v).sum()) for v in vals]
@@ -744,8 +744,67 @@ def test_slice_scanner_vs_numpy(ctx):
             assert (got == idx).all()
         f, pos = sc.find_first_eq(v)
         assert f == (idx.size > 0) and (not f or pos == idx[0])
-    with pytest.raises(bm.BmxError):
-        sc.find_eq(0)
+    t0, f0 = sc.find_eq(0)                                   # value 0 = find_zero (src/bmsparsevec_algo.h:4366)
+    assert f0 == bool((col == 0).any()) and t0.count() == int((col == 0).sum())
+    assert sc.find_eq_counts([0, 7, 0]).tolist() == [int((col == 0).sum()), int((col == 7).sum()), int((col == 0).sum())]
+
+
+def _bits_of(t, n):
+    return np.unpackbits(t.to_words((n + 31) // 32).view(np.uint8), bitorder="little")[:n].astype(bool)
+
+
+@pytest.mark.parametrize("case", ["dense12", "sparse40", "gap_planes"])
+def test_slice_scanner_range_search_vs_numpy(ctx, case):
+    """find_gt / find_ge / find_lt / find_le / find_range / find_zero / find_nonzero (src/bmsparsevec_algo.h:
+    1135-1174, 2290, 2690-2880, 4464) against a plain numpy column, incl. NULL elements (stored as 0, excluded
+    wherever the predicate admits 0: needs_null_correct_*, :1703-1735), absent planes, bounds with bits above
+    every plane, rows past size() and planes of every block kind"""
+    rng = np.random.default_rng({"dense12": 21, "sparse40": 22, "gap_planes": 23}[case])
+    n = 5 * 65536 + 4321
+    if case == "dense12":
+        col = rng.integers(0, 4000, size=n).astype(np.uint64); nplanes = 12
+    elif case == "sparse40":
+        col = np.where(rng.random(n) < 0.01, rng.integers(1, 1 << 40, size=n), 0).astype(np.uint64); nplanes = 40
+    else:   # long runs of equal values: GAP / FULL / NULL plane blocks
+        col = np.repeat(rng.integers(0, 64, size=n // 997 + 1), 997)[:n].astype(np.uint64); nplanes = 7
+        col[65536:2 * 65536] = 63                                      # FULL blocks in the low planes
+    notnull = rng.random(n) < 0.9
+    col[~notnull] = 0
+    def upload(bits):
+        w = np.packbits(np.concatenate([bits.astype(np.uint8), np.zeros((-n) % 32, np.uint8)]), bitorder="little").view(np.uint32)
+        return bm.bit_import_u32(ctx, w, True)
+    slices = []
+    for b in range(nplanes):
+        bits = ((col >> np.uint64(b)) & np.uint64(1)).astype(bool)
+        slices.append(upload(bits) if bits.any() else None)
+    nn = upload(notnull)
+    for with_null in (False, True):
+        sc = bm.slice_scanner(ctx, slices, size=n, not_null=nn if with_null else None)
+        valid = notnull if with_null else np.ones(n, bool)
+        bounds = [0, 1, 2, 5, 63, 64, 100, 1000, 3999, 4000, 4095, 4096, (1 << nplanes) - 1, 1 << nplanes, (1 << 40) + 5]
+        bounds += [int(x) for x in rng.choice(col[col > 0], 4)]
+        for v in bounds:
+            V = np.uint64(v)
+            exp = {"gt": col > V, "ge": (col >= V) & (valid if v == 0 else True), "lt": (col < V) & valid, "le": (col <= V) & valid}
+            got = {"gt": sc.find_gt(v), "ge": sc.find_ge(v), "lt": sc.find_lt(v), "le": sc.find_le(v)}
+            for k in exp:
+                assert (_bits_of(got[k], n) == exp[k]).all(), (case, with_null, k, v)
+                assert got[k].count() == int(np.count_nonzero(exp[k]))
+            assert sc.count(bm.CMP_GT, v) == int((col > V).sum())
+        for lo, hi in [(0, 0), (0, 10), (5, 5), (10, 3), (100, 3000), (1, (1 << 40)), (4000, 1 << 50)] + \
+                      [tuple(int(x) for x in rng.choice(col[col > 0], 2)) for _ in range(3)]:
+            a, b = min(lo, hi), max(lo, hi)
+            exp = (col >= np.uint64(a)) & (col <= np.uint64(b)) & (valid if a == 0 else True)
+            t = sc.find_range(lo, hi)
+            assert (_bits_of(t, n) == exp).all(), (case, with_null, lo, hi)
+            assert sc.count(bm.CMP_RANGE, lo, hi) == int(exp.sum())
+        assert (_bits_of(sc.find_zero(), n) == ((col == 0) & valid)).all()
+        assert (_bits_of(sc.find_nonzero(), n) == (col != 0)).all()
+        t, f = sc.find_eq(0)
+        assert (_bits_of(t, n) == ((col == 0) & valid)).all() and f == bool(((col == 0) & valid).any())
+    # rows past size() never appear, whatever the planes hold there
+    sc = bm.slice_scanner(ctx, slices, size=n - 70000)
+    assert sc.find_le(1 << 50).count() == n - 70000 and sc.find_zero().count() == int((col[:n - 70000] == 0).sum())
 
 
 def test_block_range_shards_add_up(ctx, port):
