@@ -357,11 +357,12 @@ class arg_groups:
 class agg_run_options:
     """bm::agg_run_options<OBvects, OCounts> (src/bmaggregator.h:62-103)"""
 
-    def __init__(self, make_results: bool = True, compute_counts: bool = False):
-        self.make_results, self.compute_counts = make_results, compute_counts
+    def __init__(self, make_results: bool = True, compute_counts: bool = False, search_masks: bool = False):
+        self.make_results, self.compute_counts, self.search_masks = make_results, compute_counts, search_masks
 
     def is_make_results(self): return self.make_results
     def is_compute_counts(self): return self.compute_counts
+    def is_masks(self): return self.search_masks                          # :78: the pipeline honours set_range_hint
 
 
 agg_opt_disable_bvects_and_counts = agg_run_options(False, False)    # :84
@@ -462,6 +463,17 @@ class aggregator:
         self.opt_mode = False            # opt_none, :917
         self.compute_count = False
         self._count = 0
+        self._range = None               # set_range_hint, :837-839
+
+    def set_range_hint(self, frm: int, to: int) -> bool:                 # :481,974
+        """where results need to be searched: find_first_and_sub visits the block columns of the range only (a
+        one-block range is also bit-masked); combine_and_sub(pipe) honours it when the pipeline options enable
+        search masks.  -> True if the range is one-block bound"""
+        self._range = (int(frm), int(to))
+        return (int(frm) >> 16) == (int(to) >> 16)
+
+    def reset_range_hint(self):                                          # :486,962
+        self._range = None
 
     def set_optimization(self, opt: bool = True):                        # :359
         self.opt_mode = bool(opt)
@@ -528,12 +540,23 @@ class aggregator:
         a = list(bv_src_and) if bv_src_and is not None else self.ag.arg_bv0
         s = list(bv_src_sub) if bv_src_sub is not None else self.ag.arg_bv1
         found, idx = C.c_int(), C.c_uint64()
-        check(lib().bmx_find_first_and_sub(self.ctx._h, _handles(a), len(a), _handles(s), len(s), C.byref(found), C.byref(idx)))
+        if self._range is not None:
+            check(lib().bmx_find_first_and_sub_range(self.ctx._h, _handles(a), len(a), _handles(s), len(s),
+                                                     self._range[0], self._range[1], C.byref(found), C.byref(idx)))
+        else:
+            check(lib().bmx_find_first_and_sub(self.ctx._h, _handles(a), len(a), _handles(s), len(s), C.byref(found), C.byref(idx)))
         return bool(found.value), int(idx.value)
 
-    def _run_pipeline(self, pipe: pipeline, nb_from: int = 0, nb_to: int = ID_MAX):
+    def _hint_blocks(self, pipe: pipeline):
+        if self._range is not None and pipe.opt.is_masks():
+            return self._range[0] >> 16, (self._range[1] >> 16) + 1
+        return 0, ID_MAX
+
+    def _run_pipeline(self, pipe: pipeline, nb_from: int | None = None, nb_to: int | None = None):
         if not pipe.is_complete():
             raise RuntimeError("pipeline is not complete()")
+        if nb_from is None:
+            nb_from, nb_to = self._hint_blocks(pipe)
         out = np.zeros(max(pipe.size(), 1), np.uint64)
         check(lib().bmx_pipeline_run_counts(self.ctx._h, pipe._h, nb_from, nb_to,
                                             out.ctypes.data_as(C.POINTER(C.c_uint64))))
@@ -549,8 +572,9 @@ class aggregator:
         ort = C.c_void_p()
         want_res = pipe.opt.is_make_results()
         want_cnt = pipe.opt.is_compute_counts()
-        check(lib().bmx_pipeline_run_results(
-            self.ctx._h, pipe._h, res if want_res else None,
+        nbf, nbt = self._hint_blocks(pipe)
+        check(lib().bmx_pipeline_run_results_range(
+            self.ctx._h, pipe._h, nbf, nbt, res if want_res else None,
             cnt.ctypes.data_as(C.POINTER(C.c_uint64)) if (want_cnt and want_res) else None,
             pipe._or_target._h if (pipe._want_or_target and pipe._or_target is not None) else None,
             C.byref(ort) if pipe._want_or_target else None))

@@ -69,6 +69,7 @@ def lib() -> C.CDLL:
         "bmx_agg_or_opt": (i32, [vp, P(vp), C.c_size_t, i32, P(vp)]),
         "bmx_agg_and_sub": (i32, [vp, P(vp), C.c_size_t, P(vp), C.c_size_t, P(vp), P(i32)]),
         "bmx_find_first_and_sub": (i32, [vp, P(vp), C.c_size_t, P(vp), C.c_size_t, P(i32), P(u64)]),
+        "bmx_find_first_and_sub_range": (i32, [vp, P(vp), C.c_size_t, P(vp), C.c_size_t, u64, u64, P(i32), P(u64)]),
         "bmx_agg_shift_right_and": (i32, [vp, P(vp), C.c_size_t, i32, i32, P(vp), P(i32)]),
         "bmx_agg_shift_right_and_count": (i32, [vp, P(vp), C.c_size_t, P(u64)]),
         "bmx_slice_compare": (i32, [vp, P(vp), C.c_size_t, i32, u64, u64, u64, vp, P(vp), P(u64)]),
@@ -77,6 +78,7 @@ def lib() -> C.CDLL:
         "bmx_pipeline_run_counts": (i32, [vp, vp, u32, u32, P(u64)]),
         "bmx_pipeline_run_counts_dev": (i32, [vp, vp, u32, u32, vp]),
         "bmx_pipeline_run_results": (i32, [vp, vp, P(vp), P(u64), vp, P(vp)]),
+        "bmx_pipeline_run_results_range": (i32, [vp, vp, u32, u32, P(vp), P(u64), vp, P(vp)]),
         "bmx_pipeline_operand_bytes": (i32, [vp, vp, u32, u32, P(u64)]),
         "bmx_pipeline_describe": (i32, [vp, vp, u32, u32, C.c_char_p, C.c_size_t, P(u32)]),
         "bmx_rs_build": (i32, [vp, vp, P(vp)]),

@@ -1174,7 +1174,7 @@ int bmx_agg_and_sub(bmx_ctx* ctx, const bmx_vec* const* src_and, size_t n_and,
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_agg_and_sub<2>), dim3((ncols + 3) / 4), dim3(256), lds, ctx->stream,
                            p->d_dmat, p->d_meta + 1, p->d_meta + 2, p->col_stride, ncols,
                            1 /* combine_and_sub always stores with opt_compress, :1210 */, ctx->xcd_swz,
-                           v->d_bits, v->d_desc, st);
+                           v->d_bits, v->d_desc, st, 0u, 0xFFFFFFFFu);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) rc = fail_hip(e, "k_agg_and_sub", __LINE__);
     }
@@ -1187,10 +1187,26 @@ int bmx_agg_and_sub(bmx_ctx* ctx, const bmx_vec* const* src_and, size_t n_and,
 }
 
 // combine_and_sub(pipe) with result vectors / counts / OR target (src/bmaggregator.h:1292-1449)
+static int run_results_impl(bmx_ctx* ctx, bmx_pipeline* p, uint32_t nb_from, uint32_t nb_to, bmx_vec** results_out, uint64_t* counts_out,
+                            const bmx_vec* or_target_in, bmx_vec** or_target_out);
+
 int bmx_pipeline_run_results(bmx_ctx* ctx, bmx_pipeline* p, bmx_vec** results_out, uint64_t* counts_out,
                              const bmx_vec* or_target_in, bmx_vec** or_target_out)
 {
+    return run_results_impl(ctx, p, 0u, 0xFFFFFFFFu, results_out, counts_out, or_target_in, or_target_out);
+}
+
+int bmx_pipeline_run_results_range(bmx_ctx* ctx, bmx_pipeline* p, uint32_t nb_from, uint32_t nb_to, bmx_vec** results_out,
+                                   uint64_t* counts_out, const bmx_vec* or_target_in, bmx_vec** or_target_out)
+{
+    return run_results_impl(ctx, p, nb_from, nb_to, results_out, counts_out, or_target_in, or_target_out);
+}
+
+static int run_results_impl(bmx_ctx* ctx, bmx_pipeline* p, uint32_t nb_from, uint32_t nb_to, bmx_vec** results_out, uint64_t* counts_out,
+                            const bmx_vec* or_target_in, bmx_vec** or_target_out)
+{
     ARGCHK(ctx && p && p->ctx == ctx && (results_out || or_target_out));
+    { int rcr = pipe_range(p, nb_from, nb_to); if (rcr) return rcr; }
     ARGCHK(!or_target_in || or_target_in->ctx == ctx);
     int rc = set_dev(ctx); if (rc) return rc;
     std::vector<bmx_vec*> res(p->ngroups, nullptr);
@@ -1203,7 +1219,7 @@ int bmx_pipeline_run_results(bmx_ctx* ctx, bmx_pipeline* p, bmx_vec** results_ou
         size_t lds = p->has_gap ? 4 * 2048 * 4 : 0;
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_agg_and_sub<2>), dim3((p->ncols + 3) / 4), dim3(256), lds, ctx->stream,
                            p->d_dmat + (*p->h_row_off)[g], p->d_meta + p->ngroups + g, p->d_meta + 2 * p->ngroups + g,
-                           p->col_stride, p->ncols, 1 /* opt_compress, :1421 */, ctx->xcd_swz, v->d_bits, v->d_desc, st);
+                           p->col_stride, p->ncols, 1 /* opt_compress, :1421 */, ctx->xcd_swz, v->d_bits, v->d_desc, st, nb_from, nb_to);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) { bmx_vec_free(ctx, v); cleanup(); return fail_hip(e, "k_agg_and_sub", __LINE__); }
         if ((rc = result_finish(ctx, v, st, offs))) { bmx_vec_free(ctx, v); cleanup(); return rc; }
@@ -1223,21 +1239,29 @@ int bmx_pipeline_run_results(bmx_ctx* ctx, bmx_pipeline* p, bmx_vec** results_ou
     return BMX_OK;
 }
 
-int bmx_find_first_and_sub(bmx_ctx* ctx, const bmx_vec* const* src_and, size_t n_and,
-                           const bmx_vec* const* src_sub, size_t n_sub, int* found, uint64_t* idx)
+static int find_first_impl(bmx_ctx* ctx, const bmx_vec* const* src_and, size_t n_and, const bmx_vec* const* src_sub, size_t n_sub,
+                           bool ranged, uint64_t from, uint64_t to, int* found, uint64_t* idx)
 {
     ARGCHK(ctx && found && idx && (n_and == 0 || src_and) && (n_sub == 0 || src_sub));
     *found = 0; *idx = 0;
     int rc = set_dev(ctx); if (rc) return rc;
     if (!n_and) return BMX_OK;
+    if (ranged && from > to) { g_last_error = "range hint: from > to"; return BMX_ERR_RANGE; }
     uint32_t an = (uint32_t)n_and, sn = (uint32_t)n_sub;
     bmx_pipeline* p = nullptr;
     if ((rc = bmx_pipeline_create(ctx, src_and, &an, src_sub, &sn, 1, &p))) return rc;
+    u32 col_from = 0, col_to = p->ncols; int has_mask = 0; u32 mf = 0, mt = 65535u;
+    if (ranged) {
+        uint64_t nbf = from >> 16, nbt = to >> 16;
+        col_from = (u32)std::min<uint64_t>(nbf, p->ncols);
+        col_to = (u32)std::min<uint64_t>(nbt + 1u, p->ncols);
+        if (nbf == nbt) { has_mask = 1; mf = (u32)(from & 65535u); mt = (u32)(to & 65535u); }
+    }
     hipError_t e = hipMemsetAsync(ctx->d_small, 0xFF, 8, ctx->stream);
-    if (e == hipSuccess && p->ncols) {
+    if (e == hipSuccess && col_to > col_from) {
         size_t lds = p->has_gap ? 4 * 2048 * 4 : 0;
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_find_first_and_sub<2>), dim3((p->ncols + 3) / 4), dim3(256), lds, ctx->stream,
-                           p->d_dmat, p->d_meta + 1, p->d_meta + 2, p->col_stride, p->ncols, ctx->d_small);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_find_first_and_sub<2>), dim3((col_to - col_from + 3) / 4), dim3(256), lds, ctx->stream,
+                           p->d_dmat, p->d_meta + 1, p->d_meta + 2, p->col_stride, col_from, col_to, has_mask, mf, mt, ctx->d_small);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(ctx->h_small, ctx->d_small, 8, hipMemcpyDeviceToHost, ctx->stream);
@@ -1246,6 +1270,19 @@ int bmx_find_first_and_sub(bmx_ctx* ctx, const bmx_vec* const* src_and, size_t n
     if (e != hipSuccess) return fail_hip(e, "bmx_find_first_and_sub", __LINE__);
     if (ctx->h_small[0] != ~0ull) { *found = 1; *idx = ctx->h_small[0]; }
     return BMX_OK;
+}
+
+int bmx_find_first_and_sub(bmx_ctx* ctx, const bmx_vec* const* src_and, size_t n_and,
+                           const bmx_vec* const* src_sub, size_t n_sub, int* found, uint64_t* idx)
+{
+    return find_first_impl(ctx, src_and, n_and, src_sub, n_sub, false, 0, 0, found, idx);
+}
+
+int bmx_find_first_and_sub_range(bmx_ctx* ctx, const bmx_vec* const* src_and, size_t n_and,
+                                 const bmx_vec* const* src_sub, size_t n_sub, uint64_t from, uint64_t to,
+                                 int* found, uint64_t* idx)
+{
+    return find_first_impl(ctx, src_and, n_and, src_sub, n_sub, true, from, to, found, idx);
 }
 
 // aggregator::combine_shift_right_and  src/bmaggregator.h:552,2494 (count form: set_compute_count, :363,2595)

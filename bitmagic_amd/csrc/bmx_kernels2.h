@@ -391,13 +391,15 @@ template <int U>
 __global__ __launch_bounds__(256)
 void k_agg_and_sub(const u64* __restrict__ dmat, const u32* __restrict__ and_n_p, const u32* __restrict__ sub_n_p,
                    u32 col_stride, u32 ncols, int opt_compress, int xcd_swz,
-                   uint4* __restrict__ slab, u64* __restrict__ desc, BlockStat* __restrict__ st)
+                   uint4* __restrict__ slab, u64* __restrict__ desc, BlockStat* __restrict__ st,
+                   u32 col_from, u32 col_to)
 {
     extern __shared__ u32 lds_dyn[];
     u32 lane = lane_id(), wave = threadIdx.x >> 6;
     u32 bid = xcd_swz ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
     u32 c = uniform32(bid * 4u + wave);
     if (c >= ncols) return;
+    if (c < col_from || c >= col_to) { store_trivial(K_NULL, c, desc, st, lane); return; }     // outside the range hint: not visited (:1339-1346)
     const u64* row = dmat + (size_t)c * col_stride;
     u64 hdr = uniform64(row[0]), flags = uniform64(row[1]);
     if (flags & ROW_EMPTY) { store_trivial(K_NULL, c, desc, st, lane); return; }
@@ -503,18 +505,22 @@ void k_pipe_counts_staged(const u64* const* __restrict__ udesc, const u32* __res
 template <int U>
 __global__ __launch_bounds__(256)
 void k_find_first_and_sub(const u64* __restrict__ dmat, const u32* __restrict__ and_n_p, const u32* __restrict__ sub_n_p,
-                          u32 col_stride, u32 ncols, u64* __restrict__ best)
+                          u32 col_stride, u32 col_from, u32 ncols, int has_mask, u32 mask_from, u32 mask_to,
+                          u64* __restrict__ best)
 {
+    // [col_from, ncols): aggregator::set_range_hint (src/bmaggregator.h:974): the search visits the block columns of
+    // the hint only (:1470-1512); has_mask: both ends of the hint lie in this one block, which is then AND-ed with
+    // the bit range [mask_from, mask_to] (range_gap_blk_, :980-988, 2354-2358)
     extern __shared__ u32 lds_dyn[];
     u32 lane = lane_id(), wave = threadIdx.x >> 6;
-    u32 c = uniform32(blockIdx.x * 4u + wave);
+    u32 c = uniform32(col_from + blockIdx.x * 4u + wave);
     if (c >= ncols) return;
     u64 cur = __hip_atomic_load(best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (((u64)c << 16) > cur) return;
     const u64* row = dmat + (size_t)c * col_stride;
     u64 hdr = uniform64(row[0]), flags = uniform64(row[1]);
     if (flags & ROW_EMPTY) return;
-    if (flags & ROW_FULL) { if (lane == 0) atomicMin(reinterpret_cast<unsigned long long*>(best), (unsigned long long)c << 16); return; }
+    if (flags & ROW_FULL) { if (lane == 0) atomicMin(reinterpret_cast<unsigned long long*>(best), ((unsigned long long)c << 16) + (has_mask ? mask_from : 0u)); return; }
     u32 nba = (u32)(hdr & 0xFFFFu), nga = (u32)((hdr >> 16) & 0xFFFFu);
     u32 nbs = (u32)((hdr >> 32) & 0xFFFFu), ngs = (u32)(hdr >> 48);
     u32 na = uniform32(and_n_p[0]), ns = uniform32(sub_n_p[0]);
@@ -530,6 +536,21 @@ void k_find_first_and_sub(const u64* __restrict__ dmat, const u32* __restrict__ 
         if (nga && gap_apply_list<GAP_AND>(pa + na - 1u, nga, lds, lane)) return;
         if (ngs && gap_apply_list<GAP_SUB>(ps + ns - 1u, ngs, lds, lane)) return;
         blk_from_lds(acc, lds, lane);
+    }
+    if (has_mask) {
+        u32 r = mask_to + 1u;                                   // rows [mask_from, mask_to] of the block
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            u32 ws[4] = {acc.r[i].x, acc.r[i].y, acc.r[i].z, acc.r[i].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                u32 lo = ((u32)i * 256u + lane * 4u + (u32)j) << 5;
+                u32 hi_m = r >= lo + 32u ? ~0u : (r <= lo ? 0u : ((1u << (r - lo)) - 1u));
+                u32 lo_m = mask_from <= lo ? ~0u : (mask_from >= lo + 32u ? 0u : (~0u << (mask_from - lo)));
+                ws[j] &= hi_m & lo_m;
+            }
+            acc.r[i].x = ws[0]; acc.r[i].y = ws[1]; acc.r[i].z = ws[2]; acc.r[i].w = ws[3];
+        }
     }
     // bit_find_first (src/bmfunc.h:9499): smallest linear bit index held by this lane, then wave min
     u32 mine = 0xFFFFFFFFu;

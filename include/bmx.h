@@ -153,6 +153,13 @@ int bmx_agg_and_sub(bmx_ctx* ctx, const bmx_vec* const* src_and, size_t n_and,
  * index of the first set bit of the AND-SUB result, nothing materialised. */
 int bmx_find_first_and_sub(bmx_ctx* ctx, const bmx_vec* const* src_and, size_t n_and,
                            const bmx_vec* const* src_sub, size_t n_sub, int* found, uint64_t* idx);
+/* the same under aggregator::set_range_hint(from, to) (src/bmaggregator.h:481,974): only block columns
+ * [from >> 16, to >> 16] are visited (:1470-1512); when both ends lie in ONE block that column is also AND-ed with
+ * the bit range [from & 65535, to & 65535] (range_gap_blk_, :980-988, 2354-2358) -- a hint spanning several blocks is
+ * block-granular, exactly like the reference. */
+int bmx_find_first_and_sub_range(bmx_ctx* ctx, const bmx_vec* const* src_and, size_t n_and,
+                                 const bmx_vec* const* src_sub, size_t n_sub, uint64_t from, uint64_t to,
+                                 int* found, uint64_t* idx);
 /* aggregator::combine_shift_right_and(bv_target, src, n, any)  src/bmaggregator.h:552,2494 (member form
  * :473,1089): T_0 = src[0], T_k = (T_{k-1} >> 1) & src[k] with ">>" moving bit p to p+1 across block
  * borders (process_shift_right_and :2618) -- result bit p is set iff src[k] has bit p-(n-1-k) for every k
@@ -213,6 +220,10 @@ int bmx_pipeline_run_counts_dev(bmx_ctx* ctx, bmx_pipeline* p, uint32_t nb_from,
  * set_search_count_limit (:255) is approximate by contract ("can find more"); it is accepted and ignored. */
 int bmx_pipeline_run_results(bmx_ctx* ctx, bmx_pipeline* p, bmx_vec** results_out, uint64_t* counts_out,
                              const bmx_vec* or_target_in, bmx_vec** or_target_out);
+/* same for a pipeline whose options enable search masks (agg_run_options<.., .., true>::is_masks(), :65,78) under
+ * set_range_hint: only block columns [nb_from, nb_to) are visited (:1312-1346); results hold nothing outside */
+int bmx_pipeline_run_results_range(bmx_ctx* ctx, bmx_pipeline* p, uint32_t nb_from, uint32_t nb_to, bmx_vec** results_out,
+                                   uint64_t* counts_out, const bmx_vec* or_target_in, bmx_vec** or_target_out);
 /* algorithmic operand bytes one run over [nb_from, nb_to) must read
  * (8192 B per bit-block operand, 2*(len+1) B per GAP operand; NULL/FULL: 0) */
 int bmx_pipeline_operand_bytes(bmx_ctx* ctx, bmx_pipeline* p, uint32_t nb_from, uint32_t nb_to,

@@ -274,10 +274,11 @@ inline size_type count_xor(const bvector& a, const bvector& b) { return detail::
 inline size_type count_sub(const bvector& a, const bvector& b) { return detail::count_op(BMX_SUB, a, b); }   // :115
 
 /// run options (src/bmaggregator.h:62-103)
-template <bool OBvects = true, bool OCounts = false>
+template <bool OBvects = true, bool OCounts = false, bool OSearchMasks = false>
 struct agg_run_options {
     static constexpr bool is_make_results() noexcept { return OBvects; }
     static constexpr bool is_compute_counts() noexcept { return OCounts; }
+    static constexpr bool is_masks() noexcept { return OSearchMasks; }          // :78: honours set_range_hint
 };
 typedef agg_run_options<false, false> agg_opt_disable_bvects_and_counts;   // :84
 typedef agg_run_options<false, true> agg_opt_only_counts;                  // :92
@@ -390,6 +391,12 @@ public:
         bv_target.adopt(r);
         return any != 0;
     }
+    /// set_range_hint(from, to) :481,974 -- where results need to be searched: find_first_and_sub visits the block
+    /// columns of the range only (one-block ranges are also bit-masked), combine_and_sub(pipe) honours it when the
+    /// pipeline options enable search masks (is_masks(), :1312-1346).  @return true if the range is one-block bound
+    bool set_range_hint(size_type from, size_type to) noexcept
+    { range_set_ = true; range_from_ = from; range_to_ = to; return (from >> 16) == (to >> 16); }
+    void reset_range_hint() noexcept { range_set_ = false; }                                 // :486,962
     /// set_optimization :359, set_compute_count :363, count() :488
     void set_optimization(bool opt_compress = true) { opt_compress_ = opt_compress; }
     void set_compute_count(bool count_mode) { compute_count_ = count_mode; count_ = 0; }
@@ -429,7 +436,9 @@ public:
         for (size_t i = 0; i < src_and_size; ++i) a[i] = bv_src_and[i]->handle();
         for (size_t i = 0; i < src_sub_size; ++i) s[i] = bv_src_sub[i]->handle();
         int found = 0; uint64_t p = 0;
-        check(bmx_find_first_and_sub(ctx_->handle(), a.data(), src_and_size, s.data(), src_sub_size, &found, &p));
+        if (range_set_) check(bmx_find_first_and_sub_range(ctx_->handle(), a.data(), src_and_size, s.data(), src_sub_size,
+                                                           range_from_, range_to_, &found, &p));
+        else check(bmx_find_first_and_sub(ctx_->handle(), a.data(), src_and_size, s.data(), src_sub_size, &found, &p));
         if (found) idx = p;
         return found != 0;
     }
@@ -440,22 +449,25 @@ public:
         if (!pipe.is_complete()) throw error(BMX_ERR_BADARG, "pipeline is not complete()");
         if (!pipe.size()) return;
         typedef typename TPipe::options_type opt;
+        // search masks enabled + a range hint: only the block columns of the hint are visited (:1312-1346)
+        uint32_t nbf = 0, nbt = 0xFFFFFFFFu;
+        if (opt::is_masks() && range_set_) { nbf = (uint32_t)(range_from_ >> 16); nbt = (uint32_t)(range_to_ >> 16) + 1u; }
         if (opt::is_make_results() || pipe.or_target_) {
             std::vector<bmx_vec*> res(pipe.size(), nullptr);
             bmx_vec* ort = nullptr;
             const bmx_vec* ort_in = (pipe.or_target_ && !pipe.or_target_->empty_handle()) ? pipe.or_target_->handle() : nullptr;
-            check(bmx_pipeline_run_results(ctx_->handle(), pipe.h_, opt::is_make_results() ? res.data() : nullptr,
-                                           (opt::is_make_results() && opt::is_compute_counts()) ? pipe.counts_.data() : nullptr,
-                                           ort_in, pipe.or_target_ ? &ort : nullptr));
+            check(bmx_pipeline_run_results_range(ctx_->handle(), pipe.h_, nbf, nbt, opt::is_make_results() ? res.data() : nullptr,
+                                                 (opt::is_make_results() && opt::is_compute_counts()) ? pipe.counts_.data() : nullptr,
+                                                 ort_in, pipe.or_target_ ? &ort : nullptr));
             for (size_t i = 0; i < pipe.results_.size(); ++i) delete pipe.results_[i];
             pipe.results_.assign(pipe.size(), nullptr);
             for (size_t g = 0; g < res.size(); ++g)
                 if (res[g]) { pipe.results_[g] = new BV(*ctx_); pipe.results_[g]->adopt(res[g]); }
             if (pipe.or_target_) pipe.or_target_->adopt(ort);
             if (opt::is_compute_counts() && !opt::is_make_results())
-                check(bmx_pipeline_run_counts(ctx_->handle(), pipe.h_, 0, 0xFFFFFFFFu, pipe.counts_.data()));
+                check(bmx_pipeline_run_counts(ctx_->handle(), pipe.h_, nbf, nbt, pipe.counts_.data()));
         } else if (opt::is_compute_counts()) {
-            check(bmx_pipeline_run_counts(ctx_->handle(), pipe.h_, 0, 0xFFFFFFFFu, pipe.counts_.data()));
+            check(bmx_pipeline_run_counts(ctx_->handle(), pipe.h_, nbf, nbt, pipe.counts_.data()));
         }
     }
 
@@ -465,6 +477,8 @@ private:
     bool opt_compress_ = false;          // opt_mode_ = opt_none, src/bmaggregator.h:917
     bool compute_count_ = false;
     size_type count_ = 0;
+    bool range_set_ = false;             // :837-839
+    size_type range_from_ = 0, range_to_ = 0;
 };
 
 } // namespace bmx

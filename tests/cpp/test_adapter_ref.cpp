@@ -220,6 +220,27 @@ int main()
             { bvect r; bmx::bvector g(ctx); r2.find_eq(S, 0u, r); bool gf = g2.find_eq(0, g); REQUIRE(r.any() == gf && same(r, g)); }
         }
     }
+    // set_range_hint + find_first_and_sub vs the real aggregator (src/bmaggregator.h:974,1458)
+    {
+        bm::aggregator<bvect> ragg; bmx::aggregator<bmx::bvector> gagg(ctx);
+        ragg.add(&hv[0]); ragg.add(&hv[1]); ragg.add(&hv[2], 1);
+        gagg.add(&gv[0]); gagg.add(&gv[1]); gagg.add(&gv[2], 1);
+        uint64_t x = 0x9E3779B97F4A7C15ull;
+        for (int it = 0; it < 40; ++it) {
+            x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+            uint64_t a = x % nbits; x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+            uint64_t b = (it & 1) ? std::min<uint64_t>(nbits - 1, a + x % 3000) : x % nbits;
+            if (a > b) std::swap(a, b);
+            bool r1 = ragg.set_range_hint(bvect::size_type(a), bvect::size_type(b));
+            bool g1 = gagg.set_range_hint(a, b);
+            bvect::size_type ri = 0; bmx::size_type gi = 0;
+            bool rf = ragg.find_first_and_sub(ri), gf = gagg.find_first_and_sub(gi);
+            REQUIRE(r1 == g1 && rf == gf && (!rf || ri == gi));
+        }
+        ragg.reset_range_hint(); gagg.reset_range_hint();
+        bvect::size_type ri = 0; bmx::size_type gi = 0;
+        REQUIRE(ragg.find_first_and_sub(ri) == gagg.find_first_and_sub(gi) && ri == gi);
+    }
     // rank / select vs bvector<>::count_to / select with the reference rs_index
     {
         bvect::rs_index_type rrs; hv[3].build_rs_index(&rrs);

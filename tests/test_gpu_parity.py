@@ -869,3 +869,52 @@ def test_full_size_shift_right_and_properties(ctx, port):
         exp = np.packbits(shifted, bitorder="little").view(np.uint32) & wb
         got = t.to_words((nb0 + 1) * 2048)[nb0 * 2048: nb0 * 2048 + nw]
         assert (got == exp).all(), nb0
+
+
+def test_range_hint(ctx, port):
+    """aggregator::set_range_hint (src/bmaggregator.h:481,974): find_first_and_sub visits the block columns of the
+    hint only, a one-block hint is also bit-masked (:1470-1512, range_gap_blk_ :980-988); combine_and_sub(pipe)
+    honours it when the pipeline options enable search masks (:1312-1346).  Expected values are derived from the
+    oracle's materialised result."""
+    nbits = 9 * 65536 + 17
+    words = [port.gen_words(SEED + 5, v, d, nbits, with_common=True) for v, d in enumerate((20000, 30000, 300, 9000))]
+    pv = [port.import_words(w, True, nbits) for w in words]
+    gv = [bm.bit_import_u32(ctx, w, True) for w in words]
+    e = port.agg_and_sub(pv[:2], pv[2:3])
+    bits = np.flatnonzero(np.unpackbits(e.to_words().view(np.uint8), bitorder="little"))
+    agg = bm.aggregator(ctx)
+    rng = np.random.default_rng(4)
+    cases = [(0, nbits - 1), (70000, 70010), (65536 * 3 + 5, 65536 * 3 + 40000), (65536 * 2, 65536 * 5 + 3), (8 * 65536 + 9, nbits - 1),
+             (5 * 65536 + 100, 5 * 65536 + 100)]
+    cases += [tuple(sorted(int(x) for x in rng.integers(0, nbits, 2))) for _ in range(20)]
+    for frm, to in cases:
+        one = agg.set_range_hint(frm, to)
+        assert one == ((frm >> 16) == (to >> 16))
+        f, idx = agg.find_first_and_sub(gv[:2], gv[2:3])
+        if one:
+            cand = bits[(bits >= frm) & (bits <= to)]
+        else:                                      # block-granular: [first bit of block(from), last bit of block(to)]
+            cand = bits[(bits >= (frm >> 16) << 16) & (bits < ((to >> 16) + 1) << 16)]
+        assert f == (cand.size > 0) and (not f or idx == cand[0]), (frm, to, f, idx, cand[:1])
+    agg.reset_range_hint()
+    assert agg.find_first_and_sub(gv[:2], gv[2:3]) == (bits.size > 0, int(bits[0]))
+    # pipeline with search masks: counts and results restricted to the block columns of the hint
+    for opt in (bm.agg_run_options(False, True, True), bm.agg_run_options(True, True, True), bm.agg_run_options(False, True, False)):
+        pipe = bm.aggregator.pipeline(ctx, opt)
+        for a, s_ in (([0, 1], [2]), ([0, 3], [])):
+            ag = pipe.add()
+            for i in a: ag.add(gv[i], 0)
+            for i in s_: ag.add(gv[i], 1)
+        pipe.complete()
+        agg.set_range_hint(65536 * 2 + 7, 65536 * 4 + 1)
+        agg.combine_and_sub(pipe)
+        cnt = pipe.get_bv_count_vector()
+        lo, hi = (2, 5) if opt.is_masks() else (0, 10)
+        exp = port.pipeline_counts([([pv[0], pv[1]], [pv[2]]), ([pv[0], pv[3]], [])], lo, hi)
+        assert (cnt == exp).all(), (opt.is_masks(), cnt, exp)
+        if opt.is_make_results():
+            for r, c in zip(pipe.get_bv_res_vector(), exp):
+                assert (r.count() if r is not None else 0) == c
+                k = r.block_table()[0]
+                assert not k[:2].any() and not k[5:].any()
+        agg.reset_range_hint()
