@@ -9,7 +9,10 @@
 // allocator rules of bm::bvector<> are untouched.
 #pragma once
 
+#include <cstdlib>
 #include <cstring>
+#include <memory>
+#include <unordered_map>
 #include <vector>
 
 #include "bvector.hpp"
@@ -219,5 +222,248 @@ void download(const gbvector& src, BMBV& dst)
                             bits.empty() ? nullptr : bits.data(), gaps.empty() ? nullptr : gaps.data()));
     install(dst, nblocks, kinds.data(), offs.data(), bits.data(), gaps.data());
 }
+
+/// process-wide default context for code that constructs its aggregators without arguments (device: BMX_DEVICE, default 0)
+inline context& default_context()
+{
+    static context ctx(std::getenv("BMX_DEVICE") ? std::atoi(std::getenv("BMX_DEVICE")) : 0);
+    return ctx;
+}
+
+/// bm::aggregator<BV> DROP-IN over HOST vectors: same constructor, add(const BV*, group) / reset() / combine_or /
+/// combine_and / combine_and_sub / find_first_and_sub / combine_shift_right_and / set_optimization / set_range_hint /
+/// pipeline<Opt> as bm::aggregator<BV> (src/bmaggregator.h:120-854, 1013-1079) -- application code changes ONE
+/// typedef:   bm::aggregator<bm::bvector<> > agg;   ->   bmx::device_aggregator<bm::bvector<> > agg;
+/// (tests/cpp builds /root/reference/samples/bvsample16/sample16.cpp exactly like that and compares its output).
+///
+/// add() takes host `const BV*`; operands are uploaded on first use and results are installed into the host target
+/// through the reference's own blocks_manager (bmx::download).  Upload cache, by vector address:
+///   * a freeze()d vector (is_ro(): immutable by construction, its arena is uploaded without a host-side gather) stays
+///     resident until invalidate() / the aggregator dies -- build the index once, query many times;
+///   * a mutable vector is uploaded again at every combine_* call unless set_cache_mutable(true) promises that
+///     invalidate(bv) is called after every change (the reference reads the live blocks at combine time, so silently
+///     re-using an old upload would not be a drop-in).
+/// A cached entry is also dropped when the vector's block-tree shape changed (size, top size, sub-array pointers).
+template <class BV>
+class device_aggregator {
+public:
+    typedef BV bvector_type;
+    typedef typename BV::size_type size_type;
+    typedef const bvector_type* bvector_type_const_ptr;
+
+    struct arg_groups {                                   // aggregator::arg_groups (src/bmaggregator.h:2925)
+        std::vector<bvector_type_const_ptr> arg_bv0, arg_bv1;
+        void reset() { arg_bv0.clear(); arg_bv1.clear(); }
+        size_t add(const BV* bv, unsigned agr_group)
+        {
+            if (agr_group > 1) throw error(BMX_ERR_RANGE, "BMX-03: Incorrect range or index [agr_group > 1]");   // BM_ERR_RANGE :2934
+            if (!bv) return 0;                                                                                  // ignored :2939
+            std::vector<bvector_type_const_ptr>& v = agr_group ? arg_bv1 : arg_bv0;
+            v.push_back(bv);
+            return v.size();
+        }
+    };
+
+    /// aggregator::pipeline<Opt> (src/bmaggregator.h:222-341) over host vectors; run with combine_and_sub(pipe)
+    template <class Opt = agg_run_options<> >
+    class pipeline {
+    public:
+        typedef Opt options_type;
+        pipeline() {}
+        ~pipeline() { for (size_t i = 0; i < groups_.size(); ++i) delete groups_[i]; for (size_t i = 0; i < results_.size(); ++i) delete results_[i]; }
+        pipeline(const pipeline&) = delete;
+        pipeline& operator=(const pipeline&) = delete;
+        arg_groups* add() { if (complete_) throw error(BMX_ERR_BADARG, "pipeline already complete()"); groups_.push_back(new arg_groups()); return groups_.back(); }
+        void complete() { complete_ = true; counts_.assign(groups_.size(), 0); }
+        bool is_complete() const noexcept { return complete_; }
+        size_t size() const noexcept { return groups_.size(); }
+        void set_or_target(BV* bv_or) noexcept { or_target_ = bv_or; }                      // :245
+        void set_search_count_limit(size_type limit) noexcept { limit_ = limit; }          // :255 (approximate by contract)
+        std::vector<BV*>& get_bv_res_vector() noexcept { return results_; }                // nullptr where a group found nothing
+        std::vector<size_type>& get_bv_count_vector() noexcept { return counts_; }
+    private:
+        friend class device_aggregator;
+        std::vector<arg_groups*> groups_;
+        std::vector<size_type> counts_;
+        std::vector<BV*> results_;
+        BV* or_target_ = nullptr;
+        size_type limit_ = ~size_type(0);
+        bool complete_ = false;
+    };
+
+    device_aggregator() : ctx_(&default_context()), agg_(*ctx_) {}
+    explicit device_aggregator(context& ctx) : ctx_(&ctx), agg_(ctx) {}
+    device_aggregator(const device_aggregator&) = delete;
+    device_aggregator& operator=(const device_aggregator&) = delete;
+
+    // ---- bm::aggregator surface ----
+    size_t add(const BV* bv, unsigned agr_group = 0) { return ag_.add(bv, agr_group); }     // :1013
+    void reset() { ag_.reset(); agg_.reset_range_hint(); }                                  // :941 (also clears the range hint, :944)
+    void set_optimization(typename BV::optmode opt = BV::opt_compress) { agg_.set_optimization(opt == BV::opt_compress); }   // :359
+    void set_compute_count(bool count_mode) { agg_.set_compute_count(count_mode); }         // :363
+    size_type count() const { return (size_type)agg_.count(); }                            // :488
+    bool set_range_hint(size_type from, size_type to) noexcept { return agg_.set_range_hint(from, to); }   // :481
+    void reset_range_hint() noexcept { agg_.reset_range_hint(); }
+
+    void combine_or(BV& bv_target) { combine_or(bv_target, ag_.arg_bv0.data(), ag_.arg_bv0.size()); }                          // :1021
+    void combine_and(BV& bv_target) { (void)combine_and_sub(bv_target, ag_.arg_bv0.data(), ag_.arg_bv0.size(), nullptr, 0, false); }   // :1030
+    bool combine_and_sub(BV& bv_target)                                                                                       // :1044
+    { return combine_and_sub(bv_target, ag_.arg_bv0.data(), ag_.arg_bv0.size(), ag_.arg_bv1.data(), ag_.arg_bv1.size(), false); }
+    bool combine_and_sub(BV& bv_target, bool any)
+    { return combine_and_sub(bv_target, ag_.arg_bv0.data(), ag_.arg_bv0.size(), ag_.arg_bv1.data(), ag_.arg_bv1.size(), any); }
+    bool find_first_and_sub(size_type& idx)                                                                                   // :1079
+    { return find_first_and_sub(idx, ag_.arg_bv0.data(), ag_.arg_bv0.size(), ag_.arg_bv1.data(), ag_.arg_bv1.size()); }
+    void combine_shift_right_and(BV& bv_target)                                                                               // :473,1089
+    { (void)combine_shift_right_and(bv_target, ag_.arg_bv0.data(), ag_.arg_bv0.size(), false); }
+
+    // C-style forms (:1101,1127,1162,1458,552)
+    void combine_or(BV& bv_target, const bvector_type_const_ptr* bv_src, size_t src_size)
+    {
+        op_scope scope(this);
+        std::vector<const bvector*> d = resident(bv_src, src_size);
+        ag_.reset();                                     // the reference clears the member arg-groups here (:1110)
+        bvector t(*ctx_);
+        agg_.combine_or(t, d.data(), d.size());
+        download(t, bv_target);
+    }
+    void combine_and(BV& bv_target, const bvector_type_const_ptr* bv_src, size_t src_size)
+    {
+        op_scope scope(this);
+        std::vector<const bvector*> d = resident(bv_src, src_size);
+        if (src_size > 1) ag_.reset();
+        bvector t(*ctx_);
+        (void)agg_.combine_and_sub(t, d.data(), d.size(), nullptr, 0, false);
+        download(t, bv_target);
+    }
+    bool combine_and_sub(BV& bv_target, const bvector_type_const_ptr* bv_src_and, size_t src_and_size,
+                         const bvector_type_const_ptr* bv_src_sub, size_t src_sub_size, bool any)
+    {
+        op_scope scope(this);
+        std::vector<const bvector*> a = resident(bv_src_and, src_and_size), s = resident(bv_src_sub, src_sub_size);
+        bvector t(*ctx_);
+        bool found = agg_.combine_and_sub(t, a.data(), a.size(), s.data(), s.size(), any);
+        download(t, bv_target);
+        return found;
+    }
+    bool find_first_and_sub(size_type& idx, const bvector_type_const_ptr* bv_src_and, size_t src_and_size,
+                            const bvector_type_const_ptr* bv_src_sub, size_t src_sub_size)
+    {
+        op_scope scope(this);
+        std::vector<const bvector*> a = resident(bv_src_and, src_and_size), s = resident(bv_src_sub, src_sub_size);
+        bmx::size_type p = 0;
+        bool found = agg_.find_first_and_sub(p, a.data(), a.size(), s.data(), s.size());
+        if (found) idx = (size_type)p;
+        return found;
+    }
+    bool combine_shift_right_and(BV& bv_target, const bvector_type_const_ptr* bv_src_and, size_t src_and_size, bool any)
+    {
+        op_scope scope(this);
+        std::vector<const bvector*> d = resident(bv_src_and, src_and_size);
+        bvector t(*ctx_);
+        bool found = agg_.combine_shift_right_and(t, d.data(), d.size(), any);
+        if (!t.empty_handle()) download(t, bv_target);   // count mode leaves the target untouched (:2593)
+        return found;
+    }
+
+    /// combine_and_sub(pipe)  :1292 -- counts land in pipe.get_bv_count_vector(), result vectors (host BV, owned by the
+    /// pipeline) in get_bv_res_vector(), the OR target is updated in place
+    template <class TPipe>
+    void combine_and_sub(TPipe& pipe)
+    {
+        if (!pipe.is_complete()) throw error(BMX_ERR_BADARG, "pipeline is not complete()");
+        if (!pipe.size()) return;
+        op_scope scope(this);
+        typedef typename TPipe::options_type opt;
+        typename aggregator<bvector>::template pipeline<opt> dp(*ctx_);
+        for (size_t g = 0; g < pipe.groups_.size(); ++g) {
+            typename aggregator<bvector>::arg_groups* dg = dp.add();
+            std::vector<const bvector*> a = resident(pipe.groups_[g]->arg_bv0.data(), pipe.groups_[g]->arg_bv0.size());
+            std::vector<const bvector*> s = resident(pipe.groups_[g]->arg_bv1.data(), pipe.groups_[g]->arg_bv1.size());
+            for (size_t i = 0; i < a.size(); ++i) dg->add(a[i], 0);
+            for (size_t i = 0; i < s.size(); ++i) dg->add(s[i], 1);
+        }
+        bvector ort(*ctx_);
+        if (pipe.or_target_) { upload(*pipe.or_target_, ort, common_blocks_); dp.set_or_target(&ort); }
+        dp.complete();
+        agg_.combine_and_sub(dp);
+        if (opt::is_compute_counts())
+            for (size_t g = 0; g < pipe.size(); ++g) pipe.counts_[g] = (size_type)dp.get_bv_count_vector()[g];
+        if (opt::is_make_results()) {
+            for (size_t i = 0; i < pipe.results_.size(); ++i) delete pipe.results_[i];
+            pipe.results_.assign(pipe.size(), nullptr);
+            for (size_t g = 0; g < pipe.size(); ++g)
+                if (bvector* r = dp.get_bv_res_vector()[g]) { pipe.results_[g] = new BV(); download(*r, *pipe.results_[g]); }
+        }
+        if (pipe.or_target_) download(ort, *pipe.or_target_);
+    }
+
+    // ---- upload cache control ----
+    void set_cache_mutable(bool on) noexcept { cache_mutable_ = on; }
+    void invalidate(const BV* bv) { cache_.erase(bv); }
+    void invalidate_all() { cache_.clear(); }
+    size_t cached_vectors() const noexcept { return cache_.size(); }
+    size_t uploads() const noexcept { return uploads_; }          ///< uploads performed so far (tests / tuning)
+    context& get_context() noexcept { return *ctx_; }
+
+private:
+    struct stamp {
+        uint64_t size = 0, top = 0, h = 0;
+        bool operator==(const stamp& o) const noexcept { return size == o.size && top == o.top && h == o.h; }
+    };
+    static stamp stamp_of(const BV& bv)
+    {
+        stamp st;
+        const typename BV::blocks_manager_type& bman = bv.get_blocks_manager();
+        st.size = bv.size();
+        if (!bman.is_init()) return st;
+        st.top = bman.top_block_size();
+        uint64_t h = 1469598103934665603ull;
+        bm::word_t*** root = bman.top_blocks_root();
+        for (unsigned i = 0; i < bman.top_block_size(); ++i) { h ^= (uint64_t)(uintptr_t)root[i]; h *= 1099511628211ull; }
+        st.h = h;
+        return st;
+    }
+    struct entry { std::unique_ptr<bvector> dev; stamp st; bool ro = false; uint32_t nblocks = 0; uint64_t epoch = 0; };
+
+    /// device copies of the operands (uploading what is not resident); every operand of one operation is uploaded
+    /// over the same block count, so that NULL tails behave as in the reference
+    std::vector<const bvector*> resident(const bvector_type_const_ptr* src, size_t n)
+    {
+        std::vector<const bvector*> out;
+        out.reserve(n);
+        for (size_t i = 0; i < n; ++i) {
+            const BV* bv = src[i];
+            if (!bv) throw error(BMX_ERR_BADARG, "BMX-02: null operand");
+            stamp st = stamp_of(*bv);
+            bool ro = bv->is_ro();
+            typename std::unordered_map<const BV*, entry>::iterator it = cache_.find(bv);
+            // uploaded earlier in THIS operation (the same vector in two lists): the copy is current by definition
+            bool keep = it != cache_.end() && it->second.st == st && it->second.ro == ro &&
+                        (ro || cache_mutable_ || it->second.epoch == epoch_);
+            if (!keep) {
+                entry e;
+                e.dev.reset(new bvector(*ctx_));
+                e.nblocks = effective_blocks(*bv);
+                upload(*bv, *e.dev, e.nblocks ? e.nblocks : 1u);
+                e.st = st; e.ro = ro; e.epoch = epoch_;
+                ++uploads_;
+                if (it != cache_.end()) it->second = std::move(e); else it = cache_.emplace(bv, std::move(e)).first;
+            }
+            if (it->second.nblocks > common_blocks_) common_blocks_ = it->second.nblocks;
+            out.push_back(it->second.dev.get());
+        }
+        return out;
+    }
+
+    context* ctx_;
+    aggregator<bvector> agg_;
+    arg_groups ag_;
+    std::unordered_map<const BV*, entry> cache_;
+    bool cache_mutable_ = false;
+    size_t uploads_ = 0;
+    uint32_t common_blocks_ = 1;
+    uint64_t epoch_ = 1;                 // one per public operation
+    struct op_scope { device_aggregator* a; explicit op_scope(device_aggregator* x) : a(x) { ++a->epoch_; } };
+};
 
 } // namespace bmx

@@ -241,6 +241,61 @@ int main()
         bvect::size_type ri = 0; bmx::size_type gi = 0;
         REQUIRE(ragg.find_first_and_sub(ri) == gagg.find_first_and_sub(gi) && ri == gi);
     }
+    // bmx::device_aggregator<bm::bvector<>>: the drop-in over HOST vectors vs bm::aggregator<bm::bvector<>>
+    // (add / combine_or / combine_and / combine_and_sub / find_first_and_sub / pipeline), and its upload cache
+    {
+        bm::aggregator<bvect> ragg; bmx::device_aggregator<bvect> dagg(ctx);
+        std::vector<bvect> fz(4);                         // frozen copies: cached across operations
+        for (unsigned v = 0; v < 4; ++v) { fz[v] = hv[v]; fz[v].freeze(); }
+        for (int round = 0; round < 2; ++round) {
+            for (unsigned v = 0; v < 3; ++v) { ragg.add(&hv[v]); dagg.add(round ? &fz[v] : &hv[v]); }
+            ragg.add(&hv[3], 1); dagg.add(round ? &fz[3] : &hv[3], 1);
+            bvect r, g;
+            bool rf = ragg.combine_and_sub(r), gf = dagg.combine_and_sub(g);
+            REQUIRE(rf == gf && g.compare(r) == 0);
+            bvect::size_type ri = 0, gi = 0;
+            REQUIRE(ragg.find_first_and_sub(ri) == dagg.find_first_and_sub(gi) && ri == gi);
+            ragg.combine_and(r); dagg.combine_and(g); REQUIRE(g.compare(r) == 0);
+            ragg.combine_or(r); dagg.combine_or(g); REQUIRE(g.compare(r) == 0);          // clears the groups (:1110)
+            ragg.combine_and(r); dagg.combine_and(g); REQUIRE(!r.any() && !g.any());      // empty AND group => cleared target
+            ragg.reset(); dagg.reset();
+        }
+        size_t up0 = dagg.uploads();
+        for (unsigned v = 0; v < 4; ++v) dagg.add(&fz[v]);
+        bvect g; dagg.combine_or(g);
+        REQUIRE(dagg.uploads() == up0);                   // frozen vectors were resident already
+        dagg.add(&hv[0]); dagg.add(&hv[1]); dagg.combine_and(g);
+        REQUIRE(dagg.uploads() == up0 + 2);               // mutable vectors are uploaded again ...
+        hv[0].set(12345); hv[0].clear_bit(12345);         // (a change the cache could not see)
+        dagg.add(&hv[0]); dagg.add(&hv[1]); dagg.combine_and(g);
+        REQUIRE(dagg.uploads() == up0 + 4);
+        dagg.set_cache_mutable(true);                     // ... unless the caller takes responsibility
+        dagg.add(&hv[0]); dagg.add(&hv[1]); dagg.combine_and(g);
+        dagg.add(&hv[0]); dagg.add(&hv[1]); dagg.combine_and(g);
+        REQUIRE(dagg.uploads() == up0 + 4);               // the copies of the previous operation are re-used
+        dagg.invalidate(&hv[0]);
+        dagg.add(&hv[0]); dagg.add(&hv[1]); dagg.combine_and(g);
+        REQUIRE(dagg.uploads() == up0 + 5);
+        { bm::aggregator<bvect> ra2; ra2.add(&hv[0]); ra2.add(&hv[1]); bvect r; ra2.combine_and(r); REQUIRE(g.compare(r) == 0); }
+        // pipeline over host vectors: counts + result vectors + OR target
+        typedef bm::agg_run_options<true, true> ropt; typedef bmx::agg_run_options<true, true> gopt;
+        bm::aggregator<bvect>::pipeline<ropt> rp; bmx::device_aggregator<bvect>::pipeline<gopt> gp;
+        bvect r_or, g_or; rp.set_or_target(&r_or); gp.set_or_target(&g_or);
+        for (unsigned q = 0; q < 5; ++q) {
+            auto* ra = rp.add(); auto* ga = gp.add();
+            ra->add(&hv[q % 4], 0); ga->add(&hv[q % 4], 0);
+            ra->add(&hv[(q + 1) % 4], 0); ga->add(&hv[(q + 1) % 4], 0);
+            if (q & 1) { ra->add(&hv[(q + 2) % 4], 1); ga->add(&hv[(q + 2) % 4], 1); }
+        }
+        rp.complete(); gp.complete();
+        bm::aggregator<bvect> ra3; ra3.combine_and_sub(rp); dagg.combine_and_sub(gp);
+        for (unsigned q = 0; q < 5; ++q) {
+            REQUIRE(rp.get_bv_count_vector()[q] == gp.get_bv_count_vector()[q]);
+            const bvect* rr = rp.get_bv_res_vector()[q]; const bvect* gr = gp.get_bv_res_vector()[q];
+            REQUIRE((rr == nullptr) == (gr == nullptr) && (!rr || gr->compare(*rr) == 0));
+        }
+        REQUIRE(g_or.compare(r_or) == 0 && g_or.any());
+    }
     // rank / select vs bvector<>::count_to / select with the reference rs_index
     {
         bvect::rs_index_type rrs; hv[3].build_rs_index(&rrs);

@@ -64,3 +64,18 @@ def test_cpp_adapter_with_real_bitmagic_on_gpu():
         pytest.skip("oracle/_ref/test_adapter_ref was not prebuilt (needs the reference headers at build time)")
     r = subprocess.run([exe], env=_env(), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "test_adapter_ref ok" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_reference_sample16_runs_unchanged_on_the_gpu():
+    """the reference's own samples/bvsample16/sample16.cpp (aggregator OR / AND / AND-SUB over host bm::bvector<>)
+    compiled with ONLY the aggregator type changed to bmx::device_aggregator<bm::bvector<>> (tests/cpp/Makefile
+    generates the 2-line edit from the source where it lies) prints exactly what the unmodified CPU build prints"""
+    cpu = os.path.join(ROOT, "oracle", "_ref", "sample16_cpu")
+    gpu = os.path.join(ROOT, "oracle", "_ref", "sample16_gpu")
+    if not (os.path.exists(cpu) and os.path.exists(gpu)):
+        pytest.skip("oracle/_ref/sample16_{cpu,gpu} were not prebuilt (needs the reference sources at build time)")
+    a = subprocess.run([cpu], env=_env(), capture_output=True, text=True, timeout=300)
+    b = subprocess.run([gpu], env=_env(), capture_output=True, text=True, timeout=300)
+    assert a.returncode == 0 and b.returncode == 0, a.stderr + b.stderr
+    assert "AND-SUB:" in a.stdout and a.stdout == b.stdout, (a.stdout, b.stdout)
