@@ -225,13 +225,17 @@ int bmx_ctx_create(int device, void* stream, bmx_ctx** out)
     CTXCHK(hipHostMalloc((void**)&ctx->h_small, 64 * sizeof(u64)));
     CTXCHK(hipMalloc((void**)&ctx->d_slots, COUNT_SLOTS * COUNT_SLOT_STRIDE * sizeof(u64)));
     CTXCHK(hipMemsetAsync(ctx->d_slots, 0, COUNT_SLOTS * COUNT_SLOT_STRIDE * sizeof(u64), ctx->stream));
+    CTXCHK(hipMalloc((void**)&ctx->d_zero, 256));
+    CTXCHK(hipMemsetAsync(ctx->d_zero, 0, 256, ctx->stream));
+    CTXCHK(hipMalloc((void**)&ctx->d_done, FOLD_DONE_WORDS * 4));
+    CTXCHK(hipMemsetAsync(ctx->d_done, 0, FOLD_DONE_WORDS * 4, ctx->stream));
 #undef CTXCHK
     if (const char* e = getenv("BMX_POOL_MAX_MB")) { long long mb = atoll(e); if (mb >= 0) ctx->pool_cap = (uint64_t)mb << 20; }
     // launch-shape knobs from the environment go through the same validation as bmx_ctx_set_tuning;
     // an invalid value is ignored (the default stays)
     static const char* const env_keys[][2] = {
         {"BMX_PIPE_UNROLL", "pipe_unroll"}, {"BMX_PIPE_ROWS", "pipe_rows"}, {"BMX_PIPE_NT", "pipe_nt"},
-        {"BMX_PIPE_WG", "pipe_wg"}, {"BMX_PIPE_WINDOW", "pipe_window"}, {"BMX_PIPE_SPLIT", "pipe_split"}, {"BMX_OR_TILE", "or_tile"}, {"BMX_XCD_SWIZZLE", "xcd_swizzle"}};
+        {"BMX_PIPE_WG", "pipe_wg"}, {"BMX_PIPE_WINDOW", "pipe_window"}, {"BMX_PIPE_SPLIT", "pipe_split"}, {"BMX_OR_TILE", "or_tile"}, {"BMX_OR_WINDOW", "or_window"}, {"BMX_XCD_SWIZZLE", "xcd_swizzle"}};
     for (auto& kv : env_keys)
         if (const char* e = getenv(kv[0])) (void)bmx_ctx_set_tuning(ctx, kv[1], atoi(e));
     g_last_error.clear();
@@ -252,6 +256,8 @@ int bmx_ctx_destroy(bmx_ctx* ctx)
     if (ctx->aux) (void)hipFree(ctx->aux);
     if (ctx->d_small) (void)hipFree(ctx->d_small);
     if (ctx->d_slots) (void)hipFree(ctx->d_slots);
+    if (ctx->d_done) (void)hipFree(ctx->d_done);
+    if (ctx->d_zero) (void)hipFree(ctx->d_zero);
     if (ctx->h_small) (void)hipHostFree(ctx->h_small);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -273,6 +279,7 @@ int bmx_ctx_set_tuning(bmx_ctx* ctx, const char* key, int value)
     else if (k == "pipe_split") { ARGCHK(value >= -1 && value <= 1); ctx->pipe_split = value; }
     else if (k == "pipe_window") { ARGCHK(value >= -1); ctx->pipe_window = value; }
     else if (k == "or_tile") { ARGCHK(value >= 0 && value <= 3); ctx->or_tile = value; }
+    else if (k == "or_window") { ARGCHK(value >= -9); ctx->or_window = value; }
     else if (k == "pipe_wg") { ARGCHK(value == 0 || (value >= 64 && value <= 1024 && value % 64 == 0)); ctx->pipe_wg = value; }
     else if (k == "xcd_swizzle") ctx->xcd_swz = value != 0;
     else { g_last_error = "unknown tuning key"; return BMX_ERR_BADARG; }
@@ -606,13 +613,11 @@ int bmx_i_count_async(bmx_ctx* ctx, const bmx_vec* a, int slot)
 {
     ARGCHK(ctx && a && a->ctx == ctx && slot >= 0 && slot < 64);
     int rc = set_dev(ctx); if (rc) return rc;
-    if (a->nblocks) {
-        hipLaunchKernelGGL(k_vec_count, dim3((a->nblocks + 3) / 4), dim3(256), 0, ctx->stream, a->d_desc, a->nblocks, ctx->d_slots);
-        KCHK();
-    }
-    hipLaunchKernelGGL(k_sum_slots, dim3(1), dim3(64), 0, ctx->stream, ctx->d_slots, ctx->d_small + slot);
+    if (!a->nblocks) { ctx->h_small[slot] = 0; return BMX_OK; }
+    // the last workgroup folds the partial counts and writes the total straight into the pinned word the host reads
+    hipLaunchKernelGGL(k_vec_count, dim3((a->nblocks + 3) / 4), dim3(256), 0, ctx->stream, a->d_desc, a->nblocks,
+                       FoldOut{ctx->d_slots, ctx->d_done, ctx->h_small + slot});
     KCHK();
-    HIPCHK(hipMemcpyAsync(ctx->h_small + slot, ctx->d_small + slot, 8, hipMemcpyDeviceToHost, ctx->stream));
     return BMX_OK;
 }
 
@@ -1020,30 +1025,47 @@ int bmx_op2(bmx_ctx* ctx, int op, const bmx_vec* a, const bmx_vec* b, int opt_co
     }
     bmx_vec* v; BlockStat* st; u32* offs;
     if ((rc = result_begin(ctx, nbits, nblocks, &v, &st, &offs))) return rc;
+    // no GAP block can come out (neither operand holds one, no re-compression): the kernel folds the kind counts itself
+    // and the layout scan is skipped -- k_op2, one synchronise, done -- unless result blocks vanished (then the scan /
+    // compaction path below decides what to do with the slab)
+    bool no_gap = !opt_compress && a->counts[BMX_GAP] == 0 && b->counts[BMX_GAP] == 0;
     if (nblocks) {
         hipLaunchKernelGGL(k_op2, dim3((nblocks + 3) / 4), dim3(256), 0, ctx->stream, op,
                            a->d_desc, a->nblocks, b->d_desc, b->nblocks, nblocks, opt_compress,
-                           v->d_bits, v->d_desc, st);
-        KCHK();
+                           v->d_bits, v->d_desc, st,
+                           no_gap ? FoldOut{ctx->d_slots, ctx->d_done, ctx->h_small + 2} : FoldOut{nullptr, nullptr, nullptr});
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess && no_gap) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) { bmx_vec_free(ctx, v); return fail_hip(e, "k_op2", __LINE__); }
+        if (no_gap && ctx->h_small[2 + BMX_GAP] == 0 && ctx->h_small[2 + BMX_BIT] == nblocks) {
+            for (int k = 0; k < 4; ++k) v->counts[k] = (uint32_t)ctx->h_small[2 + k];
+            *result = v;
+            return BMX_OK;
+        }
     }
     if ((rc = result_finish(ctx, v, st, offs))) { bmx_vec_free(ctx, v); return rc; }
     *result = v;
     return BMX_OK;
 }
 
-int bmx_count_op2_dev(bmx_ctx* ctx, int op, const bmx_vec* a, const bmx_vec* b, uint64_t* d_count)
+static int count_op2_launch(bmx_ctx* ctx, int op, const bmx_vec* a, const bmx_vec* b, u64* out, bool out_is_host)
 {
-    ARGCHK(ctx && a && b && d_count && a->ctx == ctx && b->ctx == ctx && op >= BMX_AND && op <= BMX_SUB);
+    ARGCHK(ctx && a && b && out && a->ctx == ctx && b->ctx == ctx && op >= BMX_AND && op <= BMX_SUB);
     int rc = set_dev(ctx); if (rc) return rc;
     uint32_t nblocks = std::max(a->nblocks, b->nblocks);
-    if (nblocks) {
-        hipLaunchKernelGGL(k_count_op2, dim3((nblocks + 3) / 4), dim3(256), 0, ctx->stream, op,
-                           a->d_desc, a->nblocks, b->d_desc, b->nblocks, nblocks, ctx->d_slots);
-        KCHK();
+    if (!nblocks) {
+        if (out_is_host) *out = 0; else HIPCHK(hipMemsetAsync(out, 0, 8, ctx->stream));
+        return BMX_OK;
     }
-    hipLaunchKernelGGL(k_sum_slots, dim3(1), dim3(64), 0, ctx->stream, ctx->d_slots, (u64*)d_count);
+    hipLaunchKernelGGL(k_count_op2, dim3((nblocks + 3) / 4), dim3(256), 0, ctx->stream, op,
+                       a->d_desc, a->nblocks, b->d_desc, b->nblocks, nblocks, FoldOut{ctx->d_slots, ctx->d_done, out});
     KCHK();
     return BMX_OK;
+}
+
+int bmx_count_op2_dev(bmx_ctx* ctx, int op, const bmx_vec* a, const bmx_vec* b, uint64_t* d_count)
+{
+    return count_op2_launch(ctx, op, a, b, (u64*)d_count, false);
 }
 
 } // extern "C"
@@ -1051,10 +1073,7 @@ int bmx_count_op2_dev(bmx_ctx* ctx, int op, const bmx_vec* a, const bmx_vec* b, 
 int bmx_i_count_op2_async(bmx_ctx* ctx, int op, const bmx_vec* a, const bmx_vec* b, int slot)
 {
     ARGCHK(ctx && slot >= 0 && slot < 64);
-    int rc = bmx_count_op2_dev(ctx, op, a, b, ctx->d_small + slot);
-    if (rc) return rc;
-    HIPCHK(hipMemcpyAsync(ctx->h_small + slot, ctx->d_small + slot, 8, hipMemcpyDeviceToHost, ctx->stream));
-    return BMX_OK;
+    return count_op2_launch(ctx, op, a, b, ctx->h_small + slot, true);
 }
 
 extern "C" {
@@ -1105,11 +1124,24 @@ static int agg_or_impl(bmx_ctx* ctx, const bmx_vec* const* src, size_t n, int op
         hipError_t e = hipMemcpyAsync(d_descs, descs.data(), n * 8, hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(d_nblk, nblk.data(), n * 4, hipMemcpyHostToDevice, ctx->stream);
         size_t lds = (size_t)OR_TILE * 8192 + OR_TILE * 4;
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_agg_or_gap_tiled), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        // or_tile: 0 = single-bit fast path (default), 1 = the round-1 run code, 2 = two operands per lane per step;
+        // tuning build, or_window = -9: loads only (the memory floor of the access pattern)
+        u32 ntiles = (ncols + OR_TILE - 1) / OR_TILE;
+#ifdef BMX_TUNE
+        auto tiled = ctx->or_window == -9 ? (ctx->or_tile == 2 ? k_agg_or_gap_tiled<9, 2> : k_agg_or_gap_tiled<9, 1>) :
+                     ctx->or_tile == 0 ? k_agg_or_gap_tiled<1, 1> : ctx->or_tile == 2 ? k_agg_or_gap_tiled<1, 2> : k_agg_or_gap_tiled<0, 1>;
+#else
+        auto tiled = ctx->or_tile == 0 ? k_agg_or_gap_tiled<1, 1> : ctx->or_tile == 2 ? k_agg_or_gap_tiled<1, 2> : k_agg_or_gap_tiled<0, 1>;
+#endif
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(tiled), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e == hipSuccess) {
-            hipLaunchKernelGGL(k_agg_or_gap_tiled, dim3((ncols + OR_TILE - 1) / OR_TILE), dim3(1024), lds, ctx->stream,
-                               (const u64* const*)d_descs, (const u32*)d_nblk, (u32)n, ncols, opt_compress, v->d_bits, v->d_desc, st);
-            e = hipGetLastError();
+            u32 win = ctx->or_window <= 0 ? ntiles : (u32)ctx->or_window;        // windows measured: no gain here
+            u32 nwin = (ntiles + win - 1) / win, per = (ntiles + nwin - 1) / nwin;
+            for (u32 t0 = 0; t0 < ntiles && e == hipSuccess; t0 += per) {
+                hipLaunchKernelGGL(tiled, dim3(std::min(per, ntiles - t0)), dim3(1024), lds, ctx->stream,
+                                   (const u64* const*)d_descs, (const u32*)d_nblk, (u32)n, ncols, opt_compress, v->d_bits, v->d_desc, st, t0);
+                e = hipGetLastError();
+            }
         }
         if (e == hipSuccess) rc = result_finish(ctx, v, st, offs);
         else rc = fail_hip(e, "bmx_agg_or (tiled)", __LINE__);

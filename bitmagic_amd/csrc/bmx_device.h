@@ -441,6 +441,57 @@ __device__ __forceinline__ void gap_or_lane_fast(const GapHead& h, u64 gaddr, u3
     }
 }
 
+// Variant 2 of the run application (VALU-bound kernel: fewer instructions per set bit).  In a sparse vector nearly
+// every block starts with a 0-run and nearly every 1-run is ONE bit: then the u16 stream is a list of bit positions
+// (every second word), and a run costs alignbit + sub + shift + shift + address + select + ds_or.  Runs that span more
+// than one bit (or blocks that start with a 1-run) take the general path of gap_or_chunk_fast.
+__device__ __forceinline__ void gap_or_chunk_v2(u32* lds, const u32 x[5], u32 c, int lim)
+{
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        u32 y = __builtin_amdgcn_alignbit(x[i + 1], x[i], 16);       // lo16 = end of the 0-run, hi16 = end of the 1-run
+        u32 e = y >> 16;
+        u32 d = e - (y & 0xFFFFu);                                   // length of the 1-run
+        bool act = (int)(8u * c + 2u * (u32)i) <= lim;
+        bool single = d == 1u;
+        atomicOr(&lds[e >> 5], (act && single) ? (1u << (e & 31u)) : 0u);
+        if (act && !single) {                                        // rare for sparse operands
+            u32 s = e - d + 1u;
+            u32 wl = s >> 5, wr = e >> 5;
+            u32 lo = 1u << (s & 31u), hi2 = 2u << (e & 31u);
+            if (wl == wr) atomicOr(&lds[wl], hi2 - lo);
+            else {
+                atomicOr(&lds[wl], 0u - lo);
+                atomicOr(&lds[wr], hi2 - 1u);
+                for (u32 w = wl + 1u; w < wr; ++w) lds[w] = ~0u;
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ void gap_or_lane_v2(const GapHead& h, u64 gaddr, u32* lds)
+{
+    u32 hdr = h.c[0].x & 0xFFFFu;
+    u32 len = hdr >> 3;
+    bool odd_runs = (hdr & 1u) != 0u;
+    if (__ballot(odd_runs) != 0ull) { gap_or_lane_fast(h, gaddr, lds); return; }     // some block starts with a 1-run: general code for the wave
+    int lim = (int)len - 2;
+    u32 nchunks = (len + 8u) >> 3;
+    { u32 x[5] = {h.c[0].x, h.c[0].y, h.c[0].z, h.c[0].w, h.c[1].x}; gap_or_chunk_v2(lds, x, 0, lim); }
+    if (nchunks > 1u) { u32 x[5] = {h.c[1].x, h.c[1].y, h.c[1].z, h.c[1].w, h.c[2].x}; gap_or_chunk_v2(lds, x, 1, lim); }
+    if (nchunks > 2u) { u32 x[5] = {h.c[2].x, h.c[2].y, h.c[2].z, h.c[2].w, h.c[3].x}; gap_or_chunk_v2(lds, x, 2, lim); }
+    if (nchunks > 3u) {
+        gcptr4 g4 = (gcptr4)(uintptr_t)gaddr;
+        u32x4 cur = h.c[3];
+        for (u32 c = 3; c < nchunks; ++c) {
+            u32x4 nxt = (c + 1u < nchunks) ? g4[c + 1u] : cur;
+            u32 x[5] = {cur.x, cur.y, cur.z, cur.w, nxt.x};
+            gap_or_chunk_v2(lds, x, c, lim);
+            cur = nxt;
+        }
+    }
+}
+
 __device__ __forceinline__ bool lds_blk_is_zero(const u32* lds, u32 lane)
 {
     const u32x4* l4 = reinterpret_cast<const u32x4*>(lds);

@@ -34,6 +34,8 @@ struct bmx_ctx {
     void* aux = nullptr; size_t aux_bytes = 0;              // stats / offsets / totals
     u64* d_small = nullptr;                                 // 64 x u64 result words
     u64* d_slots = nullptr;                                 // COUNT_SLOTS striped count accumulators (kept zero between launches)
+    u64* d_zero = nullptr;                                  // 256 bytes of zeros: what an invalid slot of an unconditional load reads
+    u32* d_done = nullptr;                                  // workgroup ticket of the in-kernel folds (kept zero between launches)
     u64* h_small = nullptr;                                 // pinned mirror
     // caching device allocator: results of same-shaped operations re-use their blocks instead of
     // paying hipMalloc / hipFree (which synchronises the device) on every call
@@ -50,6 +52,7 @@ struct bmx_ctx {
     int pipe_slots = 16;       // plane blocks staged at a time (16: 1024-thread WG; 8: two 512-thread WGs per CU)
     int pipe_split = -1;       // few columns: waves of a workgroup share one column's operand list: -1 auto, 0 never, 1 always
     int or_tile = 0;           // k_agg_or_gap_tiled variant (0 = default)
+    int or_window = 0;         // column tiles per launch of k_agg_or_gap_tiled: 0 / -1 = all in one launch (windows measured: no gain)
     int xcd_swz = 1;
 };
 

@@ -252,9 +252,91 @@ void k_sum_slots(u64* __restrict__ slots, u64* __restrict__ out)
     if (lane == 0) *out = v;
 }
 
+// Fan-in with the fold inside the kernel: the LAST workgroup to arrive sums the 64 slots, leaves them clean, and
+// writes the total to *out -- device memory or pinned host memory (hipHostMalloc is device-visible), so a
+// host-synchronous count needs no second launch and no copy: launch, synchronise, read.
+// No fences: on a multi-XCD part an agent-scope release / acquire pair costs an L2 write-back + invalidate per
+// workgroup (measured: the 45 us count_and kernel became 215 us).  Everything the workgroups exchange goes through
+// device-scope atomics, which execute at the memory side and are coherent across XCDs by themselves; program order
+// between a workgroup's slot update and its ticket is enforced by waiting for the returning atomic (vmcnt).
+// Tickets are two-level -- one counter per slot (its own 128-B line), then one global counter hit 64 times -- so no
+// single word sees thousands of serialised atomics.
+struct FoldOut { u64* slots; u32* done; u64* out; };     // done: [0] global ticket, [32 * (1 + s)] ticket of slot s
+#define FOLD_DONE_WORDS (32u * (COUNT_SLOTS + 1u))
+
+// adds `v` to the workgroup's slot; true for the single thread that must fold (all slots are final then)
+__device__ __forceinline__ bool fold_publish(u64 v, FoldOut f)
+{
+    u32 s_ = blockIdx.x % COUNT_SLOTS;
+    u64* slot = f.slots + s_ * COUNT_SLOT_STRIDE;
+    if (v) {
+        (void)__hip_atomic_fetch_add(slot, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the add has been performed before the ticket is drawn
+    }
+    u32 expect = gridDim.x / COUNT_SLOTS + (s_ < gridDim.x % COUNT_SLOTS ? 1u : 0u);
+    u32 k = __hip_atomic_fetch_add(f.done + 32u * (1u + s_), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (k != expect - 1u) return false;
+    __hip_atomic_store(f.done + 32u * (1u + s_), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    u32 used = gridDim.x < COUNT_SLOTS ? gridDim.x : COUNT_SLOTS;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    u32 g = __hip_atomic_fetch_add(f.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (g != used - 1u) return false;
+    __hip_atomic_store(f.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return true;
+}
+
+__device__ __forceinline__ void count_fanin_fold(u32 wave_count, FoldOut f, u32 lane, u32 wave)
+{
+    __shared__ u32 part[16];
+    u32 nw = blockDim.x >> 6;
+    if (lane == 0) part[wave] = wave_count;
+    __syncthreads();
+    if (wave == 0) {
+        u32 folder = 0;
+        if (lane == 0) {
+            u64 t = 0;
+            for (u32 i = 0; i < nw; ++i) t += part[i];
+            folder = fold_publish(t, f) ? 1u : 0u;
+        }
+        if (__shfl(folder, 0, 64)) {                            // the whole wave folds: one slot per lane, one round trip
+            u64 v = __hip_atomic_exchange(f.slots + lane * COUNT_SLOT_STRIDE, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+            if (lane == 0) __hip_atomic_store(f.out, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
+// Same pattern for the block KINDS of a result vector (kind counts packed 4 x 16 bit per slot: a slot sees at most
+// nblocks / 64 <= 16,384 blocks): out[k] = number of result blocks of kind k.  Lets an operation that cannot produce GAP
+// blocks skip the layout scan (k_scan_layout) altogether.
+__device__ __forceinline__ void kind_fanin_fold(u32 kind /* 0..3, 4 = none */, FoldOut f, u32 lane, u32 wave)
+{
+    __shared__ u32 wk[16];
+    u32 nw = blockDim.x >> 6;
+    if (lane == 0) wk[wave] = kind;
+    __syncthreads();
+    if (wave == 0) {
+        u32 folder = 0;
+        if (lane == 0) {
+            u64 t = 0;
+            for (u32 i = 0; i < nw; ++i) if (wk[i] < 4u) t += 1ull << (16u * wk[i]);
+            folder = fold_publish(t, f) ? 1u : 0u;
+        }
+        if (__shfl(folder, 0, 64)) {
+            u64 v = __hip_atomic_exchange(f.slots + lane * COUNT_SLOT_STRIDE, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                u32 c = (u32)((v >> (16 * k)) & 0xFFFFull);
+                c = wave_sum(c);
+                if (lane == 0) __hip_atomic_store(f.out + k, (u64)c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    }
+}
+
 // bvector::count()  src/bm.h:2431 -> block_bitcount src/bmblocks.h:1710
 __global__ __launch_bounds__(256)
-void k_vec_count(const u64* __restrict__ desc, u32 nblocks, u64* __restrict__ slots)
+void k_vec_count(const u64* __restrict__ desc, u32 nblocks, FoldOut fold)
 {
     u32 lane = lane_id(), wave = threadIdx.x >> 6;
     u32 nb = uniform32(blockIdx.x * 4u + wave);
@@ -266,7 +348,7 @@ void k_vec_count(const u64* __restrict__ desc, u32 nblocks, u64* __restrict__ sl
         else if (k == K_BIT) { Blk b; blk_load(b, as_gc4(DESC_P(d)), lane); c = wave_sum(blk_lane_popcount(b)); }
         else if (k == K_GAP) c = wave_sum(gap_lane_popcount(as_gc16(DESC_P(d)), lane, GMETA(d)));
     }
-    count_fanin(c, slots, lane, wave);
+    count_fanin_fold(c, fold, lane, wave);
 }
 
 // expand a vector into raw words (nblocks_out blocks; blocks past the table are zero)

@@ -26,7 +26,7 @@
 //                  result is dropped; an all-ones result stays a GAP block of ONE run (it does not become FULL)
 enum { ST_OPT = 1, ST_FORCE_BIT = 2, ST_TEST_ZERO = 4, ST_TEST_ONE = 8, ST_FORCE_GAP = 16, ST_GAP_RESULT = 32 };
 
-__device__ __forceinline__ void store_result_mode(const Blk& acc, u32 nb, u32 mode,
+__device__ __forceinline__ u32 store_result_mode(const Blk& acc, u32 nb, u32 mode,
                                                   uint4* __restrict__ slab, u64* __restrict__ desc,
                                                   BlockStat* __restrict__ st, u32 lane)
 {
@@ -50,6 +50,7 @@ __device__ __forceinline__ void store_result_mode(const Blk& acc, u32 nb, u32 mo
         st[nb] = BlockStat{pop, runs, first, kind};
         desc[nb] = (kind == K_BIT) ? DESC_MAKE(slot, K_BIT) : DESC_MAKE(0, kind == K_GAP ? K_NULL : kind);
     }
+    return kind;
 }
 
 __device__ __forceinline__ void store_result(const Blk& acc, u32 nb, int opt_compress,
@@ -176,33 +177,28 @@ __device__ __forceinline__ u64 desc_at(const u64* __restrict__ d, u32 n, u32 nb)
     return nb < n ? uniform64(d[nb]) : 0ull;
 }
 
-__global__ __launch_bounds__(256)
-void k_op2(int op, const u64* __restrict__ da, u32 na, const u64* __restrict__ db, u32 nbk,
-           u32 nblocks, int opt_compress, uint4* __restrict__ slab, u64* __restrict__ desc,
-           BlockStat* __restrict__ st)
+// one result block of a pairwise operation; returns its kind
+__device__ __forceinline__ u32 op2_block(int op, u64 a, u64 b, u32 nb, int opt_compress, u32* l,
+                                         uint4* __restrict__ slab, u64* __restrict__ desc, BlockStat* __restrict__ st, u32 lane)
 {
-    __shared__ u32 lds[4 * 2048];
-    u32 lane = lane_id(), wave = threadIdx.x >> 6;
-    u32 nb = uniform32(blockIdx.x * 4u + wave);
-    if (nb >= nblocks) return;
-    u64 a = desc_at(da, na, nb), b = desc_at(db, nbk, nb);
     u32 ka = DESC_K(a), kb = DESC_K(b);
     // shortcuts that produce NULL / FULL without reading anything
+    u32 trivial = 4u;
     if (op == BMX_AND) {
-        if (ka == K_NULL || kb == K_NULL) { store_trivial(K_NULL, nb, desc, st, lane); return; }
-        if (ka == K_FULL && kb == K_FULL) { store_trivial(K_FULL, nb, desc, st, lane); return; }
+        if (ka == K_NULL || kb == K_NULL) trivial = K_NULL;
+        else if (ka == K_FULL && kb == K_FULL) trivial = K_FULL;
     } else if (op == BMX_OR) {
-        if (ka == K_FULL || kb == K_FULL) { store_trivial(K_FULL, nb, desc, st, lane); return; }
-        if (ka == K_NULL && kb == K_NULL) { store_trivial(K_NULL, nb, desc, st, lane); return; }
+        if (ka == K_FULL || kb == K_FULL) trivial = K_FULL;
+        else if (ka == K_NULL && kb == K_NULL) trivial = K_NULL;
     } else if (op == BMX_XOR) {
-        if ((ka == K_NULL && kb == K_NULL) || (ka == K_FULL && kb == K_FULL)) { store_trivial(K_NULL, nb, desc, st, lane); return; }
-        if ((ka == K_NULL && kb == K_FULL) || (ka == K_FULL && kb == K_NULL)) { store_trivial(K_FULL, nb, desc, st, lane); return; }
+        if ((ka == K_NULL && kb == K_NULL) || (ka == K_FULL && kb == K_FULL)) trivial = K_NULL;
+        else if ((ka == K_NULL && kb == K_FULL) || (ka == K_FULL && kb == K_NULL)) trivial = K_FULL;
     } else {
-        if (ka == K_NULL || kb == K_FULL) { store_trivial(K_NULL, nb, desc, st, lane); return; }
-        if (ka == K_FULL && kb == K_NULL) { store_trivial(K_FULL, nb, desc, st, lane); return; }
+        if (ka == K_NULL || kb == K_FULL) trivial = K_NULL;
+        else if (ka == K_FULL && kb == K_NULL) trivial = K_FULL;
     }
+    if (trivial != 4u) { store_trivial(trivial, nb, desc, st, lane); return trivial; }
     Blk x, y;
-    u32* l = lds + wave * 2048u;
     blk_from_desc(a, x, l, lane);
     blk_from_desc(b, y, l, lane);
     blk_op(op, x, y);
@@ -223,14 +219,30 @@ void k_op2(int op, const u64* __restrict__ da, u32 na, const u64* __restrict__ d
         if ((bb && op != BMX_OR) || op == BMX_AND || (ka == K_GAP && op == BMX_SUB)) mode |= ST_TEST_ZERO;
         if (bb && op == BMX_OR) mode |= ST_TEST_ONE;
     }
-    store_result_mode(x, nb, mode, slab, desc, st, lane);
+    return store_result_mode(x, nb, mode, slab, desc, st, lane);
+}
+
+// kinds.slots != null: the kind counts of the result are folded inside the kernel (kind_fanin_fold) -- used when no GAP
+// block can come out (neither operand holds one and opt_compress is off), so that no layout scan is needed.
+__global__ __launch_bounds__(256)
+void k_op2(int op, const u64* __restrict__ da, u32 na, const u64* __restrict__ db, u32 nbk,
+           u32 nblocks, int opt_compress, uint4* __restrict__ slab, u64* __restrict__ desc,
+           BlockStat* __restrict__ st, FoldOut kinds)
+{
+    __shared__ u32 lds[4 * 2048];
+    u32 lane = lane_id(), wave = threadIdx.x >> 6;
+    u32 nb = uniform32(blockIdx.x * 4u + wave);
+    u32 kind = 4u;
+    if (nb < nblocks)
+        kind = op2_block(op, desc_at(da, na, nb), desc_at(db, nbk, nb), nb, opt_compress, lds + wave * 2048u, slab, desc, st, lane);
+    if (kinds.slots) kind_fanin_fold(kind, kinds, lane, wave);
 }
 
 // bm::count_and/or/xor/sub  src/bmalgo.h:49,149,81,115 (distance_operation,
 // src/bmalgo_impl.h:766,853): popcount(a OP b) without materialising.
 __global__ __launch_bounds__(256)
 void k_count_op2(int op, const u64* __restrict__ da, u32 na, const u64* __restrict__ db, u32 nbk,
-                 u32 nblocks, u64* __restrict__ slots)
+                 u32 nblocks, FoldOut fold)
 {
     __shared__ u32 lds[4 * 2048];
     u32 lane = lane_id(), wave = threadIdx.x >> 6;
@@ -250,7 +262,7 @@ void k_count_op2(int op, const u64* __restrict__ da, u32 na, const u64* __restri
             c = wave_sum(blk_lane_popcount(x));
         }
     }
-    count_fanin(c, slots, lane, wave);
+    count_fanin_fold(c, fold, lane, wave);
 }
 
 // ---------------------------------------------------------------------------
@@ -319,14 +331,25 @@ void k_agg_or(const u64* __restrict__ dmat, u32 n, u32 ncols, int opt_compress, 
 // Requires: no operand holds a bit-block (checked on the host; FULL/NULL are fine).
 // ---------------------------------------------------------------------------
 #define OR_TILE 16u
+// What bounds it (round 2, profiles/r02f + tools/gpu_runs/r02_or.sh): the memory side of THIS access pattern.  With the
+// run application compiled out (VAR 9, tuning build) the kernel still takes 3.65 ms of the 4.05 ms -- 4.4 TB/s for 16 GB
+// read as 4096 streams in 1-KiB pieces (16 columns x 64 B per operand visit), whatever the load instructions look like:
+// lane-per-block (4 x 16 B per lane), one fully coalesced 1-KiB load per operand (a row-coalesced kernel was written and
+// measured: same floor, and slower in total because 24 % of the blocks exceed 64 B), one or two operands in flight per
+// lane.  Also measured without effect: launch windows (the kernel is per-CU bound: half the CUs = half the rate), a
+// bank-conflict-free interleaved tile (-6 %), fewer VALU instructions per run (single-bit fast path, VAR 1: +2 %).
+// A 1-KiB visit is 256 B per HBM channel per row activation; the 8-KiB visits of the headline kernel stream at 6.9 TB/s.
+// The tile cannot grow: 16 accumulators are 128 KiB of the 160 KiB LDS.
+template <int VAR, int NOPS>
 __global__ __launch_bounds__(1024)
 void k_agg_or_gap_tiled(const u64* const* __restrict__ descs, const u32* __restrict__ nblk, u32 n, u32 ncols,
-                        int opt_compress, uint4* __restrict__ slab, u64* __restrict__ desc, BlockStat* __restrict__ st)
+                        int opt_compress, uint4* __restrict__ slab, u64* __restrict__ desc, BlockStat* __restrict__ st,
+                        u32 tile_base)
 {
     extern __shared__ u32 lds_dyn[];                 // OR_TILE x 2048 u32 accumulators + OR_TILE flags
     u32* full = lds_dyn + OR_TILE * 2048u;
     u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    u32 c0 = blockIdx.x * OR_TILE;
+    u32 c0 = (tile_base + blockIdx.x) * OR_TILE;
     // zero the accumulators: 1024 threads x 128 B
     u32x4* l4 = reinterpret_cast<u32x4*>(lds_dyn);
 #pragma unroll
@@ -335,9 +358,9 @@ void k_agg_or_gap_tiled(const u64* const* __restrict__ descs, const u32* __restr
     __syncthreads();
     u32 t = lane & (OR_TILE - 1u), grp = lane / OR_TILE;          // 4 operands per wave
     u32 col = c0 + t;
-    u32 ops_per_step = (blockDim.x >> 6) * (64u / OR_TILE);
+    const u32 S = (blockDim.x >> 6) * (64u / OR_TILE);             // operands one wave-step of the workgroup covers
     u32* acc = lds_dyn + t * 2048u;
-    u32 op = wave * (64u / OR_TILE) + grp;
+    u32 op = wave * (64u / OR_TILE) + grp;                        // this lane's operands: op + (j + NOPS * step) * S
     // Three dependent reads per operand (table pointer + length -> descriptor -> block head) are spread
     // over three loop iterations, each issued unconditionally (indices clamped, results masked), so that
     // no iteration waits for a load it issued itself: stage A runs 3 steps ahead, B 2, C 1.
@@ -349,26 +372,43 @@ void k_agg_or_gap_tiled(const u64* const* __restrict__ descs, const u32* __restr
     bool colok = col < ncols;
 #define TILE_STAGE_A(OP, PA, NB) { u32 oc_ = (OP) < n ? (OP) : nm1; PA = g_descs[oc_]; NB = ((OP) < n && colok) ? g_nblk[oc_] : 0u; }
 #define TILE_STAGE_B(PA, NB, D)  { u32 cc_ = col < (NB) ? col : 0u; u64 v_ = ((gcptr64)(uintptr_t)(PA))[cc_]; D = col < (NB) ? v_ : 0ull; }
-    u64 pa1, pa2, pa3; u32 nb1, nb2, nb3;
-    u64 d0, d1, d2;
-    GapHead h0 = {}, h1 = {};
-    {   // prologue: fill the pipeline
+    u64 pa1[NOPS], pa2[NOPS], pa3[NOPS]; u32 nb1[NOPS], nb2[NOPS], nb3[NOPS];
+    u64 d0[NOPS], d1[NOPS], d2[NOPS];
+    GapHead h0[NOPS], h1[NOPS];
+    const u32 STEP = S * NOPS;
+#pragma unroll
+    for (int j = 0; j < NOPS; ++j) {   // prologue: fill the pipeline
         u64 pa0; u32 nb0;
-        TILE_STAGE_A(op, pa0, nb0);
-        TILE_STAGE_A(op + ops_per_step, pa1, nb1);
-        TILE_STAGE_A(op + 2u * ops_per_step, pa2, nb2);
-        TILE_STAGE_B(pa0, nb0, d0);
-        TILE_STAGE_B(pa1, nb1, d1);
-        gap_head_fetch(h0, DESC_P(d0), DESC_K(d0) == K_GAP);
+        u32 o = op + (u32)j * S;
+        TILE_STAGE_A(o, pa0, nb0);
+        TILE_STAGE_A(o + STEP, pa1[j], nb1[j]);
+        TILE_STAGE_A(o + 2u * STEP, pa2[j], nb2[j]);
+        TILE_STAGE_B(pa0, nb0, d0[j]);
+        TILE_STAGE_B(pa1[j], nb1[j], d1[j]);
+        gap_head_fetch(h0[j], DESC_P(d0[j]), DESC_K(d0[j]) == K_GAP);
     }
-    for (; op < n; op += ops_per_step) {
-        TILE_STAGE_A(op + 3u * ops_per_step, pa3, nb3);
-        TILE_STAGE_B(pa2, nb2, d2);
-        gap_head_fetch(h1, DESC_P(d1), DESC_K(d1) == K_GAP);
-        gap_or_lane_fast(h0, DESC_P(d0), acc);
-        if (DESC_K(d0) == K_FULL) full[t] = 1u;
-        d0 = d1; d1 = d2; h0 = h1;
-        pa2 = pa3; nb2 = nb3;
+    for (; op < n; op += STEP) {
+#pragma unroll
+        for (int j = 0; j < NOPS; ++j) {
+            TILE_STAGE_A(op + (u32)j * S + 3u * STEP, pa3[j], nb3[j]);
+            TILE_STAGE_B(pa2[j], nb2[j], d2[j]);
+            gap_head_fetch(h1[j], DESC_P(d1[j]), DESC_K(d1[j]) == K_GAP);
+        }
+#pragma unroll
+        for (int j = 0; j < NOPS; ++j) {
+            if constexpr (VAR == 9) {                              // memory-pattern probe (tuning build): loads only
+                u32x4 z = h0[j].c[0] ^ h0[j].c[1] ^ h0[j].c[2] ^ h0[j].c[3];
+                if ((z.x ^ z.y ^ z.z ^ z.w) == 0x12345679u) acc[0] = 1u;
+            }
+            else if constexpr (VAR == 1) gap_or_lane_v2(h0[j], DESC_P(d0[j]), acc);
+            else gap_or_lane_fast(h0[j], DESC_P(d0[j]), acc);
+            if (DESC_K(d0[j]) == K_FULL) full[t] = 1u;
+        }
+#pragma unroll
+        for (int j = 0; j < NOPS; ++j) {
+            d0[j] = d1[j]; d1[j] = d2[j]; h0[j] = h1[j];
+            pa2[j] = pa3[j]; nb2[j] = nb3[j];
+        }
     }
 #undef TILE_STAGE_A
 #undef TILE_STAGE_B
