@@ -95,6 +95,37 @@ static int ensure(bmx_ctx* ctx, void** buf, size_t* cur, size_t need)
     return BMX_OK;
 }
 
+// Small host tables (operand pointer lists, pipeline metadata) go through a pinned ring: the copy is truly
+// asynchronous, the caller's buffer may die on return, and nobody has to synchronise the stream for it.  A region of
+// the ring is reused only after the event recorded behind the last copy has completed.
+#define STAGE_BYTES (1u << 20)
+static int h2d_staged(bmx_ctx* ctx, void* dst, const void* src, size_t bytes)
+{
+    if (!bytes) return BMX_OK;
+    if (bytes > STAGE_BYTES / 4) {                      // big table: plain copy, wait for it
+        HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        return BMX_OK;
+    }
+    size_t need = (bytes + 63u) & ~(size_t)63u;
+    if (ctx->stage_off + need > STAGE_BYTES) { HIPCHK(hipEventSynchronize(ctx->ev_stage)); ctx->stage_off = 0; }
+    char* s = ctx->h_stage + ctx->stage_off;
+    memcpy(s, src, bytes);
+    ctx->stage_off += need;
+    HIPCHK(hipMemcpyAsync(dst, s, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(hipEventRecord(ctx->ev_stage, ctx->stream));
+    return BMX_OK;
+}
+
+// few (column, group) items with long operand lists: a workgroup of 8 waves per item (k_pipe_split)
+static bool use_split(const bmx_ctx* ctx, const bmx_pipeline* p, u64 nitems)
+{
+    if (ctx->pipe_split == 0 || !nitems) return false;
+    if (ctx->pipe_split == 1) return nitems <= 65535u * 16u;
+    return nitems <= 384u && (u64)p->n_ops >= 24ull * p->ngroups;
+}
+#define SPLIT_WAVES 8
+
 // ---- launch shapes of the bit-only counts kernel --------------------------------------------------
 typedef void (*pipe_bits_fn)(const u64*, const u32*, const u32*, u32, u32, u32, u32, int, u64*);
 
@@ -223,6 +254,8 @@ int bmx_ctx_create(int device, void* stream, bmx_ctx** out)
     CTXCHK(hipEventCreate(&ctx->ev1));
     CTXCHK(hipMalloc((void**)&ctx->d_small, 64 * sizeof(u64)));
     CTXCHK(hipHostMalloc((void**)&ctx->h_small, 64 * sizeof(u64)));
+    CTXCHK(hipHostMalloc((void**)&ctx->h_stage, STAGE_BYTES));
+    CTXCHK(hipEventCreateWithFlags(&ctx->ev_stage, hipEventDisableTiming));
     CTXCHK(hipMalloc((void**)&ctx->d_slots, COUNT_SLOTS * COUNT_SLOT_STRIDE * sizeof(u64)));
     CTXCHK(hipMemsetAsync(ctx->d_slots, 0, COUNT_SLOTS * COUNT_SLOT_STRIDE * sizeof(u64), ctx->stream));
     CTXCHK(hipMalloc((void**)&ctx->d_zero, 256));
@@ -259,6 +292,8 @@ int bmx_ctx_destroy(bmx_ctx* ctx)
     if (ctx->d_done) (void)hipFree(ctx->d_done);
     if (ctx->d_zero) (void)hipFree(ctx->d_zero);
     if (ctx->h_small) (void)hipHostFree(ctx->h_small);
+    if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
+    if (ctx->ev_stage) (void)hipEventDestroy(ctx->ev_stage);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -684,7 +719,9 @@ int bmx_pipeline_create(bmx_ctx* ctx, const bmx_vec* const* and_list, const uint
     p->h_row_off = new std::vector<u32>(row_off, row_off + ngroups);
     p->h_and_n = new std::vector<u32>(m_and_n, m_and_n + ngroups);
     // distinct vectors of the pipeline (pipeline::unique_vectors(), src/bmaggregator.h:301) and the
-    // (AND | SUB << 16) plane masks of every group, 16 planes per chunk
+    // (AND | SUB << 16) plane masks of every group, 16 planes per chunk -- only where the staged kernel can be chosen
+    // (>= 32 groups, or forced by the knob): a single-group combine_and_sub pays neither the hashing nor the uploads
+    if (ngroups >= 32 || ctx->pipe_staged == 1)
     {
         std::unordered_map<const u64*, u32> plane_of;
         std::vector<const u64*> udesc; std::vector<u32> unblk;
@@ -699,9 +736,7 @@ int bmx_pipeline_create(bmx_ctx* ctx, const bmx_vec* const* and_list, const uint
         for (size_t op = 0; op < n_ops; ++op) plane_id[op] = plane(op);
         p->nplanes = (uint32_t)udesc.size();
         p->nchunks = (p->nplanes + 15u) / 16u;
-        // plane tables are only built where the staged kernel can be chosen (>= 32 groups, or forced by the knob):
-        // a single-group combine_and_sub should not pay four uploads and a sync for them
-        p->staged_ok = p->nplanes > 0 && (size_t)ngroups * p->nchunks < (1u << 28) && (ngroups >= 32 || ctx->pipe_staged == 1);
+        p->staged_ok = p->nplanes > 0 && (size_t)ngroups * p->nchunks < (1u << 28);
         if (p->staged_ok) {
             std::vector<u32> gmask((size_t)ngroups * std::max<u32>(p->nchunks, 1), 0), gskip(ngroups, 0);
             size_t a0 = 0, s0 = 0;
@@ -724,8 +759,7 @@ int bmx_pipeline_create(bmx_ctx* ctx, const bmx_vec* const* and_list, const uint
     if ((rc = dmalloc(ctx, (void**)&p->d_dmat, b_dmat)) || (rc = dmalloc(ctx, (void**)&p->d_meta, b_meta)) ||
         (rc = dmalloc(ctx, (void**)&p->d_descs, b_descs))) { bmx_pipeline_destroy(ctx, p); return rc; }
     p->bytes = b_dmat + b_meta + b_descs;
-    PIPECHK(hipMemcpyAsync(p->d_meta, meta.data(), b_meta, hipMemcpyHostToDevice, ctx->stream));
-    PIPECHK(hipMemcpyAsync(p->d_descs, descs.data(), b_descs, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = h2d_staged(ctx, p->d_meta, meta.data(), b_meta)) || (rc = h2d_staged(ctx, (void*)p->d_descs, descs.data(), b_descs))) { bmx_pipeline_destroy(ctx, p); return rc; }
     if (ncols) {
         PipeOperands po;
         po.desc = (const u64* const*)p->d_descs;
@@ -737,7 +771,8 @@ int bmx_pipeline_create(bmx_ctx* ctx, const bmx_vec* const* and_list, const uint
                            po, (u32)ngroups, ncols, col_stride, p->d_dmat);
         PIPECHK(hipGetLastError());
     }
-    PIPECHK(hipStreamSynchronize(ctx->stream));
+    // no synchronise: the tables went through the pinned ring and everything that uses the rows is ordered behind
+    // k_pipe_sort on the context's stream
     *out = p;
     return BMX_OK;
 #undef PIPECHK
@@ -841,6 +876,8 @@ int bmx_pipeline_describe(bmx_ctx* ctx, bmx_pipeline* p, uint32_t nb_from, uint3
     bool reuse = p->ngroups >= 32 && (uint64_t)p->n_ops >= 8ull * p->nplanes;
     if (p->staged_ok && (ctx->pipe_staged == 1 || (ctx->pipe_staged < 0 && reuse)))
         snprintf(buf, buf_len, "k_pipe_counts_staged<%d> x 1 launch, %u workgroups", ctx->pipe_slots, nb_to - nb_from);
+    else if (use_split(ctx, p, nitems64))
+        snprintf(buf, buf_len, "k_pipe_split<2,%d> x 1 launch, %llu workgroups", SPLIT_WAVES, (unsigned long long)nitems64);
     else if (p->has_gap)
         snprintf(buf, buf_len, "k_pipe_counts<%d> x 1 launch", ctx->pipe_unroll == 1 ? 1 : ctx->pipe_unroll == 2 ? 2 : 4);
     else {
@@ -1201,7 +1238,18 @@ int bmx_agg_and_sub(bmx_ctx* ctx, const bmx_vec* const* src_and, size_t n_and,
     bmx_pipeline* p = nullptr;
     if ((rc = bmx_pipeline_create(ctx, src_and, &an, src_sub, &sn, 1, &p))) return rc;
     if ((rc = result_begin(ctx, nbits, ncols, &v, &st, &offs))) { bmx_pipeline_destroy(ctx, p); return rc; }
-    if (ncols) {
+    if (ncols && use_split(ctx, p, ncols)) {
+        size_t lds = (size_t)SPLIT_WAVES * 8192;
+        auto fn = k_pipe_split<2, SPLIT_WAVES>;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(fn, dim3(ncols), dim3(SPLIT_WAVES * 64), lds, ctx->stream,
+                               (const u64*)p->d_dmat, (const u32*)p->d_meta, (const u32*)(p->d_meta + 1), (const u32*)(p->d_meta + 2),
+                               p->col_stride, 1u, 0u, ncols, 1, (u64*)nullptr, 1, v->d_bits, v->d_desc, st);
+            e = hipGetLastError();
+        }
+        if (e != hipSuccess) rc = fail_hip(e, "k_pipe_split", __LINE__);
+    } else if (ncols) {
         size_t lds = p->has_gap ? 4 * 2048 * 4 : 0;
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_agg_and_sub<2>), dim3((ncols + 3) / 4), dim3(256), lds, ctx->stream,
                            p->d_dmat, p->d_meta + 1, p->d_meta + 2, p->col_stride, ncols,

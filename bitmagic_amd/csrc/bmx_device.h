@@ -207,7 +207,7 @@ __device__ __forceinline__ u32 prefix_xor32(u32 x)
 
 // meta = GMETA of the block's descriptor when the caller has it: the run ends are then requested at once,
 // without a round trip for the header word.
-__device__ __forceinline__ void gap_decode(gcptr16 g, u32* lds, Blk& out, u32 lane, u32 meta = GMETA_NONE)
+__device__ __forceinline__ void gap_decode_xor(gcptr16 g, u32* lds, Blk& out, u32 lane, u32 meta = GMETA_NONE)
 {
     u32 len, sbit;
     if (meta != GMETA_NONE) { len = meta >> 1; sbit = meta & 1u; }
@@ -286,11 +286,12 @@ __device__ __forceinline__ void lds_apply_run_edges(u32* lds, u32 s, u32 e)
 
 // wave-parallel over the runs of ONE operand: lane j takes every 64th run of the wanted polarity
 template <int MODE>
-__device__ __forceinline__ void gap_apply_lds_wave(gcptr16 g, u32* lds, u32 lane)
+__device__ __forceinline__ void gap_apply_lds_wave(gcptr16 g, u32* lds, u32 lane, u32 meta = GMETA_NONE)
 {
     const u32 fill = (MODE == GAP_OR) ? ~0u : 0u;
-    u32 hdr = g[0];
-    u32 len = hdr >> 3, sbit = hdr & 1u;
+    u32 len, sbit;
+    if (meta != GMETA_NONE) { len = meta >> 1; sbit = meta & 1u; }
+    else { u32 hdr = g[0]; len = hdr >> 3; sbit = hdr & 1u; }
     const u32 want = (MODE == GAP_AND) ? 0u : 1u;
     u32 k0 = (sbit == want) ? 1u : 2u;                 // first run (1-based) with the wanted value
     // 4 steps of 64 runs per batch: the 8 run-end loads of a batch are issued together, then applied
@@ -327,6 +328,25 @@ __device__ __forceinline__ void gap_apply_lds_wave(gcptr16 g, u32* lds, u32 lane
             }
         }
     }
+}
+
+// GAP block -> register image (gap_convert_to_bitset src/bmfunc.h:5232): zero the wave's LDS block, set the 1-runs
+// run-parallel (gap_apply_lds_wave<GAP_OR>: cost follows the run count -- ~60 instructions for a sparse block, ~300 for
+// a 1,200-run one), read it back.  The fixed-cost twin gap_decode_xor (toggle scatter + prefix-XOR, ~600 instructions
+// whatever the block holds) is what round 1 used everywhere; it stays as the cross-check of the parity tests.
+__device__ __forceinline__ void gap_decode(gcptr16 g, u32* lds, Blk& out, u32 lane, u32 meta = GMETA_NONE)
+{
+    u32x4* l4 = reinterpret_cast<u32x4*>(lds);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) l4[i * 64 + lane] = (u32x4)(0u);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    gap_apply_lds_wave<GAP_OR>(g, lds, lane, meta);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) out.r[i] = l4[i * 64 + lane];
+    __builtin_amdgcn_wave_barrier();
 }
 
 // one lane walks the wanted runs of its own operand (64 operands per wave step): for many short operands.

@@ -37,6 +37,8 @@ struct bmx_ctx {
     u64* d_zero = nullptr;                                  // 256 bytes of zeros: what an invalid slot of an unconditional load reads
     u32* d_done = nullptr;                                  // workgroup ticket of the in-kernel folds (kept zero between launches)
     u64* h_small = nullptr;                                 // pinned mirror
+    char* h_stage = nullptr; size_t stage_off = 0;          // pinned ring for small host -> device tables (h2d_staged)
+    hipEvent_t ev_stage = nullptr;
     // caching device allocator: results of same-shaped operations re-use their blocks instead of
     // paying hipMalloc / hipFree (which synchronises the device) on every call
     std::multimap<size_t, void*> pool_free;

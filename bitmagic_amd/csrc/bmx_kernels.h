@@ -361,7 +361,10 @@ void k_vec_expand(const u64* __restrict__ desc, u32 nblocks, u32 nblocks_out, ui
     if (nb >= nblocks_out) return;
     u64 d = nb < nblocks ? uniform64(desc[nb]) : 0ull;
     Blk b;
-    blk_from_desc(d, b, lds + wave * 2048u, lane);
+    // the export path decodes GAP blocks with the toggle / prefix-XOR decoder: every content check of the parity tests
+    // (to_words) thereby cross-checks it against the run-parallel decoder the operations use
+    if (DESC_K(d) == K_GAP) gap_decode_xor(as_gc16(DESC_P(d)), lds + wave * 2048u, b, lane, GMETA(d));
+    else blk_from_desc(d, b, lds + wave * 2048u, lane);
     blk_store(b, as_g4(out + (size_t)nb * 512u), lane);
 }
 

@@ -465,6 +465,72 @@ void k_agg_and_sub(const u64* __restrict__ dmat, const u32* __restrict__ and_n_p
 }
 
 // ---------------------------------------------------------------------------
+// Few block columns, long operand lists (BASELINE configs[0] scale: 256 vectors of 1 Mbit = 16 columns): with one
+// wave per (column, group) the chip would run 16 waves, each folding 256 blocks one after the other.  Here a
+// workgroup of SPLIT waves owns the item: wave w folds its contiguous share of the AND / SUB bit-block lists into
+// its own register accumulator (x & ~s is associative, so the shares combine with AND), the partial results meet in
+// LDS, wave 0 reduces them, applies the GAP operands and finishes like k_pipe_counts / k_agg_and_sub.
+// mode 0: counts[g] += popcount (counts-only pipeline); mode 1: store the block (single group: combine_and_sub).
+// ---------------------------------------------------------------------------
+template <int U, int SPLIT>
+__global__ __launch_bounds__(SPLIT * 64)
+void k_pipe_split(const u64* __restrict__ dmat, const u32* __restrict__ row_off, const u32* __restrict__ and_n,
+                  const u32* __restrict__ sub_n, u32 col_stride, u32 ngroups, u32 col_from, u32 col_to, int mode,
+                  u64* __restrict__ counts, int opt_compress, uint4* __restrict__ slab, u64* __restrict__ desc,
+                  BlockStat* __restrict__ st)
+{
+    extern __shared__ u32 lds_dyn[];                               // SPLIT x 2048 u32
+    u32 lane = lane_id(), wave = threadIdx.x >> 6;
+    u32 item = blockIdx.x;
+    u32 c = col_from + item / ngroups, g = item % ngroups;
+    if (mode == 1 && c >= col_to) { if (wave == 0) store_trivial(K_NULL, c, desc, st, lane); return; }   // outside a range hint
+    const u64* row = dmat + (size_t)c * col_stride + row_off[g];
+    u64 hdr = uniform64(row[0]), flags = uniform64(row[1]);
+    if (flags & ROW_EMPTY) { if (mode == 1 && wave == 0) store_trivial(K_NULL, c, desc, st, lane); return; }
+    if (flags & ROW_FULL) {
+        if (wave == 0) {
+            if (mode == 1) store_trivial(K_FULL, c, desc, st, lane);
+            else if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long*>(&counts[g]), 65536ull);
+        }
+        return;
+    }
+    u32 nba = (u32)(hdr & 0xFFFFu), nga = (u32)((hdr >> 16) & 0xFFFFu);
+    u32 nbs = (u32)((hdr >> 32) & 0xFFFFu), ngs = (u32)(hdr >> 48);
+    u32 na = uniform32(and_n[g]), ns = uniform32(sub_n[g]);
+    const u64* pa = row + 2;
+    const u64* ps = pa + na;
+    Blk acc;
+    blk_fill(acc, ~0u);
+    {
+        u32 a0 = (u32)(((u64)nba * wave) / SPLIT), a1 = (u32)(((u64)nba * (wave + 1u)) / SPLIT);
+        u32 s0 = (u32)(((u64)nbs * wave) / SPLIT), s1 = (u32)(((u64)nbs * (wave + 1u)) / SPLIT);
+        bool zero = pipe_chain<U, false, 0>(acc, pa + a0, a1 - a0, lane);
+        if (!zero) zero = pipe_chain<U, false, 1>(acc, ps + s0, s1 - s0, lane);
+        if (zero) blk_fill(acc, 0u);
+    }
+    u32* mine = lds_dyn + wave * 2048u;
+    blk_to_lds(acc, mine, lane);
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll 1
+    for (u32 k = 1; k < (u32)SPLIT; ++k) { Blk t; blk_from_lds(t, lds_dyn + k * 2048u, lane); blk_and(acc, t); }
+    bool zero = blk_is_zero(acc);
+    if (!zero && (nga | ngs)) {
+        blk_to_lds(acc, mine, lane);
+        zero = nga && gap_apply_list<GAP_AND>(pa + na - 1u, nga, mine, lane);
+        if (!zero) zero = ngs && gap_apply_list<GAP_SUB>(ps + ns - 1u, ngs, mine, lane);
+        if (!zero) { blk_from_lds(acc, mine, lane); zero = blk_is_zero(acc); }
+    }
+    if (mode == 1) {
+        if (zero) store_trivial(K_NULL, c, desc, st, lane);
+        else store_result(acc, c, opt_compress, slab, desc, st, lane);
+    } else if (!zero) {
+        u32 cnt = wave_sum(blk_lane_popcount(acc));
+        if (lane == 0 && cnt) atomicAdd(reinterpret_cast<unsigned long long*>(&counts[g]), (unsigned long long)cnt);
+    }
+}
+
+// ---------------------------------------------------------------------------
 // LDS-staged counts pipeline for MANY arg-groups over FEW distinct vectors -- the
 // sparse_vector_scanner call pattern (bit-sliced search: every query is an AND-SUB
 // group over the same bit-plane vectors, src/bmsparsevec_algo.h:2400-2630; the

@@ -431,6 +431,19 @@ def test_launch_shape_knobs_do_not_change_results(ctx, port, tail_bits):
             assert "k_pipe_counts<" in pipe.describe()
         for k, x in (("pipe_unroll", 0), ("pipe_rows", 0), ("pipe_nt", 1), ("pipe_wg", 0), ("pipe_window", 0), ("xcd_swizzle", 1)):
             ctx.set_tuning(k, x)
+        # operand lists split over the waves of a workgroup (few columns, long lists): counts and materialised results
+        for split in (1, 0, -1):
+            ctx.set_tuning("pipe_split", split)
+            assert (agg.combine_and_sub(pipe) == exp).all(), ("split", split)
+            nb = gv[0].info()["nblocks"]
+            parts = sum(agg._run_pipeline(pipe, a, b).astype(np.int64) for a, b in [(0, 2), (2, nb)])
+            assert (parts == exp.astype(np.int64)).all(), ("split", split)
+            for a, s_ in groups[::5]:
+                t, _ = agg.combine_and_sub([gv[i] for i in a], [gv[i] for i in s_])
+                e = port.agg_and_sub([pv[i] for i in a], [pv[i] for i in s_])
+                assert (t.to_words(14 * 2048) == e.to_words(14 * 2048)).all() and t.block_table()[0].tolist() == e.flatten()[0].tolist()
+        assert "k_pipe_split" in (ctx.set_tuning("pipe_split", 1) or pipe.describe())
+        ctx.set_tuning("pipe_split", -1)
         # LDS-staged many-groups kernel forced on (19 planes = 2 chunks, FULL / NULL planes, AND-SUB masks)
         for swz, slots in ((0, 16), (1, 16), (1, 8)):
             ctx.set_tuning("pipe_staged", 1); ctx.set_tuning("xcd_swizzle", swz); ctx.set_tuning("pipe_slots", slots)
@@ -441,7 +454,7 @@ def test_launch_shape_knobs_do_not_change_results(ctx, port, tail_bits):
             assert (parts == exp.astype(np.int64)).all()
     finally:
         for k, x in (("pipe_unroll", 0), ("pipe_rows", 0), ("pipe_nt", 1), ("pipe_wg", 0), ("pipe_window", 0), ("xcd_swizzle", 1),
-                     ("pipe_staged", -1), ("pipe_slots", 16)):
+                     ("pipe_staged", -1), ("pipe_slots", 16), ("pipe_split", -1)):
             ctx.set_tuning(k, x)
     # the materialising twins use the same fold: every prefix, AND-SUB and OR
     for a, s in groups[::4]:
