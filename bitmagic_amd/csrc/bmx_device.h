@@ -561,6 +561,11 @@ __device__ __forceinline__ u32 lds_blk_popcount(const u32* lds, u32 lane)
 // acc & gap (or acc & ~gap) restricted to the set bits of acc.
 // LDS use inside the wave's 8 KiB block: run ends in words [0, 640), candidate list in
 // [640, 1152); the block itself is rebuilt from the survivors at the end.
+// Measured alternative (round 2, dropped): RUN-side filtering -- accumulator kept as an LDS bitmap A, per operand
+// B |= A & run over the kept runs (or A &= ~run over the dropped ones, whichever covers fewer words), swap, zero.
+// It needs no "few survivors" precondition, but decoding every run slot (~35 instructions per run: 390 runs per operand
+// at 0.3 %) costs more than 196 candidates x 10 probes: 4.45 ms against 2.75 ms on the all-GAP 256-way case, 3.25 against
+// 1.57 ms at 0.1 %.  Either way a (column, operand) pair costs ~300 wave instructions; the kernel is VALU-bound there.
 // ---------------------------------------------------------------------------
 #define SPARSE_CAP 1024u
 #define SPARSE_NONE 0xFFFFFFFFu
