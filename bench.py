@@ -174,7 +174,20 @@ def setup_dist(args):
     torch.cuda.set_device(local_rank)
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        # RCCL prints a version banner on STDOUT when its first communicator comes up: keep stdout for the ONE JSON line
+        # (the banner goes to stderr) by creating the communicator -- init + a first all-reduce -- under a redirect
+        sys.stdout.flush()
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            t = torch.zeros(1, dtype=torch.int64, device="cuda")
+            dist.all_reduce(t)
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for N > 1"
     return world, rank, local_rank, use_dist
 

@@ -296,6 +296,37 @@ int main()
         }
         REQUIRE(g_or.compare(r_or) == 0 && g_or.any());
     }
+    // multi-GPU facade (bmx/group.hpp): the same calls over a device GROUP -- three members on this one GPU; vectors are
+    // sharded by block range, results gathered on download -- against bm::aggregator / bm::bvector on the host
+    {
+        bmx::device_group grp({0, 0, 0});
+        REQUIRE(grp.size() == 3);
+        std::vector<bmx::gbvector> gg; gg.reserve(6);
+        for (unsigned v = 0; v < 6; ++v) { gg.emplace_back(grp); bmx::upload(hv[v], gg.back(), NB); REQUIRE(gg[v].count() == hv[v].count()); }
+        { bvect back; bmx::download(gg[2], back); REQUIRE(back.compare(hv[2]) == 0); }
+        bmx::gbvector t(grp); bvect ref, got;
+        t.bit_and(gg[0], gg[1], bmx::bvector::opt_compress); ref.bit_and(hv[0], hv[1]); bmx::download(t, got); REQUIRE(got.compare(ref) == 0);
+        t.bit_xor(gg[2], gg[3]); ref.bit_xor(hv[2], hv[3]); bmx::download(t, got); REQUIRE(got.compare(ref) == 0);
+        REQUIRE(bmx::count_and(gg[0], gg[1]) == bm::count_and(hv[0], hv[1]) && bmx::count_sub(gg[4], gg[5]) == bm::count_sub(hv[4], hv[5]));
+        bm::aggregator<bvect> ragg; bmx::aggregator<bmx::gbvector> gagg(grp);
+        for (unsigned v = 0; v < 3; ++v) { ragg.add(&hv[v]); gagg.add(&gg[v]); }
+        ragg.add(&hv[3], 1); gagg.add(&gg[3], 1);
+        bool rf = ragg.combine_and_sub(ref), gf = gagg.combine_and_sub(t);
+        bmx::download(t, got); REQUIRE(rf == gf && got.compare(ref) == 0);
+        ragg.combine_or(ref); gagg.combine_or(t); bmx::download(t, got); REQUIRE(got.compare(ref) == 0);
+        typedef bm::aggregator<bvect>::pipeline<bm::agg_opt_only_counts> rpipe_t;
+        typedef bmx::aggregator<bmx::gbvector>::pipeline<bmx::agg_opt_only_counts> gpipe_t;
+        rpipe_t rp; gpipe_t gp(grp);
+        for (unsigned q = 0; q < 4; ++q) {
+            auto* ra = rp.add(); auto* ga = gp.add();
+            ra->add(&hv[q], 0); ga->add(&gg[q], 0); ra->add(&hv[q + 1], 0); ga->add(&gg[q + 1], 0);
+            if (q & 1) { ra->add(&hv[q + 2], 1); ga->add(&gg[q + 2], 1); }
+        }
+        rp.complete(); gp.complete();
+        bm::aggregator<bvect> ra2; ra2.combine_and_sub(rp); gagg.combine_and_sub(gp);
+        for (unsigned q = 0; q < 4; ++q) REQUIRE(rp.get_bv_count_vector()[q] == gp.get_bv_count_vector()[q]);
+        REQUIRE(gp.last_ms().size() == 3);
+    }
     // rank / select vs bvector<>::count_to / select with the reference rs_index
     {
         bvect::rs_index_type rrs; hv[3].build_rs_index(&rrs);
