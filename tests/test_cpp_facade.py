@@ -79,3 +79,15 @@ def test_reference_sample16_runs_unchanged_on_the_gpu():
     b = subprocess.run([gpu], env=_env(), capture_output=True, text=True, timeout=300)
     assert a.returncode == 0 and b.returncode == 0, a.stderr + b.stderr
     assert "AND-SUB:" in a.stdout and a.stdout == b.stdout, (a.stdout, b.stdout)
+
+
+@pytest.mark.gpu
+def test_libbm_c_wrapper_gpu_edition():
+    """BitMagic's own C wrapper (lang-maps/libbm/src/libbm.cpp, compiled unmodified) next to the GPU edition of its
+    pairwise / count surface (examples/libbm_gpu.cpp): a plain C client builds vectors through the libbm API and every
+    BMX_ call must agree with its BM_ twin (counts, combine_* + BM_bvector_compare, invalidate after a CPU-side change)"""
+    exe = os.path.join(ROOT, "oracle", "_ref", "test_libbm_gpu")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/test_libbm_gpu was not prebuilt (needs the reference sources at build time)")
+    r = subprocess.run([exe], env=_env(), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "test_libbm_gpu ok" in r.stdout, r.stdout + r.stderr
