@@ -133,6 +133,24 @@ def test_error_behaviour(ctx):
     with pytest.raises(bm.BmxError) as e:
         bm.bvector.from_block_table(ctx, 65536, [7], [0], np.zeros(0, np.uint32), np.zeros(0, np.uint16))
     assert e.value.status == 2
+    # run ends must be strictly ascending (checked on the device while the block is re-packed): an interior 65535, a
+    # repeated end and a descending pair are all refused; so is a length beyond the top GAP level (1279 runs)
+    good = np.array([(4 << 3), 10, 20, 30, 65535, 0, 0, 0], np.uint16)
+    assert bm.bvector.from_block_table(ctx, 65536, [bm.GAP], [0], np.zeros(0, np.uint32), good).count() == 10 + 65505
+    for bad in ([(4 << 3), 10, 65535, 30, 65535], [(4 << 3), 10, 10, 30, 65535], [(4 << 3), 30, 20, 40, 65535]):
+        with pytest.raises(bm.BmxError) as e:
+            bm.bvector.from_block_table(ctx, 65536, [bm.GAP], [0], np.zeros(0, np.uint32), np.array(bad + [0] * 3, np.uint16))
+        assert e.value.status == 3, bad
+    long_ = np.concatenate([[1280 << 3], np.arange(0, 2 * 1279, 2), [65535]]).astype(np.uint16)
+    with pytest.raises(bm.BmxError) as e:
+        bm.bvector.from_block_table(ctx, 65536, [bm.GAP], [0], np.zeros(0, np.uint32), long_)
+    assert e.value.status == 3
+    # two GAP blocks + a bit-block in one table: a bad SECOND block is found too, and nothing leaks (mem_used returns)
+    used = ctx.mem_used()
+    two = np.concatenate([good, np.array([(2 << 3), 500, 400, 0, 0, 0, 0, 0], np.uint16)])
+    with pytest.raises(bm.BmxError):
+        bm.bvector.from_block_table(ctx, 3 * 65536, [bm.GAP, bm.BIT, bm.GAP], [0, 0, 8], np.ones(2048, np.uint32), two)
+    assert ctx.mem_used() == used
     pipe = bm.aggregator.pipeline(ctx)
     with pytest.raises(RuntimeError):
         bm.aggregator(ctx).combine_and_sub(pipe)               # not complete()
@@ -249,3 +267,52 @@ def test_block_kinds_follow_reference(ctx, port, seed):
         e, ef = port.agg_shift_right_and([pv[k] for k in sel], oc, False)
         assert f == ef and t.block_table()[0].tolist()[:nblk] == e.flatten()[0].tolist()[:nblk]
     agg.set_optimization(False)
+
+
+def test_result_memory_is_what_the_result_holds(ctx, port):
+    """a materialised result keeps only what it holds: the full-size slab is transient.  AND of two vectors that meet in
+    3 of 400 blocks: the result owns 3 bit-blocks (compacted), its download moves 3 blocks, content = oracle; a result
+    that keeps 395 of 400 blocks stays in its slab (no second pass) and its download gathers the 395 live ones"""
+    nblk = 400
+    rng = np.random.default_rng(77)
+    wa = np.zeros(nblk * 2048, np.uint32); wb = np.zeros(nblk * 2048, np.uint32)
+    wa[:] = rng.integers(0, 1 << 32, wa.size, dtype=np.uint64).astype(np.uint32)
+    for nb in (5, 200, 399):
+        wb[nb * 2048:(nb + 1) * 2048] = rng.integers(0, 1 << 32, 2048, dtype=np.uint64).astype(np.uint32)
+    a, b = bm.bit_import_u32(ctx, wa, True), bm.bit_import_u32(ctx, wb, True)
+    pa, pb = port.import_words(wa, True, wa.size * 32), port.import_words(wb, True, wb.size * 32)
+    used = ctx.mem_used()
+    t = bm.bvector.bit_and(a, b)
+    i = t.info()
+    assert i["counts"][bm.BIT] == 3 and i["bit_slab_blocks"] == 3
+    assert ctx.mem_used() - used < 3 * 8192 + 2 * (2 << 20)            # not 400 x 8 KiB: three blocks + table (pool granules)
+    k, o, bits, gaps = t.block_table()
+    assert bits.size == 3 * 2048 and sorted(o[k == bm.BIT].tolist()) == [0, 1, 2]
+    e = port.op2(0, pa, pb, False)
+    assert (t.to_words() == e.to_words()).all() and k.tolist() == e.flatten()[0].tolist()
+    back = bm.bvector.from_block_table(ctx, nblk * 65536, k, o, bits, gaps)
+    assert (back.to_words() == e.to_words()).all()
+    # nearly full result: 395 of 400 blocks survive (b2 = all ones except five empty blocks)
+    wb2 = np.full(nblk * 2048, 0xFFFFFFFF, np.uint32)
+    for nb in (0, 7, 8, 123, 398):
+        wb2[nb * 2048:(nb + 1) * 2048] = 0
+    b2 = bm.bit_import_u32(ctx, wb2, True); pb2 = port.import_words(wb2, True, wb2.size * 32)
+    t2 = bm.bvector.bit_and(a, b2)
+    i2 = t2.info()
+    assert i2["counts"][bm.BIT] == 395 and i2["bit_slab_blocks"] == 395
+    k2, o2, bits2, gaps2 = t2.block_table()
+    assert bits2.size == 395 * 2048 and sorted(o2[k2 == bm.BIT].tolist()) == list(range(395))
+    e2 = port.op2(0, pa, pb2, False)
+    back2 = bm.bvector.from_block_table(ctx, nblk * 65536, k2, o2, bits2, gaps2)
+    assert (back2.to_words() == e2.to_words()).all() and (t2.to_words() == e2.to_words()).all()
+    # a clone of a slab with unused slots keeps the ordinals; pipeline results over many groups stay small
+    t3 = bm.bvector.bit_and(t2, t2)                                      # aliasing: block-for-block copy (src/bm.h:6191)
+    assert (t3.to_words() == e2.to_words()).all() and t3.block_table()[1][k2 == bm.BIT].tolist() == o2[k2 == bm.BIT].tolist()
+    pipe = bm.aggregator.pipeline(ctx, bm.agg_run_options(True, True))
+    for _ in range(24):
+        ag = pipe.add(); ag.add(a, 0); ag.add(b, 0)
+    pipe.complete()
+    used = ctx.mem_used()
+    agg = bm.aggregator(ctx); agg.combine_and_sub(pipe)
+    assert all(r.info()["bit_slab_blocks"] <= 3 for r in pipe.get_bv_res_vector())
+    assert ctx.mem_used() - used < 24 * (3 * 8192 + (1 << 20)) + (8 << 20)   # 24 x 3 blocks, not 24 x 400
