@@ -268,7 +268,7 @@ int bmx_ctx_create(int device, void* stream, bmx_ctx** out)
     // an invalid value is ignored (the default stays)
     static const char* const env_keys[][2] = {
         {"BMX_PIPE_UNROLL", "pipe_unroll"}, {"BMX_PIPE_ROWS", "pipe_rows"}, {"BMX_PIPE_NT", "pipe_nt"},
-        {"BMX_PIPE_WG", "pipe_wg"}, {"BMX_PIPE_WINDOW", "pipe_window"}, {"BMX_PIPE_SPLIT", "pipe_split"}, {"BMX_OR_TILE", "or_tile"}, {"BMX_OR_WINDOW", "or_window"}, {"BMX_XCD_SWIZZLE", "xcd_swizzle"}};
+        {"BMX_PIPE_WG", "pipe_wg"}, {"BMX_PIPE_WINDOW", "pipe_window"}, {"BMX_PIPE_SPLIT", "pipe_split"}, {"BMX_OR_TILE", "or_tile"}, {"BMX_OR_WINDOW", "or_window"}, {"BMX_DIRECT_COLS", "direct_cols"}, {"BMX_XCD_SWIZZLE", "xcd_swizzle"}};
     for (auto& kv : env_keys)
         if (const char* e = getenv(kv[0])) (void)bmx_ctx_set_tuning(ctx, kv[1], atoi(e));
     g_last_error.clear();
@@ -314,6 +314,7 @@ int bmx_ctx_set_tuning(bmx_ctx* ctx, const char* key, int value)
     else if (k == "pipe_split") { ARGCHK(value >= -1 && value <= 1); ctx->pipe_split = value; }
     else if (k == "pipe_window") { ARGCHK(value >= -1); ctx->pipe_window = value; }
     else if (k == "or_tile") { ARGCHK(value >= 0 && value <= 3); ctx->or_tile = value; }
+    else if (k == "direct_cols") { ARGCHK(value >= 0); ctx->direct_cols = value; }
     else if (k == "or_window") { ARGCHK(value >= -9); ctx->or_window = value; }
     else if (k == "pipe_wg") { ARGCHK(value == 0 || (value >= 64 && value <= 1024 && value % 64 == 0)); ctx->pipe_wg = value; }
     else if (k == "xcd_swizzle") ctx->xcd_swz = value != 0;
@@ -1135,6 +1136,47 @@ int bmx_count_op2(bmx_ctx* ctx, int op, const bmx_vec* a, const bmx_vec* b, uint
     return BMX_OK;
 }
 
+// ---- small collections: aggregation in one launch straight from the descriptor tables (k_direct, bmx_kernels2.h) ----
+static bool use_direct(const bmx_ctx* ctx, uint32_t ncols, size_t n_ops, uint32_t mult = 1)
+{
+    return ctx->pipe_split != 0 && ncols && ncols <= (uint64_t)ctx->direct_cols * mult && n_ops >= 24u && n_ops <= DIRECT_MAX_OPS;
+}
+
+// operand table on the device: n descriptor-table pointers, then n block counts (u32); one staged copy
+static int direct_table(bmx_ctx* ctx, const bmx_vec* const* a, size_t na, const bmx_vec* const* b, size_t nb, void** d_tab)
+{
+    size_t n = na + nb;
+    std::vector<u64> tab(n + (n + 1) / 2);
+    u32* nb32 = reinterpret_cast<u32*>(tab.data() + n);
+    for (size_t i = 0; i < n; ++i) {
+        const bmx_vec* o = i < na ? a[i] : b[i - na];
+        if (!o || o->ctx != ctx) { g_last_error = "operand is null or belongs to another context"; return BMX_ERR_BADARG; }
+        tab[i] = (u64)(uintptr_t)o->d_desc; nb32[i] = o->nblocks;
+    }
+    int rc;
+    *d_tab = nullptr;
+    if ((rc = dmalloc(ctx, d_tab, tab.size() * 8)) || (rc = h2d_staged(ctx, *d_tab, tab.data(), tab.size() * 8))) { dfree(ctx, *d_tab); *d_tab = nullptr; }
+    return rc;
+}
+
+static int direct_launch(int mode, bmx_ctx* ctx, const void* d_tab, size_t n_and, size_t n_sub, u32 col_from, u32 col_to, int opt_compress,
+                         bmx_vec* v, BlockStat* st, int has_mask, u32 mf, u32 mt)
+{
+    if (col_to <= col_from) return BMX_OK;
+    size_t n = n_and + n_sub;
+    size_t lds = (size_t)SPLIT_WAVES * 8192 + 2 * (n_and + n_sub) * 8;    // partials + bit / GAP lists of both groups
+    auto fn = mode == DIRECT_AND_SUB ? k_direct<SPLIT_WAVES, DIRECT_AND_SUB> :
+              mode == DIRECT_OR ? k_direct<SPLIT_WAVES, DIRECT_OR> : k_direct<SPLIT_WAVES, DIRECT_FIND_FIRST>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(fn, dim3(col_to - col_from), dim3(SPLIT_WAVES * 64), lds, ctx->stream,
+                           (const u64* const*)d_tab, (const u32*)((const u64*)d_tab + n), (u32)n_and, (u32)n_sub, col_from, col_to,
+                           opt_compress, v ? v->d_bits : nullptr, v ? v->d_desc : nullptr, st, has_mask, mf, mt, ctx->d_small);
+        e = hipGetLastError();
+    }
+    return e == hipSuccess ? BMX_OK : fail_hip(e, "k_direct", __LINE__);
+}
+
 static int agg_or_impl(bmx_ctx* ctx, const bmx_vec* const* src, size_t n, int opt_compress, bmx_vec** result);
 
 int bmx_agg_or(bmx_ctx* ctx, const bmx_vec* const* src, size_t n, bmx_vec** result)
@@ -1164,7 +1206,15 @@ static int agg_or_impl(bmx_ctx* ctx, const bmx_vec* const* src, size_t n, int op
     }
     bmx_vec* v; BlockStat* st; u32* offs;
     if ((rc = result_begin(ctx, nbits, ncols, &v, &st, &offs))) return rc;      // empty list => cleared target (:1105)
-    if (n >= 64 && ncols && has_gap && !has_bit) {
+    if (use_direct(ctx, ncols, n)) {
+        void* d_tab = nullptr;
+        if ((rc = direct_table(ctx, src, n, nullptr, 0, &d_tab))) { bmx_vec_free(ctx, v); return rc; }
+        rc = direct_launch(DIRECT_OR, ctx, d_tab, n, 0, 0u, ncols, opt_compress, v, st, 0, 0u, 0u);
+        if (!rc) rc = result_finish(ctx, v, st, offs);
+        else (void)hipStreamSynchronize(ctx->stream);
+        dfree(ctx, d_tab);
+        if (rc) { bmx_vec_free(ctx, v); return rc; }
+    } else if (n >= 64 && ncols && has_gap && !has_bit) {
         // many GAP-only operands: column-tile kernel straight from the descriptor tables (no sort pass)
         void* d_descs = nullptr; void* d_nblk = nullptr;
         if ((rc = dmalloc(ctx, &d_descs, n * 8)) || (rc = dmalloc(ctx, &d_nblk, n * 4))) { dfree(ctx, d_descs); bmx_vec_free(ctx, v); return rc; }
@@ -1241,6 +1291,20 @@ int bmx_agg_and_sub(bmx_ctx* ctx, const bmx_vec* const* src_and, size_t n_and,
         if (ncols) HIPCHK(hipMemsetAsync(v->d_desc, 0, (size_t)ncols * 8, ctx->stream));
         v->counts[BMX_NULL] = ncols;
         HIPCHK(hipStreamSynchronize(ctx->stream));
+        *result = v;
+        return BMX_OK;
+    }
+    // small collection (few columns, many operands): one launch straight from the descriptor tables (k_direct)
+    if (use_direct(ctx, ncols, n_and + n_sub)) {
+        void* d_tab = nullptr;
+        if ((rc = direct_table(ctx, src_and, n_and, src_sub, n_sub, &d_tab))) return rc;
+        if ((rc = result_begin(ctx, nbits, ncols, &v, &st, &offs))) { dfree(ctx, d_tab); return rc; }
+        rc = direct_launch(DIRECT_AND_SUB, ctx, d_tab, n_and, n_sub, 0u, ncols, 1, v, st, 0, 0u, 0u);
+        if (!rc) rc = result_finish(ctx, v, st, offs);              // synchronises
+        else (void)hipStreamSynchronize(ctx->stream);
+        dfree(ctx, d_tab);
+        if (rc) { bmx_vec_free(ctx, v); return rc; }
+        if (any) *any = (v->counts[BMX_FULL] + v->counts[BMX_BIT] + v->counts[BMX_GAP]) != 0;
         *result = v;
         return BMX_OK;
     }
@@ -1338,15 +1402,33 @@ static int find_first_impl(bmx_ctx* ctx, const bmx_vec* const* src_and, size_t n
     if (!n_and) return BMX_OK;
     if (ranged && from > to) { g_last_error = "range hint: from > to"; return BMX_ERR_RANGE; }
     uint32_t an = (uint32_t)n_and, sn = (uint32_t)n_sub;
-    bmx_pipeline* p = nullptr;
-    if ((rc = bmx_pipeline_create(ctx, src_and, &an, src_sub, &sn, 1, &p))) return rc;
-    u32 col_from = 0, col_to = p->ncols; int has_mask = 0; u32 mf = 0, mt = 65535u;
+    u32 ncols_all = 0;
+    for (size_t i = 0; i < n_and; ++i) { ARGCHK(src_and[i]); ncols_all = std::max(ncols_all, src_and[i]->nblocks); }
+    for (size_t i = 0; i < n_sub; ++i) { ARGCHK(src_sub[i]); ncols_all = std::max(ncols_all, src_sub[i]->nblocks); }
+    u32 col_from = 0, col_to = ncols_all; int has_mask = 0; u32 mf = 0, mt = 65535u;
     if (ranged) {
         uint64_t nbf = from >> 16, nbt = to >> 16;
-        col_from = (u32)std::min<uint64_t>(nbf, p->ncols);
-        col_to = (u32)std::min<uint64_t>(nbt + 1u, p->ncols);
+        col_from = (u32)std::min<uint64_t>(nbf, ncols_all);
+        col_to = (u32)std::min<uint64_t>(nbt + 1u, ncols_all);
         if (nbf == nbt) { has_mask = 1; mf = (u32)(from & 65535u); mt = (u32)(to & 65535u); }
     }
+    // few columns to visit, many operands: one launch.  A workgroup per column is dispatched in column order, so later
+    // columns see an earlier hit and leave at once (1526 columns x 256 operands: 0.22 ms against 0.58 ms): wider limit here
+    if (use_direct(ctx, col_to > col_from ? col_to - col_from : 0u, n_and + n_sub, 8u)) {
+        void* d_tab = nullptr;
+        if ((rc = direct_table(ctx, src_and, n_and, src_sub, n_sub, &d_tab))) return rc;
+        hipError_t e = hipMemsetAsync(ctx->d_small, 0xFF, 8, ctx->stream);
+        if (e == hipSuccess) rc = direct_launch(DIRECT_FIND_FIRST, ctx, d_tab, n_and, n_sub, col_from, col_to, 0, nullptr, nullptr, has_mask, mf, mt);
+        if (e == hipSuccess && !rc) e = hipMemcpyAsync(ctx->h_small, ctx->d_small, 8, hipMemcpyDeviceToHost, ctx->stream);
+        hipError_t e2 = hipStreamSynchronize(ctx->stream);
+        dfree(ctx, d_tab);
+        if (rc) return rc;
+        if (e != hipSuccess || e2 != hipSuccess) return fail_hip(e != hipSuccess ? e : e2, "bmx_find_first_and_sub", __LINE__);
+        if (ctx->h_small[0] != ~0ull) { *found = 1; *idx = ctx->h_small[0]; }
+        return BMX_OK;
+    }
+    bmx_pipeline* p = nullptr;
+    if ((rc = bmx_pipeline_create(ctx, src_and, &an, src_sub, &sn, 1, &p))) return rc;
     hipError_t e = hipMemsetAsync(ctx->d_small, 0xFF, 8, ctx->stream);
     if (e == hipSuccess && col_to > col_from) {
         size_t lds = p->has_gap ? 4 * 2048 * 4 : 0;

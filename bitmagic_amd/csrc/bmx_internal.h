@@ -54,6 +54,7 @@ struct bmx_ctx {
     int pipe_slots = 16;       // plane blocks staged at a time (16: 1024-thread WG; 8: two 512-thread WGs per CU)
     int pipe_split = -1;       // few columns: waves of a workgroup share one column's operand list: -1 auto, 0 never, 1 always
     int or_tile = 0;           // k_agg_or_gap_tiled variant (0 = default)
+    int direct_cols = 384;     // aggregation over <= this many block columns and 24..1024 operands: one launch from the descriptor tables (k_direct); 0 = off
     int or_window = 0;         // column tiles per launch of k_agg_or_gap_tiled: 0 / -1 = all in one launch (windows measured: no gain)
     int xcd_swz = 1;
 };

@@ -604,6 +604,40 @@ void k_pipe_counts_staged(const u64* const* __restrict__ udesc, const u32* __res
     }
 }
 
+// rows [mask_from, mask_to] of a block (range_gap_blk_, src/bmaggregator.h:980-988)
+__device__ __forceinline__ void blk_bit_range(Blk& acc, u32 mask_from, u32 mask_to, u32 lane)
+{
+    u32 r = mask_to + 1u;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        u32 ws[4] = {acc.r[i].x, acc.r[i].y, acc.r[i].z, acc.r[i].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            u32 lo = ((u32)i * 256u + lane * 4u + (u32)j) << 5;
+            u32 hi_m = r >= lo + 32u ? ~0u : (r <= lo ? 0u : ((1u << (r - lo)) - 1u));
+            u32 lo_m = mask_from <= lo ? ~0u : (mask_from >= lo + 32u ? 0u : (~0u << (mask_from - lo)));
+            ws[j] &= hi_m & lo_m;
+        }
+        acc.r[i].x = ws[0]; acc.r[i].y = ws[1]; acc.r[i].z = ws[2]; acc.r[i].w = ws[3];
+    }
+}
+
+// bit_find_first (src/bmfunc.h:9499): smallest bit index of the block, 0xFFFFFFFF = none (same value in every lane)
+__device__ __forceinline__ u32 blk_first_bit(const Blk& acc, u32 lane)
+{
+    u32 mine = 0xFFFFFFFFu;
+#pragma unroll
+    for (int i = 7; i >= 0; --i) {
+        u32 w[4] = {acc.r[i].x, acc.r[i].y, acc.r[i].z, acc.r[i].w};
+#pragma unroll
+        for (int j = 3; j >= 0; --j)
+            if (w[j]) mine = (((u32)i * 256u + lane * 4u + (u32)j) << 5) + (u32)__builtin_ctz(w[j]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { u32 t = __shfl_xor(mine, o, 64); mine = t < mine ? t : mine; }
+    return mine;
+}
+
 // aggregator::find_first_and_sub  src/bmaggregator.h:1458: index of the first set bit of
 // AND(group 0) AND NOT OR(group 1) without materialising the result.  Columns are visited in
 // ascending order by the dispatcher; a wave gives up as soon as an earlier column already has a hit
@@ -643,34 +677,134 @@ void k_find_first_and_sub(const u64* __restrict__ dmat, const u32* __restrict__ 
         if (ngs && gap_apply_list<GAP_SUB>(ps + ns - 1u, ngs, lds, lane)) return;
         blk_from_lds(acc, lds, lane);
     }
-    if (has_mask) {
-        u32 r = mask_to + 1u;                                   // rows [mask_from, mask_to] of the block
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            u32 ws[4] = {acc.r[i].x, acc.r[i].y, acc.r[i].z, acc.r[i].w};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                u32 lo = ((u32)i * 256u + lane * 4u + (u32)j) << 5;
-                u32 hi_m = r >= lo + 32u ? ~0u : (r <= lo ? 0u : ((1u << (r - lo)) - 1u));
-                u32 lo_m = mask_from <= lo ? ~0u : (mask_from >= lo + 32u ? 0u : (~0u << (mask_from - lo)));
-                ws[j] &= hi_m & lo_m;
-            }
-            acc.r[i].x = ws[0]; acc.r[i].y = ws[1]; acc.r[i].z = ws[2]; acc.r[i].w = ws[3];
-        }
-    }
-    // bit_find_first (src/bmfunc.h:9499): smallest linear bit index held by this lane, then wave min
-    u32 mine = 0xFFFFFFFFu;
-#pragma unroll
-    for (int i = 7; i >= 0; --i) {
-        u32 w[4] = {acc.r[i].x, acc.r[i].y, acc.r[i].z, acc.r[i].w};
-#pragma unroll
-        for (int j = 3; j >= 0; --j)
-            if (w[j]) mine = (((u32)i * 256u + lane * 4u + (u32)j) << 5) + (u32)__builtin_ctz(w[j]);
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { u32 t = __shfl_xor(mine, o, 64); mine = t < mine ? t : mine; }
+    if (has_mask) blk_bit_range(acc, mask_from, mask_to, lane);
+    u32 mine = blk_first_bit(acc, lane);
     if (lane == 0 && mine != 0xFFFFFFFFu)
         atomicMin(reinterpret_cast<unsigned long long*>(best), ((unsigned long long)c << 16) + mine);
+}
+
+// ---------------------------------------------------------------------------
+// Aggregation over a SMALL collection in ONE launch (configs[0] scale: few block columns, many operands): no row
+// table, no sort pass.  A workgroup owns a block column: its threads classify the operands straight from the vectors'
+// descriptor tables (sort_input_blocks_and / _or rules, src/bmaggregator.h:2315,2278), bit-block and GAP pointers are
+// collected in LDS lists, the SPLIT waves fold their shares of the bit-blocks, wave 0 reduces, applies the GAP lists
+// and finishes.  Host side: one staged copy of the operand table, this kernel (and the layout scan for a stored result).
+//   MODE 0  combine_and_sub  (:1163): NULL in the AND group or FULL in the SUB group empties the column, FULL AND
+//           operands and NULL SUB operands are dropped; result stored with opt_compress (:1210)
+//   MODE 1  find_first_and_sub (:1458): same fold over columns [col_from, ncols), first bit -> atomicMin(best)
+//   MODE 2  combine_or (:1626): any FULL operand => FULL column; saturation to all-ones after >= 2 bit-blocks => FULL (:1951)
+// LDS: SPLIT x 8 KiB partials + one pointer slot per operand.
+// ---------------------------------------------------------------------------
+#define DIRECT_MAX_OPS 1024u
+enum { DIRECT_AND_SUB = 0, DIRECT_FIND_FIRST = 1, DIRECT_OR = 2 };
+template <int SPLIT, int MODE>
+__global__ __launch_bounds__(SPLIT * 64)
+void k_direct(const u64* const* __restrict__ descs, const u32* __restrict__ nblk, u32 n_and, u32 n_sub, u32 col_from, u32 ncols,
+              int opt_compress, uint4* __restrict__ slab, u64* __restrict__ desc, BlockStat* __restrict__ st,
+              int has_mask, u32 mask_from, u32 mask_to, u64* __restrict__ best)
+{
+    extern __shared__ u32 lds_dyn[];                               // SPLIT x 2048 u32, then the lists
+    u64* bitA = reinterpret_cast<u64*>(lds_dyn + SPLIT * 2048u);   // group-0 bit-blocks from the front, GAP blocks from the back
+    u64* gapA = bitA + n_and - 1u;                                 // (gap_apply_list walks backwards); nbit + ngap <= n_and
+    u64* bitS = bitA + n_and;
+    u64* gapS = bitS + n_sub - 1u;
+    __shared__ u32 cnt[8];                                         // nbitA, ngapA, nbitS, ngapS, decided
+    u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    u32 c = col_from + blockIdx.x;
+    if (MODE == DIRECT_FIND_FIRST) {
+        u64 cur = __hip_atomic_load(best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (((u64)c << 16) > cur) return;                          // an earlier column already has a hit (uniform per workgroup: one load each, monotone)
+    }
+    if (tid < 8) cnt[tid] = 0u;
+    __syncthreads();
+    for (u32 i = tid; i < n_and + n_sub; i += blockDim.x) {
+        bool is_sub = i >= n_and;
+        u32 nb = nblk[i];
+        u64 d = c < nb ? descs[i][c] : 0ull;
+        u32 k = DESC_K(d);
+        if (MODE == DIRECT_OR) {
+            if (k == K_FULL) cnt[4] = 1u;                                          // any FULL => FULL column (:2292)
+            else if (k == K_BIT) { u32 p = atomicAdd(&cnt[0], 1u); bitA[p] = DESC_P(d); }
+            else if (k == K_GAP) { u32 p = atomicAdd(&cnt[1], 1u); *(gapA - p) = DESC_P(d); }
+        } else if (!is_sub) {
+            if (k == K_NULL) cnt[4] = 1u;                                          // any NULL => empty column (:2327)
+            else if (k == K_BIT) { u32 p = atomicAdd(&cnt[0], 1u); bitA[p] = DESC_P(d); }
+            else if (k == K_GAP) { u32 p = atomicAdd(&cnt[1], 1u); *(gapA - p) = DESC_P(d); }
+        } else {
+            if (k == K_FULL) cnt[4] = 1u;                                          // FULL in the SUB group => empty (:1746)
+            else if (k == K_BIT) { u32 p = atomicAdd(&cnt[2], 1u); bitS[p] = DESC_P(d); }
+            else if (k == K_GAP) { u32 p = atomicAdd(&cnt[3], 1u); *(gapS - p) = DESC_P(d); }
+        }
+    }
+    __syncthreads();
+    const u32 nba = cnt[0], nga = cnt[1], nbs = cnt[2], ngs = cnt[3];
+    const bool nothing = !(nba | nga | nbs | ngs);
+    if (MODE == DIRECT_OR) {
+        if (cnt[4]) { if (wave == 0) store_trivial(K_FULL, c, desc, st, lane); return; }
+        if (nothing) { if (wave == 0) store_trivial(K_NULL, c, desc, st, lane); return; }
+    } else {
+        if (cnt[4]) { if (MODE == DIRECT_AND_SUB && wave == 0) store_trivial(K_NULL, c, desc, st, lane); return; }
+        if (nothing) {                                             // all FULL, nothing subtracted (:1751)
+            if (MODE == DIRECT_AND_SUB) { if (wave == 0) store_trivial(K_FULL, c, desc, st, lane); }
+            else if (tid == 0) atomicMin(reinterpret_cast<unsigned long long*>(best), ((unsigned long long)c << 16) + (has_mask ? mask_from : 0u));
+            return;
+        }
+    }
+    Blk acc;
+    blk_fill(acc, MODE == DIRECT_OR ? 0u : ~0u);
+    {
+        u32 a0 = (u32)(((u64)nba * wave) / SPLIT), a1 = (u32)(((u64)nba * (wave + 1u)) / SPLIT);
+        for (u32 k = a0; k < a1; k += 2u) {
+            u64 p0 = uniform64(bitA[k]), p1 = uniform64(bitA[k + 1u < a1 ? k + 1u : k]);
+            Blk x, y; blk_load(x, as_gc4(p0), lane); blk_load(y, as_gc4(p1), lane);
+            if (MODE == DIRECT_OR) { blk_or(acc, x); blk_or(acc, y); if (blk_is_ones(acc)) break; }      // saturated: the rest cannot change it
+            else { blk_and(acc, x); blk_and(acc, y); if (blk_is_zero(acc)) break; }                       // digest went to zero (:2081)
+        }
+        if (MODE != DIRECT_OR) {
+            u32 s0 = (u32)(((u64)nbs * wave) / SPLIT), s1 = (u32)(((u64)nbs * (wave + 1u)) / SPLIT);
+            for (u32 k = s0; k < s1; k += 2u) {
+                u64 p0 = uniform64(bitS[k]), p1 = uniform64(bitS[k + 1u < s1 ? k + 1u : k]);
+                Blk x, y; blk_load(x, as_gc4(p0), lane); blk_load(y, as_gc4(p1), lane);
+                blk_andn(acc, x); blk_andn(acc, y);
+                if (blk_is_zero(acc)) break;
+            }
+        }
+    }
+    u32* mine = lds_dyn + wave * 2048u;
+    blk_to_lds(acc, mine, lane);
+    __syncthreads();
+    if (wave != 0) return;
+#pragma unroll 1
+    for (u32 k = 1; k < (u32)SPLIT; ++k) {
+        Blk t; blk_from_lds(t, lds_dyn + k * 2048u, lane);
+        if (MODE == DIRECT_OR) blk_or(acc, t); else blk_and(acc, t);
+    }
+    if (MODE == DIRECT_OR) {
+        if (nba >= 2u && blk_is_ones(acc)) { store_trivial(K_FULL, c, desc, st, lane); return; }   // saturated (:1951)
+        if (nga) {
+            blk_to_lds(acc, mine, lane);
+            (void)gap_apply_list<GAP_OR>(gapA, nga, mine, lane);
+            blk_from_lds(acc, mine, lane);
+        }
+        store_result_mode(acc, c, opt_compress ? ST_OPT : ST_FORCE_BIT, slab, desc, st, lane);   // :1658
+        return;
+    }
+    bool zero = blk_is_zero(acc);
+    if (!zero && (nga | ngs)) {
+        blk_to_lds(acc, mine, lane);
+        zero = nga && gap_apply_list<GAP_AND>(gapA, nga, mine, lane);
+        if (!zero) zero = ngs && gap_apply_list<GAP_SUB>(gapS, ngs, mine, lane);
+        if (!zero) { blk_from_lds(acc, mine, lane); zero = blk_is_zero(acc); }
+    }
+    if (MODE == DIRECT_AND_SUB) {
+        if (zero) store_trivial(K_NULL, c, desc, st, lane);
+        else store_result(acc, c, opt_compress, slab, desc, st, lane);
+    } else if (!zero) {
+        if (has_mask) blk_bit_range(acc, mask_from, mask_to, lane);
+        u32 first = blk_first_bit(acc, lane);
+        if (lane == 0 && first != 0xFFFFFFFFu)
+            atomicMin(reinterpret_cast<unsigned long long*>(best), ((unsigned long long)c << 16) + first);
+    }
 }
 
 // ---------------------------------------------------------------------------

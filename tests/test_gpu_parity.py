@@ -504,6 +504,72 @@ def test_many_gap_operands(ctx, port, dq, nvec):
             ctx.set_tuning("pipe_staged", -1)
 
 
+@pytest.mark.parametrize("nvec,ncols", [(24, 1), (64, 16), (257, 7), (1024, 3)])
+def test_small_collection_direct_path(ctx, port, nvec, ncols):
+    """combine_and_sub over a small collection (few block columns, >= 24 operands) is ONE launch straight from the
+    descriptor tables (k_and_sub_direct): same blocks, kinds and bits as the oracle and as the row-table pipeline
+    path (pipe_split 0), over BIT / GAP / FULL / NULL operands, ragged lengths, empty AND groups' columns and
+    operand counts up to the kernel's list capacity"""
+    rng = np.random.default_rng(nvec * 31 + ncols)
+    nbits = ncols * 65536 - 77
+    words = []
+    for v in range(nvec):
+        nb = nbits if v % 6 else max(65536 - 77, nbits - 2 * 65536)          # ragged
+        kind = v % 4
+        w = port.gen_words(99, v, 64000 if kind < 2 else 600, nb)             # dense BIT / sparse GAP
+        w |= port.gen_words(99, 0xFFFFFFFF, 3000, nb)                         # shared component (the AND survives)
+        nw = (nb + 31) // 32
+        if nb % 32: w[nw - 1] &= (1 << (nb % 32)) - 1
+        w[nw:] = 0
+        for b in range(w.size // 2048):
+            r = rng.integers(0, 40)
+            if r == 0 and v % 9 == 8: w[b * 2048:(b + 1) * 2048] = 0
+            elif r < 6 and (b + 1) * 65536 <= nb: w[b * 2048:(b + 1) * 2048] = 0xFFFFFFFF
+        words.append(w)
+    gv = [bm.bit_import_u32(ctx, w, True) for w in words]
+    pv = [port.import_words(w, True, w.size * 32) for w in words]
+    nwb = ncols * 2048
+    agg = bm.aggregator(ctx)
+    na = nvec - nvec // 8
+    cases = [(list(range(nvec)), []), (list(range(na)), list(range(na, nvec))), ([1], list(range(2, nvec))),
+             ([i for i in range(nvec) if i % 6], [])]
+    try:
+        for a, s in cases:
+            e = port.agg_and_sub([pv[i] for i in a], [pv[i] for i in s])
+            for split in (-1, 0):
+                ctx.set_tuning("pipe_split", split)
+                t, any_ = agg.combine_and_sub([gv[i] for i in a], [gv[i] for i in s])
+                assert (t.to_words(nwb) == e.to_words(nwb)).all(), (len(a), len(s), split)
+                assert t.block_table()[0].tolist() == (e.flatten()[0].tolist() + [0] * ncols)[:t.info()["nblocks"]]
+                assert any_ == (e.count() != 0) and t.count() == e.count()
+                # find_first_and_sub: whole vector, a multi-block hint, a one-block hint (bit mask)
+                bits = np.flatnonzero(np.unpackbits(e.to_words(nwb).view(np.uint8), bitorder="little"))
+                assert agg.find_first_and_sub([gv[i] for i in a], [gv[i] for i in s]) == ((True, int(bits[0])) if bits.size else (False, 0))
+                hints = [(100, 60000)] + ([(65536 + 9, min(nbits - 1, 3 * 65536 + 5))] if ncols > 2 else [])
+                if bits.size: hints.append((int(bits[bits.size // 2]), int(bits[bits.size // 2]) | 0xFFFF))
+                for frm, to in hints:
+                    one = agg.set_range_hint(frm, to)
+                    cand = bits[(bits >= frm) & (bits <= to)] if one else bits[(bits >= (frm >> 16) << 16) & (bits < ((to >> 16) + 1) << 16)]
+                    f, idx = agg.find_first_and_sub([gv[i] for i in a], [gv[i] for i in s])
+                    assert f == (cand.size > 0) and (not f or idx == cand[0]), (frm, to, split)
+                agg.reset_range_hint()
+        # combine_or: with and without result optimisation (block kinds follow opt_mode, src/bmaggregator.h:1658)
+        for sel in (list(range(nvec)), [i for i in range(nvec) if i % 4 >= 2], [i for i in range(nvec) if i % 4 >= 2 and i % 9 != 8][:30]):
+            if len(sel) < 24: continue
+            for opt in (False, True):
+                eo = port.agg_or([pv[i] for i in sel], opt)
+                for split in (-1, 0):
+                    ctx.set_tuning("pipe_split", split)
+                    agg.set_optimization(opt)
+                    o = agg.combine_or([gv[i] for i in sel])
+                    assert (o.to_words(nwb) == eo.to_words(nwb)).all(), (len(sel), split)
+                    assert o.block_table()[0].tolist() == (eo.flatten()[0].tolist() + [0] * ncols)[:o.info()["nblocks"]], (len(sel), split, opt)
+            agg.set_optimization(False)
+    finally:
+        ctx.set_tuning("pipe_split", -1)
+        agg.reset_range_hint()
+
+
 @pytest.mark.parametrize("common_bits,own_dq,nvec", [(1, 30, 40), (40, 100, 70), (400, 100, 90), (520, 40, 36),
                                                      (700, 200, 50)])
 def test_sparse_state_of_gap_lists(ctx, port, common_bits, own_dq, nvec):

@@ -42,3 +42,25 @@ for staged, swz, slots in ((0, 1, 16), (1, 1, 16), (1, 1, 8)):
                       "ms": round(ms, 3), "logical_operand_GB": round(ob / 1e9, 2), "logical_TBps": round(ob / ms / 1e9, 2),
                       "unique_operand_GB": round(a.planes * a.nbits / 8e9, 2), "queries_per_s": round(a.groups / ms * 1e3, 1),
                       "nonzero_groups": int((counts > 0).sum().item())}))
+
+# ---- range search (find_gt / find_le / find_range / find_zero): one pass over the planes (bmx_slice_compare) ----
+import time
+sc = bm.slice_scanner(ctx, planes, size=a.nbits)
+plane_bytes = a.planes * ((a.nbits + 65535) // 65536) * 8192
+for name, fn, cnt_fn in (("find_gt", lambda v: sc.find_gt(v), lambda v: sc.count(bm.CMP_GT, v)),
+                         ("find_le", lambda v: sc.find_le(v), lambda v: sc.count(bm.CMP_LE, v)),
+                         ("find_range", lambda v: sc.find_range(v >> 1, v), lambda v: sc.count(bm.CMP_RANGE, v >> 1, v))):
+    vals = [int(rng.integers(1 << (a.planes - 2), 1 << (a.planes - 1))) for _ in range(6)]
+    for v in vals[:2]: cnt_fn(v)
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    cs = [cnt_fn(v) for v in vals]
+    t_cnt = (time.perf_counter() - t0) / len(vals) * 1e3
+    t0 = time.perf_counter()
+    rs = [fn(v) for v in vals]
+    ctx.synchronize()
+    t_mat = (time.perf_counter() - t0) / len(vals) * 1e3
+    assert [r.count() for r in rs] == cs
+    print(json.dumps({"pattern": "range_search", "op": name, "planes": a.planes, "rows": a.nbits, "count_only_ms": round(t_cnt, 3),
+                      "materialised_ms": round(t_mat, 3), "plane_GB": round(plane_bytes / 1e9, 2),
+                      "TBps_if_all_planes_read": round(plane_bytes / t_cnt / 1e9, 2), "example_count": cs[0]}))

@@ -13,13 +13,17 @@ def t(fn, reps=30, warm=5):
     for _ in range(reps):
         t0 = time.perf_counter(); fn(); ts.append((time.perf_counter() - t0) * 1e3)
     return round(float(np.median(ts)), 4)
-for nbits in (1_000_000, 100_000_000):
+for nbits in (1_000_000, 16_000_000, 100_000_000):
     vecs = [bm.bvector.generate(ctx, 0xB17A61C, v, 6554, nbits, with_common=True) for v in range(256)]
     agg = bm.aggregator(ctx)
     out = {"nbits": nbits, "nvec": 256}
     out["combine_and_ms"] = t(lambda: agg.combine_and_sub(vecs, []))
     out["combine_or_ms"] = t(lambda: agg.combine_or(vecs))
     out["find_first_ms"] = t(lambda: agg.find_first_and_sub(vecs, []))
+    own = [bm.bvector.generate(ctx, 0xB17A61C, v, 6554, nbits, with_common=False) for v in range(256)]   # AND dies after a few operands
+    out["combine_and_disjoint_ms"] = t(lambda: agg.combine_and_sub(own, []))
+    out["find_first_disjoint_ms"] = t(lambda: agg.find_first_and_sub(own, []))
+    del own
     def mk():
         p = bm.aggregator.pipeline(ctx); g = p.add()
         for v in vecs: g.add(v, 0)
