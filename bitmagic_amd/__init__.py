@@ -730,6 +730,26 @@ class group:
             check(lib().bmx_ctx_set_tuning(c, key.encode(), int(value)))
 
 
+class grs_index:
+    """rank-select index of a sharded vector: one bm::rs_index twin per shard + the ones before each shard"""
+
+    def __init__(self, bv: "gbvector", handle):
+        self.bv, self.grp, self._h = bv, bv.grp, handle
+
+    def __del__(self):
+        try:
+            if self._h and self.grp._h:
+                lib().bmx_grs_free(self.grp._h, self._h)
+            self._h = None
+        except Exception:
+            pass
+
+    def count(self) -> int:
+        c = C.c_uint64()
+        check(lib().bmx_grs_count(self._h, C.byref(c)))
+        return c.value
+
+
 class gbvector:
     """bit-vector sharded by block range over the members of a group (bmx_gvec)"""
 
@@ -780,6 +800,33 @@ class gbvector:
         c = C.c_uint64()
         check(lib().bmx_gvec_count(self.grp._h, self._h, C.byref(c)))
         return c.value
+
+    # -- rank / select: per-shard index, queries routed to the owning member (bmx_grs_*) --
+    def build_rs_index(self) -> "grs_index":
+        h = C.c_void_p()
+        check(lib().bmx_grs_build(self.grp._h, self._h, C.byref(h)))
+        return grs_index(self, h)
+
+    def count_to(self, n, rs: "grs_index"):
+        """ones in [0..n] inclusive; scalar or array of positions (src/bm.h:3120)"""
+        arr = np.ascontiguousarray(np.atleast_1d(n), np.uint64)
+        out = np.zeros(arr.shape, np.uint64)
+        if arr.size:
+            check(lib().bmx_grank_batch(self.grp._h, self._h, rs._h, _ptr(arr), arr.size, _ptr(out)))
+        return int(out[0]) if np.isscalar(n) else out
+
+    rank = count_to
+
+    def select(self, rank, rs: "grs_index"):
+        """-> (found, pos); rank is 1-based (src/bm.h:5350)"""
+        arr = np.ascontiguousarray(np.atleast_1d(rank), np.uint64)
+        pos = np.zeros(arr.shape, np.uint64)
+        found = np.zeros(arr.shape, np.uint8)
+        if arr.size:
+            check(lib().bmx_gselect_batch(self.grp._h, self._h, rs._h, _ptr(arr), arr.size, _ptr(pos), _ptr(found)))
+        if np.isscalar(rank):
+            return bool(found[0]), int(pos[0])
+        return found.astype(bool), pos
 
     @staticmethod
     def _op2(op, a: "gbvector", b: "gbvector", opt_mode: int = opt_none) -> "gbvector":

@@ -103,6 +103,11 @@ def lib() -> C.CDLL:
         "bmx_gvec_count": (i32, [vp, vp, P(u64)]),
         "bmx_gvec_count_op2": (i32, [vp, i32, vp, vp, P(u64)]),
         "bmx_gvec_op2": (i32, [vp, i32, vp, vp, i32, P(vp)]),
+        "bmx_grs_build": (i32, [vp, vp, P(vp)]),
+        "bmx_grs_free": (i32, [vp, vp]),
+        "bmx_grs_count": (i32, [vp, P(u64)]),
+        "bmx_grank_batch": (i32, [vp, vp, vp, vp, C.c_size_t, vp]),
+        "bmx_gselect_batch": (i32, [vp, vp, vp, vp, C.c_size_t, vp, vp]),
         "bmx_gagg_or": (i32, [vp, P(vp), C.c_size_t, i32, P(vp)]),
         "bmx_gagg_and_sub": (i32, [vp, P(vp), C.c_size_t, P(vp), C.c_size_t, P(vp), P(i32)]),
         "bmx_gpipeline_create": (i32, [vp, P(vp), P(u32), P(vp), P(u32), C.c_size_t, P(vp)]),

@@ -36,6 +36,13 @@ struct bmx_gvec {
     std::vector<bmx_vec*> shard;          // shard[m] lives on g->ctx[m], blocks shard_range(nblocks, m)
 };
 
+struct bmx_grs {
+    bmx_group* g;
+    const bmx_gvec* v;
+    std::vector<bmx_rs*> rs;              // rs[m]: index of shard m (local block numbering)
+    std::vector<uint64_t> before;         // ones in the shards before m (n + 1 entries; before[n] = total)
+};
+
 struct bmx_gpipeline {
     bmx_group* g;
     uint32_t ngroups;
@@ -328,6 +335,108 @@ int bmx_gvec_op2(bmx_group* g, int op, const bmx_gvec* a, const bmx_gvec* b, int
     });
     if (rc) { std::string keep = bmx_last_error(); bmx_gvec_free(g, v); bmx_set_last_error(keep.c_str()); return rc; }
     *result = v;
+    return BMX_OK;
+}
+
+// ---- rank / select over a sharded vector (per-shard index, one exchange of the shard totals,
+// queries routed to the shard that owns the block) ----
+int bmx_grs_free(bmx_group* g, bmx_grs* rs)
+{
+    if (!rs) return BMX_OK;
+    ARGCHK(g && rs->g == g);
+    int rc = BMX_OK;
+    for (int m = 0; m < g->n; ++m) { int r = bmx_rs_free(g->ctx[(size_t)m], rs->rs[(size_t)m]); if (r && !rc) rc = r; }
+    delete rs;
+    return rc;
+}
+
+int bmx_grs_build(bmx_group* g, const bmx_gvec* v, bmx_grs** out)
+{
+    ARGCHK(g && v && out && v->g == g);
+    *out = nullptr;
+    bmx_grs* rs = new (std::nothrow) bmx_grs();
+    if (!rs) return BMX_ERR_BADALLOC;
+    rs->g = g; rs->v = v;
+    rs->rs.assign((size_t)g->n, nullptr);
+    int rc = for_each_member(g, [&](int m) -> int { return bmx_rs_build(g->ctx[(size_t)m], v->shard[(size_t)m], &rs->rs[(size_t)m]); });
+    rs->before.assign((size_t)g->n + 1, 0);
+    for (int m = 0; m < g->n && !rc; ++m) {                     // the exchange: n x 8 bytes, exclusive scan on the host
+        uint64_t c = 0;
+        rc = bmx_rs_count(rs->rs[(size_t)m], &c);
+        rs->before[(size_t)m + 1] = rs->before[(size_t)m] + c;
+    }
+    if (rc) { std::string keep = bmx_last_error(); bmx_grs_free(g, rs); bmx_set_last_error(keep.c_str()); return rc; }
+    *out = rs;
+    return BMX_OK;
+}
+
+int bmx_grs_count(const bmx_grs* rs, uint64_t* count)
+{
+    ARGCHK(rs && count);
+    *count = rs->before.back();
+    return BMX_OK;
+}
+
+// queries are split by owner on the host, every member answers its share (one batch call per member, in parallel),
+// answers are put back in query order
+int bmx_grank_batch(bmx_group* g, const bmx_gvec* v, const bmx_grs* rs, const uint64_t* n, size_t q, uint64_t* out)
+{
+    ARGCHK(g && v && rs && v->g == g && rs->g == g && rs->v == v && (q == 0 || (n && out)));
+    std::vector<uint32_t> lo((size_t)g->n + 1, 0);
+    for (int m = 0; m < g->n; ++m) { uint32_t a, b; shard_range(v->nblocks, m, g->n, &a, &b); lo[(size_t)m] = a; lo[(size_t)m + 1] = b; }
+    std::vector<std::vector<uint64_t>> qs((size_t)g->n), ans((size_t)g->n);
+    std::vector<std::vector<size_t>> at((size_t)g->n);
+    for (size_t i = 0; i < q; ++i) {
+        uint64_t nb = n[i] >> 16;
+        if (nb >= v->nblocks) { out[i] = rs->before.back(); continue; }            // past the end: the total (src/bm.h:3133)
+        size_t m = (size_t)(std::upper_bound(lo.begin(), lo.end(), (uint32_t)nb) - lo.begin()) - 1;
+        qs[m].push_back(n[i] - (uint64_t)lo[m] * BMX_BLOCK_BITS);
+        at[m].push_back(i);
+    }
+    int rc = for_each_member(g, [&](int m) -> int {
+        size_t k = qs[(size_t)m].size();
+        if (!k) return BMX_OK;
+        ans[(size_t)m].resize(k);
+        return bmx_rank_batch(g->ctx[(size_t)m], v->shard[(size_t)m], rs->rs[(size_t)m], qs[(size_t)m].data(), k, ans[(size_t)m].data());
+    });
+    if (rc) return rc;
+    for (int m = 0; m < g->n; ++m)
+        for (size_t k = 0; k < at[(size_t)m].size(); ++k) out[at[(size_t)m][k]] = rs->before[(size_t)m] + ans[(size_t)m][k];
+    return BMX_OK;
+}
+
+int bmx_gselect_batch(bmx_group* g, const bmx_gvec* v, const bmx_grs* rs, const uint64_t* rank, size_t q,
+                      uint64_t* pos, uint8_t* found)
+{
+    ARGCHK(g && v && rs && v->g == g && rs->g == g && rs->v == v && (q == 0 || (rank && pos && found)));
+    std::vector<uint32_t> lo((size_t)g->n, 0);
+    for (int m = 0; m < g->n; ++m) { uint32_t a, b; shard_range(v->nblocks, m, g->n, &a, &b); lo[(size_t)m] = a; }
+    std::vector<std::vector<uint64_t>> qs((size_t)g->n), ans((size_t)g->n);
+    std::vector<std::vector<uint8_t>> fnd((size_t)g->n);
+    std::vector<std::vector<size_t>> at((size_t)g->n);
+    const uint64_t total = rs->before.back();
+    for (size_t i = 0; i < q; ++i) {
+        pos[i] = 0; found[i] = 0;
+        if (!rank[i] || rank[i] > total) continue;                                  // rank is 1-based (src/bm.h:5350)
+        // the shard that holds the rank-th one: before[m] < rank <= before[m + 1]
+        size_t m = (size_t)(std::lower_bound(rs->before.begin(), rs->before.end(), rank[i]) - rs->before.begin()) - 1;
+        qs[m].push_back(rank[i] - rs->before[m]);
+        at[m].push_back(i);
+    }
+    int rc = for_each_member(g, [&](int m) -> int {
+        size_t k = qs[(size_t)m].size();
+        if (!k) return BMX_OK;
+        ans[(size_t)m].resize(k); fnd[(size_t)m].resize(k);
+        return bmx_select_batch(g->ctx[(size_t)m], v->shard[(size_t)m], rs->rs[(size_t)m], qs[(size_t)m].data(), k,
+                                ans[(size_t)m].data(), fnd[(size_t)m].data());
+    });
+    if (rc) return rc;
+    for (int m = 0; m < g->n; ++m)
+        for (size_t k = 0; k < at[(size_t)m].size(); ++k) {
+            size_t i = at[(size_t)m][k];
+            found[i] = fnd[(size_t)m][k];
+            pos[i] = found[i] ? ans[(size_t)m][k] + (uint64_t)lo[(size_t)m] * BMX_BLOCK_BITS : 0;
+        }
     return BMX_OK;
 }
 

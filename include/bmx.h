@@ -268,6 +268,7 @@ int bmx_select_batch_dev(bmx_ctx* ctx, const bmx_vec* v, const bmx_rs* rs,
 typedef struct bmx_group     bmx_group;
 typedef struct bmx_gvec      bmx_gvec;
 typedef struct bmx_gpipeline bmx_gpipeline;
+typedef struct bmx_grs       bmx_grs;
 #define BMX_GROUP_HOST_SUM 0
 #define BMX_GROUP_RCCL     1
 int bmx_group_create(const int* devices, int n, int flags, bmx_group** out);
@@ -299,6 +300,15 @@ int bmx_gvec_count(bmx_group* g, const bmx_gvec* a, uint64_t* count);
 int bmx_gvec_count_op2(bmx_group* g, int op, const bmx_gvec* a, const bmx_gvec* b, uint64_t* count);
 /* bvector::bit_and/or/xor/sub (3-operand), result sharded like the operands */
 int bmx_gvec_op2(bmx_group* g, int op, const bmx_gvec* a, const bmx_gvec* b, int opt_compress, bmx_gvec** result);
+/* build_rs_index / count_to / select over a sharded vector (src/bm.h:2531,3120,5350): every member indexes its own
+ * shard, the shard totals (n x 8 B) are scanned on the host, a query goes to the member that owns its block (rank)
+ * or holds the rank-th one (select).  The index refers to `v`: free it before the vector. */
+int bmx_grs_build(bmx_group* g, const bmx_gvec* v, bmx_grs** out);
+int bmx_grs_free(bmx_group* g, bmx_grs* rs);
+int bmx_grs_count(const bmx_grs* rs, uint64_t* count);
+int bmx_grank_batch(bmx_group* g, const bmx_gvec* v, const bmx_grs* rs, const uint64_t* n, size_t q, uint64_t* out);
+int bmx_gselect_batch(bmx_group* g, const bmx_gvec* v, const bmx_grs* rs, const uint64_t* rank, size_t q,
+                      uint64_t* pos, uint8_t* found);
 /* aggregator::combine_or / combine_and_sub over sharded vectors (src/bmaggregator.h:1101,1162) */
 int bmx_gagg_or(bmx_group* g, const bmx_gvec* const* src, size_t n, int opt_compress, bmx_gvec** result);
 int bmx_gagg_and_sub(bmx_group* g, const bmx_gvec* const* src_and, size_t n_and,

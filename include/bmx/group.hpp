@@ -38,6 +38,24 @@ private:
     bmx_group* h_ = nullptr;
 };
 
+class gbvector;
+
+/// bm::rs_index twin of a sharded vector: one index per shard + the ones before each shard (bmx_grs_*)
+class grs_index {
+public:
+    grs_index() = default;
+    ~grs_index() { reset(); }
+    grs_index(const grs_index&) = delete;
+    grs_index& operator=(const grs_index&) = delete;
+    size_type count() const { uint64_t c = 0; if (h_) check(bmx_grs_count(h_, &c)); return c; }
+    bmx_grs* handle() const noexcept { return h_; }
+private:
+    friend class gbvector;
+    void reset() { if (h_) { bmx_grs_free(grp_, h_); h_ = nullptr; } }
+    bmx_group* grp_ = nullptr;
+    bmx_grs* h_ = nullptr;
+};
+
 /// bm::bvector<> twin sharded over the members of a device_group
 class gbvector {
 public:
@@ -87,6 +105,39 @@ public:
         if (!h_ || !bv.h_) return count() == 0 && bv.count() == 0;
         uint64_t c = 0; check(bmx_gvec_count_op2(grp_->handle(), BMX_XOR, h_, bv.h_, &c)); return c == 0;
     }
+    // ---- rank / select (same method set as bmx::bvector; queries are routed to the member that owns the block) ----
+    void build_rs_index(grs_index* rs) const
+    {
+        rs->reset(); rs->grp_ = grp_->handle(); require();
+        check(bmx_grs_build(grp_->handle(), h_, &rs->h_));
+    }
+    size_type count_to(size_type n, const grs_index& rs) const
+    { uint64_t out = 0; require(); check(bmx_grank_batch(grp_->handle(), h_, rs.h_, &n, 1, &out)); return out; }
+    size_type rank(size_type n, const grs_index& rs) const { return count_to(n, rs); }
+    bool select(size_type rank_in, size_type& pos, const grs_index& rs) const
+    {
+        uint64_t p = 0; uint8_t f = 0; require();
+        check(bmx_gselect_batch(grp_->handle(), h_, rs.h_, &rank_in, 1, &p, &f));
+        if (f) pos = p;
+        return f != 0;
+    }
+    size_type count_range(size_type left, size_type right, const grs_index& rs) const        // src/bm.h:3548
+    {
+        if (left > right) std::swap(left, right);
+        size_type q[2] = {right, left ? left - 1 : 0}, out[2];
+        count_to(q, 2, out, rs);
+        return out[0] - (left ? out[1] : 0);
+    }
+    bool find_rank(size_type rank_in, size_type from, size_type& pos, const grs_index& rs) const   // src/bm.h:5279
+    {
+        if (!rank_in) return false;
+        size_type before = from ? count_to(from - 1, rs) : 0;
+        return select(rank_in + before, pos, rs);
+    }
+    void count_to(const size_type* n, size_t q, size_type* out, const grs_index& rs) const
+    { require(); check(bmx_grank_batch(grp_->handle(), h_, rs.h_, n, q, out)); }
+    void select(const size_type* rank_in, size_t q, size_type* pos, uint8_t* found, const grs_index& rs) const
+    { require(); check(bmx_gselect_batch(grp_->handle(), h_, rs.h_, rank_in, q, pos, found)); }
 private:
     void require() const { if (!h_) throw error(BMX_ERR_BADARG, "BMX-02: vector holds no device data"); }
     gbvector& op3(int op, const gbvector& a, const gbvector& b, optmode opt)

@@ -326,6 +326,17 @@ int main()
         bm::aggregator<bvect> ra2; ra2.combine_and_sub(rp); gagg.combine_and_sub(gp);
         for (unsigned q = 0; q < 4; ++q) REQUIRE(rp.get_bv_count_vector()[q] == gp.get_bv_count_vector()[q]);
         REQUIRE(gp.last_ms().size() == 3);
+        // rank / select over the sharded vector against the reference rs_index on the host
+        bvect::rs_index_type rrs; hv[3].build_rs_index(&rrs);
+        bmx::grs_index grs; gg[3].build_rs_index(&grs);
+        REQUIRE(grs.count() == rrs.count());
+        for (uint64_t n = 0; n < nbits; n += 6007) REQUIRE(gg[3].count_to(n, grs) == hv[3].count_to(bvect::size_type(n), rrs));
+        for (uint64_t r = 1; r <= grs.count(); r += 1 + grs.count() / 97) {
+            uint64_t p = 0; bvect::size_type q = 0;
+            REQUIRE(gg[3].select(r, p, grs) && hv[3].select(bvect::size_type(r), q, rrs) && p == q);
+        }
+        { uint64_t p = 0; REQUIRE(!gg[3].select(grs.count() + 1, p, grs) && !gg[3].select(0, p, grs)); }
+        REQUIRE(gg[3].count_range(70000, 300000, grs) == hv[3].count_range(70000, 300000, rrs));
     }
     // rank / select vs bvector<>::count_to / select with the reference rs_index
     {

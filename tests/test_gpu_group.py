@@ -66,6 +66,24 @@ def test_group_matches_single_context_and_oracle(ctx, port, members):
     assert (got == exp).all(), (got, exp)
     ms = pipe.last_ms()
     assert len(ms) == members and all(x >= 0 for x in ms)
+    # rank / select: per-shard index + the ones before each shard; queries routed to the owner
+    rng = np.random.default_rng(members)
+    for g, s, p in zip(gv, sv, pv):
+        grs, rs, prs = g.build_rs_index(), s.build_rs_index(), port.rs_build(p)
+        c = p.count()
+        assert grs.count() == rs.count() == c
+        borders = np.array([b * 65536 + d for b in (0, 12, 13, 25, 26, 37) for d in (-1, 0, 1, 65535) if b * 65536 + d >= 0], np.uint64)
+        q = np.concatenate([rng.integers(0, nbits + 70000, size=3000).astype(np.uint64), borders])   # incl. past the end
+        assert (g.rank(q, grs) == s.rank(q, rs)).all()
+        assert (g.rank(q, grs) == prs.rank(q)).all()
+        r = np.concatenate([rng.integers(0, c + 3, size=3000).astype(np.uint64), np.array([0, 1, max(c, 1), c + 1], np.uint64)])
+        gf, gp_ = g.select(r, grs)
+        sf, sp = s.select(r, rs)
+        ppos, pf = prs.select(r)
+        assert (gf == sf).all() and (gp_[gf] == sp[sf]).all()
+        assert (gf == pf).all() and (gp_[gf] == ppos[pf]).all()
+        if c:
+            assert g.select(1, grs) == s.select(1, rs) and g.rank(nbits - 1, grs) == c
     grp.close()
 
 
