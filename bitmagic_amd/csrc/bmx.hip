@@ -268,7 +268,7 @@ int bmx_ctx_create(int device, void* stream, bmx_ctx** out)
     // an invalid value is ignored (the default stays)
     static const char* const env_keys[][2] = {
         {"BMX_PIPE_UNROLL", "pipe_unroll"}, {"BMX_PIPE_ROWS", "pipe_rows"}, {"BMX_PIPE_NT", "pipe_nt"},
-        {"BMX_PIPE_WG", "pipe_wg"}, {"BMX_PIPE_WINDOW", "pipe_window"}, {"BMX_PIPE_SPLIT", "pipe_split"}, {"BMX_OR_TILE", "or_tile"}, {"BMX_OR_WINDOW", "or_window"}, {"BMX_DIRECT_COLS", "direct_cols"}, {"BMX_XCD_SWIZZLE", "xcd_swizzle"}};
+        {"BMX_PIPE_WG", "pipe_wg"}, {"BMX_PIPE_WINDOW", "pipe_window"}, {"BMX_PIPE_SPLIT", "pipe_split"}, {"BMX_OR_TILE", "or_tile"}, {"BMX_OR_WINDOW", "or_window"}, {"BMX_DIRECT_COLS", "direct_cols"}, {"BMX_FF_WINDOW", "ff_window"}, {"BMX_XCD_SWIZZLE", "xcd_swizzle"}};
     for (auto& kv : env_keys)
         if (const char* e = getenv(kv[0])) (void)bmx_ctx_set_tuning(ctx, kv[1], atoi(e));
     g_last_error.clear();
@@ -315,6 +315,7 @@ int bmx_ctx_set_tuning(bmx_ctx* ctx, const char* key, int value)
     else if (k == "pipe_window") { ARGCHK(value >= -1); ctx->pipe_window = value; }
     else if (k == "or_tile") { ARGCHK(value >= 0 && value <= 3); ctx->or_tile = value; }
     else if (k == "direct_cols") { ARGCHK(value >= 0); ctx->direct_cols = value; }
+    else if (k == "ff_window") { ARGCHK(value >= -1); ctx->ff_window = value; }
     else if (k == "or_window") { ARGCHK(value >= -9); ctx->or_window = value; }
     else if (k == "pipe_wg") { ARGCHK(value == 0 || (value >= 64 && value <= 1024 && value % 64 == 0)); ctx->pipe_wg = value; }
     else if (k == "xcd_swizzle") ctx->xcd_swz = value != 0;
@@ -1412,13 +1413,32 @@ static int find_first_impl(bmx_ctx* ctx, const bmx_vec* const* src_and, size_t n
         col_to = (u32)std::min<uint64_t>(nbt + 1u, ncols_all);
         if (nbf == nbt) { has_mask = 1; mf = (u32)(from & 65535u); mt = (u32)(to & 65535u); }
     }
-    // few columns to visit, many operands: one launch.  A workgroup per column is dispatched in column order, so later
-    // columns see an earlier hit and leave at once (1526 columns x 256 operands: 0.22 ms against 0.58 ms): wider limit here
-    if (use_direct(ctx, col_to > col_from ? col_to - col_from : 0u, n_and + n_sub, 8u)) {
+    // The reference stops at the first column that holds a hit (src/bmaggregator.h:1470-1512).  Here the columns are
+    // visited in ASCENDING WINDOWS that grow fourfold, all enqueued at once on the stream: every workgroup / wave first
+    // looks at the best index found so far and leaves when its column lies behind it, so after a hit the remaining
+    // windows cost a launch each and nothing else -- no host round trip between windows.  (One big launch cannot do
+    // that: thousands of columns are resident before the first one finishes.)
+    const u32 ncv = col_to > col_from ? col_to - col_from : 0u;
+    const bool direct = use_direct(ctx, ncv ? 1u : 0u, n_and + n_sub);       // operand count in range; any number of columns
+    auto windows = [&](u32 first, auto&& launch) -> int {
+        if (ctx->ff_window < 0) first = ncv;                                 // knob: one launch
+        else if (ctx->ff_window > 0) first = (u32)ctx->ff_window;
+        u32 c = col_from, w = std::max(first, 1u);
+        while (c < col_to) {
+            u32 e = (col_to - c <= w + w / 2u) ? col_to : c + w;             // no tiny last window
+            int r = launch(c, e); if (r) return r;
+            c = e; w *= 4u;
+        }
+        return BMX_OK;
+    };
+    if (direct) {
+        // many operands: a workgroup of 8 waves per column straight from the descriptor tables (k_direct); 64 columns first
+        // (a hit in the first blocks is answered after ~1/8 of what two workgroups per CU would read)
         void* d_tab = nullptr;
         if ((rc = direct_table(ctx, src_and, n_and, src_sub, n_sub, &d_tab))) return rc;
         hipError_t e = hipMemsetAsync(ctx->d_small, 0xFF, 8, ctx->stream);
-        if (e == hipSuccess) rc = direct_launch(DIRECT_FIND_FIRST, ctx, d_tab, n_and, n_sub, col_from, col_to, 0, nullptr, nullptr, has_mask, mf, mt);
+        if (e == hipSuccess)
+            rc = windows(64u, [&](u32 c0, u32 c1) { return direct_launch(DIRECT_FIND_FIRST, ctx, d_tab, n_and, n_sub, c0, c1, 0, nullptr, nullptr, has_mask, mf, mt); });
         if (e == hipSuccess && !rc) e = hipMemcpyAsync(ctx->h_small, ctx->d_small, 8, hipMemcpyDeviceToHost, ctx->stream);
         hipError_t e2 = hipStreamSynchronize(ctx->stream);
         dfree(ctx, d_tab);
@@ -1430,16 +1450,20 @@ static int find_first_impl(bmx_ctx* ctx, const bmx_vec* const* src_and, size_t n
     bmx_pipeline* p = nullptr;
     if ((rc = bmx_pipeline_create(ctx, src_and, &an, src_sub, &sn, 1, &p))) return rc;
     hipError_t e = hipMemsetAsync(ctx->d_small, 0xFF, 8, ctx->stream);
-    if (e == hipSuccess && col_to > col_from) {
+    if (e == hipSuccess) {
         size_t lds = p->has_gap ? 4 * 2048 * 4 : 0;
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_find_first_and_sub<2>), dim3((col_to - col_from + 3) / 4), dim3(256), lds, ctx->stream,
-                           p->d_dmat, p->d_meta + 1, p->d_meta + 2, p->col_stride, col_from, col_to, has_mask, mf, mt, ctx->d_small);
-        e = hipGetLastError();
+        rc = windows(512u, [&](u32 c0, u32 c1) {                             // a wave per column: first window = 2 waves per CU
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_find_first_and_sub<2>), dim3((c1 - c0 + 3) / 4), dim3(256), lds, ctx->stream,
+                               p->d_dmat, p->d_meta + 1, p->d_meta + 2, p->col_stride, c0, c1, has_mask, mf, mt, ctx->d_small);
+            hipError_t le = hipGetLastError();
+            return le == hipSuccess ? BMX_OK : fail_hip(le, "k_find_first_and_sub", __LINE__);
+        });
     }
-    if (e == hipSuccess) e = hipMemcpyAsync(ctx->h_small, ctx->d_small, 8, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess && !rc) e = hipMemcpyAsync(ctx->h_small, ctx->d_small, 8, hipMemcpyDeviceToHost, ctx->stream);
+    hipError_t e2 = hipStreamSynchronize(ctx->stream);
     bmx_pipeline_destroy(ctx, p);
-    if (e != hipSuccess) return fail_hip(e, "bmx_find_first_and_sub", __LINE__);
+    if (rc) return rc;
+    if (e != hipSuccess || e2 != hipSuccess) return fail_hip(e != hipSuccess ? e : e2, "bmx_find_first_and_sub", __LINE__);
     if (ctx->h_small[0] != ~0ull) { *found = 1; *idx = ctx->h_small[0]; }
     return BMX_OK;
 }

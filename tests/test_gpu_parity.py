@@ -570,6 +570,50 @@ def test_small_collection_direct_path(ctx, port, nvec, ncols):
         agg.reset_range_hint()
 
 
+@pytest.mark.parametrize("nops", [3, 30])
+def test_find_first_launch_windows(ctx, port, nops):
+    """find_first_and_sub visits the block columns in ascending launch windows that grow fourfold (every wave looks at
+    the best hit so far and leaves when its column lies behind it): the answer never depends on the window size
+    (ff_window knob: -1 = one launch, N = first window of N columns), on where the first hit lies, or on the kernel
+    (wave-per-column for short operand lists, k_direct for long ones); with and without a range hint"""
+    ncols = 45
+    nbits = ncols * 65536 - 1000
+    rng = np.random.default_rng(nops)
+    agg = bm.aggregator(ctx)
+    try:
+        for first_col in (0, 1, 6, 7, 22, 44, None):
+            # the AND survives only from `first_col` on: a shared component restricted to the columns behind it
+            common = port.gen_words(808, 0xFFFFFFFF, 300, nbits)
+            if first_col is None: common[:] = 0
+            else: common[:first_col * 2048] = 0
+            words = []
+            for v in range(nops):
+                w = port.gen_words(808, v, 2000 if v % 3 else 40000, nbits) | common       # GAP and bit operands
+                if v == 1: w[:(ncols if first_col is None else first_col) * 2048] = 0          # nothing survives before first_col
+                words.append(w)
+            subw = port.gen_words(809, 1, 500, nbits)
+            gv = [bm.bit_import_u32(ctx, w, True) for w in words]
+            gs = bm.bit_import_u32(ctx, subw, True)
+            acc = words[0].copy()
+            for w in words[1:]: acc &= w
+            acc &= ~subw
+            bits = np.flatnonzero(np.unpackbits(acc.view(np.uint8), bitorder="little"))
+            for win in (0, -1, 1, 2, 5, 64):
+                ctx.set_tuning("ff_window", win)
+                f, idx = agg.find_first_and_sub(gv, [gs])
+                assert f == (bits.size > 0) and (not f or idx == bits[0]), (first_col, win, f, idx, bits[:1])
+                if bits.size > 10:
+                    frm, to = int(bits[5]) + 1, nbits - 1                                   # hint starting behind the 6th hit
+                    one = agg.set_range_hint(frm, to)                                      # one-block hints are bit-exact
+                    cand = bits[bits >= frm] if one else bits[bits >= (frm >> 16) << 16]
+                    f, idx = agg.find_first_and_sub(gv, [gs])
+                    assert f and idx == cand[0], (first_col, win)
+                    agg.reset_range_hint()
+    finally:
+        ctx.set_tuning("ff_window", 0)
+        agg.reset_range_hint()
+
+
 @pytest.mark.parametrize("common_bits,own_dq,nvec", [(1, 30, 40), (40, 100, 70), (400, 100, 90), (520, 40, 36),
                                                      (700, 200, 50)])
 def test_sparse_state_of_gap_lists(ctx, port, common_bits, own_dq, nvec):

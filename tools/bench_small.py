@@ -32,3 +32,19 @@ for nbits in (1_000_000, 16_000_000, 100_000_000):
     out["bit_and_ms"] = t(lambda: bm.bvector.bit_and(vecs[0], vecs[1]))
     out["count_and_ms"] = t(lambda: bm.count_and(vecs[0], vecs[1]))
     print(json.dumps(out))
+# find_first_and_sub at full size: the first hit decides the cost (ascending launch windows), 1e9-bit vectors
+for nv, label in ((256, "256 operands"), (4, "4 operands")):
+    nbits = 1_000_000_000
+    vecs = [bm.bvector.generate(ctx, 0xB17A61C, v, 6554, nbits, with_common=True) for v in range(nv)]
+    agg = bm.aggregator(ctx)
+    out = {"find_first_1e9": label}
+    out["hit_in_block_0_ms"] = t(lambda: agg.find_first_and_sub(vecs, []), reps=10, warm=2)
+    agg.set_range_hint(7000 * 65536, nbits - 1)
+    out["hit_in_block_7000_of_15259_ms"] = t(lambda: agg.find_first_and_sub(vecs, []), reps=10, warm=2)
+    agg.reset_range_hint()
+    ctx.set_tuning("ff_window", -1)
+    out["one_launch_hit_in_block_0_ms"] = t(lambda: agg.find_first_and_sub(vecs, []), reps=10, warm=2)
+    ctx.set_tuning("ff_window", 0)
+    out["combine_and_ms"] = t(lambda: agg.combine_and_sub(vecs, []), reps=5, warm=1)
+    print(json.dumps(out))
+    del vecs
