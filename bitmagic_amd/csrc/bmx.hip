@@ -1138,9 +1138,16 @@ int bmx_count_op2(bmx_ctx* ctx, int op, const bmx_vec* a, const bmx_vec* b, uint
 }
 
 // ---- small collections: aggregation in one launch straight from the descriptor tables (k_direct, bmx_kernels2.h) ----
-static bool use_direct(const bmx_ctx* ctx, uint32_t ncols, size_t n_ops, uint32_t mult = 1)
+// waves per column of the one-launch path, 0 = take the row-table pipeline instead.  Long operand lists (24..1024) over few
+// columns: 8 waves share the list.  Short lists (< 24 operands): one wave per column -- what the direct kernel saves
+// there is the pipeline object and its sort launch (~0.04 ms of host calls per aggregation).
+static int use_direct(const bmx_ctx* ctx, uint32_t ncols, size_t n_ops)
 {
-    return ctx->pipe_split != 0 && ncols && ncols <= (uint64_t)ctx->direct_cols * mult && n_ops >= 24u && n_ops <= DIRECT_MAX_OPS;
+    if (ctx->pipe_split == 0 || ctx->direct_cols <= 0 || !ncols || !n_ops) return 0;
+    // (measured, 1e9-bit operands: 2 operands 0.112 against 0.149 ms, 4: 0.163 / 0.170, 16: 0.449 / 0.421 -- beyond
+    // ~0.5 GB of operand blocks the pipelined row kernel streams faster than the saved host calls are worth)
+    if (n_ops < 24u) return (uint64_t)ncols * n_ops <= 65536u ? 1 : 0;
+    return (ncols <= (uint32_t)ctx->direct_cols && n_ops <= DIRECT_MAX_OPS) ? SPLIT_WAVES : 0;
 }
 
 // operand table on the device: n descriptor-table pointers, then n block counts (u32); one staged copy
@@ -1165,12 +1172,13 @@ static int direct_launch(int mode, bmx_ctx* ctx, const void* d_tab, size_t n_and
 {
     if (col_to <= col_from) return BMX_OK;
     size_t n = n_and + n_sub;
-    size_t lds = (size_t)SPLIT_WAVES * 8192 + 2 * (n_and + n_sub) * 8;    // partials + bit / GAP lists of both groups
-    auto fn = mode == DIRECT_AND_SUB ? k_direct<SPLIT_WAVES, DIRECT_AND_SUB> :
-              mode == DIRECT_OR ? k_direct<SPLIT_WAVES, DIRECT_OR> : k_direct<SPLIT_WAVES, DIRECT_FIND_FIRST>;
+    const int split = n < 24u ? 1 : SPLIT_WAVES;
+    size_t lds = (size_t)split * 8192 + 2 * n * 8;                          // partials + bit / GAP lists of both groups
+    auto fn = split == 1 ? (mode == DIRECT_AND_SUB ? k_direct<1, DIRECT_AND_SUB> : mode == DIRECT_OR ? k_direct<1, DIRECT_OR> : k_direct<1, DIRECT_FIND_FIRST>)
+                         : (mode == DIRECT_AND_SUB ? k_direct<SPLIT_WAVES, DIRECT_AND_SUB> : mode == DIRECT_OR ? k_direct<SPLIT_WAVES, DIRECT_OR> : k_direct<SPLIT_WAVES, DIRECT_FIND_FIRST>);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(fn, dim3(col_to - col_from), dim3(SPLIT_WAVES * 64), lds, ctx->stream,
+        hipLaunchKernelGGL(fn, dim3(col_to - col_from), dim3(split * 64), lds, ctx->stream,
                            (const u64* const*)d_tab, (const u32*)((const u64*)d_tab + n), (u32)n_and, (u32)n_sub, col_from, col_to,
                            opt_compress, v ? v->d_bits : nullptr, v ? v->d_desc : nullptr, st, has_mask, mf, mt, ctx->d_small);
         e = hipGetLastError();
@@ -1419,7 +1427,8 @@ static int find_first_impl(bmx_ctx* ctx, const bmx_vec* const* src_and, size_t n
     // windows cost a launch each and nothing else -- no host round trip between windows.  (One big launch cannot do
     // that: thousands of columns are resident before the first one finishes.)
     const u32 ncv = col_to > col_from ? col_to - col_from : 0u;
-    const bool direct = use_direct(ctx, ncv ? 1u : 0u, n_and + n_sub);       // operand count in range; any number of columns
+    // long lists: any number of columns (windows); short lists: the size rule of use_direct
+    const bool direct = use_direct(ctx, (n_and + n_sub < 24u) ? ncv : (ncv ? 1u : 0u), n_and + n_sub) != 0;
     auto windows = [&](u32 first, auto&& launch) -> int {
         if (ctx->ff_window < 0) first = ncv;                                 // knob: one launch
         else if (ctx->ff_window > 0) first = (u32)ctx->ff_window;
@@ -1438,7 +1447,7 @@ static int find_first_impl(bmx_ctx* ctx, const bmx_vec* const* src_and, size_t n
         if ((rc = direct_table(ctx, src_and, n_and, src_sub, n_sub, &d_tab))) return rc;
         hipError_t e = hipMemsetAsync(ctx->d_small, 0xFF, 8, ctx->stream);
         if (e == hipSuccess)
-            rc = windows(64u, [&](u32 c0, u32 c1) { return direct_launch(DIRECT_FIND_FIRST, ctx, d_tab, n_and, n_sub, c0, c1, 0, nullptr, nullptr, has_mask, mf, mt); });
+            rc = windows(n_and + n_sub < 24u ? 512u : 64u, [&](u32 c0, u32 c1) { return direct_launch(DIRECT_FIND_FIRST, ctx, d_tab, n_and, n_sub, c0, c1, 0, nullptr, nullptr, has_mask, mf, mt); });
         if (e == hipSuccess && !rc) e = hipMemcpyAsync(ctx->h_small, ctx->d_small, 8, hipMemcpyDeviceToHost, ctx->stream);
         hipError_t e2 = hipStreamSynchronize(ctx->stream);
         dfree(ctx, d_tab);

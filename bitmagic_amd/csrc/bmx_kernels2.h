@@ -753,19 +753,25 @@ void k_direct(const u64* const* __restrict__ descs, const u32* __restrict__ nblk
     Blk acc;
     blk_fill(acc, MODE == DIRECT_OR ? 0u : ~0u);
     {
+        // blocks in flight per wave: a lone wave per column (short lists, any number of columns) streams 4 at a time
+        constexpr u32 DEPTH = SPLIT == 1 ? 4u : 2u;
         u32 a0 = (u32)(((u64)nba * wave) / SPLIT), a1 = (u32)(((u64)nba * (wave + 1u)) / SPLIT);
-        for (u32 k = a0; k < a1; k += 2u) {
-            u64 p0 = uniform64(bitA[k]), p1 = uniform64(bitA[k + 1u < a1 ? k + 1u : k]);
-            Blk x, y; blk_load(x, as_gc4(p0), lane); blk_load(y, as_gc4(p1), lane);
-            if (MODE == DIRECT_OR) { blk_or(acc, x); blk_or(acc, y); if (blk_is_ones(acc)) break; }      // saturated: the rest cannot change it
-            else { blk_and(acc, x); blk_and(acc, y); if (blk_is_zero(acc)) break; }                       // digest went to zero (:2081)
+        for (u32 k = a0; k < a1; k += DEPTH) {
+            Blk x[DEPTH];
+#pragma unroll
+            for (u32 j = 0; j < DEPTH; ++j) blk_load(x[j], as_gc4(uniform64(bitA[k + j < a1 ? k + j : a1 - 1u])), lane);   // (a repeated operand changes nothing)
+#pragma unroll
+            for (u32 j = 0; j < DEPTH; ++j) { if (MODE == DIRECT_OR) blk_or(acc, x[j]); else blk_and(acc, x[j]); }
+            if (MODE == DIRECT_OR ? blk_is_ones(acc) : blk_is_zero(acc)) break;   // saturated / digest went to zero (:1951, :2081)
         }
         if (MODE != DIRECT_OR) {
             u32 s0 = (u32)(((u64)nbs * wave) / SPLIT), s1 = (u32)(((u64)nbs * (wave + 1u)) / SPLIT);
-            for (u32 k = s0; k < s1; k += 2u) {
-                u64 p0 = uniform64(bitS[k]), p1 = uniform64(bitS[k + 1u < s1 ? k + 1u : k]);
-                Blk x, y; blk_load(x, as_gc4(p0), lane); blk_load(y, as_gc4(p1), lane);
-                blk_andn(acc, x); blk_andn(acc, y);
+            for (u32 k = s0; k < s1; k += DEPTH) {
+                Blk x[DEPTH];
+#pragma unroll
+                for (u32 j = 0; j < DEPTH; ++j) blk_load(x[j], as_gc4(uniform64(bitS[k + j < s1 ? k + j : s1 - 1u])), lane);
+#pragma unroll
+                for (u32 j = 0; j < DEPTH; ++j) blk_andn(acc, x[j]);
                 if (blk_is_zero(acc)) break;
             }
         }

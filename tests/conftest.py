@@ -33,3 +33,12 @@ def ctx():
     c = bm.context(0)
     yield c
     c.close()
+
+
+@pytest.fixture(params=["direct", "rows"])
+def agg_path(request, ctx):
+    """both implementations of a single aggregation call: the one-launch kernel straight from the descriptor tables
+    (k_direct, the default for short operand lists and small collections) and the row-table pipeline kernels"""
+    ctx.set_tuning("direct_cols", 384 if request.param == "direct" else 0)
+    yield request.param
+    ctx.set_tuning("direct_cols", 384)

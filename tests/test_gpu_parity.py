@@ -53,7 +53,7 @@ def test_generator_matches_oracle(ctx, port, golden):
 
 
 @pytest.mark.parametrize("case", list(CASES))
-def test_golden_case(ctx, port, golden, case):
+def test_golden_case(ctx, port, golden, case, agg_path):
     g = golden["cases"][case]
     words, nbits = make_inputs(port, case)
     assert [sha(w) for w in words] == g["input_sha"]
@@ -182,7 +182,7 @@ def test_golden_case(ctx, port, golden, case):
 
 @pytest.mark.parametrize("dq,cdq,nvec", [(40, None, 9), (655, 655, 12), (6554, 6554, 40), (6554, None, 17),
                                          (32768, 20000, 33), (65500, None, 8)])
-def test_differential_vs_oracle(ctx, port, dq, cdq, nvec):
+def test_differential_vs_oracle(ctx, port, dq, cdq, nvec, agg_path):
     """seeded random vectors incl. NULL/FULL blocks and ragged lengths; aggregator ladders over operand
     prefixes / suffixes as in StressTestAggregatorAND/OR (tests/stress/t.cpp:10811-11164)"""
     rng = np.random.default_rng(dq * 131 + nvec)
@@ -247,7 +247,7 @@ def test_differential_vs_oracle(ctx, port, dq, cdq, nvec):
         assert (found == pfound).all() and (pos[found] == ppos[pfound]).all()
 
 
-def test_kats_from_reference_tests(ctx, port):
+def test_kats_from_reference_tests(ctx, port, agg_path):
     """AggregatorTest known answers (tests/stress/t.cpp:10100-10152, 10318-10373) through the HIP path"""
     def mk(bits, n=3 * 65536, ranges=()):
         p = port.new(n)
@@ -466,7 +466,7 @@ def test_launch_shape_knobs_do_not_change_results(ctx, port, tail_bits):
 
 
 @pytest.mark.parametrize("dq,nvec", [(13, 200), (60, 96), (65500, 70), (300, 33)])
-def test_many_gap_operands(ctx, port, dq, nvec):
+def test_many_gap_operands(ctx, port, dq, nvec, agg_path):
     """BASELINE configs[4] shape at test scale: combine_or / combine_and_sub / counts pipeline over many GAP
     operands per block column (lane-per-operand run scatter, >= 32 operands) incl. dense GAP (long 1-runs)"""
     nbits = 5 * 65536 + 4000
@@ -571,7 +571,7 @@ def test_small_collection_direct_path(ctx, port, nvec, ncols):
 
 
 @pytest.mark.parametrize("nops", [3, 30])
-def test_find_first_launch_windows(ctx, port, nops):
+def test_find_first_launch_windows(ctx, port, nops, agg_path):
     """find_first_and_sub visits the block columns in ascending launch windows that grow fourfold (every wave looks at
     the best hit so far and leaves when its column lies behind it): the answer never depends on the window size
     (ff_window knob: -1 = one launch, N = first window of N columns), on where the first hit lies, or on the kernel
@@ -616,7 +616,7 @@ def test_find_first_launch_windows(ctx, port, nops):
 
 @pytest.mark.parametrize("common_bits,own_dq,nvec", [(1, 30, 40), (40, 100, 70), (400, 100, 90), (520, 40, 36),
                                                      (700, 200, 50)])
-def test_sparse_state_of_gap_lists(ctx, port, common_bits, own_dq, nvec):
+def test_sparse_state_of_gap_lists(ctx, port, common_bits, own_dq, nvec, agg_path):
     """AND / SUB lists of GAP operands whose intersection SURVIVES (a shared component): the accumulator turns
     into a candidate list (<= 1024 bits) after the first operands and every further operand is a membership
     test (bmx_device.h gap_apply_sparse) -- entry at list start, after the wave-mode head, after a lane-mode
@@ -994,7 +994,7 @@ def test_full_size_shift_right_and_properties(ctx, port):
         assert (got == exp).all(), nb0
 
 
-def test_range_hint(ctx, port):
+def test_range_hint(ctx, port, agg_path):
     """aggregator::set_range_hint (src/bmaggregator.h:481,974): find_first_and_sub visits the block columns of the
     hint only, a one-block hint is also bit-masked (:1470-1512, range_gap_blk_ :980-988); combine_and_sub(pipe)
     honours it when the pipeline options enable search masks (:1312-1346).  Expected values are derived from the

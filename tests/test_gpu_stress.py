@@ -58,7 +58,7 @@ def _random_vector(rng, port, ctx, nblocks, optimize):
 
 
 @pytest.mark.parametrize("seed", range(6))
-def test_random_block_tables(ctx, port, seed):
+def test_random_block_tables(ctx, port, seed, agg_path):
     rng = np.random.default_rng(1000 + seed)
     nvec = int(rng.integers(3, 14))
     vecs = [_random_vector(rng, port, ctx, int(rng.integers(1, 9)), bool(rng.integers(0, 2))) for _ in range(nvec)]

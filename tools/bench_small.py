@@ -48,3 +48,16 @@ for nv, label in ((256, "256 operands"), (4, "4 operands")):
     out["combine_and_ms"] = t(lambda: agg.combine_and_sub(vecs, []), reps=5, warm=1)
     print(json.dumps(out))
     del vecs
+# short operand lists (one wave per column straight from the descriptor tables) against the row-table pipeline
+for nbits in (1_000_000, 1_000_000_000):
+    for nv in (2, 4, 16):
+        vecs = [bm.bvector.generate(ctx, 0xB17A61C, v, 6554, nbits, with_common=True) for v in range(nv)]
+        agg = bm.aggregator(ctx)
+        out = {"short_lists": nv, "nbits": nbits}
+        for name, dc in (("direct", 384), ("rows", 0)):
+            ctx.set_tuning("direct_cols", dc)
+            out["combine_and_%s_ms" % name] = t(lambda: agg.combine_and_sub(vecs, []), reps=10, warm=2)
+            out["combine_or_%s_ms" % name] = t(lambda: agg.combine_or(vecs), reps=10, warm=2)
+        ctx.set_tuning("direct_cols", 384)
+        print(json.dumps(out))
+        del vecs

@@ -9,7 +9,7 @@ import test_gpu_stress as S, test_gpu_parity as P
 ctx = bm.context(0); port = oracle.port()
 bad = 0
 for seed in range(60, 1500):
-    try: S.test_random_block_tables(ctx, port, seed)
+    try: S.test_random_block_tables(ctx, port, seed, "direct")
     except AssertionError as e: bad += 1; print("FAIL seed", seed, str(e)[:200])
 for args in [(2, 50, 45), (17, 80, 64), (90, 60, 33), (333, 150, 70), (600, 20, 40), (250, 300, 37)]:
     try: P.test_sparse_state_of_gap_lists(ctx, port, *args)
