@@ -87,6 +87,31 @@ def test_group_matches_single_context_and_oracle(ctx, port, members):
     grp.close()
 
 
+def test_group_with_more_members_than_blocks(ctx, port):
+    """8 members, 3 blocks: five shards are empty -- counts, pairwise ops, aggregation, rank / select still add up"""
+    nbits = 3 * 65536 - 11
+    words, pv = _vectors(port, 4, nbits, [6554, 300, 30000])
+    grp = bm.group([0] * 8)
+    gv = [bm.gbvector.from_block_table(grp, nbits, *p.flatten()) for p in pv]
+    for g, p in zip(gv, pv):
+        assert g.count() == p.count()
+    assert bm.gbvector.count_op2(bm.AND, gv[0], gv[2]) == port.count_op2(bm.AND, pv[0], pv[2])
+    t = bm.gbvector.bit_or(gv[0], gv[1])
+    assert t.count() == port.op2(bm.OR, pv[0], pv[1]).count()
+    agg = bm.gaggregator(grp)
+    r, any_ = agg.combine_and_sub([gv[0], gv[2]], [gv[1]])
+    assert r.count() == port.agg_and_sub([pv[0], pv[2]], [pv[1]]).count()
+    grs, prs = gv[2].build_rs_index(), port.rs_build(pv[2])
+    q = np.arange(0, nbits + 70000, 997, dtype=np.uint64)
+    assert (gv[2].rank(q, grs) == prs.rank(q)).all()
+    c = pv[2].count()
+    r = np.arange(0, c + 2, max(1, c // 500), dtype=np.uint64)
+    gf, gp = gv[2].select(r, grs)
+    ppos, pf = prs.select(r)
+    assert (gf == pf).all() and (gp[gf] == ppos[pf]).all()
+    grp.close()
+
+
 def test_group_generate_equals_single_generate(ctx, port):
     """bmx_gvec_generate: every member generates its own block range of the SAME logical vector"""
     nbits = 100 * 65536 + 99
