@@ -454,7 +454,9 @@ def run_pairwise(args):
                       "baseline_config": "configs[1]", "block_types_vec0": va[0].calc_stat(), "per_op": per_op,
                       "count_and": counts[:4]},
            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "k_count_op2",
+                        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                        "kernel": ("k_count_op2_stream<4, true>" if all(v.calc_stat()["bit_blocks"] == v.info()["nblocks"] for v in (va[0], vb[0]))
+                                   and va[0].info()["nblocks"] >= 2048 and os.environ.get("BMX_PAIR_STREAM", "-1") == "-1" else "k_count_op2"),
                         "algorithmic_bytes_per_launch": int(bytes_launch), "avg_launch_ms": round(k_ms, 4),
                         "timing": "hipEvent pair on the launch stream around the timed region / (steps x pairs)"}}
     if not args.no_cpu:

@@ -268,7 +268,7 @@ int bmx_ctx_create(int device, void* stream, bmx_ctx** out)
     // an invalid value is ignored (the default stays)
     static const char* const env_keys[][2] = {
         {"BMX_PIPE_UNROLL", "pipe_unroll"}, {"BMX_PIPE_ROWS", "pipe_rows"}, {"BMX_PIPE_NT", "pipe_nt"},
-        {"BMX_PIPE_WG", "pipe_wg"}, {"BMX_PIPE_WINDOW", "pipe_window"}, {"BMX_PIPE_SPLIT", "pipe_split"}, {"BMX_OR_TILE", "or_tile"}, {"BMX_OR_WINDOW", "or_window"}, {"BMX_DIRECT_COLS", "direct_cols"}, {"BMX_FF_WINDOW", "ff_window"}, {"BMX_XCD_SWIZZLE", "xcd_swizzle"}};
+        {"BMX_PIPE_WG", "pipe_wg"}, {"BMX_PIPE_WINDOW", "pipe_window"}, {"BMX_PIPE_SPLIT", "pipe_split"}, {"BMX_OR_TILE", "or_tile"}, {"BMX_OR_WINDOW", "or_window"}, {"BMX_DIRECT_COLS", "direct_cols"}, {"BMX_FF_WINDOW", "ff_window"}, {"BMX_PAIR_STREAM", "pair_stream"}, {"BMX_PAIR_WGS", "pair_wgs"}, {"BMX_XCD_SWIZZLE", "xcd_swizzle"}};
     for (auto& kv : env_keys)
         if (const char* e = getenv(kv[0])) (void)bmx_ctx_set_tuning(ctx, kv[1], atoi(e));
     g_last_error.clear();
@@ -315,6 +315,8 @@ int bmx_ctx_set_tuning(bmx_ctx* ctx, const char* key, int value)
     else if (k == "pipe_window") { ARGCHK(value >= -1); ctx->pipe_window = value; }
     else if (k == "or_tile") { ARGCHK(value >= 0 && value <= 3); ctx->or_tile = value; }
     else if (k == "direct_cols") { ARGCHK(value >= 0); ctx->direct_cols = value; }
+    else if (k == "pair_stream") { ARGCHK(value == -1 || value == 0 || value == 2 || value == 4 || value == 8); ctx->pair_stream = value; }
+    else if (k == "pair_wgs") { ARGCHK(value >= 1 && value <= 8); ctx->pair_wgs = value; }
     else if (k == "ff_window") { ARGCHK(value >= -1); ctx->ff_window = value; }
     else if (k == "or_window") { ARGCHK(value >= -9); ctx->or_window = value; }
     else if (k == "pipe_wg") { ARGCHK(value == 0 || (value >= 64 && value <= 1024 && value % 64 == 0)); ctx->pipe_wg = value; }
@@ -1104,6 +1106,20 @@ static int count_op2_launch(bmx_ctx* ctx, int op, const bmx_vec* a, const bmx_ve
     uint32_t nblocks = std::max(a->nblocks, b->nblocks);
     if (!nblocks) {
         if (out_is_host) *out = 0; else HIPCHK(hipMemsetAsync(out, 0, 8, ctx->stream));
+        return BMX_OK;
+    }
+    // bit-blocks only on both sides, same length: the streaming form (a wave per stretch of columns, one workgroup per CU)
+    if (ctx->pair_stream != 0 && a->nblocks == b->nblocks && a->counts[BMX_BIT] == nblocks && b->counts[BMX_BIT] == nblocks &&
+        nblocks >= 2048u) {
+        const u32 waves = ctx->pair_stream > 0 ? (u32)ctx->pair_stream : 4u;      // per workgroup
+        const u32 total = 256u * waves * (u32)std::max(ctx->pair_wgs, 1);        // waves of the launch
+        u32 per_wave = (nblocks + total - 1u) / total;
+        u32 grid = ((nblocks + per_wave - 1u) / per_wave + waves - 1u) / waves;
+        FoldOut fo{ctx->d_slots, ctx->d_done, out};
+        if (waves == 2u) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_count_op2_stream<2, true>), dim3(grid), dim3(128), 0, ctx->stream, op, a->d_desc, b->d_desc, nblocks, per_wave, fo);
+        else if (waves == 8u) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_count_op2_stream<8, true>), dim3(grid), dim3(512), 0, ctx->stream, op, a->d_desc, b->d_desc, nblocks, per_wave, fo);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_count_op2_stream<4, true>), dim3(grid), dim3(256), 0, ctx->stream, op, a->d_desc, b->d_desc, nblocks, per_wave, fo);
+        KCHK();
         return BMX_OK;
     }
     hipLaunchKernelGGL(k_count_op2, dim3((nblocks + 3) / 4), dim3(256), 0, ctx->stream, op,

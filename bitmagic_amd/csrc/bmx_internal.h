@@ -55,6 +55,8 @@ struct bmx_ctx {
     int pipe_split = -1;       // few columns: waves of a workgroup share one column's operand list: -1 auto, 0 never, 1 always
     int or_tile = 0;           // k_agg_or_gap_tiled variant (0 = default)
     int direct_cols = 384;     // aggregation over <= this many block columns and 24..1024 operands: one launch from the descriptor tables (k_direct); 0 = off
+    int pair_stream = -1;      // bm::count_* over two all-bit-block vectors: streaming kernel with this many waves per workgroup (-1 = 4, 0 = the column-per-wave kernel)
+    int pair_wgs = 1;          // ... and this many workgroups per CU
     int ff_window = 0;         // find_first_and_sub: block columns of the FIRST launch window (each next one is 4x larger): 0 = automatic, -1 = one launch
     int or_window = 0;         // column tiles per launch of k_agg_or_gap_tiled: 0 / -1 = all in one launch (windows measured: no gain)
     int xcd_swz = 1;

@@ -343,6 +343,30 @@ def test_full_size_pairwise_properties(ctx, port):
         del t, x, back
 
 
+@pytest.mark.parametrize("nblocks_x", [2048, 3001, 15259])
+def test_pairwise_count_streaming_kernel(ctx, port, nblocks_x):
+    """bm::count_* over two all-bit-block vectors takes the streaming kernel (a wave per stretch of columns, two
+    columns in flight); every workgroup shape of it and the column-per-wave kernel (pair_stream 0) must return the
+    same four counts; the AND count is also checked against the oracle on the same generated words"""
+    nbits = nblocks_x * 65536 - 12345
+    a = bm.bvector.generate(ctx, SEED + 9, 1, 20000, nbits)
+    b = bm.bvector.generate(ctx, SEED + 9, 2, 30000, nbits)
+    assert a.info()["counts"][bm.BIT] == nblocks_x and b.info()["counts"][bm.BIT] == nblocks_x
+    try:
+        ctx.set_tuning("pair_stream", 0)
+        ref = [bm._count_op2(op, a, b) for op in range(4)]
+        for ps, wgs in ((-1, 1), (2, 1), (2, 4), (4, 2), (8, 1), (4, 3)):
+            ctx.set_tuning("pair_stream", ps); ctx.set_tuning("pair_wgs", wgs)
+            assert [bm._count_op2(op, a, b) for op in range(4)] == ref, (ps, wgs)
+            assert bm._count_op2(bm.AND, b, a) == ref[0] and bm._count_op2(bm.SUB, b, a) == b.count() - ref[0]
+    finally:
+        ctx.set_tuning("pair_stream", -1); ctx.set_tuning("pair_wgs", 1)
+    if nblocks_x <= 3001:
+        wa = port.gen_words(SEED + 9, 1, 20000, nbits); wb = port.gen_words(SEED + 9, 2, 30000, nbits)
+        assert ref[0] == int(np.unpackbits((wa & wb).view(np.uint8)).sum())
+        assert ref[2] == int(np.unpackbits((wa ^ wb).view(np.uint8)).sum())
+
+
 def test_full_size_256way_and_count(ctx, port):
     """BASELINE config 3: aggregator AND + COUNT over 256 x 1e9-bit vectors (correlated data set A).
     Checks: shard sums == total; sampled block columns equal the oracle run on the same
