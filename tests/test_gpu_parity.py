@@ -360,7 +360,7 @@ def test_pairwise_count_streaming_kernel(ctx, port, nblocks_x):
             assert [bm._count_op2(op, a, b) for op in range(4)] == ref, (ps, wgs)
             assert bm._count_op2(bm.AND, b, a) == ref[0] and bm._count_op2(bm.SUB, b, a) == b.count() - ref[0]
     finally:
-        ctx.set_tuning("pair_stream", -1); ctx.set_tuning("pair_wgs", 1)
+        ctx.set_tuning("pair_stream", -1); ctx.set_tuning("pair_wgs", 1); ctx.set_tuning("pipe_nt", 1)
     if nblocks_x <= 3001:
         wa = port.gen_words(SEED + 9, 1, 20000, nbits); wb = port.gen_words(SEED + 9, 2, 30000, nbits)
         assert ref[0] == int(np.unpackbits((wa & wb).view(np.uint8)).sum())
