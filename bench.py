@@ -348,7 +348,11 @@ def run_headline(args):
         bits_per_step = args.nvec * args.nbits * (world if scaling == "weak" else 1)
         value = bits_per_step * args.steps / main["dt"] / 1e9
         achieved = main["op_bytes"] / (main["k_ms"] * 1e-3) / 1e9
-        traffic, tsrc = traffic_note(f"agg_and_count_{args.nvec}x{args.nbits}")
+        # the PMC figure belongs to the headline data set on one GPU (density 10 %, data set A, 6 launch windows): any other
+        # density / data set / shard runs another kernel or another launch plan and carries no traffic figure
+        headline = args.density_q16 == 6554 and not args.independent and world == 1
+        traffic, tsrc = traffic_note(f"agg_and_count_{args.nvec}x{args.nbits}") if headline else (None, None)
+        if traffic is not None and main["nlaunch"] != 6: traffic, tsrc = None, None
         res = {
             "metric": METRIC, "value": round(value, 2), "unit": "Gbit/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(main["dt"] / args.steps * 1e3, 4), "higher_is_better": True,
@@ -380,6 +384,12 @@ def run_headline(args):
                          "allreduce_us": None if main["ar_us"] is None else round(main["ar_us"], 1),
                          "step_event_ms": round(main["ev_ms"] / args.steps, 4)},
         }
+        if args.independent:
+            # data set B: the AND dies after a few operands and the kernel stops reading a column there (the reference's digest
+            # exit); full-read bytes over an early-exit time is not a bandwidth: report time and rate only
+            res["roofline"].update({"achieved": None, "frac": None, "per_rank_note": "early exit: bytes actually read are not the full operand bytes",
+                                    "note": "early-exit data set: time and Gbit/s of LOGICAL operand bits only; no bandwidth figure"})
+            res["per_rank"]["GBps"] = None
         if shard_eff:
             res["shard_1of8_on_one_gpu"] = shard_eff
         if weak:
