@@ -943,3 +943,11 @@ class gaggregator:
         h, any_ = C.c_void_p(), C.c_int()
         check(lib().bmx_gagg_and_sub(self.grp._h, _handles(a), len(a), _handles(s), len(s), C.byref(h), C.byref(any_)))
         return gbvector(self.grp, h), bool(any_.value)
+
+    def find_first_and_sub(self, bv_src_and=None, bv_src_sub=None):                      # :1079 / :1458
+        """-> (found, idx): first set bit of AND(group 0) AND NOT OR(group 1); every member searches its shard"""
+        a = list(bv_src_and) if bv_src_and is not None else self.ag.arg_bv0
+        s = list(bv_src_sub) if bv_src_sub is not None else self.ag.arg_bv1
+        found, idx = C.c_int(), C.c_uint64()
+        check(lib().bmx_gfind_first_and_sub(self.grp._h, _handles(a), len(a), _handles(s), len(s), C.byref(found), C.byref(idx)))
+        return bool(found.value), int(idx.value)

@@ -495,6 +495,35 @@ int bmx_gagg_and_sub(bmx_group* g, const bmx_gvec* const* src_and, size_t n_and,
     return BMX_OK;
 }
 
+// aggregator::find_first_and_sub over sharded vectors (src/bmaggregator.h:1458): every member searches its own shard
+// (ascending launch windows inside), the answer is the hit of the LOWEST member that found one
+int bmx_gfind_first_and_sub(bmx_group* g, const bmx_gvec* const* src_and, size_t n_and,
+                            const bmx_gvec* const* src_sub, size_t n_sub, int* found, uint64_t* idx)
+{
+    ARGCHK(g && found && idx && (n_and == 0 || src_and) && (n_sub == 0 || src_sub));
+    *found = 0; *idx = 0;
+    if (!n_and) return BMX_OK;
+    uint32_t nblocks = 0xFFFFFFFFu; uint64_t nbits = 0;
+    int rc = same_range(g, src_and, n_and, &nblocks, &nbits); if (rc) return rc;
+    rc = same_range(g, src_sub, n_sub, &nblocks, &nbits); if (rc) return rc;
+    std::vector<int> f((size_t)g->n, 0);
+    std::vector<uint64_t> pos((size_t)g->n, 0);
+    rc = for_each_member(g, [&](int m) -> int {
+        std::vector<const bmx_vec*> a(std::max<size_t>(n_and, 1)), s(std::max<size_t>(n_sub, 1));
+        for (size_t i = 0; i < n_and; ++i) a[i] = src_and[i]->shard[(size_t)m];
+        for (size_t i = 0; i < n_sub; ++i) s[i] = src_sub[i]->shard[(size_t)m];
+        return bmx_find_first_and_sub(g->ctx[(size_t)m], a.data(), n_and, s.data(), n_sub, &f[(size_t)m], &pos[(size_t)m]);
+    });
+    if (rc) return rc;
+    for (int m = 0; m < g->n; ++m)
+        if (f[(size_t)m]) {
+            uint32_t lo, hi; shard_range(nblocks, m, g->n, &lo, &hi);
+            *found = 1; *idx = (uint64_t)lo * BMX_BLOCK_BITS + pos[(size_t)m];
+            break;
+        }
+    return BMX_OK;
+}
+
 int bmx_gpipeline_destroy(bmx_group* g, bmx_gpipeline* p)
 {
     if (!p) return BMX_OK;

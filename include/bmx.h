@@ -313,6 +313,9 @@ int bmx_gselect_batch(bmx_group* g, const bmx_gvec* v, const bmx_grs* rs, const 
 int bmx_gagg_or(bmx_group* g, const bmx_gvec* const* src, size_t n, int opt_compress, bmx_gvec** result);
 int bmx_gagg_and_sub(bmx_group* g, const bmx_gvec* const* src_and, size_t n_and,
                      const bmx_gvec* const* src_sub, size_t n_sub, bmx_gvec** result, int* any);
+/* aggregator::find_first_and_sub over sharded vectors (src/bmaggregator.h:1458): the hit of the lowest shard that has one */
+int bmx_gfind_first_and_sub(bmx_group* g, const bmx_gvec* const* src_and, size_t n_and,
+                            const bmx_gvec* const* src_sub, size_t n_sub, int* found, uint64_t* idx);
 /* aggregator::pipeline + combine_and_sub(pipe), counts only (src/bmaggregator.h:1292-1399): member m runs the
  * pipeline over its shard of every operand, counts_out[g] = sum over the members */
 int bmx_gpipeline_create(bmx_group* g,

@@ -255,6 +255,20 @@ public:
         bv_target.adopt(r);
         return any != 0;
     }
+    /// find_first_and_sub(idx)  src/bmaggregator.h:1079 / C-style :1458
+    bool find_first_and_sub(size_type& idx)
+    { return find_first_and_sub(idx, ag_.arg_bv0.data(), ag_.arg_bv0.size(), ag_.arg_bv1.data(), ag_.arg_bv1.size()); }
+    bool find_first_and_sub(size_type& idx, const bvector_type_const_ptr* bv_src_and, size_t src_and_size,
+                            const bvector_type_const_ptr* bv_src_sub, size_t src_sub_size)
+    {
+        std::vector<const bmx_gvec*> a(src_and_size), s(src_sub_size);
+        for (size_t i = 0; i < src_and_size; ++i) a[i] = bv_src_and[i]->handle();
+        for (size_t i = 0; i < src_sub_size; ++i) s[i] = bv_src_sub[i]->handle();
+        int found = 0; uint64_t p = 0;
+        check(bmx_gfind_first_and_sub(grp_->handle(), a.data(), src_and_size, s.data(), src_sub_size, &found, &p));
+        if (found) idx = p;
+        return found != 0;
+    }
     template <class TPipe>
     void combine_and_sub(TPipe& pipe)
     {

@@ -313,6 +313,9 @@ int main()
         ragg.add(&hv[3], 1); gagg.add(&gg[3], 1);
         bool rf = ragg.combine_and_sub(ref), gf = gagg.combine_and_sub(t);
         bmx::download(t, got); REQUIRE(rf == gf && got.compare(ref) == 0);
+        { bvect::size_type ri = 0; uint64_t gi = 0;
+          bool rff = ragg.find_first_and_sub(ri), gff = gagg.find_first_and_sub(gi);
+          REQUIRE(rff == gff && (!rff || ri == gi)); }
         ragg.combine_or(ref); gagg.combine_or(t); bmx::download(t, got); REQUIRE(got.compare(ref) == 0);
         typedef bm::aggregator<bvect>::pipeline<bm::agg_opt_only_counts> rpipe_t;
         typedef bmx::aggregator<bmx::gbvector>::pipeline<bmx::agg_opt_only_counts> gpipe_t;

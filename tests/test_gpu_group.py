@@ -49,6 +49,12 @@ def test_group_matches_single_context_and_oracle(ctx, port, members):
     e = port.agg_and_sub([pv[0], pv[2]], [pv[1], pv[4]])
     assert t.count() == e.count() and any_ == (e.count() > 0)
     assert t.block_table()[0].tolist() == e.flatten()[0].tolist()
+    assert agg.find_first_and_sub([gv[0], gv[2]], [gv[1], gv[4]]) == port.find_first_and_sub([pv[0], pv[2]], [pv[1], pv[4]])
+    for a_, s_ in (([gv[1], gv[4]], []), ([gv[3]], [gv[0]]), ([gv[3], gv[1]], [])):
+        pa = [pv[gv.index(x)] for x in a_]; ps = [pv[gv.index(x)] for x in s_]
+        ef = port.find_first_and_sub(pa, ps)
+        gf = agg.find_first_and_sub(a_, s_)
+        assert gf[0] == ef[0] and (not ef[0] or gf[1] == ef[1])
     for oc in (False, True):
         agg.set_optimization(oc)
         o = agg.combine_or(gv)
