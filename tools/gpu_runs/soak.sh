@@ -12,10 +12,10 @@ for seed in range(60, 1500):
     try: S.test_random_block_tables(ctx, port, seed, "direct")
     except AssertionError as e: bad += 1; print("FAIL seed", seed, str(e)[:200])
 for args in [(2, 50, 45), (17, 80, 64), (90, 60, 33), (333, 150, 70), (600, 20, 40), (250, 300, 37)]:
-    try: P.test_sparse_state_of_gap_lists(ctx, port, *args)
+    try: P.test_sparse_state_of_gap_lists(ctx, port, *args, "direct")
     except AssertionError as e: bad += 1; print("FAIL sparse", args, str(e)[:200])
 for dq, nv in [(7, 130), (100, 64), (65400, 40), (2000, 35)]:
-    try: P.test_many_gap_operands(ctx, port, dq, nv)
+    try: P.test_many_gap_operands(ctx, port, dq, nv, "direct")
     except AssertionError as e: bad += 1; print("FAIL many", dq, nv, str(e)[:200])
 import numpy as np
 agg = bm.aggregator(ctx)
