@@ -612,6 +612,9 @@ class slice_scanner:
             self._size = max([p.size() for p in self.slices if p is not None], default=0)
         return self._size
 
+    def _new_pipeline(self):
+        return pipeline(self.ctx)
+
     def _groups(self, value: int):
         if value <= 0:
             raise BmxError(_ffi.ERR_BADARG, "Invalid argument", "value 0 has no AND group: find_eq(0) goes through the comparison kernel")
@@ -665,7 +668,7 @@ class slice_scanner:
 
     def find_eq_counts(self, values) -> np.ndarray:
         out = np.zeros(len(values), np.uint64)
-        pipe = pipeline(self.ctx)
+        pipe = self._new_pipeline()
         slot = []
         for q, v in enumerate(values):
             if int(v) == 0:
@@ -951,3 +954,45 @@ class gaggregator:
         found, idx = C.c_int(), C.c_uint64()
         check(lib().bmx_gfind_first_and_sub(self.grp._h, _handles(a), len(a), _handles(s), len(s), C.byref(found), C.byref(idx)))
         return bool(found.value), int(idx.value)
+
+
+class gslice_scanner(slice_scanner):
+    """slice_scanner over SHARDED bit-planes (gbvector): every member searches its own rows; results stay sharded,
+    counts are summed (bmx_gslice_compare, gaggregator, gpipeline).  Planes, not_null and size must span the same
+    block range (upload the planes with the same number of blocks)."""
+
+    def __init__(self, grp: group, slices, size: int | None = None, not_null: gbvector | None = None):
+        self.grp, self.slices = grp, list(slices)
+        self.agg = gaggregator(grp)
+        self.not_null = not_null
+        self._size = size
+
+    def size(self) -> int:
+        if self._size is None:
+            self._size = max([p.info()["nbits"] for p in self.slices if p is not None], default=0)
+        return self._size
+
+    def _new_pipeline(self):
+        return gpipeline(self.grp)
+
+    def _compare(self, pred: int, v0: int = 0, v1: int = 0, count_only: bool = False):
+        if v0 < 0 or v1 < 0 or v0 >= 1 << 64 or v1 >= 1 << 64:
+            raise BmxError(_ffi.ERR_RANGE, "Incorrect range or index", "unsigned 64-bit values only")
+        arr = (C.c_void_p * max(len(self.slices), 1))()
+        for i, p in enumerate(self.slices):
+            arr[i] = p._h if p is not None else None
+        h, cnt = C.c_void_p(), C.c_uint64()
+        check(lib().bmx_gslice_compare(self.grp._h, arr, len(self.slices), pred, v0, v1, self.size(),
+                                       self.not_null._h if self.not_null is not None else None,
+                                       None if count_only else C.byref(h), C.byref(cnt)))
+        return cnt.value if count_only else gbvector(self.grp, h)
+
+    def find_eq(self, value: int):
+        """-> (bv_out or None, found)"""
+        if int(value) == 0:
+            t = self._compare(CMP_EQ, 0)
+            return t, t.count() != 0
+        g = self._groups(int(value))
+        if g is None:
+            return None, False
+        return self.agg.combine_and_sub(g[0], g[1])

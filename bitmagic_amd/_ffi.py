@@ -111,6 +111,7 @@ def lib() -> C.CDLL:
         "bmx_gagg_or": (i32, [vp, P(vp), C.c_size_t, i32, P(vp)]),
         "bmx_gagg_and_sub": (i32, [vp, P(vp), C.c_size_t, P(vp), C.c_size_t, P(vp), P(i32)]),
         "bmx_gfind_first_and_sub": (i32, [vp, P(vp), C.c_size_t, P(vp), C.c_size_t, P(i32), P(u64)]),
+        "bmx_gslice_compare": (i32, [vp, P(vp), C.c_size_t, i32, u64, u64, u64, vp, P(vp), P(u64)]),
         "bmx_gpipeline_create": (i32, [vp, P(vp), P(u32), P(vp), P(u32), C.c_size_t, P(vp)]),
         "bmx_gpipeline_destroy": (i32, [vp, vp]),
         "bmx_gpipeline_run_counts": (i32, [vp, vp, P(u64)]),

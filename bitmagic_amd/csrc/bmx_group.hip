@@ -524,6 +524,44 @@ int bmx_gfind_first_and_sub(bmx_group* g, const bmx_gvec* const* src_and, size_t
     return BMX_OK;
 }
 
+// sparse_vector_scanner range search over SHARDED bit-planes (bmx_slice_compare per member over its rows): the planes
+// (and the not-NULL vector) must cover the same block range and `size` must end in its last block; the result is sharded
+// like the planes, the count is the sum over the members
+int bmx_gslice_compare(bmx_group* g, const bmx_gvec* const* slices, size_t nslices, int pred, uint64_t v0, uint64_t v1,
+                       uint64_t size, const bmx_gvec* not_null, bmx_gvec** result, uint64_t* count)
+{
+    ARGCHK(g && (nslices == 0 || slices) && nslices <= 64 && (result || count));
+    if (result) *result = nullptr;
+    if (count) *count = 0;
+    uint32_t nblocks = 0xFFFFFFFFu;
+    for (size_t i = 0; i < nslices; ++i) {
+        if (!slices[i]) continue;
+        if (slices[i]->g != g) { bmx_set_last_error("slice belongs to another group"); return BMX_ERR_BADARG; }
+        if (nblocks == 0xFFFFFFFFu) nblocks = slices[i]->nblocks;
+        else if (nblocks != slices[i]->nblocks) { bmx_set_last_error("sharded planes must cover the same block range (upload them with the same nblocks)"); return BMX_ERR_BADARG; }
+    }
+    uint64_t need = (size + BMX_BLOCK_BITS - 1) / BMX_BLOCK_BITS;
+    if (nblocks == 0xFFFFFFFFu) nblocks = (uint32_t)need;
+    if (need != nblocks || (not_null && (not_null->g != g || not_null->nblocks != nblocks))) {
+        bmx_set_last_error("size / not-NULL vector must span the block range of the planes"); return BMX_ERR_BADARG;
+    }
+    bmx_gvec* v = result ? gvec_new(g, size, nblocks) : nullptr;
+    if (result && !v) return BMX_ERR_BADALLOC;
+    std::vector<uint64_t> cnt((size_t)g->n, 0);
+    int rc = for_each_member(g, [&](int m) -> int {
+        uint32_t lo, hi; shard_range(nblocks, m, g->n, &lo, &hi);
+        std::vector<const bmx_vec*> sl(std::max<size_t>(nslices, 1), nullptr);
+        for (size_t i = 0; i < nslices; ++i) sl[i] = slices[i] ? slices[i]->shard[(size_t)m] : nullptr;
+        return bmx_slice_compare(g->ctx[(size_t)m], sl.data(), nslices, pred, v0, v1, shard_bits(size, lo, hi),
+                                 not_null ? not_null->shard[(size_t)m] : nullptr, v ? &v->shard[(size_t)m] : nullptr,
+                                 count ? &cnt[(size_t)m] : nullptr);
+    });
+    if (rc) { std::string keep = bmx_last_error(); if (v) bmx_gvec_free(g, v); bmx_set_last_error(keep.c_str()); return rc; }
+    if (count) for (int m = 0; m < g->n; ++m) *count += cnt[(size_t)m];
+    if (result) *result = v;
+    return BMX_OK;
+}
+
 int bmx_gpipeline_destroy(bmx_group* g, bmx_gpipeline* p)
 {
     if (!p) return BMX_OK;

@@ -316,6 +316,10 @@ int bmx_gagg_and_sub(bmx_group* g, const bmx_gvec* const* src_and, size_t n_and,
 /* aggregator::find_first_and_sub over sharded vectors (src/bmaggregator.h:1458): the hit of the lowest shard that has one */
 int bmx_gfind_first_and_sub(bmx_group* g, const bmx_gvec* const* src_and, size_t n_and,
                             const bmx_gvec* const* src_sub, size_t n_sub, int* found, uint64_t* idx);
+/* bmx_slice_compare over sharded bit-planes (scanner range search on several GPUs): planes, not_null and `size` must
+ * span the same block range; result sharded like the planes; count = sum over the members */
+int bmx_gslice_compare(bmx_group* g, const bmx_gvec* const* slices, size_t nslices, int pred, uint64_t v0, uint64_t v1,
+                       uint64_t size, const bmx_gvec* not_null, bmx_gvec** result, uint64_t* count);
 /* aggregator::pipeline + combine_and_sub(pipe), counts only (src/bmaggregator.h:1292-1399): member m runs the
  * pipeline over its shard of every operand, counts_out[g] = sum over the members */
 int bmx_gpipeline_create(bmx_group* g,

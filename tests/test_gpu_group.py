@@ -118,6 +118,60 @@ def test_group_with_more_members_than_blocks(ctx, port):
     grp.close()
 
 
+@pytest.mark.parametrize("members", [1, 3, 8])
+def test_group_slice_scanner(ctx, port, members):
+    """scanner call pattern over SHARDED bit-planes (bmx_gslice_compare + group aggregator / pipeline): range and
+    equality searches equal the single-device scanner and numpy, with NULL elements, an absent plane, and rows that
+    end inside the last block"""
+    rng = np.random.default_rng(members)
+    n = 9 * 65536 + 777
+    col = np.where(rng.random(n) < 0.6, rng.integers(0, 3000, size=n), 0).astype(np.uint64)
+    col[2 * 65536:3 * 65536] = 1023                                     # FULL blocks in the low planes
+    col &= ~np.uint64(1 << 7)                                           # plane 7 does not exist
+    notnull = rng.random(n) < 0.85
+    col[~notnull] = 0
+    nplanes = 12
+    def words(bits):
+        return np.packbits(np.concatenate([bits.astype(np.uint8), np.zeros((-n) % 32, np.uint8)]), bitorder="little").view(np.uint32)
+    grp = bm.group([0] * members)
+    gs, ss = [], []
+    for b in range(nplanes):
+        bits = ((col >> np.uint64(b)) & np.uint64(1)).astype(bool)
+        if not bits.any(): gs.append(None); ss.append(None); continue
+        p = port.import_words(words(bits), True, n)
+        gs.append(bm.gbvector.from_block_table(grp, n, *p.flatten()))
+        ss.append(bm.bvector.from_block_table(ctx, n, *p.flatten()))
+    assert gs[7] is None
+    pn = port.import_words(words(notnull), True, n)
+    gnn = bm.gbvector.from_block_table(grp, n, *pn.flatten()); snn = bm.bvector.from_block_table(ctx, n, *pn.flatten())
+    def bits_of(gv):
+        k, o, b, g = gv.block_table()
+        back = bm.bvector.from_block_table(ctx, n, k, o, b, g)
+        return np.unpackbits(back.to_words((n + 31) // 32).view(np.uint8), bitorder="little")[:n].astype(bool)
+    for with_null in (False, True):
+        gsc = bm.gslice_scanner(grp, gs, size=n, not_null=gnn if with_null else None)
+        ssc = bm.slice_scanner(ctx, ss, size=n, not_null=snn if with_null else None)
+        valid = notnull if with_null else np.ones(n, bool)
+        for v in (0, 1, 100, 1023, 1024, 2999, 5000):
+            V = np.uint64(v)
+            for pred, exp in ((bm.CMP_GT, col > V), (bm.CMP_GE, (col >= V) & (valid if v == 0 else True)),
+                              (bm.CMP_LT, (col < V) & valid), (bm.CMP_LE, (col <= V) & valid)):
+                assert gsc.count(pred, v) == ssc.count(pred, v) == int(exp.sum()), (members, with_null, pred, v)
+            assert (bits_of(gsc.find_le(v)) == ((col <= V) & valid)).all()
+            t, f = gsc.find_eq(v)
+            e = (col == V) & (valid if v == 0 else True)
+            assert f == bool(e.any()) and (t is None or (bits_of(t) == e).all()), (members, with_null, v)
+        assert gsc.count(bm.CMP_RANGE, 10, 2000) == int(((col >= 10) & (col <= 2000)).sum())
+        assert (bits_of(gsc.find_range(0, 50)) == ((col <= 50) & valid)).all()
+        assert (bits_of(gsc.find_zero()) == ((col == 0) & valid)).all() and (bits_of(gsc.find_nonzero()) == (col != 0)).all()
+        vals = [int(x) for x in rng.choice(col[col > 0], 20)] + [0, 4095, 1 << 20]
+        assert (gsc.find_eq_counts(vals) == ssc.find_eq_counts(vals)).all()
+        assert (gsc.find_eq_counts(vals) == np.array([int(((col == np.uint64(x)) & (valid if x == 0 else True)).sum()) for x in vals], np.uint64)).all()
+        ff = gsc.find_first_eq(vals[0])
+        assert ff == ssc.find_first_eq(vals[0]) == (True, int(np.flatnonzero(col == np.uint64(vals[0]))[0]))
+    grp.close()
+
+
 def test_group_generate_equals_single_generate(ctx, port):
     """bmx_gvec_generate: every member generates its own block range of the SAME logical vector"""
     nbits = 100 * 65536 + 99
