@@ -467,17 +467,20 @@ void k_agg_or_gap_tiled(const u64* const* __restrict__ descs, const u32* __restr
 // aggregator::combine_and_sub(target, ...)  src/bmaggregator.h:1162 with result
 // blocks (always stored with opt_compress, :1210-1211).  Shares the row format
 // and evaluation order of k_pipe_counts (single group).
-template <int U>
-__global__ __launch_bounds__(256)
+// WG / col_base: the launch plan of the headline kernel applies here too -- a bit-block-only aggregation over many
+// columns is launched in windows of one machine-load of waves (one 640-thread workgroup per CU, bmx.hip
+// agg_and_sub_launch): 256 x 1e9-bit combine_and materialised 5.2 -> 4.8 ms.
+template <int U, int WG = 256>
+__global__ __launch_bounds__(WG)
 void k_agg_and_sub(const u64* __restrict__ dmat, const u32* __restrict__ and_n_p, const u32* __restrict__ sub_n_p,
                    u32 col_stride, u32 ncols, int opt_compress, int xcd_swz,
                    uint4* __restrict__ slab, u64* __restrict__ desc, BlockStat* __restrict__ st,
-                   u32 col_from, u32 col_to)
+                   u32 col_from, u32 col_to, u32 col_base)
 {
     extern __shared__ u32 lds_dyn[];
     u32 lane = lane_id(), wave = threadIdx.x >> 6;
     u32 bid = xcd_swz ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
-    u32 c = uniform32(bid * 4u + wave);
+    u32 c = uniform32(col_base + bid * (u32)(WG / 64) + wave);
     if (c >= ncols) return;
     if (c < col_from || c >= col_to) { store_trivial(K_NULL, c, desc, st, lane); return; }     // outside the range hint: not visited (:1339-1346)
     const u64* row = dmat + (size_t)c * col_stride;

@@ -398,6 +398,20 @@ def test_full_size_256way_and_count(ctx, port):
         exp = port.pipeline_counts([(pvs[:256], []), (pvs[:128], []), (pvs[:2], [])], nb0, nb0 + 1)
         got = agg._run_pipeline(pipe, nb0, nb0 + 1)
         assert (got == exp).all(), (nb0, got, exp)
+    # materialised combine_and over the same operands: windowed 640-thread launches (default), odd window sizes and the
+    # single 256-thread launch must store the same vector; its population is the pipeline's count
+    res = {}
+    try:
+        for name, win in (("windows", 0), ("one_launch", -1), ("odd", 1237)):
+            ctx.set_tuning("pipe_window", win)
+            res[name], any_ = agg.combine_and_sub(vecs[:128], [])
+            assert any_ and res[name].count() == int(total[1]), name
+    finally:
+        ctx.set_tuning("pipe_window", 0)
+    assert bm.count_xor(res["windows"], res["one_launch"]) == 0 and bm.count_xor(res["windows"], res["odd"]) == 0
+    assert res["windows"].info()["counts"] == res["one_launch"].info()["counts"] == res["odd"].info()["counts"]
+    t, _ = agg.combine_and_sub(vecs[:200], vecs[200:])           # SUB group of 56 operands that hold the common component: empty
+    assert t.count() == 0
 
 
 @pytest.mark.parametrize("tail_bits", [0, 5])

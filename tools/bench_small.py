@@ -61,3 +61,13 @@ for nbits in (1_000_000, 1_000_000_000):
         ctx.set_tuning("direct_cols", 384)
         print(json.dumps(out))
         del vecs
+# materialised combine_and at full size: windowed one-workgroup-per-CU launches against one launch of 256-thread workgroups
+vecs = [bm.bvector.generate(ctx, 0xB17A61C, v, 6554, 1_000_000_000, with_common=True) for v in range(256)]
+agg = bm.aggregator(ctx)
+out = {"combine_and_256x1e9": "materialised"}
+for name, win in (("windows_ms", 0), ("one_launch_ms", -1)):
+    ctx.set_tuning("pipe_window", win)
+    out[name] = t(lambda: agg.combine_and_sub(vecs, []), reps=8, warm=2)
+ctx.set_tuning("pipe_window", 0)
+print(json.dumps(out))
+del vecs
