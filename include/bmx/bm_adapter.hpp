@@ -135,9 +135,10 @@ bool upload(const BMBV& src, DST& dst, uint32_t nblocks = 0)
 /// src/bmbmatrix.h:739,756) -> device vectors for bmx::slice_scanner (bmx/scanner.hpp).  `store` owns the
 /// device vectors; slices[i] is nullptr where the host plane does not exist.  All slices are uploaded
 /// with the same block count (the container's size) so that NULL tails behave as in the reference.
-template <class SV>
-void upload_slices(const SV& sv, context& ctx, std::vector<bvector>& store, std::vector<const bvector*>& slices,
-                   const bvector** not_null = nullptr)
+/// (CTX / DV = context + bvector, or device_group + gbvector: the planes are then sharded by block range)
+template <class SV, class CTX, class DV>
+void upload_slices(const SV& sv, CTX& ctx, std::vector<DV>& store, std::vector<const DV*>& slices,
+                   const DV** not_null = nullptr)
 {
     unsigned planes = sv.effective_slices();
     uint32_t nblocks = (uint32_t)(((uint64_t)sv.size() + BMX_BLOCK_BITS - 1) / BMX_BLOCK_BITS);

@@ -15,6 +15,7 @@
 #include <initializer_list>
 
 #include "bvector.hpp"
+#include "scanner.hpp"
 
 namespace bmx {
 
@@ -281,5 +282,15 @@ private:
     arg_groups ag_;
     bool opt_compress_ = false;
 };
+
+// ---- the scanner call pattern over sharded bit-planes (scanner.hpp): bmx::gslice_scanner ----
+template <> struct scanner_traits<gbvector> {
+    typedef device_group ctx_type;
+    typedef bmx_gvec handle_type;
+    static int compare(ctx_type& g, const handle_type* const* h, size_t n, int pred, uint64_t v0, uint64_t v1, uint64_t size,
+                       const handle_type* nn, handle_type** r, uint64_t* cnt)
+    { return bmx_gslice_compare(g.handle(), h, n, pred, v0, v1, size, nn, r, cnt); }
+};
+typedef basic_slice_scanner<gbvector> gslice_scanner;
 
 } // namespace bmx

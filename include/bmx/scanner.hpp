@@ -27,9 +27,25 @@
 
 namespace bmx {
 
-class slice_scanner {
+/// what the scanner needs from a vector family: its context type and the one-pass comparison entry of the C-ABI
+template <class BV> struct scanner_traits;
+template <> struct scanner_traits<bvector> {
+    typedef context ctx_type;
+    typedef bmx_vec handle_type;
+    static int compare(ctx_type& c, const handle_type* const* h, size_t n, int pred, uint64_t v0, uint64_t v1, uint64_t size,
+                       const handle_type* nn, handle_type** r, uint64_t* cnt)
+    { return bmx_slice_compare(c.handle(), h, n, pred, v0, v1, size, nn, r, cnt); }
+};
+
+/// BV = bmx::bvector (one device, `slice_scanner`) or bmx::gbvector (a device group, `gslice_scanner` in group.hpp:
+/// planes sharded by block range, every member searches its own rows)
+template <class BV>
+class basic_slice_scanner {
+    typedef scanner_traits<BV> traits;
+    typedef typename traits::ctx_type ctx_type;
+    typedef BV bvector;                     // (the method bodies below are written against this name)
 public:
-    explicit slice_scanner(context& ctx) : ctx_(&ctx), agg_(ctx) {}
+    explicit basic_slice_scanner(ctx_type& ctx) : ctx_(&ctx), agg_(ctx) {}
 
     /// slice i holds bit i of every element; nullptr = the plane does not exist (sv.get_slice(i) == 0).
     /// slices.size() plays effective_slices(); size = sv.size() (rows; 0 = the longest slice);
@@ -57,7 +73,7 @@ public:
     bool find_eq(uint64_t value, bvector& bv_out)
     {
         if (!value) { compare(BMX_CMP_EQ, 0, 0, &bv_out); return bv_out.any(); }
-        aggregator<bvector>::arg_groups g;
+        typename aggregator<bvector>::arg_groups g;
         if (!add_groups(value, g)) { bv_out.clear(); return false; }
         return agg_.combine_and_sub(bv_out, g.arg_bv0.data(), g.arg_bv0.size(), g.arg_bv1.data(), g.arg_bv1.size(), false);
     }
@@ -66,7 +82,7 @@ public:
     bool find_first_eq(uint64_t value, size_type& idx)
     {
         if (!value) return false;                                        // :2428
-        aggregator<bvector>::arg_groups g;
+        typename aggregator<bvector>::arg_groups g;
         if (!add_groups(value, g)) return false;
         return agg_.find_first_and_sub(idx, g.arg_bv0.data(), g.arg_bv0.size(), g.arg_bv1.data(), g.arg_bv1.size());
     }
@@ -74,15 +90,15 @@ public:
     /// counts[q] = number of rows equal to values[q] (every value != 0): one pipeline, one launch
     void find_eq_counts(const uint64_t* values, size_t n, uint64_t* counts)
     {
-        typedef aggregator<bvector>::pipeline<agg_opt_only_counts> pipe_t;
+        typedef typename aggregator<bvector>::template pipeline<agg_opt_only_counts> pipe_t;
         pipe_t pipe(*ctx_);
         std::vector<size_t> slot(n, ~size_t(0));
         for (size_t q = 0; q < n; ++q) {
             counts[q] = 0;
             if (!values[q]) { counts[q] = count(BMX_CMP_EQ, 0); continue; }
-            aggregator<bvector>::arg_groups g;
+            typename aggregator<bvector>::arg_groups g;
             if (!add_groups(values[q], g)) continue;                     // impossible value: count 0
-            aggregator<bvector>::arg_groups* pg = pipe.add();
+            typename aggregator<bvector>::arg_groups* pg = pipe.add();
             *pg = g;
             slot[q] = pipe.size() - 1;
         }
@@ -95,17 +111,18 @@ public:
 private:
     size_type compare(int pred, uint64_t v0, uint64_t v1, bvector* out)
     {
-        std::vector<const bmx_vec*> h(slices_.size() ? slices_.size() : 1, nullptr);
+        typedef typename traits::handle_type handle_type;
+        std::vector<const handle_type*> h(slices_.size() ? slices_.size() : 1, nullptr);
         for (size_t i = 0; i < slices_.size(); ++i) h[i] = slices_[i] ? slices_[i]->handle() : nullptr;
-        bmx_vec* r = nullptr; uint64_t c = 0;
-        check(bmx_slice_compare(ctx_->handle(), h.data(), slices_.size(), pred, v0, v1, size_,
-                                (not_null_ && !not_null_->empty_handle()) ? not_null_->handle() : nullptr,
-                                out ? &r : nullptr, out ? nullptr : &c));
+        handle_type* r = nullptr; uint64_t c = 0;
+        check(traits::compare(*ctx_, h.data(), slices_.size(), pred, v0, v1, size_,
+                              (not_null_ && !not_null_->empty_handle()) ? not_null_->handle() : nullptr,
+                              out ? &r : nullptr, out ? nullptr : &c));
         if (out) out->adopt(r);
         return c;
     }
     // prepare_and_sub_aggregator (src/bmsparsevec_algo.h:2593-2640)
-    bool add_groups(uint64_t value, aggregator<bvector>::arg_groups& g) const
+    bool add_groups(uint64_t value, typename aggregator<bvector>::arg_groups& g) const
     {
         for (int bit = 63; bit >= 0; --bit) {                            // backward order (:2614)
             if (!((value >> bit) & 1u)) continue;
@@ -117,11 +134,13 @@ private:
         return true;
     }
 
-    context* ctx_;
+    ctx_type* ctx_;
     aggregator<bvector> agg_;
     std::vector<const bvector*> slices_;
     size_type size_ = 0;
     const bvector* not_null_ = nullptr;
 };
+
+typedef basic_slice_scanner<bvector> slice_scanner;
 
 } // namespace bmx

@@ -16,6 +16,7 @@
 
 #include "bmx/bm_adapter.hpp"
 #include "bmx/scanner.hpp"
+#include "bmx/group.hpp"
 extern "C" {
 #include "../../oracle/bmx_oracle.h"     // only for the deterministic input generator
 }
@@ -218,6 +219,25 @@ int main()
             { bvect r; bmx::bvector g(ctx); r2.find_zero(S, r); g2.find_zero(g); REQUIRE(same(r, g)); }
             { bvect r; bmx::bvector g(ctx); r2.find_nonzero(S, r); g2.find_nonzero(g); REQUIRE(same(r, g)); }
             { bvect r; bmx::bvector g(ctx); r2.find_eq(S, 0u, r); bool gf = g2.find_eq(0, g); REQUIRE(r.any() == gf && same(r, g)); }
+            // the same searches over a device GROUP: planes sharded over three members (bmx::gslice_scanner, group.hpp)
+            bmx::device_group grp3({0, 0, 0});
+            std::vector<bmx::gbvector> st3; std::vector<const bmx::gbvector*> sl3; const bmx::gbvector* nn3 = nullptr;
+            bmx::upload_slices(S, grp3, st3, sl3, &nn3);
+            bmx::gslice_scanner g3(grp3);
+            g3.bind(sl3, S.size(), nn3);
+            auto gsame = [&](bvect& r, bmx::gbvector& g) { bvect gh; if (!g.empty_handle()) bmx::download(g, gh); return gh.compare(r) == 0; };
+            for (unsigned v : {0u, 2u, 96u, 70003u, 131072u}) {
+                bvect r; bmx::gbvector g(grp3);
+                r2.find_gt(S, v, r); g3.find_gt(v, g); REQUIRE(gsame(r, g));
+                r.clear(); r2.find_le(S, v, r); g3.find_le(v, g); REQUIRE(gsame(r, g));
+                REQUIRE(g3.count(BMX_CMP_LE, v) == r.count());
+                r.clear(); r2.find_eq(S, v, r); bool gf = g3.find_eq(v, g); REQUIRE(r.any() == gf && gsame(r, g));
+                bvect::size_type ri = 0; bmx::size_type gi = 0;
+                if (v) { bool rff = r2.find_eq(S, v, ri), gff = g3.find_first_eq(v, gi); REQUIRE(rff == gff && (!rff || ri == gi)); }
+            }
+            { bvect r; bmx::gbvector g(grp3); r2.find_range(S, 10u, 69999u, r); g3.find_range(10u, 69999u, g); REQUIRE(gsame(r, g)); }
+            { uint64_t vals3[3] = {17u, 70003u, 5000000u}, got3[3]; g3.find_eq_counts(vals3, 3, got3);
+              for (int k = 0; k < 3; ++k) { bvect r; r2.find_eq(S, (unsigned)vals3[k], r); REQUIRE(got3[k] == r.count()); } }
         }
     }
     // set_range_hint + find_first_and_sub vs the real aggregator (src/bmaggregator.h:974,1458)
