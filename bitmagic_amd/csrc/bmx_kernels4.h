@@ -46,6 +46,8 @@ __device__ __forceinline__ void blk_size_mask(Blk& m, u32 nb, u64 size, u32 lane
     }
 }
 
+// TWO: two bounds at once (find_range); the one-bound form carries half the accumulators (fewer registers, more waves per CU)
+template <bool TWO>
 __global__ __launch_bounds__(256)
 void k_slice_compare(const u64* const* __restrict__ descs /* per plane: descriptor table or null */,
                      const u32* __restrict__ nblk, u32 nplanes, u32 ncols, int pred, u64 v0, u64 v1, u64 size,
@@ -59,7 +61,7 @@ void k_slice_compare(const u64* const* __restrict__ descs /* per plane: descript
     u32 nb = uniform32(bid * 4u + wave);
     u32 cnt = 0;
     if (nb < ncols) {
-        const bool two = pred == CMP_RANGE;
+        constexpr bool two = TWO;
         // a bound with a set bit above every plane: nothing is equal to it and nothing is greater
         bool dead0 = nplanes < 64u && (v0 >> nplanes) != 0ull;
         bool dead1 = two && nplanes < 64u && (v1 >> nplanes) != 0ull;
