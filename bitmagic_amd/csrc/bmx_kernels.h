@@ -72,8 +72,12 @@ void k_block_stats(const uint4* __restrict__ raw, u32 nblocks, int optimize, Blo
 // offs[nb] = bit-block ordinal or GAP u16-word offset (multiple of 8: every GAP block starts on a
 // 16-byte boundary so a lane can fetch it with dwordx4 loads); totals[0]=n_bit, [1]=gap_words,
 // totals[2..5] = blocks per kind
-// 16,384 blocks per pass (SCAN_PER per thread), 2 barriers per pass.
+// 8,192 blocks per pass (SCAN_LAYOUT_PER per thread), 2 barriers per pass.  A 1024-thread workgroup may hold 128 VGPRs per
+// thread: the round-1 form (16 items per thread, two DPP scans per step, four per-item arrays) spilled 136 B per thread to
+// scratch and took 18.9 us for 15,259 blocks.  Now: kinds counted with ballots, the bit-block ordinal is a masked bit count,
+// one DPP scan per step, one offset array -- 12.6 us at 8 items per thread (4: 14.1 us, 16: 14.2 us).
 #define SCAN_PER 16u
+#define SCAN_LAYOUT_PER 8u
 // Wave w of the workgroup owns blocks [base + w*1024, +1024) of a pass and walks them 64 at a time
 // (lane = consecutive block: every load / store instruction is one contiguous 1 KiB / 256 B piece),
 // carrying its running sums across the 16 steps; wave totals meet in LDS once per pass.
@@ -88,25 +92,29 @@ void k_scan_layout(const BlockStat* __restrict__ st, u32 nblocks, u32* __restric
     u32 carry_bit = 0, carry_gap = 0;
     u32 kc[4] = {0, 0, 0, 0};
     const uint4* st4 = reinterpret_cast<const uint4*>(st);
-    for (u32 base = 0; base < nblocks; base += 1024u * SCAN_PER) {
-        u32 nb0 = base + w * (64u * SCAN_PER) + lane;
-        u32 kind[SCAN_PER], vg[SCAN_PER], eb[SCAN_PER], eg[SCAN_PER];
-        uint4 x[SCAN_PER];
+    for (u32 base = 0; base < nblocks; base += 1024u * SCAN_LAYOUT_PER) {
+        u32 nb0 = base + w * (64u * SCAN_LAYOUT_PER) + lane;
+        u32 kind[SCAN_LAYOUT_PER], e[SCAN_LAYOUT_PER];        // e: offset inside the wave's stretch (bit ordinal or GAP words, by kind)
+        uint4 x[SCAN_LAYOUT_PER];
 #pragma unroll
-        for (u32 i = 0; i < SCAN_PER; ++i) {
+        for (u32 i = 0; i < SCAN_LAYOUT_PER; ++i) {
             u32 nb = nb0 + i * 64u;
             x[i] = nb < nblocks ? st4[nb] : make_uint4(0u, 0u, 0u, 0xFFu);      // {pop, runs, first, kind}
         }
         u32 run_b = 0, run_g = 0;                         // wave-local running sums over the steps
 #pragma unroll
-        for (u32 i = 0; i < SCAN_PER; ++i) {
+        for (u32 i = 0; i < SCAN_LAYOUT_PER; ++i) {
             kind[i] = x[i].w;
-            vg[i] = kind[i] == K_GAP ? ((x[i].y + 1u + 7u) & ~7u) : 0u;          // GAP blocks start 16-B aligned
-            u32 isb = kind[i] == K_BIT ? 1u : 0u;
-            if (kind[i] < 4u) kc[kind[i]]++;
-            u32 ib = wave_scan_incl(isb, lane), ig = wave_scan_incl(vg[i], lane);
-            eb[i] = run_b + ib - isb; eg[i] = run_g + ig - vg[i];
-            run_b += __shfl(ib, 63, 64); run_g += __shfl(ig, 63, 64);
+            u32 vg = kind[i] == K_GAP ? ((x[i].y + 1u + 7u) & ~7u) : 0u;         // GAP blocks start 16-B aligned
+            // kinds are counted with ballots (scalar popcounts), the bit-block ordinal is a masked bit count: one DPP scan
+            // per step (the GAP words) instead of two
+            u64 mb = __ballot(kind[i] == K_BIT), mg = __ballot(kind[i] == K_GAP);
+            kc[K_BIT] += (u32)__popcll(mb); kc[K_GAP] += (u32)__popcll(mg);
+            kc[K_FULL] += (u32)__popcll(__ballot(kind[i] == K_FULL)); kc[K_NULL] += (u32)__popcll(__ballot(kind[i] == K_NULL));
+            u32 ig = wave_scan_incl(vg, lane);
+            u32 eb = run_b + __builtin_amdgcn_mbcnt_hi((u32)(mb >> 32), __builtin_amdgcn_mbcnt_lo((u32)mb, 0u));
+            e[i] = kind[i] == K_BIT ? eb : run_g + ig - vg;
+            run_b += (u32)__popcll(mb); run_g += __shfl(ig, 63, 64);
         }
         if (lane == 0) { sm[w] = run_b; sm[16 + w] = run_g; }
         __syncthreads();
@@ -115,17 +123,15 @@ void k_scan_layout(const BlockStat* __restrict__ st, u32 nblocks, u32* __restric
         for (u32 i = 0; i < 16; ++i) { u32 a = sm[i], b = sm[16 + i]; if (i < w) { ob += a; og += b; } tb += a; tg += b; }
         __syncthreads();
 #pragma unroll
-        for (u32 i = 0; i < SCAN_PER; ++i) {
+        for (u32 i = 0; i < SCAN_LAYOUT_PER; ++i) {
             u32 nb = nb0 + i * 64u;
-            if (nb < nblocks) offs[nb] = kind[i] == K_BIT ? ob + eb[i] : (kind[i] == K_GAP ? og + eg[i] : 0u);
+            if (nb < nblocks) offs[nb] = kind[i] == K_BIT ? ob + e[i] : (kind[i] == K_GAP ? og + e[i] : 0u);
         }
         carry_bit += tb; carry_gap += tg;
     }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {                        // one LDS atomic per wave, not per thread
-        u32 t = wave_sum(kc[k]);
-        if (lane == 0 && t) atomicAdd(&kcnt[k], t);
-    }
+    for (int k = 0; k < 4; ++k)                          // (wave-uniform counts) one LDS atomic per wave
+        if (lane == 0 && kc[k]) atomicAdd(&kcnt[k], kc[k]);
     __syncthreads();
     if (tid == 0) { totals[0] = carry_bit; totals[1] = carry_gap; }
     if (tid < 4) totals[2 + tid] = kcnt[tid];
