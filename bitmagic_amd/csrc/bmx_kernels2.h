@@ -497,6 +497,8 @@ void k_agg_and_sub(const u64* __restrict__ dmat, const u32* __restrict__ and_n_p
     blk_fill(acc, ~0u);
     bool zero = pipe_chain<U, true, 0>(acc, pa, nba, lane);
     if (!zero) zero = pipe_chain<U, true, 1>(acc, ps, nbs, lane);
+    // (an instantiation WITHOUT this GAP branch for the bit-block-only launch was measured: 5.4 against 4.85 ms on the
+    // 256 x 1e9-bit combine_and -- the compiler schedules the fold differently; the dead branch stays)
     if (!zero && (nga | ngs)) {
         blk_to_lds(acc, lds, lane);
         zero = nga && gap_apply_list<GAP_AND>(pa + na - 1u, nga, lds, lane);
