@@ -615,6 +615,13 @@ class slice_scanner:
     def _new_pipeline(self):
         return pipeline(self.ctx)
 
+    def _can_transpose(self) -> bool:
+        return len(self.slices) <= 32
+
+    def _eq_counts_call(self, arr, vals, out):
+        check(lib().bmx_slice_eq_counts(self.ctx._h, arr, len(self.slices), _ptr(vals), vals.size, self.size(),
+                                        self.not_null._h if self.not_null is not None else None, _ptr(out)))
+
     def _groups(self, value: int):
         if value <= 0:
             raise BmxError(_ffi.ERR_BADARG, "Invalid argument", "value 0 has no AND group: find_eq(0) goes through the comparison kernel")
@@ -666,8 +673,21 @@ class slice_scanner:
             return False, 0
         return self.agg.find_first_and_sub(g[0], g[1])
 
-    def find_eq_counts(self, values) -> np.ndarray:
+    def find_eq_counts(self, values, method: str = "auto") -> np.ndarray:
+        """counts[q] = rows equal to values[q].  method "transpose" (default when it applies: <= 32 planes, one device):
+        one pass over the planes whatever the number of queries (bmx_slice_eq_counts); "pipeline": one AND-SUB group per
+        query, the reference's formulation (prepare_and_sub_aggregator + pipeline)."""
         out = np.zeros(len(values), np.uint64)
+        if method == "auto":
+            method = "transpose" if self._can_transpose() else "pipeline"
+        if method == "transpose":
+            vals = np.ascontiguousarray([int(v) for v in values], np.uint64)
+            arr = (C.c_void_p * max(len(self.slices), 1))()
+            for i, p in enumerate(self.slices):
+                arr[i] = p._h if p is not None else None
+            if vals.size:
+                self._eq_counts_call(arr, vals, out)
+            return out
         pipe = self._new_pipeline()
         slot = []
         for q, v in enumerate(values):
@@ -974,6 +994,10 @@ class gslice_scanner(slice_scanner):
 
     def _new_pipeline(self):
         return gpipeline(self.grp)
+
+    def _eq_counts_call(self, arr, vals, out):
+        check(lib().bmx_gslice_eq_counts(self.grp._h, arr, len(self.slices), _ptr(vals), vals.size, self.size(),
+                                         self.not_null._h if self.not_null is not None else None, _ptr(out)))
 
     def _compare(self, pred: int, v0: int = 0, v1: int = 0, count_only: bool = False):
         if v0 < 0 or v1 < 0 or v0 >= 1 << 64 or v1 >= 1 << 64:

@@ -73,6 +73,7 @@ def lib() -> C.CDLL:
         "bmx_agg_shift_right_and": (i32, [vp, P(vp), C.c_size_t, i32, i32, P(vp), P(i32)]),
         "bmx_agg_shift_right_and_count": (i32, [vp, P(vp), C.c_size_t, P(u64)]),
         "bmx_slice_compare": (i32, [vp, P(vp), C.c_size_t, i32, u64, u64, u64, vp, P(vp), P(u64)]),
+        "bmx_slice_eq_counts": (i32, [vp, P(vp), C.c_size_t, vp, C.c_size_t, u64, vp, vp]),
         "bmx_pipeline_create": (i32, [vp, P(vp), P(u32), P(vp), P(u32), C.c_size_t, P(vp)]),
         "bmx_pipeline_destroy": (i32, [vp, vp]),
         "bmx_pipeline_run_counts": (i32, [vp, vp, u32, u32, P(u64)]),
@@ -112,6 +113,7 @@ def lib() -> C.CDLL:
         "bmx_gagg_and_sub": (i32, [vp, P(vp), C.c_size_t, P(vp), C.c_size_t, P(vp), P(i32)]),
         "bmx_gfind_first_and_sub": (i32, [vp, P(vp), C.c_size_t, P(vp), C.c_size_t, P(i32), P(u64)]),
         "bmx_gslice_compare": (i32, [vp, P(vp), C.c_size_t, i32, u64, u64, u64, vp, P(vp), P(u64)]),
+        "bmx_gslice_eq_counts": (i32, [vp, P(vp), C.c_size_t, vp, C.c_size_t, u64, vp, vp]),
         "bmx_gpipeline_create": (i32, [vp, P(vp), P(u32), P(vp), P(u32), C.c_size_t, P(vp)]),
         "bmx_gpipeline_destroy": (i32, [vp, vp]),
         "bmx_gpipeline_run_counts": (i32, [vp, vp, P(u64)]),

@@ -1671,6 +1671,102 @@ int bmx_slice_compare(bmx_ctx* ctx, const bmx_vec* const* slices, size_t nslices
     return BMX_OK;
 }
 
+// counts[q] = rows equal to values[q]: one pass over the planes whatever the number of queries (k_slice_eq_counts:
+// bit-matrix transposition + hash lookup); identical to the per-query AND-SUB groups of the reference
+// (src/bmsparsevec_algo.h:2593-2640).  Value 0 goes through bmx_slice_compare (NULL correction); a value with a bit
+// above the planes or in an absent plane matches nothing (:2621).
+int bmx_slice_eq_counts(bmx_ctx* ctx, const bmx_vec* const* slices, size_t nslices, const uint64_t* values, size_t n,
+                        uint64_t size, const bmx_vec* not_null, uint64_t* counts)
+{
+    ARGCHK(ctx && (nslices == 0 || slices) && (n == 0 || (values && counts)));
+    ARGCHK(!not_null || not_null->ctx == ctx);
+    if (nslices > 32) { g_last_error = "more than 32 planes: use the pipeline form (bmx_pipeline_*)"; return BMX_ERR_RANGE; }
+    int rc = set_dev(ctx); if (rc) return rc;
+    for (size_t q = 0; q < n; ++q) counts[q] = 0;
+    uint64_t nblocks64 = (size + BMX_BLOCK_BITS - 1) / BMX_BLOCK_BITS;
+    if (nblocks64 > 65536ull * 16) { g_last_error = "vector too long"; return BMX_ERR_RANGE; }
+    const uint32_t ncols = (uint32_t)nblocks64;
+    uint32_t present = 0;
+    for (size_t i = 0; i < nslices; ++i) if (slices[i]) {
+        if (slices[i]->ctx != ctx) { g_last_error = "slice belongs to another context"; return BMX_ERR_BADARG; }
+        present |= 1u << i;
+    }
+    // unique non-zero values that can match at all; value 0 through the comparison kernel
+    std::vector<uint32_t> uniq; std::vector<int64_t> slot(n, -1);
+    {
+        std::unordered_map<uint32_t, uint32_t> seen;
+        bool zero_done = false; uint64_t zero_count = 0;
+        for (size_t q = 0; q < n; ++q) {
+            uint64_t v = values[q];
+            if (!v) {
+                if (!zero_done) { if ((rc = bmx_slice_compare(ctx, slices, nslices, BMX_CMP_EQ, 0, 0, size, not_null, nullptr, &zero_count))) return rc; zero_done = true; }
+                counts[q] = zero_count; continue;
+            }
+            if ((v >> 32) || ((uint32_t)v & ~present)) continue;                    // impossible value: 0 rows
+            auto it = seen.find((uint32_t)v);
+            if (it == seen.end()) { it = seen.emplace((uint32_t)v, (uint32_t)uniq.size()).first; uniq.push_back((uint32_t)v); }
+            slot[q] = it->second;
+        }
+    }
+    if (uniq.empty() || !ncols) return BMX_OK;
+    // planes holding GAP blocks are expanded to raw bits once (k_vec_expand); the others are read through their tables
+    EqPlanes pl; memset(&pl, 0, sizeof(pl));
+    std::vector<void*> temps;
+    auto free_temps = [&]() { for (void* t : temps) dfree(ctx, t); };
+    for (size_t i = 0; i < nslices; ++i) {
+        const bmx_vec* sv = slices[i];
+        if (!sv) continue;
+        pl.nblk[i] = sv->nblocks;
+        if (sv->counts[BMX_GAP]) {
+            void* raw = nullptr;
+            if ((rc = dmalloc(ctx, &raw, (size_t)ncols * 8192))) { free_temps(); return rc; }
+            temps.push_back(raw);
+            hipLaunchKernelGGL(k_vec_expand, dim3((ncols + 3) / 4), dim3(256), 0, ctx->stream, sv->d_desc, sv->nblocks, ncols, (uint4*)raw);
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) { (void)hipStreamSynchronize(ctx->stream); free_temps(); return fail_hip(e, "k_vec_expand", __LINE__); }
+            pl.raw[i] = (const uint4*)raw;
+        } else pl.desc[i] = sv->d_desc;
+    }
+    std::vector<uint64_t> ucount(uniq.size(), 0);
+    const size_t CHUNK = 2048;
+    for (size_t u0 = 0; u0 < uniq.size() && !rc; u0 += CHUNK) {
+        const uint32_t nv = (uint32_t)std::min(CHUNK, uniq.size() - u0);
+        uint32_t tab = 64; while (tab < 2u * nv) tab <<= 1;
+        uint32_t shift = 32; for (uint32_t t = tab; t > 1; t >>= 1) --shift;
+        // host-built open-addressing table: [keys u32 x tab][idx u16 x tab]
+        std::vector<uint32_t> blob(tab + tab / 2, 0);
+        uint32_t* keys = blob.data(); uint16_t* idx = reinterpret_cast<uint16_t*>(blob.data() + tab);
+        for (uint32_t k = 0; k < nv; ++k) {
+            uint32_t v = uniq[u0 + k], h = (v * 0x9E3779B1u) >> shift;
+            while (keys[h]) h = (h + 1u) & (tab - 1u);
+            keys[h] = v; idx[h] = (uint16_t)k;
+        }
+        void* d_tab = nullptr; void* d_cnt = nullptr;
+        if ((rc = dmalloc(ctx, &d_tab, blob.size() * 4)) || (rc = dmalloc(ctx, &d_cnt, (size_t)nv * 8))) { dfree(ctx, d_tab); break; }
+        rc = h2d_staged(ctx, d_tab, blob.data(), blob.size() * 4);
+        hipError_t e = rc ? hipSuccess : hipMemsetAsync(d_cnt, 0, (size_t)nv * 8, ctx->stream);
+        if (!rc && e == hipSuccess) {
+            size_t lds = (size_t)tab * 4 + (size_t)nv * 4 + EQ_FILTER_WORDS * 4 + 4 * EQ_QUEUE * 4 + (size_t)tab * 2;
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_slice_eq_counts), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e == hipSuccess) {
+                u32 grid = std::min<u32>((ncols + 3u) / 4u, 512u);
+                hipLaunchKernelGGL(k_slice_eq_counts, dim3(grid), dim3(256), lds, ctx->stream, pl, (u32)nslices, ncols, size,
+                                   (const u32*)d_tab, (const u16*)((const u32*)d_tab + tab), tab, shift, nv, (u64*)d_cnt);
+                e = hipGetLastError();
+            }
+            if (e == hipSuccess) e = hipMemcpyAsync(ucount.data() + u0, d_cnt, (size_t)nv * 8, hipMemcpyDeviceToHost, ctx->stream);
+        }
+        hipError_t e2 = hipStreamSynchronize(ctx->stream);
+        dfree(ctx, d_tab); dfree(ctx, d_cnt);
+        if (!rc && (e != hipSuccess || e2 != hipSuccess)) rc = fail_hip(e != hipSuccess ? e : e2, "bmx_slice_eq_counts", __LINE__);
+    }
+    (void)hipStreamSynchronize(ctx->stream);
+    free_temps();
+    if (rc) return rc;
+    for (size_t q = 0; q < n; ++q) if (slot[q] >= 0) counts[q] = ucount[(size_t)slot[q]];
+    return BMX_OK;
+}
+
 // ---------------------------------------------------------------------------
 // rank / select
 // ---------------------------------------------------------------------------

@@ -562,6 +562,37 @@ int bmx_gslice_compare(bmx_group* g, const bmx_gvec* const* slices, size_t nslic
     return BMX_OK;
 }
 
+// bmx_slice_eq_counts over sharded bit-planes: every member counts over its own rows, the counts are summed
+int bmx_gslice_eq_counts(bmx_group* g, const bmx_gvec* const* slices, size_t nslices, const uint64_t* values, size_t n,
+                         uint64_t size, const bmx_gvec* not_null, uint64_t* counts)
+{
+    ARGCHK(g && (nslices == 0 || slices) && (n == 0 || (values && counts)));
+    uint32_t nblocks = 0xFFFFFFFFu;
+    for (size_t i = 0; i < nslices; ++i) {
+        if (!slices[i]) continue;
+        if (slices[i]->g != g) { bmx_set_last_error("slice belongs to another group"); return BMX_ERR_BADARG; }
+        if (nblocks == 0xFFFFFFFFu) nblocks = slices[i]->nblocks;
+        else if (nblocks != slices[i]->nblocks) { bmx_set_last_error("sharded planes must cover the same block range (upload them with the same nblocks)"); return BMX_ERR_BADARG; }
+    }
+    uint64_t need = (size + BMX_BLOCK_BITS - 1) / BMX_BLOCK_BITS;
+    if (nblocks == 0xFFFFFFFFu) nblocks = (uint32_t)need;
+    if (need != nblocks || (not_null && (not_null->g != g || not_null->nblocks != nblocks))) {
+        bmx_set_last_error("size / not-NULL vector must span the block range of the planes"); return BMX_ERR_BADARG;
+    }
+    for (size_t q = 0; q < n; ++q) counts[q] = 0;
+    std::vector<std::vector<uint64_t>> part((size_t)g->n, std::vector<uint64_t>(std::max<size_t>(n, 1), 0));
+    int rc = for_each_member(g, [&](int m) -> int {
+        uint32_t lo, hi; shard_range(nblocks, m, g->n, &lo, &hi);
+        std::vector<const bmx_vec*> sl(std::max<size_t>(nslices, 1), nullptr);
+        for (size_t i = 0; i < nslices; ++i) sl[i] = slices[i] ? slices[i]->shard[(size_t)m] : nullptr;
+        return bmx_slice_eq_counts(g->ctx[(size_t)m], sl.data(), nslices, values, n, shard_bits(size, lo, hi),
+                                   not_null ? not_null->shard[(size_t)m] : nullptr, part[(size_t)m].data());
+    });
+    if (rc) return rc;
+    for (int m = 0; m < g->n; ++m) for (size_t q = 0; q < n; ++q) counts[q] += part[(size_t)m][q];
+    return BMX_OK;
+}
+
 int bmx_gpipeline_destroy(bmx_group* g, bmx_gpipeline* p)
 {
     if (!p) return BMX_OK;

@@ -191,6 +191,12 @@ int bmx_agg_shift_right_and_count(bmx_ctx* ctx, const bmx_vec* const* src, size_
 int bmx_slice_compare(bmx_ctx* ctx, const bmx_vec* const* slices, size_t nslices, int pred, uint64_t v0, uint64_t v1,
                       uint64_t size, const bmx_vec* not_null, bmx_vec** result, uint64_t* count);
 
+/* a batch of equality searches, counts only: counts[q] = rows equal to values[q] -- what n pipelined AND-SUB groups of
+ * prepare_and_sub_aggregator compute (src/bmsparsevec_algo.h:2593-2640,3236,3408), in ONE pass over the planes whatever n is
+ * (bit-matrix transposition + hash lookup, bmx_kernels4.h).  nslices <= 32 (else BMX_ERR_RANGE: use the pipeline form). */
+int bmx_slice_eq_counts(bmx_ctx* ctx, const bmx_vec* const* slices, size_t nslices, const uint64_t* values, size_t n,
+                        uint64_t size, const bmx_vec* not_null, uint64_t* counts);
+
 /* aggregator::pipeline<agg_opt_only_counts>  src/bmaggregator.h:62-103,222-341:
  * arg-groups are given as concatenated operand lists, and_n[g] / sub_n[g] per
  * group (pipeline::add() + arg_groups::add(bv, 0|1) + complete(), :2784-2931).
@@ -320,6 +326,9 @@ int bmx_gfind_first_and_sub(bmx_group* g, const bmx_gvec* const* src_and, size_t
  * span the same block range; result sharded like the planes; count = sum over the members */
 int bmx_gslice_compare(bmx_group* g, const bmx_gvec* const* slices, size_t nslices, int pred, uint64_t v0, uint64_t v1,
                        uint64_t size, const bmx_gvec* not_null, bmx_gvec** result, uint64_t* count);
+/* bmx_slice_eq_counts over sharded bit-planes (same conditions as bmx_gslice_compare) */
+int bmx_gslice_eq_counts(bmx_group* g, const bmx_gvec* const* slices, size_t nslices, const uint64_t* values, size_t n,
+                         uint64_t size, const bmx_gvec* not_null, uint64_t* counts);
 /* aggregator::pipeline + combine_and_sub(pipe), counts only (src/bmaggregator.h:1292-1399): member m runs the
  * pipeline over its shard of every operand, counts_out[g] = sum over the members */
 int bmx_gpipeline_create(bmx_group* g,

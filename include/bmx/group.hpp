@@ -290,6 +290,9 @@ template <> struct scanner_traits<gbvector> {
     static int compare(ctx_type& g, const handle_type* const* h, size_t n, int pred, uint64_t v0, uint64_t v1, uint64_t size,
                        const handle_type* nn, handle_type** r, uint64_t* cnt)
     { return bmx_gslice_compare(g.handle(), h, n, pred, v0, v1, size, nn, r, cnt); }
+    static int eq_counts(ctx_type& g, const handle_type* const* h, size_t n, const uint64_t* values, size_t nv, uint64_t size,
+                         const handle_type* nn, uint64_t* counts)
+    { return bmx_gslice_eq_counts(g.handle(), h, n, values, nv, size, nn, counts); }
 };
 typedef basic_slice_scanner<gbvector> gslice_scanner;
 

@@ -35,6 +35,9 @@ template <> struct scanner_traits<bvector> {
     static int compare(ctx_type& c, const handle_type* const* h, size_t n, int pred, uint64_t v0, uint64_t v1, uint64_t size,
                        const handle_type* nn, handle_type** r, uint64_t* cnt)
     { return bmx_slice_compare(c.handle(), h, n, pred, v0, v1, size, nn, r, cnt); }
+    static int eq_counts(ctx_type& c, const handle_type* const* h, size_t n, const uint64_t* values, size_t nv, uint64_t size,
+                         const handle_type* nn, uint64_t* counts)
+    { return bmx_slice_eq_counts(c.handle(), h, n, values, nv, size, nn, counts); }
 };
 
 /// BV = bmx::bvector (one device, `slice_scanner`) or bmx::gbvector (a device group, `gslice_scanner` in group.hpp:
@@ -87,9 +90,19 @@ public:
         return agg_.find_first_and_sub(idx, g.arg_bv0.data(), g.arg_bv0.size(), g.arg_bv1.data(), g.arg_bv1.size());
     }
 
-    /// counts[q] = number of rows equal to values[q] (every value != 0): one pipeline, one launch
-    void find_eq_counts(const uint64_t* values, size_t n, uint64_t* counts)
+    /// counts[q] = number of rows equal to values[q].  Up to 32 planes: ONE pass over the planes whatever n is
+    /// (bmx_slice_eq_counts: bit-matrix transposition + hash lookup); more planes, or use_pipeline: one AND-SUB group
+    /// per value in one counts-only pipeline (the reference's formulation, :3236,3408)
+    void find_eq_counts(const uint64_t* values, size_t n, uint64_t* counts, bool use_pipeline = false)
     {
+        if (!use_pipeline && slices_.size() <= 32) {
+            typedef typename traits::handle_type handle_type;
+            std::vector<const handle_type*> h(slices_.size() ? slices_.size() : 1, nullptr);
+            for (size_t i = 0; i < slices_.size(); ++i) h[i] = slices_[i] ? slices_[i]->handle() : nullptr;
+            check(traits::eq_counts(*ctx_, h.data(), slices_.size(), values, n, size_,
+                                    (not_null_ && !not_null_->empty_handle()) ? not_null_->handle() : nullptr, counts));
+            return;
+        }
         typedef typename aggregator<bvector>::template pipeline<agg_opt_only_counts> pipe_t;
         pipe_t pipe(*ctx_);
         std::vector<size_t> slot(n, ~size_t(0));

@@ -186,7 +186,10 @@ int main()
             vals.push_back(v); ref_counts.push_back(r.count());
         }
         got.resize(vals.size());
-        gs.find_eq_counts(vals.data(), vals.size(), got.data());
+        gs.find_eq_counts(vals.data(), vals.size(), got.data());                     // one pass: transposition + hash lookup
+        REQUIRE(got == ref_counts);
+        std::fill(got.begin(), got.end(), ~0ull);
+        gs.find_eq_counts(vals.data(), vals.size(), got.data(), true);               // one AND-SUB group per value (pipeline)
         REQUIRE(got == ref_counts);
         // range search: find_gt / find_ge / find_lt / find_le / find_range / find_zero / find_nonzero / find_eq(0)
         // vs the real scanner (src/bmsparsevec_algo.h:1135-1174, 2290, 2690-2880, 4464), with and without NULLs

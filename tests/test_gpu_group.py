@@ -165,7 +165,8 @@ def test_group_slice_scanner(ctx, port, members):
         assert (bits_of(gsc.find_range(0, 50)) == ((col <= 50) & valid)).all()
         assert (bits_of(gsc.find_zero()) == ((col == 0) & valid)).all() and (bits_of(gsc.find_nonzero()) == (col != 0)).all()
         vals = [int(x) for x in rng.choice(col[col > 0], 20)] + [0, 4095, 1 << 20]
-        assert (gsc.find_eq_counts(vals) == ssc.find_eq_counts(vals)).all()
+        assert (gsc.find_eq_counts(vals) == ssc.find_eq_counts(vals, method="pipeline")).all()
+        assert (gsc.find_eq_counts(vals, method="pipeline") == ssc.find_eq_counts(vals)).all()
         assert (gsc.find_eq_counts(vals) == np.array([int(((col == np.uint64(x)) & (valid if x == 0 else True)).sum()) for x in vals], np.uint64)).all()
         ff = gsc.find_first_eq(vals[0])
         assert ff == ssc.find_first_eq(vals[0]) == (True, int(np.flatnonzero(col == np.uint64(vals[0]))[0]))

@@ -910,6 +910,55 @@ def test_slice_scanner_vs_numpy(ctx):
     assert sc.find_eq_counts([0, 7, 0]).tolist() == [int((col == 0).sum()), int((col == 7).sum()), int((col == 0).sum())]
 
 
+@pytest.mark.parametrize("case", ["dense12", "wide32", "gap_planes"])
+def test_batched_equality_counts_by_transposition(ctx, case):
+    """find_eq_counts in one pass over the planes (bmx_slice_eq_counts: bit-matrix transposition + hash lookup) against
+    the reference's formulation (one AND-SUB group per query, pipeline) and numpy: duplicates, value 0 with NULL
+    elements, values with a bit above every plane / in an absent plane, rows past size(), planes of every block kind
+    (GAP planes are expanded first), more unique values than one launch takes (2048)"""
+    rng = np.random.default_rng({"dense12": 31, "wide32": 32, "gap_planes": 33}[case])
+    n = 6 * 65536 + 1234
+    if case == "dense12":
+        col = rng.integers(0, 4000, size=n).astype(np.uint64); nplanes = 12
+    elif case == "wide32":
+        col = np.where(rng.random(n) < 0.3, rng.integers(1, 1 << 32, size=n), rng.integers(0, 50, size=n)).astype(np.uint64); nplanes = 32
+    else:   # long runs of equal values: GAP / FULL / NULL plane blocks
+        col = np.repeat(rng.integers(0, 64, size=n // 499 + 1), 499)[:n].astype(np.uint64); nplanes = 7
+        col[65536:2 * 65536] = 63                                      # FULL blocks in the low planes
+    col &= ~np.uint64(1 << 5)                                           # plane 5 is absent
+    notnull = rng.random(n) < 0.9
+    col[~notnull] = 0
+    def upload(bits):
+        w = np.packbits(np.concatenate([bits.astype(np.uint8), np.zeros((-n) % 32, np.uint8)]), bitorder="little").view(np.uint32)
+        return bm.bit_import_u32(ctx, w, True)
+    slices = []
+    for b in range(nplanes):
+        bits = ((col >> np.uint64(b)) & np.uint64(1)).astype(bool)
+        slices.append(upload(bits) if bits.any() else None)
+    assert slices[5] is None
+    if case == "gap_planes":
+        assert any(s is not None and s.calc_stat()["gap_blocks"] for s in slices)
+    nn = upload(notnull)
+    present = [int(x) for x in rng.choice(col[col > 0], 40)]
+    vals = present + [0, 1, 2, 32, 33, (1 << nplanes) - 1, 1 << nplanes, (1 << 40) + 3, present[0], 0, present[1]]
+    for size, with_null in ((n, False), (n, True), (n - 70000, True), (65536, False)):
+        sc = bm.slice_scanner(ctx, slices, size=size, not_null=nn if with_null else None)
+        valid = (notnull if with_null else np.ones(n, bool))[:size]
+        c = col[:size]
+        exp = [int(((c == np.uint64(v)) & (valid if v == 0 else True)).sum()) if v < (1 << 63) else 0 for v in vals]
+        got_t = sc.find_eq_counts(vals, method="transpose")
+        assert got_t.tolist() == exp, (case, size, with_null)
+        if size == n:            # (the group formulation has no notion of size(): a real container holds no bits past it)
+            assert sc.find_eq_counts(vals, method="pipeline").tolist() == exp, (case, with_null)
+    # more unique values than one launch takes: every distinct value of the column + misses
+    sc = bm.slice_scanner(ctx, slices, size=n)
+    uniq, cnts = np.unique(col, return_counts=True)
+    many = [int(v) for v in uniq[uniq > 0]][:5000] + [int(x) for x in rng.integers(1, 1 << min(nplanes, 31), size=3000)]
+    lut = {int(v): int(k) for v, k in zip(uniq, cnts)}
+    got = sc.find_eq_counts(many)
+    assert got.tolist() == [lut.get(v, 0) for v in many]
+
+
 def _bits_of(t, n):
     return np.unpackbits(t.to_words((n + 31) // 32).view(np.uint8), bitorder="little")[:n].astype(bool)
 

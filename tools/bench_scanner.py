@@ -17,8 +17,10 @@ ctx = bm.context(0, s.cuda_stream)
 planes = [bm.bvector.generate(ctx, 0xB17A61C, 500 + i, 32768, a.nbits) for i in range(a.planes)]   # 50 % planes
 rng = np.random.default_rng(3)
 pipe = bm.aggregator.pipeline(ctx)
+xs = []
 for g in range(a.groups):
     x = int(rng.integers(0, 1 << min(a.planes, 62)))
+    xs.append(x)
     ag = pipe.add()
     for i in range(a.planes):
         ag.add(planes[i], 0 if (x >> (i % 62)) & 1 else 1)
@@ -43,9 +45,23 @@ for staged, swz, slots in ((0, 1, 16), (1, 1, 16), (1, 1, 8)):
                       "unique_operand_GB": round(a.planes * a.nbits / 8e9, 2), "queries_per_s": round(a.groups / ms * 1e3, 1),
                       "nonzero_groups": int((counts > 0).sum().item())}))
 
-# ---- range search (find_gt / find_le / find_range / find_zero): one pass over the planes (bmx_slice_compare) ----
+# ---- the same batch of equality searches in ONE pass over the planes: bit-matrix transposition + hash lookup ----
 import time
 sc = bm.slice_scanner(ctx, planes, size=a.nbits)
+if a.planes <= 32:
+    for nq in (a.groups, 2048, 8192):
+        q = xs[:nq] if nq <= len(xs) else xs + [int(v) for v in rng.integers(1, 1 << a.planes, size=nq - len(xs))]
+        got = sc.find_eq_counts(q)
+        ctx.synchronize()
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter(); got = sc.find_eq_counts(q); ts.append((time.perf_counter() - t0) * 1e3)
+        ok = bool((np.asarray(got[:len(xs)], np.int64) == ref_counts.cpu().numpy()[:min(nq, len(xs))]).all()) if all(x > 0 for x in xs) else None
+        print(json.dumps({"pattern": "scanner_transposed", "planes": a.planes, "queries": nq, "nbits": a.nbits, "host_call_ms": round(min(ts), 3),
+                          "queries_per_s": round(nq / min(ts) * 1e3, 1), "plane_GB": round(a.planes * a.nbits / 8e9, 2),
+                          "plane_TBps": round(a.planes * a.nbits / 8 / min(ts) / 1e9 * (1 + (nq - 1) // 2048), 2), "counts_equal_pipeline": ok}))
+
+# ---- range search (find_gt / find_le / find_range / find_zero): one pass over the planes (bmx_slice_compare) ----
 plane_bytes = a.planes * ((a.nbits + 65535) // 65536) * 8192
 for name, fn, cnt_fn in (("find_gt", lambda v: sc.find_gt(v), lambda v: sc.count(bm.CMP_GT, v)),
                          ("find_le", lambda v: sc.find_le(v), lambda v: sc.count(bm.CMP_LE, v)),
