@@ -123,6 +123,37 @@ for seed in range(60):
     if not ok: bad += 1; print("FAIL group rank/select", seed, nblk)
     del grs, g
 grp.close()
+# batched equality counts by transposition (bmx_slice_eq_counts) vs numpy: random plane counts, value distributions
+# (dense / sparse / runs => BIT, GAP, FULL, NULL, absent planes), sizes that end inside a block, NULL elements
+for seed in range(120):
+    rng = np.random.default_rng(97000 + seed)
+    nplanes = int(rng.integers(1, 33))
+    n = int(rng.integers(1, 5 * 65536))
+    kind = seed % 4
+    hi = 1 << nplanes
+    if kind == 0: col = rng.integers(0, hi, size=n)
+    elif kind == 1: col = np.where(rng.random(n) < 0.02, rng.integers(0, hi, size=n), 0)
+    elif kind == 2: col = np.repeat(rng.integers(0, hi, size=n // 700 + 1), 700)[:n]
+    else: col = rng.integers(0, min(hi, 50), size=n)
+    col = col.astype(np.uint64)
+    notnull = rng.random(n) < 0.95
+    col[~notnull] = 0
+    def up(bits):
+        w = np.packbits(np.concatenate([bits.astype(np.uint8), np.zeros((-n) % 32, np.uint8)]), bitorder="little").view(np.uint32)
+        return bm.bit_import_u32(ctx, w, True)
+    sl = []
+    for b in range(nplanes):
+        bits = ((col >> np.uint64(b)) & np.uint64(1)).astype(bool)
+        sl.append(up(bits) if bits.any() else None)
+    nn = up(notnull)
+    size = n if seed % 3 else max(1, n - int(rng.integers(0, min(n, 70000))))
+    with_null = bool(seed % 2)
+    sc = bm.slice_scanner(ctx, sl, size=size, not_null=nn if with_null else None)
+    c = col[:size]; valid = (notnull if with_null else np.ones(n, bool))[:size]
+    pool = [int(x) for x in rng.choice(c, min(30, c.size))] + [0, 1, hi - 1, hi, (1 << 33) + 1] + [int(x) for x in rng.integers(0, hi, size=20)]
+    exp = [int(((c == np.uint64(v)) & (valid if v == 0 else True)).sum()) for v in pool]
+    got = sc.find_eq_counts(pool, method="transpose").tolist()
+    if got != exp: bad += 1; print("FAIL eq_counts", seed, nplanes, n, size, kind, with_null)
 print("soak done, failures:", bad)
 PY
 timeout 1200 python /tmp/soak.py > gpurun_out/soak.log 2>&1; tail -6 gpurun_out/soak.log
