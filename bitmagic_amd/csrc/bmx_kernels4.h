@@ -141,10 +141,11 @@ void k_slice_compare(const u64* const* __restrict__ descs /* per plane: descript
 // plane block is read ONCE whatever the number of queries; the result is the same multiset count the groups compute
 // (value 0 is not handled here: NULL elements are stored as 0, the host routes it through k_slice_compare).
 // A wave owns a block column at a time (persistent grid); GAP planes are expanded to raw bits beforehand (raw[p]).
-// Register allocation decides the speed here (247 VGPRs = two waves per SIMD): fully coalesced 8-byte loads (512 B per
-// wave load instead of 8 B at a 16-byte stride) made the compiler keep a second set of plane words in flight -- 304 VGPRs,
-// or 196 B of spills when capped -- and measured 2.5-2.7 ms against 1.67 ms.
-// ---------------------------------------------------------------------------
+// Register allocation decides the speed here (245 VGPRs = two waves per SIMD; PMC: VALU busy 55 %, 43 % of the wave
+// cycles waiting, LDS ~20 %): 8-byte loads with 512 B per wave load made the compiler keep a second set of plane words in
+// flight (304 VGPRs, or 196 B of spills when capped) and measured 2.5-2.7 ms against 1.65 ms; capping at three waves per
+// SIMD (amdgpu_waves_per_eu: 284 B of spills) measured 5.0 ms.  4-byte loads (256 B per wave load, this form) and 8-byte
+// loads at a 16-byte stride run at the same 1.65 ms.
 struct EqPlanes { const u64* desc[32]; const uint4* raw[32]; u32 nblk[32]; };
 
 __device__ __forceinline__ void bit_transpose32(u32 (&a)[32])
@@ -213,21 +214,17 @@ void k_slice_eq_counts(EqPlanes pl, u32 nplanes, u32 ncols, u64 size, const u32*
         const u64 row0 = (u64)c << 16;
         const u32 lim = size <= row0 ? 0u : (size - row0 >= 65536ull ? 65536u : (u32)(size - row0));
 #pragma unroll 1
-        for (u32 ih = 0; ih < 16u; ++ih) {                          // register row i = ih / 2, words 2 * (ih & 1) .. + 1 of every lane's quad
-            const u32 i = ih >> 1, half = ih & 1u;
-            u32x2 q[32];
-#pragma unroll
-            for (int p = 0; p < 32; ++p) {
-                if (base[p] > 1ull) q[p] = __builtin_nontemporal_load((gcptr2)(uintptr_t)base[p] + (i * 64u + lane) * 2u + half);
-                else q[p] = (u32x2)(base[p] ? ~0u : 0u);
-            }
-#pragma unroll 1
-            for (u32 jj = 0; jj < 2u; ++jj) {
+        for (u32 k = 0; k < 32u; ++k) {                             // step k: word k * 64 + lane of every plane block (256 B per wave load)
+            {
                 u32 a[32];
                 u32 any = 0u;
 #pragma unroll
-                for (int p = 0; p < 32; ++p) { a[p] = jj == 0u ? q[p].x : q[p].y; any |= a[p]; }
-                const u32 wb = ((i * 256u + lane * 4u + half * 2u + jj) << 5);          // first row of this word inside the block
+                for (int p = 0; p < 32; ++p) {
+                    if (base[p] > 1ull) a[p] = __builtin_nontemporal_load((const __attribute__((address_space(1))) u32*)(uintptr_t)base[p] + k * 64u + lane);
+                    else a[p] = base[p] ? ~0u : 0u;
+                    any |= a[p];
+                }
+                const u32 wb = ((k * 64u + lane) << 5);                               // first row of this word inside the block
                 const u32 vm = lim >= wb + 32u ? ~0u : (lim <= wb ? 0u : ((1u << (lim - wb)) - 1u));
                 if (__ballot((any & vm) != 0u) == 0ull) continue;          // 2,048 rows of zeros: nothing to look up
                 bit_transpose32(a);
@@ -251,7 +248,7 @@ void k_slice_eq_counts(EqPlanes pl, u32 nplanes, u32 ncols, u64 size, const u32*
                         u32 v = a[r];
                         if ((f[r] & 1u) && v != 0u && ((vm >> r) & 1u)) {
                             u32 h = (v * 0x9E3779B1u) >> shift;
-                            for (;;) { u32 k = keys[h]; if (k == v) { atomicAdd(&cnt[idx[h]], 1u); break; } if (k == 0u) break; h = (h + 1u) & tmask; }
+                            for (;;) { u32 kk = keys[h]; if (kk == v) { atomicAdd(&cnt[idx[h]], 1u); break; } if (kk == 0u) break; h = (h + 1u) & tmask; }
                         }
                     }
                     continue;
@@ -262,7 +259,7 @@ void k_slice_eq_counts(EqPlanes pl, u32 nplanes, u32 ncols, u64 size, const u32*
                     if (b + lane < nq) {
                         u32 v = myq[b + lane];
                         u32 h = (v * 0x9E3779B1u) >> shift;
-                        for (;;) { u32 k = keys[h]; if (k == v) { atomicAdd(&cnt[idx[h]], 1u); break; } if (k == 0u) break; h = (h + 1u) & tmask; }
+                        for (;;) { u32 kk = keys[h]; if (kk == v) { atomicAdd(&cnt[idx[h]], 1u); break; } if (kk == 0u) break; h = (h + 1u) & tmask; }
                     }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
