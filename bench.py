@@ -171,8 +171,16 @@ def setup_dist(args):
     # launched by torch.distributed.run (RANK set): always go through RCCL, also for a 1-rank job, so the
     # collective path is exercised wherever the launcher is used
     use_dist = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)
+    # test hook (tools/gpu_runs: exercising the N > 1 code path on a ONE-GPU box): every rank on device 0, gloo instead of RCCL
+    # (RCCL refuses two ranks on one device).  Timings of such a run mean nothing; it checks sharding, gathers and the JSON line.
+    one_dev = os.environ.get("BMX_BENCH_TEST_ONE_DEVICE") == "1"
+    if one_dev:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
-    if use_dist:
+    if use_dist and one_dev:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    elif use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # RCCL prints a version banner on STDOUT when its first communicator comes up: keep stdout for the ONE JSON line
         # (the banner goes to stderr) by creating the communicator -- init + a first all-reduce -- under a redirect
@@ -232,7 +240,7 @@ def event_avg_ms(fn, reps, ctx):
 def gather_floats(x: float, use_dist, world):
     import torch
     import torch.distributed as dist
-    t = torch.tensor([x], dtype=torch.float64, device="cuda")
+    t = torch.tensor([x], dtype=torch.float64, device="cpu" if os.environ.get("BMX_BENCH_TEST_ONE_DEVICE") == "1" else "cuda")
     if not use_dist:
         return [float(x)]
     out = [torch.zeros_like(t) for _ in range(world)]
