@@ -57,6 +57,7 @@ struct bmx_ctx {
     int direct_cols = 384;     // aggregation over <= this many block columns and 24..1024 operands: one launch from the descriptor tables (k_direct); 0 = off
     int pair_stream = -1;      // bm::count_* over two all-bit-block vectors: streaming kernel with this many waves per workgroup (-1 = 4, 0 = the column-per-wave kernel)
     int pair_wgs = 1;          // ... and this many workgroups per CU
+    int gap_count = -1;        // GAP-only counts pipelines: counting formulation (k_pipe_counts_gapcount): -1 = automatic, 0 = off, 1 = force
     int ff_window = 0;         // find_first_and_sub: block columns of the FIRST launch window (each next one is 4x larger): 0 = automatic, -1 = one launch
     int or_window = 0;         // column tiles per launch of k_agg_or_gap_tiled: 0 / -1 = all in one launch (windows measured: no gain)
     int xcd_swz = 1;
@@ -75,6 +76,8 @@ struct bmx_pipeline {
     bmx_ctx* ctx;
     uint32_t ngroups, ncols, col_stride, n_ops;
     bool has_gap;
+    bool has_bit = false;      // any operand vector holds a bit-block
+    uint32_t gap_avg_words = 0;  // average GAP block size of the operands (16-bit words incl. padding)
     uint64_t nbits;                       // max size of the operands
     // LDS-staged path (k_pipe_counts_staged): distinct vectors ("planes") + per-group plane masks
     uint32_t nplanes, nchunks; bool staged_ok;

@@ -652,6 +652,51 @@ def test_find_first_launch_windows(ctx, port, nops, agg_path):
         agg.reset_range_hint()
 
 
+@pytest.mark.parametrize("dq,nvec,nsub", [(200, 40, 0), (60, 300, 0), (300, 64, 9), (350, 33, 3), (13, 257, 2), (65500, 36, 1)])
+def test_gap_only_pipeline_counting_formulation(ctx, port, dq, nvec, nsub):
+    """counts pipelines whose operands hold no bit-block take the counting formulation (k_pipe_counts_gapcount: byte
+    counters of 1-run starts / ends per position + one prefix scan, cover == n): same counts as the run-by-run kernel
+    (gap_count 0) and the oracle; more than 255 operands (two counting chunks), SUB groups, FULL / NULL blocks, dense GAP
+    (long 1-runs), several groups in one pipeline, block-range runs"""
+    nblk = 5
+    nbits = nblk * 65536 - 333
+    rng = np.random.default_rng(dq + nvec)
+    common = port.gen_words(5150, 0xFFFFFFFF, max(dq // 2, 3), nbits)
+    words = []
+    for v in range(nvec + nsub):
+        w = port.gen_words(5150, v, dq, nbits)
+        if v < nvec: w |= common                                        # the AND survives
+        if v % 11 == 5: w[2048:4096] = 0xFFFFFFFF                       # FULL block
+        if v % 13 == 7 and v >= nvec: w[3 * 2048:4 * 2048] = 0          # NULL block in a SUB operand
+        words.append(w)
+    gv = [bm.bit_import_u32(ctx, w, True) for w in words]
+    pv = [port.import_words(w, True, nbits) for w in words]
+    assert all(v.calc_stat()["bit_blocks"] == 0 for v in gv), "the case must stay GAP-only"
+    groups = [(list(range(nvec)), list(range(nvec, nvec + nsub))), (list(range(0, nvec, 2)), []), (list(range(nvec // 2)), list(range(nvec, nvec + nsub))[:1])]
+    exp = port.pipeline_counts([([pv[i] for i in a], [pv[i] for i in s]) for a, s in groups])
+    pipe = bm.aggregator.pipeline(ctx)
+    for a, s in groups:
+        ag = pipe.add()
+        for i in a: ag.add(gv[i], 0)
+        for i in s: ag.add(gv[i], 1)
+    pipe.complete()
+    agg = bm.aggregator(ctx)
+    try:
+        ctx.set_tuning("pipe_split", 0)                  # (few items with long lists would take the workgroup-split kernel)
+        for gc in (1, 0, -1):
+            ctx.set_tuning("gap_count", gc)
+            if gc == 1: assert "gapcount" in pipe.describe()
+            if gc == 0: assert "gapcount" not in pipe.describe()
+            got = agg.combine_and_sub(pipe)
+            assert (got == exp).all(), (gc, got, exp)
+            parts = sum(agg._run_pipeline(pipe, a, b).astype(np.int64) for a, b in [(0, 2), (2, 3), (3, nblk)])
+            assert (parts == exp.astype(np.int64)).all(), gc
+        ctx.set_tuning("pipe_split", -1); ctx.set_tuning("gap_count", -1)
+        assert (agg.combine_and_sub(pipe) == exp).all()   # default selection (workgroup-split kernel for so few items)
+    finally:
+        ctx.set_tuning("gap_count", -1); ctx.set_tuning("pipe_split", -1)
+
+
 @pytest.mark.parametrize("common_bits,own_dq,nvec", [(1, 30, 40), (40, 100, 70), (400, 100, 90), (520, 40, 36),
                                                      (700, 200, 50)])
 def test_sparse_state_of_gap_lists(ctx, port, common_bits, own_dq, nvec, agg_path):
