@@ -269,7 +269,7 @@ int bmx_ctx_create(int device, void* stream, bmx_ctx** out)
     // an invalid value is ignored (the default stays)
     static const char* const env_keys[][2] = {
         {"BMX_PIPE_UNROLL", "pipe_unroll"}, {"BMX_PIPE_ROWS", "pipe_rows"}, {"BMX_PIPE_NT", "pipe_nt"},
-        {"BMX_PIPE_WG", "pipe_wg"}, {"BMX_PIPE_WINDOW", "pipe_window"}, {"BMX_PIPE_SPLIT", "pipe_split"}, {"BMX_OR_TILE", "or_tile"}, {"BMX_OR_WINDOW", "or_window"}, {"BMX_DIRECT_COLS", "direct_cols"}, {"BMX_FF_WINDOW", "ff_window"}, {"BMX_GAP_COUNT", "gap_count"}, {"BMX_PAIR_STREAM", "pair_stream"}, {"BMX_PAIR_WGS", "pair_wgs"}, {"BMX_XCD_SWIZZLE", "xcd_swizzle"}};
+        {"BMX_PIPE_WG", "pipe_wg"}, {"BMX_PIPE_WINDOW", "pipe_window"}, {"BMX_PIPE_SPLIT", "pipe_split"}, {"BMX_OR_TILE", "or_tile"}, {"BMX_OR_WINDOW", "or_window"}, {"BMX_DIRECT_COLS", "direct_cols"}, {"BMX_FF_WINDOW", "ff_window"}, {"BMX_GAP_COUNT", "gap_count"}, {"BMX_RANGE_HALVES", "range_halves"}, {"BMX_PAIR_STREAM", "pair_stream"}, {"BMX_PAIR_WGS", "pair_wgs"}, {"BMX_XCD_SWIZZLE", "xcd_swizzle"}};
     for (auto& kv : env_keys)
         if (const char* e = getenv(kv[0])) (void)bmx_ctx_set_tuning(ctx, kv[1], atoi(e));
     g_last_error.clear();
@@ -318,6 +318,7 @@ int bmx_ctx_set_tuning(bmx_ctx* ctx, const char* key, int value)
     else if (k == "direct_cols") { ARGCHK(value >= 0); ctx->direct_cols = value; }
     else if (k == "pair_stream") { ARGCHK(value == -1 || value == 0 || value == 2 || value == 4 || value == 8); ctx->pair_stream = value; }
     else if (k == "pair_wgs") { ARGCHK(value >= 1 && value <= 8); ctx->pair_wgs = value; }
+    else if (k == "range_halves") { ARGCHK(value == 0 || value == 1); ctx->range_halves = value; }
     else if (k == "gap_count") { ARGCHK(value >= -1 && value <= 1); ctx->gap_count = value; }
     else if (k == "ff_window") { ARGCHK(value >= -1); ctx->ff_window = value; }
     else if (k == "or_window") { ARGCHK(value >= -9); ctx->or_window = value; }
@@ -1684,11 +1685,18 @@ int bmx_slice_compare(bmx_ctx* ctx, const bmx_vec* const* slices, size_t nslices
     hipError_t e = hipMemcpyAsync(d_descs, descs.data(), nal * 8, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d_nblk, nblk.data(), nal * 4, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) {
+        if (ctx->range_halves)                                              // half-block passes (half the accumulators, twice the waves)
+            hipLaunchKernelGGL(pred == BMX_CMP_RANGE ? k_slice_compare_halves<true> : k_slice_compare_halves<false>, dim3((ncols + 3) / 4), dim3(256), 0, ctx->stream,
+                               (const u64* const*)d_descs, (const u32*)d_nblk, (u32)nslices, ncols, pred, v0, v1, size,
+                               not_null ? (const u64*)not_null->d_desc : nullptr, not_null ? not_null->nblocks : 0u, null_correct,
+                               result ? 0 : 1, ctx->xcd_swz, v ? v->d_bits : nullptr, v ? v->d_desc : nullptr, st, ctx->d_slots);
+        else {
         auto cmp_fn = pred == BMX_CMP_RANGE ? k_slice_compare<true> : k_slice_compare<false>;
         hipLaunchKernelGGL(cmp_fn, dim3((ncols + 3) / 4), dim3(256), 0, ctx->stream,
                            (const u64* const*)d_descs, (const u32*)d_nblk, (u32)nslices, ncols, pred, v0, v1, size,
                            not_null ? (const u64*)not_null->d_desc : nullptr, not_null ? not_null->nblocks : 0u, null_correct,
                            result ? 0 : 1, ctx->xcd_swz, v ? v->d_bits : nullptr, v ? v->d_desc : nullptr, st, ctx->d_slots);
+        }
         e = hipGetLastError();
     }
     if (e == hipSuccess && !result) {

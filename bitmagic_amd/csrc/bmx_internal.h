@@ -57,6 +57,7 @@ struct bmx_ctx {
     int direct_cols = 384;     // aggregation over <= this many block columns and 24..1024 operands: one launch from the descriptor tables (k_direct); 0 = off
     int pair_stream = -1;      // bm::count_* over two all-bit-block vectors: streaming kernel with this many waves per workgroup (-1 = 4, 0 = the column-per-wave kernel)
     int pair_wgs = 1;          // ... and this many workgroups per CU
+    int range_halves = 1;      // comparison search in half-block passes (k_slice_compare_halves) instead of whole-block accumulators (k_slice_compare)
     int gap_count = -1;        // GAP-only counts pipelines: counting formulation (k_pipe_counts_gapcount): -1 = automatic, 0 = off, 1 = force
     int ff_window = 0;         // find_first_and_sub: block columns of the FIRST launch window (each next one is 4x larger): 0 = automatic, -1 = one launch
     int or_window = 0;         // column tiles per launch of k_agg_or_gap_tiled: 0 / -1 = all in one launch (windows measured: no gain)

@@ -1041,18 +1041,24 @@ def test_slice_scanner_range_search_vs_numpy(ctx, case):
         for v in bounds:
             V = np.uint64(v)
             exp = {"gt": col > V, "ge": (col >= V) & (valid if v == 0 else True), "lt": (col < V) & valid, "le": (col <= V) & valid}
-            got = {"gt": sc.find_gt(v), "ge": sc.find_ge(v), "lt": sc.find_lt(v), "le": sc.find_le(v)}
-            for k in exp:
-                assert (_bits_of(got[k], n) == exp[k]).all(), (case, with_null, k, v)
-                assert got[k].count() == int(np.count_nonzero(exp[k]))
+            for halves in (1, 0):                      # half-block passes (default) and the whole-block kernel
+                ctx.set_tuning("range_halves", halves)
+                got = {"gt": sc.find_gt(v), "ge": sc.find_ge(v), "lt": sc.find_lt(v), "le": sc.find_le(v)}
+                for k in exp:
+                    assert (_bits_of(got[k], n) == exp[k]).all(), (case, with_null, k, v, halves)
+                    assert got[k].count() == int(np.count_nonzero(exp[k]))
+            ctx.set_tuning("range_halves", 1)
             assert sc.count(bm.CMP_GT, v) == int((col > V).sum())
         for lo, hi in [(0, 0), (0, 10), (5, 5), (10, 3), (100, 3000), (1, (1 << 40)), (4000, 1 << 50)] + \
                       [tuple(int(x) for x in rng.choice(col[col > 0], 2)) for _ in range(3)]:
             a, b = min(lo, hi), max(lo, hi)
             exp = (col >= np.uint64(a)) & (col <= np.uint64(b)) & (valid if a == 0 else True)
-            t = sc.find_range(lo, hi)
-            assert (_bits_of(t, n) == exp).all(), (case, with_null, lo, hi)
-            assert sc.count(bm.CMP_RANGE, lo, hi) == int(exp.sum())
+            for halves in (1, 0):                      # half-block passes (default) and the four-accumulator kernel
+                ctx.set_tuning("range_halves", halves)
+                t = sc.find_range(lo, hi)
+                assert (_bits_of(t, n) == exp).all(), (case, with_null, lo, hi, halves)
+                assert sc.count(bm.CMP_RANGE, lo, hi) == int(exp.sum())
+            ctx.set_tuning("range_halves", 1)
         assert (_bits_of(sc.find_zero(), n) == ((col == 0) & valid)).all()
         assert (_bits_of(sc.find_nonzero(), n) == (col != 0)).all()
         t, f = sc.find_eq(0)
