@@ -136,22 +136,26 @@ void k_slice_compare(const u64* const* __restrict__ descs /* per plane: descript
 // walks the planes of its column twice, over register rows 0..3 and then 4..7 of every block: half the accumulators, the
 // same bytes read (two 4-KiB pieces per plane block instead of one 8-KiB piece), the "nobody is equal any more" exit per half.
 // Same result: the predicate is evaluated independently per row.
-__device__ __forceinline__ void part4_from_desc(u64 d, Part<4>& P, u32 h, u32* lds, u32 lane)
+template <int RP>
+__device__ __forceinline__ void part_from_desc(u64 d, Part<RP>& P, u32 h, u32* lds, u32 lane)
 {
     u32 k = DESC_K(d);
-    if (k == K_BIT) part_load<4, false>(P, as_gc4(DESC_P(d)) + h * 256u, lane);
+    if (k == K_BIT) part_load<RP, false>(P, as_gc4(DESC_P(d)) + h * (u32)RP * 64u, lane);
     else if (k == K_GAP) {
         Blk t;
         gap_decode(as_gc16(DESC_P(d)), lds, t, lane, GMETA(d));
 #pragma unroll
-        for (int i = 0; i < 4; ++i) P.r[i] = h ? t.r[4 + i] : t.r[i];
+        for (int i = 0; i < RP; ++i) {
+#pragma unroll
+            for (int q = 0; q < 8 / RP; ++q) if ((u32)q == h) P.r[i] = t.r[q * RP + i];
+        }
     } else {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) P.r[i] = (u32x4)(k == K_FULL ? ~0u : 0u);
+        for (int i = 0; i < RP; ++i) P.r[i] = (u32x4)(k == K_FULL ? ~0u : 0u);
     }
 }
 
-template <bool TWO>
+template <bool TWO, int RP>
 __global__ __launch_bounds__(256)
 void k_slice_compare_halves(const u64* const* __restrict__ descs, const u32* __restrict__ nblk, u32 nplanes, u32 ncols, int pred, u64 v0, u64 v1, u64 size,
                           const u64* __restrict__ nn_desc, u32 nn_blocks, int null_correct, int count_only, int xcd_swz,
@@ -170,10 +174,10 @@ void k_slice_compare_halves(const u64* const* __restrict__ descs, const u32* __r
         const u32 lim = size <= base ? 0u : (size - base >= 65536ull ? 65536u : (u32)(size - base));
         Blk out;
 #pragma unroll 1
-        for (u32 h = 0; h < 2u; ++h) {
-            Part<4> gt0, eq0, gt1, eq1;
+        for (u32 h = 0; h < (u32)(8 / RP); ++h) {
+            Part<RP> gt0, eq0, gt1, eq1;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { gt0.r[i] = (u32x4)(0u); gt1.r[i] = (u32x4)(0u); eq0.r[i] = (u32x4)(dead0 ? 0u : ~0u); eq1.r[i] = (u32x4)((TWO && !dead1) ? ~0u : 0u); }
+            for (int i = 0; i < RP; ++i) { gt0.r[i] = (u32x4)(0u); gt1.r[i] = (u32x4)(0u); eq0.r[i] = (u32x4)(dead0 ? 0u : ~0u); eq1.r[i] = (u32x4)((TWO && !dead1) ? ~0u : 0u); }
             bool live = !dead0 || (TWO && !dead1);
             for (u32 b = nplanes; b-- > 0u && live; ) {
                 const u64* dt = (const u64*)uniform64((u64)(uintptr_t)descs[b]);
@@ -181,27 +185,27 @@ void k_slice_compare_halves(const u64* const* __restrict__ descs, const u32* __r
                 u32 bit0 = (u32)(v0 >> b) & 1u, bit1 = (u32)(v1 >> b) & 1u;
                 if (DESC_K(d) == K_NULL) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) { if (bit0) eq0.r[i] = (u32x4)(0u); if (TWO && bit1) eq1.r[i] = (u32x4)(0u); }
+                    for (int i = 0; i < RP; ++i) { if (bit0) eq0.r[i] = (u32x4)(0u); if (TWO && bit1) eq1.r[i] = (u32x4)(0u); }
                 } else {
-                    Part<4> P;
-                    part4_from_desc(d, P, h, l, lane);
+                    Part<RP> P;
+                    part_from_desc<RP>(d, P, h, l, lane);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
+                    for (int i = 0; i < RP; ++i) {
                         if (bit0) eq0.r[i] &= P.r[i]; else { gt0.r[i] |= eq0.r[i] & P.r[i]; eq0.r[i] &= ~P.r[i]; }
                         if (TWO) { if (bit1) eq1.r[i] &= P.r[i]; else { gt1.r[i] |= eq1.r[i] & P.r[i]; eq1.r[i] &= ~P.r[i]; } }
                     }
                 }
                 u32 any = 0u;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) { u32x4 t = TWO ? (eq0.r[i] | eq1.r[i]) : eq0.r[i]; any |= t.x | t.y | t.z | t.w; }
+                for (int i = 0; i < RP; ++i) { u32x4 t = TWO ? (eq0.r[i] | eq1.r[i]) : eq0.r[i]; any |= t.x | t.y | t.z | t.w; }
                 live = __ballot(any != 0u) != 0ull;
             }
-            Part<4> res;                                                   // the predicate, inside [0, size), not NULL where 0 is admitted
-            Part<4> nn;
+            Part<RP> res;                                                   // the predicate, inside [0, size), not NULL where 0 is admitted
+            Part<RP> nn;
             bool use_nn = null_correct && nn_desc;
-            if (use_nn) part4_from_desc(nb < nn_blocks ? uniform64(nn_desc[nb]) : 0ull, nn, h, l, lane);
+            if (use_nn) part_from_desc<RP>(nb < nn_blocks ? uniform64(nn_desc[nb]) : 0ull, nn, h, l, lane);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < RP; ++i) {
                 u32x4 r;
                 switch (pred) {
                 case CMP_GT: r = gt0.r[i]; break;
@@ -212,7 +216,7 @@ void k_slice_compare_halves(const u64* const* __restrict__ descs, const u32* __r
                 case CMP_EQ: case CMP_ZERO: r = eq0.r[i]; break;
                 default: r = ~eq0.r[i]; break;                              // NONZERO
                 }
-                u32 w0 = (((h * 4u + (u32)i) * 256u + lane * 4u) << 5);    // first row of word .x
+                u32 w0 = (((h * (u32)RP + (u32)i) * 256u + lane * 4u) << 5);    // first row of word .x
                 u32 ws[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { u32 lo = w0 + (u32)j * 32u; ws[j] = lim >= lo + 32u ? ~0u : (lim <= lo ? 0u : ((1u << (lim - lo)) - 1u)); }
@@ -223,11 +227,14 @@ void k_slice_compare_halves(const u64* const* __restrict__ descs, const u32* __r
             if (count_only) {
                 u32 c = 0;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) { c += __popcll(((u64)res.r[i].y << 32) | res.r[i].x); c += __popcll(((u64)res.r[i].w << 32) | res.r[i].z); }
+                for (int i = 0; i < RP; ++i) { c += __popcll(((u64)res.r[i].y << 32) | res.r[i].x); c += __popcll(((u64)res.r[i].w << 32) | res.r[i].z); }
                 cnt += c;
             } else {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) { if (h) out.r[4 + i] = res.r[i]; else out.r[i] = res.r[i]; }
+                for (int i = 0; i < RP; ++i) {
+#pragma unroll
+                    for (int q = 0; q < 8 / RP; ++q) if ((u32)q == h) out.r[q * RP + i] = res.r[i];
+                }
             }
         }
         if (count_only) cnt = wave_sum(cnt);
