@@ -1685,13 +1685,14 @@ int bmx_slice_compare(bmx_ctx* ctx, const bmx_vec* const* slices, size_t nslices
     hipError_t e = hipMemcpyAsync(d_descs, descs.data(), nal * 8, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d_nblk, nblk.data(), nal * 4, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) {
-        if (ctx->range_halves)                                              // half-block passes (half the accumulators, twice the waves)
+        if (ctx->range_halves) {                                            // partial-block passes (fewer accumulators, more waves)
             // (measured: one bound -- half blocks 0.372 ms, quarter blocks 0.422; two bounds -- half blocks 0.536 ms, quarter blocks 0.473)
-            hipLaunchKernelGGL(pred == BMX_CMP_RANGE ? k_slice_compare_halves<true, 2> : k_slice_compare_halves<false, 4>, dim3((ncols + 3) / 4), dim3(256), 0, ctx->stream,
+            auto hfn = pred == BMX_CMP_RANGE ? k_slice_compare_halves<true, 2> : k_slice_compare_halves<false, 4>;
+            hipLaunchKernelGGL(hfn, dim3((ncols + 3) / 4), dim3(256), 0, ctx->stream,
                                (const u64* const*)d_descs, (const u32*)d_nblk, (u32)nslices, ncols, pred, v0, v1, size,
                                not_null ? (const u64*)not_null->d_desc : nullptr, not_null ? not_null->nblocks : 0u, null_correct,
                                result ? 0 : 1, ctx->xcd_swz, v ? v->d_bits : nullptr, v ? v->d_desc : nullptr, st, ctx->d_slots);
-        else {
+        } else {
         auto cmp_fn = pred == BMX_CMP_RANGE ? k_slice_compare<true> : k_slice_compare<false>;
         hipLaunchKernelGGL(cmp_fn, dim3((ncols + 3) / 4), dim3(256), 0, ctx->stream,
                            (const u64* const*)d_descs, (const u32*)d_nblk, (u32)nslices, ncols, pred, v0, v1, size,
