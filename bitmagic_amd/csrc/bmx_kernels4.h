@@ -263,11 +263,25 @@ struct EqPlanes { const u64* desc[32]; const uint4* raw[32]; u32 nblk[32]; };
 
 __device__ __forceinline__ void bit_transpose32(u32 (&a)[32])
 {
-    // out[r] bit p = in[p] bit r (LSB numbering); Hacker's Delight 7-3 with the shifts mirrored
+    // out[r] bit p = in[p] bit r (LSB numbering); Hacker's Delight 7-3 with the shifts mirrored.  The two coarse stages move
+    // whole bytes: one v_perm_b32 per output word instead of shift / xor / and / xor / shift / xor
 #pragma unroll
-    for (int s = 0; s < 5; ++s) {
+    for (int k = 0; k < 16; ++k) {                                  // j = 16: halves
+        u32 x = a[k], y = a[k + 16];
+        a[k] = __builtin_amdgcn_perm(y, x, 0x05040100u);
+        a[k + 16] = __builtin_amdgcn_perm(y, x, 0x07060302u);
+    }
+#pragma unroll
+    for (int k = 0; k < 32; ++k) {                                  // j = 8: bytes
+        if (k & 8) continue;
+        u32 x = a[k], y = a[k + 8];
+        a[k] = __builtin_amdgcn_perm(y, x, 0x06020400u);
+        a[k + 8] = __builtin_amdgcn_perm(y, x, 0x07030501u);
+    }
+#pragma unroll
+    for (int s = 2; s < 5; ++s) {
         const int j = 16 >> s;
-        const u32 m = s == 0 ? 0x0000FFFFu : s == 1 ? 0x00FF00FFu : s == 2 ? 0x0F0F0F0Fu : s == 3 ? 0x33333333u : 0x55555555u;
+        const u32 m = s == 2 ? 0x0F0F0F0Fu : s == 3 ? 0x33333333u : 0x55555555u;
 #pragma unroll
         for (int k = 0; k < 32; ++k) {
             if (k & j) continue;
