@@ -1795,10 +1795,11 @@ int bmx_slice_eq_counts(bmx_ctx* ctx, const bmx_vec* const* slices, size_t nslic
         hipError_t e = rc ? hipSuccess : hipMemsetAsync(d_cnt, 0, (size_t)nv * 8, ctx->stream);
         if (!rc && e == hipSuccess) {
             size_t lds = (size_t)tab * 4 + (size_t)nv * 4 + EQ_FILTER_WORDS * 4 + 4 * EQ_QUEUE * 4 + (size_t)tab * 2;
-            e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_slice_eq_counts), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            auto eqfn = nslices <= 16 ? k_slice_eq_counts<16> : k_slice_eq_counts<32>;
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(eqfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e == hipSuccess) {
                 u32 grid = std::min<u32>((ncols + 3u) / 4u, 512u);
-                hipLaunchKernelGGL(k_slice_eq_counts, dim3(grid), dim3(256), lds, ctx->stream, pl, (u32)nslices, ncols, size,
+                hipLaunchKernelGGL(eqfn, dim3(grid), dim3(256), lds, ctx->stream, pl, (u32)nslices, ncols, size,
                                    (const u32*)d_tab, (const u16*)((const u32*)d_tab + tab), tab, shift, nv, (u64*)d_cnt);
                 e = hipGetLastError();
             }

@@ -298,10 +298,12 @@ __device__ __forceinline__ void bit_transpose32(u32 (&a)[32])
 // straight from the row loop: 32 divergent probe loops per step, each an LDS round trip with a few lanes alive -- 15.9 ms
 // per pass over 32 planes x 1e9 rows instead of ~1 ms.)
 #define EQ_FILTER_WORDS 2048u
-#define EQ_QUEUE 512u
+#define EQ_QUEUE 2048u                  // one slot per row of a step: the queue cannot overflow, whatever share of the rows is looked for
 typedef u32 u32x2 __attribute__((ext_vector_type(2)));
 typedef const __attribute__((address_space(1))) u32x2* gcptr2;
 
+// NP = 16: containers of up to 16 planes -- planes 16..31 are compile-time zeros and the butterfly folds away over them
+template <int NP>
 __global__ __launch_bounds__(256)
 void k_slice_eq_counts(EqPlanes pl, u32 nplanes, u32 ncols, u64 size, const u32* __restrict__ g_keys, const u16* __restrict__ g_idx,
                        u32 tab_size /* power of two */, u32 shift, u32 nvals, u64* __restrict__ counts)
@@ -329,7 +331,7 @@ void k_slice_eq_counts(EqPlanes pl, u32 nplanes, u32 ncols, u64 size, const u32*
 #pragma unroll
         for (int p = 0; p < 32; ++p) {
             u64 b = 0ull;
-            if ((u32)p < nplanes) {
+            if (p < NP && (u32)p < nplanes) {
                 if (pl.raw[p]) b = (u64)(uintptr_t)(pl.raw[p] + (size_t)c * 512u);
                 else if (pl.desc[p] && c < pl.nblk[p]) {
                     u64 d = uniform64(pl.desc[p][c]);
@@ -347,6 +349,7 @@ void k_slice_eq_counts(EqPlanes pl, u32 nplanes, u32 ncols, u64 size, const u32*
                 u32 any = 0u;
 #pragma unroll
                 for (int p = 0; p < 32; ++p) {
+                    if (p >= NP) { a[p] = 0u; continue; }
                     if (base[p] > 1ull) a[p] = __builtin_nontemporal_load((const __attribute__((address_space(1))) u32*)(uintptr_t)base[p] + k * 64u + lane);
                     else a[p] = base[p] ? ~0u : 0u;
                     any |= a[p];
@@ -365,20 +368,9 @@ void k_slice_eq_counts(EqPlanes pl, u32 nplanes, u32 ncols, u64 size, const u32*
                     u64 m = __ballot(hit);
                     if (m) {
                         u32 pos = nq + __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
-                        if (hit && pos < EQ_QUEUE) myq[pos] = a[r];
+                        if (hit) myq[pos] = a[r];
                         nq += (u32)__popcll(m);
                     }
-                }
-                if (nq > EQ_QUEUE) {                                        // (never with <= 2,048 values; keeps the result exact anyway)
-#pragma unroll 1
-                    for (int r = 0; r < 32; ++r) {
-                        u32 v = a[r];
-                        if ((f[r] & 1u) && v != 0u && ((vm >> r) & 1u)) {
-                            u32 h = (v * 0x9E3779B1u) >> shift;
-                            for (;;) { u32 kk = keys[h]; if (kk == v) { atomicAdd(&cnt[idx[h]], 1u); break; } if (kk == 0u) break; h = (h + 1u) & tmask; }
-                        }
-                    }
-                    continue;
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 __builtin_amdgcn_wave_barrier();

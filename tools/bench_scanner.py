@@ -61,6 +61,17 @@ if a.planes <= 32:
                           "queries_per_s": round(nq / min(ts) * 1e3, 1), "plane_GB": round(a.planes * a.nbits / 8e9, 2),
                           "plane_TBps": round(a.planes * a.nbits / 8 / min(ts) / 1e9 * (1 + (nq - 1) // 2048), 2), "counts_equal_pipeline": ok}))
 
+# a 12-plane container (values < 4096, every row non-zero): the 16-plane instantiation
+if a.planes >= 12:
+    sc12 = bm.slice_scanner(ctx, planes[:12], size=a.nbits)
+    q = [int(v) for v in rng.integers(1, 1 << 12, size=2048)]
+    got = sc12.find_eq_counts(q); ctx.synchronize()
+    ts = []
+    for _ in range(3):
+        t0 = time.perf_counter(); got = sc12.find_eq_counts(q); ts.append((time.perf_counter() - t0) * 1e3)
+    print(json.dumps({"pattern": "scanner_transposed", "planes": 12, "queries": 2048, "nbits": a.nbits, "host_call_ms": round(min(ts), 3),
+                      "sum_counts": int(np.asarray(got, np.int64).sum())}))
+
 # ---- range search (find_gt / find_le / find_range / find_zero): one pass over the planes (bmx_slice_compare) ----
 plane_bytes = a.planes * ((a.nbits + 65535) // 65536) * 8192
 for name, fn, cnt_fn in (("find_gt", lambda v: sc.find_gt(v), lambda v: sc.count(bm.CMP_GT, v)),
