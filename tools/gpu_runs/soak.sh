@@ -154,6 +154,57 @@ for seed in range(120):
     exp = [int(((c == np.uint64(v)) & (valid if v == 0 else True)).sum()) for v in pool]
     got = sc.find_eq_counts(pool, method="transpose").tolist()
     if got != exp: bad += 1; print("FAIL eq_counts", seed, nplanes, n, size, kind, with_null)
+# counts pipelines over GAP-only operands: counting formulation (gap_count 1) vs the run-by-run kernel vs the oracle; and the
+# comparison searches in partial-block passes vs the whole-block kernel vs numpy
+ctx.set_tuning("pipe_split", 0)
+for seed in range(80):
+    rng = np.random.default_rng(99000 + seed)
+    nblk = int(rng.integers(1, 5)); nbits = nblk * 65536 - int(rng.integers(0, 3000))
+    nvec = int(rng.integers(2, 300)); nsub = int(rng.integers(0, 12))
+    dq = int(rng.choice([5, 40, 150, 300, 65520, 65000]))
+    common = port.gen_words(7000 + seed, 0xFFFFFFFF, max(dq // 3, 2) if dq < 1000 else 65400, nbits)
+    ws = []
+    for v in range(nvec + nsub):
+        w = port.gen_words(7000 + seed, v, dq if dq < 1000 or v % 2 else 65530, nbits)
+        if v < nvec: w = w | common
+        if rng.integers(0, 15) == 0: w[:2048] = 0xFFFFFFFF if v < nvec else 0
+        ws.append(w)
+    gvs = [bm.bit_import_u32(ctx, w, True) for w in ws]
+    if any(v.calc_stat()["bit_blocks"] for v in gvs): continue
+    pvs = [port.import_words(w, True, nbits) for w in ws]
+    groups = [(list(range(nvec)), list(range(nvec, nvec + nsub))), (list(range(0, nvec, 3)), [])]
+    exp = port.pipeline_counts([([pvs[i] for i in a], [pvs[i] for i in s_]) for a, s_ in groups])
+    pipe = bm.aggregator.pipeline(ctx)
+    for a, s_ in groups:
+        ag = pipe.add()
+        for i in a: ag.add(gvs[i], 0)
+        for i in s_: ag.add(gvs[i], 1)
+    pipe.complete()
+    for gc in (1, 0):
+        ctx.set_tuning("gap_count", gc)
+        got = agg.combine_and_sub(pipe)
+        if not (got == exp).all(): bad += 1; print("FAIL gapcount", seed, gc, nvec, nsub, dq, got, exp)
+ctx.set_tuning("gap_count", -1); ctx.set_tuning("pipe_split", -1)
+for seed in range(60):
+    rng = np.random.default_rng(99500 + seed)
+    nplanes = int(rng.integers(1, 20)); n = int(rng.integers(1, 4 * 65536)); hi = 1 << nplanes
+    col = (rng.integers(0, hi, size=n) if seed % 2 else np.repeat(rng.integers(0, hi, size=n // 300 + 1), 300)[:n]).astype(np.uint64)
+    def up(bits):
+        w = np.packbits(np.concatenate([bits.astype(np.uint8), np.zeros((-n) % 32, np.uint8)]), bitorder="little").view(np.uint32)
+        return bm.bit_import_u32(ctx, w, True)
+    sl = []
+    for b in range(nplanes):
+        bits = ((col >> np.uint64(b)) & np.uint64(1)).astype(bool)
+        sl.append(up(bits) if bits.any() else None)
+    sc = bm.slice_scanner(ctx, sl, size=n)
+    for _ in range(6):
+        v0, v1 = sorted(int(x) for x in rng.integers(0, hi + 3, size=2))
+        exp = [int((col > np.uint64(v0)).sum()), int((col <= np.uint64(v0)).sum()), int(((col >= np.uint64(v0)) & (col <= np.uint64(v1))).sum())]
+        for halves in (1, 0):
+            ctx.set_tuning("range_halves", halves)
+            got = [sc.count(bm.CMP_GT, v0), sc.find_le(v0).count(), sc.count(bm.CMP_RANGE, v0, v1)]
+            if got != exp: bad += 1; print("FAIL compare", seed, halves, v0, v1, got, exp)
+ctx.set_tuning("range_halves", 1)
 print("soak done, failures:", bad)
 PY
 timeout 1200 python /tmp/soak.py > gpurun_out/soak.log 2>&1; tail -6 gpurun_out/soak.log
