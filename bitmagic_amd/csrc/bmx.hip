@@ -1693,11 +1693,11 @@ int bmx_slice_compare(bmx_ctx* ctx, const bmx_vec* const* slices, size_t nslices
                                not_null ? (const u64*)not_null->d_desc : nullptr, not_null ? not_null->nblocks : 0u, null_correct,
                                result ? 0 : 1, ctx->xcd_swz, v ? v->d_bits : nullptr, v ? v->d_desc : nullptr, st, ctx->d_slots);
         } else {
-        auto cmp_fn = pred == BMX_CMP_RANGE ? k_slice_compare<true> : k_slice_compare<false>;
-        hipLaunchKernelGGL(cmp_fn, dim3((ncols + 3) / 4), dim3(256), 0, ctx->stream,
-                           (const u64* const*)d_descs, (const u32*)d_nblk, (u32)nslices, ncols, pred, v0, v1, size,
-                           not_null ? (const u64*)not_null->d_desc : nullptr, not_null ? not_null->nblocks : 0u, null_correct,
-                           result ? 0 : 1, ctx->xcd_swz, v ? v->d_bits : nullptr, v ? v->d_desc : nullptr, st, ctx->d_slots);
+            auto cmp_fn = pred == BMX_CMP_RANGE ? k_slice_compare<true> : k_slice_compare<false>;
+            hipLaunchKernelGGL(cmp_fn, dim3((ncols + 3) / 4), dim3(256), 0, ctx->stream,
+                               (const u64* const*)d_descs, (const u32*)d_nblk, (u32)nslices, ncols, pred, v0, v1, size,
+                               not_null ? (const u64*)not_null->d_desc : nullptr, not_null ? not_null->nblocks : 0u, null_correct,
+                               result ? 0 : 1, ctx->xcd_swz, v ? v->d_bits : nullptr, v ? v->d_desc : nullptr, st, ctx->d_slots);
         }
         e = hipGetLastError();
     }
