@@ -657,6 +657,13 @@ int bmx_i_count_async(bmx_ctx* ctx, const bmx_vec* a, int slot)
     int rc = set_dev(ctx); if (rc) return rc;
     if (!a->nblocks) { ctx->h_small[slot] = 0; return BMX_OK; }
     // the last workgroup folds the partial counts and writes the total straight into the pinned word the host reads
+    if (ctx->pair_stream != 0 && a->counts[BMX_BIT] == a->nblocks && a->nblocks >= 2048u) {     // bit-blocks only: the streaming form
+        const u32 total = 256u * 4u * (u32)std::max(ctx->pair_wgs, 1);
+        u32 per_wave = (a->nblocks + total - 1u) / total;
+        u32 grid = ((a->nblocks + per_wave - 1u) / per_wave + 3u) / 4u;
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_count_op2_stream<4, true, 1>), dim3(grid), dim3(256), 0, ctx->stream, 0, a->d_desc, a->d_desc,
+                           a->nblocks, per_wave, FoldOut{ctx->d_slots, ctx->d_done, ctx->h_small + slot});
+    } else
     hipLaunchKernelGGL(k_vec_count, dim3((a->nblocks + 3) / 4), dim3(256), 0, ctx->stream, a->d_desc, a->nblocks,
                        FoldOut{ctx->d_slots, ctx->d_done, ctx->h_small + slot});
     KCHK();

@@ -270,10 +270,11 @@ void k_count_op2(int op, const u64* __restrict__ da, u32 na, const u64* __restri
 // columns in flight -- the loads of column c+1 are issued before column c is counted, descriptor pairs are fetched two
 // columns ahead with scalar loads -- instead of one short-lived wave per column (descriptor -> data -> count -> exit,
 // three workgroup rounds per CU).  Same result: a sum of per-column popcounts.
-template <int WAVES, bool NT>
+template <int WAVES, bool NT, int NOPS = 2>
 __global__ __launch_bounds__(WAVES * 64)
 void k_count_op2_stream(int op, const u64* __restrict__ da, const u64* __restrict__ db, u32 nblocks, u32 per_wave, FoldOut fold)
 {
+    // NOPS = 1: bvector::count() of an all-bit-block vector (db unused): the same stream with one operand
     u32 lane = lane_id(), wave = threadIdx.x >> 6;
     u32 w = uniform32(blockIdx.x * (u32)WAVES + wave);
     u32 c0 = w * per_wave;
@@ -282,24 +283,26 @@ void k_count_op2_stream(int op, const u64* __restrict__ da, const u64* __restric
     if (c0 < c1) {
         const u32 last = nblocks - 1u;
         auto ptr = [&](const u64* __restrict__ d, u32 c) { return DESC_P(uniform64(d[c < last ? c : last])); };   // (clamped: prefetch past the end is harmless)
+        auto load = [&](Blk& x, Blk& y, u64 pa, u64 pb) {
+            part_load<8, NT>(x, as_gc4(pa), lane);
+            if (NOPS == 2) part_load<8, NT>(y, as_gc4(pb), lane);
+        };
+        auto eat = [&](Blk& x, const Blk& y) { if (NOPS == 2) blk_op(op, x, y); cnt += blk_lane_popcount(x); };
         Blk x0, y0, x1, y1;
         u32 c = c0;
-        part_load<8, NT>(x0, as_gc4(ptr(da, c)), lane); part_load<8, NT>(y0, as_gc4(ptr(db, c)), lane);
-        u64 a1 = ptr(da, c + 1u), b1 = ptr(db, c + 1u), a2 = ptr(da, c + 2u), b2 = ptr(db, c + 2u);
+        load(x0, y0, ptr(da, c), NOPS == 2 ? ptr(db, c) : 0ull);
+        u64 a1 = ptr(da, c + 1u), b1 = NOPS == 2 ? ptr(db, c + 1u) : 0ull, a2 = ptr(da, c + 2u), b2 = NOPS == 2 ? ptr(db, c + 2u) : 0ull;
         for (; c + 2u < c1; c += 2u) {                       // columns c (in buffer 0), c+1, c+2 exist
-            part_load<8, NT>(x1, as_gc4(a1), lane); part_load<8, NT>(y1, as_gc4(b1), lane);
-            u64 a3 = ptr(da, c + 3u), b3 = ptr(db, c + 3u);
-            blk_op(op, x0, y0); cnt += blk_lane_popcount(x0);
-            part_load<8, NT>(x0, as_gc4(a2), lane); part_load<8, NT>(y0, as_gc4(b2), lane);
-            u64 a4 = ptr(da, c + 4u), b4 = ptr(db, c + 4u);
-            blk_op(op, x1, y1); cnt += blk_lane_popcount(x1);
+            load(x1, y1, a1, b1);
+            u64 a3 = ptr(da, c + 3u), b3 = NOPS == 2 ? ptr(db, c + 3u) : 0ull;
+            eat(x0, y0);
+            load(x0, y0, a2, b2);
+            u64 a4 = ptr(da, c + 4u), b4 = NOPS == 2 ? ptr(db, c + 4u) : 0ull;
+            eat(x1, y1);
             a1 = a3; b1 = b3; a2 = a4; b2 = b4;
         }
-        if (c + 1u < c1) {
-            part_load<8, NT>(x1, as_gc4(a1), lane); part_load<8, NT>(y1, as_gc4(b1), lane);
-            blk_op(op, x0, y0); cnt += blk_lane_popcount(x0);
-            blk_op(op, x1, y1); cnt += blk_lane_popcount(x1);
-        } else { blk_op(op, x0, y0); cnt += blk_lane_popcount(x0); }
+        if (c + 1u < c1) { load(x1, y1, a1, b1); eat(x0, y0); eat(x1, y1); }
+        else eat(x0, y0);
         cnt = wave_sum(cnt);
     }
     count_fanin_fold(cnt, fold, lane, wave);

@@ -355,9 +355,11 @@ def test_pairwise_count_streaming_kernel(ctx, port, nblocks_x):
     try:
         ctx.set_tuning("pair_stream", 0)
         ref = [bm._count_op2(op, a, b) for op in range(4)]
+        ca, cb = a.count(), b.count()                       # (count() of an all-bit vector takes the one-operand form of the same kernel)
         for ps, wgs in ((-1, 1), (2, 1), (2, 4), (4, 2), (8, 1), (4, 3)):
             ctx.set_tuning("pair_stream", ps); ctx.set_tuning("pair_wgs", wgs)
             assert [bm._count_op2(op, a, b) for op in range(4)] == ref, (ps, wgs)
+            assert (a.count(), b.count()) == (ca, cb) and ca + cb == ref[0] + ref[1]
             assert bm._count_op2(bm.AND, b, a) == ref[0] and bm._count_op2(bm.SUB, b, a) == b.count() - ref[0]
     finally:
         ctx.set_tuning("pair_stream", -1); ctx.set_tuning("pair_wgs", 1); ctx.set_tuning("pipe_nt", 1)
