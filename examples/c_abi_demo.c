@@ -35,6 +35,27 @@ int main(void)
     printf("count(a)=%llu count_and=%llu count(a&b)=%llu rank(last)=%llu\n",
            (unsigned long long)ca, (unsigned long long)cand, (unsigned long long)ct, (unsigned long long)r);
     int ok = ca == 32768u && cand == 16384u && ct == cand && r == ct;
+    {   /* the same through a device GROUP (here: device 0 listed twice = two shards on one GPU; {0,1,...,7} on a node):
+           vectors are sharded by block range, the only exchange is the sum of the counts */
+        int devs[2] = {0, 0};
+        bmx_group* grp = NULL;
+        bmx_gvec *ga = NULL, *gb = NULL;
+        uint8_t kinds[2] = {BMX_BIT, BMX_BIT}; uint32_t offs[2] = {0, 0};          /* two blocks, both = the same 8 KiB */
+        uint64_t gc = 0, gand = 0, sel = 0; uint8_t found = 0; uint64_t one = 1;
+        bmx_grs* grs = NULL;
+        CHECK(bmx_group_create(devs, 2, BMX_GROUP_HOST_SUM, &grp));
+        CHECK(bmx_gvec_upload(grp, 2 * BMX_BLOCK_BITS, 2, kinds, offs, a, 1, NULL, 0, &ga));
+        CHECK(bmx_gvec_upload(grp, 2 * BMX_BLOCK_BITS, 2, kinds, offs, b, 1, NULL, 0, &gb));
+        CHECK(bmx_gvec_count(grp, ga, &gc));
+        CHECK(bmx_gvec_count_op2(grp, BMX_AND, ga, gb, &gand));
+        CHECK(bmx_grs_build(grp, gb, &grs));
+        CHECK(bmx_gselect_batch(grp, gb, grs, &one, 1, &sel, &found));               /* first set bit of b: bit 32 */
+        printf("group: count(a)=%llu count_and=%llu select(1)=%llu\n", (unsigned long long)gc, (unsigned long long)gand, (unsigned long long)sel);
+        ok = ok && gc == 2 * ca && gand == 2 * cand && found && sel == 32u;
+        bmx_grs_free(grp, grs);
+        bmx_gvec_free(grp, ga); bmx_gvec_free(grp, gb);
+        bmx_group_destroy(grp);
+    }
     bmx_rs_free(ctx, rs);
     bmx_vec_free(ctx, vt); bmx_vec_free(ctx, va); bmx_vec_free(ctx, vb);
     bmx_ctx_destroy(ctx);
