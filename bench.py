@@ -463,6 +463,13 @@ def run_pairwise(args):
     k_ms = ev_ms / args.steps / npairs
     bytes_launch = sum(pair_bytes) / npairs
     achieved = bytes_launch / k_ms / 1e6
+    c1_traffic, c1_tsrc = None, None
+    if args.nbits == 1_000_000_000 and dq == 6554 and os.environ.get("BMX_PAIR_STREAM", "-1") == "-1":
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_config1.json")))
+            c1_traffic, c1_tsrc = tj["hbm_bytes_per_launch"], tj["source"] + " (PMC pass of a separate rocprofv3 run, not measured in this run)"
+        except Exception:
+            pass
     res = {"metric": "Gbit/s of operand bits, pairwise count_and on 1e9-bit vectors (HBM-cold rotation)",
            "value": round(2 * args.nbits * npairs * args.steps / dt / 1e9, 2), "unit": "Gbit/s", "n_gpus": 1,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
@@ -472,7 +479,7 @@ def run_pairwise(args):
                       "baseline_config": "configs[1]", "block_types_vec0": va[0].calc_stat(), "per_op": per_op,
                       "count_and": counts[:4]},
            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": c1_traffic, "traffic_source": c1_tsrc,
                         "kernel": ("k_count_op2_stream<4, true>" if all(v.calc_stat()["bit_blocks"] == v.info()["nblocks"] for v in (va[0], vb[0]))
                                    and va[0].info()["nblocks"] >= 2048 and os.environ.get("BMX_PAIR_STREAM", "-1") == "-1" else "k_count_op2"),
                         "algorithmic_bytes_per_launch": int(bytes_launch), "avg_launch_ms": round(k_ms, 4),
