@@ -820,9 +820,9 @@ static bool use_gapcount(const bmx_ctx* ctx, const bmx_pipeline* p)
 {
     if (ctx->gap_count == 0 || !p->has_gap || p->has_bit) return false;
     if (ctx->gap_count > 0) return true;
-    // measured on the 256-way AND over 1e9-bit vectors: blocks of ~780 words (0.3 %) 2.73 -> 2.23 ms, blocks of ~260 words
-    // (0.1 %) 1.58 -> 1.65 ms -- the per-column scan and zeroing only pay off with long run lists
-    return (uint64_t)p->n_ops >= 32ull * p->ngroups && p->gap_avg_words >= 512u;
+    // measured on the 256-way AND over 1e9-bit vectors: blocks of ~780 words (0.3 %) 2.71 -> 2.09 ms, ~390 words (0.15 %)
+    // 1.65 -> 1.57 ms, ~265 words (0.1 %) 1.58 -> 1.54 ms -- below that the per-column scan and zeroing stop paying off
+    return (uint64_t)p->n_ops >= 32ull * p->ngroups && p->gap_avg_words >= 240u;
 }
 extern "C" {
 
