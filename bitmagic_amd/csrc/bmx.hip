@@ -816,10 +816,11 @@ static int pipe_range(const bmx_pipeline* p, uint32_t& nb_from, uint32_t& nb_to)
 } // extern "C"
 // GAP-only pipelines with long operand lists: count the covering operands per position (k_pipe_counts_gapcount) instead
 // of applying them one by one.  gap_count: -1 = automatic (>= 32 operands per group on average), 0 = off, 1 = whenever it applies
-static bool use_gapcount(const bmx_ctx* ctx, const bmx_pipeline* p)
+static bool use_gapcount(const bmx_ctx* ctx, const bmx_pipeline* p, uint64_t ops_of_group = 0)
 {
     if (ctx->gap_count == 0 || !p->has_gap || p->has_bit) return false;
     if (ctx->gap_count > 0) return true;
+    if (ops_of_group) return ops_of_group >= 32u && p->gap_avg_words >= 240u;          // one group (materialising form)
     // measured on the 256-way AND over 1e9-bit vectors: blocks of ~780 words (0.3 %) 2.71 -> 2.09 ms, ~390 words (0.15 %)
     // 1.65 -> 1.57 ms, ~265 words (0.1 %) 1.58 -> 1.54 ms -- below that the per-column scan and zeroing stop paying off
     return (uint64_t)p->n_ops >= 32ull * p->ngroups && p->gap_avg_words >= 240u;
@@ -894,9 +895,10 @@ int bmx_pipeline_run_counts_dev(bmx_ctx* ctx, bmx_pipeline* p, uint32_t nb_from,
     if (use_gapcount(ctx, p)) {
         // every operand block is GAP (or NULL / FULL): the counting formulation, one 1024-thread workgroup per (column, group)
         size_t lds = (size_t)(16384 * 2 + 2048) * 4;
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pipe_counts_gapcount), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_pipe_counts_gapcount, dim3((u32)nitems64), dim3(1024), lds, ctx->stream,
-                           p->d_dmat, row_off, and_n, sub_n, p->col_stride, p->ngroups, nb_from, (u32)nitems64, (u64*)d_counts);
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pipe_counts_gapcount<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pipe_counts_gapcount<false>), dim3((u32)nitems64), dim3(1024), lds, ctx->stream,
+                           p->d_dmat, row_off, and_n, sub_n, p->col_stride, p->ngroups, nb_from, (u32)nitems64, (u64*)d_counts,
+                           (uint4*)nullptr, (u64*)nullptr, (BlockStat*)nullptr, 0u, 0xFFFFFFFFu);
         KCHK();
         return BMX_OK;
     }
@@ -1358,6 +1360,18 @@ static int agg_and_sub_launch(bmx_ctx* ctx, const bmx_pipeline* p, uint32_t g, b
     const u32* sn = p->d_meta + 2 * p->ngroups + g;
     const u32 ncols = p->ncols;
     hipError_t e = hipSuccess;
+    if (ncols && use_gapcount(ctx, p, (*p->h_and_n)[g])) {
+        // GAP-only operands, a long list: the counting formulation, one 1024-thread workgroup per column, result block stored
+        size_t lds = (size_t)(16384 * 2 + 2048) * 4;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_pipe_counts_gapcount<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pipe_counts_gapcount<true>), dim3(ncols), dim3(1024), lds, ctx->stream,
+                               rows, p->d_meta /* row_off[0] is added below: rows already points at group g */, an, sn, p->col_stride, 1u, 0u, ncols, (u64*)nullptr,
+                               v->d_bits, v->d_desc, st, nb_from, nb_to);
+            e = hipGetLastError();
+        }
+        return e == hipSuccess ? BMX_OK : fail_hip(e, "k_pipe_counts_gapcount", __LINE__);
+    }
     if (!p->has_gap && ncols >= 2560u && ctx->pipe_window >= 0 && (ctx->pipe_wg == 0 || ctx->pipe_wg == 640)) {
         // (640 threads = 10 waves per CU; 512 measured: 4.98 against 4.86 ms on the 256 x 1e9-bit combine_and)
         const u32 wpb = 10u;

@@ -140,10 +140,14 @@ __device__ __forceinline__ bool gc_scan_combine(const u32* S, const u32* E, u32*
     return *flag != 0u;
 }
 
+// STORE: the single-group materialising form (combine_and_sub over GAP-only operands): the column's bitmap is stored as a
+// result block (opt_compress, src/bmaggregator.h:1210) instead of being counted; columns outside [hint_from, hint_to) are NULL
+template <bool STORE>
 __global__ __launch_bounds__(1024)
 void k_pipe_counts_gapcount(const u64* __restrict__ dmat, const u32* __restrict__ row_off, const u32* __restrict__ and_n,
                             const u32* __restrict__ sub_n, u32 col_stride, u32 ngroups, u32 col_from, u32 nitems,
-                            u64* __restrict__ counts)
+                            u64* __restrict__ counts, uint4* __restrict__ slab, u64* __restrict__ desc, BlockStat* __restrict__ st,
+                            u32 hint_from, u32 hint_to)
 {
     extern __shared__ u32 lds_dyn[];
     u32* S = lds_dyn;                       // 65,536 byte counters
@@ -156,10 +160,16 @@ void k_pipe_counts_gapcount(const u64* __restrict__ dmat, const u32* __restrict_
     const u32 item = blockIdx.x;
     if (item >= nitems) return;
     const u32 c = item / ngroups, g = item - c * ngroups;
-    const u64* row = dmat + (size_t)(col_from + c) * col_stride + row_off[g];
+    const u32 col = col_from + c;
+    if (STORE && (col < hint_from || col >= hint_to)) { if (wave == 0) store_trivial(K_NULL, col, desc, st, lane); return; }
+    const u64* row = dmat + (size_t)col * col_stride + row_off[g];
     const u64 hdr = uniform64(row[0]), flags = uniform64(row[1]);
-    if (flags & ROW_EMPTY) return;
-    if (flags & ROW_FULL) { if (tid == 0) atomicAdd(reinterpret_cast<unsigned long long*>(&counts[g]), 65536ull); return; }
+    if (flags & ROW_EMPTY) { if (STORE && wave == 0) store_trivial(K_NULL, col, desc, st, lane); return; }
+    if (flags & ROW_FULL) {
+        if (STORE) { if (wave == 0) store_trivial(K_FULL, col, desc, st, lane); }
+        else if (tid == 0) atomicAdd(reinterpret_cast<unsigned long long*>(&counts[g]), 65536ull);
+        return;
+    }
     const u32 nga = (u32)((hdr >> 16) & 0xFFFFu), ngs = (u32)(hdr >> 48);       // (no bit-block operands in these pipelines)
     const u32 na = uniform32(and_n[g]), ns = uniform32(sub_n[g]);
     const u64* pa_back = row + 2 + na - 1u;                                     // GAP pointers are packed from the back of a region
@@ -198,6 +208,13 @@ void k_pipe_counts_gapcount(const u64* __restrict__ dmat, const u32* __restrict_
         gc_accumulate(S, E, ps_back, i0, n, lane, wave);
         __syncthreads();
         alive = gc_scan_combine<true>(S, E, B, n, scan_sm, &flag, tid);
+    }
+    if (STORE) {
+        if (wave == 0) {
+            if (!alive) store_trivial(K_NULL, col, desc, st, lane);
+            else { Blk t; blk_from_lds(t, B, lane); store_result(t, col, 1, slab, desc, st, lane); }
+        }
+        return;
     }
     if (!alive) return;
     u32 cnt = wave_sum((u32)__popc(B[2u * tid]) + (u32)__popc(B[2u * tid + 1u]));

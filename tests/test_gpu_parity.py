@@ -693,10 +693,21 @@ def test_gap_only_pipeline_counting_formulation(ctx, port, dq, nvec, nsub):
             assert (got == exp).all(), (gc, got, exp)
             parts = sum(agg._run_pipeline(pipe, a, b).astype(np.int64) for a, b in [(0, 2), (2, 3), (3, nblk)])
             assert (parts == exp.astype(np.int64)).all(), gc
+        # the materialising form (combine_and_sub over GAP-only operands stores the column bitmap as a result block):
+        # same bits and block kinds as the run-by-run kernel and the oracle
+        ctx.set_tuning("direct_cols", 0)                 # (so few columns would take the one-launch kernel)
+        for a, s in groups[:2]:
+            e = port.agg_and_sub([pv[i] for i in a], [pv[i] for i in s])
+            for gc in (1, 0):
+                ctx.set_tuning("gap_count", gc)
+                t, any_ = agg.combine_and_sub([gv[i] for i in a], [gv[i] for i in s])
+                assert (t.to_words(nblk * 2048) == e.to_words(nblk * 2048)).all(), (gc, len(a), len(s))
+                assert t.block_table()[0].tolist() == (e.flatten()[0].tolist() + [0] * nblk)[:t.info()["nblocks"]] and any_ == (e.count() != 0)
+        ctx.set_tuning("direct_cols", 384)
         ctx.set_tuning("pipe_split", -1); ctx.set_tuning("gap_count", -1)
         assert (agg.combine_and_sub(pipe) == exp).all()   # default selection (workgroup-split kernel for so few items)
     finally:
-        ctx.set_tuning("gap_count", -1); ctx.set_tuning("pipe_split", -1)
+        ctx.set_tuning("gap_count", -1); ctx.set_tuning("pipe_split", -1); ctx.set_tuning("direct_cols", 384)
 
 
 @pytest.mark.parametrize("common_bits,own_dq,nvec", [(1, 30, 40), (40, 100, 70), (400, 100, 90), (520, 40, 36),

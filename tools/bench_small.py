@@ -71,3 +71,14 @@ for name, win in (("windows_ms", 0), ("one_launch_ms", -1)):
 ctx.set_tuning("pipe_window", 0)
 print(json.dumps(out))
 del vecs
+# materialised combine_and over 256 GAP-only vectors (0.3 %): counting formulation against the run-by-run kernel
+vecs = [bm.bvector.generate(ctx, 0xB17A61C, v, 197, 1_000_000_000, with_common=True) for v in range(256)]
+agg = bm.aggregator(ctx)
+out = {"combine_and_256x1e9_gap_only": "materialised"}
+for name, gc in (("counting_ms", -1), ("run_by_run_ms", 0)):
+    ctx.set_tuning("gap_count", gc)
+    out[name] = t(lambda: agg.combine_and_sub(vecs, []), reps=8, warm=2)
+    out[name.replace("_ms", "_count")] = agg.combine_and_sub(vecs, [])[0].count()
+ctx.set_tuning("gap_count", -1)
+print(json.dumps(out))
+del vecs
