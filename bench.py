@@ -8,22 +8,27 @@ Default workload (BASELINE.json configs[2], the configuration the metric is quot
   Bernoulli 10 % (mirrors GenerateTestCollection, tests/perf/perf.cpp:234-267), so no
   early exit is possible and every operand block must be read.
 
-A "step" = one pass of the hot path over the resident vectors (one kernel launch, plus for N > 1 one RCCL
-all-reduce of the 8-byte popcount).  Inputs are generated on the device and are resident in HBM before the
-timed region starts.
+A "step" = one pass of the hot path over the resident vectors (the launches of one run, plus for N > 1 the
+exchange of the 8-byte popcount).  Inputs are generated on the device and are resident in HBM before the timed
+region starts.
 
-N > 1 (python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N), --scaling:
-  strong (default for N > 1): the collection is FIXED at 256 x 1e9 bits; rank r holds only the block range
-      shard_range(15259, r, N) of every vector (bmx_vec_generate_shard), runs the same fused kernel over its
-      shard and the only exchange is one RCCL all-reduce of the popcount -- the block-range sharding north_star
-      names (column independence: src/bmaggregator.h:1184-1218).  value = 256e9 bits / step time.
-  weak: every rank owns its own 256 x 1e9-bit collection (a document-sharded index).  Reported as the second
-      figure "weak_scaling" of the strong line unless --no-weak.
+--gpus N, N > 1 -- three ways in, all of them use N GPUs or exit non-zero (never an n_gpus: 1 line):
+  * launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` (RANK in the environment):
+    one process per GPU, torch.distributed over RCCL, one all-reduce of the count per step ("mode": "torchrun");
+  * plain `python bench.py --gpus N` (no RANK): ONE process drives N devices through the product's own multi-GPU
+    layer -- bmx_group_create(devices, N, BMX_GROUP_RCCL) + bmx_gpipeline_run_counts: kernels enqueued on every
+    member, then an in-library ncclAllReduce over xGMI ("mode": "group"; --group-exchange host sums on the host);
+  * `python bench.py --gpus N --launcher torchrun`: re-executes itself under torch.distributed.run.
+  --scaling strong (default): the collection is FIXED at 256 x 1e9 bits; rank / member r holds only its block range
+      of every vector (column independence: src/bmaggregator.h:1184-1218).  value = 256e9 bits / step time.
+  weak: every rank owns its own 256 x 1e9-bit share.  Reported as the second figure "weak_scaling" of the strong line
+      unless --no-weak.
 
 --config 1|3|4 run the other BASELINE configs through the same JSON schema (roofline + cpu_baseline):
   1 pairwise count_and/or/xor/sub + materialised ops on 1e9-bit vectors, rotating over distinct vector pairs so
     that nothing is served from the 256 MB Infinity Cache;  3 rank/select, 10 M queries on a 4e9-bit vector;
-  4 combine_or over 4096 x 4e9-bit sparse vectors, block-range sharded over the ranks.
+  4 combine_or over 4096 x 4e9-bit sparse vectors, block-range sharded over the ranks / members.
+The default run (config 2, one GPU) appends their one-line summaries as "other_configs" (--no-others skips them).
 """
 from __future__ import annotations
 
@@ -38,14 +43,16 @@ sys.path.insert(0, ROOT)
 
 SEED = 0xB17A61C
 NBITS_1G = 1_000_000_000
+NBITS_4G = 4_000_000_000
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s)
 METRIC = "Gbits/s + % HBM roofline, 256-way fused AND+COUNT on 1B-bit vectors"
+ONE_DEV_HOOK = "BMX_BENCH_TEST_ONE_DEVICE"     # test hook: every rank / member on device 0 (see setup_dist)
 
 
 # ----------------------------------------------------------------------------------------------------
 # CPU baseline: the reference itself (oracle/_ref, kind "reference") or the C port, timed on the GPU box's
-# host cores.  Only this leg of bench.py touches oracle/ -- as the thing measured NEXT to the GPU, never
-# as the product path.
+# host cores.  Only these legs of bench.py touch oracle/ -- as the thing measured NEXT to the GPU and as the
+# checker of its results, never as the product path.
 # ----------------------------------------------------------------------------------------------------
 def _pick_oracle():
     import oracle
@@ -93,26 +100,108 @@ def cpu_baseline_1core(nvec: int, dq: int, nbits: int, sample_blocks: int, gpu_c
 
 
 def _cpu_worker_main(argv):
-    """`bench.py --cpu-worker lo hi nvec dq nbits reps`: one independent replica (SURVEY section 8d "secondary = one
-    replica per core"): block columns [lo, hi) of every vector -- block ranges are independent, so the per-shard
-    counts add up exactly.  Builds its inputs, prints READY, waits for a line on stdin, runs `reps` passes."""
-    lo, hi, nvec, dq, nbits, reps = (int(x) for x in argv)
-    P, orc, kind = _pick_oracle()
-    sbits = max(min(nbits, hi * 65536) - lo * 65536, 0)
-    vecs = []
-    for v in range(nvec):
-        w = P.gen_words(SEED, v, dq, nbits, with_common=True, word_off=lo * 2048, nwords=(hi - lo) * 2048)
-        vecs.append(orc.import_words(w, True, sbits))
-    groups = [(vecs, [])]
-    sys.stdout.write("READY\n"); sys.stdout.flush()
-    sys.stdin.readline()
-    spans, cnt = [], 0
-    for _ in range(reps):
-        t0 = time.perf_counter()                         # CLOCK_MONOTONIC: comparable across processes
-        cnt = int(orc.pipeline_counts(groups)[0]) if hi > lo else 0
-        spans.append((t0, time.perf_counter()))
-    sys.stdout.write(json.dumps({"count": cnt, "spans": spans, "kind": kind, "impl": orc.name}) + "\n")
-    sys.stdout.flush()
+    """`bench.py --cpu-worker <kind> ...`: one independent replica (SURVEY section 8d "secondary = one replica per
+    core") over block columns [lo, hi) of the workload -- block ranges are independent, so per-range results add up
+    exactly.  Builds its inputs, prints READY, waits for a line on stdin, works, prints one JSON line.
+      and  lo hi nvec dq nbits reps      the headline: counts-only 256-way AND
+      pair lo hi ida idb dq nbits reps   configs[1]: count_and/or/xor/sub of one pair
+      rank lo hi id dq nbits             configs[3]: count of the range, then (second stdin line = JSON {"n": [...],
+                                         "r": [...]} in range-local coordinates) rank / select answers
+      or   nvec dq nbits b0,b1,...       configs[4]: combine_or over nvec vectors restricted to each listed block
+    """
+    kind, rest = argv[0], argv[1:]
+    P, orc, okind = _pick_oracle()
+
+    def build(vec_id, dq, nbits, lo, hi, with_common):
+        sbits = max(min(nbits, hi * 65536) - lo * 65536, 0)
+        w = P.gen_words(SEED, vec_id, dq, nbits, with_common=with_common, word_off=lo * 2048, nwords=(hi - lo) * 2048)
+        return orc.import_words(w, True, sbits)
+
+    def ready():
+        sys.stdout.write("READY\n"); sys.stdout.flush()
+        sys.stdin.readline()
+
+    def reply(obj):
+        obj.update({"kind": okind, "impl": orc.name})
+        sys.stdout.write(json.dumps(obj) + "\n"); sys.stdout.flush()
+
+    if kind == "and":
+        lo, hi, nvec, dq, nbits, reps = (int(x) for x in rest)
+        vecs = [build(v, dq, nbits, lo, hi, True) for v in range(nvec)]
+        groups = [(vecs, [])]
+        ready()
+        spans, cnt = [], 0
+        for _ in range(reps):
+            t0 = time.perf_counter()                     # CLOCK_MONOTONIC: comparable across processes
+            cnt = int(orc.pipeline_counts(groups)[0]) if hi > lo else 0
+            spans.append((t0, time.perf_counter()))
+        reply({"count": cnt, "spans": spans})
+    elif kind == "pair":
+        lo, hi, ida, idb, dq, nbits, reps = (int(x) for x in rest)
+        a, b = build(ida, dq, nbits, lo, hi, False), build(idb, dq, nbits, lo, hi, False)
+        ready()
+        spans, counts = [], [0, 0, 0, 0]
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            c = int(orc.count_op2(0, a, b)) if hi > lo else 0
+            spans.append((t0, time.perf_counter()))
+            counts[0] = c
+        for op in (1, 2, 3):
+            counts[op] = int(orc.count_op2(op, a, b)) if hi > lo else 0
+        reply({"counts": counts, "spans": spans})
+    elif kind == "rank":
+        import numpy as np
+        lo, hi, vid, dq, nbits = (int(x) for x in rest)
+        v = build(vid, dq, nbits, lo, hi, False)
+        rs = orc.rs_build(v) if hi > lo else None
+        ready()
+        reply({"count": int(rs.count()) if rs is not None else 0})
+        q = json.loads(sys.stdin.readline())
+        n = np.asarray(q.get("n", []), dtype=np.uint64); r = np.asarray(q.get("r", []), dtype=np.uint64)
+        ans_n = [int(x) for x in rs.rank(n)] if n.size else []
+        ans_r = []
+        if r.size:
+            pos, _found = rs.select(r)                   # oracle RS.select -> (pos, found)
+            ans_r = [int(x) for x in np.asarray(pos)]
+        reply({"rank": ans_n, "select": ans_r})
+    elif kind == "or":
+        nvec, dq, nbits = (int(x) for x in rest[:3])
+        blocks = [int(x) for x in rest[3].split(",") if x != ""]
+        per = {b: [build(10000 + i, dq, nbits, b, b + 1, False) for i in range(nvec)] for b in blocks}
+        ready()
+        t0 = time.perf_counter()
+        counts = {str(b): int(orc.agg_or(per[b]).count()) for b in blocks}
+        reply({"counts": counts, "seconds": time.perf_counter() - t0})
+    else:
+        raise SystemExit(f"unknown cpu worker kind {kind}")
+
+
+def _spawn_workers(arglists):
+    import subprocess
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker"] + [str(a) for a in al],
+                              stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True, cwd=ROOT) for al in arglists]
+    return procs
+
+
+def _finish_workers(procs):
+    for p in procs:
+        try:
+            p.stdin.close()
+        except Exception:
+            pass
+        try:
+            p.wait(timeout=30)
+        except Exception:
+            p.kill()
+
+
+def _go(procs):
+    for p in procs:
+        line = p.stdout.readline()
+        if line.strip() != "READY":
+            raise RuntimeError(f"cpu worker failed to start: {line!r}")
+    for p in procs:
+        p.stdin.write("go\n"); p.stdin.flush()
 
 
 def cpu_baseline_allcores(nvec: int, dq: int, nbits: int, cores: int, reps: int = 3):
@@ -120,36 +209,17 @@ def cpu_baseline_allcores(nvec: int, dq: int, nbits: int, cores: int, reps: int 
     `cores` worker processes (plain interpreters that never load HIP).  Returns the exact full-size count (pins
     the GPU's headline result against the reference) and the aggregate rate = all operand bits x reps /
     (last end - first start) of the passes, all replicas running at once."""
-    import subprocess
     from bitmagic_amd.sharding import shard_range
     nblocks = (nbits + 65535) // 65536
     cores = max(1, min(cores, nblocks))
     t0 = time.perf_counter()
-    procs = []
-    for w in range(cores):
-        lo, hi = shard_range(nblocks, w, cores)
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", str(lo), str(hi), str(nvec),
-                                       str(dq), str(nbits), str(reps)], stdin=subprocess.PIPE, stdout=subprocess.PIPE,
-                                      text=True, cwd=ROOT))
+    procs = _spawn_workers([["and", *shard_range(nblocks, w, cores), nvec, dq, nbits, reps] for w in range(cores)])
     try:
-        for p in procs:
-            line = p.stdout.readline()
-            if line.strip() != "READY":
-                raise RuntimeError(f"cpu worker failed to start: {line!r}")
+        _go(procs)
         t_ready = time.perf_counter() - t0
-        for p in procs:
-            p.stdin.write("go\n"); p.stdin.flush()
         res = [json.loads(p.stdout.readline()) for p in procs]
     finally:
-        for p in procs:
-            try:
-                p.stdin.close()
-            except Exception:
-                pass
-            try:
-                p.wait(timeout=30)
-            except Exception:
-                p.kill()
+        _finish_workers(procs)
     full = sum(r["count"] for r in res)
     first = min(r["spans"][0][0] for r in res); last = max(r["spans"][-1][1] for r in res)
     bits = nvec * nblocks * 65536
@@ -161,68 +231,186 @@ def cpu_baseline_allcores(nvec: int, dq: int, nbits: int, cores: int, reps: int 
                                f"input build {t_ready:.1f}s not timed"}
 
 
+def cpu_pair_allcores(ida: int, idb: int, dq: int, nbits: int, cores: int, reps: int = 3):
+    """configs[1] on all host cores: count_and/or/xor/sub of ONE full-size pair, block ranges fanned out"""
+    from bitmagic_amd.sharding import shard_range
+    nblocks = (nbits + 65535) // 65536
+    cores = max(1, min(cores, nblocks))
+    procs = _spawn_workers([["pair", *shard_range(nblocks, w, cores), ida, idb, dq, nbits, reps] for w in range(cores)])
+    try:
+        _go(procs)
+        res = [json.loads(p.stdout.readline()) for p in procs]
+    finally:
+        _finish_workers(procs)
+    counts = [sum(r["counts"][op] for r in res) for op in range(4)]
+    first = min(r["spans"][0][0] for r in res); last = max(r["spans"][-1][1] for r in res)
+    return {"full_counts": counts, "allcores_gbit_s": round(2 * nblocks * 65536 * reps / (last - first) / 1e9, 1), "cores_used": cores}
+
+
+def cpu_rank_allcores(vid: int, dq: int, nbits: int, cores: int, sample_n, sample_r_fn):
+    """configs[3] on all host cores: every worker indexes its block range of the 4e9-bit vector; the range totals are
+    prefix-summed here (the one exchange SURVEY section 8(e) names), sampled rank / select queries are routed to the
+    range that owns them.  sample_r_fn(total) -> the sampled 1-based ranks.  -> (total, rank answers, select answers)"""
+    import numpy as np
+    from bitmagic_amd.sharding import shard_range
+    nblocks = (nbits + 65535) // 65536
+    cores = max(1, min(cores, nblocks))
+    ranges = [shard_range(nblocks, w, cores) for w in range(cores)]
+    procs = _spawn_workers([["rank", lo, hi, vid, dq, nbits] for lo, hi in ranges])
+    try:
+        _go(procs)
+        cnt = [json.loads(p.stdout.readline())["count"] for p in procs]
+        before = np.concatenate([[0], np.cumsum(np.asarray(cnt, dtype=np.uint64))]).astype(np.uint64)
+        total = int(before[-1])
+        sample_n = np.asarray(sample_n, dtype=np.uint64)
+        sample_r = np.asarray(sample_r_fn(total), dtype=np.uint64)
+        los = np.asarray([lo for lo, _ in ranges], dtype=np.uint64)
+        own_n = np.searchsorted(los, sample_n >> np.uint64(16), side="right") - 1
+        own_r = np.searchsorted(before, sample_r, side="left") - 1          # before[m] < r <= before[m + 1]
+        for w, p in enumerate(procs):
+            qn = sample_n[own_n == w] - los[w] * np.uint64(65536)
+            qr = sample_r[own_r == w] - before[w]
+            p.stdin.write(json.dumps({"n": [int(x) for x in qn], "r": [int(x) for x in qr]}) + "\n"); p.stdin.flush()
+        ans_n = np.zeros(sample_n.size, np.uint64); ans_r = np.zeros(sample_r.size, np.uint64)
+        for w, p in enumerate(procs):
+            a = json.loads(p.stdout.readline())
+            ans_n[own_n == w] = np.asarray(a["rank"], dtype=np.uint64) + before[w]
+            ans_r[own_r == w] = np.asarray(a["select"], dtype=np.uint64) + los[w] * np.uint64(65536)
+    finally:
+        _finish_workers(procs)
+    return total, sample_n, ans_n, sample_r, ans_r
+
+
+def cpu_or_sample(nvec: int, dq: int, nbits: int, blocks, cores: int):
+    """configs[4] on all host cores, bounded: combine_or over ALL nvec vectors restricted to each sampled block column
+    (a column is independent, src/bmaggregator.h:1113-1121).  -> {block: count}, busiest worker's seconds"""
+    blocks = list(blocks)
+    cores = max(1, min(cores, len(blocks)))
+    lists = [blocks[w::cores] for w in range(cores)]
+    procs = _spawn_workers([["or", nvec, dq, nbits, ",".join(str(b) for b in bl)] for bl in lists])
+    try:
+        _go(procs)
+        res = [json.loads(p.stdout.readline()) for p in procs]
+    finally:
+        _finish_workers(procs)
+    counts = {}
+    for r in res:
+        counts.update({int(k): v for k, v in r["counts"].items()})
+    return counts, max(r["seconds"] for r in res), res[0]["kind"], res[0]["impl"], cores
+
+
 # ----------------------------------------------------------------------------------------------------
-def setup_dist(args):
-    import torch
-    import torch.distributed as dist
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    # launched by torch.distributed.run (RANK set): always go through RCCL, also for a 1-rank job, so the
-    # collective path is exercised wherever the launcher is used
-    use_dist = world > 1 or ("RANK" in os.environ and "MASTER_PORT" in os.environ)
-    # test hook (tools/gpu_runs: exercising the N > 1 code path on a ONE-GPU box): every rank on device 0, gloo instead of RCCL
-    # (RCCL refuses two ranks on one device).  Timings of such a run mean nothing; it checks sharding, gathers and the JSON line.
-    one_dev = os.environ.get("BMX_BENCH_TEST_ONE_DEVICE") == "1"
-    if one_dev:
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    if use_dist and one_dev:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo", rank=rank, world_size=world)
-    elif use_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # RCCL prints a version banner on STDOUT when its first communicator comes up: keep stdout for the ONE JSON line
-        # (the banner goes to stderr) by creating the communicator -- init + a first all-reduce -- under a redirect
-        sys.stdout.flush()
-        saved = os.dup(1)
-        os.dup2(2, 1)
-        try:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-            t = torch.zeros(1, dtype=torch.int64, device="cuda")
-            dist.all_reduce(t)
-            torch.cuda.synchronize()
-        finally:
-            sys.stdout.flush()
-            os.dup2(saved, 1)
-            os.close(saved)
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for N > 1"
-    return world, rank, local_rank, use_dist
+# process set-up
+# ----------------------------------------------------------------------------------------------------
+class Env:
+    """how this process takes part in the run: mode single | torchrun | group"""
+    def __init__(self, args):
+        import torch
+        self.torch = torch
+        self.args = args
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.one_dev = os.environ.get(ONE_DEV_HOOK) == "1"
+        launched = "RANK" in os.environ and "MASTER_PORT" in os.environ
+        self.mode = "torchrun" if launched else ("group" if args.gpus > 1 else "single")
+        self.use_dist = launched
+        self.dist = None
+        self.stream = None
+        self.ctx = None
+
+    def need_devices(self, n):
+        have = self.torch.cuda.device_count()
+        if not self.one_dev and have < n:
+            sys.stderr.write(f"bench.py: --gpus {n} needs {n} visible devices, found {have}\n")
+            sys.exit(2)
+
+    def setup(self):
+        """single / torchrun: one device, one explicit stream shared by the HIP kernels, torch and RCCL"""
+        import bitmagic_amd as bm
+        torch, args = self.torch, self.args
+        if self.mode == "torchrun":
+            if self.world != args.gpus:
+                sys.stderr.write(f"bench.py: --gpus {args.gpus} but torch.distributed.run started {self.world} ranks\n")
+                sys.exit(2)
+            self.need_devices(self.world)
+        else:
+            self.need_devices(1)
+        if self.one_dev:
+            # test hook (exercising the N > 1 code path on a ONE-GPU box): every rank on device 0, gloo instead of RCCL
+            # (RCCL refuses two ranks on one device).  Timings of such a run mean nothing; it checks sharding,
+            # gathers and the JSON line.
+            self.local_rank = 0
+        torch.cuda.set_device(self.local_rank)
+        if self.use_dist:
+            import torch.distributed as dist
+            self.dist = dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if self.one_dev:
+                dist.init_process_group("gloo", rank=self.rank, world_size=self.world)
+            else:
+                # RCCL prints a version banner on STDOUT when its first communicator comes up: keep stdout for the ONE
+                # JSON line (the banner goes to stderr) by creating the communicator under a redirect
+                sys.stdout.flush()
+                saved = os.dup(1)
+                os.dup2(2, 1)
+                try:
+                    dist.init_process_group("nccl", rank=self.rank, world_size=self.world,
+                                            device_id=torch.device("cuda", self.local_rank))
+                    t = torch.zeros(1, dtype=torch.int64, device="cuda")
+                    dist.all_reduce(t)
+                    torch.cuda.synchronize()
+                finally:
+                    sys.stdout.flush()
+                    os.dup2(saved, 1)
+                    os.close(saved)
+        self.stream = torch.cuda.Stream()
+        torch.cuda.set_stream(self.stream)
+        self.ctx = bm.context(self.local_rank, self.stream.cuda_stream)
+        return self
+
+    def rccl_ranks(self):
+        if not self.use_dist:
+            return None
+        return self.dist.get_world_size()
+
+    def finish(self):
+        if self.use_dist:
+            self.dist.destroy_process_group()
 
 
-def timed_region(step, steps, warmup, ctx, use_dist):
+def reexec_torchrun(args):
+    """`bench.py --gpus N --launcher torchrun` without RANK: become the launcher"""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    argv = [a for a in sys.argv[1:] if a != "--launcher" and a != "torchrun" and not a.startswith("--launcher=")]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    os.execv(sys.executable, cmd)
+
+
+def timed_region(step, steps, warmup, env):
     """W warm-up steps, then EXACTLY `steps` steps bracketed by barrier + synchronize; wall time = max over ranks.
     Also returns the HIP-event time of the same region on the launch stream."""
-    import torch
-    import torch.distributed as dist
+    torch, dist = env.torch, env.dist
     for _ in range(warmup):
         step()
     torch.cuda.synchronize()
-    if use_dist:
+    if env.use_dist:
         dist.barrier()
     torch.cuda.synchronize()
-    ctx.timer_start()                                    # HIP events on the launch stream
+    env.ctx.timer_start()                                # HIP events on the launch stream
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
-    ev_ms = ctx.timer_stop_ms()
+    ev_ms = env.ctx.timer_stop_ms()
     torch.cuda.synchronize()
-    if use_dist:
+    if env.use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    if use_dist:
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cpu" if env.one_dev else "cuda")
+    if env.use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     return float(tmax.item()), ev_ms
 
@@ -237,14 +425,13 @@ def event_avg_ms(fn, reps, ctx):
     return ctx.timer_stop_ms() / reps
 
 
-def gather_floats(x: float, use_dist, world):
-    import torch
-    import torch.distributed as dist
-    t = torch.tensor([x], dtype=torch.float64, device="cpu" if os.environ.get("BMX_BENCH_TEST_ONE_DEVICE") == "1" else "cuda")
-    if not use_dist:
+def gather_floats(x: float, env):
+    torch = env.torch
+    t = torch.tensor([x], dtype=torch.float64, device="cpu" if env.one_dev else "cuda")
+    if not env.use_dist:
         return [float(x)]
-    out = [torch.zeros_like(t) for _ in range(world)]
-    dist.all_gather(out, t)
+    out = [torch.zeros_like(t) for _ in range(env.world)]
+    env.dist.all_gather(out, t)
     return [float(o.item()) for o in out]
 
 
@@ -261,30 +448,53 @@ def traffic_note(workload: str):
     return None, None
 
 
+def traffic_file(name: str):
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", name)))
+        return tj["hbm_bytes_per_launch"], tj["source"] + " (PMC pass of a separate rocprofv3 run, not measured in this run)", tj
+    except Exception:
+        return None, None, {}
+
+
+def dataset_label(args):
+    """the data set as it was actually generated (density from --density-q16, not a fixed string)"""
+    pct = args.density_q16 / 65536 * 100
+    d = f"{pct:.3g}%"
+    if args.independent:
+        return f"data set B (independent Bernoulli {d}: the AND dies early)"
+    return f"data set A (common {d} OR noise {d}: no early exit)"
+
+
+def headline_workload(args, scaling, world):
+    return (f"aggregator pipeline combine_and_sub counts-only: {args.nvec}-way AND+COUNT, "
+            f"{args.nvec} x {args.nbits}-bit vectors " + ("per GPU, " if scaling == "weak" and world > 1 else "in total, ")
+            + dataset_label(args))
+
+
 # ----------------------------------------------------------------------------------------------------
 # configs[2]: the headline
 # ----------------------------------------------------------------------------------------------------
-def run_headline(args):
-    # CPU legs first (rank 0 of a 1-GPU run only), before torch / HIP are loaded into this process
-    cpu = None
+def headline_cpu(args):
+    """CPU legs (rank 0 of a 1-GPU run only), before torch / HIP are loaded into this process"""
     nblocks_full = (args.nbits + 65535) // 65536
     sb = min(args.cpu_sample_blocks, nblocks_full)
-    if int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.no_cpu:
-        try:
-            cpu = cpu_baseline_1core(args.nvec, args.density_q16, args.nbits, sb, None)
-            if not args.no_allcores and not args.independent:
-                ncores = args.cpu_cores or len(os.sched_getaffinity(0))
-                cpu.update(cpu_baseline_allcores(args.nvec, args.density_q16, args.nbits, ncores))
-        except Exception as e:  # the baseline is a reported number, never the product path
-            cpu = {"value": None, "unit": "Gbit/s", "cores": 1, "kind": "port", "sample": f"failed: {e}"}
-    import torch
-    import torch.distributed as dist
+    try:
+        cpu = cpu_baseline_1core(args.nvec, args.density_q16, args.nbits, sb, None)
+        if not args.no_allcores and not args.independent:
+            ncores = args.cpu_cores or len(os.sched_getaffinity(0))
+            cpu.update(cpu_baseline_allcores(args.nvec, args.density_q16, args.nbits, ncores))
+    except Exception as e:  # the baseline is a reported number, never the product path
+        cpu = {"value": None, "unit": "Gbit/s", "cores": 1, "kind": "port", "sample": f"failed: {e}"}
+    return cpu
+
+
+def run_headline(args, env, cpu):
     import bitmagic_amd as bm
-    world, rank, local_rank, use_dist = setup_dist(args)
+    torch, dist = env.torch, env.dist
+    world, rank, use_dist, ctx = env.world, env.rank, env.use_dist, env.ctx
+    nblocks_full = (args.nbits + 65535) // 65536
+    sb = min(args.cpu_sample_blocks, nblocks_full)
     scaling = args.scaling if args.scaling != "auto" else "strong"       # N = 1: both modes are the same run
-    tstream = torch.cuda.Stream()                        # one explicit stream shared by the HIP kernels, torch and RCCL
-    torch.cuda.set_stream(tstream)
-    ctx = bm.context(local_rank, tstream.cuda_stream)
     counts = torch.zeros(1, dtype=torch.int64, device="cuda")
     agg = bm.aggregator(ctx)
 
@@ -316,21 +526,20 @@ def run_headline(args):
             kernel()
             if use_dist:
                 dist.all_reduce(counts)                  # RCCL: 8 bytes per arg-group, same stream as the kernel
-        dt, ev_ms = timed_region(step, args.steps, args.warmup, ctx, use_dist)
+        dt, ev_ms = timed_region(step, args.steps, args.warmup, env)
         total = int(counts.item())
         k_ms = event_avg_ms(kernel, max(5, min(args.steps, 20)), ctx)      # the kernel alone
         ar_us = None
         if use_dist:
             ar_us = event_avg_ms(lambda: dist.all_reduce(counts), 20, ctx) * 1e3
-        r = {"dt": dt, "ev_ms": ev_ms, "count": total, "op_bytes": op_bytes, "k_ms": k_ms, "ar_us": ar_us,
-             "build_s": t_build, "blocks": hi - lo, "plan": pipe.describe(), "nlaunch": pipe.launches(), "stat0": vecs[0].calc_stat(), "mem": ctx.mem_used(),
-             "pipe": pipe, "vecs": vecs}
-        return r
+        return {"dt": dt, "ev_ms": ev_ms, "count": total, "op_bytes": op_bytes, "k_ms": k_ms, "ar_us": ar_us,
+                "build_s": t_build, "blocks": hi - lo, "plan": pipe.describe(), "nlaunch": pipe.launches(),
+                "stat0": vecs[0].calc_stat(), "mem": ctx.mem_used(), "pipe": pipe, "vecs": vecs}
 
     main = run_mode(scaling)
-    k_all = gather_floats(main["k_ms"], use_dist, world)
-    bytes_all = gather_floats(float(main["op_bytes"]), use_dist, world)
-    # 1-GPU shard efficiency (VERDICT r1 item 1c): the 1/8 block range of the same collection, time x 8 vs the full time
+    k_all = gather_floats(main["k_ms"], env)
+    bytes_all = gather_floats(float(main["op_bytes"]), env)
+    # 1-GPU shard efficiency: the 1/8 block range of the same collection, time x 8 vs the full time
     shard_eff = None
     if world == 1 and scaling == "strong" and not args.no_shard_probe and not args.independent:
         lo, hi = bm.shard_range(nblocks_full, 0, 8)
@@ -341,7 +550,7 @@ def run_headline(args):
                      "rate_vs_full": round((b_sh / t_sh) / (main["op_bytes"] / main["k_ms"]), 4),
                      "note": "block columns [0, 1907) of the resident collection = what one of 8 GPUs runs under --scaling strong"}
     gpu_sample = None
-    if world == 1 and not args.no_cpu:
+    if world == 1 and cpu is not None:
         gpu_sample = int(agg._run_pipeline(main["pipe"], 0, sb)[0])
     weak = None
     del main["pipe"], main["vecs"]
@@ -350,96 +559,210 @@ def run_headline(args):
         w = run_mode("weak")
         weak = {"value": round(world * args.nvec * args.nbits * args.steps / w["dt"] / 1e9, 2), "unit": "Gbit/s",
                 "ms_per_step": round(w["dt"] / args.steps * 1e3, 4), "result_count": w["count"],
-                "note": "every rank owns its own 256 x 1e9-bit collection (document-sharded index)"}
+                "note": f"every rank owns its own {args.nvec} x {args.nbits}-bit collection (document-sharded index)"}
         del w["pipe"], w["vecs"]
-    if rank == 0:
-        bits_per_step = args.nvec * args.nbits * (world if scaling == "weak" else 1)
-        value = bits_per_step * args.steps / main["dt"] / 1e9
-        achieved = main["op_bytes"] / (main["k_ms"] * 1e-3) / 1e9
-        # the PMC figure belongs to the headline data set on one GPU (density 10 %, data set A, 6 launch windows): any other
-        # density / data set / shard runs another kernel or another launch plan and carries no traffic figure
-        headline = args.density_q16 == 6554 and not args.independent and world == 1
-        traffic, tsrc = traffic_note(f"agg_and_count_{args.nvec}x{args.nbits}") if headline else (None, None)
-        if traffic is not None and main["nlaunch"] != 6: traffic, tsrc = None, None
-        res = {
-            "metric": METRIC, "value": round(value, 2), "unit": "Gbit/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(main["dt"] / args.steps * 1e3, 4), "higher_is_better": True,
-            "scaling": scaling, "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": f"aggregator pipeline combine_and_sub counts-only: {args.nvec}-way AND+COUNT, "
-                                   f"{args.nvec} x {args.nbits}-bit vectors "
-                                   + ("per GPU, " if scaling == "weak" and world > 1 else "in total, ")
-                                   + ("data set B (independent 10%)" if args.independent else
-                                      "data set A (common 10% OR noise 10%, no early exit)"),
-                       "baseline_config": "configs[2]", "vectors": args.nvec, "bits_per_vector": args.nbits,
-                       "density_q16": args.density_q16, "blocks_per_vector": nblocks_full,
-                       "block_types_vec0": main["stat0"],
-                       "sharding": (f"block-range shards: rank r holds blocks shard_range({nblocks_full}, r, {world}) of every vector"
-                                    if scaling == "strong" else f"document shards x{world}"),
-                       "blocks_per_rank": main["blocks"], "result_count": main["count"],
-                       "build_seconds": round(main["build_s"], 2), "hbm_resident_bytes": main["mem"]},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": tsrc,
-                         "kernel": main["plan"], "launches_per_step": main["nlaunch"],
-                         "algorithmic_bytes_per_launch": main["op_bytes"] // main["nlaunch"],
-                         "avg_launch_ms": round(main["k_ms"] / main["nlaunch"], 4),
-                         "algorithmic_bytes_per_step": main["op_bytes"], "kernel_ms_per_step": round(main["k_ms"], 4),
-                         "scope": "rank 0's GPU",
-                         "timing": "hipEvent pair on the launch stream around back-to-back passes of the kernel alone (a pass = "
-                                   "launches_per_step launches over equal column windows); avg_launch_ms = pass time / launches, "
-                                   "inter-launch gaps included"},
-            "per_rank": {"kernel_ms": [round(x, 4) for x in k_all],
-                         "GBps": [round(b / (k * 1e-3) / 1e9, 1) for b, k in zip(bytes_all, k_all)],
-                         "allreduce_us": None if main["ar_us"] is None else round(main["ar_us"], 1),
-                         "step_event_ms": round(main["ev_ms"] / args.steps, 4)},
-        }
-        if args.independent:
-            # data set B: the AND dies after a few operands and the kernel stops reading a column there (the reference's digest
-            # exit); full-read bytes over an early-exit time is not a bandwidth: report time and rate only
-            res["roofline"].update({"achieved": None, "frac": None, "per_rank_note": "early exit: bytes actually read are not the full operand bytes",
-                                    "note": "early-exit data set: time and Gbit/s of LOGICAL operand bits only; no bandwidth figure"})
-            res["per_rank"]["GBps"] = None
-        if shard_eff:
-            res["shard_1of8_on_one_gpu"] = shard_eff
-        if weak:
-            res["weak_scaling"] = weak
-        if cpu is not None:
-            if cpu.get("value") is not None and not args.independent:
-                cpu["matches_gpu"] = bool(cpu["count"] == gpu_sample)
-                if "full_count" in cpu:
-                    cpu["matches_gpu_full"] = bool(cpu["full_count"] == main["count"])
-            res["cpu_baseline"] = cpu
-        print(json.dumps(res))
-    if use_dist:
-        dist.destroy_process_group()
+    ctx.trim()
+    if rank != 0:
+        return None
+    bits_per_step = args.nvec * args.nbits * (world if scaling == "weak" else 1)
+    value = bits_per_step * args.steps / main["dt"] / 1e9
+    achieved = main["op_bytes"] / (main["k_ms"] * 1e-3) / 1e9
+    # the PMC figure belongs to the headline data set on one GPU (density 10 %, data set A, 6 launch windows): any other
+    # density / data set / shard runs another kernel or another launch plan and carries no traffic figure
+    headline = args.density_q16 == 6554 and not args.independent and world == 1
+    traffic, tsrc = traffic_note(f"agg_and_count_{args.nvec}x{args.nbits}") if headline else (None, None)
+    if traffic is not None and main["nlaunch"] != 6: traffic, tsrc = None, None
+    res = {
+        "metric": METRIC, "value": round(value, 2), "unit": "Gbit/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(main["dt"] / args.steps * 1e3, 4), "higher_is_better": True,
+        "scaling": scaling, "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+        "mode": env.mode,
+        "config": {"workload": headline_workload(args, scaling, world),
+                   "baseline_config": "configs[2]", "vectors": args.nvec, "bits_per_vector": args.nbits,
+                   "density_q16": args.density_q16, "blocks_per_vector": nblocks_full,
+                   "block_types_vec0": main["stat0"],
+                   "sharding": (f"block-range shards: rank r holds blocks shard_range({nblocks_full}, r, {world}) of every vector"
+                                if scaling == "strong" else f"document shards x{world}"),
+                   "blocks_per_rank": main["blocks"], "result_count": main["count"],
+                   "build_seconds": round(main["build_s"], 2), "hbm_resident_bytes": main["mem"]},
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": tsrc,
+                     "kernel": main["plan"], "launches_per_step": main["nlaunch"],
+                     "algorithmic_bytes_per_launch": main["op_bytes"] // main["nlaunch"],
+                     "avg_launch_ms": round(main["k_ms"] / main["nlaunch"], 4),
+                     "algorithmic_bytes_per_step": main["op_bytes"], "kernel_ms_per_step": round(main["k_ms"], 4),
+                     "scope": "rank 0's GPU",
+                     "timing": "hipEvent pair on the launch stream around back-to-back passes of the kernel alone (a pass = "
+                               "launches_per_step launches over equal column windows); avg_launch_ms = pass time / launches, "
+                               "inter-launch gaps included"},
+        "per_rank": {"kernel_ms": [round(x, 4) for x in k_all],
+                     "GBps": [round(b / (k * 1e-3) / 1e9, 1) for b, k in zip(bytes_all, k_all)],
+                     "allreduce_us": None if main["ar_us"] is None else round(main["ar_us"], 1),
+                     "rccl_ranks": env.rccl_ranks(),
+                     "step_event_ms": round(main["ev_ms"] / args.steps, 4)},
+    }
+    if args.independent:
+        # data set B: the AND dies after a few operands and the kernel stops reading a column there (the reference's digest
+        # exit); full-read bytes over an early-exit time is not a bandwidth: report time and rate only
+        res["roofline"].update({"achieved": None, "frac": None, "per_rank_note": "early exit: bytes actually read are not the full operand bytes",
+                                "note": "early-exit data set: time and Gbit/s of LOGICAL operand bits only; no bandwidth figure"})
+        res["per_rank"]["GBps"] = None
+    if shard_eff:
+        res["shard_1of8_on_one_gpu"] = shard_eff
+    if weak:
+        res["weak_scaling"] = weak
+    if cpu is not None:
+        if cpu.get("value") is not None and not args.independent:
+            cpu["matches_gpu"] = bool(cpu["count"] == gpu_sample)
+            if "full_count" in cpu:
+                cpu["matches_gpu_full"] = bool(cpu["full_count"] == main["count"])
+        res["cpu_baseline"] = cpu
+    return res
+
+
+def run_headline_group(args):
+    """plain `bench.py --gpus N` (no launcher): ONE process, N devices, through the product's multi-GPU layer
+    (bmx_group + bmx_gpipeline_run_counts; include/bmx.h "device groups")"""
+    import torch
+    import bitmagic_amd as bm
+    n = args.gpus
+    one_dev = os.environ.get(ONE_DEV_HOOK) == "1"
+    have = torch.cuda.device_count()
+    if not one_dev and have < n:
+        sys.stderr.write(f"bench.py: --gpus {n} needs {n} visible devices, found {have}\n")
+        sys.exit(2)
+    devices = [0] * n if one_dev else list(range(n))
+    want_rccl = args.group_exchange == "rccl" and not one_dev
+    rccl_error = None
+    grp = None
+    if want_rccl:
+        sys.stdout.flush()
+        saved = os.dup(1); os.dup2(2, 1)                # RCCL's banner goes to stderr, stdout carries the ONE JSON line
+        try:
+            grp = bm.group(devices, bm.GROUP_RCCL)
+        except Exception as e:
+            rccl_error = str(e)
+        finally:
+            sys.stdout.flush(); os.dup2(saved, 1); os.close(saved)
+    if grp is None:
+        grp = bm.group(devices, bm.GROUP_HOST_SUM)
+    exchange = "rccl_allreduce" if (want_rccl and rccl_error is None) else "host_sum"
+    rccl_ranks = grp.rccl_ranks()
+    nblocks_full = (args.nbits + 65535) // 65536
+    scaling = args.scaling if args.scaling != "auto" else "strong"
+    gagg = bm.gaggregator(grp)
+
+    def sync_all():
+        for d in sorted(set(devices)):
+            torch.cuda.synchronize(d)
+
+    def run_mode(mode):
+        nbits = args.nbits if mode == "strong" else args.nbits * n      # weak: every member holds a 1e9-bit share
+        t0 = time.perf_counter()
+        vecs = [bm.gbvector.generate(grp, SEED, v, args.density_q16, nbits, with_common=not args.independent)
+                for v in range(args.nvec)]
+        pipe = bm.gpipeline(grp)
+        ag = pipe.add()
+        for v in vecs:
+            ag.add(v, 0)
+        pipe.complete()
+        sync_all()
+        t_build = time.perf_counter() - t0
+        step = lambda: gagg.combine_and_sub(pipe)
+        for _ in range(args.warmup):
+            step()
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            cnt = step()
+        sync_all()
+        dt = time.perf_counter() - t0
+        k_ms = [0.0] * n; x_ms = [0.0] * n
+        reps = max(5, min(args.steps, 20))
+        for _ in range(reps):                            # per-member device times (HIP events on the member streams)
+            step()
+            k_ms = [a + b for a, b in zip(k_ms, pipe.last_ms())]
+            x_ms = [a + b for a, b in zip(x_ms, pipe.last_exchange_ms())]
+        k_ms = [a / reps for a in k_ms]; x_ms = [a / reps for a in x_ms]
+        plan, nlaunch = pipe.describe(0)
+        r = {"dt": dt, "count": int(cnt[0]), "k_ms": k_ms, "x_ms": x_ms, "bytes": pipe.operand_bytes(), "plan": plan,
+             "nlaunch": nlaunch, "build_s": t_build, "stat0": vecs[0].info(),
+             "ranges": [grp.shard_range((nbits + 65535) // 65536, m) for m in range(n)]}
+        del pipe, vecs
+        return r
+
+    main = run_mode(scaling)
+    weak = None
+    if scaling == "strong" and not args.no_weak:
+        w = run_mode("weak")
+        weak = {"value": round(n * args.nvec * args.nbits * args.steps / w["dt"] / 1e9, 2), "unit": "Gbit/s",
+                "ms_per_step": round(w["dt"] / args.steps * 1e3, 4), "result_count": w["count"],
+                "note": f"{args.nvec} vectors of {n} x {args.nbits} bits: every member holds a {args.nbits}-bit share of each"}
+    bits_per_step = args.nvec * args.nbits * (n if scaling == "weak" else 1)
+    value = bits_per_step * args.steps / main["dt"] / 1e9
+    achieved = main["bytes"][0] / (main["k_ms"][0] * 1e-3) / 1e9
+    c = main["stat0"]["counts"]
+    res = {
+        "metric": METRIC, "value": round(value, 2), "unit": "Gbit/s", "n_gpus": n, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(main["dt"] / args.steps * 1e3, 4), "higher_is_better": True,
+        "scaling": scaling, "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+        "mode": "group", "exchange": exchange,
+        "config": {"workload": headline_workload(args, scaling, n), "baseline_config": "configs[2]", "vectors": args.nvec,
+                   "bits_per_vector": args.nbits, "density_q16": args.density_q16, "blocks_per_vector": nblocks_full,
+                   "block_types_vec0": {"null_blocks": c[0], "full_blocks": c[1], "bit_blocks": c[2], "gap_blocks": c[3]},
+                   "sharding": "bmx_group: member m holds blocks bmx_group_shard_range(nblocks, m) of every vector",
+                   "member_block_ranges": main["ranges"], "devices": devices, "result_count": main["count"],
+                   "build_seconds": round(main["build_s"], 2)},
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "kernel": main["plan"],
+                     "launches_per_step": main["nlaunch"], "algorithmic_bytes_per_launch": main["bytes"][0] // max(main["nlaunch"], 1),
+                     "avg_launch_ms": round(main["k_ms"][0] / max(main["nlaunch"], 1), 4),
+                     "algorithmic_bytes_per_step": main["bytes"][0], "kernel_ms_per_step": round(main["k_ms"][0], 4),
+                     "scope": "member 0's GPU",
+                     "timing": "hipEvent pair on member 0's stream around its launches of one bmx_gpipeline_run_counts call, "
+                               "averaged over the calls after the timed region"},
+        "per_rank": {"kernel_ms": [round(x, 4) for x in main["k_ms"]],
+                     "GBps": [round(b / (k * 1e-3) / 1e9, 1) if k > 0 else None for b, k in zip(main["bytes"], main["k_ms"])],
+                     "allreduce_us": round(max(main["x_ms"]) * 1e3, 1), "rccl_ranks": rccl_ranks,
+                     "exchange_us_per_member": [round(x * 1e3, 1) for x in main["x_ms"]],
+                     "note": "allreduce_us = device time from the end of a member's kernel to the end of the exchange (it "
+                             "includes waiting for the slowest member)"},
+    }
+    if one_dev:
+        res["test_hook"] = f"{ONE_DEV_HOOK}=1: all members on device 0; timings mean nothing"
+    if rccl_error is not None:
+        res["rccl_error"] = rccl_error
+    if weak:
+        res["weak_scaling"] = weak
+    grp.close()
+    return res
 
 
 # ----------------------------------------------------------------------------------------------------
 # configs[1]: pairwise ops on 1e9-bit vectors, HBM-cold
 # ----------------------------------------------------------------------------------------------------
-def run_pairwise(args):
+def run_pairwise(args, env, dq=None, quick=False):
     import ctypes as C
-    import torch
     import bitmagic_amd as bm
     from bitmagic_amd import _ffi
-    world, rank, local_rank, use_dist = setup_dist(args)
-    s = torch.cuda.Stream(); torch.cuda.set_stream(s)
-    ctx = bm.context(local_rank, s.cuda_stream)
+    torch, ctx = env.torch, env.ctx
     L = _ffi.lib()
-    dq = args.density_q16
+    dq = args.density_q16 if dq is None else dq
+    nbits = args.nbits
     npairs = args.pairs                                  # distinct pairs: npairs x 250 MB >> 256 MB Infinity Cache
-    va = [bm.bvector.generate(ctx, SEED, 2 * i + 1, dq, args.nbits) for i in range(npairs)]
-    vb = [bm.bvector.generate(ctx, SEED, 2 * i + 2, dq, args.nbits) for i in range(npairs)]
+    va = [bm.bvector.generate(ctx, SEED, 2 * i + 1, dq, nbits) for i in range(npairs)]
+    vb = [bm.bvector.generate(ctx, SEED, 2 * i + 2, dq, nbits) for i in range(npairs)]
     pair_bytes = []
     for a, b in zip(va, vb):
         ia, ib = a.info(), b.info()
         pair_bytes.append((ia["counts"][2] + ib["counts"][2]) * 8192 + 2 * (ia["gap_words"] + ib["gap_words"]))
-    dcnt = torch.zeros(npairs, dtype=torch.int64, device="cuda")
+    dcnt = torch.zeros(4 * npairs, dtype=torch.int64, device="cuda")
     per_op = {}
     for op, name in enumerate(["and", "or", "xor", "sub"]):
         def sweep(op=op):
             for i in range(npairs):
-                L.bmx_count_op2_dev(ctx._h, op, va[i]._h, vb[i]._h, C.c_void_p(dcnt.data_ptr() + 8 * i))
-        ms = event_avg_ms(sweep, 5, ctx) / npairs
+                L.bmx_count_op2_dev(ctx._h, op, va[i]._h, vb[i]._h, C.c_void_p(dcnt.data_ptr() + 8 * (op * npairs + i)))
+        ms = event_avg_ms(sweep, 3 if quick else 5, ctx) / npairs
         per_op[name] = {"kernel_ms": round(ms, 4), "GBps": round(sum(pair_bytes) / npairs / ms / 1e6, 1)}
         # materialised result (opt_none), whole host call incl. result creation
         keep = []
@@ -453,69 +776,85 @@ def run_pairwise(args):
         per_op[name]["materialised_host_call_ms"] = round(host_ms, 4)
         per_op[name]["materialised_GBps"] = round((pair_bytes[-1] + out_blocks * 8192) / host_ms / 1e6, 1)
         keep.clear()
+    torch.cuda.synchronize()
+    all_counts = dcnt.cpu().tolist()
+    pair0 = [all_counts[op * npairs] for op in range(4)]
     # timed region per the contract: a "step" = count_and over every pair (npairs launches)
     def step():
         for i in range(npairs):
             L.bmx_count_op2_dev(ctx._h, 0, va[i]._h, vb[i]._h, C.c_void_p(dcnt.data_ptr() + 8 * i))
-    dt, ev_ms = timed_region(step, args.steps, args.warmup, ctx, use_dist)
+    steps, warmup = (5, 2) if quick else (args.steps, args.warmup)
+    dt, ev_ms = timed_region(step, steps, warmup, env)
     torch.cuda.synchronize()
     counts = dcnt.cpu().tolist()
-    k_ms = ev_ms / args.steps / npairs
+    k_ms = ev_ms / steps / npairs
     bytes_launch = sum(pair_bytes) / npairs
     achieved = bytes_launch / k_ms / 1e6
+    all_bit = all(v.calc_stat()["bit_blocks"] == v.info()["nblocks"] for v in (va[0], vb[0]))
     c1_traffic, c1_tsrc = None, None
-    if args.nbits == 1_000_000_000 and dq == 6554 and os.environ.get("BMX_PAIR_STREAM", "-1") == "-1":
-        try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic_config1.json")))
-            c1_traffic, c1_tsrc = tj["hbm_bytes_per_launch"], tj["source"] + " (PMC pass of a separate rocprofv3 run, not measured in this run)"
-        except Exception:
-            pass
+    if nbits == NBITS_1G and dq == 6554 and os.environ.get("BMX_PAIR_STREAM", "-1") == "-1":
+        c1_traffic, c1_tsrc, _ = traffic_file("traffic_config1.json")
+    pct = dq / 65536 * 100
     res = {"metric": "Gbit/s of operand bits, pairwise count_and on 1e9-bit vectors (HBM-cold rotation)",
-           "value": round(2 * args.nbits * npairs * args.steps / dt / 1e9, 2), "unit": "Gbit/s", "n_gpus": 1,
-           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+           "value": round(2 * nbits * npairs * steps / dt / 1e9, 2), "unit": "Gbit/s", "n_gpus": 1,
+           "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 4),
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-           "config": {"workload": f"bm::count_and/or/xor/sub + bit_and/or/xor/sub on 2 x {args.nbits}-bit vectors, density q16 {dq}, "
+           "config": {"workload": f"bm::count_and/or/xor/sub + bit_and/or/xor/sub on 2 x {nbits}-bit vectors, Bernoulli {pct:.3g}% (density q16 {dq}), "
                                   f"rotating over {npairs} distinct pairs ({sum(pair_bytes) / 1e9:.2f} GB: not Infinity-Cache resident)",
                       "baseline_config": "configs[1]", "block_types_vec0": va[0].calc_stat(), "per_op": per_op,
-                      "count_and": counts[:4]},
+                      "count_and": counts[:4], "pair0_counts_and_or_xor_sub": pair0},
            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": c1_traffic, "traffic_source": c1_tsrc,
-                        "kernel": ("k_count_op2_stream<4, true>" if all(v.calc_stat()["bit_blocks"] == v.info()["nblocks"] for v in (va[0], vb[0]))
-                                   and va[0].info()["nblocks"] >= 2048 and os.environ.get("BMX_PAIR_STREAM", "-1") == "-1" else "k_count_op2"),
+                        "kernel": L_pair_kernel_name(all_bit, va[0].info()["nblocks"]),
                         "algorithmic_bytes_per_launch": int(bytes_launch), "avg_launch_ms": round(k_ms, 4),
                         "timing": "hipEvent pair on the launch stream around the timed region / (steps x pairs)"}}
+    del va, vb
+    ctx.trim()
     if not args.no_cpu:
         try:
             P, orc, kind = _pick_oracle()
-            sb = min(2048, (args.nbits + 65535) // 65536)
-            wa = P.gen_words(SEED, 1, dq, args.nbits, word_off=0, nwords=sb * 2048)
-            wb = P.gen_words(SEED, 2, dq, args.nbits, word_off=0, nwords=sb * 2048)
+            sb = min(2048, (nbits + 65535) // 65536)
+            wa = P.gen_words(SEED, 1, dq, nbits, word_off=0, nwords=sb * 2048)
+            wb = P.gen_words(SEED, 2, dq, nbits, word_off=0, nwords=sb * 2048)
             ha, hb = orc.import_words(wa, True, sb * 65536), orc.import_words(wb, True, sb * 65536)
             best = None
             for _ in range(20):
                 t0 = time.perf_counter(); c = orc.count_op2(0, ha, hb); d = time.perf_counter() - t0
                 best = d if best is None else min(best, d)
-            res["cpu_baseline"] = {"value": round(2 * sb * 65536 / best / 1e9, 2), "unit": "Gbit/s", "cores": 1, "kind": kind,
-                                   "impl": orc.name, "sample": f"bm::count_and on the first {sb} blocks of pair 0, best of 20", "count": int(c)}
+            cpu = {"value": round(2 * sb * 65536 / best / 1e9, 2), "unit": "Gbit/s", "cores": 1, "kind": kind,
+                   "impl": orc.name, "sample": f"bm::count_and on the first {sb} blocks of pair 0, best of 20", "count": int(c)}
+            if not args.no_allcores:
+                ncores = args.cpu_cores or len(os.sched_getaffinity(0))
+                full = cpu_pair_allcores(1, 2, dq, nbits, ncores)
+                cpu.update({"full_counts_and_or_xor_sub": full["full_counts"], "allcores_gbit_s": full["allcores_gbit_s"],
+                            "cores_used": full["cores_used"],
+                            "allcores_sample": "count_and/or/xor/sub of the WHOLE pair 0, block ranges fanned over the host cores",
+                            "matches_gpu_full": bool(full["full_counts"] == pair0)})
+            res["cpu_baseline"] = cpu
         except Exception as e:
             res["cpu_baseline"] = {"value": None, "unit": "Gbit/s", "cores": 1, "kind": "port", "sample": f"failed: {e}"}
-    print(json.dumps(res))
+    return res
+
+
+def L_pair_kernel_name(all_bit, nblocks):
+    env_ps = os.environ.get("BMX_PAIR_STREAM", "-1")
+    if all_bit and nblocks >= 2048 and env_ps == "-1":
+        return "k_count_op2_stream<4, true>"
+    return "k_count_op2 / k_count_op2_mixed (see bmx_count_op2 in bmx.hip)"
 
 
 # ----------------------------------------------------------------------------------------------------
 # configs[3]: rank / select, 10 M random queries on one 4e9-bit vector
 # ----------------------------------------------------------------------------------------------------
-def run_rank_select(args):
+def run_rank_select(args, env, quick=False):
+    import ctypes as C
     import numpy as np
-    import torch
     import bitmagic_amd as bm
     from bitmagic_amd import _ffi
-    world, rank, local_rank, use_dist = setup_dist(args)
-    s = torch.cuda.Stream(); torch.cuda.set_stream(s)
-    ctx = bm.context(local_rank, s.cuda_stream)
+    torch, ctx = env.torch, env.ctx
     L = _ffi.lib()
-    nbits, nq = 4_000_000_000, args.queries
-    v = bm.bvector.generate(ctx, SEED, 7, args.density_q16, nbits)
+    nbits, nq, dq = NBITS_4G, args.queries, args.density_q16
+    v = bm.bvector.generate(ctx, SEED, 7, dq, nbits)
     rs = v.build_rs_index()
     build_ms = event_avg_ms(lambda: v.build_rs_index(), 3, ctx)
     g = torch.Generator(device="cuda"); g.manual_seed(1)
@@ -529,57 +868,97 @@ def run_rank_select(args):
     rank_ms = event_avg_ms(do_rank, 10, ctx); sel_ms = event_avg_ms(do_sel, 10, ctx)
     def step():
         do_rank(); do_sel()
-    dt, ev_ms = timed_region(step, args.steps, args.warmup, ctx, use_dist)
+    steps, warmup = (5, 2) if quick else (args.steps, args.warmup)
+    dt, ev_ms = timed_region(step, steps, warmup, env)
     chk = torch.zeros(nq, dtype=torch.int64, device="cuda")
     _ffi.check(L.bmx_rank_batch_dev(ctx._h, v._h, rs._h, pos.data_ptr(), nq, chk.data_ptr())); torch.cuda.synchronize()
     ok = bool((chk == qr).all().item()) and bool(found.all().item())
-    # rank touches 8 (rcount) + 2 (cum) + 8 (desc) + 128 B (bit line) per query; HBM moves 128 B lines
-    line_bytes = nq * (4 * 128)
-    achieved = line_bytes / rank_ms / 1e6
+    # the same rank batch with the queries sorted by position (every bit line is then touched by neighbours in time):
+    # what bucketing the batch by block index could gain at most, next to what sorting costs
+    qs, _ = torch.sort(qn)
+    sorted_ms = event_avg_ms(lambda: _ffi.check(L.bmx_rank_batch_dev(ctx._h, v._h, rs._h, qs.data_ptr(), nq, out.data_ptr())), 5, ctx)
+    sort_ms = event_avg_ms(lambda: torch.sort(qn), 3, ctx)
+    # the bound: random 128-byte lines per second this box gathers from a buffer as large as the vector's bit slab
+    info = v.info()
+    slab_bytes = max(info["counts"][2] * 8192, 1 << 20)
+    pm = C.c_float()
+    _ffi.check(L.bmx_probe_random_lines(ctx._h, slab_bytes, nq, 5, C.byref(pm)))
+    ceil_lines_s = nq / (pm.value * 1e-3)
+    rank_lines_s = nq / (rank_ms * 1e-3)
+    sel_lines_s = nq / (sel_ms * 1e-3)
+    traffic, tsrc, tj = traffic_file("traffic_config3.json")
+    pct = dq / 65536 * 100
     res = {"metric": "M queries/s, rank + select (bmrs.h RS-index) on one 4e9-bit vector",
-           "value": round(2 * nq * args.steps / dt / 1e6, 1), "unit": "Mqueries/s", "n_gpus": 1, "steps": args.steps,
-           "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True,
+           "value": round(2 * nq * steps / dt / 1e6, 1), "unit": "Mqueries/s", "n_gpus": 1, "steps": steps,
+           "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 4), "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-           "config": {"workload": f"{nq} random rank(n) + {nq} random select(r) per step on a {nbits}-bit vector, density q16 {args.density_q16}",
+           "config": {"workload": f"{nq} random rank(n) + {nq} random select(r) per step on a {nbits}-bit vector, Bernoulli {pct:.3g}% (density q16 {dq})",
                       "baseline_config": "configs[3]", "block_types": v.calc_stat(), "count": cnt,
                       "rs_build_ms": round(build_ms, 4), "rank_ms": round(rank_ms, 4), "select_ms": round(sel_ms, 4),
                       "rank_Mq_s": round(nq / rank_ms / 1e3, 1), "select_Mq_s": round(nq / sel_ms / 1e3, 1),
-                      "rank_select_roundtrip_ok": ok},
-           "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "k_rank",
-                        "algorithmic_bytes_per_launch": line_bytes, "avg_launch_ms": round(rank_ms, 4),
-                        "note": "random access: 4 distinct 128-B lines per rank query (running count, cumulative row, descriptor, bit line); "
-                                "the bound is the HBM transaction rate, not streaming bandwidth"}}
+                      "rank_select_roundtrip_ok": ok,
+                      "rank_ms_sorted_queries": round(sorted_ms, 4), "sort_ms_torch": round(sort_ms, 4),
+                      "bucketing_note": "rank over the same queries pre-sorted by position vs the cost of sorting them (torch.sort): "
+                                        "bucketing a batch by block pays only if sort + sorted run < the unsorted run"},
+           "roofline": {"bound": "hbm", "achieved": round(rank_lines_s / 1e9, 3), "peak": round(ceil_lines_s / 1e9, 3),
+                        "unit": "G lines/s (random 128-byte lines)", "frac": round(rank_lines_s / ceil_lines_s, 4),
+                        "traffic": traffic, "traffic_source": tsrc, "kernel": "k_rank",
+                        "algorithmic_bytes_per_launch": nq * 128, "avg_launch_ms": round(rank_ms, 4),
+                        "peak_source": f"bmx_probe_random_lines in this run: {nq} random 128-B lines (8 lanes x 16 B, the access shape of "
+                                       f"a rank query's bit line) over a {slab_bytes / 1e6:.0f} MB buffer in {pm.value:.4f} ms",
+                        "select": {"kernel": "k_select", "achieved": round(sel_lines_s / 1e9, 3), "frac": round(sel_lines_s / ceil_lines_s, 4),
+                                   "avg_launch_ms": round(sel_ms, 4),
+                                   "note": "one bit line per query after two dependent index round trips"},
+                        "as_bandwidth_GBps": round(nq * 128 / rank_ms / 1e6, 1),
+                        "note": "random access: ONE 128-B bit line per rank query comes from HBM / Infinity Cache (500 MB slab); the "
+                                "three index reads (running count 488 KB, descriptor 488 KB, cumulative row 7.8 MB) are L2 hits -- the "
+                                "bound is the transaction rate of random lines (SURVEY section 8(d)), measured by the probe, not the "
+                                "8 TB/s streaming peak"}}
     if not args.no_cpu:
         try:
             P, orc, kind = _pick_oracle()
             sbits = 512 * 65536
-            w = P.gen_words(SEED, 7, args.density_q16, nbits, word_off=0, nwords=512 * 2048)
+            w = P.gen_words(SEED, 7, dq, nbits, word_off=0, nwords=512 * 2048)
             hv = orc.import_words(w, True, sbits); hrs = orc.rs_build(hv)
             rng = np.random.default_rng(1)
             q = rng.integers(0, sbits, 1_000_000, dtype=np.uint64)
             t0 = time.perf_counter(); r = hrs.rank(q); d1 = time.perf_counter() - t0
             rr = rng.integers(1, hrs.count() + 1, 1_000_000, dtype=np.uint64)
             t0 = time.perf_counter(); hrs.select(rr); d2 = time.perf_counter() - t0
-            res["cpu_baseline"] = {"value": round(2e6 / (d1 + d2) / 1e6, 2), "unit": "Mqueries/s", "cores": 1, "kind": kind, "impl": orc.name,
-                                   "sample": "1 M rank + 1 M select on the first 512 blocks (cache-friendlier than the 4e9-bit vector)",
-                                   "rank_Mq_s": round(1.0 / d1, 2), "select_Mq_s": round(1.0 / d2, 2)}
+            cpu = {"value": round(2e6 / (d1 + d2) / 1e6, 2), "unit": "Mqueries/s", "cores": 1, "kind": kind, "impl": orc.name,
+                   "sample": "1 M rank + 1 M select on the first 512 blocks (cache-friendlier than the 4e9-bit vector)",
+                   "rank_Mq_s": round(1.0 / d1, 2), "select_Mq_s": round(1.0 / d2, 2)}
+            if not args.no_allcores:
+                # full-size check: total count + sampled rank / select answers of the reference over the WHOLE vector
+                ncores = args.cpu_cores or len(os.sched_getaffinity(0))
+                ns = 20000
+                sn = rng.integers(0, nbits, ns, dtype=np.uint64)
+                total, sn, an, sr, ar = cpu_rank_allcores(7, dq, nbits, ncores, sn,
+                                                          lambda tot: rng.integers(1, tot + 1, ns, dtype=np.uint64))
+                g_rank = v.count_to(sn, rs)
+                g_found, g_pos = v.select(sr, rs)
+                cpu.update({"full_count": total, "sampled_queries": 2 * ns, "cores_used": min(ncores, (nbits + 65535) // 65536),
+                            "allcores_sample": f"the whole {nbits}-bit vector indexed by block range over the host cores; total count + "
+                                               f"{ns} rank + {ns} select answers compared with the GPU's",
+                            "matches_gpu_full": bool(total == cnt and (np.asarray(g_rank) == an).all()
+                                                     and np.asarray(g_found).all() and (np.asarray(g_pos) == ar).all())})
+            res["cpu_baseline"] = cpu
         except Exception as e:
             res["cpu_baseline"] = {"value": None, "unit": "Mqueries/s", "cores": 1, "kind": "port", "sample": f"failed: {e}"}
-    print(json.dumps(res))
+    del rs, v
+    ctx.trim()
+    return res
 
 
 # ----------------------------------------------------------------------------------------------------
 # configs[4]: combine_or over 4096 x 4e9-bit sparse vectors, block-range sharded over the ranks (strong)
 # ----------------------------------------------------------------------------------------------------
-def run_or_sharded(args):
-    import torch
-    import torch.distributed as dist
+def run_or_sharded(args, env, quick=False):
+    import numpy as np
     import bitmagic_amd as bm
-    world, rank, local_rank, use_dist = setup_dist(args)
-    s = torch.cuda.Stream(); torch.cuda.set_stream(s)
-    ctx = bm.context(local_rank, s.cuda_stream)
-    nbits, nvec, dq = 4_000_000_000, args.or_vecs, 13                  # 13/65536 = 0.02 %
+    torch, dist, ctx = env.torch, env.dist, env.ctx
+    world, rank, use_dist = env.world, env.rank, env.use_dist
+    nbits, nvec, dq = NBITS_4G, args.or_vecs, 13                       # 13/65536 = 0.02 %
     nblocks = (nbits + 65535) // 65536
     lo, hi = bm.shard_range(nblocks, rank, world)
     t0 = time.perf_counter()
@@ -587,7 +966,7 @@ def run_or_sharded(args):
     ctx.synchronize(); t_build = time.perf_counter() - t0
     gap_bytes = sum(v.info()["gap_words"] for v in vecs) * 2
     agg = bm.aggregator(ctx)
-    cnt = torch.zeros(1, dtype=torch.int64, device="cuda")
+    cnt = torch.zeros(1, dtype=torch.int64, device="cpu" if env.one_dev else "cuda")
     last = []
     def step():
         t = agg.combine_or(vecs)
@@ -595,25 +974,29 @@ def run_or_sharded(args):
         if use_dist:
             dist.all_reduce(cnt)
         last[:] = [t]
-    dt, ev_ms = timed_region(step, args.steps, args.warmup, ctx, use_dist)
-    gb = torch.tensor([gap_bytes], dtype=torch.int64, device="cuda")
+    steps, warmup = (3, 1) if quick else (args.steps, args.warmup)
+    dt, ev_ms = timed_region(step, steps, warmup, env)
+    gb = torch.tensor([gap_bytes], dtype=torch.int64, device="cpu" if env.one_dev else "cuda")
     if use_dist:
         dist.all_reduce(gb)
     tot_bytes = int(gb.item())
+    res = None
     if rank == 0:
-        ms = dt / args.steps * 1e3
-        achieved = gap_bytes / (ev_ms / args.steps) / 1e6
+        ms = dt / steps * 1e3
+        achieved = gap_bytes / (ev_ms / steps) / 1e6
+        traffic, tsrc, _ = traffic_file("traffic_config4.json") if (world == 1 and nvec == 4096) else (None, None, None)
         res = {"metric": "Gbit/s of logical operand bits, aggregator combine_or over 4096 x 4e9-bit sparse vectors",
-               "value": round(nvec * nbits * args.steps / dt / 1e9, 1), "unit": "Gbit/s", "n_gpus": world, "steps": args.steps,
-               "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "strong",
-               "vs_baseline": None, "dtype": "u16", "data": "synthetic",
+               "value": round(nvec * nbits * steps / dt / 1e9, 1), "unit": "Gbit/s", "n_gpus": world, "steps": steps,
+               "warmup": warmup, "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "strong",
+               "vs_baseline": None, "dtype": "u16", "data": "synthetic", "mode": env.mode,
                "config": {"workload": f"aggregator::combine_or over {nvec} x {nbits}-bit vectors at 0.02 % (all GAP blocks), result materialised + counted",
                           "baseline_config": "configs[4]", "block_types_vec0": vecs[0].calc_stat(), "blocks_per_rank": hi - lo,
                           "gap_operand_bytes_total": tot_bytes, "result_count": int(cnt.item()),
                           "result_types_rank0": last[0].calc_stat(), "build_seconds": round(t_build, 1)},
                "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "k_agg_or_gap_tiled",
-                            "algorithmic_bytes_per_launch": gap_bytes, "avg_launch_ms": round(ev_ms / args.steps, 4),
+                            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": tsrc,
+                            "kernel": os.environ.get("BMX_OR_KERNEL_NAME", "combine_or over GAP-only operands (bmx_agg_or; see kernel_stats in profiles/)"),
+                            "algorithmic_bytes_per_launch": gap_bytes, "avg_launch_ms": round(ev_ms / steps, 4),
                             "note": "host call incl. result creation, layout scan and count; algorithmic bytes = 2 x (len + 1) per GAP operand"}}
         if not args.no_cpu and world == 1:
             try:
@@ -621,13 +1004,97 @@ def run_or_sharded(args):
                 sb, nv = 64, min(nvec, 1024)
                 hv = [orc.import_words(P.gen_words(SEED, 10000 + i, dq, nbits, word_off=0, nwords=sb * 2048), True, sb * 65536) for i in range(nv)]
                 t0 = time.perf_counter(); r = orc.agg_or(hv); d = time.perf_counter() - t0
-                res["cpu_baseline"] = {"value": round(nv * sb * 65536 / d / 1e9, 1), "unit": "Gbit/s", "cores": 1, "kind": kind, "impl": orc.name,
-                                       "sample": f"combine_or over {nv} vectors x first {sb} blocks, one pass", "count": r.count()}
+                cpu = {"value": round(nv * sb * 65536 / d / 1e9, 1), "unit": "Gbit/s", "cores": 1, "kind": kind, "impl": orc.name,
+                       "sample": f"combine_or over {nv} vectors x first {sb} blocks, one pass", "count": r.count()}
+                del hv
+                if not args.no_allcores:
+                    # bounded full-width check: ALL nvec vectors, a spread sample of block columns, against the GPU result's
+                    # count over exactly those columns
+                    ncores = args.cpu_cores or len(os.sched_getaffinity(0))
+                    nsample = min(nblocks, max(8, min(ncores, 64)))
+                    blocks = sorted(set(int(x) for x in np.linspace(0, nblocks - 1, nsample)))
+                    ref, secs, _k, _i, used = cpu_or_sample(nvec, dq, nbits, blocks, ncores)
+                    t = last[0]
+                    trs = t.build_rs_index()
+                    l = np.asarray(blocks, dtype=np.uint64) * np.uint64(65536)
+                    r_ = np.minimum(l + np.uint64(65535), np.uint64(nbits - 1))
+                    got = t.count_range(l, r_, trs)
+                    cpu.update({"sampled_block_columns": len(blocks), "cores_used": used,
+                                "allcores_sample": f"combine_or over ALL {nvec} vectors on {len(blocks)} block columns spread over the range "
+                                                   f"(one column per worker process, {secs:.1f} s), compared with count_range of the GPU result",
+                                "matches_gpu_sample": bool([int(x) for x in got] == [ref[b] for b in blocks])})
+                res["cpu_baseline"] = cpu
             except Exception as e:
                 res["cpu_baseline"] = {"value": None, "unit": "Gbit/s", "cores": 1, "kind": "port", "sample": f"failed: {e}"}
-        print(json.dumps(res))
-    if use_dist:
-        dist.destroy_process_group()
+    last.clear()
+    del vecs
+    ctx.trim()
+    return res
+
+
+def run_or_group(args):
+    """configs[4] through the product's device group: plain `bench.py --config 4 --gpus N`"""
+    import torch
+    import bitmagic_amd as bm
+    n = args.gpus
+    one_dev = os.environ.get(ONE_DEV_HOOK) == "1"
+    have = torch.cuda.device_count()
+    if not one_dev and have < n:
+        sys.stderr.write(f"bench.py: --gpus {n} needs {n} visible devices, found {have}\n")
+        sys.exit(2)
+    devices = [0] * n if one_dev else list(range(n))
+    grp = bm.group(devices, bm.GROUP_HOST_SUM)
+    nbits, nvec, dq = NBITS_4G, args.or_vecs, 13
+    t0 = time.perf_counter()
+    vecs = [bm.gbvector.generate(grp, SEED, 10000 + i, dq, nbits) for i in range(nvec)]
+    for d in sorted(set(devices)): torch.cuda.synchronize(d)
+    t_build = time.perf_counter() - t0
+    gap_bytes = sum(v.info()["gap_words"] for v in vecs) * 2
+    gagg = bm.gaggregator(grp)
+    keep = []
+    def step():
+        t = gagg.combine_or(vecs)
+        keep[:] = [t, t.count()]
+    for _ in range(args.warmup): step()
+    for d in sorted(set(devices)): torch.cuda.synchronize(d)
+    t0 = time.perf_counter()
+    for _ in range(args.steps): step()
+    for d in sorted(set(devices)): torch.cuda.synchronize(d)
+    dt = time.perf_counter() - t0
+    ms = dt / args.steps * 1e3
+    res = {"metric": "Gbit/s of logical operand bits, aggregator combine_or over 4096 x 4e9-bit sparse vectors",
+           "value": round(nvec * nbits * args.steps / dt / 1e9, 1), "unit": "Gbit/s", "n_gpus": n, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "strong",
+           "vs_baseline": None, "dtype": "u16", "data": "synthetic", "mode": "group", "exchange": "host_sum",
+           "config": {"workload": f"aggregator::combine_or over {nvec} x {nbits}-bit vectors at 0.02 % (all GAP blocks), result materialised (sharded) + counted",
+                      "baseline_config": "configs[4]", "devices": devices, "gap_operand_bytes_total": gap_bytes,
+                      "result_count": int(keep[1]), "build_seconds": round(t_build, 1)},
+           "roofline": {"bound": "hbm", "achieved": round(gap_bytes / ms / 1e6, 1), "peak": HBM_PEAK_GBS * n, "unit": "GB/s",
+                        "frac": round(gap_bytes / ms / 1e6 / (HBM_PEAK_GBS * n), 4), "traffic": None,
+                        "kernel": "bmx_gagg_or: bmx_agg_or per member on persistent workers",
+                        "algorithmic_bytes_per_launch": gap_bytes, "avg_launch_ms": round(ms, 4),
+                        "note": "whole host call over all members (result creation, layout scan, count); peak = n x 8 TB/s"}}
+    keep.clear(); del vecs
+    grp.close()
+    return res
+
+
+def summary_of(res):
+    """one-line summary of another config's result for the headline line's "other_configs" """
+    if res is None:
+        return None
+    out = {"metric": res["metric"], "value": res["value"], "unit": res["unit"], "ms_per_step": res["ms_per_step"],
+           "steps": res["steps"], "workload": res["config"]["workload"],
+           "roofline": {k: res["roofline"].get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "kernel", "avg_launch_ms", "traffic")}}
+    cpu = res.get("cpu_baseline")
+    if cpu:
+        out["cpu_baseline"] = {k: cpu.get(k) for k in ("value", "unit", "cores", "kind", "matches_gpu_full", "matches_gpu_sample") if k in cpu}
+    for k in ("per_op", "rank_ms", "select_ms", "rank_Mq_s", "select_Mq_s", "rank_select_roundtrip_ok", "result_count"):
+        if k in res["config"]:
+            out[k] = res["config"][k]
+    if "select" in res["roofline"]:
+        out["roofline"]["select_frac"] = res["roofline"]["select"]["frac"]
+    return out
 
 
 def main():
@@ -639,6 +1106,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", type=int, default=2, choices=[1, 2, 3, 4], help="BASELINE.json configs[] index (2 = the headline)")
     ap.add_argument("--scaling", default="auto", choices=["auto", "strong", "weak"])
+    ap.add_argument("--launcher", default="auto", choices=["auto", "group", "torchrun"],
+                    help="--gpus N > 1 without RANK in the environment: 'group' (default) = one process over the product's "
+                         "device group (bmx_group + RCCL); 'torchrun' = re-execute under torch.distributed.run")
+    ap.add_argument("--group-exchange", default="rccl", choices=["rccl", "host"], help="group mode: in-library ncclAllReduce or host sum")
     ap.add_argument("--nvec", type=int, default=256)
     ap.add_argument("--nbits", type=int, default=NBITS_1G)
     ap.add_argument("--density-q16", type=int, default=6554)      # 10 %
@@ -649,18 +1120,59 @@ def main():
     ap.add_argument("--no-allcores", action="store_true")
     ap.add_argument("--no-weak", action="store_true")
     ap.add_argument("--no-shard-probe", action="store_true")
+    ap.add_argument("--no-others", action="store_true", help="headline run: skip the one-line summaries of configs 1, 3, 4")
     ap.add_argument("--pairs", type=int, default=6)
     ap.add_argument("--queries", type=int, default=10_000_000)
     ap.add_argument("--or-vecs", type=int, default=4096)
     args = ap.parse_args()
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    launched = "RANK" in os.environ and "MASTER_PORT" in os.environ
+    if args.gpus > 1 and not launched:
+        if args.launcher == "torchrun":
+            return reexec_torchrun(args)
+        if args.config == 2:
+            print(json.dumps(run_headline_group(args))); return
+        if args.config == 4:
+            print(json.dumps(run_or_group(args))); return
+        sys.stderr.write(f"bench.py: --config {args.config} is a one-GPU configuration; --gpus {args.gpus} is not supported for it\n")
+        sys.exit(2)
+    if launched and int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={os.environ.get('WORLD_SIZE')}\n")
+        sys.exit(2)
+    if launched and args.gpus > 1 and args.config in (1, 3):
+        sys.stderr.write(f"bench.py: --config {args.config} is a one-GPU configuration\n")
+        sys.exit(2)
+    single = int(os.environ.get("WORLD_SIZE", "1")) == 1
+    cpu = None
+    if args.config == 2 and single and not args.no_cpu:
+        cpu = headline_cpu(args)                         # before torch / HIP are loaded into this process
+    env = Env(args).setup()
     if args.config == 1:
-        run_pairwise(args)
+        res = run_pairwise(args, env)
     elif args.config == 3:
-        run_rank_select(args)
+        res = run_rank_select(args, env)
     elif args.config == 4:
-        run_or_sharded(args)
+        res = run_or_sharded(args, env)
     else:
-        run_headline(args)
+        res = run_headline(args, env, cpu)
+        standard = (args.nvec == 256 and args.nbits == NBITS_1G and args.density_q16 == 6554 and not args.independent)
+        if res is not None and single and standard and not args.no_others:
+            others = {}
+            for name, fn in (("configs[1]", lambda: run_pairwise(args, env, quick=True)),
+                             ("configs[3]", lambda: run_rank_select(args, env, quick=True)),
+                             ("configs[4]", lambda: run_or_sharded(args, env, quick=True))):
+                try:
+                    t0 = time.perf_counter()
+                    s = summary_of(fn())
+                    s["wall_s"] = round(time.perf_counter() - t0, 1)
+                    others[name] = s
+                except Exception as e:                   # a failing side leg must not take the headline line with it
+                    others[name] = {"error": str(e)}
+            res["other_configs"] = others
+    if res is not None:
+        print(json.dumps(res))
+    env.finish()
 
 
 if __name__ == "__main__":

@@ -752,6 +752,39 @@ class group:
             check(lib().bmx_group_ctx(self._h, m, C.byref(c)))
             check(lib().bmx_ctx_set_tuning(c, key.encode(), int(value)))
 
+    # -- byte-weighted shard borders (src/bmblocks.h:556-564: NULL ranges cost nothing) --
+    def set_partition(self, nblocks: int, bounds) -> None:
+        b = np.ascontiguousarray(bounds, np.uint32)
+        if b.size != self.size() + 1:
+            raise ValueError("need size() + 1 borders")
+        check(lib().bmx_group_set_partition(self._h, nblocks, _ptr(b)))
+
+    def partition_by_weight(self, weight) -> np.ndarray:
+        """cut [0, len(weight)) where the running weight reaches m/n of the total; -> the n + 1 borders"""
+        w = np.ascontiguousarray(weight, np.uint64)
+        out = np.zeros(self.size() + 1, np.uint32)
+        check(lib().bmx_group_partition_by_weight(self._h, w.size, _ptr(w) if w.size else None, _ptr(out)))
+        return out
+
+    def partition_for_tables(self, tables) -> np.ndarray:
+        """borders from the algorithmic operand bytes of a collection of host block tables
+        [(kinds, offs, bit_slab, gap_slab), ...] of equal length (bmx_block_table_weights per table)"""
+        tables = list(tables)
+        nblocks = len(tables[0][0])
+        w = np.zeros(nblocks, np.uint64)
+        for kinds, offs, _bits, gaps in tables:
+            kinds = np.ascontiguousarray(kinds, np.uint8); offs = np.ascontiguousarray(offs, np.uint32)
+            gaps = np.ascontiguousarray(gaps, np.uint16)
+            if kinds.size != nblocks:
+                raise ValueError("block tables of one partition must have the same length")
+            check(lib().bmx_block_table_weights(nblocks, _ptr(kinds), _ptr(offs), _ptr(gaps) if gaps.size else None, gaps.size, _ptr(w)))
+        return self.partition_by_weight(w)
+
+    def rccl_ranks(self) -> int:
+        n = C.c_int()
+        check(lib().bmx_group_rccl_ranks(self._h, C.byref(n)))
+        return n.value
+
 
 class grs_index:
     """rank-select index of a sharded vector: one bm::rs_index twin per shard + the ones before each shard"""
@@ -912,6 +945,22 @@ class gpipeline:
         ms = (C.c_float * self.grp.size())()
         check(lib().bmx_gpipeline_last_ms(self.grp._h, self._h, ms))
         return list(ms)
+
+    def last_exchange_ms(self) -> list:
+        ms = (C.c_float * self.grp.size())()
+        check(lib().bmx_gpipeline_last_exchange_ms(self.grp._h, self._h, ms))
+        return list(ms)
+
+    def operand_bytes(self) -> list:
+        b = (C.c_uint64 * self.grp.size())()
+        check(lib().bmx_gpipeline_operand_bytes(self.grp._h, self._h, b))
+        return list(b)
+
+    def describe(self, member: int = 0):
+        buf = C.create_string_buffer(512)
+        nl = C.c_uint32()
+        check(lib().bmx_gpipeline_describe(self.grp._h, self._h, member, buf, 512, C.byref(nl)))
+        return buf.value.decode(), nl.value
 
     def __del__(self):
         try:

@@ -95,6 +95,10 @@ def lib() -> C.CDLL:
         "bmx_group_size": (i32, [vp, P(i32)]),
         "bmx_group_ctx": (i32, [vp, i32, P(vp)]),
         "bmx_group_shard_range": (i32, [vp, u32, i32, P(u32), P(u32)]),
+        "bmx_block_table_weights": (i32, [u32, vp, vp, vp, u64, vp]),
+        "bmx_group_partition_by_weight": (i32, [vp, u32, vp, vp]),
+        "bmx_group_set_partition": (i32, [vp, u32, vp]),
+        "bmx_group_rccl_ranks": (i32, [vp, P(i32)]),
         "bmx_gvec_upload": (i32, [vp, u64, u32, vp, vp, vp, u32, vp, u64, P(vp)]),
         "bmx_gvec_generate": (i32, [vp, u64, u32, i32, u32, u64, i32, P(vp)]),
         "bmx_gvec_free": (i32, [vp, vp]),
@@ -118,6 +122,10 @@ def lib() -> C.CDLL:
         "bmx_gpipeline_destroy": (i32, [vp, vp]),
         "bmx_gpipeline_run_counts": (i32, [vp, vp, P(u64)]),
         "bmx_gpipeline_last_ms": (i32, [vp, vp, P(C.c_float)]),
+        "bmx_gpipeline_last_exchange_ms": (i32, [vp, vp, P(C.c_float)]),
+        "bmx_gpipeline_operand_bytes": (i32, [vp, vp, P(u64)]),
+        "bmx_gpipeline_describe": (i32, [vp, vp, i32, C.c_char_p, C.c_size_t, P(u32)]),
+        "bmx_probe_random_lines": (i32, [vp, u64, u64, i32, P(C.c_float)]),
         "bmx_timer_start": (i32, [vp]),
         "bmx_timer_stop_ms": (i32, [vp, P(C.c_float)]),
     }

@@ -394,6 +394,32 @@ int bmx_timer_stop_ms(bmx_ctx* ctx, float* ms)
     return BMX_OK;
 }
 
+// Measurement helper (like the timer): how many random 128-byte lines per second this box gathers from a buffer of
+// buf_bytes -- the bound of rank / select ("random access => bound by HBM transaction rate").
+int bmx_probe_random_lines(bmx_ctx* ctx, uint64_t buf_bytes, uint64_t nlines, int iters, float* ms_per_pass)
+{
+    ARGCHK(ctx && ms_per_pass && buf_bytes >= 128 && nlines >= 1 && iters >= 1);
+    int rc = set_dev(ctx); if (rc) return rc;
+    void* buf = nullptr;
+    u64 nl = buf_bytes / 128;
+    HIPCHK(hipMalloc(&buf, nl * 128));
+    hipError_t e = hipMemsetAsync(buf, 0x5A, nl * 128, ctx->stream);
+    u32 grid = (u32)std::min<u64>((nlines * 8 + 255) / 256, 256u * 16u);
+    for (int it = -1; it < iters && e == hipSuccess; ++it) {
+        if (it == 0) e = hipEventRecord(ctx->ev0, ctx->stream);
+        hipLaunchKernelGGL(k_probe_lines, dim3(grid), dim3(256), 0, ctx->stream, (const uint4*)buf, nl, nlines,
+                           0xB17A61Cull + (u64)(it + 1) * 7919ull, ctx->d_small);
+    }
+    if (e == hipSuccess) e = hipEventRecord(ctx->ev1, ctx->stream);
+    if (e == hipSuccess) e = hipEventSynchronize(ctx->ev1);
+    float ms = 0;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
+    (void)hipFree(buf);
+    if (e != hipSuccess) return fail_hip(e, "bmx_probe_random_lines", __LINE__);
+    *ms_per_pass = ms / iters;
+    return BMX_OK;
+}
+
 // ---------------------------------------------------------------------------
 // vectors
 // ---------------------------------------------------------------------------

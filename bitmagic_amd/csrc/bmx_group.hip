@@ -12,14 +12,43 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <condition_variable>
 #include <cstdio>
 #include <cstring>
+#include <functional>
+#include <memory>
+#include <mutex>
 #include <new>
 #include <thread>
+
+// a cut of the linear block range [0, nblocks) into one contiguous piece per member: member m holds blocks
+// [bounds[m], bounds[m + 1]).  ONE partition per (group, nblocks): every vector of that length is cut at the same
+// borders, so block columns stay aligned across the operands of an operation.
+struct bmx_partition {
+    uint32_t nblocks = 0;
+    std::vector<uint32_t> bounds;         // n + 1 entries, bounds[0] = 0, bounds[n] = nblocks
+};
+typedef std::shared_ptr<const bmx_partition> part_ref;
+
+// persistent per-member host workers (members 1..n-1; member 0 runs on the calling thread): the synchronous
+// single-device entry points are dispatched to them instead of spawning n threads per call
+struct bmx_workers {
+    std::mutex mu;
+    std::condition_variable cv_go, cv_done;
+    std::vector<std::thread> th;
+    const std::function<int(int)>* fn = nullptr;
+    uint64_t gen = 0;
+    int pending = 0;
+    bool stop = false;
+    std::vector<int> rc;
+    std::vector<std::string> msg;
+};
 
 struct bmx_group {
     int n = 0, flags = 0;
     std::vector<bmx_ctx*> ctx;
+    std::map<uint32_t, part_ref> parts;   // partition in force per vector length (default: equal block counts)
+    bmx_workers* wk = nullptr;
     // RCCL (optional, loaded on demand: the library has no link-time dependency on librccl)
     void* rccl = nullptr;
     std::vector<void*> comm;
@@ -27,13 +56,15 @@ struct bmx_group {
     int (*p_group_start)() = nullptr;
     int (*p_group_end)() = nullptr;
     int (*p_comm_destroy)(void*) = nullptr;
+    int (*p_comm_count)(void*, int*) = nullptr;
     const char* (*p_errstr)(int) = nullptr;
 };
 
 struct bmx_gvec {
     bmx_group* g;
     uint64_t nbits; uint32_t nblocks;
-    std::vector<bmx_vec*> shard;          // shard[m] lives on g->ctx[m], blocks shard_range(nblocks, m)
+    part_ref part;                        // the cut this vector was sharded with
+    std::vector<bmx_vec*> shard;          // shard[m] lives on g->ctx[m], blocks [part->bounds[m], part->bounds[m + 1])
 };
 
 struct bmx_grs {
@@ -49,34 +80,103 @@ struct bmx_gpipeline {
     std::vector<bmx_pipeline*> pipe;
     std::vector<u64*> d_counts;           // per member: ngroups x u64 on the device
     u64* h_counts = nullptr;              // pinned, n x ngroups
-    std::vector<hipEvent_t> ev0, ev1;
-    std::vector<float> last_ms;
+    std::vector<hipEvent_t> ev0, ev1, ev2;
+    std::vector<float> last_ms, last_xchg_ms;
 };
 
-static void shard_range(uint32_t nblocks, int m, int n, uint32_t* lo, uint32_t* hi)
+static void equal_range(uint32_t nblocks, int m, int n, uint32_t* lo, uint32_t* hi)
 {
     uint32_t q = nblocks / (uint32_t)n, r = nblocks % (uint32_t)n, mm = (uint32_t)m;
     *lo = mm * q + std::min(mm, r);
     *hi = *lo + q + (mm < r ? 1u : 0u);
 }
 
-// run fn(m) for every member on its own host thread (the single-device entry points are synchronous);
-// returns the first non-zero status and carries that thread's error text over to the caller's
-template <class F>
-static int for_each_member(bmx_group* g, F fn)
+// the partition in force for vectors of `nblocks` blocks (created on first use: equal block counts)
+static part_ref part_for(bmx_group* g, uint32_t nblocks)
 {
-    std::vector<int> rc((size_t)g->n, BMX_OK);
-    std::vector<std::string> msg((size_t)g->n);
-    auto body = [&](int m) { rc[(size_t)m] = fn(m); if (rc[(size_t)m]) msg[(size_t)m] = bmx_last_error(); };
-    if (g->n == 1) body(0);
-    else {
-        std::vector<std::thread> th;
-        th.reserve((size_t)g->n);
-        for (int m = 0; m < g->n; ++m) th.emplace_back(body, m);
-        for (auto& t : th) t.join();
+    auto it = g->parts.find(nblocks);
+    if (it != g->parts.end()) return it->second;
+    auto p = std::make_shared<bmx_partition>();
+    p->nblocks = nblocks;
+    p->bounds.resize((size_t)g->n + 1);
+    for (int m = 0; m < g->n; ++m) { uint32_t lo, hi; equal_range(nblocks, m, g->n, &lo, &hi); p->bounds[(size_t)m] = lo; p->bounds[(size_t)m + 1] = hi; }
+    part_ref r = p;
+    g->parts[nblocks] = r;
+    return r;
+}
+
+static inline void shard_of(const bmx_gvec* v, int m, uint32_t* lo, uint32_t* hi)
+{
+    *lo = v->part->bounds[(size_t)m]; *hi = v->part->bounds[(size_t)m + 1];
+}
+
+static void worker_main(bmx_group* g, int m)
+{
+    bmx_workers* w = g->wk;
+    (void)hipSetDevice(g->ctx[(size_t)m]->device);
+    uint64_t seen = 0;
+    for (;;) {
+        const std::function<int(int)>* fn;
+        {
+            std::unique_lock<std::mutex> lk(w->mu);
+            w->cv_go.wait(lk, [&] { return w->stop || w->gen != seen; });
+            if (w->stop) return;
+            seen = w->gen; fn = w->fn;
+        }
+        int rc = (*fn)(m);
+        std::string msg = rc ? bmx_last_error() : "";
+        {
+            std::lock_guard<std::mutex> lk(w->mu);
+            w->rc[(size_t)m] = rc; w->msg[(size_t)m] = std::move(msg);
+            if (--w->pending == 0) w->cv_done.notify_one();
+        }
     }
-    for (int m = 0; m < g->n; ++m)
-        if (rc[(size_t)m]) { bmx_set_last_error(msg[(size_t)m].c_str()); return rc[(size_t)m]; }
+}
+
+static int workers_start(bmx_group* g)
+{
+    if (g->n <= 1) return BMX_OK;
+    g->wk = new (std::nothrow) bmx_workers();
+    if (!g->wk) return BMX_ERR_BADALLOC;
+    g->wk->rc.assign((size_t)g->n, BMX_OK); g->wk->msg.assign((size_t)g->n, std::string());
+    for (int m = 1; m < g->n; ++m) g->wk->th.emplace_back(worker_main, g, m);
+    return BMX_OK;
+}
+
+static void workers_stop(bmx_group* g)
+{
+    if (!g->wk) return;
+    { std::lock_guard<std::mutex> lk(g->wk->mu); g->wk->stop = true; }
+    g->wk->cv_go.notify_all();
+    for (auto& t : g->wk->th) t.join();
+    delete g->wk; g->wk = nullptr;
+}
+
+// run fn(m) for every member: member 0 on the calling thread, the others on their persistent workers (the
+// single-device entry points are synchronous); returns the first non-zero status and carries that member's error
+// text over to the caller's thread
+static int for_each_member(bmx_group* g, const std::function<int(int)>& fn)
+{
+    if (g->n == 1 || !g->wk) {
+        for (int m = 0; m < g->n; ++m) { int rc = fn(m); if (rc) return rc; }
+        return BMX_OK;
+    }
+    bmx_workers* w = g->wk;
+    {
+        std::lock_guard<std::mutex> lk(w->mu);
+        w->fn = &fn; w->pending = g->n - 1; ++w->gen;
+    }
+    w->cv_go.notify_all();
+    int rc0 = fn(0);
+    std::string msg0 = rc0 ? bmx_last_error() : "";
+    {
+        std::unique_lock<std::mutex> lk(w->mu);
+        w->cv_done.wait(lk, [&] { return w->pending == 0; });
+        w->fn = nullptr;
+    }
+    if (rc0) { bmx_set_last_error(msg0.c_str()); return rc0; }
+    for (int m = 1; m < g->n; ++m)
+        if (w->rc[(size_t)m]) { bmx_set_last_error(w->msg[(size_t)m].c_str()); return w->rc[(size_t)m]; }
     return BMX_OK;
 }
 
@@ -98,6 +198,7 @@ static int load_rccl(bmx_group* g, const int* devices)
     g->p_group_end = (int (*)())dlsym(g->rccl, "ncclGroupEnd");
     g->p_comm_destroy = (int (*)(void*))dlsym(g->rccl, "ncclCommDestroy");
     g->p_errstr = (const char* (*)(int))dlsym(g->rccl, "ncclGetErrorString");
+    g->p_comm_count = (int (*)(void*, int*))dlsym(g->rccl, "ncclCommCount");
     if (!p_init_all || !g->p_allreduce || !g->p_group_start || !g->p_group_end || !g->p_comm_destroy) {
         bmx_set_last_error("BMX_GROUP_RCCL: librccl.so lacks the expected entry points"); return BMX_ERR_DEVICE;
     }
@@ -129,6 +230,7 @@ int bmx_group_create(const int* devices, int n, int flags, bmx_group** out)
         g->ctx.push_back(c);
     }
     if (flags & BMX_GROUP_RCCL) { int rc = load_rccl(g, devices); if (rc) { bmx_group_destroy(g); return rc; } }
+    { int rc = workers_start(g); if (rc) { bmx_group_destroy(g); return rc; } }
     *out = g;
     return BMX_OK;
 }
@@ -136,6 +238,7 @@ int bmx_group_create(const int* devices, int n, int flags, bmx_group** out)
 int bmx_group_destroy(bmx_group* g)
 {
     if (!g) return BMX_OK;
+    workers_stop(g);
     for (size_t m = 0; m < g->comm.size(); ++m) if (g->comm[m] && g->p_comm_destroy) (void)g->p_comm_destroy(g->comm[m]);
     for (bmx_ctx* c : g->ctx) bmx_ctx_destroy(c);
     // librccl stays loaded: unloading a library that registered HIP fat binaries is not safe
@@ -157,7 +260,86 @@ int bmx_group_shard_range(const bmx_group* g, uint32_t nblocks, int member, uint
 {
     ARGCHK(g && nb_from && nb_to);
     if (member < 0 || member >= g->n) { bmx_set_last_error("member index out of range"); return BMX_ERR_RANGE; }
-    shard_range(nblocks, member, g->n, nb_from, nb_to);
+    part_ref p = part_for(const_cast<bmx_group*>(g), nblocks);
+    *nb_from = p->bounds[(size_t)member]; *nb_to = p->bounds[(size_t)member + 1];
+    return BMX_OK;
+}
+
+// ---- byte-weighted shard borders ("weighted by non-NULL operand bytes") ----
+static bool part_in_use(const bmx_group* g, uint32_t nblocks)
+{
+    auto it = g->parts.find(nblocks);
+    return it != g->parts.end() && it->second.use_count() > 1;       // a live vector / pipeline holds a reference
+}
+
+int bmx_group_set_partition(bmx_group* g, uint32_t nblocks, const uint32_t* bounds)
+{
+    ARGCHK(g && bounds);
+    if (bounds[0] != 0 || bounds[g->n] != nblocks) { bmx_set_last_error("partition must start at 0 and end at nblocks"); return BMX_ERR_RANGE; }
+    for (int m = 0; m < g->n; ++m)
+        if (bounds[m] > bounds[m + 1]) { bmx_set_last_error("partition borders must not decrease"); return BMX_ERR_RANGE; }
+    auto it = g->parts.find(nblocks);
+    if (it != g->parts.end() && std::equal(it->second->bounds.begin(), it->second->bounds.end(), bounds)) return BMX_OK;
+    if (part_in_use(g, nblocks)) {
+        bmx_set_last_error("vectors of this length are already sharded with other borders: free them first");
+        return BMX_ERR_BADARG;
+    }
+    auto p = std::make_shared<bmx_partition>();
+    p->nblocks = nblocks;
+    p->bounds.assign(bounds, bounds + g->n + 1);
+    g->parts[nblocks] = p;
+    return BMX_OK;
+}
+
+int bmx_group_partition_by_weight(bmx_group* g, uint32_t nblocks, const uint64_t* weight, uint32_t* bounds_out)
+{
+    ARGCHK(g && (nblocks == 0 || weight));
+    // border m = the first block at which the running weight reaches m/n of the total: every member gets the same
+    // share of operand BYTES (not of block columns); empty stretches (NULL top-level ranges, src/bmblocks.h:556-564)
+    // cost nothing and therefore do not count
+    unsigned __int128 total = 0;
+    for (uint32_t i = 0; i < nblocks; ++i) total += weight[i];
+    std::vector<uint32_t> b((size_t)g->n + 1, 0);
+    b[(size_t)g->n] = nblocks;
+    if (total == 0) { for (int m = 0; m < g->n; ++m) { uint32_t lo, hi; equal_range(nblocks, m, g->n, &lo, &hi); b[(size_t)m] = lo; } }
+    else {
+        unsigned __int128 run = 0; uint32_t i = 0;
+        for (int m = 1; m < g->n; ++m) {
+            unsigned __int128 want = total * (unsigned)m / (unsigned)g->n;
+            // advance while adding block i keeps the running weight closer to (or below) the target
+            while (i < nblocks && run + weight[i] / 2 < want) { run += weight[i]; ++i; }
+            b[(size_t)m] = i;
+        }
+    }
+    int rc = bmx_group_set_partition(g, nblocks, b.data());
+    if (rc) return rc;
+    if (bounds_out) memcpy(bounds_out, b.data(), ((size_t)g->n + 1) * sizeof(uint32_t));
+    return BMX_OK;
+}
+
+int bmx_block_table_weights(uint32_t nblocks, const uint8_t* kinds, const uint32_t* offs,
+                            const uint16_t* gap_slab, uint64_t gap_words, uint64_t* weight)
+{
+    ARGCHK(weight && (nblocks == 0 || (kinds && offs)));
+    for (uint32_t nb = 0; nb < nblocks; ++nb) {
+        if (kinds[nb] == BMX_BIT) weight[nb] += 8192u;
+        else if (kinds[nb] == BMX_GAP) {
+            if (!gap_slab || offs[nb] >= gap_words) { bmx_set_last_error("GAP offset out of range"); return BMX_ERR_RANGE; }
+            weight[nb] += 2u * ((uint64_t)(gap_slab[offs[nb]] >> 3) + 1u);
+        } else if (kinds[nb] > BMX_GAP) { bmx_set_last_error("bad block kind"); return BMX_ERR_BADARG; }
+    }
+    return BMX_OK;
+}
+
+int bmx_group_rccl_ranks(const bmx_group* g, int* n)
+{
+    ARGCHK(g && n);
+    *n = 0;
+    if (!(g->flags & BMX_GROUP_RCCL) || g->comm.empty() || !g->p_comm_count) return BMX_OK;
+    int c = 0;
+    int r = g->p_comm_count(g->comm[0], &c);
+    if (r != 0) { bmx_set_last_error("ncclCommCount failed"); return BMX_ERR_DEVICE; }
+    *n = c;
     return BMX_OK;
 }
 
@@ -166,6 +348,7 @@ static bmx_gvec* gvec_new(bmx_group* g, uint64_t nbits, uint32_t nblocks)
     bmx_gvec* v = new (std::nothrow) bmx_gvec();
     if (!v) return nullptr;
     v->g = g; v->nbits = nbits; v->nblocks = nblocks;
+    v->part = part_for(g, nblocks);
     v->shard.assign((size_t)g->n, nullptr);
     return v;
 }
@@ -195,7 +378,7 @@ int bmx_gvec_upload(bmx_group* g, uint64_t nbits, uint32_t nblocks, const uint8_
     bmx_gvec* v = gvec_new(g, nbits, nblocks);
     if (!v) return BMX_ERR_BADALLOC;
     int rc = for_each_member(g, [&](int m) -> int {
-        uint32_t lo, hi; shard_range(nblocks, m, g->n, &lo, &hi);
+        uint32_t lo, hi; shard_of(v, m, &lo, &hi);
         // the piece of each slab this shard references: [min offset, max end) -- exact for tables in block
         // order (what a tree walk or a frozen arena yields), still correct for any other order
         uint32_t bmin = 0xFFFFFFFFu, bmax = 0; uint64_t gmin = ~0ull, gmax = 0;
@@ -233,7 +416,7 @@ int bmx_gvec_generate(bmx_group* g, uint64_t seed, uint32_t vec_id, int with_com
     bmx_gvec* v = gvec_new(g, nbits, (uint32_t)nblocks64);
     if (!v) return BMX_ERR_BADALLOC;
     int rc = for_each_member(g, [&](int m) -> int {
-        uint32_t lo, hi; shard_range(v->nblocks, m, g->n, &lo, &hi);
+        uint32_t lo, hi; shard_of(v, m, &lo, &hi);
         return bmx_vec_generate_shard(g->ctx[(size_t)m], seed, vec_id, with_common, density_q16, nbits, lo, hi, optimize,
                                       &v->shard[(size_t)m]);
     });
@@ -274,7 +457,7 @@ int bmx_gvec_download(bmx_group* g, const bmx_gvec* v, uint8_t* kinds, uint32_t*
     ARGCHK(g && v && v->g == g);
     uint32_t bbase = 0; uint64_t gbase = 0;
     for (int m = 0; m < g->n; ++m) {
-        uint32_t lo, hi; shard_range(v->nblocks, m, g->n, &lo, &hi);
+        uint32_t lo, hi; shard_of(v, m, &lo, &hi);
         const bmx_vec* s = v->shard[(size_t)m];
         uint32_t sb; uint64_t sg;
         int rc = bmx_vec_info(s, nullptr, nullptr, nullptr, &sb, &sg); if (rc) return rc;
@@ -311,7 +494,7 @@ int bmx_gvec_count(bmx_group* g, const bmx_gvec* a, uint64_t* count)
 int bmx_gvec_count_op2(bmx_group* g, int op, const bmx_gvec* a, const bmx_gvec* b, uint64_t* count)
 {
     ARGCHK(g && a && b && count && a->g == g && b->g == g);
-    if (a->nblocks != b->nblocks) { bmx_set_last_error("sharded operands must cover the same block range (upload them with the same nblocks)"); return BMX_ERR_BADARG; }
+    if (a->nblocks != b->nblocks || a->part != b->part) { bmx_set_last_error("sharded operands must cover the same block range (upload them with the same nblocks)"); return BMX_ERR_BADARG; }
     for (int m = 0; m < g->n; ++m) {
         int rc = bmx_i_count_op2_async(g->ctx[(size_t)m], op, a->shard[(size_t)m], b->shard[(size_t)m], 0);
         if (rc) { (void)sync_all(g); return rc; }
@@ -327,7 +510,7 @@ int bmx_gvec_op2(bmx_group* g, int op, const bmx_gvec* a, const bmx_gvec* b, int
 {
     ARGCHK(g && a && b && result && a->g == g && b->g == g);
     *result = nullptr;
-    if (a->nblocks != b->nblocks) { bmx_set_last_error("sharded operands must cover the same block range (upload them with the same nblocks)"); return BMX_ERR_BADARG; }
+    if (a->nblocks != b->nblocks || a->part != b->part) { bmx_set_last_error("sharded operands must cover the same block range (upload them with the same nblocks)"); return BMX_ERR_BADARG; }
     bmx_gvec* v = gvec_new(g, std::max(a->nbits, b->nbits), a->nblocks);
     if (!v) return BMX_ERR_BADALLOC;
     int rc = for_each_member(g, [&](int m) -> int {
@@ -383,7 +566,7 @@ int bmx_grank_batch(bmx_group* g, const bmx_gvec* v, const bmx_grs* rs, const ui
 {
     ARGCHK(g && v && rs && v->g == g && rs->g == g && rs->v == v && (q == 0 || (n && out)));
     std::vector<uint32_t> lo((size_t)g->n + 1, 0);
-    for (int m = 0; m < g->n; ++m) { uint32_t a, b; shard_range(v->nblocks, m, g->n, &a, &b); lo[(size_t)m] = a; lo[(size_t)m + 1] = b; }
+    for (int m = 0; m < g->n; ++m) { uint32_t a, b; shard_of(v, m, &a, &b); lo[(size_t)m] = a; lo[(size_t)m + 1] = b; }
     std::vector<std::vector<uint64_t>> qs((size_t)g->n), ans((size_t)g->n);
     std::vector<std::vector<size_t>> at((size_t)g->n);
     for (size_t i = 0; i < q; ++i) {
@@ -410,7 +593,7 @@ int bmx_gselect_batch(bmx_group* g, const bmx_gvec* v, const bmx_grs* rs, const 
 {
     ARGCHK(g && v && rs && v->g == g && rs->g == g && rs->v == v && (q == 0 || (rank && pos && found)));
     std::vector<uint32_t> lo((size_t)g->n, 0);
-    for (int m = 0; m < g->n; ++m) { uint32_t a, b; shard_range(v->nblocks, m, g->n, &a, &b); lo[(size_t)m] = a; }
+    for (int m = 0; m < g->n; ++m) { uint32_t a, b; shard_of(v, m, &a, &b); lo[(size_t)m] = a; }
     std::vector<std::vector<uint64_t>> qs((size_t)g->n), ans((size_t)g->n);
     std::vector<std::vector<uint8_t>> fnd((size_t)g->n);
     std::vector<std::vector<size_t>> at((size_t)g->n);
@@ -445,7 +628,7 @@ static int same_range(bmx_group* g, const bmx_gvec* const* src, size_t n, uint32
     for (size_t i = 0; i < n; ++i) {
         if (!src[i] || src[i]->g != g) { bmx_set_last_error("operand is null or belongs to another group"); return BMX_ERR_BADARG; }
         if (*nblocks == 0xFFFFFFFFu) *nblocks = src[i]->nblocks;
-        else if (src[i]->nblocks != *nblocks) { bmx_set_last_error("sharded operands must cover the same block range (upload them with the same nblocks)"); return BMX_ERR_BADARG; }
+        else if (src[i]->nblocks != *nblocks || src[i]->part != part_for(g, *nblocks)) { bmx_set_last_error("sharded operands must cover the same block range (upload them with the same nblocks)"); return BMX_ERR_BADARG; }
         *nbits = std::max(*nbits, src[i]->nbits);
     }
     return BMX_OK;
@@ -517,7 +700,7 @@ int bmx_gfind_first_and_sub(bmx_group* g, const bmx_gvec* const* src_and, size_t
     if (rc) return rc;
     for (int m = 0; m < g->n; ++m)
         if (f[(size_t)m]) {
-            uint32_t lo, hi; shard_range(nblocks, m, g->n, &lo, &hi);
+            uint32_t lo = src_and[0]->part->bounds[(size_t)m];
             *found = 1; *idx = (uint64_t)lo * BMX_BLOCK_BITS + pos[(size_t)m];
             break;
         }
@@ -547,9 +730,10 @@ int bmx_gslice_compare(bmx_group* g, const bmx_gvec* const* slices, size_t nslic
     }
     bmx_gvec* v = result ? gvec_new(g, size, nblocks) : nullptr;
     if (result && !v) return BMX_ERR_BADALLOC;
+    part_ref pr = part_for(g, nblocks);
     std::vector<uint64_t> cnt((size_t)g->n, 0);
     int rc = for_each_member(g, [&](int m) -> int {
-        uint32_t lo, hi; shard_range(nblocks, m, g->n, &lo, &hi);
+        uint32_t lo = pr->bounds[(size_t)m], hi = pr->bounds[(size_t)m + 1];
         std::vector<const bmx_vec*> sl(std::max<size_t>(nslices, 1), nullptr);
         for (size_t i = 0; i < nslices; ++i) sl[i] = slices[i] ? slices[i]->shard[(size_t)m] : nullptr;
         return bmx_slice_compare(g->ctx[(size_t)m], sl.data(), nslices, pred, v0, v1, shard_bits(size, lo, hi),
@@ -580,9 +764,10 @@ int bmx_gslice_eq_counts(bmx_group* g, const bmx_gvec* const* slices, size_t nsl
         bmx_set_last_error("size / not-NULL vector must span the block range of the planes"); return BMX_ERR_BADARG;
     }
     for (size_t q = 0; q < n; ++q) counts[q] = 0;
+    part_ref pr = part_for(g, nblocks);
     std::vector<std::vector<uint64_t>> part((size_t)g->n, std::vector<uint64_t>(std::max<size_t>(n, 1), 0));
     int rc = for_each_member(g, [&](int m) -> int {
-        uint32_t lo, hi; shard_range(nblocks, m, g->n, &lo, &hi);
+        uint32_t lo = pr->bounds[(size_t)m], hi = pr->bounds[(size_t)m + 1];
         std::vector<const bmx_vec*> sl(std::max<size_t>(nslices, 1), nullptr);
         for (size_t i = 0; i < nslices; ++i) sl[i] = slices[i] ? slices[i]->shard[(size_t)m] : nullptr;
         return bmx_slice_eq_counts(g->ctx[(size_t)m], sl.data(), nslices, values, n, shard_bits(size, lo, hi),
@@ -605,6 +790,7 @@ int bmx_gpipeline_destroy(bmx_group* g, bmx_gpipeline* p)
         if ((size_t)m < p->d_counts.size() && p->d_counts[(size_t)m]) (void)hipFree(p->d_counts[(size_t)m]);
         if ((size_t)m < p->ev0.size() && p->ev0[(size_t)m]) (void)hipEventDestroy(p->ev0[(size_t)m]);
         if ((size_t)m < p->ev1.size() && p->ev1[(size_t)m]) (void)hipEventDestroy(p->ev1[(size_t)m]);
+        if ((size_t)m < p->ev2.size() && p->ev2[(size_t)m]) (void)hipEventDestroy(p->ev2[(size_t)m]);
     }
     if (p->h_counts) (void)hipHostFree(p->h_counts);
     delete p;
@@ -627,7 +813,8 @@ int bmx_gpipeline_create(bmx_group* g, const bmx_gvec* const* and_list, const ui
     if (!p) return BMX_ERR_BADALLOC;
     p->g = g; p->ngroups = (uint32_t)ngroups;
     p->pipe.assign((size_t)g->n, nullptr); p->d_counts.assign((size_t)g->n, nullptr);
-    p->ev0.assign((size_t)g->n, nullptr); p->ev1.assign((size_t)g->n, nullptr); p->last_ms.assign((size_t)g->n, 0.f);
+    p->ev0.assign((size_t)g->n, nullptr); p->ev1.assign((size_t)g->n, nullptr); p->ev2.assign((size_t)g->n, nullptr);
+    p->last_ms.assign((size_t)g->n, 0.f); p->last_xchg_ms.assign((size_t)g->n, 0.f);
     rc = for_each_member(g, [&](int m) -> int {
         bmx_ctx* c = g->ctx[(size_t)m];
         std::vector<const bmx_vec*> a(std::max<size_t>(tot_and, 1)), s(std::max<size_t>(tot_sub, 1));
@@ -639,6 +826,7 @@ int bmx_gpipeline_create(bmx_group* g, const bmx_gvec* const* and_list, const ui
         HIPCHK(hipMalloc((void**)&p->d_counts[(size_t)m], ngroups * 8));
         HIPCHK(hipEventCreate(&p->ev0[(size_t)m]));
         HIPCHK(hipEventCreate(&p->ev1[(size_t)m]));
+        HIPCHK(hipEventCreate(&p->ev2[(size_t)m]));
         return BMX_OK;
     });
     if (!rc) {
@@ -650,21 +838,22 @@ int bmx_gpipeline_create(bmx_group* g, const bmx_gvec* const* and_list, const ui
     return BMX_OK;
 }
 
-int bmx_gpipeline_run_counts(bmx_group* g, bmx_gpipeline* p, uint64_t* counts_out)
+// everything of one run that is enqueued: kernels on every member first, then the exchange.  A failure in the middle
+// must not leave the other members' work in flight when the caller sees the error: the wrapper below drains every
+// stream before it returns (no early return past enqueued work)
+static int gpipeline_enqueue(bmx_group* g, bmx_gpipeline* p, bool rccl)
 {
-    ARGCHK(g && p && p->g == g && counts_out);
     const size_t ng = p->ngroups;
-    // 1. enqueue the counts kernel on every member (asynchronous: all devices start before any is waited for)
+    // 1. the counts kernel on every member (asynchronous: all devices start before any is waited for)
     for (int m = 0; m < g->n; ++m) {
         bmx_ctx* c = g->ctx[(size_t)m];
         HIPCHK(hipSetDevice(c->device));
         HIPCHK(hipEventRecord(p->ev0[(size_t)m], c->stream));
         int rc = bmx_pipeline_run_counts_dev(c, p->pipe[(size_t)m], 0u, 0xFFFFFFFFu, p->d_counts[(size_t)m]);
-        if (rc) { (void)sync_all(g); return rc; }
+        if (rc) return rc;
         HIPCHK(hipEventRecord(p->ev1[(size_t)m], c->stream));
     }
     // 2. the only exchange: the popcounts (8 B per arg-group)
-    const bool rccl = (g->flags & BMX_GROUP_RCCL) && !g->comm.empty();
     if (rccl) {
         int r = g->p_group_start();
         for (int m = 0; m < g->n && r == 0; ++m) {
@@ -676,7 +865,12 @@ int bmx_gpipeline_run_counts(bmx_group* g, bmx_gpipeline* p, uint64_t* counts_ou
         int r2 = g->p_group_end();
         if (r || r2) {
             std::string msg = "RCCL all-reduce failed: "; msg += g->p_errstr ? g->p_errstr(r ? r : r2) : "?";
-            (void)sync_all(g); bmx_set_last_error(msg.c_str()); return BMX_ERR_DEVICE;
+            bmx_set_last_error(msg.c_str()); return BMX_ERR_DEVICE;
+        }
+        for (int m = 0; m < g->n; ++m) {
+            bmx_ctx* c = g->ctx[(size_t)m];
+            HIPCHK(hipSetDevice(c->device));
+            HIPCHK(hipEventRecord(p->ev2[(size_t)m], c->stream));
         }
         bmx_ctx* c0 = g->ctx[0];
         HIPCHK(hipSetDevice(c0->device));
@@ -686,19 +880,31 @@ int bmx_gpipeline_run_counts(bmx_group* g, bmx_gpipeline* p, uint64_t* counts_ou
             bmx_ctx* c = g->ctx[(size_t)m];
             HIPCHK(hipSetDevice(c->device));
             HIPCHK(hipMemcpyAsync(p->h_counts + (size_t)m * ng, p->d_counts[(size_t)m], ng * 8, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipEventRecord(p->ev2[(size_t)m], c->stream));
         }
     }
-    int rc = sync_all(g); if (rc) return rc;
+    return BMX_OK;
+}
+
+int bmx_gpipeline_run_counts(bmx_group* g, bmx_gpipeline* p, uint64_t* counts_out)
+{
+    ARGCHK(g && p && p->g == g && counts_out);
+    const size_t ng = p->ngroups;
+    const bool rccl = (g->flags & BMX_GROUP_RCCL) && !g->comm.empty();
+    int rc = gpipeline_enqueue(g, p, rccl);
+    if (rc) { std::string keep = bmx_last_error(); (void)sync_all(g); bmx_set_last_error(keep.c_str()); return rc; }
+    rc = sync_all(g); if (rc) return rc;
     for (size_t k = 0; k < ng; ++k) {
         uint64_t t = p->h_counts[k];
         if (!rccl) for (int m = 1; m < g->n; ++m) t += p->h_counts[(size_t)m * ng + k];
         counts_out[k] = t;
     }
     for (int m = 0; m < g->n; ++m) {
-        float ms = 0.f;
+        float ms = 0.f, xs = 0.f;
         (void)hipSetDevice(g->ctx[(size_t)m]->device);
         if (hipEventElapsedTime(&ms, p->ev0[(size_t)m], p->ev1[(size_t)m]) != hipSuccess) { (void)hipGetLastError(); ms = 0.f; }
-        p->last_ms[(size_t)m] = ms;
+        if (hipEventElapsedTime(&xs, p->ev1[(size_t)m], p->ev2[(size_t)m]) != hipSuccess) { (void)hipGetLastError(); xs = 0.f; }
+        p->last_ms[(size_t)m] = ms; p->last_xchg_ms[(size_t)m] = xs;
     }
     return BMX_OK;
 }
@@ -708,6 +914,29 @@ int bmx_gpipeline_last_ms(bmx_group* g, const bmx_gpipeline* p, float* ms)
     ARGCHK(g && p && p->g == g && ms);
     for (int m = 0; m < g->n; ++m) ms[m] = p->last_ms[(size_t)m];
     return BMX_OK;
+}
+
+int bmx_gpipeline_last_exchange_ms(bmx_group* g, const bmx_gpipeline* p, float* ms)
+{
+    ARGCHK(g && p && p->g == g && ms);
+    for (int m = 0; m < g->n; ++m) ms[m] = p->last_xchg_ms[(size_t)m];
+    return BMX_OK;
+}
+
+int bmx_gpipeline_operand_bytes(bmx_group* g, bmx_gpipeline* p, uint64_t* bytes_per_member)
+{
+    ARGCHK(g && p && p->g == g && bytes_per_member);
+    for (int m = 0; m < g->n; ++m) {
+        int rc = bmx_pipeline_operand_bytes(g->ctx[(size_t)m], p->pipe[(size_t)m], 0u, 0xFFFFFFFFu, &bytes_per_member[m]);
+        if (rc) return rc;
+    }
+    return BMX_OK;
+}
+
+int bmx_gpipeline_describe(bmx_group* g, bmx_gpipeline* p, int member, char* buf, size_t buf_len, uint32_t* n_launches)
+{
+    ARGCHK(g && p && p->g == g && member >= 0 && member < g->n);
+    return bmx_pipeline_describe(g->ctx[(size_t)member], p->pipe[(size_t)member], 0u, 0xFFFFFFFFu, buf, buf_len, n_launches);
 }
 
 } // extern "C"

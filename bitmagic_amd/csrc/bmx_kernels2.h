@@ -1050,6 +1050,31 @@ __device__ __forceinline__ u32 gap_group_count_range(gcptr16 g, u32 meta, u32 lo
     return c;
 }
 
+// Random 128-byte-line gather over a scratch buffer: the transaction-rate ceiling rank / select are measured against
+// (bmx_probe_random_lines).  Same access shape as k_rank's bit-line read: 8 lanes share one line, 16 B each; the line
+// index comes from a counter hash, four independent lines per lane per round.
+__global__ __launch_bounds__(256)
+void k_probe_lines(const uint4* __restrict__ buf, u64 nlines_buf, u64 nq, u64 seed, u64* __restrict__ sink)
+{
+    u32 sub = threadIdx.x & 7u;
+    u64 qi = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 3;
+    u64 stride = ((u64)gridDim.x * blockDim.x) >> 3;
+    u32 acc = 0;
+    for (; qi < nq; qi += 4ull * stride) {
+        uint4 v[4];
+#pragma unroll
+        for (u32 j = 0; j < 4; ++j) {
+            u64 z = (qi + j * stride) * 0x9E3779B97F4A7C15ull + seed;
+            z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull; z ^= z >> 27; z *= 0x94D049BB133111EBull; z ^= z >> 31;
+            u64 line = (u64)(((unsigned __int128)z * nlines_buf) >> 64);
+            v[j] = buf[line * 8u + sub];
+        }
+#pragma unroll
+        for (u32 j = 0; j < 4; ++j) acc += (qi + j * stride < nq) ? (v[j].x ^ v[j].y ^ v[j].z ^ v[j].w) : 0u;
+    }
+    if (acc == 0x9E3779B9u) sink[0] = acc;                  // keeps the loads alive; the buffer never holds that pattern
+}
+
 // bvector::count_to / rank(n, rs)  src/bm.h:3120 -- ones in [0..n]
 __global__ __launch_bounds__(256)
 void k_rank(const u64* __restrict__ desc, u32 nblocks, const u64* __restrict__ rcount, const u16* __restrict__ cum,

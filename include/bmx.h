@@ -267,7 +267,8 @@ int bmx_select_batch_dev(bmx_ctx* ctx, const bmx_vec* v, const bmx_rs* rs,
  * src/bm.h:6226-6271), so a group of n devices shards the linear block range [0, nblocks) into n contiguous
  * pieces: member m holds blocks bmx_group_shard_range(nblocks, m) of EVERY vector (a "sharded vector",
  * bmx_gvec); operand bits never cross xGMI.  One host thread drives all members: kernels are enqueued on every
- * member's stream before the first one is waited for; the only exchange is the sum of the per-member popcounts
+ * member's stream before the first one is waited for (calls that materialise vectors run the synchronous single-device
+ * entry on persistent per-member worker threads); the only exchange is the sum of the per-member popcounts
  * (8 B per arg-group), done on the host (default) or by an RCCL all-reduce over xGMI (BMX_GROUP_RCCL; librccl is
  * loaded on demand, devices must be distinct).  Materialised results stay sharded; bmx_gvec_download gathers.
  * A device may appear several times in `devices` (several streams on one GPU; what the 1-GPU tests use). */
@@ -282,8 +283,26 @@ int bmx_group_destroy(bmx_group* g);
 int bmx_group_size(const bmx_group* g, int* n);
 /* member m's context (owned by the group): e.g. to set tuning knobs or upload private vectors */
 int bmx_group_ctx(const bmx_group* g, int member, bmx_ctx** ctx);
-/* contiguous, exhaustive, balanced to within one block */
+/* the cut in force for vectors of nblocks blocks: contiguous, exhaustive; by default balanced to within one block */
 int bmx_group_shard_range(const bmx_group* g, uint32_t nblocks, int member, uint32_t* nb_from, uint32_t* nb_to);
+/* Byte-weighted shard borders (shards "weighted by non-NULL operand bytes").  A group keeps ONE
+ * cut of [0, nblocks) per vector length, so the block columns of all operands of an operation stay on the same member;
+ * the default cut gives every member the same number of block columns.  An index with empty stretches (NULL top-level
+ * ranges cost nothing: blocks_manager::get_block_ptr, src/bmblocks.h:556-564) would leave members idle under it:
+ *   bmx_block_table_weights       adds the algorithmic operand bytes of one host block table to weight[nblocks]
+ *                                 (8192 B per bit-block, 2 x (len + 1) B per GAP block, 0 for NULL / FULL); call it for
+ *                                 every vector of the collection
+ *   bmx_group_partition_by_weight cuts where the running weight reaches m/n of the total and makes that cut the one in
+ *                                 force for vectors of nblocks blocks (bounds_out: n + 1 borders, may be NULL)
+ *   bmx_group_set_partition       the same with explicit borders (bounds[0] = 0 <= ... <= bounds[n] = nblocks)
+ * Both must be called before the first vector of that length is created in the group (BMX_ERR_BADARG while vectors cut
+ * with other borders are alive).  bmx_group_shard_range reports the cut in force. */
+int bmx_block_table_weights(uint32_t nblocks, const uint8_t* kinds, const uint32_t* offs,
+                            const uint16_t* gap_slab, uint64_t gap_words, uint64_t* weight);
+int bmx_group_partition_by_weight(bmx_group* g, uint32_t nblocks, const uint64_t* weight, uint32_t* bounds_out);
+int bmx_group_set_partition(bmx_group* g, uint32_t nblocks, const uint32_t* bounds);
+/* ranks of the group's RCCL communicator as RCCL reports them (ncclCommCount); 0 for a host-sum group */
+int bmx_group_rccl_ranks(const bmx_group* g, int* n);
 /* bmx_vec_upload for a group: the block table is cut at the shard borders, every member receives its piece */
 int bmx_gvec_upload(bmx_group* g, uint64_t nbits, uint32_t nblocks,
                     const uint8_t* kinds, const uint32_t* offs,
@@ -339,10 +358,21 @@ int bmx_gpipeline_destroy(bmx_group* g, bmx_gpipeline* p);
 int bmx_gpipeline_run_counts(bmx_group* g, bmx_gpipeline* p, uint64_t* counts_out);
 /* per-member device time of the last bmx_gpipeline_run_counts (HIP events on the member streams), ms[n] */
 int bmx_gpipeline_last_ms(bmx_group* g, const bmx_gpipeline* p, float* ms);
+/* per-member device time between the end of the kernel and the end of the exchange (RCCL all-reduce, or the 8-byte
+ * copy to the host) of the last run, ms[n] */
+int bmx_gpipeline_last_exchange_ms(bmx_group* g, const bmx_gpipeline* p, float* ms);
+/* bmx_pipeline_operand_bytes / bmx_pipeline_describe per member (benchmark reports) */
+int bmx_gpipeline_operand_bytes(bmx_group* g, bmx_gpipeline* p, uint64_t* bytes_per_member);
+int bmx_gpipeline_describe(bmx_group* g, bmx_gpipeline* p, int member, char* buf, size_t buf_len, uint32_t* n_launches);
 
 /* ---- timing helper: HIP events on the context's stream ---- */
 int bmx_timer_start(bmx_ctx* ctx);
 int bmx_timer_stop_ms(bmx_ctx* ctx, float* ms);   /* synchronises on the stop event */
+
+/* measurement helper: ms of one pass of `nlines` random 128-byte-line reads (8 lanes x 16 B per line, the access shape
+ * of a rank query's bit line) over a scratch buffer of buf_bytes -- the gather ceiling that bench.py --config 3 divides
+ * the rank / select rates by (random access is bound by the HBM transaction rate) */
+int bmx_probe_random_lines(bmx_ctx* ctx, uint64_t buf_bytes, uint64_t nlines, int iters, float* ms_per_pass);
 
 #ifdef __cplusplus
 }

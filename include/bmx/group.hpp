@@ -35,6 +35,21 @@ public:
     {
         for (int m = 0; m < size(); ++m) { bmx_ctx* c = nullptr; check(bmx_group_ctx(h_, m, &c)); check(bmx_ctx_set_tuning(c, key, value)); }
     }
+    /// byte-weighted shard borders: weight[nb] = operand bytes of block column nb summed over the
+    /// collection (bmx_block_table_weights per vector); must precede the first vector of that length.  -> n + 1 borders
+    std::vector<uint32_t> partition_by_weight(const std::vector<uint64_t>& weight)
+    {
+        std::vector<uint32_t> b((size_t)size() + 1, 0);
+        check(bmx_group_partition_by_weight(h_, (uint32_t)weight.size(), weight.data(), b.data()));
+        return b;
+    }
+    void set_partition(uint32_t nblocks, const std::vector<uint32_t>& bounds)
+    {
+        if ((int)bounds.size() != size() + 1) check(BMX_ERR_BADARG);
+        check(bmx_group_set_partition(h_, nblocks, bounds.data()));
+    }
+    /// ranks of the in-library RCCL communicator (0 for a host-sum group)
+    int rccl_ranks() const { int n = 0; check(bmx_group_rccl_ranks(h_, &n)); return n; }
 private:
     bmx_group* h_ = nullptr;
 };

@@ -95,3 +95,25 @@ def test_shard_ranges_cover_every_block_once():
             assert all(a[1] == b[0] for a, b in zip(r, r[1:]))
             sizes = [hi - lo for lo, hi in r]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    """`python bench.py --gpus 8` without a launcher must use 8 devices or exit non-zero -- never print a 1-GPU line
+    (VERDICT r2 item 1).  On this CPU box no device is visible, so both in-process and torchrun-style starts must fail."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() >= 8:
+        pytest.skip("8 devices visible: nothing to refuse")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "BMX_BENCH_TEST_ONE_DEVICE")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--no-cpu", "--steps", "1", "--warmup", "0"],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0
+    assert not any(l.startswith("{") for l in out.stdout.splitlines())
+    assert "needs 8 visible devices" in out.stderr
+    # a launcher that started fewer ranks than --gpus asks for is refused as well
+    env2 = dict(env, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_PORT="29999", MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--no-cpu", "--steps", "1", "--warmup", "0"],
+                         env=env2, capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and not any(l.startswith("{") for l in out.stdout.splitlines())

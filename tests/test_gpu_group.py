@@ -230,3 +230,115 @@ def test_group_full_size_headline_shards(ctx):
     p.complete()
     exp = int(a.combine_and_sub(p)[0])
     assert got == exp and got > 90_000_000
+
+
+def test_byte_weighted_shard_borders(ctx, port):
+    """shards weighted by non-NULL operand bytes.  A collection whose first half is NULL (empty top-level
+    ranges, src/bmblocks.h:556-564): equal block counts would leave half of the members idle; the weighted cut gives
+    every member the same share of operand bytes, results stay identical to the single-context ones."""
+    nblk, members = 64, 4
+    nbits = nblk * 65536
+    tabs, pv = [], []
+    for v in range(6):
+        w = port.gen_words(SEED + 5, v, [6554, 300, 30000][v % 3], nbits)
+        w[: (nblk // 2) * 2048] = 0                      # first half empty -> NULL blocks
+        p = port.import_words(w, True, nbits)
+        pv.append(p); tabs.append(p.flatten())
+    grp = bm.group([0] * members)
+    # default cut: equal block counts
+    assert [grp.shard_range(nblk, m) for m in range(members)] == [(0, 16), (16, 32), (32, 48), (48, 64)]
+    bounds = grp.partition_for_tables(tabs)
+    assert bounds[0] == 0 and bounds[-1] == nblk and all(bounds[i] <= bounds[i + 1] for i in range(members))
+    assert bounds[1] >= nblk // 2                         # the empty half costs nothing: it all lands on member 0
+    assert [grp.shard_range(nblk, m) for m in range(members)] == [(int(bounds[m]), int(bounds[m + 1])) for m in range(members)]
+    # per-member operand bytes within 10 % of each other (what decides the busy time of an HBM-bound pass)
+    wsum = np.zeros(nblk, np.uint64)
+    for k, o, b, g in tabs:
+        for nb in range(nblk):
+            wsum[nb] += 8192 if k[nb] == 2 else (2 * ((int(g[o[nb]]) >> 3) + 1) if k[nb] == 3 else 0)
+    per = [int(wsum[bounds[m]:bounds[m + 1]].sum()) for m in range(members)]
+    assert max(per) <= 1.10 * (sum(per) / members), per
+    gv = [bm.gbvector.from_block_table(grp, nbits, *t) for t in tabs]
+    # borders cannot change under live vectors
+    with pytest.raises(bm.BmxError):
+        grp.set_partition(nblk, [0, 16, 32, 48, 64])
+    for g, p in zip(gv, pv):
+        assert g.count() == p.count()
+        assert g.block_table()[0].tolist() == p.flatten()[0].tolist()
+    agg = bm.gaggregator(grp)
+    t, _ = agg.combine_and_sub([gv[0], gv[3]], [gv[1]])
+    e = port.agg_and_sub([pv[0], pv[3]], [pv[1]])
+    assert t.count() == e.count() and t.block_table()[0].tolist() == e.flatten()[0].tolist()
+    o = agg.combine_or(gv)
+    assert o.count() == port.agg_or(pv).count()
+    pipe = bm.gpipeline(grp)
+    for a_, s_ in (([0, 3], []), ([2, 5], [1]), ([4], [0, 2])):
+        ag = pipe.add()
+        for i in a_: ag.add(gv[i], 0)
+        for i in s_: ag.add(gv[i], 1)
+    pipe.complete()
+    got = agg.combine_and_sub(pipe)
+    exp = port.pipeline_counts([([pv[i] for i in a_], [pv[i] for i in s_]) for a_, s_ in (([0, 3], []), ([2, 5], [1]), ([4], [0, 2]))])
+    assert got.tolist() == [int(x) for x in exp]
+    # member busy times: the pipeline's per-member operand bytes follow the cut
+    pb = pipe.operand_bytes()
+    assert sum(pb) > 0 and len(pipe.last_ms()) == members and len(pipe.last_exchange_ms()) == members
+    rs = gv[0].build_rs_index()
+    q = np.array([0, nbits // 2 - 1, nbits // 2, nbits // 2 + 70000, nbits - 1], np.uint64)
+    assert (gv[0].count_to(q, rs) == port.rs_build(pv[0]).rank(q)).all()
+    f, pos = gv[0].select(np.array([1, 5, pv[0].count()], np.uint64), rs)
+    epos, ef = port.rs_build(pv[0]).select(np.array([1, 5, pv[0].count()], np.uint64))
+    assert f.all() and (pos == epos).all()
+    del pipe, rs, gv, t, o
+    grp.set_partition(nblk, [0, 16, 32, 48, 64])          # no live vectors: allowed again
+    grp.close()
+
+
+def test_group_workers_persist_across_calls(port):
+    """the materialising group calls run on persistent per-member workers: many calls, same results, errors carried over"""
+    nbits = 10 * 65536
+    pv = [port.import_words(port.gen_words(SEED + 9, v, 6554, nbits), True, nbits) for v in range(3)]
+    grp = bm.group([0] * 4)
+    gv = [bm.gbvector.from_block_table(grp, nbits, *p.flatten()) for p in pv]
+    exp = [port.op2(op, pv[0], pv[1], False).count() for op in range(4)]
+    for _ in range(50):
+        for op in range(4):
+            assert bm.gbvector._op2(op, gv[0], gv[1]).count() == exp[op]
+    other = bm.group([0] * 2)
+    ov = bm.gbvector.from_block_table(other, nbits, *pv[2].flatten())
+    with pytest.raises(bm.BmxError):
+        bm.gbvector._op2(0, gv[0], ov)
+    with pytest.raises(bm.BmxError):                     # a malformed table is refused by a worker, the text reaches the caller
+        k, o, b, g = pv[0].flatten()
+        bad = k.copy(); bad[7] = 9
+        bm.gbvector.from_block_table(grp, nbits, bad, o, b, g)
+    assert bm.gbvector._op2(0, gv[0], gv[1]).count() == exp[0]
+    grp.close(); other.close()
+
+
+def test_bench_plain_gpus2_uses_two_members():
+    """`python bench.py --gpus 2` with no RANK in the environment must itself run 2 GPUs (here: the one-device test hook,
+    two members of a bmx_group on device 0) and say so; never an n_gpus: 1 line for --gpus 2"""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ); env["BMX_BENCH_TEST_ONE_DEVICE"] = "1"
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"): env.pop(k, None)
+    nbits = 40 * 65536 + 99
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--nvec", "16", "--nbits", str(nbits),
+                          "--steps", "3", "--warmup", "1", "--no-cpu"], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    j = json.loads(line)
+    assert j["n_gpus"] == 2 and j["mode"] == "group" and len(j["per_rank"]["kernel_ms"]) == 2
+    import oracle
+    P = oracle.port()
+    vecs = [P.import_words(P.gen_words(SEED, v, 6554, nbits, with_common=True), True, nbits) for v in range(16)]
+    assert j["config"]["result_count"] == int(P.pipeline_counts([(vecs, [])])[0])
+    assert j["weak_scaling"]["result_count"] > 0
+    # without the hook a 1-GPU box must refuse --gpus 2 instead of printing a 1-GPU line
+    env.pop("BMX_BENCH_TEST_ONE_DEVICE")
+    import torch
+    if torch.cuda.device_count() < 2:
+        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--nvec", "4", "--nbits", str(nbits),
+                              "--steps", "1", "--warmup", "0", "--no-cpu"], env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode != 0 and not any(l.startswith("{") for l in out.stdout.splitlines())
