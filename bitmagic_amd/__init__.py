@@ -86,6 +86,17 @@ class context:
     def trim(self):
         check(lib().bmx_ctx_trim(self._h))
 
+    # -- packed collections (include/bmx.h "packed collections"): operand sets the engine keeps column-major --
+    def collection_prepare(self, vecs, role: int = 1) -> None:
+        """build the packed collection of an operand list now; role: ROLE_AND (0), ROLE_OR (1), ROLE_SUB (2)"""
+        vecs = list(vecs)
+        check(lib().bmx_collection_prepare(self._h, _handles(vecs), len(vecs), int(role)))
+
+    def pack_stats(self) -> dict:
+        n, b, ms = C.c_uint32(), C.c_uint64(), C.c_float()
+        check(lib().bmx_ctx_pack_stats(self._h, C.byref(n), C.byref(b), C.byref(ms)))
+        return {"collections": n.value, "bytes": b.value, "last_build_ms": ms.value}
+
     def mem_used(self) -> int:
         b = C.c_uint64()
         check(lib().bmx_ctx_mem_used(self._h, C.byref(b)))
@@ -712,6 +723,7 @@ class slice_scanner:
 # multi-GPU: device groups (include/bmx.h "device groups")
 # ---------------------------------------------------------------------------------------------------
 GROUP_HOST_SUM, GROUP_RCCL = 0, 1
+ROLE_AND, ROLE_OR, ROLE_SUB = 0, 1, 2
 
 
 class group:

@@ -8,8 +8,10 @@
 #include "bmx_kernels3.h"
 #include "bmx_kernels4.h"
 #include "bmx_kernels5.h"
+#include "bmx_kernels6.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -35,6 +37,8 @@ int bmx_fail_hip(hipError_t e, const char* what, const char* file, int line)
 void bmx_set_last_error(const char* msg) { g_last_error = msg ? msg : ""; }
 static int fail_hip(hipError_t e, const char* what, int line) { return bmx_fail_hip(e, what, "bmx.hip", line); }
 
+static void coll_free(bmx_ctx* ctx, size_t idx);
+static void coll_drop_vector(bmx_ctx* ctx, uint64_t uid);
 static int set_dev(const bmx_ctx* ctx) { HIPCHK(hipSetDevice(ctx->device)); return BMX_OK; }
 
 static size_t pool_round(size_t bytes)
@@ -93,6 +97,197 @@ static int ensure(bmx_ctx* ctx, void** buf, size_t* cur, size_t need)
     if (*buf) { HIPCHK(hipStreamSynchronize(ctx->stream)); (void)hipFree(*buf); *buf = nullptr; *cur = 0; }
     HIPCHK(hipMalloc(buf, need));
     *cur = need;
+    return BMX_OK;
+}
+
+// ---------------------------------------------------------------------------
+// column-major packed GAP collections (bmx_kernels6.h): cache keyed by the operand set
+// ---------------------------------------------------------------------------
+static void coll_free(bmx_ctx* ctx, size_t idx)
+{
+    bmx_coll* c = ctx->colls[idx];
+    dfree(ctx, c->d_runs); dfree(ctx, c->d_off); dfree(ctx, c->d_cnt); dfree(ctx, c->d_flags);
+    ctx->pack_bytes -= std::min<uint64_t>(ctx->pack_bytes, c->bytes);
+    ctx->colls.erase(ctx->colls.begin() + (long)idx);
+    delete c;
+}
+
+// a vector is going away (the caller has synchronised the stream): every collection that holds its runs goes with it
+static void coll_drop_vector(bmx_ctx* ctx, uint64_t uid)
+{
+    for (size_t i = ctx->colls.size(); i-- > 0;)
+        if (std::binary_search(ctx->colls[i]->sorted.begin(), ctx->colls[i]->sorted.end(), uid)) coll_free(ctx, i);
+}
+
+static u64 coll_hash(const bmx_vec* const* v, size_t n, int polarity)
+{
+    u64 h = 0x9E3779B97F4A7C15ull ^ (u64)polarity;
+    for (size_t i = 0; i < n; ++i) { h ^= v[i]->uid + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2); }
+    return h;
+}
+
+// may this operand list go through a packed collection at all?  GAP / NULL / FULL blocks only, enough operands
+static bool coll_eligible(const bmx_ctx* ctx, const bmx_vec* const* v, size_t n, size_t min_n = 64)
+{
+    if (ctx->gap_pack == 0 || n < min_n) return false;
+    bool any_gap = false;
+    for (size_t i = 0; i < n; ++i) {
+        if (!v[i] || v[i]->ctx != ctx || v[i]->counts[BMX_BIT] != 0) return false;
+        any_gap |= v[i]->counts[BMX_GAP] != 0;
+    }
+    return any_gap;
+}
+
+static bmx_coll* coll_find(bmx_ctx* ctx, const bmx_vec* const* v, size_t n, int polarity, u64 h)
+{
+    for (bmx_coll* c : ctx->colls) {
+        if (c->hash != h || c->polarity != polarity || c->key.size() != n) continue;
+        bool same = true;
+        for (size_t i = 0; i < n && same; ++i) same = c->key[i] == v[i]->uid;
+        if (same) { c->last_use = ++ctx->coll_tick; return c; }
+    }
+    return nullptr;
+}
+
+// transposes the GAP blocks of the operand set into column-major interval bags.  Everything runs on the context's stream.
+static int coll_build(bmx_ctx* ctx, const bmx_vec* const* v, size_t n, int polarity, u64 h, bmx_coll** out)
+{
+    *out = nullptr;
+    int rc;
+    uint32_t ncols = 0; uint64_t alg = 0;
+    std::vector<const u64*> descs(n); std::vector<uint32_t> nblk(n);
+    for (size_t i = 0; i < n; ++i) {
+        descs[i] = v[i]->d_desc; nblk[i] = v[i]->nblocks; ncols = std::max(ncols, v[i]->nblocks);
+        alg += 2ull * v[i]->gap_words;                    // (device slabs pad blocks to 16 B: an upper bound, refined below)
+    }
+    if (!ncols) return BMX_OK;
+    bmx_coll* c = new (std::nothrow) bmx_coll();
+    if (!c) return BMX_ERR_BADALLOC;
+    c->hash = h; c->polarity = polarity; c->ncols = ncols; c->nvec = (uint32_t)n;
+    c->d_runs = nullptr; c->d_off = nullptr; c->d_cnt = nullptr; c->d_flags = nullptr;
+    c->entries = 0; c->bytes = 0; c->has_bit = false; c->build_ms = 0.f; c->alg_bytes = alg;
+    c->key.resize(n);
+    for (size_t i = 0; i < n; ++i) c->key[i] = v[i]->uid;
+    c->sorted = c->key; std::sort(c->sorted.begin(), c->sorted.end());
+    void* d_descs = nullptr; void* d_nblk = nullptr; u32* d_pre = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    auto fail = [&](int code) {
+        (void)hipStreamSynchronize(ctx->stream);
+        dfree(ctx, d_descs); dfree(ctx, d_nblk); dfree(ctx, d_pre);
+        dfree(ctx, c->d_runs); dfree(ctx, c->d_off); dfree(ctx, c->d_cnt); dfree(ctx, c->d_flags);
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+        delete c;
+        return code;
+    };
+    if ((rc = dmalloc(ctx, &d_descs, n * 8)) || (rc = dmalloc(ctx, &d_nblk, n * 4)) ||
+        (rc = dmalloc(ctx, (void**)&d_pre, (size_t)n * ncols * 4)) ||
+        (rc = dmalloc(ctx, (void**)&c->d_off, ((size_t)ncols + 1) * 8)) || (rc = dmalloc(ctx, (void**)&c->d_cnt, (size_t)ncols * 4)) ||
+        (rc = dmalloc(ctx, (void**)&c->d_flags, (size_t)ncols * 4))) return fail(rc);
+    hipError_t e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    if (e == hipSuccess) e = hipEventRecord(e0, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_descs, descs.data(), n * 8, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_nblk, nblk.data(), n * 4, hipMemcpyHostToDevice, ctx->stream);
+    if (e != hipSuccess) return fail(fail_hip(e, "coll_build", __LINE__));
+    hipLaunchKernelGGL(k_coll_count, dim3((ncols + 255) / 256), dim3(256), 0, ctx->stream, (const u64* const*)d_descs,
+                       (const u32*)d_nblk, (u32)n, ncols, (u32)polarity, d_pre, c->d_cnt, c->d_flags);
+    hipLaunchKernelGGL(k_coll_offsets, dim3(1), dim3(1024), 0, ctx->stream, (const u32*)c->d_cnt, ncols, c->d_off);
+    e = hipGetLastError();
+    u64 total = 0;
+    if (e == hipSuccess) e = hipMemcpyAsync(&total, c->d_off + ncols, 8, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);          // (descs / nblk are read from pageable memory: they are done too)
+    if (e != hipSuccess) return fail(fail_hip(e, "coll_build (count)", __LINE__));
+    c->entries = total;
+    if ((rc = dmalloc(ctx, (void**)&c->d_runs, std::max<size_t>((size_t)total * 4, 64)))) return fail(rc);
+    // lanes per block by the average number of entries of a block
+    uint64_t nblocks_gap = 0;
+    for (size_t i = 0; i < n; ++i) nblocks_gap += v[i]->counts[BMX_GAP];
+    uint64_t avg = nblocks_gap ? total / nblocks_gap : 0;
+    if (total) {
+        if (avg <= 24) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_coll_scatter<8>), dim3((u32)n, (ncols + 31) / 32), dim3(256), 0, ctx->stream,
+                                          (const u64* const*)d_descs, (const u32*)d_nblk, ncols, (u32)polarity, (const u32*)d_pre, (const u64*)c->d_off, c->d_runs);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_coll_scatter<64>), dim3((u32)n, (ncols + 3) / 4), dim3(256), 0, ctx->stream,
+                                (const u64* const*)d_descs, (const u32*)d_nblk, ncols, (u32)polarity, (const u32*)d_pre, (const u64*)c->d_off, c->d_runs);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipEventRecord(e1, ctx->stream);
+    if (e == hipSuccess) e = hipEventSynchronize(e1);
+    if (e == hipSuccess) e = hipEventElapsedTime(&c->build_ms, e0, e1);
+    if (e != hipSuccess) return fail(fail_hip(e, "coll_build (scatter)", __LINE__));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    dfree(ctx, d_descs); dfree(ctx, d_nblk); dfree(ctx, d_pre);
+    c->bytes = (uint64_t)total * 4 + (uint64_t)ncols * 16 + 8;
+    c->last_use = ++ctx->coll_tick;
+    ctx->last_pack_ms = c->build_ms;
+    // make room: least recently used collections go first
+    while (!ctx->colls.empty() && ctx->pack_bytes + c->bytes > ctx->pack_cap) {
+        size_t lru = 0;
+        for (size_t i = 1; i < ctx->colls.size(); ++i) if (ctx->colls[i]->last_use < ctx->colls[lru]->last_use) lru = i;
+        coll_free(ctx, lru);
+    }
+    ctx->colls.push_back(c);
+    ctx->pack_bytes += c->bytes;
+    *out = c;
+    return BMX_OK;
+}
+
+// the collection of this operand set if there is (or, by the packing policy, should now be) one; *out = nullptr: use the
+// descriptor-table kernels.  force: build at first sight (bmx_collection_prepare, gap_pack 1)
+static int coll_get(bmx_ctx* ctx, const bmx_vec* const* v, size_t n, int polarity, bool force, bmx_coll** out, size_t min_n = 64)
+{
+    *out = nullptr;
+    if (!coll_eligible(ctx, v, n, min_n)) return BMX_OK;
+    u64 h = coll_hash(v, n, polarity);
+    if (bmx_coll* c = coll_find(ctx, v, n, polarity, h)) { *out = c; return BMX_OK; }
+    if (!force && ctx->gap_pack != 1) {
+        if (ctx->coll_seen.size() > 4096) ctx->coll_seen.clear();
+        if (++ctx->coll_seen[h] < 2u) return BMX_OK;        // first sighting of this set: not worth a transposition yet
+    }
+    uint64_t need = 0;
+    for (size_t i = 0; i < n; ++i) need += 2ull * v[i]->gap_words;
+    if (need > ctx->pack_cap) return BMX_OK;
+    int rc = coll_build(ctx, v, n, polarity, h, out);
+    ctx->coll_seen.erase(h);
+    return rc;
+}
+
+// one workgroup per block column over [col_from, col_to); a = the AND / OR bag, s = the SUB bag (may be null)
+static int coll_launch(int mode, bmx_ctx* ctx, const bmx_coll* a, const bmx_coll* s, u32 col_from, u32 col_to, int opt_compress,
+                       u64* d_counts, bmx_vec* v, BlockStat* st, u32 hint_from, u32 hint_to)
+{
+    if (col_to <= col_from) return BMX_OK;
+    const u32 grid = col_to - col_from;
+#define COLL_ARGS dim3(grid), dim3(256), 0, ctx->stream, (const u32*)a->d_runs, (const u64*)a->d_off, (const u32*)a->d_cnt, \
+        (const u32*)a->d_flags, a->ncols, (const u32*)(s ? s->d_runs : nullptr), (const u64*)(s ? s->d_off : nullptr), \
+        (const u32*)(s ? s->d_cnt : nullptr), (const u32*)(s ? s->d_flags : nullptr), s ? s->ncols : 0u, col_from, col_to, opt_compress, \
+        d_counts, v ? v->d_bits : (uint4*)nullptr, v ? v->d_desc : (u64*)nullptr, st, hint_from, hint_to
+    if (mode == COLL_OR) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_coll_apply<COLL_OR, 256>), COLL_ARGS);
+    else if (mode == COLL_AND_STORE) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_coll_apply<COLL_AND_STORE, 256>), COLL_ARGS);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_coll_apply<COLL_AND_COUNT, 256>), COLL_ARGS);
+#undef COLL_ARGS
+    KCHK();
+    return BMX_OK;
+}
+
+// the packed form of an AND list + SUB list, if both can (and by policy should) be used: *a = nullptr otherwise
+static int coll_get_and_sub(bmx_ctx* ctx, const bmx_vec* const* va, size_t na, const bmx_vec* const* vs, size_t ns,
+                            bmx_coll** a, bmx_coll** s)
+{
+    *a = nullptr; *s = nullptr;
+    if (!coll_eligible(ctx, va, na)) return BMX_OK;
+    if (ns && !coll_eligible(ctx, vs, ns, 1)) {
+        // a SUB list without GAP blocks (NULL / FULL only) has nothing to pack but is still fine: flags only -- keep it simple:
+        // such lists and lists with bit-blocks take the descriptor-table kernels
+        return BMX_OK;
+    }
+    int rc = coll_get(ctx, va, na, 0, false, a);
+    if (rc || !*a) return rc;
+    if (ns) {
+        rc = coll_get(ctx, vs, ns, 1, ctx->gap_pack == 1 || true, s, 1);      // the AND bag exists: its SUB partner is built with it
+        if (rc) return rc;
+        if (!*s) *a = nullptr;
+    }
     return BMX_OK;
 }
 
@@ -264,12 +459,13 @@ int bmx_ctx_create(int device, void* stream, bmx_ctx** out)
     CTXCHK(hipMalloc((void**)&ctx->d_done, FOLD_DONE_WORDS * 4));
     CTXCHK(hipMemsetAsync(ctx->d_done, 0, FOLD_DONE_WORDS * 4, ctx->stream));
 #undef CTXCHK
+    if (const char* e = getenv("BMX_PACK_MAX_MB")) { long long mb = atoll(e); if (mb >= 0) ctx->pack_cap = (uint64_t)mb << 20; }
     if (const char* e = getenv("BMX_POOL_MAX_MB")) { long long mb = atoll(e); if (mb >= 0) ctx->pool_cap = (uint64_t)mb << 20; }
     // launch-shape knobs from the environment go through the same validation as bmx_ctx_set_tuning;
     // an invalid value is ignored (the default stays)
     static const char* const env_keys[][2] = {
         {"BMX_PIPE_UNROLL", "pipe_unroll"}, {"BMX_PIPE_ROWS", "pipe_rows"}, {"BMX_PIPE_NT", "pipe_nt"},
-        {"BMX_PIPE_WG", "pipe_wg"}, {"BMX_PIPE_WINDOW", "pipe_window"}, {"BMX_PIPE_SPLIT", "pipe_split"}, {"BMX_OR_TILE", "or_tile"}, {"BMX_OR_WINDOW", "or_window"}, {"BMX_DIRECT_COLS", "direct_cols"}, {"BMX_FF_WINDOW", "ff_window"}, {"BMX_GAP_COUNT", "gap_count"}, {"BMX_RANGE_HALVES", "range_halves"}, {"BMX_PAIR_STREAM", "pair_stream"}, {"BMX_PAIR_WGS", "pair_wgs"}, {"BMX_XCD_SWIZZLE", "xcd_swizzle"}};
+        {"BMX_PIPE_WG", "pipe_wg"}, {"BMX_PIPE_WINDOW", "pipe_window"}, {"BMX_PIPE_SPLIT", "pipe_split"}, {"BMX_OR_TILE", "or_tile"}, {"BMX_OR_WINDOW", "or_window"}, {"BMX_DIRECT_COLS", "direct_cols"}, {"BMX_FF_WINDOW", "ff_window"}, {"BMX_GAP_COUNT", "gap_count"}, {"BMX_RANGE_HALVES", "range_halves"}, {"BMX_PAIR_STREAM", "pair_stream"}, {"BMX_PAIR_WGS", "pair_wgs"}, {"BMX_RS_UNROLL", "rs_unroll"}, {"BMX_GAP_PACK", "gap_pack"}, {"BMX_XCD_SWIZZLE", "xcd_swizzle"}};
     for (auto& kv : env_keys)
         if (const char* e = getenv(kv[0])) (void)bmx_ctx_set_tuning(ctx, kv[1], atoi(e));
     g_last_error.clear();
@@ -282,6 +478,7 @@ int bmx_ctx_destroy(bmx_ctx* ctx)
     if (!ctx) return BMX_OK;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    while (!ctx->colls.empty()) coll_free(ctx, ctx->colls.size() - 1);
     pool_trim(ctx);
     // vectors / pipelines the caller never freed: their handles die with the context, the device memory must not leak
     for (auto& kv : ctx->pool_live) (void)hipFree(kv.first);
@@ -322,6 +519,8 @@ int bmx_ctx_set_tuning(bmx_ctx* ctx, const char* key, int value)
     else if (k == "gap_count") { ARGCHK(value >= -1 && value <= 1); ctx->gap_count = value; }
     else if (k == "ff_window") { ARGCHK(value >= -1); ctx->ff_window = value; }
     else if (k == "or_window") { ARGCHK(value >= -9); ctx->or_window = value; }
+    else if (k == "gap_pack") { ARGCHK(value >= -1 && value <= 1); ctx->gap_pack = value; }
+    else if (k == "rs_unroll") { ARGCHK(value == 0 || value == 1 || value == 2 || value == 4); ctx->rs_unroll = value; }
     else if (k == "pipe_wg") { ARGCHK(value == 0 || (value >= 64 && value <= 1024 && value % 64 == 0)); ctx->pipe_wg = value; }
     else if (k == "xcd_swizzle") ctx->xcd_swz = value != 0;
     else { g_last_error = "unknown tuning key"; return BMX_ERR_BADARG; }
@@ -384,6 +583,28 @@ int bmx_ctx_mem_used(const bmx_ctx* ctx, uint64_t* bytes)
     return BMX_OK;
 }
 
+int bmx_collection_prepare(bmx_ctx* ctx, const bmx_vec* const* vecs, size_t n, int role)
+{
+    ARGCHK(ctx && (n == 0 || vecs) && (role == BMX_ROLE_OR || role == BMX_ROLE_AND || role == BMX_ROLE_SUB));
+    int rc = set_dev(ctx); if (rc) return rc;
+    for (size_t i = 0; i < n; ++i) if (!vecs[i] || vecs[i]->ctx != ctx) { g_last_error = "operand is null or belongs to another context"; return BMX_ERR_BADARG; }
+    if (!coll_eligible(ctx, vecs, n, role == BMX_ROLE_SUB ? 1 : 64)) {
+        g_last_error = "not packable: needs >= 64 operands (SUB list: >= 1) made of GAP / NULL / FULL blocks only, and gap_pack != 0";
+        return BMX_ERR_BADARG;
+    }
+    bmx_coll* c = nullptr;
+    return coll_get(ctx, vecs, n, role == BMX_ROLE_AND ? 0 : 1, true, &c, role == BMX_ROLE_SUB ? 1 : 64);
+}
+
+int bmx_ctx_pack_stats(const bmx_ctx* ctx, uint32_t* n_collections, uint64_t* bytes, float* last_build_ms)
+{
+    ARGCHK(ctx);
+    if (n_collections) *n_collections = (uint32_t)ctx->colls.size();
+    if (bytes) *bytes = ctx->pack_bytes;
+    if (last_build_ms) *last_build_ms = ctx->last_pack_ms;
+    return BMX_OK;
+}
+
 int bmx_timer_start(bmx_ctx* ctx) { ARGCHK(ctx); HIPCHK(hipEventRecord(ctx->ev0, ctx->stream)); return BMX_OK; }
 int bmx_timer_stop_ms(bmx_ctx* ctx, float* ms)
 {
@@ -428,6 +649,8 @@ static bmx_vec* vec_alloc_host(bmx_ctx* ctx, uint64_t nbits, uint32_t nblocks)
     bmx_vec* v = new (std::nothrow) bmx_vec();
     if (!v) return nullptr;
     memset(v, 0, sizeof(*v));
+    static std::atomic<uint64_t> next_uid{1};
+    v->uid = next_uid.fetch_add(1);
     v->ctx = ctx; v->nbits = nbits; v->nblocks = nblocks;
     return v;
 }
@@ -452,6 +675,7 @@ int bmx_vec_free(bmx_ctx* ctx, bmx_vec* v)
     ARGCHK(ctx && v->ctx == ctx);
     int rc = set_dev(ctx); if (rc) return rc;
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    coll_drop_vector(ctx, v->uid);
     dfree(ctx, v->d_desc); dfree(ctx, v->d_bits); dfree(ctx, v->d_gaps); dfree(ctx, v->d_ord);
     delete v;
     return BMX_OK;
@@ -759,6 +983,14 @@ int bmx_pipeline_create(bmx_ctx* ctx, const bmx_vec* const* and_list, const uint
     p->nbits = max_bits;
     p->h_row_off = new std::vector<u32>(row_off, row_off + ngroups);
     p->h_and_n = new std::vector<u32>(m_and_n, m_and_n + ngroups);
+    if (ngroups == 1 && has_gap && !has_bit && ctx->gap_pack != 0 && tot_and >= 64) {
+        // one arg-group over GAP-only operands: remember the operand vectors (like the reference's pipeline, :2939) so that
+        // a run can go through the packed collection of the set
+        p->h_vecs = new std::vector<const bmx_vec*>();
+        p->h_vecs->reserve(tot_and + tot_sub);
+        for (size_t i = 0; i < tot_and; ++i) p->h_vecs->push_back(and_list[i]);
+        for (size_t i = 0; i < tot_sub; ++i) p->h_vecs->push_back(sub_list[i]);
+    }
     // distinct vectors of the pipeline (pipeline::unique_vectors(), src/bmaggregator.h:301) and the
     // (AND | SUB << 16) plane masks of every group, 16 planes per chunk -- only where the staged kernel can be chosen
     // (>= 32 groups, or forced by the knob): a single-group combine_and_sub pays neither the hashing nor the uploads
@@ -827,7 +1059,7 @@ int bmx_pipeline_destroy(bmx_ctx* ctx, bmx_pipeline* p)
     HIPCHK(hipStreamSynchronize(ctx->stream));
     dfree(ctx, p->d_dmat); dfree(ctx, p->d_meta); dfree(ctx, (void*)p->d_descs);
     dfree(ctx, (void*)p->d_udesc); dfree(ctx, p->d_unblk); dfree(ctx, p->d_gmask); dfree(ctx, p->d_gskip);
-    delete p->h_row_off; delete p->h_and_n;
+    delete p->h_row_off; delete p->h_and_n; delete p->h_vecs;
     delete p;
     return BMX_OK;
 }
@@ -918,6 +1150,13 @@ int bmx_pipeline_run_counts_dev(bmx_ctx* ctx, bmx_pipeline* p, uint32_t nb_from,
         return BMX_OK;
     }
     if (nitems64 > 0xFFFFFFF0ull) { g_last_error = "too many (column, group) items in one run"; return BMX_ERR_RANGE; }
+    if (p->h_vecs && !p->has_bit) {
+        // one arg-group over GAP-only operands seen before: the packed collection of the operand set (bmx_kernels6.h)
+        bmx_coll *ca = nullptr, *cs = nullptr;
+        const size_t na = (*p->h_and_n)[0], ns = p->h_vecs->size() - na;
+        if ((rc = coll_get_and_sub(ctx, p->h_vecs->data(), na, p->h_vecs->data() + na, ns, &ca, &cs))) return rc;
+        if (ca) return coll_launch(COLL_AND_COUNT, ctx, ca, cs, nb_from, nb_to, 1, (u64*)d_counts, nullptr, nullptr, 0u, 0xFFFFFFFFu);
+    }
     if (use_gapcount(ctx, p)) {
         // every operand block is GAP (or NULL / FULL): the counting formulation, one 1024-thread workgroup per (column, group)
         size_t lds = (size_t)(16384 * 2 + 2048) * 4;
@@ -964,6 +1203,9 @@ int bmx_pipeline_describe(bmx_ctx* ctx, bmx_pipeline* p, uint32_t nb_from, uint3
         snprintf(buf, buf_len, "k_pipe_counts_staged<%d> x 1 launch, %u workgroups", ctx->pipe_slots, nb_to - nb_from);
     else if (use_split(ctx, p, nitems64))
         snprintf(buf, buf_len, "k_pipe_split<2,%d> x 1 launch, %llu workgroups", SPLIT_WAVES, (unsigned long long)nitems64);
+    else if (p->h_vecs && !p->has_bit && ctx->gap_pack != 0 &&
+             coll_find(ctx, p->h_vecs->data(), (*p->h_and_n)[0], 0, coll_hash(p->h_vecs->data(), (*p->h_and_n)[0], 0)))
+        snprintf(buf, buf_len, "k_coll_apply<AND_COUNT,256> x 1 launch, %llu workgroups (packed collection of the operand set)", (unsigned long long)nitems64);
     else if (use_gapcount(ctx, p))
         snprintf(buf, buf_len, "k_pipe_counts_gapcount x 1 launch, %llu workgroups", (unsigned long long)nitems64);
     else if (p->has_gap)
@@ -1304,6 +1546,7 @@ static int agg_or_impl(bmx_ctx* ctx, const bmx_vec* const* src, size_t n, int op
         has_bit |= src[i]->counts[BMX_BIT] != 0;
     }
     bmx_vec* v; BlockStat* st; u32* offs;
+    bmx_coll* packed = nullptr;
     if ((rc = result_begin(ctx, nbits, ncols, &v, &st, &offs))) return rc;      // empty list => cleared target (:1105)
     if (use_direct(ctx, ncols, n)) {
         void* d_tab = nullptr;
@@ -1313,6 +1556,13 @@ static int agg_or_impl(bmx_ctx* ctx, const bmx_vec* const* src, size_t n, int op
         else (void)hipStreamSynchronize(ctx->stream);
         dfree(ctx, d_tab);
         if (rc) { bmx_vec_free(ctx, v); return rc; }
+    } else if (n >= 64 && ncols && has_gap && !has_bit && (rc = coll_get(ctx, src, n, 1, false, &packed)) == BMX_OK && packed) {
+        // many GAP-only operands, seen before: one sequential stream per block column (packed collection, bmx_kernels6.h)
+        rc = coll_launch(COLL_OR, ctx, packed, nullptr, 0u, ncols, opt_compress, nullptr, v, st, 0u, 0xFFFFFFFFu);
+        if (!rc) rc = result_finish(ctx, v, st, offs);
+        else (void)hipStreamSynchronize(ctx->stream);
+        if (rc) { bmx_vec_free(ctx, v); return rc; }
+    } else if (rc) { bmx_vec_free(ctx, v); return rc;
     } else if (n >= 64 && ncols && has_gap && !has_bit) {
         // many GAP-only operands: column-tile kernel straight from the descriptor tables (no sort pass)
         void* d_descs = nullptr; void* d_nblk = nullptr;
@@ -1454,6 +1704,24 @@ int bmx_agg_and_sub(bmx_ctx* ctx, const bmx_vec* const* src_and, size_t n_and,
         if (any) *any = (v->counts[BMX_FULL] + v->counts[BMX_BIT] + v->counts[BMX_GAP]) != 0;
         *result = v;
         return BMX_OK;
+    }
+    {
+        // GAP-only operand sets seen before: packed collections, one sequential stream per block column (bmx_kernels6.h)
+        bmx_coll *ca = nullptr, *cs = nullptr;
+        bool ok = true;
+        for (size_t i = 0; i < n_and && ok; ++i) ok = src_and[i]->ctx == ctx;
+        for (size_t i = 0; i < n_sub && ok; ++i) ok = src_sub[i]->ctx == ctx;
+        if (ok && ncols && (rc = coll_get_and_sub(ctx, src_and, n_and, src_sub, n_sub, &ca, &cs))) return rc;
+        if (ca) {
+            if ((rc = result_begin(ctx, nbits, ncols, &v, &st, &offs))) return rc;
+            rc = coll_launch(COLL_AND_STORE, ctx, ca, cs, 0u, ncols, 1, nullptr, v, st, 0u, 0xFFFFFFFFu);
+            if (!rc) rc = result_finish(ctx, v, st, offs);
+            else (void)hipStreamSynchronize(ctx->stream);
+            if (rc) { bmx_vec_free(ctx, v); return rc; }
+            if (any) *any = (v->counts[BMX_FULL] + v->counts[BMX_BIT] + v->counts[BMX_GAP]) != 0;
+            *result = v;
+            return BMX_OK;
+        }
     }
     uint32_t an = (uint32_t)n_and, sn = (uint32_t)n_sub;
     bmx_pipeline* p = nullptr;
@@ -1927,6 +2195,7 @@ int bmx_rs_export(bmx_ctx* ctx, const bmx_rs* rs, uint32_t* bcount, uint64_t* su
     return BMX_OK;
 }
 
+#define RS_UNROLL_DEFAULT 4
 static u32 query_grid(size_t q) { return (u32)std::min<size_t>((q * 8 + 255) / 256, 256u * 16u); }
 
 int bmx_rank_batch_dev(bmx_ctx* ctx, const bmx_vec* v, const bmx_rs* rs, const uint64_t* d_n, size_t q, uint64_t* d_out)
@@ -1934,8 +2203,14 @@ int bmx_rank_batch_dev(bmx_ctx* ctx, const bmx_vec* v, const bmx_rs* rs, const u
     ARGCHK(ctx && v && rs && v->ctx == ctx && rs->ctx == ctx && rs->nblocks == v->nblocks && (q == 0 || (d_n && d_out)));
     int rc = set_dev(ctx); if (rc) return rc;
     if (!q) return BMX_OK;
-    hipLaunchKernelGGL(k_rank, dim3(query_grid(q)), dim3(256), 0, ctx->stream, v->d_desc, v->nblocks,
-                       rs->d_rcount, rs->d_cum, rs->d_gidx, rs->count, (const u64*)d_n, (u64)q, (u64*)d_out);
+#define RANK_ARGS dim3(query_grid(q)), dim3(256), 0, ctx->stream, v->d_desc, v->nblocks, \
+                  rs->d_rcount, rs->d_cum, rs->d_gidx, rs->count, (const u64*)d_n, (u64)q, (u64*)d_out
+    // queries in flight per group of 8 lanes (rs_unroll: 0 = automatic; batches too small to fill the chip keep 1)
+    int uq = ctx->rs_unroll ? ctx->rs_unroll : (q >= (1u << 16) ? RS_UNROLL_DEFAULT : 1);
+    if (uq == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rank_q<4>), RANK_ARGS);
+    else if (uq == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rank_q<2>), RANK_ARGS);
+    else hipLaunchKernelGGL(k_rank, RANK_ARGS);
+#undef RANK_ARGS
     KCHK();
     return BMX_OK;
 }
@@ -1946,9 +2221,14 @@ int bmx_select_batch_dev(bmx_ctx* ctx, const bmx_vec* v, const bmx_rs* rs, const
     ARGCHK(ctx && v && rs && v->ctx == ctx && rs->ctx == ctx && rs->nblocks == v->nblocks && (q == 0 || (d_rank && d_pos && d_found)));
     int rc = set_dev(ctx); if (rc) return rc;
     if (!q) return BMX_OK;
-    hipLaunchKernelGGL(k_select, dim3(query_grid(q)), dim3(256), 0, ctx->stream, v->d_desc, v->nblocks,
-                       rs->d_rcount, rs->d_cum, rs->d_gidx, rs->d_sample, rs->nsamples, rs->sample_shift, rs->count,
-                       (const u64*)d_rank, (u64)q, (u64*)d_pos, (u8*)d_found);
+#define SEL_ARGS dim3(query_grid(q)), dim3(256), 0, ctx->stream, v->d_desc, v->nblocks, \
+                 rs->d_rcount, rs->d_cum, rs->d_gidx, rs->d_sample, rs->nsamples, rs->sample_shift, rs->count, \
+                 (const u64*)d_rank, (u64)q, (u64*)d_pos, (u8*)d_found
+    int uq = ctx->rs_unroll ? ctx->rs_unroll : (q >= (1u << 16) ? RS_UNROLL_DEFAULT : 1);
+    if (uq == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_select_q<4>), SEL_ARGS);
+    else if (uq == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_select_q<2>), SEL_ARGS);
+    else hipLaunchKernelGGL(k_select, SEL_ARGS);
+#undef SEL_ARGS
     KCHK();
     return BMX_OK;
 }

@@ -61,11 +61,19 @@ struct bmx_ctx {
     int gap_count = -1;        // GAP-only counts pipelines: counting formulation (k_pipe_counts_gapcount): -1 = automatic, 0 = off, 1 = force
     int ff_window = 0;         // find_first_and_sub: block columns of the FIRST launch window (each next one is 4x larger): 0 = automatic, -1 = one launch
     int or_window = 0;         // column tiles per launch of k_agg_or_gap_tiled: 0 / -1 = all in one launch (windows measured: no gain)
+    // column-major packed GAP collections (bmx_kernels6.h), cached by operand set
+    std::vector<struct bmx_coll*> colls;
+    std::unordered_map<u64, u32> coll_seen;   // hash of an operand set -> sightings so far (automatic packing waits for the second)
+    int gap_pack = -1;         // aggregation over >= 64 GAP-only operands through a packed collection: -1 = from the second use of an operand set, 0 = never, 1 = at first use
+    uint64_t pack_cap = 96ull << 30, pack_bytes = 0, coll_tick = 0;
+    float last_pack_ms = 0.f;
+    int rs_unroll = 0;         // rank / select: queries in flight per group of 8 lanes (k_rank_q / k_select_q): 0 = automatic, 1 = one (k_rank / k_select), 2, 4
     int xcd_swz = 1;
 };
 
 struct bmx_vec {
     bmx_ctx* ctx;
+    uint64_t uid;                                             // never reused: keys of the packed-collection cache
     uint64_t nbits; uint32_t nblocks;
     uint32_t counts[4]; uint64_t gap_words; uint32_t n_bit;   // n_bit = slots of d_bits
     u64* d_desc; uint4* d_bits; u16* d_gaps;
@@ -89,6 +97,20 @@ struct bmx_pipeline {
     u32* d_meta;       // row_off | and_n | sub_n | and_off | sub_off (ngroups each) | nblocks (n_ops)
     const u64** d_descs;
     size_t bytes;
+    std::vector<const bmx_vec*>* h_vecs = nullptr;   // single-group pipelines: the operand vectors (AND list, then SUB list) for the packed path
+};
+
+// a column-major packed interval collection of one operand set (bmx_kernels6.h)
+struct bmx_coll {
+    std::vector<uint64_t> key;            // uids in list order
+    std::vector<uint64_t> sorted;         // the same, sorted (membership test when a vector is freed)
+    u64 hash; int polarity;
+    uint32_t ncols, nvec;
+    u32* d_runs; u64* d_off; u32* d_cnt; u32* d_flags;
+    uint64_t entries, bytes, last_use;
+    uint64_t alg_bytes;                   // algorithmic bytes of the GAP operands: sum of 2 x (len + 1)
+    bool has_bit;                         // a bit-block was found while counting: unusable
+    float build_ms;
 };
 
 struct bmx_rs {

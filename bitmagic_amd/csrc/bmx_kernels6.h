@@ -1,0 +1,290 @@
+// bmx_kernels6.h -- column-major packed GAP collections (round 3).
+#pragma once
+#include "bmx_kernels5.h"
+
+// ---------------------------------------------------------------------------
+// Why.  combine_or / combine_and[_sub] over MANY GAP-only operands (BASELINE configs[4]: 4096 sparse vectors; the all-GAP
+// 256-way AND) read every operand's block of a column from that operand's own slab: thousands of streams visited in
+// pieces of ~60 B .. 1.5 KiB.  Round 2 measured the floor of that access pattern with the run application compiled out
+// (3.78 of 4.14 ms): the layout, not the arithmetic, is the bound.  Vectors are immutable and
+// device-resident, so the library owns the layout: the GAP blocks of an operand SET are transposed ONCE into
+// column-major order and every later aggregation over that set streams one contiguous region per block column.
+//
+// What is stored.  A block column of the collection is a flat bag of INTERVALS, one 32-bit entry per run:
+// start | end << 16 (both inclusive, 0..65535).  Which runs depends on the role of the set:
+//   polarity 1 (OR list, SUB list): the 1-runs of every GAP operand.  OR = union of the bag.
+//   polarity 0 (AND list):          the 0-runs.  AND_i x_i = NOT OR_i NOT x_i: the AND of the operands is the complement of
+//                                   the union of their 0-runs (the reference clears the 0-runs one operand at a time:
+//                                   gap_and_to_bitset, src/bmfunc.h:4847; process_gap_blocks_and, src/bmaggregator.h:1820).
+// Operand identity is gone -- neither union needs it -- so a column is one sequential stream whatever the operand count,
+// and a NULL / FULL operand of a column is a per-column flag (any NULL ends an AND column, src/bmaggregator.h:2327;
+// any FULL saturates an OR column, :2300; FULL operands of an AND list are ignored, :2346).
+// The same information as the GAP blocks themselves (Appendix B: run k covers e[k-1]+1 .. e[k]): 4 B per run of the wanted
+// polarity ~= 2 x len bytes per block, i.e. the algorithmic bytes of SURVEY section 8(d) minus headers.
+//
+// How a bag is applied (coll_apply_run): every entry is independent.  A run inside one 32-bit word is ONE ds_or.  A longer
+// run ORs its two edge words and covers the words in between through a word-granular counting trick: +1 at the first
+// interior word, -1 behind the last one in a 2048-entry array D; one prefix sum over D at the end of the column marks the
+// covered words (coll_fold).  At most four LDS atomics per run whatever its length, no per-operand loop, no decode.
+// LDS per workgroup: bitmap 8 KiB + D 8 KiB (+ 8 KiB for the SUB bag): several workgroups per CU overlap their phases.
+// ---------------------------------------------------------------------------
+
+#define COLL_FLAG_FULL 1u       // some operand of the column is a FULL block
+#define COLL_FLAG_NULL 2u       // some operand of the column is NULL (or shorter than the column index)
+#define COLL_FLAG_BIT  4u       // some operand holds a bit-block here: the packed path cannot be used (host falls back)
+#define COLL_NGAP(f) ((f) >> 8) // GAP operands of the column
+
+typedef const __attribute__((address_space(1))) u64* coll_gc64;
+typedef const __attribute__((address_space(1))) u32* coll_gc32;
+
+// runs of the wanted polarity in a GAP block with GMETA m = len << 1 | start bit
+__device__ __forceinline__ u32 coll_runs_of(u32 meta, u32 polarity)
+{
+    u32 len = meta >> 1, s = meta & 1u;
+    u32 ones = s ? (len + 1u) >> 1 : len >> 1;
+    return polarity ? ones : len - ones;
+}
+
+// pass 1: one thread per block column walks the operand list (lanes = consecutive columns: every read of an operand's
+// descriptor table is coalesced): pre[i][c] = entries of column c that precede operand i, cnt[c] = entries of the column,
+// flags[c] = FULL / NULL / bit-block marks | GAP operand count << 8
+__global__ __launch_bounds__(256)
+void k_coll_count(const u64* const* __restrict__ descs, const u32* __restrict__ nblk, u32 n, u32 ncols, u32 polarity,
+                  u32* __restrict__ pre, u32* __restrict__ cnt, u32* __restrict__ flags)
+{
+    u32 c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ncols) return;
+    u32 run = 0, fl = 0, ngap = 0;
+    for (u32 i = 0; i < n; ++i) {
+        u32 nb = nblk[i];
+        u64 d = c < nb ? descs[i][c] : 0ull;                    // beyond the operand's end: NULL
+        u32 k = DESC_K(d);
+        pre[(size_t)i * ncols + c] = run;
+        if (k == K_GAP) { run += coll_runs_of(GMETA(d), polarity); ++ngap; }
+        else if (k == K_FULL) fl |= COLL_FLAG_FULL;
+        else if (k == K_NULL) fl |= COLL_FLAG_NULL;
+        else fl |= COLL_FLAG_BIT;
+    }
+    cnt[c] = run;
+    flags[c] = fl | (ngap << 8);
+}
+
+// pass 2: column offsets (in entries; every column starts on a 16-byte boundary): exclusive scan of cnt rounded up to 4.
+// Single workgroup; off[ncols] = total.
+__global__ __launch_bounds__(1024)
+void k_coll_offsets(const u32* __restrict__ cnt, u32 ncols, u64* __restrict__ off)
+{
+    __shared__ u64 sm[16];
+    u32 tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
+    u64 carry = 0;
+    for (u32 base = 0; base < ncols; base += 1024u) {
+        u32 c = base + tid;
+        u32 v = c < ncols ? (cnt[c] + 3u) & ~3u : 0u;
+        u32 incl = wave_scan_incl(v, lane);
+        if (lane == 63) sm[w] = incl;
+        __syncthreads();
+        u64 offw = 0, tot = 0;
+#pragma unroll
+        for (u32 i = 0; i < 16; ++i) { u64 a = sm[i]; if (i < w) offw += a; tot += a; }
+        __syncthreads();
+        if (c < ncols) off[c] = carry + offw + (u64)(incl - v);
+        carry += tot;
+    }
+    if (tid == 0) off[ncols] = carry;
+}
+
+// pass 3: L lanes per (operand, column) write the block's runs of the wanted polarity behind the entries of the operands
+// before it.  grid.x = operand (adjacent workgroups fill adjacent pieces of the same columns), grid.y = tile of 256 / L columns
+template <int L>
+__global__ __launch_bounds__(256)
+void k_coll_scatter(const u64* const* __restrict__ descs, const u32* __restrict__ nblk, u32 ncols, u32 polarity,
+                    const u32* __restrict__ pre, const u64* __restrict__ off, u32* __restrict__ runs)
+{
+    const u32 i = blockIdx.x;
+    const u32 t = threadIdx.x % L;
+    const u32 c = blockIdx.y * (256u / L) + threadIdx.x / L;
+    if (c >= ncols || c >= nblk[i]) return;
+    u64 d = descs[i][c];
+    if (DESC_K(d) != K_GAP) return;
+    u32 meta = GMETA(d), len = meta >> 1, s = meta & 1u;
+    u32 m_cnt = coll_runs_of(meta, polarity);
+    gcptr16 g = as_gc16(DESC_P(d));
+    u32* out = runs + off[c] + pre[(size_t)i * ncols + c];
+    // run k (1-based) has the value s ^ ((k - 1) & 1) and covers e[k-1]+1 .. e[k] (e[0] = -1; word k of the block = e[k])
+    u32 k0 = (s == polarity) ? 1u : 2u;
+    for (u32 m = t; m < m_cnt; m += L) {
+        u32 k = k0 + 2u * m;
+        u32 start = k == 1u ? 0u : (u32)g[k - 1u] + 1u;
+        u32 end = (u32)g[k <= len ? k : len];
+        out[m] = start | (end << 16);
+    }
+}
+
+// ---- applying a bag ----
+__device__ __forceinline__ void coll_apply_run(u32 r, bool valid, u32* U, int* D, u32& any_long)
+{
+    u32 s = r & 0xFFFFu, e = r >> 16;
+    u32 ws = s >> 5, we = e >> 5;
+    u32 lo = ~0u << (s & 31u), hi = ~0u >> (31u - (e & 31u));
+    bool same = ws == we;
+    if (valid) atomicOr(&U[ws], same ? (lo & hi) : lo);
+    if (valid && !same) {
+        atomicOr(&U[we], hi);
+        if (we - ws > 1u) { atomicAdd(&D[ws + 1u], 1); atomicSub(&D[we], 1); any_long = 1u; }
+    }
+}
+
+// all entries [0, cnt) of one column, 16 bytes per lane per load, four loads in flight per lane; returns (per thread)
+// whether it produced an interior-word span
+template <int WG>
+__device__ __forceinline__ u32 coll_apply_bag(const u32* __restrict__ runs, u64 off, u32 cnt, u32* U, int* D, u32 tid)
+{
+    gcptr4 p = as_gc4(runs + off);
+    const u32 nq = (cnt + 3u) >> 2;
+    u32 any_long = 0u;
+    for (u32 q0 = tid; q0 < nq; q0 += 4u * WG) {
+        u32x4 v[4];
+#pragma unroll
+        for (u32 j = 0; j < 4; ++j) { u32 q = q0 + j * WG; v[j] = __builtin_nontemporal_load(&p[q < nq ? q : nq - 1u]); }
+#pragma unroll
+        for (u32 j = 0; j < 4; ++j) {
+            u32 q = q0 + j * WG;
+            bool in = q < nq;
+            u32 e0 = q * 4u;
+            coll_apply_run(v[j].x, in && e0 < cnt, U, D, any_long);
+            coll_apply_run(v[j].y, in && e0 + 1u < cnt, U, D, any_long);
+            coll_apply_run(v[j].z, in && e0 + 2u < cnt, U, D, any_long);
+            coll_apply_run(v[j].w, in && e0 + 3u < cnt, U, D, any_long);
+        }
+    }
+    return any_long;
+}
+
+// interior words covered by a long run: prefix sum of D over the 2048 words; covered words become all ones.  D is left
+// zeroed.  Called by the whole workgroup between barriers; sm: WG / 64 ints.
+template <int WG>
+__device__ __forceinline__ void coll_fold(u32* U, int* D, int* sm, u32 tid)
+{
+    constexpr u32 W = 2048u / WG;                     // words per thread (8 for 256 threads)
+    const u32 lane = tid & 63u, wave = tid >> 6;
+    int d[W]; int sum = 0;
+#pragma unroll
+    for (u32 k = 0; k < W; k += 4u) {
+        u32x4 t = *reinterpret_cast<u32x4*>(&D[tid * W + k]);
+        d[k] = (int)t.x; d[k + 1] = (int)t.y; d[k + 2] = (int)t.z; d[k + 3] = (int)t.w;
+        *reinterpret_cast<u32x4*>(&D[tid * W + k]) = (u32x4)(0u);
+    }
+#pragma unroll
+    for (u32 k = 0; k < W; ++k) sum += d[k];
+    int incl = (int)wave_scan_incl((u32)sum, lane);
+    if (lane == 63) sm[wave] = incl;
+    __syncthreads();
+    int running = incl - sum;
+#pragma unroll
+    for (u32 i = 0; i < WG / 64u; ++i) if (i < wave) running += sm[i];
+#pragma unroll
+    for (u32 k = 0; k < W; ++k) { running += d[k]; if (running > 0) U[tid * W + k] = ~0u; }
+    __syncthreads();
+}
+
+enum { COLL_OR = 0, COLL_AND_STORE = 1, COLL_AND_COUNT = 2 };
+
+// One workgroup per block column.
+//   COLL_OR         result = union of the bag (polarity 1), stored with the aggregator's optimisation mode
+//                   (combine_or, src/bmaggregator.h:1101,1658)
+//   COLL_AND_STORE  result = NOT union(AND bag, polarity 0) AND NOT union(SUB bag, polarity 1), stored with opt_compress
+//                   (combine_and_sub, :1162,1210)
+//   COLL_AND_COUNT  the same, counted (counts-only pipeline of one arg-group, :1292-1399)
+template <int MODE, int WG>
+__global__ __launch_bounds__(WG)
+void k_coll_apply(const u32* __restrict__ runs, const u64* __restrict__ off, const u32* __restrict__ cnt,
+                  const u32* __restrict__ flags, u32 ncols_a,
+                  const u32* __restrict__ s_runs, const u64* __restrict__ s_off, const u32* __restrict__ s_cnt,
+                  const u32* __restrict__ s_flags, u32 ncols_s,
+                  u32 col_base, u32 ncols, int opt_compress, u64* __restrict__ counts,
+                  uint4* __restrict__ slab, u64* __restrict__ desc, BlockStat* __restrict__ st, u32 hint_from, u32 hint_to)
+{
+    __shared__ __attribute__((aligned(16))) u32 U[2048];
+    __shared__ __attribute__((aligned(16))) int D[2048];
+    __shared__ int sm[WG / 64];
+    __shared__ u32 s_long;
+    __shared__ u32 part[WG / 64];
+    const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const u32 c = col_base + blockIdx.x;
+    if (c >= ncols) return;
+    if (MODE != COLL_OR && (c < hint_from || c >= hint_to)) {
+        if (MODE == COLL_AND_STORE && wave == 0) store_trivial(K_NULL, c, desc, st, lane);
+        return;
+    }
+    const u32 fl = c < ncols_a ? uniform32(flags[c]) : (MODE == COLL_OR ? 0u : COLL_FLAG_NULL);
+    const u32 n_ent = c < ncols_a ? uniform32(cnt[c]) : 0u;
+    if (MODE == COLL_OR) {
+        if (fl & COLL_FLAG_FULL) { if (wave == 0) store_trivial(K_FULL, c, desc, st, lane); return; }
+        if (COLL_NGAP(fl) == 0u) { if (wave == 0) store_trivial(K_NULL, c, desc, st, lane); return; }
+    } else {
+        const u32 sfl = (s_flags && c < ncols_s) ? uniform32(s_flags[c]) : 0u;
+        // any NULL operand in the AND list, or a FULL one in the SUB list: the column is empty (:2327, :1746)
+        if ((fl & COLL_FLAG_NULL) || (sfl & COLL_FLAG_FULL)) {
+            if (MODE == COLL_AND_STORE && wave == 0) store_trivial(K_NULL, c, desc, st, lane);
+            return;
+        }
+    }
+    constexpr u32 W = 2048u / WG;
+#pragma unroll
+    for (u32 k = 0; k < W; k += 4u) {
+        *reinterpret_cast<u32x4*>(&U[tid * W + k]) = (u32x4)(0u);
+        *reinterpret_cast<u32x4*>(&D[tid * W + k]) = (u32x4)(0u);
+    }
+    if (tid == 0) s_long = 0u;
+    __syncthreads();
+    u32 al = coll_apply_bag<WG>(runs, uniform64(off[c < ncols_a ? c : 0u]), n_ent, U, D, tid);
+    if (al) s_long = 1u;
+    __syncthreads();
+    if (s_long) coll_fold<WG>(U, D, sm, tid);                 // (block-uniform; the barriers inside are reached by every thread)
+    if (MODE == COLL_OR) {
+        if (wave == 0) {
+            Blk b; blk_from_lds(b, U, lane);
+            store_result_mode(b, c, opt_compress ? ST_OPT : ST_FORCE_BIT, slab, desc, st, lane);
+        }
+        return;
+    }
+    // AND: the accumulator is the complement of the union of the 0-runs ...
+    u32 acc[W];
+#pragma unroll
+    for (u32 k = 0; k < W; ++k) acc[k] = ~U[tid * W + k];
+    // ... minus the union of the SUB bag's 1-runs
+    const u32 s_ent = (s_cnt && c < ncols_s) ? uniform32(s_cnt[c]) : 0u;
+    if (s_ent) {
+        __syncthreads();
+#pragma unroll
+        for (u32 k = 0; k < W; k += 4u) *reinterpret_cast<u32x4*>(&U[tid * W + k]) = (u32x4)(0u);
+        if (tid == 0) s_long = 0u;
+        __syncthreads();
+        u32 sl = coll_apply_bag<WG>(s_runs, uniform64(s_off[c]), s_ent, U, D, tid);
+        if (sl) s_long = 1u;
+        __syncthreads();
+        if (s_long) coll_fold<WG>(U, D, sm, tid);
+#pragma unroll
+        for (u32 k = 0; k < W; ++k) acc[k] &= ~U[tid * W + k];
+    }
+    if (MODE == COLL_AND_COUNT) {
+        u32 pc = 0;
+#pragma unroll
+        for (u32 k = 0; k < W; ++k) pc += (u32)__popc(acc[k]);
+        pc = wave_sum(pc);
+        if (lane == 0) part[wave] = pc;
+        __syncthreads();
+        if (tid == 0) {
+            u32 t = 0;
+#pragma unroll
+            for (u32 i = 0; i < WG / 64u; ++i) t += part[i];
+            if (t) atomicAdd(reinterpret_cast<unsigned long long*>(&counts[0]), (unsigned long long)t);
+        }
+        return;
+    }
+    __syncthreads();
+#pragma unroll
+    for (u32 k = 0; k < W; ++k) U[tid * W + k] = acc[k];
+    __syncthreads();
+    if (wave == 0) { Blk b; blk_from_lds(b, U, lane); store_result(b, c, 1, slab, desc, st, lane); }
+}

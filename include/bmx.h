@@ -77,7 +77,7 @@ int bmx_ctx_synchronize(bmx_ctx* ctx);
 /* launch-shape knobs of the counts pipeline (results never depend on them; 0 / -1 = automatic):
  * "pipe_rows" 0|8|4|2|1 (KiB of a block per work item), "pipe_unroll" 0|1|2|4|8|16, "pipe_nt" 0|1,
  * "pipe_wg" 0|64..1024 (multiples of 64; the default build carries 256, 384, 512, 640, 768), "pipe_staged" -1|0|1, "pipe_slots" 8|16,
- * "pipe_window" -1|0|N (block columns per launch), "pipe_split" -1|0|1, "direct_cols" 0..N (one-launch aggregation over small collections), "ff_window" -1|0|N (first launch window of find_first_and_sub), "pair_stream" -1|0|2|4|8 and "pair_wgs" 1..8 (shape of the streaming pairwise count kernel), "gap_count" -1|0|1 (counting formulation for GAP-only counts pipelines), "range_halves" 0|1 (comparison search in half-block passes), "or_tile" 0..3, "xcd_swizzle" 0|1.  Environment twins (BMX_PIPE_ROWS, ...) pass the same checks. */
+ * "pipe_window" -1|0|N (block columns per launch), "pipe_split" -1|0|1, "direct_cols" 0..N (one-launch aggregation over small collections), "ff_window" -1|0|N (first launch window of find_first_and_sub), "pair_stream" -1|0|2|4|8 and "pair_wgs" 1..8 (shape of the streaming pairwise count kernel), "gap_count" -1|0|1 (counting formulation for GAP-only counts pipelines), "range_halves" 0|1 (comparison search in half-block passes), "rs_unroll" 0|1|2|4 (rank / select queries in flight per group of 8 lanes), "gap_pack" -1|0|1 (packed collections, see below), "or_tile" 0..3, "xcd_swizzle" 0|1.  Environment twins (BMX_PIPE_ROWS, ...) pass the same checks. */
 int bmx_ctx_set_tuning(bmx_ctx* ctx, const char* key, int value);
 /* The context keeps freed device blocks in a size-keyed cache (results of same-shaped
  * operations re-use them instead of paying hipMalloc/hipFree, which synchronises the
@@ -196,6 +196,21 @@ int bmx_slice_compare(bmx_ctx* ctx, const bmx_vec* const* slices, size_t nslices
  * (bit-matrix transposition + hash lookup, bmx_kernels4.h).  nslices <= 32 (else BMX_ERR_RANGE: use the pipeline form). */
 int bmx_slice_eq_counts(bmx_ctx* ctx, const bmx_vec* const* slices, size_t nslices, const uint64_t* values, size_t n,
                         uint64_t size, const bmx_vec* not_null, uint64_t* counts);
+
+/* ---- packed collections: the layout the engine keeps for operand SETS it sees again (bmx_kernels6.h) ----
+ * Vectors are immutable and device-resident, so the library owns their layout.  combine_or / combine_and / combine_and_sub
+ * / a one-group counts pipeline over >= 64 operands made of GAP (+ NULL / FULL) blocks read thousands of separate slabs in
+ * small pieces (src/bmaggregator.h:1808-1924 walks them operand by operand); from the SECOND time an operand set is used
+ * the engine transposes its GAP blocks once into column-major order (one contiguous run list per block column, cached by
+ * the operand set, dropped when one of its vectors is freed, LRU under BMX_PACK_MAX_MB) and streams that instead.
+ * Results are identical either way.  Tuning key "gap_pack": -1 = from the second use (default), 0 = never, 1 = first use.
+ *   bmx_collection_prepare  builds the collection of an operand list now (role: how the list will be used)
+ *   bmx_ctx_pack_stats      collections held, their bytes, device time of the last build */
+#define BMX_ROLE_AND 0
+#define BMX_ROLE_OR  1
+#define BMX_ROLE_SUB 2
+int bmx_collection_prepare(bmx_ctx* ctx, const bmx_vec* const* vecs, size_t n, int role);
+int bmx_ctx_pack_stats(const bmx_ctx* ctx, uint32_t* n_collections, uint64_t* bytes, float* last_build_ms);
 
 /* aggregator::pipeline<agg_opt_only_counts>  src/bmaggregator.h:62-103,222-341:
  * arg-groups are given as concatenated operand lists, and_n[g] / sub_n[g] per

@@ -289,7 +289,8 @@ def test_byte_weighted_shard_borders(ctx, port):
     f, pos = gv[0].select(np.array([1, 5, pv[0].count()], np.uint64), rs)
     epos, ef = port.rs_build(pv[0]).select(np.array([1, 5, pv[0].count()], np.uint64))
     assert f.all() and (pos == epos).all()
-    del pipe, rs, gv, t, o
+    del pipe, rs, gv, t, o, g, ag
+    import gc; gc.collect()
     grp.set_partition(nblk, [0, 16, 32, 48, 64])          # no live vectors: allowed again
     grp.close()
 

@@ -1192,3 +1192,168 @@ def test_range_hint(ctx, port, agg_path):
                 k = r.block_table()[0]
                 assert not k[:2].any() and not k[5:].any()
         agg.reset_range_hint()
+
+
+@pytest.mark.parametrize("unroll", [1, 2, 4])
+def test_rank_select_queries_in_flight_forms(port, unroll):
+    """k_rank_q / k_select_q (Q queries per group of 8 lanes in flight) and the one-query kernels must give the oracle's
+    answers on every block kind -- NULL, FULL, bit, sparse and dense GAP -- incl. dead queries (rank 0, rank > count,
+    position past the end) and batches that do not fill the last round"""
+    c = bm.context(0)
+    c.set_tuning("rs_unroll", unroll)
+    rng = np.random.default_rng(1234 + unroll)
+    nblk = 23
+    nbits = nblk * 65536 - 777
+    p = port.new(nbits)
+    words = np.zeros(nblk * 2048, np.uint32)
+    for nb in range(nblk):
+        kind = nb % 6
+        if kind == 0: continue                                            # NULL
+        lo = nb * 2048
+        if kind == 1: words[lo:lo + 2048] = 0xFFFFFFFF                   # FULL
+        elif kind == 2: words[lo:lo + 2048] = rng.integers(0, 1 << 32, 2048, dtype=np.uint64).astype(np.uint32)   # bit
+        elif kind == 3:                                                   # sparse GAP
+            for b in rng.integers(0, 65536, 40): words[lo + (b >> 5)] |= np.uint32(1 << (b & 31))
+        elif kind == 4:                                                   # long runs (GAP with few, wide runs)
+            words[lo + 100:lo + 900] = 0xFFFFFFFF; words[lo + 1500:lo + 1600] = 0xFFFFFFFF
+        else:                                                             # many short runs: still GAP (< 1276 runs)
+            for b in rng.integers(0, 65536, 500): words[lo + (b >> 5)] |= np.uint32(1 << (b & 31))
+    last_bits = nbits - (nblk - 1) * 65536
+    tail = np.unpackbits(words[(nblk - 1) * 2048:].view(np.uint8), bitorder="little"); tail[last_bits:] = 0
+    words[(nblk - 1) * 2048:] = np.packbits(tail, bitorder="little").view(np.uint32)
+    p = port.import_words(words, True, nbits)
+    assert set(p.flatten()[0].tolist()) == {0, 1, 2, 3}
+    v = bm.bvector.from_block_table(c, nbits, *p.flatten())
+    rs, prs = v.build_rs_index(), port.rs_build(p)
+    cnt = p.count()
+    for nq in (1, 7, 8, 9, 63, 1000, 4097):
+        q = np.concatenate([rng.integers(0, nbits, size=nq).astype(np.uint64), np.array([0, nbits - 1, nbits, nbits + 70000, 65535, 65536], np.uint64)])
+        assert (v.rank(q, rs) == prs.rank(q)).all(), (unroll, nq)
+        r = np.concatenate([rng.integers(1, cnt + 1, size=nq).astype(np.uint64), np.array([1, cnt, 0, cnt + 1, 2 ** 40], np.uint64)])
+        found, pos = v.select(r, rs)
+        ppos, pfound = prs.select(r)
+        assert (found == pfound).all() and (pos[found] == ppos[pfound]).all(), (unroll, nq)
+        assert (pos[~found] == 0).all()
+    del rs, v
+    c.close()
+
+
+def _sparse_collection(port, rng, nvec, nbits, dq, long_runs=False, ragged=False, specials=True):
+    """GAP-only operands (no bit-blocks): sparse noise OR a shared component (so that ANDs survive), optionally wide
+    1-runs (multi-word intervals), NULL / FULL blocks and operands shorter than the others"""
+    nblk = (nbits + 65535) // 65536
+    words = []
+    common = port.gen_words(4242, 0xFFFFFFFF, max(dq // 2, 3), nbits)
+    for v in range(nvec):
+        nb = nbits
+        if ragged and v % 7 == 3:
+            nb = max(65536 - 99, nbits - (1 + v % 3) * 65536)
+        w = port.gen_words(4242, v, dq, nb) | common[: ((nb + 63) // 64) * 2]
+        nw = (nb + 31) // 32
+        if nb % 32: w[nw - 1] &= np.uint32((1 << (nb % 32)) - 1)
+        w[nw:] = 0
+        if long_runs:
+            for _ in range(6):
+                a = int(rng.integers(0, nw - 40)); l = int(rng.integers(1, 40))
+                w[a:a + l] = 0xFFFFFFFF
+        if specials:
+            for b in range(w.size // 2048):
+                r = rng.integers(0, 30)
+                if r == 0 and v % 11 == 5: w[b * 2048:(b + 1) * 2048] = 0                      # NULL block
+                elif r == 1 and (b + 1) * 65536 <= nb: w[b * 2048:(b + 1) * 2048] = 0xFFFFFFFF   # FULL block
+        words.append(w)
+    return words
+
+
+@pytest.mark.parametrize("dq,nvec,long_runs", [(13, 200, False), (150, 96, True), (400, 64, True), (30, 300, False)])
+def test_packed_gap_collections(port, dq, nvec, long_runs):
+    """combine_or / combine_and / combine_and_sub / one-group counts pipelines over GAP-only operand sets through the
+    column-major packed collection (bmx_kernels6.h, gap_pack 1) must equal the oracle bit for bit AND block kind for
+    block kind, and equal what the descriptor-table kernels (gap_pack 0) produce: NULL / FULL operands, operands of
+    different lengths, single-bit runs, runs spanning many words, SUB lists of any size"""
+    rng = np.random.default_rng(dq * 1000 + nvec)
+    nbits = 6 * 65536 + 1234
+    words = _sparse_collection(port, rng, nvec, nbits, dq, long_runs=long_runs, ragged=True)
+    pv = [port.import_words(w, True, w.size * 32) for w in words]
+    assert all(p.flatten()[0].tolist().count(2) == 0 for p in pv), "operands must be free of bit-blocks"
+    nwb = 7 * 2048
+    results = {}
+    for mode in (1, 0):
+        c = bm.context(0)
+        c.set_tuning("gap_pack", mode)
+        c.set_tuning("direct_cols", 0); c.set_tuning("pipe_split", 0)   # (few columns: keep the one-launch small-collection kernels out of the way)
+        gv = [bm.bit_import_u32(c, w, True) for w in words]
+        agg = bm.aggregator(c)
+        out = []
+        for opt in (False, True):
+            agg.set_optimization(opt)
+            o = agg.combine_or(gv)
+            e = port.agg_or(pv, opt)
+            assert (o.to_words(nwb) == e.to_words(nwb)).all(), (mode, opt)
+            assert o.block_table()[0].tolist() == (e.flatten()[0].tolist() + [0] * 8)[:o.info()["nblocks"]], (mode, opt)
+            out.append(o.block_table()[0].tolist())
+        agg.set_optimization(False)
+        half = nvec // 2
+        for a, s in [(list(range(nvec)), []), (list(range(half)), list(range(half, nvec))), (list(range(0, nvec, 2)), [1, 3]),
+                     (list(range(nvec - 64, nvec)), [0]), (list(range(64)), list(range(64, nvec)))]:
+            t, any_ = agg.combine_and_sub([gv[i] for i in a], [gv[i] for i in s])
+            e = port.agg_and_sub([pv[i] for i in a], [pv[i] for i in s])
+            assert (t.to_words(nwb) == e.to_words(nwb)).all(), (mode, len(a), len(s))
+            assert t.block_table()[0].tolist() == (e.flatten()[0].tolist() + [0] * 8)[:t.info()["nblocks"]], (mode, len(a), len(s))
+            assert any_ == (e.count() > 0)
+            pipe = bm.aggregator.pipeline(c)
+            ag = pipe.add()
+            for i in a: ag.add(gv[i], 0)
+            for i in s: ag.add(gv[i], 1)
+            pipe.complete()
+            assert int(agg.combine_and_sub(pipe)[0]) == e.count(), (mode, len(a), len(s))
+            assert int(agg._run_pipeline(pipe, 1, 4)[0]) == int(port.pipeline_counts([([pv[i] for i in a], [pv[i] for i in s])], 1, 4)[0])
+            out.append(t.block_table()[0].tolist())
+        st = c.pack_stats()
+        assert (st["collections"] > 0) == (mode == 1), st
+        results[mode] = out
+        if mode == 1:
+            # a freed operand takes the collections that hold its runs with it
+            before = c.pack_stats()["collections"]
+            del gv[0], o, t, pipe
+            import gc; gc.collect()
+            assert c.pack_stats()["collections"] < before
+        del gv
+        c.close()
+    assert results[0] == results[1]
+
+
+def test_packed_collection_policy_and_prepare(port):
+    """gap_pack -1 (default): the first use of an operand set runs the descriptor-table kernels, the second builds the
+    collection; bmx_collection_prepare builds at once; results never depend on which path ran"""
+    rng = np.random.default_rng(77)
+    nbits = 4 * 65536
+    words = _sparse_collection(port, rng, 80, nbits, 40, specials=False)
+    pv = [port.import_words(w, True, nbits) for w in words]
+    c = bm.context(0)
+    c.set_tuning("direct_cols", 0); c.set_tuning("pipe_split", 0)
+    gv = [bm.bit_import_u32(c, w, True) for w in words]
+    agg = bm.aggregator(c)
+    e = port.agg_or(pv)
+    assert c.pack_stats()["collections"] == 0
+    o1 = agg.combine_or(gv)
+    assert c.pack_stats()["collections"] == 0
+    o2 = agg.combine_or(gv)
+    st = c.pack_stats()
+    assert st["collections"] == 1 and st["bytes"] > 0 and st["last_build_ms"] > 0
+    o3 = agg.combine_or(gv)
+    assert c.pack_stats()["collections"] == 1
+    for o in (o1, o2, o3):
+        assert (o.to_words() == e.to_words(o.info()["nblocks"] * 2048)).all()
+    c.collection_prepare(gv, bm.ROLE_AND)
+    assert c.pack_stats()["collections"] == 2
+    t, _ = agg.combine_and_sub(gv, [])
+    assert c.pack_stats()["collections"] == 2
+    assert (t.to_words() == port.agg_and_sub(pv, []).to_words(t.info()["nblocks"] * 2048)).all()
+    with pytest.raises(bm.BmxError):
+        c.collection_prepare(gv[:10], bm.ROLE_OR)          # too few operands for a collection
+    dense = bm.bit_import_u32(c, port.gen_words(1, 1, 30000, nbits), True)
+    with pytest.raises(bm.BmxError):
+        c.collection_prepare(gv + [dense], bm.ROLE_OR)     # bit-blocks cannot be packed
+    del gv, o1, o2, o3, t, dense
+    c.close()
