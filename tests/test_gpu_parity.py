@@ -1194,13 +1194,13 @@ def test_range_hint(ctx, port, agg_path):
         agg.reset_range_hint()
 
 
-@pytest.mark.parametrize("unroll", [1, 2, 4])
+@pytest.mark.parametrize("unroll", [8, 2, 4])
 def test_rank_select_queries_in_flight_forms(port, unroll):
-    """k_rank_q / k_select_q (Q queries per group of 8 lanes in flight) and the one-query kernels must give the oracle's
+    """k_rank_l<2|4> (fewer lanes per query = more queries in flight) and the 8-lane kernels must give the oracle's
     answers on every block kind -- NULL, FULL, bit, sparse and dense GAP -- incl. dead queries (rank 0, rank > count,
     position past the end) and batches that do not fill the last round"""
     c = bm.context(0)
-    c.set_tuning("rs_unroll", unroll)
+    c.set_tuning("rs_lanes", unroll)
     rng = np.random.default_rng(1234 + unroll)
     nblk = 23
     nbits = nblk * 65536 - 777
@@ -1315,7 +1315,11 @@ def test_packed_gap_collections(port, dq, nvec, long_runs):
         if mode == 1:
             # a freed operand takes the collections that hold its runs with it
             before = c.pack_stats()["collections"]
-            del gv[0], o, t, pipe
+            del o, t, pipe, ag
+            agg.reset()
+            g0 = gv.pop(0)
+            assert c.pack_stats()["collections"] == before
+            del g0
             import gc; gc.collect()
             assert c.pack_stats()["collections"] < before
         del gv
