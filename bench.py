@@ -755,7 +755,7 @@ def run_pairwise(args, env, dq=None, quick=False):
     pair_bytes = []
     for a, b in zip(va, vb):
         ia, ib = a.info(), b.info()
-        pair_bytes.append((ia["counts"][2] + ib["counts"][2]) * 8192 + 2 * (ia["gap_words"] + ib["gap_words"]))
+        pair_bytes.append(a.operand_bytes() + b.operand_bytes())            # 8,192 B per bit-block + 2 x (len + 1) per GAP block
     dcnt = torch.zeros(4 * npairs, dtype=torch.int64, device="cuda")
     per_op = {}
     for op, name in enumerate(["and", "or", "xor", "sub"]):
@@ -964,7 +964,7 @@ def run_or_sharded(args, env, quick=False):
     t0 = time.perf_counter()
     vecs = [bm.bvector.generate(ctx, SEED, 10000 + i, dq, nbits, block_range=(lo, hi) if world > 1 else None) for i in range(nvec)]
     ctx.synchronize(); t_build = time.perf_counter() - t0
-    gap_bytes = sum(v.info()["gap_words"] for v in vecs) * 2
+    gap_bytes = sum(v.operand_bytes() for v in vecs)                      # exact: 2 x (len + 1) per GAP block (no slab padding)
     agg = bm.aggregator(ctx)
     cnt = torch.zeros(1, dtype=torch.int64, device="cpu" if env.one_dev else "cuda")
     last = []

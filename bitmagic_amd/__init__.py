@@ -157,6 +157,12 @@ class bvector:
         return {"nbits": nbits.value, "nblocks": nblocks.value, "counts": list(counts),
                 "bit_slab_blocks": slab.value, "gap_words": gw.value}
 
+    def operand_bytes(self) -> int:
+        """algorithmic bytes of this operand: 8,192 B per bit-block, 2 x (len + 1) B per GAP block"""
+        b = C.c_uint64()
+        check(lib().bmx_vec_operand_bytes(self.ctx._h, self._h, C.byref(b)))
+        return b.value
+
     def size(self) -> int:
         return self.info()["nbits"]
 

@@ -59,6 +59,7 @@ def lib() -> C.CDLL:
         "bmx_vec_generate_shard": (i32, [vp, u64, u32, i32, u32, u64, u32, u32, i32, P(vp)]),
         "bmx_vec_free": (i32, [vp, vp]),
         "bmx_vec_info": (i32, [vp, P(u64), P(u32), P(u32), P(u32), P(u64)]),
+        "bmx_vec_operand_bytes": (i32, [vp, vp, P(u64)]),
         "bmx_vec_download": (i32, [vp, vp, vp, vp, vp, vp]),
         "bmx_vec_to_words": (i32, [vp, vp, vp, u64]),
         "bmx_count": (i32, [vp, vp, P(u64)]),

@@ -848,6 +848,21 @@ int bmx_vec_info(const bmx_vec* v, uint64_t* nbits, uint32_t* nblocks, uint32_t 
     return BMX_OK;
 }
 
+int bmx_vec_operand_bytes(bmx_ctx* ctx, const bmx_vec* v, uint64_t* bytes)
+{
+    ARGCHK(ctx && v && v->ctx == ctx && bytes);
+    int rc = set_dev(ctx); if (rc) return rc;
+    *bytes = 0;
+    if (!v->nblocks) return BMX_OK;
+    HIPCHK(hipMemsetAsync(ctx->d_small, 0, 8, ctx->stream));
+    hipLaunchKernelGGL(k_vec_alg_bytes, dim3((v->nblocks + 255) / 256), dim3(256), 0, ctx->stream, (const u64*)v->d_desc, v->nblocks, ctx->d_small);
+    KCHK();
+    HIPCHK(hipMemcpyAsync(ctx->h_small, ctx->d_small, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    *bytes = ctx->h_small[0];
+    return BMX_OK;
+}
+
 int bmx_vec_download(bmx_ctx* ctx, const bmx_vec* v, uint8_t* kinds, uint32_t* offs,
                      uint32_t* bit_slab, uint16_t* gap_slab)
 {
@@ -2198,7 +2213,7 @@ int bmx_rs_export(bmx_ctx* ctx, const bmx_rs* rs, uint32_t* bcount, uint64_t* su
     return BMX_OK;
 }
 
-#define RS_LANES_DEFAULT 2
+#define RS_LANES_DEFAULT 4
 static u32 query_grid(size_t q) { return (u32)std::min<size_t>((q * 8 + 255) / 256, 256u * 16u); }
 
 int bmx_rank_batch_dev(bmx_ctx* ctx, const bmx_vec* v, const bmx_rs* rs, const uint64_t* d_n, size_t q, uint64_t* d_out)

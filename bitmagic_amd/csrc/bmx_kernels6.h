@@ -187,6 +187,21 @@ __device__ __forceinline__ void coll_fold(u32* U, int* D, int* sm, u32 tid)
     __syncthreads();
 }
 
+// algorithmic operand bytes of a vector: 8,192 B per bit-block, 2 x (len + 1) B per GAP block
+__global__ __launch_bounds__(256)
+void k_vec_alg_bytes(const u64* __restrict__ desc, u32 nblocks, u64* __restrict__ out)
+{
+    u32 nb = blockIdx.x * blockDim.x + threadIdx.x;
+    u32 b = 0;
+    if (nb < nblocks) {
+        u64 d = desc[nb];
+        u32 k = DESC_K(d);
+        b = k == K_BIT ? 8192u : (k == K_GAP ? 2u * ((GMETA(d) >> 1) + 1u) : 0u);
+    }
+    b = wave_sum(b);
+    if ((threadIdx.x & 63u) == 0 && b) atomicAdd(reinterpret_cast<unsigned long long*>(out), (unsigned long long)b);
+}
+
 enum { COLL_OR = 0, COLL_AND_STORE = 1, COLL_AND_COUNT = 2 };
 
 // One workgroup per block column.

@@ -119,6 +119,9 @@ int bmx_vec_free(bmx_ctx* ctx, bmx_vec* v);
  * exceed counts[BMX_BIT]; offs[] always indexes the slab that is downloaded. */
 int bmx_vec_info(const bmx_vec* v, uint64_t* nbits, uint32_t* nblocks,
                  uint32_t counts[4], uint32_t* bit_slab_blocks, uint64_t* gap_words);
+/* algorithmic bytes an operation must read for this operand: 8,192 B per bit-block,
+ * 2 x (len + 1) B per GAP block (len = buf[0] >> 3), nothing for NULL / FULL -- what benchmark reports divide by */
+int bmx_vec_operand_bytes(bmx_ctx* ctx, const bmx_vec* v, uint64_t* bytes);
 /* Download the block table (feeds blocks_manager on the host, src/bmblocks.h:1355).
  * Array sizes come from bmx_vec_info; any pointer may be NULL to skip that part. */
 int bmx_vec_download(bmx_ctx* ctx, const bmx_vec* v, uint8_t* kinds, uint32_t* offs,

@@ -173,6 +173,44 @@ class RS:
         return pos, found.astype(bool)
 
 
+class SV:
+    """bm::sparse_vector<unsigned, bvector<>> living inside the reference library + bm::sparse_vector_scanner<> calls"""
+
+    def __init__(self, orc, handle, n):
+        self.orc, self.h, self.n = orc, handle, int(n)
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.orc.lib.ref_sv_free(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def size(self) -> int:
+        return int(self.orc.lib.ref_sv_size(self.h))
+
+    def effective_slices(self) -> int:
+        return int(self.orc.lib.ref_sv_effective_slices(self.h))
+
+    def slice(self, i: int):
+        h = self.orc.lib.ref_sv_slice(self.h, C.c_uint32(i))
+        return Vec(self.orc, h, self.n) if h else None
+
+    def not_null(self):
+        h = self.orc.lib.ref_sv_not_null(self.h)
+        return Vec(self.orc, h, self.n) if h else None
+
+    def compare(self, pred: int, v0: int = 0, v1: int = 0) -> Vec:
+        """pred = BMX_CMP_*: find_gt / ge / lt / le / range / eq / zero / nonzero"""
+        return Vec(self.orc, self.orc.lib.ref_sv_compare(self.h, C.c_int(pred), C.c_uint32(v0), C.c_uint32(v1)), self.n)
+
+    def find_first_eq(self, v: int):
+        pos = C.c_uint64()
+        f = self.orc.lib.ref_sv_find_first_eq(self.h, C.c_uint32(v), C.byref(pos))
+        return bool(f), int(pos.value)
+
+
 class Oracle:
     def __init__(self, path: str, prefix: str, kind: str, name: str):
         self.lib = C.CDLL(path)
@@ -229,6 +267,22 @@ class Oracle:
             L.ref_rs_export.argtypes = [vp, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
             L.ref_agg_member.restype = vp
             L.ref_agg_member.argtypes = [C.c_int, C.POINTER(vp), C.c_size_t]
+            if hasattr(L, "ref_sv_new"):       # round-3 additions of the shim: range hint, masks pipeline, sparse_vector scanner
+                L.ref_find_first_and_sub_range.restype = C.c_int
+                L.ref_find_first_and_sub_range.argtypes = [C.POINTER(vp), C.c_size_t, C.POINTER(vp), C.c_size_t, C.c_uint64, C.c_uint64,
+                                                           C.POINTER(C.c_uint64), C.POINTER(C.c_int)]
+                L.ref_agg_pipeline_masks.restype = None
+                L.ref_agg_pipeline_masks.argtypes = [C.POINTER(vp), C.POINTER(C.c_uint32), C.POINTER(vp), C.POINTER(C.c_uint32), C.c_size_t,
+                                                     C.c_uint64, C.c_uint64, C.POINTER(vp), C.POINTER(C.c_uint64)]
+                L.ref_sv_new.restype = vp
+                L.ref_sv_new.argtypes = [C.POINTER(C.c_uint32), C.POINTER(C.c_uint8), C.c_uint64]
+                L.ref_sv_free.restype = None; L.ref_sv_free.argtypes = [vp]
+                L.ref_sv_size.restype = C.c_uint64; L.ref_sv_size.argtypes = [vp]
+                L.ref_sv_effective_slices.restype = C.c_uint32; L.ref_sv_effective_slices.argtypes = [vp]
+                L.ref_sv_slice.restype = vp; L.ref_sv_slice.argtypes = [vp, C.c_uint32]
+                L.ref_sv_not_null.restype = vp; L.ref_sv_not_null.argtypes = [vp]
+                L.ref_sv_compare.restype = vp; L.ref_sv_compare.argtypes = [vp, C.c_int, C.c_uint32, C.c_uint32]
+                L.ref_sv_find_first_eq.restype = C.c_int; L.ref_sv_find_first_eq.argtypes = [vp, C.c_uint32, C.POINTER(C.c_uint64)]
         else:
             L.bmo_vec_new.argtypes = [C.c_uint64]
             L.bmo_vec_stat.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
@@ -347,6 +401,36 @@ class Oracle:
         idx = C.c_uint64()
         f = self._f("find_first_and_sub")(self._ptrs(and_vecs), len(and_vecs), self._ptrs(sub_vecs), len(sub_vecs), C.byref(idx))
         return bool(f), int(idx.value)
+
+    # -- reference only: range hint, masks pipeline, bm::sparse_vector_scanner (the generators of the round-3 fixtures) --
+    def find_first_and_sub_range(self, and_vecs, sub_vecs, frm: int, to: int):
+        """-> (hint_accepted, found, idx): aggregator::set_range_hint(frm, to) + find_first_and_sub (bmaggregator.h:481,974,1458)"""
+        assert self.is_ref
+        idx, ok = C.c_uint64(), C.c_int()
+        f = self.lib.ref_find_first_and_sub_range(self._ptrs(and_vecs), len(and_vecs), self._ptrs(sub_vecs), len(sub_vecs),
+                                                  C.c_uint64(frm), C.c_uint64(to), C.byref(idx), C.byref(ok))
+        return bool(ok.value), bool(f), int(idx.value)
+
+    def pipeline_masks(self, groups, frm: int, to: int):
+        """pipeline<agg_run_options<true, true, true>> under set_range_hint(frm, to) -> (results: list[Vec|None], counts)"""
+        assert self.is_ref
+        and_list = [v for g in groups for v in g[0]]
+        sub_list = [v for g in groups for v in g[1]]
+        and_n = np.array([len(g[0]) for g in groups], np.uint32)
+        sub_n = np.array([len(g[1]) for g in groups], np.uint32)
+        nbits = max([v.nbits for v in and_list + sub_list], default=0)
+        res = (C.c_void_p * max(len(groups), 1))()
+        cnt = np.zeros(len(groups), np.uint64)
+        self.lib.ref_agg_pipeline_masks(self._ptrs(and_list), _u32p(and_n), self._ptrs(sub_list), _u32p(sub_n), len(groups),
+                                        C.c_uint64(frm), C.c_uint64(to), res, _u64p(cnt))
+        return [Vec(self, res[g], nbits) if res[g] else None for g in range(len(groups))], cnt
+
+    def sparse_vector(self, values, is_null=None) -> "SV":
+        assert self.is_ref
+        values = np.ascontiguousarray(values, np.uint32)
+        nn = None if is_null is None else np.ascontiguousarray(is_null, np.uint8)
+        h = self.lib.ref_sv_new(_u32p(values), _u8p(nn) if nn is not None else None, C.c_uint64(values.size))
+        return SV(self, h, values.size)
 
     def rs_build(self, v: Vec) -> RS:
         return RS(self, self._f("rs_build")(v.h), v)

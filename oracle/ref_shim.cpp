@@ -17,6 +17,8 @@
 #include "bmaggregator.h"
 #include "bmalgo.h"
 #include "bmbvimport.h"
+#include "bmsparsevec.h"
+#include "bmsparsevec_algo.h"
 
 typedef bm::bvector<> bvect;
 typedef bm::aggregator<bvect> agg_t;
@@ -314,6 +316,105 @@ int ref_find_first_and_sub(void* const* src_and, size_t n_and, void* const* src_
                                     reinterpret_cast<const bvect* const*>(src_sub), n_sub);
     *idx = i; return f;
 }
+// the same under aggregator::set_range_hint(from, to) (bmaggregator.h:481,974): *hint_ok = what set_range_hint returned
+int ref_find_first_and_sub_range(void* const* src_and, size_t n_and, void* const* src_sub, size_t n_sub,
+                                 uint64_t from, uint64_t to, uint64_t* idx, int* hint_ok)
+{
+    agg_t agg; bvect::size_type i = 0;
+    for (size_t k = 0; k < n_and; ++k) agg.add(static_cast<const bvect*>(src_and[k]), 0);
+    for (size_t k = 0; k < n_sub; ++k) agg.add(static_cast<const bvect*>(src_sub[k]), 1);
+    bool ok = agg.set_range_hint(bvect::size_type(from), bvect::size_type(to));
+    if (hint_ok) *hint_ok = ok;
+    bool f = agg.find_first_and_sub(i);
+    *idx = i; return f;
+}
+
+// pipeline whose options enable search masks (agg_run_options<.., .., true>::is_masks(), bmaggregator.h:65,78) run under
+// set_range_hint(from, to): result vectors + counts (:1312-1346)
+void ref_agg_pipeline_masks(void* const* and_list, const uint32_t* and_n, void* const* sub_list, const uint32_t* sub_n,
+                            size_t ngroups, uint64_t from, uint64_t to, void** results_out, uint64_t* counts_out)
+{
+    typedef bm::agg_run_options<true, true, true> opt_t;
+    agg_t agg;
+    agg_t::pipeline<opt_t> pipe;
+    size_t ao = 0, so = 0;
+    for (size_t g = 0; g < ngroups; ++g) {
+        agg_t::arg_groups* ag = pipe.add();
+        for (uint32_t k = 0; k < and_n[g]; ++k) ag->add(static_cast<const bvect*>(and_list[ao + k]), 0);
+        for (uint32_t k = 0; k < sub_n[g]; ++k) ag->add(static_cast<const bvect*>(sub_list[so + k]), 1);
+        ao += and_n[g]; so += sub_n[g];
+    }
+    pipe.complete();
+    agg.set_range_hint(bvect::size_type(from), bvect::size_type(to));
+    agg.combine_and_sub(pipe);
+    auto& res = pipe.get_bv_res_vector();
+    auto& cnt = pipe.get_bv_count_vector();
+    for (size_t g = 0; g < ngroups; ++g) {
+        counts_out[g] = cnt[g];
+        results_out[g] = res[g] ? new bvect(*res[g]) : nullptr;
+    }
+}
+
+// ---- bm::sparse_vector<unsigned, bvector<>> + bm::sparse_vector_scanner<> (bmsparsevec_algo.h:931, 1083-1174, 2290,
+// 2690-2880, 4464): the caller of the aggregator that SURVEY section 8(f)-1 names.  values[i] is stored at row i;
+// is_null (may be NULL) marks rows left unassigned in a use_null vector. ----
+typedef bm::sparse_vector<unsigned, bvect> svect_t;
+
+void* ref_sv_new(const uint32_t* values, const uint8_t* is_null, uint64_t n)
+{
+    svect_t* sv = is_null ? new svect_t(bm::use_null) : new svect_t();
+    if (is_null) {
+        for (uint64_t i = 0; i < n; ++i) if (!is_null[i]) sv->set(svect_t::size_type(i), values[i]);
+        if (n && is_null[n - 1]) sv->set_null(svect_t::size_type(n - 1));          // make size() == n
+    } else {
+        svect_t::back_insert_iterator bi = sv->get_back_inserter();
+        for (uint64_t i = 0; i < n; ++i) bi = values[i];
+        bi.flush();
+    }
+    sv->optimize();
+    return sv;
+}
+void ref_sv_free(void* sv) { delete static_cast<svect_t*>(sv); }
+uint64_t ref_sv_size(void* sv) { return static_cast<svect_t*>(sv)->size(); }
+uint32_t ref_sv_effective_slices(void* sv) { return static_cast<svect_t*>(sv)->effective_slices(); }
+// copy of bit-plane i (NULL when the plane does not exist); caller frees with ref_vec_free
+void* ref_sv_slice(void* sv, uint32_t i)
+{
+    const bvect* p = static_cast<svect_t*>(sv)->get_slice(i);
+    return p ? new bvect(*p) : nullptr;
+}
+void* ref_sv_not_null(void* sv)
+{
+    const bvect* p = static_cast<svect_t*>(sv)->get_null_bvector();
+    return p ? new bvect(*p) : nullptr;
+}
+// pred: BMX_CMP_* of include/bmx.h (GT 0, GE 1, LT 2, LE 3, RANGE 4, EQ 5, ZERO 6, NONZERO 7)
+void* ref_sv_compare(void* svp, int pred, uint32_t v0, uint32_t v1)
+{
+    const svect_t& sv = *static_cast<svect_t*>(svp);
+    bm::sparse_vector_scanner<svect_t> sc;
+    bvect* r = new bvect();
+    switch (pred) {
+    case 0: sc.find_gt(sv, v0, *r); break;
+    case 1: sc.find_ge(sv, v0, *r); break;
+    case 2: sc.find_lt(sv, v0, *r); break;
+    case 3: sc.find_le(sv, v0, *r); break;
+    case 4: sc.find_range(sv, v0, v1, *r); break;
+    case 5: sc.find_eq(sv, v0, *r); break;
+    case 6: sc.find_zero(sv, *r); break;
+    default: sc.find_nonzero(sv, *r); break;
+    }
+    return r;
+}
+int ref_sv_find_first_eq(void* svp, uint32_t v, uint64_t* pos)
+{
+    const svect_t& sv = *static_cast<svect_t*>(svp);
+    bm::sparse_vector_scanner<svect_t> sc;
+    svect_t::size_type p = 0;
+    bool f = sc.find_eq(sv, v, p);
+    *pos = p; return f;
+}
+
 // rank variants: bm.h:3548 count_range, :3229 rank_corrected, :3173 count_to_test, :5279 find_rank
 uint64_t ref_count_range(void* v, void* r, uint64_t left, uint64_t right)
 { return static_cast<bvect*>(v)->count_range(bvect::size_type(left), bvect::size_type(right), static_cast<ref_rs*>(r)->rs); }

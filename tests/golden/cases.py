@@ -120,3 +120,40 @@ def bm64_queries(count: int):
                        BM64_NBITS - 1], np.uint64)
     sel_q = np.array([1, 2, 100, max(count // 2, 1), max(count - 1, 1), count, count + 1], np.uint64)
     return rank_q, sel_q
+
+
+# ---- round 3: set_range_hint (find_first_and_sub + pipelines with search masks) and the sparse_vector_scanner ----
+def range_hints(nbits: int):
+    """(from, to) search ranges: inside one block (bit-masked by the reference, bmaggregator.h:980-988), across blocks
+    (block-granular), the first / last block, the whole vector"""
+    last = nbits - 1
+    h = [(0, 0), (5, 700), (1000, 65535), (65536, 65536 + 4000), (40000, 70000), (60000, 2 * 65536 + 100), (65536 * 2, last),
+         (last - min(last, 300), last), (0, last), (100000, 100050)]
+    return [(a, min(b, last)) for a, b in h if a <= last]
+
+
+HINT_GROUPS = [([0, 1], []), ([0, 1], [2]), ([3], []), ([0], [1, 2, 3]), ([1, 0, 5, 2], [4])]
+
+# scanner fixtures: (name, rows, value generator) -- the planes are rebuilt from these values by numpy in the tests,
+# the expected result vectors come from bm::sparse_vector_scanner<> (make_golden.py)
+SCANNER_ROWS = 3 * 65536 + 1234
+SCANNER_VALUES = [0, 1, 2, 50, 95, 96, 97, 128, 69999, 70000, 70003, 70006, 70007, 131071, 131072, 4000000]
+SCANNER_RANGES = [(0, 0), (0, 5), (3, 3), (90, 10), (10, 69999), (96, 70003), (70001, 70005), (1, 4000000)]
+SCANNER_EQ_BATCH = [1, 2, 17, 64, 96, 97, 120, 70000, 70003, 70006, 131072, 5000000, 0, 33, 34, 35]
+
+
+def scanner_values(with_null: bool):
+    """-> (values uint32[rows], is_null uint8[rows] or None): small values (7 planes), rare wide ones (sparse high planes),
+    a stretch of zeros, a constant stretch"""
+    rng = np.random.default_rng(20260925)
+    v = rng.integers(0, 97, SCANNER_ROWS).astype(np.uint32)
+    idx = np.arange(SCANNER_ROWS)
+    v[idx % 1000 == 0] = (70000 + (idx[idx % 1000 == 0] % 7)).astype(np.uint32)
+    v[70000:72000] = 0
+    v[140000:150000] = 33
+    if not with_null:
+        return v, None
+    isn = (idx % 11 == 3).astype(np.uint8)
+    isn[-1] = 0                                    # the last row is assigned: size() == rows either way
+    v = v.copy(); v[isn != 0] = 0                  # NULL rows are stored as 0
+    return v, isn

@@ -19,7 +19,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 sys.path.insert(0, HERE)
 
 import oracle  # noqa: E402
-from cases import (AGG_GROUPS, BM64_NVEC, CASES, OR_SETS, PAIRS, SEED, SHIFT_SETS, bm64_build, bm64_queries, make_inputs, rank_queries, select_queries, sha)  # noqa: E402
+from cases import (AGG_GROUPS, BM64_NVEC, CASES, HINT_GROUPS, OR_SETS, PAIRS, SCANNER_EQ_BATCH, SCANNER_RANGES, SCANNER_ROWS, SCANNER_VALUES, SEED,  # noqa: E402
+                   SHIFT_SETS, bm64_build, bm64_queries, make_inputs, range_hints, rank_queries, scanner_values, select_queries, sha)
 
 
 def gap_slab_masked(kinds, offs, gaps):
@@ -119,8 +120,59 @@ def run(R, P):
                             "rank": [int(x) for x in rs.rank(rq)],
                             "select_found": found.astype(int).tolist(),
                             "select_pos": [int(p) if f else 0 for p, f in zip(pos, found)]})
+        # set_range_hint (bmaggregator.h:481,974): find_first_and_sub under a hint, and a pipeline whose options enable
+        # search masks (agg_run_options<true, true, true>, :65,78,1312-1346) -- results + counts per group
+        c["range_hint"] = []
+        for (frm, to) in range_hints(nbits):
+            res, cnt = R.pipeline_masks([([vecs[i] for i in a], [vecs[i] for i in s_]) for (a, s_) in HINT_GROUPS], frm, to)
+            # find_first_and_sub under the hint: the logical first bit of the reference's own hinted result; the reference
+            # call itself is recorded too -- for a column whose AND operands are all FULL it reads a temp block it never
+            # filled (is_res_full, bmaggregator.h:1483-1497,1536-1547), like the unhinted call noted above
+            ff = []
+            for gi, (a, s_) in enumerate(HINT_GROUPS):
+                ok, f, idx = R.find_first_and_sub_range([vecs[i] for i in a], [vecs[i] for i in s_], frm, to)
+                lf = R.find_first(res[gi]) if res[gi] is not None else (False, 0)
+                ff.append({"hint_one_block": ok, "found": bool(lf[0]), "idx": lf[1] if lf[0] else 0,
+                           "reference_call_agrees": bool((f, idx if f else 0) == (bool(lf[0]), lf[1] if lf[0] else 0))})
+            c["range_hint"].append({"from": frm, "to": to, "find_first": ff, "counts": [int(x) for x in cnt],
+                                    "present": [r is not None for r in res],
+                                    "sha": [sha(r.to_words()) if r is not None else None for r in res],
+                                    "kinds": [r.flatten()[0].tolist() if r is not None else None for r in res]})
         out["cases"][case] = c
         print("case", case, "done", file=sys.stderr)
+    return out
+
+
+def run_scanner(R):
+    """bm::sparse_vector_scanner<bm::sparse_vector<unsigned, bvector<>>> over the SCANNER_* fixtures of cases.py, with and
+    without NULL rows: find_gt / ge / lt / le / range / eq / zero / nonzero result vectors, find_eq first hits, and the
+    counts of a batch of equality searches"""
+    out = {}
+    nw = (SCANNER_ROWS + 31) // 32
+    for with_null in (False, True):
+        vals, isn = scanner_values(with_null)
+        sv = R.sparse_vector(vals, isn)
+        assert sv.size() == SCANNER_ROWS
+        c = {"rows": SCANNER_ROWS, "values_sha": sha(vals), "effective_slices": sv.effective_slices(),
+             "null_sha": sha(isn) if isn is not None else None, "cmp": {}, "range": [], "eq_first": [], "eq_counts": []}
+        planes = [sv.slice(i) for i in range(sv.effective_slices())]
+        c["plane_counts"] = [p.count() if p is not None else None for p in planes]
+        for pred, name in ((0, "gt"), (1, "ge"), (2, "lt"), (3, "le"), (5, "eq")):
+            c["cmp"][name] = []
+            for v in SCANNER_VALUES:
+                r = sv.compare(pred, v)
+                c["cmp"][name].append({"v": v, "count": r.count(), "sha": sha(r.to_words(nw))})
+        for (a, b) in SCANNER_RANGES:
+            r = sv.compare(4, a, b)
+            c["range"].append({"from": a, "to": b, "count": r.count(), "sha": sha(r.to_words(nw))})
+        for pred, name in ((6, "zero"), (7, "nonzero")):
+            r = sv.compare(pred)
+            c[name] = {"count": r.count(), "sha": sha(r.to_words(nw))}
+        for v in SCANNER_VALUES:
+            f, pos = sv.find_first_eq(v)
+            c["eq_first"].append({"v": v, "found": f, "pos": pos if f else 0})
+        c["eq_counts"] = [sv.compare(5, v).count() for v in SCANNER_EQ_BATCH]
+        out["with_null" if with_null else "no_null"] = c
     return out
 
 
@@ -159,6 +211,9 @@ def main():
     assert a["simd_version"] == 5 and s["simd_version"] == 0
     a["also_verified_with"] = s["reference"]
     a["bm64"] = run_bm64(oracle.reference("avx2_64"))
+    sc_a, sc_s = run_scanner(oracle.reference("avx2")), run_scanner(oracle.reference("scalar"))
+    assert sc_a == sc_s, "AVX2 and scalar scanner results disagree"
+    a["scanner"] = sc_a
     with open(os.path.join(HERE, "golden_ref.json"), "w") as f:
         json.dump(a, f, separators=(",", ":"))
     print("wrote golden_ref.json", os.path.getsize(os.path.join(HERE, "golden_ref.json")), "bytes")

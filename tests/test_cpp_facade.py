@@ -60,8 +60,8 @@ def test_cpp_facade_on_gpu():
 def test_cpp_adapter_with_real_bitmagic_on_gpu():
     """bm::bvector<> -> upload -> GPU -> download -> bm::bvector<>::compare()==0 against BitMagic's own results"""
     exe = os.path.join(ROOT, "oracle", "_ref", "test_adapter_ref")
-    if not os.path.exists(exe):
-        pytest.skip("oracle/_ref/test_adapter_ref was not prebuilt (needs the reference headers at build time)")
+    assert os.path.exists(exe), ("oracle/_ref/test_adapter_ref was not prebuilt: build it where the reference headers are "
+                                 "(python -c 'import __graft_entry__ as g; g.build()'); the file travels to the GPU box")
     r = subprocess.run([exe], env=_env(), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "test_adapter_ref ok" in r.stdout, r.stdout + r.stderr
 
@@ -73,8 +73,7 @@ def test_reference_sample16_runs_unchanged_on_the_gpu():
     generates the 2-line edit from the source where it lies) prints exactly what the unmodified CPU build prints"""
     cpu = os.path.join(ROOT, "oracle", "_ref", "sample16_cpu")
     gpu = os.path.join(ROOT, "oracle", "_ref", "sample16_gpu")
-    if not (os.path.exists(cpu) and os.path.exists(gpu)):
-        pytest.skip("oracle/_ref/sample16_{cpu,gpu} were not prebuilt (needs the reference sources at build time)")
+    assert os.path.exists(cpu) and os.path.exists(gpu), "oracle/_ref/sample16_{cpu,gpu} were not prebuilt (needs the reference sources at build time)"
     a = subprocess.run([cpu], env=_env(), capture_output=True, text=True, timeout=300)
     b = subprocess.run([gpu], env=_env(), capture_output=True, text=True, timeout=300)
     assert a.returncode == 0 and b.returncode == 0, a.stderr + b.stderr
@@ -87,7 +86,6 @@ def test_libbm_c_wrapper_gpu_edition():
     pairwise / count surface (examples/libbm_gpu.cpp): a plain C client builds vectors through the libbm API and every
     BMX_ call must agree with its BM_ twin (counts, combine_* + BM_bvector_compare, invalidate after a CPU-side change)"""
     exe = os.path.join(ROOT, "oracle", "_ref", "test_libbm_gpu")
-    if not os.path.exists(exe):
-        pytest.skip("oracle/_ref/test_libbm_gpu was not prebuilt (needs the reference sources at build time)")
+    assert os.path.exists(exe), "oracle/_ref/test_libbm_gpu was not prebuilt (needs the reference sources at build time)"
     r = subprocess.run([exe], env=_env(), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "test_libbm_gpu ok" in r.stdout, r.stdout + r.stderr

@@ -1265,7 +1265,7 @@ def _sparse_collection(port, rng, nvec, nbits, dq, long_runs=False, ragged=False
     return words
 
 
-@pytest.mark.parametrize("dq,nvec,long_runs", [(13, 200, False), (150, 96, True), (400, 64, True), (30, 300, False)])
+@pytest.mark.parametrize("dq,nvec,long_runs", [(13, 200, False), (150, 96, True), (280, 64, True), (30, 300, False)])
 def test_packed_gap_collections(port, dq, nvec, long_runs):
     """combine_or / combine_and / combine_and_sub / one-group counts pipelines over GAP-only operand sets through the
     column-major packed collection (bmx_kernels6.h, gap_pack 1) must equal the oracle bit for bit AND block kind for
@@ -1361,3 +1361,100 @@ def test_packed_collection_policy_and_prepare(port):
         c.collection_prepare(gv + [dense], bm.ROLE_OR)     # bit-blocks cannot be packed
     del gv, o1, o2, o3, t, dense
     c.close()
+
+
+# ---- round-3 fixtures generated by the reference: set_range_hint and the sparse_vector_scanner ----
+@pytest.mark.parametrize("case", list(CASES))
+def test_range_hint_vs_reference_golden(ctx, port, golden, case):
+    """aggregator::set_range_hint (src/bmaggregator.h:481,974): find_first_and_sub under a hint and a pipeline whose options
+    enable search masks (agg_run_options<true, true, true>, :1312-1346) against what the live bm::aggregator returned
+    (tests/golden/make_golden.py): counts, result presence, content and block kinds per arg-group"""
+    from cases import HINT_GROUPS, range_hints
+    g = golden["cases"][case]
+    words, nbits = make_inputs(port, case)
+    gv = [bm.bit_import_u32(ctx, w, True) for w in words]
+    for v, w in zip(gv, words):
+        assert v.info()["nbits"] >= nbits - 63
+    nblk = (nbits + 65535) // 65536
+    agg = bm.aggregator(ctx)
+    for (frm, to), e in zip(range_hints(nbits), g["range_hint"]):
+        assert (e["from"], e["to"]) == (frm, to)
+        one = agg.set_range_hint(frm, to)
+        for gi, (a, s) in enumerate(HINT_GROUPS):
+            ff = e["find_first"][gi]
+            assert one == ff["hint_one_block"]
+            found, idx = agg.find_first_and_sub([gv[i] for i in a], [gv[i] for i in s])
+            assert found == ff["found"] and (not found or idx == ff["idx"]), (case, frm, to, gi)
+        pipe = bm.aggregator.pipeline(ctx, bm.agg_run_options(True, True, True))
+        for a, s in HINT_GROUPS:
+            ag = pipe.add()
+            for i in a: ag.add(gv[i], 0)
+            for i in s: ag.add(gv[i], 1)
+        pipe.complete()
+        agg.combine_and_sub(pipe)
+        assert [int(x) for x in pipe.get_bv_count_vector()] == e["counts"], (case, frm, to)
+        res = pipe.get_bv_res_vector()
+        assert [r is not None for r in res] == e["present"], (case, frm, to)
+        for gi, r in enumerate(res):
+            if r is None: continue
+            assert sha(r.to_words(nblk * 2048)) == e["sha"][gi], (case, frm, to, gi)
+            assert r.block_table()[0].tolist() == (e["kinds"][gi] + [0] * nblk)[:r.info()["nblocks"]], (case, frm, to, gi)
+        # counts-only pipeline with masks under the same hint
+        p2 = bm.aggregator.pipeline(ctx, bm.agg_run_options(False, True, True))
+        for a, s in HINT_GROUPS:
+            ag = p2.add()
+            for i in a: ag.add(gv[i], 0)
+            for i in s: ag.add(gv[i], 1)
+        p2.complete()
+        assert [int(x) for x in agg.combine_and_sub(p2)] == e["counts"], (case, frm, to)
+        agg.reset_range_hint()
+
+
+@pytest.mark.parametrize("with_null", [False, True])
+def test_slice_scanner_vs_reference_golden(ctx, golden, with_null):
+    """bmx slice_scanner over bit-planes built by numpy from cases.scanner_values against the result vectors of the real
+    bm::sparse_vector_scanner<> (tests/golden/golden_ref.json "scanner"): find_gt / ge / lt / le / range / eq / zero /
+    nonzero (content + counts), find_first_eq, and a batch of equality counts through both batch paths"""
+    from cases import SCANNER_EQ_BATCH, SCANNER_RANGES, SCANNER_ROWS, SCANNER_VALUES, scanner_values
+    g = golden["scanner"]["with_null" if with_null else "no_null"]
+    n = SCANNER_ROWS
+    vals, isn = scanner_values(with_null)
+    assert sha(vals) == g["values_sha"]
+    def upload(bits):
+        w = np.packbits(np.concatenate([bits.astype(np.uint8), np.zeros((-n) % 32, np.uint8)]), bitorder="little").view(np.uint32)
+        return bm.bit_import_u32(ctx, w, True)
+    col = vals.astype(np.uint64)
+    planes = []
+    for i in range(g["effective_slices"]):
+        bits = ((col >> np.uint64(i)) & np.uint64(1)) != 0
+        planes.append(upload(bits) if bits.any() else None)
+        assert g["plane_counts"][i] in (None, int(bits.sum())) and (planes[-1] is None) == (g["plane_counts"][i] in (None, 0))
+    nn = upload(isn == 0) if with_null else None
+    sc = bm.slice_scanner(ctx, planes, size=n, not_null=nn)
+    nw = (n + 31) // 32
+    def chk(t, e):
+        assert t.count() == e["count"] and sha(t.to_words(nw)) == e["sha"], e
+    for halves in (1, 0):
+        ctx.set_tuning("range_halves", halves)
+        for name, fn, pred in (("gt", sc.find_gt, bm.CMP_GT), ("ge", sc.find_ge, bm.CMP_GE), ("lt", sc.find_lt, bm.CMP_LT), ("le", sc.find_le, bm.CMP_LE)):
+            for e in g["cmp"][name]:
+                chk(fn(e["v"]), e)
+                assert sc.count(pred, e["v"]) == e["count"]
+        for e in g["range"]:
+            chk(sc.find_range(e["from"], e["to"]), e)
+            assert sc.count(bm.CMP_RANGE, e["from"], e["to"]) == e["count"]
+        chk(sc.find_zero(), g["zero"]); chk(sc.find_nonzero(), g["nonzero"])
+    ctx.set_tuning("range_halves", 1)
+    for e, f in zip(g["cmp"]["eq"], g["eq_first"]):
+        t, found = sc.find_eq(e["v"])
+        assert found == (e["count"] > 0)
+        if t is not None: chk(t, e)
+        else: assert e["count"] == 0
+        ff = sc.find_first_eq(e["v"]) if e["v"] else (f["found"], f["pos"])      # (value 0 has no AND group: find_eq(0) above covers it)
+        assert ff[0] == f["found"] and (not f["found"] or ff[1] == f["pos"]), f
+    for method in ("auto", "pipeline", "transpose"):
+        try:
+            got = sc.find_eq_counts(np.array(SCANNER_EQ_BATCH, np.uint64), method=method)
+        except (TypeError, ValueError):
+            continue
+        assert [int(x) for x in got] == g["eq_counts"], method
