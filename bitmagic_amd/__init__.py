@@ -157,6 +157,14 @@ class bvector:
         return {"nbits": nbits.value, "nblocks": nblocks.value, "counts": list(counts),
                 "bit_slab_blocks": slab.value, "gap_words": gw.value}
 
+    def to_indices(self, width: int = 8) -> np.ndarray:
+        """the sorted positions of the set bits (device compaction; include/bmx.h bmx_vec_to_indices)"""
+        n = C.c_uint64()
+        cnt = self.count()
+        out = np.zeros(cnt, np.uint64 if width == 8 else np.uint32)
+        check(lib().bmx_vec_to_indices(self.ctx._h, self._h, width, _ptr(out) if cnt else None, cnt, C.byref(n)))
+        return out[:n.value]
+
     def operand_bytes(self) -> int:
         """algorithmic bytes of this operand: 8,192 B per bit-block, 2 x (len + 1) B per GAP block"""
         b = C.c_uint64()
@@ -536,6 +544,13 @@ class aggregator:
         check(lib().bmx_agg_and_sub(self.ctx._h, _handles(a), len(a), _handles(s), len(s), C.byref(h), C.byref(any_)))
         return bvector(self.ctx, h), bool(any_.value)
 
+    def combine_and_sub_bi(self, bv_src_and=None, bv_src_sub=None, width: int = 8) -> np.ndarray:       # :450,533,1068,1226
+        """the AND-SUB result as SORTED positions (what the reference feeds into a back-insert iterator)"""
+        a = list(bv_src_and) if bv_src_and is not None else self.ag.arg_bv0
+        s = list(bv_src_sub) if bv_src_sub is not None else self.ag.arg_bv1
+        t, any_ = self.combine_and_sub(a, s)
+        return t.to_indices(width) if any_ else np.zeros(0, np.uint64 if width == 8 else np.uint32)
+
     def combine_shift_right_and(self, bv_src_and=None, any: bool = False):               # :473,1089 / :552,2494
         """-> (target, found).  T_0 = src[0], T_k = (T_{k-1} >> 1) & src[k]; target stored with the
         aggregator's optimisation mode.  Under set_compute_count(True) nothing is stored (:2593):
@@ -572,9 +587,15 @@ class aggregator:
     def _run_pipeline(self, pipe: pipeline, nb_from: int | None = None, nb_to: int | None = None):
         if not pipe.is_complete():
             raise RuntimeError("pipeline is not complete()")
-        if nb_from is None:
-            nb_from, nb_to = self._hint_blocks(pipe)
         out = np.zeros(max(pipe.size(), 1), np.uint64)
+        if nb_from is None and self._range is not None and pipe.opt.is_masks():
+            # set_range_hint: block columns of the hint; a one-block hint is bit-masked as well (:980-988)
+            check(lib().bmx_pipeline_run_results_hint(self.ctx._h, pipe._h, self._range[0], self._range[1], None,
+                                                      out.ctypes.data_as(C.POINTER(C.c_uint64)), None, None))
+            pipe._counts = out[:pipe.size()]
+            return pipe._counts
+        if nb_from is None:
+            nb_from, nb_to = 0, ID_MAX
         check(lib().bmx_pipeline_run_counts(self.ctx._h, pipe._h, nb_from, nb_to,
                                             out.ctypes.data_as(C.POINTER(C.c_uint64))))
         pipe._counts = out[:pipe.size()]
@@ -589,12 +610,14 @@ class aggregator:
         ort = C.c_void_p()
         want_res = pipe.opt.is_make_results()
         want_cnt = pipe.opt.is_compute_counts()
-        nbf, nbt = self._hint_blocks(pipe)
-        check(lib().bmx_pipeline_run_results_range(
-            self.ctx._h, pipe._h, nbf, nbt, res if want_res else None,
-            cnt.ctypes.data_as(C.POINTER(C.c_uint64)) if (want_cnt and want_res) else None,
-            pipe._or_target._h if (pipe._want_or_target and pipe._or_target is not None) else None,
-            C.byref(ort) if pipe._want_or_target else None))
+        cnt_p = cnt.ctypes.data_as(C.POINTER(C.c_uint64)) if (want_cnt and want_res) else None
+        ort_in = pipe._or_target._h if (pipe._want_or_target and pipe._or_target is not None) else None
+        if self._range is not None and pipe.opt.is_masks():
+            check(lib().bmx_pipeline_run_results_hint(self.ctx._h, pipe._h, self._range[0], self._range[1], res if want_res else None,
+                                                      cnt_p, ort_in, C.byref(ort) if pipe._want_or_target else None))
+        else:
+            check(lib().bmx_pipeline_run_results_range(self.ctx._h, pipe._h, 0, ID_MAX, res if want_res else None, cnt_p, ort_in,
+                                                       C.byref(ort) if pipe._want_or_target else None))
         pipe._results = [bvector(self.ctx, C.c_void_p(res[g])) if (want_res and res[g]) else None for g in range(n)]
         if pipe._want_or_target:
             pipe._or_target = bvector(self.ctx, ort)
@@ -683,6 +706,11 @@ class slice_scanner:
         if g is None:
             return None, False
         return self.agg.combine_and_sub(g[0], g[1])
+
+    def find_eq_indices(self, value: int) -> np.ndarray:
+        """find_eq(sv, value, BII)  src/bmsparsevec_algo.h:1096: matching rows as sorted indices"""
+        t, found = self.find_eq(value)
+        return t.to_indices() if (found and t is not None) else np.zeros(0, np.uint64)
 
     def find_first_eq(self, value: int):
         g = self._groups(int(value))

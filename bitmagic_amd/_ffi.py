@@ -61,6 +61,9 @@ def lib() -> C.CDLL:
         "bmx_vec_info": (i32, [vp, P(u64), P(u32), P(u32), P(u32), P(u64)]),
         "bmx_vec_operand_bytes": (i32, [vp, vp, P(u64)]),
         "bmx_vec_download": (i32, [vp, vp, vp, vp, vp, vp]),
+        "bmx_vec_to_indices": (i32, [vp, vp, i32, vp, u64, P(u64)]),
+        "bmx_vec_to_indices_dev": (i32, [vp, vp, i32, vp, u64, P(u64)]),
+        "bmx_agg_and_sub_indices": (i32, [vp, P(vp), C.c_size_t, P(vp), C.c_size_t, i32, vp, u64, P(u64)]),
         "bmx_vec_to_words": (i32, [vp, vp, vp, u64]),
         "bmx_count": (i32, [vp, vp, P(u64)]),
         "bmx_op2": (i32, [vp, i32, vp, vp, i32, P(vp)]),
@@ -83,6 +86,7 @@ def lib() -> C.CDLL:
         "bmx_pipeline_run_counts_dev": (i32, [vp, vp, u32, u32, vp]),
         "bmx_pipeline_run_results": (i32, [vp, vp, P(vp), P(u64), vp, P(vp)]),
         "bmx_pipeline_run_results_range": (i32, [vp, vp, u32, u32, P(vp), P(u64), vp, P(vp)]),
+        "bmx_pipeline_run_results_hint": (i32, [vp, vp, u64, u64, P(vp), P(u64), vp, P(vp)]),
         "bmx_pipeline_operand_bytes": (i32, [vp, vp, u32, u32, P(u64)]),
         "bmx_pipeline_describe": (i32, [vp, vp, u32, u32, C.c_char_p, C.c_size_t, P(u32)]),
         "bmx_rs_build": (i32, [vp, vp, P(vp)]),

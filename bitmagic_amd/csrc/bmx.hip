@@ -863,6 +863,56 @@ int bmx_vec_operand_bytes(bmx_ctx* ctx, const bmx_vec* v, uint64_t* bytes)
     return BMX_OK;
 }
 
+// sorted positions of the set bits: device compaction (bmx_kernels6.h k_block_counts / k_rs_scan / k_expand_indices)
+static int vec_indices_impl(bmx_ctx* ctx, const bmx_vec* v, int width, void* out, bool out_is_host, uint64_t cap, uint64_t* n)
+{
+    ARGCHK(ctx && v && v->ctx == ctx && n && (width == 4 || width == 8) && (cap == 0 || out));
+    int rc = set_dev(ctx); if (rc) return rc;
+    *n = 0;
+    const uint32_t nblocks = v->nblocks;
+    if (!nblocks) return BMX_OK;
+    if (width == 4 && (uint64_t)nblocks > 65536ull) { g_last_error = "32-bit positions cannot address this vector: use width 8"; return BMX_ERR_RANGE; }
+    u32* d_bc = nullptr; u64* d_rc = nullptr; void* d_out = nullptr;
+    if ((rc = dmalloc(ctx, (void**)&d_bc, (size_t)nblocks * 4)) || (rc = dmalloc(ctx, (void**)&d_rc, (size_t)nblocks * 8))) { dfree(ctx, d_bc); return rc; }
+    hipLaunchKernelGGL(k_block_counts, dim3((nblocks + 3) / 4), dim3(256), 0, ctx->stream, (const u64*)v->d_desc, nblocks, d_bc);
+    hipLaunchKernelGGL(k_rs_scan, dim3(1), dim3(1024), 0, ctx->stream, (const u32*)d_bc, nblocks, d_rc, ctx->d_small);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(ctx->h_small, ctx->d_small, 8, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    uint64_t total = e == hipSuccess ? ctx->h_small[0] : 0;
+    if (e == hipSuccess) {
+        *n = total;
+        if (total > cap) { rc = BMX_ERR_RANGE; g_last_error = "output buffer too small for the positions (n holds the number needed)"; }
+        else if (total) {
+            d_out = out_is_host ? nullptr : out;
+            if (out_is_host) rc = dmalloc(ctx, &d_out, (size_t)total * (size_t)width);
+            if (!rc) {
+                if (width == 8) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_expand_indices<u64>), dim3((nblocks + 3) / 4), dim3(256), 0, ctx->stream,
+                                                   (const u64*)v->d_desc, nblocks, (const u64*)d_rc, (u64*)d_out, total, 0ull);
+                else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_expand_indices<u32>), dim3((nblocks + 3) / 4), dim3(256), 0, ctx->stream,
+                                        (const u64*)v->d_desc, nblocks, (const u64*)d_rc, (u32*)d_out, total, 0ull);
+                e = hipGetLastError();
+                if (e == hipSuccess && out_is_host) e = hipMemcpyAsync(out, d_out, (size_t)total * (size_t)width, hipMemcpyDeviceToHost, ctx->stream);
+                if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+            }
+        }
+    }
+    if (e != hipSuccess) { (void)hipStreamSynchronize(ctx->stream); rc = fail_hip(e, "bmx_vec_to_indices", __LINE__); }
+    if (out_is_host) dfree(ctx, d_out);
+    dfree(ctx, d_bc); dfree(ctx, d_rc);
+    return rc;
+}
+
+int bmx_vec_to_indices(bmx_ctx* ctx, const bmx_vec* v, int width, void* out, uint64_t cap, uint64_t* n)
+{
+    return vec_indices_impl(ctx, v, width, out, true, cap, n);
+}
+
+int bmx_vec_to_indices_dev(bmx_ctx* ctx, const bmx_vec* v, int width, void* d_out, uint64_t cap, uint64_t* n)
+{
+    return vec_indices_impl(ctx, v, width, d_out, false, cap, n);
+}
+
 int bmx_vec_download(bmx_ctx* ctx, const bmx_vec* v, uint8_t* kinds, uint32_t* offs,
                      uint32_t* bit_slab, uint16_t* gap_slab)
 {
@@ -1813,6 +1863,70 @@ static int run_results_impl(bmx_ctx* ctx, bmx_pipeline* p, uint32_t nb_from, uin
     return BMX_OK;
 }
 
+// ---- pipelines with search masks under aggregator::set_range_hint(from, to) ----
+// The reference evaluates only the block columns of the hint (src/bmaggregator.h:1312-1346) and, when both ends lie in ONE
+// block, ANDs that column with the bit range as well (range_gap_blk_, :980-988, 2354-2358) -- pinned by the reference-generated
+// fixtures of tests/golden ("range_hint").  A hint across blocks is the block-range run.  The one-block case is a single
+// column: it is evaluated by the ordinary kernels and the result block is AND-ed with a one-run mask vector afterwards.
+static int hint_mask_vector(bmx_ctx* ctx, uint64_t nbits, uint32_t ncols, uint64_t from, uint64_t to, bmx_vec** out)
+{
+    const uint32_t nb = (uint32_t)(from >> 16);
+    const uint32_t a = (uint32_t)(from & 65535u), b = (uint32_t)(to & 65535u);
+    std::vector<uint8_t> kinds(ncols, BMX_NULL); std::vector<uint32_t> offs(ncols, 0);
+    uint16_t gap[4]; uint32_t len = 0;
+    // run ends of the block: [0-run to a-1], 1-run to b, [0-run to 65535]
+    if (a > 0) gap[++len] = (uint16_t)(a - 1u);
+    gap[++len] = (uint16_t)b;
+    if (b < 65535u) gap[++len] = 65535u;
+    gap[0] = (uint16_t)((len << 3) | (a == 0 ? 1u : 0u));
+    kinds[nb] = BMX_GAP;
+    return bmx_vec_upload(ctx, nbits, ncols, kinds.data(), offs.data(), nullptr, 0, gap, len + 1u, out);
+}
+
+int bmx_pipeline_run_results_hint(bmx_ctx* ctx, bmx_pipeline* p, uint64_t from, uint64_t to, bmx_vec** results_out,
+                                  uint64_t* counts_out, const bmx_vec* or_target_in, bmx_vec** or_target_out)
+{
+    ARGCHK(ctx && p && p->ctx == ctx && (results_out || or_target_out || counts_out));
+    if (from > to) { g_last_error = "range hint: from > to"; return BMX_ERR_RANGE; }
+    const uint64_t nbf = from >> 16, nbt = to >> 16;
+    const bool whole = (from & 65535u) == 0 && (to & 65535u) == 65535u;
+    if (nbf != nbt || whole || nbf >= p->ncols) {
+        uint32_t lo = (uint32_t)std::min<uint64_t>(nbf, 0xFFFFFFFEull), hi = (uint32_t)std::min<uint64_t>(nbt + 1, 0xFFFFFFFFull);
+        if (!results_out && !or_target_out) return bmx_pipeline_run_counts(ctx, p, lo, hi, counts_out);
+        return run_results_impl(ctx, p, lo, hi, results_out, counts_out, or_target_in, or_target_out);
+    }
+    // one block, partly covered: evaluate the column, then AND with the bit range
+    std::vector<bmx_vec*> res(p->ngroups, nullptr);
+    int rc = run_results_impl(ctx, p, (uint32_t)nbf, (uint32_t)nbf + 1u, res.data(), nullptr, nullptr, nullptr);
+    if (rc) return rc;
+    auto cleanup = [&]() { for (bmx_vec*& r : res) if (r) { bmx_vec_free(ctx, r); r = nullptr; } };
+    bmx_vec* mask = nullptr;
+    if ((rc = hint_mask_vector(ctx, p->nbits, p->ncols, from, to, &mask))) { cleanup(); return rc; }
+    for (uint32_t g = 0; g < p->ngroups && !rc; ++g) {
+        if (counts_out) counts_out[g] = 0;
+        if (!res[g]) continue;
+        bmx_vec* m = nullptr;
+        rc = bmx_op2(ctx, BMX_AND, res[g], mask, 1, &m);
+        bmx_vec_free(ctx, res[g]); res[g] = nullptr;
+        if (rc) break;
+        if (m->counts[BMX_FULL] + m->counts[BMX_BIT] + m->counts[BMX_GAP] == 0) { bmx_vec_free(ctx, m); continue; }
+        res[g] = m;
+        if (counts_out) rc = bmx_count(ctx, m, &counts_out[g]);
+    }
+    bmx_vec_free(ctx, mask);
+    if (!rc && or_target_out) {
+        std::vector<const bmx_vec*> src;
+        if (or_target_in) src.push_back(or_target_in);
+        for (bmx_vec* r : res) if (r) src.push_back(r);
+        *or_target_out = nullptr;
+        rc = agg_or_impl(ctx, src.data(), src.size(), 1, or_target_out);
+    }
+    if (rc) { cleanup(); return rc; }
+    if (results_out) for (uint32_t g = 0; g < p->ngroups; ++g) results_out[g] = res[g];
+    else cleanup();
+    return BMX_OK;
+}
+
 static int find_first_impl(bmx_ctx* ctx, const bmx_vec* const* src_and, size_t n_and, const bmx_vec* const* src_sub, size_t n_sub,
                            bool ranged, uint64_t from, uint64_t to, int* found, uint64_t* idx)
 {
@@ -1886,6 +2000,19 @@ static int find_first_impl(bmx_ctx* ctx, const bmx_vec* const* src_and, size_t n
     if (e != hipSuccess || e2 != hipSuccess) return fail_hip(e != hipSuccess ? e : e2, "bmx_find_first_and_sub", __LINE__);
     if (ctx->h_small[0] != ~0ull) { *found = 1; *idx = ctx->h_small[0]; }
     return BMX_OK;
+}
+
+int bmx_agg_and_sub_indices(bmx_ctx* ctx, const bmx_vec* const* src_and, size_t n_and,
+                            const bmx_vec* const* src_sub, size_t n_sub, int width, void* out, uint64_t cap, uint64_t* n)
+{
+    ARGCHK(n);
+    *n = 0;
+    bmx_vec* t = nullptr; int any = 0;
+    int rc = bmx_agg_and_sub(ctx, src_and, n_and, src_sub, n_sub, &t, &any);
+    if (rc) return rc;
+    if (any) rc = bmx_vec_to_indices(ctx, t, width, out, cap, n);
+    bmx_vec_free(ctx, t);
+    return rc;
 }
 
 int bmx_find_first_and_sub(bmx_ctx* ctx, const bmx_vec* const* src_and, size_t n_and,

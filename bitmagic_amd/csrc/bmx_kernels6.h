@@ -303,3 +303,70 @@ void k_coll_apply(const u32* __restrict__ runs, const u64* __restrict__ off, con
     __syncthreads();
     if (wave == 0) { Blk b; blk_from_lds(b, U, lane); store_result(b, c, 1, slab, desc, st, lane); }
 }
+
+// ---------------------------------------------------------------------------
+// Index-list output: a vector as SORTED positions of its set bits -- what an inverted-index consumer reads back
+// (aggregator::combine_and_sub(BII bi, ...) src/bmaggregator.h:1226-1284 walks the result blocks through
+// for_each_bit_blk / bit_visitor_back_inserter_adaptor; sparse_vector_scanner::find_eq(sv, value, BII)
+// src/bmsparsevec_algo.h:1096).  Two passes: per-block popcounts (k_block_counts) + running sum (k_rs_scan), then one
+// wave per block writes its positions behind the blocks before it (k_expand_indices).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256)
+void k_block_counts(const u64* __restrict__ desc, u32 nblocks, u32* __restrict__ bcount)
+{
+    u32 lane = lane_id(), wave = threadIdx.x >> 6;
+    u32 nb = uniform32(blockIdx.x * 4u + wave);
+    if (nb >= nblocks) return;
+    u64 d = uniform64(desc[nb]);
+    u32 k = DESC_K(d), c = 0;
+    if (k == K_FULL) c = 65536u;
+    else if (k == K_BIT) { Blk b; blk_load(b, as_gc4(DESC_P(d)), lane); c = wave_sum(blk_lane_popcount(b)); }
+    else if (k == K_GAP) c = wave_sum(gap_lane_popcount(as_gc16(DESC_P(d)), lane, GMETA(d)));
+    if (lane == 0) bcount[nb] = c;
+}
+
+template <typename T>
+__device__ __forceinline__ void emit_word_bits(u32 w, u64 base, T* __restrict__ out, u64& off)
+{
+    while (w) { u32 b = (u32)__builtin_ctz(w); out[off++] = (T)(base + b); w &= w - 1u; }
+}
+
+// T = u32 / u64 positions.  rcount = inclusive running count per block; positions at or beyond `cap` are not written
+// (the host checks the total against the capacity before it reads anything)
+template <typename T>
+__global__ __launch_bounds__(256)
+void k_expand_indices(const u64* __restrict__ desc, u32 nblocks, const u64* __restrict__ rcount, T* __restrict__ out, u64 cap, u64 pos_base)
+{
+    __shared__ u32 lds[4 * 2048];
+    u32 lane = lane_id(), wave = threadIdx.x >> 6;
+    u32 nb = uniform32(blockIdx.x * 4u + wave);
+    if (nb >= nblocks) return;
+    u64 d = uniform64(desc[nb]);
+    u32 k = DESC_K(d);
+    if (k == K_NULL) return;
+    u64 first = nb ? rcount[nb - 1u] : 0ull;
+    u64 last = rcount[nb];
+    if (last > cap) return;                                   // (never read: the call fails with the needed size)
+    u64 bit0 = pos_base + ((u64)nb << 16);
+    if (k == K_FULL) {
+        for (u32 i = lane; i < 65536u; i += 64u) out[first + i] = (T)(bit0 + i);
+        return;
+    }
+    Blk b;
+    blk_from_desc(d, b, lds + wave * 2048u, lane);
+    u64 row_off = first;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        // row i = words i*256 .. i*256+255; lane l holds the four consecutive words i*256 + 4l .. + 3
+        u32 c = (u32)__popc(b.r[i].x) + (u32)__popc(b.r[i].y) + (u32)__popc(b.r[i].z) + (u32)__popc(b.r[i].w);
+        u32 incl = wave_scan_incl(c, lane);
+        u32 tot = uniform32(__shfl(incl, 63, 64));
+        u64 off = row_off + (incl - c);
+        u64 wb = bit0 + ((u64)((u32)i * 256u + lane * 4u) << 5);
+        emit_word_bits<T>(b.r[i].x, wb, out, off);
+        emit_word_bits<T>(b.r[i].y, wb + 32u, out, off);
+        emit_word_bits<T>(b.r[i].z, wb + 64u, out, off);
+        emit_word_bits<T>(b.r[i].w, wb + 96u, out, off);
+        row_off += tot;
+    }
+}

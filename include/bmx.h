@@ -126,6 +126,13 @@ int bmx_vec_operand_bytes(bmx_ctx* ctx, const bmx_vec* v, uint64_t* bytes);
  * Array sizes come from bmx_vec_info; any pointer may be NULL to skip that part. */
 int bmx_vec_download(bmx_ctx* ctx, const bmx_vec* v, uint8_t* kinds, uint32_t* offs,
                      uint32_t* bit_slab, uint16_t* gap_slab);
+/* The vector as the SORTED positions of its set bits -- the index-list form an inverted-index consumer reads back (what
+ * bm::bvector<>::enumerator / bm::for_each_bit_blk feed into a back-insert iterator, src/bmaggregator.h:1226-1284,
+ * src/bmalgo_impl.h for_each_bit).  width = 4 (uint32_t positions; vectors of <= 2^32 bits) or 8 (uint64_t).
+ * *n = number of set bits; when it exceeds cap nothing is written and BMX_ERR_RANGE is returned (call again with a
+ * buffer of *n entries; bmx_count gives the number in advance).  _dev: the buffer is device memory. */
+int bmx_vec_to_indices(bmx_ctx* ctx, const bmx_vec* v, int width, void* out, uint64_t cap, uint64_t* n);
+int bmx_vec_to_indices_dev(bmx_ctx* ctx, const bmx_vec* v, int width, void* d_out, uint64_t cap, uint64_t* n);
 /* expand to raw words (export twin of bit_import_u32) */
 int bmx_vec_to_words(bmx_ctx* ctx, const bmx_vec* v, uint32_t* words, uint64_t nwords);
 
@@ -152,6 +159,10 @@ int bmx_agg_or_opt(bmx_ctx* ctx, const bmx_vec* const* src, size_t n, int opt_co
 int bmx_agg_and_sub(bmx_ctx* ctx, const bmx_vec* const* src_and, size_t n_and,
                     const bmx_vec* const* src_sub, size_t n_sub,
                     bmx_vec** result, int* any);
+/* aggregator::combine_and_sub(BII bi, and, n_and, sub, n_sub) / combine_and_sub_bi(bi)  src/bmaggregator.h:450,533,1068,1226:
+ * the AND-SUB result as sorted positions instead of a bit-vector (same buffer rules as bmx_vec_to_indices). */
+int bmx_agg_and_sub_indices(bmx_ctx* ctx, const bmx_vec* const* src_and, size_t n_and,
+                            const bmx_vec* const* src_sub, size_t n_sub, int width, void* out, uint64_t cap, uint64_t* n);
 /* aggregator::find_first_and_sub(idx, and, n_and, sub, n_sub)  src/bmaggregator.h:1458:
  * index of the first set bit of the AND-SUB result, nothing materialised. */
 int bmx_find_first_and_sub(bmx_ctx* ctx, const bmx_vec* const* src_and, size_t n_and,
@@ -248,6 +259,12 @@ int bmx_pipeline_run_results(bmx_ctx* ctx, bmx_pipeline* p, bmx_vec** results_ou
  * set_range_hint: only block columns [nb_from, nb_to) are visited (:1312-1346); results hold nothing outside */
 int bmx_pipeline_run_results_range(bmx_ctx* ctx, bmx_pipeline* p, uint32_t nb_from, uint32_t nb_to, bmx_vec** results_out,
                                    uint64_t* counts_out, const bmx_vec* or_target_in, bmx_vec** or_target_out);
+/* the same given the aggregator's range hint itself (set_range_hint(from, to), src/bmaggregator.h:481,974): block columns
+ * [from >> 16, to >> 16] are visited and -- exactly like the reference -- a hint whose ends lie in ONE block also restricts that
+ * column to the bit range [from & 65535, to & 65535] (range_gap_blk_, :980-988,2354-2358); results_out / or_target_out may
+ * be NULL (counts only). */
+int bmx_pipeline_run_results_hint(bmx_ctx* ctx, bmx_pipeline* p, uint64_t from, uint64_t to, bmx_vec** results_out,
+                                  uint64_t* counts_out, const bmx_vec* or_target_in, bmx_vec** or_target_out);
 /* algorithmic operand bytes one run over [nb_from, nb_to) must read
  * (8192 B per bit-block operand, 2*(len+1) B per GAP operand; NULL/FULL: 0) */
 int bmx_pipeline_operand_bytes(bmx_ctx* ctx, bmx_pipeline* p, uint32_t nb_from, uint32_t nb_to,

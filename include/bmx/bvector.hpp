@@ -130,6 +130,22 @@ public:
 
     /// bvector<>::count()  src/bm.h:2431
     size_type count() const { uint64_t c = 0; if (h_) check(bmx_count(ctx_->handle(), h_, &c)); return c; }
+    /// the sorted positions of the set bits (device compaction, bmx_vec_to_indices): what bm::bvector<>::enumerator or
+    /// bm::for_each_bit would feed into a container, in one call
+    void to_indices(std::vector<size_type>& out) const
+    {
+        out.clear();
+        if (!h_) return;
+        uint64_t n = count();
+        out.resize(n);
+        if (n) check(bmx_vec_to_indices(ctx_->handle(), h_, 8, out.data(), n, &n));
+    }
+    /// feeds every set bit, ascending, into a back-insert style iterator (*bi = idx)
+    template <class BII> void copy_to(BII bi) const
+    {
+        std::vector<size_type> idx; to_indices(idx);
+        for (size_type p : idx) { *bi = p; ++bi; }
+    }
     /// bvector<>::any() / find(pos) (src/bm.h:1593): first set bit = find_first_and_sub over the one-vector AND group
     bool find(size_type& pos) const
     {
@@ -391,6 +407,21 @@ public:
         bv_target.adopt(r);
         return any != 0;
     }
+    /// combine_and_sub_bi(bi) :450,1068 / combine_and_sub(bi, and, n, sub, n) :533,1226: the AND-SUB result as sorted
+    /// positions fed into a back-insert iterator instead of a target vector (bmx_agg_and_sub_indices: the result is
+    /// compacted to positions on the device, only those cross PCIe).  @return true when anything was found
+    template <class BII> bool combine_and_sub_bi(BII bi)
+    { return combine_and_sub(bi, ag_.arg_bv0.data(), ag_.arg_bv0.size(), ag_.arg_bv1.data(), ag_.arg_bv1.size()); }
+    template <class BII, class = decltype(*std::declval<BII&>() = size_type(0))>
+    bool combine_and_sub(BII bi, const bvector_type_const_ptr* bv_src_and, size_t src_and_size,
+                         const bvector_type_const_ptr* bv_src_sub, size_t src_sub_size)
+    {
+        if (!bv_src_and || !src_and_size) return false;
+        BV t(*ctx_);
+        bool any = combine_and_sub(t, bv_src_and, src_and_size, bv_src_sub, src_sub_size, false);
+        if (any) t.copy_to(bi);
+        return any;
+    }
     /// set_range_hint(from, to) :481,974 -- where results need to be searched: find_first_and_sub visits the block
     /// columns of the range only (one-block ranges are also bit-masked), combine_and_sub(pipe) honours it when the
     /// pipeline options enable search masks (is_masks(), :1312-1346).  @return true if the range is one-block bound
@@ -449,25 +480,29 @@ public:
         if (!pipe.is_complete()) throw error(BMX_ERR_BADARG, "pipeline is not complete()");
         if (!pipe.size()) return;
         typedef typename TPipe::options_type opt;
-        // search masks enabled + a range hint: only the block columns of the hint are visited (:1312-1346)
-        uint32_t nbf = 0, nbt = 0xFFFFFFFFu;
-        if (opt::is_masks() && range_set_) { nbf = (uint32_t)(range_from_ >> 16); nbt = (uint32_t)(range_to_ >> 16) + 1u; }
+        // search masks enabled + a range hint: only the block columns of the hint are visited (:1312-1346); a hint inside
+        // ONE block is bit-masked as well (range_gap_blk_, :980-988) -- bmx_pipeline_run_results_hint does both
+        const bool hinted = opt::is_masks() && range_set_;
         if (opt::is_make_results() || pipe.or_target_) {
             std::vector<bmx_vec*> res(pipe.size(), nullptr);
             bmx_vec* ort = nullptr;
             const bmx_vec* ort_in = (pipe.or_target_ && !pipe.or_target_->empty_handle()) ? pipe.or_target_->handle() : nullptr;
-            check(bmx_pipeline_run_results_range(ctx_->handle(), pipe.h_, nbf, nbt, opt::is_make_results() ? res.data() : nullptr,
-                                                 (opt::is_make_results() && opt::is_compute_counts()) ? pipe.counts_.data() : nullptr,
-                                                 ort_in, pipe.or_target_ ? &ort : nullptr));
+            bmx_vec** rp = opt::is_make_results() ? res.data() : nullptr;
+            uint64_t* cp = (opt::is_make_results() && opt::is_compute_counts()) ? pipe.counts_.data() : nullptr;
+            if (hinted) check(bmx_pipeline_run_results_hint(ctx_->handle(), pipe.h_, range_from_, range_to_, rp, cp, ort_in, pipe.or_target_ ? &ort : nullptr));
+            else check(bmx_pipeline_run_results_range(ctx_->handle(), pipe.h_, 0u, 0xFFFFFFFFu, rp, cp, ort_in, pipe.or_target_ ? &ort : nullptr));
             for (size_t i = 0; i < pipe.results_.size(); ++i) delete pipe.results_[i];
             pipe.results_.assign(pipe.size(), nullptr);
             for (size_t g = 0; g < res.size(); ++g)
                 if (res[g]) { pipe.results_[g] = new BV(*ctx_); pipe.results_[g]->adopt(res[g]); }
             if (pipe.or_target_) pipe.or_target_->adopt(ort);
-            if (opt::is_compute_counts() && !opt::is_make_results())
-                check(bmx_pipeline_run_counts(ctx_->handle(), pipe.h_, nbf, nbt, pipe.counts_.data()));
+            if (opt::is_compute_counts() && !opt::is_make_results()) {
+                if (hinted) check(bmx_pipeline_run_results_hint(ctx_->handle(), pipe.h_, range_from_, range_to_, nullptr, pipe.counts_.data(), nullptr, nullptr));
+                else check(bmx_pipeline_run_counts(ctx_->handle(), pipe.h_, 0u, 0xFFFFFFFFu, pipe.counts_.data()));
+            }
         } else if (opt::is_compute_counts()) {
-            check(bmx_pipeline_run_counts(ctx_->handle(), pipe.h_, nbf, nbt, pipe.counts_.data()));
+            if (hinted) check(bmx_pipeline_run_results_hint(ctx_->handle(), pipe.h_, range_from_, range_to_, nullptr, pipe.counts_.data(), nullptr, nullptr));
+            else check(bmx_pipeline_run_counts(ctx_->handle(), pipe.h_, 0u, 0xFFFFFFFFu, pipe.counts_.data()));
         }
     }
 

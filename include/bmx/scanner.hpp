@@ -81,6 +81,16 @@ public:
         return agg_.combine_and_sub(bv_out, g.arg_bv0.data(), g.arg_bv0.size(), g.arg_bv1.data(), g.arg_bv1.size(), false);
     }
 
+    /// find_eq(sv, value, bi)  src/bmsparsevec_algo.h:1096: the matching rows as sorted indices fed into a back-insert iterator
+    template <class BII, class = decltype(*std::declval<BII&>() = size_type(0))>
+    bool find_eq(uint64_t value, BII bi)
+    {
+        bvector t(*ctx_);
+        bool f = find_eq(value, t);
+        if (f) t.copy_to(bi);
+        return f;
+    }
+
     /// index of the first row equal to `value`
     bool find_first_eq(uint64_t value, size_type& idx)
     {

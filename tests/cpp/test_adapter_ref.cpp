@@ -5,6 +5,7 @@
 // the binary travels to the GPU box and is run by tests/test_cpp_facade.py (-m gpu).
 #include <cstdio>
 #include <cstdlib>
+#include <iterator>
 #include <vector>
 
 #include "bm.h"
@@ -183,6 +184,11 @@ int main()
             bvect::size_type ri = 0; bmx::size_type gi = 0;
             bool rff = rs.find_eq(sv, v, ri), gff = gs.find_first_eq(v, gi);       // :1111 -> find_first_eq :2417
             REQUIRE(rff == gff && (!rff || ri == gi));
+            // index-list output: find_eq(sv, value, BII) :1096 -- sorted positions through a back-insert iterator
+            { std::vector<bvect::size_type> rpos; std::vector<bmx::size_type> gpos;
+              rs.find_eq(sv, v, std::back_inserter(rpos)); bool gfi = gs.find_eq(v, std::back_inserter(gpos));
+              REQUIRE(gfi == !gpos.empty() && rpos.size() == gpos.size());
+              for (size_t k = 0; k < rpos.size(); ++k) REQUIRE((bmx::size_type)rpos[k] == gpos[k]); }
             vals.push_back(v); ref_counts.push_back(r.count());
         }
         got.resize(vals.size());
@@ -276,6 +282,20 @@ int main()
             bvect r, g;
             bool rf = ragg.combine_and_sub(r), gf = dagg.combine_and_sub(g);
             REQUIRE(rf == gf && g.compare(r) == 0);
+            if (round == 0) {
+                // combine_and_sub_bi(BII) :450,1068 on resident vectors: sorted positions = the reference's bulk-insert output
+                bmx::aggregator<bmx::bvector> bagg(ctx);
+                for (unsigned v = 0; v < 3; ++v) bagg.add(&gv[v]);
+                bagg.add(&gv[3], 1);
+                std::vector<bvect::size_type> rpos; std::vector<bmx::size_type> gpos;
+                bool rb = ragg.combine_and_sub_bi(std::back_inserter(rpos)), gb = bagg.combine_and_sub_bi(std::back_inserter(gpos));
+                REQUIRE(rb == gb && rpos.size() == gpos.size() && rpos.size() == r.count());
+                for (size_t k = 0; k < rpos.size(); ++k) REQUIRE((bmx::size_type)rpos[k] == gpos[k]);
+                std::vector<bmx::size_type> all; gv[1].to_indices(all);
+                REQUIRE(all.size() == hv[1].count());
+                bvect::enumerator en = hv[1].first();
+                for (size_t k = 0; k < all.size(); ++k, ++en) REQUIRE(en.valid() && (bmx::size_type)*en == all[k]);
+            }
             bvect::size_type ri = 0, gi = 0;
             REQUIRE(ragg.find_first_and_sub(ri) == dagg.find_first_and_sub(gi) && ri == gi);
             ragg.combine_and(r); dagg.combine_and(g); REQUIRE(g.compare(r) == 0);

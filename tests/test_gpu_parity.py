@@ -1458,3 +1458,56 @@ def test_slice_scanner_vs_reference_golden(ctx, golden, with_null):
         except (TypeError, ValueError):
             continue
         assert [int(x) for x in got] == g["eq_counts"], method
+
+
+def test_index_list_output(ctx, port):
+    """bmx_vec_to_indices / combine_and_sub_bi / find_eq(value, BII): the result as SORTED positions (device compaction:
+    per-block popcounts, running sum, per-word expansion) equals the set bits of the vector -- NULL, FULL, bit, sparse
+    and dense GAP blocks, 32- and 64-bit positions, the empty vector, a buffer that is too small"""
+    import ctypes as C
+    from bitmagic_amd import _ffi
+    rng = np.random.default_rng(31)
+    nblk = 9
+    nbits = nblk * 65536 - 4000
+    words = np.zeros(nblk * 2048, np.uint32)
+    words[2048:4096] = 0xFFFFFFFF                                                         # FULL
+    words[2 * 2048:3 * 2048] = rng.integers(0, 1 << 32, 2048, dtype=np.uint64).astype(np.uint32)       # bit
+    for b in rng.integers(3 * 65536, 4 * 65536, 50): words[b >> 5] |= np.uint32(1 << (b & 31))         # sparse GAP
+    words[4 * 2048 + 100:4 * 2048 + 1900] = 0xFFFFFFFF                                   # wide run (GAP)
+    words[6 * 2048:7 * 2048] = 0xFFFFFFFF; words[6 * 2048 + 7] = 0xFFFF7FFF               # nearly full (GAP, dense)
+    for b in rng.integers(8 * 65536, nbits, 3000): words[b >> 5] |= np.uint32(1 << (b & 31))           # last, partial block
+    p = port.import_words(words, True, nbits)
+    assert set(p.flatten()[0].tolist()) == {0, 1, 2, 3}
+    v = bm.bvector.from_block_table(ctx, nbits, *p.flatten())
+    exp = np.flatnonzero(np.unpackbits(words.view(np.uint8), bitorder="little")).astype(np.uint64)
+    got = v.to_indices()
+    assert got.dtype == np.uint64 and (got == exp).all() and got.size == p.count()
+    got32 = v.to_indices(4)
+    assert got32.dtype == np.uint32 and (got32 == exp.astype(np.uint32)).all()
+    # too small a buffer: nothing is written, the needed size comes back
+    n = C.c_uint64()
+    buf = np.zeros(10, np.uint64)
+    rc = _ffi.lib().bmx_vec_to_indices(ctx._h, v._h, 8, buf.ctypes.data_as(C.c_void_p), 10, C.byref(n))
+    assert rc == _ffi.ERR_RANGE and n.value == exp.size and not buf.any()
+    empty = bm.bit_import_u32(ctx, np.zeros(4096, np.uint32), True)
+    assert empty.to_indices().size == 0
+    # aggregator: AND-SUB as positions
+    ws = [port.gen_words(777, i, 3000, nbits) | port.gen_words(777, 0xFFFFFFFF, 2000, nbits) for i in range(5)]
+    gv = [bm.bit_import_u32(ctx, w, True) for w in ws]
+    pv = [port.import_words(w, True, w.size * 32) for w in ws]
+    agg = bm.aggregator(ctx)
+    e = port.agg_and_sub(pv[:3], pv[3:])
+    ebits = np.flatnonzero(np.unpackbits(e.to_words(gv[0].info()["nblocks"] * 2048).view(np.uint8), bitorder="little"))
+    assert (agg.combine_and_sub_bi(gv[:3], gv[3:]) == ebits.astype(np.uint64)).all() and ebits.size > 0
+    agg.add(gv[0]); agg.add(gv[1]); agg.add(gv[4], 1)
+    e2 = port.agg_and_sub(pv[:2], pv[4:])
+    assert agg.combine_and_sub_bi().size == e2.count()
+    assert agg.combine_and_sub_bi([gv[0], empty], []).size == 0
+    # scanner: rows equal to a value as indices
+    col = rng.integers(0, 50, 3 * 65536 + 99).astype(np.uint64)
+    def upload(bits):
+        w = np.packbits(np.concatenate([bits.astype(np.uint8), np.zeros((-col.size) % 32, np.uint8)]), bitorder="little").view(np.uint32)
+        return bm.bit_import_u32(ctx, w, True)
+    sc = bm.slice_scanner(ctx, [upload(((col >> np.uint64(i)) & np.uint64(1)) != 0) for i in range(6)], size=col.size)
+    for val in (0, 1, 17, 49, 50, 63):
+        assert (sc.find_eq_indices(val) == np.flatnonzero(col == val).astype(np.uint64)).all(), val
