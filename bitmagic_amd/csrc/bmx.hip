@@ -462,6 +462,7 @@ int bmx_ctx_create(int device, void* stream, bmx_ctx** out)
     CTXCHK(hipMalloc((void**)&ctx->d_done, FOLD_DONE_WORDS * 4));
     CTXCHK(hipMemsetAsync(ctx->d_done, 0, FOLD_DONE_WORDS * 4, ctx->stream));
 #undef CTXCHK
+    { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, device) == hipSuccess && v > 0) ctx->max_lds_bytes = (uint32_t)v; else (void)hipGetLastError(); }
     if (const char* e = getenv("BMX_PACK_MAX_MB")) { long long mb = atoll(e); if (mb >= 0) ctx->pack_cap = (uint64_t)mb << 20; }
     if (const char* e = getenv("BMX_POOL_MAX_MB")) { long long mb = atoll(e); if (mb >= 0) ctx->pool_cap = (uint64_t)mb << 20; }
     // launch-shape knobs from the environment go through the same validation as bmx_ctx_set_tuning;
@@ -1141,10 +1142,13 @@ static int pipe_range(const bmx_pipeline* p, uint32_t& nb_from, uint32_t& nb_to)
 
 } // extern "C"
 // GAP-only pipelines with long operand lists: count the covering operands per position (k_pipe_counts_gapcount) instead
-// of applying them one by one.  gap_count: -1 = automatic (>= 32 operands per group on average), 0 = off, 1 = whenever it applies
+// of applying them one by one.  gap_count: -1 = automatic (>= 32 operands per group on average AND GAP blocks of >= 240 words on average), 0 = off, 1 = whenever it applies
 static bool use_gapcount(const bmx_ctx* ctx, const bmx_pipeline* p, uint64_t ops_of_group = 0)
 {
     if (ctx->gap_count == 0 || !p->has_gap || p->has_bit) return false;
+    // k_pipe_counts_gapcount needs 136 KiB of dynamic LDS (+ its static arrays): a device / runtime that does not grant
+    // that per workgroup keeps the run-by-run kernel instead of failing the run
+    if (ctx->max_lds_bytes < (16384u * 2u + 2048u) * 4u + 1024u) return false;
     if (ctx->gap_count > 0) return true;
     if (ops_of_group) return ops_of_group >= 32u && p->gap_avg_words >= 240u;          // one group (materialising form)
     // measured on the 256-way AND over 1e9-bit vectors: blocks of ~780 words (0.3 %) 2.71 -> 2.09 ms, ~390 words (0.15 %)

@@ -67,6 +67,7 @@ struct bmx_ctx {
     int gap_pack = -1;         // aggregation over >= 64 GAP-only operands through a packed collection: -1 = from the second use of an operand set, 0 = never, 1 = at first use
     uint64_t pack_cap = 96ull << 30, pack_bytes = 0, coll_tick = 0;
     float last_pack_ms = 0.f;
+    uint32_t max_lds_bytes = 160u * 1024u;   // hipDeviceAttributeMaxSharedMemoryPerBlock of the device (queried at creation)
     int rs_lanes = 0;          // rank: lanes per query (k_rank_l): 0 = automatic, 8 = the original kernel, 2, 4
     int xcd_swz = 1;
 };

@@ -271,6 +271,13 @@ struct FoldOut { u64* slots; u32* done; u64* out; };     // done: [0] global tic
 #define FOLD_DONE_WORDS (32u * (COUNT_SLOTS + 1u))
 
 // adds `v` to the workgroup's slot; true for the single thread that must fold (all slots are final then)
+// The ordering below (slot add performed before the ticket is drawn) rests on gfx9 semantics: a returning device-scope
+// atomic is counted by vmcnt, so `s_waitcnt vmcnt(0)` after it means "performed at L2".  gfx10+ count stores / atomics
+// without return in vscnt instead, and the HIP memory model as such gives relaxed atomics no order: refuse to build this
+// scheme for anything but the gfx9 family (this library targets gfx950 only) rather than count wrongly there.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__GFX9__)
+#error "fold_publish orders relaxed atomics with s_waitcnt vmcnt(0): valid on the gfx9 family (gfx90a/gfx942/gfx950) only"
+#endif
 __device__ __forceinline__ bool fold_publish(u64 v, FoldOut f)
 {
     u32 s_ = blockIdx.x % COUNT_SLOTS;

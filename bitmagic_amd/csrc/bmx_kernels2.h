@@ -759,12 +759,15 @@ void k_direct(const u64* const* __restrict__ descs, const u32* __restrict__ nblk
     __shared__ u32 cnt[8];                                         // nbitA, ngapA, nbitS, ngapS, decided
     u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     u32 c = col_from + blockIdx.x;
-    if (MODE == DIRECT_FIND_FIRST) {
-        u64 cur = __hip_atomic_load(best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (((u64)c << 16) > cur) return;                          // an earlier column already has a hit (uniform per workgroup: one load each, monotone)
-    }
     if (tid < 8) cnt[tid] = 0u;
-    __syncthreads();
+    if (MODE == DIRECT_FIND_FIRST) {
+        // an earlier column already has a hit: the whole workgroup leaves.  ONE thread reads the best hit so far and the
+        // workgroup branches on that single value after a barrier -- *best only moves down, so per-wave loads could see
+        // different values and part of a workgroup would skip the barriers below
+        if (tid == 0) cnt[5] = (((u64)c << 16) > __hip_atomic_load(best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) ? 1u : 0u;
+        __syncthreads();
+        if (cnt[5]) return;
+    } else __syncthreads();
     for (u32 i = tid; i < n_and + n_sub; i += blockDim.x) {
         bool is_sub = i >= n_and;
         u32 nb = nblk[i];

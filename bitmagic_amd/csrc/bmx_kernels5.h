@@ -11,8 +11,8 @@
 // take two LDS atomics per 1-run whatever its length; cover(p) = sum_{q<=p} S[q] - sum_{q<p} E[q] is one prefix scan over
 // the block; the AND of n operands is cover == n, the SUB group is cover != 0.
 // A 1024-thread workgroup owns a (column, group); the first AND operand is decoded into the bitmap B, the others are
-// counted in chunks of <= 255 (byte counters); run ends are fetched with 16-byte loads, 8 ends per lane, four operands
-// ahead.  LDS: S 64 KiB + E 64 KiB + B 8 KiB.
+// counted in chunks of <= 255 (byte counters); run ends are fetched with 16-byte loads, 8 ends per lane, GC_AHEAD (6)
+// operands ahead.  LDS: S 64 KiB + E 64 KiB + B 8 KiB.
 // ---------------------------------------------------------------------------
 #define GC_WAVES 16u
 #define GC_AHEAD 6

@@ -399,6 +399,10 @@ public:
     }
 
     // ---- upload cache control ----
+    // Device copies are keyed by the host vector's ADDRESS plus a stamp (size, top size, sub-array pointers, a sampled
+    // content hash).  The reference aggregator reads live blocks; this drop-in does so for mutable vectors by uploading
+    // them again on every operation.  Copies that are KEPT across operations -- frozen (read-only) vectors, and mutable
+    // ones under set_cache_mutable(true) -- must be invalidate()d before the vector is destroyed or changed in place.
     void set_cache_mutable(bool on) noexcept { cache_mutable_ = on; }
     void invalidate(const BV* bv) { cache_.erase(bv); }
     void invalidate_all() { cache_.clear(); }
@@ -421,6 +425,22 @@ private:
         uint64_t h = 1469598103934665603ull;
         bm::word_t*** root = bman.top_blocks_root();
         for (unsigned i = 0; i < bman.top_block_size(); ++i) { h ^= (uint64_t)(uintptr_t)root[i]; h *= 1099511628211ull; }
+        // a cheap CONTENT sample on top of the shape: up to 64 blocks spread over the vector, pointer + three words each.
+        // It catches a vector that was destroyed and replaced by another one at the same address with the allocator
+        // handing out the same sub-arrays; it cannot prove equality -- call invalidate(bv) before a cached
+        // vector is destroyed or (with set_cache_mutable) changed in place.
+        const unsigned nb_total = bman.top_block_size() * bm::set_sub_array_size;
+        const unsigned step = nb_total > 64u ? nb_total / 64u : 1u;
+        for (unsigned nb = 0; nb < nb_total; nb += step) {
+            bm::word_t** sub = root[nb >> bm::set_array_shift];
+            if (!sub || sub == (bm::word_t**)FULL_BLOCK_FAKE_ADDR) continue;
+            const bm::word_t* blk = sub[nb & bm::set_array_mask];
+            h ^= (uint64_t)(uintptr_t)blk + nb; h *= 1099511628211ull;
+            if (!blk || blk == FULL_BLOCK_FAKE_ADDR) continue;
+            if (BM_IS_GAP(blk)) { const bm::gap_word_t* g = BMGAP_PTR(blk); h ^= ((uint64_t)g[0] << 16) | g[1]; }
+            else h ^= ((uint64_t)blk[0] << 32) ^ ((uint64_t)blk[bm::set_block_size / 2] << 16) ^ blk[bm::set_block_size - 1];
+            h *= 1099511628211ull;
+        }
         st.h = h;
         return st;
     }
