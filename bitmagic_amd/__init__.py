@@ -641,11 +641,16 @@ class slice_scanner:
     effective_slices(); size = sv.size() (rows; default: the longest slice); not_null = sv.get_null_bvector().
     A batch of equality searches is one counts-only pipeline launch; a comparison search is one pass over the planes."""
 
-    def __init__(self, ctx: context, slices: Sequence[bvector | None], size: int | None = None, not_null: bvector | None = None):
+    def __init__(self, ctx: context, slices: Sequence[bvector | None], size: int | None = None, not_null: bvector | None = None,
+                 signed: bool = False):
+        """signed: the planes of a bm::sparse_vector<int, ..> -- slices[0] is the sign, slices[1..] the magnitude
+        (base_sparse_vector::s2u, src/bmbmatrix.h:2536): the comparison searches then take signed bounds
+        (find_gt_horizontal_s, src/bmsparsevec_algo.h:1484,3033)"""
         self.ctx, self.slices = ctx, list(slices)
         self.agg = aggregator(ctx)
         self.not_null = not_null
         self._size = size
+        self.signed = bool(signed)
 
     def size(self) -> int:
         if self._size is None:
@@ -675,16 +680,63 @@ class slice_scanner:
         return a, s
 
     def _compare(self, pred: int, v0: int = 0, v1: int = 0, count_only: bool = False):
-        if v0 < 0 or v1 < 0 or v0 >= 1 << 64 or v1 >= 1 << 64:
-            raise BmxError(_ffi.ERR_RANGE, "Incorrect range or index", "unsigned 64-bit values only")
         arr = (C.c_void_p * max(len(self.slices), 1))()
         for i, p in enumerate(self.slices):
             arr[i] = p._h if p is not None else None
         h, cnt = C.c_void_p(), C.c_uint64()
-        check(lib().bmx_slice_compare(self.ctx._h, arr, len(self.slices), pred, v0, v1, self.size(),
-                                      self.not_null._h if self.not_null is not None else None,
+        nn = self.not_null._h if self.not_null is not None else None
+        if self.signed:
+            if not (-(1 << 63) <= v0 < (1 << 63) and -(1 << 63) <= v1 < (1 << 63)):
+                raise BmxError(_ffi.ERR_RANGE, "Incorrect range or index", "signed 64-bit values only")
+            check(lib().bmx_slice_compare_signed(self.ctx._h, arr, len(self.slices), pred, v0, v1, self.size(), nn,
+                                                 None if count_only else C.byref(h), C.byref(cnt)))
+            return cnt.value if count_only else bvector(self.ctx, h)
+        if v0 < 0 or v1 < 0 or v0 >= 1 << 64 or v1 >= 1 << 64:
+            raise BmxError(_ffi.ERR_RANGE, "Incorrect range or index", "unsigned 64-bit values only")
+        check(lib().bmx_slice_compare(self.ctx._h, arr, len(self.slices), pred, v0, v1, self.size(), nn,
                                       None if count_only else C.byref(h), C.byref(cnt)))
         return cnt.value if count_only else bvector(self.ctx, h)
+
+    def compare_stat(self, pred: int, v0: int = 0, v1: int = 0):
+        """-> (count, plane_bytes): the count of a comparison search and the plane bytes its walk had to read"""
+        arr = (C.c_void_p * max(len(self.slices), 1))()
+        for i, p in enumerate(self.slices):
+            arr[i] = p._h if p is not None else None
+        cnt, pb = C.c_uint64(), C.c_uint64()
+        check(lib().bmx_slice_compare_stat(self.ctx._h, arr, len(self.slices), pred, v0, v1, self.size(),
+                                           self.not_null._h if self.not_null is not None else None, C.byref(cnt), C.byref(pb)))
+        return cnt.value, pb.value
+
+    def find_eq_in(self, values, bv_out: "bvector | None" = None) -> "bvector":
+        """find_eq(sv, start, end, bv_out)  src/bmsparsevec_algo.h:1399: rows whose value is IN the list, OR-ed into
+        bv_out (as the reference does); one pipeline run with an OR target (one AND-SUB group per distinct value)"""
+        vals = sorted(set(int(v) for v in values))
+        acc = bv_out
+        if 0 in vals:
+            z = self._compare(CMP_EQ, 0)
+            acc = z if acc is None else bvector.bit_or(acc, z, opt_compress)
+        pipe = pipeline(self.ctx, agg_opt_disable_bvects_and_counts)
+        pipe.set_or_target(acc)
+        for v in vals:
+            if v == 0:
+                continue
+            g = self._groups(v)
+            if g is None:
+                continue
+            ag = pipe.add()
+            for x in g[0]: ag.add(x, 0)
+            for x in g[1]: ag.add(x, 1)
+        if pipe.size():
+            pipe.complete()
+            self.agg.combine_and_sub(pipe)
+            return pipe.get_or_target()
+        return acc if acc is not None else self._compare(CMP_GT, (1 << 64) - 1)       # nothing to look for: empty result
+
+    def invert(self, bv: "bvector") -> "bvector":
+        """scanner.invert(sv, bv)  src/bmsparsevec_algo.h:2321: the other rows of [0, size), NULL rows excluded"""
+        zero_planes = slice_scanner(self.ctx, [], size=self.size(), not_null=self.not_null)
+        rows = zero_planes._compare(CMP_ZERO)            # no planes: every (not NULL) row of [0, size)
+        return bvector.bit_sub(rows, bv, opt_compress)
 
     def find_gt(self, value: int) -> bvector: return self._compare(CMP_GT, value)              # :2690
     def find_ge(self, value: int) -> bvector: return self._compare(CMP_GE, value)              # :2717

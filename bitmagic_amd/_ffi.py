@@ -77,6 +77,8 @@ def lib() -> C.CDLL:
         "bmx_agg_shift_right_and": (i32, [vp, P(vp), C.c_size_t, i32, i32, P(vp), P(i32)]),
         "bmx_agg_shift_right_and_count": (i32, [vp, P(vp), C.c_size_t, P(u64)]),
         "bmx_slice_compare": (i32, [vp, P(vp), C.c_size_t, i32, u64, u64, u64, vp, P(vp), P(u64)]),
+        "bmx_slice_compare_signed": (i32, [vp, P(vp), C.c_size_t, i32, C.c_int64, C.c_int64, u64, vp, P(vp), P(u64)]),
+        "bmx_slice_compare_stat": (i32, [vp, P(vp), C.c_size_t, i32, u64, u64, u64, vp, P(u64), P(u64)]),
         "bmx_slice_eq_counts": (i32, [vp, P(vp), C.c_size_t, vp, C.c_size_t, u64, vp, vp]),
         "bmx_collection_prepare": (i32, [vp, P(vp), C.c_size_t, i32]),
         "bmx_ctx_pack_stats": (i32, [vp, P(u32), P(u64), P(C.c_float)]),

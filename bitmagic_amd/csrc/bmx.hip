@@ -2111,19 +2111,87 @@ int bmx_agg_shift_right_and_count(bmx_ctx* ctx, const bmx_vec* const* src, size_
 }
 
 // sparse_vector_scanner<SV>::find_gt/ge/lt/le/range/eq/zero/nonzero over resident slices (bmx_kernels4.h)
-int bmx_slice_compare(bmx_ctx* ctx, const bmx_vec* const* slices, size_t nslices, int pred, uint64_t v0, uint64_t v1,
-                      uint64_t size, const bmx_vec* not_null, bmx_vec** result, uint64_t* count)
+// shared body of bmx_slice_compare / bmx_slice_compare_signed: `slices` are the planes the magnitude walk runs over;
+// sign / sign_mode: the sign plane of a signed container and how the magnitude predicate combines with it (bmx_kernels4.h);
+// null_correct: the predicate admits value 0, so NULL rows (stored as 0) must be removed
+static int slice_compare_impl(bmx_ctx* ctx, const bmx_vec* const* slices, size_t nslices, int pred, uint64_t v0, uint64_t v1,
+                              uint64_t size, const bmx_vec* not_null, int null_correct, const bmx_vec* sign, int sign_mode,
+                              bmx_vec** result, uint64_t* count, uint64_t* plane_bytes)
 {
-    ARGCHK(ctx && (nslices == 0 || slices) && nslices <= 64 && pred >= BMX_CMP_GT && pred <= BMX_CMP_NONZERO && (result || count));
-    ARGCHK(!not_null || not_null->ctx == ctx);
     if (result) *result = nullptr;
     if (count) *count = 0;
+    if (plane_bytes) *plane_bytes = 0;
     int rc = set_dev(ctx); if (rc) return rc;
-    if (pred == BMX_CMP_RANGE && v1 < v0) std::swap(v0, v1);              // bm::xor_swap(from, to), :2872
-    if (pred == BMX_CMP_ZERO || pred == BMX_CMP_NONZERO) v0 = 0;
     uint64_t nblocks64 = (size + BMX_BLOCK_BITS - 1) / BMX_BLOCK_BITS;
     if (nblocks64 > 65536ull * 16) { g_last_error = "vector too long"; return BMX_ERR_RANGE; }
     uint32_t ncols = (uint32_t)nblocks64;
+    std::vector<const u64*> descs(std::max<size_t>(nslices, 1), nullptr);
+    std::vector<u32> nblk(std::max<size_t>(nslices, 1), 0);
+    for (size_t i = 0; i < nslices; ++i) {
+        if (!slices[i]) continue;                                           // plane does not exist
+        if (slices[i]->ctx != ctx) { g_last_error = "slice belongs to another context"; return BMX_ERR_BADARG; }
+        descs[i] = slices[i]->d_desc; nblk[i] = slices[i]->nblocks;
+    }
+    const bool sgn = sign_mode != SIGN_NONE || pred == CMP_SRANGE;
+    const bool two = pred == BMX_CMP_RANGE || pred == CMP_SRANGE;
+    bmx_vec* v = nullptr; BlockStat* st = nullptr; u32* offs = nullptr;
+    if (result && (rc = result_begin(ctx, size, ncols, &v, &st, &offs))) return rc;
+    if (!ncols) { if (result) *result = v; return BMX_OK; }
+    void* d_descs = nullptr; void* d_nblk = nullptr;
+    size_t nal = std::max<size_t>(nslices, 1);
+    if ((rc = dmalloc(ctx, &d_descs, nal * 8)) || (rc = dmalloc(ctx, &d_nblk, nal * 4))) { dfree(ctx, d_descs); if (v) bmx_vec_free(ctx, v); return rc; }
+    hipError_t e = hipMemcpyAsync(d_descs, descs.data(), nal * 8, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_nblk, nblk.data(), nal * 4, hipMemcpyHostToDevice, ctx->stream);
+    u64* d_stat = plane_bytes ? ctx->d_small + 8 : nullptr;
+    if (e == hipSuccess && d_stat) e = hipMemsetAsync(d_stat, 0, 8, ctx->stream);
+    if (e == hipSuccess) {
+#define CMP_ARGS dim3((ncols + 3) / 4), dim3(256), 0, ctx->stream, \
+            (const u64* const*)d_descs, (const u32*)d_nblk, (u32)nslices, ncols, pred, v0, v1, size, \
+            not_null ? (const u64*)not_null->d_desc : nullptr, not_null ? not_null->nblocks : 0u, null_correct, \
+            result ? 0 : 1, ctx->xcd_swz, v ? v->d_bits : nullptr, v ? v->d_desc : nullptr, st, ctx->d_slots, \
+            sign ? (const u64*)sign->d_desc : nullptr, sign ? sign->nblocks : 0u, sign_mode, d_stat
+        if (ctx->range_halves) {                                            // partial-block passes (fewer accumulators, more waves)
+            // (measured: one bound -- half blocks 0.372 ms, quarter blocks 0.422; two bounds -- half blocks 0.536 ms, quarter blocks 0.473)
+            if (sgn) { if (two) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_slice_compare_halves<true, 2, true>), CMP_ARGS);
+                       else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_slice_compare_halves<false, 4, true>), CMP_ARGS); }
+            else if (two) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_slice_compare_halves<true, 2>), CMP_ARGS);
+            else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_slice_compare_halves<false, 4>), CMP_ARGS);
+        } else {
+            if (sgn) { if (two) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_slice_compare<true, true>), CMP_ARGS);
+                       else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_slice_compare<false, true>), CMP_ARGS); }
+            else if (two) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_slice_compare<true>), CMP_ARGS);
+            else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_slice_compare<false>), CMP_ARGS);
+        }
+#undef CMP_ARGS
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess && !result) {
+        hipLaunchKernelGGL(k_sum_slots, dim3(1), dim3(64), 0, ctx->stream, ctx->d_slots, ctx->d_small);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(ctx->h_small, ctx->d_small, 8, hipMemcpyDeviceToHost, ctx->stream);
+    }
+    if (e == hipSuccess && d_stat) e = hipMemcpyAsync(ctx->h_small + 8, d_stat, 8, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess && result) rc = result_finish(ctx, v, st, offs);
+    else if (e != hipSuccess) rc = fail_hip(e, "bmx_slice_compare", __LINE__);
+    hipError_t e2 = hipStreamSynchronize(ctx->stream);
+    if (!rc && e2 != hipSuccess) rc = fail_hip(e2, "bmx_slice_compare", __LINE__);
+    dfree(ctx, d_descs); dfree(ctx, d_nblk);
+    if (rc) { if (v) bmx_vec_free(ctx, v); return rc; }
+    if (plane_bytes) *plane_bytes = ctx->h_small[8];
+    if (result) {
+        *result = v;
+        if (count) { rc = bmx_count(ctx, v, count); if (rc) return rc; }
+    } else *count = ctx->h_small[0];
+    return BMX_OK;
+}
+
+static int slice_compare_unsigned(bmx_ctx* ctx, const bmx_vec* const* slices, size_t nslices, int pred, uint64_t v0, uint64_t v1,
+                                  uint64_t size, const bmx_vec* not_null, bmx_vec** result, uint64_t* count, uint64_t* plane_bytes)
+{
+    ARGCHK(ctx && (nslices == 0 || slices) && nslices <= 64 && pred >= BMX_CMP_GT && pred <= BMX_CMP_NONZERO && (result || count));
+    ARGCHK(!not_null || not_null->ctx == ctx);
+    if (pred == BMX_CMP_RANGE && v1 < v0) std::swap(v0, v1);              // bm::xor_swap(from, to), :2872
+    if (pred == BMX_CMP_ZERO || pred == BMX_CMP_NONZERO) v0 = 0;
     // which results can contain value 0 = where NULL elements hide (needs_null_correct_*, :1703-1735, unsigned)
     int null_correct = 0;
     switch (pred) {
@@ -2133,54 +2201,63 @@ int bmx_slice_compare(bmx_ctx* ctx, const bmx_vec* const* slices, size_t nslices
     case BMX_CMP_EQ: null_correct = v0 == 0; break;
     default: break;
     }
-    std::vector<const u64*> descs(std::max<size_t>(nslices, 1), nullptr);
-    std::vector<u32> nblk(std::max<size_t>(nslices, 1), 0);
-    for (size_t i = 0; i < nslices; ++i) {
-        if (!slices[i]) continue;                                           // plane does not exist
-        if (slices[i]->ctx != ctx) { g_last_error = "slice belongs to another context"; return BMX_ERR_BADARG; }
-        descs[i] = slices[i]->d_desc; nblk[i] = slices[i]->nblocks;
+    return slice_compare_impl(ctx, slices, nslices, pred, v0, v1, size, not_null, null_correct, nullptr, SIGN_NONE, result, count, plane_bytes);
+}
+
+int bmx_slice_compare(bmx_ctx* ctx, const bmx_vec* const* slices, size_t nslices, int pred, uint64_t v0, uint64_t v1,
+                      uint64_t size, const bmx_vec* not_null, bmx_vec** result, uint64_t* count)
+{
+    return slice_compare_unsigned(ctx, slices, nslices, pred, v0, v1, size, not_null, result, count, nullptr);
+}
+
+int bmx_slice_compare_stat(bmx_ctx* ctx, const bmx_vec* const* slices, size_t nslices, int pred, uint64_t v0, uint64_t v1,
+                           uint64_t size, const bmx_vec* not_null, uint64_t* count, uint64_t* plane_bytes)
+{
+    ARGCHK(count && plane_bytes);
+    return slice_compare_unsigned(ctx, slices, nslices, pred, v0, v1, size, not_null, nullptr, count, plane_bytes);
+}
+
+// signed containers: slices[0] = the sign plane, slices[1..] = magnitude planes (s2u encoding, src/bmbmatrix.h:2536-2548)
+int bmx_slice_compare_signed(bmx_ctx* ctx, const bmx_vec* const* slices, size_t nslices, int pred, int64_t v0, int64_t v1,
+                             uint64_t size, const bmx_vec* not_null, bmx_vec** result, uint64_t* count)
+{
+    ARGCHK(ctx && (nslices == 0 || slices) && nslices <= 65 && pred >= BMX_CMP_GT && pred <= BMX_CMP_NONZERO && (result || count));
+    ARGCHK(!not_null || not_null->ctx == ctx);
+    const bmx_vec* sign = nslices ? slices[0] : nullptr;
+    if (sign && sign->ctx != ctx) { g_last_error = "slice belongs to another context"; return BMX_ERR_BADARG; }
+    const bmx_vec* const* mag = nslices ? slices + 1 : slices;
+    const size_t nmag = nslices ? nslices - 1 : 0;
+    if (pred == BMX_CMP_RANGE && v1 < v0) std::swap(v0, v1);
+    // magnitude of a bound: v >= 0 -> v, v < 0 -> -(v + 1)
+    auto magn = [](int64_t v) -> uint64_t { return v >= 0 ? (uint64_t)v : (uint64_t)(-(v + 1)); };
+    // does value 0 satisfy the predicate?  (NULL rows are stored as sign 0, magnitude 0)
+    bool admits0;
+    switch (pred) {
+    case BMX_CMP_GT: admits0 = 0 > v0; break;
+    case BMX_CMP_GE: admits0 = 0 >= v0; break;
+    case BMX_CMP_LT: admits0 = 0 < v0; break;
+    case BMX_CMP_LE: admits0 = 0 <= v0; break;
+    case BMX_CMP_RANGE: admits0 = v0 <= 0 && 0 <= v1; break;
+    case BMX_CMP_EQ: admits0 = v0 == 0; break;
+    case BMX_CMP_ZERO: admits0 = true; break;
+    default: admits0 = false; break;
     }
-    bmx_vec* v = nullptr; BlockStat* st = nullptr; u32* offs = nullptr;
-    if (result && (rc = result_begin(ctx, size, ncols, &v, &st, &offs))) return rc;
-    if (!ncols) { if (result) *result = v; return BMX_OK; }
-    void* d_descs = nullptr; void* d_nblk = nullptr;
-    size_t nal = std::max<size_t>(nslices, 1);
-    if ((rc = dmalloc(ctx, &d_descs, nal * 8)) || (rc = dmalloc(ctx, &d_nblk, nal * 4))) { dfree(ctx, d_descs); if (v) bmx_vec_free(ctx, v); return rc; }
-    hipError_t e = hipMemcpyAsync(d_descs, descs.data(), nal * 8, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_nblk, nblk.data(), nal * 4, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) {
-        if (ctx->range_halves) {                                            // partial-block passes (fewer accumulators, more waves)
-            // (measured: one bound -- half blocks 0.372 ms, quarter blocks 0.422; two bounds -- half blocks 0.536 ms, quarter blocks 0.473)
-            auto hfn = pred == BMX_CMP_RANGE ? k_slice_compare_halves<true, 2> : k_slice_compare_halves<false, 4>;
-            hipLaunchKernelGGL(hfn, dim3((ncols + 3) / 4), dim3(256), 0, ctx->stream,
-                               (const u64* const*)d_descs, (const u32*)d_nblk, (u32)nslices, ncols, pred, v0, v1, size,
-                               not_null ? (const u64*)not_null->d_desc : nullptr, not_null ? not_null->nblocks : 0u, null_correct,
-                               result ? 0 : 1, ctx->xcd_swz, v ? v->d_bits : nullptr, v ? v->d_desc : nullptr, st, ctx->d_slots);
-        } else {
-            auto cmp_fn = pred == BMX_CMP_RANGE ? k_slice_compare<true> : k_slice_compare<false>;
-            hipLaunchKernelGGL(cmp_fn, dim3((ncols + 3) / 4), dim3(256), 0, ctx->stream,
-                               (const u64* const*)d_descs, (const u32*)d_nblk, (u32)nslices, ncols, pred, v0, v1, size,
-                               not_null ? (const u64*)not_null->d_desc : nullptr, not_null ? not_null->nblocks : 0u, null_correct,
-                               result ? 0 : 1, ctx->xcd_swz, v ? v->d_bits : nullptr, v ? v->d_desc : nullptr, st, ctx->d_slots);
-        }
-        e = hipGetLastError();
+    int kp = pred, mode = SIGN_NONE; uint64_t b0 = 0, b1 = 0;
+    switch (pred) {
+    case BMX_CMP_GT: if (v0 >= 0) { kp = CMP_GT; b0 = magn(v0); mode = SIGN_NONNEG_ONLY; } else { kp = CMP_LT; b0 = magn(v0); mode = SIGN_NONNEG_ALL; } break;
+    case BMX_CMP_GE: if (v0 >= 0) { kp = CMP_GE; b0 = magn(v0); mode = SIGN_NONNEG_ONLY; } else { kp = CMP_LE; b0 = magn(v0); mode = SIGN_NONNEG_ALL; } break;
+    case BMX_CMP_LT: if (v0 >= 0) { kp = CMP_LT; b0 = magn(v0); mode = SIGN_NEG_ALL; } else { kp = CMP_GT; b0 = magn(v0); mode = SIGN_NEG_ONLY; } break;
+    case BMX_CMP_LE: if (v0 >= 0) { kp = CMP_LE; b0 = magn(v0); mode = SIGN_NEG_ALL; } else { kp = CMP_GE; b0 = magn(v0); mode = SIGN_NEG_ONLY; } break;
+    case BMX_CMP_EQ: kp = CMP_EQ; b0 = magn(v0); mode = v0 >= 0 ? SIGN_NONNEG_ONLY : SIGN_NEG_ONLY; break;
+    case BMX_CMP_RANGE:
+        if (v0 >= 0) { kp = CMP_RANGE; b0 = magn(v0); b1 = magn(v1); mode = SIGN_NONNEG_ONLY; }
+        else if (v1 < 0) { kp = CMP_RANGE; b0 = magn(v1); b1 = magn(v0); mode = SIGN_NEG_ONLY; }      // v0 <= v1 < 0: magnitudes swap order
+        else { kp = CMP_SRANGE; b0 = magn(v1); b1 = magn(v0); mode = SIGN_NONE; }                   // v0 < 0 <= v1
+        break;
+    case BMX_CMP_ZERO: kp = CMP_ZERO; mode = SIGN_NONNEG_ONLY; break;                              // sign 0, magnitude 0
+    default: kp = CMP_NONZERO; mode = SIGN_NEG_ALL; break;                                          // any magnitude bit, or negative (-1 = sign only)
     }
-    if (e == hipSuccess && !result) {
-        hipLaunchKernelGGL(k_sum_slots, dim3(1), dim3(64), 0, ctx->stream, ctx->d_slots, ctx->d_small);
-        e = hipGetLastError();
-        if (e == hipSuccess) e = hipMemcpyAsync(ctx->h_small, ctx->d_small, 8, hipMemcpyDeviceToHost, ctx->stream);
-    }
-    if (e == hipSuccess && result) rc = result_finish(ctx, v, st, offs);
-    else if (e != hipSuccess) rc = fail_hip(e, "bmx_slice_compare", __LINE__);
-    hipError_t e2 = hipStreamSynchronize(ctx->stream);
-    if (!rc && e2 != hipSuccess) rc = fail_hip(e2, "bmx_slice_compare", __LINE__);
-    dfree(ctx, d_descs); dfree(ctx, d_nblk);
-    if (rc) { if (v) bmx_vec_free(ctx, v); return rc; }
-    if (result) {
-        *result = v;
-        if (count) { rc = bmx_count(ctx, v, count); if (rc) return rc; }
-    } else *count = ctx->h_small[0];
-    return BMX_OK;
+    return slice_compare_impl(ctx, mag, nmag, kp, b0, b1, size, not_null, admits0 ? 1 : 0, sign, mode, result, count, nullptr);
 }
 
 // counts[q] = rows equal to values[q]: one pass over the planes whatever the number of queries (k_slice_eq_counts:

@@ -24,7 +24,30 @@
 //   NONZERO = ~eq(0)  ZERO = eq(0)          -- all restricted to rows [0, size) and, where flagged, to not-NULL rows.
 // Results are identical sets: both compute {i : sv[i] OP value} over the same planes.
 // ---------------------------------------------------------------------------
-enum { CMP_GT = 0, CMP_GE = 1, CMP_LT = 2, CMP_LE = 3, CMP_RANGE = 4, CMP_EQ = 5, CMP_ZERO = 6, CMP_NONZERO = 7 };
+enum { CMP_GT = 0, CMP_GE = 1, CMP_LT = 2, CMP_LE = 3, CMP_RANGE = 4, CMP_EQ = 5, CMP_ZERO = 6, CMP_NONZERO = 7,
+       CMP_SRANGE = 8 /* signed range across zero: magnitude <= v0 where the sign plane is clear, <= v1 where it is set */ };
+
+// Signed containers (bm::sparse_vector<int, ..>): plane 0 is the SIGN, planes 1.. hold the magnitude -- v >= 0 is stored
+// as v << 1, v < 0 as ((-(v + 1)) << 1) | 1 (base_sparse_vector::s2u, src/bmbmatrix.h:2536-2548).  A signed comparison is
+// an unsigned comparison of the magnitude planes on ONE side of the sign and all / none of the rows on the other (the
+// reference builds it from whole-vector passes: find_gt_horizontal_s, src/bmsparsevec_algo.h:3033-3160): the same one-pass
+// walk over planes 1.., then one of these combinations with the sign block S.
+enum { SIGN_NONE = 0,
+       SIGN_NONNEG_ONLY = 1,      // r & ~S          rows >= 0 that satisfy the magnitude predicate
+       SIGN_NONNEG_ALL = 2,       // (r & S) | ~S    every row >= 0, plus the negative ones that satisfy it
+       SIGN_NEG_ONLY = 3,         // r & S
+       SIGN_NEG_ALL = 4 };        // (r & ~S) | S
+
+__device__ __forceinline__ u32x4 sign_combine(u32x4 r, u32x4 S, int mode)
+{
+    switch (mode) {
+    case SIGN_NONNEG_ONLY: return r & ~S;
+    case SIGN_NONNEG_ALL:  return (r & S) | ~S;
+    case SIGN_NEG_ONLY:    return r & S;
+    case SIGN_NEG_ALL:     return (r & ~S) | S;
+    default:               return r;
+    }
+}
 
 // rows [0, size) of block nb as a register image
 __device__ __forceinline__ void blk_size_mask(Blk& m, u32 nb, u64 size, u32 lane)
@@ -47,13 +70,14 @@ __device__ __forceinline__ void blk_size_mask(Blk& m, u32 nb, u64 size, u32 lane
 }
 
 // TWO: two bounds at once (find_range); the one-bound form carries half the accumulators (fewer registers, more waves per CU)
-template <bool TWO>
+template <bool TWO, bool SGN = false>
 __global__ __launch_bounds__(256)
 void k_slice_compare(const u64* const* __restrict__ descs /* per plane: descriptor table or null */,
                      const u32* __restrict__ nblk, u32 nplanes, u32 ncols, int pred, u64 v0, u64 v1, u64 size,
                      const u64* __restrict__ nn_desc /* not-NULL vector or null */, u32 nn_blocks, int null_correct,
                      int count_only, int xcd_swz,
-                     uint4* __restrict__ slab, u64* __restrict__ desc, BlockStat* __restrict__ st, u64* __restrict__ slots)
+                     uint4* __restrict__ slab, u64* __restrict__ desc, BlockStat* __restrict__ st, u64* __restrict__ slots,
+                     const u64* __restrict__ sign_desc, u32 sign_blocks, int sign_mode, u64* __restrict__ stat)
 {
     __shared__ u32 lds[4 * 2048];
     u32 lane = lane_id(), wave = threadIdx.x >> 6;
@@ -62,6 +86,7 @@ void k_slice_compare(const u64* const* __restrict__ descs /* per plane: descript
     u32 cnt = 0;
     if (nb < ncols) {
         constexpr bool two = TWO;
+        u32 read_bytes = 0;
         // a bound with a set bit above every plane: nothing is equal to it and nothing is greater
         bool dead0 = nplanes < 64u && (v0 >> nplanes) != 0ull;
         bool dead1 = two && nplanes < 64u && (v1 >> nplanes) != 0ull;
@@ -80,6 +105,7 @@ void k_slice_compare(const u64* const* __restrict__ descs /* per plane: descript
             } else {
                 Blk P;
                 blk_from_desc(d, P, l, lane);
+                read_bytes += DESC_K(d) == K_BIT ? 8192u : (DESC_K(d) == K_GAP ? 2u * ((GMETA(d) >> 1) + 1u) : 0u);
                 if (bit0) blk_and(eq0, P);
                 else {
 #pragma unroll
@@ -110,12 +136,22 @@ void k_slice_compare(const u64* const* __restrict__ descs /* per plane: descript
             break;
         case CMP_RANGE: res = gt0; blk_or(res, eq0); blk_andn(res, gt1); break;
         case CMP_EQ: case CMP_ZERO: res = eq0; break;
+        case CMP_SRANGE: break;                                          // (combined with the sign block below)
         default:                                                         // NONZERO
 #pragma unroll
             for (int i = 0; i < 8; ++i) res.r[i] = ~eq0.r[i];
             break;
         }
         Blk m;
+        if (SGN && (sign_mode != SIGN_NONE || pred == CMP_SRANGE)) {
+            u64 sd = (sign_desc && nb < sign_blocks) ? uniform64(sign_desc[nb]) : 0ull;
+            blk_from_desc(sd, m, l, lane);                                // the sign block S
+            read_bytes += DESC_K(sd) == K_BIT ? 8192u : (DESC_K(sd) == K_GAP ? 2u * ((GMETA(sd) >> 1) + 1u) : 0u);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                res.r[i] = pred == CMP_SRANGE ? ((~gt0.r[i] & ~m.r[i]) | (~gt1.r[i] & m.r[i])) : sign_combine(res.r[i], m.r[i], sign_mode);
+        }
+        if (stat && lane == 0 && read_bytes) atomicAdd(reinterpret_cast<unsigned long long*>(stat), (unsigned long long)read_bytes);
         blk_size_mask(m, nb, size, lane);
         blk_and(res, m);
         if (null_correct && nn_desc) {
@@ -155,11 +191,12 @@ __device__ __forceinline__ void part_from_desc(u64 d, Part<RP>& P, u32 h, u32* l
     }
 }
 
-template <bool TWO, int RP>
+template <bool TWO, int RP, bool SGN = false>
 __global__ __launch_bounds__(256)
 void k_slice_compare_halves(const u64* const* __restrict__ descs, const u32* __restrict__ nblk, u32 nplanes, u32 ncols, int pred, u64 v0, u64 v1, u64 size,
                           const u64* __restrict__ nn_desc, u32 nn_blocks, int null_correct, int count_only, int xcd_swz,
-                          uint4* __restrict__ slab, u64* __restrict__ desc, BlockStat* __restrict__ st, u64* __restrict__ slots)
+                          uint4* __restrict__ slab, u64* __restrict__ desc, BlockStat* __restrict__ st, u64* __restrict__ slots,
+                          const u64* __restrict__ sign_desc, u32 sign_blocks, int sign_mode, u64* __restrict__ stat)
 {
     __shared__ u32 lds[4 * 2048];
     u32 lane = lane_id(), wave = threadIdx.x >> 6;
@@ -173,6 +210,9 @@ void k_slice_compare_halves(const u64* const* __restrict__ descs, const u32* __r
         const u64 base = (u64)nb << 16;
         const u32 lim = size <= base ? 0u : (size - base >= 65536ull ? 65536u : (u32)(size - base));
         Blk out;
+        u32 read_bytes = 0;
+        const bool use_sign = SGN && (sign_mode != SIGN_NONE || pred == CMP_SRANGE);
+        const u64 sd = (use_sign && sign_desc && nb < sign_blocks) ? uniform64(sign_desc[nb]) : 0ull;
 #pragma unroll 1
         for (u32 h = 0; h < (u32)(8 / RP); ++h) {
             Part<RP> gt0, eq0, gt1, eq1;
@@ -189,6 +229,8 @@ void k_slice_compare_halves(const u64* const* __restrict__ descs, const u32* __r
                 } else {
                     Part<RP> P;
                     part_from_desc<RP>(d, P, h, l, lane);
+                    // (a bit-block piece is RP KiB; a GAP block is decoded whole by each pass that needs it)
+                    read_bytes += DESC_K(d) == K_BIT ? (u32)RP * 1024u : (DESC_K(d) == K_GAP ? 2u * ((GMETA(d) >> 1) + 1u) : 0u);
 #pragma unroll
                     for (int i = 0; i < RP; ++i) {
                         if (bit0) eq0.r[i] &= P.r[i]; else { gt0.r[i] |= eq0.r[i] & P.r[i]; eq0.r[i] &= ~P.r[i]; }
@@ -204,6 +246,11 @@ void k_slice_compare_halves(const u64* const* __restrict__ descs, const u32* __r
             Part<RP> nn;
             bool use_nn = null_correct && nn_desc;
             if (use_nn) part_from_desc<RP>(nb < nn_blocks ? uniform64(nn_desc[nb]) : 0ull, nn, h, l, lane);
+            Part<SGN ? RP : 1> S;
+            if constexpr (SGN) if (use_sign) {
+                part_from_desc<RP>(sd, S, h, l, lane);
+                read_bytes += DESC_K(sd) == K_BIT ? (u32)RP * 1024u : (DESC_K(sd) == K_GAP ? 2u * ((GMETA(sd) >> 1) + 1u) : 0u);
+            }
 #pragma unroll
             for (int i = 0; i < RP; ++i) {
                 u32x4 r;
@@ -214,8 +261,10 @@ void k_slice_compare_halves(const u64* const* __restrict__ descs, const u32* __r
                 case CMP_LE: r = ~gt0.r[i]; break;
                 case CMP_RANGE: r = (gt0.r[i] | eq0.r[i]) & ~gt1.r[i]; break;
                 case CMP_EQ: case CMP_ZERO: r = eq0.r[i]; break;
+                case CMP_SRANGE: if constexpr (SGN) r = (~gt0.r[i] & ~S.r[i]) | (~gt1.r[i] & S.r[i]); else r = (u32x4)(0u); break;
                 default: r = ~eq0.r[i]; break;                              // NONZERO
                 }
+                if constexpr (SGN) if (use_sign && pred != CMP_SRANGE) r = sign_combine(r, S.r[i], sign_mode);
                 u32 w0 = (((h * (u32)RP + (u32)i) * 256u + lane * 4u) << 5);    // first row of word .x
                 u32 ws[4];
 #pragma unroll
@@ -237,6 +286,7 @@ void k_slice_compare_halves(const u64* const* __restrict__ descs, const u32* __r
                 }
             }
         }
+        if (stat && lane == 0 && read_bytes) atomicAdd(reinterpret_cast<unsigned long long*>(stat), (unsigned long long)read_bytes);
         if (count_only) cnt = wave_sum(cnt);
         else if (blk_is_zero(out)) store_trivial(K_NULL, nb, desc, st, lane);
         else store_result(out, nb, 1, slab, desc, st, lane);

@@ -205,6 +205,18 @@ int bmx_agg_shift_right_and_count(bmx_ctx* ctx, const bmx_vec* const* src, size_
 int bmx_slice_compare(bmx_ctx* ctx, const bmx_vec* const* slices, size_t nslices, int pred, uint64_t v0, uint64_t v1,
                       uint64_t size, const bmx_vec* not_null, bmx_vec** result, uint64_t* count);
 
+/* The same for SIGNED containers (bm::sparse_vector<int, ..>): slices[0] is the sign plane, slices[1..] the magnitude planes
+ * of the reference's encoding (v >= 0 -> v << 1, v < 0 -> ((-(v + 1)) << 1) | 1: base_sparse_vector::s2u, src/bmbmatrix.h:2536);
+ * bounds are signed.  What the reference builds from whole-vector passes (find_gt_horizontal_s, src/bmsparsevec_algo.h:1484,
+ * 3033-3160, and find_ge / lt / le / range on top of it) is the same one pass over the magnitude planes combined with the sign
+ * block in the kernel.  NULL rows (stored as +0) drop out wherever the predicate admits 0. */
+int bmx_slice_compare_signed(bmx_ctx* ctx, const bmx_vec* const* slices, size_t nslices, int pred, int64_t v0, int64_t v1,
+                             uint64_t size, const bmx_vec* not_null, bmx_vec** result, uint64_t* count);
+/* bmx_slice_compare (count only) that also reports the plane bytes the walk actually had to read -- it stops in a block column
+ * as soon as no row is "equal so far" -- i.e. the ALGORITHMIC bytes of this search (benchmark reports divide by them) */
+int bmx_slice_compare_stat(bmx_ctx* ctx, const bmx_vec* const* slices, size_t nslices, int pred, uint64_t v0, uint64_t v1,
+                           uint64_t size, const bmx_vec* not_null, uint64_t* count, uint64_t* plane_bytes);
+
 /* a batch of equality searches, counts only: counts[q] = rows equal to values[q] -- what n pipelined AND-SUB groups of
  * prepare_and_sub_aggregator compute (src/bmsparsevec_algo.h:2593-2640,3236,3408), in ONE pass over the planes whatever n is
  * (bit-matrix transposition + hash lookup, bmx_kernels4.h).  nslices <= 32 (else BMX_ERR_RANGE: use the pipeline form). */

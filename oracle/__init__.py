@@ -210,6 +210,43 @@ class SV:
         f = self.orc.lib.ref_sv_find_first_eq(self.h, C.c_uint32(v), C.byref(pos))
         return bool(f), int(pos.value)
 
+    def find_eq_in(self, values) -> Vec:
+        """find_eq(sv, start, end, bv_out): rows whose value is IN the list (bmsparsevec_algo.h:1399)"""
+        v = np.ascontiguousarray(values, np.uint32)
+        return Vec(self.orc, self.orc.lib.ref_sv_find_eq_in(self.h, _u32p(v), C.c_size_t(v.size)), self.n)
+
+    def invert(self, bv: Vec) -> Vec:
+        """scanner.invert(sv, bv) on a copy of bv (bmsparsevec_algo.h:2321)"""
+        return Vec(self.orc, self.orc.lib.ref_sv_invert(self.h, bv.h), self.n)
+
+
+class SVS:
+    """bm::sparse_vector<int, bvector<>> (signed) + scanner calls"""
+
+    def __init__(self, orc, handle, n):
+        self.orc, self.h, self.n = orc, handle, int(n)
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.orc.lib.ref_svs_free(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def size(self) -> int:
+        return int(self.orc.lib.ref_svs_size(self.h))
+
+    def effective_slices(self) -> int:
+        return int(self.orc.lib.ref_svs_effective_slices(self.h))
+
+    def slice(self, i: int):
+        h = self.orc.lib.ref_svs_slice(self.h, C.c_uint32(i))
+        return Vec(self.orc, h, self.n) if h else None
+
+    def compare(self, pred: int, v0: int = 0, v1: int = 0) -> Vec:
+        return Vec(self.orc, self.orc.lib.ref_svs_compare(self.h, C.c_int(pred), C.c_int32(v0), C.c_int32(v1)), self.n)
+
 
 class Oracle:
     def __init__(self, path: str, prefix: str, kind: str, name: str):
@@ -283,6 +320,15 @@ class Oracle:
                 L.ref_sv_not_null.restype = vp; L.ref_sv_not_null.argtypes = [vp]
                 L.ref_sv_compare.restype = vp; L.ref_sv_compare.argtypes = [vp, C.c_int, C.c_uint32, C.c_uint32]
                 L.ref_sv_find_first_eq.restype = C.c_int; L.ref_sv_find_first_eq.argtypes = [vp, C.c_uint32, C.POINTER(C.c_uint64)]
+            if hasattr(L, "ref_svs_new"):
+                L.ref_svs_new.restype = vp; L.ref_svs_new.argtypes = [C.POINTER(C.c_int32), C.POINTER(C.c_uint8), C.c_uint64]
+                L.ref_svs_free.restype = None; L.ref_svs_free.argtypes = [vp]
+                L.ref_svs_size.restype = C.c_uint64; L.ref_svs_size.argtypes = [vp]
+                L.ref_svs_effective_slices.restype = C.c_uint32; L.ref_svs_effective_slices.argtypes = [vp]
+                L.ref_svs_slice.restype = vp; L.ref_svs_slice.argtypes = [vp, C.c_uint32]
+                L.ref_svs_compare.restype = vp; L.ref_svs_compare.argtypes = [vp, C.c_int, C.c_int32, C.c_int32]
+                L.ref_sv_find_eq_in.restype = vp; L.ref_sv_find_eq_in.argtypes = [vp, C.POINTER(C.c_uint32), C.c_size_t]
+                L.ref_sv_invert.restype = vp; L.ref_sv_invert.argtypes = [vp, vp]
         else:
             L.bmo_vec_new.argtypes = [C.c_uint64]
             L.bmo_vec_stat.argtypes = [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
@@ -431,6 +477,13 @@ class Oracle:
         nn = None if is_null is None else np.ascontiguousarray(is_null, np.uint8)
         h = self.lib.ref_sv_new(_u32p(values), _u8p(nn) if nn is not None else None, C.c_uint64(values.size))
         return SV(self, h, values.size)
+
+    def sparse_vector_signed(self, values, is_null=None) -> "SVS":
+        assert self.is_ref
+        values = np.ascontiguousarray(values, np.int32)
+        nn = None if is_null is None else np.ascontiguousarray(is_null, np.uint8)
+        h = self.lib.ref_svs_new(values.ctypes.data_as(C.POINTER(C.c_int32)), _u8p(nn) if nn is not None else None, C.c_uint64(values.size))
+        return SVS(self, h, values.size)
 
     def rs_build(self, v: Vec) -> RS:
         return RS(self, self._f("rs_build")(v.h), v)

@@ -415,6 +415,66 @@ int ref_sv_find_first_eq(void* svp, uint32_t v, uint64_t* pos)
     *pos = p; return f;
 }
 
+// ---- signed containers: bm::sparse_vector<int, bvector<>> (sign plane 0 + magnitude planes, s2u encoding) ----
+typedef bm::sparse_vector<int, bvect> svects_t;
+
+void* ref_svs_new(const int32_t* values, const uint8_t* is_null, uint64_t n)
+{
+    svects_t* sv = is_null ? new svects_t(bm::use_null) : new svects_t();
+    if (is_null) {
+        for (uint64_t i = 0; i < n; ++i) if (!is_null[i]) sv->set(svects_t::size_type(i), values[i]);
+        if (n && is_null[n - 1]) sv->set_null(svects_t::size_type(n - 1));
+    } else {
+        svects_t::back_insert_iterator bi = sv->get_back_inserter();
+        for (uint64_t i = 0; i < n; ++i) bi = values[i];
+        bi.flush();
+    }
+    sv->optimize();
+    return sv;
+}
+void ref_svs_free(void* sv) { delete static_cast<svects_t*>(sv); }
+uint64_t ref_svs_size(void* sv) { return static_cast<svects_t*>(sv)->size(); }
+uint32_t ref_svs_effective_slices(void* sv) { return static_cast<svects_t*>(sv)->effective_slices(); }
+void* ref_svs_slice(void* sv, uint32_t i)
+{
+    const bvect* p = static_cast<svects_t*>(sv)->get_slice(i);
+    return p ? new bvect(*p) : nullptr;
+}
+void* ref_svs_compare(void* svp, int pred, int32_t v0, int32_t v1)
+{
+    const svects_t& sv = *static_cast<svects_t*>(svp);
+    bm::sparse_vector_scanner<svects_t> sc;
+    bvect* r = new bvect();
+    switch (pred) {
+    case 0: sc.find_gt(sv, v0, *r); break;
+    case 1: sc.find_ge(sv, v0, *r); break;
+    case 2: sc.find_lt(sv, v0, *r); break;
+    case 3: sc.find_le(sv, v0, *r); break;
+    case 4: sc.find_range(sv, v0, v1, *r); break;
+    case 5: sc.find_eq(sv, v0, *r); break;
+    case 6: sc.find_zero(sv, *r); break;
+    default: sc.find_nonzero(sv, *r); break;
+    }
+    return r;
+}
+// scanner leftovers on the unsigned container: IN-list find_eq(sv, start, end, bv_out) (bmsparsevec_algo.h:1399) and invert (:2321)
+void* ref_sv_find_eq_in(void* svp, const uint32_t* values, size_t n)
+{
+    const svect_t& sv = *static_cast<svect_t*>(svp);
+    bm::sparse_vector_scanner<svect_t> sc;
+    bvect* r = new bvect();
+    sc.find_eq(sv, values, values + n, *r);
+    return r;
+}
+void* ref_sv_invert(void* svp, void* bv)
+{
+    const svect_t& sv = *static_cast<svect_t*>(svp);
+    bm::sparse_vector_scanner<svect_t> sc;
+    bvect* r = new bvect(*static_cast<bvect*>(bv));
+    sc.invert(sv, *r);
+    return r;
+}
+
 // rank variants: bm.h:3548 count_range, :3229 rank_corrected, :3173 count_to_test, :5279 find_rank
 uint64_t ref_count_range(void* v, void* r, uint64_t left, uint64_t right)
 { return static_cast<bvect*>(v)->count_range(bvect::size_type(left), bvect::size_type(right), static_cast<ref_rs*>(r)->rs); }

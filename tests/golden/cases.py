@@ -157,3 +157,29 @@ def scanner_values(with_null: bool):
     isn[-1] = 0                                    # the last row is assigned: size() == rows either way
     v = v.copy(); v[isn != 0] = 0                  # NULL rows are stored as 0
     return v, isn
+
+
+# signed containers (bm::sparse_vector<int, ..>), IN-list find_eq and invert
+SCANNER_S_VALUES = [-2147483648, -70001, -70000, -97, -96, -50, -2, -1, 0, 1, 2, 50, 96, 97, 70000, 70003, 2147483647]
+SCANNER_S_RANGES = [(-5, 5), (-50, -10), (10, 50), (0, 0), (-1, -1), (-1, 0), (-70003, 70003), (-2147483648, -1), (0, 2147483647), (40, -40)]
+SCANNER_IN_LISTS = [[1, 2, 3], [0, 33], [96, 70003, 5000000], [17], [0], [50, 50, 51]]
+
+
+def scanner_values_signed(with_null: bool):
+    """-> (values int32[rows], is_null or None): the unsigned fixture's magnitudes with alternating signs, the extremes
+    of the type, a stretch of -1 (sign plane only) and of zeros"""
+    u, isn = scanner_values(with_null)
+    v = u.astype(np.int64)
+    idx = np.arange(SCANNER_ROWS)
+    v[idx % 3 == 1] = -v[idx % 3 == 1]
+    v[5] = -2147483648; v[6] = 2147483647
+    v[100000:101000] = -1
+    if isn is not None:
+        v[isn != 0] = 0
+    return v.astype(np.int32), isn
+
+
+def s2u(v: np.ndarray) -> np.ndarray:
+    """base_sparse_vector::s2u (src/bmbmatrix.h:2536-2548): sign in bit 0, magnitude above it"""
+    v = v.astype(np.int64)
+    return np.where(v >= 0, v << 1, ((-(v + 1)) << 1) | 1).astype(np.uint64)

@@ -19,8 +19,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 sys.path.insert(0, HERE)
 
 import oracle  # noqa: E402
-from cases import (AGG_GROUPS, BM64_NVEC, CASES, HINT_GROUPS, OR_SETS, PAIRS, SCANNER_EQ_BATCH, SCANNER_RANGES, SCANNER_ROWS, SCANNER_VALUES, SEED,  # noqa: E402
-                   SHIFT_SETS, bm64_build, bm64_queries, make_inputs, range_hints, rank_queries, scanner_values, select_queries, sha)
+from cases import (AGG_GROUPS, BM64_NVEC, CASES, HINT_GROUPS, OR_SETS, PAIRS, SCANNER_EQ_BATCH, SCANNER_IN_LISTS, SCANNER_RANGES, SCANNER_ROWS,  # noqa: E402
+                   SCANNER_S_RANGES, SCANNER_S_VALUES, SCANNER_VALUES, SEED, SHIFT_SETS, bm64_build, bm64_queries, make_inputs, range_hints,
+                   rank_queries, scanner_values, scanner_values_signed, select_queries, sha)
 
 
 def gap_slab_masked(kinds, offs, gaps):
@@ -172,7 +173,32 @@ def run_scanner(R):
             f, pos = sv.find_first_eq(v)
             c["eq_first"].append({"v": v, "found": f, "pos": pos if f else 0})
         c["eq_counts"] = [sv.compare(5, v).count() for v in SCANNER_EQ_BATCH]
+        # IN-list find_eq(sv, start, end, bv_out) (:1399) and invert (:2321, applied to the find_gt(50) result)
+        c["in_list"] = []
+        for lst in SCANNER_IN_LISTS:
+            r = sv.find_eq_in(lst)
+            c["in_list"].append({"values": lst, "count": r.count(), "sha": sha(r.to_words(nw))})
+        inv = sv.invert(sv.compare(0, 50))
+        c["invert_gt50"] = {"count": inv.count(), "sha": sha(inv.to_words(nw))}
         out["with_null" if with_null else "no_null"] = c
+        # the signed container over the same rows
+        vals_s, isn_s = scanner_values_signed(with_null)
+        svs = R.sparse_vector_signed(vals_s, isn_s)
+        assert svs.size() == SCANNER_ROWS
+        cs = {"rows": SCANNER_ROWS, "values_sha": sha(vals_s), "effective_slices": svs.effective_slices(), "cmp": {}, "range": []}
+        cs["plane_counts"] = [(svs.slice(i).count() if svs.slice(i) is not None else None) for i in range(svs.effective_slices())]
+        for pred, name in ((0, "gt"), (1, "ge"), (2, "lt"), (3, "le"), (5, "eq")):
+            cs["cmp"][name] = []
+            for v in SCANNER_S_VALUES:
+                r = svs.compare(pred, v)
+                cs["cmp"][name].append({"v": v, "count": r.count(), "sha": sha(r.to_words(nw))})
+        for (a, b) in SCANNER_S_RANGES:
+            r = svs.compare(4, a, b)
+            cs["range"].append({"from": a, "to": b, "count": r.count(), "sha": sha(r.to_words(nw))})
+        for pred, name in ((6, "zero"), (7, "nonzero")):
+            r = svs.compare(pred)
+            cs[name] = {"count": r.count(), "sha": sha(r.to_words(nw))}
+        out["signed_with_null" if with_null else "signed_no_null"] = cs
     return out
 
 

@@ -1511,3 +1511,65 @@ def test_index_list_output(ctx, port):
     sc = bm.slice_scanner(ctx, [upload(((col >> np.uint64(i)) & np.uint64(1)) != 0) for i in range(6)], size=col.size)
     for val in (0, 1, 17, 49, 50, 63):
         assert (sc.find_eq_indices(val) == np.flatnonzero(col == val).astype(np.uint64)).all(), val
+
+
+@pytest.mark.parametrize("with_null", [False, True])
+def test_signed_scanner_inlist_invert_vs_reference_golden(ctx, golden, with_null):
+    """bmx_slice_compare_signed (sign plane + magnitude planes, one pass), IN-list find_eq (pipeline with an OR target) and
+    invert against the reference-generated fixtures: bm::sparse_vector_scanner<sparse_vector<int>> results incl. INT_MIN /
+    INT_MAX bounds, ranges across zero, NULL rows; both kernel shapes (half-block passes and whole blocks)"""
+    from cases import (SCANNER_IN_LISTS, SCANNER_ROWS, s2u, scanner_values, scanner_values_signed)
+    n = SCANNER_ROWS
+    nw = (n + 31) // 32
+    def upload(bits):
+        w = np.packbits(np.concatenate([bits.astype(np.uint8), np.zeros((-n) % 32, np.uint8)]), bitorder="little").view(np.uint32)
+        return bm.bit_import_u32(ctx, w, True)
+    def chk(t, e):
+        assert t.count() == e["count"] and sha(t.to_words(nw)) == e["sha"], e
+    g = golden["scanner"]["signed_with_null" if with_null else "signed_no_null"]
+    vals, isn = scanner_values_signed(with_null)
+    assert sha(vals) == g["values_sha"]
+    u = s2u(vals)
+    planes = []
+    for i in range(g["effective_slices"]):
+        bits = ((u >> np.uint64(i)) & np.uint64(1)) != 0
+        planes.append(upload(bits) if bits.any() else None)
+    nn = upload(isn == 0) if with_null else None
+    sc = bm.slice_scanner(ctx, planes, size=n, not_null=nn, signed=True)
+    for halves in (1, 0):
+        ctx.set_tuning("range_halves", halves)
+        for name, fn, pred in (("gt", sc.find_gt, bm.CMP_GT), ("ge", sc.find_ge, bm.CMP_GE), ("lt", sc.find_lt, bm.CMP_LT),
+                               ("le", sc.find_le, bm.CMP_LE)):
+            for e in g["cmp"][name]:
+                chk(fn(e["v"]), e)
+                assert sc.count(pred, e["v"]) == e["count"], (name, e["v"])
+        for e in g["cmp"]["eq"]:
+            assert sc.count(bm.CMP_EQ, e["v"]) == e["count"]
+            chk(sc._compare(bm.CMP_EQ, e["v"]), e)
+        for e in g["range"]:
+            chk(sc.find_range(e["from"], e["to"]), e)
+            assert sc.count(bm.CMP_RANGE, e["from"], e["to"]) == e["count"]
+        chk(sc.find_zero(), g["zero"]); chk(sc.find_nonzero(), g["nonzero"])
+    ctx.set_tuning("range_halves", 1)
+    # unsigned container: IN-list and invert
+    gu = golden["scanner"]["with_null" if with_null else "no_null"]
+    uv, uisn = scanner_values(with_null)
+    col = uv.astype(np.uint64)
+    uplanes = []
+    for i in range(gu["effective_slices"]):
+        bits = ((col >> np.uint64(i)) & np.uint64(1)) != 0
+        uplanes.append(upload(bits) if bits.any() else None)
+    usc = bm.slice_scanner(ctx, uplanes, size=n, not_null=upload(uisn == 0) if with_null else None)
+    for e, lst in zip(gu["in_list"], SCANNER_IN_LISTS):
+        chk(usc.find_eq_in(lst), e)
+    # OR-ed into an existing vector, as the reference does
+    pre = usc.find_gt(96)
+    t = usc.find_eq_in([1, 2, 3], pre)
+    exp = (col > 96) | np.isin(col, [1, 2, 3])
+    assert t.count() == int(exp.sum())
+    chk(usc.invert(usc.find_gt(50)), gu["invert_gt50"])
+    # the plane bytes a range search actually reads are at most all of them and at least the top plane
+    cnt, pb = usc.compare_stat(bm.CMP_GT, 50)
+    assert cnt == int((col > 50).sum())
+    total = sum(p.operand_bytes() for p in uplanes if p is not None)
+    assert 0 < pb <= total
