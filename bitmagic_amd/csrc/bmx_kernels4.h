@@ -229,8 +229,9 @@ void k_slice_compare_halves(const u64* const* __restrict__ descs, const u32* __r
                 } else {
                     Part<RP> P;
                     part_from_desc<RP>(d, P, h, l, lane);
-                    // (a bit-block piece is RP KiB; a GAP block is decoded whole by each pass that needs it)
-                    read_bytes += DESC_K(d) == K_BIT ? (u32)RP * 1024u : (DESC_K(d) == K_GAP ? 2u * ((GMETA(d) >> 1) + 1u) : 0u);
+                    // (algorithmic bytes: a bit-block piece is RP KiB; a GAP block -- decoded whole by every pass that needs it --
+                    // is charged its share of the passes, so that a column never counts more than its planes hold)
+                    read_bytes += DESC_K(d) == K_BIT ? (u32)RP * 1024u : (DESC_K(d) == K_GAP ? (2u * ((GMETA(d) >> 1) + 1u) * (u32)RP) / 8u : 0u);
 #pragma unroll
                     for (int i = 0; i < RP; ++i) {
                         if (bit0) eq0.r[i] &= P.r[i]; else { gt0.r[i] |= eq0.r[i] & P.r[i]; eq0.r[i] &= ~P.r[i]; }
@@ -249,7 +250,7 @@ void k_slice_compare_halves(const u64* const* __restrict__ descs, const u32* __r
             Part<SGN ? RP : 1> S;
             if constexpr (SGN) if (use_sign) {
                 part_from_desc<RP>(sd, S, h, l, lane);
-                read_bytes += DESC_K(sd) == K_BIT ? (u32)RP * 1024u : (DESC_K(sd) == K_GAP ? 2u * ((GMETA(sd) >> 1) + 1u) : 0u);
+                read_bytes += DESC_K(sd) == K_BIT ? (u32)RP * 1024u : (DESC_K(sd) == K_GAP ? (2u * ((GMETA(sd) >> 1) + 1u) * (u32)RP) / 8u : 0u);
             }
 #pragma unroll
             for (int i = 0; i < RP; ++i) {

@@ -1573,3 +1573,40 @@ def test_signed_scanner_inlist_invert_vs_reference_golden(ctx, golden, with_null
     assert cnt == int((col > 50).sum())
     total = sum(p.operand_bytes() for p in uplanes if p is not None)
     assert 0 < pb <= total
+
+
+def test_pairwise_count_mixed_streaming_kernel(ctx, port):
+    """bm::count_and/or/xor/sub over long vectors of ANY block kinds (k_count_op2_mixed: a wave streams a stretch of
+    columns sorted by load shape, GAP blocks prefetched into registers and decoded from there) vs the oracle and vs the
+    column-per-wave kernel (pair_mixed 0): bit / sparse GAP / dense GAP / long runs / > 1,023-word GAP blocks / NULL /
+    FULL on either side, operands of different lengths"""
+    rng = np.random.default_rng(4711)
+    nblk_a, nblk_b = 2300, 2177
+    def build(nblk, seed):
+        w = port.gen_words(9001, seed, 655, nblk * 65536)                      # 1 %: bit / GAP mix
+        for nb in range(nblk):
+            r = rng.integers(0, 12)
+            lo = nb * 2048
+            if r == 0: w[lo:lo + 2048] = 0
+            elif r == 1: w[lo:lo + 2048] = 0xFFFFFFFF
+            elif r == 2:                                                        # long runs -> GAP with wide 1-runs
+                w[lo:lo + 2048] = 0; w[lo + 10:lo + 700] = 0xFFFFFFFF; w[lo + 1200:lo + 1210] = 0xFFFFFFFF; w[lo + 2047] = 0x80000000
+            elif r == 3:                                                        # ~1,100 runs: a GAP block longer than 1,023 words
+                w[lo:lo + 2048] = 0
+                for b in rng.choice(65536, 560, replace=False): w[lo + (b >> 5)] |= np.uint32(1 << (b & 31))
+            elif r == 4: w[lo:lo + 2048] = ~w[lo:lo + 2048]                     # dense: 0-runs are the short ones
+            elif r == 5: w[lo:lo + 2048] = rng.integers(0, 1 << 32, 2048, dtype=np.uint64).astype(np.uint32)
+        return w
+    wa, wb = build(nblk_a, 1), build(nblk_b, 2)
+    pa, pb = port.import_words(wa, True, wa.size * 32), port.import_words(wb, True, wb.size * 32)
+    ka, kb = pa.flatten()[0], pb.flatten()[0]
+    assert set(ka.tolist()) == {0, 1, 2, 3} and set(kb.tolist()) == {0, 1, 2, 3}
+    assert max(int(x) for x in pa.flatten()[3][::1][:1]) >= 0
+    ga, gb = bm.bvector.from_block_table(ctx, wa.size * 32, *pa.flatten()), bm.bvector.from_block_table(ctx, wb.size * 32, *pb.flatten())
+    exp = [[port.count_op2(op, x, y) for op in range(4)] for x, y in ((pa, pb), (pb, pa), (pa, pa))]
+    for mixed in (1, 0):
+        ctx.set_tuning("pair_mixed", mixed)
+        got = [[bm._count_op2(op, x, y) for op in range(4)] for x, y in ((ga, gb), (gb, ga), (ga, ga))]
+        assert got == exp, (mixed, got, exp)
+    ctx.set_tuning("pair_mixed", 1)
+    assert ga.count() == pa.count()

@@ -88,6 +88,15 @@ for name, fn, cnt_fn in (("find_gt", lambda v: sc.find_gt(v), lambda v: sc.count
     ctx.synchronize()
     t_mat = (time.perf_counter() - t0) / len(vals) * 1e3
     assert [r.count() for r in rs] == cs
+    # algorithmic bytes of a comparison search: the plane blocks the walk had to read before every row of a block column was
+    # decided (it stops in a column once no row is "equal so far"), counted by the kernel itself (bmx_slice_compare_stat)
+    if name == "find_range":
+        alg = None                        # (the stat entry takes one bound; the two-bound walk reads at least as much)
+    else:
+        pred = bm.CMP_GT if name == "find_gt" else bm.CMP_LE
+        alg = sum(sc.compare_stat(pred, v)[1] for v in vals) / len(vals)
     print(json.dumps({"pattern": "range_search", "op": name, "planes": a.planes, "rows": a.nbits, "count_only_ms": round(t_cnt, 3),
-                      "materialised_ms": round(t_mat, 3), "plane_GB": round(plane_bytes / 1e9, 2),
-                      "TBps_if_all_planes_read": round(plane_bytes / t_cnt / 1e9, 2), "example_count": cs[0]}))
+                      "materialised_ms": round(t_mat, 3), "all_planes_GB": round(plane_bytes / 1e9, 2),
+                      "algorithmic_GB": None if alg is None else round(alg / 1e9, 3),
+                      "GBps": None if alg is None else round(alg / t_cnt / 1e6, 1),
+                      "frac_of_8TBps": None if alg is None else round(alg / t_cnt / 1e6 / 8000.0, 4), "example_count": cs[0]}))
