@@ -9,7 +9,6 @@
 #include "bmx_kernels4.h"
 #include "bmx_kernels5.h"
 #include "bmx_kernels6.h"
-#include "bmx_kernels7.h"
 
 #include <algorithm>
 #include <atomic>
@@ -470,7 +469,7 @@ int bmx_ctx_create(int device, void* stream, bmx_ctx** out)
     // an invalid value is ignored (the default stays)
     static const char* const env_keys[][2] = {
         {"BMX_PIPE_UNROLL", "pipe_unroll"}, {"BMX_PIPE_ROWS", "pipe_rows"}, {"BMX_PIPE_NT", "pipe_nt"},
-        {"BMX_PIPE_WG", "pipe_wg"}, {"BMX_PIPE_WINDOW", "pipe_window"}, {"BMX_PIPE_SPLIT", "pipe_split"}, {"BMX_OR_TILE", "or_tile"}, {"BMX_OR_WINDOW", "or_window"}, {"BMX_DIRECT_COLS", "direct_cols"}, {"BMX_FF_WINDOW", "ff_window"}, {"BMX_GAP_COUNT", "gap_count"}, {"BMX_RANGE_HALVES", "range_halves"}, {"BMX_PAIR_STREAM", "pair_stream"}, {"BMX_PAIR_WGS", "pair_wgs"}, {"BMX_RS_LANES", "rs_lanes"}, {"BMX_PAIR_MIXED", "pair_mixed"}, {"BMX_GAP_PACK", "gap_pack"}, {"BMX_XCD_SWIZZLE", "xcd_swizzle"}};
+        {"BMX_PIPE_WG", "pipe_wg"}, {"BMX_PIPE_WINDOW", "pipe_window"}, {"BMX_PIPE_SPLIT", "pipe_split"}, {"BMX_OR_TILE", "or_tile"}, {"BMX_OR_WINDOW", "or_window"}, {"BMX_DIRECT_COLS", "direct_cols"}, {"BMX_FF_WINDOW", "ff_window"}, {"BMX_GAP_COUNT", "gap_count"}, {"BMX_RANGE_HALVES", "range_halves"}, {"BMX_PAIR_STREAM", "pair_stream"}, {"BMX_PAIR_WGS", "pair_wgs"}, {"BMX_RS_LANES", "rs_lanes"}, {"BMX_GAP_PACK", "gap_pack"}, {"BMX_XCD_SWIZZLE", "xcd_swizzle"}};
     for (auto& kv : env_keys)
         if (const char* e = getenv(kv[0])) (void)bmx_ctx_set_tuning(ctx, kv[1], atoi(e));
     g_last_error.clear();
@@ -525,7 +524,6 @@ int bmx_ctx_set_tuning(bmx_ctx* ctx, const char* key, int value)
     else if (k == "ff_window") { ARGCHK(value >= -1); ctx->ff_window = value; }
     else if (k == "or_window") { ARGCHK(value >= -9); ctx->or_window = value; }
     else if (k == "gap_pack") { ARGCHK(value >= -1 && value <= 1); ctx->gap_pack = value; }
-    else if (k == "pair_mixed") { ARGCHK(value == 0 || value == 1); ctx->pair_mixed = value; }
     else if (k == "rs_lanes") { ARGCHK(value == 0 || value == 2 || value == 4 || value == 8); ctx->rs_lanes = value; }
     else if (k == "pipe_wg") { ARGCHK(value == 0 || (value >= 64 && value <= 1024 && value % 64 == 0)); ctx->pipe_wg = value; }
     else if (k == "xcd_swizzle") ctx->xcd_swz = value != 0;
@@ -1512,17 +1510,11 @@ static int count_op2_launch(bmx_ctx* ctx, int op, const bmx_vec* a, const bmx_ve
         KCHK();
         return BMX_OK;
     }
-    // any block kinds, long vectors: the same stream with the columns of a wave's stretch sorted by load shape (bmx_kernels7.h)
-    if (ctx->pair_mixed != 0 && nblocks >= 2048u) {
-        const u32 waves = 4u;
-        const u32 total = 256u * waves * (u32)std::max(ctx->pair_wgs, 1);
-        u32 per_wave = std::min(64u, (nblocks + total - 1u) / total);
-        u32 grid = ((nblocks + per_wave - 1u) / per_wave + waves - 1u) / waves;
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_count_op2_mixed<4>), dim3(grid), dim3(256), 0, ctx->stream, op,
-                           a->d_desc, a->nblocks, b->d_desc, b->nblocks, nblocks, per_wave, FoldOut{ctx->d_slots, ctx->d_done, out});
-        KCHK();
-        return BMX_OK;
-    }
+    // (round 3: a streaming form for operands of ANY block kinds was built and measured -- a wave owning a stretch of
+    // columns, sorted by load shape so that every pipelined loop issues a uniform number of loads, GAP blocks prefetched
+    // into registers and decoded from there: 52-58 us against the 45.9 us of this kernel on the 1 % mixed case at one to
+    // eight workgroups per CU (profiles/r03g, r03h); each of the nine shape loops fills and drains its own pipeline over
+    // ~4 columns.  Dropped.)
     hipLaunchKernelGGL(k_count_op2, dim3((nblocks + 3) / 4), dim3(256), 0, ctx->stream, op,
                        a->d_desc, a->nblocks, b->d_desc, b->nblocks, nblocks, FoldOut{ctx->d_slots, ctx->d_done, out});
     KCHK();

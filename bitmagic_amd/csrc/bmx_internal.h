@@ -56,7 +56,6 @@ struct bmx_ctx {
     int or_tile = 0;           // k_agg_or_gap_tiled variant (0 = default)
     int direct_cols = 384;     // aggregation over <= this many block columns and 24..1024 operands: one launch from the descriptor tables (k_direct); 0 = off
     int pair_stream = -1;      // bm::count_* over two all-bit-block vectors: streaming kernel with this many waves per workgroup (-1 = 4, 0 = the column-per-wave kernel)
-    int pair_mixed = 1;        // bm::count_* over vectors of any block kinds (>= 2048 blocks): the shape-sorted streaming kernel k_count_op2_mixed (0 = the column-per-wave kernel)
     int pair_wgs = 1;          // ... and this many workgroups per CU
     int range_halves = 1;      // comparison search in half-block passes (k_slice_compare_halves) instead of whole-block accumulators (k_slice_compare)
     int gap_count = -1;        // GAP-only counts pipelines: counting formulation (k_pipe_counts_gapcount): -1 = automatic, 0 = off, 1 = force

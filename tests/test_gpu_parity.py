@@ -1575,11 +1575,9 @@ def test_signed_scanner_inlist_invert_vs_reference_golden(ctx, golden, with_null
     assert 0 < pb <= total
 
 
-def test_pairwise_count_mixed_streaming_kernel(ctx, port):
-    """bm::count_and/or/xor/sub over long vectors of ANY block kinds (k_count_op2_mixed: a wave streams a stretch of
-    columns sorted by load shape, GAP blocks prefetched into registers and decoded from there) vs the oracle and vs the
-    column-per-wave kernel (pair_mixed 0): bit / sparse GAP / dense GAP / long runs / > 1,023-word GAP blocks / NULL /
-    FULL on either side, operands of different lengths"""
+def test_pairwise_count_long_mixed_vectors(ctx, port):
+    """bm::count_and/or/xor/sub over long vectors (> 2,048 blocks) of ANY block kinds vs the oracle: bit / sparse GAP /
+    dense GAP / long runs / > 1,023-word GAP blocks / NULL / FULL on either side, operands of different lengths"""
     rng = np.random.default_rng(4711)
     nblk_a, nblk_b = 2300, 2177
     def build(nblk, seed):
@@ -1604,9 +1602,6 @@ def test_pairwise_count_mixed_streaming_kernel(ctx, port):
     assert max(int(x) for x in pa.flatten()[3][::1][:1]) >= 0
     ga, gb = bm.bvector.from_block_table(ctx, wa.size * 32, *pa.flatten()), bm.bvector.from_block_table(ctx, wb.size * 32, *pb.flatten())
     exp = [[port.count_op2(op, x, y) for op in range(4)] for x, y in ((pa, pb), (pb, pa), (pa, pa))]
-    for mixed in (1, 0):
-        ctx.set_tuning("pair_mixed", mixed)
-        got = [[bm._count_op2(op, x, y) for op in range(4)] for x, y in ((ga, gb), (gb, ga), (ga, ga))]
-        assert got == exp, (mixed, got, exp)
-    ctx.set_tuning("pair_mixed", 1)
+    got = [[bm._count_op2(op, x, y) for op in range(4)] for x, y in ((ga, gb), (gb, ga), (ga, ga))]
+    assert got == exp, (got, exp)
     assert ga.count() == pa.count()
