@@ -260,15 +260,29 @@ static int coll_launch(int mode, bmx_ctx* ctx, const bmx_coll* a, const bmx_coll
                        u64* d_counts, bmx_vec* v, BlockStat* st, u32 hint_from, u32 hint_to)
 {
     if (col_to <= col_from) return BMX_OK;
-    const u32 grid = col_to - col_from;
-#define COLL_ARGS dim3(grid), dim3(256), 0, ctx->stream, (const u32*)a->d_runs, (const u64*)a->d_off, (const u32*)a->d_cnt, \
+    const u32 grid_all = col_to - col_from;
+#define COLL_ARGS_WG(W) dim3(grid), dim3(W), 0, ctx->stream, (const u32*)a->d_runs, (const u64*)a->d_off, (const u32*)a->d_cnt, \
         (const u32*)a->d_flags, a->ncols, (const u32*)(s ? s->d_runs : nullptr), (const u64*)(s ? s->d_off : nullptr), \
-        (const u32*)(s ? s->d_cnt : nullptr), (const u32*)(s ? s->d_flags : nullptr), s ? s->ncols : 0u, col_from, col_to, opt_compress, \
+        (const u32*)(s ? s->d_cnt : nullptr), (const u32*)(s ? s->d_flags : nullptr), s ? s->ncols : 0u, cbase, col_to, opt_compress, \
         d_counts, v ? v->d_bits : (uint4*)nullptr, v ? v->d_desc : (u64*)nullptr, st, hint_from, hint_to
-    if (mode == COLL_OR) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_coll_apply<COLL_OR, 256>), COLL_ARGS);
-    else if (mode == COLL_AND_STORE) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_coll_apply<COLL_AND_STORE, 256>), COLL_ARGS);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_coll_apply<COLL_AND_COUNT, 256>), COLL_ARGS);
-#undef COLL_ARGS
+    // coll_shape (tuning): 0 = 256 threads, 1 = 256 threads + prefetch, 2 = 512 threads, 3 = 512 threads + prefetch
+#define COLL_LAUNCH(M) do { \
+        switch (ctx->coll_shape) { \
+        case 1: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_coll_apply<M, 256, true>), COLL_ARGS_WG(256)); break; \
+        case 2: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_coll_apply<M, 512, false>), COLL_ARGS_WG(512)); break; \
+        case 3: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_coll_apply<M, 512, true>), COLL_ARGS_WG(512)); break; \
+        default: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_coll_apply<M, 256, false>), COLL_ARGS_WG(256)); break; } } while (0)
+    // launch windows (coll_window columns per launch; 0 = one launch)
+    const u32 win = ctx->coll_window > 0 ? (u32)ctx->coll_window : grid_all;
+    for (u32 w0 = 0; w0 < grid_all; w0 += win) {
+        const u32 grid = std::min(win, grid_all - w0);
+        const u32 cbase = col_from + w0;
+        if (mode == COLL_OR) COLL_LAUNCH(COLL_OR);
+        else if (mode == COLL_AND_STORE) COLL_LAUNCH(COLL_AND_STORE);
+        else COLL_LAUNCH(COLL_AND_COUNT);
+    }
+#undef COLL_LAUNCH
+#undef COLL_ARGS_WG
     KCHK();
     return BMX_OK;
 }
@@ -469,7 +483,7 @@ int bmx_ctx_create(int device, void* stream, bmx_ctx** out)
     // an invalid value is ignored (the default stays)
     static const char* const env_keys[][2] = {
         {"BMX_PIPE_UNROLL", "pipe_unroll"}, {"BMX_PIPE_ROWS", "pipe_rows"}, {"BMX_PIPE_NT", "pipe_nt"},
-        {"BMX_PIPE_WG", "pipe_wg"}, {"BMX_PIPE_WINDOW", "pipe_window"}, {"BMX_PIPE_SPLIT", "pipe_split"}, {"BMX_OR_TILE", "or_tile"}, {"BMX_OR_WINDOW", "or_window"}, {"BMX_DIRECT_COLS", "direct_cols"}, {"BMX_FF_WINDOW", "ff_window"}, {"BMX_GAP_COUNT", "gap_count"}, {"BMX_RANGE_HALVES", "range_halves"}, {"BMX_PAIR_STREAM", "pair_stream"}, {"BMX_PAIR_WGS", "pair_wgs"}, {"BMX_RS_LANES", "rs_lanes"}, {"BMX_GAP_PACK", "gap_pack"}, {"BMX_XCD_SWIZZLE", "xcd_swizzle"}};
+        {"BMX_PIPE_WG", "pipe_wg"}, {"BMX_PIPE_WINDOW", "pipe_window"}, {"BMX_PIPE_SPLIT", "pipe_split"}, {"BMX_OR_TILE", "or_tile"}, {"BMX_OR_WINDOW", "or_window"}, {"BMX_DIRECT_COLS", "direct_cols"}, {"BMX_FF_WINDOW", "ff_window"}, {"BMX_GAP_COUNT", "gap_count"}, {"BMX_RANGE_HALVES", "range_halves"}, {"BMX_PAIR_STREAM", "pair_stream"}, {"BMX_PAIR_WGS", "pair_wgs"}, {"BMX_RS_LANES", "rs_lanes"}, {"BMX_COLL_SHAPE", "coll_shape"}, {"BMX_COLL_WINDOW", "coll_window"}, {"BMX_GAP_PACK", "gap_pack"}, {"BMX_XCD_SWIZZLE", "xcd_swizzle"}};
     for (auto& kv : env_keys)
         if (const char* e = getenv(kv[0])) (void)bmx_ctx_set_tuning(ctx, kv[1], atoi(e));
     g_last_error.clear();
@@ -524,6 +538,8 @@ int bmx_ctx_set_tuning(bmx_ctx* ctx, const char* key, int value)
     else if (k == "ff_window") { ARGCHK(value >= -1); ctx->ff_window = value; }
     else if (k == "or_window") { ARGCHK(value >= -9); ctx->or_window = value; }
     else if (k == "gap_pack") { ARGCHK(value >= -1 && value <= 1); ctx->gap_pack = value; }
+    else if (k == "coll_shape") { ARGCHK(value >= 0 && value <= 3); ctx->coll_shape = value; }
+    else if (k == "coll_window") { ARGCHK(value >= 0); ctx->coll_window = value; }
     else if (k == "rs_lanes") { ARGCHK(value == 0 || value == 2 || value == 4 || value == 8); ctx->rs_lanes = value; }
     else if (k == "pipe_wg") { ARGCHK(value == 0 || (value >= 64 && value <= 1024 && value % 64 == 0)); ctx->pipe_wg = value; }
     else if (k == "xcd_swizzle") ctx->xcd_swz = value != 0;

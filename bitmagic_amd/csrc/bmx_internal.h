@@ -68,6 +68,8 @@ struct bmx_ctx {
     uint64_t pack_cap = 96ull << 30, pack_bytes = 0, coll_tick = 0;
     float last_pack_ms = 0.f;
     uint32_t max_lds_bytes = 160u * 1024u;   // hipDeviceAttributeMaxSharedMemoryPerBlock of the device (queried at creation)
+    int coll_shape = 2;        // k_coll_apply shape: 0 = 256 threads, 1 = 256 + prefetch, 2 = 512 (default: configs[4] 2.50 vs 2.61 ms, the AND cases equal), 3 = 512 + prefetch
+    int coll_window = 0;       // block columns per launch of k_coll_apply (0 = one launch)
     int rs_lanes = 0;          // rank: lanes per query (k_rank_l): 0 = automatic, 8 = the original kernel, 2, 4
     int xcd_swz = 1;
 };

@@ -134,18 +134,21 @@ __device__ __forceinline__ void coll_apply_run(u32 r, bool valid, u32* U, int* D
     }
 }
 
-// all entries [0, cnt) of one column, 16 bytes per lane per load, four loads in flight per lane; returns (per thread)
-// whether it produced an interior-word span
-template <int WG>
+// all entries [0, cnt) of one column, 16 bytes per lane per load, four loads per batch; PF: the next batch is requested
+// before the current one is applied (two batches in flight per lane; indices past the end are clamped to the column's last
+// chunk so that every iteration issues the same loads).  Returns (per thread) whether it produced an interior-word span
+template <int WG, bool PF>
 __device__ __forceinline__ u32 coll_apply_bag(const u32* __restrict__ runs, u64 off, u32 cnt, u32* U, int* D, u32 tid)
 {
     gcptr4 p = as_gc4(runs + off);
     const u32 nq = (cnt + 3u) >> 2;
     u32 any_long = 0u;
-    for (u32 q0 = tid; q0 < nq; q0 += 4u * WG) {
-        u32x4 v[4];
+    if (!nq) return 0u;
+    auto fetch = [&](u32x4 (&v)[4], u32 q0) {
 #pragma unroll
         for (u32 j = 0; j < 4; ++j) { u32 q = q0 + j * WG; v[j] = __builtin_nontemporal_load(&p[q < nq ? q : nq - 1u]); }
+    };
+    auto apply = [&](const u32x4 (&v)[4], u32 q0) {
 #pragma unroll
         for (u32 j = 0; j < 4; ++j) {
             u32 q = q0 + j * WG;
@@ -156,6 +159,20 @@ __device__ __forceinline__ u32 coll_apply_bag(const u32* __restrict__ runs, u64 
             coll_apply_run(v[j].z, in && e0 + 2u < cnt, U, D, any_long);
             coll_apply_run(v[j].w, in && e0 + 3u < cnt, U, D, any_long);
         }
+    };
+    if constexpr (PF) {
+        // every thread of the workgroup runs the same number of rounds (the bound does not depend on tid)
+        u32x4 a[4], b[4];
+        const u32 rounds = (nq + 4u * WG - 1u) / (4u * WG);
+        fetch(a, tid);
+        for (u32 r = 0; r < rounds; r += 2u) {
+            fetch(b, tid + (r + 1u) * 4u * WG);
+            apply(a, tid + r * 4u * WG);
+            fetch(a, tid + (r + 2u) * 4u * WG);
+            apply(b, tid + (r + 1u) * 4u * WG);
+        }
+    } else {
+        for (u32 q0 = tid; q0 < nq; q0 += 4u * WG) { u32x4 v[4]; fetch(v, q0); apply(v, q0); }
     }
     return any_long;
 }
@@ -210,7 +227,7 @@ enum { COLL_OR = 0, COLL_AND_STORE = 1, COLL_AND_COUNT = 2 };
 //   COLL_AND_STORE  result = NOT union(AND bag, polarity 0) AND NOT union(SUB bag, polarity 1), stored with opt_compress
 //                   (combine_and_sub, :1162,1210)
 //   COLL_AND_COUNT  the same, counted (counts-only pipeline of one arg-group, :1292-1399)
-template <int MODE, int WG>
+template <int MODE, int WG, bool PF = false>
 __global__ __launch_bounds__(WG)
 void k_coll_apply(const u32* __restrict__ runs, const u64* __restrict__ off, const u32* __restrict__ cnt,
                   const u32* __restrict__ flags, u32 ncols_a,
@@ -252,7 +269,7 @@ void k_coll_apply(const u32* __restrict__ runs, const u64* __restrict__ off, con
     }
     if (tid == 0) s_long = 0u;
     __syncthreads();
-    u32 al = coll_apply_bag<WG>(runs, uniform64(off[c < ncols_a ? c : 0u]), n_ent, U, D, tid);
+    u32 al = coll_apply_bag<WG, PF>(runs, uniform64(off[c < ncols_a ? c : 0u]), n_ent, U, D, tid);
     if (al) s_long = 1u;
     __syncthreads();
     if (s_long) coll_fold<WG>(U, D, sm, tid);                 // (block-uniform; the barriers inside are reached by every thread)
@@ -275,7 +292,7 @@ void k_coll_apply(const u32* __restrict__ runs, const u64* __restrict__ off, con
         for (u32 k = 0; k < W; k += 4u) *reinterpret_cast<u32x4*>(&U[tid * W + k]) = (u32x4)(0u);
         if (tid == 0) s_long = 0u;
         __syncthreads();
-        u32 sl = coll_apply_bag<WG>(s_runs, uniform64(s_off[c]), s_ent, U, D, tid);
+        u32 sl = coll_apply_bag<WG, PF>(s_runs, uniform64(s_off[c]), s_ent, U, D, tid);
         if (sl) s_long = 1u;
         __syncthreads();
         if (s_long) coll_fold<WG>(U, D, sm, tid);
