@@ -224,6 +224,48 @@ void download(const gbvector& src, BMBV& dst)
     install(dst, nblocks, kinds.data(), offs.data(), bits.data(), gaps.data());
 }
 
+/// bm::bvector<>::build_rs_index(&rs) with the block popcounts computed on the GPU: `dev` is the device copy of `bv`
+/// (bmx::upload), the index words come back through bmx_rs_export in the reference's own layout and are installed with
+/// the calls build_rs_index itself uses (src/bm.h:2531-2660: init / set_total / resize / resize_effective_super_blocks /
+/// set_null_super_block / set_full_super_block / register_super_block).  The HOST index then answers single
+/// count_to / rank / select calls at CPU latency (~50 ns; a device launch per single query costs ~20 us), while batches
+/// of queries go to bmx::bvector::count_to / select on the device copy.
+template <class BMBV>
+void build_rs_index(const BMBV& bv, const bvector& dev, typename BMBV::rs_index_type* rs_idx)
+{
+    typedef typename BMBV::size_type bm_size_type;
+    rs_idx->init();
+    const typename BMBV::blocks_manager_type& bman = bv.get_blocks_manager();
+    if (!bman.is_init()) return;
+    bm_size_type last_bit;
+    if (!bv.find_reverse(last_bit)) return;
+    uint64_t nb = (uint64_t)(last_bit >> bm::set_block_shift);
+    const unsigned real_top_blocks = bman.find_real_top_blocks();
+    const unsigned max_top_blocks = bman.find_max_top_blocks();
+    if (nb < (uint64_t)max_top_blocks * bm::set_sub_array_size) nb = (uint64_t)max_top_blocks * bm::set_sub_array_size;
+    rs_idx->set_total((bm_size_type)(nb + 1));
+    rs_idx->resize((typename BMBV::block_idx_type)(nb + 1));
+    rs_idx->resize_effective_super_blocks(real_top_blocks);
+    rs_index drs;
+    dev.build_rs_index(&drs);
+    const uint32_t dev_blocks = dev.block_count();
+    std::vector<uint32_t> bcount; std::vector<uint64_t> sub;
+    drs.export_blocks(bcount, sub, dev_blocks);
+    bm::word_t*** blk_root = bman.top_blocks_root();
+    unsigned bc[bm::set_sub_array_size]; bm::id64_t sc[bm::set_sub_array_size];
+    for (unsigned i = 0; i < max_top_blocks; ++i) {
+        bm::word_t** blk_blk = blk_root[i];
+        if (!blk_blk) { rs_idx->set_null_super_block(i); continue; }
+        if ((bm::word_t*)blk_blk == FULL_BLOCK_FAKE_ADDR) { rs_idx->set_full_super_block(i); continue; }
+        for (unsigned j = 0; j < bm::set_sub_array_size; ++j) {
+            const uint64_t b = (uint64_t)i * bm::set_sub_array_size + j;
+            bc[j] = b < dev_blocks ? bcount[(size_t)b] : 0u;
+            sc[j] = b < dev_blocks ? (bm::id64_t)sub[(size_t)b] : 0ull;
+        }
+        rs_idx->register_super_block(i, &bc[0], &sc[0]);
+    }
+}
+
 /// process-wide default context for code that constructs its aggregators without arguments (device: BMX_DEVICE, default 0)
 inline context& default_context()
 {

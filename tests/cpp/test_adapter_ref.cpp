@@ -249,6 +249,25 @@ int main()
               for (int k = 0; k < 3; ++k) { bvect r; r2.find_eq(S, (unsigned)vals3[k], r); REQUIRE(got3[k] == r.count()); } }
         }
     }
+    // host rs_index filled from the GPU-built index (bmx::build_rs_index): identical answers to the reference's own index
+    for (unsigned v = 0; v < 4; ++v) {
+        bvect::rs_index_type rs_ref, rs_gpu;
+        hv[v].build_rs_index(&rs_ref);
+        bmx::build_rs_index(hv[v], gv[v], &rs_gpu);
+        REQUIRE(rs_ref.count() == rs_gpu.count() && rs_ref.get_total() == rs_gpu.get_total());
+        uint64_t x = 0x2545F4914F6CDD1Dull + v;
+        for (int it = 0; it < 3000; ++it) {
+            x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+            bvect::size_type n = (bvect::size_type)(x % nbits);
+            REQUIRE(hv[v].count_to(n, rs_ref) == hv[v].count_to(n, rs_gpu));
+            bvect::size_type cnt = rs_ref.count();
+            if (cnt) {
+                bvect::size_type r = (bvect::size_type)(1 + (x >> 20) % cnt), p1 = 0, p2 = 0;
+                bool f1 = hv[v].select(r, p1, rs_ref), f2 = hv[v].select(r, p2, rs_gpu);
+                REQUIRE(f1 == f2 && p1 == p2);
+            }
+        }
+    }
     // set_range_hint + find_first_and_sub vs the real aggregator (src/bmaggregator.h:974,1458)
     {
         bm::aggregator<bvect> ragg; bmx::aggregator<bmx::bvector> gagg(ctx);
