@@ -70,6 +70,7 @@ struct bmx_ctx {
     uint32_t max_lds_bytes = 160u * 1024u;   // hipDeviceAttributeMaxSharedMemoryPerBlock of the device (queried at creation)
     int coll_shape = 2;        // k_coll_apply shape: 0 = 256 threads, 1 = 256 + prefetch, 2 = 512 (default: configs[4] 2.50 vs 2.61 ms, the AND cases equal), 3 = 512 + prefetch
     int coll_window = 0;       // block columns per launch of k_coll_apply (0 = one launch)
+    int rs_lines = 1;          // build_rs_index also lays the vector out as rank lines (one 128-B line per rank query; +108 % memory next to the vector): 0 = off
     int rs_lanes = 0;          // rank: lanes per query (k_rank_l): 0 = automatic, 8 = the original kernel, 2, 4
     int xcd_swz = 1;
 };
@@ -122,6 +123,7 @@ struct bmx_rs {
     u32* d_bcount; u64* d_sub; u64* d_rcount; u16* d_cum;
     u16* d_gidx;                                          // GAP blocks: first run reaching each 1024-bit wave
     u64* d_sample; uint32_t nsamples, sample_shift;       // top level of the select search (<= 2048 entries)
+    u32* d_lines;                                         // rank lines: 69 x 128 B per block (count before the line + 960 bits), or null
     size_t bytes;
 };
 

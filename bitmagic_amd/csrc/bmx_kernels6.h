@@ -387,3 +387,90 @@ void k_expand_indices(const u64* __restrict__ desc, u32 nblocks, const u64* __re
         row_off += tot;
     }
 }
+
+// ---------------------------------------------------------------------------
+// Rank lines (round 3): count_to / rank with ONE random 128-byte line per query.
+// k_rank reads four things per query -- descriptor, running count, cumulative count of the 1024-bit wave, the bit line --
+// and the PMC shows 1.6 lines per query leaving the L2 (the 7.8 MB cumulative table does not stay in a 4 MB L2): 0.8 of the
+// box's random-line rate by traffic, 0.49 by what the query needs.  The classic fix of succinct rank dictionaries
+// (rank9 / poppy: counts interleaved with the bits they describe) maps directly onto 128-byte lines: a line holds a 64-bit
+// count of the ones BEFORE it in the whole vector and the next 960 bits, so rank(n) = header + popcount of the line's bits
+// up to n -- one line, no index table, no block kinds (GAP / FULL / NULL blocks are stored expanded).  A 64 Kbit block is 69
+// lines (the last one partly used): 8,832 B per block = +7.8 % over raw bits, on top of the vector itself: HBM capacity is
+// not the constraint here (a 4e9-bit vector: 539 MB next to its 500 MB).  Same results by construction: the header is the
+// running count the index already has, the rest is a popcount.
+// ---------------------------------------------------------------------------
+#define RL_LINES 69u            // ceil(65536 / 960)
+#define RL_BITS 960u            // data bits per line (30 words behind the 2-word header)
+
+__global__ __launch_bounds__(256)
+void k_rs_lines(const u64* __restrict__ desc, u32 nblocks, const u64* __restrict__ rcount, u32* __restrict__ lines)
+{
+    __shared__ u32 lds_all[4 * 2048];
+    __shared__ u64 hdr_all[4 * 72];
+    u32 lane = lane_id(), wave = threadIdx.x >> 6;
+    u32 nb = uniform32(blockIdx.x * 4u + wave);
+    if (nb >= nblocks) return;
+    u32* lds = lds_all + wave * 2048u;
+    u64* hdr = hdr_all + wave * 72u;
+    Blk b;
+    blk_from_desc(uniform64(desc[nb]), b, lds, lane);
+    blk_to_lds(b, lds, lane);                                 // linear word order
+    const u64 before = nb ? rcount[nb - 1u] : 0ull;
+    // ones of every line, then their exclusive prefix: lanes 0..63 own lines 0..63, lanes 0..4 also lines 64..68
+    u32 c0 = 0, c1 = 0;
+    for (u32 t = 0; t < 30u; ++t) {
+        u32 w0 = lane * 30u + t, w1 = (lane + 64u) * 30u + t;
+        c0 += w0 < 2048u ? (u32)__popc(lds[w0]) : 0u;
+        c1 += (lane + 64u < RL_LINES && w1 < 2048u) ? (u32)__popc(lds[w1]) : 0u;
+    }
+    u32 i0 = wave_scan_incl(c0, lane);
+    u32 tot0 = uniform32(__shfl(i0, 63, 64));
+    u32 i1 = wave_scan_incl(c1, lane);
+    hdr[lane] = before + (u64)(i0 - c0);
+    if (lane + 64u < RL_LINES) hdr[lane + 64u] = before + (u64)tot0 + (u64)(i1 - c1);
+    u32* out = lines + (size_t)nb * (RL_LINES * 32u);
+    for (u32 o = lane; o < RL_LINES * 32u; o += 64u) {        // coalesced 256-byte stores
+        u32 line = o >> 5, t = o & 31u;
+        u32 v;
+        if (t < 2u) { u64 h = hdr[line]; v = t ? (u32)(h >> 32) : (u32)h; }
+        else { u32 w = line * 30u + (t - 2u); v = w < 2048u ? lds[w] : 0u; }
+        out[o] = v;
+    }
+}
+
+template <u32 LPQ>
+__global__ __launch_bounds__(256)
+void k_rank_lines(const u32* __restrict__ lines, u32 nblocks, u64 total, const u64* __restrict__ q, u64 nq, u64* __restrict__ out)
+{
+    constexpr u32 NV = 8u / LPQ;
+    const u32 sub = threadIdx.x & (LPQ - 1u);
+    u64 qi = ((u64)blockIdx.x * blockDim.x + threadIdx.x) / LPQ;
+    const u64 stride = ((u64)gridDim.x * blockDim.x) / LPQ;
+    const u64 nq_round = (nq + (64u / LPQ) - 1ull) / (64u / LPQ) * (64u / LPQ);
+    for (; qi < nq_round; qi += stride) {
+        const bool live = qi < nq;
+        const u64 n = live ? q[qi] : 0ull;
+        const u64 nb64 = n >> 16;
+        const bool in = live && nb64 < nblocks;
+        const u32 off = in ? (u32)(n & 0xFFFFu) : 0u;
+        const u32 j = off / RL_BITS, pos = off - j * RL_BITS;            // line of the block, bit inside its data words
+        gcptr4 p = as_gc4(lines + ((size_t)(in ? (u32)nb64 : 0u) * RL_LINES + j) * 32u) + sub * NV;
+        u32x4 v[NV];
+#pragma unroll
+        for (u32 i = 0; i < NV; ++i) v[i] = p[i];
+        u32 part = 0;
+#pragma unroll
+        for (u32 i = 0; i < NV; ++i) {
+            const u32 w = (sub * NV + i) * 4u;                            // word of the line held in v[i].x
+            // data word d = w - 2 covers bits [32 d, 32 d + 31] of the line; words 0, 1 are the header
+            if (w >= 2u) part += word_count_to(v[i].x, w - 2u, pos);
+            if (w + 1u >= 2u) part += word_count_to(v[i].y, w + 1u - 2u, pos);
+            part += word_count_to(v[i].z, w, pos) + word_count_to(v[i].w, w + 1u, pos);
+        }
+#pragma unroll
+        for (u32 o = 1; o < LPQ; o <<= 1) part += __shfl_xor(part, o, 64);
+        const u64 head = ((u64)v[0].y << 32) | v[0].x;                   // valid in the group's lane 0 (sub == 0)
+        if (live && sub == 0) out[qi] = in ? head + part : total;        // past the end: the total (src/bm.h:3133)
+    }
+}

@@ -1194,13 +1194,15 @@ def test_range_hint(ctx, port, agg_path):
         agg.reset_range_hint()
 
 
-@pytest.mark.parametrize("unroll", [8, 2, 4])
-def test_rank_select_queries_in_flight_forms(port, unroll):
-    """k_rank_l<2|4> (fewer lanes per query = more queries in flight) and the 8-lane kernels must give the oracle's
-    answers on every block kind -- NULL, FULL, bit, sparse and dense GAP -- incl. dead queries (rank 0, rank > count,
-    position past the end) and batches that do not fill the last round"""
+@pytest.mark.parametrize("unroll,lines", [(8, 0), (2, 0), (4, 0), (2, 1), (4, 1)])
+def test_rank_select_queries_in_flight_forms(port, unroll, lines):
+    """k_rank_l<2|4> (fewer lanes per query = more queries in flight), k_rank_lines<2|4> (the vector laid out as rank
+    lines: one 128-byte line per query) and the 8-lane kernels must give the oracle's answers on every block kind --
+    NULL, FULL, bit, sparse and dense GAP -- incl. dead queries (rank 0, rank > count, position past the end) and
+    batches that do not fill the last round"""
     c = bm.context(0)
     c.set_tuning("rs_lanes", unroll)
+    c.set_tuning("rs_lines", lines)
     rng = np.random.default_rng(1234 + unroll)
     nblk = 23
     nbits = nblk * 65536 - 777
@@ -1228,7 +1230,9 @@ def test_rank_select_queries_in_flight_forms(port, unroll):
     cnt = p.count()
     for nq in (1, 7, 8, 9, 63, 1000, 4097):
         q = np.concatenate([rng.integers(0, nbits, size=nq).astype(np.uint64), np.array([0, nbits - 1, nbits, nbits + 70000, 65535, 65536], np.uint64)])
-        assert (v.rank(q, rs) == prs.rank(q)).all(), (unroll, nq)
+        assert (v.rank(q, rs) == prs.rank(q)).all(), (unroll, lines, nq)
+        every = np.arange(max(0, int(q[0]) - 2000), min(nbits, int(q[0]) + 2000), dtype=np.uint64)    # every position around a query: all line / word borders
+        assert (v.rank(every, rs) == prs.rank(every)).all(), (unroll, lines, nq)
         r = np.concatenate([rng.integers(1, cnt + 1, size=nq).astype(np.uint64), np.array([1, cnt, 0, cnt + 1, 2 ** 40], np.uint64)])
         found, pos = v.select(r, rs)
         ppos, pfound = prs.select(r)
