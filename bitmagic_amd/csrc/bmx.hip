@@ -2452,7 +2452,8 @@ int bmx_rs_export(bmx_ctx* ctx, const bmx_rs* rs, uint32_t* bcount, uint64_t* su
     return BMX_OK;
 }
 
-#define RS_LANES_DEFAULT 4
+#define RS_LANES_DEFAULT 2
+#define RS_SELECT_LANES_DEFAULT 4
 static u32 query_grid(size_t q) { return (u32)std::min<size_t>((q * 8 + 255) / 256, 256u * 16u); }
 
 int bmx_rank_batch_dev(bmx_ctx* ctx, const bmx_vec* v, const bmx_rs* rs, const uint64_t* d_n, size_t q, uint64_t* d_out)
@@ -2483,9 +2484,15 @@ int bmx_select_batch_dev(bmx_ctx* ctx, const bmx_vec* v, const bmx_rs* rs, const
     ARGCHK(ctx && v && rs && v->ctx == ctx && rs->ctx == ctx && rs->nblocks == v->nblocks && (q == 0 || (d_rank && d_pos && d_found)));
     int rc = set_dev(ctx); if (rc) return rc;
     if (!q) return BMX_OK;
-    hipLaunchKernelGGL(k_select, dim3(query_grid(q)), dim3(256), 0, ctx->stream, v->d_desc, v->nblocks,
-                       rs->d_rcount, rs->d_cum, rs->d_gidx, rs->d_sample, rs->nsamples, rs->sample_shift, rs->count,
-                       (const u64*)d_rank, (u64)q, (u64*)d_pos, (u8*)d_found);
+    int lpq = ctx->rs_lanes ? ctx->rs_lanes : (q >= (1u << 16) ? RS_SELECT_LANES_DEFAULT : 8);
+    u32 grid = (u32)std::min<size_t>((q * (size_t)lpq + 255) / 256, 256u * 16u);
+#define SEL_ARGS dim3(grid), dim3(256), 0, ctx->stream, v->d_desc, v->nblocks, \
+                 rs->d_rcount, rs->d_cum, rs->d_gidx, rs->d_sample, rs->nsamples, rs->sample_shift, rs->count, \
+                 (const u64*)d_rank, (u64)q, (u64*)d_pos, (u8*)d_found
+    if (lpq == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_select_l<2>), SEL_ARGS);
+    else if (lpq == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_select_l<4>), SEL_ARGS);
+    else hipLaunchKernelGGL(k_select, SEL_ARGS);
+#undef SEL_ARGS
     KCHK();
     return BMX_OK;
 }

@@ -474,3 +474,179 @@ void k_rank_lines(const u32* __restrict__ lines, u32 nblocks, u64 total, const u
         if (live && sub == 0) out[qi] = in ? head + part : total;        // past the end: the total (src/bm.h:3133)
     }
 }
+
+// ---------------------------------------------------------------------------
+// k_select with LPQ = 2 / 4 lanes per query (k_select gives a query 8 lanes).  select is three dependent stages -- the last
+// <= 32 running counts, then previous count + descriptor + cumulative row, then the bit line -- and the PMC shows it at
+// half the random-line rate its 2 lines per query would allow: it is bound by how many queries a CU keeps in flight, so
+// fewer lanes per query (16 / 32 queries per wave step instead of 8) is the lever.  Same arithmetic, regrouped.
+// ---------------------------------------------------------------------------
+template <u32 LPQ>
+__device__ __forceinline__ u32 group_sum(u32 v)
+{
+#pragma unroll
+    for (u32 o = 1; o < LPQ; o <<= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+template <u32 LPQ>
+__device__ __forceinline__ u32 group_max(u32 v)
+{
+#pragma unroll
+    for (u32 o = 1; o < LPQ; o <<= 1) { u32 t = __shfl_xor(v, o, 64); v = t > v ? t : v; }
+    return v;
+}
+// exclusive prefix of `mine` inside the group of LPQ lanes; total in `tot`
+template <u32 LPQ>
+__device__ __forceinline__ u32 group_excl(u32 mine, u32 sub, u32 lane, u32& tot)
+{
+    u32 incl = mine;
+#pragma unroll
+    for (u32 o = 1; o < LPQ; o <<= 1) { u32 t = __shfl_up(incl, o, 64); if (sub >= o) incl += t; }
+    tot = __shfl(incl, (lane & ~(LPQ - 1u)) + (LPQ - 1u), 64);
+    return incl - mine;
+}
+
+template <u32 LPQ>
+__global__ __launch_bounds__(256)
+void k_select_l(const u64* __restrict__ desc, u32 nblocks, const u64* __restrict__ rcount, const u16* __restrict__ cum,
+                const u16* __restrict__ gidx, const u64* __restrict__ sample, u32 nsamples, u32 shift,
+                u64 total, const u64* __restrict__ q, u64 nq, u64* __restrict__ pos, u8* __restrict__ found)
+{
+    constexpr u32 NV = 8u / LPQ;                  // 16-byte pieces of a 128-byte row / line per lane
+    constexpr u32 NR = 32u / LPQ;                 // running counts of the last level per lane
+    __shared__ u64 s_sample[2048];
+    for (u32 i = threadIdx.x; i < nsamples; i += blockDim.x) s_sample[i] = sample[i];
+    __syncthreads();
+    const u32 lane = lane_id();
+    const u32 sub = lane & (LPQ - 1u);
+    u64 qi = ((u64)blockIdx.x * blockDim.x + threadIdx.x) / LPQ;
+    const u64 stride = ((u64)gridDim.x * blockDim.x) / LPQ;
+    const u64 nq_round = (nq + (64u / LPQ) - 1ull) / (64u / LPQ) * (64u / LPQ);
+    for (; qi < nq_round; qi += stride) {
+        const bool live = qi < nq;
+        const u64 r = live ? q[qi] : 0ull;
+        const bool ok = live && r != 0ull && r <= total && nblocks != 0u;
+        u32 sr_lo = 0, sr_hi = 0;
+        if (ok) {
+            // rs_index::find (src/bmrs.h:492): top level in LDS
+            u32 glo = 0, ghi = nsamples - 1u;
+            while (glo < ghi) { u32 mid = glo + ((ghi - glo) >> 1); if (s_sample[mid] < r) glo = mid + 1u; else ghi = mid; }
+            u32 lo = glo << shift, hi = ((glo + 1u) << shift) - 1u;
+            if (hi > nblocks - 1u) hi = nblocks - 1u;
+            while (hi - lo >= 32u) { u32 mid = lo + ((hi - lo) >> 1); if (rcount[mid] < r) lo = mid + 1u; else hi = mid; }
+            sr_lo = lo; sr_hi = hi;
+        }
+        // stage 1: the last <= 32 running counts, NR per lane (unconditional reads, index clamped)
+        u32 below = 0;
+        {
+            u64 rc[NR];
+#pragma unroll
+            for (u32 t = 0; t < NR; ++t) { u32 idx = sr_lo + sub * NR + t; rc[t] = rcount[idx <= sr_hi ? idx : sr_hi]; }
+#pragma unroll
+            for (u32 t = 0; t < NR; ++t) { u32 idx = sr_lo + sub * NR + t; below += (ok && idx <= sr_hi && rc[t] < r) ? 1u : 0u; }
+        }
+        below = group_sum<LPQ>(below);
+        const u32 nb = ok ? sr_lo + below : 0u;
+        // stage 2: previous running count, descriptor, my share of the 64-entry cumulative row
+        const u64 prev = rcount[nb ? nb - 1u : 0u];
+        const u64 d = desc[nb];
+        u32x4 cv[NV];
+#pragma unroll
+        for (u32 i = 0; i < NV; ++i) cv[i] = as_gc4(cum + (size_t)nb * 64u)[sub * NV + i];
+        const u32 kd = ok ? DESC_K(d) : K_NULL;
+        u32 rr = 0, w = 0; u64 result = 0;
+        if (ok) {
+            rr = (u32)(r - (nb ? prev : 0ull));                       // 1..65536 inside the block
+            if (kd == K_FULL) result = ((u64)nb << 16) + rr - 1u;
+        }
+        {
+            // digest wave: the last w with cum[w] < rr (cum[0] = 0 < rr always; the row is non-decreasing)
+            u32 nlt = 0, best = 0;
+#pragma unroll
+            for (u32 i = 0; i < NV; ++i) {
+                const u32 c16[8] = {cv[i].x & 0xFFFFu, cv[i].x >> 16, cv[i].y & 0xFFFFu, cv[i].y >> 16, cv[i].z & 0xFFFFu, cv[i].z >> 16, cv[i].w & 0xFFFFu, cv[i].w >> 16};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { bool lt = c16[j] < rr; nlt += lt ? 1u : 0u; best = (lt && c16[j] > best) ? c16[j] : best; }
+            }
+            nlt = group_sum<LPQ>(nlt);
+            best = group_max<LPQ>(best);
+            if (ok && kd != K_FULL) { w = nlt - 1u; rr -= best; }        // 1..1024 inside the wave
+        }
+        // stage 3: bit-blocks: my share of the wave's 128-byte line (others read their valid cumulative row and ignore it)
+        u32x4 v[NV];
+        {
+            gcptr4 p = kd == K_BIT ? as_gc4(DESC_P(d)) + w * 8u + sub * NV : as_gc4(cum + (size_t)nb * 64u) + sub * NV;
+#pragma unroll
+            for (u32 i = 0; i < NV; ++i) v[i] = p[i];
+        }
+        {
+            const bool isb = kd == K_BIT;
+            u32 wd[4 * NV]; u32 mine = 0;
+#pragma unroll
+            for (u32 i = 0; i < NV; ++i) {
+                wd[4 * i] = isb ? v[i].x : 0u; wd[4 * i + 1] = isb ? v[i].y : 0u; wd[4 * i + 2] = isb ? v[i].z : 0u; wd[4 * i + 3] = isb ? v[i].w : 0u;
+            }
+#pragma unroll
+            for (u32 k = 0; k < 4 * NV; ++k) mine += (u32)__popc(wd[k]);
+            u32 tot;
+            const u32 excl = group_excl<LPQ>(mine, sub, lane, tot);
+            if (isb && rr > excl && rr <= excl + mine) {
+                u32 need = rr - excl;                                // 1..mine within my words
+                u32 word = 0, wi = 0; bool got = false;
+#pragma unroll
+                for (u32 k = 0; k < 4 * NV; ++k) {
+                    const u32 pc = (u32)__popc(wd[k]);
+                    if (!got) { if (need <= pc) { word = wd[k]; wi = k; got = true; } else need -= pc; }
+                }
+                for (u32 s_ = 1; s_ < need; ++s_) word &= word - 1u;     // word_select (src/bmfunc.h:1084)
+                const u32 bit = (w * 32u + sub * 4u * NV + wi) * 32u + (u32)__builtin_ctz(word);
+                pos[qi] = ((u64)nb << 16) + bit;
+            }
+        }
+        {
+            // GAP blocks: gap_find_rank (src/bmfunc.h:3457) restricted to the digest wave, LPQ lanes x 4 runs per round
+            const bool gq = ok && kd == K_GAP;
+            if (__ballot(gq) != 0ull) {
+                gcptr16 g = gq ? as_gc16(DESC_P(d)) : (gcptr16)(uintptr_t)cum;       // idle lanes read a valid dummy
+                u32 len = 0, s0 = 0, lo = 1, need = rr;
+                const u32 from = w << 10;
+                if (gq) { len = GMETA(d) >> 1; s0 = GMETA(d) & 1u; lo = gidx[(size_t)nb * 64u + w]; }
+                bool searching = gq;
+                for (u32 k0 = lo; __ballot(searching && k0 <= len) != 0ull; k0 += 4u * LPQ) {
+                    const u32 kf = k0 + sub * 4u;
+                    u32 ev[5];
+#pragma unroll
+                    for (u32 t = 0; t < 5; ++t) { u32 kk = kf - 1u + t; ev[t] = (u32)g[(searching && kk <= len) ? kk : 1u]; }
+                    u32 cnt[4], st[4], mine = 0;
+#pragma unroll
+                    for (u32 t = 0; t < 4; ++t) {
+                        const u32 k = kf + t;
+                        const bool one = searching && k <= len && (s0 ^ ((k - 1u) & 1u)) != 0u;
+                        u32 start = (k == 1u) ? 0u : ev[t] + 1u;
+                        if (start < from) start = from;
+                        st[t] = start;
+                        cnt[t] = (one && ev[t + 1u] >= start) ? ev[t + 1u] - start + 1u : 0u;
+                        mine += cnt[t];
+                    }
+                    u32 gtot;
+                    const u32 excl = group_excl<LPQ>(mine, sub, lane, gtot);
+                    if (searching && mine != 0u && need > excl && need <= excl + mine) {
+                        u32 rem = need - excl;
+#pragma unroll
+                        for (u32 t = 0; t < 4; ++t) {
+                            if (rem != 0u && rem <= cnt[t]) { pos[qi] = ((u64)nb << 16) + st[t] + rem - 1u; rem = 0u; }
+                            else if (rem != 0u) rem -= cnt[t];
+                        }
+                    }
+                    if (searching && need <= gtot) searching = false;        // some lane of the group had the hit
+                    else need -= gtot;
+                }
+            }
+        }
+        if (live && sub == 0) {
+            found[qi] = ok ? 1 : 0;
+            if (!ok) pos[qi] = 0;
+            else if (kd != K_BIT && kd != K_GAP) pos[qi] = result;
+        }
+    }
+}
