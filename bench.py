@@ -895,6 +895,7 @@ def run_rank_select(args, env, quick=False):
            "config": {"workload": f"{nq} random rank(n) + {nq} random select(r) per step on a {nbits}-bit vector, Bernoulli {pct:.3g}% (density q16 {dq})",
                       "baseline_config": "configs[3]", "block_types": v.calc_stat(), "count": cnt,
                       "rs_build_ms": round(build_ms, 4), "rank_ms": round(rank_ms, 4), "select_ms": round(sel_ms, 4),
+                      "hbm_resident_bytes": ctx.mem_used(),
                       "rank_Mq_s": round(nq / rank_ms / 1e3, 1), "select_Mq_s": round(nq / sel_ms / 1e3, 1),
                       "rank_select_roundtrip_ok": ok,
                       "rank_ms_sorted_queries": round(sorted_ms, 4), "sort_ms_torch": round(sort_ms, 4),
@@ -902,18 +903,19 @@ def run_rank_select(args, env, quick=False):
                                         "bucketing a batch by block pays only if sort + sorted run < the unsorted run"},
            "roofline": {"bound": "hbm", "achieved": round(rank_lines_s / 1e9, 3), "peak": round(ceil_lines_s / 1e9, 3),
                         "unit": "G lines/s (random 128-byte lines)", "frac": round(rank_lines_s / ceil_lines_s, 4),
-                        "traffic": traffic, "traffic_source": tsrc, "kernel": "k_rank",
+                        "traffic": traffic, "traffic_source": tsrc,
+                        "kernel": ("k_rank_lines<2> (the vector laid out as rank lines by build_rs_index: count before the line + 960 bits per 128-B line)"
+                                   if os.environ.get("BMX_RS_LINES", "1") != "0" and os.environ.get("BMX_RS_LANES", "0") != "8" else "k_rank_l / k_rank (descriptor + running count + cumulative row + bit line)"),
                         "algorithmic_bytes_per_launch": nq * 128, "avg_launch_ms": round(rank_ms, 4),
                         "peak_source": f"bmx_probe_random_lines in this run: {nq} random 128-B lines (8 lanes x 16 B, the access shape of "
                                        f"a rank query's bit line) over a {slab_bytes / 1e6:.0f} MB buffer in {pm.value:.4f} ms",
-                        "select": {"kernel": "k_select", "achieved": round(sel_lines_s / 1e9, 3), "frac": round(sel_lines_s / ceil_lines_s, 4),
+                        "select": {"kernel": "k_select_l<4>", "achieved": round(sel_lines_s / 1e9, 3), "frac": round(sel_lines_s / ceil_lines_s, 4),
                                    "avg_launch_ms": round(sel_ms, 4),
-                                   "note": "one bit line per query after two dependent index round trips"},
+                                   "note": "one bit line per query after two dependent index round trips (running counts, cumulative row)"},
                         "as_bandwidth_GBps": round(nq * 128 / rank_ms / 1e6, 1),
-                        "note": "random access: ONE 128-B bit line per rank query comes from HBM / Infinity Cache (500 MB slab); the "
-                                "three index reads (running count 488 KB, descriptor 488 KB, cumulative row 7.8 MB) are L2 hits -- the "
-                                "bound is the transaction rate of random lines (SURVEY section 8(d)), measured by the probe, not the "
-                                "8 TB/s streaming peak"}}
+                        "note": "random access: ONE 128-B line per rank query is what the algorithm needs, and with the rank-line layout "
+                                "(running count interleaved with the bits) it is also all the kernel reads; the bound is the transaction "
+                                "rate of random lines (SURVEY section 8(d)), measured by the probe, not the 8 TB/s streaming peak"}}
     if not args.no_cpu:
         try:
             P, orc, kind = _pick_oracle()
