@@ -257,14 +257,14 @@ static int coll_get(bmx_ctx* ctx, const bmx_vec* const* v, size_t n, int polarit
 
 // one workgroup per block column over [col_from, col_to); a = the AND / OR bag, s = the SUB bag (may be null)
 static int coll_launch(int mode, bmx_ctx* ctx, const bmx_coll* a, const bmx_coll* s, u32 col_from, u32 col_to, int opt_compress,
-                       u64* d_counts, bmx_vec* v, BlockStat* st, u32 hint_from, u32 hint_to)
+                       u64* d_counts, bmx_vec* v, BlockStat* st, u32 hint_from, u32 hint_to, FoldOut kinds = FoldOut{nullptr, nullptr, nullptr})
 {
     if (col_to <= col_from) return BMX_OK;
     const u32 grid_all = col_to - col_from;
 #define COLL_ARGS_WG(W) dim3(grid), dim3(W), 0, ctx->stream, (const u32*)a->d_runs, (const u64*)a->d_off, (const u32*)a->d_cnt, \
         (const u32*)a->d_flags, a->ncols, (const u32*)(s ? s->d_runs : nullptr), (const u64*)(s ? s->d_off : nullptr), \
         (const u32*)(s ? s->d_cnt : nullptr), (const u32*)(s ? s->d_flags : nullptr), s ? s->ncols : 0u, cbase, col_to, opt_compress, \
-        d_counts, v ? v->d_bits : (uint4*)nullptr, v ? v->d_desc : (u64*)nullptr, st, hint_from, hint_to
+        d_counts, v ? v->d_bits : (uint4*)nullptr, v ? v->d_desc : (u64*)nullptr, st, hint_from, hint_to, kinds
     // coll_shape (tuning): 0 = 256 threads, 1 = 256 threads + prefetch, 2 = 512 threads, 3 = 512 threads + prefetch
 #define COLL_LAUNCH(M) do { \
         switch (ctx->coll_shape) { \
@@ -1652,9 +1652,23 @@ static int agg_or_impl(bmx_ctx* ctx, const bmx_vec* const* src, size_t n, int op
         if (rc) { bmx_vec_free(ctx, v); return rc; }
     } else if (n >= 64 && ncols && has_gap && !has_bit && (rc = coll_get(ctx, src, n, 1, false, &packed)) == BMX_OK && packed) {
         // many GAP-only operands, seen before: one sequential stream per block column (packed collection, bmx_kernels6.h)
-        rc = coll_launch(COLL_OR, ctx, packed, nullptr, 0u, ncols, opt_compress, nullptr, v, st, 0u, 0xFFFFFFFFu);
-        if (!rc) rc = result_finish(ctx, v, st, offs);
-        else (void)hipStreamSynchronize(ctx->stream);
+        // without opt_compress no GAP block can come out: the kernel folds the kind counts of its result itself and, when every
+        // block turned out to be a bit-block (the OR of thousands of sparse vectors), the layout scan is skipped (one launch
+        // window only: the fold's tickets count the workgroups of ONE launch)
+        const bool fold = !opt_compress && ctx->coll_window == 0;
+        rc = coll_launch(COLL_OR, ctx, packed, nullptr, 0u, ncols, opt_compress, nullptr, v, st, 0u, 0xFFFFFFFFu,
+                         fold ? FoldOut{ctx->d_slots, ctx->d_done, ctx->h_small + 2} : FoldOut{nullptr, nullptr, nullptr});
+        bool done = false;
+        if (!rc && fold) {
+            hipError_t e = hipStreamSynchronize(ctx->stream);
+            if (e != hipSuccess) rc = fail_hip(e, "k_coll_apply", __LINE__);
+            else if (ctx->h_small[2 + BMX_GAP] == 0 && ctx->h_small[2 + BMX_BIT] == ncols) {
+                for (int k = 0; k < 4; ++k) v->counts[k] = (uint32_t)ctx->h_small[2 + k];
+                done = true;
+            }
+        }
+        if (!rc && !done) rc = result_finish(ctx, v, st, offs);
+        else if (rc) (void)hipStreamSynchronize(ctx->stream);
         if (rc) { bmx_vec_free(ctx, v); return rc; }
     } else if (rc) { bmx_vec_free(ctx, v); return rc;
     } else if (n >= 64 && ncols && has_gap && !has_bit) {

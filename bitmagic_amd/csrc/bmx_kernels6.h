@@ -234,7 +234,8 @@ void k_coll_apply(const u32* __restrict__ runs, const u64* __restrict__ off, con
                   const u32* __restrict__ s_runs, const u64* __restrict__ s_off, const u32* __restrict__ s_cnt,
                   const u32* __restrict__ s_flags, u32 ncols_s,
                   u32 col_base, u32 ncols, int opt_compress, u64* __restrict__ counts,
-                  uint4* __restrict__ slab, u64* __restrict__ desc, BlockStat* __restrict__ st, u32 hint_from, u32 hint_to)
+                  uint4* __restrict__ slab, u64* __restrict__ desc, BlockStat* __restrict__ st, u32 hint_from, u32 hint_to,
+                  FoldOut kinds /* COLL_OR without opt_compress: the result's kind counts folded in-kernel (no layout scan) */)
 {
     __shared__ __attribute__((aligned(16))) u32 U[2048];
     __shared__ __attribute__((aligned(16))) int D[2048];
@@ -251,8 +252,13 @@ void k_coll_apply(const u32* __restrict__ runs, const u64* __restrict__ off, con
     const u32 fl = c < ncols_a ? uniform32(flags[c]) : (MODE == COLL_OR ? 0u : COLL_FLAG_NULL);
     const u32 n_ent = c < ncols_a ? uniform32(cnt[c]) : 0u;
     if (MODE == COLL_OR) {
-        if (fl & COLL_FLAG_FULL) { if (wave == 0) store_trivial(K_FULL, c, desc, st, lane); return; }
-        if (COLL_NGAP(fl) == 0u) { if (wave == 0) store_trivial(K_NULL, c, desc, st, lane); return; }
+        // trivial columns (every thread of the workgroup takes the same path: the kind fold below has a barrier)
+        if ((fl & COLL_FLAG_FULL) || COLL_NGAP(fl) == 0u) {
+            const u32 k = (fl & COLL_FLAG_FULL) ? (u32)K_FULL : (u32)K_NULL;
+            if (wave == 0) store_trivial(k, c, desc, st, lane);
+            if (kinds.slots) kind_fanin_fold(wave == 0 ? k : 4u, kinds, lane, wave);
+            return;
+        }
     } else {
         const u32 sfl = (s_flags && c < ncols_s) ? uniform32(s_flags[c]) : 0u;
         // any NULL operand in the AND list, or a FULL one in the SUB list: the column is empty (:2327, :1746)
@@ -274,10 +280,12 @@ void k_coll_apply(const u32* __restrict__ runs, const u64* __restrict__ off, con
     __syncthreads();
     if (s_long) coll_fold<WG>(U, D, sm, tid);                 // (block-uniform; the barriers inside are reached by every thread)
     if (MODE == COLL_OR) {
+        u32 kind = 4u;
         if (wave == 0) {
             Blk b; blk_from_lds(b, U, lane);
-            store_result_mode(b, c, opt_compress ? ST_OPT : ST_FORCE_BIT, slab, desc, st, lane);
+            kind = store_result_mode(b, c, opt_compress ? ST_OPT : ST_FORCE_BIT, slab, desc, st, lane);
         }
+        if (kinds.slots) kind_fanin_fold(kind, kinds, lane, wave);
         return;
     }
     // AND: the accumulator is the complement of the union of the 0-runs ...
