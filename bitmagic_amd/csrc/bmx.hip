@@ -483,7 +483,7 @@ int bmx_ctx_create(int device, void* stream, bmx_ctx** out)
     // an invalid value is ignored (the default stays)
     static const char* const env_keys[][2] = {
         {"BMX_PIPE_UNROLL", "pipe_unroll"}, {"BMX_PIPE_ROWS", "pipe_rows"}, {"BMX_PIPE_NT", "pipe_nt"},
-        {"BMX_PIPE_WG", "pipe_wg"}, {"BMX_PIPE_WINDOW", "pipe_window"}, {"BMX_PIPE_SPLIT", "pipe_split"}, {"BMX_OR_TILE", "or_tile"}, {"BMX_OR_WINDOW", "or_window"}, {"BMX_DIRECT_COLS", "direct_cols"}, {"BMX_FF_WINDOW", "ff_window"}, {"BMX_GAP_COUNT", "gap_count"}, {"BMX_RANGE_HALVES", "range_halves"}, {"BMX_PAIR_STREAM", "pair_stream"}, {"BMX_PAIR_WGS", "pair_wgs"}, {"BMX_RS_LANES", "rs_lanes"}, {"BMX_RS_LINES", "rs_lines"}, {"BMX_COLL_SHAPE", "coll_shape"}, {"BMX_COLL_WINDOW", "coll_window"}, {"BMX_GAP_PACK", "gap_pack"}, {"BMX_XCD_SWIZZLE", "xcd_swizzle"}};
+        {"BMX_PIPE_WG", "pipe_wg"}, {"BMX_PIPE_WINDOW", "pipe_window"}, {"BMX_PIPE_SPLIT", "pipe_split"}, {"BMX_OR_TILE", "or_tile"}, {"BMX_OR_WINDOW", "or_window"}, {"BMX_DIRECT_COLS", "direct_cols"}, {"BMX_FF_WINDOW", "ff_window"}, {"BMX_GAP_COUNT", "gap_count"}, {"BMX_RANGE_HALVES", "range_halves"}, {"BMX_PAIR_STREAM", "pair_stream"}, {"BMX_PAIR_WGS", "pair_wgs"}, {"BMX_RS_LANES", "rs_lanes"}, {"BMX_RS_LINES", "rs_lines"}, {"BMX_RS_SELECT_LINES", "rs_select_lines"}, {"BMX_COLL_SHAPE", "coll_shape"}, {"BMX_COLL_WINDOW", "coll_window"}, {"BMX_GAP_PACK", "gap_pack"}, {"BMX_XCD_SWIZZLE", "xcd_swizzle"}};
     for (auto& kv : env_keys)
         if (const char* e = getenv(kv[0])) (void)bmx_ctx_set_tuning(ctx, kv[1], atoi(e));
     g_last_error.clear();
@@ -540,6 +540,7 @@ int bmx_ctx_set_tuning(bmx_ctx* ctx, const char* key, int value)
     else if (k == "gap_pack") { ARGCHK(value >= -1 && value <= 1); ctx->gap_pack = value; }
     else if (k == "coll_shape") { ARGCHK(value >= 0 && value <= 3); ctx->coll_shape = value; }
     else if (k == "coll_window") { ARGCHK(value >= 0); ctx->coll_window = value; }
+    else if (k == "rs_select_lines") { ARGCHK(value == 0 || value == 1); ctx->rs_select_lines = value; }
     else if (k == "rs_lines") { ARGCHK(value == 0 || value == 1); ctx->rs_lines = value; }
     else if (k == "rs_lanes") { ARGCHK(value == 0 || value == 2 || value == 4 || value == 8); ctx->rs_lanes = value; }
     else if (k == "pipe_wg") { ARGCHK(value == 0 || (value >= 64 && value <= 1024 && value % 64 == 0)); ctx->pipe_wg = value; }
@@ -2428,10 +2429,10 @@ int bmx_rs_build(bmx_ctx* ctx, const bmx_vec* v, bmx_rs** out)
         if (ctx->rs_lines) {
             // rank lines (bmx_kernels6.h): the vector once more, interleaved with its running counts -- one line per rank query
             size_t bl = (size_t)v->nblocks * RL_LINES * 128u;
-            if ((rc = dmalloc(ctx, (void**)&rs->d_lines, bl))) { bmx_rs_free(ctx, rs); return rc; }
-            rs->bytes += bl;
+            if ((rc = dmalloc(ctx, (void**)&rs->d_lines, bl)) || (rc = dmalloc(ctx, (void**)&rs->d_dir8, (size_t)v->nblocks * 16u))) { bmx_rs_free(ctx, rs); return rc; }
+            rs->bytes += bl + (size_t)v->nblocks * 16u;
             hipLaunchKernelGGL(k_rs_lines, dim3((v->nblocks + 3) / 4), dim3(256), 0, ctx->stream,
-                               v->d_desc, v->nblocks, (const u64*)rs->d_rcount, rs->d_lines);
+                               v->d_desc, v->nblocks, (const u64*)rs->d_rcount, rs->d_lines, rs->d_dir8);
             RSCHK(hipGetLastError());
         }
         RSCHK(hipMemcpyAsync(ctx->h_small, ctx->d_small, 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -2449,7 +2450,7 @@ int bmx_rs_free(bmx_ctx* ctx, bmx_rs* rs)
     ARGCHK(ctx && rs->ctx == ctx);
     int rc = set_dev(ctx); if (rc) return rc;
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    dfree(ctx, rs->d_bcount); dfree(ctx, rs->d_sub); dfree(ctx, rs->d_rcount); dfree(ctx, rs->d_cum); dfree(ctx, rs->d_gidx); dfree(ctx, rs->d_sample); dfree(ctx, rs->d_lines);
+    dfree(ctx, rs->d_bcount); dfree(ctx, rs->d_sub); dfree(ctx, rs->d_rcount); dfree(ctx, rs->d_cum); dfree(ctx, rs->d_gidx); dfree(ctx, rs->d_sample); dfree(ctx, rs->d_lines); dfree(ctx, rs->d_dir8);
     delete rs;
     return BMX_OK;
 }
@@ -2503,7 +2504,15 @@ int bmx_select_batch_dev(bmx_ctx* ctx, const bmx_vec* v, const bmx_rs* rs, const
 #define SEL_ARGS dim3(grid), dim3(256), 0, ctx->stream, v->d_desc, v->nblocks, \
                  rs->d_rcount, rs->d_cum, rs->d_gidx, rs->d_sample, rs->nsamples, rs->sample_shift, rs->count, \
                  (const u64*)d_rank, (u64)q, (u64*)d_pos, (u8*)d_found
-    if (lpq == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_select_l<2>), SEL_ARGS);
+    if (rs->d_lines && lpq != 8 && ctx->rs_select_lines) {
+        if (lpq == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_select_lines<2>), dim3(grid), dim3(256), 0, ctx->stream, (const u32*)rs->d_lines, (const u16*)rs->d_dir8,
+                                         v->nblocks, (const u64*)rs->d_rcount, (const u64*)rs->d_sample, rs->nsamples, rs->sample_shift, rs->count,
+                                         (const u64*)d_rank, (u64)q, (u64*)d_pos, (u8*)d_found);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_select_lines<4>), dim3(grid), dim3(256), 0, ctx->stream, (const u32*)rs->d_lines, (const u16*)rs->d_dir8,
+                                v->nblocks, (const u64*)rs->d_rcount, (const u64*)rs->d_sample, rs->nsamples, rs->sample_shift, rs->count,
+                                (const u64*)d_rank, (u64)q, (u64*)d_pos, (u8*)d_found);
+    }
+    else if (lpq == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_select_l<2>), SEL_ARGS);
     else if (lpq == 4) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_select_l<4>), SEL_ARGS);
     else hipLaunchKernelGGL(k_select, SEL_ARGS);
 #undef SEL_ARGS

@@ -71,6 +71,7 @@ struct bmx_ctx {
     int coll_shape = 2;        // k_coll_apply shape: 0 = 256 threads, 1 = 256 + prefetch, 2 = 512 (default: configs[4] 2.50 vs 2.61 ms, the AND cases equal), 3 = 512 + prefetch
     int coll_window = 0;       // block columns per launch of k_coll_apply (0 = one launch)
     int rs_lines = 1;          // build_rs_index also lays the vector out as rank lines (one 128-B line per rank query; +108 % memory next to the vector): 0 = off
+    int rs_select_lines = 1;   // select through the rank lines (octant directory + interpolated line guess verified by the line headers): 0 = k_select_l
     int rs_lanes = 0;          // rank: lanes per query (k_rank_l): 0 = automatic, 8 = the original kernel, 2, 4
     int xcd_swz = 1;
 };
@@ -124,6 +125,7 @@ struct bmx_rs {
     u16* d_gidx;                                          // GAP blocks: first run reaching each 1024-bit wave
     u64* d_sample; uint32_t nsamples, sample_shift;       // top level of the select search (<= 2048 entries)
     u32* d_lines;                                         // rank lines: 69 x 128 B per block (count before the line + 960 bits), or null
+    u16* d_dir8;                                          // with rank lines: ones of a block before each of its eight 8,192-bit octants
     size_t bytes;
 };
 

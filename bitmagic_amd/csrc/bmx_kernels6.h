@@ -412,7 +412,8 @@ void k_expand_indices(const u64* __restrict__ desc, u32 nblocks, const u64* __re
 #define RL_BITS 960u            // data bits per line (30 words behind the 2-word header)
 
 __global__ __launch_bounds__(256)
-void k_rs_lines(const u64* __restrict__ desc, u32 nblocks, const u64* __restrict__ rcount, u32* __restrict__ lines)
+void k_rs_lines(const u64* __restrict__ desc, u32 nblocks, const u64* __restrict__ rcount, u32* __restrict__ lines,
+                u16* __restrict__ dir8 /* [nblocks][8]: ones of the block before bit 8192 k */)
 {
     __shared__ u32 lds_all[4 * 2048];
     __shared__ u64 hdr_all[4 * 72];
@@ -437,6 +438,14 @@ void k_rs_lines(const u64* __restrict__ desc, u32 nblocks, const u64* __restrict
     u32 i1 = wave_scan_incl(c1, lane);
     hdr[lane] = before + (u64)(i0 - c0);
     if (lane + 64u < RL_LINES) hdr[lane + 64u] = before + (u64)tot0 + (u64)(i1 - c1);
+    // the block's coarse directory for select: ones before every 8,192-bit octant (256 words each)
+    {
+        u32 pc = 0;
+        for (u32 t = 0; t < 32u; ++t) pc += (u32)__popc(lds[lane * 32u + t]);      // lane = 32 words = 1/64 of the block
+        u32 incl = wave_scan_incl(pc, lane);
+        u32 excl = incl - pc;
+        if ((lane & 7u) == 0u) dir8[(size_t)nb * 8u + (lane >> 3)] = (u16)excl;    // lanes 0, 8, 16, ..: 256 words apiece
+    }
     u32* out = lines + (size_t)nb * (RL_LINES * 32u);
     for (u32 o = lane; o < RL_LINES * 32u; o += 64u) {        // coalesced 256-byte stores
         u32 line = o >> 5, t = o & 31u;
@@ -655,6 +664,124 @@ void k_select_l(const u64* __restrict__ desc, u32 nblocks, const u64* __restrict
             found[qi] = ok ? 1 : 0;
             if (!ok) pos[qi] = 0;
             else if (kd != K_BIT && kd != K_GAP) pos[qi] = result;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// select over rank lines (round 3).  k_select[_l] reads, per query, <= 32 running counts (L2), the block's 128-byte
+// cumulative row (misses the L2 six times out of ten) and the bit line: 2 lines per query past the L2 and a long
+// instruction path.  With the vector laid out as rank lines the block search stays (LDS samples + <= 32 running counts),
+// then a 16-byte directory entry (ones before every 8,192-bit octant of the block: 1 MB for 4e9 bits, L2-resident) gives
+// the octant, the line inside it is GUESSED by interpolation (ones are spread evenly enough in most data) and verified
+// against the line's own header -- the exact count of ones before it -- stepping to the neighbour line when the guess is
+// off.  One line per query when the guess holds, and never a wrong answer: the headers decide, not the guess.
+// ---------------------------------------------------------------------------
+template <u32 LPQ>
+__global__ __launch_bounds__(256)
+void k_select_lines(const u32* __restrict__ lines, const u16* __restrict__ dir8, u32 nblocks, const u64* __restrict__ rcount,
+                    const u64* __restrict__ sample, u32 nsamples, u32 shift, u64 total,
+                    const u64* __restrict__ q, u64 nq, u64* __restrict__ pos, u8* __restrict__ found)
+{
+    constexpr u32 NV = 8u / LPQ;
+    constexpr u32 NR = 32u / LPQ;
+    __shared__ u64 s_sample[2048];
+    for (u32 i = threadIdx.x; i < nsamples; i += blockDim.x) s_sample[i] = sample[i];
+    __syncthreads();
+    const u32 lane = lane_id();
+    const u32 sub = lane & (LPQ - 1u);
+    u64 qi = ((u64)blockIdx.x * blockDim.x + threadIdx.x) / LPQ;
+    const u64 stride = ((u64)gridDim.x * blockDim.x) / LPQ;
+    const u64 nq_round = (nq + (64u / LPQ) - 1ull) / (64u / LPQ) * (64u / LPQ);
+    for (; qi < nq_round; qi += stride) {
+        const bool live = qi < nq;
+        const u64 r = live ? q[qi] : 0ull;
+        const bool ok = live && r != 0ull && r <= total && nblocks != 0u;
+        u32 sr_lo = 0, sr_hi = 0;
+        if (ok) {
+            u32 glo = 0, ghi = nsamples - 1u;
+            while (glo < ghi) { u32 mid = glo + ((ghi - glo) >> 1); if (s_sample[mid] < r) glo = mid + 1u; else ghi = mid; }
+            u32 lo = glo << shift, hi = ((glo + 1u) << shift) - 1u;
+            if (hi > nblocks - 1u) hi = nblocks - 1u;
+            while (hi - lo >= 32u) { u32 mid = lo + ((hi - lo) >> 1); if (rcount[mid] < r) lo = mid + 1u; else hi = mid; }
+            sr_lo = lo; sr_hi = hi;
+        }
+        u32 below = 0;
+        {
+            u64 rc[NR];
+#pragma unroll
+            for (u32 t = 0; t < NR; ++t) { u32 idx = sr_lo + sub * NR + t; rc[t] = rcount[idx <= sr_hi ? idx : sr_hi]; }
+#pragma unroll
+            for (u32 t = 0; t < NR; ++t) { u32 idx = sr_lo + sub * NR + t; below += (ok && idx <= sr_hi && rc[t] < r) ? 1u : 0u; }
+        }
+        below = group_sum<LPQ>(below);
+        const u32 nb = ok ? sr_lo + below : 0u;
+        // ones before the block / in the block, and the octant directory of the block (three independent L2-resident reads)
+        const u64 prev = rcount[nb ? nb - 1u : 0u];
+        const u64 cur = rcount[nb];
+        const u32x4 dv = *reinterpret_cast<const __attribute__((address_space(1))) u32x4*>((uintptr_t)(dir8 + (size_t)nb * 8u));
+        const u64 before = nb ? prev : 0ull;
+        const u32 rr = ok ? (u32)(r - before) : 1u;                 // 1..65536 inside the block
+        const u32 btot = ok ? (u32)(cur - before) : 1u;
+        const u32 d8[8] = {dv.x & 0xFFFFu, dv.x >> 16, dv.y & 0xFFFFu, dv.y >> 16, dv.z & 0xFFFFu, dv.z >> 16, dv.w & 0xFFFFu, dv.w >> 16};
+        u32 k = 0;
+#pragma unroll
+        for (u32 t = 1; t < 8u; ++t) k += (d8[t] < rr) ? 1u : 0u;        // the last octant with fewer than rr ones before it (non-decreasing)
+        u32 ob = 0, oe = 0;
+#pragma unroll
+        for (u32 t = 0; t < 8u; ++t) { if (t == k) ob = d8[t]; if (t == k + 1u) oe = d8[t]; }
+        if (k == 7u) oe = btot;
+        const u32 cw = oe > ob ? oe - ob : 1u;                        // ones inside the octant (>= 1: the rr-th one is there)
+        // interpolated bit position of the rr-th one inside the octant -> the line to look at first
+        u32 guess = (k << 13) + (u32)(((u64)(rr - ob - 1u) * 8192ull) / cw);
+        if (guess > 65535u) guess = 65535u;
+        u32 j = guess / RL_BITS;
+        bool searching = ok;
+        u64 result = 0;
+        for (u32 it = 0; __ballot(searching) != 0ull && it < 80u; ++it) {
+            gcptr4 p = as_gc4(lines + ((size_t)nb * RL_LINES + j) * 32u) + sub * NV;
+            u32x4 v[NV];
+#pragma unroll
+            for (u32 i = 0; i < NV; ++i) v[i] = p[i];
+            u32 wd[4 * NV];
+#pragma unroll
+            for (u32 i = 0; i < NV; ++i) { wd[4 * i] = v[i].x; wd[4 * i + 1] = v[i].y; wd[4 * i + 2] = v[i].z; wd[4 * i + 3] = v[i].w; }
+            // the header (count before the line, whole vector) sits in the first two words of the group's lane 0
+            u32 hlo = sub == 0 ? wd[0] : 0u, hhi = sub == 0 ? wd[1] : 0u;
+            hlo = __shfl(hlo, lane & ~(LPQ - 1u), 64); hhi = __shfl(hhi, lane & ~(LPQ - 1u), 64);
+            const u64 hdr = ((u64)hhi << 32) | hlo;
+            if (sub == 0) { wd[0] = 0u; wd[1] = 0u; }
+            u32 mine = 0;
+#pragma unroll
+            for (u32 t = 0; t < 4 * NV; ++t) mine += (u32)__popc(wd[t]);
+            u32 ltot;
+            const u32 excl = group_excl<LPQ>(mine, sub, lane, ltot);
+            const u64 hb = hdr - before;                              // ones of the block before this line
+            const bool left = searching && (u64)rr <= hb;             // the rr-th one lies in an earlier line
+            const bool right = searching && (u64)rr > hb + ltot;      // ... in a later one
+            if (searching && !left && !right) {
+                const u32 need0 = rr - (u32)hb;                       // 1..ltot inside this line
+                if (need0 > excl && need0 <= excl + mine) {
+                    u32 need = need0 - excl, word = 0, wi = 0; bool got = false;
+#pragma unroll
+                    for (u32 t = 0; t < 4 * NV; ++t) {
+                        const u32 pc = (u32)__popc(wd[t]);
+                        if (!got) { if (need <= pc) { word = wd[t]; wi = t; got = true; } else need -= pc; }
+                    }
+                    for (u32 s_ = 1; s_ < need; ++s_) word &= word - 1u;
+                    // line word index (sub * 4 NV + wi), data word = that - 2, bit of the line = 32 * data word + ctz
+                    const u32 bit = j * RL_BITS + ((sub * 4u * NV + wi) - 2u) * 32u + (u32)__builtin_ctz(word);
+                    pos[qi] = ((u64)nb << 16) + bit;
+                }
+                searching = false;
+            }
+            if (left) j = j ? j - 1u : 0u;
+            if (right) j = j + 1u < RL_LINES ? j + 1u : RL_LINES - 1u;
+        }
+        (void)result;
+        if (live && sub == 0) {
+            found[qi] = ok ? 1 : 0;
+            if (!ok) pos[qi] = 0;
         }
     }
 }
