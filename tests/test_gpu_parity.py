@@ -1609,3 +1609,33 @@ def test_pairwise_count_long_mixed_vectors(ctx, port):
     got = [[bm._count_op2(op, x, y) for op in range(4)] for x, y in ((ga, gb), (gb, ga), (ga, ga))]
     assert got == exp, (got, exp)
     assert ga.count() == pa.count()
+
+
+def test_full_size_pairwise_and_rank_select_vs_reference_on_all_cores(ctx):
+    """BASELINE configs[1] and configs[3] at FULL size against the reference itself (oracle/_ref, the unmodified BitMagic;
+    the C port where it is absent) fanned over the host cores by block range -- not only identities: the four counts of a
+    whole 2 x 1e9-bit pair, and the total + sampled rank / select answers over a 4e9-bit vector (per-range indexes, totals
+    prefix-summed: the one exchange SURVEY 8(e) names)"""
+    import os, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path: sys.path.insert(0, root)
+    import bench
+    cores = min(len(os.sched_getaffinity(0)), 128)
+    nbits = 1_000_000_000
+    for dq in (6554, 655):
+        a = bm.bvector.generate(ctx, bench.SEED, 1, dq, nbits); b = bm.bvector.generate(ctx, bench.SEED, 2, dq, nbits)
+        ref = bench.cpu_pair_allcores(1, 2, dq, nbits, cores, reps=1)
+        assert [bm._count_op2(op, a, b) for op in range(4)] == ref["full_counts"], dq
+        del a, b
+    nb4 = 4_000_000_000
+    rng = np.random.default_rng(5)
+    for dq in (6554, 655):
+        v = bm.bvector.generate(ctx, bench.SEED, 7, dq, nb4)
+        rs = v.build_rs_index()
+        sn = rng.integers(0, nb4, 5000, dtype=np.uint64)
+        total, sn, an, sr, ar = bench.cpu_rank_allcores(7, dq, nb4, cores, sn, lambda tot: rng.integers(1, tot + 1, 5000, dtype=np.uint64))
+        assert rs.count() == total == v.count()
+        assert (v.count_to(sn, rs) == an).all()
+        f, p = v.select(sr, rs)
+        assert f.all() and (p == ar).all()
+        del rs, v
