@@ -483,7 +483,7 @@ int bmx_ctx_create(int device, void* stream, bmx_ctx** out)
     // an invalid value is ignored (the default stays)
     static const char* const env_keys[][2] = {
         {"BMX_PIPE_UNROLL", "pipe_unroll"}, {"BMX_PIPE_ROWS", "pipe_rows"}, {"BMX_PIPE_NT", "pipe_nt"},
-        {"BMX_PIPE_WG", "pipe_wg"}, {"BMX_PIPE_WINDOW", "pipe_window"}, {"BMX_PIPE_SPLIT", "pipe_split"}, {"BMX_OR_TILE", "or_tile"}, {"BMX_OR_WINDOW", "or_window"}, {"BMX_DIRECT_COLS", "direct_cols"}, {"BMX_FF_WINDOW", "ff_window"}, {"BMX_GAP_COUNT", "gap_count"}, {"BMX_RANGE_HALVES", "range_halves"}, {"BMX_PAIR_STREAM", "pair_stream"}, {"BMX_PAIR_WGS", "pair_wgs"}, {"BMX_RS_LANES", "rs_lanes"}, {"BMX_RS_LINES", "rs_lines"}, {"BMX_RS_SELECT_LINES", "rs_select_lines"}, {"BMX_COLL_SHAPE", "coll_shape"}, {"BMX_COLL_WINDOW", "coll_window"}, {"BMX_GAP_PACK", "gap_pack"}, {"BMX_XCD_SWIZZLE", "xcd_swizzle"}};
+        {"BMX_PIPE_WG", "pipe_wg"}, {"BMX_PIPE_WINDOW", "pipe_window"}, {"BMX_PIPE_SPLIT", "pipe_split"}, {"BMX_OR_TILE", "or_tile"}, {"BMX_OR_WINDOW", "or_window"}, {"BMX_DIRECT_COLS", "direct_cols"}, {"BMX_FF_WINDOW", "ff_window"}, {"BMX_GAP_COUNT", "gap_count"}, {"BMX_RANGE_HALVES", "range_halves"}, {"BMX_PAIR_STREAM", "pair_stream"}, {"BMX_PAIR_WGS", "pair_wgs"}, {"BMX_RS_LANES", "rs_lanes"}, {"BMX_RS_LINES", "rs_lines"}, {"BMX_RS_SELECT_LINES", "rs_select_lines"}, {"BMX_COLL_SHAPE", "coll_shape"}, {"BMX_COLL_WINDOW", "coll_window"}, {"BMX_EQ_BIG", "eq_big"}, {"BMX_EQ_BIG_SHAPE", "eq_big_shape"}, {"BMX_OP2_WGS", "op2_wgs"}, {"BMX_GAP_PACK", "gap_pack"}, {"BMX_XCD_SWIZZLE", "xcd_swizzle"}};
     for (auto& kv : env_keys)
         if (const char* e = getenv(kv[0])) (void)bmx_ctx_set_tuning(ctx, kv[1], atoi(e));
     g_last_error.clear();
@@ -539,6 +539,9 @@ int bmx_ctx_set_tuning(bmx_ctx* ctx, const char* key, int value)
     else if (k == "or_window") { ARGCHK(value >= -9); ctx->or_window = value; }
     else if (k == "gap_pack") { ARGCHK(value >= -1 && value <= 1); ctx->gap_pack = value; }
     else if (k == "coll_shape") { ARGCHK(value >= 0 && value <= 3); ctx->coll_shape = value; }
+    else if (k == "op2_wgs") { ARGCHK(value >= 1 && value <= 8); ctx->op2_wgs = value; }
+    else if (k == "eq_big_shape") { ARGCHK(value >= 0 && value <= 1); ctx->eq_big_shape = value; }
+    else if (k == "eq_big") { ARGCHK(value >= -1 && value <= 1); ctx->eq_big = value; }
     else if (k == "coll_window") { ARGCHK(value >= 0); ctx->coll_window = value; }
     else if (k == "rs_select_lines") { ARGCHK(value == 0 || value == 1); ctx->rs_select_lines = value; }
     else if (k == "rs_lines") { ARGCHK(value == 0 || value == 1); ctx->rs_lines = value; }
@@ -1487,6 +1490,16 @@ int bmx_op2(bmx_ctx* ctx, int op, const bmx_vec* a, const bmx_vec* b, int opt_co
     // compaction path below decides what to do with the slab)
     bool no_gap = !opt_compress && a->counts[BMX_GAP] == 0 && b->counts[BMX_GAP] == 0;
     if (nblocks) {
+        // bit-blocks only on both sides: the streaming form (one machine-load of waves, each owning a stretch of columns)
+        const bool stream = no_gap && ctx->pair_stream != 0 && a->nblocks == b->nblocks && a->counts[BMX_BIT] == nblocks &&
+                            b->counts[BMX_BIT] == nblocks && nblocks >= 2048u;
+        if (stream) {
+            const u32 waves = 4u, total = 256u * waves * (u32)std::max(ctx->op2_wgs, 1);
+            const u32 per_wave = (nblocks + total - 1u) / total;
+            const u32 grid = ((nblocks + per_wave - 1u) / per_wave + waves - 1u) / waves;
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_op2_stream<4>), dim3(grid), dim3(256), 0, ctx->stream, op, a->d_desc, b->d_desc, nblocks, per_wave,
+                               v->d_bits, v->d_desc, st, FoldOut{ctx->d_slots, ctx->d_done, ctx->h_small + 2});
+        } else
         hipLaunchKernelGGL(k_op2, dim3((nblocks + 3) / 4), dim3(256), 0, ctx->stream, op,
                            a->d_desc, a->nblocks, b->d_desc, b->nblocks, nblocks, opt_compress,
                            v->d_bits, v->d_desc, st,
@@ -2354,9 +2367,46 @@ int bmx_slice_eq_counts(bmx_ctx* ctx, const bmx_vec* const* slices, size_t nslic
         } else pl.desc[i] = sv->d_desc;
     }
     std::vector<uint64_t> ucount(uniq.size(), 0);
-    const size_t CHUNK = 2048;
+    // up to 2,048 values: the table with ordinals (2 workgroups per CU); more: the lean {key, count} table shared by 512
+    // threads, up to EQB_MAX_VALUES per pass over the planes (eq_big: 0 = never, 1 = always, -1 = by the batch size)
+    const bool big = ctx->eq_big == 1 || (ctx->eq_big < 0 && uniq.size() > 2048) ;
+    const size_t cap = big ? EQB_MAX_VALUES : 2048;
+    const size_t npass = (uniq.size() + cap - 1) / cap;
+    const size_t CHUNK = (uniq.size() + npass - 1) / npass;
     for (size_t u0 = 0; u0 < uniq.size() && !rc; u0 += CHUNK) {
         const uint32_t nv = (uint32_t)std::min(CHUNK, uniq.size() - u0);
+        if (big) {
+            const uint32_t tab = EQB_SLOTS(nv);
+            std::vector<uint32_t> keys(tab, 0), where(nv);
+            for (uint32_t k = 0; k < nv; ++k) {
+                uint32_t v = uniq[u0 + k], h = (uint32_t)(((uint64_t)(uint32_t)(v * 0x9E3779B1u) * tab) >> 32);
+                while (keys[h]) h = h + 1u == tab ? 0u : h + 1u;
+                keys[h] = v; where[k] = h;
+            }
+            void* d_tab = nullptr; void* d_cnt = nullptr;
+            if ((rc = dmalloc(ctx, &d_tab, (size_t)tab * 4)) || (rc = dmalloc(ctx, &d_cnt, (size_t)tab * 8))) { dfree(ctx, d_tab); break; }
+            std::vector<uint64_t> scount(tab, 0);
+            rc = h2d_staged(ctx, d_tab, keys.data(), (size_t)tab * 4);
+            hipError_t e = rc ? hipSuccess : hipMemsetAsync(d_cnt, 0, (size_t)tab * 8, ctx->stream);
+            if (!rc && e == hipSuccess) {
+                const bool wide = ctx->eq_big_shape == 1;                      // 32 KiB filter + 512-entry queues | 16 KiB + 1,024
+                size_t lds = (size_t)tab * 8 + (wide ? (1u << 15) + 8u * 512u * 4u : (1u << 14) + 8u * 1024u * 4u);
+                auto eqfn = wide ? (nslices <= 16 ? k_slice_eq_counts_big<16, 18, 512> : k_slice_eq_counts_big<32, 18, 512>)
+                                 : (nslices <= 16 ? k_slice_eq_counts_big<16, 17, 1024> : k_slice_eq_counts_big<32, 17, 1024>);
+                e = hipFuncSetAttribute(reinterpret_cast<const void*>(eqfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                if (e == hipSuccess) {
+                    u32 grid = std::min<u32>((ncols + 7u) / 8u, 256u);
+                    hipLaunchKernelGGL(eqfn, dim3(grid), dim3(512), lds, ctx->stream, pl, (u32)nslices, ncols, size, (const u32*)d_tab, tab, (u64*)d_cnt);
+                    e = hipGetLastError();
+                }
+                if (e == hipSuccess) e = hipMemcpyAsync(scount.data(), d_cnt, (size_t)tab * 8, hipMemcpyDeviceToHost, ctx->stream);
+            }
+            hipError_t e2 = hipStreamSynchronize(ctx->stream);
+            dfree(ctx, d_tab); dfree(ctx, d_cnt);
+            if (!rc && (e != hipSuccess || e2 != hipSuccess)) rc = fail_hip(e != hipSuccess ? e : e2, "bmx_slice_eq_counts", __LINE__);
+            if (!rc) for (uint32_t k = 0; k < nv; ++k) ucount[u0 + k] = scount[where[k]];
+            continue;
+        }
         uint32_t tab = 64; while (tab < 2u * nv) tab <<= 1;
         uint32_t shift = 32; for (uint32_t t = tab; t > 1; t >>= 1) --shift;
         // host-built open-addressing table: [keys u32 x tab][idx u16 x tab]

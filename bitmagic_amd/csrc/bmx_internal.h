@@ -69,6 +69,9 @@ struct bmx_ctx {
     float last_pack_ms = 0.f;
     uint32_t max_lds_bytes = 160u * 1024u;   // hipDeviceAttributeMaxSharedMemoryPerBlock of the device (queried at creation)
     int coll_shape = 2;        // k_coll_apply shape: 0 = 256 threads, 1 = 256 + prefetch, 2 = 512 (default: configs[4] 2.50 vs 2.61 ms, the AND cases equal), 3 = 512 + prefetch
+    int op2_wgs = 2;           // workgroups per CU of the streaming materialised pairwise kernel (k_op2_stream)
+    int eq_big_shape = 1;      // lean table: 1 = 256 Kbit filter + 512-entry queues, 0 = 128 Kbit + 1,024
+    int eq_big = -1;           // batched equality counts: -1 = lean 9,216-value table when the batch has more than 2,048 values, 0 = never, 1 = always
     int coll_window = 0;       // block columns per launch of k_coll_apply (0 = one launch)
     int rs_lines = 1;          // build_rs_index also lays the vector out as rank lines (one 128-B line per rank query; +108 % memory next to the vector): 0 = off
     int rs_select_lines = 1;   // select through the rank lines (octant directory + interpolated line guess verified by the line headers): 0 = k_select_l

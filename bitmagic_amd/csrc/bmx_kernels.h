@@ -322,17 +322,18 @@ __device__ __forceinline__ void count_fanin_fold(u32 wave_count, FoldOut f, u32 
 // Same pattern for the block KINDS of a result vector (kind counts packed 4 x 16 bit per slot: a slot sees at most
 // nblocks / 64 <= 16,384 blocks): out[k] = number of result blocks of kind k.  Lets an operation that cannot produce GAP
 // blocks skip the layout scan (k_scan_layout) altogether.
-__device__ __forceinline__ void kind_fanin_fold(u32 kind /* 0..3, 4 = none */, FoldOut f, u32 lane, u32 wave)
+// packed: the wave hands over the kinds of ALL the blocks it produced (4 x 16-bit counters)
+__device__ __forceinline__ void kind_fanin_fold_packed(u64 wave_kinds, FoldOut f, u32 lane, u32 wave)
 {
-    __shared__ u32 wk[16];
+    __shared__ u64 wk[16];
     u32 nw = blockDim.x >> 6;
-    if (lane == 0) wk[wave] = kind;
+    if (lane == 0) wk[wave] = wave_kinds;
     __syncthreads();
     if (wave == 0) {
         u32 folder = 0;
         if (lane == 0) {
             u64 t = 0;
-            for (u32 i = 0; i < nw; ++i) if (wk[i] < 4u) t += 1ull << (16u * wk[i]);
+            for (u32 i = 0; i < nw; ++i) t += wk[i];
             folder = fold_publish(t, f) ? 1u : 0u;
         }
         if (__shfl(folder, 0, 64)) {
@@ -345,6 +346,10 @@ __device__ __forceinline__ void kind_fanin_fold(u32 kind /* 0..3, 4 = none */, F
             }
         }
     }
+}
+__device__ __forceinline__ void kind_fanin_fold(u32 kind /* 0..3, 4 = none */, FoldOut f, u32 lane, u32 wave)
+{
+    kind_fanin_fold_packed(kind < 4u ? 1ull << (16u * kind) : 0ull, f, lane, wave);
 }
 
 // bvector::count()  src/bm.h:2431 -> block_bitcount src/bmblocks.h:1710

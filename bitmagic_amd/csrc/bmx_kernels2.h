@@ -308,6 +308,65 @@ void k_count_op2_stream(int op, const u64* __restrict__ da, const u64* __restric
     count_fanin_fold(cnt, fold, lane, wave);
 }
 
+// bit_and/or/xor/sub(bv1, bv2) under the same conditions (bit-blocks only on both sides, opt_none): the materialising twin of
+// the stream above.  A computed B x B block is stored as a bit-block unless the operation itself tests it (all-zero -> NULL
+// for AND / XOR / SUB, all-ones -> FULL for OR: ST_TEST_ZERO / ST_TEST_ONE of op2_block), so the classification is two wave
+// votes -- no popcount, no run count (st[].pop / runs of a bit-block are read by nothing) -- and the kinds of the wave's
+// whole stretch are folded once at the end.  Results are written with non-temporal stores.
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64)
+void k_op2_stream(int op, const u64* __restrict__ da, const u64* __restrict__ db, u32 nblocks, u32 per_wave,
+                  uint4* __restrict__ slab, u64* __restrict__ desc, BlockStat* __restrict__ st, FoldOut kinds)
+{
+    u32 lane = lane_id(), wave = threadIdx.x >> 6;
+    u32 w = uniform32(blockIdx.x * (u32)WAVES + wave);
+    u32 c0 = w * per_wave;
+    u32 c1 = c0 + per_wave < nblocks ? c0 + per_wave : nblocks;
+    u64 kc = 0ull;
+    if (c0 < c1) {
+        const u32 last = nblocks - 1u;
+        auto ptr = [&](const u64* __restrict__ d, u32 c) { return DESC_P(uniform64(d[c < last ? c : last])); };
+        auto load = [&](Blk& x, Blk& y, u64 pa, u64 pb) { part_load<8, true>(x, as_gc4(pa), lane); part_load<8, true>(y, as_gc4(pb), lane); };
+        auto eat = [&](Blk& x, const Blk& y, u32 c) {
+            blk_op(op, x, y);
+            u32 o = 0u, a = ~0u;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { o |= x.r[i].x | x.r[i].y | x.r[i].z | x.r[i].w; a &= x.r[i].x & x.r[i].y & x.r[i].z & x.r[i].w; }
+            const bool zero = __ballot(o != 0u) == 0ull, ones = __ballot(a != ~0u) == 0ull;
+            u32 kind = K_BIT;
+            if (op != BMX_OR && zero) kind = K_NULL;
+            if (op == BMX_OR && ones) kind = K_FULL;
+            uint4* slot = slab + (size_t)c * 512u;
+            if (kind == K_BIT) {
+                gptr4 p = as_g4(slot);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) __builtin_nontemporal_store(x.r[i], &p[i * 64 + lane]);
+            }
+            if (lane == 0) {
+                st[c] = BlockStat{0u, kind == K_BIT ? 2u : 1u, ones ? 1u : 0u, kind};
+                desc[c] = (kind == K_BIT) ? DESC_MAKE(slot, K_BIT) : DESC_MAKE(0, kind);
+            }
+            kc += 1ull << (16u * kind);
+        };
+        Blk x0, y0, x1, y1;
+        u32 c = c0;
+        load(x0, y0, ptr(da, c), ptr(db, c));
+        u64 a1 = ptr(da, c + 1u), b1 = ptr(db, c + 1u), a2 = ptr(da, c + 2u), b2 = ptr(db, c + 2u);
+        for (; c + 2u < c1; c += 2u) {
+            load(x1, y1, a1, b1);
+            u64 a3 = ptr(da, c + 3u), b3 = ptr(db, c + 3u);
+            eat(x0, y0, c);
+            load(x0, y0, a2, b2);
+            u64 a4 = ptr(da, c + 4u), b4 = ptr(db, c + 4u);
+            eat(x1, y1, c + 1u);
+            a1 = a3; b1 = b3; a2 = a4; b2 = b4;
+        }
+        if (c + 1u < c1) { load(x1, y1, a1, b1); eat(x0, y0, c); eat(x1, y1, c + 1u); }
+        else eat(x0, y0, c);
+    }
+    kind_fanin_fold_packed(kc, kinds, lane, wave);
+}
+
 // ---------------------------------------------------------------------------
 // OR-group classification (aggregator::sort_input_blocks_or src/bmaggregator.h:2278):
 // row = [hdr, flags, region(n)]; hdr = nbit | ngap<<16; any FULL => ROW_FULL;

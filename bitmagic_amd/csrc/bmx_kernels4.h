@@ -441,3 +441,104 @@ void k_slice_eq_counts(EqPlanes pl, u32 nplanes, u32 ncols, u64 size, const u32*
     for (u32 i = threadIdx.x; i < nvals; i += blockDim.x)
         if (cnt[i]) atomicAdd(reinterpret_cast<unsigned long long*>(&counts[i]), (unsigned long long)cnt[i]);
 }
+
+// The same pass for MORE queried values than the 2,048-value table above takes (round 3; the host used to re-read the planes
+// once per 2,048 values: 8,192 queries = 4 passes).  What bounds the batch is LDS, so the table is made leaner instead of
+// the planes being re-read: a slot is {key, count} -- the count sits WITH the key (no ordinal array; the host, which built
+// the table, maps slots back to queries), any table size (multiplicative range reduction instead of a power-of-two mask)
+// at 1.5 slots per value, 512 threads sharing one table, per-wave queues of 1,024 entries flushed inside a step when more
+// than half full (a step can produce 2,048 survivors), and a 128 Kbit filter so that ~9,000 values still leave few false
+// probes.  LDS = 12 B x slots + 16 KiB filter + 32 KiB queues: up to 9,216 values in ONE pass over the planes.
+#define EQB_MAX_VALUES 9216u
+#define EQB_SLOTS(nv) ((((nv) * 3u / 2u) + 63u) & ~63u)
+
+// FBITS = log2 of the filter bits (17: 16 KiB, 18: 32 KiB), QSZ = queue entries per wave (flushed when more than half full;
+// checked every QSZ / 128 rows of a step, which add at most QSZ / 2 survivors)
+template <int NP, int FBITS, int QSZ>
+__global__ __launch_bounds__(512)
+void k_slice_eq_counts_big(EqPlanes pl, u32 nplanes, u32 ncols, u64 size, const u32* __restrict__ g_keys, u32 tab, u64* __restrict__ counts /* per slot */)
+{
+    extern __shared__ u32 lds_dyn[];
+    u32* keys = lds_dyn;                                            // tab keys (0 = empty)
+    u32* cnt = keys + tab;                                          // tab counters
+    u32* filt = cnt + tab;                                          // presence filter, 2^FBITS bits
+    constexpr u32 FW = 1u << (FBITS - 5);
+    u32* queue = filt + FW;                                         // 8 waves x QSZ survivors
+    for (u32 i = threadIdx.x; i < FW; i += blockDim.x) filt[i] = 0u;
+    for (u32 i = threadIdx.x; i < tab; i += blockDim.x) cnt[i] = 0u;
+    __syncthreads();
+    for (u32 i = threadIdx.x; i < tab; i += blockDim.x) {
+        u32 k = g_keys[i];
+        keys[i] = k;
+        if (k) { u32 hb = (k * 0x85EBCA6Bu) >> (32 - FBITS); atomicOr(&filt[hb >> 5], 1u << (hb & 31u)); }
+    }
+    __syncthreads();
+    const u32 lane = lane_id(), wave = threadIdx.x >> 6;
+    u32* myq = queue + wave * (u32)QSZ;
+    for (u32 c = uniform32(blockIdx.x * 8u + wave); c < ncols; c += gridDim.x * 8u) {
+        u64 base[32];
+#pragma unroll
+        for (int p = 0; p < 32; ++p) {
+            u64 b = 0ull;
+            if (p < NP && (u32)p < nplanes) {
+                if (pl.raw[p]) b = (u64)(uintptr_t)(pl.raw[p] + (size_t)c * 512u);
+                else if (pl.desc[p] && c < pl.nblk[p]) {
+                    u64 d = uniform64(pl.desc[p][c]);
+                    b = DESC_K(d) == K_BIT ? DESC_P(d) : (DESC_K(d) == K_FULL ? 1ull : 0ull);
+                }
+            }
+            base[p] = uniform64(b);
+        }
+        const u64 row0 = (u64)c << 16;
+        const u32 lim = size <= row0 ? 0u : (size - row0 >= 65536ull ? 65536u : (u32)(size - row0));
+#pragma unroll 1
+        for (u32 k = 0; k < 32u; ++k) {
+            u32 a[32];
+            u32 any = 0u;
+#pragma unroll
+            for (int p = 0; p < 32; ++p) {
+                if (p >= NP) { a[p] = 0u; continue; }
+                if (base[p] > 1ull) a[p] = __builtin_nontemporal_load((const __attribute__((address_space(1))) u32*)(uintptr_t)base[p] + k * 64u + lane);
+                else a[p] = base[p] ? ~0u : 0u;
+                any |= a[p];
+            }
+            const u32 wb = ((k * 64u + lane) << 5);
+            const u32 vm = lim >= wb + 32u ? ~0u : (lim <= wb ? 0u : ((1u << (lim - wb)) - 1u));
+            if (__ballot((any & vm) != 0u) == 0ull) continue;
+            bit_transpose32(a);
+            u32 f[32];
+#pragma unroll
+            for (int r = 0; r < 32; ++r) { u32 hb = (a[r] * 0x85EBCA6Bu) >> (32 - FBITS); f[r] = filt[hb >> 5] >> (hb & 31u); }
+            u32 nq = 0;
+            auto flush = [&]() {
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                for (u32 b = 0; b < nq; b += 64u) {
+                    if (b + lane < nq) {
+                        u32 v = myq[b + lane];
+                        u32 h = __umulhi(v * 0x9E3779B1u, tab);
+                        for (;;) { u32 kk = keys[h]; if (kk == v) { atomicAdd(&cnt[h], 1u); break; } if (kk == 0u) break; h = h + 1u == tab ? 0u : h + 1u; }
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                nq = 0;
+            };
+#pragma unroll
+            for (int r = 0; r < 32; ++r) {
+                bool hit = (f[r] & 1u) && a[r] != 0u && ((vm >> r) & 1u);
+                u64 m = __ballot(hit);
+                if (m) {
+                    u32 pos = nq + __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
+                    if (hit) myq[pos] = a[r];
+                    nq += (u32)__popcll(m);
+                }
+                if ((r & (QSZ / 128 - 1)) == QSZ / 128 - 1 && r != 31 && nq > (u32)QSZ / 2u) flush();
+            }
+            if (nq) flush();
+        }
+    }
+    __syncthreads();
+    for (u32 i = threadIdx.x; i < tab; i += blockDim.x)
+        if (cnt[i]) atomicAdd(reinterpret_cast<unsigned long long*>(&counts[i]), (unsigned long long)cnt[i]);
+}

@@ -369,6 +369,41 @@ def test_pairwise_count_streaming_kernel(ctx, port, nblocks_x):
         assert ref[2] == int(np.unpackbits((wa ^ wb).view(np.uint8)).sum())
 
 
+@pytest.mark.parametrize("nblocks_x", [2048, 3001])
+def test_pairwise_materialised_streaming_kernel(ctx, port, nblocks_x):
+    """bit_and/or/xor/sub over two all-bit-block vectors take the streaming kernel (k_op2_stream); every shape of it and the
+    block-per-wave kernel (pair_stream 0) must produce the same words AND the same block kinds as the oracle: blocks
+    that come out all-zero (-> NULL for AND / XOR / SUB) and all-ones (-> FULL for OR only) are planted"""
+    rng = np.random.default_rng(nblocks_x)
+    nw = nblocks_x * 2048 - 77
+    wa = rng.integers(0, 1 << 32, size=nw, dtype=np.uint64).astype(np.uint32)
+    wb = rng.integers(0, 1 << 32, size=nw, dtype=np.uint64).astype(np.uint32)
+    B = 2048
+    wa[3 * B:4 * B] = 0                                           # AND / SUB -> NULL, OR / XOR -> copy of b
+    wb[5 * B:6 * B] = 0xFFFFFFFF                                  # OR -> FULL, SUB -> NULL
+    wa[7 * B:8 * B] = wb[7 * B:8 * B]                             # XOR / SUB -> NULL
+    wa[9 * B:10 * B] = ~wb[9 * B:10 * B]                          # AND -> NULL, OR / XOR -> all ones (XOR keeps a bit-block)
+    wa[(nblocks_x - 1) * B:] = 0; wb[(nblocks_x - 1) * B:] = 0     # the short last block
+    a = bm.bit_import_u32(ctx, wa, False); b = bm.bit_import_u32(ctx, wb, False)
+    assert a.info()["counts"][bm.BIT] == nblocks_x and b.info()["counts"][bm.BIT] == nblocks_x
+    pa = port.import_words(wa, False, nw * 32); pb = port.import_words(wb, False, nw * 32)
+    fns = ((bm.bvector.bit_and, bm.AND), (bm.bvector.bit_or, bm.OR), (bm.bvector.bit_xor, bm.XOR), (bm.bvector.bit_sub, bm.SUB))
+    try:
+        for ps, wgs in ((0, 1), (-1, 1), (-1, 2), (-1, 3), (-1, 8)):
+            ctx.set_tuning("pair_stream", ps); ctx.set_tuning("op2_wgs", wgs)
+            for fn, op in fns:
+                t = fn(a, b)
+                e = port.op2(op, pa, pb, 0)
+                assert t.block_table()[0].tolist() == e.flatten()[0].tolist(), (ps, wgs, op)
+                assert (t.to_words(nw) == e.to_words(nw)).all(), (ps, wgs, op)
+                assert t.count() == e.count()
+                st = t.calc_stat()
+                assert st["bit_blocks"] == t.block_table()[0].tolist().count(bm.BIT)
+                del t
+    finally:
+        ctx.set_tuning("pair_stream", -1); ctx.set_tuning("op2_wgs", 2)
+
+
 def test_full_size_256way_and_count(ctx, port):
     """BASELINE config 3: aggregator AND + COUNT over 256 x 1e9-bit vectors (correlated data set A).
     Checks: shard sums == total; sampled block columns equal the oracle run on the same
@@ -1015,6 +1050,17 @@ def test_batched_equality_counts_by_transposition(ctx, case):
     lut = {int(v): int(k) for v, k in zip(uniq, cnts)}
     got = sc.find_eq_counts(many)
     assert got.tolist() == [lut.get(v, 0) for v in many]
+    # the two table forms (k_slice_eq_counts: 2,048 values per pass; k_slice_eq_counts_big: 9,216) on small and large
+    # batches, incl. more values than ONE pass of the big form takes
+    more = many + [int(x) for x in rng.integers(1, 1 << min(nplanes, 31), size=14000)]
+    exp_small = [lut.get(v, 0) if v else int((col == 0).sum()) for v in vals]
+    try:
+        for eb, shape in ((0, 1), (1, 0), (1, 1), (-1, 1)):
+            ctx.set_tuning("eq_big", eb); ctx.set_tuning("eq_big_shape", shape)
+            assert sc.find_eq_counts(vals).tolist() == exp_small, (eb, shape)
+            assert sc.find_eq_counts(more).tolist() == [lut.get(v, 0) for v in more], (eb, shape)
+    finally:
+        ctx.set_tuning("eq_big", -1); ctx.set_tuning("eq_big_shape", 1)
 
 
 def _bits_of(t, n):

@@ -49,7 +49,8 @@ for staged, swz, slots in ((0, 1, 16), (1, 1, 16), (1, 1, 8)):
 import time
 sc = bm.slice_scanner(ctx, planes, size=a.nbits)
 if a.planes <= 32:
-    for nq in (a.groups, 2048, 8192):
+    for nq, eq_big, shape in ((a.groups, -1, 1), (2048, 0, 1), (2048, 1, 1), (4096, -1, 1), (8192, 0, 1), (8192, -1, 0), (8192, -1, 1), (16384, -1, 1)):
+        ctx.set_tuning("eq_big", eq_big); ctx.set_tuning("eq_big_shape", shape)
         q = xs[:nq] if nq <= len(xs) else xs + [int(v) for v in rng.integers(1, 1 << a.planes, size=nq - len(xs))]
         got = sc.find_eq_counts(q)
         ctx.synchronize()
@@ -57,9 +58,14 @@ if a.planes <= 32:
         for _ in range(3):
             t0 = time.perf_counter(); got = sc.find_eq_counts(q); ts.append((time.perf_counter() - t0) * 1e3)
         ok = bool((np.asarray(got[:len(xs)], np.int64) == ref_counts.cpu().numpy()[:min(nq, len(xs))]).all()) if all(x > 0 for x in xs) else None
-        print(json.dumps({"pattern": "scanner_transposed", "planes": a.planes, "queries": nq, "nbits": a.nbits, "host_call_ms": round(min(ts), 3),
-                          "queries_per_s": round(nq / min(ts) * 1e3, 1), "plane_GB": round(a.planes * a.nbits / 8e9, 2),
-                          "plane_TBps": round(a.planes * a.nbits / 8 / min(ts) / 1e9 * (1 + (nq - 1) // 2048), 2), "counts_equal_pipeline": ok}))
+        nu = len(set(q))
+        big = eq_big == 1 or (eq_big < 0 and nu > 2048)
+        passes = -(-nu // (9216 if big else 2048))
+        print(json.dumps({"pattern": "scanner_transposed", "planes": a.planes, "queries": nq, "unique": nu, "nbits": a.nbits,
+                          "table": ("k_slice_eq_counts_big<%s>" % ("18,512" if shape else "17,1024")) if big else "k_slice_eq_counts", "passes_over_the_planes": passes,
+                          "host_call_ms": round(min(ts), 3), "queries_per_s": round(nq / min(ts) * 1e3, 1), "plane_GB": round(a.planes * a.nbits / 8e9, 2),
+                          "plane_TBps": round(a.planes * a.nbits / 8 / min(ts) / 1e9 * passes, 2), "counts_equal_pipeline": ok}))
+    ctx.set_tuning("eq_big", -1)
 
 # a 12-plane container (values < 4096, every row non-zero): the 16-plane instantiation
 if a.planes >= 12:
