@@ -483,7 +483,7 @@ int bmx_ctx_create(int device, void* stream, bmx_ctx** out)
     // an invalid value is ignored (the default stays)
     static const char* const env_keys[][2] = {
         {"BMX_PIPE_UNROLL", "pipe_unroll"}, {"BMX_PIPE_ROWS", "pipe_rows"}, {"BMX_PIPE_NT", "pipe_nt"},
-        {"BMX_PIPE_WG", "pipe_wg"}, {"BMX_PIPE_WINDOW", "pipe_window"}, {"BMX_PIPE_SPLIT", "pipe_split"}, {"BMX_OR_TILE", "or_tile"}, {"BMX_OR_WINDOW", "or_window"}, {"BMX_DIRECT_COLS", "direct_cols"}, {"BMX_FF_WINDOW", "ff_window"}, {"BMX_GAP_COUNT", "gap_count"}, {"BMX_RANGE_HALVES", "range_halves"}, {"BMX_PAIR_STREAM", "pair_stream"}, {"BMX_PAIR_WGS", "pair_wgs"}, {"BMX_RS_LANES", "rs_lanes"}, {"BMX_RS_LINES", "rs_lines"}, {"BMX_RS_SELECT_LINES", "rs_select_lines"}, {"BMX_COLL_SHAPE", "coll_shape"}, {"BMX_COLL_WINDOW", "coll_window"}, {"BMX_EQ_BIG", "eq_big"}, {"BMX_EQ_BIG_SHAPE", "eq_big_shape"}, {"BMX_OP2_WGS", "op2_wgs"}, {"BMX_GAP_PACK", "gap_pack"}, {"BMX_XCD_SWIZZLE", "xcd_swizzle"}};
+        {"BMX_PIPE_WG", "pipe_wg"}, {"BMX_PIPE_WINDOW", "pipe_window"}, {"BMX_PIPE_SPLIT", "pipe_split"}, {"BMX_OR_TILE", "or_tile"}, {"BMX_OR_WINDOW", "or_window"}, {"BMX_DIRECT_COLS", "direct_cols"}, {"BMX_FF_WINDOW", "ff_window"}, {"BMX_GAP_COUNT", "gap_count"}, {"BMX_RANGE_HALVES", "range_halves"}, {"BMX_PAIR_STREAM", "pair_stream"}, {"BMX_PAIR_WGS", "pair_wgs"}, {"BMX_RS_LANES", "rs_lanes"}, {"BMX_RS_LINES", "rs_lines"}, {"BMX_RS_SELECT_LINES", "rs_select_lines"}, {"BMX_COLL_SHAPE", "coll_shape"}, {"BMX_COLL_WINDOW", "coll_window"}, {"BMX_EQ_BIG", "eq_big"}, {"BMX_PAIR_LOOP", "pair_loop"}, {"BMX_PAIR_NT", "pair_nt"}, {"BMX_EQ_BIG_SHAPE", "eq_big_shape"}, {"BMX_OP2_WGS", "op2_wgs"}, {"BMX_GAP_PACK", "gap_pack"}, {"BMX_XCD_SWIZZLE", "xcd_swizzle"}};
     for (auto& kv : env_keys)
         if (const char* e = getenv(kv[0])) (void)bmx_ctx_set_tuning(ctx, kv[1], atoi(e));
     g_last_error.clear();
@@ -540,6 +540,8 @@ int bmx_ctx_set_tuning(bmx_ctx* ctx, const char* key, int value)
     else if (k == "gap_pack") { ARGCHK(value >= -1 && value <= 1); ctx->gap_pack = value; }
     else if (k == "coll_shape") { ARGCHK(value >= 0 && value <= 3); ctx->coll_shape = value; }
     else if (k == "op2_wgs") { ARGCHK(value >= 1 && value <= 8); ctx->op2_wgs = value; }
+    else if (k == "pair_nt") { ARGCHK(value >= 0 && value <= 1); ctx->pair_nt = value; }
+    else if (k == "pair_loop") { ARGCHK(value >= -1 && value <= 5); ctx->pair_loop = value; }
     else if (k == "eq_big_shape") { ARGCHK(value >= 0 && value <= 1); ctx->eq_big_shape = value; }
     else if (k == "eq_big") { ARGCHK(value >= -1 && value <= 1); ctx->eq_big = value; }
     else if (k == "coll_window") { ARGCHK(value >= 0); ctx->coll_window = value; }
@@ -1546,6 +1548,17 @@ static int count_op2_launch(bmx_ctx* ctx, int op, const bmx_vec* a, const bmx_ve
     // into registers and decoded from there: 52-58 us against the 45.9 us of this kernel on the 1 % mixed case at one to
     // eight workgroups per CU (profiles/r03g, r03h); each of the nine shape loops fills and drains its own pipeline over
     // ~4 columns.  Dropped.)
+    // mixed kinds, long vectors: the persistent form (one memory round trip per column, GAP blocks decoded from registers)
+    if (ctx->pair_loop != 0 && nblocks >= 2048u) {
+        const u32 wgs = (u32)(ctx->pair_loop > 0 ? ctx->pair_loop : 4);     // workgroups per CU = waves per SIMD
+        const u32 grid = std::min<u32>((nblocks + 3u) / 4u, 256u * wgs);
+        auto fn = ctx->pair_nt ? (wgs <= 2u ? k_count_op2_loop<4, 2, true> : wgs == 3u ? k_count_op2_loop<4, 3, true> : k_count_op2_loop<4, 4, true>)
+                                  : (wgs <= 2u ? k_count_op2_loop<4, 2, false> : wgs == 3u ? k_count_op2_loop<4, 3, false> : k_count_op2_loop<4, 4, false>);
+        hipLaunchKernelGGL(fn, dim3(grid), dim3(256), 0, ctx->stream, op,
+                           a->d_desc, a->nblocks, b->d_desc, b->nblocks, nblocks, FoldOut{ctx->d_slots, ctx->d_done, out});
+        KCHK();
+        return BMX_OK;
+    }
     hipLaunchKernelGGL(k_count_op2, dim3((nblocks + 3) / 4), dim3(256), 0, ctx->stream, op,
                        a->d_desc, a->nblocks, b->d_desc, b->nblocks, nblocks, FoldOut{ctx->d_slots, ctx->d_done, out});
     KCHK();

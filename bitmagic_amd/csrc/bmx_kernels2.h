@@ -265,6 +265,104 @@ void k_count_op2(int op, const u64* __restrict__ da, u32 na, const u64* __restri
     count_fanin_fold(c, fold, lane, wave);
 }
 
+// bm::count_* over operands of ANY block kinds, persistent form (round 3).  k_count_op2 above pays, per column, a wave
+// launch, a descriptor round trip, the block loads, and -- for a GAP operand -- one more round trip per 512 runs (2-byte
+// gathers, batch after batch) before anything is counted; the mixed 1 % case of BASELINE configs[1] (two thirds bit-blocks,
+// one third ~1,300-run GAP blocks) ran at 53 % of HBM with less data than the all-bit case.  Here a wave stays and walks
+// every (grid waves)-th column: the descriptors of its next column are fetched while the current one is counted, and ALL
+// the loads of a column are issued before anything is decoded -- 8 x 16 B per lane for a bit-block, the whole run list of
+// a GAP block as 3 x 16 B per lane (<= 1,280 words; lanes past the end re-read chunk 0) -- so a column costs ONE memory
+// round trip whatever its kinds; the GAP block is then set into the wave's LDS block straight from those registers
+// (gap_apply_chunk: the 4 wanted runs of a 16-B chunk, the first word of the next chunk comes from the neighbour lane).
+// The loads of an operand are issued WITHOUT control flow, whatever its kind: eight 16-byte loads per lane from one base
+// pointer -- the eight rows of a bit-block; for a GAP block its run list in the first three (chunk index clamped to the
+// block, the other five re-read chunk 0: one cached line); NULL / FULL read `safe` (any 16 readable bytes).  (With a branch
+// per kind around the loads hipcc merges the two register images of the operand with copies that WAIT for the loads inside
+// the issue phase: the second operand's loads then leave after the first operand's have landed.)
+template <bool NT>
+__device__ __forceinline__ void op2_issue(u64 d, const u64* __restrict__ safe, Blk& x, u32 lane)
+{
+    const u32 k = DESC_K(d);
+    const bool bit = k == K_BIT, gap = k == K_GAP;
+    const u64 base = (bit || gap) ? DESC_P(d) : (u64)(uintptr_t)safe;
+    const u32 nch = gap ? ((GMETA(d) >> 1) + 8u) >> 3 : 0u;       // 16-B chunks holding words 0..len of a GAP block
+    gcptr4 p = as_gc4(base);
+#pragma unroll
+    for (u32 j = 0; j < 8; ++j) {
+        const u32 ci = j * 64u + lane;
+        const u32 at = bit ? ci : (ci < nch ? ci : 0u);
+        x.r[j] = NT ? __builtin_nontemporal_load(&p[at]) : p[at];
+    }
+}
+
+__device__ __forceinline__ void op2_finish(u64 d, Blk& x, u32* l, u32 lane)
+{
+    const u32 k = DESC_K(d);
+    if (k == K_BIT) return;
+    if (k != K_GAP) { blk_fill(x, k == K_FULL ? ~0u : 0u); return; }
+    const u32 meta = GMETA(d), len = meta >> 1;
+    const bool odd_runs = (meta & 1u) != 0u;                     // wanted (1-)runs are 1,3,5,.. when the block starts with 1
+    const u32 nch = (len + 8u) >> 3;
+    u32x4* l4 = reinterpret_cast<u32x4*>(l);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) l4[i * 64 + lane] = (u32x4)(0u);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (u32 j = 0; j < 3; ++j) {
+        if (j * 64u >= nch) break;                                // wave-uniform
+        const u32 ci = j * 64u + lane;
+        u32 nx = __shfl_down(x.r[j].x, 1, 64);
+        const u32 wrap = j < 2u ? __builtin_amdgcn_readfirstlane(x.r[j < 2u ? j + 1u : j].x) : 0u;
+        if (lane == 63u) nx = wrap;
+        if (ci < nch) {
+            const u32 xs[5] = {x.r[j].x, x.r[j].y, x.r[j].z, x.r[j].w, nx};
+            gap_apply_chunk<GAP_OR>(l, xs, ci, len, odd_runs);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) x.r[i] = l4[i * 64 + lane];
+    __builtin_amdgcn_wave_barrier();
+}
+
+// WPE = waves per SIMD the register allocation is held to; NT: non-temporal loads
+template <int WAVES, int WPE, bool NT>
+__global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WPE)))
+void k_count_op2_loop(int op, const u64* __restrict__ da, u32 na, const u64* __restrict__ db, u32 nbk, u32 nblocks, FoldOut fold)
+{
+    __shared__ u32 lds[WAVES * 2048];
+    const u32 lane = lane_id(), wave = threadIdx.x >> 6;
+    u32* l = lds + wave * 2048u;
+    const u32 total = gridDim.x * (u32)WAVES;
+    u32 cnt = 0;
+    u32 c = uniform32(blockIdx.x * (u32)WAVES + wave);
+    // descriptors of the wave's NEXT column: requested with plain (per-lane, same address) loads one iteration ahead and
+    // made wave-uniform only when they are needed -- a readfirstlane right after the load would wait for it on the spot
+    auto raw = [&](const u64* __restrict__ d, u32 n, u32 col) -> u64 { return col < n ? d[col] : 0ull; };
+    u64 ar = raw(da, na, c), br = raw(db, nbk, c);
+    for (; c < nblocks; c += total) {
+        const u64 a = uniform64(ar), b = uniform64(br);
+        ar = raw(da, na, c + total); br = raw(db, nbk, c + total);
+        const u32 ka = DESC_K(a), kb = DESC_K(b);
+        const bool skip = (ka == K_NULL && kb == K_NULL) || (op == BMX_AND && (ka == K_NULL || kb == K_NULL)) ||
+                          (op == BMX_SUB && (ka == K_NULL || kb == K_FULL));
+        if (!skip) {
+            Blk x, y;
+            op2_issue<NT>(a, da, x, lane);
+            op2_issue<NT>(b, da, y, lane);
+            __builtin_amdgcn_sched_barrier(0);                    // (every load of the column leaves before anything is decoded)
+            op2_finish(a, x, l, lane);
+            op2_finish(b, y, l, lane);
+            blk_op(op, x, y);
+            cnt += blk_lane_popcount(x);
+        }
+    }
+    cnt = wave_sum(cnt);
+    count_fanin_fold(cnt, fold, lane, wave);
+}
+
 // bm::count_* when BOTH operands consist of bit-blocks only (the 10 % / 50 % cases of BASELINE configs[1]): the launch is
 // one machine-load of waves (one workgroup per CU) and a wave streams a CONTIGUOUS stretch of block columns with two
 // columns in flight -- the loads of column c+1 are issued before column c is counted, descriptor pairs are fetched two

@@ -1652,8 +1652,13 @@ def test_pairwise_count_long_mixed_vectors(ctx, port):
     assert max(int(x) for x in pa.flatten()[3][::1][:1]) >= 0
     ga, gb = bm.bvector.from_block_table(ctx, wa.size * 32, *pa.flatten()), bm.bvector.from_block_table(ctx, wb.size * 32, *pb.flatten())
     exp = [[port.count_op2(op, x, y) for op in range(4)] for x, y in ((pa, pb), (pb, pa), (pa, pa))]
-    got = [[bm._count_op2(op, x, y) for op in range(4)] for x, y in ((ga, gb), (gb, ga), (ga, ga))]
-    assert got == exp, (got, exp)
+    try:
+        for pl in (0, 2, 3, 4, -1):              # a wave per column / the persistent kernel at 2, 3, 4 waves per SIMD / default
+            ctx.set_tuning("pair_loop", pl)
+            got = [[bm._count_op2(op, x, y) for op in range(4)] for x, y in ((ga, gb), (gb, ga), (ga, ga))]
+            assert got == exp, (pl, got, exp)
+    finally:
+        ctx.set_tuning("pair_loop", -1)
     assert ga.count() == pa.count()
 
 
