@@ -836,6 +836,15 @@ def run_pairwise(args, env, dq=None, quick=False):
     return res
 
 
+def _select_kernel_name():
+    sl = os.environ.get("BMX_RS_SELECT_LINES", "2")
+    if os.environ.get("BMX_RS_LINES", "1") == "0" or sl == "0":
+        return "k_select_l<4> (block index: running counts, cumulative row, bit line)"
+    if sl == "1":
+        return "k_select_lines<4> (block index + octant directory, then the rank line guessed by interpolation and verified by its header)"
+    return "k_select_sdir<4> (select directory over the rank lines: the line of every 2^k-th one, interpolated guess verified by the line's header)"
+
+
 def L_pair_kernel_name(all_bit, nblocks):
     env_ps = os.environ.get("BMX_PAIR_STREAM", "-1")
     if all_bit and nblocks >= 2048 and env_ps == "-1":
@@ -913,9 +922,11 @@ def run_rank_select(args, env, quick=False):
                         "algorithmic_bytes_per_launch": nq * 128, "avg_launch_ms": round(rank_ms, 4),
                         "peak_source": f"bmx_probe_random_lines in this run: {nq} random 128-B lines (8 lanes x 16 B, the access shape of "
                                        f"a rank query's bit line) over a {slab_bytes / 1e6:.0f} MB buffer in {pm.value:.4f} ms",
-                        "select": {"kernel": "k_select_l<4>", "achieved": round(sel_lines_s / 1e9, 3), "frac": round(sel_lines_s / ceil_lines_s, 4),
+                        "select": {"kernel": _select_kernel_name(), "achieved": round(sel_lines_s / 1e9, 3), "frac": round(sel_lines_s / ceil_lines_s, 4),
                                    "avg_launch_ms": round(sel_ms, 4),
-                                   "note": "one bit line per query after two dependent index round trips (running counts, cumulative row)"},
+                                   "note": "queries per second against the same random-line rate: a select is at least TWO dependent reads "
+                                           "(a directory entry, L2-resident, then the line; a second line when the interpolated guess is off by one), "
+                                           "so 0.5 is the ceiling of this ratio"},
                         "as_bandwidth_GBps": round(nq * 128 / rank_ms / 1e6, 1),
                         "note": "random access: ONE 128-B line per rank query is what the algorithm needs, and with the rank-line layout "
                                 "(running count interleaved with the bits) it is also all the kernel reads; the bound is the transaction "

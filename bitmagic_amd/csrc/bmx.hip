@@ -483,7 +483,7 @@ int bmx_ctx_create(int device, void* stream, bmx_ctx** out)
     // an invalid value is ignored (the default stays)
     static const char* const env_keys[][2] = {
         {"BMX_PIPE_UNROLL", "pipe_unroll"}, {"BMX_PIPE_ROWS", "pipe_rows"}, {"BMX_PIPE_NT", "pipe_nt"},
-        {"BMX_PIPE_WG", "pipe_wg"}, {"BMX_PIPE_WINDOW", "pipe_window"}, {"BMX_PIPE_SPLIT", "pipe_split"}, {"BMX_OR_TILE", "or_tile"}, {"BMX_OR_WINDOW", "or_window"}, {"BMX_DIRECT_COLS", "direct_cols"}, {"BMX_FF_WINDOW", "ff_window"}, {"BMX_GAP_COUNT", "gap_count"}, {"BMX_RANGE_HALVES", "range_halves"}, {"BMX_PAIR_STREAM", "pair_stream"}, {"BMX_PAIR_WGS", "pair_wgs"}, {"BMX_RS_LANES", "rs_lanes"}, {"BMX_RS_LINES", "rs_lines"}, {"BMX_RS_SELECT_LINES", "rs_select_lines"}, {"BMX_COLL_SHAPE", "coll_shape"}, {"BMX_COLL_WINDOW", "coll_window"}, {"BMX_EQ_BIG", "eq_big"}, {"BMX_PAIR_LOOP", "pair_loop"}, {"BMX_PAIR_NT", "pair_nt"}, {"BMX_EQ_BIG_SHAPE", "eq_big_shape"}, {"BMX_OP2_WGS", "op2_wgs"}, {"BMX_GAP_PACK", "gap_pack"}, {"BMX_XCD_SWIZZLE", "xcd_swizzle"}};
+        {"BMX_PIPE_WG", "pipe_wg"}, {"BMX_PIPE_WINDOW", "pipe_window"}, {"BMX_PIPE_SPLIT", "pipe_split"}, {"BMX_OR_TILE", "or_tile"}, {"BMX_OR_WINDOW", "or_window"}, {"BMX_DIRECT_COLS", "direct_cols"}, {"BMX_FF_WINDOW", "ff_window"}, {"BMX_GAP_COUNT", "gap_count"}, {"BMX_RANGE_HALVES", "range_halves"}, {"BMX_PAIR_STREAM", "pair_stream"}, {"BMX_PAIR_WGS", "pair_wgs"}, {"BMX_RS_LANES", "rs_lanes"}, {"BMX_RS_LINES", "rs_lines"}, {"BMX_RS_SELECT_LINES", "rs_select_lines"}, {"BMX_RS_SDIR_SHIFT", "rs_sdir_shift"}, {"BMX_COLL_SHAPE", "coll_shape"}, {"BMX_COLL_WINDOW", "coll_window"}, {"BMX_EQ_BIG", "eq_big"}, {"BMX_PAIR_LOOP", "pair_loop"}, {"BMX_PAIR_NT", "pair_nt"}, {"BMX_EQ_BIG_SHAPE", "eq_big_shape"}, {"BMX_OP2_WGS", "op2_wgs"}, {"BMX_GAP_PACK", "gap_pack"}, {"BMX_XCD_SWIZZLE", "xcd_swizzle"}};
     for (auto& kv : env_keys)
         if (const char* e = getenv(kv[0])) (void)bmx_ctx_set_tuning(ctx, kv[1], atoi(e));
     g_last_error.clear();
@@ -545,7 +545,8 @@ int bmx_ctx_set_tuning(bmx_ctx* ctx, const char* key, int value)
     else if (k == "eq_big_shape") { ARGCHK(value >= 0 && value <= 1); ctx->eq_big_shape = value; }
     else if (k == "eq_big") { ARGCHK(value >= -1 && value <= 1); ctx->eq_big = value; }
     else if (k == "coll_window") { ARGCHK(value >= 0); ctx->coll_window = value; }
-    else if (k == "rs_select_lines") { ARGCHK(value == 0 || value == 1); ctx->rs_select_lines = value; }
+    else if (k == "rs_select_lines") { ARGCHK(value >= 0 && value <= 2); ctx->rs_select_lines = value; }
+    else if (k == "rs_sdir_shift") { ARGCHK(value == 0 || (value >= 6 && value <= 20)); ctx->rs_sdir_shift = value; }
     else if (k == "rs_lines") { ARGCHK(value == 0 || value == 1); ctx->rs_lines = value; }
     else if (k == "rs_lanes") { ARGCHK(value == 0 || value == 2 || value == 4 || value == 8); ctx->rs_lanes = value; }
     else if (k == "pipe_wg") { ARGCHK(value == 0 || (value >= 64 && value <= 1024 && value % 64 == 0)); ctx->pipe_wg = value; }
@@ -2500,8 +2501,25 @@ int bmx_rs_build(bmx_ctx* ctx, const bmx_vec* v, bmx_rs** out)
         }
         RSCHK(hipMemcpyAsync(ctx->h_small, ctx->d_small, 8, hipMemcpyDeviceToHost, ctx->stream));
         RSCHK(hipStreamSynchronize(ctx->stream));
-#undef RSCHK
         rs->count = ctx->h_small[0];
+        if (rs->d_lines && rs->count) {
+            // select directory over the lines: the line of every 2^shift-th one (+ sentinel); k_select_sdir
+            const uint64_t nlines = (uint64_t)v->nblocks * RL_LINES;
+            uint32_t sh = (uint32_t)ctx->rs_sdir_shift;
+            if (ctx->rs_sdir_shift <= 0) {                        // automatic: 2^sh next to 10 x (ones per line)
+                const double want = 10.0 * (double)rs->count / (double)nlines;
+                sh = 6u; while (sh < 20u && (double)(1ull << sh) * 1.4142 < want) ++sh;
+            }
+            while (((rs->count >> sh) + 2ull) * 4ull > (8ull << 20) && sh < 24u) ++sh;
+            rs->sdir_shift = sh; rs->sdir_entries = ((rs->count + (1ull << sh) - 1ull) >> sh) + 1ull;
+            if ((rc = dmalloc(ctx, (void**)&rs->d_sdir, (size_t)rs->sdir_entries * 4u + 16u))) { bmx_rs_free(ctx, rs); return rc; }
+            rs->bytes += (size_t)rs->sdir_entries * 4u;
+            hipLaunchKernelGGL(k_rs_sdir, dim3((u32)((nlines + 255u) / 256u)), dim3(256), 0, ctx->stream,
+                               (const u32*)rs->d_lines, (u64)nlines, (u64)rs->count, sh, rs->d_sdir, (u64)rs->sdir_entries);
+            RSCHK(hipGetLastError());
+            RSCHK(hipStreamSynchronize(ctx->stream));
+        }
+#undef RSCHK
     }
     *out = rs;
     return BMX_OK;
@@ -2513,7 +2531,7 @@ int bmx_rs_free(bmx_ctx* ctx, bmx_rs* rs)
     ARGCHK(ctx && rs->ctx == ctx);
     int rc = set_dev(ctx); if (rc) return rc;
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    dfree(ctx, rs->d_bcount); dfree(ctx, rs->d_sub); dfree(ctx, rs->d_rcount); dfree(ctx, rs->d_cum); dfree(ctx, rs->d_gidx); dfree(ctx, rs->d_sample); dfree(ctx, rs->d_lines); dfree(ctx, rs->d_dir8);
+    dfree(ctx, rs->d_bcount); dfree(ctx, rs->d_sub); dfree(ctx, rs->d_rcount); dfree(ctx, rs->d_cum); dfree(ctx, rs->d_gidx); dfree(ctx, rs->d_sample); dfree(ctx, rs->d_lines); dfree(ctx, rs->d_dir8); dfree(ctx, rs->d_sdir);
     delete rs;
     return BMX_OK;
 }
@@ -2567,7 +2585,13 @@ int bmx_select_batch_dev(bmx_ctx* ctx, const bmx_vec* v, const bmx_rs* rs, const
 #define SEL_ARGS dim3(grid), dim3(256), 0, ctx->stream, v->d_desc, v->nblocks, \
                  rs->d_rcount, rs->d_cum, rs->d_gidx, rs->d_sample, rs->nsamples, rs->sample_shift, rs->count, \
                  (const u64*)d_rank, (u64)q, (u64*)d_pos, (u8*)d_found
-    if (rs->d_lines && lpq != 8 && ctx->rs_select_lines) {
+    if (rs->d_sdir && lpq != 8 && ctx->rs_select_lines == 2) {
+        if (lpq == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_select_sdir<2>), dim3(grid), dim3(256), 0, ctx->stream, (const u32*)rs->d_lines, (const u32*)rs->d_sdir,
+                                         rs->sdir_shift, rs->count, (const u64*)d_rank, (u64)q, (u64*)d_pos, (u8*)d_found);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_select_sdir<4>), dim3(grid), dim3(256), 0, ctx->stream, (const u32*)rs->d_lines, (const u32*)rs->d_sdir,
+                                rs->sdir_shift, rs->count, (const u64*)d_rank, (u64)q, (u64*)d_pos, (u8*)d_found);
+    }
+    else if (rs->d_lines && lpq != 8 && ctx->rs_select_lines) {
         if (lpq == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_select_lines<2>), dim3(grid), dim3(256), 0, ctx->stream, (const u32*)rs->d_lines, (const u16*)rs->d_dir8,
                                          v->nblocks, (const u64*)rs->d_rcount, (const u64*)rs->d_sample, rs->nsamples, rs->sample_shift, rs->count,
                                          (const u64*)d_rank, (u64)q, (u64*)d_pos, (u8*)d_found);

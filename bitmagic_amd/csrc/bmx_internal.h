@@ -76,7 +76,8 @@ struct bmx_ctx {
     int eq_big = -1;           // batched equality counts: -1 = lean 9,216-value table when the batch has more than 2,048 values, 0 = never, 1 = always
     int coll_window = 0;       // block columns per launch of k_coll_apply (0 = one launch)
     int rs_lines = 1;          // build_rs_index also lays the vector out as rank lines (one 128-B line per rank query; +108 % memory next to the vector): 0 = off
-    int rs_select_lines = 1;   // select through the rank lines (octant directory + interpolated line guess verified by the line headers): 0 = k_select_l
+    int rs_sdir_shift = 0;     // ones per select-directory entry = 2^this; 0 = from the density (an entry per ~10 lines); grown when the directory would pass 8 MB
+    int rs_select_lines = 2;   // select through the rank lines (octant directory + interpolated line guess verified by the line headers): 0 = k_select_l, 2 = select directory over the lines (k_select_sdir)
     int rs_lanes = 0;          // rank: lanes per query (k_rank_l): 0 = automatic, 8 = the original kernel, 2, 4
     int xcd_swz = 1;
 };
@@ -130,6 +131,7 @@ struct bmx_rs {
     u16* d_gidx;                                          // GAP blocks: first run reaching each 1024-bit wave
     u64* d_sample; uint32_t nsamples, sample_shift;       // top level of the select search (<= 2048 entries)
     u32* d_lines;                                         // rank lines: 69 x 128 B per block (count before the line + 960 bits), or null
+    u32* d_sdir; uint32_t sdir_shift; uint64_t sdir_entries;  // with rank lines: select directory (line of every 2^shift-th one) + sentinel
     u16* d_dir8;                                          // with rank lines: ones of a block before each of its eight 8,192-bit octants
     size_t bytes;
 };

@@ -785,3 +785,109 @@ void k_select_lines(const u32* __restrict__ lines, const u16* __restrict__ dir8,
         }
     }
 }
+
+// ---------------------------------------------------------------------------
+// select through a SELECT directory over the rank lines (round 3).  k_select_lines above still walks the block index first:
+// sample search, <= 32 running counts, then two more table reads (running counts of the block, its octant directory) before
+// the line -- three dependent round trips and a long instruction path per query (0.72 ms for 10 M queries where rank, one
+// line per query, takes 0.21 ms).  The headers of the rank lines already ARE a sorted global sequence (ones before every
+// line), so select is a search over lines, and the classic sampled-select directory starts it next to the answer:
+//     sdir[m] = the line holding one number m S (0-based), m = 0 .. ceil(total / S) - 1;  sdir[last + 1] = the last line
+// (S = the power of two next to 10 x the vector's average ones per line, so an entry spans ~10 lines whatever the density
+// and the interpolation lands within a fraction of a line: 4 bytes per ~10 lines = 0.4 % of the lines, ~2 MB for a 4e9-bit
+// vector: L2-resident).  A query reads TWO adjacent entries (the target line lies between them), guesses the line by
+// interpolation, reads it, and lets the header decide: found / earlier / later.  A miss takes up to three secant steps
+// (the header says how many ones away the answer is), then bisects between the bounds the headers have established, so
+// skewed data costs O(log) lines instead of a walk.  Two dependent round trips (directory, line) when
+// the guess holds -- and never a wrong answer: the headers decide, not the guess.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256)
+void k_rs_sdir(const u32* __restrict__ lines, u64 nlines, u64 total, u32 shift, u32* __restrict__ sdir, u64 nent /* incl. the sentinel */)
+{
+    const u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nlines) return;
+    const u64 h = *reinterpret_cast<const u64*>(lines + j * 32u);
+    const u64 hn = j + 1u < nlines ? *reinterpret_cast<const u64*>(lines + (j + 1u) * 32u) : total;
+    const u64 S = 1ull << shift;
+    for (u64 m = (h + S - 1u) >> shift; (m << shift) < hn; ++m) sdir[m] = (u32)j;      // ones h .. hn - 1 (0-based) live in line j
+    if (j == nlines - 1u) sdir[nent - 1u] = (u32)j;
+}
+
+template <u32 LPQ>
+__global__ __launch_bounds__(256)
+void k_select_sdir(const u32* __restrict__ lines, const u32* __restrict__ sdir, u32 shift, u64 total,
+                   const u64* __restrict__ q, u64 nq, u64* __restrict__ pos, u8* __restrict__ found)
+{
+    constexpr u32 NV = 8u / LPQ;
+    const u32 lane = lane_id();
+    const u32 sub = lane & (LPQ - 1u);
+    u64 qi = ((u64)blockIdx.x * blockDim.x + threadIdx.x) / LPQ;
+    const u64 stride = ((u64)gridDim.x * blockDim.x) / LPQ;
+    const u64 nq_round = (nq + (64u / LPQ) - 1ull) / (64u / LPQ) * (64u / LPQ);
+    for (; qi < nq_round; qi += stride) {
+        const bool live = qi < nq;
+        const u64 r = live ? q[qi] : 0ull;
+        const bool ok = live && r != 0ull && r <= total;
+        const u64 idx0 = ok ? r - 1u : 0ull;
+        const u64 m = idx0 >> shift;
+        u32 lo = sdir[m], hi = sdir[m + 1u];
+        const u32 fr = (u32)(idx0 & ((1ull << shift) - 1u));
+        u32 j = lo + (u32)(((u64)(hi - lo) * fr) >> shift);
+        const u64 span = (u64)(hi - lo) + 1u;                        // lines the 2^shift ones of this entry are spread over
+        bool searching = ok;
+        for (u32 it = 0; __ballot(searching) != 0ull && it < 64u; ++it) {
+            gcptr4 p = as_gc4(lines + (size_t)j * 32u) + sub * NV;
+            u32x4 v[NV];
+#pragma unroll
+            for (u32 i = 0; i < NV; ++i) v[i] = p[i];
+            u32 wd[4 * NV];
+#pragma unroll
+            for (u32 i = 0; i < NV; ++i) { wd[4 * i] = v[i].x; wd[4 * i + 1] = v[i].y; wd[4 * i + 2] = v[i].z; wd[4 * i + 3] = v[i].w; }
+            u32 hlo = sub == 0 ? wd[0] : 0u, hhi = sub == 0 ? wd[1] : 0u;
+            hlo = __shfl(hlo, lane & ~(LPQ - 1u), 64); hhi = __shfl(hhi, lane & ~(LPQ - 1u), 64);
+            const u64 hdr = ((u64)hhi << 32) | hlo;                   // ones of the vector before this line
+            if (sub == 0) { wd[0] = 0u; wd[1] = 0u; }
+            u32 mine = 0;
+#pragma unroll
+            for (u32 t = 0; t < 4 * NV; ++t) mine += (u32)__popc(wd[t]);
+            u32 ltot;
+            const u32 excl = group_excl<LPQ>(mine, sub, lane, ltot);
+            const bool left = searching && r <= hdr;                  // the r-th one lies in an earlier line
+            const bool right = searching && r > hdr + ltot;           // ... in a later one
+            if (searching && !left && !right) {
+                const u32 need0 = (u32)(r - hdr);                     // 1..ltot inside this line
+                if (need0 > excl && need0 <= excl + mine) {
+                    u32 need = need0 - excl, word = 0, wi = 0; bool got = false;
+#pragma unroll
+                    for (u32 t = 0; t < 4 * NV; ++t) {
+                        const u32 pc = (u32)__popc(wd[t]);
+                        if (!got) { if (need <= pc) { word = wd[t]; wi = t; got = true; } else need -= pc; }
+                    }
+                    for (u32 s_ = 1; s_ < need; ++s_) word &= word - 1u;
+                    const u32 nb = j / RL_LINES, lj = j - nb * RL_LINES;
+                    const u32 bit = lj * RL_BITS + ((sub * 4u * NV + wi) - 2u) * 32u + (u32)__builtin_ctz(word);
+                    pos[qi] = ((u64)nb << 16) + bit;
+                }
+                searching = false;
+            }
+            if (left) hi = j - 1u;
+            if (right) lo = j + 1u;
+            if (left || right) {
+                if (lo > hi) { searching = false; }                   // (cannot happen with consistent headers)
+                else if (it < 3u) {
+                    // secant step: the header says how many ones away the answer is; opl = ones per line around here
+                    const u64 away = left ? hdr - r : r - hdr - ltot - 1u;
+                    u64 step = 1u + ((away * span) >> shift);                 // away / (S / span) lines, at least the neighbour
+                    if (step > (u64)(hi - lo) + 1u) step = (u64)(hi - lo) + 1u;
+                    u32 nj = left ? (j >= step ? j - (u32)step : 0u) : j + (u32)step;
+                    j = nj < lo ? lo : (nj > hi ? hi : nj);
+                }
+                else j = lo + ((hi - lo) >> 1);
+            }
+        }
+        if (live && sub == 0) {
+            found[qi] = ok ? 1 : 0;
+            if (!ok) pos[qi] = 0;
+        }
+    }
+}

@@ -1240,8 +1240,8 @@ def test_range_hint(ctx, port, agg_path):
         agg.reset_range_hint()
 
 
-@pytest.mark.parametrize("unroll,lines", [(8, 0), (2, 0), (4, 0), (2, 1), (4, 1)])
-def test_rank_select_queries_in_flight_forms(port, unroll, lines):
+@pytest.mark.parametrize("unroll,lines,sel", [(8, 0, 0), (2, 0, 0), (4, 0, 0), (2, 1, 1), (4, 1, 1), (2, 1, 2), (4, 1, 2), (4, 1, (2, 6)), (4, 1, (2, 16))])
+def test_rank_select_queries_in_flight_forms(port, unroll, lines, sel):
     """k_rank_l<2|4> (fewer lanes per query = more queries in flight), k_rank_lines<2|4> (the vector laid out as rank
     lines: one 128-byte line per query) and the 8-lane kernels must give the oracle's answers on every block kind --
     NULL, FULL, bit, sparse and dense GAP -- incl. dead queries (rank 0, rank > count, position past the end) and
@@ -1249,6 +1249,10 @@ def test_rank_select_queries_in_flight_forms(port, unroll, lines):
     c = bm.context(0)
     c.set_tuning("rs_lanes", unroll)
     c.set_tuning("rs_lines", lines)
+    # select over the lines: 1 = block index + octant directory (k_select_lines), 2 = select directory (k_select_sdir;
+    # with 64 ones per entry -- several entries per line -- and with one entry for the whole vector: the bisection path)
+    if isinstance(sel, tuple): c.set_tuning("rs_sdir_shift", sel[1]); sel = sel[0]
+    c.set_tuning("rs_select_lines", sel)
     rng = np.random.default_rng(1234 + unroll)
     nblk = 23
     nbits = nblk * 65536 - 777
@@ -1284,6 +1288,11 @@ def test_rank_select_queries_in_flight_forms(port, unroll, lines):
         ppos, pfound = prs.select(r)
         assert (found == pfound).all() and (pos[found] == ppos[pfound]).all(), (unroll, nq)
         assert (pos[~found] == 0).all()
+    # every one of the vector, in order: select(k) must walk the set bits (all line borders, empty blocks in between)
+    allr = np.arange(1, cnt + 1, dtype=np.uint64)[:: max(1, cnt // 200000)]
+    found, pos = v.select(allr, rs)
+    ppos, pfound = prs.select(allr)
+    assert found.all() and (pos == ppos).all()
     del rs, v
     c.close()
 
