@@ -794,6 +794,8 @@ def run_pairwise(args, env, dq=None, quick=False):
     c1_traffic, c1_tsrc = None, None
     if nbits == NBITS_1G and dq == 6554 and os.environ.get("BMX_PAIR_STREAM", "-1") == "-1":
         c1_traffic, c1_tsrc, _ = traffic_file("traffic_config1.json")
+    elif nbits == NBITS_1G and dq == 655 and os.environ.get("BMX_PAIR_LOOP", "-1") == "-1":
+        c1_traffic, c1_tsrc, _ = traffic_file("traffic_config1_1pct.json")
     pct = dq / 65536 * 100
     res = {"metric": "Gbit/s of operand bits, pairwise count_and on 1e9-bit vectors (HBM-cold rotation)",
            "value": round(2 * nbits * npairs * steps / dt / 1e9, 2), "unit": "Gbit/s", "n_gpus": 1,
@@ -1025,7 +1027,7 @@ def run_or_sharded(args, env, quick=False):
                                                         "used (gap_pack -1); the timed steps stream that copy, the build is not in the timed region"}},
                "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": tsrc,
-                            "kernel": ("k_coll_apply<OR,256>: one workgroup per block column over the packed collection of the operand set"
+                            "kernel": ("k_coll_apply<OR,512>: one workgroup per block column over the packed collection of the operand set"
                                        if pack["collections"] else "k_agg_or_gap_tiled<1,1> (descriptor-table kernel: no packed collection in use)"),
                             "algorithmic_bytes_per_launch": gap_bytes, "avg_launch_ms": round(ev_ms / steps, 4),
                             "note": "host call incl. result creation, layout scan and count; algorithmic bytes = 2 x (len + 1) per GAP operand"}}

@@ -1301,7 +1301,7 @@ int bmx_pipeline_describe(bmx_ctx* ctx, bmx_pipeline* p, uint32_t nb_from, uint3
         snprintf(buf, buf_len, "k_pipe_split<2,%d> x 1 launch, %llu workgroups", SPLIT_WAVES, (unsigned long long)nitems64);
     else if (p->h_vecs && !p->has_bit && ctx->gap_pack != 0 &&
              coll_find(ctx, p->h_vecs->data(), (*p->h_and_n)[0], 0, coll_hash(p->h_vecs->data(), (*p->h_and_n)[0], 0)))
-        snprintf(buf, buf_len, "k_coll_apply<AND_COUNT,256> x 1 launch, %llu workgroups (packed collection of the operand set)", (unsigned long long)nitems64);
+        snprintf(buf, buf_len, "k_coll_apply<AND_COUNT,512> x 1 launch, %llu workgroups (packed collection of the operand set)", (unsigned long long)nitems64);
     else if (use_gapcount(ctx, p))
         snprintf(buf, buf_len, "k_pipe_counts_gapcount x 1 launch, %llu workgroups", (unsigned long long)nitems64);
     else if (p->has_gap)

@@ -44,6 +44,12 @@ rm -rf /tmp/ks; timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/ks -o c4 -f
 cp $(find /tmp/ks -name "*kernel_stats.csv" | head -1) $O/kernel_stats_config4.csv
 rm -rf /tmp/ks; timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/ks -o d -f csv -- python bench.py --density-q16 197 --no-cpu --no-others --no-shard-probe > $O/bench_dq197_under_rocprof.json 2>> $O/err.txt
 cp $(find /tmp/ks -name "*kernel_stats.csv" | head -1) $O/kernel_stats_dq197.csv
+rm -rf /tmp/ks; timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/ks -o c1 -f csv -- python bench.py --config 1 --no-cpu > $O/bench_config1_under_rocprof.json 2>> $O/err.txt
+cp $(find /tmp/ks -name "*kernel_stats.csv" | head -1) $O/kernel_stats_config1.csv
+rm -rf /tmp/ks; timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/ks -o c1p -f csv -- python bench.py --config 1 --density-q16 655 --no-cpu > $O/bench_config1_1pct_under_rocprof.json 2>> $O/err.txt
+cp $(find /tmp/ks -name "*kernel_stats.csv" | head -1) $O/kernel_stats_config1_1pct.csv
+pmc_of $O/pmc_config1.txt "k_count_op2_stream|k_op2_stream" -- --config 1 --no-cpu --steps 3 --warmup 1
+pmc_of $O/pmc_config1_1pct.txt "k_count_op2_loop" -- --config 1 --density-q16 655 --no-cpu --steps 3 --warmup 1
 pmc_of $O/pmc_headline.txt k_pipe_counts_bits2 -- --steps 3 --warmup 1 --no-cpu --no-others --no-shard-probe
 pmc_of $O/pmc_config3.txt "k_rank|k_select|k_probe_lines" -- --config 3 --no-cpu --steps 3 --warmup 1
 pmc_of $O/pmc_config4.txt k_coll_apply -- --config 4 --no-cpu --steps 4 --warmup 2
