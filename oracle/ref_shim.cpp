@@ -19,6 +19,8 @@
 #include "bmbvimport.h"
 #include "bmsparsevec.h"
 #include "bmsparsevec_algo.h"
+#include "bmserial.h"
+#include <chrono>
 
 typedef bm::bvector<> bvect;
 typedef bm::aggregator<bvect> agg_t;
@@ -497,6 +499,37 @@ unsigned ref_bit_to_gap(uint16_t* dest, const uint32_t* blk)
 { return bm::bit_to_gap(dest, blk, bm::gap_equiv_len * 2); }
 void ref_gap_convert_to_bitset(uint32_t* dest, const uint16_t* gap) { bm::gap_convert_to_bitset(dest, gap); }
 uint32_t ref_gap_bit_count(const uint16_t* gap) { return bm::gap_bit_count_unr(gap); }
+
+// ---- serialisation (src/bmserial.h) -- only to MEASURE what SURVEY section 8(f)-3's second leg would be about: the size of a
+// BLOB next to the vector's own blocks and how fast the reference's own deserializer turns it back into blocks on a host core
+// (tools/cpu_blob_decode_rate.py).  Nothing in the product path touches BLOBs.
+// level: serializer::set_compression_level (5 = the default: BIC + digests).  Returns the BLOB size; the bytes go to *out
+// when cap is large enough.
+uint64_t ref_serialize(void* v, unsigned level, unsigned char* out, uint64_t cap)
+{
+    bm::serializer<bvect> ser;
+    ser.set_compression_level(level);
+    bm::serializer<bvect>::buffer buf;
+    ser.serialize(*static_cast<bvect*>(v), buf, 0);
+    if (out && cap >= buf.size()) memcpy(out, buf.data(), buf.size());
+    return buf.size();
+}
+
+// deserialises `reps` times into fresh vectors; returns the last one, *best_seconds = the fastest pass
+void* ref_deserialize_timed(const unsigned char* blob, unsigned reps, double* best_seconds)
+{
+    bvect* last = nullptr; double best = 1e30;
+    for (unsigned r = 0; r < (reps ? reps : 1u); ++r) {
+        delete last;
+        last = new bvect();
+        auto t0 = std::chrono::steady_clock::now();
+        bm::deserialize(*last, blob);
+        double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (dt < best) best = dt;
+    }
+    if (best_seconds) *best_seconds = best;
+    return last;
+}
 
 } // extern "C"
 #pragma GCC visibility pop
