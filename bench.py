@@ -853,8 +853,8 @@ def L_pair_kernel_name(all_bit, nblocks):
         return "k_count_op2_stream<4, true>"
     env_pl = os.environ.get("BMX_PAIR_LOOP", "-1")
     if nblocks >= 2048 and env_pl != "0":
-        return "k_count_op2_loop<4,%s,%s> (persistent: a wave walks every 4096th column, one memory round trip per column)" % (
-            "3" if env_pl == "3" else "4", "false" if os.environ.get("BMX_PAIR_NT", "1") == "0" else "true")
+        return "k_count_op2_loop<4,%s> (persistent: a wave walks every 4096th column, one memory round trip per column)" % (
+            "false" if os.environ.get("BMX_PAIR_NT", "1") == "0" else "true")
     return "k_count_op2 (a wave per block column)"
 
 

@@ -1553,8 +1553,7 @@ static int count_op2_launch(bmx_ctx* ctx, int op, const bmx_vec* a, const bmx_ve
     if (ctx->pair_loop != 0 && nblocks >= 2048u) {
         const u32 wgs = (u32)(ctx->pair_loop > 0 ? ctx->pair_loop : 4);     // workgroups per CU = waves per SIMD
         const u32 grid = std::min<u32>((nblocks + 3u) / 4u, 256u * wgs);
-        auto fn = ctx->pair_nt ? (wgs <= 2u ? k_count_op2_loop<4, 2, true> : wgs == 3u ? k_count_op2_loop<4, 3, true> : k_count_op2_loop<4, 4, true>)
-                                  : (wgs <= 2u ? k_count_op2_loop<4, 2, false> : wgs == 3u ? k_count_op2_loop<4, 3, false> : k_count_op2_loop<4, 4, false>);
+        auto fn = ctx->pair_nt ? k_count_op2_loop<4, true> : k_count_op2_loop<4, false>;
         hipLaunchKernelGGL(fn, dim3(grid), dim3(256), 0, ctx->stream, op,
                            a->d_desc, a->nblocks, b->d_desc, b->nblocks, nblocks, FoldOut{ctx->d_slots, ctx->d_done, out});
         KCHK();

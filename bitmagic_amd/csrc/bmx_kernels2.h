@@ -327,9 +327,9 @@ __device__ __forceinline__ void op2_finish(u64 d, Blk& x, u32* l, u32 lane)
     __builtin_amdgcn_wave_barrier();
 }
 
-// WPE = waves per SIMD the register allocation is held to; NT: non-temporal loads
-template <int WAVES, int WPE, bool NT>
-__global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(WPE)))
+// NT: non-temporal loads.  Register allocation held to four waves per SIMD (128 VGPRs: two block images + the decode)
+template <int WAVES, bool NT>
+__global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4)))
 void k_count_op2_loop(int op, const u64* __restrict__ da, u32 na, const u64* __restrict__ db, u32 nbk, u32 nblocks, FoldOut fold)
 {
     __shared__ u32 lds[WAVES * 2048];
