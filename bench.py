@@ -777,6 +777,27 @@ def run_pairwise(args, env, dq=None, quick=False):
         per_op[name]["materialised_GBps"] = round((pair_bytes[-1] + out_blocks * 8192) / host_ms / 1e6, 1)
         keep.clear()
     torch.cuda.synchronize()
+    # what the box gives a plain 2-read : 1-write elementwise kernel of the same sizes (torch.bitwise_and(out=) over rotating
+    # 125 MB tensors): the yardstick for the materialised ops above, whose kernel moves the same bytes
+    rw_probe = None
+    if not quick:
+        try:
+            nw = (nbits + 63) // 64
+            xs = [torch.randint(0, 1 << 62, (nw,), dtype=torch.int64, device="cuda") for _ in range(3 * 3)]
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            for i in range(3): torch.bitwise_and(xs[3 * i], xs[3 * i + 1], out=xs[3 * i + 2])
+            torch.cuda.synchronize(); e0.record()
+            reps = 12
+            for r in range(reps):
+                i = r % 3
+                torch.bitwise_and(xs[3 * i], xs[3 * i + 1], out=xs[3 * i + 2])
+            e1.record(); torch.cuda.synchronize()
+            pms = e0.elapsed_time(e1) / reps
+            rw_probe = {"kernel": "torch.bitwise_and(a, b, out=c) on int64 tensors of the same size, rotating over 3 triples", "ms": round(pms, 4),
+                        "GBps_read_plus_written": round(3 * nw * 8 / pms / 1e6, 1)}
+            del xs
+        except Exception as e:
+            rw_probe = {"error": str(e)}
     all_counts = dcnt.cpu().tolist()
     pair0 = [all_counts[op * npairs] for op in range(4)]
     # timed region per the contract: a "step" = count_and over every pair (npairs launches)
@@ -803,7 +824,7 @@ def run_pairwise(args, env, dq=None, quick=False):
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
            "config": {"workload": f"bm::count_and/or/xor/sub + bit_and/or/xor/sub on 2 x {nbits}-bit vectors, Bernoulli {pct:.3g}% (density q16 {dq}), "
                                   f"rotating over {npairs} distinct pairs ({sum(pair_bytes) / 1e9:.2f} GB: not Infinity-Cache resident)",
-                      "baseline_config": "configs[1]", "block_types_vec0": va[0].calc_stat(), "per_op": per_op,
+                      "baseline_config": "configs[1]", "block_types_vec0": va[0].calc_stat(), "per_op": per_op, "read_write_probe": rw_probe,
                       "count_and": counts[:4], "pair0_counts_and_or_xor_sub": pair0},
            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": c1_traffic, "traffic_source": c1_tsrc,

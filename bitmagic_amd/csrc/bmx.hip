@@ -483,7 +483,7 @@ int bmx_ctx_create(int device, void* stream, bmx_ctx** out)
     // an invalid value is ignored (the default stays)
     static const char* const env_keys[][2] = {
         {"BMX_PIPE_UNROLL", "pipe_unroll"}, {"BMX_PIPE_ROWS", "pipe_rows"}, {"BMX_PIPE_NT", "pipe_nt"},
-        {"BMX_PIPE_WG", "pipe_wg"}, {"BMX_PIPE_WINDOW", "pipe_window"}, {"BMX_PIPE_SPLIT", "pipe_split"}, {"BMX_OR_TILE", "or_tile"}, {"BMX_OR_WINDOW", "or_window"}, {"BMX_DIRECT_COLS", "direct_cols"}, {"BMX_FF_WINDOW", "ff_window"}, {"BMX_GAP_COUNT", "gap_count"}, {"BMX_RANGE_HALVES", "range_halves"}, {"BMX_PAIR_STREAM", "pair_stream"}, {"BMX_PAIR_WGS", "pair_wgs"}, {"BMX_RS_LANES", "rs_lanes"}, {"BMX_RS_LINES", "rs_lines"}, {"BMX_RS_SELECT_LINES", "rs_select_lines"}, {"BMX_RS_SDIR_SHIFT", "rs_sdir_shift"}, {"BMX_COLL_SHAPE", "coll_shape"}, {"BMX_COLL_WINDOW", "coll_window"}, {"BMX_EQ_BIG", "eq_big"}, {"BMX_PAIR_LOOP", "pair_loop"}, {"BMX_PAIR_NT", "pair_nt"}, {"BMX_EQ_BIG_SHAPE", "eq_big_shape"}, {"BMX_OP2_WGS", "op2_wgs"}, {"BMX_GAP_PACK", "gap_pack"}, {"BMX_XCD_SWIZZLE", "xcd_swizzle"}};
+        {"BMX_PIPE_WG", "pipe_wg"}, {"BMX_PIPE_WINDOW", "pipe_window"}, {"BMX_PIPE_SPLIT", "pipe_split"}, {"BMX_OR_TILE", "or_tile"}, {"BMX_OR_WINDOW", "or_window"}, {"BMX_DIRECT_COLS", "direct_cols"}, {"BMX_FF_WINDOW", "ff_window"}, {"BMX_GAP_COUNT", "gap_count"}, {"BMX_RANGE_HALVES", "range_halves"}, {"BMX_PAIR_STREAM", "pair_stream"}, {"BMX_PAIR_WGS", "pair_wgs"}, {"BMX_RS_LANES", "rs_lanes"}, {"BMX_RS_LINES", "rs_lines"}, {"BMX_RS_SELECT_LINES", "rs_select_lines"}, {"BMX_RS_SDIR_SHIFT", "rs_sdir_shift"}, {"BMX_COLL_SHAPE", "coll_shape"}, {"BMX_COLL_WINDOW", "coll_window"}, {"BMX_EQ_BIG", "eq_big"}, {"BMX_PAIR_LOOP", "pair_loop"}, {"BMX_PAIR_NT", "pair_nt"}, {"BMX_EQ_BIG_SHAPE", "eq_big_shape"}, {"BMX_OP2_WGS", "op2_wgs"}, {"BMX_OP2_NT", "op2_nt"}, {"BMX_GAP_PACK", "gap_pack"}, {"BMX_XCD_SWIZZLE", "xcd_swizzle"}};
     for (auto& kv : env_keys)
         if (const char* e = getenv(kv[0])) (void)bmx_ctx_set_tuning(ctx, kv[1], atoi(e));
     g_last_error.clear();
@@ -539,6 +539,7 @@ int bmx_ctx_set_tuning(bmx_ctx* ctx, const char* key, int value)
     else if (k == "or_window") { ARGCHK(value >= -9); ctx->or_window = value; }
     else if (k == "gap_pack") { ARGCHK(value >= -1 && value <= 1); ctx->gap_pack = value; }
     else if (k == "coll_shape") { ARGCHK(value >= 0 && value <= 3); ctx->coll_shape = value; }
+    else if (k == "op2_nt") { ARGCHK(value >= 0 && value <= 3); ctx->op2_nt = value; }
     else if (k == "op2_wgs") { ARGCHK(value >= 1 && value <= 8); ctx->op2_wgs = value; }
     else if (k == "pair_nt") { ARGCHK(value >= 0 && value <= 1); ctx->pair_nt = value; }
     else if (k == "pair_loop") { ARGCHK(value >= -1 && value <= 5); ctx->pair_loop = value; }
@@ -1500,7 +1501,9 @@ int bmx_op2(bmx_ctx* ctx, int op, const bmx_vec* a, const bmx_vec* b, int opt_co
             const u32 waves = 4u, total = 256u * waves * (u32)std::max(ctx->op2_wgs, 1);
             const u32 per_wave = (nblocks + total - 1u) / total;
             const u32 grid = ((nblocks + per_wave - 1u) / per_wave + waves - 1u) / waves;
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_op2_stream<4>), dim3(grid), dim3(256), 0, ctx->stream, op, a->d_desc, b->d_desc, nblocks, per_wave,
+            auto fn = ctx->op2_nt == 3 ? k_op2_stream<4, true, true> : ctx->op2_nt == 2 ? k_op2_stream<4, false, true>
+                    : ctx->op2_nt == 1 ? k_op2_stream<4, true, false> : k_op2_stream<4, false, false>;
+            hipLaunchKernelGGL(fn, dim3(grid), dim3(256), 0, ctx->stream, op, a->d_desc, b->d_desc, nblocks, per_wave,
                                v->d_bits, v->d_desc, st, FoldOut{ctx->d_slots, ctx->d_done, ctx->h_small + 2});
         } else
         hipLaunchKernelGGL(k_op2, dim3((nblocks + 3) / 4), dim3(256), 0, ctx->stream, op,

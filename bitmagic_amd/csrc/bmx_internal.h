@@ -71,7 +71,8 @@ struct bmx_ctx {
     int coll_shape = 2;        // k_coll_apply shape: 0 = 256 threads, 1 = 256 + prefetch, 2 = 512 (default: configs[4] 2.50 vs 2.61 ms, the AND cases equal), 3 = 512 + prefetch
     int pair_nt = 1;           // ... with non-temporal loads
     int pair_loop = -1;        // pairwise counts over mixed block kinds: -1 = persistent kernel (4 workgroups per CU), 0 = a wave per column, N = workgroups per CU
-    int op2_wgs = 2;           // workgroups per CU of the streaming materialised pairwise kernel (k_op2_stream)
+    int op2_nt = 3;            // ... bit 0: non-temporal loads, bit 1: non-temporal stores
+    int op2_wgs = 4;           // workgroups per CU of the streaming materialised pairwise kernel (k_op2_stream)
     int eq_big_shape = 1;      // lean table: 1 = 256 Kbit filter + 512-entry queues, 0 = 128 Kbit + 1,024
     int eq_big = -1;           // batched equality counts: -1 = lean 9,216-value table when the batch has more than 2,048 values, 0 = never, 1 = always
     int coll_window = 0;       // block columns per launch of k_coll_apply (0 = one launch)

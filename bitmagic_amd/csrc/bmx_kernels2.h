@@ -411,7 +411,7 @@ void k_count_op2_stream(int op, const u64* __restrict__ da, const u64* __restric
 // for AND / XOR / SUB, all-ones -> FULL for OR: ST_TEST_ZERO / ST_TEST_ONE of op2_block), so the classification is two wave
 // votes -- no popcount, no run count (st[].pop / runs of a bit-block are read by nothing) -- and the kinds of the wave's
 // whole stretch are folded once at the end.  Results are written with non-temporal stores.
-template <int WAVES>
+template <int WAVES, bool LNT, bool SNT>
 __global__ __launch_bounds__(WAVES * 64)
 void k_op2_stream(int op, const u64* __restrict__ da, const u64* __restrict__ db, u32 nblocks, u32 per_wave,
                   uint4* __restrict__ slab, u64* __restrict__ desc, BlockStat* __restrict__ st, FoldOut kinds)
@@ -424,7 +424,7 @@ void k_op2_stream(int op, const u64* __restrict__ da, const u64* __restrict__ db
     if (c0 < c1) {
         const u32 last = nblocks - 1u;
         auto ptr = [&](const u64* __restrict__ d, u32 c) { return DESC_P(uniform64(d[c < last ? c : last])); };
-        auto load = [&](Blk& x, Blk& y, u64 pa, u64 pb) { part_load<8, true>(x, as_gc4(pa), lane); part_load<8, true>(y, as_gc4(pb), lane); };
+        auto load = [&](Blk& x, Blk& y, u64 pa, u64 pb) { part_load<8, LNT>(x, as_gc4(pa), lane); part_load<8, LNT>(y, as_gc4(pb), lane); };
         auto eat = [&](Blk& x, const Blk& y, u32 c) {
             blk_op(op, x, y);
             u32 o = 0u, a = ~0u;
@@ -438,7 +438,7 @@ void k_op2_stream(int op, const u64* __restrict__ da, const u64* __restrict__ db
             if (kind == K_BIT) {
                 gptr4 p = as_g4(slot);
 #pragma unroll
-                for (int i = 0; i < 8; ++i) __builtin_nontemporal_store(x.r[i], &p[i * 64 + lane]);
+                for (int i = 0; i < 8; ++i) { if (SNT) __builtin_nontemporal_store(x.r[i], &p[i * 64 + lane]); else p[i * 64 + lane] = x.r[i]; }
             }
             if (lane == 0) {
                 st[c] = BlockStat{0u, kind == K_BIT ? 2u : 1u, ones ? 1u : 0u, kind};

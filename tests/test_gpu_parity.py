@@ -401,7 +401,7 @@ def test_pairwise_materialised_streaming_kernel(ctx, port, nblocks_x):
                 assert st["bit_blocks"] == t.block_table()[0].tolist().count(bm.BIT)
                 del t
     finally:
-        ctx.set_tuning("pair_stream", -1); ctx.set_tuning("op2_wgs", 2)
+        ctx.set_tuning("pair_stream", -1); ctx.set_tuning("op2_wgs", 4)
 
 
 def test_full_size_256way_and_count(ctx, port):
