@@ -389,8 +389,8 @@ def test_pairwise_materialised_streaming_kernel(ctx, port, nblocks_x):
     pa = port.import_words(wa, False, nw * 32); pb = port.import_words(wb, False, nw * 32)
     fns = ((bm.bvector.bit_and, bm.AND), (bm.bvector.bit_or, bm.OR), (bm.bvector.bit_xor, bm.XOR), (bm.bvector.bit_sub, bm.SUB))
     try:
-        for ps, wgs in ((0, 1), (-1, 1), (-1, 2), (-1, 3), (-1, 8)):
-            ctx.set_tuning("pair_stream", ps); ctx.set_tuning("op2_wgs", wgs)
+        for ps, wgs, nt in ((0, 1, 3), (-1, 1, 3), (-1, 2, 0), (-1, 3, 1), (-1, 8, 2)):
+            ctx.set_tuning("pair_stream", ps); ctx.set_tuning("op2_wgs", wgs); ctx.set_tuning("op2_nt", nt)
             for fn, op in fns:
                 t = fn(a, b)
                 e = port.op2(op, pa, pb, 0)
@@ -401,7 +401,7 @@ def test_pairwise_materialised_streaming_kernel(ctx, port, nblocks_x):
                 assert st["bit_blocks"] == t.block_table()[0].tolist().count(bm.BIT)
                 del t
     finally:
-        ctx.set_tuning("pair_stream", -1); ctx.set_tuning("op2_wgs", 4)
+        ctx.set_tuning("pair_stream", -1); ctx.set_tuning("op2_wgs", 4); ctx.set_tuning("op2_nt", 3)
 
 
 def test_full_size_256way_and_count(ctx, port):
