@@ -255,6 +255,15 @@ static int coll_get(bmx_ctx* ctx, const bmx_vec* const* v, size_t n, int polarit
     return rc;
 }
 
+// (tuning build only: BMX_DIAG_COLL = 512 -> loads alone, 1024 -> no fold / store, 1536 -> both; results are then meaningless)
+static int coll_diag_bits()
+{
+#ifdef BMX_DIAG
+    if (const char* e = getenv("BMX_DIAG_COLL")) return atoi(e) & (512 | 1024);
+#endif
+    return 0;
+}
+
 // one workgroup per block column over [col_from, col_to); a = the AND / OR bag, s = the SUB bag (may be null)
 static int coll_launch(int mode, bmx_ctx* ctx, const bmx_coll* a, const bmx_coll* s, u32 col_from, u32 col_to, int opt_compress,
                        u64* d_counts, bmx_vec* v, BlockStat* st, u32 hint_from, u32 hint_to, FoldOut kinds = FoldOut{nullptr, nullptr, nullptr})
@@ -263,7 +272,7 @@ static int coll_launch(int mode, bmx_ctx* ctx, const bmx_coll* a, const bmx_coll
     const u32 grid_all = col_to - col_from;
 #define COLL_ARGS_WG(W) dim3(grid), dim3(W), 0, ctx->stream, (const u32*)a->d_runs, (const u64*)a->d_off, (const u32*)a->d_cnt, \
         (const u32*)a->d_flags, a->ncols, (const u32*)(s ? s->d_runs : nullptr), (const u64*)(s ? s->d_off : nullptr), \
-        (const u32*)(s ? s->d_cnt : nullptr), (const u32*)(s ? s->d_flags : nullptr), s ? s->ncols : 0u, cbase, col_to, opt_compress, \
+        (const u32*)(s ? s->d_cnt : nullptr), (const u32*)(s ? s->d_flags : nullptr), s ? s->ncols : 0u, cbase, col_to, opt_compress | coll_diag_bits(), \
         d_counts, v ? v->d_bits : (uint4*)nullptr, v ? v->d_desc : (u64*)nullptr, st, hint_from, hint_to, kinds
     // coll_shape (tuning): 0 = 256 threads, 1 = 256 threads + prefetch, 2 = 512 threads, 3 = 512 threads + prefetch
 #define COLL_LAUNCH(M) do { \

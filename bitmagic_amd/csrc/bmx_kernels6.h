@@ -138,7 +138,7 @@ __device__ __forceinline__ void coll_apply_run(u32 r, bool valid, u32* U, int* D
 // before the current one is applied (two batches in flight per lane; indices past the end are clamped to the column's last
 // chunk so that every iteration issues the same loads).  Returns (per thread) whether it produced an interior-word span
 template <int WG, bool PF>
-__device__ __forceinline__ u32 coll_apply_bag(const u32* __restrict__ runs, u64 off, u32 cnt, u32* U, int* D, u32 tid)
+__device__ __forceinline__ u32 coll_apply_bag(const u32* __restrict__ runs, u64 off, u32 cnt, u32* U, int* D, u32 tid, bool diag_loads_only = false)
 {
     gcptr4 p = as_gc4(runs + off);
     const u32 nq = (cnt + 3u) >> 2;
@@ -149,6 +149,14 @@ __device__ __forceinline__ u32 coll_apply_bag(const u32* __restrict__ runs, u64 
         for (u32 j = 0; j < 4; ++j) { u32 q = q0 + j * WG; v[j] = __builtin_nontemporal_load(&p[q < nq ? q : nq - 1u]); }
     };
     auto apply = [&](const u32x4 (&v)[4], u32 q0) {
+#ifdef BMX_DIAG
+        if (diag_loads_only) {                                // timing probe: the loads alone (one OR per value keeps them alive)
+            u32 t = 0;
+            for (u32 j = 0; j < 4; ++j) t |= v[j].x | v[j].y | v[j].z | v[j].w;
+            if (t == 0x12345u) U[tid] = t;
+            return;
+        }
+#endif
 #pragma unroll
         for (u32 j = 0; j < 4; ++j) {
             u32 q = q0 + j * WG;
@@ -243,6 +251,10 @@ void k_coll_apply(const u32* __restrict__ runs, const u64* __restrict__ off, con
     __shared__ u32 s_long;
     __shared__ u32 part[WG / 64];
     const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+#ifdef BMX_DIAG
+    const int diag = opt_compress & 1536;                     // (tuning build: timing probes, see coll_diag_bits in bmx.hip)
+    opt_compress &= 1;
+#endif
     const u32 c = col_base + blockIdx.x;
     if (c >= ncols) return;
     if (MODE != COLL_OR && (c < hint_from || c >= hint_to)) {
@@ -275,7 +287,12 @@ void k_coll_apply(const u32* __restrict__ runs, const u64* __restrict__ off, con
     }
     if (tid == 0) s_long = 0u;
     __syncthreads();
+#ifdef BMX_DIAG
+    u32 al = coll_apply_bag<WG, PF>(runs, uniform64(off[c < ncols_a ? c : 0u]), n_ent, U, D, tid, (diag & 512) != 0);
+    if (diag & 1024) return;                                  // timing probe: no fold, no store
+#else
     u32 al = coll_apply_bag<WG, PF>(runs, uniform64(off[c < ncols_a ? c : 0u]), n_ent, U, D, tid);
+#endif
     if (al) s_long = 1u;
     __syncthreads();
     if (s_long) coll_fold<WG>(U, D, sm, tid);                 // (block-uniform; the barriers inside are reached by every thread)
