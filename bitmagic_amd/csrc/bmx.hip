@@ -280,6 +280,8 @@ static int coll_launch(int mode, bmx_ctx* ctx, const bmx_coll* a, const bmx_coll
         case 1: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_coll_apply<M, 256, true>), COLL_ARGS_WG(256)); break; \
         case 2: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_coll_apply<M, 512, false>), COLL_ARGS_WG(512)); break; \
         case 3: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_coll_apply<M, 512, true>), COLL_ARGS_WG(512)); break; \
+        case 4: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_coll_apply<M, 512, false, true>), COLL_ARGS_WG(512)); break; \
+        case 5: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_coll_apply<M, 512, true, true>), COLL_ARGS_WG(512)); break; \
         default: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_coll_apply<M, 256, false>), COLL_ARGS_WG(256)); break; } } while (0)
     // launch windows (coll_window columns per launch; 0 = one launch)
     const u32 win = ctx->coll_window > 0 ? (u32)ctx->coll_window : grid_all;
@@ -547,7 +549,7 @@ int bmx_ctx_set_tuning(bmx_ctx* ctx, const char* key, int value)
     else if (k == "ff_window") { ARGCHK(value >= -1); ctx->ff_window = value; }
     else if (k == "or_window") { ARGCHK(value >= -9); ctx->or_window = value; }
     else if (k == "gap_pack") { ARGCHK(value >= -1 && value <= 1); ctx->gap_pack = value; }
-    else if (k == "coll_shape") { ARGCHK(value >= 0 && value <= 3); ctx->coll_shape = value; }
+    else if (k == "coll_shape") { ARGCHK(value >= 0 && value <= 5); ctx->coll_shape = value; }
     else if (k == "op2_nt") { ARGCHK(value >= 0 && value <= 3); ctx->op2_nt = value; }
     else if (k == "op2_wgs") { ARGCHK(value >= 1 && value <= 8); ctx->op2_wgs = value; }
     else if (k == "pair_nt") { ARGCHK(value >= 0 && value <= 1); ctx->pair_nt = value; }

@@ -137,16 +137,20 @@ __device__ __forceinline__ void coll_apply_run(u32 r, bool valid, u32* U, int* D
 // all entries [0, cnt) of one column, 16 bytes per lane per load, four loads per batch; PF: the next batch is requested
 // before the current one is applied (two batches in flight per lane; indices past the end are clamped to the column's last
 // chunk so that every iteration issues the same loads).  Returns (per thread) whether it produced an interior-word span
-template <int WG, bool PF>
+// CW: the four loads of a lane are 1 KiB apart, i.e. a WAVE reads 4 KiB in one piece per batch (instead of four 1-KiB pieces
+// 8 KiB apart with the workgroup covering 32 KiB between them)
+template <int WG, bool PF, bool CW = false>
 __device__ __forceinline__ u32 coll_apply_bag(const u32* __restrict__ runs, u64 off, u32 cnt, u32* U, int* D, u32 tid, bool diag_loads_only = false)
 {
     gcptr4 p = as_gc4(runs + off);
     const u32 nq = (cnt + 3u) >> 2;
     u32 any_long = 0u;
     if (!nq) return 0u;
+    constexpr u32 JS = CW ? 64u : (u32)WG;                    // distance between a lane's loads of one batch (16-byte units)
+    const u32 first = CW ? (tid >> 6) * 256u + (tid & 63u) : tid;
     auto fetch = [&](u32x4 (&v)[4], u32 q0) {
 #pragma unroll
-        for (u32 j = 0; j < 4; ++j) { u32 q = q0 + j * WG; v[j] = __builtin_nontemporal_load(&p[q < nq ? q : nq - 1u]); }
+        for (u32 j = 0; j < 4; ++j) { u32 q = q0 + j * JS; v[j] = __builtin_nontemporal_load(&p[q < nq ? q : nq - 1u]); }
     };
     auto apply = [&](const u32x4 (&v)[4], u32 q0) {
 #ifdef BMX_DIAG
@@ -159,7 +163,7 @@ __device__ __forceinline__ u32 coll_apply_bag(const u32* __restrict__ runs, u64 
 #endif
 #pragma unroll
         for (u32 j = 0; j < 4; ++j) {
-            u32 q = q0 + j * WG;
+            u32 q = q0 + j * JS;
             bool in = q < nq;
             u32 e0 = q * 4u;
             coll_apply_run(v[j].x, in && e0 < cnt, U, D, any_long);
@@ -172,15 +176,16 @@ __device__ __forceinline__ u32 coll_apply_bag(const u32* __restrict__ runs, u64 
         // every thread of the workgroup runs the same number of rounds (the bound does not depend on tid)
         u32x4 a[4], b[4];
         const u32 rounds = (nq + 4u * WG - 1u) / (4u * WG);
-        fetch(a, tid);
+        fetch(a, first);
         for (u32 r = 0; r < rounds; r += 2u) {
-            fetch(b, tid + (r + 1u) * 4u * WG);
-            apply(a, tid + r * 4u * WG);
-            fetch(a, tid + (r + 2u) * 4u * WG);
-            apply(b, tid + (r + 1u) * 4u * WG);
+            fetch(b, first + (r + 1u) * 4u * WG);
+            apply(a, first + r * 4u * WG);
+            fetch(a, first + (r + 2u) * 4u * WG);
+            apply(b, first + (r + 1u) * 4u * WG);
         }
     } else {
-        for (u32 q0 = tid; q0 < nq; q0 += 4u * WG) { u32x4 v[4]; fetch(v, q0); apply(v, q0); }
+        const u32 rounds = (nq + 4u * WG - 1u) / (4u * WG);
+        for (u32 r = 0; r < rounds; ++r) { u32x4 v[4]; fetch(v, first + r * 4u * WG); apply(v, first + r * 4u * WG); }
     }
     return any_long;
 }
@@ -235,7 +240,7 @@ enum { COLL_OR = 0, COLL_AND_STORE = 1, COLL_AND_COUNT = 2 };
 //   COLL_AND_STORE  result = NOT union(AND bag, polarity 0) AND NOT union(SUB bag, polarity 1), stored with opt_compress
 //                   (combine_and_sub, :1162,1210)
 //   COLL_AND_COUNT  the same, counted (counts-only pipeline of one arg-group, :1292-1399)
-template <int MODE, int WG, bool PF = false>
+template <int MODE, int WG, bool PF = false, bool CW = false>
 __global__ __launch_bounds__(WG)
 void k_coll_apply(const u32* __restrict__ runs, const u64* __restrict__ off, const u32* __restrict__ cnt,
                   const u32* __restrict__ flags, u32 ncols_a,
@@ -288,10 +293,10 @@ void k_coll_apply(const u32* __restrict__ runs, const u64* __restrict__ off, con
     if (tid == 0) s_long = 0u;
     __syncthreads();
 #ifdef BMX_DIAG
-    u32 al = coll_apply_bag<WG, PF>(runs, uniform64(off[c < ncols_a ? c : 0u]), n_ent, U, D, tid, (diag & 512) != 0);
+    u32 al = coll_apply_bag<WG, PF, CW>(runs, uniform64(off[c < ncols_a ? c : 0u]), n_ent, U, D, tid, (diag & 512) != 0);
     if (diag & 1024) return;                                  // timing probe: no fold, no store
 #else
-    u32 al = coll_apply_bag<WG, PF>(runs, uniform64(off[c < ncols_a ? c : 0u]), n_ent, U, D, tid);
+    u32 al = coll_apply_bag<WG, PF, CW>(runs, uniform64(off[c < ncols_a ? c : 0u]), n_ent, U, D, tid);
 #endif
     if (al) s_long = 1u;
     __syncthreads();
@@ -317,7 +322,7 @@ void k_coll_apply(const u32* __restrict__ runs, const u64* __restrict__ off, con
         for (u32 k = 0; k < W; k += 4u) *reinterpret_cast<u32x4*>(&U[tid * W + k]) = (u32x4)(0u);
         if (tid == 0) s_long = 0u;
         __syncthreads();
-        u32 sl = coll_apply_bag<WG, PF>(s_runs, uniform64(s_off[c]), s_ent, U, D, tid);
+        u32 sl = coll_apply_bag<WG, PF, CW>(s_runs, uniform64(s_off[c]), s_ent, U, D, tid);
         if (sl) s_long = 1u;
         __syncthreads();
         if (s_long) coll_fold<WG>(U, D, sm, tid);

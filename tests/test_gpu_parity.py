@@ -1063,6 +1063,39 @@ def test_batched_equality_counts_by_transposition(ctx, case):
         ctx.set_tuning("eq_big", -1); ctx.set_tuning("eq_big_shape", 1)
 
 
+def test_packed_collection_kernel_shapes(port):
+    """every launch shape of k_coll_apply (256 / 512 threads, with and without the second batch in flight, a wave's batch as
+    four 1-KiB pieces or one 4-KiB piece) must produce the oracle's bits and block kinds for OR, AND-SUB and the counts"""
+    rng = np.random.default_rng(77)
+    nvec, nbits = 96, 5 * 65536 + 4321
+    words = _sparse_collection(port, rng, nvec, nbits, 300, long_runs=True, ragged=True)
+    pv = [port.import_words(w, True, w.size * 32) for w in words]
+    nwb = 6 * 2048
+    e_or = port.agg_or(pv, False)
+    e_as = port.agg_and_sub(pv[:80], pv[80:])
+    for shape in range(6):
+        c = bm.context(0)
+        c.set_tuning("gap_pack", 1); c.set_tuning("coll_shape", shape)
+        c.set_tuning("direct_cols", 0); c.set_tuning("pipe_split", 0)
+        gv = [bm.bit_import_u32(c, w, True) for w in words]
+        agg = bm.aggregator(c)
+        o = agg.combine_or(gv)
+        assert (o.to_words(nwb) == e_or.to_words(nwb)).all(), shape
+        assert o.block_table()[0].tolist() == (e_or.flatten()[0].tolist() + [0] * 8)[:o.info()["nblocks"]], shape
+        t, any_ = agg.combine_and_sub(gv[:80], gv[80:])
+        assert (t.to_words(nwb) == e_as.to_words(nwb)).all(), shape
+        assert t.block_table()[0].tolist() == (e_as.flatten()[0].tolist() + [0] * 8)[:t.info()["nblocks"]], shape
+        pipe = bm.aggregator.pipeline(c)
+        ag = pipe.add()
+        for v in gv[:80]: ag.add(v, 0)
+        for v in gv[80:]: ag.add(v, 1)
+        pipe.complete()
+        assert int(agg.combine_and_sub(pipe)[0]) == e_as.count(), shape
+        assert c.pack_stats()["collections"] > 0
+        del o, t, pipe, ag, agg, gv
+        c.close()
+
+
 def _bits_of(t, n):
     return np.unpackbits(t.to_words((n + 31) // 32).view(np.uint8), bitorder="little")[:n].astype(bool)
 
