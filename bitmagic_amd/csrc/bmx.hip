@@ -2396,7 +2396,8 @@ int bmx_slice_eq_counts(bmx_ctx* ctx, const bmx_vec* const* slices, size_t nslic
     std::vector<uint64_t> ucount(uniq.size(), 0);
     // up to 2,048 values: the table with ordinals (2 workgroups per CU); more: the lean {key, count} table shared by 512
     // threads, up to EQB_MAX_VALUES per pass over the planes (eq_big: 0 = never, 1 = always, -1 = by the batch size)
-    const bool big = ctx->eq_big == 1 || (ctx->eq_big < 0 && uniq.size() > 2048) ;
+    // (the lean table wants up to 156 KiB of LDS per workgroup: without that much the 2,048-value form takes every batch)
+    const bool big = (ctx->eq_big == 1 || (ctx->eq_big < 0 && uniq.size() > 2048)) && ctx->max_lds_bytes >= EQB_SLOTS(EQB_MAX_VALUES) * 8u + (1u << 15) + 8u * 512u * 4u;
     const size_t cap = big ? EQB_MAX_VALUES : 2048;
     const size_t npass = (uniq.size() + cap - 1) / cap;
     const size_t CHUNK = (uniq.size() + npass - 1) / npass;

@@ -856,7 +856,7 @@ void k_select_sdir(const u32* __restrict__ lines, const u32* __restrict__ sdir, 
         const u32 fr = (u32)(idx0 & ((1ull << shift) - 1u));
         u32 j = lo + (u32)(((u64)(hi - lo) * fr) >> shift);
         const u64 span = (u64)(hi - lo) + 1u;                        // lines the 2^shift ones of this entry are spread over
-        bool searching = ok;
+        bool searching = ok, failed = false;
         for (u32 it = 0; __ballot(searching) != 0ull && it < 64u; ++it) {
             gcptr4 p = as_gc4(lines + (size_t)j * 32u) + sub * NV;
             u32x4 v[NV];
@@ -895,7 +895,7 @@ void k_select_sdir(const u32* __restrict__ lines, const u32* __restrict__ sdir, 
             if (left) hi = j - 1u;
             if (right) lo = j + 1u;
             if (left || right) {
-                if (lo > hi) { searching = false; }                   // (cannot happen with consistent headers)
+                if (lo > hi) { searching = false; failed = true; }    // (cannot happen with consistent headers: reported as not found)
                 else if (it < 3u) {
                     // secant step: the header says how many ones away the answer is; opl = ones per line around here
                     const u64 away = left ? hdr - r : r - hdr - ltot - 1u;
@@ -907,9 +907,10 @@ void k_select_sdir(const u32* __restrict__ lines, const u32* __restrict__ sdir, 
                 else j = lo + ((hi - lo) >> 1);
             }
         }
+        failed = failed || searching;                                // (iteration cap reached: same)
         if (live && sub == 0) {
-            found[qi] = ok ? 1 : 0;
-            if (!ok) pos[qi] = 0;
+            found[qi] = (ok && !failed) ? 1 : 0;
+            if (!ok || failed) pos[qi] = 0;
         }
     }
 }
