@@ -418,6 +418,19 @@ void k_expand_indices(const u64* __restrict__ desc, u32 nblocks, const u64* __re
     }
 }
 
+// position of the k-th set bit (k = 1..popcount) of a word, without a loop: five halving steps on popcounts (word_select,
+// src/bmfunc.h:1084, does `w &= w - 1` k - 1 times: up to 31 dependent iterations that a wave runs for its slowest lane)
+__device__ __forceinline__ u32 select_in_word(u32 w, u32 k)
+{
+    u32 pos = 0u, c;
+    c = (u32)__popc(w & 0xFFFFu); { const bool m = k > c; k -= m ? c : 0u; pos += m ? 16u : 0u; w = m ? w >> 16 : w; }
+    c = (u32)__popc(w & 0xFFu);   { const bool m = k > c; k -= m ? c : 0u; pos += m ? 8u : 0u;  w = m ? w >> 8 : w; }
+    c = (u32)__popc(w & 0xFu);    { const bool m = k > c; k -= m ? c : 0u; pos += m ? 4u : 0u;  w = m ? w >> 4 : w; }
+    c = (u32)__popc(w & 0x3u);    { const bool m = k > c; k -= m ? c : 0u; pos += m ? 2u : 0u;  w = m ? w >> 2 : w; }
+    c = w & 1u;                   { const bool m = k > c; pos += m ? 1u : 0u; }
+    return pos;
+}
+
 // ---------------------------------------------------------------------------
 // Rank lines (round 3): count_to / rank with ONE random 128-byte line per query.
 // k_rank reads four things per query -- descriptor, running count, cumulative count of the 1024-bit wave, the bit line --
@@ -478,6 +491,67 @@ void k_rs_lines(const u64* __restrict__ desc, u32 nblocks, const u64* __restrict
     }
 }
 
+// Groups of 2 or 4 lanes sit inside a quad: their exchanges are DPP quad permutes (one VALU instruction each) instead of
+// ds_bpermute round trips through the LDS crossbar (__shfl*).  quad_perm control = sel0 | sel1 << 2 | sel2 << 4 | sel3 << 6.
+template <int CTRL>
+__device__ __forceinline__ u32 quad_perm(u32 v) { return (u32)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false); }
+// the value of the group's lane 0 in every lane of the group
+template <u32 LPQ>
+__device__ __forceinline__ u32 group_first(u32 v, u32 lane)
+{
+    if constexpr (LPQ == 4u) return quad_perm<0x00>(v);                       // [0,0,0,0]
+    else if constexpr (LPQ == 2u) return quad_perm<0xA0>(v);                  // [0,0,2,2]
+    else return __shfl(v, lane & ~(LPQ - 1u), 64);
+}
+template <u32 LPQ>
+__device__ __forceinline__ u32 group_sum(u32 v)
+{
+    if constexpr (LPQ == 2u || LPQ == 4u) {
+        v += quad_perm<0xB1>(v);                                              // [1,0,3,2]: lane ^ 1
+        if constexpr (LPQ == 4u) v += quad_perm<0x4E>(v);                     // [2,3,0,1]: lane ^ 2
+        return v;
+    } else {
+#pragma unroll
+        for (u32 o = 1; o < LPQ; o <<= 1) v += __shfl_xor(v, o, 64);
+        return v;
+    }
+}
+template <u32 LPQ>
+__device__ __forceinline__ u32 group_max(u32 v)
+{
+    if constexpr (LPQ == 2u || LPQ == 4u) {
+        u32 t = quad_perm<0xB1>(v); v = t > v ? t : v;
+        if constexpr (LPQ == 4u) { t = quad_perm<0x4E>(v); v = t > v ? t : v; }
+        return v;
+    } else {
+#pragma unroll
+        for (u32 o = 1; o < LPQ; o <<= 1) { u32 t = __shfl_xor(v, o, 64); v = t > v ? t : v; }
+        return v;
+    }
+}
+// exclusive prefix of `mine` inside the group of LPQ lanes; total in `tot`
+template <u32 LPQ>
+__device__ __forceinline__ u32 group_excl(u32 mine, u32 sub, u32 lane, u32& tot)
+{
+    u32 incl = mine;
+    if constexpr (LPQ == 2u) {
+        const u32 t = quad_perm<0xA0>(incl);                                  // [0,0,2,2]: the lower lane of the pair
+        if (sub >= 1u) incl += t;
+        tot = quad_perm<0xF5>(incl);                                          // [1,1,3,3]: the pair's upper lane
+    } else if constexpr (LPQ == 4u) {
+        u32 t = quad_perm<0x90>(incl);                                        // [0,0,1,2]: lane - 1
+        if (sub >= 1u) incl += t;
+        t = quad_perm<0x44>(incl);                                            // [0,1,0,1]: lane - 2
+        if (sub >= 2u) incl += t;
+        tot = quad_perm<0xFF>(incl);                                          // [3,3,3,3]
+    } else {
+#pragma unroll
+        for (u32 o = 1; o < LPQ; o <<= 1) { u32 t = __shfl_up(incl, o, 64); if (sub >= o) incl += t; }
+        tot = __shfl(incl, (lane & ~(LPQ - 1u)) + (LPQ - 1u), 64);
+    }
+    return incl - mine;
+}
+
 template <u32 LPQ>
 __global__ __launch_bounds__(256)
 void k_rank_lines(const u32* __restrict__ lines, u32 nblocks, u64 total, const u64* __restrict__ q, u64 nq, u64* __restrict__ out)
@@ -507,8 +581,7 @@ void k_rank_lines(const u32* __restrict__ lines, u32 nblocks, u64 total, const u
             if (w + 1u >= 2u) part += word_count_to(v[i].y, w + 1u - 2u, pos);
             part += word_count_to(v[i].z, w, pos) + word_count_to(v[i].w, w + 1u, pos);
         }
-#pragma unroll
-        for (u32 o = 1; o < LPQ; o <<= 1) part += __shfl_xor(part, o, 64);
+        part = group_sum<LPQ>(part);
         const u64 head = ((u64)v[0].y << 32) | v[0].x;                   // valid in the group's lane 0 (sub == 0)
         if (live && sub == 0) out[qi] = in ? head + part : total;        // past the end: the total (src/bm.h:3133)
     }
@@ -520,31 +593,6 @@ void k_rank_lines(const u32* __restrict__ lines, u32 nblocks, u64 total, const u
 // half the random-line rate its 2 lines per query would allow: it is bound by how many queries a CU keeps in flight, so
 // fewer lanes per query (16 / 32 queries per wave step instead of 8) is the lever.  Same arithmetic, regrouped.
 // ---------------------------------------------------------------------------
-template <u32 LPQ>
-__device__ __forceinline__ u32 group_sum(u32 v)
-{
-#pragma unroll
-    for (u32 o = 1; o < LPQ; o <<= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-template <u32 LPQ>
-__device__ __forceinline__ u32 group_max(u32 v)
-{
-#pragma unroll
-    for (u32 o = 1; o < LPQ; o <<= 1) { u32 t = __shfl_xor(v, o, 64); v = t > v ? t : v; }
-    return v;
-}
-// exclusive prefix of `mine` inside the group of LPQ lanes; total in `tot`
-template <u32 LPQ>
-__device__ __forceinline__ u32 group_excl(u32 mine, u32 sub, u32 lane, u32& tot)
-{
-    u32 incl = mine;
-#pragma unroll
-    for (u32 o = 1; o < LPQ; o <<= 1) { u32 t = __shfl_up(incl, o, 64); if (sub >= o) incl += t; }
-    tot = __shfl(incl, (lane & ~(LPQ - 1u)) + (LPQ - 1u), 64);
-    return incl - mine;
-}
-
 template <u32 LPQ>
 __global__ __launch_bounds__(256)
 void k_select_l(const u64* __restrict__ desc, u32 nblocks, const u64* __restrict__ rcount, const u16* __restrict__ cum,
@@ -637,8 +685,7 @@ void k_select_l(const u64* __restrict__ desc, u32 nblocks, const u64* __restrict
                     const u32 pc = (u32)__popc(wd[k]);
                     if (!got) { if (need <= pc) { word = wd[k]; wi = k; got = true; } else need -= pc; }
                 }
-                for (u32 s_ = 1; s_ < need; ++s_) word &= word - 1u;     // word_select (src/bmfunc.h:1084)
-                const u32 bit = (w * 32u + sub * 4u * NV + wi) * 32u + (u32)__builtin_ctz(word);
+                const u32 bit = (w * 32u + sub * 4u * NV + wi) * 32u + select_in_word(word, need);   // word_select (src/bmfunc.h:1084)
                 pos[qi] = ((u64)nb << 16) + bit;
             }
         }
@@ -770,7 +817,7 @@ void k_select_lines(const u32* __restrict__ lines, const u16* __restrict__ dir8,
             for (u32 i = 0; i < NV; ++i) { wd[4 * i] = v[i].x; wd[4 * i + 1] = v[i].y; wd[4 * i + 2] = v[i].z; wd[4 * i + 3] = v[i].w; }
             // the header (count before the line, whole vector) sits in the first two words of the group's lane 0
             u32 hlo = sub == 0 ? wd[0] : 0u, hhi = sub == 0 ? wd[1] : 0u;
-            hlo = __shfl(hlo, lane & ~(LPQ - 1u), 64); hhi = __shfl(hhi, lane & ~(LPQ - 1u), 64);
+            hlo = group_first<LPQ>(hlo, lane); hhi = group_first<LPQ>(hhi, lane);
             const u64 hdr = ((u64)hhi << 32) | hlo;
             if (sub == 0) { wd[0] = 0u; wd[1] = 0u; }
             u32 mine = 0;
@@ -790,9 +837,8 @@ void k_select_lines(const u32* __restrict__ lines, const u16* __restrict__ dir8,
                         const u32 pc = (u32)__popc(wd[t]);
                         if (!got) { if (need <= pc) { word = wd[t]; wi = t; got = true; } else need -= pc; }
                     }
-                    for (u32 s_ = 1; s_ < need; ++s_) word &= word - 1u;
-                    // line word index (sub * 4 NV + wi), data word = that - 2, bit of the line = 32 * data word + ctz
-                    const u32 bit = j * RL_BITS + ((sub * 4u * NV + wi) - 2u) * 32u + (u32)__builtin_ctz(word);
+                    // line word index (sub * 4 NV + wi), data word = that - 2, bit of the line = 32 * data word + bit of the word
+                    const u32 bit = j * RL_BITS + ((sub * 4u * NV + wi) - 2u) * 32u + select_in_word(word, need);
                     pos[qi] = ((u64)nb << 16) + bit;
                 }
                 searching = false;
@@ -866,7 +912,7 @@ void k_select_sdir(const u32* __restrict__ lines, const u32* __restrict__ sdir, 
 #pragma unroll
             for (u32 i = 0; i < NV; ++i) { wd[4 * i] = v[i].x; wd[4 * i + 1] = v[i].y; wd[4 * i + 2] = v[i].z; wd[4 * i + 3] = v[i].w; }
             u32 hlo = sub == 0 ? wd[0] : 0u, hhi = sub == 0 ? wd[1] : 0u;
-            hlo = __shfl(hlo, lane & ~(LPQ - 1u), 64); hhi = __shfl(hhi, lane & ~(LPQ - 1u), 64);
+            hlo = group_first<LPQ>(hlo, lane); hhi = group_first<LPQ>(hhi, lane);
             const u64 hdr = ((u64)hhi << 32) | hlo;                   // ones of the vector before this line
             if (sub == 0) { wd[0] = 0u; wd[1] = 0u; }
             u32 mine = 0;
@@ -885,9 +931,8 @@ void k_select_sdir(const u32* __restrict__ lines, const u32* __restrict__ sdir, 
                         const u32 pc = (u32)__popc(wd[t]);
                         if (!got) { if (need <= pc) { word = wd[t]; wi = t; got = true; } else need -= pc; }
                     }
-                    for (u32 s_ = 1; s_ < need; ++s_) word &= word - 1u;
                     const u32 nb = j / RL_LINES, lj = j - nb * RL_LINES;
-                    const u32 bit = lj * RL_BITS + ((sub * 4u * NV + wi) - 2u) * 32u + (u32)__builtin_ctz(word);
+                    const u32 bit = lj * RL_BITS + ((sub * 4u * NV + wi) - 2u) * 32u + select_in_word(word, need);
                     pos[qi] = ((u64)nb << 16) + bit;
                 }
                 searching = false;
