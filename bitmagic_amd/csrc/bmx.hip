@@ -554,7 +554,7 @@ int bmx_ctx_set_tuning(bmx_ctx* ctx, const char* key, int value)
     else if (k == "op2_wgs") { ARGCHK(value >= 1 && value <= 8); ctx->op2_wgs = value; }
     else if (k == "pair_nt") { ARGCHK(value >= 0 && value <= 1); ctx->pair_nt = value; }
     else if (k == "pair_loop") { ARGCHK(value >= -1 && value <= 5); ctx->pair_loop = value; }
-    else if (k == "eq_big_shape") { ARGCHK(value >= 0 && value <= 1); ctx->eq_big_shape = value; }
+    else if (k == "eq_big_shape") { ARGCHK(value >= 0 && value <= 2); ctx->eq_big_shape = value; }
     else if (k == "eq_big") { ARGCHK(value >= -1 && value <= 1); ctx->eq_big = value; }
     else if (k == "coll_window") { ARGCHK(value >= 0); ctx->coll_window = value; }
     else if (k == "rs_select_lines") { ARGCHK(value >= 0 && value <= 2); ctx->rs_select_lines = value; }
@@ -2397,8 +2397,10 @@ int bmx_slice_eq_counts(bmx_ctx* ctx, const bmx_vec* const* slices, size_t nslic
     // up to 2,048 values: the table with ordinals (2 workgroups per CU); more: the lean {key, count} table shared by 512
     // threads, up to EQB_MAX_VALUES per pass over the planes (eq_big: 0 = never, 1 = always, -1 = by the batch size)
     // (the lean table wants up to 156 KiB of LDS per workgroup: without that much the 2,048-value form takes every batch)
-    const bool big = (ctx->eq_big == 1 || (ctx->eq_big < 0 && uniq.size() > 2048)) && ctx->max_lds_bytes >= EQB_SLOTS(EQB_MAX_VALUES) * 8u + (1u << 15) + 8u * 512u * 4u;
-    const size_t cap = big ? EQB_MAX_VALUES : 2048;
+    // automatic: the lean table with 768 threads for every batch over more than 16 planes; up to 16 planes (dense value
+    // spaces: most rows are looked up) the 2,048-value kernel keeps batches it can take in one pass (2.33 vs 2.86 ms)
+    const bool big = (ctx->eq_big == 1 || (ctx->eq_big < 0 && uniq.size() > ((ctx->eq_big_shape == 2 && nslices > 16) ? 0u : 2048u))) && ctx->max_lds_bytes >= EQB_SLOTS(EQB_MAX_VALUES) * 8u + (1u << 15) + 8u * 512u * 4u;
+    const size_t cap = big ? (ctx->eq_big_shape == 2 ? 8704u : EQB_MAX_VALUES) : 2048;       // (768 threads: 24 KiB of queues)
     const size_t npass = (uniq.size() + cap - 1) / cap;
     const size_t CHUNK = (uniq.size() + npass - 1) / npass;
     for (size_t u0 = 0; u0 < uniq.size() && !rc; u0 += CHUNK) {
@@ -2417,14 +2419,18 @@ int bmx_slice_eq_counts(bmx_ctx* ctx, const bmx_vec* const* slices, size_t nslic
             rc = h2d_staged(ctx, d_tab, keys.data(), (size_t)tab * 4);
             hipError_t e = rc ? hipSuccess : hipMemsetAsync(d_cnt, 0, (size_t)tab * 8, ctx->stream);
             if (!rc && e == hipSuccess) {
-                const bool wide = ctx->eq_big_shape == 1;                      // 32 KiB filter + 512-entry queues | 16 KiB + 1,024
-                size_t lds = (size_t)tab * 8 + (wide ? (1u << 15) + 8u * 512u * 4u : (1u << 14) + 8u * 1024u * 4u);
-                auto eqfn = wide ? (nslices <= 16 ? k_slice_eq_counts_big<16, 18, 512> : k_slice_eq_counts_big<32, 18, 512>)
-                                 : (nslices <= 16 ? k_slice_eq_counts_big<16, 17, 1024> : k_slice_eq_counts_big<32, 17, 1024>);
+                // eq_big_shape: 0 = 512 threads, 16 KiB filter, 1,024-entry queues; 1 = 512 threads, 32 KiB filter, 512-entry queues;
+                // 2 = 768 threads with the registers held to 3 waves per SIMD (8 filter reads in flight instead of 32), 32 KiB + 512
+                const int shp = ctx->eq_big_shape;
+                const u32 wg = shp == 2 ? 768u : 512u, nw = wg / 64u;
+                size_t lds = (size_t)tab * 8 + (shp >= 1 ? (1u << 15) + nw * 512u * 4u : (1u << 14) + nw * 1024u * 4u);
+                auto eqfn = shp == 2 ? (nslices <= 16 ? k_slice_eq_counts_big<16, 18, 512, 768, 3, 8> : k_slice_eq_counts_big<32, 18, 512, 768, 3, 8>)
+                          : shp == 1 ? (nslices <= 16 ? k_slice_eq_counts_big<16, 18, 512> : k_slice_eq_counts_big<32, 18, 512>)
+                                     : (nslices <= 16 ? k_slice_eq_counts_big<16, 17, 1024> : k_slice_eq_counts_big<32, 17, 1024>);
                 e = hipFuncSetAttribute(reinterpret_cast<const void*>(eqfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
                 if (e == hipSuccess) {
-                    u32 grid = std::min<u32>((ncols + 7u) / 8u, 256u);
-                    hipLaunchKernelGGL(eqfn, dim3(grid), dim3(512), lds, ctx->stream, pl, (u32)nslices, ncols, size, (const u32*)d_tab, tab, (u64*)d_cnt);
+                    u32 grid = std::min<u32>((ncols + nw - 1u) / nw, 256u);
+                    hipLaunchKernelGGL(eqfn, dim3(grid), dim3(wg), lds, ctx->stream, pl, (u32)nslices, ncols, size, (const u32*)d_tab, tab, (u64*)d_cnt);
                     e = hipGetLastError();
                 }
                 if (e == hipSuccess) e = hipMemcpyAsync(scount.data(), d_cnt, (size_t)tab * 8, hipMemcpyDeviceToHost, ctx->stream);

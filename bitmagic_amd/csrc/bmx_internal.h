@@ -73,7 +73,7 @@ struct bmx_ctx {
     int pair_loop = -1;        // pairwise counts over mixed block kinds: -1 = persistent kernel (4 workgroups per CU), 0 = a wave per column, N = workgroups per CU
     int op2_nt = 3;            // ... bit 0: non-temporal loads, bit 1: non-temporal stores
     int op2_wgs = 4;           // workgroups per CU of the streaming materialised pairwise kernel (k_op2_stream)
-    int eq_big_shape = 1;      // lean table: 1 = 256 Kbit filter + 512-entry queues, 0 = 128 Kbit + 1,024
+    int eq_big_shape = 2;      // lean table: 2 = 768 threads at 3 waves per SIMD, 8 filter reads in flight, 256 Kbit filter, 512-entry queues -- taken for every batch size over more than 16 planes; 1 = 512 threads, 2 waves per SIMD; 0 = 128 Kbit filter + 1,024-entry queues
     int eq_big = -1;           // batched equality counts: -1 = lean 9,216-value table when the batch has more than 2,048 values, 0 = never, 1 = always
     int coll_window = 0;       // block columns per launch of k_coll_apply (0 = one launch)
     int rs_lines = 1;          // build_rs_index also lays the vector out as rank lines (one 128-B line per rank query; +108 % memory next to the vector): 0 = off

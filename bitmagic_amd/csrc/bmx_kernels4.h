@@ -454,8 +454,10 @@ void k_slice_eq_counts(EqPlanes pl, u32 nplanes, u32 ncols, u64 size, const u32*
 
 // FBITS = log2 of the filter bits (17: 16 KiB, 18: 32 KiB), QSZ = queue entries per wave (flushed when more than half full;
 // checked every QSZ / 128 rows of a step, which add at most QSZ / 2 survivors)
-template <int NP, int FBITS, int QSZ>
-__global__ __launch_bounds__(512)
+// WG = threads per workgroup (all waves share the table), WPE = waves per SIMD the registers are held to, FG = filter reads
+// in flight per lane (32: all rows of a step at once, 243 VGPRs = 2 waves per SIMD; 8: 168 VGPRs = 3 waves per SIMD)
+template <int NP, int FBITS, int QSZ, int WG = 512, int WPE = 2, int FG = 32>
+__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(WPE)))
 void k_slice_eq_counts_big(EqPlanes pl, u32 nplanes, u32 ncols, u64 size, const u32* __restrict__ g_keys, u32 tab, u64* __restrict__ counts /* per slot */)
 {
     extern __shared__ u32 lds_dyn[];
@@ -475,7 +477,8 @@ void k_slice_eq_counts_big(EqPlanes pl, u32 nplanes, u32 ncols, u64 size, const 
     __syncthreads();
     const u32 lane = lane_id(), wave = threadIdx.x >> 6;
     u32* myq = queue + wave * (u32)QSZ;
-    for (u32 c = uniform32(blockIdx.x * 8u + wave); c < ncols; c += gridDim.x * 8u) {
+    constexpr u32 NW = (u32)WG / 64u;
+    for (u32 c = uniform32(blockIdx.x * NW + wave); c < ncols; c += gridDim.x * NW) {
         u64 base[32];
 #pragma unroll
         for (int p = 0; p < 32; ++p) {
@@ -506,9 +509,6 @@ void k_slice_eq_counts_big(EqPlanes pl, u32 nplanes, u32 ncols, u64 size, const 
             const u32 vm = lim >= wb + 32u ? ~0u : (lim <= wb ? 0u : ((1u << (lim - wb)) - 1u));
             if (__ballot((any & vm) != 0u) == 0ull) continue;
             bit_transpose32(a);
-            u32 f[32];
-#pragma unroll
-            for (int r = 0; r < 32; ++r) { u32 hb = (a[r] * 0x85EBCA6Bu) >> (32 - FBITS); f[r] = filt[hb >> 5] >> (hb & 31u); }
             u32 nq = 0;
             auto flush = [&]() {
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -525,15 +525,22 @@ void k_slice_eq_counts_big(EqPlanes pl, u32 nplanes, u32 ncols, u64 size, const 
                 nq = 0;
             };
 #pragma unroll
-            for (int r = 0; r < 32; ++r) {
-                bool hit = (f[r] & 1u) && a[r] != 0u && ((vm >> r) & 1u);
-                u64 m = __ballot(hit);
-                if (m) {
-                    u32 pos = nq + __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
-                    if (hit) myq[pos] = a[r];
-                    nq += (u32)__popcll(m);
+            for (int r0 = 0; r0 < 32; r0 += FG) {
+                u32 f[FG];
+#pragma unroll
+                for (int r = 0; r < FG; ++r) { u32 hb = (a[r0 + r] * 0x85EBCA6Bu) >> (32 - FBITS); f[r] = filt[hb >> 5] >> (hb & 31u); }
+#pragma unroll
+                for (int rr = 0; rr < FG; ++rr) {
+                    const int r = r0 + rr;
+                    bool hit = (f[rr] & 1u) && a[r] != 0u && ((vm >> r) & 1u);
+                    u64 m = __ballot(hit);
+                    if (m) {
+                        u32 pos = nq + __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
+                        if (hit) myq[pos] = a[r];
+                        nq += (u32)__popcll(m);
+                    }
+                    if ((r & (QSZ / 128 - 1)) == QSZ / 128 - 1 && r != 31 && nq > (u32)QSZ / 2u) flush();
                 }
-                if ((r & (QSZ / 128 - 1)) == QSZ / 128 - 1 && r != 31 && nq > (u32)QSZ / 2u) flush();
             }
             if (nq) flush();
         }

@@ -1055,12 +1055,12 @@ def test_batched_equality_counts_by_transposition(ctx, case):
     more = many + [int(x) for x in rng.integers(1, 1 << min(nplanes, 31), size=14000)]
     exp_small = [lut.get(v, 0) if v else int((col == 0).sum()) for v in vals]
     try:
-        for eb, shape in ((0, 1), (1, 0), (1, 1), (-1, 1)):
+        for eb, shape in ((0, 1), (1, 0), (1, 1), (1, 2), (-1, 1), (-1, 2)):
             ctx.set_tuning("eq_big", eb); ctx.set_tuning("eq_big_shape", shape)
             assert sc.find_eq_counts(vals).tolist() == exp_small, (eb, shape)
             assert sc.find_eq_counts(more).tolist() == [lut.get(v, 0) for v in more], (eb, shape)
     finally:
-        ctx.set_tuning("eq_big", -1); ctx.set_tuning("eq_big_shape", 1)
+        ctx.set_tuning("eq_big", -1); ctx.set_tuning("eq_big_shape", 2)
 
 
 def test_packed_collection_kernel_shapes(port):

@@ -49,7 +49,7 @@ for staged, swz, slots in ((0, 1, 16), (1, 1, 16), (1, 1, 8)):
 import time
 sc = bm.slice_scanner(ctx, planes, size=a.nbits)
 if a.planes <= 32:
-    for nq, eq_big, shape in ((a.groups, -1, 1), (2048, 0, 1), (2048, 1, 1), (4096, -1, 1), (8192, 0, 1), (8192, -1, 0), (8192, -1, 1), (16384, -1, 1)):
+    for nq, eq_big, shape in ((a.groups, 0, 1), (a.groups, -1, 2), (2048, 0, 1), (2048, 1, 1), (2048, 1, 2), (4096, -1, 1), (4096, -1, 2), (8192, 0, 1), (8192, -1, 0), (8192, -1, 1), (8192, -1, 2), (16384, -1, 1), (16384, -1, 2)):
         ctx.set_tuning("eq_big", eq_big); ctx.set_tuning("eq_big_shape", shape)
         q = xs[:nq] if nq <= len(xs) else xs + [int(v) for v in rng.integers(1, 1 << a.planes, size=nq - len(xs))]
         got = sc.find_eq_counts(q)
@@ -59,24 +59,28 @@ if a.planes <= 32:
             t0 = time.perf_counter(); got = sc.find_eq_counts(q); ts.append((time.perf_counter() - t0) * 1e3)
         ok = bool((np.asarray(got[:len(xs)], np.int64) == ref_counts.cpu().numpy()[:min(nq, len(xs))]).all()) if all(x > 0 for x in xs) else None
         nu = len(set(q))
-        big = eq_big == 1 or (eq_big < 0 and nu > 2048)
-        passes = -(-nu // (9216 if big else 2048))
+        big = eq_big == 1 or (eq_big < 0 and (nu > 2048 or shape == 2))
+        passes = -(-nu // ((8704 if shape == 2 else 9216) if big else 2048))
         print(json.dumps({"pattern": "scanner_transposed", "planes": a.planes, "queries": nq, "unique": nu, "nbits": a.nbits,
-                          "table": ("k_slice_eq_counts_big<%s>" % ("18,512" if shape else "17,1024")) if big else "k_slice_eq_counts", "passes_over_the_planes": passes,
+                          "table": ("k_slice_eq_counts_big<%s>" % ("18,512,768 threads,3 waves" if shape == 2 else "18,512" if shape else "17,1024")) if big else "k_slice_eq_counts", "passes_over_the_planes": passes,
                           "host_call_ms": round(min(ts), 3), "queries_per_s": round(nq / min(ts) * 1e3, 1), "plane_GB": round(a.planes * a.nbits / 8e9, 2),
                           "plane_TBps": round(a.planes * a.nbits / 8 / min(ts) / 1e9 * passes, 2), "counts_equal_pipeline": ok}))
-    ctx.set_tuning("eq_big", -1)
+    ctx.set_tuning("eq_big", -1); ctx.set_tuning("eq_big_shape", 2)
 
 # a 12-plane container (values < 4096, every row non-zero): the 16-plane instantiation
 if a.planes >= 12:
     sc12 = bm.slice_scanner(ctx, planes[:12], size=a.nbits)
     q = [int(v) for v in rng.integers(1, 1 << 12, size=2048)]
-    got = sc12.find_eq_counts(q); ctx.synchronize()
-    ts = []
-    for _ in range(3):
-        t0 = time.perf_counter(); got = sc12.find_eq_counts(q); ts.append((time.perf_counter() - t0) * 1e3)
-    print(json.dumps({"pattern": "scanner_transposed", "planes": 12, "queries": 2048, "nbits": a.nbits, "host_call_ms": round(min(ts), 3),
-                      "sum_counts": int(np.asarray(got, np.int64).sum())}))
+    for eq_big, shape in ((-1, 2), (1, 2)):
+        ctx.set_tuning("eq_big", eq_big); ctx.set_tuning("eq_big_shape", shape)
+        got = sc12.find_eq_counts(q); ctx.synchronize()
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter(); got = sc12.find_eq_counts(q); ts.append((time.perf_counter() - t0) * 1e3)
+        print(json.dumps({"pattern": "scanner_transposed", "planes": 12, "queries": 2048, "nbits": a.nbits,
+                          "table": "k_slice_eq_counts<16>" if eq_big <= 0 else "k_slice_eq_counts_big<16,18,512,768 threads,3 waves>",
+                          "host_call_ms": round(min(ts), 3), "sum_counts": int(np.asarray(got, np.int64).sum())}))
+    ctx.set_tuning("eq_big", -1); ctx.set_tuning("eq_big_shape", 2)
 
 # ---- range search (find_gt / find_le / find_range / find_zero): one pass over the planes (bmx_slice_compare) ----
 plane_bytes = a.planes * ((a.nbits + 65535) // 65536) * 8192
