@@ -1032,7 +1032,13 @@ def run_or_sharded(args, env, quick=False):
     res = None
     if rank == 0:
         ms = dt / steps * 1e3
-        achieved = gap_bytes / (ev_ms / steps) / 1e6
+        # bytes one launch has to move: the operands' run lists + the stored result.  With a packed collection the run lists
+        # are what the collection holds (split bags keep an isolated bit in 2 B where the reference's GAP block spends 4 B),
+        # so the roofline is taken on THOSE bytes; the reference-format figure is reported next to it
+        result_bytes = last[0].calc_stat()["bit_blocks"] * 8192
+        needed = (pack["bytes"] if pack["collections"] else gap_bytes) + result_bytes
+        achieved = needed / (ev_ms / steps) / 1e6
+        ref_fmt = gap_bytes / (ev_ms / steps) / 1e6
         traffic, tsrc, _ = traffic_file("traffic_config4.json") if (world == 1 and nvec == 4096) else (None, None, None)
         res = {"metric": "Gbit/s of logical operand bits, aggregator combine_or over 4096 x 4e9-bit sparse vectors",
                "value": round(nvec * nbits * steps / dt / 1e9, 1), "unit": "Gbit/s", "n_gpus": world, "steps": steps,
@@ -1050,8 +1056,12 @@ def run_or_sharded(args, env, quick=False):
                             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": tsrc,
                             "kernel": ("k_coll_apply<OR,512>: one workgroup per block column over the packed collection of the operand set"
                                        if pack["collections"] else "k_agg_or_gap_tiled<1,1> (descriptor-table kernel: no packed collection in use)"),
-                            "algorithmic_bytes_per_launch": gap_bytes, "avg_launch_ms": round(ev_ms / steps, 4),
-                            "note": "host call incl. result creation, layout scan and count; algorithmic bytes = 2 x (len + 1) per GAP operand"}}
+                            "algorithmic_bytes_per_launch": needed, "avg_launch_ms": round(ev_ms / steps, 4),
+                            "reference_format_bytes_per_launch": gap_bytes, "reference_format_GBps": round(ref_fmt, 1),
+                            "note": "host call incl. result creation and count.  algorithmic bytes = the run lists as this path keeps them "
+                                    "(the packed collection: 4 B per multi-bit run, 2 B per single-bit run) + 8,192 B per stored result block; "
+                                    "reference_format_* = the same time against 2 x (len + 1) B per GAP operand (SURVEY section 8(d)), which the "
+                                    "collection undercuts for sparse operands"}}
         if not args.no_cpu and world == 1:
             try:
                 P, orc, kind = _pick_oracle()

@@ -106,7 +106,7 @@ static int ensure(bmx_ctx* ctx, void** buf, size_t* cur, size_t need)
 static void coll_free(bmx_ctx* ctx, size_t idx)
 {
     bmx_coll* c = ctx->colls[idx];
-    dfree(ctx, c->d_runs); dfree(ctx, c->d_off); dfree(ctx, c->d_cnt); dfree(ctx, c->d_flags);
+    dfree(ctx, c->d_runs); dfree(ctx, c->d_off); dfree(ctx, c->d_cnt); dfree(ctx, c->d_flags); dfree(ctx, c->d_cnt_s);
     ctx->pack_bytes -= std::min<uint64_t>(ctx->pack_bytes, c->bytes);
     ctx->colls.erase(ctx->colls.begin() + (long)idx);
     delete c;
@@ -164,17 +164,18 @@ static int coll_build(bmx_ctx* ctx, const bmx_vec* const* v, size_t n, int polar
     bmx_coll* c = new (std::nothrow) bmx_coll();
     if (!c) return BMX_ERR_BADALLOC;
     c->hash = h; c->polarity = polarity; c->ncols = ncols; c->nvec = (uint32_t)n;
-    c->d_runs = nullptr; c->d_off = nullptr; c->d_cnt = nullptr; c->d_flags = nullptr;
+    c->d_runs = nullptr; c->d_off = nullptr; c->d_cnt = nullptr; c->d_flags = nullptr; c->d_cnt_s = nullptr;
     c->entries = 0; c->bytes = 0; c->has_bit = false; c->build_ms = 0.f; c->alg_bytes = alg;
     c->key.resize(n);
     for (size_t i = 0; i < n; ++i) c->key[i] = v[i]->uid;
     c->sorted = c->key; std::sort(c->sorted.begin(), c->sorted.end());
-    void* d_descs = nullptr; void* d_nblk = nullptr; u32* d_pre = nullptr;
+    void* d_descs = nullptr; void* d_nblk = nullptr; u32* d_pre = nullptr; u32* d_sgl = nullptr; u32* d_words = nullptr;
+    const bool split = polarity == 1 && ctx->coll_split != 0;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     auto fail = [&](int code) {
         (void)hipStreamSynchronize(ctx->stream);
-        dfree(ctx, d_descs); dfree(ctx, d_nblk); dfree(ctx, d_pre);
-        dfree(ctx, c->d_runs); dfree(ctx, c->d_off); dfree(ctx, c->d_cnt); dfree(ctx, c->d_flags);
+        dfree(ctx, d_descs); dfree(ctx, d_nblk); dfree(ctx, d_pre); dfree(ctx, d_sgl); dfree(ctx, d_words);
+        dfree(ctx, c->d_runs); dfree(ctx, c->d_off); dfree(ctx, c->d_cnt); dfree(ctx, c->d_flags); dfree(ctx, c->d_cnt_s);
         if (e0) (void)hipEventDestroy(e0);
         if (e1) (void)hipEventDestroy(e1);
         delete c;
@@ -184,6 +185,12 @@ static int coll_build(bmx_ctx* ctx, const bmx_vec* const* v, size_t n, int polar
         (rc = dmalloc(ctx, (void**)&d_pre, (size_t)n * ncols * 4)) ||
         (rc = dmalloc(ctx, (void**)&c->d_off, ((size_t)ncols + 1) * 8)) || (rc = dmalloc(ctx, (void**)&c->d_cnt, (size_t)ncols * 4)) ||
         (rc = dmalloc(ctx, (void**)&c->d_flags, (size_t)ncols * 4))) return fail(rc);
+    if (split && ((rc = dmalloc(ctx, (void**)&d_sgl, (size_t)n * ncols * 4)) || (rc = dmalloc(ctx, (void**)&d_words, (size_t)ncols * 4)) ||
+                  (rc = dmalloc(ctx, (void**)&c->d_cnt_s, (size_t)ncols * 4)))) return fail(rc);
+    // lanes per block in the passes that walk run lists: by the average block length
+    uint64_t nblocks_gap = 0, gap_words_all = 0;
+    for (size_t i = 0; i < n; ++i) { nblocks_gap += v[i]->counts[BMX_GAP]; gap_words_all += v[i]->gap_words; }
+    const bool short_blocks = nblocks_gap && gap_words_all / nblocks_gap <= 56;          // (<= ~24 runs of one polarity per block)
     hipError_t e = hipEventCreate(&e0);
     if (e == hipSuccess) e = hipEventCreate(&e1);
     if (e == hipSuccess) e = hipEventRecord(e0, ctx->stream);
@@ -192,6 +199,16 @@ static int coll_build(bmx_ctx* ctx, const bmx_vec* const* v, size_t n, int polar
     if (e != hipSuccess) return fail(fail_hip(e, "coll_build", __LINE__));
     hipLaunchKernelGGL(k_coll_count, dim3((ncols + 255) / 256), dim3(256), 0, ctx->stream, (const u64* const*)d_descs,
                        (const u32*)d_nblk, (u32)n, ncols, (u32)polarity, d_pre, c->d_cnt, c->d_flags);
+    if (split) {
+        // single-bit runs per (operand, column) -> their prefix per column -> the column's size in 32-bit words
+        if (short_blocks) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_coll_count_singles<8>), dim3((u32)n, (ncols + 31) / 32), dim3(256), 0, ctx->stream,
+                                             (const u64* const*)d_descs, (const u32*)d_nblk, ncols, d_sgl);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_coll_count_singles<64>), dim3((u32)n, (ncols + 3) / 4), dim3(256), 0, ctx->stream,
+                                (const u64* const*)d_descs, (const u32*)d_nblk, ncols, d_sgl);
+        hipLaunchKernelGGL(k_coll_prefix_singles, dim3((ncols + 255) / 256), dim3(256), 0, ctx->stream, d_sgl, (u32)n, ncols,
+                           (const u32*)c->d_cnt, c->d_cnt_s, d_words);
+        hipLaunchKernelGGL(k_coll_offsets, dim3(1), dim3(1024), 0, ctx->stream, (const u32*)d_words, ncols, c->d_off);
+    } else
     hipLaunchKernelGGL(k_coll_offsets, dim3(1), dim3(1024), 0, ctx->stream, (const u32*)c->d_cnt, ncols, c->d_off);
     e = hipGetLastError();
     u64 total = 0;
@@ -200,12 +217,16 @@ static int coll_build(bmx_ctx* ctx, const bmx_vec* const* v, size_t n, int polar
     if (e != hipSuccess) return fail(fail_hip(e, "coll_build (count)", __LINE__));
     c->entries = total;
     if ((rc = dmalloc(ctx, (void**)&c->d_runs, std::max<size_t>((size_t)total * 4, 64)))) return fail(rc);
-    // lanes per block by the average number of entries of a block
-    uint64_t nblocks_gap = 0;
-    for (size_t i = 0; i < n; ++i) nblocks_gap += v[i]->counts[BMX_GAP];
-    uint64_t avg = nblocks_gap ? total / nblocks_gap : 0;
-    if (total) {
-        if (avg <= 24) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_coll_scatter<8>), dim3((u32)n, (ncols + 31) / 32), dim3(256), 0, ctx->stream,
+    if (total && split) {
+        if (short_blocks) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_coll_scatter_split<8>), dim3((u32)n, (ncols + 31) / 32), dim3(256), 0, ctx->stream,
+                                             (const u64* const*)d_descs, (const u32*)d_nblk, ncols, (const u32*)d_pre, (const u32*)d_sgl,
+                                             (const u32*)c->d_cnt, (const u32*)c->d_cnt_s, (const u64*)c->d_off, c->d_runs);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_coll_scatter_split<64>), dim3((u32)n, (ncols + 3) / 4), dim3(256), 0, ctx->stream,
+                                (const u64* const*)d_descs, (const u32*)d_nblk, ncols, (const u32*)d_pre, (const u32*)d_sgl,
+                                (const u32*)c->d_cnt, (const u32*)c->d_cnt_s, (const u64*)c->d_off, c->d_runs);
+        e = hipGetLastError();
+    } else if (total) {
+        if (short_blocks) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_coll_scatter<8>), dim3((u32)n, (ncols + 31) / 32), dim3(256), 0, ctx->stream,
                                           (const u64* const*)d_descs, (const u32*)d_nblk, ncols, (u32)polarity, (const u32*)d_pre, (const u64*)c->d_off, c->d_runs);
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_coll_scatter<64>), dim3((u32)n, (ncols + 3) / 4), dim3(256), 0, ctx->stream,
                                 (const u64* const*)d_descs, (const u32*)d_nblk, ncols, (u32)polarity, (const u32*)d_pre, (const u64*)c->d_off, c->d_runs);
@@ -216,8 +237,8 @@ static int coll_build(bmx_ctx* ctx, const bmx_vec* const* v, size_t n, int polar
     if (e == hipSuccess) e = hipEventElapsedTime(&c->build_ms, e0, e1);
     if (e != hipSuccess) return fail(fail_hip(e, "coll_build (scatter)", __LINE__));
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    dfree(ctx, d_descs); dfree(ctx, d_nblk); dfree(ctx, d_pre);
-    c->bytes = (uint64_t)total * 4 + (uint64_t)ncols * 16 + 8;
+    dfree(ctx, d_descs); dfree(ctx, d_nblk); dfree(ctx, d_pre); dfree(ctx, d_sgl); dfree(ctx, d_words);
+    c->bytes = (uint64_t)total * 4 + (uint64_t)ncols * (split ? 20 : 16) + 8;
     c->last_use = ++ctx->coll_tick;
     ctx->last_pack_ms = c->build_ms;
     // make room: least recently used collections go first
@@ -273,7 +294,8 @@ static int coll_launch(int mode, bmx_ctx* ctx, const bmx_coll* a, const bmx_coll
 #define COLL_ARGS_WG(W) dim3(grid), dim3(W), 0, ctx->stream, (const u32*)a->d_runs, (const u64*)a->d_off, (const u32*)a->d_cnt, \
         (const u32*)a->d_flags, a->ncols, (const u32*)(s ? s->d_runs : nullptr), (const u64*)(s ? s->d_off : nullptr), \
         (const u32*)(s ? s->d_cnt : nullptr), (const u32*)(s ? s->d_flags : nullptr), s ? s->ncols : 0u, cbase, col_to, opt_compress | coll_diag_bits(), \
-        d_counts, v ? v->d_bits : (uint4*)nullptr, v ? v->d_desc : (u64*)nullptr, st, hint_from, hint_to, kinds
+        d_counts, v ? v->d_bits : (uint4*)nullptr, v ? v->d_desc : (u64*)nullptr, st, hint_from, hint_to, kinds, \
+        (const u32*)a->d_cnt_s, (const u32*)(s ? s->d_cnt_s : nullptr)
     // coll_shape (tuning): 0 = 256 threads, 1 = 256 threads + prefetch, 2 = 512 threads, 3 = 512 threads + prefetch
 #define COLL_LAUNCH(M) do { \
         switch (ctx->coll_shape) { \
@@ -494,7 +516,7 @@ int bmx_ctx_create(int device, void* stream, bmx_ctx** out)
     // an invalid value is ignored (the default stays)
     static const char* const env_keys[][2] = {
         {"BMX_PIPE_UNROLL", "pipe_unroll"}, {"BMX_PIPE_ROWS", "pipe_rows"}, {"BMX_PIPE_NT", "pipe_nt"},
-        {"BMX_PIPE_WG", "pipe_wg"}, {"BMX_PIPE_WINDOW", "pipe_window"}, {"BMX_PIPE_SPLIT", "pipe_split"}, {"BMX_OR_TILE", "or_tile"}, {"BMX_OR_WINDOW", "or_window"}, {"BMX_DIRECT_COLS", "direct_cols"}, {"BMX_FF_WINDOW", "ff_window"}, {"BMX_GAP_COUNT", "gap_count"}, {"BMX_RANGE_HALVES", "range_halves"}, {"BMX_PAIR_STREAM", "pair_stream"}, {"BMX_PAIR_WGS", "pair_wgs"}, {"BMX_RS_LANES", "rs_lanes"}, {"BMX_RS_LINES", "rs_lines"}, {"BMX_RS_SELECT_LINES", "rs_select_lines"}, {"BMX_RS_SDIR_SHIFT", "rs_sdir_shift"}, {"BMX_COLL_SHAPE", "coll_shape"}, {"BMX_COLL_WINDOW", "coll_window"}, {"BMX_EQ_BIG", "eq_big"}, {"BMX_PAIR_LOOP", "pair_loop"}, {"BMX_PAIR_NT", "pair_nt"}, {"BMX_EQ_BIG_SHAPE", "eq_big_shape"}, {"BMX_OP2_WGS", "op2_wgs"}, {"BMX_OP2_NT", "op2_nt"}, {"BMX_GAP_PACK", "gap_pack"}, {"BMX_XCD_SWIZZLE", "xcd_swizzle"}};
+        {"BMX_PIPE_WG", "pipe_wg"}, {"BMX_PIPE_WINDOW", "pipe_window"}, {"BMX_PIPE_SPLIT", "pipe_split"}, {"BMX_OR_TILE", "or_tile"}, {"BMX_OR_WINDOW", "or_window"}, {"BMX_DIRECT_COLS", "direct_cols"}, {"BMX_FF_WINDOW", "ff_window"}, {"BMX_GAP_COUNT", "gap_count"}, {"BMX_RANGE_HALVES", "range_halves"}, {"BMX_PAIR_STREAM", "pair_stream"}, {"BMX_PAIR_WGS", "pair_wgs"}, {"BMX_RS_LANES", "rs_lanes"}, {"BMX_RS_LINES", "rs_lines"}, {"BMX_RS_SELECT_LINES", "rs_select_lines"}, {"BMX_RS_SDIR_SHIFT", "rs_sdir_shift"}, {"BMX_COLL_SHAPE", "coll_shape"}, {"BMX_COLL_WINDOW", "coll_window"}, {"BMX_COLL_SPLIT", "coll_split"}, {"BMX_EQ_BIG", "eq_big"}, {"BMX_PAIR_LOOP", "pair_loop"}, {"BMX_PAIR_NT", "pair_nt"}, {"BMX_EQ_BIG_SHAPE", "eq_big_shape"}, {"BMX_OP2_WGS", "op2_wgs"}, {"BMX_OP2_NT", "op2_nt"}, {"BMX_GAP_PACK", "gap_pack"}, {"BMX_XCD_SWIZZLE", "xcd_swizzle"}};
     for (auto& kv : env_keys)
         if (const char* e = getenv(kv[0])) (void)bmx_ctx_set_tuning(ctx, kv[1], atoi(e));
     g_last_error.clear();
@@ -556,6 +578,7 @@ int bmx_ctx_set_tuning(bmx_ctx* ctx, const char* key, int value)
     else if (k == "pair_loop") { ARGCHK(value >= -1 && value <= 5); ctx->pair_loop = value; }
     else if (k == "eq_big_shape") { ARGCHK(value >= 0 && value <= 2); ctx->eq_big_shape = value; }
     else if (k == "eq_big") { ARGCHK(value >= -1 && value <= 1); ctx->eq_big = value; }
+    else if (k == "coll_split") { ARGCHK(value == 0 || value == 1); ctx->coll_split = value; }
     else if (k == "coll_window") { ARGCHK(value >= 0); ctx->coll_window = value; }
     else if (k == "rs_select_lines") { ARGCHK(value >= 0 && value <= 2); ctx->rs_select_lines = value; }
     else if (k == "rs_sdir_shift") { ARGCHK(value == 0 || (value >= 6 && value <= 20)); ctx->rs_sdir_shift = value; }

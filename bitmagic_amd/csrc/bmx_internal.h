@@ -68,6 +68,7 @@ struct bmx_ctx {
     uint64_t pack_cap = 96ull << 30, pack_bytes = 0, coll_tick = 0;
     float last_pack_ms = 0.f;
     uint32_t max_lds_bytes = 160u * 1024u;   // hipDeviceAttributeMaxSharedMemoryPerBlock of the device (queried at creation)
+    int coll_split = 1;        // polarity-1 collections keep single-bit runs as 16-bit positions (half the bytes per isolated bit)
     int coll_shape = 4;        // k_coll_apply shape: 0 = 256 threads, 1 = 256 + prefetch, 2 = 512 (configs[4] 2.50 vs 2.61 ms, the AND cases equal), 3 = 512 + prefetch, 4 = 512 with a wave's batch as ONE 4-KiB piece (default: -2.8 % / -1.7 %, profiles/r03ag), 5 = 4 + prefetch
     int pair_nt = 1;           // ... with non-temporal loads
     int pair_loop = -1;        // pairwise counts over mixed block kinds: -1 = persistent kernel (4 workgroups per CU), 0 = a wave per column, N = workgroups per CU
@@ -119,6 +120,7 @@ struct bmx_coll {
     u64 hash; int polarity;
     uint32_t ncols, nvec;
     u32* d_runs; u64* d_off; u32* d_cnt; u32* d_flags;
+    u32* d_cnt_s;                         // split bag (polarity 1): single-bit runs per column, kept as 16-bit positions behind the multi-bit runs; else null
     uint64_t entries, bytes, last_use;
     uint64_t alg_bytes;                   // algorithmic bytes of the GAP operands: sum of 2 x (len + 1)
     bool has_bit;                         // a bit-block was found while counting: unusable

@@ -120,6 +120,102 @@ void k_coll_scatter(const u64* const* __restrict__ descs, const u32* __restrict_
     }
 }
 
+// ---- split bags (round 3): single-bit runs as 16-bit positions ----
+// A bag of 1-runs of SPARSE operands is almost all single bits, and a single bit does not need a start and an end: the
+// polarity-1 collection keeps, per column, the runs longer than one bit as before (32-bit start | end << 16, padded to 4)
+// and behind them the single-bit runs as 16-bit positions (padded to 8): half the bytes per run of the reference's own GAP
+// encoding (two 16-bit run ends per isolated bit).  The bag is a set, so nothing else changes: same union, same result.
+//   cnt[c]   = 1-runs of the column (as before), cnt_s[c] = the single-bit ones among them
+//   off[c]   = first 32-bit word of the column; multis at [off, off + round4(cnt - cnt_s)), singles behind them
+
+// count pass: L lanes per (operand, column) count the single-bit 1-runs of the block -> sgl[i][c] (raw count)
+template <int L>
+__global__ __launch_bounds__(256)
+void k_coll_count_singles(const u64* const* __restrict__ descs, const u32* __restrict__ nblk, u32 ncols, u32* __restrict__ sgl)
+{
+    const u32 i = blockIdx.x;
+    const u32 t = threadIdx.x % L;
+    const u32 c = blockIdx.y * (256u / L) + threadIdx.x / L;
+    const bool in = c < ncols && c < nblk[i];
+    u64 d = in ? descs[i][c] : 0ull;
+    u32 ns = 0;
+    if (DESC_K(d) == K_GAP) {
+        const u32 meta = GMETA(d), len = meta >> 1, s = meta & 1u;
+        const u32 m_cnt = coll_runs_of(meta, 1u);
+        gcptr16 g = as_gc16(DESC_P(d));
+        const u32 k0 = s ? 1u : 2u;
+        for (u32 m = t; m < m_cnt; m += L) {
+            const u32 k = k0 + 2u * m;
+            const u32 start = k == 1u ? 0u : (u32)g[k - 1u] + 1u, end = (u32)g[k <= len ? k : len];
+            ns += start == end ? 1u : 0u;
+        }
+    }
+#pragma unroll
+    for (u32 o = 1; o < (u32)L; o <<= 1) ns += __shfl_xor(ns, o, 64);
+    if (in && t == 0) sgl[(size_t)i * ncols + c] = ns;
+    else if (!in && t == 0 && c < ncols) sgl[(size_t)i * ncols + c] = 0u;
+}
+
+// per column: exclusive prefix of the singles over the operand list (in place), cnt_s[c], and the column's size in 32-bit words
+__global__ __launch_bounds__(256)
+void k_coll_prefix_singles(u32* __restrict__ sgl, u32 n, u32 ncols, const u32* __restrict__ cnt, u32* __restrict__ cnt_s, u32* __restrict__ words)
+{
+    const u32 c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ncols) return;
+    u32 run = 0;
+    for (u32 i = 0; i < n; ++i) { const u32 t = sgl[(size_t)i * ncols + c]; sgl[(size_t)i * ncols + c] = run; run += t; }
+    cnt_s[c] = run;
+    const u32 nm = cnt[c] - run;
+    words[c] = ((nm + 3u) & ~3u) + (((run + 7u) & ~7u) >> 1);
+}
+
+// scatter pass: L lanes per (operand, column); lane t takes a contiguous share of the block's 1-runs, counts its singles,
+// the group agrees on the write positions (exclusive prefix over the L lanes), then every lane writes its runs
+template <int L>
+__global__ __launch_bounds__(256)
+void k_coll_scatter_split(const u64* const* __restrict__ descs, const u32* __restrict__ nblk, u32 ncols,
+                          const u32* __restrict__ pre /* 1-runs before operand i */, const u32* __restrict__ pre_s /* singles before operand i */,
+                          const u32* __restrict__ cnt, const u32* __restrict__ cnt_s, const u64* __restrict__ off, u32* __restrict__ runs)
+{
+    const u32 i = blockIdx.x;
+    const u32 t = threadIdx.x % L;
+    const u32 c = blockIdx.y * (256u / L) + threadIdx.x / L;
+    const bool in = c < ncols && c < nblk[i];
+    u64 d = in ? descs[i][c] : 0ull;
+    const bool gap = DESC_K(d) == K_GAP;
+    const u32 meta = GMETA(d), len = meta >> 1, s = meta & 1u;
+    const u32 m_cnt = gap ? coll_runs_of(meta, 1u) : 0u;
+    gcptr16 g = as_gc16(gap ? DESC_P(d) : 0ull);
+    const u32 k0 = s ? 1u : 2u;
+    const u32 per = (m_cnt + (u32)L - 1u) / (u32)L;
+    const u32 m0 = t * per < m_cnt ? t * per : m_cnt, m1 = m0 + per < m_cnt ? m0 + per : m_cnt;
+    u32 ns = 0;
+    for (u32 m = m0; m < m1; ++m) {
+        const u32 k = k0 + 2u * m;
+        const u32 start = k == 1u ? 0u : (u32)g[k - 1u] + 1u, end = (u32)g[k <= len ? k : len];
+        ns += start == end ? 1u : 0u;
+    }
+    const u32 nmul = (m1 - m0) - ns;
+    // exclusive prefixes inside the group of L lanes (all lanes of the wave take part: the shuffles are unconditional)
+    u32 is = ns, im = nmul;
+#pragma unroll
+    for (u32 o = 1; o < (u32)L; o <<= 1) {
+        const u32 a = __shfl_up(is, o, 64), b = __shfl_up(im, o, 64);
+        if (t >= o) { is += a; im += b; }
+    }
+    if (!gap || m0 == m1) return;
+    const u64 base = off[c];
+    const u32 ps = pre_s[(size_t)i * ncols + c], pt = pre[(size_t)i * ncols + c];
+    const u32 nm_col = cnt[c] - cnt_s[c];
+    u32* om = runs + base + (pt - ps) + (im - nmul);
+    u16* os = reinterpret_cast<u16*>(runs + base + ((nm_col + 3u) & ~3u)) + ps + (is - ns);
+    for (u32 m = m0; m < m1; ++m) {
+        const u32 k = k0 + 2u * m;
+        const u32 start = k == 1u ? 0u : (u32)g[k - 1u] + 1u, end = (u32)g[k <= len ? k : len];
+        if (start == end) *os++ = (u16)start; else *om++ = start | (end << 16);
+    }
+}
+
 // ---- applying a bag ----
 __device__ __forceinline__ void coll_apply_run(u32 r, bool valid, u32* U, int* D, u32& any_long)
 {
@@ -190,6 +286,37 @@ __device__ __forceinline__ u32 coll_apply_bag(const u32* __restrict__ runs, u64 
     return any_long;
 }
 
+// the single-bit runs of a split bag: ns 16-bit positions behind the multi-bit runs; 16 bytes = 8 positions per lane and load,
+// the same batch shape as coll_apply_bag
+template <int WG, bool CW>
+__device__ __forceinline__ void coll_apply_singles(const u32* __restrict__ words, u64 off_words, u32 ns, u32* U, u32 tid)
+{
+    gcptr4 p = as_gc4(words + off_words);
+    const u32 nq = (ns + 7u) >> 3;
+    if (!nq) return;
+    constexpr u32 JS = CW ? 64u : (u32)WG;
+    const u32 first = CW ? (tid >> 6) * 256u + (tid & 63u) : tid;
+    const u32 rounds = (nq + 4u * WG - 1u) / (4u * WG);
+    for (u32 r = 0; r < rounds; ++r) {
+        u32x4 v[4];
+        const u32 q0 = first + r * 4u * WG;
+#pragma unroll
+        for (u32 j = 0; j < 4; ++j) { u32 q = q0 + j * JS; v[j] = __builtin_nontemporal_load(&p[q < nq ? q : nq - 1u]); }
+#pragma unroll
+        for (u32 j = 0; j < 4; ++j) {
+            const u32 q = q0 + j * JS;
+            const u32 e0 = q * 8u;
+            const u32 w4[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+#pragma unroll
+            for (u32 t = 0; t < 4; ++t) {
+                const u32 lo = w4[t] & 0xFFFFu, hi = w4[t] >> 16;
+                if (q < nq && e0 + 2u * t < ns) atomicOr(&U[lo >> 5], 1u << (lo & 31u));
+                if (q < nq && e0 + 2u * t + 1u < ns) atomicOr(&U[hi >> 5], 1u << (hi & 31u));
+            }
+        }
+    }
+}
+
 // interior words covered by a long run: prefix sum of D over the 2048 words; covered words become all ones.  D is left
 // zeroed.  Called by the whole workgroup between barriers; sm: WG / 64 ints.
 template <int WG>
@@ -248,7 +375,9 @@ void k_coll_apply(const u32* __restrict__ runs, const u64* __restrict__ off, con
                   const u32* __restrict__ s_flags, u32 ncols_s,
                   u32 col_base, u32 ncols, int opt_compress, u64* __restrict__ counts,
                   uint4* __restrict__ slab, u64* __restrict__ desc, BlockStat* __restrict__ st, u32 hint_from, u32 hint_to,
-                  FoldOut kinds /* COLL_OR without opt_compress: the result's kind counts folded in-kernel (no layout scan) */)
+                  FoldOut kinds /* COLL_OR without opt_compress: the result's kind counts folded in-kernel (no layout scan) */,
+                  const u32* __restrict__ a_cnt_s /* OR bag in the split format: its singles per column (else null) */,
+                  const u32* __restrict__ s_cnt_s /* the same for the SUB bag */)
 {
     __shared__ __attribute__((aligned(16))) u32 U[2048];
     __shared__ __attribute__((aligned(16))) int D[2048];
@@ -292,12 +421,16 @@ void k_coll_apply(const u32* __restrict__ runs, const u64* __restrict__ off, con
     }
     if (tid == 0) s_long = 0u;
     __syncthreads();
+    const u64 a_off = uniform64(off[c < ncols_a ? c : 0u]);
+    const u32 a_ns = (a_cnt_s && c < ncols_a) ? uniform32(a_cnt_s[c]) : 0u;     // (split bag: the singles among the n_ent runs)
+    const u32 a_nm = n_ent - a_ns;
 #ifdef BMX_DIAG
-    u32 al = coll_apply_bag<WG, PF, CW>(runs, uniform64(off[c < ncols_a ? c : 0u]), n_ent, U, D, tid, (diag & 512) != 0);
+    u32 al = coll_apply_bag<WG, PF, CW>(runs, a_off, a_nm, U, D, tid, (diag & 512) != 0);
     if (diag & 1024) return;                                  // timing probe: no fold, no store
 #else
-    u32 al = coll_apply_bag<WG, PF, CW>(runs, uniform64(off[c < ncols_a ? c : 0u]), n_ent, U, D, tid);
+    u32 al = coll_apply_bag<WG, PF, CW>(runs, a_off, a_nm, U, D, tid);
 #endif
+    if (a_ns) coll_apply_singles<WG, CW>(runs, a_off + ((a_nm + 3u) & ~3u), a_ns, U, tid);
     if (al) s_long = 1u;
     __syncthreads();
     if (s_long) coll_fold<WG>(U, D, sm, tid);                 // (block-uniform; the barriers inside are reached by every thread)
@@ -322,7 +455,10 @@ void k_coll_apply(const u32* __restrict__ runs, const u64* __restrict__ off, con
         for (u32 k = 0; k < W; k += 4u) *reinterpret_cast<u32x4*>(&U[tid * W + k]) = (u32x4)(0u);
         if (tid == 0) s_long = 0u;
         __syncthreads();
-        u32 sl = coll_apply_bag<WG, PF, CW>(s_runs, uniform64(s_off[c]), s_ent, U, D, tid);
+        const u64 so = uniform64(s_off[c]);
+        const u32 s_ns = s_cnt_s ? uniform32(s_cnt_s[c]) : 0u, s_nm = s_ent - s_ns;
+        u32 sl = coll_apply_bag<WG, PF, CW>(s_runs, so, s_nm, U, D, tid);
+        if (s_ns) coll_apply_singles<WG, CW>(s_runs, so + ((s_nm + 3u) & ~3u), s_ns, U, tid);
         if (sl) s_long = 1u;
         __syncthreads();
         if (s_long) coll_fold<WG>(U, D, sm, tid);

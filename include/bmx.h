@@ -229,7 +229,8 @@ int bmx_slice_eq_counts(bmx_ctx* ctx, const bmx_vec* const* slices, size_t nslic
  * small pieces (src/bmaggregator.h:1808-1924 walks them operand by operand); from the SECOND time an operand set is used
  * the engine transposes its GAP blocks once into column-major order (one contiguous run list per block column, cached by
  * the operand set, dropped when one of its vectors is freed, LRU under BMX_PACK_MAX_MB) and streams that instead.
- * Results are identical either way.  Tuning key "gap_pack": -1 = from the second use (default), 0 = never, 1 = first use.
+ * Results are identical either way.  Tuning key "gap_pack": -1 = from the second use (default), 0 = never, 1 = first use;
+ * "coll_split" 0|1: OR / SUB collections keep a single-bit run as one 16-bit position (default 1: half the bytes for sparse operands).
  *   bmx_collection_prepare  builds the collection of an operand list now (role: how the list will be used)
  *   bmx_ctx_pack_stats      collections held, their bytes, device time of the last build */
 #define BMX_ROLE_AND 0

@@ -1065,7 +1065,9 @@ def test_batched_equality_counts_by_transposition(ctx, case):
 
 def test_packed_collection_kernel_shapes(port):
     """every launch shape of k_coll_apply (256 / 512 threads, with and without the second batch in flight, a wave's batch as
-    four 1-KiB pieces or one 4-KiB piece) must produce the oracle's bits and block kinds for OR, AND-SUB and the counts"""
+    four 1-KiB pieces or one 4-KiB piece) and both bag formats (split: single-bit runs as 16-bit positions behind the
+    multi-bit runs; plain: every run a 32-bit interval) must produce the oracle's bits and block kinds for OR, AND-SUB
+    (the SUB bag is a polarity-1 bag too) and the counts; the operands mix isolated bits, wide runs, NULL / FULL blocks"""
     rng = np.random.default_rng(77)
     nvec, nbits = 96, 5 * 65536 + 4321
     words = _sparse_collection(port, rng, nvec, nbits, 300, long_runs=True, ragged=True)
@@ -1073,9 +1075,9 @@ def test_packed_collection_kernel_shapes(port):
     nwb = 6 * 2048
     e_or = port.agg_or(pv, False)
     e_as = port.agg_and_sub(pv[:80], pv[80:])
-    for shape in range(6):
+    for shape, split in [(sh, 1) for sh in range(6)] + [(4, 0), (0, 0)]:      # split: single-bit runs kept as 16-bit positions (default) or not
         c = bm.context(0)
-        c.set_tuning("gap_pack", 1); c.set_tuning("coll_shape", shape)
+        c.set_tuning("gap_pack", 1); c.set_tuning("coll_shape", shape); c.set_tuning("coll_split", split)
         c.set_tuning("direct_cols", 0); c.set_tuning("pipe_split", 0)
         gv = [bm.bit_import_u32(c, w, True) for w in words]
         agg = bm.aggregator(c)
@@ -1370,9 +1372,9 @@ def test_packed_gap_collections(port, dq, nvec, long_runs):
     assert all(p.flatten()[0].tolist().count(2) == 0 for p in pv), "operands must be free of bit-blocks"
     nwb = 7 * 2048
     results = {}
-    for mode in (1, 0):
+    for mode in (1, 2, 0):                                             # packed with split bags (default) / packed with plain bags / table kernels
         c = bm.context(0)
-        c.set_tuning("gap_pack", mode)
+        c.set_tuning("gap_pack", min(mode, 1)); c.set_tuning("coll_split", 1 if mode == 1 else 0)
         c.set_tuning("direct_cols", 0); c.set_tuning("pipe_split", 0)   # (few columns: keep the one-launch small-collection kernels out of the way)
         gv = [bm.bit_import_u32(c, w, True) for w in words]
         agg = bm.aggregator(c)
@@ -1402,9 +1404,9 @@ def test_packed_gap_collections(port, dq, nvec, long_runs):
             assert int(agg._run_pipeline(pipe, 1, 4)[0]) == int(port.pipeline_counts([([pv[i] for i in a], [pv[i] for i in s])], 1, 4)[0])
             out.append(t.block_table()[0].tolist())
         st = c.pack_stats()
-        assert (st["collections"] > 0) == (mode == 1), st
+        assert (st["collections"] > 0) == (mode >= 1), st
         results[mode] = out
-        if mode == 1:
+        if mode >= 1:
             # a freed operand takes the collections that hold its runs with it
             before = c.pack_stats()["collections"]
             del o, t, pipe, ag
@@ -1416,7 +1418,7 @@ def test_packed_gap_collections(port, dq, nvec, long_runs):
             assert c.pack_stats()["collections"] < before
         del gv
         c.close()
-    assert results[0] == results[1]
+    assert results[0] == results[1] == results[2]
 
 
 def test_packed_collection_policy_and_prepare(port):
