@@ -804,7 +804,7 @@ def run_pairwise(args, env, dq=None, quick=False):
     def step():
         for i in range(npairs):
             L.bmx_count_op2_dev(ctx._h, 0, va[i]._h, vb[i]._h, C.c_void_p(dcnt.data_ptr() + 8 * i))
-    steps, warmup = (5, 2) if quick else (args.steps, args.warmup)
+    steps, warmup = (20, 3) if quick else (args.steps, args.warmup)      # (steps of well under a millisecond: enough of them for a stable wall time)
     dt, ev_ms = timed_region(step, steps, warmup, env)
     torch.cuda.synchronize()
     counts = dcnt.cpu().tolist()
@@ -904,7 +904,7 @@ def run_rank_select(args, env, quick=False):
     rank_ms = event_avg_ms(do_rank, 10, ctx); sel_ms = event_avg_ms(do_sel, 10, ctx)
     def step():
         do_rank(); do_sel()
-    steps, warmup = (5, 2) if quick else (args.steps, args.warmup)
+    steps, warmup = (20, 3) if quick else (args.steps, args.warmup)      # (steps of well under a millisecond: enough of them for a stable wall time)
     dt, ev_ms = timed_region(step, steps, warmup, env)
     chk = torch.zeros(nq, dtype=torch.int64, device="cuda")
     _ffi.check(L.bmx_rank_batch_dev(ctx._h, v._h, rs._h, pos.data_ptr(), nq, chk.data_ptr())); torch.cuda.synchronize()
@@ -1022,7 +1022,7 @@ def run_or_sharded(args, env, quick=False):
         if use_dist:
             dist.all_reduce(cnt)
         last[:] = [t]
-    steps, warmup = (3, 2) if quick else (args.steps, max(args.warmup, 2))     # (the second use of the set builds its packed collection)
+    steps, warmup = (10, 3) if quick else (args.steps, max(args.warmup, 2))    # (the second use of the set builds its packed collection)
     dt, ev_ms = timed_region(step, steps, warmup, env)
     pack = ctx.pack_stats()
     gb = torch.tensor([gap_bytes], dtype=torch.int64, device="cpu" if env.one_dev else "cuda")
