@@ -9,6 +9,7 @@
 #include "bmx_kernels4.h"
 #include "bmx_kernels5.h"
 #include "bmx_kernels6.h"
+#include "bmx_kernels7.h"
 
 #include <algorithm>
 #include <atomic>
@@ -508,6 +509,10 @@ int bmx_ctx_create(int device, void* stream, bmx_ctx** out)
     CTXCHK(hipMemsetAsync(ctx->d_zero, 0, 256, ctx->stream));
     CTXCHK(hipMalloc((void**)&ctx->d_done, FOLD_DONE_WORDS * 4));
     CTXCHK(hipMemsetAsync(ctx->d_done, 0, FOLD_DONE_WORDS * 4, ctx->stream));
+    CTXCHK(hipMalloc((void**)&ctx->d_slots2, COUNT_SLOTS * COUNT_SLOT_STRIDE * sizeof(u64)));
+    CTXCHK(hipMemsetAsync(ctx->d_slots2, 0, COUNT_SLOTS * COUNT_SLOT_STRIDE * sizeof(u64), ctx->stream));
+    CTXCHK(hipMalloc((void**)&ctx->d_done2, FOLD_DONE_WORDS * 4));
+    CTXCHK(hipMemsetAsync(ctx->d_done2, 0, FOLD_DONE_WORDS * 4, ctx->stream));
 #undef CTXCHK
     { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, device) == hipSuccess && v > 0) ctx->max_lds_bytes = (uint32_t)v; else (void)hipGetLastError(); }
     if (const char* e = getenv("BMX_PACK_MAX_MB")) { long long mb = atoll(e); if (mb >= 0) ctx->pack_cap = (uint64_t)mb << 20; }
@@ -516,7 +521,7 @@ int bmx_ctx_create(int device, void* stream, bmx_ctx** out)
     // an invalid value is ignored (the default stays)
     static const char* const env_keys[][2] = {
         {"BMX_PIPE_UNROLL", "pipe_unroll"}, {"BMX_PIPE_ROWS", "pipe_rows"}, {"BMX_PIPE_NT", "pipe_nt"},
-        {"BMX_PIPE_WG", "pipe_wg"}, {"BMX_PIPE_WINDOW", "pipe_window"}, {"BMX_PIPE_SPLIT", "pipe_split"}, {"BMX_OR_TILE", "or_tile"}, {"BMX_OR_WINDOW", "or_window"}, {"BMX_DIRECT_COLS", "direct_cols"}, {"BMX_FF_WINDOW", "ff_window"}, {"BMX_GAP_COUNT", "gap_count"}, {"BMX_RANGE_HALVES", "range_halves"}, {"BMX_PAIR_STREAM", "pair_stream"}, {"BMX_PAIR_WGS", "pair_wgs"}, {"BMX_RS_LANES", "rs_lanes"}, {"BMX_RS_LINES", "rs_lines"}, {"BMX_RS_SELECT_LINES", "rs_select_lines"}, {"BMX_RS_SDIR_SHIFT", "rs_sdir_shift"}, {"BMX_COLL_SHAPE", "coll_shape"}, {"BMX_COLL_WINDOW", "coll_window"}, {"BMX_COLL_SPLIT", "coll_split"}, {"BMX_EQ_BIG", "eq_big"}, {"BMX_PAIR_LOOP", "pair_loop"}, {"BMX_PAIR_NT", "pair_nt"}, {"BMX_EQ_BIG_SHAPE", "eq_big_shape"}, {"BMX_OP2_WGS", "op2_wgs"}, {"BMX_OP2_NT", "op2_nt"}, {"BMX_GAP_PACK", "gap_pack"}, {"BMX_XCD_SWIZZLE", "xcd_swizzle"}};
+        {"BMX_PIPE_WG", "pipe_wg"}, {"BMX_PIPE_WINDOW", "pipe_window"}, {"BMX_PIPE_SPLIT", "pipe_split"}, {"BMX_OR_TILE", "or_tile"}, {"BMX_OR_ROWS", "or_rows"}, {"BMX_OR_DEPTH", "or_depth"}, {"BMX_OR_WINDOW", "or_window"}, {"BMX_DIRECT_COLS", "direct_cols"}, {"BMX_FF_WINDOW", "ff_window"}, {"BMX_GAP_COUNT", "gap_count"}, {"BMX_RANGE_HALVES", "range_halves"}, {"BMX_PAIR_STREAM", "pair_stream"}, {"BMX_PAIR_WGS", "pair_wgs"}, {"BMX_RS_LANES", "rs_lanes"}, {"BMX_RS_LINES", "rs_lines"}, {"BMX_RS_SELECT_LINES", "rs_select_lines"}, {"BMX_RS_SDIR_SHIFT", "rs_sdir_shift"}, {"BMX_COLL_SHAPE", "coll_shape"}, {"BMX_COLL_WINDOW", "coll_window"}, {"BMX_COLL_SPLIT", "coll_split"}, {"BMX_EQ_BIG", "eq_big"}, {"BMX_PAIR_LOOP", "pair_loop"}, {"BMX_PAIR_NT", "pair_nt"}, {"BMX_EQ_BIG_SHAPE", "eq_big_shape"}, {"BMX_OP2_WGS", "op2_wgs"}, {"BMX_OP2_NT", "op2_nt"}, {"BMX_GAP_PACK", "gap_pack"}, {"BMX_XCD_SWIZZLE", "xcd_swizzle"}};
     for (auto& kv : env_keys)
         if (const char* e = getenv(kv[0])) (void)bmx_ctx_set_tuning(ctx, kv[1], atoi(e));
     g_last_error.clear();
@@ -539,6 +544,8 @@ int bmx_ctx_destroy(bmx_ctx* ctx)
     if (ctx->d_small) (void)hipFree(ctx->d_small);
     if (ctx->d_slots) (void)hipFree(ctx->d_slots);
     if (ctx->d_done) (void)hipFree(ctx->d_done);
+    if (ctx->d_slots2) (void)hipFree(ctx->d_slots2);
+    if (ctx->d_done2) (void)hipFree(ctx->d_done2);
     if (ctx->d_zero) (void)hipFree(ctx->d_zero);
     if (ctx->h_small) (void)hipHostFree(ctx->h_small);
     if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
@@ -563,6 +570,8 @@ int bmx_ctx_set_tuning(bmx_ctx* ctx, const char* key, int value)
     else if (k == "pipe_split") { ARGCHK(value >= -1 && value <= 1); ctx->pipe_split = value; }
     else if (k == "pipe_window") { ARGCHK(value >= -1); ctx->pipe_window = value; }
     else if (k == "or_tile") { ARGCHK(value >= 0 && value <= 3); ctx->or_tile = value; }
+    else if (k == "or_rows") { ARGCHK(value >= -1 && value <= 1); ctx->or_rows = value; }
+    else if (k == "or_depth") { ARGCHK(value == 4 || value == 8); ctx->or_depth = value; }
     else if (k == "direct_cols") { ARGCHK(value >= 0); ctx->direct_cols = value; }
     else if (k == "pair_stream") { ARGCHK(value == -1 || value == 0 || value == 2 || value == 4 || value == 8); ctx->pair_stream = value; }
     else if (k == "pair_wgs") { ARGCHK(value >= 1 && value <= 8); ctx->pair_wgs = value; }
@@ -728,7 +737,25 @@ static int vec_alloc_device(bmx_vec* v, uint32_t n_bit, uint64_t gap_words)
     if ((rc = dmalloc(ctx, (void**)&v->d_desc, b_desc))) return rc;
     if ((rc = dmalloc(ctx, (void**)&v->d_bits, b_bits))) return rc;
     if ((rc = dmalloc(ctx, (void**)&v->d_gaps, b_gaps))) return rc;
+    // padding words between GAP blocks (and the guard) read 0xFFFF: no run end but a block's last has that value, which is
+    // how k_agg_or_rows (bmx_kernels7.h) tells a run from padding without the block's length
+    if (gap_words) HIPCHK(hipMemsetAsync(v->d_gaps, 0xFF, b_gaps, ctx->stream));
     v->bytes = std::max<size_t>(b_desc, 16) + std::max<size_t>(b_bits, 16) + std::max<size_t>(b_gaps, 16);
+    return BMX_OK;
+}
+
+// tile directory (bmx_kernels7.h): built on the stream once the vector's descriptors are final; vectors without GAP / FULL
+// blocks have none (they contribute nothing to a union and are left out of its operand table)
+static int vec_build_tdir(bmx_ctx* ctx, bmx_vec* v)
+{
+    if (v->d_tdir || !v->nblocks || !(v->counts[BMX_GAP] | v->counts[BMX_FULL])) return BMX_OK;
+    const u32 ntiles = (v->nblocks + ORR_TILE - 1u) / ORR_TILE;
+    int rc = dmalloc(ctx, &v->d_tdir, (size_t)ntiles * 32);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_build_tdir, dim3((ntiles + 255) / 256), dim3(256), 0, ctx->stream, (const u64*)v->d_desc, v->nblocks,
+                       (u64)(uintptr_t)v->d_gaps, (u32x4*)v->d_tdir, ntiles);
+    KCHK();
+    v->bytes += (size_t)ntiles * 32;
     return BMX_OK;
 }
 
@@ -739,7 +766,7 @@ int bmx_vec_free(bmx_ctx* ctx, bmx_vec* v)
     int rc = set_dev(ctx); if (rc) return rc;
     HIPCHK(hipStreamSynchronize(ctx->stream));
     coll_drop_vector(ctx, v->uid);
-    dfree(ctx, v->d_desc); dfree(ctx, v->d_bits); dfree(ctx, v->d_gaps); dfree(ctx, v->d_ord);
+    dfree(ctx, v->d_desc); dfree(ctx, v->d_bits); dfree(ctx, v->d_gaps); dfree(ctx, v->d_ord); dfree(ctx, v->d_tdir);
     delete v;
     return BMX_OK;
 }
@@ -803,6 +830,7 @@ int bmx_vec_upload(bmx_ctx* ctx, uint64_t nbits, uint32_t nblocks,
         UPCHK(hipGetLastError());
         UPCHK(hipMemcpyAsync(ctx->h_small, ctx->d_small, 8, hipMemcpyDeviceToHost, ctx->stream));
     }
+    if ((rc = vec_build_tdir(ctx, v))) { (void)hipStreamSynchronize(ctx->stream); bmx_vec_free(ctx, v); return rc; }
     UPCHK(hipStreamSynchronize(ctx->stream));
 #undef UPCHK
     if (any_gap && ctx->h_small[0]) {
@@ -841,6 +869,7 @@ static int vec_from_raw(bmx_ctx* ctx, uint64_t nbits, uint32_t nblocks, int opti
         hipLaunchKernelGGL(k_emit_blocks, dim3((nblocks + 3) / 4), dim3(256), 0, ctx->stream,
                            raw, nblocks, st, offs, v->d_bits, v->d_gaps, v->d_desc);
         RAWCHK(hipGetLastError());
+        if ((rc = vec_build_tdir(ctx, v))) { (void)hipStreamSynchronize(ctx->stream); bmx_vec_free(ctx, v); return rc; }
         RAWCHK(hipStreamSynchronize(ctx->stream));
     }
 #undef RAWCHK
@@ -1053,6 +1082,7 @@ extern "C" {
 int bmx_count(bmx_ctx* ctx, const bmx_vec* a, uint64_t* count)
 {
     ARGCHK(ctx && a && count && a->ctx == ctx);
+    if (a->count_valid) { *count = a->count; return BMX_OK; }      // folded by the kernel that produced the vector
     int rc = bmx_i_count_async(ctx, a, 0); if (rc) return rc;
     HIPCHK(hipStreamSynchronize(ctx->stream));
     *count = ctx->h_small[0];
@@ -1434,6 +1464,7 @@ static int result_finish(bmx_ctx* ctx, bmx_vec* v, BlockStat* st, u32* offs)
     if (gap_words) {
         size_t b_gaps = (size_t)gap_words * 2 + 64;      // + guard, see vec_alloc_device
         if ((rc = dmalloc(ctx, (void**)&v->d_gaps, b_gaps))) return rc;
+        HIPCHK(hipMemsetAsync(v->d_gaps, 0xFF, b_gaps, ctx->stream));      // padding words read 0xFFFF (see vec_alloc_device)
         v->bytes += std::max<size_t>(b_gaps, 16);
         v->gap_words = gap_words;
         hipLaunchKernelGGL(k_emit_gaps, dim3((nblocks + 3) / 4), dim3(256), 0, ctx->stream,
@@ -1457,6 +1488,7 @@ static int result_finish(bmx_ctx* ctx, bmx_vec* v, BlockStat* st, u32* offs)
         HIPCHK(hipMemcpyAsync(v->d_ord, offs, (size_t)nblocks * 4, hipMemcpyDeviceToDevice, ctx->stream));
         pending = true;
     }
+    if (v->counts[BMX_GAP] | v->counts[BMX_FULL]) { if ((rc = vec_build_tdir(ctx, v))) return rc; pending = true; }
     if (pending) HIPCHK(hipStreamSynchronize(ctx->stream));
     if (old_slab) dfree(ctx, old_slab);
     if (live == 0) {                          // nothing lives in the slab: give it back
@@ -1492,8 +1524,10 @@ static int vec_clone(bmx_ctx* ctx, const bmx_vec* a, bmx_vec** out)
                            (u64)(uintptr_t)a->d_bits, (u64)(uintptr_t)v->d_bits, (u64)(uintptr_t)a->d_gaps, (u64)(uintptr_t)v->d_gaps);
         e = hipGetLastError();
     }
+    if (e == hipSuccess && (rc = vec_build_tdir(ctx, v))) { (void)hipStreamSynchronize(ctx->stream); bmx_vec_free(ctx, v); return rc; }
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) { bmx_vec_free(ctx, v); return fail_hip(e, "vec_clone", __LINE__); }
+    if (a->count_valid) { v->count = a->count; v->count_valid = true; }
     *out = v;
     return BMX_OK;
 }
@@ -1678,6 +1712,19 @@ static int direct_launch(int mode, bmx_ctx* ctx, const void* d_tab, size_t n_and
 
 static int agg_or_impl(bmx_ctx* ctx, const bmx_vec* const* src, size_t n, int opt_compress, bmx_vec** result);
 
+// combine_or over >= 64 GAP-only operands: the row kernel (bmx_kernels7.h) when the operands are sparse enough for a tile of
+// ORR_TILE = 14 blocks to fit one 1-KiB row (<= 64 chunks of 16 B) nearly always, i.e. <= 4.1 chunks per GAP block on average
+static bool or_rows_wanted(const bmx_ctx* ctx, const bmx_vec* const* src, size_t n)
+{
+    if (ctx->or_rows == 0) return false;
+    uint64_t words = 0, blocks = 0;
+    for (size_t i = 0; i < n; ++i) {
+        if (!src[i]->d_tdir && (src[i]->counts[BMX_GAP] | src[i]->counts[BMX_FULL])) return false;   // (cannot happen: every creation path builds it)
+        words += src[i]->gap_words; blocks += src[i]->counts[BMX_GAP];
+    }
+    return ctx->or_rows == 1 || (blocks && words * 10ull <= blocks * 328ull);     // <= 4.1 chunks of 8 words per GAP block
+}
+
 int bmx_agg_or(bmx_ctx* ctx, const bmx_vec* const* src, size_t n, bmx_vec** result)
 {
     return agg_or_impl(ctx, src, n, 0 /* opt_mode_ = opt_none, src/bmaggregator.h:917 */, result);
@@ -1735,6 +1782,40 @@ static int agg_or_impl(bmx_ctx* ctx, const bmx_vec* const* src, size_t n, int op
         else if (rc) (void)hipStreamSynchronize(ctx->stream);
         if (rc) { bmx_vec_free(ctx, v); return rc; }
     } else if (rc) { bmx_vec_free(ctx, v); return rc;
+    } else if (n >= 64 && ncols && has_gap && !has_bit && or_rows_wanted(ctx, src, n)) {
+        // many SPARSE GAP-only operands: rows of 16 block columns read through the vectors' tile directories (k_agg_or_rows,
+        // bmx_kernels7.h); the kernel folds the block kinds and the popcount of its result (no layout scan when every block
+        // came out as a bit-block, no count pass later)
+        std::vector<u64> tab; tab.reserve(n * 4);
+        for (size_t i = 0; i < n; ++i) {
+            const bmx_vec* o = src[i];
+            if (!o->d_tdir) continue;                                          // NULL blocks only: contributes nothing
+            tab.push_back((u64)(uintptr_t)o->d_tdir); tab.push_back((u64)(uintptr_t)o->d_gaps);
+            tab.push_back((u64)(uintptr_t)o->d_desc); tab.push_back((u64)o->nblocks);
+        }
+        const u32 nops = (u32)(tab.size() / 4);
+        void* d_tab = nullptr;
+        if ((rc = dmalloc(ctx, &d_tab, std::max<size_t>(tab.size() * 8, 64))) || (rc = h2d_staged(ctx, d_tab, tab.data(), tab.size() * 8))) {
+            dfree(ctx, d_tab); bmx_vec_free(ctx, v); return rc;
+        }
+        const size_t lds = (size_t)ORR_TILE * 8192 + 64;
+        const u32 ntiles = (ncols + ORR_TILE - 1) / ORR_TILE;
+        auto rows = ctx->or_depth == 8 ? k_agg_or_rows<8> : k_agg_or_rows<4>;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rows), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(rows, dim3(ntiles), dim3(1024), lds, ctx->stream, (const u32x4*)d_tab, nops, ncols, opt_compress, ctx->xcd_swz,
+                               v->d_bits, v->d_desc, st, FoldOut{ctx->d_slots, ctx->d_done, ctx->h_small + 2},
+                               FoldOut{ctx->d_slots2, ctx->d_done2, ctx->h_small + 8});
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        dfree(ctx, d_tab);
+        if (e != hipSuccess) { bmx_vec_free(ctx, v); return fail_hip(e, "bmx_agg_or (rows)", __LINE__); }
+        const uint64_t total = ctx->h_small[8];
+        if (ctx->h_small[2 + BMX_GAP] == 0 && ctx->h_small[2 + BMX_BIT] == ncols) {
+            for (int k = 0; k < 4; ++k) v->counts[k] = (uint32_t)ctx->h_small[2 + k];
+        } else if ((rc = result_finish(ctx, v, st, offs))) { bmx_vec_free(ctx, v); return rc; }
+        v->count = total; v->count_valid = true;
     } else if (n >= 64 && ncols && has_gap && !has_bit) {
         // many GAP-only operands: column-tile kernel straight from the descriptor tables (no sort pass)
         void* d_descs = nullptr; void* d_nblk = nullptr;

@@ -34,6 +34,7 @@ struct bmx_ctx {
     void* aux = nullptr; size_t aux_bytes = 0;              // stats / offsets / totals
     u64* d_small = nullptr;                                 // 64 x u64 result words
     u64* d_slots = nullptr;                                 // COUNT_SLOTS striped count accumulators (kept zero between launches)
+    u64* d_slots2 = nullptr; u32* d_done2 = nullptr;        // a second fold (slots + tickets) for kernels that fold block kinds AND a count
     u64* d_zero = nullptr;                                  // 256 bytes of zeros: what an invalid slot of an unconditional load reads
     u32* d_done = nullptr;                                  // workgroup ticket of the in-kernel folds (kept zero between launches)
     u64* h_small = nullptr;                                 // pinned mirror
@@ -61,6 +62,8 @@ struct bmx_ctx {
     int gap_count = -1;        // GAP-only counts pipelines: counting formulation (k_pipe_counts_gapcount): -1 = automatic, 0 = off, 1 = force
     int ff_window = 0;         // find_first_and_sub: block columns of the FIRST launch window (each next one is 4x larger): 0 = automatic, -1 = one launch
     int or_window = 0;         // column tiles per launch of k_agg_or_gap_tiled: 0 / -1 = all in one launch (windows measured: no gain)
+    int or_rows = -1;          // combine_or over >= 64 GAP-only operands through the tile directories (k_agg_or_rows, bmx_kernels7.h): -1 = when the operands average <= 4.1 chunks per GAP block, 0 = never (k_agg_or_gap_tiled), 1 = always
+    int or_depth = 4;          // ... rows (operands) in flight per wave: 4 or 8
     // column-major packed GAP collections (bmx_kernels6.h), cached by operand set
     std::vector<struct bmx_coll*> colls;
     std::unordered_map<u64, u32> coll_seen;   // hash of an operand set -> sightings so far (automatic packing waits for the second)
@@ -91,6 +94,8 @@ struct bmx_vec {
     uint32_t counts[4]; uint64_t gap_words; uint32_t n_bit;   // n_bit = slots of d_bits
     u64* d_desc; uint4* d_bits; u16* d_gaps;
     u32* d_ord;        // result vectors whose slab has unused slots: ordinal of every bit-block (download gathers), else null
+    void* d_tdir;      // tile directory (bmx_kernels7.h): 32 B per 14 blocks, vectors with GAP or FULL blocks only, else null
+    uint64_t count; bool count_valid;                         // popcount of the vector when the kernel that produced it folded one
     size_t bytes;
 };
 

@@ -211,7 +211,7 @@ void k_gap_repack(const u16* __restrict__ raw, const u32* __restrict__ src_off, 
     u32 padded = (len + 1u + 7u) & ~7u;
     bool bad = false;
     for (u32 k = lane; k < padded; k += 64u) {
-        u32 cur = k <= len ? (u32)src[k] : 0u;
+        u32 cur = k <= len ? (u32)src[k] : 0xFFFFu;                // padding words: 0xFFFF (what k_agg_or_rows reads as "no run", bmx_kernels7.h)
         if (k >= 2u && k <= len && (u32)src[k - 1u] >= cur) bad = true;
         if (k == len && cur != 65535u) bad = true;
         dst[k] = (u16)cur;

@@ -1421,6 +1421,46 @@ def test_packed_gap_collections(port, dq, nvec, long_runs):
     assert results[0] == results[1] == results[2]
 
 
+@pytest.mark.parametrize("dq,nvec,long_runs,nblk", [(13, 200, False, 40), (13, 1100, False, 19), (150, 96, True, 35), (30, 300, True, 7), (3, 70, False, 33)])
+def test_combine_or_row_kernel(port, dq, nvec, long_runs, nblk):
+    """combine_or over >= 64 GAP-only operands through the tile directories (k_agg_or_rows, bmx_kernels7.h; or_rows 1, both
+    depths) = the oracle bit for bit, block kind for block kind (with and without the aggregator's optimisation), with the
+    popcount the kernel folds, and = the column-tile kernel (or_rows 0): sparse rows (<= 64 chunks per tile), tiles the
+    directory hands to the descriptor path (dense GAP blocks, FULL blocks), NULL columns inside a tile, operands shorter
+    than the others, more than 1,024 operands (a wave's second batch of records), a partial last tile"""
+    rng = np.random.default_rng(dq * 977 + nvec)
+    nbits = nblk * 65536 - 4321
+    words = _sparse_collection(port, rng, nvec, nbits, dq, long_runs=long_runs, ragged=True)
+    for v in range(0, nvec, 9):                                        # whole stretches of NULL blocks (NULL columns inside tiles)
+        b0 = int(rng.integers(0, nblk - 1)); b1 = min(nblk, b0 + int(rng.integers(1, 6)))
+        words[v][b0 * 2048:b1 * 2048] = 0
+    pv = [port.import_words(w, True, w.size * 32) for w in words]
+    assert all(p.flatten()[0].tolist().count(2) == 0 for p in pv), "operands must be free of bit-blocks"
+    nwb = (nblk + 1) * 2048
+    tables = {}
+    for mode, depth in ((1, 4), (1, 8), (0, 4)):
+        c = bm.context(0)
+        c.set_tuning("gap_pack", 0); c.set_tuning("direct_cols", 0); c.set_tuning("pipe_split", 0)
+        c.set_tuning("or_rows", mode); c.set_tuning("or_depth", depth)
+        gv = [bm.bit_import_u32(c, w, True) for w in words]
+        agg = bm.aggregator(c)
+        out = []
+        for opt in (False, True):
+            agg.set_optimization(opt)
+            for sel in (slice(None), slice(3, 3 + 64), slice(1, None, 2)):
+                o = agg.combine_or(gv[sel])
+                e = port.agg_or(pv[sel], opt)
+                assert (o.to_words(nwb) == e.to_words(nwb)).all(), (mode, depth, opt, sel)
+                assert o.block_table()[0].tolist() == (e.flatten()[0].tolist() + [0] * 8)[:o.info()["nblocks"]], (mode, depth, opt, sel)
+                assert o.count() == e.count(), (mode, depth, opt, sel)
+                assert bm.count_xor(o, o) == 0 and bm.count_and(o, o) == e.count()
+                out.append(o.block_table()[0].tolist())
+        tables[(mode, depth)] = out
+        del gv, o
+        c.close()
+    assert tables[(1, 4)] == tables[(1, 8)] == tables[(0, 4)]
+
+
 def test_packed_collection_policy_and_prepare(port):
     """gap_pack -1 (default): the first use of an operand set runs the descriptor-table kernels, the second builds the
     collection; bmx_collection_prepare builds at once; results never depend on which path ran"""

@@ -1,0 +1,125 @@
+// pieces_probe.hip -- what bounds "N streams read in P-byte pieces" on MI355X?  (round 4)
+//
+// The descriptor-table combine_or kernel (k_agg_or_gap_tiled) visits each of 4096 operand slabs in ~1-KiB pieces
+// (16 block columns x ~56 B of GAP data) and was measured at 4.4 TB/s with the run application compiled out.  This
+// stand-alone probe reproduces ONLY the access pattern, so that the candidates can be told apart:
+//   alloc  = sep   : every stream its own hipMalloc (what bmx_vec_upload / generate did through round 3)
+//            arena : all streams carved from ONE hipMalloc (stride = stream bytes rounded to 256 B)
+//            pow2  : one hipMalloc, stride exactly 4 MiB (channel / bank aliasing test)
+//   piece  = bytes one workgroup reads from one stream per visit (1 KiB = one dwordx4 wave load)
+//   wg     = threads per workgroup; lds = dynamic LDS bytes requested (131072 -> one workgroup per CU, as the tiled kernel)
+// Work item = one piece index; a workgroup walks ALL streams for its piece index (wave w takes streams w, w + W, ...),
+// DEPTH wave loads in flight per wave.
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 pieces_probe.hip -o ../bin/pieces_probe
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include <string>
+
+#define CHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s (line %d)\n", #x, hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
+
+typedef unsigned int u32;
+typedef unsigned long long u64;
+typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(1))) u32x4* gptr;
+
+template <int DEPTH, int LPP>   // LPP = 16-byte loads per lane per piece (piece = LPP KiB)
+__global__ void k_pieces(const u64* __restrict__ bases, u32 nstreams, u32 npieces, u32* __restrict__ sink)
+{
+    extern __shared__ u32 lds[];
+    const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6, W = blockDim.x >> 6;
+    const u32 piece = blockIdx.x;
+    if (piece >= npieces) return;
+    const u64 off = (u64)piece * (LPP * 1024u) + lane * 16u;
+    u32x4 acc = (u32x4)(0u);
+    u32 s = wave;
+    for (; s + (DEPTH - 1) * W < nstreams; s += DEPTH * W) {
+        u32x4 v[DEPTH][LPP];
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            const u64 bv = bases[s + d * W];
+            u64 b = (u64)(u32)__builtin_amdgcn_readfirstlane((u32)bv) | ((u64)(u32)__builtin_amdgcn_readfirstlane((u32)(bv >> 32)) << 32);
+            gptr p = (gptr)(b + off);
+#pragma unroll
+            for (int l = 0; l < LPP; ++l) v[d][l] = __builtin_nontemporal_load(p + l * 64);
+        }
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d)
+#pragma unroll
+            for (int l = 0; l < LPP; ++l) acc ^= v[d][l];
+    }
+    for (; s < nstreams; s += W) {
+        gptr p = (gptr)(bases[s] + off);
+#pragma unroll
+        for (int l = 0; l < LPP; ++l) acc ^= __builtin_nontemporal_load(p + l * 64);
+    }
+    u32 x = acc.x ^ acc.y ^ acc.z ^ acc.w;
+    if (x == 0x12345679u) { lds[threadIdx.x] = x; sink[0] = lds[(threadIdx.x + 1) % blockDim.x]; }
+}
+
+typedef void (*kfn)(const u64*, u32, u32, u32*);
+static kfn pick(int depth, int lpp)
+{
+#define K(D, L) if (depth == D && lpp == L) return k_pieces<D, L>;
+    K(1, 1) K(2, 1) K(4, 1) K(8, 1) K(1, 2) K(2, 2) K(4, 2) K(1, 4) K(2, 4) K(4, 4) K(1, 8) K(2, 8)
+#undef K
+    return nullptr;
+}
+
+int main(int argc, char** argv)
+{
+    u32 nstreams = 4096; u64 stream_bytes = 3418016;    // configs[4]: 61,036 GAP blocks x ~56 B
+    if (argc > 1) nstreams = (u32)atoi(argv[1]);
+    if (argc > 2) stream_bytes = strtoull(argv[2], nullptr, 10);
+    CHK(hipSetDevice(0));
+    hipStream_t st; CHK(hipStreamCreate(&st));
+    hipEvent_t e0, e1; CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
+    u32* sink; CHK(hipMalloc(&sink, 64));
+    u64* d_bases; CHK(hipMalloc(&d_bases, (size_t)nstreams * 8));
+    const char* allocs[3] = {"sep", "arena", "pow2"};
+    for (int am = 0; am < 3; ++am) {
+        std::vector<void*> owned; std::vector<u64> bases(nstreams);
+        u64 stride = 0;
+        if (am == 0) {
+            for (u32 s = 0; s < nstreams; ++s) { void* p; CHK(hipMalloc(&p, (stream_bytes + (2u << 20) - 1) / (2u << 20) * (2u << 20))); owned.push_back(p); bases[s] = (u64)(uintptr_t)p; }
+        } else {
+            stride = am == 1 ? (stream_bytes + 255) / 256 * 256 : (4ull << 20);
+            void* p; CHK(hipMalloc(&p, stride * nstreams + (1u << 20))); owned.push_back(p);
+            for (u32 s = 0; s < nstreams; ++s) bases[s] = (u64)(uintptr_t)p + stride * s;
+        }
+        for (void* p : owned) CHK(hipMemsetAsync(p, 0x5a, am == 0 ? stream_bytes : stride * nstreams, st));
+        CHK(hipMemcpy(d_bases, bases.data(), (size_t)nstreams * 8, hipMemcpyHostToDevice));
+        CHK(hipStreamSynchronize(st));
+        struct Cfg { int lpp, depth, wg, lds; };
+        const Cfg cfgs[] = {
+            {1, 4, 1024, 131072}, {1, 8, 1024, 131072}, {1, 2, 1024, 131072},     // the tiled kernel's residency: 16 waves per CU
+            {1, 4, 256, 0}, {1, 8, 256, 0},                                      // 8 small workgroups per CU
+            {2, 4, 1024, 131072}, {2, 4, 256, 0},
+            {4, 2, 1024, 131072}, {4, 4, 256, 0}, {4, 2, 256, 0},
+            {8, 2, 256, 0}, {8, 1, 1024, 131072},
+        };
+        for (const Cfg& c : cfgs) {
+            kfn k = pick(c.depth, c.lpp);
+            if (!k) continue;
+            CHK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            u32 npieces = (u32)(stream_bytes / (c.lpp * 1024u));
+            float best = 1e9f;
+            for (int rep = 0; rep < 4; ++rep) {
+                CHK(hipEventRecord(e0, st));
+                hipLaunchKernelGGL(k, dim3(npieces), dim3(c.wg), c.lds, st, (const u64*)d_bases, nstreams, npieces, sink);
+                CHK(hipEventRecord(e1, st));
+                CHK(hipEventSynchronize(e1));
+                float ms; CHK(hipEventElapsedTime(&ms, e0, e1));
+                if (rep && ms < best) best = ms;
+            }
+            double bytes = (double)npieces * c.lpp * 1024.0 * nstreams;
+            printf("{\"alloc\": \"%s\", \"piece\": %d, \"depth\": %d, \"wg\": %d, \"lds\": %d, \"ms\": %.4f, \"GBps\": %.1f}\n",
+                   allocs[am], c.lpp * 1024, c.depth, c.wg, c.lds, best, bytes / best / 1e6);
+            fflush(stdout);
+        }
+        for (void* p : owned) CHK(hipFree(p));
+    }
+    return 0;
+}
