@@ -750,12 +750,12 @@ static int vec_build_tdir(bmx_ctx* ctx, bmx_vec* v)
 {
     if (v->d_tdir || !v->nblocks || !(v->counts[BMX_GAP] | v->counts[BMX_FULL])) return BMX_OK;
     const u32 ntiles = (v->nblocks + ORR_TILE - 1u) / ORR_TILE;
-    int rc = dmalloc(ctx, &v->d_tdir, (size_t)ntiles * 32);
+    int rc = dmalloc(ctx, &v->d_tdir, (size_t)ntiles * 16);
     if (rc) return rc;
     hipLaunchKernelGGL(k_build_tdir, dim3((ntiles + 255) / 256), dim3(256), 0, ctx->stream, (const u64*)v->d_desc, v->nblocks,
                        (u64)(uintptr_t)v->d_gaps, (u32x4*)v->d_tdir, ntiles);
     KCHK();
-    v->bytes += (size_t)ntiles * 32;
+    v->bytes += (size_t)ntiles * 16;
     return BMX_OK;
 }
 
@@ -1714,6 +1714,14 @@ static int agg_or_impl(bmx_ctx* ctx, const bmx_vec* const* src, size_t n, int op
 
 // combine_or over >= 64 GAP-only operands: the row kernel (bmx_kernels7.h) when the operands are sparse enough for a tile of
 // ORR_TILE = 14 blocks to fit one 1-KiB row (<= 64 chunks of 16 B) nearly always, i.e. <= 4.1 chunks per GAP block on average
+// (tuning build only: BMX_DIAG_ROWS = 512 -> the row loads alone; results are then meaningless)
+static int or_rows_diag_bits()
+{
+#ifdef BMX_DIAG
+    if (const char* e = getenv("BMX_DIAG_ROWS")) return atoi(e) & 512;
+#endif
+    return 0;
+}
 static bool or_rows_wanted(const bmx_ctx* ctx, const bmx_vec* const* src, size_t n)
 {
     if (ctx->or_rows == 0) return false;
@@ -1803,7 +1811,7 @@ static int agg_or_impl(bmx_ctx* ctx, const bmx_vec* const* src, size_t n, int op
         auto rows = ctx->or_depth == 8 ? k_agg_or_rows<8> : k_agg_or_rows<4>;
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rows), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e == hipSuccess) {
-            hipLaunchKernelGGL(rows, dim3(ntiles), dim3(1024), lds, ctx->stream, (const u32x4*)d_tab, nops, ncols, opt_compress, ctx->xcd_swz,
+            hipLaunchKernelGGL(rows, dim3(ntiles), dim3(1024), lds, ctx->stream, (const u32x4*)d_tab, nops, ncols, opt_compress | or_rows_diag_bits(), ctx->xcd_swz,
                                v->d_bits, v->d_desc, st, FoldOut{ctx->d_slots, ctx->d_done, ctx->h_small + 2},
                                FoldOut{ctx->d_slots2, ctx->d_done2, ctx->h_small + 8});
             e = hipGetLastError();

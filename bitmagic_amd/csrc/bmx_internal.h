@@ -94,7 +94,7 @@ struct bmx_vec {
     uint32_t counts[4]; uint64_t gap_words; uint32_t n_bit;   // n_bit = slots of d_bits
     u64* d_desc; uint4* d_bits; u16* d_gaps;
     u32* d_ord;        // result vectors whose slab has unused slots: ordinal of every bit-block (download gathers), else null
-    void* d_tdir;      // tile directory (bmx_kernels7.h): 32 B per 14 blocks, vectors with GAP or FULL blocks only, else null
+    void* d_tdir;      // tile directory (bmx_kernels7.h): 16 B per 14 blocks, vectors with GAP or FULL blocks only, else null
     uint64_t count; bool count_valid;                         // popcount of the vector when the kernel that produced it folded one
     size_t bytes;
 };

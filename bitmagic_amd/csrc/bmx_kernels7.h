@@ -16,23 +16,25 @@
 //
 // This kernel works on tiles of ORR_TILE = 14 block columns (14 accumulators = 112 KiB of LDS, one 1024-thread workgroup
 // per CU) and changes how an operand's piece arrives:
-//  * TILE DIRECTORY (k_build_tdir, built once when a vector is created: 32 B per 14 blocks next to the 8 B per block of
+//  * TILE DIRECTORY (k_build_tdir, built once when a vector is created: 16 B per 14 blocks next to the 8 B per block of
 //    the descriptor table): where the GAP data of the tile's blocks starts in the vector's slab (the device slab keeps GAP
 //    blocks in block order, back to back on 16-byte boundaries), how many 16-byte chunks it spans (n <= 64), which of the
-//    columns hold GAP blocks, a 64-bit mask M of the chunks that START a block and a mask O of the chunks whose block
-//    starts with a 1-run.  (14 columns, not 16: configs[4]
+//    columns hold GAP blocks and a 64-bit mask M of the chunks that START a block.  (14 columns, not 16: configs[4]
 //    averages 3.9 chunks per block, so 16 blocks pass 64 chunks a third of the time and 14 blocks 0.3 % of the time.)
 //  * ROWS: the piece is read as ONE wave load (lane L takes chunk L, 16 B), four or eight rows (= operands) in flight per
 //    wave.  Because blocks are 16-byte aligned a chunk belongs to exactly one block: lane L's block is the popcount of M
-//    at or below L and its start bit is O's bit L -- no header, no length: the slab's padding words are 0xFFFF (the
-//    creation paths see to it), a value no run end but a block's last one has, so a word pair whose first half is 0xFFFF is
-//    no run.  Every lane applies the four 1-run slots of its chunk: a single-bit run (nearly all of them in a sparse
+//    at or below L -- no header, no length: the slab's padding words are 0xFFFF (the creation paths see to it), a value
+//    no run end but a block's last one has, so a word pair whose first half is 0xFFFF is no run; blocks that start with a
+//    1-run (bit 0 of the block set: one block in 5,000 at configs[4]'s density) hand their tile to the descriptor path.
+//    The directory also says whether ANY 1-run of the tile is longer than one bit (TREC_LONG; the builder reads the run
+//    lists once): a tile without one -- 96 % of configs[4]'s -- is applied with six vector instructions per run and no
+//    test but "is this pair a run".  Every lane applies the four 1-run slots of its chunk: a single-bit run (nearly all of them in a sparse
 //    operand) is one ds_or without control flow, anything else takes ONE shared branch per chunk -- all 64 lanes busy
 //    whatever the block lengths, ~50 vector instructions per KiB of run lists.
 //  * RECORDS: a wave owns every 16th operand; the directory records of 64 of its operands are fetched by ONE gather (lane j
 //    = operand j of the batch), one batch ahead, and handed to the row loop through v_readlane: no per-row dependent
 //    chain, 16 B instead of 128 B of descriptors per (operand, tile).
-// Tiles the directory cannot describe (more than 64 chunks, a FULL block, GAP data not contiguous) carry a flag and are
+// Tiles the directory cannot describe (more than 64 chunks, a FULL block, a block starting with a 1-run, GAP data not contiguous) carry a flag and are
 // applied from the descriptor table by 14 lanes after the batch (the old way, out of the hot loop): correct for any input, fast for the sparse ones this
 // kernel exists for.  The host picks this kernel when the operands average <= 4.1 chunks per GAP block (bmx.hip).
 // ---------------------------------------------------------------------------
@@ -41,19 +43,20 @@
 #define TREC_SLOW 0x80u
 #define TREC_NCH(i) ((i) & 0x7Fu)
 #define TREC_GAPMASK(i) (((i) >> 8) & 0x3FFFu)
+#define TREC_ALLGAP 0x400000u                 // every column of the tile holds a GAP block: a block's ordinal is its column
+#define TREC_LONG   0x800000u                 // some 1-run of the tile is longer than one bit
 
-// tile directory of one vector: one thread per tile of ORR_TILE block columns; entry (2 x 16 B) =
-//   {first chunk of the tile in the slab, n chunks | TREC_SLOW | GAP columns << 8, M lo, M hi} {O lo, O hi, 0, 0}
-// M = chunks that start a block, O = chunks of blocks that start with a 1-run (extended over the lanes past the last chunk:
-// they repeat its address and must parse it the same way)
+// tile directory of one vector: one thread per tile of ORR_TILE block columns; entry (16 B) =
+//   {first chunk of the tile in the slab, n chunks | TREC_SLOW | GAP columns << 8 | TREC_ALLGAP, M lo, M hi}
+// M = chunks that start a block
 __global__ __launch_bounds__(256)
 void k_build_tdir(const u64* __restrict__ desc, u32 nblocks, u64 gaps_base, u32x4* __restrict__ tdir, u32 ntiles)
 {
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= ntiles) return;
-    u64 next = 0, first = 0, M = 0, O = 0;
+    u64 next = 0, first = 0, M = 0;
     bool have = false, slow = false;
-    u32 nch = 0, gapmask = 0, last_odd = 0;
+    u32 nch = 0, gapmask = 0;
     for (u32 k = 0; k < ORR_TILE; ++k) {
         const u32 c = t * ORR_TILE + k;
         const u64 d = c < nblocks ? desc[c] : 0ull;
@@ -64,24 +67,35 @@ void k_build_tdir(const u64* __restrict__ desc, u32 nblocks, u64 gaps_base, u32x
             const u32 ch = ((meta >> 1) + 1u + 7u) >> 3;          // header + len run ends, in 16-byte chunks
             if (!have) { first = a; have = true; }
             else if (a != next) slow = true;                      // not back to back: the row load would read something else
-            if (nch < 64u) {
-                M |= 1ull << nch;
-                const u32 hi = nch + ch < 64u ? nch + ch : 64u;
-                if (meta & 1u) O |= (hi == 64u ? ~0ull : (1ull << hi) - 1ull) & ~((1ull << nch) - 1ull);
-            }
-            last_odd = meta & 1u;
+            if (meta & 1u) slow = true;                           // starts with a 1-run: the row code pairs words as (0-run end, 1-run end)
+            if (nch < 64u) M |= 1ull << nch;
             gapmask |= 1u << k;
             nch += ch; next = a + (u64)ch * 16u;
         } else if (kind != K_NULL) slow = true;                   // FULL (or a bit-block): the descriptor path takes the tile
     }
     if (nch > 64u || ((first - gaps_base) & 15ull) || ((first - gaps_base) >> 36)) slow = true;
-    if (last_odd && nch < 64u) O |= ~((1ull << nch) - 1ull);
-    u32x4 r0, r1;
-    r0.x = (have && !slow) ? (u32)((first - gaps_base) >> 4) : 0u;
-    r0.y = (slow ? TREC_SLOW : nch) | (gapmask << 8);
-    r0.z = slow ? 0u : (u32)M; r0.w = slow ? 0u : (u32)(M >> 32);
-    r1.x = slow ? 0u : (u32)O; r1.y = slow ? 0u : (u32)(O >> 32); r1.z = 0u; r1.w = 0u;
-    tdir[2u * t] = r0; tdir[2u * t + 1u] = r1;
+    // any 1-run longer than one bit?  The same word pairs the row kernel forms: (word 2i + 1, word 2i + 2) of every chunk, the
+    // last one reaching into the next chunk (padding words are 0xFFFF by now: the writers of the slab ran before this kernel)
+    bool any_long = false;
+    if (have && !slow) {
+        gcptr4 g = (gcptr4)(uintptr_t)first;
+        u32x4 cur = g[0];
+        for (u32 q = 0; q < nch; ++q) {
+            const u32x4 nxt = q + 1u < nch ? g[q + 1u] : (u32x4)(0xFFFFFFFFu);
+            const u32 x[5] = {cur.x, cur.y, cur.z, cur.w, nxt.x};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const u32 p = x[i] >> 16, e = x[i + 1] & 0xFFFFu;
+                any_long = any_long || (p != 0xFFFFu && e - p != 1u);
+            }
+            cur = nxt;
+        }
+    }
+    u32x4 r;
+    r.x = (have && !slow) ? (u32)((first - gaps_base) >> 4) : 0u;
+    r.y = (slow ? TREC_SLOW : nch) | (gapmask << 8) | (gapmask == (1u << ORR_TILE) - 1u ? TREC_ALLGAP : 0u) | (any_long ? TREC_LONG : 0u);
+    r.z = slow ? 0u : (u32)M; r.w = slow ? 0u : (u32)(M >> 32);
+    tdir[t] = r;
 }
 
 // position of the r-th (0-based) set bit of a 16-bit mask
@@ -95,8 +109,13 @@ __device__ __forceinline__ u32 nth_set_bit16(u32 m, u32 r)
     return pos;
 }
 
-// records of one batch of 64 operands of a wave: lane j holds operand j's
-struct OrRec { u32 alo, ahi, info, mlo, mhi, olo, ohi, dlo, dhi, nblk; };
+// records of one batch of 64 operands of a wave: lane j holds operand j's.  A device address has 48 bits: the upper half of
+// ahi carries the row's chunk count (bits 16..22), the all-GAP flag (bit 23) and the long-run flag (bit 24), so that the row loop reads four words
+// (alo, ahi, mlo, mhi) per row and `info` only for a tile with NULL columns
+struct OrRec { u32 alo, ahi, mlo, mhi, info, dlo, dhi, nblk; };
+#define OREC_NCH(ahi) (((ahi) >> 16) & 0x7Fu)
+#define OREC_ALLGAP(ahi) ((ahi) & 0x800000u)
+#define OREC_LONG(ahi) ((ahi) & 0x1000000u)
 
 // operand table entry (host-built, 32 B): tile directory, GAP slab, descriptor table, blocks
 //   e0 = {tdir lo, tdir hi, gaps lo, gaps hi}, e1 = {desc lo, desc hi, nblocks, 0}
@@ -109,20 +128,21 @@ __device__ __forceinline__ bool or_rec_ok(const u32x4& e0, const u32x4& e1, u32 
 {
     return op < n && (e0.x | e0.y) != 0u && tile < (e1.z + ORR_TILE - 1u) / ORR_TILE;
 }
-__device__ __forceinline__ void or_rec_fetch_b(u32x4& t0, u32x4& t1, const u32x4& e0, const u32x4& e1, u32 op, u32 n, u32 tile, gcptr4 dummy)
+__device__ __forceinline__ u32x4 or_rec_fetch_b(const u32x4& e0, const u32x4& e1, u32 op, u32 n, u32 tile, gcptr4 dummy)
 {
     const u64 td = (u64)e0.x | ((u64)e0.y << 32);
-    gcptr4 p = or_rec_ok(e0, e1, op, n, tile) ? (gcptr4)(uintptr_t)td + 2u * tile : dummy;
-    t0 = p[0]; t1 = p[1];
+    gcptr4 p = or_rec_ok(e0, e1, op, n, tile) ? (gcptr4)(uintptr_t)td + tile : dummy;
+    return *p;
 }
 // an empty (or slow) row still loads something: its address is the operand table's
-__device__ __forceinline__ void or_rec_make(OrRec& r, const u32x4& e0, const u32x4& e1, const u32x4& t0, const u32x4& t1, u32 op, u32 n, u32 tile, u64 dummy)
+__device__ __forceinline__ void or_rec_make(OrRec& r, const u32x4& e0, const u32x4& e1, const u32x4& t, u32 op, u32 n, u32 tile, u64 dummy)
 {
     const bool ok = or_rec_ok(e0, e1, op, n, tile);
-    const u32 info = ok ? t0.y : 0u;
-    const u64 a = TREC_NCH(info) ? ((u64)e0.z | ((u64)e0.w << 32)) + ((u64)t0.x << 4) : dummy;
-    r.alo = (u32)a; r.ahi = (u32)(a >> 32);
-    r.info = info; r.mlo = ok ? t0.z : 0u; r.mhi = ok ? t0.w : 0u; r.olo = ok ? t1.x : 0u; r.ohi = ok ? t1.y : 0u;
+    const u32 info = ok ? t.y : 0u;
+    const u32 nch = TREC_NCH(info);
+    const u64 a = nch ? ((u64)e0.z | ((u64)e0.w << 32)) + ((u64)t.x << 4) : dummy;
+    r.alo = (u32)a; r.ahi = ((u32)(a >> 32) & 0xFFFFu) | (nch << 16) | ((info & TREC_ALLGAP) ? 0x800000u : 0u) | ((info & TREC_LONG) ? 0x1000000u : 0u);
+    r.info = info; r.mlo = ok ? t.z : 0u; r.mhi = ok ? t.w : 0u;
     r.dlo = e1.x; r.dhi = e1.y; r.nblk = ok ? e1.z : 0u;
 }
 
@@ -141,41 +161,38 @@ __device__ __forceinline__ void or_set_range(u32* acc, u32 s, u32 e)
 }
 
 // one row = the GAP data of one operand's tile, lane L holding its L-th 16-byte chunk (lanes past the last chunk hold a
-// copy of it and stay out).  Words of the chunk: block words k = 8q .. 8q + 7 (k = 0: the header; run k ends at word k and
-// has the value s ^ ((k - 1) & 1), src/bmfunc.h:4684).  The four 1-run slots of the chunk are the word pairs (end of the
-// 0-run before, end of the 1-run): words (2i + 1, 2i + 2) for a block that starts with a 0-run, (2i, 2i + 1) for one that
-// starts with a 1-run -- one v_alignbit with a per-lane shift of 16 or 0 bits lines both up as lo16 = previous end,
-// hi16 = end.  A pair is a run iff its lo16 is not 0xFFFF (the last word of a block and every padding word).
-__device__ __forceinline__ void or_row_apply(const u32x4& c, u32 nx, u32 info, u32 mlo, u32 mhi, u32 olo, u32 ohi, u32* accs,
-                                             u32 lane, u32 le_lo, u32 le_hi, u32 bit_lo, u32 bit_hi)
+// copy of it and stay out).  Words of the chunk: block words k = 8q .. 8q + 7 (k = 0: the header; run k ends at word k; the
+// blocks here start with a 0-run, so run k is a 1-run for even k, src/bmfunc.h:4684).  The four 1-run slots of the chunk
+// are the word pairs (end of the 0-run before, end of the 1-run) = words (2i + 1, 2i + 2): lo16 = previous end, hi16 =
+// end.  A pair is a run iff its lo16 is not 0xFFFF (the last word of a block and every padding word).
+__device__ __forceinline__ void or_row_apply(const u32x4& c, u32 nx, u32 nch, bool has_long, u32* acc, u32 lane)
 {
-    if (lane < TREC_NCH(info)) {
-        const u32 gapmask = TREC_GAPMASK(info);
-        u32 col = (u32)__popc(mlo & le_lo) + (u32)__popc(mhi & le_hi) - 1u;    // ordinal of this lane's block among the tile's GAP blocks
-        if (gapmask != (1u << ORR_TILE) - 1u) col = nth_set_bit16(gapmask, col);  // (wave-uniform branch) NULL columns in the tile
-        u32* acc = accs + col * 2048u;
-        const bool odd = ((olo & bit_lo) | (ohi & bit_hi)) != 0u;
-        const bool head = ((mlo & bit_lo) | (mhi & bit_hi)) != 0u;         // this chunk starts its block (word 0 = the header)
-        const u32 sh = odd ? 0u : 16u;
+    if (lane < nch) {
         const u32 x[5] = {c.x, c.y, c.z, c.w, nx};
-        bool rare = false;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const u32 y = __builtin_amdgcn_alignbit(x[i + 1], x[i], sh);
-            const u32 e = y >> 16, p = y & 0xFFFFu;
-            bool single = e - p == 1u;                                     // the run is one bit
-            if (i == 0) single = single && !(odd && head);                 // (run 1 of a 1-start block: its lo16 is the header, not a run end)
-            atomicOr(&acc[e >> 5], single ? 1u << (e & 31u) : 0u);
-            rare = rare || (!single && p != 0xFFFFu);
-        }
-        if (rare) {                                                        // runs longer than one bit, the first run of a 1-start block
+        if (!has_long) {                                                   // (wave-uniform) every run of the tile is one bit
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const u32 y = __builtin_amdgcn_alignbit(x[i + 1], x[i], sh);
+                const u32 y = __builtin_amdgcn_alignbit(x[i + 1], x[i], 16);
+                const u32 e = y >> 16;
+                atomicOr(&acc[e >> 5], (y & 0xFFFFu) != 0xFFFFu ? 1u << (e & 31u) : 0u);
+            }
+        } else {
+            bool rare = false;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const u32 y = __builtin_amdgcn_alignbit(x[i + 1], x[i], 16);
                 const u32 e = y >> 16, p = y & 0xFFFFu;
-                const bool first_run = i == 0 && odd && head;
-                if (first_run) or_set_range(acc, 0u, e);
-                else if (p != 0xFFFFu && e - p != 1u) or_set_range(acc, p + 1u, e);
+                const bool single = e - p == 1u;                           // the run is one bit
+                atomicOr(&acc[e >> 5], single ? 1u << (e & 31u) : 0u);
+                rare = rare || (!single && p != 0xFFFFu);
+            }
+            if (rare) {                                                    // runs longer than one bit
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const u32 y = __builtin_amdgcn_alignbit(x[i + 1], x[i], 16);
+                    const u32 e = y >> 16, p = y & 0xFFFFu;
+                    if (p != 0xFFFFu && e - p != 1u) or_set_range(acc, p + 1u, e);
+                }
             }
         }
     }
@@ -218,44 +235,51 @@ void k_agg_or_rows(const u32x4* __restrict__ optab_, u32 n, u32 ncols, int opt_c
     __syncthreads();
     const u32 le_lo = lane >= 31u ? ~0u : (2u << lane) - 1u;
     const u32 le_hi = lane < 32u ? 0u : (lane == 63u ? ~0u : (2u << (lane - 32u)) - 1u);
-    const u32 bit_lo = lane < 32u ? 1u << lane : 0u, bit_hi = lane < 32u ? 0u : 1u << (lane - 32u);
     // operands of this wave: wave + 16 * (64 * batch + j), j = the lane that keeps the record
     const u32 nrows = wave < n ? (n - wave + 15u) / 16u : 0u;
     const u32 nbatch = (nrows + 63u) / 64u;
     auto op_of = [&](u32 b) { return wave + 16u * (64u * b + lane); };
-    u32x4 a0, a1, b0, b1, t0, t1;
+    u32x4 a0, a1, b0, b1, t;
     OrRec cur, nxt;
     or_rec_fetch_a(a0, a1, optab, op_of(0u), n);
     or_rec_fetch_a(b0, b1, optab, op_of(1u), n);
-    or_rec_fetch_b(t0, t1, a0, a1, op_of(0u), n, tile, optab);
-    or_rec_make(cur, a0, a1, t0, t1, op_of(0u), n, tile, dummy);
+    t = or_rec_fetch_b(a0, a1, op_of(0u), n, tile, optab);
+    or_rec_make(cur, a0, a1, t, op_of(0u), n, tile, dummy);
     u32x4 c[DEPTH];
+    const u32 lane16 = lane << 4;
     // a row's load: lanes beyond the row's chunks repeat its last chunk (same address: no extra traffic), an empty row reads
     // the operand table -- every load is issued unconditionally, so the compiler's vmcnt bookkeeping stays exact
     auto issue = [&](u32x4& dst, const OrRec& rec, u32 j) {
-        const u32 nch = TREC_NCH((u32)__builtin_amdgcn_readlane((int)rec.info, (int)j));
-        const u64 a = (u64)(u32)__builtin_amdgcn_readlane((int)rec.alo, (int)j) | ((u64)(u32)__builtin_amdgcn_readlane((int)rec.ahi, (int)j) << 32);
-        const u32 last = nch ? nch - 1u : 0u;
-        dst = ((gcptr4)(uintptr_t)a)[lane < last ? lane : last];
+        const u32 ahi = (u32)__builtin_amdgcn_readlane((int)rec.ahi, (int)j);
+        const u32 nch = OREC_NCH(ahi);
+        const u64 a = (u64)(u32)__builtin_amdgcn_readlane((int)rec.alo, (int)j) | ((u64)(ahi & 0xFFFFu) << 32);
+        const u32 last16 = nch ? (nch - 1u) << 4 : 0u;
+        dst = *(gcptr4)(uintptr_t)(a + (lane16 < last16 ? lane16 : last16));
     };
 #pragma unroll
     for (int k = 0; k < DEPTH; ++k) issue(c[k], cur, (u32)k);
     for (u32 b = 0; b < nbatch; ++b) {
         // the next batch's records (their table entries were requested a batch ago), the table entries of the one after
-        or_rec_fetch_b(t0, t1, b0, b1, op_of(b + 1u), n, tile, optab);
+        t = or_rec_fetch_b(b0, b1, op_of(b + 1u), n, tile, optab);
         u32x4 n0, n1;
         or_rec_fetch_a(n0, n1, optab, op_of(b + 2u), n);
         for (u32 j = 0; j < 64u; j += DEPTH) {
-            if (j + DEPTH == 64u) or_rec_make(nxt, b0, b1, t0, t1, op_of(b + 1u), n, tile, dummy);   // (uniform) first needed by the look-ahead below
+            if (j + DEPTH == 64u) or_rec_make(nxt, b0, b1, t, op_of(b + 1u), n, tile, dummy);   // (uniform) first needed by the look-ahead below
 #pragma unroll
             for (int k = 0; k < DEPTH; ++k) {
                 const u32 jj = j + (u32)k;
-                const u32 info = (u32)__builtin_amdgcn_readlane((int)cur.info, (int)jj);
+                const u32 ahi = (u32)__builtin_amdgcn_readlane((int)cur.ahi, (int)jj);
+                const u32 mlo = (u32)__builtin_amdgcn_readlane((int)cur.mlo, (int)jj), mhi = (u32)__builtin_amdgcn_readlane((int)cur.mhi, (int)jj);
                 // the next chunk's first dword (lane 63: all ones, i.e. "no run")
                 const u32 nx = (u32)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)c[k].x, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
-                or_row_apply(c[k], nx, info, (u32)__builtin_amdgcn_readlane((int)cur.mlo, (int)jj), (u32)__builtin_amdgcn_readlane((int)cur.mhi, (int)jj),
-                             (u32)__builtin_amdgcn_readlane((int)cur.olo, (int)jj), (u32)__builtin_amdgcn_readlane((int)cur.ohi, (int)jj),
-                             lds_dyn, lane, le_lo, le_hi, bit_lo, bit_hi);
+                u32 col = (u32)__popc(mlo & le_lo) + (u32)__popc(mhi & le_hi) - 1u;      // ordinal of this lane's block among the tile's GAP blocks
+                if (!OREC_ALLGAP(ahi))                                                   // (wave-uniform) NULL columns in the tile
+                    col = nth_set_bit16(TREC_GAPMASK((u32)__builtin_amdgcn_readlane((int)cur.info, (int)jj)), col) & 15u;
+#ifdef BMX_DIAG
+                if (opt_compress & 512) { if ((c[k].x ^ c[k].y ^ c[k].z ^ c[k].w ^ nx ^ col) == 0x12345679u) lds_dyn[lane] = 1u; }   // timing probe: the loads alone
+                else
+#endif
+                or_row_apply(c[k], nx, OREC_NCH(ahi), OREC_LONG(ahi) != 0u, lds_dyn + col * 2048u, lane);
                 if (j + DEPTH < 64u) issue(c[k], cur, jj + DEPTH);
                 else issue(c[k], nxt, (u32)k);
             }
@@ -280,7 +304,7 @@ void k_agg_or_rows(const u32x4* __restrict__ optab_, u32 n, u32 ncols, int opt_c
             else {
                 Blk bk;
                 blk_from_lds(bk, lds_dyn + tc * 2048u, lane);
-                kind = store_result_mode(bk, cc, opt_compress ? ST_OPT : ST_FORCE_BIT, slab, desc, st, lane);
+                kind = store_result_mode(bk, cc, (opt_compress & 1) ? ST_OPT : ST_FORCE_BIT, slab, desc, st, lane);
                 pop = uniform32(wave_sum(blk_lane_popcount(bk)));
             }
         }
