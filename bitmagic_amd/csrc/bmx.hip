@@ -10,6 +10,7 @@
 #include "bmx_kernels5.h"
 #include "bmx_kernels6.h"
 #include "bmx_kernels7.h"
+#include "bmx_kernels8.h"
 
 #include <algorithm>
 #include <atomic>
@@ -40,6 +41,7 @@ static int fail_hip(hipError_t e, const char* what, int line) { return bmx_fail_
 
 static void coll_free(bmx_ctx* ctx, size_t idx);
 static void coll_drop_vector(bmx_ctx* ctx, uint64_t uid);
+static bool coll_evict_one(bmx_ctx* ctx);
 static int set_dev(const bmx_ctx* ctx) { HIPCHK(hipSetDevice(ctx->device)); return BMX_OK; }
 
 static size_t pool_round(size_t bytes)
@@ -66,6 +68,8 @@ static int dmalloc(bmx_ctx* ctx, void** p, size_t bytes)
             ctx->pool_free.clear(); ctx->pool_cached = 0;
             e = hipMalloc(p, sz);
         }
+        // packed collections are copies the library made for speed: under memory pressure they go, least recently used first
+        while (e == hipErrorOutOfMemory && coll_evict_one(ctx)) { (void)hipGetLastError(); e = hipMalloc(p, sz); }
         if (e != hipSuccess) return fail_hip(e, "hipMalloc", __LINE__);
     }
     ctx->pool_live[*p] = sz;
@@ -102,14 +106,17 @@ static int ensure(bmx_ctx* ctx, void** buf, size_t* cur, size_t need)
 }
 
 // ---------------------------------------------------------------------------
-// column-major packed GAP collections (bmx_kernels6.h): cache keyed by the operand set
+// column-major packed GAP collections (bmx_kernels6.h, member directory bmx_kernels8.h)
 // ---------------------------------------------------------------------------
 static void coll_free(bmx_ctx* ctx, size_t idx)
 {
     bmx_coll* c = ctx->colls[idx];
     dfree(ctx, c->d_runs); dfree(ctx, c->d_off); dfree(ctx, c->d_cnt); dfree(ctx, c->d_flags); dfree(ctx, c->d_cnt_s);
+    dfree(ctx, c->d_dir); dfree(ctx, c->d_dir_s);
     ctx->pack_bytes -= std::min<uint64_t>(ctx->pack_bytes, c->bytes);
     ctx->colls.erase(ctx->colls.begin() + (long)idx);
+    ++ctx->coll_gen;                                       // pipelines that resolved their groups against a collection look again
+    delete c->index;
     delete c;
 }
 
@@ -117,20 +124,25 @@ static void coll_free(bmx_ctx* ctx, size_t idx)
 static void coll_drop_vector(bmx_ctx* ctx, uint64_t uid)
 {
     for (size_t i = ctx->colls.size(); i-- > 0;)
-        if (std::binary_search(ctx->colls[i]->sorted.begin(), ctx->colls[i]->sorted.end(), uid)) coll_free(ctx, i);
+        if (ctx->colls[i]->index->count(uid)) coll_free(ctx, i);
 }
 
-static u64 coll_hash(const bmx_vec* const* v, size_t n, int polarity)
+// device memory is short: the least recently used collection goes (the caller retries its allocation); false = none left
+static bool coll_evict_one(bmx_ctx* ctx)
 {
-    u64 h = 0x9E3779B97F4A7C15ull ^ (u64)polarity;
-    for (size_t i = 0; i < n; ++i) { h ^= v[i]->uid + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2); }
-    return h;
+    if (ctx->colls.empty() || ctx->coll_building) return false;
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) return false;    // (nothing may still read it)
+    size_t lru = 0;
+    for (size_t i = 1; i < ctx->colls.size(); ++i) if (ctx->colls[i]->last_use < ctx->colls[lru]->last_use) lru = i;
+    coll_free(ctx, lru);
+    for (auto& kv : ctx->pool_free) (void)hipFree(kv.second);             // its blocks went to the pool: give them to the driver
+    ctx->pool_free.clear(); ctx->pool_cached = 0;
+    return true;
 }
 
-// may this operand list go through a packed collection at all?  GAP / NULL / FULL blocks only, enough operands
-static bool coll_eligible(const bmx_ctx* ctx, const bmx_vec* const* v, size_t n, size_t min_n = 64)
+// may this operand list be packed at all?  GAP / NULL / FULL blocks only (and at least one GAP block)
+static bool coll_packable(const bmx_ctx* ctx, const bmx_vec* const* v, size_t n)
 {
-    if (ctx->gap_pack == 0 || n < min_n) return false;
     bool any_gap = false;
     for (size_t i = 0; i < n; ++i) {
         if (!v[i] || v[i]->ctx != ctx || v[i]->counts[BMX_BIT] != 0) return false;
@@ -139,19 +151,39 @@ static bool coll_eligible(const bmx_ctx* ctx, const bmx_vec* const* v, size_t n,
     return any_gap;
 }
 
-static bmx_coll* coll_find(bmx_ctx* ctx, const bmx_vec* const* v, size_t n, int polarity, u64 h)
+// A collection of the wanted polarity that holds EVERY vector of the list (any order, repeats allowed: the unions are
+// idempotent).  members[k] = member index of list element k; full = the list names every member, i.e. the whole column
+// regions can be streamed.  Among several covering collections the one the list fills completely wins, then the smallest.
+static bmx_coll* coll_cover(bmx_ctx* ctx, const uint64_t* uids, size_t n, int polarity, std::vector<u32>* members, bool* full)
 {
+    bmx_coll* best = nullptr; bool best_full = false;
+    std::vector<u32> idx(n);
     for (bmx_coll* c : ctx->colls) {
-        if (c->hash != h || c->polarity != polarity || c->key.size() != n) continue;
-        bool same = true;
-        for (size_t i = 0; i < n && same; ++i) same = c->key[i] == v[i]->uid;
-        if (same) { c->last_use = ++ctx->coll_tick; return c; }
+        if (c->polarity != polarity || !n || c->has_bit) continue;
+        if (!c->index->count(uids[0])) continue;
+        bool all = true;
+        for (size_t i = 0; i < n && all; ++i) {
+            auto it = c->index->find(uids[i]);
+            if (it == c->index->end()) all = false; else idx[i] = it->second;
+        }
+        if (!all) continue;
+        bool f = false;
+        if (n >= c->index->size()) {                       // names every distinct member?
+            std::vector<u8> seen(c->nvec, 0); size_t distinct = 0;
+            for (size_t i = 0; i < n; ++i) if (!seen[idx[i]]) { seen[idx[i]] = 1; ++distinct; }
+            f = distinct == c->index->size();
+        }
+        if (!best || (f && !best_full) || (f == best_full && c->nvec < best->nvec)) {
+            best = c; best_full = f;
+            if (members) *members = idx;
+        }
     }
-    return nullptr;
+    if (best) { best->last_use = ++ctx->coll_tick; if (full) *full = best_full; }
+    return best;
 }
 
 // transposes the GAP blocks of the operand set into column-major interval bags.  Everything runs on the context's stream.
-static int coll_build(bmx_ctx* ctx, const bmx_vec* const* v, size_t n, int polarity, u64 h, bmx_coll** out, const bmx_coll* keep)
+static int coll_build(bmx_ctx* ctx, const bmx_vec* const* v, size_t n, int polarity, bmx_coll** out, const bmx_coll* keep)
 {
     *out = nullptr;
     int rc;
@@ -164,12 +196,14 @@ static int coll_build(bmx_ctx* ctx, const bmx_vec* const* v, size_t n, int polar
     if (!ncols || (ncols + 3u) / 4u > 65535u) return BMX_OK;        // (grid.y of the scatter pass; longer vectors keep the table kernels)
     bmx_coll* c = new (std::nothrow) bmx_coll();
     if (!c) return BMX_ERR_BADALLOC;
-    c->hash = h; c->polarity = polarity; c->ncols = ncols; c->nvec = (uint32_t)n;
-    c->d_runs = nullptr; c->d_off = nullptr; c->d_cnt = nullptr; c->d_flags = nullptr; c->d_cnt_s = nullptr;
-    c->entries = 0; c->bytes = 0; c->has_bit = false; c->build_ms = 0.f; c->alg_bytes = alg;
+    c->polarity = polarity; c->ncols = ncols; c->nvec = (uint32_t)n;
+    c->d_runs = nullptr; c->d_off = nullptr; c->d_cnt = nullptr; c->d_flags = nullptr; c->d_cnt_s = nullptr; c->d_dir = nullptr; c->d_dir_s = nullptr;
+    c->entries = 0; c->bytes = 0; c->has_bit = false; c->build_ms = 0.f; c->alg_bytes = alg; c->prepared = false;
     c->key.resize(n);
-    for (size_t i = 0; i < n; ++i) c->key[i] = v[i]->uid;
-    c->sorted = c->key; std::sort(c->sorted.begin(), c->sorted.end());
+    c->index = new (std::nothrow) std::unordered_map<uint64_t, uint32_t>();
+    if (!c->index) { delete c; return BMX_ERR_BADALLOC; }
+    for (size_t i = 0; i < n; ++i) { c->key[i] = v[i]->uid; c->index->emplace(v[i]->uid, (uint32_t)i); }      // (a repeated vector keeps its first index)
+    struct BuildGuard { bmx_ctx* c; BuildGuard(bmx_ctx* x) : c(x) { ++c->coll_building; } ~BuildGuard() { --c->coll_building; } } guard(ctx);   // (no eviction from under a build)
     void* d_descs = nullptr; void* d_nblk = nullptr; u32* d_pre = nullptr; u32* d_sgl = nullptr; u32* d_words = nullptr;
     const bool split = polarity == 1 && ctx->coll_split != 0;
     hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -177,8 +211,10 @@ static int coll_build(bmx_ctx* ctx, const bmx_vec* const* v, size_t n, int polar
         (void)hipStreamSynchronize(ctx->stream);
         dfree(ctx, d_descs); dfree(ctx, d_nblk); dfree(ctx, d_pre); dfree(ctx, d_sgl); dfree(ctx, d_words);
         dfree(ctx, c->d_runs); dfree(ctx, c->d_off); dfree(ctx, c->d_cnt); dfree(ctx, c->d_flags); dfree(ctx, c->d_cnt_s);
+        dfree(ctx, c->d_dir); dfree(ctx, c->d_dir_s);
         if (e0) (void)hipEventDestroy(e0);
         if (e1) (void)hipEventDestroy(e1);
+        delete c->index;
         delete c;
         return code;
     };
@@ -233,13 +269,23 @@ static int coll_build(bmx_ctx* ctx, const bmx_vec* const* v, size_t n, int polar
                                 (const u64* const*)d_descs, (const u32*)d_nblk, ncols, (u32)polarity, (const u32*)d_pre, (const u64*)c->d_off, c->d_runs);
         e = hipGetLastError();
     }
+    // the member directory (bmx_kernels8.h): the prefixes of the passes above, column-major, with the members' block kinds
+    const size_t dir_bytes = ((size_t)n + 1) * ncols * 4;
+    if (e == hipSuccess && ((rc = dmalloc(ctx, (void**)&c->d_dir, dir_bytes)) || (split && (rc = dmalloc(ctx, (void**)&c->d_dir_s, dir_bytes))))) return fail(rc);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_coll_dir, dim3((ncols + 31) / 32, ((u32)n + 1 + 31) / 32), dim3(1024), 0, ctx->stream, (const u32*)d_pre, (const u32*)d_sgl,
+                           (const u32*)c->d_cnt, (const u32*)c->d_cnt_s, (u32)n, ncols, c->d_dir, c->d_dir_s);
+        e = hipGetLastError();
+    }
     if (e == hipSuccess) e = hipEventRecord(e1, ctx->stream);
     if (e == hipSuccess) e = hipEventSynchronize(e1);
     if (e == hipSuccess) e = hipEventElapsedTime(&c->build_ms, e0, e1);
     if (e != hipSuccess) return fail(fail_hip(e, "coll_build (scatter)", __LINE__));
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     dfree(ctx, d_descs); dfree(ctx, d_nblk); dfree(ctx, d_pre); dfree(ctx, d_sgl); dfree(ctx, d_words);
-    c->bytes = (uint64_t)total * 4 + (uint64_t)ncols * (split ? 20 : 16) + 8;
+    c->bytes = (uint64_t)total * 4 + (uint64_t)ncols * (split ? 20 : 16) + 8 + (uint64_t)dir_bytes * (split ? 2 : 1);
+    c->run_bytes = (uint64_t)total * 4;
+    c->id = ++ctx->coll_next_id;
     c->last_use = ++ctx->coll_tick;
     ctx->last_pack_ms = c->build_ms;
     // make room: least recently used collections go first
@@ -252,28 +298,28 @@ static int coll_build(bmx_ctx* ctx, const bmx_vec* const* v, size_t n, int polar
     }
     ctx->colls.push_back(c);
     ctx->pack_bytes += c->bytes;
+    ++ctx->coll_gen;
     *out = c;
     return BMX_OK;
 }
 
-// the collection of this operand set if there is (or, by the packing policy, should now be) one; *out = nullptr: use the
-// descriptor-table kernels.  force: build at first sight (bmx_collection_prepare, gap_pack 1)
-static int coll_get(bmx_ctx* ctx, const bmx_vec* const* v, size_t n, int polarity, bool force, bmx_coll** out, size_t min_n = 64,
-                    const bmx_coll* keep = nullptr)
+// Which collection serves this operand list?  One that holds every vector of it (coll_cover) -- prepared by
+// bmx_collection_prepare, or, with gap_pack 1, built here at the first use of a list of >= min_n packable vectors.
+// *out = nullptr: none, the descriptor-table kernels take the call.  members / full as coll_cover.
+static int coll_resolve(bmx_ctx* ctx, const bmx_vec* const* v, size_t n, int polarity, size_t min_n, bool may_build, bmx_coll** out,
+                        std::vector<u32>* members, bool* full, const bmx_coll* keep = nullptr)
 {
-    *out = nullptr;
-    if (!coll_eligible(ctx, v, n, min_n)) return BMX_OK;
-    u64 h = coll_hash(v, n, polarity);
-    if (bmx_coll* c = coll_find(ctx, v, n, polarity, h)) { *out = c; return BMX_OK; }
-    if (!force && ctx->gap_pack != 1) {
-        if (ctx->coll_seen.size() > 4096) ctx->coll_seen.clear();
-        if (++ctx->coll_seen[h] < 2u) return BMX_OK;        // first sighting of this set: not worth a transposition yet
-    }
+    *out = nullptr; *full = false;
+    if (ctx->gap_pack == 0 || !n || (ctx->colls.empty() && !(ctx->gap_pack == 1 && may_build))) return BMX_OK;
+    std::vector<uint64_t> uids(n);
+    for (size_t i = 0; i < n; ++i) { if (!v[i] || v[i]->ctx != ctx || v[i]->counts[BMX_BIT]) return BMX_OK; uids[i] = v[i]->uid; }
+    if (bmx_coll* c = coll_cover(ctx, uids.data(), n, polarity, members, full)) { *out = c; return BMX_OK; }
+    if (ctx->gap_pack != 1 || !may_build || n < min_n || !coll_packable(ctx, v, n)) return BMX_OK;
     uint64_t need = 0;
     for (size_t i = 0; i < n; ++i) need += 2ull * v[i]->gap_words;
     if (need > ctx->pack_cap) return BMX_OK;
-    int rc = coll_build(ctx, v, n, polarity, h, out, keep);
-    ctx->coll_seen.erase(h);
+    int rc = coll_build(ctx, v, n, polarity, out, keep);
+    if (!rc && *out) { *full = true; if (members) { members->resize(n); for (size_t i = 0; i < n; ++i) (*members)[i] = (*(*out)->index)[uids[i]]; } }
     return rc;
 }
 
@@ -321,26 +367,47 @@ static int coll_launch(int mode, bmx_ctx* ctx, const bmx_coll* a, const bmx_coll
     return BMX_OK;
 }
 
-// the packed form of an AND list + SUB list, if both can (and by policy should) be used: *a = nullptr otherwise
-static int coll_get_and_sub(bmx_ctx* ctx, const bmx_vec* const* va, size_t na, const bmx_vec* const* vs, size_t ns,
-                            bmx_coll** a, bmx_coll** s)
+// the collections of an AND list + SUB list, if both lists are served by one: *a = nullptr otherwise.  full = both lists
+// name their whole collection (the streaming kernel applies); else ma / ms are the member indices for k_coll_members
+static int coll_resolve_and_sub(bmx_ctx* ctx, const bmx_vec* const* va, size_t na, const bmx_vec* const* vs, size_t ns,
+                                bmx_coll** a, bmx_coll** s, std::vector<u32>* ma, std::vector<u32>* ms, bool* full)
 {
-    *a = nullptr; *s = nullptr;
-    if (!coll_eligible(ctx, va, na)) return BMX_OK;
-    if (ns && !coll_eligible(ctx, vs, ns, 1)) {
-        // a SUB list without GAP blocks (NULL / FULL only) has nothing to pack but is still fine: flags only -- keep it simple:
-        // such lists and lists with bit-blocks take the descriptor-table kernels
-        return BMX_OK;
-    }
-    int rc = coll_get(ctx, va, na, 0, false, a);
+    *a = nullptr; *s = nullptr; *full = false;
+    bool fa = false, fs = true;
+    int rc = coll_resolve(ctx, va, na, 0, 64, true, a, ma, &fa);
     if (rc || !*a) return rc;
     if (ns) {
-        rc = coll_get(ctx, vs, ns, 1, true, s, 1, *a);      // the AND bag exists: its SUB partner is built with it (and must not evict it)
+        rc = coll_resolve(ctx, vs, ns, 1, 1, true, s, ms, &fs, *a);       // (built with gap_pack 1: must not evict its AND partner)
         if (rc) return rc;
         if (!*s) *a = nullptr;
     }
+    *full = fa && fs;
     return BMX_OK;
 }
+
+static CollView coll_view(const bmx_coll* c)
+{
+    if (!c) return CollView{nullptr, nullptr, nullptr, nullptr, 0u, 0u};
+    return CollView{c->d_runs, c->d_off, c->d_dir, c->d_dir_s, c->nvec, c->ncols};
+}
+
+// k_coll_members over [col_from, col_to): d_midx / d_groups are device arrays (member indices, arg-groups)
+static int coll_members_launch(int mode, bmx_ctx* ctx, const bmx_coll* a, const bmx_coll* s, const u32* d_midx, const CollGroup* d_groups, u32 ngroups,
+                               u32 col_from, u32 col_to, int opt_compress, u64* d_counts, bmx_vec* v, BlockStat* st)
+{
+    if (col_to <= col_from) return BMX_OK;
+#define CM_ARGS dim3(col_to - col_from), dim3(512), 0, ctx->stream, coll_view(a), coll_view(s), d_midx, d_groups, ngroups, col_from, col_to, opt_compress, \
+        d_counts, v ? v->d_bits : (uint4*)nullptr, v ? v->d_desc : (u64*)nullptr, st
+    if (mode == CM_OR_STORE) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_coll_members<CM_OR_STORE, 512>), CM_ARGS);
+    else if (mode == CM_AND_STORE) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_coll_members<CM_AND_STORE, 512>), CM_ARGS);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_coll_members<CM_AND_COUNT, 512>), CM_ARGS);
+#undef CM_ARGS
+    KCHK();
+    return BMX_OK;
+}
+
+// one arg-group for a one-shot call: member indices (A list, then S list) + the group record, staged to the device
+static int coll_members_upload(bmx_ctx* ctx, const std::vector<u32>& ma, const std::vector<u32>& ms, void** d_buf, const u32** d_midx, const CollGroup** d_groups);
 
 // Small host tables (operand pointer lists, pipeline metadata) go through a pinned ring: the copy is truly
 // asynchronous, the caller's buffer may die on return, and nobody has to synchronise the stream for it.  A region of
@@ -361,6 +428,21 @@ static int h2d_staged(bmx_ctx* ctx, void* dst, const void* src, size_t bytes)
     ctx->stage_off += need;
     HIPCHK(hipMemcpyAsync(dst, s, bytes, hipMemcpyHostToDevice, ctx->stream));
     HIPCHK(hipEventRecord(ctx->ev_stage, ctx->stream));
+    return BMX_OK;
+}
+
+static int coll_members_upload(bmx_ctx* ctx, const std::vector<u32>& ma, const std::vector<u32>& ms, void** d_buf, const u32** d_midx, const CollGroup** d_groups)
+{
+    const size_t nm = ma.size() + ms.size(), goff = (nm * 4 + 15) & ~(size_t)15;
+    std::vector<u8> h(goff + sizeof(CollGroup));
+    if (!ma.empty()) memcpy(h.data(), ma.data(), ma.size() * 4);
+    if (!ms.empty()) memcpy(h.data() + ma.size() * 4, ms.data(), ms.size() * 4);
+    const CollGroup g{0u, (u32)ma.size(), (u32)ma.size(), (u32)ms.size()};
+    memcpy(h.data() + goff, &g, sizeof(g));
+    *d_buf = nullptr;
+    int rc;
+    if ((rc = dmalloc(ctx, d_buf, h.size())) || (rc = h2d_staged(ctx, *d_buf, h.data(), h.size()))) { dfree(ctx, *d_buf); *d_buf = nullptr; return rc; }
+    *d_midx = (const u32*)*d_buf; *d_groups = (const CollGroup*)((const char*)*d_buf + goff);
     return BMX_OK;
 }
 
@@ -515,6 +597,7 @@ int bmx_ctx_create(int device, void* stream, bmx_ctx** out)
     CTXCHK(hipMemsetAsync(ctx->d_done2, 0, FOLD_DONE_WORDS * 4, ctx->stream));
 #undef CTXCHK
     { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, device) == hipSuccess && v > 0) ctx->max_lds_bytes = (uint32_t)v; else (void)hipGetLastError(); }
+    { size_t fr = 0, tot = 0; if (hipMemGetInfo(&fr, &tot) == hipSuccess && fr) ctx->pack_cap = (uint64_t)fr / 4; else (void)hipGetLastError(); }   // packed copies: at most a quarter of what is free now
     if (const char* e = getenv("BMX_PACK_MAX_MB")) { long long mb = atoll(e); if (mb >= 0) ctx->pack_cap = (uint64_t)mb << 20; }
     if (const char* e = getenv("BMX_POOL_MAX_MB")) { long long mb = atoll(e); if (mb >= 0) ctx->pool_cap = (uint64_t)mb << 20; }
     // launch-shape knobs from the environment go through the same validation as bmx_ctx_set_tuning;
@@ -657,15 +740,28 @@ int bmx_ctx_mem_used(const bmx_ctx* ctx, uint64_t* bytes)
 
 int bmx_collection_prepare(bmx_ctx* ctx, const bmx_vec* const* vecs, size_t n, int role)
 {
-    ARGCHK(ctx && (n == 0 || vecs) && (role == BMX_ROLE_OR || role == BMX_ROLE_AND || role == BMX_ROLE_SUB));
+    ARGCHK(ctx && n > 0 && vecs && (role == BMX_ROLE_OR || role == BMX_ROLE_AND || role == BMX_ROLE_SUB));
     int rc = set_dev(ctx); if (rc) return rc;
     for (size_t i = 0; i < n; ++i) if (!vecs[i] || vecs[i]->ctx != ctx) { g_last_error = "operand is null or belongs to another context"; return BMX_ERR_BADARG; }
-    if (!coll_eligible(ctx, vecs, n, role == BMX_ROLE_SUB ? 1 : 64)) {
-        g_last_error = "not packable: needs >= 64 operands (SUB list: >= 1) made of GAP / NULL / FULL blocks only, and gap_pack != 0";
+    if (ctx->gap_pack == 0 || !coll_packable(ctx, vecs, n) || n > 65535) {
+        g_last_error = "not packable: needs 1..65535 vectors made of GAP / NULL / FULL blocks only (at least one GAP block), and gap_pack != 0";
         return BMX_ERR_BADARG;
     }
+    const int polarity = role == BMX_ROLE_AND ? 0 : 1;
+    for (bmx_coll* c : ctx->colls) {                         // the same list in the same role is already there
+        if (c->polarity != polarity || c->key.size() != n) continue;
+        bool same = true;
+        for (size_t i = 0; i < n && same; ++i) same = c->key[i] == vecs[i]->uid;
+        if (same) { c->prepared = true; c->last_use = ++ctx->coll_tick; return BMX_OK; }
+    }
+    uint64_t need = 0;
+    for (size_t i = 0; i < n; ++i) need += 2ull * vecs[i]->gap_words;
+    if (need > ctx->pack_cap) { g_last_error = "collection larger than the packing budget (BMX_PACK_MAX_MB)"; return BMX_ERR_BADALLOC; }
     bmx_coll* c = nullptr;
-    return coll_get(ctx, vecs, n, role == BMX_ROLE_AND ? 0 : 1, true, &c, role == BMX_ROLE_SUB ? 1 : 64);
+    rc = coll_build(ctx, vecs, n, polarity, &c, nullptr);
+    if (!rc && !c) { g_last_error = "vectors too long for a packed collection"; return BMX_ERR_RANGE; }
+    if (!rc) c->prepared = true;
+    return rc;
 }
 
 int bmx_ctx_pack_stats(const bmx_ctx* ctx, uint32_t* n_collections, uint64_t* bytes, float* last_build_ms)
@@ -724,6 +820,7 @@ static bmx_vec* vec_alloc_host(bmx_ctx* ctx, uint64_t nbits, uint32_t nblocks)
     static std::atomic<uint64_t> next_uid{1};
     v->uid = next_uid.fetch_add(1);
     v->ctx = ctx; v->nbits = nbits; v->nblocks = nblocks;
+    ctx->live_vecs[v->uid] = v;
     return v;
 }
 
@@ -766,6 +863,7 @@ int bmx_vec_free(bmx_ctx* ctx, bmx_vec* v)
     int rc = set_dev(ctx); if (rc) return rc;
     HIPCHK(hipStreamSynchronize(ctx->stream));
     coll_drop_vector(ctx, v->uid);
+    ctx->live_vecs.erase(v->uid);
     dfree(ctx, v->d_desc); dfree(ctx, v->d_bits); dfree(ctx, v->d_gaps); dfree(ctx, v->d_ord); dfree(ctx, v->d_tdir);
     delete v;
     return BMX_OK;
@@ -1141,13 +1239,14 @@ int bmx_pipeline_create(bmx_ctx* ctx, const bmx_vec* const* and_list, const uint
     p->nbits = max_bits;
     p->h_row_off = new std::vector<u32>(row_off, row_off + ngroups);
     p->h_and_n = new std::vector<u32>(m_and_n, m_and_n + ngroups);
-    if (ngroups == 1 && has_gap && !has_bit && ctx->gap_pack != 0 && tot_and >= 64) {
-        // one arg-group over GAP-only operands: remember the operand vectors (like the reference's pipeline, :2939) so that
-        // a run can go through the packed collection of the set
-        p->h_vecs = new std::vector<const bmx_vec*>();
-        p->h_vecs->reserve(tot_and + tot_sub);
-        for (size_t i = 0; i < tot_and; ++i) p->h_vecs->push_back(and_list[i]);
-        for (size_t i = 0; i < tot_sub; ++i) p->h_vecs->push_back(sub_list[i]);
+    p->h_sub_n = new std::vector<u32>(m_sub_n, m_sub_n + ngroups);
+    if (has_gap && !has_bit && tot_and) {
+        // GAP-only operands: remember WHICH vectors (uids, not pointers) so that a run can be served by the packed collections
+        // that hold them (the reference's pipeline keeps bvector pointers, :2939; here a freed vector is just not found)
+        p->h_uids = new std::vector<uint64_t>();
+        p->h_uids->reserve(tot_and + tot_sub);
+        for (size_t i = 0; i < tot_and; ++i) p->h_uids->push_back(and_list[i]->uid);
+        for (size_t i = 0; i < tot_sub; ++i) p->h_uids->push_back(sub_list[i]->uid);
     }
     // distinct vectors of the pipeline (pipeline::unique_vectors(), src/bmaggregator.h:301) and the
     // (AND | SUB << 16) plane masks of every group, 16 planes per chunk -- only where the staged kernel can be chosen
@@ -1217,7 +1316,8 @@ int bmx_pipeline_destroy(bmx_ctx* ctx, bmx_pipeline* p)
     HIPCHK(hipStreamSynchronize(ctx->stream));
     dfree(ctx, p->d_dmat); dfree(ctx, p->d_meta); dfree(ctx, (void*)p->d_descs);
     dfree(ctx, (void*)p->d_udesc); dfree(ctx, p->d_unblk); dfree(ctx, p->d_gmask); dfree(ctx, p->d_gskip);
-    delete p->h_row_off; delete p->h_and_n; delete p->h_vecs;
+    dfree(ctx, p->cm_buf);
+    delete p->h_row_off; delete p->h_and_n; delete p->h_sub_n; delete p->h_uids;
     delete p;
     return BMX_OK;
 }
@@ -1244,9 +1344,83 @@ static bool use_gapcount(const bmx_ctx* ctx, const bmx_pipeline* p, uint64_t ops
     // 1.65 -> 1.57 ms, ~265 words (0.1 %) 1.58 -> 1.54 ms -- below that the per-column scan and zeroing stop paying off
     return (uint64_t)p->n_ops >= 32ull * p->ngroups && p->gap_avg_words >= 240u;
 }
+// The arg-groups of a GAP-only pipeline against the collections in force: every AND list inside ONE polarity-0 collection
+// and every SUB list inside ONE polarity-1 collection => the groups become member-index lists (k_coll_members), or -- one
+// group naming whole collections -- the streaming kernel.  Looked at again whenever a collection appeared or went.
+// may_build: the synchronous entries may build the collections of a one-group pipeline under gap_pack 1; the asynchronous
+// (_dev) entry never builds (it must not block the host or put a transposition into the caller's timed region).
+static bmx_coll* coll_by_id(bmx_ctx* ctx, uint64_t id)
+{
+    if (!id) return nullptr;
+    for (bmx_coll* c : ctx->colls) if (c->id == id) return c;
+    return nullptr;
+}
+static int pipe_resolve_colls(bmx_ctx* ctx, bmx_pipeline* p, bool may_build, bmx_coll** a, bmx_coll** s)
+{
+    *a = nullptr; *s = nullptr;
+    if (!p->h_uids || ctx->gap_pack == 0) return BMX_OK;
+    size_t tot_and = 0, tot_sub = 0;
+    for (u32 g = 0; g < p->ngroups; ++g) { tot_and += (*p->h_and_n)[g]; tot_sub += (*p->h_sub_n)[g]; }
+    if (p->cm_gen != ctx->coll_gen || (may_build && ctx->gap_pack == 1 && !p->cm_a_id)) {
+        int rc;
+        if (p->cm_buf) { HIPCHK(hipStreamSynchronize(ctx->stream)); dfree(ctx, p->cm_buf); p->cm_buf = nullptr; }
+        p->cm_a_id = p->cm_s_id = 0; p->cm_full = false;
+        std::vector<u32> ma, ms; bool fa = false, fs = true;
+        const uint64_t* uids = p->h_uids->data();
+        bmx_coll* ca = coll_cover(ctx, uids, tot_and, 0, &ma, &fa);
+        bmx_coll* cs = (ca && tot_sub) ? coll_cover(ctx, uids + tot_and, tot_sub, 1, &ms, &fs) : nullptr;
+        if (!ca && may_build && ctx->gap_pack == 1 && p->ngroups == 1 && tot_and >= 64) {
+            // one arg-group of >= 64 packable vectors, first synchronous run: build its collections now (gap_pack 1)
+            std::vector<const bmx_vec*> va, vs;
+            bool ok = true;
+            for (size_t i = 0; i < tot_and + tot_sub && ok; ++i) {
+                auto it = ctx->live_vecs.find(uids[i]);
+                if (it == ctx->live_vecs.end()) ok = false; else (i < tot_and ? va : vs).push_back(it->second);
+            }
+            if (ok) {
+                bool full = false;
+                if ((rc = coll_resolve_and_sub(ctx, va.data(), va.size(), vs.data(), vs.size(), &ca, &cs, &ma, &ms, &full))) return rc;
+                fa = fs = full;
+            }
+        }
+        p->cm_gen = ctx->coll_gen;
+        if (ca && (!tot_sub || cs)) {
+            p->cm_a_id = ca->id; p->cm_s_id = cs ? cs->id : 0;
+            p->cm_full = p->ngroups == 1 && fa && (!tot_sub || fs);
+            // member indices (AND lists of all groups, then SUB lists) + one CollGroup per arg-group
+            const size_t goff = ((tot_and + tot_sub) * 4 + 15) & ~(size_t)15;
+            std::vector<u8> h(goff + (size_t)p->ngroups * sizeof(CollGroup));
+            if (tot_and) memcpy(h.data(), ma.data(), tot_and * 4);
+            if (tot_sub) memcpy(h.data() + tot_and * 4, ms.data(), tot_sub * 4);
+            CollGroup* gr = reinterpret_cast<CollGroup*>(h.data() + goff);
+            u32 ao = 0, so = (u32)tot_and;
+            for (u32 g = 0; g < p->ngroups; ++g) {
+                gr[g] = CollGroup{ao, (*p->h_and_n)[g], so, (*p->h_sub_n)[g]};
+                ao += (*p->h_and_n)[g]; so += (*p->h_sub_n)[g];
+            }
+            if ((rc = dmalloc(ctx, &p->cm_buf, h.size())) || (rc = h2d_staged(ctx, p->cm_buf, h.data(), h.size()))) {
+                dfree(ctx, p->cm_buf); p->cm_buf = nullptr; p->cm_a_id = p->cm_s_id = 0; return rc;
+            }
+            p->cm_groups_off = goff;
+        }
+    }
+    *a = coll_by_id(ctx, p->cm_a_id);
+    *s = coll_by_id(ctx, p->cm_s_id);
+    if (!*a || (p->cm_s_id && !*s)) { *a = nullptr; *s = nullptr; return BMX_OK; }
+    (*a)->last_use = ++ctx->coll_tick; if (*s) (*s)->last_use = ctx->coll_tick;
+    return BMX_OK;
+}
+
+static int pipeline_run_counts_impl(bmx_ctx* ctx, bmx_pipeline* p, uint32_t nb_from, uint32_t nb_to, uint64_t* d_counts, bool may_build);
+
 extern "C" {
 
 int bmx_pipeline_run_counts_dev(bmx_ctx* ctx, bmx_pipeline* p, uint32_t nb_from, uint32_t nb_to, uint64_t* d_counts)
+{
+    return pipeline_run_counts_impl(ctx, p, nb_from, nb_to, d_counts, false);
+}
+
+static int pipeline_run_counts_impl(bmx_ctx* ctx, bmx_pipeline* p, uint32_t nb_from, uint32_t nb_to, uint64_t* d_counts, bool may_build)
 {
     ARGCHK(ctx && p && p->ctx == ctx && d_counts);
     int rc = set_dev(ctx); if (rc) return rc;
@@ -1255,6 +1429,14 @@ int bmx_pipeline_run_counts_dev(bmx_ctx* ctx, bmx_pipeline* p, uint32_t nb_from,
     u64 nitems64 = (u64)(nb_to - nb_from) * p->ngroups;
     if (!nitems64) return BMX_OK;
     const u32* row_off = p->d_meta; const u32* and_n = p->d_meta + p->ngroups; const u32* sub_n = p->d_meta + 2 * p->ngroups;
+    if (p->h_uids) {
+        // GAP-only operands held by packed collections: the column regions of the collections instead of the operands' slabs
+        bmx_coll *ca = nullptr, *cs = nullptr;
+        if ((rc = pipe_resolve_colls(ctx, p, may_build, &ca, &cs))) return rc;
+        if (ca && p->cm_full) return coll_launch(COLL_AND_COUNT, ctx, ca, cs, nb_from, nb_to, 1, (u64*)d_counts, nullptr, nullptr, 0u, 0xFFFFFFFFu);
+        if (ca) return coll_members_launch(CM_AND_COUNT, ctx, ca, cs, (const u32*)p->cm_buf, (const CollGroup*)((const char*)p->cm_buf + p->cm_groups_off),
+                                           p->ngroups, nb_from, nb_to, 1, (u64*)d_counts, nullptr, nullptr);
+    }
     {
         // many groups over few distinct vectors: every plane block is re-used >= 8 times per column
         bool reuse = p->ngroups >= 32 && (uint64_t)p->n_ops >= 8ull * p->nplanes;
@@ -1311,13 +1493,6 @@ int bmx_pipeline_run_counts_dev(bmx_ctx* ctx, bmx_pipeline* p, uint32_t nb_from,
         return BMX_OK;
     }
     if (nitems64 > 0xFFFFFFF0ull) { g_last_error = "too many (column, group) items in one run"; return BMX_ERR_RANGE; }
-    if (p->h_vecs && !p->has_bit) {
-        // one arg-group over GAP-only operands seen before: the packed collection of the operand set (bmx_kernels6.h)
-        bmx_coll *ca = nullptr, *cs = nullptr;
-        const size_t na = (*p->h_and_n)[0], ns = p->h_vecs->size() - na;
-        if ((rc = coll_get_and_sub(ctx, p->h_vecs->data(), na, p->h_vecs->data() + na, ns, &ca, &cs))) return rc;
-        if (ca) return coll_launch(COLL_AND_COUNT, ctx, ca, cs, nb_from, nb_to, 1, (u64*)d_counts, nullptr, nullptr, 0u, 0xFFFFFFFFu);
-    }
     if (use_gapcount(ctx, p)) {
         // every operand block is GAP (or NULL / FULL): the counting formulation, one 1024-thread workgroup per (column, group)
         size_t lds = (size_t)(16384 * 2 + 2048) * 4;
@@ -1360,13 +1535,14 @@ int bmx_pipeline_describe(bmx_ctx* ctx, bmx_pipeline* p, uint32_t nb_from, uint3
     int rc = pipe_range(p, nb_from, nb_to); if (rc) return rc;
     u64 nitems64 = (u64)(nb_to - nb_from) * p->ngroups;
     bool reuse = p->ngroups >= 32 && (uint64_t)p->n_ops >= 8ull * p->nplanes;
-    if (p->staged_ok && (ctx->pipe_staged == 1 || (ctx->pipe_staged < 0 && reuse)))
+    if (p->h_uids && ctx->gap_pack != 0 && p->cm_gen == ctx->coll_gen && coll_by_id(ctx, p->cm_a_id) && (!p->cm_s_id || coll_by_id(ctx, p->cm_s_id))) {
+        if (p->cm_full) snprintf(buf, buf_len, "k_coll_apply<AND_COUNT,512> x 1 launch, %llu workgroups (packed collection of the operand set)", (unsigned long long)nitems64);
+        else snprintf(buf, buf_len, "k_coll_members<AND_COUNT,512> x 1 launch, %u workgroups x %u groups (members of a packed collection)", nb_to - nb_from, p->ngroups);
+    }
+    else if (p->staged_ok && (ctx->pipe_staged == 1 || (ctx->pipe_staged < 0 && reuse)))
         snprintf(buf, buf_len, "k_pipe_counts_staged<%d> x 1 launch, %u workgroups", ctx->pipe_slots, nb_to - nb_from);
     else if (use_split(ctx, p, nitems64))
         snprintf(buf, buf_len, "k_pipe_split<2,%d> x 1 launch, %llu workgroups", SPLIT_WAVES, (unsigned long long)nitems64);
-    else if (p->h_vecs && !p->has_bit && ctx->gap_pack != 0 &&
-             coll_find(ctx, p->h_vecs->data(), (*p->h_and_n)[0], 0, coll_hash(p->h_vecs->data(), (*p->h_and_n)[0], 0)))
-        snprintf(buf, buf_len, "k_coll_apply<AND_COUNT,512> x 1 launch, %llu workgroups (packed collection of the operand set)", (unsigned long long)nitems64);
     else if (use_gapcount(ctx, p))
         snprintf(buf, buf_len, "k_pipe_counts_gapcount x 1 launch, %llu workgroups", (unsigned long long)nitems64);
     else if (p->has_gap)
@@ -1391,7 +1567,7 @@ int bmx_pipeline_run_counts(bmx_ctx* ctx, bmx_pipeline* p, uint32_t nb_from, uin
     size_t bytes = (size_t)p->ngroups * 8;
     if (p->ngroups <= 64) d_counts = ctx->d_small;
     else if ((rc = dmalloc(ctx, (void**)&d_counts, bytes))) return rc;
-    rc = bmx_pipeline_run_counts_dev(ctx, p, nb_from, nb_to, d_counts);
+    rc = pipeline_run_counts_impl(ctx, p, nb_from, nb_to, d_counts, true);
     if (!rc) {
         hipError_t e = hipMemcpyAsync(counts_out, d_counts, bytes, hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
@@ -1759,7 +1935,7 @@ static int agg_or_impl(bmx_ctx* ctx, const bmx_vec* const* src, size_t n, int op
         has_bit |= src[i]->counts[BMX_BIT] != 0;
     }
     bmx_vec* v; BlockStat* st; u32* offs;
-    bmx_coll* packed = nullptr;
+    bmx_coll* packed = nullptr; std::vector<u32> members; bool packed_full = false;
     if ((rc = result_begin(ctx, nbits, ncols, &v, &st, &offs))) return rc;      // empty list => cleared target (:1105)
     if (use_direct(ctx, ncols, n)) {
         void* d_tab = nullptr;
@@ -1769,8 +1945,19 @@ static int agg_or_impl(bmx_ctx* ctx, const bmx_vec* const* src, size_t n, int op
         else (void)hipStreamSynchronize(ctx->stream);
         dfree(ctx, d_tab);
         if (rc) { bmx_vec_free(ctx, v); return rc; }
-    } else if (n >= 64 && ncols && has_gap && !has_bit && (rc = coll_get(ctx, src, n, 1, false, &packed)) == BMX_OK && packed) {
-        // many GAP-only operands, seen before: one sequential stream per block column (packed collection, bmx_kernels6.h)
+    } else if (n >= 16 && ncols && has_gap && !has_bit && (rc = coll_resolve(ctx, src, n, 1, 64, true, &packed, &members, &packed_full)) == BMX_OK && packed && !packed_full) {
+        // GAP-only operands that are SOME of the vectors of a packed collection: their pieces of its column regions
+        // (k_coll_members, bmx_kernels8.h)
+        void* d_buf = nullptr; const u32* d_midx = nullptr; const CollGroup* d_groups = nullptr;
+        if ((rc = coll_members_upload(ctx, members, std::vector<u32>(), &d_buf, &d_midx, &d_groups))) { bmx_vec_free(ctx, v); return rc; }
+        rc = coll_members_launch(CM_OR_STORE, ctx, packed, nullptr, d_midx, d_groups, 1u, 0u, ncols, opt_compress, nullptr, v, st);
+        if (!rc) rc = result_finish(ctx, v, st, offs);
+        else (void)hipStreamSynchronize(ctx->stream);
+        dfree(ctx, d_buf);
+        if (rc) { bmx_vec_free(ctx, v); return rc; }
+    } else if (rc) { bmx_vec_free(ctx, v); return rc;
+    } else if (packed) {
+        // GAP-only operands = ALL the vectors of a packed collection: one sequential stream per block column (bmx_kernels6.h)
         // without opt_compress no GAP block can come out: the kernel folds the kind counts of its result itself and, when every
         // block turned out to be a bit-block (the OR of thousands of sparse vectors), the layout scan is skipped (one launch
         // window only: the fold's tickets count the workgroups of ONE launch)
@@ -1967,17 +2154,26 @@ int bmx_agg_and_sub(bmx_ctx* ctx, const bmx_vec* const* src_and, size_t n_and,
         return BMX_OK;
     }
     {
-        // GAP-only operand sets seen before: packed collections, one sequential stream per block column (bmx_kernels6.h)
+        // GAP-only operands held by packed collections: the whole column regions (the lists name every vector of their
+        // collections, bmx_kernels6.h) or the lists' pieces of them (k_coll_members, bmx_kernels8.h)
         bmx_coll *ca = nullptr, *cs = nullptr;
+        std::vector<u32> ma, ms; bool full = false;
         bool ok = true;
         for (size_t i = 0; i < n_and && ok; ++i) ok = src_and[i]->ctx == ctx;
         for (size_t i = 0; i < n_sub && ok; ++i) ok = src_sub[i]->ctx == ctx;
-        if (ok && ncols && (rc = coll_get_and_sub(ctx, src_and, n_and, src_sub, n_sub, &ca, &cs))) return rc;
+        if (ok && ncols && (rc = coll_resolve_and_sub(ctx, src_and, n_and, src_sub, n_sub, &ca, &cs, &ma, &ms, &full))) return rc;
         if (ca) {
             if ((rc = result_begin(ctx, nbits, ncols, &v, &st, &offs))) return rc;
-            rc = coll_launch(COLL_AND_STORE, ctx, ca, cs, 0u, ncols, 1, nullptr, v, st, 0u, 0xFFFFFFFFu);
+            void* d_buf = nullptr;
+            if (full) rc = coll_launch(COLL_AND_STORE, ctx, ca, cs, 0u, ncols, 1, nullptr, v, st, 0u, 0xFFFFFFFFu);
+            else {
+                const u32* d_midx = nullptr; const CollGroup* d_groups = nullptr;
+                rc = coll_members_upload(ctx, ma, ms, &d_buf, &d_midx, &d_groups);
+                if (!rc) rc = coll_members_launch(CM_AND_STORE, ctx, ca, cs, d_midx, d_groups, 1u, 0u, ncols, 1, nullptr, v, st);
+            }
             if (!rc) rc = result_finish(ctx, v, st, offs);
             else (void)hipStreamSynchronize(ctx->stream);
+            dfree(ctx, d_buf);
             if (rc) { bmx_vec_free(ctx, v); return rc; }
             if (any) *any = (v->counts[BMX_FULL] + v->counts[BMX_BIT] + v->counts[BMX_GAP]) != 0;
             *result = v;
@@ -2038,7 +2234,12 @@ static int run_results_impl(bmx_ctx* ctx, bmx_pipeline* p, uint32_t nb_from, uin
         if (!(*p->h_and_n)[g] || !p->ncols) continue;                       // empty AND group: skipped (:1352)
         bmx_vec* v; BlockStat* st; u32* offs;
         if ((rc = result_begin(ctx, p->nbits, p->ncols, &v, &st, &offs))) { cleanup(); return rc; }
-        if ((rc = agg_and_sub_launch(ctx, p, g, v, st, nb_from, nb_to))) { bmx_vec_free(ctx, v); cleanup(); return rc; }
+        bmx_coll *ca = nullptr, *cs = nullptr;
+        if (p->h_uids && nb_from == 0 && nb_to >= p->ncols && (rc = pipe_resolve_colls(ctx, p, false, &ca, &cs))) { bmx_vec_free(ctx, v); cleanup(); return rc; }
+        if (ca) rc = coll_members_launch(CM_AND_STORE, ctx, ca, cs, (const u32*)p->cm_buf, (const CollGroup*)((const char*)p->cm_buf + p->cm_groups_off) + g,
+                                         1u, 0u, p->ncols, 1, nullptr, v, st);       // (the group's members inside the packed collections)
+        else rc = agg_and_sub_launch(ctx, p, g, v, st, nb_from, nb_to);
+        if (rc) { bmx_vec_free(ctx, v); cleanup(); return rc; }
         if ((rc = result_finish(ctx, v, st, offs))) { bmx_vec_free(ctx, v); cleanup(); return rc; }
         if (v->counts[BMX_FULL] + v->counts[BMX_BIT] + v->counts[BMX_GAP] == 0) { bmx_vec_free(ctx, v); continue; }   // nothing found: stays NULL (:1406)
         res[g] = v;

@@ -66,9 +66,11 @@ struct bmx_ctx {
     int or_depth = 4;          // ... rows (operands) in flight per wave: 4 or 8
     // column-major packed GAP collections (bmx_kernels6.h), cached by operand set
     std::vector<struct bmx_coll*> colls;
-    std::unordered_map<u64, u32> coll_seen;   // hash of an operand set -> sightings so far (automatic packing waits for the second)
-    int gap_pack = -1;         // aggregation over >= 64 GAP-only operands through a packed collection: -1 = from the second use of an operand set, 0 = never, 1 = at first use
-    uint64_t pack_cap = 96ull << 30, pack_bytes = 0, coll_tick = 0;
+    int gap_pack = -1;         // aggregation over GAP-only operands through a packed collection: -1 = the collections bmx_collection_prepare built, 0 = never, 1 = also build one at the first use of a list of >= 64 packable vectors
+    uint64_t pack_cap = 16ull << 30, pack_bytes = 0, coll_tick = 0;     // pack_cap: a quarter of the device's free memory at context creation (BMX_PACK_MAX_MB overrides)
+    uint64_t coll_gen = 0, coll_next_id = 0;   // coll_gen changes whenever a collection appears or goes: pipelines re-resolve their groups then
+    int coll_building = 0;                     // > 0 while a collection is being built (no eviction from under it)
+    std::unordered_map<uint64_t, struct bmx_vec*> live_vecs;   // uid -> vector, for callers that hold uids (pipelines) instead of pointers
     float last_pack_ms = 0.f;
     uint32_t max_lds_bytes = 160u * 1024u;   // hipDeviceAttributeMaxSharedMemoryPerBlock of the device (queried at creation)
     int coll_split = 1;        // polarity-1 collections keep single-bit runs as 16-bit positions (half the bytes per isolated bit)
@@ -111,24 +113,34 @@ struct bmx_pipeline {
     const u64** d_udesc; u32* d_unblk; u32* d_gmask; u32* d_gskip;
     std::vector<u32>* h_row_off;          // host copy: row offset of each group inside a column record
     std::vector<u32>* h_and_n;            // host copy: AND operands per group
+    std::vector<u32>* h_sub_n = nullptr;  // host copy: SUB operands per group
     u64* d_dmat;
     u32* d_meta;       // row_off | and_n | sub_n | and_off | sub_off (ngroups each) | nblocks (n_ops)
     const u64** d_descs;
     size_t bytes;
-    std::vector<const bmx_vec*>* h_vecs = nullptr;   // single-group pipelines: the operand vectors (AND list, then SUB list) for the packed path
+    // GAP-only pipelines: the uids of the operand vectors (AND lists, then SUB lists, in group order) -- never the pointers: a
+    // vector freed before the pipeline is simply not found in any collection any more -- and what they resolved to
+    std::vector<uint64_t>* h_uids = nullptr;
+    uint64_t cm_gen = ~0ull;            // ctx->coll_gen at the last resolution
+    uint64_t cm_a_id = 0, cm_s_id = 0;  // collections serving the AND lists / SUB lists (0 = none)
+    bool cm_full = false;               // one group whose lists name their whole collections: the streaming kernel
+    void* cm_buf = nullptr;             // device: member indices + CollGroup[ngroups]
+    size_t cm_groups_off = 0;
 };
 
-// a column-major packed interval collection of one operand set (bmx_kernels6.h)
+// a column-major packed interval collection of a set of vectors (bmx_kernels6.h) with its member directory (bmx_kernels8.h)
 struct bmx_coll {
-    std::vector<uint64_t> key;            // uids in list order
-    std::vector<uint64_t> sorted;         // the same, sorted (membership test when a vector is freed)
-    u64 hash; int polarity;
+    std::vector<uint64_t> key;            // member uids in member order
+    std::unordered_map<uint64_t, uint32_t>* index;   // uid -> member index
+    int polarity;
     uint32_t ncols, nvec;
     u32* d_runs; u64* d_off; u32* d_cnt; u32* d_flags;
     u32* d_cnt_s;                         // split bag (polarity 1): single-bit runs per column, kept as 16-bit positions behind the multi-bit runs; else null
-    uint64_t entries, bytes, last_use;
+    u32* d_dir; u32* d_dir_s;             // member directory [ncols][nvec + 1]: entries (split: multi-bit runs) before member i | kind << 30; singles before member i
+    uint64_t entries, bytes, run_bytes, last_use, id;
     uint64_t alg_bytes;                   // algorithmic bytes of the GAP operands: sum of 2 x (len + 1)
     bool has_bit;                         // a bit-block was found while counting: unusable
+    bool prepared;                        // built by bmx_collection_prepare (not by the gap_pack 1 policy)
     float build_ms;
 };
 

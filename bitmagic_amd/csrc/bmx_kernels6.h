@@ -46,7 +46,7 @@ __device__ __forceinline__ u32 coll_runs_of(u32 meta, u32 polarity)
 }
 
 // pass 1: one thread per block column walks the operand list (lanes = consecutive columns: every read of an operand's
-// descriptor table is coalesced): pre[i][c] = entries of column c that precede operand i, cnt[c] = entries of the column,
+// descriptor table is coalesced): pre[i][c] = entries of column c that precede operand i (< 2^30) | operand i's block kind << 30, cnt[c] = entries of the column,
 // flags[c] = FULL / NULL / bit-block marks | GAP operand count << 8
 __global__ __launch_bounds__(256)
 void k_coll_count(const u64* const* __restrict__ descs, const u32* __restrict__ nblk, u32 n, u32 ncols, u32 polarity,
@@ -59,7 +59,7 @@ void k_coll_count(const u64* const* __restrict__ descs, const u32* __restrict__ 
         u32 nb = nblk[i];
         u64 d = c < nb ? descs[i][c] : 0ull;                    // beyond the operand's end: NULL
         u32 k = DESC_K(d);
-        pre[(size_t)i * ncols + c] = run;
+        pre[(size_t)i * ncols + c] = run | (k << 30);             // (the operand's block kind rides in the two top bits: member directory, bmx_kernels8.h)
         if (k == K_GAP) { run += coll_runs_of(GMETA(d), polarity); ++ngap; }
         else if (k == K_FULL) fl |= COLL_FLAG_FULL;
         else if (k == K_NULL) fl |= COLL_FLAG_NULL;
@@ -109,7 +109,7 @@ void k_coll_scatter(const u64* const* __restrict__ descs, const u32* __restrict_
     u32 meta = GMETA(d), len = meta >> 1, s = meta & 1u;
     u32 m_cnt = coll_runs_of(meta, polarity);
     gcptr16 g = as_gc16(DESC_P(d));
-    u32* out = runs + off[c] + pre[(size_t)i * ncols + c];
+    u32* out = runs + off[c] + (pre[(size_t)i * ncols + c] & 0x3FFFFFFFu);
     // run k (1-based) has the value s ^ ((k - 1) & 1) and covers e[k-1]+1 .. e[k] (e[0] = -1; word k of the block = e[k])
     u32 k0 = (s == polarity) ? 1u : 2u;
     for (u32 m = t; m < m_cnt; m += L) {
@@ -205,7 +205,7 @@ void k_coll_scatter_split(const u64* const* __restrict__ descs, const u32* __res
     }
     if (!gap || m0 == m1) return;
     const u64 base = off[c];
-    const u32 ps = pre_s[(size_t)i * ncols + c], pt = pre[(size_t)i * ncols + c];
+    const u32 ps = pre_s[(size_t)i * ncols + c], pt = pre[(size_t)i * ncols + c] & 0x3FFFFFFFu;
     const u32 nm_col = cnt[c] - cnt_s[c];
     u32* om = runs + base + (pt - ps) + (im - nmul);
     u16* os = reinterpret_cast<u16*>(runs + base + ((nm_col + 3u) & ~3u)) + ps + (is - ns);

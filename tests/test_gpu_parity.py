@@ -1462,8 +1462,9 @@ def test_combine_or_row_kernel(port, dq, nvec, long_runs, nblk):
 
 
 def test_packed_collection_policy_and_prepare(port):
-    """gap_pack -1 (default): the first use of an operand set runs the descriptor-table kernels, the second builds the
-    collection; bmx_collection_prepare builds at once; results never depend on which path ran"""
+    """gap_pack -1 (default): collections exist only where bmx_collection_prepare built them -- no aggregation builds one on
+    the side; gap_pack 1: the first use of a list of >= 64 packable vectors builds its collection; results never depend on
+    which path ran"""
     rng = np.random.default_rng(77)
     nbits = 4 * 65536
     words = _sparse_collection(port, rng, 80, nbits, 40, specials=False)
@@ -1473,28 +1474,132 @@ def test_packed_collection_policy_and_prepare(port):
     gv = [bm.bit_import_u32(c, w, True) for w in words]
     agg = bm.aggregator(c)
     e = port.agg_or(pv)
-    assert c.pack_stats()["collections"] == 0
     o1 = agg.combine_or(gv)
-    assert c.pack_stats()["collections"] == 0
     o2 = agg.combine_or(gv)
+    assert c.pack_stats()["collections"] == 0                # default policy: nothing is built behind the caller's back
+    c.collection_prepare(gv, bm.ROLE_OR)
     st = c.pack_stats()
     assert st["collections"] == 1 and st["bytes"] > 0 and st["last_build_ms"] > 0
-    o3 = agg.combine_or(gv)
+    c.collection_prepare(gv, bm.ROLE_OR)                      # the same list in the same role: already there
     assert c.pack_stats()["collections"] == 1
-    for o in (o1, o2, o3):
+    o3 = agg.combine_or(gv)
+    o4 = agg.combine_or(gv[::-1])                             # any order
+    o5 = agg.combine_or(gv + gv[:7])                          # repeats
+    assert c.pack_stats()["collections"] == 1
+    for o in (o1, o2, o3, o4, o5):
         assert (o.to_words() == e.to_words(o.info()["nblocks"] * 2048)).all()
     c.collection_prepare(gv, bm.ROLE_AND)
     assert c.pack_stats()["collections"] == 2
     t, _ = agg.combine_and_sub(gv, [])
     assert c.pack_stats()["collections"] == 2
     assert (t.to_words() == port.agg_and_sub(pv, []).to_words(t.info()["nblocks"] * 2048)).all()
-    with pytest.raises(bm.BmxError):
-        c.collection_prepare(gv[:10], bm.ROLE_OR)          # too few operands for a collection
+    c.collection_prepare(gv[:10], bm.ROLE_OR)                 # a small collection is a collection too
+    assert c.pack_stats()["collections"] == 3
     dense = bm.bit_import_u32(c, port.gen_words(1, 1, 30000, nbits), True)
     with pytest.raises(bm.BmxError):
         c.collection_prepare(gv + [dense], bm.ROLE_OR)     # bit-blocks cannot be packed
-    del gv, o1, o2, o3, t, dense
+    del gv, o1, o2, o3, o4, o5, t, dense
     c.close()
+    # gap_pack 1: built at first use
+    c = bm.context(0)
+    c.set_tuning("direct_cols", 0); c.set_tuning("pipe_split", 0); c.set_tuning("gap_pack", 1)
+    gv = [bm.bit_import_u32(c, w, True) for w in words]
+    agg = bm.aggregator(c)
+    o1 = agg.combine_or(gv)
+    assert c.pack_stats()["collections"] == 1
+    assert (o1.to_words() == e.to_words(o1.info()["nblocks"] * 2048)).all()
+    del gv, o1
+    c.close()
+
+
+@pytest.mark.parametrize("dq,nvec,long_runs,nblk", [(13, 300, False, 9), (150, 120, True, 6), (40, 1100, False, 3)])
+def test_prepared_collection_subsets_and_pipelines(port, dq, nvec, long_runs, nblk):
+    """ONE prepared collection per role serves any later aggregation over its vectors (member directory, bmx_kernels8.h):
+    combine_or / combine_and_sub over 20 random subsets in random order (with repeats), a 64-group counts pipeline and a
+    64-group results pipeline (AND lists and SUB lists drawn from the collection's vectors) = the oracle's bits, block
+    kinds and counts, = what the descriptor-table kernels give (gap_pack 0), and no further collection is built"""
+    rng = np.random.default_rng(dq * 31 + nvec)
+    nbits = nblk * 65536 - 1234
+    words = _sparse_collection(port, rng, nvec, nbits, dq, long_runs=long_runs, ragged=True)
+    pv = [port.import_words(w, True, w.size * 32) for w in words]
+    assert all(p.flatten()[0].tolist().count(2) == 0 for p in pv), "operands must be free of bit-blocks"
+    nwb = (nblk + 1) * 2048
+    subsets = []
+    for k in range(20):
+        m = int(rng.integers(16, nvec))
+        sel = rng.choice(nvec, size=m, replace=(k % 5 == 4)).tolist()
+        subsets.append(sel)
+    groups = []
+    for g in range(64):
+        na = int(rng.integers(1, 4)) if g % 8 else int(rng.integers(20, 60))
+        ns = int(rng.integers(0, 40))
+        a = rng.choice(nvec, size=na, replace=False).tolist()
+        s_ = [i for i in rng.choice(nvec, size=ns, replace=False).tolist() if i not in a]
+        groups.append((a, s_))
+    groups[5] = (groups[5][0], [])                                         # no SUB list
+    outs = {}
+    for mode in ("prepared", "tables"):
+        c = bm.context(0)
+        c.set_tuning("direct_cols", 0); c.set_tuning("pipe_split", 0)
+        if mode == "tables": c.set_tuning("gap_pack", 0)
+        gv = [bm.bit_import_u32(c, w, True) for w in words]
+        if mode == "prepared":
+            c.collection_prepare(gv, bm.ROLE_OR)                           # polarity 1: OR lists and SUB lists
+            c.collection_prepare(gv, bm.ROLE_AND)                          # polarity 0: AND lists
+            ncoll = c.pack_stats()["collections"]
+            assert ncoll == 2
+        agg = bm.aggregator(c)
+        out = []
+        for k, sel in enumerate(subsets):
+            opt = bool(k & 1)
+            agg.set_optimization(opt)
+            o = agg.combine_or([gv[i] for i in sel])
+            e = port.agg_or([pv[i] for i in sel], opt)
+            assert (o.to_words(nwb) == e.to_words(nwb)).all(), (mode, k)
+            assert o.block_table()[0].tolist() == (e.flatten()[0].tolist() + [0] * 8)[:o.info()["nblocks"]], (mode, k)
+            out.append(o.block_table()[0].tolist())
+            agg.set_optimization(False)
+            half = len(sel) // 3
+            t, any_ = agg.combine_and_sub([gv[i] for i in sel[:half]], [gv[i] for i in sel[half:]])
+            e = port.agg_and_sub([pv[i] for i in sel[:half]], [pv[i] for i in sel[half:]])
+            assert (t.to_words(nwb) == e.to_words(nwb)).all(), (mode, k)
+            assert t.block_table()[0].tolist() == (e.flatten()[0].tolist() + [0] * 8)[:t.info()["nblocks"]], (mode, k)
+            assert any_ == (e.count() > 0)
+            out.append(t.block_table()[0].tolist())
+        # 64 arg-groups, counts only
+        pipe = bm.aggregator.pipeline(c)
+        for a, s_ in groups:
+            ag = pipe.add()
+            for i in a: ag.add(gv[i], 0)
+            for i in s_: ag.add(gv[i], 1)
+        pipe.complete()
+        got = [int(x) for x in agg.combine_and_sub(pipe)]
+        exp = [port.agg_and_sub([pv[i] for i in a], [pv[i] for i in s_]).count() for a, s_ in groups]
+        assert got == exp, mode
+        if mode == "prepared": assert "k_coll_members" in pipe.describe(), pipe.describe()
+        part = [int(x) for x in agg._run_pipeline(pipe, 1, max(2, nblk - 1))]
+        assert part == [int(x) for x in port.pipeline_counts([([pv[i] for i in a], [pv[i] for i in s_]) for a, s_ in groups], 1, max(2, nblk - 1))], mode
+        # 64 arg-groups, result vectors + counts
+        pipe2 = bm.aggregator.pipeline(c, bm.agg_run_options(True, True))
+        for a, s_ in groups:
+            ag = pipe2.add()
+            for i in a: ag.add(gv[i], 0)
+            for i in s_: ag.add(gv[i], 1)
+        pipe2.complete()
+        agg.combine_and_sub(pipe2)
+        assert [int(x) for x in pipe2.get_bv_count_vector()] == exp, mode
+        for (a, s_), r in zip(groups, pipe2.get_bv_res_vector()):
+            e = port.agg_and_sub([pv[i] for i in a], [pv[i] for i in s_])
+            if e.count() == 0:
+                assert r is None
+                continue
+            assert (r.to_words(nwb) == e.to_words(nwb)).all(), mode
+            assert r.block_table()[0].tolist() == (e.flatten()[0].tolist() + [0] * 8)[:r.info()["nblocks"]], mode
+        if mode == "prepared": assert c.pack_stats()["collections"] == ncoll      # nothing was built on the side
+        outs[mode] = out
+        del gv, o, t, pipe, pipe2, ag
+        c.close()
+    assert outs["prepared"] == outs["tables"]
 
 
 # ---- round-3 fixtures generated by the reference: set_range_hint and the sparse_vector_scanner ----
