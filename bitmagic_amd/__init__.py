@@ -95,7 +95,9 @@ class context:
     def pack_stats(self) -> dict:
         n, b, ms = C.c_uint32(), C.c_uint64(), C.c_float()
         check(lib().bmx_ctx_pack_stats(self._h, C.byref(n), C.byref(b), C.byref(ms)))
-        return {"collections": n.value, "bytes": b.value, "last_build_ms": ms.value}
+        rb = C.c_uint64()
+        check(lib().bmx_ctx_pack_run_bytes(self._h, C.byref(rb)))
+        return {"collections": n.value, "bytes": b.value, "run_bytes": rb.value, "last_build_ms": ms.value}
 
     def mem_used(self) -> int:
         b = C.c_uint64()

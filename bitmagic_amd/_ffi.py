@@ -82,6 +82,7 @@ def lib() -> C.CDLL:
         "bmx_slice_eq_counts": (i32, [vp, P(vp), C.c_size_t, vp, C.c_size_t, u64, vp, vp]),
         "bmx_collection_prepare": (i32, [vp, P(vp), C.c_size_t, i32]),
         "bmx_ctx_pack_stats": (i32, [vp, P(u32), P(u64), P(C.c_float)]),
+        "bmx_ctx_pack_run_bytes": (i32, [vp, P(u64)]),
         "bmx_pipeline_create": (i32, [vp, P(vp), P(u32), P(vp), P(u32), C.c_size_t, P(vp)]),
         "bmx_pipeline_destroy": (i32, [vp, vp]),
         "bmx_pipeline_run_counts": (i32, [vp, vp, u32, u32, P(u64)]),

@@ -14,6 +14,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -51,7 +52,19 @@ static size_t pool_round(size_t bytes)
     return (bytes + g - 1) / g * g;
 }
 
+static int dmalloc_(bmx_ctx* ctx, void** p, size_t bytes);
 static int dmalloc(bmx_ctx* ctx, void** p, size_t bytes)
+{
+    static const bool trace = getenv("BMX_TRACE_ALLOC") != nullptr;
+    if (!trace || bytes < (64u << 20)) return dmalloc_(ctx, p, bytes);
+    const auto t0 = std::chrono::steady_clock::now();
+    const size_t cached = ctx->pool_cached;
+    int rc = dmalloc_(ctx, p, bytes);
+    fprintf(stderr, "[bmx] dmalloc %.1f MB: %.2f ms (%s)\n", bytes / 1048576.0,
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), ctx->pool_cached < cached ? "pool" : "hipMalloc");
+    return rc;
+}
+static int dmalloc_(bmx_ctx* ctx, void** p, size_t bytes)
 {
     *p = nullptr;
     size_t sz = pool_round(bytes);
@@ -770,6 +783,15 @@ int bmx_ctx_pack_stats(const bmx_ctx* ctx, uint32_t* n_collections, uint64_t* by
     if (n_collections) *n_collections = (uint32_t)ctx->colls.size();
     if (bytes) *bytes = ctx->pack_bytes;
     if (last_build_ms) *last_build_ms = ctx->last_pack_ms;
+    return BMX_OK;
+}
+
+int bmx_ctx_pack_run_bytes(const bmx_ctx* ctx, uint64_t* bytes)
+{
+    ARGCHK(ctx && bytes);
+    uint64_t b = 0;
+    for (const bmx_coll* c : ctx->colls) b += c->run_bytes;
+    *bytes = b;
     return BMX_OK;
 }
 
@@ -1945,9 +1967,12 @@ static int agg_or_impl(bmx_ctx* ctx, const bmx_vec* const* src, size_t n, int op
         else (void)hipStreamSynchronize(ctx->stream);
         dfree(ctx, d_tab);
         if (rc) { bmx_vec_free(ctx, v); return rc; }
-    } else if (n >= 16 && ncols && has_gap && !has_bit && (rc = coll_resolve(ctx, src, n, 1, 64, true, &packed, &members, &packed_full)) == BMX_OK && packed && !packed_full) {
+    } else if (n >= 16 && ncols && has_gap && !has_bit && (rc = coll_resolve(ctx, src, n, 1, 64, true, &packed, &members, &packed_full)) == BMX_OK && packed && !packed_full &&
+               !(n >= 64 && or_rows_wanted(ctx, src, n))) {
         // GAP-only operands that are SOME of the vectors of a packed collection: their pieces of its column regions
-        // (k_coll_members, bmx_kernels8.h)
+        // (k_coll_members, bmx_kernels8.h).  Sparse lists of >= 64 vectors take the row kernel below instead: a member's piece
+        // of a column is ~26 bytes there, and reading them one by one (9.1 ms for 2,048 of configs[4]'s 4,096 vectors) loses
+        // to the rows of 14 columns the vectors' own tile directories give (1.7 ms, profiles/r04i)
         void* d_buf = nullptr; const u32* d_midx = nullptr; const CollGroup* d_groups = nullptr;
         if ((rc = coll_members_upload(ctx, members, std::vector<u32>(), &d_buf, &d_midx, &d_groups))) { bmx_vec_free(ctx, v); return rc; }
         rc = coll_members_launch(CM_OR_STORE, ctx, packed, nullptr, d_midx, d_groups, 1u, 0u, ncols, opt_compress, nullptr, v, st);
@@ -1956,7 +1981,7 @@ static int agg_or_impl(bmx_ctx* ctx, const bmx_vec* const* src, size_t n, int op
         dfree(ctx, d_buf);
         if (rc) { bmx_vec_free(ctx, v); return rc; }
     } else if (rc) { bmx_vec_free(ctx, v); return rc;
-    } else if (packed) {
+    } else if (packed && packed_full) {
         // GAP-only operands = ALL the vectors of a packed collection: one sequential stream per block column (bmx_kernels6.h)
         // without opt_compress no GAP block can come out: the kernel folds the kind counts of its result itself and, when every
         // block turned out to be a bit-block (the OR of thousands of sparse vectors), the layout scan is skipped (one launch

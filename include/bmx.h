@@ -223,27 +223,39 @@ int bmx_slice_compare_stat(bmx_ctx* ctx, const bmx_vec* const* slices, size_t ns
 int bmx_slice_eq_counts(bmx_ctx* ctx, const bmx_vec* const* slices, size_t nslices, const uint64_t* values, size_t n,
                         uint64_t size, const bmx_vec* not_null, uint64_t* counts);
 
-/* ---- packed collections: the layout the engine keeps for operand SETS it sees again (bmx_kernels6.h) ----
+/* ---- packed collections: a column-major copy of the GAP run lists of a SET of vectors (bmx_kernels6.h, bmx_kernels8.h) ----
  * Vectors are immutable and device-resident, so the library owns their layout.  combine_or / combine_and / combine_and_sub
- * / a one-group counts pipeline over >= 64 operands made of GAP (+ NULL / FULL) blocks read thousands of separate slabs in
- * small pieces (src/bmaggregator.h:1808-1924 walks them operand by operand); from the SECOND time an operand set is used
- * the engine transposes its GAP blocks once into column-major order (one contiguous run list per block column, cached by
- * the operand set, dropped when one of its vectors is freed, LRU under BMX_PACK_MAX_MB) and streams that instead.
- * Results are identical either way.  Tuning key "gap_pack": -1 = from the second use (default), 0 = never, 1 = first use;
- * "coll_split" 0|1: OR / SUB collections keep a single-bit run as one 16-bit position (default 1: half the bytes for sparse operands).
- *   bmx_collection_prepare  builds the collection of an operand list now (role: how the list will be used)
- *   bmx_ctx_pack_stats      collections held, their bytes, device time of the last build */
+ * and pipelines over many operands made of GAP (+ NULL / FULL) blocks read thousands of separate slabs in small pieces
+ * (src/bmaggregator.h:1808-1924 walks them operand by operand).  bmx_collection_prepare transposes the GAP blocks of a
+ * list of vectors ONCE into column-major order -- one contiguous run list per block column plus a member directory (where
+ * each vector's runs sit inside every column) -- and from then on EVERY aggregation whose operands are vectors of that
+ * collection is served by it, whatever subset of them it names, in whatever order, with or without repeats:
+ *   - a list naming all the collection's vectors streams the column regions (k_coll_apply);
+ *   - any other list, and every arg-group of a pipeline (many groups over shared operands, :1292-1399), reads its members'
+ *     pieces of the regions through the directory (k_coll_members).
+ * Roles: an OR list or SUB list needs the vectors' 1-runs (BMX_ROLE_OR = BMX_ROLE_SUB), an AND list their 0-runs
+ * (BMX_ROLE_AND: AND_i x_i = NOT OR_i NOT x_i); an index searched both ways prepares both.  Results are identical to the
+ * descriptor-table kernels.  A collection lives until one of its vectors is freed, it is the least recently used one when
+ * device memory runs short (budget: a quarter of the free HBM at context creation, BMX_PACK_MAX_MB), or the context goes.
+ * Tuning key "gap_pack": -1 (default) = use what bmx_collection_prepare built, nothing is built on the side; 0 = never use
+ * collections; 1 = also build one at the FIRST use of a list of >= 64 packable vectors (synchronous entries only).
+ * "coll_split" 0|1: OR / SUB collections keep a single-bit run as one 16-bit position (default 1: half the bytes for sparse
+ * vectors).
+ *   bmx_collection_prepare  builds the collection of the list in the role (1..65535 vectors without bit-blocks)
+ *   bmx_ctx_pack_stats      collections held, their bytes (runs + directories), device time of the last build
+ *   bmx_ctx_pack_run_bytes  the run-list bytes alone: what a full aggregation over the collections streams */
 #define BMX_ROLE_AND 0
 #define BMX_ROLE_OR  1
 #define BMX_ROLE_SUB 2
 int bmx_collection_prepare(bmx_ctx* ctx, const bmx_vec* const* vecs, size_t n, int role);
 int bmx_ctx_pack_stats(const bmx_ctx* ctx, uint32_t* n_collections, uint64_t* bytes, float* last_build_ms);
+int bmx_ctx_pack_run_bytes(const bmx_ctx* ctx, uint64_t* bytes);
 
 /* aggregator::pipeline<agg_opt_only_counts>  src/bmaggregator.h:62-103,222-341:
  * arg-groups are given as concatenated operand lists, and_n[g] / sub_n[g] per
  * group (pipeline::add() + arg_groups::add(bv, 0|1) + complete(), :2784-2931).
  * Lifetime: like the reference's pipeline, which stores bvector POINTERS (:2939), the object references its
- * operand vectors: they must stay alive (not bmx_vec_free'd) until bmx_pipeline_destroy.
+ * operand vectors (their device tables): they must stay alive (not bmx_vec_free'd) until bmx_pipeline_destroy.
  * Limits: < 2^20 groups, <= 65535 operands per list, total operands + 2 x groups < 2^32 (else BMX_ERR_RANGE). */
 int bmx_pipeline_create(bmx_ctx* ctx,
                         const bmx_vec* const* and_list, const uint32_t* and_n,

@@ -1,0 +1,7 @@
+#!/bin/bash
+export TMPDIR=/tmp
+O=gpurun_out/${1:-r04j}; rm -rf $O; mkdir -p $O
+timeout 600 rocprofv3 --kernel-trace --stats -d $O/p -o x -f csv -- python tools/prof_prepare.py > $O/out.txt 2> $O/err.txt
+cat $O/out.txt
+f=$(find $O/p -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/kernel_stats_prepare.csv && grep -E "k_coll|copyBuffer|fillBuffer" $O/kernel_stats_prepare.csv | sed 's/(.*)"/"/' | cut -c1-150
+rm -rf $O/p
