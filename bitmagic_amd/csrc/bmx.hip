@@ -380,6 +380,16 @@ static int coll_launch(int mode, bmx_ctx* ctx, const bmx_coll* a, const bmx_coll
     return BMX_OK;
 }
 
+// Is the member-directory path (k_coll_members) the better one for lists that name only SOME vectors of their collections?
+// Measured (tools/bench_pipeline_coll.py, profiles/r04_coll): it wins where the blocks are sparse and the lists long -- 16
+// groups x 257 vectors of configs[4]'s density: 11.8 against 58.7 ms -- and loses to the descriptor-table kernels where a
+// member's piece of a column is a few hundred bytes or the lists are short (64 groups x 32 vectors at 0.1 %: 8.5 against 6.1 ms).
+static bool coll_members_wanted(const bmx_ctx* ctx, uint64_t gap_words, uint64_t gap_blocks, uint64_t ops, uint64_t ngroups)
+{
+    if (ctx->coll_members >= 0) return ctx->coll_members != 0;
+    return gap_blocks && gap_words <= 48ull * gap_blocks && ops >= 32ull * ngroups;
+}
+
 // the collections of an AND list + SUB list, if both lists are served by one: *a = nullptr otherwise.  full = both lists
 // name their whole collection (the streaming kernel applies); else ma / ms are the member indices for k_coll_members
 static int coll_resolve_and_sub(bmx_ctx* ctx, const bmx_vec* const* va, size_t na, const bmx_vec* const* vs, size_t ns,
@@ -409,11 +419,13 @@ static int coll_members_launch(int mode, bmx_ctx* ctx, const bmx_coll* a, const 
                                u32 col_from, u32 col_to, int opt_compress, u64* d_counts, bmx_vec* v, BlockStat* st)
 {
     if (col_to <= col_from) return BMX_OK;
-#define CM_ARGS dim3(col_to - col_from), dim3(512), 0, ctx->stream, coll_view(a), coll_view(s), d_midx, d_groups, ngroups, col_from, col_to, opt_compress, \
+    const u64 nitems = (u64)(col_to - col_from) * ngroups;
+    if ((nitems + CM_WAVES - 1) / CM_WAVES > 0x7FFFFFFFull) { g_last_error = "too many (column, group) items in one run"; return BMX_ERR_RANGE; }
+#define CM_ARGS dim3((u32)((nitems + CM_WAVES - 1) / CM_WAVES)), dim3(CM_WAVES * 64), 0, ctx->stream, coll_view(a), coll_view(s), d_midx, d_groups, ngroups, col_from, col_to, opt_compress, \
         d_counts, v ? v->d_bits : (uint4*)nullptr, v ? v->d_desc : (u64*)nullptr, st
-    if (mode == CM_OR_STORE) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_coll_members<CM_OR_STORE, 512>), CM_ARGS);
-    else if (mode == CM_AND_STORE) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_coll_members<CM_AND_STORE, 512>), CM_ARGS);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_coll_members<CM_AND_COUNT, 512>), CM_ARGS);
+    if (mode == CM_OR_STORE) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_coll_members<CM_OR_STORE>), CM_ARGS);
+    else if (mode == CM_AND_STORE) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_coll_members<CM_AND_STORE>), CM_ARGS);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_coll_members<CM_AND_COUNT>), CM_ARGS);
 #undef CM_ARGS
     KCHK();
     return BMX_OK;
@@ -617,7 +629,7 @@ int bmx_ctx_create(int device, void* stream, bmx_ctx** out)
     // an invalid value is ignored (the default stays)
     static const char* const env_keys[][2] = {
         {"BMX_PIPE_UNROLL", "pipe_unroll"}, {"BMX_PIPE_ROWS", "pipe_rows"}, {"BMX_PIPE_NT", "pipe_nt"},
-        {"BMX_PIPE_WG", "pipe_wg"}, {"BMX_PIPE_WINDOW", "pipe_window"}, {"BMX_PIPE_SPLIT", "pipe_split"}, {"BMX_OR_TILE", "or_tile"}, {"BMX_OR_ROWS", "or_rows"}, {"BMX_OR_DEPTH", "or_depth"}, {"BMX_OR_WINDOW", "or_window"}, {"BMX_DIRECT_COLS", "direct_cols"}, {"BMX_FF_WINDOW", "ff_window"}, {"BMX_GAP_COUNT", "gap_count"}, {"BMX_RANGE_HALVES", "range_halves"}, {"BMX_PAIR_STREAM", "pair_stream"}, {"BMX_PAIR_WGS", "pair_wgs"}, {"BMX_RS_LANES", "rs_lanes"}, {"BMX_RS_LINES", "rs_lines"}, {"BMX_RS_SELECT_LINES", "rs_select_lines"}, {"BMX_RS_SDIR_SHIFT", "rs_sdir_shift"}, {"BMX_COLL_SHAPE", "coll_shape"}, {"BMX_COLL_WINDOW", "coll_window"}, {"BMX_COLL_SPLIT", "coll_split"}, {"BMX_EQ_BIG", "eq_big"}, {"BMX_PAIR_LOOP", "pair_loop"}, {"BMX_PAIR_NT", "pair_nt"}, {"BMX_EQ_BIG_SHAPE", "eq_big_shape"}, {"BMX_OP2_WGS", "op2_wgs"}, {"BMX_OP2_NT", "op2_nt"}, {"BMX_GAP_PACK", "gap_pack"}, {"BMX_XCD_SWIZZLE", "xcd_swizzle"}};
+        {"BMX_PIPE_WG", "pipe_wg"}, {"BMX_PIPE_WINDOW", "pipe_window"}, {"BMX_PIPE_SPLIT", "pipe_split"}, {"BMX_OR_TILE", "or_tile"}, {"BMX_OR_ROWS", "or_rows"}, {"BMX_OR_DEPTH", "or_depth"}, {"BMX_OR_WINDOW", "or_window"}, {"BMX_DIRECT_COLS", "direct_cols"}, {"BMX_FF_WINDOW", "ff_window"}, {"BMX_GAP_COUNT", "gap_count"}, {"BMX_RANGE_HALVES", "range_halves"}, {"BMX_PAIR_STREAM", "pair_stream"}, {"BMX_PAIR_WGS", "pair_wgs"}, {"BMX_RS_LANES", "rs_lanes"}, {"BMX_RS_LINES", "rs_lines"}, {"BMX_RS_SELECT_LINES", "rs_select_lines"}, {"BMX_RS_SDIR_SHIFT", "rs_sdir_shift"}, {"BMX_COLL_SHAPE", "coll_shape"}, {"BMX_COLL_WINDOW", "coll_window"}, {"BMX_COLL_SPLIT", "coll_split"}, {"BMX_EQ_BIG", "eq_big"}, {"BMX_PAIR_LOOP", "pair_loop"}, {"BMX_PAIR_NT", "pair_nt"}, {"BMX_EQ_BIG_SHAPE", "eq_big_shape"}, {"BMX_OP2_WGS", "op2_wgs"}, {"BMX_OP2_NT", "op2_nt"}, {"BMX_GAP_PACK", "gap_pack"}, {"BMX_COLL_MEMBERS", "coll_members"}, {"BMX_XCD_SWIZZLE", "xcd_swizzle"}};
     for (auto& kv : env_keys)
         if (const char* e = getenv(kv[0])) (void)bmx_ctx_set_tuning(ctx, kv[1], atoi(e));
     g_last_error.clear();
@@ -676,6 +688,7 @@ int bmx_ctx_set_tuning(bmx_ctx* ctx, const char* key, int value)
     else if (k == "ff_window") { ARGCHK(value >= -1); ctx->ff_window = value; }
     else if (k == "or_window") { ARGCHK(value >= -9); ctx->or_window = value; }
     else if (k == "gap_pack") { ARGCHK(value >= -1 && value <= 1); ctx->gap_pack = value; }
+    else if (k == "coll_members") { ARGCHK(value >= -1 && value <= 1); ctx->coll_members = value; ++ctx->coll_gen; }
     else if (k == "coll_shape") { ARGCHK(value >= 0 && value <= 5); ctx->coll_shape = value; }
     else if (k == "op2_nt") { ARGCHK(value >= 0 && value <= 3); ctx->op2_nt = value; }
     else if (k == "op2_wgs") { ARGCHK(value >= 1 && value <= 8); ctx->op2_wgs = value; }
@@ -1406,6 +1419,8 @@ static int pipe_resolve_colls(bmx_ctx* ctx, bmx_pipeline* p, bool may_build, bmx
             }
         }
         p->cm_gen = ctx->coll_gen;
+        const bool whole = p->ngroups == 1 && fa && (!tot_sub || fs);
+        if (ca && !whole && !coll_members_wanted(ctx, (uint64_t)p->gap_avg_words, 1, p->n_ops, p->ngroups)) ca = nullptr;      // (the table kernels serve these groups better)
         if (ca && (!tot_sub || cs)) {
             p->cm_a_id = ca->id; p->cm_s_id = cs ? cs->id : 0;
             p->cm_full = p->ngroups == 1 && fa && (!tot_sub || fs);
@@ -1559,7 +1574,7 @@ int bmx_pipeline_describe(bmx_ctx* ctx, bmx_pipeline* p, uint32_t nb_from, uint3
     bool reuse = p->ngroups >= 32 && (uint64_t)p->n_ops >= 8ull * p->nplanes;
     if (p->h_uids && ctx->gap_pack != 0 && p->cm_gen == ctx->coll_gen && coll_by_id(ctx, p->cm_a_id) && (!p->cm_s_id || coll_by_id(ctx, p->cm_s_id))) {
         if (p->cm_full) snprintf(buf, buf_len, "k_coll_apply<AND_COUNT,512> x 1 launch, %llu workgroups (packed collection of the operand set)", (unsigned long long)nitems64);
-        else snprintf(buf, buf_len, "k_coll_members<AND_COUNT,512> x 1 launch, %u workgroups x %u groups (members of a packed collection)", nb_to - nb_from, p->ngroups);
+        else snprintf(buf, buf_len, "k_coll_members<AND_COUNT> x 1 launch, a wave per (column, group): %u x %u items (members of a packed collection)", nb_to - nb_from, p->ngroups);
     }
     else if (p->staged_ok && (ctx->pipe_staged == 1 || (ctx->pipe_staged < 0 && reuse)))
         snprintf(buf, buf_len, "k_pipe_counts_staged<%d> x 1 launch, %u workgroups", ctx->pipe_slots, nb_to - nb_from);
@@ -1909,6 +1924,12 @@ static int direct_launch(int mode, bmx_ctx* ctx, const void* d_tab, size_t n_and
 }
 
 static int agg_or_impl(bmx_ctx* ctx, const bmx_vec* const* src, size_t n, int opt_compress, bmx_vec** result);
+static bool coll_members_wanted_list(const bmx_ctx* ctx, const bmx_vec* const* src, size_t n)
+{
+    uint64_t gw = 0, gb = 0;
+    for (size_t i = 0; i < n; ++i) { gw += src[i]->gap_words; gb += src[i]->counts[BMX_GAP]; }
+    return coll_members_wanted(ctx, gw, gb, n, 1);
+}
 
 // combine_or over >= 64 GAP-only operands: the row kernel (bmx_kernels7.h) when the operands are sparse enough for a tile of
 // ORR_TILE = 14 blocks to fit one 1-KiB row (<= 64 chunks of 16 B) nearly always, i.e. <= 4.1 chunks per GAP block on average
@@ -1968,7 +1989,7 @@ static int agg_or_impl(bmx_ctx* ctx, const bmx_vec* const* src, size_t n, int op
         dfree(ctx, d_tab);
         if (rc) { bmx_vec_free(ctx, v); return rc; }
     } else if (n >= 16 && ncols && has_gap && !has_bit && (rc = coll_resolve(ctx, src, n, 1, 64, true, &packed, &members, &packed_full)) == BMX_OK && packed && !packed_full &&
-               !(n >= 64 && or_rows_wanted(ctx, src, n))) {
+               !(ctx->coll_members < 0 && n >= 64 && or_rows_wanted(ctx, src, n)) && coll_members_wanted_list(ctx, src, n)) {
         // GAP-only operands that are SOME of the vectors of a packed collection: their pieces of its column regions
         // (k_coll_members, bmx_kernels8.h).  Sparse lists of >= 64 vectors take the row kernel below instead: a member's piece
         // of a column is ~26 bytes there, and reading them one by one (9.1 ms for 2,048 of configs[4]'s 4,096 vectors) loses
@@ -2187,6 +2208,12 @@ int bmx_agg_and_sub(bmx_ctx* ctx, const bmx_vec* const* src_and, size_t n_and,
         for (size_t i = 0; i < n_and && ok; ++i) ok = src_and[i]->ctx == ctx;
         for (size_t i = 0; i < n_sub && ok; ++i) ok = src_sub[i]->ctx == ctx;
         if (ok && ncols && (rc = coll_resolve_and_sub(ctx, src_and, n_and, src_sub, n_sub, &ca, &cs, &ma, &ms, &full))) return rc;
+        if (ca && !full) {
+            uint64_t gw = 0, gb = 0;
+            for (size_t i = 0; i < n_and; ++i) { gw += src_and[i]->gap_words; gb += src_and[i]->counts[BMX_GAP]; }
+            for (size_t i = 0; i < n_sub; ++i) { gw += src_sub[i]->gap_words; gb += src_sub[i]->counts[BMX_GAP]; }
+            if (!coll_members_wanted(ctx, gw, gb, n_and + n_sub, 1)) ca = nullptr;
+        }
         if (ca) {
             if ((rc = result_begin(ctx, nbits, ncols, &v, &st, &offs))) return rc;
             void* d_buf = nullptr;

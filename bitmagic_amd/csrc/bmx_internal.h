@@ -69,6 +69,7 @@ struct bmx_ctx {
     int gap_pack = -1;         // aggregation over GAP-only operands through a packed collection: -1 = the collections bmx_collection_prepare built, 0 = never, 1 = also build one at the first use of a list of >= 64 packable vectors
     uint64_t pack_cap = 16ull << 30, pack_bytes = 0, coll_tick = 0;     // pack_cap: a quarter of the device's free memory at context creation (BMX_PACK_MAX_MB overrides)
     uint64_t coll_gen = 0, coll_next_id = 0;   // coll_gen changes whenever a collection appears or goes: pipelines re-resolve their groups then
+    int coll_members = -1;     // lists naming only SOME vectors of their collection through the member directory (k_coll_members): -1 = where it pays (sparse blocks, >= 32 operands per group), 0 = never, 1 = always
     int coll_building = 0;                     // > 0 while a collection is being built (no eviction from under it)
     std::unordered_map<uint64_t, struct bmx_vec*> live_vecs;   // uid -> vector, for callers that hold uids (pipelines) instead of pointers
     float last_pack_ms = 0.f;

@@ -51,120 +51,150 @@ struct CollGroup { u32 a_off, a_n, s_off, s_n; };       // member-index ranges o
 #define CMF_FULL 2u
 #define CMF_GAP  4u
 
-// the runs of the listed members of column c into U / D (coll_apply_run, bmx_kernels6.h); flags: kinds met
-template <int WG>
-__device__ __forceinline__ u32 coll_members_apply(const CollView& C, u32 c, const u32* __restrict__ midx, u32 m, u32* U, int* D, u32 tid, u32& flags)
+__device__ __forceinline__ u32 wave_max_u32(u32 v)
 {
-    u32 any_long = 0u;
-    if (c >= C.ncols) { if (m && tid == 0) flags |= CMF_NULL; return 0u; }       // past the collection's last column: every member is NULL there
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const u32 t = (u32)__shfl_xor((int)v, o, 64); v = t > v ? t : v; }
+    return v;
+}
+
+// The listed members' runs of column c into the wave's bitmap U (2048 words of LDS).  Four members per step, 16 lanes each:
+// the lanes of a quarter-wave read consecutive entries of their member's piece (one request however short the piece).  A run
+// inside one or two words is the owning lane's one or two ds_or; a run with interior words -- nearly every 0-run of a sparse
+// AND-list member -- leaves its edges to the lane and has the WAVE store the interior, 64 words per instruction.
+// Returns the kinds met (CMF_*), the same in every lane.
+__device__ __forceinline__ void coll_wave_run(u32 r, bool valid, u32* U, u32 lane)
+{
+    const u32 s = r & 0xFFFFu, e = r >> 16;
+    const u32 ws = s >> 5, we = e >> 5;
+    const u32 lo = ~0u << (s & 31u), hi = ~0u >> (31u - (e & 31u));
+    const bool same = ws == we;
+    if (valid) atomicOr(&U[ws], same ? (lo & hi) : lo);
+    if (valid && !same) atomicOr(&U[we], hi);
+    u64 lm = __ballot(valid && we > ws + 1u);
+    while (lm) {                                                       // (wave-uniform loop over the lanes that hold a long run)
+        const u32 l = (u32)__builtin_ctzll(lm);
+        lm &= lm - 1ull;
+        const u32 w0 = (u32)__builtin_amdgcn_readlane((int)ws, (int)l) + 1u, w1 = (u32)__builtin_amdgcn_readlane((int)we, (int)l);
+        for (u32 w = w0 + lane; w < w1; w += 64u) U[w] = ~0u;          // an OR accumulator only gains bits: a plain store of all-ones loses nothing
+    }
+}
+
+// 64 members at a time, so that the dependent reads of a member (its index -> its directory words -> its entries) are three
+// round trips for the whole batch instead of three per member: lane j fetches member j's index and directory words, then,
+// round after round (a round = up to 16 entries of every member), the entries of all 16 quads are requested before the
+// first one is applied.
+__device__ __forceinline__ u32 coll_wave_members(const CollView& C, u32 c, const u32* __restrict__ midx, u32 m, u32* U, u32 lane)
+{
+    if (!m) return 0u;
+    if (c >= C.ncols) return CMF_NULL;                                 // past the collection's last column: every member is NULL there
     const u32* dm = C.dir + (size_t)c * (C.nvec + 1u);
     const u32* ds = C.dir_s ? C.dir_s + (size_t)c * (C.nvec + 1u) : nullptr;
     const u64 off = C.off[c];
     const u32 nm_col = dm[C.nvec] & CDIR_MASK;
     const u32* multis = C.runs + off;
     const u16* singles = reinterpret_cast<const u16*>(C.runs + off + ((nm_col + 3u) & ~3u));
-    for (u32 j = tid; j < m; j += (u32)WG) {
-        const u32 i = midx[j];
-        const u32 a0 = dm[i], b = dm[i + 1u] & CDIR_MASK;
-        const u32 kind = CDIR_KIND(a0);
-        flags |= kind == K_NULL ? CMF_NULL : kind == K_FULL ? CMF_FULL : CMF_GAP;
-        for (u32 e = a0 & CDIR_MASK; e < b; ++e) coll_apply_run(multis[e], true, U, D, any_long);
-        if (ds) {
-            const u32 sb = ds[i + 1u];
-            for (u32 e = ds[i]; e < sb; ++e) { const u32 p = singles[e]; atomicOr(&U[p >> 5], 1u << (p & 31u)); }
+    const u32 sub = lane & 15u, grp = lane >> 4;
+    u32 flags = 0u;
+    for (u32 j0 = 0; j0 < m; j0 += 64u) {
+        const bool in = j0 + lane < m;
+        const u32 i = in ? midx[j0 + lane] : 0u;
+        const u32 a0 = in ? dm[i] : 0u, b = in ? dm[i + 1u] & CDIR_MASK : 0u;
+        const u32 sa = (in && ds) ? ds[i] : 0u, sb = (in && ds) ? ds[i + 1u] : 0u;
+        if (in) { const u32 kind = CDIR_KIND(a0); flags |= kind == K_NULL ? CMF_NULL : kind == K_FULL ? CMF_FULL : CMF_GAP; }
+        const u32 a = a0 & CDIR_MASK;
+        const u32 mc = m - j0 < 64u ? m - j0 : 64u, nsteps = (mc + 3u) >> 2;
+        for (u32 k16 = 0; ; k16 += 16u) {
+            if (__ballot(in && (b - a > k16 || sb - sa > k16)) == 0ull) break;      // nobody has entries left in this round
+            u32 em[16], es[16], vm = 0u, vs = 0u;
+#pragma unroll
+            for (u32 q = 0; q < 16u; ++q) {
+                em[q] = 0u; es[q] = 0u;
+                if (q < nsteps) {                                      // (wave-uniform)
+                    const int src = (int)((4u * q + grp) << 2);
+                    const u32 aq = (u32)__builtin_amdgcn_ds_bpermute(src, (int)a), bq = (u32)__builtin_amdgcn_ds_bpermute(src, (int)b);
+                    const u32 saq = (u32)__builtin_amdgcn_ds_bpermute(src, (int)sa), sbq = (u32)__builtin_amdgcn_ds_bpermute(src, (int)sb);
+                    const u32 e = aq + k16 + sub, se = saq + k16 + sub;
+                    if (e < bq) { em[q] = multis[e]; vm |= 1u << q; }
+                    if (se < sbq) { es[q] = singles[se]; vs |= 1u << q; }
+                }
+            }
+#pragma unroll
+            for (u32 q = 0; q < 16u; ++q) {
+                if (q < nsteps) {
+                    coll_wave_run(em[q], (vm >> q) & 1u, U, lane);
+                    if ((vs >> q) & 1u) atomicOr(&U[es[q] >> 5], 1u << (es[q] & 31u));
+                }
+            }
         }
     }
-    return any_long;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) flags |= __shfl_xor(flags, o, 64);
+    return flags;
 }
 
 enum { CM_OR_STORE = 0, CM_AND_STORE = 1, CM_AND_COUNT = 2 };
 
-// One workgroup per block column; the arg-groups of a counts pipeline are walked inside (the column's region stays in the
-// caches across them).
+// One WAVE per (block column, arg-group) item, items of a column next to each other (the column's region stays in the caches
+// across its groups), four waves per workgroup, 8 KiB of LDS per wave.
 //   CM_OR_STORE   result = union of the listed members of A (polarity 1), stored with the aggregator's optimisation mode
 //   CM_AND_STORE  result = AND of the listed members of A (polarity 0: complement of the union of their 0-runs) minus the
 //                 union of the listed members of S (polarity 1), stored with opt_compress (combine_and_sub, :1162,1210)
 //   CM_AND_COUNT  the same per arg-group, counted (:1392-1399)
-template <int MODE, int WG>
-__global__ __launch_bounds__(WG)
+#define CM_WAVES 4
+template <int MODE>
+__global__ __launch_bounds__(CM_WAVES * 64)
 void k_coll_members(CollView A, CollView S, const u32* __restrict__ midx, const CollGroup* __restrict__ groups, u32 ngroups,
                     u32 col_base, u32 ncols, int opt_compress, u64* __restrict__ counts,
                     uint4* __restrict__ slab, u64* __restrict__ desc, BlockStat* __restrict__ st)
 {
-    __shared__ __attribute__((aligned(16))) u32 U[2048];
-    __shared__ __attribute__((aligned(16))) int D[2048];
-    __shared__ int sm[WG / 64];
-    __shared__ u32 s_long, s_flags;
-    __shared__ u32 part[WG / 64];
-    const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const u32 c = col_base + blockIdx.x;
-    if (c >= ncols) return;
-    constexpr u32 W = 2048u / WG;
-    for (u32 g = 0; g < ngroups; ++g) {
-        const u32 a_off = uniform32(groups[g].a_off), a_n = uniform32(groups[g].a_n);
-        const u32 s_off = uniform32(groups[g].s_off), s_n = uniform32(groups[g].s_n);
-        __syncthreads();                                               // (the previous group's readers of U / part are done)
+    __shared__ __attribute__((aligned(16))) u32 lds_all[CM_WAVES * 2048];
+    const u32 lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const u64 item = (u64)blockIdx.x * CM_WAVES + wave;
+    const u32 c = col_base + (u32)(item / ngroups), g = (u32)(item % ngroups);
+    if (c >= ncols) return;                                            // (no workgroup barrier below: a wave may leave)
+    u32* U = lds_all + wave * 2048u;
+    const u32 a_off = uniform32(groups[g].a_off), a_n = uniform32(groups[g].a_n);
+    const u32 s_off = uniform32(groups[g].s_off), s_n = uniform32(groups[g].s_n);
+    auto zero = [&]() {
+        u32x4* u4 = reinterpret_cast<u32x4*>(U);
 #pragma unroll
-        for (u32 k = 0; k < W; k += 4u) {
-            *reinterpret_cast<u32x4*>(&U[tid * W + k]) = (u32x4)(0u);
-            *reinterpret_cast<u32x4*>(&D[tid * W + k]) = (u32x4)(0u);
-        }
-        if (tid == 0) { s_long = 0u; s_flags = 0u; }
-        __syncthreads();
-        u32 fl = 0u;
-        u32 al = coll_members_apply<WG>(A, c, midx + a_off, a_n, U, D, tid, fl);
-        if (fl) atomicOr(&s_flags, fl);
-        if (al) s_long = 1u;
-        __syncthreads();
-        const u32 fa = s_flags;
-        if (s_long) coll_fold<WG>(U, D, sm, tid);
-        if (MODE == CM_OR_STORE) {
-            // any FULL member saturates the column (:2300); no GAP member: nothing to store (:2294)
-            if ((fa & CMF_FULL) || !(fa & CMF_GAP)) { if (wave == 0) store_trivial((fa & CMF_FULL) ? (u32)K_FULL : (u32)K_NULL, c, desc, st, lane); }
-            else if (wave == 0) { Blk b; blk_from_lds(b, U, lane); (void)store_result_mode(b, c, opt_compress ? ST_OPT : ST_FORCE_BIT, slab, desc, st, lane); }
-            continue;
-        }
-        // AND: an empty AND list or a NULL member ends the column (:1170, :2327); FULL members are ignored (:2346)
-        bool empty = a_n == 0u || (fa & CMF_NULL);
-        u32 acc[W];
-#pragma unroll
-        for (u32 k = 0; k < W; ++k) acc[k] = ~U[tid * W + k];
-        if (!empty && s_n) {
-            __syncthreads();
-#pragma unroll
-            for (u32 k = 0; k < W; k += 4u) *reinterpret_cast<u32x4*>(&U[tid * W + k]) = (u32x4)(0u);
-            if (tid == 0) { s_long = 0u; s_flags = 0u; }
-            __syncthreads();
-            u32 fs = 0u;
-            u32 sl = coll_members_apply<WG>(S, c, midx + s_off, s_n, U, D, tid, fs);
-            if (fs) atomicOr(&s_flags, fs);
-            if (sl) s_long = 1u;
-            __syncthreads();
-            if (s_flags & CMF_FULL) empty = true;                      // a FULL block in the SUB list empties the column (:1746)
-            if (s_long) coll_fold<WG>(U, D, sm, tid);
-#pragma unroll
-            for (u32 k = 0; k < W; ++k) acc[k] &= ~U[tid * W + k];
-        }
-        if (MODE == CM_AND_COUNT) {
-            u32 pc = 0;
-#pragma unroll
-            for (u32 k = 0; k < W; ++k) pc += (u32)__popc(acc[k]);
-            pc = empty ? 0u : wave_sum(pc);
-            if (lane == 0) part[wave] = pc;
-            __syncthreads();
-            if (tid == 0) {
-                u32 t = 0;
-#pragma unroll
-                for (u32 i = 0; i < WG / 64u; ++i) t += part[i];
-                if (t) atomicAdd(reinterpret_cast<unsigned long long*>(&counts[g]), (unsigned long long)t);
-            }
-            continue;
-        }
-        if (empty) { if (wave == 0) store_trivial(K_NULL, c, desc, st, lane); continue; }
-        __syncthreads();
-#pragma unroll
-        for (u32 k = 0; k < W; ++k) U[tid * W + k] = acc[k];
-        __syncthreads();
-        if (wave == 0) { Blk b; blk_from_lds(b, U, lane); store_result(b, c, 1, slab, desc, st, lane); }
+        for (int i = 0; i < 8; ++i) u4[i * 64 + lane] = (u32x4)(0u);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+    auto settle = [&]() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); };
+    zero();
+    const u32 fa = coll_wave_members(A, c, midx + a_off, a_n, U, lane);
+    settle();
+    if (MODE == CM_OR_STORE) {
+        // any FULL member saturates the column (:2300); no GAP member: nothing to store (:2294)
+        if ((fa & CMF_FULL) || !(fa & CMF_GAP)) { store_trivial((fa & CMF_FULL) ? (u32)K_FULL : (u32)K_NULL, c, desc, st, lane); return; }
+        Blk b; blk_from_lds(b, U, lane);
+        (void)store_result_mode(b, c, opt_compress ? ST_OPT : ST_FORCE_BIT, slab, desc, st, lane);
+        return;
     }
+    // AND: an empty AND list or a NULL member ends the column (:1170, :2327); FULL members are ignored (:2346)
+    bool empty = a_n == 0u || (fa & CMF_NULL);
+    Blk acc;
+    blk_from_lds(acc, U, lane);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc.r[i] = ~acc.r[i];
+    if (!empty && s_n) {
+        settle();
+        zero();
+        const u32 fs = coll_wave_members(S, c, midx + s_off, s_n, U, lane);
+        settle();
+        if (fs & CMF_FULL) empty = true;                               // a FULL block in the SUB list empties the column (:1746)
+        Blk sb; blk_from_lds(sb, U, lane);
+        blk_andn(acc, sb);
+    }
+    if (MODE == CM_AND_COUNT) {
+        if (empty) return;
+        const u32 pc = wave_sum(blk_lane_popcount(acc));
+        if (lane == 0 && pc) atomicAdd(reinterpret_cast<unsigned long long*>(&counts[g]), (unsigned long long)pc);
+        return;
+    }
+    if (empty) { store_trivial(K_NULL, c, desc, st, lane); return; }
+    store_result(acc, c, 1, slab, desc, st, lane);
 }

@@ -1542,6 +1542,7 @@ def test_prepared_collection_subsets_and_pipelines(port, dq, nvec, long_runs, nb
         c = bm.context(0)
         c.set_tuning("direct_cols", 0); c.set_tuning("pipe_split", 0)
         if mode == "tables": c.set_tuning("gap_pack", 0)
+        else: c.set_tuning("coll_members", 1)                              # (always through the member directory, also where the tables would be picked)
         gv = [bm.bit_import_u32(c, w, True) for w in words]
         if mode == "prepared":
             c.collection_prepare(gv, bm.ROLE_OR)                           # polarity 1: OR lists and SUB lists
