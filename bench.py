@@ -1041,14 +1041,17 @@ def run_or_sharded(args, env, quick=False):
         dist.all_reduce(gb)
     tot_bytes = int(gb.item())
     # ---- build: the packed collection of the set, then the same call again
-    t0 = time.perf_counter(); ctx.collection_prepare(vecs, bm.ROLE_OR); ctx.synchronize(); prep_wall_ms = (time.perf_counter() - t0) * 1e3
+    have_coll = os.environ.get("BMX_GAP_PACK", "-1") != "0"               # (gap_pack 0: collections are switched off altogether)
+    prep_wall_ms = 0.0
+    if have_coll:
+        t0 = time.perf_counter(); ctx.collection_prepare(vecs, bm.ROLE_OR); ctx.synchronize(); prep_wall_ms = (time.perf_counter() - t0) * 1e3
     pack = ctx.pack_stats()
     step(); step()
     warm_ms = event_avg_ms(step, 6 if quick else 10, ctx)
     warm_count = int(cnt.item())
     # ---- a subset of the collection's vectors (half of them, shuffled): member directory vs the cold path on the same list
     sub = None
-    if world == 1 and nvec >= 128:
+    if world == 1 and nvec >= 128 and have_coll:
         rng = np.random.default_rng(5)
         pick = rng.permutation(nvec)[: nvec // 2]
         sarr = (C.c_void_p * len(pick))(*[vecs[int(i)]._h for i in pick])

@@ -6,7 +6,7 @@ timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "row_kerne
 tail -5 $O/pytest.log
 for cfg in "rows1_d4:BMX_OR_ROWS=1 BMX_OR_DEPTH=4" "rows1_d8:BMX_OR_ROWS=1 BMX_OR_DEPTH=8" "rows1_d4_noswz:BMX_OR_ROWS=1 BMX_OR_DEPTH=4 BMX_XCD_SWIZZLE=0" "rows0:BMX_OR_ROWS=0"; do
   name=${cfg%%:*}; envs=${cfg#*:}
-  env $envs BMX_GAP_PACK=0 timeout 600 python bench.py --config 4 --no-cpu --steps 6 --warmup 2 > $O/c4_$name.json 2> $O/c4_$name.err
+  env $envs timeout 600 python bench.py --config 4 --no-cpu --steps 6 --warmup 2 > $O/c4_$name.json 2> $O/c4_$name.err
   python - <<PY
 import json
 try:
