@@ -629,7 +629,7 @@ int bmx_ctx_create(int device, void* stream, bmx_ctx** out)
     // an invalid value is ignored (the default stays)
     static const char* const env_keys[][2] = {
         {"BMX_PIPE_UNROLL", "pipe_unroll"}, {"BMX_PIPE_ROWS", "pipe_rows"}, {"BMX_PIPE_NT", "pipe_nt"},
-        {"BMX_PIPE_WG", "pipe_wg"}, {"BMX_PIPE_WINDOW", "pipe_window"}, {"BMX_PIPE_SPLIT", "pipe_split"}, {"BMX_OR_TILE", "or_tile"}, {"BMX_OR_ROWS", "or_rows"}, {"BMX_OR_DEPTH", "or_depth"}, {"BMX_OR_WINDOW", "or_window"}, {"BMX_DIRECT_COLS", "direct_cols"}, {"BMX_FF_WINDOW", "ff_window"}, {"BMX_GAP_COUNT", "gap_count"}, {"BMX_RANGE_HALVES", "range_halves"}, {"BMX_PAIR_STREAM", "pair_stream"}, {"BMX_PAIR_WGS", "pair_wgs"}, {"BMX_RS_LANES", "rs_lanes"}, {"BMX_RS_LINES", "rs_lines"}, {"BMX_RS_SELECT_LINES", "rs_select_lines"}, {"BMX_RS_SDIR_SHIFT", "rs_sdir_shift"}, {"BMX_COLL_SHAPE", "coll_shape"}, {"BMX_COLL_WINDOW", "coll_window"}, {"BMX_COLL_SPLIT", "coll_split"}, {"BMX_EQ_BIG", "eq_big"}, {"BMX_PAIR_LOOP", "pair_loop"}, {"BMX_PAIR_NT", "pair_nt"}, {"BMX_EQ_BIG_SHAPE", "eq_big_shape"}, {"BMX_OP2_WGS", "op2_wgs"}, {"BMX_OP2_NT", "op2_nt"}, {"BMX_GAP_PACK", "gap_pack"}, {"BMX_COLL_MEMBERS", "coll_members"}, {"BMX_XCD_SWIZZLE", "xcd_swizzle"}};
+        {"BMX_PIPE_WG", "pipe_wg"}, {"BMX_PIPE_WINDOW", "pipe_window"}, {"BMX_PIPE_SPLIT", "pipe_split"}, {"BMX_OR_TILE", "or_tile"}, {"BMX_OR_ROWS", "or_rows"}, {"BMX_OR_DEPTH", "or_depth"}, {"BMX_OR_WINDOW", "or_window"}, {"BMX_DIRECT_COLS", "direct_cols"}, {"BMX_FF_WINDOW", "ff_window"}, {"BMX_GAP_COUNT", "gap_count"}, {"BMX_RANGE_HALVES", "range_halves"}, {"BMX_PAIR_STREAM", "pair_stream"}, {"BMX_PAIR_WGS", "pair_wgs"}, {"BMX_RS_LANES", "rs_lanes"}, {"BMX_RS_LINES", "rs_lines"}, {"BMX_RS_SELECT_LINES", "rs_select_lines"}, {"BMX_RS_SDIR_SHIFT", "rs_sdir_shift"}, {"BMX_COLL_SHAPE", "coll_shape"}, {"BMX_COLL_WINDOW", "coll_window"}, {"BMX_COLL_SPLIT", "coll_split"}, {"BMX_EQ_BIG", "eq_big"}, {"BMX_PAIR_LOOP", "pair_loop"}, {"BMX_PAIR_NT", "pair_nt"}, {"BMX_EQ_BIG_SHAPE", "eq_big_shape"}, {"BMX_OP2_WGS", "op2_wgs"}, {"BMX_OP2_LOOP", "op2_loop"}, {"BMX_OP2_NT", "op2_nt"}, {"BMX_GAP_PACK", "gap_pack"}, {"BMX_COLL_MEMBERS", "coll_members"}, {"BMX_XCD_SWIZZLE", "xcd_swizzle"}};
     for (auto& kv : env_keys)
         if (const char* e = getenv(kv[0])) (void)bmx_ctx_set_tuning(ctx, kv[1], atoi(e));
     g_last_error.clear();
@@ -691,6 +691,7 @@ int bmx_ctx_set_tuning(bmx_ctx* ctx, const char* key, int value)
     else if (k == "coll_members") { ARGCHK(value >= -1 && value <= 1); ctx->coll_members = value; ++ctx->coll_gen; }
     else if (k == "coll_shape") { ARGCHK(value >= 0 && value <= 5); ctx->coll_shape = value; }
     else if (k == "op2_nt") { ARGCHK(value >= 0 && value <= 3); ctx->op2_nt = value; }
+    else if (k == "op2_loop") { ARGCHK(value >= -1 && value <= 8); ctx->op2_loop = value; }
     else if (k == "op2_wgs") { ARGCHK(value >= 1 && value <= 8); ctx->op2_wgs = value; }
     else if (k == "pair_nt") { ARGCHK(value >= 0 && value <= 1); ctx->pair_nt = value; }
     else if (k == "pair_loop") { ARGCHK(value >= -1 && value <= 5); ctx->pair_loop = value; }
@@ -869,9 +870,8 @@ static int vec_alloc_device(bmx_vec* v, uint32_t n_bit, uint64_t gap_words)
     if ((rc = dmalloc(ctx, (void**)&v->d_desc, b_desc))) return rc;
     if ((rc = dmalloc(ctx, (void**)&v->d_bits, b_bits))) return rc;
     if ((rc = dmalloc(ctx, (void**)&v->d_gaps, b_gaps))) return rc;
-    // padding words between GAP blocks (and the guard) read 0xFFFF: no run end but a block's last has that value, which is
-    // how k_agg_or_rows (bmx_kernels7.h) tells a run from padding without the block's length
-    if (gap_words) HIPCHK(hipMemsetAsync(v->d_gaps, 0xFF, b_gaps, ctx->stream));
+    // (padding words between GAP blocks read 0xFFFF -- what k_agg_or_rows relies on, bmx_kernels7.h: the kernels that write
+    // GAP blocks into the slab, k_emit_blocks / k_emit_gaps / k_gap_repack, write them)
     v->bytes = std::max<size_t>(b_desc, 16) + std::max<size_t>(b_bits, 16) + std::max<size_t>(b_gaps, 16);
     return BMX_OK;
 }
@@ -1677,7 +1677,6 @@ static int result_finish(bmx_ctx* ctx, bmx_vec* v, BlockStat* st, u32* offs)
     if (gap_words) {
         size_t b_gaps = (size_t)gap_words * 2 + 64;      // + guard, see vec_alloc_device
         if ((rc = dmalloc(ctx, (void**)&v->d_gaps, b_gaps))) return rc;
-        HIPCHK(hipMemsetAsync(v->d_gaps, 0xFF, b_gaps, ctx->stream));      // padding words read 0xFFFF (see vec_alloc_device)
         v->bytes += std::max<size_t>(b_gaps, 16);
         v->gap_words = gap_words;
         hipLaunchKernelGGL(k_emit_gaps, dim3((nblocks + 3) / 4), dim3(256), 0, ctx->stream,
@@ -1701,7 +1700,6 @@ static int result_finish(bmx_ctx* ctx, bmx_vec* v, BlockStat* st, u32* offs)
         HIPCHK(hipMemcpyAsync(v->d_ord, offs, (size_t)nblocks * 4, hipMemcpyDeviceToDevice, ctx->stream));
         pending = true;
     }
-    if (v->counts[BMX_GAP] | v->counts[BMX_FULL]) { if ((rc = vec_build_tdir(ctx, v))) return rc; pending = true; }
     if (pending) HIPCHK(hipStreamSynchronize(ctx->stream));
     if (old_slab) dfree(ctx, old_slab);
     if (live == 0) {                          // nothing lives in the slab: give it back
@@ -1737,7 +1735,6 @@ static int vec_clone(bmx_ctx* ctx, const bmx_vec* a, bmx_vec** out)
                            (u64)(uintptr_t)a->d_bits, (u64)(uintptr_t)v->d_bits, (u64)(uintptr_t)a->d_gaps, (u64)(uintptr_t)v->d_gaps);
         e = hipGetLastError();
     }
-    if (e == hipSuccess && (rc = vec_build_tdir(ctx, v))) { (void)hipStreamSynchronize(ctx->stream); bmx_vec_free(ctx, v); return rc; }
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) { bmx_vec_free(ctx, v); return fail_hip(e, "vec_clone", __LINE__); }
     if (a->count_valid) { v->count = a->count; v->count_valid = true; }
@@ -1773,7 +1770,7 @@ int bmx_op2(bmx_ctx* ctx, int op, const bmx_vec* a, const bmx_vec* b, int opt_co
     // no GAP block can come out (neither operand holds one, no re-compression): the kernel folds the kind counts itself
     // and the layout scan is skipped -- k_op2, one synchronise, done -- unless result blocks vanished (then the scan /
     // compaction path below decides what to do with the slab)
-    bool no_gap = !opt_compress && a->counts[BMX_GAP] == 0 && b->counts[BMX_GAP] == 0;
+    bool no_gap = !opt_compress && a->counts[BMX_GAP] == 0 && b->counts[BMX_GAP] == 0, folded = false;
     if (nblocks) {
         // bit-blocks only on both sides: the streaming form (one machine-load of waves, each owning a stretch of columns)
         const bool stream = no_gap && ctx->pair_stream != 0 && a->nblocks == b->nblocks && a->counts[BMX_BIT] == nblocks &&
@@ -1786,15 +1783,25 @@ int bmx_op2(bmx_ctx* ctx, int op, const bmx_vec* a, const bmx_vec* b, int opt_co
                     : ctx->op2_nt == 1 ? k_op2_stream<4, true, false> : k_op2_stream<4, false, false>;
             hipLaunchKernelGGL(fn, dim3(grid), dim3(256), 0, ctx->stream, op, a->d_desc, b->d_desc, nblocks, per_wave,
                                v->d_bits, v->d_desc, st, FoldOut{ctx->d_slots, ctx->d_done, ctx->h_small + 2});
+        } else if (ctx->op2_loop != 0 && nblocks >= 2048u) {
+            // any block kinds, long vectors: the persistent form (one memory round trip per column, GAP blocks decoded from registers)
+            const u32 wgs = (u32)(ctx->op2_loop > 0 ? ctx->op2_loop : 4);        // workgroups per CU = waves per SIMD
+            const u32 grid = std::min<u32>((nblocks + 3u) / 4u, 256u * wgs);
+            auto fn = (ctx->op2_nt & 1) ? k_op2_loop<4, true> : k_op2_loop<4, false>;
+            // the kinds are folded whatever the operands hold: when every block came out as a bit-block (OR / XOR of two 1 % vectors:
+            // their GAP x GAP results pass the 1,276-run limit) there is nothing for the layout scan to lay out
+            hipLaunchKernelGGL(fn, dim3(grid), dim3(256), 0, ctx->stream, op, a->d_desc, a->nblocks, b->d_desc, b->nblocks, nblocks, opt_compress,
+                               v->d_bits, v->d_desc, st, (no_gap || op == BMX_OR || op == BMX_XOR) ? FoldOut{ctx->d_slots, ctx->d_done, ctx->h_small + 2} : FoldOut{nullptr, nullptr, nullptr});
+            folded = op == BMX_OR || op == BMX_XOR;                         // (AND / SUB over GAP operands keep GAP results: straight to the layout scan, no extra synchronise)
         } else
         hipLaunchKernelGGL(k_op2, dim3((nblocks + 3) / 4), dim3(256), 0, ctx->stream, op,
                            a->d_desc, a->nblocks, b->d_desc, b->nblocks, nblocks, opt_compress,
                            v->d_bits, v->d_desc, st,
                            no_gap ? FoldOut{ctx->d_slots, ctx->d_done, ctx->h_small + 2} : FoldOut{nullptr, nullptr, nullptr});
         hipError_t e = hipGetLastError();
-        if (e == hipSuccess && no_gap) e = hipStreamSynchronize(ctx->stream);
+        if (e == hipSuccess && (no_gap || folded)) e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) { bmx_vec_free(ctx, v); return fail_hip(e, "k_op2", __LINE__); }
-        if (no_gap && ctx->h_small[2 + BMX_GAP] == 0 && ctx->h_small[2 + BMX_BIT] == nblocks) {
+        if ((no_gap || folded) && ctx->h_small[2 + BMX_GAP] == 0 && ctx->h_small[2 + BMX_BIT] == nblocks) {
             for (int k = 0; k < 4; ++k) v->counts[k] = (uint32_t)ctx->h_small[2 + k];
             *result = v;
             return BMX_OK;
@@ -1946,7 +1953,6 @@ static bool or_rows_wanted(const bmx_ctx* ctx, const bmx_vec* const* src, size_t
     if (ctx->or_rows == 0) return false;
     uint64_t words = 0, blocks = 0;
     for (size_t i = 0; i < n; ++i) {
-        if (!src[i]->d_tdir && (src[i]->counts[BMX_GAP] | src[i]->counts[BMX_FULL])) return false;   // (cannot happen: every creation path builds it)
         words += src[i]->gap_words; blocks += src[i]->counts[BMX_GAP];
     }
     return ctx->or_rows == 1 || (blocks && words * 10ull <= blocks * 328ull);     // <= 4.1 chunks of 8 words per GAP block
@@ -2030,6 +2036,9 @@ static int agg_or_impl(bmx_ctx* ctx, const bmx_vec* const* src, size_t n, int op
         std::vector<u64> tab; tab.reserve(n * 4);
         for (size_t i = 0; i < n; ++i) {
             const bmx_vec* o = src[i];
+            // uploaded / imported / generated vectors carry their tile directory; a RESULT vector (or a clone) gets its own the
+            // first time it is an operand here (the directory is a cache of the immutable vector's layout: logically const)
+            if (!o->d_tdir && (rc = vec_build_tdir(ctx, const_cast<bmx_vec*>(o)))) { (void)hipStreamSynchronize(ctx->stream); bmx_vec_free(ctx, v); return rc; }
             if (!o->d_tdir) continue;                                          // NULL blocks only: contributes nothing
             tab.push_back((u64)(uintptr_t)o->d_tdir); tab.push_back((u64)(uintptr_t)o->d_gaps);
             tab.push_back((u64)(uintptr_t)o->d_desc); tab.push_back((u64)o->nblocks);

@@ -79,6 +79,7 @@ struct bmx_ctx {
     int pair_nt = 1;           // ... with non-temporal loads
     int pair_loop = -1;        // pairwise counts over mixed block kinds: -1 = persistent kernel (4 workgroups per CU), 0 = a wave per column, N = workgroups per CU
     int op2_nt = 3;            // ... bit 0: non-temporal loads, bit 1: non-temporal stores
+    int op2_loop = -1;         // materialised pairwise ops over mixed block kinds (>= 2,048 blocks): -1 = persistent kernel (k_op2_loop, 4 workgroups per CU), 0 = a wave per column (k_op2), N = workgroups per CU
     int op2_wgs = 4;           // workgroups per CU of the streaming materialised pairwise kernel (k_op2_stream)
     int eq_big_shape = 2;      // lean table: 2 = 768 threads at 3 waves per SIMD, 8 filter reads in flight, 256 Kbit filter, 512-entry queues -- taken for every batch size over more than 16 planes; 1 = 512 threads, 2 waves per SIMD; 0 = 128 Kbit filter + 1,024-entry queues
     int eq_big = -1;           // batched equality counts: -1 = lean 9,216-value table when the batch has more than 2,048 values, 0 = never, 1 = always

@@ -187,6 +187,9 @@ void k_emit_blocks(const uint4* __restrict__ raw, u32 nblocks, const BlockStat* 
         g[len] = 65535u;
         desc[nb] = DESC_MAKE_GAP(g, len, st[nb].first);
     }
+    // padding words up to the next 16-byte boundary read 0xFFFF: no run end but a block's last has that value, which is how
+    // k_agg_or_rows (bmx_kernels7.h) tells a run from padding without the block's length
+    if (lane >= 1u && lane <= 7u && len + lane < ((len + 1u + 7u) & ~7u)) g[len + lane] = 0xFFFFu;
 }
 
 // ---------------------------------------------------------------------------

@@ -26,6 +26,7 @@
 //                  result is dropped; an all-ones result stays a GAP block of ONE run (it does not become FULL)
 enum { ST_OPT = 1, ST_FORCE_BIT = 2, ST_TEST_ZERO = 4, ST_TEST_ONE = 8, ST_FORCE_GAP = 16, ST_GAP_RESULT = 32 };
 
+template <bool SNT = false>
 __device__ __forceinline__ u32 store_result_mode(const Blk& acc, u32 nb, u32 mode,
                                                   uint4* __restrict__ slab, u64* __restrict__ desc,
                                                   BlockStat* __restrict__ st, u32 lane)
@@ -45,7 +46,13 @@ __device__ __forceinline__ u32 store_result_mode(const Blk& acc, u32 nb, u32 mod
         if ((mode & ST_TEST_ONE) && runs == 1u && first) kind = K_FULL;
     }
     uint4* slot = slab + (size_t)nb * 512u;
-    if (kind == K_BIT || kind == K_GAP) blk_store(acc, as_g4(slot), lane);
+    if (kind == K_BIT || kind == K_GAP) {
+        if (SNT) {                                               // written once, read by a later kernel: keep it out of the way of the operand streams
+            gptr4 p = as_g4(slot);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) __builtin_nontemporal_store(acc.r[i], &p[i * 64 + lane]);
+        } else blk_store(acc, as_g4(slot), lane);
+    }
     if (lane == 0) {
         st[nb] = BlockStat{pop, runs, first, kind};
         desc[nb] = (kind == K_BIT) ? DESC_MAKE(slot, K_BIT) : DESC_MAKE(0, kind == K_GAP ? K_NULL : kind);
@@ -121,6 +128,9 @@ void k_emit_gaps(const uint4* __restrict__ slab, u32 nblocks, const BlockStat* _
         g[len] = 65535u;
         desc[nb] = DESC_MAKE_GAP(g, len, st[nb].first);
     }
+    // padding words up to the next 16-byte boundary read 0xFFFF: no run end but a block's last has that value, which is how
+    // k_agg_or_rows (bmx_kernels7.h) tells a run from padding without the block's length
+    if (lane >= 1u && lane <= 7u && len + lane < ((len + 1u + 7u) & ~7u)) g[len + lane] = 0xFFFFu;
 }
 
 // result slab -> right-sized slab: bit-block nb moves to ordinal offs[nb] (from k_scan_layout) and its
@@ -177,49 +187,57 @@ __device__ __forceinline__ u64 desc_at(const u64* __restrict__ d, u32 n, u32 nb)
     return nb < n ? uniform64(d[nb]) : 0ull;
 }
 
+// NULL / FULL results that need no block data; 4 = the block has to be computed
+__device__ __forceinline__ u32 op2_trivial(int op, u32 ka, u32 kb)
+{
+    if (op == BMX_AND) {
+        if (ka == K_NULL || kb == K_NULL) return K_NULL;
+        if (ka == K_FULL && kb == K_FULL) return K_FULL;
+    } else if (op == BMX_OR) {
+        if (ka == K_FULL || kb == K_FULL) return K_FULL;
+        if (ka == K_NULL && kb == K_NULL) return K_NULL;
+    } else if (op == BMX_XOR) {
+        if ((ka == K_NULL && kb == K_NULL) || (ka == K_FULL && kb == K_FULL)) return K_NULL;
+        if ((ka == K_NULL && kb == K_FULL) || (ka == K_FULL && kb == K_NULL)) return K_FULL;
+    } else {
+        if (ka == K_NULL || kb == K_FULL) return K_NULL;
+        if (ka == K_FULL && kb == K_NULL) return K_FULL;
+    }
+    return 4u;
+}
+
+// how the produced block is classified: the reference case by case (see ST_* above)
+__device__ __forceinline__ u32 op2_store_mode(int op, u32 ka, u32 kb, int opt_compress)
+{
+    u32 copy_of = 4u;                                        // kind of the operand that is merely copied (4 = none)
+    if (op == BMX_AND) { if (ka == K_FULL) copy_of = kb; else if (kb == K_FULL) copy_of = ka; }
+    else if (op == BMX_OR) { if (ka == K_NULL) copy_of = kb; else if (kb == K_NULL) copy_of = ka; }
+    else if (op == BMX_XOR) { if (ka == K_NULL || ka == K_FULL) copy_of = kb; else if (kb == K_NULL || kb == K_FULL) copy_of = ka; }
+    else { if (kb == K_NULL) copy_of = ka; }
+    if (copy_of == K_BIT) return ST_FORCE_BIT;
+    if (copy_of == K_GAP) return ST_FORCE_GAP;
+    if (ka == K_GAP && kb == K_GAP) return ST_FORCE_GAP | ST_GAP_RESULT;
+    if (opt_compress) return ST_OPT;
+    const bool bb = ka != K_GAP && kb != K_GAP;               // bit x bit (FULL in SUB counts as a real all-ones block)
+    u32 mode = 0u;
+    if ((bb && op != BMX_OR) || op == BMX_AND || (ka == K_GAP && op == BMX_SUB)) mode |= ST_TEST_ZERO;
+    if (bb && op == BMX_OR) mode |= ST_TEST_ONE;
+    return mode;
+}
+
 // one result block of a pairwise operation; returns its kind
 __device__ __forceinline__ u32 op2_block(int op, u64 a, u64 b, u32 nb, int opt_compress, u32* l,
                                          uint4* __restrict__ slab, u64* __restrict__ desc, BlockStat* __restrict__ st, u32 lane)
 {
     u32 ka = DESC_K(a), kb = DESC_K(b);
     // shortcuts that produce NULL / FULL without reading anything
-    u32 trivial = 4u;
-    if (op == BMX_AND) {
-        if (ka == K_NULL || kb == K_NULL) trivial = K_NULL;
-        else if (ka == K_FULL && kb == K_FULL) trivial = K_FULL;
-    } else if (op == BMX_OR) {
-        if (ka == K_FULL || kb == K_FULL) trivial = K_FULL;
-        else if (ka == K_NULL && kb == K_NULL) trivial = K_NULL;
-    } else if (op == BMX_XOR) {
-        if ((ka == K_NULL && kb == K_NULL) || (ka == K_FULL && kb == K_FULL)) trivial = K_NULL;
-        else if ((ka == K_NULL && kb == K_FULL) || (ka == K_FULL && kb == K_NULL)) trivial = K_FULL;
-    } else {
-        if (ka == K_NULL || kb == K_FULL) trivial = K_NULL;
-        else if (ka == K_FULL && kb == K_NULL) trivial = K_FULL;
-    }
+    const u32 trivial = op2_trivial(op, ka, kb);
     if (trivial != 4u) { store_trivial(trivial, nb, desc, st, lane); return trivial; }
     Blk x, y;
     blk_from_desc(a, x, l, lane);
     blk_from_desc(b, y, l, lane);
     blk_op(op, x, y);
-    // classification of the produced block follows the reference case by case (see ST_* above)
-    u32 mode;
-    u32 copy_of = 4u;                                        // kind of the operand that is merely copied (4 = none)
-    if (op == BMX_AND) { if (ka == K_FULL) copy_of = kb; else if (kb == K_FULL) copy_of = ka; }
-    else if (op == BMX_OR) { if (ka == K_NULL) copy_of = kb; else if (kb == K_NULL) copy_of = ka; }
-    else if (op == BMX_XOR) { if (ka == K_NULL || ka == K_FULL) copy_of = kb; else if (kb == K_NULL || kb == K_FULL) copy_of = ka; }
-    else { if (kb == K_NULL) copy_of = ka; }
-    if (copy_of == K_BIT) mode = ST_FORCE_BIT;
-    else if (copy_of == K_GAP) mode = ST_FORCE_GAP;
-    else if (ka == K_GAP && kb == K_GAP) mode = ST_FORCE_GAP | ST_GAP_RESULT;
-    else if (opt_compress) mode = ST_OPT;
-    else {
-        bool bb = ka != K_GAP && kb != K_GAP;                 // bit x bit (FULL in SUB counts as a real all-ones block)
-        mode = 0u;
-        if ((bb && op != BMX_OR) || op == BMX_AND || (ka == K_GAP && op == BMX_SUB)) mode |= ST_TEST_ZERO;
-        if (bb && op == BMX_OR) mode |= ST_TEST_ONE;
-    }
-    return store_result_mode(x, nb, mode, slab, desc, st, lane);
+    return store_result_mode(x, nb, op2_store_mode(op, ka, kb, opt_compress), slab, desc, st, lane);
 }
 
 // kinds.slots != null: the kind counts of the result are folded inside the kernel (kind_fanin_fold) -- used when no GAP
@@ -361,6 +379,46 @@ void k_count_op2_loop(int op, const u64* __restrict__ da, u32 na, const u64* __r
     }
     cnt = wave_sum(cnt);
     count_fanin_fold(cnt, fold, lane, wave);
+}
+
+// bit_and / bit_or / bit_xor / bit_sub over operands of ANY block kinds, persistent form (round 4): the materialising twin of
+// k_count_op2_loop.  k_op2 pays, per column, a wave launch, a descriptor round trip, the block loads and -- for a GAP operand
+// -- one more round trip per 512 runs before anything is combined.  Here a wave stays and walks every (grid waves)-th column:
+// next descriptors one column ahead, ALL loads of a column issued without control flow (op2_issue), GAP operands decoded from
+// those registers (op2_finish), the result classified exactly as op2_block does and stored with non-temporal stores, the
+// kinds of everything the wave produced folded once at the end (kinds.slots != null: no layout scan when no GAP block came out).
+template <int WAVES, bool NT>
+__global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4)))
+void k_op2_loop(int op, const u64* __restrict__ da, u32 na, const u64* __restrict__ db, u32 nbk, u32 nblocks, int opt_compress,
+                uint4* __restrict__ slab, u64* __restrict__ desc, BlockStat* __restrict__ st, FoldOut kinds)
+{
+    __shared__ u32 lds[WAVES * 2048];
+    const u32 lane = lane_id(), wave = threadIdx.x >> 6;
+    u32* l = lds + wave * 2048u;
+    const u32 total = gridDim.x * (u32)WAVES;
+    u64 kc = 0ull;
+    u32 c = uniform32(blockIdx.x * (u32)WAVES + wave);
+    auto raw = [&](const u64* __restrict__ d, u32 n, u32 col) -> u64 { return col < n ? d[col] : 0ull; };
+    u64 ar = raw(da, na, c), br = raw(db, nbk, c);
+    for (; c < nblocks; c += total) {
+        const u64 a = uniform64(ar), b = uniform64(br);
+        ar = raw(da, na, c + total); br = raw(db, nbk, c + total);
+        const u32 ka = DESC_K(a), kb = DESC_K(b);
+        u32 kind = op2_trivial(op, ka, kb);
+        if (kind != 4u) store_trivial(kind, c, desc, st, lane);
+        else {
+            Blk x, y;
+            op2_issue<NT>(a, da, x, lane);
+            op2_issue<NT>(b, da, y, lane);
+            __builtin_amdgcn_sched_barrier(0);                    // (every load of the column leaves before anything is decoded)
+            op2_finish(a, x, l, lane);
+            op2_finish(b, y, l, lane);
+            blk_op(op, x, y);
+            kind = store_result_mode<true>(x, c, op2_store_mode(op, ka, kb, opt_compress), slab, desc, st, lane);
+        }
+        kc += 1ull << (16u * kind);
+    }
+    if (kinds.slots) kind_fanin_fold_packed(kc, kinds, lane, wave);
 }
 
 // bm::count_* when BOTH operands consist of bit-blocks only (the 10 % / 50 % cases of BASELINE configs[1]): the launch is

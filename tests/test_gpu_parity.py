@@ -1852,6 +1852,55 @@ def test_pairwise_count_long_mixed_vectors(ctx, port):
     assert ga.count() == pa.count()
 
 
+def test_pairwise_materialised_long_mixed_vectors(ctx, port):
+    """bit_and/or/xor/sub over long vectors (> 2,048 blocks) of ANY block kinds: the persistent kernel (k_op2_loop, 2 / 4 / 8
+    workgroups per CU, plain and non-temporal loads) and the wave-per-column kernel (op2_loop 0) = the oracle's bits AND block
+    kinds, with and without opt_compress: bit / sparse GAP / dense GAP / long runs / > 1,023-word GAP blocks / NULL / FULL on
+    either side, operands of different lengths"""
+    rng = np.random.default_rng(1234)
+    nblk_a, nblk_b = 2200, 2101
+    def build(nblk, seed):
+        w = port.gen_words(9002, seed, 655, nblk * 65536)                      # 1 %: bit / GAP mix
+        for nb in range(nblk):
+            r = rng.integers(0, 12)
+            lo = nb * 2048
+            if r == 0: w[lo:lo + 2048] = 0
+            elif r == 1: w[lo:lo + 2048] = 0xFFFFFFFF
+            elif r == 2:
+                w[lo:lo + 2048] = 0; w[lo + 10:lo + 700] = 0xFFFFFFFF; w[lo + 1200:lo + 1210] = 0xFFFFFFFF; w[lo + 2047] = 0x80000000
+            elif r == 3:
+                w[lo:lo + 2048] = 0
+                for b in rng.choice(65536, 560, replace=False): w[lo + (b >> 5)] |= np.uint32(1 << (b & 31))
+            elif r == 4: w[lo:lo + 2048] = ~w[lo:lo + 2048]
+            elif r == 5: w[lo:lo + 2048] = rng.integers(0, 1 << 32, 2048, dtype=np.uint64).astype(np.uint32)
+        return w
+    wa, wb = build(nblk_a, 1), build(nblk_b, 2)
+    pa, pb = port.import_words(wa, True, wa.size * 32), port.import_words(wb, True, wb.size * 32)
+    assert set(pa.flatten()[0].tolist()) == {0, 1, 2, 3} and set(pb.flatten()[0].tolist()) == {0, 1, 2, 3}
+    ga, gb = bm.bvector.from_block_table(ctx, wa.size * 32, *pa.flatten()), bm.bvector.from_block_table(ctx, wb.size * 32, *pb.flatten())
+    nw = max(wa.size, wb.size)
+    exp = {}
+    for opt in (0, 1):
+        for op in range(4):
+            for name, (x, y) in (("ab", (pa, pb)), ("ba", (pb, pa))):
+                e = port.op2(op, x, y, opt)
+                exp[(opt, op, name)] = (e.flatten()[0].tolist(), e.to_words(nw), e.count())
+    try:
+        for loop, nt in ((0, 3), (2, 3), (4, 2), (8, 3), (-1, 3)):
+            ctx.set_tuning("op2_loop", loop); ctx.set_tuning("op2_nt", nt)
+            for opt in (0, 1):
+                for op in range(4):
+                    for name, (x, y) in (("ab", (ga, gb)), ("ba", (gb, ga))):
+                        t = bm.bvector._op2(op, x, y, bm.opt_compress if opt else bm.opt_none)
+                        kinds, words, cnt = exp[(opt, op, name)]
+                        assert t.block_table()[0].tolist() == kinds, (loop, nt, opt, op, name)
+                        assert (t.to_words(nw) == words).all(), (loop, nt, opt, op, name)
+                        assert t.count() == cnt
+                        del t
+    finally:
+        ctx.set_tuning("op2_loop", -1); ctx.set_tuning("op2_nt", 3)
+
+
 def test_full_size_pairwise_and_rank_select_vs_reference_on_all_cores(ctx):
     """BASELINE configs[1] and configs[3] at FULL size against the reference itself (oracle/_ref, the unmodified BitMagic;
     the C port where it is absent) fanned over the host cores by block range -- not only identities: the four counts of a
