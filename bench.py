@@ -780,7 +780,21 @@ def run_pairwise(args, env, dq=None, quick=False):
     # what the box gives a plain 2-read : 1-write elementwise kernel of the same sizes (torch.bitwise_and(out=) over rotating
     # 125 MB tensors): the yardstick for the materialised ops above, whose kernel moves the same bytes
     rw_probe = None
+    own_probe = None
     if not quick:
+        try:
+            # the library's own yardstick: c = a & b in the launch shape of k_op2_stream (non-temporal 16-byte loads / stores),
+            # no descriptors, no classification -- at 1, 2, 4, 8 workgroups per CU, rotating over 3 buffer triples
+            best = None
+            for wgs in (1, 2, 4, 8):
+                pm = C.c_float()
+                _ffi.check(L.bmx_probe_stream_rw(ctx._h, ((nbits + 65535) // 65536) * 8192, 3, wgs, 12, C.byref(pm)))
+                if best is None or pm.value < best[1]: best = (wgs, pm.value)
+            nb_bytes = ((nbits + 65535) // 65536) * 8192
+            own_probe = {"kernel": "k_probe_rw<4> (bmx_probe_stream_rw): c = a & b, a wave per stretch of 8-KiB blocks, nt loads + nt stores",
+                         "best_wgs_per_cu": best[0], "ms": round(best[1], 4), "GBps_read_plus_written": round(3 * nb_bytes / best[1] / 1e6, 1)}
+        except Exception as e:
+            own_probe = {"error": str(e)}
         try:
             nw = (nbits + 63) // 64
             xs = [torch.randint(0, 1 << 62, (nw,), dtype=torch.int64, device="cuda") for _ in range(3 * 3)]
@@ -824,7 +838,7 @@ def run_pairwise(args, env, dq=None, quick=False):
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
            "config": {"workload": f"bm::count_and/or/xor/sub + bit_and/or/xor/sub on 2 x {nbits}-bit vectors, Bernoulli {pct:.3g}% (density q16 {dq}), "
                                   f"rotating over {npairs} distinct pairs ({sum(pair_bytes) / 1e9:.2f} GB: not Infinity-Cache resident)",
-                      "baseline_config": "configs[1]", "block_types_vec0": va[0].calc_stat(), "per_op": per_op, "read_write_probe": rw_probe,
+                      "baseline_config": "configs[1]", "block_types_vec0": va[0].calc_stat(), "per_op": per_op, "read_write_probe": rw_probe, "own_read_write_probe": own_probe,
                       "count_and": counts[:4], "pair0_counts_and_or_xor_sub": pair0},
            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": c1_traffic, "traffic_source": c1_tsrc,

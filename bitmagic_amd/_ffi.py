@@ -136,6 +136,7 @@ def lib() -> C.CDLL:
         "bmx_gpipeline_operand_bytes": (i32, [vp, vp, P(u64)]),
         "bmx_gpipeline_describe": (i32, [vp, vp, i32, C.c_char_p, C.c_size_t, P(u32)]),
         "bmx_probe_random_lines": (i32, [vp, u64, u64, i32, P(C.c_float)]),
+        "bmx_probe_stream_rw": (i32, [vp, u64, i32, i32, i32, P(C.c_float)]),
         "bmx_timer_start": (i32, [vp]),
         "bmx_timer_stop_ms": (i32, [vp, P(C.c_float)]),
     }

@@ -709,6 +709,38 @@ int bmx_ctx_set_tuning(bmx_ctx* ctx, const char* key, int value)
     return BMX_OK;
 }
 
+// Measurement helper: ms of one pass of c = a & b over three buffers of `bytes` each, in the launch shape of k_op2_stream
+// (a wave per stretch of 8-KiB blocks, non-temporal 16-byte loads and stores): the yardstick bench.py --config 1 puts next
+// to the materialised pairwise operations.  The passes rotate over `sets` buffer triples so that nothing is served by the
+// Infinity Cache.
+int bmx_probe_stream_rw(bmx_ctx* ctx, uint64_t bytes, int sets, int wgs_per_cu, int iters, float* ms_per_pass)
+{
+    ARGCHK(ctx && ms_per_pass && bytes >= 8192 && sets >= 1 && sets <= 8 && wgs_per_cu >= 1 && wgs_per_cu <= 8 && iters >= 1);
+    int rc = set_dev(ctx); if (rc) return rc;
+    const u64 nblk = bytes / 8192;
+    if (nblk > 0x7FFFFFFFull) { g_last_error = "probe buffer too large"; return BMX_ERR_RANGE; }
+    void* buf = nullptr;
+    HIPCHK(hipMalloc(&buf, (size_t)nblk * 8192 * 3 * sets));
+    hipError_t e = hipMemsetAsync(buf, 0x5A, (size_t)nblk * 8192 * 3 * sets, ctx->stream);
+    const u32 waves = 4u, total = 256u * waves * (u32)wgs_per_cu;
+    const u32 per_wave = (u32)((nblk + total - 1u) / total);
+    const u32 grid = (u32)(((nblk + per_wave - 1u) / per_wave + waves - 1u) / waves);
+    for (int it = -2; it < iters && e == hipSuccess; ++it) {
+        if (it == 0) e = hipEventRecord(ctx->ev0, ctx->stream);
+        uint4* base = (uint4*)buf + (size_t)((it + 2) % sets) * nblk * 512u * 3u;
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_probe_rw<4>), dim3(grid), dim3(256), 0, ctx->stream, (const uint4*)base, (const uint4*)(base + nblk * 512u),
+                           base + 2u * nblk * 512u, (u32)nblk, per_wave);
+    }
+    if (e == hipSuccess) e = hipEventRecord(ctx->ev1, ctx->stream);
+    if (e == hipSuccess) e = hipEventSynchronize(ctx->ev1);
+    float ms = 0;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
+    (void)hipFree(buf);
+    if (e != hipSuccess) return fail_hip(e, "bmx_probe_stream_rw", __LINE__);
+    *ms_per_pass = ms / iters;
+    return BMX_OK;
+}
+
 #ifdef BMX_DIAG
 int bmx_diag_stream_read(bmx_ctx* ctx, uint64_t bytes, int nt, uint32_t blocks_per_wave, int pattern, int iters, float* ms_per_pass)
 {

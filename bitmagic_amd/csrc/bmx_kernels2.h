@@ -523,6 +523,41 @@ void k_op2_stream(int op, const u64* __restrict__ da, const u64* __restrict__ db
     kind_fanin_fold_packed(kc, kinds, lane, wave);
 }
 
+// The yardstick of k_op2_stream: the same launch shape (a wave per stretch of 8-KiB blocks, two blocks in flight, non-temporal
+// 16-byte loads and stores) doing nothing but c = a & b -- no descriptors, no classification, no per-block records.  What this
+// box gives a 2-read : 1-write stream of that shape (bmx_probe_stream_rw).
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64)
+void k_probe_rw(const uint4* __restrict__ a, const uint4* __restrict__ b, uint4* __restrict__ c, u32 nblocks, u32 per_wave)
+{
+    const u32 lane = lane_id(), wave = threadIdx.x >> 6;
+    const u32 w = uniform32(blockIdx.x * (u32)WAVES + wave);
+    const u32 c0 = w * per_wave;
+    const u32 c1 = c0 + per_wave < nblocks ? c0 + per_wave : nblocks;
+    if (c0 >= c1) return;
+    auto load = [&](Blk& x, Blk& y, u32 col) {
+        const u32 cc = col < nblocks ? col : nblocks - 1u;
+        part_load<8, true>(x, as_gc4(a + (size_t)cc * 512u), lane); part_load<8, true>(y, as_gc4(b + (size_t)cc * 512u), lane);
+    };
+    auto eat = [&](Blk& x, const Blk& y, u32 col) {
+        blk_and(x, y);
+        gptr4 p = as_g4(c + (size_t)col * 512u);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) __builtin_nontemporal_store(x.r[i], &p[i * 64 + lane]);
+    };
+    Blk x0, y0, x1, y1;
+    u32 col = c0;
+    load(x0, y0, col);
+    for (; col + 2u < c1; col += 2u) {
+        load(x1, y1, col + 1u);
+        eat(x0, y0, col);
+        load(x0, y0, col + 2u);
+        eat(x1, y1, col + 1u);
+    }
+    if (col + 1u < c1) { load(x1, y1, col + 1u); eat(x0, y0, col); eat(x1, y1, col + 1u); }
+    else eat(x0, y0, col);
+}
+
 // ---------------------------------------------------------------------------
 // OR-group classification (aggregator::sort_input_blocks_or src/bmaggregator.h:2278):
 // row = [hdr, flags, region(n)]; hdr = nbit | ngap<<16; any FULL => ROW_FULL;

@@ -434,6 +434,12 @@ int bmx_timer_stop_ms(bmx_ctx* ctx, float* ms);   /* synchronises on the stop ev
  * the rank / select rates by (random access is bound by the HBM transaction rate) */
 int bmx_probe_random_lines(bmx_ctx* ctx, uint64_t buf_bytes, uint64_t nlines, int iters, float* ms_per_pass);
 
+/* measurement helper: ms of one pass of c = a & b over three buffers of `bytes` each (rotating over `sets` triples so that the
+ * Infinity Cache serves nothing) in the launch shape of the streaming pairwise kernel -- a wave per stretch of 8-KiB blocks,
+ * wgs_per_cu workgroups of 4 waves per CU, non-temporal 16-byte loads and stores: what this box gives a 2-read : 1-write
+ * stream, the yardstick bench.py --config 1 reports next to bvector::bit_and/or/xor/sub (src/bm.h:6185) */
+int bmx_probe_stream_rw(bmx_ctx* ctx, uint64_t bytes, int sets, int wgs_per_cu, int iters, float* ms_per_pass);
+
 #ifdef __cplusplus
 }
 #endif
