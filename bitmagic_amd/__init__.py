@@ -324,6 +324,12 @@ class rs_index:
         check(lib().bmx_rs_count(self._h, C.byref(c)))
         return c.value
 
+    def info(self) -> dict:
+        """device bytes of the index and whether it holds rank lines (memory policy: tuning key rs_lines)"""
+        b, h = C.c_uint64(), C.c_int32()
+        check(lib().bmx_rs_info(self._h, C.byref(b), C.byref(h)))
+        return {"bytes": b.value, "has_lines": bool(h.value)}
+
     def export(self):
         """-> bcount[nb], sub_count[nb] (first | second<<16 | aux0<<32 | aux1<<48)"""
         n = self.bv.info()["nblocks"]

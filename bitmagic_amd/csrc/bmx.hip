@@ -701,7 +701,7 @@ int bmx_ctx_set_tuning(bmx_ctx* ctx, const char* key, int value)
     else if (k == "coll_window") { ARGCHK(value >= 0); ctx->coll_window = value; }
     else if (k == "rs_select_lines") { ARGCHK(value >= 0 && value <= 2); ctx->rs_select_lines = value; }
     else if (k == "rs_sdir_shift") { ARGCHK(value == 0 || (value >= 6 && value <= 20)); ctx->rs_sdir_shift = value; }
-    else if (k == "rs_lines") { ARGCHK(value == 0 || value == 1); ctx->rs_lines = value; }
+    else if (k == "rs_lines") { ARGCHK(value >= 0 && value <= 2); ctx->rs_lines = value; }
     else if (k == "rs_lanes") { ARGCHK(value == 0 || value == 2 || value == 4 || value == 8); ctx->rs_lanes = value; }
     else if (k == "pipe_wg") { ARGCHK(value == 0 || (value >= 64 && value <= 1024 && value % 64 == 0)); ctx->pipe_wg = value; }
     else if (k == "xcd_swizzle") ctx->xcd_swz = value != 0;
@@ -2901,7 +2901,7 @@ int bmx_rs_build(bmx_ctx* ctx, const bmx_vec* v, bmx_rs** out)
     if ((rc = dmalloc(ctx, (void**)&rs->d_bcount, b1)) || (rc = dmalloc(ctx, (void**)&rs->d_sub, b2)) ||
         (rc = dmalloc(ctx, (void**)&rs->d_rcount, b3)) || (rc = dmalloc(ctx, (void**)&rs->d_cum, b4)) ||
         (rc = dmalloc(ctx, (void**)&rs->d_gidx, b4))) { bmx_rs_free(ctx, rs); return rc; }
-    rs->bytes = b1 + b2 + b3 + b4;
+    rs->bytes = b1 + b2 + b3 + 2 * b4;
     if (v->nblocks) {
 #define RSCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { int r_ = fail_hip(e_, #call, __LINE__); bmx_rs_free(ctx, rs); return r_; } } while (0)
         hipLaunchKernelGGL(k_rs_build, dim3((v->nblocks + 3) / 4), dim3(256), 0, ctx->stream,
@@ -2916,9 +2916,17 @@ int bmx_rs_build(bmx_ctx* ctx, const bmx_vec* v, bmx_rs** out)
         hipLaunchKernelGGL(k_rs_sample, dim3((rs->nsamples + 255) / 256), dim3(256), 0, ctx->stream,
                            rs->d_rcount, v->nblocks, shift, rs->nsamples, rs->d_sample);
         RSCHK(hipGetLastError());
-        if (ctx->rs_lines) {
-            // rank lines (bmx_kernels6.h): the vector once more, interleaved with its running counts -- one line per rank query
-            size_t bl = (size_t)v->nblocks * RL_LINES * 128u;
+        // rank lines (bmx_kernels6.h): the vector once more, interleaved with its running counts -- one line per rank query.
+        // Memory policy (rs_lines 1): they are built where they cost no more than 1.2 x what the vector itself holds on the
+        // device, i.e. for vectors that are bit-blocks almost throughout; a sparse vector (GAP / NULL / FULL blocks: a 4e9-bit
+        // operand of configs[4] is 3.4 MB, its lines would be 539 MB) keeps the table kernels (k_rank_l / k_select_l over the
+        // running counts, src/bmrs.h:39-155 is 0.7 MB for such a vector too).  Line numbers are 32-bit: 69 lines per block
+        // pass 2^32 at 62.2 M blocks = 510 GB of bit-blocks under this policy, more than a device holds; refused anyway.
+        const size_t lines_bytes = (size_t)v->nblocks * RL_LINES * 128u;
+        const bool lines_fit = (uint64_t)v->nblocks * RL_LINES < 0xFFFFFFFFull;
+        const bool want_lines = lines_fit && (ctx->rs_lines == 2 || (ctx->rs_lines == 1 && (double)lines_bytes <= 1.2 * (double)v->bytes));
+        if (want_lines) {
+            size_t bl = lines_bytes;
             if ((rc = dmalloc(ctx, (void**)&rs->d_lines, bl)) || (rc = dmalloc(ctx, (void**)&rs->d_dir8, (size_t)v->nblocks * 16u))) { bmx_rs_free(ctx, rs); return rc; }
             rs->bytes += bl + (size_t)v->nblocks * 16u;
             hipLaunchKernelGGL(k_rs_lines, dim3((v->nblocks + 3) / 4), dim3(256), 0, ctx->stream,
@@ -2948,6 +2956,14 @@ int bmx_rs_build(bmx_ctx* ctx, const bmx_vec* v, bmx_rs** out)
 #undef RSCHK
     }
     *out = rs;
+    return BMX_OK;
+}
+
+int bmx_rs_info(const bmx_rs* rs, uint64_t* bytes, int* has_lines)
+{
+    ARGCHK(rs);
+    if (bytes) *bytes = rs->bytes;
+    if (has_lines) *has_lines = rs->d_lines ? 1 : 0;
     return BMX_OK;
 }
 

@@ -84,7 +84,7 @@ struct bmx_ctx {
     int eq_big_shape = 2;      // lean table: 2 = 768 threads at 3 waves per SIMD, 8 filter reads in flight, 256 Kbit filter, 512-entry queues -- taken for every batch size over more than 16 planes; 1 = 512 threads, 2 waves per SIMD; 0 = 128 Kbit filter + 1,024-entry queues
     int eq_big = -1;           // batched equality counts: -1 = lean 9,216-value table when the batch has more than 2,048 values, 0 = never, 1 = always
     int coll_window = 0;       // block columns per launch of k_coll_apply (0 = one launch)
-    int rs_lines = 1;          // build_rs_index also lays the vector out as rank lines (one 128-B line per rank query; +108 % memory next to the vector): 0 = off
+    int rs_lines = 1;          // build_rs_index also lays the vector out as rank lines (one 128-B line per rank query; +108 % of the raw bits): 1 = where that is <= 1.2 x the vector's own device bytes (dense vectors), 2 = always, 0 = never
     int rs_sdir_shift = 0;     // ones per select-directory entry = 2^this; 0 = from the density (an entry per ~10 lines); grown when the directory would pass 8 MB
     int rs_select_lines = 2;   // select through the rank lines (octant directory + interpolated line guess verified by the line headers): 0 = k_select_l, 2 = select directory over the lines (k_select_sdir)
     int rs_lanes = 0;          // rank: lanes per query (k_rank_l): 0 = automatic, 8 = the original kernel, 2, 4

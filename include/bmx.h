@@ -304,6 +304,10 @@ int bmx_pipeline_describe(bmx_ctx* ctx, bmx_pipeline* p, uint32_t nb_from, uint3
 /* bvector::build_rs_index  src/bm.h:2531 */
 int bmx_rs_build(bmx_ctx* ctx, const bmx_vec* v, bmx_rs** out);
 int bmx_rs_free(bmx_ctx* ctx, bmx_rs* rs);
+/* what the index holds on the device (rs_index itself is ~0.7 MB per 4e9 bits, src/bmrs.h:39-155; here: running counts and a
+ * 256-byte row per block, plus -- for vectors that are bit-blocks almost throughout, tuning key "rs_lines" -- the rank lines:
+ * the vector laid out once more with its running counts interleaved, +108 % of the raw bits) */
+int bmx_rs_info(const bmx_rs* rs, uint64_t* bytes, int* has_lines);
 /* rs_index::count()  src/bmrs.h:340 */
 int bmx_rs_count(const bmx_rs* rs, uint64_t* count);
 /* reference-compatible per-block arrays so a host rs_index can be filled:

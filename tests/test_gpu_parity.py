@@ -404,6 +404,39 @@ def test_pairwise_materialised_streaming_kernel(ctx, port, nblocks_x):
         ctx.set_tuning("pair_stream", -1); ctx.set_tuning("op2_wgs", 4); ctx.set_tuning("op2_nt", 3)
 
 
+def test_rank_line_memory_policy(ctx, port):
+    """build_rs_index lays a vector out as rank lines only where that costs <= 1.2 x the vector's own device bytes (rs_lines 1):
+    a dense vector gets them, a sparse GAP vector (a configs[4] operand: 3.4 MB against 539 MB of lines) does not, and rank /
+    select answer the same either way"""
+    nbits = 600 * 65536 - 99
+    dense = bm.bit_import_u32(ctx, port.gen_words(5, 1, 6554, nbits), True)
+    sparse = bm.bit_import_u32(ctx, port.gen_words(5, 2, 13, nbits), True)
+    assert sparse.calc_stat()["bit_blocks"] == 0
+    rd, rsp = dense.build_rs_index(), sparse.build_rs_index()
+    idn, isp = rd.info(), rsp.info()
+    assert idn["has_lines"] and not isp["has_lines"]
+    dev_bytes = lambda v: v.info()["gap_words"] * 2 + v.info()["nblocks"] * 8 + v.info()["counts"][bm.BIT] * 8192
+    assert isp["bytes"] <= 1.2 * dev_bytes(sparse) + 600 * 300                # O(nblocks): running counts + two 128-byte rows per block
+    assert idn["bytes"] <= 1.2 * dev_bytes(dense) + 600 * 300 + 16 * 600
+    ps = port.import_words(port.gen_words(5, 2, 13, nbits), True, nbits)
+    prs = port.rs_build(ps)
+    rng = np.random.default_rng(3)
+    q = rng.integers(0, nbits, 5000, dtype=np.uint64)
+    assert (np.asarray(sparse.count_to(q, rsp)) == prs.rank(q)).all()
+    r = rng.integers(1, prs.count() + 1, 5000, dtype=np.uint64)
+    f, pos = sparse.select(r, rsp)
+    assert np.asarray(f).all() and (np.asarray(pos) == prs.select(r)[0]).all()
+    ctx.set_tuning("rs_lines", 2)                                                # forced: same answers through the lines
+    try:
+        rl = sparse.build_rs_index()
+        assert rl.info()["has_lines"]
+        assert (np.asarray(sparse.count_to(q, rl)) == prs.rank(q)).all()
+        f2, pos2 = sparse.select(r, rl)
+        assert np.asarray(f2).all() and (np.asarray(pos2) == np.asarray(pos)).all()
+    finally:
+        ctx.set_tuning("rs_lines", 1)
+
+
 def test_full_size_256way_and_count(ctx, port):
     """BASELINE config 3: aggregator AND + COUNT over 256 x 1e9-bit vectors (correlated data set A).
     Checks: shard sums == total; sampled block columns equal the oracle run on the same
@@ -1283,7 +1316,7 @@ def test_rank_select_queries_in_flight_forms(port, unroll, lines, sel):
     batches that do not fill the last round"""
     c = bm.context(0)
     c.set_tuning("rs_lanes", unroll)
-    c.set_tuning("rs_lines", lines)
+    c.set_tuning("rs_lines", 2 if lines else 0)                           # (2 = lines whatever the memory policy says: this vector is mostly NULL / FULL / GAP)
     # select over the lines: 1 = block index + octant directory (k_select_lines), 2 = select directory (k_select_sdir;
     # with 64 ones per entry -- several entries per line -- and with one entry for the whole vector: the bisection path)
     if isinstance(sel, tuple): c.set_tuning("rs_sdir_shift", sel[1]); sel = sel[0]
