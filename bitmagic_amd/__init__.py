@@ -37,6 +37,7 @@ AND, OR, XOR, SUB = 0, 1, 2, 3
 BLOCK_WORDS, BLOCK_BITS = 2048, 65536
 opt_none, opt_compress = 0, 3        # bvector::optmode (src/bm.h:129-135)
 ID_MAX = 0xFFFFFFFF                  # bm::id_max (src/bmconst.h:109)
+ID_MAX64 = 0xFFFFFFFFFFFFFFFF
 
 __all__ = ["context", "bvector", "aggregator", "slice_scanner", "rs_index", "group", "gbvector", "gaggregator", "gpipeline", "bit_import_u32", "count_and", "count_or",
            "count_xor", "count_sub", "BmxError", "simd_version", "device_count", "agg_run_options",
@@ -428,8 +429,16 @@ class pipeline:
         return self._or_target
 
     def set_search_count_limit(self, limit: int):
-        """(:255) approximate by contract -- "can find more, cannot find less" -- accepted and ignored"""
+        """(:255, honoured at :1365) a group needs no more than `limit` hits: "can find more, cannot find less"; the counts
+        run walks the block columns in ascending launch windows and stops launching once every group has enough"""
         self.search_count_limit = limit
+        if self._h:
+            check(lib().bmx_pipeline_set_search_count_limit(self.ctx._h, self._h, min(int(limit), ID_MAX64)))
+
+    def last_windows(self):
+        a, b = C.c_uint32(), C.c_uint32()
+        check(lib().bmx_pipeline_last_windows(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
 
     def get_bv_res_vector(self) -> list:
         return self._results
@@ -453,6 +462,8 @@ class pipeline:
         check(lib().bmx_pipeline_create(self.ctx._h, _handles(and_list), and_n, _handles(sub_list), sub_n,
                                         len(self.groups), C.byref(h)))
         self._h = h
+        if self.search_count_limit not in (ID_MAX, ID_MAX64):
+            check(lib().bmx_pipeline_set_search_count_limit(self.ctx._h, self._h, int(self.search_count_limit)))
 
     def is_complete(self) -> bool:
         return self._h is not None
@@ -1040,6 +1051,8 @@ class gpipeline:
         check(lib().bmx_gpipeline_create(self.grp._h, _handles(and_list), and_n, _handles(sub_list), sub_n,
                                          len(self.groups), C.byref(h)))
         self._h = h
+        if self.search_count_limit not in (ID_MAX, ID_MAX64):
+            check(lib().bmx_pipeline_set_search_count_limit(self.ctx._h, self._h, int(self.search_count_limit)))
 
     def is_complete(self) -> bool:
         return self._h is not None

@@ -1628,6 +1628,21 @@ int bmx_pipeline_describe(bmx_ctx* ctx, bmx_pipeline* p, uint32_t nb_from, uint3
     return BMX_OK;
 }
 
+int bmx_pipeline_set_search_count_limit(bmx_ctx* ctx, bmx_pipeline* p, uint64_t limit)
+{
+    ARGCHK(ctx && p && p->ctx == ctx);
+    p->search_limit = limit ? limit : ~0ull;
+    return BMX_OK;
+}
+
+int bmx_pipeline_last_windows(const bmx_pipeline* p, uint32_t* launched, uint32_t* planned)
+{
+    ARGCHK(p);
+    if (launched) *launched = p->last_windows;
+    if (planned) *planned = p->last_windows_planned;
+    return BMX_OK;
+}
+
 int bmx_pipeline_run_counts(bmx_ctx* ctx, bmx_pipeline* p, uint32_t nb_from, uint32_t nb_to, uint64_t* counts_out)
 {
     ARGCHK(ctx && p && p->ctx == ctx && counts_out);
@@ -1636,6 +1651,37 @@ int bmx_pipeline_run_counts(bmx_ctx* ctx, bmx_pipeline* p, uint32_t nb_from, uin
     size_t bytes = (size_t)p->ngroups * 8;
     if (p->ngroups <= 64) d_counts = ctx->d_small;
     else if ((rc = dmalloc(ctx, (void**)&d_counts, bytes))) return rc;
+    p->last_windows = p->last_windows_planned = 1;
+    if (p->search_limit != ~0ull) {
+        // set_search_count_limit (:255, honoured at :1365: a group whose count has reached the limit is not evaluated on the
+        // following blocks -- "can find more, cannot find less").  Here: ascending launch windows of block columns (as
+        // find_first_and_sub walks them), the counts read back after each; once EVERY group holds >= limit hits the remaining
+        // windows are not launched.  A group returns >= min(limit, its true count) and never more than its true count.
+        uint32_t f = nb_from, t = nb_to;
+        if ((rc = pipe_range(p, f, t))) { if (p->ngroups > 64) dfree(ctx, d_counts); return rc; }
+        std::vector<uint64_t> part(p->ngroups);
+        for (u32 g = 0; g < p->ngroups; ++g) counts_out[g] = 0;
+        const u32 ncols = t - f;
+        u32 w = std::max<u32>(ncols / 64u, 16u), planned = 0;
+        for (u32 c = 0, ww = w; c < ncols; c += ww, ww *= 4u) ++planned;
+        p->last_windows_planned = planned; p->last_windows = 0;
+        for (u32 c = 0; c < ncols && !rc; c += w, w *= 4u) {
+            const u32 c1 = (u32)std::min<u64>((u64)c + w, ncols);
+            rc = pipeline_run_counts_impl(ctx, p, f + c, f + c1, d_counts, p->last_windows == 0);
+            if (!rc) {
+                hipError_t e = hipMemcpyAsync(part.data(), d_counts, bytes, hipMemcpyDeviceToHost, ctx->stream);
+                if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+                if (e != hipSuccess) rc = fail_hip(e, "counts readback", __LINE__);
+            }
+            if (rc) break;
+            ++p->last_windows;
+            bool all = true;
+            for (u32 g = 0; g < p->ngroups; ++g) { counts_out[g] += part[g]; all = all && counts_out[g] >= p->search_limit; }
+            if (all) break;
+        }
+        if (p->ngroups > 64) dfree(ctx, d_counts);
+        return rc;
+    }
     rc = pipeline_run_counts_impl(ctx, p, nb_from, nb_to, d_counts, true);
     if (!rc) {
         hipError_t e = hipMemcpyAsync(counts_out, d_counts, bytes, hipMemcpyDeviceToHost, ctx->stream);

@@ -122,6 +122,8 @@ struct bmx_pipeline {
     size_t bytes;
     // GAP-only pipelines: the uids of the operand vectors (AND lists, then SUB lists, in group order) -- never the pointers: a
     // vector freed before the pipeline is simply not found in any collection any more -- and what they resolved to
+    uint64_t search_limit = ~0ull;       // pipeline::set_search_count_limit (src/bmaggregator.h:255): a group needs no more than this many hits
+    uint32_t last_windows = 0, last_windows_planned = 0;   // launch windows of the last synchronous counts run under a limit
     std::vector<uint64_t>* h_uids = nullptr;
     uint64_t cm_gen = ~0ull;            // ctx->coll_gen at the last resolution
     uint64_t cm_a_id = 0, cm_s_id = 0;  // collections serving the AND lists / SUB lists (0 = none)

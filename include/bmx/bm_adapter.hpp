@@ -321,7 +321,7 @@ public:
         bool is_complete() const noexcept { return complete_; }
         size_t size() const noexcept { return groups_.size(); }
         void set_or_target(BV* bv_or) noexcept { or_target_ = bv_or; }                      // :245
-        void set_search_count_limit(size_type limit) noexcept { limit_ = limit; }          // :255 (approximate by contract)
+        void set_search_count_limit(size_type limit) noexcept { limit_ = limit; }          // :255 (forwarded to the device pipeline)
         std::vector<BV*>& get_bv_res_vector() noexcept { return results_; }                // nullptr where a group found nothing
         std::vector<size_type>& get_bv_count_vector() noexcept { return counts_; }
     private:
@@ -427,6 +427,7 @@ public:
         }
         bvector ort(*ctx_);
         if (pipe.or_target_) { upload(*pipe.or_target_, ort, common_blocks_); dp.set_or_target(&ort); }
+        if (pipe.limit_ != ~size_type(0)) dp.set_search_count_limit((typename aggregator<bvector>::size_type)pipe.limit_);   // :255
         dp.complete();
         agg_.combine_and_sub(dp);
         if (opt::is_compute_counts())

@@ -335,8 +335,13 @@ public:
         }
         /// set_or_target (:245): group results are OR-ed into *bv_or (re-seated to the updated device vector)
         void set_or_target(BV* bv_or) noexcept { or_target_ = bv_or; }
-        /// set_search_count_limit (:255): approximate by contract ("can find more"); accepted and ignored
-        void set_search_count_limit(size_type limit) noexcept { search_count_limit_ = limit; }
+        /// set_search_count_limit (:255, honoured at :1365): a group needs no more than `limit` hits ("can find more, cannot find
+        /// less"): the counts run stops launching block-column windows once every group has enough
+        void set_search_count_limit(size_type limit)
+        {
+            search_count_limit_ = limit;
+            if (h_) check(bmx_pipeline_set_search_count_limit(ctx_->handle(), h_, (uint64_t)limit));
+        }
         /// result vectors (nullptr where a group found nothing, :1406-1415); owned by the pipeline
         std::vector<BV*>& get_bv_res_vector() noexcept { return results_; }
         pipeline(const pipeline&) = delete;
@@ -353,6 +358,7 @@ public:
                 for (size_t i = 0; i < groups_[g]->arg_bv1.size(); ++i) sl.push_back(groups_[g]->arg_bv1[i]->handle());
             }
             check(bmx_pipeline_create(ctx_->handle(), al.data(), an.data(), sl.data(), sn.data(), groups_.size(), &h_));
+            if (search_count_limit_ != ~size_type(0)) check(bmx_pipeline_set_search_count_limit(ctx_->handle(), h_, (uint64_t)search_count_limit_));
             counts_.assign(groups_.size(), 0);
         }
         const std::vector<size_type>& get_bv_count_vector() const noexcept { return counts_; }

@@ -437,6 +437,37 @@ def test_rank_line_memory_policy(ctx, port):
         ctx.set_tuning("rs_lines", 1)
 
 
+def test_pipeline_search_count_limit(ctx, port):
+    """pipeline::set_search_count_limit (src/bmaggregator.h:255, honoured at :1365: "can find more, cannot find less"): with
+    limit L every group returns >= min(L, its true count) and <= its true count, and once every group has enough the remaining
+    launch windows of block columns are not launched"""
+    nbits = 3000 * 65536
+    gv = [bm.bvector.generate(ctx, SEED, 40 + i, 6554, nbits, with_common=True) for i in range(6)]
+    agg = bm.aggregator(ctx)
+    def mk(limit=None):
+        pipe = bm.aggregator.pipeline(ctx)
+        for a, s in (([0, 1], [2]), ([0, 1, 2, 3], []), ([4], [5, 0])):
+            ag = pipe.add()
+            for i in a: ag.add(gv[i], 0)
+            for i in s: ag.add(gv[i], 1)
+        if limit is not None: pipe.set_search_count_limit(limit)
+        pipe.complete()
+        return pipe
+    full = [int(x) for x in agg.combine_and_sub(mk())]
+    assert min(full) > 20000
+    for limit in (1, 100, min(full) // 2, max(full) * 2):
+        p = mk(limit)
+        got = [int(x) for x in agg.combine_and_sub(p)]
+        launched, planned = p.last_windows()
+        assert all(min(limit, t) <= g <= t for g, t in zip(got, full)), (limit, got, full)
+        if limit <= 100: assert launched == 1 and planned > 1, (limit, launched, planned)      # the first window already has enough for every group
+        if limit == min(full) // 2: assert 1 < launched <= planned
+        if limit > max(full): assert launched == planned and got == full
+    p = mk(); p.set_search_count_limit(3)                                          # after complete()
+    got = [int(x) for x in agg.combine_and_sub(p)]
+    assert p.last_windows()[0] == 1 and all(3 <= g <= t for g, t in zip(got, full))
+
+
 def test_full_size_256way_and_count(ctx, port):
     """BASELINE config 3: aggregator AND + COUNT over 256 x 1e9-bit vectors (correlated data set A).
     Checks: shard sums == total; sampled block columns equal the oracle run on the same
