@@ -1302,6 +1302,7 @@ int bmx_pipeline_create(bmx_ctx* ctx, const bmx_vec* const* and_list, const uint
     bmx_pipeline* p = new (std::nothrow) bmx_pipeline();
     if (!p) return BMX_ERR_BADALLOC;
     memset(p, 0, sizeof(*p));
+    p->search_limit = ~0ull; p->cm_gen = ~0ull;               // (the memset above wiped the member initialisers)
     p->ctx = ctx; p->ngroups = (uint32_t)ngroups; p->ncols = ncols; p->col_stride = col_stride; p->n_ops = (uint32_t)n_ops; p->has_gap = has_gap; p->has_bit = has_bit; p->gap_avg_words = gap_blocks_sum ? (uint32_t)(gap_words_sum / gap_blocks_sum) : 0u;
     p->nbits = max_bits;
     p->h_row_off = new std::vector<u32>(row_off, row_off + ngroups);

@@ -453,8 +453,9 @@ def test_pipeline_search_count_limit(ctx, port):
         if limit is not None: pipe.set_search_count_limit(limit)
         pipe.complete()
         return pipe
-    full = [int(x) for x in agg.combine_and_sub(mk())]
-    assert min(full) > 20000
+    p0 = mk()
+    full = [int(x) for x in agg.combine_and_sub(p0)]
+    assert min(full) > 1000000 and p0.last_windows() == (1, 1)
     for limit in (1, 100, min(full) // 2, max(full) * 2):
         p = mk(limit)
         got = [int(x) for x in agg.combine_and_sub(p)]
