@@ -758,6 +758,7 @@ def run_pairwise(args, env, dq=None, quick=False):
         pair_bytes.append(a.operand_bytes() + b.operand_bytes())            # 8,192 B per bit-block + 2 x (len + 1) per GAP block
     dcnt = torch.zeros(4 * npairs, dtype=torch.int64, device="cuda")
     per_op = {}
+    mat0 = []
     for op, name in enumerate(["and", "or", "xor", "sub"]):
         def sweep(op=op):
             for i in range(npairs):
@@ -771,6 +772,7 @@ def run_pairwise(args, env, dq=None, quick=False):
                 keep.append(bm.bvector._op2(op, va[i], vb[i], bm.opt_none))
                 if len(keep) > 2: keep.pop(0)
         mat(); ctx.synchronize()
+        mat0.append(int(bm.bvector._op2(op, va[0], vb[0], bm.opt_none).count()))     # the materialised result of pair 0, counted (checked against the reference below)
         t0 = time.perf_counter(); mat(); ctx.synchronize(); host_ms = (time.perf_counter() - t0) * 1e3 / npairs
         out_blocks = keep[-1].info()["counts"][2]
         per_op[name]["materialised_host_call_ms"] = round(host_ms, 4)
@@ -839,7 +841,7 @@ def run_pairwise(args, env, dq=None, quick=False):
            "config": {"workload": f"bm::count_and/or/xor/sub + bit_and/or/xor/sub on 2 x {nbits}-bit vectors, Bernoulli {pct:.3g}% (density q16 {dq}), "
                                   f"rotating over {npairs} distinct pairs ({sum(pair_bytes) / 1e9:.2f} GB: not Infinity-Cache resident)",
                       "baseline_config": "configs[1]", "block_types_vec0": va[0].calc_stat(), "per_op": per_op, "read_write_probe": rw_probe, "own_read_write_probe": own_probe,
-                      "count_and": counts[:4], "pair0_counts_and_or_xor_sub": pair0},
+                      "count_and": counts[:4], "pair0_counts_and_or_xor_sub": pair0, "pair0_materialised_counts": mat0},
            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": c1_traffic, "traffic_source": c1_tsrc,
                         "kernel": L_pair_kernel_name(all_bit, va[0].info()["nblocks"]),
@@ -866,7 +868,8 @@ def run_pairwise(args, env, dq=None, quick=False):
                 cpu.update({"full_counts_and_or_xor_sub": full["full_counts"], "allcores_gbit_s": full["allcores_gbit_s"],
                             "cores_used": full["cores_used"],
                             "allcores_sample": "count_and/or/xor/sub of the WHOLE pair 0, block ranges fanned over the host cores",
-                            "matches_gpu_full": bool(full["full_counts"] == pair0)})
+                            "matches_gpu_full": bool(full["full_counts"] == pair0),
+                            "matches_gpu_full_materialised": bool(full["full_counts"] == mat0)})
             res["cpu_baseline"] = cpu
         except Exception as e:
             res["cpu_baseline"] = {"value": None, "unit": "Gbit/s", "cores": 1, "kind": "port", "sample": f"failed: {e}"}
@@ -896,14 +899,14 @@ def L_pair_kernel_name(all_bit, nblocks):
 # ----------------------------------------------------------------------------------------------------
 # configs[3]: rank / select, 10 M random queries on one 4e9-bit vector
 # ----------------------------------------------------------------------------------------------------
-def run_rank_select(args, env, quick=False):
+def run_rank_select(args, env, quick=False, dq=None):
     import ctypes as C
     import numpy as np
     import bitmagic_amd as bm
     from bitmagic_amd import _ffi
     torch, ctx = env.torch, env.ctx
     L = _ffi.lib()
-    nbits, nq, dq = NBITS_4G, args.queries, args.density_q16
+    nbits, nq, dq = NBITS_4G, args.queries, (args.density_q16 if dq is None else dq)
     v = bm.bvector.generate(ctx, SEED, 7, dq, nbits)
     rs = v.build_rs_index()
     build_ms = event_avg_ms(lambda: v.build_rs_index(), 3, ctx)
@@ -1157,6 +1160,50 @@ def run_or_sharded(args, env, quick=False):
     return res
 
 
+def run_plumbing(args, env):
+    """BASELINE configs[0]: two 1 M-bit bm::bvector<> at 10 %: bit_and + count on the CPU reference with AVX2 OFF (the scalar
+    build of the unmodified BitMagic, oracle/_ref/libbmref_scalar.so) -- the reference's own tests/perf shape
+    (AndCountTest, tests/perf/perf.cpp:2281) -- next to the same two calls through the GPU engine (16 blocks: launch-bound,
+    reported for completeness; the numbers that matter at this size are equal results)."""
+    import bitmagic_amd as bm
+    import oracle
+    ctx = env.ctx
+    nbits, dq = 1_000_000, 6554
+    P = oracle.port()
+    have_scalar = oracle.have_reference("scalar")
+    orc = oracle.reference("scalar") if have_scalar else P
+    wa, wb = P.gen_words(SEED, 1, dq, nbits), P.gen_words(SEED, 2, dq, nbits)
+    ha, hb = orc.import_words(wa, True, nbits), orc.import_words(wb, True, nbits)
+    reps = 2000
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        r = orc.op2(0, ha, hb, 0); c_cpu = r.count()
+    d_and = (time.perf_counter() - t0) / reps
+    t0 = time.perf_counter()
+    for _ in range(reps): c2 = orc.count_op2(0, ha, hb)
+    d_cnt = (time.perf_counter() - t0) / reps
+    ga, gb = bm.bit_import_u32(ctx, wa, True), bm.bit_import_u32(ctx, wb, True)
+    def step():
+        t = bm.bvector.bit_and(ga, gb); step.c = t.count()
+    steps, warmup = max(args.steps, 20), max(args.warmup, 3)
+    dt, ev_ms = timed_region(step, steps, warmup, env)
+    ob = ga.operand_bytes() + gb.operand_bytes()
+    ms = dt / steps * 1e3
+    res = {"metric": "Gbit/s of operand bits, bit_and + count on two 1M-bit vectors (plumbing case)", "value": round(2 * nbits * steps / dt / 1e9, 3),
+           "unit": "Gbit/s", "n_gpus": 1, "steps": steps, "warmup": warmup, "ms_per_step": round(ms, 4), "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+           "config": {"workload": "two 1,000,000-bit vectors at 10 % (16 blocks each): bvector::bit_and (3-operand) + count()", "baseline_config": "configs[0]",
+                      "block_types_vec0": ga.calc_stat(), "gpu_count": int(step.c), "cpu_count": int(c_cpu), "counts_equal": bool(step.c == c_cpu == c2)},
+           "roofline": {"bound": "hbm", "achieved": round(ob / (ev_ms / steps) / 1e6, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(ob / (ev_ms / steps) / 1e6 / HBM_PEAK_GBS, 6), "traffic": None, "kernel": "k_op2 + k_vec_count (16 waves each)",
+                        "algorithmic_bytes_per_launch": int(ob), "avg_launch_ms": round(ev_ms / steps, 4),
+                        "note": "two host calls over 16 blocks: launch latency, not bandwidth; configs[0] is the CPU-runnable plumbing case"},
+           "cpu_baseline": {"value": round(2 * nbits / d_and / 1e9, 2), "unit": "Gbit/s", "cores": 1, "kind": "reference" if have_scalar else "port",
+                            "impl": orc.name, "sample": f"bit_and (3-operand, new result vector) + count(), {reps} repetitions; AVX2 off (scalar build)",
+                            "count_and_only_Gbit_s": round(2 * nbits / d_cnt / 1e9, 2), "us_per_bit_and_plus_count": round(d_and * 1e6, 2)}}
+    return res
+
+
 def run_or_group(args):
     """configs[4] through the product's device group: plain `bench.py --config 4 --gpus N`"""
     import torch
@@ -1218,7 +1265,7 @@ def summary_of(res):
            "roofline": {k: res["roofline"].get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "kernel", "avg_launch_ms", "traffic")}}
     cpu = res.get("cpu_baseline")
     if cpu:
-        out["cpu_baseline"] = {k: cpu.get(k) for k in ("value", "unit", "cores", "kind", "matches_gpu_full", "matches_gpu_sample") if k in cpu}
+        out["cpu_baseline"] = {k: cpu.get(k) for k in ("value", "unit", "cores", "kind", "matches_gpu_full", "matches_gpu_full_materialised", "matches_gpu_sample") if k in cpu}
     for k in ("per_op", "rank_ms", "select_ms", "rank_Mq_s", "select_Mq_s", "rank_select_roundtrip_ok", "result_count", "cold_ms", "build_ms", "warm_ms",
               "break_even_calls", "subset_of_the_collection"):
         if k in res["config"]:
@@ -1237,7 +1284,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", type=int, default=2, choices=[1, 2, 3, 4], help="BASELINE.json configs[] index (2 = the headline)")
+    ap.add_argument("--config", type=int, default=2, choices=[0, 1, 2, 3, 4], help="BASELINE.json configs[] index (2 = the headline)")
     ap.add_argument("--scaling", default="auto", choices=["auto", "strong", "weak"])
     ap.add_argument("--launcher", default="auto", choices=["auto", "group", "torchrun"],
                     help="--gpus N > 1 without RANK in the environment: 'group' (default) = one process over the product's "
@@ -1273,7 +1320,7 @@ def main():
     if launched and int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
         sys.stderr.write(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={os.environ.get('WORLD_SIZE')}\n")
         sys.exit(2)
-    if launched and args.gpus > 1 and args.config in (1, 3):
+    if launched and args.gpus > 1 and args.config in (0, 1, 3):
         sys.stderr.write(f"bench.py: --config {args.config} is a one-GPU configuration\n")
         sys.exit(2)
     single = int(os.environ.get("WORLD_SIZE", "1")) == 1
@@ -1281,7 +1328,9 @@ def main():
     if args.config == 2 and single and not args.no_cpu:
         cpu = headline_cpu(args)                         # before torch / HIP are loaded into this process
     env = Env(args).setup()
-    if args.config == 1:
+    if args.config == 0:
+        res = run_plumbing(args, env)
+    elif args.config == 1:
         res = run_pairwise(args, env)
     elif args.config == 3:
         res = run_rank_select(args, env)
@@ -1292,8 +1341,12 @@ def main():
         standard = (args.nvec == 256 and args.nbits == NBITS_1G and args.density_q16 == 6554 and not args.independent)
         if res is not None and single and standard and not args.no_others:
             others = {}
-            for name, fn in (("configs[1]", lambda: run_pairwise(args, env, quick=True)),
+            for name, fn in (("configs[0]", lambda: run_plumbing(args, env)),
+                             ("configs[1]", lambda: run_pairwise(args, env, quick=True)),
+                             ("configs[1] at 1 %", lambda: run_pairwise(args, env, dq=655, quick=True)),
+                             ("configs[1] at 50 %", lambda: run_pairwise(args, env, dq=32768, quick=True)),
                              ("configs[3]", lambda: run_rank_select(args, env, quick=True)),
+                             ("configs[3] at 1 %", lambda: run_rank_select(args, env, quick=True, dq=655)),
                              ("configs[4]", lambda: run_or_sharded(args, env, quick=True))):
                 try:
                     t0 = time.perf_counter()

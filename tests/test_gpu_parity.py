@@ -1031,6 +1031,28 @@ def test_full_size_or_of_4096_sparse_vectors(ctx, port):
             acc |= port.gen_words(SEED, 10000 + i, dq, nbits, word_off=nb0 * 2048, nwords=nw)
         got = t.to_words((nb0 + 1) * 2048)[nb0 * 2048: nb0 * 2048 + nw]
         assert (got == acc).all()
+    # the three ways the library has of doing this aggregation at FULL size give the same vector bit for bit and block kind
+    # for block kind: the row kernel (tile directories, the default first call), the column-tile kernel (or_rows 0) and the
+    # streaming kernel over the prepared packed collection
+    kinds = t.block_table()[0]
+    ctx.set_tuning("or_rows", 0)
+    try:
+        t_tiled = agg.combine_or(vecs)
+    finally:
+        ctx.set_tuning("or_rows", -1)
+    assert t_tiled.count() == tc and bm.count_xor(t, t_tiled) == 0 and (t_tiled.block_table()[0] == kinds).all()
+    assert ctx.pack_stats()["collections"] == 0
+    ctx.collection_prepare(vecs, bm.ROLE_OR)
+    assert ctx.pack_stats()["collections"] == 1
+    t_packed = agg.combine_or(vecs)
+    assert t_packed.count() == tc and bm.count_xor(t, t_packed) == 0 and (t_packed.block_table()[0] == kinds).all()
+    t_shuffled = agg.combine_or(vecs[::-1])                          # any order: still the whole collection
+    assert bm.count_xor(t, t_shuffled) == 0
+    for nb0 in (5, 61035):
+        nw = min(2048, (nbits + 31) // 32 - nb0 * 2048)
+        a0 = t.to_words((nb0 + 1) * 2048)[nb0 * 2048: nb0 * 2048 + nw]
+        assert (t_packed.to_words((nb0 + 1) * 2048)[nb0 * 2048: nb0 * 2048 + nw] == a0).all()
+    del t_tiled, t_packed, t_shuffled
 
 
 def test_slice_scanner_vs_numpy(ctx):
