@@ -730,8 +730,9 @@ def run_headline_group(args):
     }
     if one_dev:
         res["test_hook"] = f"{ONE_DEV_HOOK}=1: all members on device 0; timings mean nothing"
-    if rccl_error is not None:
-        res["rccl_error"] = rccl_error
+    res["rccl_ranks"] = rccl_ranks                              # (also under per_rank) printed whatever the exchange turned out to be
+    res["rccl_error"] = rccl_error
+    res["rccl_requested"] = bool(want_rccl)
     if weak:
         res["weak_scaling"] = weak
     grp.close()
@@ -1216,12 +1217,16 @@ def run_or_group(args):
         sys.exit(2)
     devices = [0] * n if one_dev else list(range(n))
     grp = bm.group(devices, bm.GROUP_HOST_SUM)
-    nbits, nvec, dq = NBITS_4G, args.or_vecs, 13
+    nbits, nvec, dq = (args.nbits if args.nbits != NBITS_1G else NBITS_4G), args.or_vecs, 13
     t0 = time.perf_counter()
     vecs = [bm.gbvector.generate(grp, SEED, 10000 + i, dq, nbits) for i in range(nvec)]
     for d in sorted(set(devices)): torch.cuda.synchronize(d)
     t_build = time.perf_counter() - t0
     gap_bytes = sum(v.info()["gap_words"] for v in vecs) * 2
+    member_bytes = [0] * n                                        # what every member holds of the operands: the balance of the cut
+    for v in vecs[:: max(1, nvec // 64)]:
+        for m in range(n):
+            member_bytes[m] += v.shard_info(m)["gap_words"] * 2
     import ctypes as C
     from bitmagic_amd import _ffi
     L = _ffi.lib()
@@ -1242,10 +1247,13 @@ def run_or_group(args):
     res = {"metric": "Gbit/s of logical operand bits, aggregator combine_or over 4096 x 4e9-bit sparse vectors",
            "value": round(nvec * nbits * args.steps / dt / 1e9, 1), "unit": "Gbit/s", "n_gpus": n, "steps": args.steps,
            "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "strong",
-           "vs_baseline": None, "dtype": "u16", "data": "synthetic", "mode": "group", "exchange": "host_sum",
+           "vs_baseline": None, "dtype": "u16", "data": "synthetic", "mode": "group", "exchange": "host_sum", "rccl_ranks": 0, "rccl_error": None,
+           "rccl_requested": False,
            "config": {"workload": f"aggregator::combine_or over {nvec} x {nbits}-bit vectors at 0.02 % (all GAP blocks), result materialised (sharded) + counted",
                       "baseline_config": "configs[4]", "devices": devices, "gap_operand_bytes_total": gap_bytes,
-                      "result_count": int(keep[1]), "build_seconds": round(t_build, 1)},
+                      "result_count": int(keep[1]), "build_seconds": round(t_build, 1),
+                      "member_block_ranges": [grp.shard_range((nbits + 65535) // 65536, m) for m in range(n)],
+                      "member_gap_bytes": member_bytes},
            "roofline": {"bound": "hbm", "achieved": round(gap_bytes / ms / 1e6, 1), "peak": HBM_PEAK_GBS * n, "unit": "GB/s",
                         "frac": round(gap_bytes / ms / 1e6 / (HBM_PEAK_GBS * n), 4), "traffic": None,
                         "kernel": "bmx_gagg_or: bmx_agg_or per member on persistent workers",
@@ -1312,7 +1320,14 @@ def main():
         if args.launcher == "torchrun":
             return reexec_torchrun(args)
         if args.config == 2:
-            print(json.dumps(run_headline_group(args))); return
+            res = run_headline_group(args)
+            print(json.dumps(res))
+            # the in-library all-reduce was asked for and did not come up over all N ranks: say so with the exit status too
+            # (the line above still carries the host-sum measurement, its `exchange`, `rccl_ranks` and `rccl_error`)
+            if res.get("rccl_requested") and res.get("rccl_ranks") != args.gpus:
+                sys.stderr.write(f"bench.py: --group-exchange rccl: {res.get('rccl_ranks')} RCCL ranks for --gpus {args.gpus} ({res.get('rccl_error')})\n")
+                sys.exit(3)
+            return
         if args.config == 4:
             print(json.dumps(run_or_group(args))); return
         sys.stderr.write(f"bench.py: --config {args.config} is a one-GPU configuration; --gpus {args.gpus} is not supported for it\n")

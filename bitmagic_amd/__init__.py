@@ -961,6 +961,15 @@ class gbvector:
         return {"nbits": nbits.value, "nblocks": nblocks.value, "counts": list(counts),
                 "bit_slab_blocks": slab.value, "gap_words": gw.value}
 
+    def shard_info(self, member: int):
+        """bmx_vec_info of member m's shard (what that member holds of this vector)"""
+        sh = C.c_void_p()
+        check(lib().bmx_gvec_shard(self._h, member, C.byref(sh)))
+        nbits, nblocks, slab, gw = C.c_uint64(), C.c_uint32(), C.c_uint32(), C.c_uint64()
+        counts = (C.c_uint32 * 4)()
+        check(lib().bmx_vec_info(sh, C.byref(nbits), C.byref(nblocks), counts, C.byref(slab), C.byref(gw)))
+        return {"nbits": nbits.value, "nblocks": nblocks.value, "counts": list(counts), "bit_slab_blocks": slab.value, "gap_words": gw.value}
+
     def block_table(self):
         i = self.info()
         kinds = np.zeros(i["nblocks"], np.uint8); offs = np.zeros(i["nblocks"], np.uint32)
@@ -1051,8 +1060,6 @@ class gpipeline:
         check(lib().bmx_gpipeline_create(self.grp._h, _handles(and_list), and_n, _handles(sub_list), sub_n,
                                          len(self.groups), C.byref(h)))
         self._h = h
-        if self.search_count_limit not in (ID_MAX, ID_MAX64):
-            check(lib().bmx_pipeline_set_search_count_limit(self.ctx._h, self._h, int(self.search_count_limit)))
 
     def is_complete(self) -> bool:
         return self._h is not None

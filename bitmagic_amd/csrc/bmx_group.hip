@@ -18,6 +18,7 @@
 #include <functional>
 #include <memory>
 #include <mutex>
+#include <chrono>
 #include <new>
 #include <thread>
 
@@ -33,6 +34,7 @@ typedef std::shared_ptr<const bmx_partition> part_ref;
 // persistent per-member host workers (members 1..n-1; member 0 runs on the calling thread): the synchronous
 // single-device entry points are dispatched to them instead of spawning n threads per call
 struct bmx_workers {
+    std::mutex call_mu;                         // serialises for_each_member callers
     std::mutex mu;
     std::condition_variable cv_go, cv_done;
     std::vector<std::thread> th;
@@ -123,7 +125,10 @@ static void worker_main(bmx_group* g, int m)
             if (w->stop) return;
             seen = w->gen; fn = w->fn;
         }
-        int rc = (*fn)(m);
+        int rc;
+        try { rc = (*fn)(m); }                                    // (a member lambda allocates: nothing may unwind out of a worker)
+        catch (const std::bad_alloc&) { rc = BMX_ERR_BADALLOC; bmx_set_last_error("out of host memory in a group member"); }
+        catch (...) { rc = BMX_ERR_DEVICE; bmx_set_last_error("unexpected exception in a group member"); }
         std::string msg = rc ? bmx_last_error() : "";
         {
             std::lock_guard<std::mutex> lk(w->mu);
@@ -157,17 +162,25 @@ static void workers_stop(bmx_group* g)
 // text over to the caller's thread
 static int for_each_member(bmx_group* g, const std::function<int(int)>& fn)
 {
+    auto guarded = [&](int m) -> int {
+        try { return fn(m); }
+        catch (const std::bad_alloc&) { bmx_set_last_error("out of host memory in a group member"); return BMX_ERR_BADALLOC; }
+        catch (...) { bmx_set_last_error("unexpected exception in a group member"); return BMX_ERR_DEVICE; }
+    };
     if (g->n == 1 || !g->wk) {
-        for (int m = 0; m < g->n; ++m) { int rc = fn(m); if (rc) return rc; }
+        for (int m = 0; m < g->n; ++m) { int rc = guarded(m); if (rc) return rc; }
         return BMX_OK;
     }
     bmx_workers* w = g->wk;
+    // one driver at a time: the workers have ONE job slot (a second host thread calling into the same group waits here;
+    // include/bmx.h asks for one driving thread per group anyway)
+    std::lock_guard<std::mutex> call(w->call_mu);
     {
         std::lock_guard<std::mutex> lk(w->mu);
         w->fn = &fn; w->pending = g->n - 1; ++w->gen;
     }
     w->cv_go.notify_all();
-    int rc0 = fn(0);
+    int rc0 = guarded(0);                                        // (never unwinds: the workers still hold &fn until pending drains below)
     std::string msg0 = rc0 ? bmx_last_error() : "";
     {
         std::unique_lock<std::mutex> lk(w->mu);
@@ -203,7 +216,29 @@ static int load_rccl(bmx_group* g, const int* devices)
         bmx_set_last_error("BMX_GROUP_RCCL: librccl.so lacks the expected entry points"); return BMX_ERR_DEVICE;
     }
     g->comm.assign((size_t)g->n, nullptr);
-    int r = p_init_all(g->comm.data(), g->n, devices);
+    // ncclCommInitAll can hang on a node whose fabric is not up (it has never run with > 1 rank in this repo's CI): run it on a
+    // helper thread and give up with a clear message after BMX_RCCL_INIT_TIMEOUT_S seconds (default 120) instead of blocking
+    // the caller for ever; the helper is left behind in that case (the communicators are not used)
+    int timeout_s = 120;
+    if (const char* e = getenv("BMX_RCCL_INIT_TIMEOUT_S")) { int t = atoi(e); if (t > 0) timeout_s = t; }
+    struct InitState { std::mutex mu; std::condition_variable cv; bool done = false; int r = 0; std::vector<void*> comm; std::vector<int> devs; };
+    auto st = std::make_shared<InitState>();
+    st->comm.assign((size_t)g->n, nullptr); st->devs.assign(devices, devices + g->n);
+    const int nn = g->n;
+    std::thread([st, p_init_all, nn] {
+        int r = p_init_all(st->comm.data(), nn, st->devs.data());
+        std::lock_guard<std::mutex> lk(st->mu); st->r = r; st->done = true; st->cv.notify_all();
+    }).detach();
+    int r;
+    {
+        std::unique_lock<std::mutex> lk(st->mu);
+        if (!st->cv.wait_for(lk, std::chrono::seconds(timeout_s), [&] { return st->done; })) {
+            char buf[200];
+            snprintf(buf, sizeof(buf), "ncclCommInitAll over %d devices did not return within %d s (BMX_RCCL_INIT_TIMEOUT_S): use BMX_GROUP_HOST_SUM", nn, timeout_s);
+            bmx_set_last_error(buf); g->comm.clear(); return BMX_ERR_DEVICE;
+        }
+        r = st->r; g->comm = st->comm;
+    }
     if (r != 0) {
         std::string m = "ncclCommInitAll failed: "; m += g->p_errstr ? g->p_errstr(r) : "?";
         bmx_set_last_error(m.c_str()); g->comm.clear(); return BMX_ERR_DEVICE;

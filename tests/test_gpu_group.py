@@ -343,3 +343,42 @@ def test_bench_plain_gpus2_uses_two_members():
         out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--nvec", "4", "--nbits", str(nbits),
                               "--steps", "1", "--warmup", "0", "--no-cpu"], env=env, capture_output=True, text=True, timeout=600)
         assert out.returncode != 0 and not any(l.startswith("{") for l in out.stdout.splitlines())
+
+
+def test_bench_gpus8_through_the_one_device_hook():
+    """the 8-GPU invocations the driver will make, on ONE device (test hook: 8 members of a bmx_group on device 0): the headline
+    `bench.py --gpus 8` and `bench.py --config 4 --gpus 8` must run, say n_gpus 8, print exchange / rccl_ranks / rccl_error
+    whatever happened, balance the members and return the single-context results"""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ); env["BMX_BENCH_TEST_ONE_DEVICE"] = "1"
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"): env.pop(k, None)
+    nbits = 203 * 65536 + 99
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--nvec", "16", "--nbits", str(nbits),
+                          "--steps", "3", "--warmup", "1", "--no-cpu", "--no-weak"], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    j = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert j["n_gpus"] == 8 and j["mode"] == "group" and len(j["per_rank"]["kernel_ms"]) == 8
+    for k in ("exchange", "rccl_ranks", "rccl_error", "rccl_requested"): assert k in j
+    assert j["exchange"] == "host_sum" and j["rccl_ranks"] == 0                 # (one device: RCCL cannot come up; the hook says so)
+    rng_ = j["config"]["member_block_ranges"]
+    assert rng_[0][0] == 0 and rng_[-1][1] == 204 and all(a[1] == b[0] for a, b in zip(rng_, rng_[1:]))
+    assert max(b - a for a, b in rng_) - min(b - a for a, b in rng_) <= 1
+    import oracle
+    P = oracle.port()
+    vecs = [P.import_words(P.gen_words(SEED, v, 6554, nbits, with_common=True), True, nbits) for v in range(16)]
+    assert j["config"]["result_count"] == int(P.pipeline_counts([(vecs, [])])[0])
+    # configs[4] shape over 8 members
+    nb4 = 333 * 65536 - 5
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", "4", "--gpus", "8", "--or-vecs", "96", "--nbits", str(nb4),
+                          "--steps", "2", "--warmup", "1", "--no-cpu"], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    j4 = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert j4["n_gpus"] == 8 and j4["mode"] == "group"
+    for k in ("exchange", "rccl_ranks", "rccl_error"): assert k in j4
+    mb = j4["config"]["member_gap_bytes"]
+    assert len(mb) == 8 and min(mb) > 0 and max(mb) <= 1.25 * min(mb), mb                 # the members hold about the same bytes
+    ctx1 = bm.context(0)
+    vv = [bm.bvector.generate(ctx1, SEED, 10000 + i, 13, nb4) for i in range(96)]
+    assert j4["config"]["result_count"] == bm.aggregator(ctx1).combine_or(vv).count()
+    del vv; ctx1.close()
