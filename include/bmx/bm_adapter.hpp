@@ -427,7 +427,7 @@ public:
         }
         bvector ort(*ctx_);
         if (pipe.or_target_) { upload(*pipe.or_target_, ort, common_blocks_); dp.set_or_target(&ort); }
-        if (pipe.limit_ != ~size_type(0)) dp.set_search_count_limit((typename aggregator<bvector>::size_type)pipe.limit_);   // :255
+        if (pipe.limit_ != ~size_type(0)) dp.set_search_count_limit((bvector::size_type)pipe.limit_);   // :255
         dp.complete();
         agg_.combine_and_sub(dp);
         if (opt::is_compute_counts())

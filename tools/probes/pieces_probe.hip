@@ -68,6 +68,13 @@ static kfn pick(int depth, int lpp)
     return nullptr;
 }
 
+__global__ void k_fill_random(u64* p, u64 n, u64 seed)
+{
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
+        u64 z = (i + seed) * 0x9E3779B97F4A7C15ull; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; p[i] = z ^ (z >> 31);
+    }
+}
+
 int main(int argc, char** argv)
 {
     u32 nstreams = 4096; u64 stream_bytes = 3418016;    // configs[4]: 61,036 GAP blocks x ~56 B
@@ -89,7 +96,12 @@ int main(int argc, char** argv)
             void* p; CHK(hipMalloc(&p, stride * nstreams + (1u << 20))); owned.push_back(p);
             for (u32 s = 0; s < nstreams; ++s) bases[s] = (u64)(uintptr_t)p + stride * s;
         }
-        for (void* p : owned) CHK(hipMemsetAsync(p, 0x5a, am == 0 ? stream_bytes : stride * nstreams, st));
+        const bool rnd = argc > 3 && atoi(argv[3]) != 0;          // argv[3] = 1: random data instead of a constant byte (data-dependent power / clocks)
+        for (void* p : owned) {
+            const u64 bytes = am == 0 ? stream_bytes : stride * nstreams;
+            if (rnd) hipLaunchKernelGGL(k_fill_random, dim3(1024), dim3(256), 0, st, (u64*)p, bytes / 8, (u64)(uintptr_t)p);
+            else CHK(hipMemsetAsync(p, 0x5a, bytes, st));
+        }
         CHK(hipMemcpy(d_bases, bases.data(), (size_t)nstreams * 8, hipMemcpyHostToDevice));
         CHK(hipStreamSynchronize(st));
         struct Cfg { int lpp, depth, wg, lds; };
@@ -100,7 +112,10 @@ int main(int argc, char** argv)
             {4, 2, 1024, 131072}, {4, 4, 256, 0}, {4, 2, 256, 0},
             {8, 2, 256, 0}, {8, 1, 1024, 131072},
         };
+        const bool quick = argc > 4 && atoi(argv[4]) != 0;
+        int ci = 0;
         for (const Cfg& c : cfgs) {
+            if (quick && ci++ >= 2) break;
             kfn k = pick(c.depth, c.lpp);
             if (!k) continue;
             CHK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
