@@ -435,25 +435,23 @@ def gather_floats(x: float, env):
     return [float(o.item()) for o in out]
 
 
-def traffic_note(workload: str):
-    """HBM bytes per launch from the PMC passes of the last profiling run (rocprofv3 --pmc cannot run inside
-    this process): a constant read from profiles/traffic_latest.json, labelled with its source"""
-    tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-    try:
-        tj = json.load(open(tpath))
-        if tj.get("workload") == workload:
-            return tj.get("hbm_bytes_per_launch"), f"{tj.get('source', 'profiles/traffic_latest.json')} (PMC passes of a separate rocprofv3 run, not measured in this run)"
-    except Exception:
-        pass
-    return None, None
-
-
-def traffic_file(name: str):
+def traffic_file(name: str, kernel: str = None, workload: str = None):
+    """HBM bytes per launch from the PMC passes of a separate rocprofv3 run (rocprofv3 --pmc cannot run inside this process):
+    a constant read from profiles/<name>, which is stamped with the kernel and the commit it was measured on
+    (tools/make_traffic_json.py).  The figure is DROPPED -- traffic null, the reason in traffic_source -- when the file
+    carries no stamp, or when the kernel this run reports is not the one the file was measured on."""
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", name)))
-        return tj["hbm_bytes_per_launch"], tj["source"] + " (PMC pass of a separate rocprofv3 run, not measured in this run)", tj
     except Exception:
         return None, None, {}
+    if workload is not None and tj.get("workload") != workload:
+        return None, None, tj
+    if not tj.get("kernel") or not tj.get("commit"):
+        return None, f"dropped: profiles/{name} is not stamped with the kernel / commit it was measured on", tj
+    if kernel is not None and tj["kernel"] not in kernel:
+        return None, f"dropped: profiles/{name} was measured on {tj['kernel']} (commit {tj['commit']}), this run used {kernel[:60]}", tj
+    return (tj["hbm_bytes_per_launch"],
+            f"{tj['source']} [kernel {tj['kernel']}, commit {tj['commit']}] (PMC passes of a separate rocprofv3 run, not measured in this run)", tj)
 
 
 def dataset_label(args):
@@ -570,7 +568,7 @@ def run_headline(args, env, cpu):
     # the PMC figure belongs to the headline data set on one GPU (density 10 %, data set A, 6 launch windows): any other
     # density / data set / shard runs another kernel or another launch plan and carries no traffic figure
     headline = args.density_q16 == 6554 and not args.independent and world == 1
-    traffic, tsrc = traffic_note(f"agg_and_count_{args.nvec}x{args.nbits}") if headline else (None, None)
+    traffic, tsrc, _ = traffic_file("traffic_latest.json", kernel=main["plan"], workload=f"agg_and_count_{args.nvec}x{args.nbits}") if headline else (None, None, {})
     if traffic is not None and main["nlaunch"] != 6: traffic, tsrc = None, None
     res = {
         "metric": METRIC, "value": round(value, 2), "unit": "Gbit/s", "n_gpus": world, "steps": args.steps,
@@ -831,9 +829,9 @@ def run_pairwise(args, env, dq=None, quick=False):
     all_bit = all(v.calc_stat()["bit_blocks"] == v.info()["nblocks"] for v in (va[0], vb[0]))
     c1_traffic, c1_tsrc = None, None
     if nbits == NBITS_1G and dq == 6554 and os.environ.get("BMX_PAIR_STREAM", "-1") == "-1":
-        c1_traffic, c1_tsrc, _ = traffic_file("traffic_config1.json")
+        c1_traffic, c1_tsrc, _ = traffic_file("traffic_config1.json", kernel=L_pair_kernel_name(all_bit, va[0].info()["nblocks"]))
     elif nbits == NBITS_1G and dq == 655 and os.environ.get("BMX_PAIR_LOOP", "-1") == "-1":
-        c1_traffic, c1_tsrc, _ = traffic_file("traffic_config1_1pct.json")
+        c1_traffic, c1_tsrc, _ = traffic_file("traffic_config1_1pct.json", kernel=L_pair_kernel_name(all_bit, va[0].info()["nblocks"]))
     pct = dq / 65536 * 100
     res = {"metric": "Gbit/s of operand bits, pairwise count_and on 1e9-bit vectors (HBM-cold rotation)",
            "value": round(2 * nbits * npairs * steps / dt / 1e9, 2), "unit": "Gbit/s", "n_gpus": 1,
@@ -940,7 +938,9 @@ def run_rank_select(args, env, quick=False, dq=None):
     ceil_lines_s = nq / (pm.value * 1e-3)
     rank_lines_s = nq / (rank_ms * 1e-3)
     sel_lines_s = nq / (sel_ms * 1e-3)
-    traffic, tsrc, tj = traffic_file("traffic_config3.json")
+    rank_kernel = ("k_rank_lines<2> (the vector laid out as rank lines by build_rs_index: count before the line + 960 bits per 128-B line)"
+                   if rs.info()["has_lines"] and os.environ.get("BMX_RS_LANES", "0") != "8" else "k_rank_l / k_rank (descriptor + running count + cumulative row + bit line)")
+    traffic, tsrc, tj = traffic_file("traffic_config3.json", kernel=rank_kernel) if (nbits == NBITS_4G and dq == 6554 and nq == 10_000_000) else (None, None, {})
     pct = dq / 65536 * 100
     res = {"metric": "M queries/s, rank + select (bmrs.h RS-index) on one 4e9-bit vector",
            "value": round(2 * nq * steps / dt / 1e6, 1), "unit": "Mqueries/s", "n_gpus": 1, "steps": steps,
@@ -958,8 +958,7 @@ def run_rank_select(args, env, quick=False, dq=None):
            "roofline": {"bound": "hbm", "achieved": round(rank_lines_s / 1e9, 3), "peak": round(ceil_lines_s / 1e9, 3),
                         "unit": "G lines/s (random 128-byte lines)", "frac": round(rank_lines_s / ceil_lines_s, 4),
                         "traffic": traffic, "traffic_source": tsrc,
-                        "kernel": ("k_rank_lines<2> (the vector laid out as rank lines by build_rs_index: count before the line + 960 bits per 128-B line)"
-                                   if os.environ.get("BMX_RS_LINES", "1") != "0" and os.environ.get("BMX_RS_LANES", "0") != "8" else "k_rank_l / k_rank (descriptor + running count + cumulative row + bit line)"),
+                        "kernel": rank_kernel,
                         "algorithmic_bytes_per_launch": nq * 128, "avg_launch_ms": round(rank_ms, 4),
                         "peak_source": f"bmx_probe_random_lines in this run: {nq} random 128-B lines (8 lanes x 16 B, the access shape of "
                                        f"a rank query's bit line) over a {slab_bytes / 1e6:.0f} MB buffer in {pm.value:.4f} ms",
@@ -1093,11 +1092,9 @@ def run_or_sharded(args, env, quick=False):
         rows = os.environ.get("BMX_OR_ROWS", "-1") != "0"
         kname = ("k_agg_or_rows<4>: tiles of 14 block columns, one coalesced row per (operand, tile) through the vectors' tile directories"
                  if rows else "k_agg_or_gap_tiled<1,1> (descriptor-table kernel)")
-        traffic, tsrc, tj = traffic_file("traffic_config4.json") if (world == 1 and nvec == 4096) else (None, None, {})
-        if tj and tj.get("kernel", "") not in kname:                       # the PMC pass was taken on another kernel: not this run's traffic
-            traffic, tsrc = None, f"dropped: profiles/traffic_config4.json was measured on {tj.get('kernel')}"
+        traffic, tsrc, tj = traffic_file("traffic_config4.json", kernel=kname) if (world == 1 and nvec == 4096) else (None, None, {})
         wneed = pack["run_bytes"] + result_bytes
-        wtraffic, wtsrc, wtj = traffic_file("traffic_config4_warm.json") if (world == 1 and nvec == 4096) else (None, None, {})
+        wtraffic, wtsrc, wtj = traffic_file("traffic_config4_warm.json", kernel="k_coll_apply<OR,512>") if (world == 1 and nvec == 4096) else (None, None, {})
         res = {"metric": "Gbit/s of logical operand bits, aggregator combine_or over 4096 x 4e9-bit sparse vectors (first call, operands in the reference's format)",
                "value": round(nvec * nbits * steps / dt / 1e9, 1), "unit": "Gbit/s", "n_gpus": world, "steps": steps,
                "warmup": warmup, "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "strong",

@@ -2964,14 +2964,14 @@ int bmx_rs_build(bmx_ctx* ctx, const bmx_vec* v, bmx_rs** out)
                            rs->d_rcount, v->nblocks, shift, rs->nsamples, rs->d_sample);
         RSCHK(hipGetLastError());
         // rank lines (bmx_kernels6.h): the vector once more, interleaved with its running counts -- one line per rank query.
-        // Memory policy (rs_lines 1): they are built where they cost no more than 1.2 x what the vector itself holds on the
-        // device, i.e. for vectors that are bit-blocks almost throughout; a sparse vector (GAP / NULL / FULL blocks: a 4e9-bit
+        // Memory policy (rs_lines 1): they are built where they cost no more than 2 x what the vector itself holds on the
+        // device, i.e. for vectors with bit-blocks in more than about half of their block columns (configs[3]'s 66%); a sparse vector (GAP / NULL / FULL blocks: a 4e9-bit
         // operand of configs[4] is 3.4 MB, its lines would be 539 MB) keeps the table kernels (k_rank_l / k_select_l over the
         // running counts, src/bmrs.h:39-155 is 0.7 MB for such a vector too).  Line numbers are 32-bit: 69 lines per block
         // pass 2^32 at 62.2 M blocks = 510 GB of bit-blocks under this policy, more than a device holds; refused anyway.
         const size_t lines_bytes = (size_t)v->nblocks * RL_LINES * 128u;
         const bool lines_fit = (uint64_t)v->nblocks * RL_LINES < 0xFFFFFFFFull;
-        const bool want_lines = lines_fit && (ctx->rs_lines == 2 || (ctx->rs_lines == 1 && (double)lines_bytes <= 1.2 * (double)v->bytes));
+        const bool want_lines = lines_fit && (ctx->rs_lines == 2 || (ctx->rs_lines == 1 && (double)lines_bytes <= 2.0 * (double)v->bytes));
         if (want_lines) {
             size_t bl = lines_bytes;
             if ((rc = dmalloc(ctx, (void**)&rs->d_lines, bl)) || (rc = dmalloc(ctx, (void**)&rs->d_dir8, (size_t)v->nblocks * 16u))) { bmx_rs_free(ctx, rs); return rc; }
