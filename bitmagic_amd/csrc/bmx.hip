@@ -2023,7 +2023,7 @@ static bool coll_members_wanted_list(const bmx_ctx* ctx, const bmx_vec* const* s
 static int or_rows_diag_bits()
 {
 #ifdef BMX_DIAG
-    if (const char* e = getenv("BMX_DIAG_ROWS")) return atoi(e) & 512;
+    if (const char* e = getenv("BMX_DIAG_ROWS")) return atoi(e) & (512 | 1024 | 2048);
 #endif
     return 0;
 }

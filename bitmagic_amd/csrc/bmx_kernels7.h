@@ -301,6 +301,9 @@ void k_agg_or_rows(const u32x4* __restrict__ optab_, u32 n, u32 ncols, int opt_c
         const u32 tc = wave, cc = c0 + tc;
         if (tc < ORR_TILE && cc < ncols) {
             if (full[tc]) { store_trivial(K_FULL, cc, desc, st, lane); kind = K_FULL; pop = 65536u; }
+#ifdef BMX_DIAG
+            else if (opt_compress & 2048) { store_trivial(K_NULL, cc, desc, st, lane); kind = K_NULL; }   // timing probe: nothing classified or stored
+#endif
             else {
                 Blk bk;
                 blk_from_lds(bk, lds_dyn + tc * 2048u, lane);
@@ -309,6 +312,9 @@ void k_agg_or_rows(const u32x4* __restrict__ optab_, u32 n, u32 ncols, int opt_c
             }
         }
     }
+#ifdef BMX_DIAG
+    if (opt_compress & 1024) return;                                         // timing probe: no folds
+#endif
     kind_fanin_fold(kind, kinds, lane, wave);
     count_fanin_fold(pop, total, lane, wave);
 }

@@ -25,7 +25,7 @@ typedef unsigned long long u64;
 typedef u32 u32x4 __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(1))) u32x4* gptr;
 
-template <int DEPTH, int LPP>   // LPP = 16-byte loads per lane per piece (piece = LPP KiB)
+template <int DEPTH, int LPP, int WORK = 0>   // WORK: 0 loads only, 1 + the row arithmetic of k_agg_or_rows, 2 + its LDS atomics; LPP = 16-byte loads per lane per piece (piece = LPP KiB)
 __global__ void k_pieces(const u64* __restrict__ bases, u32 nstreams, u32 npieces, u32* __restrict__ sink)
 {
     extern __shared__ u32 lds[];
@@ -34,6 +34,7 @@ __global__ void k_pieces(const u64* __restrict__ bases, u32 nstreams, u32 npiece
     if (piece >= npieces) return;
     const u64 off = (u64)piece * (LPP * 1024u) + lane * 16u;
     u32x4 acc = (u32x4)(0u);
+    u64 work_mask = 0x1111111111111111ull;
     u32 s = wave;
     for (; s + (DEPTH - 1) * W < nstreams; s += DEPTH * W) {
         u32x4 v[DEPTH][LPP];
@@ -46,9 +47,24 @@ __global__ void k_pieces(const u64* __restrict__ bases, u32 nstreams, u32 npiece
             for (int l = 0; l < LPP; ++l) v[d][l] = __builtin_nontemporal_load(p + l * 64);
         }
 #pragma unroll
-        for (int d = 0; d < DEPTH; ++d)
+        for (int d = 0; d < DEPTH; ++d) {
 #pragma unroll
             for (int l = 0; l < LPP; ++l) acc ^= v[d][l];
+            if (WORK) {                                  // what k_agg_or_rows does with a row, without its records: pairs -> LDS atomics (2) or VALU only (1)
+                const u32 nx = (u32)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)v[d][0].x, 0x130, 0xf, 0xf, false);
+                const u32 x[5] = {v[d][0].x, v[d][0].y, v[d][0].z, v[d][0].w, nx};
+                const u32 col = (u32)__popcll(work_mask & ((2ull << lane) - 1ull)) % 14u;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const u32 y = __builtin_amdgcn_alignbit(x[i + 1], x[i], 16);
+                    const u32 e = y >> 16;
+                    const u32 bit = (y & 0xFFFFu) != 0xFFFFu ? 1u << (e & 31u) : 0u;
+                    if (WORK == 2) atomicOr(&lds[col * 2048u + (e >> 5)], bit);
+                    else acc.x += bit * (e >> 5);
+                }
+                work_mask = work_mask * 6364136223846793005ull + 1442695040888963407ull + v[d][0].x * 0;   // (uniform: a new start mask per row)
+            }
+        }
     }
     for (; s < nstreams; s += W) {
         gptr p = (gptr)(bases[s] + off);
@@ -60,8 +76,11 @@ __global__ void k_pieces(const u64* __restrict__ bases, u32 nstreams, u32 npiece
 }
 
 typedef void (*kfn)(const u64*, u32, u32, u32*);
-static kfn pick(int depth, int lpp)
+static kfn pick(int depth, int lpp, int work)
 {
+    if (work == 1 && lpp == 1) return depth == 8 ? k_pieces<8, 1, 1> : k_pieces<4, 1, 1>;
+    if (work == 2 && lpp == 1) return depth == 8 ? k_pieces<8, 1, 2> : k_pieces<4, 1, 2>;
+    if (work) return nullptr;
 #define K(D, L) if (depth == D && lpp == L) return k_pieces<D, L>;
     K(1, 1) K(2, 1) K(4, 1) K(8, 1) K(1, 2) K(2, 2) K(4, 2) K(1, 4) K(2, 4) K(4, 4) K(1, 8) K(2, 8)
 #undef K
@@ -113,10 +132,11 @@ int main(int argc, char** argv)
             {8, 2, 256, 0}, {8, 1, 1024, 131072},
         };
         const bool quick = argc > 4 && atoi(argv[4]) != 0;
+        const int work = argc > 5 ? atoi(argv[5]) : 0;                     // argv[5]: 1 = + row arithmetic, 2 = + LDS atomics (lpp 1 configurations only)
         int ci = 0;
         for (const Cfg& c : cfgs) {
             if (quick && ci++ >= 2) break;
-            kfn k = pick(c.depth, c.lpp);
+            kfn k = pick(c.depth, c.lpp, work);
             if (!k) continue;
             CHK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
             u32 npieces = (u32)(stream_bytes / (c.lpp * 1024u));

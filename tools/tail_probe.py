@@ -10,7 +10,7 @@ def main():
     ctx = bm.context(0)
     L = _ffi.lib()
     nvec = 4096
-    for ntiles in (4352, 4360, 4480, 4608):
+    for ntiles in ([int(a) for a in sys.argv[1:]] or (4352, 4360, 4480, 4608)):
         nbits = min(ntiles * 14 * 65536, 4_000_000_000) if ntiles == 4360 else ntiles * 14 * 65536
         vecs = [bm.bvector.generate(ctx, 1234, 10000 + i, 13, nbits) for i in range(nvec)]
         arr = (C.c_void_p * nvec)(*[v._h for v in vecs])
@@ -26,6 +26,6 @@ def main():
         ctx.synchronize(); ms = (time.perf_counter() - t0) * 100
         gb = sum(v.operand_bytes() for v in vecs) / 1e9
         print(json.dumps({"ntiles": (nbits + 65535) // 65536 // 14 + ((nbits + 65535) // 65536 % 14 != 0), "nbits": nbits, "ms": round(ms, 4), "rounds": round(ntiles / 256, 3),
-                          "GB": round(gb, 3), "ms_per_round": round(ms / (ntiles / 256), 4), "count": r.count()}), flush=True)
+                          "GB": round(gb, 3), "ms_per_round": round(ms / (ntiles / 256), 4), "count": r.count(), "diag": os.environ.get("BMX_DIAG_ROWS", "")}), flush=True)
         del vecs, arr, r
 main()
