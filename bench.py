@@ -508,6 +508,14 @@ def run_headline(args, env, cpu):
             lo, hi = 0, nblocks_full
             vecs = [bm.bvector.generate(ctx, SEED, base_id + v if world > 1 else v, args.density_q16, args.nbits,
                                         with_common=not args.independent) for v in range(args.nvec)]
+        # a collection of vectors WITHOUT bit-blocks (densities below ~0.4 %) is an index the application prepares once at load
+        # time (bmx_collection_prepare, the AND role: the vectors' 0-runs in column-major order); collections are never built
+        # behind the caller's back, so the bench does what such a caller does and reports the one-time cost
+        prep_ms = None
+        if all(v.info()["counts"][bm.BIT] == 0 for v in vecs) and os.environ.get("BMX_GAP_PACK", "-1") != "0" and not args.no_prepare:
+            ctx.synchronize(); tp = time.perf_counter()
+            ctx.collection_prepare(vecs, bm.ROLE_AND); ctx.synchronize()
+            prep_ms = (time.perf_counter() - tp) * 1e3
         pipe = bm.aggregator.pipeline(ctx)
         ag = pipe.add()
         for v in vecs:
@@ -532,7 +540,7 @@ def run_headline(args, env, cpu):
             ar_us = event_avg_ms(lambda: dist.all_reduce(counts), 20, ctx) * 1e3
         return {"dt": dt, "ev_ms": ev_ms, "count": total, "op_bytes": op_bytes, "k_ms": k_ms, "ar_us": ar_us,
                 "build_s": t_build, "blocks": hi - lo, "plan": pipe.describe(), "nlaunch": pipe.launches(),
-                "stat0": vecs[0].calc_stat(), "mem": ctx.mem_used(), "pipe": pipe, "vecs": vecs}
+                "stat0": vecs[0].calc_stat(), "mem": ctx.mem_used(), "pipe": pipe, "vecs": vecs, "prep_ms": prep_ms}
 
     main = run_mode(scaling)
     k_all = gather_floats(main["k_ms"], env)
@@ -582,7 +590,8 @@ def run_headline(args, env, cpu):
                    "sharding": (f"block-range shards: rank r holds blocks shard_range({nblocks_full}, r, {world}) of every vector"
                                 if scaling == "strong" else f"document shards x{world}"),
                    "blocks_per_rank": main["blocks"], "result_count": main["count"],
-                   "build_seconds": round(main["build_s"], 2), "hbm_resident_bytes": main["mem"]},
+                   "build_seconds": round(main["build_s"], 2), "hbm_resident_bytes": main["mem"],
+                   "prepared_collection_ms": None if main["prep_ms"] is None else round(main["prep_ms"], 2)},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": tsrc,
                      "kernel": main["plan"], "launches_per_step": main["nlaunch"],
@@ -1068,7 +1077,7 @@ def run_or_sharded(args, env, quick=False):
     warm_count = int(cnt.item())
     # ---- a subset of the collection's vectors (half of them, shuffled): member directory vs the cold path on the same list
     sub = None
-    if world == 1 and nvec >= 128 and have_coll:
+    if world == 1 and nvec >= 128 and have_coll and not args.no_subset:
         rng = np.random.default_rng(5)
         pick = rng.permutation(nvec)[: nvec // 2]
         sarr = (C.c_void_p * len(pick))(*[vecs[int(i)]._h for i in pick])
@@ -1077,12 +1086,18 @@ def run_or_sharded(args, env, quick=False):
             keep[:] = [call(sarr, len(pick))]
         sub_call(); sub_call()
         sub_coll_ms = event_avg_ms(sub_call, 5, ctx); c1 = keep[0].count()
+        ctx.set_tuning("coll_members", 1)                                 # forced: the members' pieces of the column regions
+        sub_call(); sub_call()
+        sub_dir_ms = event_avg_ms(sub_call, 3, ctx); c3 = keep[0].count()
+        ctx.set_tuning("coll_members", -1)
         ctx.set_tuning("gap_pack", 0)
         sub_call(); sub_call()
         sub_cold_ms = event_avg_ms(sub_call, 5, ctx); c2 = keep[0].count()
         ctx.set_tuning("gap_pack", -1)
-        sub = {"vectors": int(len(pick)), "through_member_directory_ms": round(sub_coll_ms, 4), "cold_path_ms": round(sub_cold_ms, 4),
-               "same_count": bool(c1 == c2)}
+        sub = {"vectors": int(len(pick)), "default_dispatch_ms": round(sub_coll_ms, 4), "member_directory_forced_ms": round(sub_dir_ms, 4),
+               "no_collection_ms": round(sub_cold_ms, 4), "same_count": bool(c1 == c2 == c3),
+               "note": "a sparse OR list of >= 64 vectors takes the row kernel over the vectors' own slabs even when a collection covers it "
+                       "(a member's piece of a column is ~26 B there); the member directory serves AND / SUB lists and pipelines of long lists"}
         keep.clear()
     res = None
     if rank == 0:
@@ -1304,6 +1319,8 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-allcores", action="store_true")
     ap.add_argument("--no-weak", action="store_true")
+    ap.add_argument("--no-subset", action="store_true", help="config 4: skip the subset-of-the-collection line (PMC passes: full-size launches only)")
+    ap.add_argument("--no-prepare", action="store_true", help="GAP-only collections: do not prepare the packed collection (descriptor-table kernels)")
     ap.add_argument("--no-shard-probe", action="store_true")
     ap.add_argument("--no-others", action="store_true", help="headline run: skip the one-line summaries of configs 1, 3, 4")
     ap.add_argument("--pairs", type=int, default=6)

@@ -416,8 +416,8 @@ def test_rank_line_memory_policy(ctx, port):
     idn, isp = rd.info(), rsp.info()
     assert idn["has_lines"] and not isp["has_lines"]
     dev_bytes = lambda v: v.info()["gap_words"] * 2 + v.info()["nblocks"] * 8 + v.info()["counts"][bm.BIT] * 8192
-    assert isp["bytes"] <= 2.0 * dev_bytes(sparse) + 600 * 300                # O(nblocks): running counts + two 128-byte rows per block
-    assert idn["bytes"] <= 2.0 * dev_bytes(dense) + 600 * 300 + 16 * 600
+    assert isp["bytes"] <= 1.2 * dev_bytes(sparse) + 600 * 300                # O(nblocks): running counts + two 128-byte rows per block
+    assert idn["bytes"] <= 1.2 * dev_bytes(dense) + 600 * 300 + 16 * 600
     ps = port.import_words(port.gen_words(5, 2, 13, nbits), True, nbits)
     prs = port.rs_build(ps)
     rng = np.random.default_rng(3)
@@ -435,6 +435,50 @@ def test_rank_line_memory_policy(ctx, port):
         assert np.asarray(f2).all() and (np.asarray(pos2) == np.asarray(pos)).all()
     finally:
         ctx.set_tuning("rs_lines", 1)
+
+
+def test_rank_select_past_2_32_rank_lines(port):
+    """a vector of 62.3 M blocks (4.08e12 bits: 69 rank lines per block would pass 2^32 line numbers, which are 32-bit): the
+    index is built WITHOUT lines whatever rs_lines says (bmx_rs_build refuses them), stays O(nblocks), and rank / select over
+    the mostly-NULL vector answer what the positions of its bits say (blocks of every kind far beyond bit 2^32 and 2^41)"""
+    nblk_small = 6
+    rng = np.random.default_rng(62)
+    w = np.zeros(nblk_small * 2048, np.uint32)
+    for b, n in ((0, 900), (1, 40), (3, 5), (5, 300)):                        # GAP blocks
+        for q in rng.integers(0, 65536, size=n): w[b * 2048 + (int(q) >> 5)] |= np.uint32(1 << (int(q) & 31))
+    w[2 * 2048:3 * 2048] = rng.integers(0, 1 << 32, size=2048, dtype=np.uint64).astype(np.uint32)   # a bit-block
+    w[4 * 2048:5 * 2048] = 0xFFFFFFFF                                         # a FULL block
+    small = port.import_words(w, True, nblk_small * 65536)
+    k, o, b, g = small.flatten()
+    assert sorted(set(k.tolist())) == [1, 2, 3]
+    nblk = 62_300_000
+    where = [0, 7, 31_000_000, 40_000_001, 62_200_123, nblk - 1]              # the six blocks, spread over the range
+    kinds = np.zeros(nblk, np.uint8); offs = np.zeros(nblk, np.uint32)
+    for i, nb in enumerate(where): kinds[nb] = k[i]; offs[nb] = o[i]
+    bits = np.unpackbits(w.view(np.uint8), bitorder="little").reshape(nblk_small, 65536)
+    pos = np.concatenate([np.flatnonzero(bits[i]).astype(np.uint64) + np.uint64(nb) * np.uint64(65536) for i, nb in enumerate(where)])
+    assert (np.diff(pos.astype(np.int64)) > 0).all()
+    c = bm.context(0)
+    try:
+        for mode in (1, 2):
+            c.set_tuning("rs_lines", mode)
+            v = bm.bvector.from_block_table(c, nblk * 65536, kinds, offs, b, g)
+            assert v.count() == pos.size
+            rs = v.build_rs_index()
+            inf = rs.info()
+            assert not inf["has_lines"] and rs.count() == pos.size
+            assert inf["bytes"] <= nblk * 300 + (1 << 20)
+            q = np.concatenate([rng.integers(0, nblk * 65536, size=4000, dtype=np.uint64), pos[::7], pos[::11] + np.uint64(1),
+                                np.array([0, nblk * 65536 - 1, (1 << 32) - 1, 1 << 32, 1 << 41], np.uint64)])
+            assert (np.asarray(v.count_to(q, rs)) == np.searchsorted(pos, q, side="right")).all()
+            r = np.concatenate([rng.integers(1, pos.size + 1, size=4000, dtype=np.uint64), np.array([1, pos.size, pos.size + 1], np.uint64)])
+            f, p_ = v.select(r, rs)
+            f = np.asarray(f).astype(bool); p_ = np.asarray(p_)
+            assert (f == (r <= pos.size)).all()
+            assert (p_[f] == pos[(r[f] - 1).astype(np.int64)]).all()
+            del rs, v
+    finally:
+        c.close()
 
 
 def test_pipeline_search_count_limit(ctx, port):
@@ -1597,6 +1641,40 @@ def test_packed_collection_policy_and_prepare(port):
     assert (o1.to_words() == e.to_words(o1.info()["nblocks"] * 2048)).all()
     del gv, o1
     c.close()
+
+
+def test_packed_collection_budget(port, monkeypatch):
+    """the packing budget (a quarter of the free HBM at context creation; BMX_PACK_MAX_MB): a collection that does not fit is
+    refused with BMX_ERR_BADALLOC and nothing else changes; collections that fit one at a time push the least recently used
+    one out; aggregations keep answering the same through whichever path is left"""
+    rng = np.random.default_rng(5)
+    nbits = 48 * 65536
+    words = _sparse_collection(port, rng, 240, nbits, 80, specials=False)
+    pv = [port.import_words(w, True, nbits) for w in words]
+    monkeypatch.setenv("BMX_PACK_MAX_MB", "1")
+    c = bm.context(0)
+    try:
+        c.set_tuning("direct_cols", 0); c.set_tuning("pipe_split", 0)
+        gv = [bm.bit_import_u32(c, w, True) for w in words]
+        agg = bm.aggregator(c)
+        e_all = port.agg_or(pv, False)
+        with pytest.raises(bm.BmxError):                       # 240 vectors x 48 columns x ~120 runs: 5 MB of run lists
+            c.collection_prepare(gv, bm.ROLE_OR)
+        assert c.pack_stats()["collections"] == 0
+        o = agg.combine_or(gv)
+        assert (o.to_words() == e_all.to_words(o.info()["nblocks"] * 2048)).all()
+        parts = [gv[0:30], gv[30:60], gv[60:90], gv[90:120]]
+        for k, part in enumerate(parts):                       # each ~0.35 MB (0.7 MB of GAP words: under the budget): two fit, the next one pushes the least recently used one out
+            c.collection_prepare(part, bm.ROLE_OR)
+            st = c.pack_stats()
+            assert 1 <= st["collections"] <= 2 and st["bytes"] <= (1 << 20), (k, st)
+        for k, part in enumerate(parts):                       # every part still aggregates to the oracle's bits (packed or not)
+            o = agg.combine_or(part)
+            e = port.agg_or(pv[30 * k:30 * k + 30], False)
+            assert (o.to_words() == e.to_words(o.info()["nblocks"] * 2048)).all(), k
+        del gv, o, agg
+    finally:
+        c.close()
 
 
 @pytest.mark.parametrize("dq,nvec,long_runs,nblk", [(13, 300, False, 9), (150, 120, True, 6), (40, 1100, False, 3)])
