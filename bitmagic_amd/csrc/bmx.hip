@@ -620,6 +620,8 @@ int bmx_ctx_create(int device, void* stream, bmx_ctx** out)
     CTXCHK(hipMemsetAsync(ctx->d_slots2, 0, COUNT_SLOTS * COUNT_SLOT_STRIDE * sizeof(u64), ctx->stream));
     CTXCHK(hipMalloc((void**)&ctx->d_done2, FOLD_DONE_WORDS * 4));
     CTXCHK(hipMemsetAsync(ctx->d_done2, 0, FOLD_DONE_WORDS * 4, ctx->stream));
+    CTXCHK(hipMalloc((void**)&ctx->d_cursor, 64));
+    CTXCHK(hipMemsetAsync(ctx->d_cursor, 0, 64, ctx->stream));
 #undef CTXCHK
     { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, device) == hipSuccess && v > 0) ctx->max_lds_bytes = (uint32_t)v; else (void)hipGetLastError(); }
     { size_t fr = 0, tot = 0; if (hipMemGetInfo(&fr, &tot) == hipSuccess && fr) ctx->pack_cap = (uint64_t)fr / 4; else (void)hipGetLastError(); }   // packed copies: at most a quarter of what is free now
@@ -654,6 +656,7 @@ int bmx_ctx_destroy(bmx_ctx* ctx)
     if (ctx->d_done) (void)hipFree(ctx->d_done);
     if (ctx->d_slots2) (void)hipFree(ctx->d_slots2);
     if (ctx->d_done2) (void)hipFree(ctx->d_done2);
+    if (ctx->d_cursor) (void)hipFree(ctx->d_cursor);
     if (ctx->d_zero) (void)hipFree(ctx->d_zero);
     if (ctx->h_small) (void)hipHostFree(ctx->h_small);
     if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
@@ -1090,6 +1093,24 @@ int bmx_vec_generate(bmx_ctx* ctx, uint64_t seed, uint32_t vec_id, int with_comm
     return bmx_vec_generate_shard(ctx, seed, vec_id, with_common, density_q16, nbits, 0u, 0xFFFFFFFFu, optimize, out);
 }
 
+} // extern "C"
+
+// ordinals of the bit-blocks of a result whose slab has unused slots (what the layout scan would have left in d_ord): computed
+// when a download first needs them, so that the operation that produced the vector does not pay a scan for it
+static int vec_build_ord(bmx_ctx* ctx, bmx_vec* v)
+{
+    if (v->d_ord || !v->nblocks) { v->ord_lazy = false; return BMX_OK; }
+    int rc;
+    if ((rc = dmalloc(ctx, (void**)&v->d_ord, (size_t)v->nblocks * 4))) return rc;
+    hipLaunchKernelGGL(k_ord_from_desc, dim3(1), dim3(1024), 0, ctx->stream, (const u64*)v->d_desc, v->nblocks, v->d_ord);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { dfree(ctx, v->d_ord); v->d_ord = nullptr; return fail_hip(e, "k_ord_from_desc", __LINE__); }
+    v->ord_lazy = false;
+    return BMX_OK;
+}
+
+extern "C" {
+
 int bmx_vec_info(const bmx_vec* v, uint64_t* nbits, uint32_t* nblocks, uint32_t counts[4],
                  uint32_t* bit_slab_blocks, uint64_t* gap_words)
 {
@@ -1097,7 +1118,7 @@ int bmx_vec_info(const bmx_vec* v, uint64_t* nbits, uint32_t* nblocks, uint32_t 
     if (nbits) *nbits = v->nbits;
     if (nblocks) *nblocks = v->nblocks;
     if (counts) memcpy(counts, v->counts, sizeof(v->counts));
-    if (bit_slab_blocks) *bit_slab_blocks = v->d_ord ? v->counts[BMX_BIT] : v->n_bit;   // a slab with unused slots is gathered on download
+    if (bit_slab_blocks) *bit_slab_blocks = (v->d_ord || v->ord_lazy) ? v->counts[BMX_BIT] : v->n_bit;   // a slab with unused slots is gathered on download
     if (gap_words) *gap_words = v->gap_words;
     return BMX_OK;
 }
@@ -1172,6 +1193,7 @@ int bmx_vec_download(bmx_ctx* ctx, const bmx_vec* v, uint8_t* kinds, uint32_t* o
 {
     ARGCHK(ctx && v && v->ctx == ctx);
     int rc = set_dev(ctx); if (rc) return rc;
+    if (v->ord_lazy && !v->d_ord && (rc = vec_build_ord(ctx, const_cast<bmx_vec*>(v)))) return rc;   // (a cache of the immutable vector's layout: logically const)
     if (kinds || offs) {
         std::vector<u64> desc(std::max<uint32_t>(v->nblocks, 1));
         std::vector<u32> ord;
@@ -1805,6 +1827,7 @@ static int vec_clone(bmx_ctx* ctx, const bmx_vec* a, bmx_vec** out)
     hipError_t e = hipSuccess;
     if (b_bits) e = hipMemcpyAsync(v->d_bits, a->d_bits, b_bits, hipMemcpyDeviceToDevice, ctx->stream);
     if (e == hipSuccess && b_gaps) e = hipMemcpyAsync(v->d_gaps, a->d_gaps, b_gaps, hipMemcpyDeviceToDevice, ctx->stream);
+    v->ord_lazy = a->ord_lazy;
     if (e == hipSuccess && a->d_ord && a->nblocks) {
         if ((rc = dmalloc(ctx, (void**)&v->d_ord, (size_t)a->nblocks * 4))) { bmx_vec_free(ctx, v); return rc; }
         e = hipMemcpyAsync(v->d_ord, a->d_ord, (size_t)a->nblocks * 4, hipMemcpyDeviceToDevice, ctx->stream);
@@ -1820,6 +1843,42 @@ static int vec_clone(bmx_ctx* ctx, const bmx_vec* a, bmx_vec** out)
     *out = v;
     return BMX_OK;
 }
+
+} // extern "C"
+
+// The tail of a pairwise operation whose kernel laid its GAP candidates out itself (k_op2_loop with a cursor; the stream has
+// been synchronised): kinds in h_small[2..5], GAP words in h_small[6], offsets in offs[].  k_emit_gaps is enqueued into a slab
+// of exactly those words and NOT waited for (st / offs live in the context's scratch, which the next operation touches only
+// behind it on the same stream).  A bit slab sparse enough to be compacted takes the scan path (result_finish) as before; a
+// nearly full one is kept, its ordinals left to the first download.
+static int op2_finish_laid_out(bmx_ctx* ctx, bmx_vec* v, BlockStat* st, u32* offs)
+{
+    const uint32_t nblocks = v->nblocks;
+    uint32_t counts[4];
+    for (int k = 0; k < 4; ++k) counts[k] = (uint32_t)ctx->h_small[2 + k];
+    const uint64_t used = ctx->h_small[6];
+    if ((uint64_t)counts[0] + counts[1] + counts[2] + counts[3] != nblocks || (used == 0) != (counts[BMX_GAP] == 0)) {
+        g_last_error = "bmx_op2: inconsistent fold of the result block kinds"; return BMX_ERR_DEVICE;
+    }
+    const uint32_t live = counts[BMX_BIT];
+    if (live && live < nblocks && (uint64_t)live * 8u < (uint64_t)nblocks * 7u) return result_finish(ctx, v, st, offs);
+    int rc;
+    memcpy(v->counts, counts, sizeof(counts));
+    if (used) {
+        const size_t b_gaps = (size_t)used * 2 + 64;                  // + guard, see vec_alloc_device
+        if ((rc = dmalloc(ctx, (void**)&v->d_gaps, b_gaps))) return rc;
+        v->bytes += std::max<size_t>(b_gaps, 16);
+        v->gap_words = used;
+        hipLaunchKernelGGL(k_emit_gaps, dim3((nblocks + 3) / 4), dim3(256), 0, ctx->stream,
+                           v->d_bits, nblocks, st, offs, v->d_gaps, v->d_desc);
+        KCHK();
+    }
+    if (live == 0) { dfree(ctx, v->d_bits); v->d_bits = nullptr; v->n_bit = 0; }     // (stream-ordered: whoever gets the slab next runs behind k_emit_gaps)
+    else if (live < nblocks) v->ord_lazy = true;
+    return BMX_OK;
+}
+
+extern "C" {
 
 int bmx_op2(bmx_ctx* ctx, int op, const bmx_vec* a, const bmx_vec* b, int opt_compress, bmx_vec** result)
 {
@@ -1849,7 +1908,7 @@ int bmx_op2(bmx_ctx* ctx, int op, const bmx_vec* a, const bmx_vec* b, int opt_co
     // no GAP block can come out (neither operand holds one, no re-compression): the kernel folds the kind counts itself
     // and the layout scan is skipped -- k_op2, one synchronise, done -- unless result blocks vanished (then the scan /
     // compaction path below decides what to do with the slab)
-    bool no_gap = !opt_compress && a->counts[BMX_GAP] == 0 && b->counts[BMX_GAP] == 0, folded = false;
+    bool no_gap = !opt_compress && a->counts[BMX_GAP] == 0 && b->counts[BMX_GAP] == 0, folded = false, emit = false;
     if (nblocks) {
         // bit-blocks only on both sides: the streaming form (one machine-load of waves, each owning a stretch of columns)
         const bool stream = no_gap && ctx->pair_stream != 0 && a->nblocks == b->nblocks && a->counts[BMX_BIT] == nblocks &&
@@ -1867,11 +1926,17 @@ int bmx_op2(bmx_ctx* ctx, int op, const bmx_vec* a, const bmx_vec* b, int opt_co
             const u32 wgs = (u32)(ctx->op2_loop > 0 ? ctx->op2_loop : 4);        // workgroups per CU = waves per SIMD
             const u32 grid = std::min<u32>((nblocks + 3u) / 4u, 256u * wgs);
             auto fn = (ctx->op2_nt & 1) ? k_op2_loop<4, true> : k_op2_loop<4, false>;
+            // Without re-compression the kernel also lays its GAP candidates out (a bump cursor instead of the layout scan) and folds
+            // the kinds: what is left after the one synchronise is an asynchronous k_emit_gaps into a slab of exactly the words the
+            // cursor counted -- unless the bit slab turns out sparse enough to be compacted, which takes the scan path as before.
+            // (The 16-bit kind counters of a fold slot hold 64 x 65,535 blocks.)
+            emit = !opt_compress && !no_gap && nblocks <= 2000000u;
             // the kinds are folded whatever the operands hold: when every block came out as a bit-block (OR / XOR of two 1 % vectors:
             // their GAP x GAP results pass the 1,276-run limit) there is nothing for the layout scan to lay out
             hipLaunchKernelGGL(fn, dim3(grid), dim3(256), 0, ctx->stream, op, a->d_desc, a->nblocks, b->d_desc, b->nblocks, nblocks, opt_compress,
-                               v->d_bits, v->d_desc, st, (no_gap || op == BMX_OR || op == BMX_XOR) ? FoldOut{ctx->d_slots, ctx->d_done, ctx->h_small + 2} : FoldOut{nullptr, nullptr, nullptr});
-            folded = op == BMX_OR || op == BMX_XOR;                         // (AND / SUB over GAP operands keep GAP results: straight to the layout scan, no extra synchronise)
+                               v->d_bits, v->d_desc, st, (emit || no_gap || op == BMX_OR || op == BMX_XOR) ? FoldOut{ctx->d_slots, ctx->d_done, ctx->h_small + 2} : FoldOut{nullptr, nullptr, nullptr},
+                               emit ? offs : nullptr, ctx->d_cursor);
+            folded = emit || op == BMX_OR || op == BMX_XOR;                 // (with re-compression AND / SUB go straight to the layout scan, no extra synchronise)
         } else
         hipLaunchKernelGGL(k_op2, dim3((nblocks + 3) / 4), dim3(256), 0, ctx->stream, op,
                            a->d_desc, a->nblocks, b->d_desc, b->nblocks, nblocks, opt_compress,
@@ -1880,6 +1945,12 @@ int bmx_op2(bmx_ctx* ctx, int op, const bmx_vec* a, const bmx_vec* b, int opt_co
         hipError_t e = hipGetLastError();
         if (e == hipSuccess && (no_gap || folded)) e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) { bmx_vec_free(ctx, v); return fail_hip(e, "k_op2", __LINE__); }
+        if (emit) {
+            rc = op2_finish_laid_out(ctx, v, st, offs);
+            if (rc) { bmx_vec_free(ctx, v); return rc; }
+            *result = v;
+            return BMX_OK;
+        }
         if ((no_gap || folded) && ctx->h_small[2 + BMX_GAP] == 0 && ctx->h_small[2 + BMX_BIT] == nblocks) {
             for (int k = 0; k < 4; ++k) v->counts[k] = (uint32_t)ctx->h_small[2 + k];
             *result = v;

@@ -35,6 +35,7 @@ struct bmx_ctx {
     u64* d_small = nullptr;                                 // 64 x u64 result words
     u64* d_slots = nullptr;                                 // COUNT_SLOTS striped count accumulators (kept zero between launches)
     u64* d_slots2 = nullptr; u32* d_done2 = nullptr;        // a second fold (slots + tickets) for kernels that fold block kinds AND a count
+    u32* d_cursor = nullptr;                                // bump cursor of kernels that write GAP results themselves (k_op2_loop); zero between launches
     u64* d_zero = nullptr;                                  // 256 bytes of zeros: what an invalid slot of an unconditional load reads
     u32* d_done = nullptr;                                  // workgroup ticket of the in-kernel folds (kept zero between launches)
     u64* h_small = nullptr;                                 // pinned mirror
@@ -98,6 +99,7 @@ struct bmx_vec {
     uint32_t counts[4]; uint64_t gap_words; uint32_t n_bit;   // n_bit = slots of d_bits
     u64* d_desc; uint4* d_bits; u16* d_gaps;
     u32* d_ord;        // result vectors whose slab has unused slots: ordinal of every bit-block (download gathers), else null
+    bool ord_lazy;     // ... whose ordinals have not been computed yet (vec_build_ord does it when a download first needs them)
     void* d_tdir;      // tile directory (bmx_kernels7.h): 16 B per 14 blocks, vectors with GAP or FULL blocks only, else null
     uint64_t count; bool count_valid;                         // popcount of the vector when the kernel that produced it folded one
     size_t bytes;

@@ -26,10 +26,46 @@
 //                  result is dropped; an all-ones result stays a GAP block of ONE run (it does not become FULL)
 enum { ST_OPT = 1, ST_FORCE_BIT = 2, ST_TEST_ZERO = 4, ST_TEST_ONE = 8, ST_FORCE_GAP = 16, ST_GAP_RESULT = 32 };
 
+// bit_block_to_gap (src/bmfunc.h:5542) from the transition masks of a block (blk_transitions): run k ends just before the
+// k-th transition.  Writes the block's len + 1 words at g (16-byte aligned) and its 0xFFFF padding; all 64 lanes call.
+__device__ __forceinline__ void gap_emit_from_transitions(const Blk& t, u32 len, u32 first, u16* __restrict__ g, u32 lane)
+{
+    u32 idx_base = 1u;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        u32 c = __popc(t.r[i].x) + __popc(t.r[i].y) + __popc(t.r[i].z) + __popc(t.r[i].w);
+        u32 incl = wave_scan_incl(c, lane);
+        u32 idx = idx_base + incl - c;
+        u32 wbase = (u32)i * 256u + lane * 4u;
+        u32 tw[4] = {t.r[i].x, t.r[i].y, t.r[i].z, t.r[i].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            u32 m = tw[j];
+            while (m) {
+                u32 k = __builtin_ctz(m); m &= m - 1u;
+                g[idx++] = (u16)((wbase + j) * 32u + k - 1u);
+            }
+        }
+        idx_base += __shfl(incl, 63, 64);
+    }
+    if (lane == 0) {
+        u32 level = len <= 124u ? 0u : len <= 252u ? 1u : len <= 508u ? 2u : 3u;
+        g[0] = (u16)((len << 3) | (level << 1) | first);
+        g[len] = 65535u;
+    }
+    // padding words up to the next 16-byte boundary read 0xFFFF: no run end but a block's last has that value, which is how
+    // k_agg_or_rows (bmx_kernels7.h) tells a run from padding without the block's length
+    if (lane >= 1u && lane <= 7u && len + lane < ((len + 1u + 7u) & ~7u)) g[len + lane] = 0xFFFFu;
+}
+
+// gap_offs != null: the producing kernel also lays the GAP candidates out -- a bump allocation of their 16-byte-padded
+// words from *gap_cursor, the offset left in gap_offs[nb] where k_emit_gaps looks for it -- so that no layout scan has to
+// run between the kernel and k_emit_gaps (the order of the blocks in the GAP slab is then the order of arrival).
 template <bool SNT = false>
 __device__ __forceinline__ u32 store_result_mode(const Blk& acc, u32 nb, u32 mode,
                                                   uint4* __restrict__ slab, u64* __restrict__ desc,
-                                                  BlockStat* __restrict__ st, u32 lane)
+                                                  BlockStat* __restrict__ st, u32 lane,
+                                                  u32* __restrict__ gap_offs = nullptr, u32* __restrict__ gap_cursor = nullptr)
 {
     Blk t;
     u32 pop = wave_sum(blk_lane_popcount(acc));
@@ -56,6 +92,8 @@ __device__ __forceinline__ u32 store_result_mode(const Blk& acc, u32 nb, u32 mod
     if (lane == 0) {
         st[nb] = BlockStat{pop, runs, first, kind};
         desc[nb] = (kind == K_BIT) ? DESC_MAKE(slot, K_BIT) : DESC_MAKE(0, kind == K_GAP ? K_NULL : kind);
+        if (kind == K_GAP && gap_offs)
+            gap_offs[nb] = __hip_atomic_fetch_add(gap_cursor, (runs + 1u + 7u) & ~7u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     return kind;
 }
@@ -90,7 +128,7 @@ __device__ __forceinline__ void store_trivial(u32 kind, u32 nb, u64* __restrict_
     }
 }
 
-// GAP conversion of the parked candidates (bit_block_to_gap src/bmfunc.h:5542)
+// GAP conversion of the parked candidates
 __global__ __launch_bounds__(256)
 void k_emit_gaps(const uint4* __restrict__ slab, u32 nblocks, const BlockStat* __restrict__ st,
                  const u32* __restrict__ offs, u16* __restrict__ gap_slab, u64* __restrict__ desc)
@@ -104,33 +142,33 @@ void k_emit_gaps(const uint4* __restrict__ slab, u32 nblocks, const BlockStat* _
     (void)blk_transitions(b, t, lane);
     u16* g = gap_slab + offs[nb];
     u32 len = uniform32(st[nb].runs);
-    u32 idx_base = 1u;
+    u32 first = uniform32(st[nb].first);
+    gap_emit_from_transitions(t, len, first, g, lane);
+    if (lane == 0) desc[nb] = DESC_MAKE_GAP(g, len, first);
+}
+
+// ord[nb] = number of bit-blocks before block nb (what k_scan_layout leaves in offs[] for bit-blocks), from the descriptor
+// table alone: one workgroup, 1024 blocks per step
+__global__ __launch_bounds__(1024)
+void k_ord_from_desc(const u64* __restrict__ desc, u32 nblocks, u32* __restrict__ ord)
+{
+    __shared__ u32 wsum[16];
+    const u32 tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
+    u32 carry = 0;
+    for (u32 base = 0; base < nblocks; base += 1024u) {
+        const u32 nb = base + tid;
+        const bool bit = nb < nblocks && DESC_K(desc[nb]) == K_BIT;
+        const u64 m = __ballot(bit);
+        const u32 before = __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
+        if (lane == 0) wsum[w] = (u32)__popcll(m);
+        __syncthreads();
+        u32 off = carry, tot = 0;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        u32 c = __popc(t.r[i].x) + __popc(t.r[i].y) + __popc(t.r[i].z) + __popc(t.r[i].w);
-        u32 incl = wave_scan_incl(c, lane);
-        u32 idx = idx_base + incl - c;
-        u32 wbase = (u32)i * 256u + lane * 4u;
-        u32 tw[4] = {t.r[i].x, t.r[i].y, t.r[i].z, t.r[i].w};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            u32 m = tw[j];
-            while (m) {
-                u32 k = __builtin_ctz(m); m &= m - 1u;
-                g[idx++] = (u16)((wbase + j) * 32u + k - 1u);
-            }
-        }
-        idx_base += __shfl(incl, 63, 64);
+        for (u32 i = 0; i < 16; ++i) { const u32 x = wsum[i]; if (i < w) off += x; tot += x; }
+        __syncthreads();
+        if (nb < nblocks) ord[nb] = bit ? off + before : 0u;
+        carry += tot;
     }
-    if (lane == 0) {
-        u32 level = len <= 124u ? 0u : len <= 252u ? 1u : len <= 508u ? 2u : 3u;
-        g[0] = (u16)((len << 3) | (level << 1) | st[nb].first);
-        g[len] = 65535u;
-        desc[nb] = DESC_MAKE_GAP(g, len, st[nb].first);
-    }
-    // padding words up to the next 16-byte boundary read 0xFFFF: no run end but a block's last has that value, which is how
-    // k_agg_or_rows (bmx_kernels7.h) tells a run from padding without the block's length
-    if (lane >= 1u && lane <= 7u && len + lane < ((len + 1u + 7u) & ~7u)) g[len + lane] = 0xFFFFu;
 }
 
 // result slab -> right-sized slab: bit-block nb moves to ordinal offs[nb] (from k_scan_layout) and its
@@ -166,7 +204,7 @@ void k_gather_bits(const u64* __restrict__ desc, const u32* __restrict__ ord, u3
 
 // descriptors of a cloned vector: same kinds, pointers moved into the clone's slabs
 __global__ __launch_bounds__(256)
-void k_rebase_desc(const u64* __restrict__ in, u64* __restrict__ out, u32 n, u64 old_bits, u64 new_bits, u64 old_gaps, u64 new_gaps)
+void k_rebase_desc(const u64* in, u64* out, u32 n, u64 old_bits, u64 new_bits, u64 old_gaps, u64 new_gaps)
 {
     u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -390,8 +428,11 @@ void k_count_op2_loop(int op, const u64* __restrict__ da, u32 na, const u64* __r
 template <int WAVES, bool NT>
 __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4)))
 void k_op2_loop(int op, const u64* __restrict__ da, u32 na, const u64* __restrict__ db, u32 nbk, u32 nblocks, int opt_compress,
-                uint4* __restrict__ slab, u64* __restrict__ desc, BlockStat* __restrict__ st, FoldOut kinds)
+                uint4* __restrict__ slab, u64* __restrict__ desc, BlockStat* __restrict__ st, FoldOut kinds,
+                u32* __restrict__ gap_offs, u32* __restrict__ gap_cursor)
 {
+    // gap_offs != null: this kernel lays the GAP candidates out itself (bump allocation from *gap_cursor, offsets in gap_offs[];
+    // the last workgroup of the fold hands the cursor to kinds.out[4] and leaves it at zero): no layout scan before k_emit_gaps
     __shared__ u32 lds[WAVES * 2048];
     const u32 lane = lane_id(), wave = threadIdx.x >> 6;
     u32* l = lds + wave * 2048u;
@@ -414,11 +455,11 @@ void k_op2_loop(int op, const u64* __restrict__ da, u32 na, const u64* __restric
             op2_finish(a, x, l, lane);
             op2_finish(b, y, l, lane);
             blk_op(op, x, y);
-            kind = store_result_mode<true>(x, c, op2_store_mode(op, ka, kb, opt_compress), slab, desc, st, lane);
+            kind = store_result_mode<true>(x, c, op2_store_mode(op, ka, kb, opt_compress), slab, desc, st, lane, gap_offs, gap_cursor);
         }
         kc += 1ull << (16u * kind);
     }
-    if (kinds.slots) kind_fanin_fold_packed(kc, kinds, lane, wave);
+    if (kinds.slots) kind_fanin_fold_packed(kc, kinds, lane, wave, gap_offs ? gap_cursor : nullptr);
 }
 
 // bm::count_* when BOTH operands consist of bit-blocks only (the 10 % / 50 % cases of BASELINE configs[1]): the launch is
