@@ -77,6 +77,7 @@ static int dmalloc_(bmx_ctx* ctx, void** p, size_t bytes)
         hipError_t e = hipMalloc(p, sz);
         if (e == hipErrorOutOfMemory && !ctx->pool_free.empty()) {          // give the cache back and retry
             (void)hipGetLastError();
+            if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);        // (a pooled block may still be read by enqueued work)
             for (auto& kv : ctx->pool_free) (void)hipFree(kv.second);
             ctx->pool_free.clear(); ctx->pool_cached = 0;
             e = hipMalloc(p, sz);
@@ -90,21 +91,23 @@ static int dmalloc_(bmx_ctx* ctx, void** p, size_t bytes)
     return BMX_OK;
 }
 
-// the caller guarantees no kernel still uses p (handles are freed after a stream synchronise)
+// Work enqueued on the context's stream may still use p: a pooled block is only ever handed to work that is enqueued behind
+// it on the same stream, and a block that really leaves (pool full, foreign pointer) waits for the stream first.
 static void dfree(bmx_ctx* ctx, void* p)
 {
     if (!p) return;
     auto it = ctx->pool_live.find(p);
-    if (it == ctx->pool_live.end()) { (void)hipFree(p); return; }
+    if (it == ctx->pool_live.end()) { if (ctx->stream) (void)hipStreamSynchronize(ctx->stream); (void)hipFree(p); return; }
     size_t sz = it->second;
     ctx->pool_live.erase(it);
     ctx->mem_used -= std::min<uint64_t>(ctx->mem_used, sz);
     if (ctx->pool_cached + sz <= ctx->pool_cap) { ctx->pool_free.emplace(sz, p); ctx->pool_cached += sz; }
-    else (void)hipFree(p);
+    else { if (ctx->stream) (void)hipStreamSynchronize(ctx->stream); (void)hipFree(p); }
 }
 
 static void pool_trim(bmx_ctx* ctx)
 {
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (auto& kv : ctx->pool_free) (void)hipFree(kv.second);
     ctx->pool_free.clear(); ctx->pool_cached = 0;
 }
@@ -1801,7 +1804,11 @@ static int result_finish(bmx_ctx* ctx, bmx_vec* v, BlockStat* st, u32* offs)
         HIPCHK(hipMemcpyAsync(v->d_ord, offs, (size_t)nblocks * 4, hipMemcpyDeviceToDevice, ctx->stream));
         pending = true;
     }
-    if (pending) HIPCHK(hipStreamSynchronize(ctx->stream));
+    // Nothing enqueued above is waited for: everything it reads (st / offs in the context's scratch, the old slab) is next
+    // touched by work that is enqueued BEHIND it on the same stream -- the scratch by the next operation (ensure() synchronises
+    // before it ever re-allocates), a pooled block by whoever is handed it next (hipFree, when the pool overflows, synchronises
+    // the device) -- and the host needs nothing more from the device here: the kinds came with the synchronise above.
+    (void)pending;
     if (old_slab) dfree(ctx, old_slab);
     if (live == 0) {                          // nothing lives in the slab: give it back
         dfree(ctx, v->d_bits); v->d_bits = nullptr; v->n_bit = 0;
