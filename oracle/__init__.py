@@ -424,6 +424,31 @@ class Oracle:
                                        len(groups), C.c_uint32(nb_from), C.c_uint32(nb_to), _u64p(out))
         return out
 
+    def pipeline_counts_limit(self, groups, limit: int) -> np.ndarray:
+        """pipeline::set_search_count_limit(limit) + counts-only run.  The reference (src/bmaggregator.h:255,1361-1367) stops
+        evaluating a group on the blocks that follow the one where its count reached the limit; the port restates exactly that
+        rule from per-block counts (the block range form of its pipeline)."""
+        if self.is_ref:
+            and_list = [v for g in groups for v in g[0]]
+            sub_list = [v for g in groups for v in g[1]]
+            and_n = np.array([len(g[0]) for g in groups], np.uint32)
+            sub_n = np.array([len(g[1]) for g in groups], np.uint32)
+            out = np.zeros(len(groups), np.uint64)
+            fn = self.lib.ref_agg_pipeline_counts_limit
+            fn.restype = None
+            fn.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_uint32), C.POINTER(C.c_void_p), C.POINTER(C.c_uint32), C.c_size_t,
+                           C.c_uint64, C.POINTER(C.c_uint64)]
+            fn(self._ptrs(and_list), _u32p(and_n), self._ptrs(sub_list), _u32p(sub_n), len(groups), C.c_uint64(limit), _u64p(out))
+            return out
+        nb = max([v.nblocks for g in groups for v in g[0] + g[1]], default=0)
+        out = np.zeros(len(groups), np.uint64)
+        for b in range(nb):
+            live = out < np.uint64(limit)
+            if not live.any(): break
+            per = self.pipeline_counts(groups, b, b + 1)
+            out[live] += per[live]
+        return out
+
     def pipeline_results(self, groups):
         """-> (results: list[Vec|None], counts: np.ndarray, or_target: Vec)"""
         and_list = [v for g in groups for v in g[0]]

@@ -238,6 +238,28 @@ void ref_agg_pipeline_counts(void* const* and_list, const uint32_t* and_n,
     for (size_t g = 0; g < ngroups; ++g) counts_out[g] = cnt[g];
 }
 
+// the same with pipeline::set_search_count_limit (bmaggregator.h:255-261; honoured per block at :1361-1367: a group whose
+// count has reached the limit is not evaluated on the blocks that follow)
+void ref_agg_pipeline_counts_limit(void* const* and_list, const uint32_t* and_n,
+                                   void* const* sub_list, const uint32_t* sub_n,
+                                   size_t ngroups, uint64_t limit, uint64_t* counts_out)
+{
+    agg_t agg;
+    agg_t::pipeline<bm::agg_opt_only_counts> pipe;
+    pipe.set_search_count_limit(bvect::size_type(limit));
+    size_t ao = 0, so = 0;
+    for (size_t g = 0; g < ngroups; ++g) {
+        agg_t::arg_groups* ag = pipe.add();
+        for (uint32_t k = 0; k < and_n[g]; ++k) ag->add(static_cast<const bvect*>(and_list[ao + k]), 0);
+        for (uint32_t k = 0; k < sub_n[g]; ++k) ag->add(static_cast<const bvect*>(sub_list[so + k]), 1);
+        ao += and_n[g]; so += sub_n[g];
+    }
+    pipe.complete();
+    agg.combine_and_sub(pipe);
+    auto& cnt = pipe.get_bv_count_vector();
+    for (size_t g = 0; g < ngroups; ++g) counts_out[g] = cnt[g];
+}
+
 // full pipeline: pipeline<agg_opt_bvect_and_counts> with an OR target (bmaggregator.h:62-103,222-341,1292-1449)
 // results_out[g] = new bvector (caller frees with ref_vec_free) or NULL when the group found nothing;
 // *or_target_out = new bvector holding the OR of all group results.

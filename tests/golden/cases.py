@@ -101,6 +101,10 @@ BM64_NBITS = 6_500_000_000            # 99,183 blocks; block 65,536 starts at bi
 BM64_NVEC = 4
 
 
+# pipeline::set_search_count_limit values of the golden cases (1 = stop after the first block with a hit)
+SEARCH_LIMITS = [1, 40, 3000, 0xFFFFFFFF]                   # (the last one = bm::id_max, the default: no limit)
+
+
 def bm64_build(o, seed: int):
     """one test vector, built bit by bit through the oracle / reference API (same calls on both)"""
     rng = np.random.default_rng(1000 + seed)

@@ -20,7 +20,7 @@ sys.path.insert(0, HERE)
 
 import oracle  # noqa: E402
 from cases import (AGG_GROUPS, BM64_NVEC, CASES, HINT_GROUPS, OR_SETS, PAIRS, SCANNER_EQ_BATCH, SCANNER_IN_LISTS, SCANNER_RANGES, SCANNER_ROWS,  # noqa: E402
-                   SCANNER_S_RANGES, SCANNER_S_VALUES, SCANNER_VALUES, SEED, SHIFT_SETS, bm64_build, bm64_queries, make_inputs, range_hints,
+                   SCANNER_S_RANGES, SCANNER_S_VALUES, SCANNER_VALUES, SEARCH_LIMITS, SEED, SHIFT_SETS, bm64_build, bm64_queries, make_inputs, range_hints,
                    rank_queries, scanner_values, scanner_values_signed, select_queries, sha)
 
 
@@ -93,6 +93,16 @@ def run(R, P):
         cnt = R.pipeline_counts([([vecs[i] for i in a], [vecs[i] for i in s]) for (a, s) in AGG_GROUPS])
         c["pipeline_counts"] = [int(x) for x in cnt]
         assert c["pipeline_counts"] == [g["count"] for g in c["agg_and_sub"]]
+        # pipeline::set_search_count_limit (bmaggregator.h:255, honoured per block at :1361-1367): the reference's counts under a
+        # limit ("can find more, cannot find less"), and the oracle's restatement of the rule checked against them on the spot
+        groups_rp = lambda O, vv: [([vv[i] for i in a], [vv[i] for i in s]) for (a, s) in AGG_GROUPS]
+        c["search_limit"] = {}
+        pvecs = [P.import_words(w, True, nbits) for w in words]
+        for lim in SEARCH_LIMITS:
+            rc_ = [int(x) for x in R.pipeline_counts_limit(groups_rp(R, vecs), lim)]
+            assert all(min(lim, t) <= x <= t for x, t in zip(rc_, c["pipeline_counts"])), (case, lim)
+            assert rc_ == [int(x) for x in P.pipeline_counts_limit(groups_rp(P, pvecs), lim)], (case, lim)
+            c["search_limit"][str(lim)] = rc_
         # full pipeline (agg_opt_bvect_and_counts + OR target), AggregatorTest t.cpp:10378-10580 shape
         res, rc, ort = R.pipeline_results([([vecs[i] for i in a], [vecs[i] for i in s_]) for (a, s_) in AGG_GROUPS])
         assert [int(x) for x in rc] == c["pipeline_counts"]

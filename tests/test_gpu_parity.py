@@ -128,6 +128,19 @@ def test_golden_case(ctx, port, golden, case, agg_path):
     cnt = agg.combine_and_sub(pipe)
     assert [int(x) for x in cnt] == g["pipeline_counts"]
     assert [int(x) for x in pipe.get_bv_count_vector()] == g["pipeline_counts"]
+    # pipeline::set_search_count_limit against what the REFERENCE returned under the same limit (golden "search_limit"): it
+    # stops a group after the block where its count reached the limit, the library after the launch window -- both walk the
+    # blocks in ascending order, so reference <= library <= true count, group by group ("can find more, cannot find less")
+    for lim, ref_counts in g["search_limit"].items():
+        pl = bm.aggregator.pipeline(ctx)
+        for (a, s) in AGG_GROUPS:
+            ag = pl.add()
+            for i in a: ag.add(vecs[i], 0)
+            for i in s: ag.add(vecs[i], 1)
+        pl.set_search_count_limit(int(lim))
+        pl.complete()
+        got = [int(x) for x in agg.combine_and_sub(pl)]
+        assert all(r <= x <= t for r, x, t in zip(ref_counts, got, g["pipeline_counts"])), (lim, ref_counts, got)
     # block-range shards add up (multi-GPU premise)
     nb = vecs[0].info()["nblocks"]
     parts = sum(agg._run_pipeline(pipe, a, b).astype(np.int64) for a, b in [(0, 1), (1, nb)])
@@ -2061,6 +2074,18 @@ def test_pairwise_materialised_long_mixed_vectors(ctx, port):
                         assert t.block_table()[0].tolist() == kinds, (loop, nt, opt, op, name)
                         assert (t.to_words(nw) == words).all(), (loop, nt, opt, op, name)
                         assert t.count() == cnt
+                        if loop in (-1, 0) and name == "ab":
+                            # the result as a host block table (GAP blocks laid out by the kernel in arrival order, ordinals of the
+                            # kept bit slab computed at this first download) and back: same vector; and as an operand of later
+                            # operations (its clone, a count against itself, an OR with an operand)
+                            k2, o2, b2, g2 = t.block_table()
+                            back = bm.bvector.from_block_table(ctx, t.info()["nbits"], k2, o2, b2, g2)
+                            assert bm.count_xor(back, t) == 0 and back.block_table()[0].tolist() == kinds
+                            assert bm.count_and(t, t) == cnt
+                            u = bm.bvector._op2(bm.OR, t, x, bm.opt_none)
+                            eu = port.op2(bm.OR, port.op2(op, pa, pb, opt), pa, False)
+                            assert (u.to_words(nw) == eu.to_words(nw)).all() and u.block_table()[0].tolist() == eu.flatten()[0].tolist()
+                            del back, u
                         del t
     finally:
         ctx.set_tuning("op2_loop", -1); ctx.set_tuning("op2_nt", 3)

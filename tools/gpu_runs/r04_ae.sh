@@ -1,0 +1,4 @@
+#!/bin/bash
+export TMPDIR=/tmp
+O=gpurun_out/${1:-r04ae}; rm -rf $O; mkdir -p $O
+timeout 1500 python -m pytest tests -q -m gpu -x > $O/pytest.txt 2>&1; echo "rc $?" >> $O/pytest.txt; tail -4 $O/pytest.txt
