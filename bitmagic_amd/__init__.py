@@ -211,6 +211,17 @@ class bvector:
         return bvector(a.ctx, h)
 
     @staticmethod
+    def op2_async(op, a, b) -> "pending":
+        """bmx_op2_dev: the three-operand operation (opt_none) enqueued on the context's stream; a / b are vectors without GAP
+        blocks or unresolved results of earlier op2_async calls; -> pending (wait() gives the vector)"""
+        ctx = a.ctx
+        h = C.c_void_p()
+        av, ap = (a._h, None) if isinstance(a, bvector) else (None, a._h)
+        bv, bp = (b._h, None) if isinstance(b, bvector) else (None, b._h)
+        check(lib().bmx_op2_dev(ctx._h, op, av, ap, bv, bp, C.byref(h)))
+        return pending(ctx, h)
+
+    @staticmethod
     def bit_and(a, b, opt_mode=opt_none):
         return bvector._op2(AND, a, b, opt_mode)
 
@@ -347,6 +358,29 @@ def bit_import_u32(ctx: context, words, optimize: bool = True) -> bvector:
     h = C.c_void_p()
     check(lib().bmx_vec_import_bits(ctx._h, _ptr(words) if words.size else None, words.size, int(optimize), C.byref(h)))
     return bvector(ctx, h)
+
+
+class pending:
+    """an asynchronous result (bmx_op2_dev) that has not been resolved into a vector yet: usable as an operand of further
+    bvector.op2_async calls, and nowhere else"""
+
+    def __init__(self, ctx: context, h):
+        self.ctx, self._h = ctx, h
+
+    def wait(self) -> bvector:
+        """bmx_pending_wait: waits for this result, -> the vector (the handle is consumed)"""
+        h = C.c_void_p()
+        ph, self._h = self._h, None
+        check(lib().bmx_pending_wait(self.ctx._h, ph, C.byref(h)))
+        return bvector(self.ctx, h)
+
+    def __del__(self):
+        try:
+            if self._h and self.ctx._h:
+                lib().bmx_pending_free(self.ctx._h, self._h)
+        except Exception:
+            pass
+        self._h = None
 
 
 def _count_op2(op, a: bvector, b: bvector) -> int:

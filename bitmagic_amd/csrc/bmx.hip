@@ -623,6 +623,7 @@ int bmx_ctx_create(int device, void* stream, bmx_ctx** out)
     CTXCHK(hipMemsetAsync(ctx->d_slots2, 0, COUNT_SLOTS * COUNT_SLOT_STRIDE * sizeof(u64), ctx->stream));
     CTXCHK(hipMalloc((void**)&ctx->d_done2, FOLD_DONE_WORDS * 4));
     CTXCHK(hipMemsetAsync(ctx->d_done2, 0, FOLD_DONE_WORDS * 4, ctx->stream));
+    CTXCHK(hipHostMalloc((void**)&ctx->h_pend, 64 * 8 * sizeof(u64)));
     CTXCHK(hipMalloc((void**)&ctx->d_cursor, 64));
     CTXCHK(hipMemsetAsync(ctx->d_cursor, 0, 64, ctx->stream));
 #undef CTXCHK
@@ -660,6 +661,7 @@ int bmx_ctx_destroy(bmx_ctx* ctx)
     if (ctx->d_slots2) (void)hipFree(ctx->d_slots2);
     if (ctx->d_done2) (void)hipFree(ctx->d_done2);
     if (ctx->d_cursor) (void)hipFree(ctx->d_cursor);
+    if (ctx->h_pend) (void)hipHostFree(ctx->h_pend);
     if (ctx->d_zero) (void)hipFree(ctx->d_zero);
     if (ctx->h_small) (void)hipHostFree(ctx->h_small);
     if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
@@ -1967,6 +1969,118 @@ int bmx_op2(bmx_ctx* ctx, int op, const bmx_vec* a, const bmx_vec* b, int opt_co
     if ((rc = result_finish(ctx, v, st, offs))) { bmx_vec_free(ctx, v); return rc; }
     *result = v;
     return BMX_OK;
+}
+
+// ---- asynchronous 3-operand operations (bmx_op2_dev / bmx_pending_wait / bmx_pending_free) ----
+// What the synchronous bmx_op2 waits for is not the result -- that is complete on the stream when the kernel ends -- but the
+// COUNTS of its block kinds, which decide on the host how the next operation over it is dispatched.  Operands without GAP
+// blocks under opt_none cannot produce a GAP block, so their result needs no layout pass at all: the kernel folds the kind
+// counts into a pinned slot, the call returns at once, and a later operation that takes the unresolved result as an operand
+// simply runs the kernel that asks nothing of its operands' kinds (k_op2_loop / k_op2).  One synchronise resolves a whole chain.
+int bmx_op2_dev(bmx_ctx* ctx, int op, const bmx_vec* a, const bmx_pending* pa, const bmx_vec* b, const bmx_pending* pb, bmx_pending** out)
+{
+    ARGCHK(ctx && out && op >= BMX_AND && op <= BMX_SUB && ((a != nullptr) != (pa != nullptr)) && ((b != nullptr) != (pb != nullptr)));
+    *out = nullptr;
+    ARGCHK((!a || a->ctx == ctx) && (!b || b->ctx == ctx) && (!pa || pa->ctx == ctx) && (!pb || pb->ctx == ctx));
+    if ((a && a->counts[BMX_GAP]) || (b && b->counts[BMX_GAP])) { g_last_error = "bmx_op2_dev takes operands without GAP blocks (bmx_op2 handles every kind)"; return BMX_ERR_BADARG; }
+    int rc = set_dev(ctx); if (rc) return rc;
+    const bmx_vec* va = a ? a : pa->v; const bmx_vec* vb = b ? b : pb->v;
+    const uint32_t nblocks = std::max(va->nblocks, vb->nblocks);
+    const uint64_t nbits = std::max(va->nbits, vb->nbits);
+    int slot = -1;
+    for (int i = 0; i < 64; ++i) if (!(ctx->pend_used >> i & 1ull)) { slot = i; break; }
+    if (slot < 0) { g_last_error = "bmx_op2_dev: 64 unresolved results are outstanding (bmx_pending_wait / bmx_pending_free them)"; return BMX_ERR_RANGE; }
+    bmx_pending* p = new (std::nothrow) bmx_pending();
+    if (!p) return BMX_ERR_BADALLOC;
+    p->ctx = ctx; p->v = nullptr; p->slot = slot; p->ev = nullptr;
+    bmx_vec* v; BlockStat* st; u32* offs;
+    if ((rc = result_begin(ctx, nbits, nblocks, &v, &st, &offs))) { delete p; return rc; }
+    u64* hs = ctx->h_pend + (size_t)slot * 8;
+    for (int k = 0; k < 8; ++k) hs[k] = 0;
+    hipError_t e = hipEventCreateWithFlags(&p->ev, hipEventDisableTiming);
+    if (e != hipSuccess) { bmx_vec_free(ctx, v); delete p; return fail_hip(e, "hipEventCreate", __LINE__); }
+    const FoldOut fo{ctx->d_slots, ctx->d_done, hs};
+    const bool same = (a && b && a == b) || (pa && pb && pa == pb);
+    if (!nblocks) hs[BMX_NULL] = 0;
+    else if (same && (op == BMX_XOR || op == BMX_SUB)) {                    // x ^ x, x - x: empty (src/bm.h:6081, 6412)
+        e = hipMemsetAsync(v->d_desc, 0, (size_t)nblocks * 8, ctx->stream);
+        hs[BMX_NULL] = nblocks;
+    } else {
+        const bool stream = a && b && ctx->pair_stream != 0 && a->nblocks == b->nblocks && a->counts[BMX_BIT] == nblocks &&
+                            b->counts[BMX_BIT] == nblocks && nblocks >= 2048u;
+        if (stream) {
+            const u32 waves = 4u, total = 256u * waves * (u32)std::max(ctx->op2_wgs, 1);
+            const u32 per_wave = (nblocks + total - 1u) / total;
+            const u32 grid = ((nblocks + per_wave - 1u) / per_wave + waves - 1u) / waves;
+            auto fn = ctx->op2_nt == 3 ? k_op2_stream<4, true, true> : ctx->op2_nt == 2 ? k_op2_stream<4, false, true>
+                    : ctx->op2_nt == 1 ? k_op2_stream<4, true, false> : k_op2_stream<4, false, false>;
+            hipLaunchKernelGGL(fn, dim3(grid), dim3(256), 0, ctx->stream, op, va->d_desc, vb->d_desc, nblocks, per_wave, v->d_bits, v->d_desc, st, fo);
+        } else if (ctx->op2_loop != 0 && nblocks >= 2048u) {
+            const u32 wgs = (u32)(ctx->op2_loop > 0 ? ctx->op2_loop : 4);
+            const u32 grid = std::min<u32>((nblocks + 3u) / 4u, 256u * wgs);
+            auto fn = (ctx->op2_nt & 1) ? k_op2_loop<4, true> : k_op2_loop<4, false>;
+            hipLaunchKernelGGL(fn, dim3(grid), dim3(256), 0, ctx->stream, op, va->d_desc, va->nblocks, vb->d_desc, vb->nblocks, nblocks, 0,
+                               v->d_bits, v->d_desc, st, fo, (u32*)nullptr, ctx->d_cursor);
+        } else
+            hipLaunchKernelGGL(k_op2, dim3((nblocks + 3) / 4), dim3(256), 0, ctx->stream, op, va->d_desc, va->nblocks, vb->d_desc, vb->nblocks, nblocks, 0,
+                               v->d_bits, v->d_desc, st, fo);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipEventRecord(p->ev, ctx->stream);
+    if (e != hipSuccess) { (void)hipStreamSynchronize(ctx->stream); (void)hipEventDestroy(p->ev); bmx_vec_free(ctx, v); delete p; return fail_hip(e, "bmx_op2_dev", __LINE__); }
+    ctx->pend_used |= 1ull << slot;
+    p->v = v;
+    *out = p;
+    return BMX_OK;
+}
+
+int bmx_pending_wait(bmx_ctx* ctx, bmx_pending* p, bmx_vec** out)
+{
+    ARGCHK(ctx && p && out && p->ctx == ctx && p->v);
+    *out = nullptr;
+    int rc = set_dev(ctx); if (rc) return rc;
+    HIPCHK(hipEventSynchronize(p->ev));
+    bmx_vec* v = p->v;
+    const u64* hs = ctx->h_pend + (size_t)p->slot * 8;
+    const uint32_t nblocks = v->nblocks;
+    for (int k = 0; k < 4; ++k) v->counts[k] = (uint32_t)hs[k];
+    const bool ok = (uint64_t)v->counts[0] + v->counts[1] + v->counts[2] + v->counts[3] == nblocks && v->counts[BMX_GAP] == 0;
+    ctx->pend_used &= ~(1ull << p->slot);
+    (void)hipEventDestroy(p->ev);
+    p->v = nullptr;
+    delete p;
+    if (!ok) { (void)hipStreamSynchronize(ctx->stream); bmx_vec_free(ctx, v); g_last_error = "bmx_pending_wait: inconsistent fold of the result block kinds"; return BMX_ERR_DEVICE; }
+    // the slab, as result_finish treats it: nothing alive -> back to the pool; sparse -> the survivors into a right-sized slab
+    // (ordinals from the descriptor table; enqueued, not waited for); nearly full -> kept, ordinals at the first download
+    const uint32_t live = v->counts[BMX_BIT];
+    if (live == 0) { dfree(ctx, v->d_bits); v->d_bits = nullptr; v->n_bit = 0; }
+    else if ((uint64_t)live * 8u < (uint64_t)nblocks * 7u) {
+        uint4* packed = nullptr; u32* ord = nullptr;
+        if ((rc = dmalloc(ctx, (void**)&packed, (size_t)live * 8192)) || (rc = dmalloc(ctx, (void**)&ord, (size_t)nblocks * 4))) {
+            dfree(ctx, packed); bmx_vec_free(ctx, v); return rc;
+        }
+        hipLaunchKernelGGL(k_ord_from_desc, dim3(1), dim3(1024), 0, ctx->stream, (const u64*)v->d_desc, nblocks, ord);
+        hipLaunchKernelGGL(k_compact_bits, dim3((nblocks + 3) / 4), dim3(256), 0, ctx->stream,
+                           (const uint4*)v->d_bits, nblocks, (const BlockStat*)nullptr, (const u32*)ord, packed, v->d_desc);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { (void)hipStreamSynchronize(ctx->stream); dfree(ctx, packed); dfree(ctx, ord); bmx_vec_free(ctx, v); return fail_hip(e, "bmx_pending_wait (compaction)", __LINE__); }
+        dfree(ctx, ord); dfree(ctx, v->d_bits);                          // (stream-ordered, see dfree)
+        v->d_bits = packed; v->n_bit = live;
+    } else if (live < nblocks) v->ord_lazy = true;
+    *out = v;
+    return BMX_OK;
+}
+
+int bmx_pending_free(bmx_ctx* ctx, bmx_pending* p)
+{
+    if (!p) return BMX_OK;
+    ARGCHK(ctx && p->ctx == ctx);
+    (void)hipEventSynchronize(p->ev);
+    (void)hipEventDestroy(p->ev);
+    ctx->pend_used &= ~(1ull << p->slot);
+    int rc = p->v ? bmx_vec_free(ctx, p->v) : BMX_OK;
+    delete p;
+    return rc;
 }
 
 static int count_op2_launch(bmx_ctx* ctx, int op, const bmx_vec* a, const bmx_vec* b, u64* out, bool out_is_host)

@@ -35,6 +35,7 @@ struct bmx_ctx {
     u64* d_small = nullptr;                                 // 64 x u64 result words
     u64* d_slots = nullptr;                                 // COUNT_SLOTS striped count accumulators (kept zero between launches)
     u64* d_slots2 = nullptr; u32* d_done2 = nullptr;        // a second fold (slots + tickets) for kernels that fold block kinds AND a count
+    u64* h_pend = nullptr; uint64_t pend_used = 0;         // 64 pinned slots (8 x u64) for the kind counts of unresolved asynchronous results
     u32* d_cursor = nullptr;                                // bump cursor of kernels that write GAP results themselves (k_op2_loop); zero between launches
     u64* d_zero = nullptr;                                  // 256 bytes of zeros: what an invalid slot of an unconditional load reads
     u32* d_done = nullptr;                                  // workgroup ticket of the in-kernel folds (kept zero between launches)
@@ -148,6 +149,15 @@ struct bmx_coll {
     bool has_bit;                         // a bit-block was found while counting: unusable
     bool prepared;                        // built by bmx_collection_prepare (not by the gap_pack 1 policy)
     float build_ms;
+};
+
+// an asynchronous result (bmx_op2_dev): the vector is complete on the stream, its block-kind counts are on their way into a
+// pinned slot; bmx_pending_wait turns it into an ordinary vector.  A handle type of its own: no other entry can be handed one.
+struct bmx_pending {
+    bmx_ctx* ctx;
+    bmx_vec* v;
+    int slot;
+    hipEvent_t ev;
 };
 
 struct bmx_rs {

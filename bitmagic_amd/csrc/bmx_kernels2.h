@@ -175,12 +175,12 @@ void k_ord_from_desc(const u64* __restrict__ desc, u32 nblocks, u32* __restrict_
 // descriptor follows.  One wave per block column.
 __global__ __launch_bounds__(256)
 void k_compact_bits(const uint4* __restrict__ slab, u32 nblocks, const BlockStat* __restrict__ st,
-                    const u32* __restrict__ offs, uint4* __restrict__ packed, u64* __restrict__ desc)
+                    const u32* __restrict__ offs, uint4* __restrict__ packed, u64* desc)
 {
     u32 lane = lane_id();
     u32 nb = uniform32(blockIdx.x * 4u + (threadIdx.x >> 6));
     if (nb >= nblocks) return;
-    if (uniform32(st[nb].kind) != K_BIT) return;
+    if (uniform32(st ? st[nb].kind : DESC_K(desc[nb])) != K_BIT) return;    // (st == null: the kinds as the descriptor table has them)
     Blk b;
     blk_load(b, as_gc4(slab + (size_t)nb * 512u), lane);
     uint4* dst = packed + (size_t)uniform32(offs[nb]) * 512u;

@@ -60,6 +60,7 @@ extern "C" {
 
 typedef struct bmx_ctx      bmx_ctx;
 typedef struct bmx_vec      bmx_vec;
+typedef struct bmx_pending  bmx_pending;  /* an asynchronous result that has not been resolved into a vector yet (bmx_op2_dev) */
 typedef struct bmx_pipeline bmx_pipeline;
 typedef struct bmx_rs       bmx_rs;
 
@@ -143,6 +144,21 @@ int bmx_count(bmx_ctx* ctx, const bmx_vec* a, uint64_t* count);
  * opt_compress != 0 re-compresses produced blocks (opt_compress, src/bm.h:6263). */
 int bmx_op2(bmx_ctx* ctx, int op, const bmx_vec* a, const bmx_vec* b, int opt_compress,
             bmx_vec** result);
+/* The same three-operand operations (src/bm.h:6185,5973,6072,6403; opt_none), ASYNCHRONOUS on the context's stream: the call
+ * enqueues the kernel and returns.  What bmx_op2 waits for is not the result -- it is complete on the stream when the kernel
+ * ends -- but the counts of its block kinds, which the host needs to dispatch later operations over it; here they travel to
+ * pinned memory behind the kernel and are read when the result is resolved.  Each operand is EITHER a vector (a / b) OR an
+ * unresolved result of an earlier bmx_op2_dev (pa / pb) -- exactly one of each pair is non-NULL -- so a chain of operations
+ * stays on the stream and pays one synchronise at its end instead of one per operation.  Operands must hold no GAP blocks
+ * (then no GAP block can come out and the result needs no layout pass; BMX_ERR_BADARG otherwise: use bmx_op2).
+ *   bmx_pending_wait   waits for THIS result only, turns it into an ordinary vector (*out; the handle is consumed)
+ *   bmx_pending_free   drops an unresolved result (it may still be an operand of operations enqueued earlier)
+ * At most 64 unresolved results per context (BMX_ERR_RANGE).  bmx_pending is a handle type of its own: no other entry point
+ * accepts one, so a vector whose kind counts are not known yet can never reach a dispatch decision. */
+int bmx_op2_dev(bmx_ctx* ctx, int op, const bmx_vec* a, const bmx_pending* pa, const bmx_vec* b, const bmx_pending* pb,
+                bmx_pending** out);
+int bmx_pending_wait(bmx_ctx* ctx, bmx_pending* p, bmx_vec** out);
+int bmx_pending_free(bmx_ctx* ctx, bmx_pending* p);
 /* bm::count_and/count_or/count_xor/count_sub  src/bmalgo.h:49,149,81,115 */
 int bmx_count_op2(bmx_ctx* ctx, int op, const bmx_vec* a, const bmx_vec* b, uint64_t* count);
 /* same, asynchronous on the context's stream; d_count is DEVICE memory (one uint64) */

@@ -2091,6 +2091,57 @@ def test_pairwise_materialised_long_mixed_vectors(ctx, port):
         ctx.set_tuning("op2_loop", -1); ctx.set_tuning("op2_nt", 3)
 
 
+@pytest.mark.parametrize("nblk", [3, 2300])
+def test_async_pairwise_chain(ctx, port, nblk):
+    """bmx_op2_dev / bmx_pending_wait: chains of three-operand operations that stay on the stream (operands = vectors without
+    GAP blocks or unresolved results) give the oracle's bits AND block kinds after one wait at the end -- the streaming kernel
+    (two all-bit-block vectors), the persistent and the wave-per-column kernels (operands with NULL / FULL blocks, unresolved
+    operands, different lengths), results that come out empty or sparse (compacted at the wait), an operand used twice,
+    waiting out of order, dropping an unresolved result; GAP operands and other entry points refuse"""
+    rng = np.random.default_rng(nblk)
+    def build(seed, dq, nb, holes):
+        w = port.gen_words(777, seed, dq, nb * 65536)
+        for b in rng.choice(nb, size=holes, replace=False):
+            w[b * 2048:(b + 1) * 2048] = 0 if b % 2 else 0xFFFFFFFF
+        return w
+    ws = [build(1, 20000, nblk, 0), build(2, 30000, nblk, 0), build(3, 25000, nblk, max(1, nblk // 5)), build(4, 32768, max(1, nblk - 1), max(1, nblk // 3))]
+    pv = [port.import_words(w, False, w.size * 32) if i < 2 else port.import_words(w, True, w.size * 32) for i, w in enumerate(ws)]
+    gv = [bm.bit_import_u32(ctx, w, False) if i < 2 else bm.bit_import_u32(ctx, w, True) for i, w in enumerate(ws)]
+    assert all(v.calc_stat()["gap_blocks"] == 0 for v in gv)
+    nw = nblk * 2048
+    def same(t, e):
+        return (t.to_words(nw) == e.to_words(nw)).all() and t.block_table()[0].tolist() == (e.flatten()[0].tolist() + [0] * nblk)[:t.info()["nblocks"]] and t.count() == e.count()
+    # a chain: r1 = v0 & v1 (streaming kernel); r2 = r1 | v2 (unresolved operand); r3 = r2 - v3; r4 = r3 ^ r1; r5 = r4 & r4
+    r1 = bm.bvector.op2_async(bm.AND, gv[0], gv[1])
+    r2 = bm.bvector.op2_async(bm.OR, r1, gv[2])
+    r3 = bm.bvector.op2_async(bm.SUB, r2, gv[3])
+    r4 = bm.bvector.op2_async(bm.XOR, r3, r1)
+    r5 = bm.bvector.op2_async(bm.AND, r4, r4)
+    r6 = bm.bvector.op2_async(bm.XOR, r4, r4)                                   # empty
+    r7 = bm.bvector.op2_async(bm.AND, gv[2], gv[3])                             # sparse-ish: NULL / FULL holes on both sides
+    e1 = port.op2(bm.AND, pv[0], pv[1], False); e2 = port.op2(bm.OR, e1, pv[2], False); e3 = port.op2(bm.SUB, e2, pv[3], False)
+    e4 = port.op2(bm.XOR, e3, e1, False); e5 = port.op2(bm.AND, e4, e4, False); e6 = port.op2(bm.XOR, e4, e4, False)
+    e7 = port.op2(bm.AND, pv[2], pv[3], False)
+    t5 = r5.wait()                                                              # out of order: the last link first
+    assert same(t5, e5)
+    t7, t6, t4, t3, t2, t1 = r7.wait(), r6.wait(), r4.wait(), r3.wait(), r2.wait(), r1.wait()
+    for t, e in ((t1, e1), (t2, e2), (t3, e3), (t4, e4), (t6, e6), (t7, e7)):
+        assert same(t, e)
+    assert t6.count() == 0
+    # resolved results are ordinary vectors: operands of the synchronous entries, downloadable
+    u = bm.bvector.bit_or(t3, t7)
+    assert same(u, port.op2(bm.OR, e3, e7, False))
+    k, o, b, g = t7.block_table()
+    assert bm.count_xor(bm.bvector.from_block_table(ctx, t7.info()["nbits"], k, o, b, g), t7) == 0
+    # dropping an unresolved result that later operations read; GAP operands are refused
+    d1 = bm.bvector.op2_async(bm.OR, gv[0], gv[2]); d2 = bm.bvector.op2_async(bm.AND, d1, gv[1]); del d1
+    assert same(d2.wait(), port.op2(bm.AND, port.op2(bm.OR, pv[0], pv[2], False), pv[1], False))
+    gapv = bm.bit_import_u32(ctx, port.gen_words(777, 9, 13, nblk * 65536), True)
+    if gapv.calc_stat()["gap_blocks"]:
+        with pytest.raises(bm.BmxError):
+            bm.bvector.op2_async(bm.AND, gapv, gv[0])
+
+
 def test_full_size_pairwise_and_rank_select_vs_reference_on_all_cores(ctx):
     """BASELINE configs[1] and configs[3] at FULL size against the reference itself (oracle/_ref, the unmodified BitMagic;
     the C port where it is absent) fanned over the host cores by block range -- not only identities: the four counts of a
