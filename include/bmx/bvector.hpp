@@ -263,6 +263,57 @@ private:
     bmx_vec* h_ = nullptr;
 };
 
+/// An asynchronous result (bmx_op2_dev): complete on the context's stream, not yet an ordinary vector.  It is accepted as an
+/// operand by bit_op_async() and by nothing else; wait() waits for it and moves it into a bvector.  No counterpart in the
+/// reference (its vectors live on the host); the operations are those of bvector::bit_and/or/xor/sub, src/bm.h:6185,5973,6072,6403.
+class pending {
+public:
+    pending(context& ctx, bmx_pending* h) : ctx_(&ctx), h_(h) {}
+    pending(const pending&) = delete;
+    pending& operator=(const pending&) = delete;
+    pending(pending&& o) noexcept : ctx_(o.ctx_), h_(o.h_) { o.h_ = nullptr; }
+    ~pending() { if (h_) bmx_pending_free(ctx_->handle(), h_); }
+    const bmx_pending* handle() const noexcept { return h_; }
+    context& get_context() const noexcept { return *ctx_; }
+    /// waits for this result only; the handle is consumed
+    void wait(bvector& target)
+    {
+        bmx_vec* v = nullptr;
+        bmx_pending* h = h_; h_ = nullptr;
+        check(bmx_pending_wait(ctx_->handle(), h, &v));
+        target.adopt(v);
+    }
+private:
+    context* ctx_;
+    bmx_pending* h_;
+};
+
+/// op = BMX_AND / BMX_OR / BMX_XOR / BMX_SUB over operands WITHOUT GAP blocks (vectors or unresolved results): enqueued, not waited for
+inline pending bit_op_async(int op, const bvector& a, const bvector& b)
+{
+    bmx_pending* p = nullptr;
+    check(bmx_op2_dev(a.get_context().handle(), op, a.handle(), nullptr, b.handle(), nullptr, &p));
+    return pending(a.get_context(), p);
+}
+inline pending bit_op_async(int op, const pending& a, const bvector& b)
+{
+    bmx_pending* p = nullptr;
+    check(bmx_op2_dev(a.get_context().handle(), op, nullptr, a.handle(), b.handle(), nullptr, &p));
+    return pending(a.get_context(), p);
+}
+inline pending bit_op_async(int op, const bvector& a, const pending& b)
+{
+    bmx_pending* p = nullptr;
+    check(bmx_op2_dev(a.get_context().handle(), op, a.handle(), nullptr, nullptr, b.handle(), &p));
+    return pending(a.get_context(), p);
+}
+inline pending bit_op_async(int op, const pending& a, const pending& b)
+{
+    bmx_pending* p = nullptr;
+    check(bmx_op2_dev(a.get_context().handle(), op, nullptr, a.handle(), nullptr, b.handle(), &p));
+    return pending(a.get_context(), p);
+}
+
 /// bm::bit_import_u32(bv, bit_arr, bit_arr_size, optimize)  src/bmbvimport.h:46
 inline void bit_import_u32(bvector& bv, const unsigned int* bit_arr, size_type bit_arr_size, bool optimize)
 {

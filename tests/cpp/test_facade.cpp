@@ -54,6 +54,27 @@ int main()
         REQUIRE(u.equal(t));
         bmo_vec_free(e);
     }
+    // asynchronous chain over vectors without GAP blocks (bmx_op2_dev): ((a & b) | c) - a, one wait at the end = the synchronous result
+    {
+        std::vector<bmx::bvector> dv; std::vector<bmo_vec*> dp;
+        for (unsigned v = 0; v < 3; ++v) {
+            std::vector<uint32_t> w((nbits + 31) / 32);
+            bmo_gen_words(SEED, 50 + v, 0, 20000 + 3000 * v, nbits, 0, w.size(), w.data());
+            dv.emplace_back(ctx); bmx::bit_import_u32(dv[v], w.data(), w.size(), false);
+            dp.push_back(bmo_vec_import(w.data(), w.size(), 0));
+        }
+        bmx::pending p1 = bmx::bit_op_async(BMX_AND, dv[0], dv[1]);
+        bmx::pending p2 = bmx::bit_op_async(BMX_OR, p1, dv[2]);
+        bmx::pending p3 = bmx::bit_op_async(BMX_SUB, p2, dv[0]);
+        bmx::bvector r(ctx), s1(ctx), s2(ctx), s3(ctx);
+        p3.wait(r);
+        s1.bit_and(dv[0], dv[1]); s2.bit_or(s1, dv[2]); s3.bit_sub(s2, dv[0]);
+        REQUIRE(r.equal(s3));
+        bmo_vec* e1 = bmo_op2(0, dp[0], dp[1], 0); bmo_vec* e2 = bmo_op2(1, e1, dp[2], 0); bmo_vec* e3 = bmo_op2(3, e2, dp[0], 0);
+        REQUIRE(r.count() == bmo_vec_count(e3));
+        bmo_vec_free(e1); bmo_vec_free(e2); bmo_vec_free(e3);
+        for (auto* q : dp) bmo_vec_free(q);
+    }
     // aggregator, member API
     bmx::aggregator<bmx::bvector> agg(ctx);
     for (unsigned v = 0; v < 4; ++v) agg.add(&gv[v]);

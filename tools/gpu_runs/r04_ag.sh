@@ -1,0 +1,4 @@
+#!/bin/bash
+export TMPDIR=/tmp
+O=gpurun_out/${1:-r04ag}; rm -rf $O; mkdir -p $O
+timeout 1800 python -m pytest tests -q -m gpu > $O/pytest.txt 2>&1; echo "rc $?" >> $O/pytest.txt; tail -5 $O/pytest.txt
