@@ -1019,7 +1019,7 @@ int bmx_vec_upload(bmx_ctx* ctx, uint64_t nbits, uint32_t nblocks,
 static int vec_from_raw(bmx_ctx* ctx, uint64_t nbits, uint32_t nblocks, int optimize, bmx_vec** out)
 {
     int rc;
-    size_t aux_need = (size_t)nblocks * (sizeof(BlockStat) + 4) + 64;
+    size_t aux_need = (size_t)nblocks * (sizeof(BlockStat) + 4 + 4) + 64;      // st[], offs[], and a block list behind them (result_list())
     if ((rc = ensure(ctx, &ctx->aux, &ctx->aux_bytes, aux_need))) return rc;
     BlockStat* st = (BlockStat*)ctx->aux;
     u32* offs = (u32*)((char*)ctx->aux + (size_t)nblocks * sizeof(BlockStat));
@@ -1865,8 +1865,8 @@ static int op2_finish_laid_out(bmx_ctx* ctx, bmx_vec* v, BlockStat* st, u32* off
     const uint32_t nblocks = v->nblocks;
     uint32_t counts[4];
     for (int k = 0; k < 4; ++k) counts[k] = (uint32_t)ctx->h_small[2 + k];
-    const uint64_t used = ctx->h_small[6];
-    if ((uint64_t)counts[0] + counts[1] + counts[2] + counts[3] != nblocks || (used == 0) != (counts[BMX_GAP] == 0)) {
+    const uint64_t used = ctx->h_small[6] & 0xFFFFFFFFFFull, ncand = ctx->h_small[6] >> 40;      // the cursor: words | candidates << 40
+    if ((uint64_t)counts[0] + counts[1] + counts[2] + counts[3] != nblocks || ncand != counts[BMX_GAP] || (used == 0) != (ncand == 0)) {
         g_last_error = "bmx_op2: inconsistent fold of the result block kinds"; return BMX_ERR_DEVICE;
     }
     const uint32_t live = counts[BMX_BIT];
@@ -1878,11 +1878,11 @@ static int op2_finish_laid_out(bmx_ctx* ctx, bmx_vec* v, BlockStat* st, u32* off
         if ((rc = dmalloc(ctx, (void**)&v->d_gaps, b_gaps))) return rc;
         v->bytes += std::max<size_t>(b_gaps, 16);
         v->gap_words = used;
-        hipLaunchKernelGGL(k_emit_gaps, dim3((nblocks + 3) / 4), dim3(256), 0, ctx->stream,
-                           v->d_bits, nblocks, st, offs, v->d_gaps, v->d_desc);
+        hipLaunchKernelGGL(k_emit_gaps_list, dim3(((u32)ncand + 3) / 4), dim3(256), 0, ctx->stream,
+                           v->d_bits, (const u32*)(offs + nblocks), (u32)ncand, st, offs, v->d_gaps, v->d_desc);
         KCHK();
     }
-    if (live == 0) { dfree(ctx, v->d_bits); v->d_bits = nullptr; v->n_bit = 0; }     // (stream-ordered: whoever gets the slab next runs behind k_emit_gaps)
+    if (live == 0) { dfree(ctx, v->d_bits); v->d_bits = nullptr; v->n_bit = 0; }     // (stream-ordered: whoever gets the slab next runs behind k_emit_gaps_list)
     else if (live < nblocks) v->ord_lazy = true;
     return BMX_OK;
 }
@@ -1944,7 +1944,7 @@ int bmx_op2(bmx_ctx* ctx, int op, const bmx_vec* a, const bmx_vec* b, int opt_co
             // their GAP x GAP results pass the 1,276-run limit) there is nothing for the layout scan to lay out
             hipLaunchKernelGGL(fn, dim3(grid), dim3(256), 0, ctx->stream, op, a->d_desc, a->nblocks, b->d_desc, b->nblocks, nblocks, opt_compress,
                                v->d_bits, v->d_desc, st, (emit || no_gap || op == BMX_OR || op == BMX_XOR) ? FoldOut{ctx->d_slots, ctx->d_done, ctx->h_small + 2} : FoldOut{nullptr, nullptr, nullptr},
-                               emit ? offs : nullptr, ctx->d_cursor);
+                               emit ? offs : nullptr, ctx->d_cursor, emit ? offs + nblocks : nullptr);
             folded = emit || op == BMX_OR || op == BMX_XOR;                 // (with re-compression AND / SUB go straight to the layout scan, no extra synchronise)
         } else
         hipLaunchKernelGGL(k_op2, dim3((nblocks + 3) / 4), dim3(256), 0, ctx->stream, op,
@@ -2020,7 +2020,7 @@ int bmx_op2_dev(bmx_ctx* ctx, int op, const bmx_vec* a, const bmx_pending* pa, c
             const u32 grid = std::min<u32>((nblocks + 3u) / 4u, 256u * wgs);
             auto fn = (ctx->op2_nt & 1) ? k_op2_loop<4, true> : k_op2_loop<4, false>;
             hipLaunchKernelGGL(fn, dim3(grid), dim3(256), 0, ctx->stream, op, va->d_desc, va->nblocks, vb->d_desc, vb->nblocks, nblocks, 0,
-                               v->d_bits, v->d_desc, st, fo, (u32*)nullptr, ctx->d_cursor);
+                               v->d_bits, v->d_desc, st, fo, (u32*)nullptr, ctx->d_cursor, (u32*)nullptr);
         } else
             hipLaunchKernelGGL(k_op2, dim3((nblocks + 3) / 4), dim3(256), 0, ctx->stream, op, va->d_desc, va->nblocks, vb->d_desc, vb->nblocks, nblocks, 0,
                                v->d_bits, v->d_desc, st, fo);

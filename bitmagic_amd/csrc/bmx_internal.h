@@ -36,7 +36,7 @@ struct bmx_ctx {
     u64* d_slots = nullptr;                                 // COUNT_SLOTS striped count accumulators (kept zero between launches)
     u64* d_slots2 = nullptr; u32* d_done2 = nullptr;        // a second fold (slots + tickets) for kernels that fold block kinds AND a count
     u64* h_pend = nullptr; uint64_t pend_used = 0;         // 64 pinned slots (8 x u64) for the kind counts of unresolved asynchronous results
-    u32* d_cursor = nullptr;                                // bump cursor of kernels that write GAP results themselves (k_op2_loop); zero between launches
+    u64* d_cursor = nullptr;                                // bump cursor of kernels that write GAP results themselves (k_op2_loop); zero between launches
     u64* d_zero = nullptr;                                  // 256 bytes of zeros: what an invalid slot of an unconditional load reads
     u32* d_done = nullptr;                                  // workgroup ticket of the in-kernel folds (kept zero between launches)
     u64* h_small = nullptr;                                 // pinned mirror

@@ -328,7 +328,7 @@ __device__ __forceinline__ void count_fanin_fold(u32 wave_count, FoldOut f, u32 
 // packed: the wave hands over the kinds of ALL the blocks it produced (4 x 16-bit counters)
 // extra != null: a device counter the workgroups bumped before their tickets (a bump allocator's cursor): the folding
 // workgroup hands its value to out[4] and leaves it at zero for the next launch
-__device__ __forceinline__ void kind_fanin_fold_packed(u64 wave_kinds, FoldOut f, u32 lane, u32 wave, u32* extra = nullptr)
+__device__ __forceinline__ void kind_fanin_fold_packed(u64 wave_kinds, FoldOut f, u32 lane, u32 wave, u64* extra = nullptr)
 {
     __shared__ u64 wk[16];
     u32 nw = blockDim.x >> 6;
@@ -350,8 +350,8 @@ __device__ __forceinline__ void kind_fanin_fold_packed(u64 wave_kinds, FoldOut f
                 if (lane == 0) __hip_atomic_store(f.out + k, (u64)c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
             if (extra && lane == 0) {
-                const u32 cur = __hip_atomic_exchange(extra, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(f.out + 4, (u64)cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                const u64 cur = __hip_atomic_exchange(extra, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(f.out + 4, cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }
     }

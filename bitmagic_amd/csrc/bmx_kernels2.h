@@ -59,13 +59,15 @@ __device__ __forceinline__ void gap_emit_from_transitions(const Blk& t, u32 len,
 }
 
 // gap_offs != null: the producing kernel also lays the GAP candidates out -- a bump allocation of their 16-byte-padded
-// words from *gap_cursor, the offset left in gap_offs[nb] where k_emit_gaps looks for it -- so that no layout scan has to
-// run between the kernel and k_emit_gaps (the order of the blocks in the GAP slab is then the order of arrival).
+// words from *gap_cursor, the offset left in gap_offs[nb] where k_emit_gaps looks for it, the block appended to gap_list[] --
+// so that no layout scan has to run between the kernel and k_emit_gaps (the order of the blocks in the GAP slab is then the
+// order of arrival) and k_emit_gaps_list launches over the candidates only.
 template <bool SNT = false>
 __device__ __forceinline__ u32 store_result_mode(const Blk& acc, u32 nb, u32 mode,
                                                   uint4* __restrict__ slab, u64* __restrict__ desc,
                                                   BlockStat* __restrict__ st, u32 lane,
-                                                  u32* __restrict__ gap_offs = nullptr, u32* __restrict__ gap_cursor = nullptr)
+                                                  u32* __restrict__ gap_offs = nullptr, u64* __restrict__ gap_cursor = nullptr,
+                                                  u32* __restrict__ gap_list = nullptr)
 {
     Blk t;
     u32 pop = wave_sum(blk_lane_popcount(acc));
@@ -92,8 +94,12 @@ __device__ __forceinline__ u32 store_result_mode(const Blk& acc, u32 nb, u32 mod
     if (lane == 0) {
         st[nb] = BlockStat{pop, runs, first, kind};
         desc[nb] = (kind == K_BIT) ? DESC_MAKE(slot, K_BIT) : DESC_MAKE(0, kind == K_GAP ? K_NULL : kind);
-        if (kind == K_GAP && gap_offs)
-            gap_offs[nb] = __hip_atomic_fetch_add(gap_cursor, (runs + 1u + 7u) & ~7u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (kind == K_GAP && gap_offs) {
+            // one atomic for both: the low 40 bits of the cursor count padded words, the bits above count candidates
+            const u64 cur = __hip_atomic_fetch_add(gap_cursor, (1ull << 40) | (u64)((runs + 1u + 7u) & ~7u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            gap_offs[nb] = (u32)(cur & 0xFFFFFFFFFFull);
+            gap_list[(u32)(cur >> 40)] = nb;
+        }
     }
     return kind;
 }
@@ -126,6 +132,25 @@ __device__ __forceinline__ void store_trivial(u32 kind, u32 nb, u64* __restrict_
         st[nb] = BlockStat{kind == K_FULL ? 65536u : 0u, 1u, kind == K_FULL ? 1u : 0u, kind};
         desc[nb] = DESC_MAKE(0, kind);
     }
+}
+
+// GAP conversion of the parked candidates named by a list (the kernel that produced them appended them: store_result_mode)
+__global__ __launch_bounds__(256)
+void k_emit_gaps_list(const uint4* __restrict__ slab, const u32* __restrict__ list, u32 n, const BlockStat* __restrict__ st,
+                      const u32* __restrict__ offs, u16* __restrict__ gap_slab, u64* __restrict__ desc)
+{
+    u32 lane = lane_id();
+    u32 i = uniform32(blockIdx.x * 4u + (threadIdx.x >> 6));
+    if (i >= n) return;
+    const u32 nb = uniform32(list[i]);
+    Blk b, t;
+    blk_load(b, as_gc4(slab + (size_t)nb * 512u), lane);
+    (void)blk_transitions(b, t, lane);
+    u16* g = gap_slab + offs[nb];
+    u32 len = uniform32(st[nb].runs);
+    u32 first = uniform32(st[nb].first);
+    gap_emit_from_transitions(t, len, first, g, lane);
+    if (lane == 0) desc[nb] = DESC_MAKE_GAP(g, len, first);
 }
 
 // GAP conversion of the parked candidates
@@ -429,7 +454,7 @@ template <int WAVES, bool NT>
 __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4)))
 void k_op2_loop(int op, const u64* __restrict__ da, u32 na, const u64* __restrict__ db, u32 nbk, u32 nblocks, int opt_compress,
                 uint4* __restrict__ slab, u64* __restrict__ desc, BlockStat* __restrict__ st, FoldOut kinds,
-                u32* __restrict__ gap_offs, u32* __restrict__ gap_cursor)
+                u32* __restrict__ gap_offs, u64* __restrict__ gap_cursor, u32* __restrict__ gap_list)
 {
     // gap_offs != null: this kernel lays the GAP candidates out itself (bump allocation from *gap_cursor, offsets in gap_offs[];
     // the last workgroup of the fold hands the cursor to kinds.out[4] and leaves it at zero): no layout scan before k_emit_gaps
@@ -455,7 +480,7 @@ void k_op2_loop(int op, const u64* __restrict__ da, u32 na, const u64* __restric
             op2_finish(a, x, l, lane);
             op2_finish(b, y, l, lane);
             blk_op(op, x, y);
-            kind = store_result_mode<true>(x, c, op2_store_mode(op, ka, kb, opt_compress), slab, desc, st, lane, gap_offs, gap_cursor);
+            kind = store_result_mode<true>(x, c, op2_store_mode(op, ka, kb, opt_compress), slab, desc, st, lane, gap_offs, gap_cursor, gap_list);
         }
         kc += 1ull << (16u * kind);
     }
