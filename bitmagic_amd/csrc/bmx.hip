@@ -1987,6 +1987,7 @@ int bmx_op2_dev(bmx_ctx* ctx, int op, const bmx_vec* a, const bmx_pending* pa, c
     const bmx_vec* va = a ? a : pa->v; const bmx_vec* vb = b ? b : pb->v;
     const uint32_t nblocks = std::max(va->nblocks, vb->nblocks);
     const uint64_t nbits = std::max(va->nbits, vb->nbits);
+    if (nblocks > 2000000u) { g_last_error = "bmx_op2_dev: more than 2,000,000 blocks (the in-kernel fold of the kind counts holds 64 x 65,535): use bmx_op2"; return BMX_ERR_RANGE; }
     int slot = -1;
     for (int i = 0; i < 64; ++i) if (!(ctx->pend_used >> i & 1ull)) { slot = i; break; }
     if (slot < 0) { g_last_error = "bmx_op2_dev: 64 unresolved results are outstanding (bmx_pending_wait / bmx_pending_free them)"; return BMX_ERR_RANGE; }
