@@ -78,7 +78,7 @@ int bmx_ctx_synchronize(bmx_ctx* ctx);
 /* launch-shape knobs of the counts pipeline (results never depend on them; 0 / -1 = automatic):
  * "pipe_rows" 0|8|4|2|1 (KiB of a block per work item), "pipe_unroll" 0|1|2|4|8|16, "pipe_nt" 0|1,
  * "pipe_wg" 0|64..1024 (multiples of 64; the default build carries 256, 384, 512, 640, 768), "pipe_staged" -1|0|1, "pipe_slots" 8|16,
- * "pipe_window" -1|0|N (block columns per launch), "pipe_split" -1|0|1, "direct_cols" 0..N (one-launch aggregation over small collections), "ff_window" -1|0|N (first launch window of find_first_and_sub), "pair_stream" -1|0|2|4|8 and "pair_wgs" 1..8 (shape of the streaming pairwise count kernel), "pair_loop" -1|0|1..5 and "pair_nt" 0|1 (persistent pairwise count kernel for mixed block kinds: workgroups per CU, non-temporal loads), "eq_big_shape" 0|1|2, "gap_count" -1|0|1 (counting formulation for GAP-only counts pipelines), "range_halves" 0|1 (comparison search in half-block passes), "rs_lanes" 0|2|4|8 (lanes per rank query), "rs_lines" 0|1|2 (build_rs_index also lays the vector out as rank lines: one 128-byte line per rank query), "rs_select_lines" 0|1|2 (select through the block index | the lines + octant directory | the select directory over the lines) and "rs_sdir_shift" 0|6..20 (log2 of the ones per select-directory entry; 0 = an entry per ~10 lines), "gap_pack" -1|0|1 (packed collections, see below), "eq_big" -1|0|1 (table form of bmx_slice_eq_counts), "op2_wgs" 1..8 and "op2_nt" 0..3 (streaming bit_and/or/xor/sub kernel: workgroups per CU; bit 0 / 1 = non-temporal loads / stores), "or_tile" 0..3, "xcd_swizzle" 0|1.  Environment twins (BMX_PIPE_ROWS, ...) pass the same checks. */
+ * "pipe_window" -1|0|N (block columns per launch), "pipe_split" -1|0|1, "direct_cols" 0..N (one-launch aggregation over small collections), "ff_window" -1|0|N (first launch window of find_first_and_sub), "pair_stream" -1|0|2|4|8 and "pair_wgs" 1..8 (shape of the streaming pairwise count kernel), "pair_loop" -1|0|1..5 and "pair_nt" 0|1 (persistent pairwise count kernel for mixed block kinds: workgroups per CU, non-temporal loads), "eq_big_shape" 0|1|2, "gap_count" -1|0|1 (counting formulation for GAP-only counts pipelines), "range_halves" 0|1 (comparison search in half-block passes), "rs_lanes" 0|2|4|8 (lanes per rank query), "rs_lines" 0|1|2 (build_rs_index also lays the vector out as rank lines: one 128-byte line per rank query), "rs_select_lines" 0|1|2 (select through the block index | the lines + octant directory | the select directory over the lines) and "rs_sdir_shift" 0|6..20 (log2 of the ones per select-directory entry; 0 = an entry per ~10 lines), "gap_pack" -1|0|1 (packed collections, see below), "eq_big" -1|0|1 (table form of bmx_slice_eq_counts), "op2_wgs" 1..8 and "op2_nt" 0..3 (streaming bit_and/or/xor/sub kernel: workgroups per CU; bit 0 / 1 = non-temporal loads / stores), "op2_loop" -1|0|1..8 (persistent bit_and/or/xor/sub kernel for mixed block kinds: workgroups per CU), "or_rows" -1|0|1 and "or_depth" 4|8 (combine_or over >= 64 sparse GAP-only operands through the vectors' tile directories: automatic | never | always; rows in flight per wave), "coll_members" -1|0|1 (lists that are SOME vectors of a prepared collection: the member directory automatic | never | whenever covered), "or_tile" 0..3, "xcd_swizzle" 0|1.  Environment twins (BMX_PIPE_ROWS, ...) pass the same checks. */
 int bmx_ctx_set_tuning(bmx_ctx* ctx, const char* key, int value);
 /* The context keeps freed device blocks in a size-keyed cache (results of same-shaped
  * operations re-use them instead of paying hipMalloc/hipFree, which synchronises the
