@@ -1,4 +1,5 @@
 #!/bin/bash
+# round 4, run ab: configs[1] at 1 % with k_op2_loop laying its GAP candidates out (bench + rocprofv3 --stats), pairwise / op2 tests, soak part C
 export TMPDIR=/tmp
 O=gpurun_out/${1:-r04ab}; rm -rf $O; mkdir -p $O
 timeout 600 python bench.py --config 1 --density-q16 655 --no-cpu > $O/bench_c1_1pct_plain.json 2>> $O/err.txt

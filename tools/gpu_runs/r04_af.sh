@@ -1,4 +1,5 @@
 #!/bin/bash
+# round 4, run af: the asynchronous entry (bmx_op2_dev): its tests and the configs[1] lines with materialised_async_ms_per_op
 export TMPDIR=/tmp
 O=gpurun_out/${1:-r04af}; rm -rf $O; mkdir -p $O
 timeout 900 python -m pytest tests -q -m gpu -x -k "async_pairwise or pairwise or golden_case" > $O/pytest_sel.txt 2>&1; echo "rc $?" >> $O/pytest_sel.txt; tail -12 $O/pytest_sel.txt

@@ -1,4 +1,5 @@
 #!/bin/bash
+# round 4, run ah: k_emit_gaps_list (GAP candidates named by a list): pairwise tests, soak, per-op host-call times
 export TMPDIR=/tmp
 O=gpurun_out/${1:-r04ah}; rm -rf $O; mkdir -p $O
 timeout 900 python -m pytest tests -q -m gpu -x -k "pairwise or op2 or stress or golden or random_block or async" > $O/pytest_sel.txt 2>&1; echo "rc $?" >> $O/pytest_sel.txt; tail -3 $O/pytest_sel.txt

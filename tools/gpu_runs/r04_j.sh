@@ -1,4 +1,5 @@
 #!/bin/bash
+# round 4, run j: bmx_collection_prepare kernel by kernel (rocprofv3 --stats over tools/prof_prepare.py; profiles/r04_coll/kernel_stats_prepare.csv)
 export TMPDIR=/tmp
 O=gpurun_out/${1:-r04j}; rm -rf $O; mkdir -p $O
 timeout 600 rocprofv3 --kernel-trace --stats -d $O/p -o x -f csv -- python tools/prof_prepare.py > $O/out.txt 2> $O/err.txt

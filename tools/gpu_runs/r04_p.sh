@@ -1,4 +1,5 @@
 #!/bin/bash
+# round 4, run p: select against lanes per query x select-directory granularity (profiles/r04_select)
 export TMPDIR=/tmp
 O=gpurun_out/${1:-r04p}; mkdir -p $O
 for lanes in 2 4; do for sh in 0 11 12; do
