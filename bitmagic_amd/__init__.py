@@ -892,6 +892,10 @@ class group:
         check(lib().bmx_group_size(self._h, C.byref(n)))
         return n.value
 
+    def collection_prepare(self, vecs, role: int):
+        """bmx_gcollection_prepare: every member transposes its block range of the (sharded) vectors"""
+        check(lib().bmx_gcollection_prepare(self._h, _handles(vecs), len(vecs), role))
+
     def shard_range(self, nblocks: int, member: int) -> tuple[int, int]:
         lo, hi = C.c_uint32(), C.c_uint32()
         check(lib().bmx_group_shard_range(self._h, nblocks, member, C.byref(lo), C.byref(hi)))
@@ -902,6 +906,14 @@ class group:
             c = C.c_void_p()
             check(lib().bmx_group_ctx(self._h, m, C.byref(c)))
             check(lib().bmx_ctx_set_tuning(c, key.encode(), int(value)))
+
+    def member_pack_stats(self, member: int) -> dict:
+        """bmx_ctx_pack_stats of one member's context: the collections it holds for its block range"""
+        c = C.c_void_p()
+        check(lib().bmx_group_ctx(self._h, member, C.byref(c)))
+        n, b, ms = C.c_uint32(), C.c_uint64(), C.c_float()
+        check(lib().bmx_ctx_pack_stats(c, C.byref(n), C.byref(b), C.byref(ms)))
+        return {"collections": n.value, "bytes": b.value, "last_build_ms": ms.value}
 
     # -- byte-weighted shard borders (SURVEY section 8(e); src/bmblocks.h:556-564: NULL ranges cost nothing) --
     def set_partition(self, nblocks: int, bounds) -> None:
@@ -1094,6 +1106,14 @@ class gpipeline:
         check(lib().bmx_gpipeline_create(self.grp._h, _handles(and_list), and_n, _handles(sub_list), sub_n,
                                          len(self.groups), C.byref(h)))
         self._h = h
+        if getattr(self, "search_count_limit", None) is not None:
+            check(lib().bmx_gpipeline_set_search_count_limit(self.grp._h, self._h, min(int(self.search_count_limit), ID_MAX64)))
+
+    def set_search_count_limit(self, limit: int):
+        """pipeline::set_search_count_limit (src/bmaggregator.h:255) over shards: every member searches under the same limit"""
+        self.search_count_limit = limit
+        if self._h:
+            check(lib().bmx_gpipeline_set_search_count_limit(self.grp._h, self._h, min(int(limit), ID_MAX64)))
 
     def is_complete(self) -> bool:
         return self._h is not None

@@ -137,6 +137,8 @@ def lib() -> C.CDLL:
         "bmx_gpipeline_create": (i32, [vp, P(vp), P(u32), P(vp), P(u32), C.c_size_t, P(vp)]),
         "bmx_gpipeline_destroy": (i32, [vp, vp]),
         "bmx_gpipeline_run_counts": (i32, [vp, vp, P(u64)]),
+        "bmx_gpipeline_set_search_count_limit": (i32, [vp, vp, u64]),
+        "bmx_gcollection_prepare": (i32, [vp, P(vp), C.c_size_t, i32]),
         "bmx_gpipeline_last_ms": (i32, [vp, vp, P(C.c_float)]),
         "bmx_gpipeline_last_exchange_ms": (i32, [vp, vp, P(C.c_float)]),
         "bmx_gpipeline_operand_bytes": (i32, [vp, vp, P(u64)]),

@@ -84,6 +84,7 @@ struct bmx_gpipeline {
     u64* h_counts = nullptr;              // pinned, n x ngroups
     std::vector<hipEvent_t> ev0, ev1, ev2;
     std::vector<float> last_ms, last_xchg_ms;
+    uint64_t search_limit = ~0ull;        // pipeline::set_search_count_limit: forwarded to every member's pipeline
 };
 
 static void equal_range(uint32_t nblocks, int m, int n, uint32_t* lo, uint32_t* hi)
@@ -669,6 +670,24 @@ static int same_range(bmx_group* g, const bmx_gvec* const* src, size_t n, uint32
     return BMX_OK;
 }
 
+// bmx_collection_prepare over shards: every member transposes ITS block range of the vectors (the collection of member m
+// serves the aggregations member m runs: bmx_gagg_or / bmx_gagg_and_sub / bmx_gpipeline_* dispatch per member context)
+int bmx_gcollection_prepare(bmx_group* g, const bmx_gvec* const* vecs, size_t n, int role)
+{
+    ARGCHK(g && vecs && n >= 1);
+    uint32_t nblocks = 0xFFFFFFFFu; uint64_t nbits = 0;
+    int rc = same_range(g, vecs, n, &nblocks, &nbits); if (rc) return rc;
+    return for_each_member(g, [&](int m) -> int {
+        std::vector<const bmx_vec*> h(n);
+        for (size_t i = 0; i < n; ++i) h[i] = vecs[i]->shard[(size_t)m];
+        // a shard without a single GAP block (a member whose block range is empty or all NULL) has nothing to transpose
+        bool any_gap = false;
+        for (size_t i = 0; i < n && !any_gap; ++i) { uint32_t c[4] = {0, 0, 0, 0}; (void)bmx_vec_info(h[i], nullptr, nullptr, c, nullptr, nullptr); any_gap = c[BMX_GAP] != 0; }
+        if (!any_gap) return BMX_OK;
+        return bmx_collection_prepare(g->ctx[(size_t)m], h.data(), n, role);
+    });
+}
+
 int bmx_gagg_or(bmx_group* g, const bmx_gvec* const* src, size_t n, int opt_compress, bmx_gvec** result)
 {
     ARGCHK(g && result && (n == 0 || src));
@@ -921,10 +940,37 @@ static int gpipeline_enqueue(bmx_group* g, bmx_gpipeline* p, bool rccl)
     return BMX_OK;
 }
 
+// pipeline::set_search_count_limit over shards (src/bmaggregator.h:255,1365).  Every member runs its own windowed search with
+// the SAME limit: either some member reaches the limit on its shard alone (then the sum has), or every member returns its
+// full shard count (then the sum is the true count) -- sum >= min(limit, true count) and <= true count, the reference's
+// contract ("can find more, cannot find less"), with no exchange between the windows.
+int bmx_gpipeline_set_search_count_limit(bmx_group* g, bmx_gpipeline* p, uint64_t limit)
+{
+    ARGCHK(g && p && p->g == g);
+    for (int m = 0; m < g->n; ++m) {
+        int rc = bmx_pipeline_set_search_count_limit(g->ctx[(size_t)m], p->pipe[(size_t)m], limit);
+        if (rc) return rc;
+    }
+    p->search_limit = limit == 0 ? ~0ull : limit;
+    return BMX_OK;
+}
+
 int bmx_gpipeline_run_counts(bmx_group* g, bmx_gpipeline* p, uint64_t* counts_out)
 {
     ARGCHK(g && p && p->g == g && counts_out);
     const size_t ng = p->ngroups;
+    if (p->search_limit != ~0ull) {
+        // under a limit the members run their windowed (synchronous) searches side by side on the group's workers; counts are
+        // summed on the host (8 bytes per arg-group and member)
+        std::vector<uint64_t> part((size_t)g->n * std::max<size_t>(ng, 1), 0);
+        int rc = for_each_member(g, [&](int m) -> int {
+            return bmx_pipeline_run_counts(g->ctx[(size_t)m], p->pipe[(size_t)m], 0u, 0xFFFFFFFFu, part.data() + (size_t)m * ng);
+        });
+        if (rc) return rc;
+        for (size_t k = 0; k < ng; ++k) { uint64_t t = 0; for (int m = 0; m < g->n; ++m) t += part[(size_t)m * ng + k]; counts_out[k] = t; }
+        for (int m = 0; m < g->n; ++m) { p->last_ms[(size_t)m] = 0.f; p->last_xchg_ms[(size_t)m] = 0.f; }
+        return BMX_OK;
+    }
     const bool rccl = (g->flags & BMX_GROUP_RCCL) && !g->comm.empty();
     int rc = gpipeline_enqueue(g, p, rccl);
     if (rc) { std::string keep = bmx_last_error(); (void)sync_all(g); bmx_set_last_error(keep.c_str()); return rc; }

@@ -445,6 +445,13 @@ int bmx_gpipeline_create(bmx_group* g,
                          size_t ngroups, bmx_gpipeline** out);
 int bmx_gpipeline_destroy(bmx_group* g, bmx_gpipeline* p);
 int bmx_gpipeline_run_counts(bmx_group* g, bmx_gpipeline* p, uint64_t* counts_out);
+/* pipeline::set_search_count_limit over shards (src/bmaggregator.h:255,1365): every member searches its shard under the same
+ * limit (ascending launch windows, see bmx_pipeline_set_search_count_limit), the counts are summed: counts_out[g] is
+ * >= min(limit, the group's true count) and <= the true count.  limit 0 / UINT64_MAX = no limit. */
+int bmx_gpipeline_set_search_count_limit(bmx_group* g, bmx_gpipeline* p, uint64_t limit);
+/* bmx_collection_prepare over shards: member m transposes its block range of the vectors; the aggregations and pipelines of
+ * the group then use it member by member (roles as BMX_ROLE_*) */
+int bmx_gcollection_prepare(bmx_group* g, const bmx_gvec* const* vecs, size_t n, int role);
 /* per-member device time of the last bmx_gpipeline_run_counts (HIP events on the member streams), ms[n] */
 int bmx_gpipeline_last_ms(bmx_group* g, const bmx_gpipeline* p, float* ms);
 /* per-member device time between the end of the kernel and the end of the exchange (RCCL all-reduce, or the 8-byte

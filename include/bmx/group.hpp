@@ -186,6 +186,15 @@ inline size_type count_or(const gbvector& a, const gbvector& b) { return detail:
 inline size_type count_xor(const gbvector& a, const gbvector& b) { return detail::gcount_op(BMX_XOR, a, b); }
 inline size_type count_sub(const gbvector& a, const gbvector& b) { return detail::gcount_op(BMX_SUB, a, b); }
 
+/// bmx_gcollection_prepare: every member of the group transposes its block range of the vectors into a packed collection
+/// (role BMX_ROLE_OR / BMX_ROLE_AND / BMX_ROLE_SUB); the group's aggregations and pipelines over those vectors then use it
+inline void collection_prepare(device_group& g, const std::vector<const gbvector*>& vecs, int role)
+{
+    std::vector<const bmx_gvec*> h(vecs.size());
+    for (size_t i = 0; i < vecs.size(); ++i) h[i] = vecs[i]->handle();
+    check(bmx_gcollection_prepare(g.handle(), h.data(), h.size(), role));
+}
+
 /// bm::aggregator<BV> over sharded vectors: the overload of bmx::aggregator that takes a device group
 template <>
 class aggregator<gbvector> {
@@ -230,6 +239,13 @@ public:
             }
             check(bmx_gpipeline_create(grp_->handle(), al.data(), an.data(), sl.data(), sn.data(), groups_.size(), &h_));
             counts_.assign(groups_.size(), 0);
+            if (limit_ != ~0ull) check(bmx_gpipeline_set_search_count_limit(grp_->handle(), h_, limit_));
+        }
+        /// pipeline::set_search_count_limit (src/bmaggregator.h:255): every member searches its shard under the same limit
+        void set_search_count_limit(size_type limit)
+        {
+            limit_ = limit;
+            if (h_) check(bmx_gpipeline_set_search_count_limit(grp_->handle(), h_, limit_));
         }
         const std::vector<size_type>& get_bv_count_vector() const noexcept { return counts_; }
         /// device time each member spent in the last run (HIP events), ms
@@ -240,6 +256,7 @@ public:
         std::vector<arg_groups*> groups_;
         std::vector<size_type> counts_;
         bmx_gpipeline* h_ = nullptr;
+        uint64_t limit_ = ~0ull;
     };
 
     explicit aggregator(device_group& g) : grp_(&g) {}

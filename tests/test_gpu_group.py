@@ -295,6 +295,53 @@ def test_byte_weighted_shard_borders(ctx, port):
     grp.close()
 
 
+@pytest.mark.parametrize("members", [1, 3])
+def test_group_prepared_collections_and_search_limit(port, members):
+    """round 4 over shards: bmx_gcollection_prepare (every member transposes its block range; aggregations and pipelines of the
+    group then use the collections member by member) and bmx_gpipeline_set_search_count_limit (every member under the same
+    limit: the sum is >= min(limit, true) and <= true): results = the oracle's, = the group without collections / without a limit"""
+    import test_gpu_parity as P
+    rng = np.random.default_rng(31 + members)
+    nblk = 23
+    nbits = nblk * 65536 - 777
+    words = P._sparse_collection(port, rng, 90, nbits, 40, long_runs=True, ragged=False, specials=True)
+    pv = [port.import_words(w, True, nbits) for w in words]
+    assert all(p.flatten()[0].tolist().count(2) == 0 for p in pv)
+    grp = bm.group([0] * members)
+    try:
+        gv = [bm.gbvector.from_block_table(grp, nbits, *p.flatten()) for p in pv]
+        agg = bm.gaggregator(grp)
+        grp.collection_prepare(gv, bm.ROLE_OR); grp.collection_prepare(gv, bm.ROLE_AND)
+        for m in range(members):
+            assert grp.member_pack_stats(m)["collections"] in (0, 2)           # (0: a member whose shard holds no GAP block)
+        assert sum(grp.member_pack_stats(m)["collections"] for m in range(members)) >= 2
+        nw = nblk * 2048
+        for sel in (list(range(90)), rng.choice(90, size=40, replace=False).tolist(), list(range(89, 20, -1))):
+            o = agg.combine_or([gv[i] for i in sel]); e = port.agg_or([pv[i] for i in sel], False)
+            assert o.count() == e.count() and o.block_table()[0].tolist() == e.flatten()[0].tolist()
+            t, any_ = agg.combine_and_sub([gv[i] for i in sel[:8]], [gv[i] for i in sel[8:]])
+            e = port.agg_and_sub([pv[i] for i in sel[:8]], [pv[i] for i in sel[8:]])
+            assert t.count() == e.count() and any_ == (e.count() > 0) and t.block_table()[0].tolist() == e.flatten()[0].tolist()
+        groups = [(rng.choice(90, size=int(rng.integers(1, 40)), replace=False).tolist(), rng.choice(90, size=int(rng.integers(0, 50)), replace=False).tolist()) for _ in range(12)]
+        groups = [(a, [i for i in s_ if i not in a]) for a, s_ in groups]
+        def run(limit):
+            pipe = bm.gaggregator.pipeline(grp)
+            for a, s_ in groups:
+                ag = pipe.add()
+                for i in a: ag.add(gv[i], 0)
+                for i in s_: ag.add(gv[i], 1)
+            if limit is not None: pipe.set_search_count_limit(limit)
+            pipe.complete()
+            return [int(x) for x in agg.combine_and_sub(pipe)]
+        true = [int(x) for x in port.pipeline_counts([([pv[i] for i in a], [pv[i] for i in s_]) for a, s_ in groups])]
+        assert run(None) == true
+        for limit in (1, 25, max(true) + 1):
+            got = run(limit)
+            assert all(min(limit, t) <= x <= t for x, t in zip(got, true)), (limit, got, true)
+    finally:
+        grp.close()
+
+
 def test_group_workers_persist_across_calls(port):
     """the materialising group calls run on persistent per-member workers: many calls, same results, errors carried over"""
     nbits = 10 * 65536
