@@ -765,7 +765,6 @@ def run_pairwise(args, env, dq=None, quick=False):
         ia, ib = a.info(), b.info()
         pair_bytes.append(a.operand_bytes() + b.operand_bytes())            # 8,192 B per bit-block + 2 x (len + 1) per GAP block
     dcnt = torch.zeros(4 * npairs, dtype=torch.int64, device="cuda")
-    all_bit_pairs = all(v.info()["counts"][bm.GAP] == 0 for v in va + vb)
     per_op = {}
     mat0 = []
     for op, name in enumerate(["and", "or", "xor", "sub"]):
@@ -787,9 +786,9 @@ def run_pairwise(args, env, dq=None, quick=False):
         per_op[name]["materialised_host_call_ms"] = round(host_ms, 4)
         per_op[name]["materialised_GBps"] = round((pair_bytes[-1] + out_blocks * 8192) / host_ms / 1e6, 1)
         keep.clear()
-        # the same operations through the asynchronous entry (bmx_op2_dev: operands without GAP blocks): every pair enqueued, ONE wait
-        # per sweep -- what a caller that chains / batches operations pays per operation
-        if all_bit_pairs:
+        # the same operations through the asynchronous entry (bmx_op2_dev): every pair enqueued, ONE wait per sweep -- what a caller
+        # that chains / batches operations pays per operation
+        if True:
             def mat_async(op=op):
                 ps = [bm.bvector.op2_async(op, va[i], vb[i]) for i in range(npairs)]
                 return [p.wait() for p in ps]

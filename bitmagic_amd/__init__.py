@@ -212,8 +212,8 @@ class bvector:
 
     @staticmethod
     def op2_async(op, a, b) -> "pending":
-        """bmx_op2_dev: the three-operand operation (opt_none) enqueued on the context's stream; a / b are vectors without GAP
-        blocks or unresolved results of earlier op2_async calls; -> pending (wait() gives the vector)"""
+        """bmx_op2_dev: the three-operand operation (opt_none) enqueued on the context's stream; a / b are vectors (any block
+        kinds) or unresolved results of earlier op2_async calls; -> pending (wait() gives the vector)"""
         ctx = a.ctx
         h = C.c_void_p()
         av, ap = (a._h, None) if isinstance(a, bvector) else (None, a._h)

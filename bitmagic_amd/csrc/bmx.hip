@@ -1982,7 +1982,11 @@ int bmx_op2_dev(bmx_ctx* ctx, int op, const bmx_vec* a, const bmx_pending* pa, c
     ARGCHK(ctx && out && op >= BMX_AND && op <= BMX_SUB && ((a != nullptr) != (pa != nullptr)) && ((b != nullptr) != (pb != nullptr)));
     *out = nullptr;
     ARGCHK((!a || a->ctx == ctx) && (!b || b->ctx == ctx) && (!pa || pa->ctx == ctx) && (!pb || pb->ctx == ctx));
-    if ((a && a->counts[BMX_GAP]) || (b && b->counts[BMX_GAP])) { g_last_error = "bmx_op2_dev takes operands without GAP blocks (bmx_op2 handles every kind)"; return BMX_ERR_BADARG; }
+    // operands that may hold GAP blocks: the result may hold GAP blocks too -- at most the operands' GAP words together
+    // (a copied GAP block, a GAP x GAP result of at most len(a) + len(b) runs) -- so its GAP slab is allocated at that bound,
+    // the kernel lays the candidates out itself and k_emit_gaps converts them right behind it: the descriptors are complete
+    // on the stream and the result can be an operand at once; bmx_pending_wait trims the slab
+    const uint64_t gap_bound = (a ? (a->counts[BMX_GAP] ? a->gap_words : 0) : pa->gap_bound) + (b ? (b->counts[BMX_GAP] ? b->gap_words : 0) : pb->gap_bound);
     int rc = set_dev(ctx); if (rc) return rc;
     const bmx_vec* va = a ? a : pa->v; const bmx_vec* vb = b ? b : pb->v;
     const uint32_t nblocks = std::max(va->nblocks, vb->nblocks);
@@ -1993,13 +1997,24 @@ int bmx_op2_dev(bmx_ctx* ctx, int op, const bmx_vec* a, const bmx_pending* pa, c
     if (slot < 0) { g_last_error = "bmx_op2_dev: 64 unresolved results are outstanding (bmx_pending_wait / bmx_pending_free them)"; return BMX_ERR_RANGE; }
     bmx_pending* p = new (std::nothrow) bmx_pending();
     if (!p) return BMX_ERR_BADALLOC;
-    p->ctx = ctx; p->v = nullptr; p->slot = slot; p->ev = nullptr;
+    p->ctx = ctx; p->v = nullptr; p->slot = slot; p->ev = nullptr; p->gap_bound = 0; p->scratch = nullptr;
     bmx_vec* v; BlockStat* st; u32* offs;
     if ((rc = result_begin(ctx, nbits, nblocks, &v, &st, &offs))) { delete p; return rc; }
+    u16* gap_slab = nullptr;
+    if (gap_bound && nblocks) {
+        // this result's own st[] / offs[] / candidate list (the context's scratch is the next operation's) and its GAP slab
+        const uint64_t bound = gap_bound + 8u;
+        if ((rc = dmalloc(ctx, &p->scratch, (size_t)nblocks * (sizeof(BlockStat) + 8) + 64)) || (rc = dmalloc(ctx, (void**)&gap_slab, (size_t)bound * 2 + 64))) {
+            dfree(ctx, p->scratch); bmx_vec_free(ctx, v); delete p; return rc;
+        }
+        st = (BlockStat*)p->scratch; offs = (u32*)((char*)p->scratch + (size_t)nblocks * sizeof(BlockStat));
+        v->d_gaps = gap_slab; v->gap_words = bound; v->bytes += (size_t)bound * 2 + 64;
+        p->gap_bound = bound;
+    }
     u64* hs = ctx->h_pend + (size_t)slot * 8;
     for (int k = 0; k < 8; ++k) hs[k] = 0;
     hipError_t e = hipEventCreateWithFlags(&p->ev, hipEventDisableTiming);
-    if (e != hipSuccess) { bmx_vec_free(ctx, v); delete p; return fail_hip(e, "hipEventCreate", __LINE__); }
+    if (e != hipSuccess) { dfree(ctx, p->scratch); bmx_vec_free(ctx, v); delete p; return fail_hip(e, "hipEventCreate", __LINE__); }
     const FoldOut fo{ctx->d_slots, ctx->d_done, hs};
     const bool same = (a && b && a == b) || (pa && pb && pa == pb);
     if (!nblocks) hs[BMX_NULL] = 0;
@@ -2009,7 +2024,14 @@ int bmx_op2_dev(bmx_ctx* ctx, int op, const bmx_vec* a, const bmx_pending* pa, c
     } else {
         const bool stream = a && b && ctx->pair_stream != 0 && a->nblocks == b->nblocks && a->counts[BMX_BIT] == nblocks &&
                             b->counts[BMX_BIT] == nblocks && nblocks >= 2048u;
-        if (stream) {
+        if (gap_slab) {
+            const u32 wgs = (u32)(ctx->op2_loop > 0 ? ctx->op2_loop : 4);
+            const u32 grid = std::min<u32>((nblocks + 3u) / 4u, 256u * wgs);
+            auto fn = (ctx->op2_nt & 1) ? k_op2_loop<4, true> : k_op2_loop<4, false>;
+            hipLaunchKernelGGL(fn, dim3(grid), dim3(256), 0, ctx->stream, op, va->d_desc, va->nblocks, vb->d_desc, vb->nblocks, nblocks, 0,
+                               v->d_bits, v->d_desc, st, fo, offs, ctx->d_cursor, offs + nblocks);
+            hipLaunchKernelGGL(k_emit_gaps, dim3((nblocks + 3) / 4), dim3(256), 0, ctx->stream, v->d_bits, nblocks, st, offs, gap_slab, v->d_desc);
+        } else if (stream) {
             const u32 waves = 4u, total = 256u * waves * (u32)std::max(ctx->op2_wgs, 1);
             const u32 per_wave = (nblocks + total - 1u) / total;
             const u32 grid = ((nblocks + per_wave - 1u) / per_wave + waves - 1u) / waves;
@@ -2028,7 +2050,7 @@ int bmx_op2_dev(bmx_ctx* ctx, int op, const bmx_vec* a, const bmx_pending* pa, c
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipEventRecord(p->ev, ctx->stream);
-    if (e != hipSuccess) { (void)hipStreamSynchronize(ctx->stream); (void)hipEventDestroy(p->ev); bmx_vec_free(ctx, v); delete p; return fail_hip(e, "bmx_op2_dev", __LINE__); }
+    if (e != hipSuccess) { (void)hipStreamSynchronize(ctx->stream); (void)hipEventDestroy(p->ev); dfree(ctx, p->scratch); bmx_vec_free(ctx, v); delete p; return fail_hip(e, "bmx_op2_dev", __LINE__); }
     ctx->pend_used |= 1ull << slot;
     p->v = v;
     *out = p;
@@ -2045,12 +2067,34 @@ int bmx_pending_wait(bmx_ctx* ctx, bmx_pending* p, bmx_vec** out)
     const u64* hs = ctx->h_pend + (size_t)p->slot * 8;
     const uint32_t nblocks = v->nblocks;
     for (int k = 0; k < 4; ++k) v->counts[k] = (uint32_t)hs[k];
-    const bool ok = (uint64_t)v->counts[0] + v->counts[1] + v->counts[2] + v->counts[3] == nblocks && v->counts[BMX_GAP] == 0;
+    const uint64_t used = hs[4] & 0xFFFFFFFFFFull, ncand = hs[4] >> 40, bound = p->gap_bound;
+    const bool ok = (uint64_t)v->counts[0] + v->counts[1] + v->counts[2] + v->counts[3] == nblocks && ncand == v->counts[BMX_GAP] &&
+                    used <= bound && (used == 0) == (ncand == 0);
     ctx->pend_used &= ~(1ull << p->slot);
     (void)hipEventDestroy(p->ev);
+    dfree(ctx, p->scratch);                                           // (k_emit_gaps, which read it, ran before the event)
     p->v = nullptr;
     delete p;
     if (!ok) { (void)hipStreamSynchronize(ctx->stream); bmx_vec_free(ctx, v); g_last_error = "bmx_pending_wait: inconsistent fold of the result block kinds"; return BMX_ERR_DEVICE; }
+    if (bound) {
+        // the GAP slab was allocated at the operands' bound: give it back when nothing landed in it, move the data into a slab of
+        // its own size when the bound is far off (a copy and a descriptor rebase, enqueued)
+        v->bytes -= std::min<size_t>(v->bytes, (size_t)bound * 2 + 64);
+        if (!used) { dfree(ctx, v->d_gaps); v->d_gaps = nullptr; v->gap_words = 0; }
+        else if (bound > 2 * used + 4096) {
+            u16* small_ = nullptr;
+            if ((rc = dmalloc(ctx, (void**)&small_, (size_t)used * 2 + 64))) { bmx_vec_free(ctx, v); return rc; }
+            hipError_t e = hipMemcpyAsync(small_, v->d_gaps, (size_t)used * 2, hipMemcpyDeviceToDevice, ctx->stream);
+            if (e == hipSuccess) {
+                hipLaunchKernelGGL(k_rebase_desc, dim3((nblocks + 255) / 256), dim3(256), 0, ctx->stream, (const u64*)v->d_desc, v->d_desc, nblocks,
+                                   (u64)(uintptr_t)v->d_bits, (u64)(uintptr_t)v->d_bits, (u64)(uintptr_t)v->d_gaps, (u64)(uintptr_t)small_);
+                e = hipGetLastError();
+            }
+            if (e != hipSuccess) { (void)hipStreamSynchronize(ctx->stream); dfree(ctx, small_); bmx_vec_free(ctx, v); return fail_hip(e, "bmx_pending_wait (GAP slab)", __LINE__); }
+            dfree(ctx, v->d_gaps);
+            v->d_gaps = small_; v->gap_words = used; v->bytes += (size_t)used * 2 + 64;
+        } else { v->gap_words = used; v->bytes += (size_t)bound * 2 + 64; }
+    }
     // the slab, as result_finish treats it: nothing alive -> back to the pool; sparse -> the survivors into a right-sized slab
     // (ordinals from the descriptor table; enqueued, not waited for); nearly full -> kept, ordinals at the first download
     const uint32_t live = v->counts[BMX_BIT];
@@ -2079,6 +2123,7 @@ int bmx_pending_free(bmx_ctx* ctx, bmx_pending* p)
     (void)hipEventSynchronize(p->ev);
     (void)hipEventDestroy(p->ev);
     ctx->pend_used &= ~(1ull << p->slot);
+    dfree(ctx, p->scratch);
     int rc = p->v ? bmx_vec_free(ctx, p->v) : BMX_OK;
     delete p;
     return rc;

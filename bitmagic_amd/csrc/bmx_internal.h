@@ -158,6 +158,8 @@ struct bmx_pending {
     bmx_vec* v;
     int slot;
     hipEvent_t ev;
+    uint64_t gap_bound;       // upper bound of the GAP words the result holds (0: it cannot hold a GAP block); its GAP slab has that size
+    void* scratch;            // st[] / offs[] / candidate list of the producing kernel (GAP path), until the result is resolved
 };
 
 struct bmx_rs {

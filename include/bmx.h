@@ -149,8 +149,10 @@ int bmx_op2(bmx_ctx* ctx, int op, const bmx_vec* a, const bmx_vec* b, int opt_co
  * ends -- but the counts of its block kinds, which the host needs to dispatch later operations over it; here they travel to
  * pinned memory behind the kernel and are read when the result is resolved.  Each operand is EITHER a vector (a / b) OR an
  * unresolved result of an earlier bmx_op2_dev (pa / pb) -- exactly one of each pair is non-NULL -- so a chain of operations
- * stays on the stream and pays one synchronise at its end instead of one per operation.  Operands must hold no GAP blocks
- * (then no GAP block can come out and the result needs no layout pass; BMX_ERR_BADARG otherwise: use bmx_op2).
+ * stays on the stream and pays one synchronise at its end instead of one per operation.  Operands of any block kinds: where
+ * they hold GAP blocks the result may too (at most the operands' GAP words together), so its GAP slab is allocated at that
+ * bound, the kernel lays the GAP results out itself and their conversion is enqueued right behind it -- the descriptors are
+ * complete on the stream, bmx_pending_wait trims the slab.
  *   bmx_pending_wait   waits for THIS result only, turns it into an ordinary vector (*out; the handle is consumed)
  *   bmx_pending_free   drops an unresolved result (it may still be an operand of operations enqueued earlier)
  * At most 64 unresolved results per context and 2,000,000 blocks (1.3e11 bits) per operand (BMX_ERR_RANGE).  bmx_pending is a handle type of its own: no other entry point

@@ -2097,7 +2097,7 @@ def test_async_pairwise_chain(ctx, port, nblk):
     GAP blocks or unresolved results) give the oracle's bits AND block kinds after one wait at the end -- the streaming kernel
     (two all-bit-block vectors), the persistent and the wave-per-column kernels (operands with NULL / FULL blocks, unresolved
     operands, different lengths), results that come out empty or sparse (compacted at the wait), an operand used twice,
-    waiting out of order, dropping an unresolved result; GAP operands and other entry points refuse"""
+    waiting out of order, dropping an unresolved result; chains over operands WITH GAP blocks (results with GAP blocks as operands)"""
     rng = np.random.default_rng(nblk)
     def build(seed, dq, nb, holes):
         w = port.gen_words(777, seed, dq, nb * 65536)
@@ -2136,10 +2136,26 @@ def test_async_pairwise_chain(ctx, port, nblk):
     # dropping an unresolved result that later operations read; GAP operands are refused
     d1 = bm.bvector.op2_async(bm.OR, gv[0], gv[2]); d2 = bm.bvector.op2_async(bm.AND, d1, gv[1]); del d1
     assert same(d2.wait(), port.op2(bm.AND, port.op2(bm.OR, pv[0], pv[2], False), pv[1], False))
-    gapv = bm.bit_import_u32(ctx, port.gen_words(777, 9, 13, nblk * 65536), True)
-    if gapv.calc_stat()["gap_blocks"]:
-        with pytest.raises(bm.BmxError):
-            bm.bvector.op2_async(bm.AND, gapv, gv[0])
+    # operands WITH GAP blocks (sparse, mixed 1 %, long runs): the results hold GAP blocks too -- laid out by the kernel, converted
+    # right behind it, usable as operands at once; kinds and bits = the oracle's for every link
+    mw = [port.gen_words(777, 20, 13, nblk * 65536), port.gen_words(777, 21, 655, nblk * 65536), port.gen_words(777, 22, 300, nblk * 65536)]
+    mw[2][100:700] = 0xFFFFFFFF
+    mp = [port.import_words(w, True, w.size * 32) for w in mw]
+    mg = [bm.bit_import_u32(ctx, w, True) for w in mw]
+    assert sum(v.calc_stat()["gap_blocks"] for v in mg) > 0
+    q1 = bm.bvector.op2_async(bm.OR, mg[0], mg[2])                             # GAP | GAP
+    q2 = bm.bvector.op2_async(bm.AND, q1, mg[1])                               # unresolved (GAP candidates) & mixed
+    q3 = bm.bvector.op2_async(bm.SUB, mg[1], q2)
+    q4 = bm.bvector.op2_async(bm.XOR, q3, gv[0])                               # ... against a dense vector
+    q5 = bm.bvector.op2_async(bm.AND, mg[0], mg[0])                            # a vector with itself: a copy, GAP blocks stay GAP
+    f1 = port.op2(bm.OR, mp[0], mp[2], False); f2 = port.op2(bm.AND, f1, mp[1], False); f3 = port.op2(bm.SUB, mp[1], f2, False)
+    f4 = port.op2(bm.XOR, f3, pv[0], False); f5 = port.op2(bm.AND, mp[0], mp[0], False)
+    u4 = q4.wait(); u5 = q5.wait(); u1 = q1.wait(); u3 = q3.wait(); u2 = q2.wait()
+    for t, e in ((u1, f1), (u2, f2), (u3, f3), (u4, f4), (u5, f5)):
+        assert same(t, e)
+    k, o, b, g = u2.block_table()                                               # GAP data in arrival order, trimmed slab: a plain host table
+    assert bm.count_xor(bm.bvector.from_block_table(ctx, u2.info()["nbits"], k, o, b, g), u2) == 0
+    assert same(bm.bvector.bit_or(u1, u3), port.op2(bm.OR, f1, f3, False))
 
 
 def test_full_size_pairwise_and_rank_select_vs_reference_on_all_cores(ctx):
