@@ -1997,7 +1997,34 @@ int bmx_op2_dev(bmx_ctx* ctx, int op, const bmx_vec* a, const bmx_pending* pa, c
     if (slot < 0) { g_last_error = "bmx_op2_dev: 64 unresolved results are outstanding (bmx_pending_wait / bmx_pending_free them)"; return BMX_ERR_RANGE; }
     bmx_pending* p = new (std::nothrow) bmx_pending();
     if (!p) return BMX_ERR_BADALLOC;
-    p->ctx = ctx; p->v = nullptr; p->slot = slot; p->ev = nullptr; p->gap_bound = 0; p->scratch = nullptr;
+    p->ctx = ctx; p->v = nullptr; p->slot = slot; p->ev = nullptr; p->gap_bound = 0; p->scratch = nullptr; p->resolved = false;
+    if (((a && a == b) || (pa && pa == pb)) && (op == BMX_AND || op == BMX_OR)) {
+        // aliasing as the reference handles it up front (src/bm.h:6191-6195, 5984-5988): x & x, x | x are block-for-block copies,
+        // nothing is re-classified.  An unresolved operand is waited for here (its kind counts are the copy's).
+        const bmx_vec* src = a ? a : pa->v;
+        uint32_t cnt[4]; uint64_t used = src->gap_words;
+        memcpy(cnt, src->counts, sizeof(cnt));
+        if (pa && !pa->resolved) {
+            hipError_t ew = hipEventSynchronize(pa->ev);
+            if (ew != hipSuccess) { delete p; return fail_hip(ew, "bmx_op2_dev (alias)", __LINE__); }
+            const u64* ps = ctx->h_pend + (size_t)pa->slot * 8;
+            for (int k = 0; k < 4; ++k) cnt[k] = (uint32_t)ps[k];
+            used = ps[4] & 0xFFFFFFFFFFull;
+        }
+        bmx_vec* c = nullptr;
+        if ((rc = vec_clone(ctx, src, &c))) { delete p; return rc; }
+        memcpy(c->counts, cnt, sizeof(cnt));
+        c->count_valid = false;
+        if (c->d_gaps) c->gap_words = used;                                  // (an unresolved source: its slab is sized at the bound, its data end at `used`)
+        if (c->d_bits && c->n_bit == c->nblocks && cnt[BMX_BIT] < c->nblocks && !c->d_ord) c->ord_lazy = true;
+        hipError_t ee = hipEventCreateWithFlags(&p->ev, hipEventDisableTiming);
+        if (ee == hipSuccess) ee = hipEventRecord(p->ev, ctx->stream);
+        if (ee != hipSuccess) { bmx_vec_free(ctx, c); delete p; return fail_hip(ee, "bmx_op2_dev (alias)", __LINE__); }
+        p->v = c; p->resolved = true; p->gap_bound = c->d_gaps ? c->gap_words : 0;
+        ctx->pend_used |= 1ull << slot;
+        *out = p;
+        return BMX_OK;
+    }
     bmx_vec* v; BlockStat* st; u32* offs;
     if ((rc = result_begin(ctx, nbits, nblocks, &v, &st, &offs))) { delete p; return rc; }
     u16* gap_slab = nullptr;
@@ -2064,6 +2091,14 @@ int bmx_pending_wait(bmx_ctx* ctx, bmx_pending* p, bmx_vec** out)
     int rc = set_dev(ctx); if (rc) return rc;
     HIPCHK(hipEventSynchronize(p->ev));
     bmx_vec* v = p->v;
+    if (p->resolved) {
+        ctx->pend_used &= ~(1ull << p->slot);
+        (void)hipEventDestroy(p->ev);
+        p->v = nullptr;
+        delete p;
+        *out = v;
+        return BMX_OK;
+    }
     const u64* hs = ctx->h_pend + (size_t)p->slot * 8;
     const uint32_t nblocks = v->nblocks;
     for (int k = 0; k < 4; ++k) v->counts[k] = (uint32_t)hs[k];

@@ -160,6 +160,7 @@ struct bmx_pending {
     hipEvent_t ev;
     uint64_t gap_bound;       // upper bound of the GAP words the result holds (0: it cannot hold a GAP block); its GAP slab has that size
     void* scratch;            // st[] / offs[] / candidate list of the producing kernel (GAP path), until the result is resolved
+    bool resolved;            // the vector is already an ordinary one (x & x, x | x: a block-for-block copy): the wait only hands it over
 };
 
 struct bmx_rs {

@@ -153,6 +153,8 @@ int bmx_op2(bmx_ctx* ctx, int op, const bmx_vec* a, const bmx_vec* b, int opt_co
  * they hold GAP blocks the result may too (at most the operands' GAP words together), so its GAP slab is allocated at that
  * bound, the kernel lays the GAP results out itself and their conversion is enqueued right behind it -- the descriptors are
  * complete on the stream, bmx_pending_wait trims the slab.
+ * Aliased operands follow the reference's rule (src/bm.h:6191, 5984, 6081, 6412): x & x and x | x are block-for-block copies
+ * (an unresolved x is waited for), x ^ x and x - x are empty.
  *   bmx_pending_wait   waits for THIS result only, turns it into an ordinary vector (*out; the handle is consumed)
  *   bmx_pending_free   drops an unresolved result (it may still be an operand of operations enqueued earlier)
  * At most 64 unresolved results per context and 2,000,000 blocks (1.3e11 bits) per operand (BMX_ERR_RANGE).  bmx_pending is a handle type of its own: no other entry point

@@ -3,7 +3,8 @@
     upload, results of earlier operations, clones), random tile shapes, long runs, NULL / FULL blocks, ragged lengths;
 (B) k_coll_members: random subsets / pipelines over prepared collections;
 (C) k_op2_loop: materialised pairwise operations over long vectors of mixed block kinds, both optimisation modes;
-(D) pipeline::set_search_count_limit on random pipelines.
+(D) pipeline::set_search_count_limit on random pipelines;
+(E) bmx_op2_dev / bmx_pending_wait: random chains over random block tables and long mixed vectors, waits in random order.
 Usage: python tools/soak_r04.py [rounds]   (prints one FAIL line per difference, then "soak_r04 done, failures: N")"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -13,6 +14,7 @@ import oracle, bitmagic_amd as bm
 import test_gpu_parity as P
 
 ROUNDS = int(sys.argv[1]) if len(sys.argv) > 1 else 240
+ONLY = sys.argv[2] if len(sys.argv) > 2 else "ABCDE"                 # parts to run
 port = oracle.port()
 bad = 0
 
@@ -30,7 +32,7 @@ def kinds_equal(g, e):
 
 
 # ---------------------------------------------------------------- (A) row kernel
-for seed in range(ROUNDS):
+for seed in range(ROUNDS if "A" in ONLY else 0):
     rng = np.random.default_rng(410000 + seed)
     nblk = int(rng.integers(1, 48)); nvec = int(rng.integers(64, 360))
     dq = int(rng.choice([3, 13, 13, 40, 120, 260]))
@@ -77,7 +79,7 @@ for seed in range(ROUNDS):
 print("A done, failures so far:", bad, flush=True)
 
 # ---------------------------------------------------------------- (B) member directory over prepared collections
-for seed in range(max(ROUNDS // 2, 4)):
+for seed in range(max(ROUNDS // 2, 4) if "B" in ONLY else 0):
     rng = np.random.default_rng(420000 + seed)
     nblk = int(rng.integers(1, 20)); nvec = int(rng.integers(40, 300))
     dq = int(rng.choice([5, 13, 40, 150, 280]))
@@ -126,7 +128,7 @@ print("B done, failures so far:", bad, flush=True)
 
 # ---------------------------------------------------------------- (C) persistent materialising pairwise kernel
 ctx = bm.context(0)
-for seed in range(max(ROUNDS // 3, 3)):
+for seed in range(max(ROUNDS // 3, 3) if "C" in ONLY else 0):
     rng = np.random.default_rng(430000 + seed)
     nblk = int(rng.integers(2048, 2500)); nbits = nblk * 65536 - int(rng.integers(0, 60000))
     vs = []
@@ -154,7 +156,7 @@ print("C done, failures so far:", bad, flush=True)
 
 # ---------------------------------------------------------------- (D) search count limit
 agg = bm.aggregator(ctx)
-for seed in range(max(ROUNDS // 3, 3)):
+for seed in range(max(ROUNDS // 3, 3) if "D" in ONLY else 0):
     rng = np.random.default_rng(440000 + seed)
     nblk = int(rng.integers(300, 4000)); nbits = nblk * 65536
     nv = int(rng.integers(3, 9))
@@ -178,4 +180,36 @@ for seed in range(max(ROUNDS // 3, 3)):
         got, win = run(limit)
         if not all(min(limit, f) <= x <= f for x, f in zip(got, full)): fail("search limit", seed, limit, got, full, win)
     del gv
+# ---------------------------------------------------------------- (E) asynchronous chains (bmx_op2_dev / bmx_pending_wait)
+import test_gpu_stress as S
+for seed in range(max(ROUNDS // 2, 4) if "E" in ONLY else 0):
+    rng = np.random.default_rng(450000 + seed)
+    nblk = int(rng.integers(1, 30)) if seed % 4 else int(rng.integers(2048, 2200))
+    if nblk < 2048:
+        base = [S._random_vector(rng, port, ctx, nblk, bool(rng.integers(0, 2))) for _ in range(4)]
+    else:
+        base = []
+        for v in range(3):
+            w = port.gen_words(9900 + seed, v, int(rng.choice([13, 655, 6554, 40000])), nblk * 65536)
+            for _ in range(20):
+                b = int(rng.integers(0, nblk)); w[b * 2048:(b + 1) * 2048] = 0 if rng.integers(0, 2) else 0xFFFFFFFF
+            opt = bool(rng.integers(0, 4))
+            base.append((port.import_words(w, opt, w.size * 32), bm.bit_import_u32(ctx, w, opt)))
+    nw = (nblk + 1) * 2048
+    exp = [b_[0] for b_ in base]; dev = [b_[1] for b_ in base]            # dev[i]: bvector or pending
+    chain = []
+    for step in range(int(rng.integers(2, 8))):
+        i, j = (int(x) for x in rng.integers(0, len(dev), 2)); op = int(rng.integers(0, 4))
+        chain.append((op, i, j))
+        dev.append(bm.bvector.op2_async(op, dev[i], dev[j])); exp.append(port.op2(op, exp[i], exp[j], False))
+    order = [k for k in range(len(base), len(dev))]; rng.shuffle(order)
+    drop = order.pop() if len(order) > 2 and rng.integers(0, 3) == 0 else None   # one unresolved result is dropped instead of waited for
+    for k in order:
+        t = dev[k].wait(); e = exp[k]
+        okw, okk, okc = bool((t.to_words(nw) == e.to_words(nw)).all()), kinds_equal(t, e), t.count() == e.count()
+        if not (okw and okk and okc): fail("async chain", seed, k, nblk, "bits" if not okw else "", "kinds" if not okk else "", "count" if not okc else "", chain, len(base),
+                                           t.block_table()[0].tolist()[:30], e.flatten()[0].tolist()[:30])
+        dev[k] = t
+    del dev, exp, base
+print("E done, failures so far:", bad, flush=True)
 print("soak_r04 done, failures:", bad, flush=True)
