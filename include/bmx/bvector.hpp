@@ -288,7 +288,7 @@ private:
     bmx_pending* h_;
 };
 
-/// op = BMX_AND / BMX_OR / BMX_XOR / BMX_SUB over operands WITHOUT GAP blocks (vectors or unresolved results): enqueued, not waited for
+/// op = BMX_AND / BMX_OR / BMX_XOR / BMX_SUB (opt_none) over vectors of any block kinds or unresolved results: enqueued, not waited for
 inline pending bit_op_async(int op, const bvector& a, const bvector& b)
 {
     bmx_pending* p = nullptr;

@@ -54,7 +54,7 @@ int main()
         REQUIRE(u.equal(t));
         bmo_vec_free(e);
     }
-    // asynchronous chain over vectors without GAP blocks (bmx_op2_dev): ((a & b) | c) - a, one wait at the end = the synchronous result
+    // asynchronous chain (bmx_op2_dev; dense vectors here): ((a & b) | c) - a, one wait at the end = the synchronous result
     {
         std::vector<bmx::bvector> dv; std::vector<bmo_vec*> dp;
         for (unsigned v = 0; v < 3; ++v) {
