@@ -93,6 +93,23 @@ void k_coll_offsets(const u32* __restrict__ cnt, u32 ncols, u64* __restrict__ of
     if (tid == 0) off[ncols] = carry;
 }
 
+// The wanted runs of one 16-byte chunk of a GAP block, from registers (round 4: the build read every run end with a 2-byte load).
+// Chunk q holds words 8q .. 8q + 7 of the block (word 0 = header, word k = end of run k); nx = the first dword of chunk q + 1.
+// (s = 1: the block starts with a run of the wanted polarity.)  A block that starts with a 0-run (s = 0) has its 1-runs at even k: run m = (words 2m + 1, 2m + 2) -- the chunk's pairs
+// (1,2) (3,4) (5,6) (7, next 0); a block that starts with a 1-run (s = 1) at odd k: run m = (words 2m, 2m + 1) -- pairs
+// (0,1) (2,3) (4,5) (6,7), run 0 starting at bit 0.  Slot i of chunk q is run m = 4q + i, valid while m < m_cnt.
+struct CollPairs { u32 start[4], end[4]; };
+__device__ __forceinline__ void coll_chunk_pairs(const u32x4& x, u32 nx, u32 s, u32 q, CollPairs& p)
+{
+    const u32 w[9] = {x.x & 0xFFFFu, x.x >> 16, x.y & 0xFFFFu, x.y >> 16, x.z & 0xFFFFu, x.z >> 16, x.w & 0xFFFFu, x.w >> 16, nx & 0xFFFFu};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const u32 lo = s ? w[2 * i] : w[2 * i + 1], hi = s ? w[2 * i + 1] : w[2 * i + 2];
+        p.start[i] = (s && q == 0u && i == 0) ? 0u : lo + 1u;
+        p.end[i] = hi;
+    }
+}
+
 // pass 3: L lanes per (operand, column) write the block's runs of the wanted polarity behind the entries of the operands
 // before it.  grid.x = operand (adjacent workgroups fill adjacent pieces of the same columns), grid.y = tile of 256 / L columns
 template <int L>
@@ -108,15 +125,20 @@ void k_coll_scatter(const u64* const* __restrict__ descs, const u32* __restrict_
     if (DESC_K(d) != K_GAP) return;
     u32 meta = GMETA(d), len = meta >> 1, s = meta & 1u;
     u32 m_cnt = coll_runs_of(meta, polarity);
-    gcptr16 g = as_gc16(DESC_P(d));
     u32* out = runs + off[c] + (pre[(size_t)i * ncols + c] & 0x3FFFFFFFu);
-    // run k (1-based) has the value s ^ ((k - 1) & 1) and covers e[k-1]+1 .. e[k] (e[0] = -1; word k of the block = e[k])
-    u32 k0 = (s == polarity) ? 1u : 2u;
-    for (u32 m = t; m < m_cnt; m += L) {
-        u32 k = k0 + 2u * m;
-        u32 start = k == 1u ? 0u : (u32)g[k - 1u] + 1u;
-        u32 end = (u32)g[k <= len ? k : len];
-        out[m] = start | (end << 16);
+    // run k (1-based) has the value s ^ ((k - 1) & 1) and covers e[k-1]+1 .. e[k] (e[0] = -1; word k of the block = e[k]): the
+    // wanted runs are every second one from k = 1 (the block starts with a wanted run) or k = 2; lane t takes chunks t, t + L, ...
+    // as 16-byte loads (coll_chunk_pairs below), run m lands in out[m]
+    const u32 s_eff = s == polarity ? 1u : 0u;
+    const u32 nchunks = (len + 1u + 7u) >> 3;
+    gcptr4 g4 = as_gc4(DESC_P(d));
+    for (u32 q = t; q < nchunks; q += (u32)L) {
+        const u32x4 x = g4[q];
+        const u32 nx = q + 1u < nchunks ? g4[q + 1u].x : 0xFFFFFFFFu;
+        CollPairs p;
+        coll_chunk_pairs(x, nx, s_eff, q, p);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (4u * q + (u32)k < m_cnt) out[4u * q + (u32)k] = p.start[k] | (p.end[k] << 16);
     }
 }
 
@@ -128,7 +150,8 @@ void k_coll_scatter(const u64* const* __restrict__ descs, const u32* __restrict_
 //   cnt[c]   = 1-runs of the column (as before), cnt_s[c] = the single-bit ones among them
 //   off[c]   = first 32-bit word of the column; multis at [off, off + round4(cnt - cnt_s)), singles behind them
 
-// count pass: L lanes per (operand, column) count the single-bit 1-runs of the block -> sgl[i][c] (raw count)
+// count pass: L lanes per (operand, column) count the single-bit 1-runs of the block -> sgl[i][c] (raw count); lane t takes
+// chunks t, t + L, ... of the block as 16-byte loads
 template <int L>
 __global__ __launch_bounds__(256)
 void k_coll_count_singles(const u64* const* __restrict__ descs, const u32* __restrict__ nblk, u32 ncols, u32* __restrict__ sgl)
@@ -142,12 +165,15 @@ void k_coll_count_singles(const u64* const* __restrict__ descs, const u32* __res
     if (DESC_K(d) == K_GAP) {
         const u32 meta = GMETA(d), len = meta >> 1, s = meta & 1u;
         const u32 m_cnt = coll_runs_of(meta, 1u);
-        gcptr16 g = as_gc16(DESC_P(d));
-        const u32 k0 = s ? 1u : 2u;
-        for (u32 m = t; m < m_cnt; m += L) {
-            const u32 k = k0 + 2u * m;
-            const u32 start = k == 1u ? 0u : (u32)g[k - 1u] + 1u, end = (u32)g[k <= len ? k : len];
-            ns += start == end ? 1u : 0u;
+        const u32 nchunks = (len + 1u + 7u) >> 3;
+        gcptr4 g4 = as_gc4(DESC_P(d));
+        for (u32 q = t; q < nchunks; q += (u32)L) {
+            const u32x4 x = g4[q];
+            const u32 nx = q + 1u < nchunks ? g4[q + 1u].x : 0xFFFFFFFFu;
+            CollPairs p;
+            coll_chunk_pairs(x, nx, s, q, p);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) ns += (4u * q + (u32)k < m_cnt && p.start[k] == p.end[k]) ? 1u : 0u;
         }
     }
 #pragma unroll
@@ -169,8 +195,9 @@ void k_coll_prefix_singles(u32* __restrict__ sgl, u32 n, u32 ncols, const u32* _
     words[c] = ((nm + 3u) & ~3u) + (((run + 7u) & ~7u) >> 1);
 }
 
-// scatter pass: L lanes per (operand, column); lane t takes a contiguous share of the block's 1-runs, counts its singles,
-// the group agrees on the write positions (exclusive prefix over the L lanes), then every lane writes its runs
+// scatter pass: L lanes per (operand, column); lane t takes chunks t, t + L, ... of the block as 16-byte loads, the group
+// agrees on the write positions (exclusive prefix over the L lanes, a running base over the rounds), every lane writes its
+// runs.  (The member's piece of the column is a SET: the order of its entries is free.)
 template <int L>
 __global__ __launch_bounds__(256)
 void k_coll_scatter_split(const u64* const* __restrict__ descs, const u32* __restrict__ nblk, u32 ncols,
@@ -182,37 +209,46 @@ void k_coll_scatter_split(const u64* const* __restrict__ descs, const u32* __res
     const u32 c = blockIdx.y * (256u / L) + threadIdx.x / L;
     const bool in = c < ncols && c < nblk[i];
     u64 d = in ? descs[i][c] : 0ull;
-    const bool gap = DESC_K(d) == K_GAP;
+    if (DESC_K(d) != K_GAP) return;                       // (a whole group of L lanes leaves together)
     const u32 meta = GMETA(d), len = meta >> 1, s = meta & 1u;
-    const u32 m_cnt = gap ? coll_runs_of(meta, 1u) : 0u;
-    gcptr16 g = as_gc16(gap ? DESC_P(d) : 0ull);
-    const u32 k0 = s ? 1u : 2u;
-    const u32 per = (m_cnt + (u32)L - 1u) / (u32)L;
-    const u32 m0 = t * per < m_cnt ? t * per : m_cnt, m1 = m0 + per < m_cnt ? m0 + per : m_cnt;
-    u32 ns = 0;
-    for (u32 m = m0; m < m1; ++m) {
-        const u32 k = k0 + 2u * m;
-        const u32 start = k == 1u ? 0u : (u32)g[k - 1u] + 1u, end = (u32)g[k <= len ? k : len];
-        ns += start == end ? 1u : 0u;
-    }
-    const u32 nmul = (m1 - m0) - ns;
-    // exclusive prefixes inside the group of L lanes (all lanes of the wave take part: the shuffles are unconditional)
-    u32 is = ns, im = nmul;
-#pragma unroll
-    for (u32 o = 1; o < (u32)L; o <<= 1) {
-        const u32 a = __shfl_up(is, o, 64), b = __shfl_up(im, o, 64);
-        if (t >= o) { is += a; im += b; }
-    }
-    if (!gap || m0 == m1) return;
+    const u32 m_cnt = coll_runs_of(meta, 1u);
+    if (!m_cnt) return;
+    const u32 nchunks = (len + 1u + 7u) >> 3;
+    gcptr4 g4 = as_gc4(DESC_P(d));
     const u64 base = off[c];
     const u32 ps = pre_s[(size_t)i * ncols + c], pt = pre[(size_t)i * ncols + c] & 0x3FFFFFFFu;
     const u32 nm_col = cnt[c] - cnt_s[c];
-    u32* om = runs + base + (pt - ps) + (im - nmul);
-    u16* os = reinterpret_cast<u16*>(runs + base + ((nm_col + 3u) & ~3u)) + ps + (is - ns);
-    for (u32 m = m0; m < m1; ++m) {
-        const u32 k = k0 + 2u * m;
-        const u32 start = k == 1u ? 0u : (u32)g[k - 1u] + 1u, end = (u32)g[k <= len ? k : len];
-        if (start == end) *os++ = (u16)start; else *om++ = start | (end << 16);
+    u32* om = runs + base + (pt - ps);
+    u16* os = reinterpret_cast<u16*>(runs + base + ((nm_col + 3u) & ~3u)) + ps;
+    const u32 lane = threadIdx.x & 63u, last = (lane & ~((u32)L - 1u)) + (u32)L - 1u;
+    for (u32 q0 = 0; q0 < nchunks; q0 += (u32)L) {
+        const u32 q = q0 + t;
+        const bool have = q < nchunks;
+        const u32x4 x = have ? g4[q] : (u32x4)(0u);
+        const u32 nx = (have && q + 1u < nchunks) ? g4[q + 1u].x : 0xFFFFFFFFu;
+        CollPairs p;
+        coll_chunk_pairs(x, nx, s, q, p);
+        bool valid[4], single[4];
+        u32 ns = 0, nm = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            valid[k] = have && 4u * q + (u32)k < m_cnt;
+            single[k] = valid[k] && p.start[k] == p.end[k];
+            ns += single[k] ? 1u : 0u; nm += (valid[k] && !single[k]) ? 1u : 0u;
+        }
+        u32 is = ns, im = nm;                             // inclusive prefixes inside the group
+#pragma unroll
+        for (u32 o = 1; o < (u32)L; o <<= 1) {
+            const u32 a = __shfl_up(is, o, 64), b = __shfl_up(im, o, 64);
+            if (t >= o) { is += a; im += b; }
+        }
+        u16* ws = os + (is - ns); u32* wm = om + (im - nm);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (single[k]) *ws++ = (u16)p.start[k];
+            else if (valid[k]) *wm++ = p.start[k] | (p.end[k] << 16);
+        }
+        os += __shfl(is, (int)last, 64); om += __shfl(im, (int)last, 64);
     }
 }
 
