@@ -117,3 +117,33 @@ def test_bench_refuses_more_gpus_than_visible():
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--no-cpu", "--steps", "1", "--warmup", "0"],
                          env=env2, capture_output=True, text=True, timeout=300)
     assert out.returncode != 0 and not any(l.startswith("{") for l in out.stdout.splitlines())
+
+
+def test_traffic_figures_are_stamped_and_dropped_on_mismatch(tmp_path, monkeypatch):
+    """roofline.traffic comes from PMC passes of a separate rocprofv3 run (profiles/traffic_*.json): every committed file carries
+    the kernel and the commit it was measured on, and bench.py drops a figure -- traffic None, the reason in traffic_source --
+    when the stamp is missing or names another kernel than the one the run reports"""
+    import json
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path: sys.path.insert(0, root)
+    import bench
+    import glob
+    files = sorted(glob.glob(os.path.join(root, "profiles", "traffic_*.json")))
+    assert len(files) >= 6
+    for f in files:
+        j = json.load(open(f))
+        assert j.get("kernel") and j.get("commit") and j.get("hbm_bytes_per_launch", 0) > 0 and j.get("workload"), f
+    # the live loader: right kernel -> the figure; another kernel -> dropped with a reason; workload filter
+    t, src, _ = bench.traffic_file("traffic_config4.json", kernel="k_agg_or_rows<4>: tiles of 14 block columns")
+    assert t and "k_agg_or_rows" in src and "commit" in src
+    t, src, _ = bench.traffic_file("traffic_config4.json", kernel="k_agg_or_gap_tiled<1,1> (descriptor-table kernel)")
+    assert t is None and src.startswith("dropped")
+    t, src, _ = bench.traffic_file("traffic_latest.json", kernel="k_pipe_counts_bits2<4,true,640,8> x 6 launches", workload="agg_and_count_64x1000000000")
+    assert t is None and src is None                          # another workload: no figure, nothing to explain
+    # an unstamped file is refused
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    os.makedirs(tmp_path / "profiles")
+    json.dump({"workload": "w", "hbm_bytes_per_launch": 1, "source": "s"}, open(tmp_path / "profiles" / "traffic_x.json", "w"))
+    t, src, _ = bench.traffic_file("traffic_x.json", kernel="k")
+    assert t is None and "not stamped" in src
