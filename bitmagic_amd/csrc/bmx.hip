@@ -254,9 +254,9 @@ static int coll_build(bmx_ctx* ctx, const bmx_vec* const* v, size_t n, int polar
                        (const u32*)d_nblk, (u32)n, ncols, (u32)polarity, d_pre, c->d_cnt, c->d_flags);
     if (split) {
         // single-bit runs per (operand, column) -> their prefix per column -> the column's size in 32-bit words
-        if (short_blocks) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_coll_count_singles<8>), dim3((u32)n, (ncols + 31) / 32), dim3(256), 0, ctx->stream,
+        if (short_blocks) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_coll_count_singles<8>), dim3((u32)n, ((ncols + 31) / 32 + COLL_YT - 1) / COLL_YT), dim3(256), 0, ctx->stream,
                                              (const u64* const*)d_descs, (const u32*)d_nblk, ncols, d_sgl);
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_coll_count_singles<64>), dim3((u32)n, (ncols + 3) / 4), dim3(256), 0, ctx->stream,
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_coll_count_singles<64>), dim3((u32)n, ((ncols + 3) / 4 + COLL_YT - 1) / COLL_YT), dim3(256), 0, ctx->stream,
                                 (const u64* const*)d_descs, (const u32*)d_nblk, ncols, d_sgl);
         hipLaunchKernelGGL(k_coll_prefix_singles, dim3((ncols + 255) / 256), dim3(256), 0, ctx->stream, d_sgl, (u32)n, ncols,
                            (const u32*)c->d_cnt, c->d_cnt_s, d_words);
@@ -271,17 +271,17 @@ static int coll_build(bmx_ctx* ctx, const bmx_vec* const* v, size_t n, int polar
     c->entries = total;
     if ((rc = dmalloc(ctx, (void**)&c->d_runs, std::max<size_t>((size_t)total * 4, 64)))) return fail(rc);
     if (total && split) {
-        if (short_blocks) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_coll_scatter_split<8>), dim3((u32)n, (ncols + 31) / 32), dim3(256), 0, ctx->stream,
+        if (short_blocks) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_coll_scatter_split<8>), dim3((u32)n, ((ncols + 31) / 32 + COLL_YT - 1) / COLL_YT), dim3(256), 0, ctx->stream,
                                              (const u64* const*)d_descs, (const u32*)d_nblk, ncols, (const u32*)d_pre, (const u32*)d_sgl,
                                              (const u32*)c->d_cnt, (const u32*)c->d_cnt_s, (const u64*)c->d_off, c->d_runs);
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_coll_scatter_split<64>), dim3((u32)n, (ncols + 3) / 4), dim3(256), 0, ctx->stream,
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_coll_scatter_split<64>), dim3((u32)n, ((ncols + 3) / 4 + COLL_YT - 1) / COLL_YT), dim3(256), 0, ctx->stream,
                                 (const u64* const*)d_descs, (const u32*)d_nblk, ncols, (const u32*)d_pre, (const u32*)d_sgl,
                                 (const u32*)c->d_cnt, (const u32*)c->d_cnt_s, (const u64*)c->d_off, c->d_runs);
         e = hipGetLastError();
     } else if (total) {
-        if (short_blocks) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_coll_scatter<8>), dim3((u32)n, (ncols + 31) / 32), dim3(256), 0, ctx->stream,
+        if (short_blocks) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_coll_scatter<8>), dim3((u32)n, ((ncols + 31) / 32 + COLL_YT - 1) / COLL_YT), dim3(256), 0, ctx->stream,
                                           (const u64* const*)d_descs, (const u32*)d_nblk, ncols, (u32)polarity, (const u32*)d_pre, (const u64*)c->d_off, c->d_runs);
-        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_coll_scatter<64>), dim3((u32)n, (ncols + 3) / 4), dim3(256), 0, ctx->stream,
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_coll_scatter<64>), dim3((u32)n, ((ncols + 3) / 4 + COLL_YT - 1) / COLL_YT), dim3(256), 0, ctx->stream,
                                 (const u64* const*)d_descs, (const u32*)d_nblk, ncols, (u32)polarity, (const u32*)d_pre, (const u64*)c->d_off, c->d_runs);
         e = hipGetLastError();
     }

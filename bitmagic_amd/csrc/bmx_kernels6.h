@@ -93,6 +93,10 @@ void k_coll_offsets(const u32* __restrict__ cnt, u32 ncols, u64* __restrict__ of
     if (tid == 0) off[ncols] = carry;
 }
 
+// COLL_YT column tiles per workgroup in the passes that walk (operand, column) blocks: a workgroup per tile was 7.8 M workgroups of
+// 32 blocks each for configs[4] -- bound by the dispatch rate, not by memory
+#define COLL_YT 8u
+
 // The wanted runs of one 16-byte chunk of a GAP block, from registers (round 4: the build read every run end with a 2-byte load).
 // Chunk q holds words 8q .. 8q + 7 of the block (word 0 = header, word k = end of run k); nx = the first dword of chunk q + 1.
 // (s = 1: the block starts with a run of the wanted polarity.)  A block that starts with a 0-run (s = 0) has its 1-runs at even k: run m = (words 2m + 1, 2m + 2) -- the chunk's pairs
@@ -119,26 +123,33 @@ void k_coll_scatter(const u64* const* __restrict__ descs, const u32* __restrict_
 {
     const u32 i = blockIdx.x;
     const u32 t = threadIdx.x % L;
-    const u32 c = blockIdx.y * (256u / L) + threadIdx.x / L;
-    if (c >= ncols || c >= nblk[i]) return;
-    u64 d = descs[i][c];
-    if (DESC_K(d) != K_GAP) return;
-    u32 meta = GMETA(d), len = meta >> 1, s = meta & 1u;
-    u32 m_cnt = coll_runs_of(meta, polarity);
-    u32* out = runs + off[c] + (pre[(size_t)i * ncols + c] & 0x3FFFFFFFu);
-    // run k (1-based) has the value s ^ ((k - 1) & 1) and covers e[k-1]+1 .. e[k] (e[0] = -1; word k of the block = e[k]): the
-    // wanted runs are every second one from k = 1 (the block starts with a wanted run) or k = 2; lane t takes chunks t, t + L, ...
-    // as 16-byte loads (coll_chunk_pairs below), run m lands in out[m]
-    const u32 s_eff = s == polarity ? 1u : 0u;
-    const u32 nchunks = (len + 1u + 7u) >> 3;
-    gcptr4 g4 = as_gc4(DESC_P(d));
-    for (u32 q = t; q < nchunks; q += (u32)L) {
-        const u32x4 x = g4[q];
-        const u32 nx = q + 1u < nchunks ? g4[q + 1u].x : 0xFFFFFFFFu;
-        CollPairs p;
-        coll_chunk_pairs(x, nx, s_eff, q, p);
+    const u32 nb_i = nblk[i];
+    const u64* __restrict__ di = descs[i];
+    auto dload = [&](u32 by) -> u64 { const u32 c = by * (256u / L) + threadIdx.x / L; return (c < ncols && c < nb_i) ? di[c] : 0ull; };
+    u64 dn = dload(blockIdx.y * COLL_YT);                 // the next tile's descriptor is requested a tile ahead
+    for (u32 by = blockIdx.y * COLL_YT; by < (blockIdx.y + 1u) * COLL_YT; ++by) {
+        const u32 c = by * (256u / L) + threadIdx.x / L;
+        if (by * (256u / L) >= ncols) break;
+        const u64 d = dn;
+        dn = dload(by + 1u);
+        if (DESC_K(d) != K_GAP) continue;
+        u32 meta = GMETA(d), len = meta >> 1, s = meta & 1u;
+        u32 m_cnt = coll_runs_of(meta, polarity);
+        u32* out = runs + off[c] + (pre[(size_t)i * ncols + c] & 0x3FFFFFFFu);
+        // run k (1-based) has the value s ^ ((k - 1) & 1) and covers e[k-1]+1 .. e[k] (e[0] = -1; word k of the block = e[k]): the
+        // wanted runs are every second one from k = 1 (the block starts with a wanted run) or k = 2; lane t takes chunks t, t + L, ...
+        // as 16-byte loads (coll_chunk_pairs), run m lands in out[m]
+        const u32 s_eff = s == polarity ? 1u : 0u;
+        const u32 nchunks = (len + 1u + 7u) >> 3;
+        gcptr4 g4 = as_gc4(DESC_P(d));
+        for (u32 q = t; q < nchunks; q += (u32)L) {
+            const u32x4 x = g4[q];
+            const u32 nx = q + 1u < nchunks ? g4[q + 1u].x : 0xFFFFFFFFu;
+            CollPairs p;
+            coll_chunk_pairs(x, nx, s_eff, q, p);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) if (4u * q + (u32)k < m_cnt) out[4u * q + (u32)k] = p.start[k] | (p.end[k] << 16);
+            for (int k = 0; k < 4; ++k) if (4u * q + (u32)k < m_cnt) out[4u * q + (u32)k] = p.start[k] | (p.end[k] << 16);
+        }
     }
 }
 
@@ -158,28 +169,36 @@ void k_coll_count_singles(const u64* const* __restrict__ descs, const u32* __res
 {
     const u32 i = blockIdx.x;
     const u32 t = threadIdx.x % L;
-    const u32 c = blockIdx.y * (256u / L) + threadIdx.x / L;
-    const bool in = c < ncols && c < nblk[i];
-    u64 d = in ? descs[i][c] : 0ull;
-    u32 ns = 0;
-    if (DESC_K(d) == K_GAP) {
-        const u32 meta = GMETA(d), len = meta >> 1, s = meta & 1u;
-        const u32 m_cnt = coll_runs_of(meta, 1u);
-        const u32 nchunks = (len + 1u + 7u) >> 3;
-        gcptr4 g4 = as_gc4(DESC_P(d));
-        for (u32 q = t; q < nchunks; q += (u32)L) {
-            const u32x4 x = g4[q];
-            const u32 nx = q + 1u < nchunks ? g4[q + 1u].x : 0xFFFFFFFFu;
-            CollPairs p;
-            coll_chunk_pairs(x, nx, s, q, p);
+    const u32 nb_i = nblk[i];
+    const u64* __restrict__ di = descs[i];
+    auto dload = [&](u32 by) -> u64 { const u32 c = by * (256u / L) + threadIdx.x / L; return (c < ncols && c < nb_i) ? di[c] : 0ull; };
+    u64 dn = dload(blockIdx.y * COLL_YT);                 // the next tile's descriptor is requested a tile ahead
+    for (u32 by = blockIdx.y * COLL_YT; by < (blockIdx.y + 1u) * COLL_YT; ++by) {
+        const u32 c = by * (256u / L) + threadIdx.x / L;
+        if (by * (256u / L) >= ncols) break;
+        const bool in = c < ncols && c < nb_i;
+        const u64 d = dn;
+        dn = dload(by + 1u);
+        u32 ns = 0;
+        if (DESC_K(d) == K_GAP) {
+            const u32 meta = GMETA(d), len = meta >> 1, s = meta & 1u;
+            const u32 m_cnt = coll_runs_of(meta, 1u);
+            const u32 nchunks = (len + 1u + 7u) >> 3;
+            gcptr4 g4 = as_gc4(DESC_P(d));
+            for (u32 q = t; q < nchunks; q += (u32)L) {
+                const u32x4 x = g4[q];
+                const u32 nx = q + 1u < nchunks ? g4[q + 1u].x : 0xFFFFFFFFu;
+                CollPairs p;
+                coll_chunk_pairs(x, nx, s, q, p);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) ns += (4u * q + (u32)k < m_cnt && p.start[k] == p.end[k]) ? 1u : 0u;
+                for (int k = 0; k < 4; ++k) ns += (4u * q + (u32)k < m_cnt && p.start[k] == p.end[k]) ? 1u : 0u;
+            }
         }
-    }
 #pragma unroll
-    for (u32 o = 1; o < (u32)L; o <<= 1) ns += __shfl_xor(ns, o, 64);
-    if (in && t == 0) sgl[(size_t)i * ncols + c] = ns;
-    else if (!in && t == 0 && c < ncols) sgl[(size_t)i * ncols + c] = 0u;
+        for (u32 o = 1; o < (u32)L; o <<= 1) ns += __shfl_xor(ns, o, 64);
+        if (in && t == 0) sgl[(size_t)i * ncols + c] = ns;
+        else if (!in && t == 0 && c < ncols) sgl[(size_t)i * ncols + c] = 0u;
+    }
 }
 
 // per column: exclusive prefix of the singles over the operand list (in place), cnt_s[c], and the column's size in 32-bit words
@@ -206,49 +225,56 @@ void k_coll_scatter_split(const u64* const* __restrict__ descs, const u32* __res
 {
     const u32 i = blockIdx.x;
     const u32 t = threadIdx.x % L;
-    const u32 c = blockIdx.y * (256u / L) + threadIdx.x / L;
-    const bool in = c < ncols && c < nblk[i];
-    u64 d = in ? descs[i][c] : 0ull;
-    if (DESC_K(d) != K_GAP) return;                       // (a whole group of L lanes leaves together)
-    const u32 meta = GMETA(d), len = meta >> 1, s = meta & 1u;
-    const u32 m_cnt = coll_runs_of(meta, 1u);
-    if (!m_cnt) return;
-    const u32 nchunks = (len + 1u + 7u) >> 3;
-    gcptr4 g4 = as_gc4(DESC_P(d));
-    const u64 base = off[c];
-    const u32 ps = pre_s[(size_t)i * ncols + c], pt = pre[(size_t)i * ncols + c] & 0x3FFFFFFFu;
-    const u32 nm_col = cnt[c] - cnt_s[c];
-    u32* om = runs + base + (pt - ps);
-    u16* os = reinterpret_cast<u16*>(runs + base + ((nm_col + 3u) & ~3u)) + ps;
+    const u32 nb_i = nblk[i];
     const u32 lane = threadIdx.x & 63u, last = (lane & ~((u32)L - 1u)) + (u32)L - 1u;
-    for (u32 q0 = 0; q0 < nchunks; q0 += (u32)L) {
-        const u32 q = q0 + t;
-        const bool have = q < nchunks;
-        const u32x4 x = have ? g4[q] : (u32x4)(0u);
-        const u32 nx = (have && q + 1u < nchunks) ? g4[q + 1u].x : 0xFFFFFFFFu;
-        CollPairs p;
-        coll_chunk_pairs(x, nx, s, q, p);
-        bool valid[4], single[4];
-        u32 ns = 0, nm = 0;
+    const u64* __restrict__ di = descs[i];
+    auto dload = [&](u32 by) -> u64 { const u32 c = by * (256u / L) + threadIdx.x / L; return (c < ncols && c < nb_i) ? di[c] : 0ull; };
+    u64 dn = dload(blockIdx.y * COLL_YT);                 // the next tile's descriptor is requested a tile ahead
+    for (u32 by = blockIdx.y * COLL_YT; by < (blockIdx.y + 1u) * COLL_YT; ++by) {
+        if (by * (256u / L) >= ncols) break;
+        const u32 c = by * (256u / L) + threadIdx.x / L;
+        const u64 d = dn;
+        dn = dload(by + 1u);
+        if (DESC_K(d) != K_GAP) continue;                     // (a whole group of L lanes skips together)
+        const u32 meta = GMETA(d), len = meta >> 1, s = meta & 1u;
+        const u32 m_cnt = coll_runs_of(meta, 1u);
+        if (!m_cnt) continue;
+        const u32 nchunks = (len + 1u + 7u) >> 3;
+        gcptr4 g4 = as_gc4(DESC_P(d));
+        const u64 base = off[c];
+        const u32 ps = pre_s[(size_t)i * ncols + c], pt = pre[(size_t)i * ncols + c] & 0x3FFFFFFFu;
+        const u32 nm_col = cnt[c] - cnt_s[c];
+        u32* om = runs + base + (pt - ps);
+        u16* os = reinterpret_cast<u16*>(runs + base + ((nm_col + 3u) & ~3u)) + ps;
+        for (u32 q0 = 0; q0 < nchunks; q0 += (u32)L) {
+            const u32 q = q0 + t;
+            const bool have = q < nchunks;
+            const u32x4 x = have ? g4[q] : (u32x4)(0u);
+            const u32 nx = (have && q + 1u < nchunks) ? g4[q + 1u].x : 0xFFFFFFFFu;
+            CollPairs p;
+            coll_chunk_pairs(x, nx, s, q, p);
+            bool valid[4], single[4];
+            u32 ns = 0, nm = 0;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            valid[k] = have && 4u * q + (u32)k < m_cnt;
-            single[k] = valid[k] && p.start[k] == p.end[k];
-            ns += single[k] ? 1u : 0u; nm += (valid[k] && !single[k]) ? 1u : 0u;
-        }
-        u32 is = ns, im = nm;                             // inclusive prefixes inside the group
+            for (int k = 0; k < 4; ++k) {
+                valid[k] = have && 4u * q + (u32)k < m_cnt;
+                single[k] = valid[k] && p.start[k] == p.end[k];
+                ns += single[k] ? 1u : 0u; nm += (valid[k] && !single[k]) ? 1u : 0u;
+            }
+            u32 is = ns, im = nm;                             // inclusive prefixes inside the group
 #pragma unroll
-        for (u32 o = 1; o < (u32)L; o <<= 1) {
-            const u32 a = __shfl_up(is, o, 64), b = __shfl_up(im, o, 64);
-            if (t >= o) { is += a; im += b; }
-        }
-        u16* ws = os + (is - ns); u32* wm = om + (im - nm);
+            for (u32 o = 1; o < (u32)L; o <<= 1) {
+                const u32 a = __shfl_up(is, o, 64), b = __shfl_up(im, o, 64);
+                if (t >= o) { is += a; im += b; }
+            }
+            u16* ws = os + (is - ns); u32* wm = om + (im - nm);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (single[k]) *ws++ = (u16)p.start[k];
-            else if (valid[k]) *wm++ = p.start[k] | (p.end[k] << 16);
+            for (int k = 0; k < 4; ++k) {
+                if (single[k]) *ws++ = (u16)p.start[k];
+                else if (valid[k]) *wm++ = p.start[k] | (p.end[k] << 16);
+            }
+            os += __shfl(is, (int)last, 64); om += __shfl(im, (int)last, 64);
         }
-        os += __shfl(is, (int)last, 64); om += __shfl(im, (int)last, 64);
     }
 }
 
