@@ -148,13 +148,26 @@ static bool coll_evict_one(bmx_ctx* ctx)
 {
     if (ctx->colls.empty() || ctx->coll_building) return false;
     if (hipStreamSynchronize(ctx->stream) != hipSuccess) return false;    // (nothing may still read it)
-    size_t lru = 0;
-    for (size_t i = 1; i < ctx->colls.size(); ++i) if (ctx->colls[i]->last_use < ctx->colls[lru]->last_use) lru = i;
+    // (a collection a running call resolved and still holds a pointer to is pinned: bmx_agg_and_sub / agg_or_impl allocate
+    // their result slab and member tables AFTER resolving)
+    size_t lru = ctx->colls.size();
+    for (size_t i = 0; i < ctx->colls.size(); ++i)
+        if (!ctx->colls[i]->pins && (lru == ctx->colls.size() || ctx->colls[i]->last_use < ctx->colls[lru]->last_use)) lru = i;
+    if (lru == ctx->colls.size()) return false;
     coll_free(ctx, lru);
     for (auto& kv : ctx->pool_free) (void)hipFree(kv.second);             // its blocks went to the pool: give them to the driver
     ctx->pool_free.clear(); ctx->pool_cached = 0;
     return true;
 }
+
+// holds collections against eviction for the duration of a scope (dmalloc under memory pressure evicts the least recently
+// used UNPINNED collection)
+struct CollPin {
+    bmx_coll* c[2] = {nullptr, nullptr};
+    void pin(bmx_coll* a, bmx_coll* b = nullptr) { release(); c[0] = a; c[1] = b; for (bmx_coll* x : c) if (x) ++x->pins; }
+    void release() { for (bmx_coll*& x : c) if (x) { --x->pins; x = nullptr; } }
+    ~CollPin() { release(); }
+};
 
 // may this operand list be packed at all?  GAP / NULL / FULL blocks only (and at least one GAP block)
 static bool coll_packable(const bmx_ctx* ctx, const bmx_vec* const* v, size_t n)
@@ -308,7 +321,7 @@ static int coll_build(bmx_ctx* ctx, const bmx_vec* const* v, size_t n, int polar
     while (ctx->pack_bytes + c->bytes > ctx->pack_cap) {
         size_t lru = ctx->colls.size();
         for (size_t i = 0; i < ctx->colls.size(); ++i)
-            if (ctx->colls[i] != keep && (lru == ctx->colls.size() || ctx->colls[i]->last_use < ctx->colls[lru]->last_use)) lru = i;
+            if (ctx->colls[i] != keep && !ctx->colls[i]->pins && (lru == ctx->colls.size() || ctx->colls[i]->last_use < ctx->colls[lru]->last_use)) lru = i;
         if (lru == ctx->colls.size()) break;
         coll_free(ctx, lru);
     }
@@ -1748,7 +1761,8 @@ int bmx_pipeline_operand_bytes(bmx_ctx* ctx, bmx_pipeline* p, uint32_t nb_from, 
 static int result_begin(bmx_ctx* ctx, uint64_t nbits, uint32_t nblocks, bmx_vec** out, BlockStat** st, u32** offs)
 {
     int rc;
-    size_t aux_need = (size_t)nblocks * (sizeof(BlockStat) + 4) + 64;
+    // st[nblocks] + offs[nblocks] + the GAP candidate list k_op2_loop writes behind offs (offs + nblocks, up to nblocks entries)
+    size_t aux_need = (size_t)nblocks * (sizeof(BlockStat) + 4 + 4) + 64;
     if ((rc = ensure(ctx, &ctx->aux, &ctx->aux_bytes, aux_need))) return rc;
     *st = (BlockStat*)ctx->aux;
     *offs = (u32*)((char*)ctx->aux + (size_t)nblocks * sizeof(BlockStat));
@@ -2337,6 +2351,7 @@ static int agg_or_impl(bmx_ctx* ctx, const bmx_vec* const* src, size_t n, int op
     }
     bmx_vec* v; BlockStat* st; u32* offs;
     bmx_coll* packed = nullptr; std::vector<u32> members; bool packed_full = false;
+    CollPin pin;
     if ((rc = result_begin(ctx, nbits, ncols, &v, &st, &offs))) return rc;      // empty list => cleared target (:1105)
     if (use_direct(ctx, ncols, n)) {
         void* d_tab = nullptr;
@@ -2348,6 +2363,7 @@ static int agg_or_impl(bmx_ctx* ctx, const bmx_vec* const* src, size_t n, int op
         if (rc) { bmx_vec_free(ctx, v); return rc; }
     } else if (n >= 16 && ncols && has_gap && !has_bit && (rc = coll_resolve(ctx, src, n, 1, 64, true, &packed, &members, &packed_full)) == BMX_OK && packed && !packed_full &&
                !(ctx->coll_members < 0 && n >= 64 && or_rows_wanted(ctx, src, n)) && coll_members_wanted_list(ctx, src, n)) {
+        pin.pin(packed);                                       // (coll_members_upload allocates: the collection must outlive it)
         // GAP-only operands that are SOME of the vectors of a packed collection: their pieces of its column regions
         // (k_coll_members, bmx_kernels8.h).  Sparse lists of >= 64 vectors take the row kernel below instead: a member's piece
         // of a column is ~26 bytes there, and reading them one by one (9.1 ms for 2,048 of configs[4]'s 4,096 vectors) loses
@@ -2361,6 +2377,7 @@ static int agg_or_impl(bmx_ctx* ctx, const bmx_vec* const* src, size_t n, int op
         if (rc) { bmx_vec_free(ctx, v); return rc; }
     } else if (rc) { bmx_vec_free(ctx, v); return rc;
     } else if (packed && packed_full) {
+        pin.pin(packed);
         // GAP-only operands = ALL the vectors of a packed collection: one sequential stream per block column (bmx_kernels6.h)
         // without opt_compress no GAP block can come out: the kernel folds the kind counts of its result itself and, when every
         // block turned out to be a bit-block (the OR of thousands of sparse vectors), the layout scan is skipped (one launch
@@ -2576,6 +2593,7 @@ int bmx_agg_and_sub(bmx_ctx* ctx, const bmx_vec* const* src_and, size_t n_and,
             if (!coll_members_wanted(ctx, gw, gb, n_and + n_sub, 1)) ca = nullptr;
         }
         if (ca) {
+            CollPin pin; pin.pin(ca, cs);                      // (result_begin / coll_members_upload allocate: no eviction from under the call)
             if ((rc = result_begin(ctx, nbits, ncols, &v, &st, &offs))) return rc;
             void* d_buf = nullptr;
             if (full) rc = coll_launch(COLL_AND_STORE, ctx, ca, cs, 0u, ncols, 1, nullptr, v, st, 0u, 0xFFFFFFFFu);

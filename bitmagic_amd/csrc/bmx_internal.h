@@ -148,6 +148,7 @@ struct bmx_coll {
     uint64_t alg_bytes;                   // algorithmic bytes of the GAP operands: sum of 2 x (len + 1)
     bool has_bit;                         // a bit-block was found while counting: unusable
     bool prepared;                        // built by bmx_collection_prepare (not by the gap_pack 1 policy)
+    int pins = 0;                         // > 0 while a one-shot call holds a raw pointer to it across allocations: never evicted then
     float build_ms;
 };
 

@@ -2186,3 +2186,28 @@ def test_full_size_pairwise_and_rank_select_vs_reference_on_all_cores(ctx):
         f, p = v.select(sr, rs)
         assert f.all() and (p == ar).all()
         del rs, v
+
+
+def test_pairwise_on_uploaded_only_operands_fresh_context(port):
+    """bmx_op2's laid-out path (k_op2_loop + bump cursor) writes a GAP candidate list behind offs[] in the
+    context's scratch.  On a FRESH context whose only vectors came through bmx_vec_upload (the C++ facade's path: nothing has
+    grown the scratch before) >= 2,048 all-GAP blocks per operand must not overrun it: results = the oracle, and vectors that
+    were allocated right before the call keep their bits."""
+    c = bm.context(0)
+    try:
+        nblk = 4100
+        wa = port.gen_words(9100, 1, 120, nblk * 65536); wb = port.gen_words(9100, 2, 120, nblk * 65536)
+        pa, pb = port.import_words(wa, True, wa.size * 32), port.import_words(wb, True, wb.size * 32)
+        ga = bm.bvector.from_block_table(c, wa.size * 32, *pa.flatten())
+        gb = bm.bvector.from_block_table(c, wb.size * 32, *pb.flatten())
+        assert ga.info()["counts"][bm.GAP] == nblk and gb.info()["counts"][bm.GAP] == nblk
+        guard = bm.bvector.from_block_table(c, wa.size * 32, *pa.flatten())      # a neighbour in device memory
+        for op in (bm.AND, bm.SUB, bm.OR, bm.XOR):
+            t = bm.bvector._op2(op, ga, gb, bm.opt_none)
+            e = port.op2(op, pa, pb, 0)
+            assert t.block_table()[0].tolist() == e.flatten()[0].tolist(), op
+            assert (t.to_words(wa.size) == e.to_words(wa.size)).all(), op
+            del t
+        assert bm.count_xor(guard, ga) == 0 and (guard.to_words(wa.size) == wa).all()
+    finally:
+        c.close()
