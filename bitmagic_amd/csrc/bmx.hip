@@ -11,6 +11,7 @@
 #include "bmx_kernels6.h"
 #include "bmx_kernels7.h"
 #include "bmx_kernels8.h"
+#include "bmx_kernels9.h"
 
 #include <algorithm>
 #include <atomic>
@@ -648,7 +649,7 @@ int bmx_ctx_create(int device, void* stream, bmx_ctx** out)
     // an invalid value is ignored (the default stays)
     static const char* const env_keys[][2] = {
         {"BMX_PIPE_UNROLL", "pipe_unroll"}, {"BMX_PIPE_ROWS", "pipe_rows"}, {"BMX_PIPE_NT", "pipe_nt"},
-        {"BMX_PIPE_WG", "pipe_wg"}, {"BMX_PIPE_WINDOW", "pipe_window"}, {"BMX_PIPE_SPLIT", "pipe_split"}, {"BMX_OR_TILE", "or_tile"}, {"BMX_OR_ROWS", "or_rows"}, {"BMX_OR_DEPTH", "or_depth"}, {"BMX_OR_WINDOW", "or_window"}, {"BMX_DIRECT_COLS", "direct_cols"}, {"BMX_FF_WINDOW", "ff_window"}, {"BMX_GAP_COUNT", "gap_count"}, {"BMX_RANGE_HALVES", "range_halves"}, {"BMX_PAIR_STREAM", "pair_stream"}, {"BMX_PAIR_WGS", "pair_wgs"}, {"BMX_RS_LANES", "rs_lanes"}, {"BMX_RS_LINES", "rs_lines"}, {"BMX_RS_SELECT_LINES", "rs_select_lines"}, {"BMX_RS_SDIR_SHIFT", "rs_sdir_shift"}, {"BMX_COLL_SHAPE", "coll_shape"}, {"BMX_COLL_WINDOW", "coll_window"}, {"BMX_COLL_SPLIT", "coll_split"}, {"BMX_EQ_BIG", "eq_big"}, {"BMX_PAIR_LOOP", "pair_loop"}, {"BMX_PAIR_NT", "pair_nt"}, {"BMX_EQ_BIG_SHAPE", "eq_big_shape"}, {"BMX_OP2_WGS", "op2_wgs"}, {"BMX_OP2_LOOP", "op2_loop"}, {"BMX_OP2_NT", "op2_nt"}, {"BMX_GAP_PACK", "gap_pack"}, {"BMX_COLL_MEMBERS", "coll_members"}, {"BMX_XCD_SWIZZLE", "xcd_swizzle"}};
+        {"BMX_PIPE_WG", "pipe_wg"}, {"BMX_PIPE_WINDOW", "pipe_window"}, {"BMX_PIPE_SPLIT", "pipe_split"}, {"BMX_OR_TILE", "or_tile"}, {"BMX_OR_ROWS", "or_rows"}, {"BMX_OR_DEPTH", "or_depth"}, {"BMX_OR_WINDOW", "or_window"}, {"BMX_DIRECT_COLS", "direct_cols"}, {"BMX_FF_WINDOW", "ff_window"}, {"BMX_GAP_COUNT", "gap_count"}, {"BMX_AND_ROWS", "and_rows"}, {"BMX_AND_ROWS_WG", "and_rows_wg"}, {"BMX_AND_ROWS_DEPTH", "and_rows_depth"}, {"BMX_AND_ROWS_NT", "and_rows_nt"}, {"BMX_RANGE_HALVES", "range_halves"}, {"BMX_PAIR_STREAM", "pair_stream"}, {"BMX_PAIR_WGS", "pair_wgs"}, {"BMX_RS_LANES", "rs_lanes"}, {"BMX_RS_LINES", "rs_lines"}, {"BMX_RS_SELECT_LINES", "rs_select_lines"}, {"BMX_RS_SDIR_SHIFT", "rs_sdir_shift"}, {"BMX_COLL_SHAPE", "coll_shape"}, {"BMX_COLL_WINDOW", "coll_window"}, {"BMX_COLL_SPLIT", "coll_split"}, {"BMX_EQ_BIG", "eq_big"}, {"BMX_PAIR_LOOP", "pair_loop"}, {"BMX_PAIR_NT", "pair_nt"}, {"BMX_EQ_BIG_SHAPE", "eq_big_shape"}, {"BMX_OP2_WGS", "op2_wgs"}, {"BMX_OP2_LOOP", "op2_loop"}, {"BMX_OP2_NT", "op2_nt"}, {"BMX_GAP_PACK", "gap_pack"}, {"BMX_COLL_MEMBERS", "coll_members"}, {"BMX_XCD_SWIZZLE", "xcd_swizzle"}};
     for (auto& kv : env_keys)
         if (const char* e = getenv(kv[0])) (void)bmx_ctx_set_tuning(ctx, kv[1], atoi(e));
     g_last_error.clear();
@@ -706,6 +707,10 @@ int bmx_ctx_set_tuning(bmx_ctx* ctx, const char* key, int value)
     else if (k == "pair_wgs") { ARGCHK(value >= 1 && value <= 8); ctx->pair_wgs = value; }
     else if (k == "range_halves") { ARGCHK(value == 0 || value == 1); ctx->range_halves = value; }
     else if (k == "gap_count") { ARGCHK(value >= -1 && value <= 1); ctx->gap_count = value; }
+    else if (k == "and_rows") { ARGCHK(value >= -1 && value <= 1); ctx->and_rows = value; }
+    else if (k == "and_rows_wg") { ARGCHK(value == 128 || value == 256 || value == 512); ctx->and_rows_wg = value; }
+    else if (k == "and_rows_depth") { ARGCHK(value == 2 || value == 3 || value == 4 || value == 8); ctx->and_rows_depth = value; }
+    else if (k == "and_rows_nt") ctx->and_rows_nt = value != 0;
     else if (k == "ff_window") { ARGCHK(value >= -1); ctx->ff_window = value; }
     else if (k == "or_window") { ARGCHK(value >= -9); ctx->or_window = value; }
     else if (k == "gap_pack") { ARGCHK(value >= -1 && value <= 1); ctx->gap_pack = value; }
@@ -1438,6 +1443,41 @@ static int pipe_range(const bmx_pipeline* p, uint32_t& nb_from, uint32_t& nb_to)
 }
 
 } // extern "C"
+// GAP-only pipelines: the union-of-0-runs kernel over the operands' own slabs (k_agg_and_rows, bmx_kernels9.h).  A workgroup
+// per (column, group) whose waves share the group's operand list.  Measured against the wave-per-item kernel k_pipe_counts
+// (16 groups of n operands over 1e9-bit vectors at 0.1 % / 0.3 %, tools/bench_and_rows.py CROSS=1, profiles/r05_and_rows):
+// n = 2: 1.49 / 1.53 against 1.64 / 1.62 ms, 4: 1.55 / 1.66 against 1.53 / 1.72, 8: 1.62 / 1.78 against 1.74 / 2.31,
+// 16: 1.74 / 1.91 against 2.40 / 3.50, 32 (8 groups): 1.57 / 1.87 against 7.3 / 8.1 (the counting kernel), 256 (1 group):
+// 0.51 / 1.35 against 1.56 / 2.10 -- a tie up to 4 operands, a win from 8 on: and_rows -1 takes it from 8 operands per group.
+static bool use_and_rows(const bmx_ctx* ctx, const bmx_pipeline* p, uint64_t ops_of_group = 0)
+{
+    if (ctx->and_rows == 0 || ctx->gap_count == 1 || !p->has_gap || p->has_bit) return false;
+    if (ctx->and_rows > 0) return true;
+    if (ops_of_group) return ops_of_group >= 8u;
+    return (uint64_t)p->n_ops >= 8ull * p->ngroups;
+}
+typedef void (*and_rows_fn)(const u64*, const u32*, const u32*, const u32*, u32, u32, u32, u32, int, u64*, uint4*, u64*, BlockStat*, u32, u32, int);
+// (tuning build only: BMX_DIAG_AROWS = 1 -> the row loads alone, 2 -> no fold / count; results are then meaningless)
+static int and_rows_diag_bits()
+{
+#ifdef BMX_DIAG
+    if (const char* e = getenv("BMX_DIAG_AROWS")) return atoi(e) & 15;
+#endif
+    return 0;
+}
+template <int MODE, bool NT>
+static and_rows_fn and_rows_kernel_nt(const bmx_ctx* ctx)
+{
+    const int d = ctx->and_rows_depth;
+    switch (ctx->and_rows_wg) {
+    case 128:  return d == 2 ? k_agg_and_rows<MODE, 128, 2, NT> : d == 8 ? k_agg_and_rows<MODE, 128, 8, NT> : d == 3 ? k_agg_and_rows<MODE, 128, 3, NT> : k_agg_and_rows<MODE, 128, 4, NT>;
+    case 256:  return d == 2 ? k_agg_and_rows<MODE, 256, 2, NT> : d == 8 ? k_agg_and_rows<MODE, 256, 8, NT> : d == 3 ? k_agg_and_rows<MODE, 256, 3, NT> : k_agg_and_rows<MODE, 256, 4, NT>;
+    default:   return d == 2 ? k_agg_and_rows<MODE, 512, 2, NT> : d == 8 ? k_agg_and_rows<MODE, 512, 8, NT> : d == 3 ? k_agg_and_rows<MODE, 512, 3, NT> : k_agg_and_rows<MODE, 512, 4, NT>;
+    }
+}
+template <int MODE>
+static and_rows_fn and_rows_kernel(const bmx_ctx* ctx) { return ctx->and_rows_nt ? and_rows_kernel_nt<MODE, true>(ctx) : and_rows_kernel_nt<MODE, false>(ctx); }
+
 // GAP-only pipelines with long operand lists: count the covering operands per position (k_pipe_counts_gapcount) instead
 // of applying them one by one.  gap_count: -1 = automatic (>= 32 operands per group on average AND GAP blocks of >= 240 words on average), 0 = off, 1 = whenever it applies
 static bool use_gapcount(const bmx_ctx* ctx, const bmx_pipeline* p, uint64_t ops_of_group = 0)
@@ -1603,6 +1643,14 @@ static int pipeline_run_counts_impl(bmx_ctx* ctx, bmx_pipeline* p, uint32_t nb_f
         return BMX_OK;
     }
     if (nitems64 > 0xFFFFFFF0ull) { g_last_error = "too many (column, group) items in one run"; return BMX_ERR_RANGE; }
+    if (use_and_rows(ctx, p)) {
+        // every operand block is GAP (or NULL / FULL): the union of the operands' 0-runs read straight from their slabs
+        hipLaunchKernelGGL(and_rows_kernel<AR_COUNT>(ctx), dim3((u32)nitems64), dim3((u32)ctx->and_rows_wg), 0, ctx->stream,
+                           (const u64*)p->d_dmat, row_off, and_n, sub_n, p->col_stride, p->ngroups, nb_from, (u32)nitems64, ctx->xcd_swz, (u64*)d_counts,
+                           (uint4*)nullptr, (u64*)nullptr, (BlockStat*)nullptr, 0u, 0xFFFFFFFFu, and_rows_diag_bits());
+        KCHK();
+        return BMX_OK;
+    }
     if (use_gapcount(ctx, p)) {
         // every operand block is GAP (or NULL / FULL): the counting formulation, one 1024-thread workgroup per (column, group)
         size_t lds = (size_t)(16384 * 2 + 2048) * 4;
@@ -1653,6 +1701,8 @@ int bmx_pipeline_describe(bmx_ctx* ctx, bmx_pipeline* p, uint32_t nb_from, uint3
         snprintf(buf, buf_len, "k_pipe_counts_staged<%d> x 1 launch, %u workgroups", ctx->pipe_slots, nb_to - nb_from);
     else if (use_split(ctx, p, nitems64))
         snprintf(buf, buf_len, "k_pipe_split<2,%d> x 1 launch, %llu workgroups", SPLIT_WAVES, (unsigned long long)nitems64);
+    else if (use_and_rows(ctx, p))
+        snprintf(buf, buf_len, "k_agg_and_rows<COUNT,%d,%d> x 1 launch, %llu workgroups", ctx->and_rows_wg, ctx->and_rows_depth, (unsigned long long)nitems64);
     else if (use_gapcount(ctx, p))
         snprintf(buf, buf_len, "k_pipe_counts_gapcount x 1 launch, %llu workgroups", (unsigned long long)nitems64);
     else if (p->has_gap)
@@ -2508,6 +2558,14 @@ static int agg_and_sub_launch(bmx_ctx* ctx, const bmx_pipeline* p, uint32_t g, b
     const u32* sn = p->d_meta + 2 * p->ngroups + g;
     const u32 ncols = p->ncols;
     hipError_t e = hipSuccess;
+    if (ncols && use_and_rows(ctx, p, (uint64_t)(*p->h_and_n)[g] + (*p->h_sub_n)[g])) {
+        // GAP-only operands: the union of 0-runs over the operands' own slabs, result block stored (bmx_kernels9.h)
+        hipLaunchKernelGGL(and_rows_kernel<AR_STORE>(ctx), dim3(ncols), dim3((u32)ctx->and_rows_wg), 0, ctx->stream,
+                           rows, p->d_meta /* row_off[0] = 0: rows already points at group g */, an, sn, p->col_stride, 1u, 0u, ncols, ctx->xcd_swz, (u64*)nullptr,
+                           v->d_bits, v->d_desc, st, nb_from, nb_to, 0);
+        e = hipGetLastError();
+        return e == hipSuccess ? BMX_OK : fail_hip(e, "k_agg_and_rows", __LINE__);
+    }
     if (ncols && use_gapcount(ctx, p, (*p->h_and_n)[g])) {
         // GAP-only operands, a long list: the counting formulation, one 1024-thread workgroup per column, result block stored
         size_t lds = (size_t)(16384 * 2 + 2048) * 4;

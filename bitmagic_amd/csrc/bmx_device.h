@@ -35,7 +35,8 @@ typedef Part<8> Blk;
 __device__ __forceinline__ gcptr4 as_gc4(u64 addr) { return (gcptr4)(uintptr_t)addr; }
 __device__ __forceinline__ gcptr4 as_gc4(const void* p) { return (gcptr4)(uintptr_t)p; }
 __device__ __forceinline__ gptr4 as_g4(void* p) { return (gptr4)(uintptr_t)p; }
-__device__ __forceinline__ gcptr16 as_gc16(u64 addr) { return (gcptr16)(uintptr_t)addr; }
+// (pipeline rows keep a GAP block's GMETA in bits 48..60 next to its pointer -- k_pipe_sort -- so the address is masked here)
+__device__ __forceinline__ gcptr16 as_gc16(u64 addr) { return (gcptr16)(uintptr_t)(addr & 0x0000FFFFFFFFFFFFull); }
 
 __device__ __forceinline__ u32 lane_id() { return threadIdx.x & 63u; }
 

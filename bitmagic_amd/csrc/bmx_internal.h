@@ -62,6 +62,10 @@ struct bmx_ctx {
     int pair_wgs = 1;          // ... and this many workgroups per CU
     int range_halves = 1;      // comparison search in half-block passes (k_slice_compare_halves) instead of whole-block accumulators (k_slice_compare)
     int gap_count = -1;        // GAP-only counts pipelines: counting formulation (k_pipe_counts_gapcount): -1 = automatic, 0 = off, 1 = force
+    int and_rows = -1;         // AND / AND-SUB over GAP-only operands straight from their slabs (k_agg_and_rows, bmx_kernels9.h): -1 = automatic (>= 8 operands per group on average), 0 = never, 1 = whenever the pipeline holds no bit-block
+    int and_rows_wg = 256;     // ... threads per workgroup (128 / 256 / 512)
+    int and_rows_nt = 0;       // ... non-temporal loads of the run lists
+    int and_rows_depth = 3;    // ... 1-KiB pieces in flight per wave (2 / 3 / 4 / 8)
     int ff_window = 0;         // find_first_and_sub: block columns of the FIRST launch window (each next one is 4x larger): 0 = automatic, -1 = one launch
     int or_window = 0;         // column tiles per launch of k_agg_or_gap_tiled: 0 / -1 = all in one launch (windows measured: no gain)
     int or_rows = -1;          // combine_or over >= 64 GAP-only operands through the tile directories (k_agg_or_rows, bmx_kernels7.h): -1 = when the operands average <= 4.1 chunks per GAP block, 0 = never (k_agg_or_gap_tiled), 1 = always

@@ -436,7 +436,7 @@ __device__ __forceinline__ bool sort_operands(const u64* const* __restrict__ des
         u64 bit_m = __ballot(kd == K_BIT), gap_m = __ballot(kd == K_GAP);
         u64 lt = (1ull << lane) - 1ull;
         if (kd == K_BIT) region[nbit + (u32)__popcll(bit_m & lt)] = DESC_P(d);
-        if (kd == K_GAP) region[n - 1u - (ngap + (u32)__popcll(gap_m & lt))] = DESC_P(d);
+        if (kd == K_GAP) region[n - 1u - (ngap + (u32)__popcll(gap_m & lt))] = d & 0x3FFFFFFFFFFFFFFFull;   // pointer | GMETA << 48 (len, start bit): consumers mask (as_gc16) or use it (bmx_kernels9.h)
         nbit += (u32)__popcll(bit_m); ngap += (u32)__popcll(gap_m);
     }
     return killed;

@@ -40,7 +40,7 @@ __device__ __forceinline__ void gc_count_chunk(u32* S, u32* E, u32x4 d, u32 c, u
 // longer block is fetched when the operand is counted
 __device__ __forceinline__ void gc_stage_load(u32x4 (&d)[2], u64 gaddr, u32 len, u32 lane)
 {
-    gcptr4 g4 = as_gc4(gaddr);
+    gcptr4 g4 = as_gc4(gaddr & 0x0000FFFFFFFFFFFFull);
     u32 nch = len ? (len + 8u) >> 3 : 0u;                       // (len 0 = an empty slot of the prefetch ring: nothing is read)
 #pragma unroll
     for (int j = 0; j < 2; ++j) { u32 c = lane + 64u * (u32)j; d[j] = c < nch ? g4[c] : (u32x4)(0u); }
@@ -56,7 +56,7 @@ __device__ __forceinline__ void gc_count_operand(u32* S, u32* E, const u32x4 (&d
         u32 c = lane + 64u * (u32)j;
         u32x4 q;
         if (j < 2) q = d[j];
-        else q = c < nch ? as_gc4(gaddr)[c] : (u32x4)(0u);         // long block: its third chunk, fetched now
+        else q = c < nch ? as_gc4(gaddr & 0x0000FFFFFFFFFFFFull)[c] : (u32x4)(0u);         // long block: its third chunk, fetched now
         u32 last = q.w >> 16;
         u32 prev = __shfl_up(last, 1, 64);
         if (lane == 0) prev = carry;

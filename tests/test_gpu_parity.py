@@ -842,6 +842,7 @@ def test_gap_only_pipeline_counting_formulation(ctx, port, dq, nvec, nsub):
     agg = bm.aggregator(ctx)
     try:
         ctx.set_tuning("pipe_split", 0)                  # (few items with long lists would take the workgroup-split kernel)
+        ctx.set_tuning("and_rows", 0)                    # (round 5: GAP-only pipelines default to k_agg_and_rows, test_and_rows_kernel)
         for gc in (1, 0, -1):
             ctx.set_tuning("gap_count", gc)
             if gc == 1: assert "gapcount" in pipe.describe()
@@ -861,10 +862,10 @@ def test_gap_only_pipeline_counting_formulation(ctx, port, dq, nvec, nsub):
                 assert (t.to_words(nblk * 2048) == e.to_words(nblk * 2048)).all(), (gc, len(a), len(s))
                 assert t.block_table()[0].tolist() == (e.flatten()[0].tolist() + [0] * nblk)[:t.info()["nblocks"]] and any_ == (e.count() != 0)
         ctx.set_tuning("direct_cols", 384)
-        ctx.set_tuning("pipe_split", -1); ctx.set_tuning("gap_count", -1)
+        ctx.set_tuning("pipe_split", -1); ctx.set_tuning("gap_count", -1); ctx.set_tuning("and_rows", -1)
         assert (agg.combine_and_sub(pipe) == exp).all()   # default selection (workgroup-split kernel for so few items)
     finally:
-        ctx.set_tuning("gap_count", -1); ctx.set_tuning("pipe_split", -1); ctx.set_tuning("direct_cols", 384)
+        ctx.set_tuning("gap_count", -1); ctx.set_tuning("pipe_split", -1); ctx.set_tuning("direct_cols", 384); ctx.set_tuning("and_rows", -1)
 
 
 @pytest.mark.parametrize("common_bits,own_dq,nvec", [(1, 30, 40), (40, 100, 70), (400, 100, 90), (520, 40, 36),
@@ -2211,3 +2212,85 @@ def test_pairwise_on_uploaded_only_operands_fresh_context(port):
         assert bm.count_xor(guard, ga) == 0 and (guard.to_words(wa.size) == wa).all()
     finally:
         c.close()
+
+
+@pytest.mark.parametrize("nvec,nsub", [(40, 0), (70, 9), (300, 33)])
+def test_and_rows_kernel(ctx, port, nvec, nsub):
+    """Round 5: AND / AND-SUB over GAP-only operands straight from the operands' slabs (k_agg_and_rows, bmx_kernels9.h: union of
+    the AND operands' 0-runs, complemented, minus the union of the SUB operands' 1-runs), counts pipelines (several groups,
+    block-range runs) and the materialising combine_and_sub: counts, bits and block kinds = the oracle and = the older
+    kernels, for every launch shape.  Blocks of one, two and three 1-KiB pieces (up to 1,201 runs), blocks that start with a
+    1-run, inverted (dense) GAP blocks, single-run blocks, FULL / NULL operands, ragged operand lengths, more than 64 operands
+    per wave (two entry batches), SUB lists longer than the AND list."""
+    nblk = 6
+    nbits = nblk * 65536 - 4321
+    nw = nblk * 2048
+    rng = np.random.default_rng(nvec * 17 + nsub)
+    common = port.gen_words(777, 0xFFFFFFFF, 40, nblk * 65536)
+    common[5] |= 1                                                     # bit 0 of the vector survives in every AND operand
+    words = []
+    for v in range(nvec + nsub):
+        nb_v = nbits if v % 7 else nbits - 2 * 65536                   # ragged: some operands end two blocks early
+        w = port.gen_words(777, v, (30, 120, 300)[v % 3], nblk * 65536)
+        for b in range(nblk):
+            lo, r = b * 2048, rng.integers(0, 16)
+            if r == 0 and v >= nvec: w[lo:lo + 2048] = 0                                       # NULL block (SUB operand)
+            elif r == 1: w[lo:lo + 2048] = 0xFFFFFFFF                                          # FULL block
+            elif r == 2: w[lo:lo + 2048] = ~w[lo:lo + 2048]                                    # dense GAP: long 1-runs, starts with a 1-run
+            elif r == 3:                                                                       # 560 isolated bits: 1,121 runs (+ the shared ones), three pieces
+                w[lo:lo + 2048] = 0
+                pos = np.arange(560) * 116 + 1 + (v % 50)
+                np.bitwise_or.at(w, lo + (pos >> 5), (np.uint32(1) << (pos & 31).astype(np.uint32)))
+            elif r == 4: w[lo] |= 1                                                            # starts with a 1-run
+            elif r == 5 and v < nvec: w[lo:lo + 2048] = 0xFFFFFFFF; w[lo + 2047] = 0x7FFFFFFF  # two runs: all ones but the last bit
+        if v < nvec: w |= common                                        # the AND survives (also in the inverted and the 600-bit blocks)
+        nwv = (nb_v + 31) // 32
+        if nb_v % 32: w[nwv - 1] &= np.uint32((1 << (nb_v % 32)) - 1)
+        w[nwv:] = 0
+        words.append(w)
+    lens = [nbits if v % 7 else nbits - 2 * 65536 for v in range(nvec + nsub)]
+    gv = [bm.bit_import_u32(ctx, w[:(n + 31) // 32], True) for w, n in zip(words, lens)]
+    pv = [port.import_words(w[:(n + 31) // 32], True, n) for w, n in zip(words, lens)]
+    assert all(v.calc_stat()["bit_blocks"] == 0 for v in gv), "the case must stay GAP-only"
+    A, S = list(range(nvec)), list(range(nvec, nvec + nsub))
+    groups = [(A, S), (A[::2], []), (A[:nvec // 2], S[:1]), (A[:17], S), (A[3:4] * 1 + A[5:21], [])]
+    exp = port.pipeline_counts([([pv[i] for i in a], [pv[i] for i in s]) for a, s in groups])
+    pipe = bm.aggregator.pipeline(ctx)
+    for a, s in groups:
+        ag = pipe.add()
+        for i in a: ag.add(gv[i], 0)
+        for i in s: ag.add(gv[i], 1)
+    pipe.complete()
+    agg = bm.aggregator(ctx)
+    try:
+        ctx.set_tuning("pipe_split", 0); ctx.set_tuning("direct_cols", 0)     # (so few items / columns would take the one-workgroup-per-item kernels)
+        for ar, wg, depth, nt in ((1, 256, 2, 0), (1, 512, 4, 1), (1, 512, 8, 0), (1, 256, 8, 1), (1, 128, 3, 0), (0, 512, 4, 0), (-1, 256, 3, 0)):
+            ctx.set_tuning("and_rows", ar); ctx.set_tuning("and_rows_wg", wg); ctx.set_tuning("and_rows_depth", depth); ctx.set_tuning("and_rows_nt", nt)
+            d = pipe.describe()
+            assert ("k_agg_and_rows<COUNT,%d,%d>" % (wg, depth) in d) == (ar != 0), d
+            got = agg.combine_and_sub(pipe)
+            assert (got == exp).all(), (ar, wg, depth, nt, got, exp)
+            parts = sum(agg._run_pipeline(pipe, a, b).astype(np.int64) for a, b in [(0, 1), (1, 4), (4, nblk)])
+            assert (parts == exp.astype(np.int64)).all(), (ar, wg, depth)
+            for a, s in groups[:4]:
+                e = port.agg_and_sub([pv[i] for i in a], [pv[i] for i in s])
+                t, any_ = agg.combine_and_sub([gv[i] for i in a], [gv[i] for i in s])
+                assert (t.to_words(nw) == e.to_words(nw)).all(), (ar, wg, depth, len(a), len(s))
+                assert t.block_table()[0].tolist() == (e.flatten()[0].tolist() + [0] * nblk)[:t.info()["nblocks"]] and any_ == (e.count() != 0)
+        # a results pipeline (one launch per group through agg_and_sub_launch) with the row kernel forced
+        ctx.set_tuning("and_rows", 1)
+        rp = bm.aggregator.pipeline(ctx, bm.agg_opt_bvect_and_counts)
+        for a, s in groups:
+            ag = rp.add()
+            for i in a: ag.add(gv[i], 0)
+            for i in s: ag.add(gv[i], 1)
+        rp.complete()
+        res = agg.combine_and_sub(rp)
+        for (a, s), r, c in zip(groups, res, rp.get_bv_count_vector()):
+            e = port.agg_and_sub([pv[i] for i in a], [pv[i] for i in s])
+            assert int(c) == e.count()
+            assert (r is None) == (e.count() == 0)
+            if r is not None: assert (r.to_words(nw) == e.to_words(nw)).all()
+    finally:
+        for k, v in (("and_rows", -1), ("and_rows_wg", 256), ("and_rows_depth", 3), ("and_rows_nt", 0), ("pipe_split", -1), ("direct_cols", 384)):
+            ctx.set_tuning(k, v)
