@@ -558,6 +558,48 @@ def run_headline(args, env, cpu):
     gpu_sample = None
     if world == 1 and cpu is not None:
         gpu_sample = int(agg._run_pipeline(main["pipe"], 0, sb)[0])
+    # the materialised form of the same aggregation: aggregator::combine_and (BASELINE configs[2] names "combine_and + count"):
+    # the WHOLE host call (row build, kernel, result layout), result stored with opt_compress (src/bmaggregator.h:1210)
+    mat = None
+    if world == 1 and scaling == "strong" and not args.no_others and not args.independent:
+        ts = []
+        for _ in range(4):
+            ctx.synchronize(); t0 = time.perf_counter()
+            t, _any = agg.combine_and_sub(main["vecs"], [])
+            ts.append((time.perf_counter() - t0) * 1e3)
+            rc, rstat = t.count(), t.calc_stat()
+            del t
+        mms = min(ts[1:])
+        mbytes = main["op_bytes"] + rstat["bit_blocks"] * 8192
+        mat = {"host_call_ms": round(mms, 4), "result_count": rc, "result_block_types": rstat, "count_equal": bool(rc == main["count"]),
+               "algorithmic_bytes": mbytes, "frac": round(mbytes / mms / 1e6 / HBM_PEAK_GBS, 4),
+               "note": "bmx_agg_and_sub over the 256 resident vectors: best of 3 whole host calls (pipeline rows built per call, "
+                       "k_agg_and_sub, result kinds + layout); bytes = operand blocks + 8,192 B per stored result block"}
+    # host -> device: what the boundary costs when the operands start on the host (SURVEY section 8(d) "separately report H2D upload time")
+    h2d = None
+    if world == 1 and scaling == "strong" and not args.no_others and not args.independent:
+        try:
+            uv = main["vecs"][1]
+            kinds, offs, bits, gaps = uv.block_table()
+            words = uv.to_words()
+            def best_of(fn, n=4):
+                tt = []
+                for _ in range(n):
+                    ctx.synchronize(); t0 = time.perf_counter(); u = fn(); ctx.synchronize(); tt.append(time.perf_counter() - t0); del u
+                return min(tt[1:])
+            tb = best_of(lambda: bm.bvector.from_block_table(ctx, args.nbits, kinds, offs, bits, gaps))
+            ti = best_of(lambda: bm.bit_import_u32(ctx, words, True))
+            nbytes = bits.nbytes + gaps.nbytes + kinds.nbytes + offs.nbytes
+            h2d = {"vector": f"one {args.nbits}-bit vector of the collection ({uv.calc_stat()['bit_blocks']} bit-blocks)", "bytes": int(nbytes),
+                   "bmx_vec_upload_ms": round(tb * 1e3, 3), "bmx_vec_upload_GBps": round(nbytes / tb / 1e9, 2),
+                   "bmx_vec_import_bits_ms": round(ti * 1e3, 3), "bmx_vec_import_bits_GBps": round(words.nbytes / ti / 1e9, 2),
+                   "whole_collection_upload_s_estimate": round(tb * args.nvec, 2),
+                   "note": "host block table (contiguous slabs = what a freeze()d bm::bvector<> hands over, include/bmx/bm_adapter.hpp flatten_view) "
+                           "-> bmx_vec_upload, pageable host memory, best of 3 calls incl. the final synchronise; import_bits = raw words, "
+                           "classified and compressed on the device.  Never part of `value`: the timed region starts with the operands resident in HBM"}
+            del kinds, offs, bits, gaps, words
+        except Exception as e:
+            h2d = {"error": str(e)}
     weak = None
     del main["pipe"], main["vecs"]
     if world > 1 and scaling == "strong" and not args.no_weak:
@@ -616,6 +658,10 @@ def run_headline(args, env, cpu):
         res["per_rank"]["GBps"] = None
     if shard_eff:
         res["shard_1of8_on_one_gpu"] = shard_eff
+    if mat:
+        res["materialised_combine_and"] = mat
+    if h2d:
+        res["h2d_upload"] = h2d
     if weak:
         res["weak_scaling"] = weak
     if cpu is not None:
@@ -989,6 +1035,9 @@ def run_rank_select(args, env, quick=False, dq=None):
                                            "(a directory entry, L2-resident, then the line; a second line when the interpolated guess is off by one), "
                                            "so 0.5 is the ceiling of this ratio"},
                         "as_bandwidth_GBps": round(nq * 128 / rank_ms / 1e6, 1),
+                        "frac_bytes": round(nq * 128 / rank_ms / 1e6 / HBM_PEAK_GBS, 4),
+                        "select_frac_bytes": round(nq * 136 / sel_ms / 1e6 / HBM_PEAK_GBS, 4),
+                        "frac_bytes_note": "the same times against the 8 TB/s streaming peak: 128 B per rank query, 128 + 8 B per select query",
                         "note": "random access: ONE 128-B line per rank query is what the algorithm needs, and with the rank-line layout "
                                 "(running count interleaved with the bits) it is also all the kernel reads; the bound is the transaction "
                                 "rate of random lines (SURVEY section 8(d)), measured by the probe, not the 8 TB/s streaming peak"}}
@@ -1185,6 +1234,89 @@ def run_or_sharded(args, env, quick=False):
     return res
 
 
+def run_sparse_and(args, env, dq=197, quick=True):
+    """configs[2] at inverted-index densities (every block of every vector a GAP block): the 256-way fused AND+COUNT, three
+    numbers kept apart as for configs[4]:
+      cold_ms  -- the counts pipeline over the operands as the reference holds them, NO packed collection in force
+                  (k_agg_and_rows, bmx_kernels9.h); `value`, `ms_per_step` and `roofline` are this run, on SURVEY 8(d) bytes
+      build_ms -- bmx_collection_prepare(vecs, ROLE_AND)
+      warm_ms  -- the same pipeline once the collection is in force (k_coll_apply<AND_COUNT>), its own roofline"""
+    import bitmagic_amd as bm
+    torch, ctx = env.torch, env.ctx
+    nvec, nbits = args.nvec, args.nbits
+    nblocks = (nbits + 65535) // 65536
+    t0 = time.perf_counter()
+    vecs = [bm.bvector.generate(ctx, SEED, v, dq, nbits, with_common=True) for v in range(nvec)]
+    ctx.synchronize(); t_build = time.perf_counter() - t0
+    if any(v.info()["counts"][bm.BIT] for v in vecs):
+        raise RuntimeError(f"density {dq}/65536 leaves bit-blocks: not the GAP-only case")
+    counts = torch.zeros(1, dtype=torch.int64, device="cuda")
+    agg = bm.aggregator(ctx)
+    pipe = bm.aggregator.pipeline(ctx)
+    ag = pipe.add()
+    for v in vecs:
+        ag.add(v, 0)
+    pipe.complete()
+    alg = pipe.operand_bytes()
+    assert ctx.pack_stats()["collections"] == 0
+    def kernel():
+        agg.run_counts_dev(pipe, counts.data_ptr())
+    steps, warmup = (10, 2) if quick else (args.steps, max(args.warmup, 1))
+    dt, ev_ms = timed_region(kernel, steps, warmup, env)                   # ---- cold: no collection exists
+    cold_count = int(counts.item())
+    cold_plan = pipe.describe()
+    cold_ms = event_avg_ms(kernel, steps, ctx)
+    assert ctx.pack_stats()["collections"] == 0
+    have_coll = os.environ.get("BMX_GAP_PACK", "-1") != "0"
+    build_ms = warm_ms = warm_plan = warm_count = None
+    if have_coll:
+        ctx.collection_prepare(vecs, bm.ROLE_AND); ctx.synchronize()
+        pack = ctx.pack_stats(); build_ms = pack["last_build_ms"]
+        kernel(); kernel()
+        warm_ms = event_avg_ms(kernel, steps, ctx)
+        warm_count = int(counts.item()); warm_plan = pipe.describe()
+    achieved = alg / cold_ms / 1e6
+    pct = dq / 65536 * 100
+    res = {"metric": METRIC + f" -- at {pct:.1f} % (GAP-only operands), first call", "value": round(nvec * nbits * steps / dt / 1e9, 1), "unit": "Gbit/s",
+           "n_gpus": 1, "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
+           "vs_baseline": None, "dtype": "u16", "data": "synthetic", "mode": env.mode,
+           "config": {"workload": f"{nvec}-way fused AND+COUNT over {nvec} x {nbits}-bit vectors, common {pct:.2f} % + own {pct:.2f} % (data set A), every block a GAP block; "
+                                  "counts pipeline over the operands in the reference's format, no packed collection",
+                      "baseline_config": "configs[2] (sparse)", "density_q16": dq, "block_types_vec0": vecs[0].calc_stat(), "result_count": cold_count,
+                      "build_seconds": round(t_build, 1), "cold_ms": round(cold_ms, 4),
+                      "build_ms": None if build_ms is None else round(build_ms, 2), "warm_ms": None if warm_ms is None else round(warm_ms, 4),
+                      "warm_count_equal": None if warm_count is None else bool(warm_count == cold_count),
+                      "break_even_calls": (round(build_ms / (cold_ms - warm_ms), 1) if (warm_ms is not None and cold_ms > warm_ms) else None)},
+           "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                        "traffic": None, "kernel": cold_plan, "algorithmic_bytes_per_launch": alg, "avg_launch_ms": round(cold_ms, 4),
+                        "note": "algorithmic bytes = 2 x (len + 1) B per GAP operand block (SURVEY section 8(d)); hipEvent pair around back-to-back runs"}}
+    if warm_ms is not None:
+        res["roofline"]["warm"] = {"kernel": warm_plan, "avg_launch_ms": round(warm_ms, 4), "achieved": round(alg / warm_ms / 1e6, 1),
+                                   "frac": round(alg / warm_ms / 1e6 / HBM_PEAK_GBS, 4), "reference_format_GBps": round(alg / warm_ms / 1e6, 1)}
+    if not args.no_cpu:
+        try:
+            sb = min(args.cpu_sample_blocks, nblocks)
+            procs = _spawn_workers([["and", 0, sb, nvec, dq, nbits, 3]])
+            try:
+                _go(procs); one = json.loads(procs[0].stdout.readline())
+            finally:
+                _finish_workers(procs)
+            best = min(b - a for a, b in one["spans"])
+            cpu = {"value": round(nvec * sb * 65536 / best / 1e9, 1), "unit": "Gbit/s", "cores": 1, "kind": one["kind"], "impl": one["impl"],
+                   "sample": f"{nvec} vectors x first {sb} blocks, counts-only pipeline, best of {len(one['spans'])} passes",
+                   "matches_gpu": bool(one["count"] == int(agg._run_pipeline(pipe, 0, sb)[0]))}
+            if not args.no_allcores:
+                ncores = args.cpu_cores or len(os.sched_getaffinity(0))
+                cpu.update(cpu_baseline_allcores(nvec, dq, nbits, ncores, reps=2))
+                cpu["matches_gpu_full"] = bool(cpu["full_count"] == cold_count)
+            res["cpu_baseline"] = cpu
+        except Exception as e:
+            res["cpu_baseline"] = {"value": None, "unit": "Gbit/s", "cores": 1, "kind": "reference", "sample": f"failed: {e}"}
+    del pipe, vecs
+    ctx.trim()
+    return res
+
+
 def run_plumbing(args, env):
     """BASELINE configs[0]: two 1 M-bit bm::bvector<> at 10 %: bit_and + count on the CPU reference with AVX2 OFF (the scalar
     build of the unmodified BitMagic, oracle/_ref/libbmref_scalar.so) -- the reference's own tests/perf shape
@@ -1294,12 +1426,12 @@ def summary_of(res):
         return None
     out = {"metric": res["metric"], "value": res["value"], "unit": res["unit"], "ms_per_step": res["ms_per_step"],
            "steps": res["steps"], "workload": res["config"]["workload"],
-           "roofline": {k: res["roofline"].get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "kernel", "avg_launch_ms", "traffic")}}
+           "roofline": {k: res["roofline"].get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "kernel", "avg_launch_ms", "traffic", "frac_bytes", "select_frac_bytes") if k in res["roofline"] or k in ("bound", "achieved", "peak", "unit", "frac", "kernel", "avg_launch_ms", "traffic")}}
     cpu = res.get("cpu_baseline")
     if cpu:
-        out["cpu_baseline"] = {k: cpu.get(k) for k in ("value", "unit", "cores", "kind", "matches_gpu_full", "matches_gpu_full_materialised", "matches_gpu_sample") if k in cpu}
+        out["cpu_baseline"] = {k: cpu.get(k) for k in ("value", "unit", "cores", "kind", "matches_gpu", "allcores_gbit_s", "cores_used", "matches_gpu_full", "matches_gpu_full_materialised", "matches_gpu_sample") if k in cpu}
     for k in ("per_op", "rank_ms", "select_ms", "rank_Mq_s", "select_Mq_s", "rank_select_roundtrip_ok", "result_count", "cold_ms", "build_ms", "warm_ms",
-              "break_even_calls", "subset_of_the_collection"):
+              "break_even_calls", "subset_of_the_collection", "own_read_write_probe"):
         if k in res["config"]:
             out[k] = res["config"][k]
     if "select" in res["roofline"]:
@@ -1388,7 +1520,9 @@ def main():
                              ("configs[1] at 50 %", lambda: run_pairwise(args, env, dq=32768, quick=True)),
                              ("configs[3]", lambda: run_rank_select(args, env, quick=True)),
                              ("configs[3] at 1 %", lambda: run_rank_select(args, env, quick=True, dq=655)),
-                             ("configs[4]", lambda: run_or_sharded(args, env, quick=True))):
+                             ("configs[4]", lambda: run_or_sharded(args, env, quick=True)),
+                             ("configs[2] at 0.3 %", lambda: run_sparse_and(args, env, dq=197)),
+                             ("configs[2] at 0.1 %", lambda: run_sparse_and(args, env, dq=66))):
                 try:
                     t0 = time.perf_counter()
                     s = summary_of(fn())

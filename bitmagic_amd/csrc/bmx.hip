@@ -534,6 +534,7 @@ static void pipe_plan(const bmx_ctx* ctx, u64 nitems, u32 ngroups, u32& rows, u3
             }
         }
     }
+    if (!ctx->pipe_nt && !ctx->pipe_wg && rows == 8u && wg > 512u) wg = 512u;               // (plain loads: the 640 / 768-thread shapes exist with non-temporal loads only)
     if (ctx->pipe_window < 0 || (ctx->pipe_window == 0 && ngroups > 4u)) window = 0u;     // many groups: operand re-use in L2 is what matters
     else if (ctx->pipe_window > 0) window = (u32)ctx->pipe_window;
     else window = (u32)std::max<u64>(pipe_window_cap(wg) / ((u64)ngroups * (8u / rows)), 1u);
@@ -551,7 +552,7 @@ static pipe_bits_fn pipe_bits_rows(u32 unroll, bool nt, u32 wg)
     if constexpr (ROWS == 8) {
         if (unroll == 4 && nt) switch (wg) { case 384: return B2(4, true, 384); case 512: return B2(4, true, 512);
                                              case 640: return B2(4, true, 640); case 768: return B2(4, true, 768); default: break; }
-        if (unroll == 4 && !nt && wg == 640) return B2(4, false, 640);
+        if (unroll == 4 && !nt && wg == 512) return B2(4, false, 512);      // (plain loads need ~196 VGPRs: two waves per SIMD, i.e. <= 512 threads; <4, false, 640> spilled)
     }
 #ifdef BMX_TUNE   // shapes of the tuning sweeps (tools/tune_pipe.py): make -C bitmagic_amd/csrc tune
     if constexpr (ROWS == 8) {
@@ -649,7 +650,7 @@ int bmx_ctx_create(int device, void* stream, bmx_ctx** out)
     // an invalid value is ignored (the default stays)
     static const char* const env_keys[][2] = {
         {"BMX_PIPE_UNROLL", "pipe_unroll"}, {"BMX_PIPE_ROWS", "pipe_rows"}, {"BMX_PIPE_NT", "pipe_nt"},
-        {"BMX_PIPE_WG", "pipe_wg"}, {"BMX_PIPE_WINDOW", "pipe_window"}, {"BMX_PIPE_SPLIT", "pipe_split"}, {"BMX_OR_TILE", "or_tile"}, {"BMX_OR_ROWS", "or_rows"}, {"BMX_OR_DEPTH", "or_depth"}, {"BMX_OR_WINDOW", "or_window"}, {"BMX_DIRECT_COLS", "direct_cols"}, {"BMX_FF_WINDOW", "ff_window"}, {"BMX_GAP_COUNT", "gap_count"}, {"BMX_AND_ROWS", "and_rows"}, {"BMX_AND_ROWS_WG", "and_rows_wg"}, {"BMX_AND_ROWS_DEPTH", "and_rows_depth"}, {"BMX_AND_ROWS_NT", "and_rows_nt"}, {"BMX_RANGE_HALVES", "range_halves"}, {"BMX_PAIR_STREAM", "pair_stream"}, {"BMX_PAIR_WGS", "pair_wgs"}, {"BMX_RS_LANES", "rs_lanes"}, {"BMX_RS_LINES", "rs_lines"}, {"BMX_RS_SELECT_LINES", "rs_select_lines"}, {"BMX_RS_SDIR_SHIFT", "rs_sdir_shift"}, {"BMX_COLL_SHAPE", "coll_shape"}, {"BMX_COLL_WINDOW", "coll_window"}, {"BMX_COLL_SPLIT", "coll_split"}, {"BMX_EQ_BIG", "eq_big"}, {"BMX_PAIR_LOOP", "pair_loop"}, {"BMX_PAIR_NT", "pair_nt"}, {"BMX_EQ_BIG_SHAPE", "eq_big_shape"}, {"BMX_OP2_WGS", "op2_wgs"}, {"BMX_OP2_LOOP", "op2_loop"}, {"BMX_OP2_NT", "op2_nt"}, {"BMX_GAP_PACK", "gap_pack"}, {"BMX_COLL_MEMBERS", "coll_members"}, {"BMX_XCD_SWIZZLE", "xcd_swizzle"}};
+        {"BMX_PIPE_WG", "pipe_wg"}, {"BMX_PIPE_WINDOW", "pipe_window"}, {"BMX_PIPE_SPLIT", "pipe_split"}, {"BMX_OR_TILE", "or_tile"}, {"BMX_OR_ROWS", "or_rows"}, {"BMX_OR_DEPTH", "or_depth"}, {"BMX_OR_WINDOW", "or_window"}, {"BMX_DIRECT_COLS", "direct_cols"}, {"BMX_FF_WINDOW", "ff_window"}, {"BMX_GAP_COUNT", "gap_count"}, {"BMX_AND_ROWS", "and_rows"}, {"BMX_AGG_SHAPE", "agg_shape"}, {"BMX_AND_ROWS_WG", "and_rows_wg"}, {"BMX_AND_ROWS_DEPTH", "and_rows_depth"}, {"BMX_AND_ROWS_NT", "and_rows_nt"}, {"BMX_RANGE_HALVES", "range_halves"}, {"BMX_PAIR_STREAM", "pair_stream"}, {"BMX_PAIR_WGS", "pair_wgs"}, {"BMX_RS_LANES", "rs_lanes"}, {"BMX_RS_LINES", "rs_lines"}, {"BMX_RS_SELECT_LINES", "rs_select_lines"}, {"BMX_RS_SDIR_SHIFT", "rs_sdir_shift"}, {"BMX_COLL_SHAPE", "coll_shape"}, {"BMX_COLL_WINDOW", "coll_window"}, {"BMX_COLL_SPLIT", "coll_split"}, {"BMX_EQ_BIG", "eq_big"}, {"BMX_PAIR_LOOP", "pair_loop"}, {"BMX_PAIR_NT", "pair_nt"}, {"BMX_EQ_BIG_SHAPE", "eq_big_shape"}, {"BMX_OP2_WGS", "op2_wgs"}, {"BMX_OP2_LOOP", "op2_loop"}, {"BMX_OP2_NT", "op2_nt"}, {"BMX_GAP_PACK", "gap_pack"}, {"BMX_COLL_MEMBERS", "coll_members"}, {"BMX_XCD_SWIZZLE", "xcd_swizzle"}};
     for (auto& kv : env_keys)
         if (const char* e = getenv(kv[0])) (void)bmx_ctx_set_tuning(ctx, kv[1], atoi(e));
     g_last_error.clear();
@@ -707,6 +708,7 @@ int bmx_ctx_set_tuning(bmx_ctx* ctx, const char* key, int value)
     else if (k == "pair_wgs") { ARGCHK(value >= 1 && value <= 8); ctx->pair_wgs = value; }
     else if (k == "range_halves") { ARGCHK(value == 0 || value == 1); ctx->range_halves = value; }
     else if (k == "gap_count") { ARGCHK(value >= -1 && value <= 1); ctx->gap_count = value; }
+    else if (k == "agg_shape") { ARGCHK(value == 0 || value == 1); ctx->agg_shape = value; }
     else if (k == "and_rows") { ARGCHK(value >= -1 && value <= 1); ctx->and_rows = value; }
     else if (k == "and_rows_wg") { ARGCHK(value == 128 || value == 256 || value == 512); ctx->and_rows_wg = value; }
     else if (k == "and_rows_depth") { ARGCHK(value == 2 || value == 3 || value == 4 || value == 8); ctx->and_rows_depth = value; }
@@ -2579,14 +2581,21 @@ static int agg_and_sub_launch(bmx_ctx* ctx, const bmx_pipeline* p, uint32_t g, b
         return e == hipSuccess ? BMX_OK : fail_hip(e, "k_pipe_counts_gapcount", __LINE__);
     }
     if (!p->has_gap && ncols >= 2560u && ctx->pipe_window >= 0 && (ctx->pipe_wg == 0 || ctx->pipe_wg == 640)) {
-        // (640 threads = 10 waves per CU; 512 measured: 4.98 against 4.86 ms on the 256 x 1e9-bit combine_and)
-        const u32 wpb = 10u;
-        const u32 cap = ctx->pipe_window > 0 ? (u32)ctx->pipe_window : pipe_window_cap(640u);
+        // (640 threads = 10 waves per CU; 512 measured: 4.98 against 4.86 ms on the 256 x 1e9-bit combine_and.  Four operand
+        // blocks in flight per wave need ~180 VGPRs, more than the 168 a 640-thread workgroup leaves a wave: <4, 640> spilled
+        // 80 B per lane to scratch.  agg_shape 0 = three blocks in flight at 640 threads (143 VGPRs), 1 = four at
+        // 512 threads (183 VGPRs, two waves per SIMD); neither touches scratch -- tests/test_abi_host.py checks the whole library)
+        const bool s512 = ctx->agg_shape == 1;
+        const u32 wpb = s512 ? 8u : 10u, wgs = wpb * 64u;
+        const u32 cap = ctx->pipe_window > 0 ? (u32)ctx->pipe_window : pipe_window_cap(wgs);
         u32 nwin = (ncols + cap - 1u) / cap, per = (ncols + nwin - 1u) / nwin;
         per = (per + wpb - 1u) / wpb * wpb;                               // whole workgroups
         for (u32 c0 = 0; c0 < ncols && e == hipSuccess; c0 += per) {
             u32 n = std::min(per, ncols - c0);
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_agg_and_sub<4, 640>), dim3((n + wpb - 1u) / wpb), dim3(640), 0, ctx->stream,
+            if (s512) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_agg_and_sub<4, 512>), dim3((n + wpb - 1u) / wpb), dim3(512), 0, ctx->stream,
+                               rows, an, sn, p->col_stride, std::min(ncols, c0 + n), 1 /* opt_compress, :1210,1421 */, 0,
+                               v->d_bits, v->d_desc, st, nb_from, nb_to, c0);
+            else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_agg_and_sub<3, 640>), dim3((n + wpb - 1u) / wpb), dim3(640), 0, ctx->stream,
                                rows, an, sn, p->col_stride, std::min(ncols, c0 + n), 1 /* opt_compress, :1210,1421 */, 0,
                                v->d_bits, v->d_desc, st, nb_from, nb_to, c0);
             e = hipGetLastError();
@@ -3226,7 +3235,7 @@ int bmx_slice_eq_counts(bmx_ctx* ctx, const bmx_vec* const* slices, size_t nslic
                 const int shp = ctx->eq_big_shape;
                 const u32 wg = shp == 2 ? 768u : 512u, nw = wg / 64u;
                 size_t lds = (size_t)tab * 8 + (shp >= 1 ? (1u << 15) + nw * 512u * 4u : (1u << 14) + nw * 1024u * 4u);
-                auto eqfn = shp == 2 ? (nslices <= 16 ? k_slice_eq_counts_big<16, 18, 512, 768, 3, 8> : k_slice_eq_counts_big<32, 18, 512, 768, 3, 8>)
+                auto eqfn = shp == 2 ? (nslices <= 16 ? k_slice_eq_counts_big<16, 18, 512, 768, 3, 8> : k_slice_eq_counts_big<32, 18, 512, 768, 3, 4>)   /* (32 planes: 4 filter reads in flight -- 8 need 3 VGPRs more than three waves per SIMD leave: 12 B of scratch) */
                           : shp == 1 ? (nslices <= 16 ? k_slice_eq_counts_big<16, 18, 512> : k_slice_eq_counts_big<32, 18, 512>)
                                      : (nslices <= 16 ? k_slice_eq_counts_big<16, 17, 1024> : k_slice_eq_counts_big<32, 17, 1024>);
                 e = hipFuncSetAttribute(reinterpret_cast<const void*>(eqfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

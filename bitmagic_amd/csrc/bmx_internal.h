@@ -62,6 +62,7 @@ struct bmx_ctx {
     int pair_wgs = 1;          // ... and this many workgroups per CU
     int range_halves = 1;      // comparison search in half-block passes (k_slice_compare_halves) instead of whole-block accumulators (k_slice_compare)
     int gap_count = -1;        // GAP-only counts pipelines: counting formulation (k_pipe_counts_gapcount): -1 = automatic, 0 = off, 1 = force
+    int agg_shape = 0;         // materialised combine_and / combine_and_sub over bit-block-only operands (k_agg_and_sub): 0 = 640 threads, three operand blocks in flight per wave, 1 = 512 threads, four in flight
     int and_rows = -1;         // AND / AND-SUB over GAP-only operands straight from their slabs (k_agg_and_rows, bmx_kernels9.h): -1 = automatic (>= 8 operands per group on average), 0 = never, 1 = whenever the pipeline holds no bit-block
     int and_rows_wg = 256;     // ... threads per workgroup (128 / 256 / 512)
     int and_rows_nt = 0;       // ... non-temporal loads of the run lists

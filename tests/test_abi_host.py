@@ -147,3 +147,20 @@ def test_traffic_figures_are_stamped_and_dropped_on_mismatch(tmp_path, monkeypat
     json.dump({"workload": "w", "hbm_bytes_per_launch": 1, "source": "s"}, open(tmp_path / "profiles" / "traffic_x.json", "w"))
     t, src, _ = bench.traffic_file("traffic_x.json", kernel="k")
     assert t is None and "not stamped" in src
+
+
+def test_no_kernel_of_the_default_build_touches_scratch():
+    """register spills on default paths (k_agg_and_sub<4,640> 80 B / lane, k_pipe_counts_bits2<4,false,640,8>
+    116 B, k_slice_eq_counts_big<32,...,8> 12 B).  The AMDGPU notes of the gfx950 code object inside libbmx.so list the
+    private segment (scratch) and the VGPR spill count of every kernel: both must be zero (tools/scratch_check.py; no GPU needed)."""
+    import importlib.util
+    import shutil
+    spec = importlib.util.spec_from_file_location("scratch_check", os.path.join(ROOT, "tools", "scratch_check.py"))
+    sc = importlib.util.module_from_spec(spec); spec.loader.exec_module(sc)
+    if not os.path.exists(sc.READELF):
+        pytest.skip("llvm-readelf of the ROCm toolchain not found")
+    ks = sc.kernels()
+    assert len(ks) > 150, "the code object's kernel records were not found"
+    # (SGPR spills go to VGPR lanes, not to memory: they are not scratch)
+    bad = {k: v for k, v in ks.items() if v["scratch"] or v["vgpr_spill"]}
+    assert not bad, bad

@@ -608,7 +608,7 @@ def test_launch_shape_knobs_do_not_change_results(ctx, port, tail_bits):
         # every launch shape the default build carries (slice size x unroll x nt x workgroup size) x launch windows
         shapes = [(8, 4, 1, wg, win) for wg in (256, 384, 512, 640, 768) for win in (0, -1, 3)]
         shapes += [(rows, u, 1, 256, win) for rows in (4, 2, 1) for u in (4, 8) for win in (0, -1)]
-        shapes += [(rows, 4, 0, 256, 0) for rows in (8, 4, 2, 1)] + [(8, 4, 0, 640, 0), (0, 0, 1, 0, 0), (0, 0, 1, 0, 2)]
+        shapes += [(rows, 4, 0, 256, 0) for rows in (8, 4, 2, 1)] + [(8, 4, 0, 512, 0), (0, 0, 0, 0, 0), (0, 0, 1, 0, 0), (0, 0, 1, 0, 2)]
         ctx.set_tuning("pipe_staged", 0)                        # many groups over few vectors would pick the LDS-staged kernel
         for rows, u, nt, wg, win in shapes:
             for swz in (1, 0):
