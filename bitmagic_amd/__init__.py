@@ -467,12 +467,20 @@ class pipeline:
         run walks the block columns in ascending launch windows and stops launching once every group has enough"""
         self.search_count_limit = limit
         if self._h:
-            check(lib().bmx_pipeline_set_search_count_limit(self.ctx._h, self._h, min(int(limit), ID_MAX64)))
+            # (bm::id_max = "no limit", as at construction: the library maps 0 / id_max / the 48-bit id_max to one plain run)
+            check(lib().bmx_pipeline_set_search_count_limit(self.ctx._h, self._h, 0 if limit in (ID_MAX, ID_MAX64) else min(int(limit), ID_MAX64)))
 
     def last_windows(self):
         a, b = C.c_uint32(), C.c_uint32()
         check(lib().bmx_pipeline_last_windows(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
+
+    def last_window_groups(self) -> list:
+        """arg-groups every launched window of the last counts run under a search limit ran over"""
+        n = C.c_uint32()
+        out = (C.c_uint32 * 64)()
+        check(lib().bmx_pipeline_last_window_groups(self._h, out, 64, C.byref(n)))
+        return [int(out[i]) for i in range(min(n.value, 64))]
 
     def get_bv_res_vector(self) -> list:
         return self._results

@@ -90,6 +90,7 @@ def lib() -> C.CDLL:
         "bmx_pipeline_destroy": (i32, [vp, vp]),
         "bmx_pipeline_set_search_count_limit": (i32, [vp, vp, u64]),
         "bmx_pipeline_last_windows": (i32, [vp, P(u32), P(u32)]),
+        "bmx_pipeline_last_window_groups": (i32, [vp, P(u32), u32, P(u32)]),
         "bmx_pipeline_run_counts": (i32, [vp, vp, u32, u32, P(u64)]),
         "bmx_pipeline_run_counts_dev": (i32, [vp, vp, u32, u32, vp]),
         "bmx_pipeline_run_results": (i32, [vp, vp, P(vp), P(u64), vp, P(vp)]),

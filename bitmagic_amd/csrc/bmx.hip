@@ -519,7 +519,7 @@ static void pipe_plan(const bmx_ctx* ctx, u64 nitems, u32 ngroups, u32& rows, u3
 {
     rows = (u32)ctx->pipe_rows;
     if (!rows) rows = nitems >= 1400u ? 8u : nitems >= 700u ? 4u : nitems >= 350u ? 2u : 1u;
-    unroll = ctx->pipe_unroll ? (u32)ctx->pipe_unroll : (rows >= 4u ? 4u : 8u);
+    unroll = ctx->pipe_unroll ? (u32)ctx->pipe_unroll : ((rows >= 4u || !ctx->pipe_nt) ? 4u : 8u);      // (plain loads: four slices in flight is the only compiled shape)
     u64 n = nitems * (8u / rows);
     wg = (u32)ctx->pipe_wg;
     if (!wg) {
@@ -1349,7 +1349,7 @@ int bmx_pipeline_create(bmx_ctx* ctx, const bmx_vec* const* and_list, const uint
     bmx_pipeline* p = new (std::nothrow) bmx_pipeline();
     if (!p) return BMX_ERR_BADALLOC;
     memset(p, 0, sizeof(*p));
-    p->search_limit = ~0ull; p->cm_gen = ~0ull;               // (the memset above wiped the member initialisers)
+    p->search_limit = ~0ull; p->cm_gen = ~0ull; p->cm_tried_gen = ~0ull - 1;     // (the memset above wiped the member initialisers)
     p->ctx = ctx; p->ngroups = (uint32_t)ngroups; p->ncols = ncols; p->col_stride = col_stride; p->n_ops = (uint32_t)n_ops; p->has_gap = has_gap; p->has_bit = has_bit; p->gap_avg_words = gap_blocks_sum ? (uint32_t)(gap_words_sum / gap_blocks_sum) : 0u;
     p->nbits = max_bits;
     p->h_row_off = new std::vector<u32>(row_off, row_off + ngroups);
@@ -1432,7 +1432,7 @@ int bmx_pipeline_destroy(bmx_ctx* ctx, bmx_pipeline* p)
     dfree(ctx, p->d_dmat); dfree(ctx, p->d_meta); dfree(ctx, (void*)p->d_descs);
     dfree(ctx, (void*)p->d_udesc); dfree(ctx, p->d_unblk); dfree(ctx, p->d_gmask); dfree(ctx, p->d_gskip);
     dfree(ctx, p->cm_buf);
-    delete p->h_row_off; delete p->h_and_n; delete p->h_sub_n; delete p->h_uids;
+    delete p->h_row_off; delete p->h_and_n; delete p->h_sub_n; delete p->h_uids; delete p->h_win_groups; delete p->h_stop;
     delete p;
     return BMX_OK;
 }
@@ -1511,9 +1511,13 @@ static int pipe_resolve_colls(bmx_ctx* ctx, bmx_pipeline* p, bool may_build, bmx
     if (!p->h_uids || ctx->gap_pack == 0) return BMX_OK;
     size_t tot_and = 0, tot_sub = 0;
     for (u32 g = 0; g < p->ngroups; ++g) { tot_and += (*p->h_and_n)[g]; tot_sub += (*p->h_sub_n)[g]; }
-    if (p->cm_gen != ctx->coll_gen || (may_build && ctx->gap_pack == 1 && !p->cm_a_id)) {
+    if (p->cm_gen != ctx->coll_gen || (may_build && ctx->gap_pack == 1 && !p->cm_a_id && p->cm_tried_gen != ctx->coll_gen)) {
         int rc;
-        if (p->cm_buf) { HIPCHK(hipStreamSynchronize(ctx->stream)); dfree(ctx, p->cm_buf); p->cm_buf = nullptr; }
+        // (no synchronise: a pooled block is only ever handed to work enqueued behind its last reader on this stream, see dfree --
+        // the asynchronous entry must not block the host here; a build that was refused is not attempted again until a collection
+        // appears or goes)
+        if (p->cm_buf) { dfree(ctx, p->cm_buf); p->cm_buf = nullptr; }
+        if (may_build && ctx->gap_pack == 1) p->cm_tried_gen = ~0ull;
         p->cm_a_id = p->cm_s_id = 0; p->cm_full = false;
         std::vector<u32> ma, ms; bool fa = false, fs = true;
         const uint64_t* uids = p->h_uids->data();
@@ -1534,6 +1538,7 @@ static int pipe_resolve_colls(bmx_ctx* ctx, bmx_pipeline* p, bool may_build, bmx
             }
         }
         p->cm_gen = ctx->coll_gen;
+        if (may_build && ctx->gap_pack == 1) p->cm_tried_gen = ctx->coll_gen;
         const bool whole = p->ngroups == 1 && fa && (!tot_sub || fs);
         if (ca && !whole && !coll_members_wanted(ctx, (uint64_t)p->gap_avg_words, 1, p->n_ops, p->ngroups)) ca = nullptr;      // (the table kernels serve these groups better)
         if (ca && (!tot_sub || cs)) {
@@ -1563,7 +1568,9 @@ static int pipe_resolve_colls(bmx_ctx* ctx, bmx_pipeline* p, bool may_build, bmx
     return BMX_OK;
 }
 
-static int pipeline_run_counts_impl(bmx_ctx* ctx, bmx_pipeline* p, uint32_t nb_from, uint32_t nb_to, uint64_t* d_counts, bool may_build);
+// a subset of a pipeline's arg-groups for one counts launch: the compacted per-group tables k_limit_step wrote
+struct GroupView { const u32* row_off; const u32* and_n; const u32* sub_n; u32 ngroups; const u32* gmask; const u32* gskip; const CollGroup* cgroups; };
+static int pipeline_run_counts_impl(bmx_ctx* ctx, bmx_pipeline* p, uint32_t nb_from, uint32_t nb_to, uint64_t* d_counts, bool may_build, const GroupView* gv = nullptr);
 
 extern "C" {
 
@@ -1572,22 +1579,25 @@ int bmx_pipeline_run_counts_dev(bmx_ctx* ctx, bmx_pipeline* p, uint32_t nb_from,
     return pipeline_run_counts_impl(ctx, p, nb_from, nb_to, d_counts, false);
 }
 
-static int pipeline_run_counts_impl(bmx_ctx* ctx, bmx_pipeline* p, uint32_t nb_from, uint32_t nb_to, uint64_t* d_counts, bool may_build)
+static int pipeline_run_counts_impl(bmx_ctx* ctx, bmx_pipeline* p, uint32_t nb_from, uint32_t nb_to, uint64_t* d_counts, bool may_build, const GroupView* gv)
 {
     ARGCHK(ctx && p && p->ctx == ctx && d_counts);
     int rc = set_dev(ctx); if (rc) return rc;
     if ((rc = pipe_range(p, nb_from, nb_to))) return rc;
-    HIPCHK(hipMemsetAsync(d_counts, 0, (size_t)p->ngroups * 8, ctx->stream));
-    u64 nitems64 = (u64)(nb_to - nb_from) * p->ngroups;
+    // gv: the run covers gv->ngroups arg-groups of the pipeline (those still below their search limit); counts[k] belongs to the
+    // k-th of them.  The kernel is chosen as for the whole pipeline.
+    const u32 ngroups = gv ? gv->ngroups : p->ngroups;
+    HIPCHK(hipMemsetAsync(d_counts, 0, (size_t)std::max(ngroups, 1u) * 8, ctx->stream));
+    u64 nitems64 = (u64)(nb_to - nb_from) * ngroups;
     if (!nitems64) return BMX_OK;
-    const u32* row_off = p->d_meta; const u32* and_n = p->d_meta + p->ngroups; const u32* sub_n = p->d_meta + 2 * p->ngroups;
+    const u32* row_off = gv ? gv->row_off : p->d_meta; const u32* and_n = gv ? gv->and_n : p->d_meta + p->ngroups; const u32* sub_n = gv ? gv->sub_n : p->d_meta + 2 * p->ngroups;
     if (p->h_uids) {
         // GAP-only operands held by packed collections: the column regions of the collections instead of the operands' slabs
         bmx_coll *ca = nullptr, *cs = nullptr;
         if ((rc = pipe_resolve_colls(ctx, p, may_build, &ca, &cs))) return rc;
         if (ca && p->cm_full) return coll_launch(COLL_AND_COUNT, ctx, ca, cs, nb_from, nb_to, 1, (u64*)d_counts, nullptr, nullptr, 0u, 0xFFFFFFFFu);
-        if (ca) return coll_members_launch(CM_AND_COUNT, ctx, ca, cs, (const u32*)p->cm_buf, (const CollGroup*)((const char*)p->cm_buf + p->cm_groups_off),
-                                           p->ngroups, nb_from, nb_to, 1, (u64*)d_counts, nullptr, nullptr);
+        if (ca) return coll_members_launch(CM_AND_COUNT, ctx, ca, cs, (const u32*)p->cm_buf, gv ? gv->cgroups : (const CollGroup*)((const char*)p->cm_buf + p->cm_groups_off),
+                                           ngroups, nb_from, nb_to, 1, (u64*)d_counts, nullptr, nullptr);
     }
     {
         // many groups over few distinct vectors: every plane block is re-used >= 8 times per column
@@ -1598,8 +1608,8 @@ static int pipeline_run_counts_impl(bmx_ctx* ctx, bmx_pipeline* p, uint32_t nb_f
 #define LAUNCH_STG(S) do { \
             HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pipe_counts_staged<S>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pipe_counts_staged<S>), dim3(nb_to - nb_from), dim3(S * 64), lds, ctx->stream, \
-                               (const u64* const*)p->d_udesc, (const u32*)p->d_unblk, p->nplanes, (const u32*)p->d_gmask, (const u32*)p->d_gskip, \
-                               p->ngroups, nb_from, nb_to - nb_from, ctx->xcd_swz, (u64*)d_counts); } while (0)
+                               (const u64* const*)p->d_udesc, (const u32*)p->d_unblk, p->nplanes, gv ? gv->gmask : (const u32*)p->d_gmask, gv ? gv->gskip : (const u32*)p->d_gskip, \
+                               ngroups, nb_from, nb_to - nb_from, ctx->xcd_swz, (u64*)d_counts); } while (0)
             if (ctx->pipe_slots == 8) LAUNCH_STG(8); else LAUNCH_STG(16);
 #undef LAUNCH_STG
             KCHK();
@@ -1612,7 +1622,7 @@ static int pipeline_run_counts_impl(bmx_ctx* ctx, bmx_pipeline* p, uint32_t nb_f
         auto fn = k_pipe_split<2, SPLIT_WAVES>;
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(fn, dim3((u32)nitems64), dim3(SPLIT_WAVES * 64), lds, ctx->stream,
-                           (const u64*)p->d_dmat, row_off, and_n, sub_n, p->col_stride, p->ngroups, nb_from, nb_to, 0, (u64*)d_counts,
+                           (const u64*)p->d_dmat, row_off, and_n, sub_n, p->col_stride, ngroups, nb_from, nb_to, 0, (u64*)d_counts,
                            0, (uint4*)nullptr, (u64*)nullptr, (BlockStat*)nullptr);
         KCHK();
         return BMX_OK;
@@ -1626,7 +1636,7 @@ static int pipeline_run_counts_impl(bmx_ctx* ctx, bmx_pipeline* p, uint32_t nb_f
         // into after its first round of workgroups (measured: +5 % on the headline, tools/chunk_probe.py; a
         // 1,908-column shard = one window runs at a higher rate than the full-size steady state).
         u32 rows, wg, unroll, window;
-        pipe_plan(ctx, nitems64, p->ngroups, rows, wg, unroll, window);
+        pipe_plan(ctx, nitems64, ngroups, rows, wg, unroll, window);
         u32 parts = 8u / rows;
         if (nitems64 * parts > 0xFFFFFFF0ull) { g_last_error = "too many work items in one run"; return BMX_ERR_RANGE; }
         pipe_bits_fn fn = pipe_bits_kernel(rows, unroll, ctx->pipe_nt != 0, wg);
@@ -1637,9 +1647,9 @@ static int pipeline_run_counts_impl(bmx_ctx* ctx, bmx_pipeline* p, uint32_t nb_f
         u32 per = (ncols + nwin - 1u) / nwin;                      // even split: no short last window
         for (u32 c0 = 0; c0 < ncols; c0 += per) {
             u32 cols = std::min(per, ncols - c0);
-            u32 nitems = cols * p->ngroups * parts, grid = (nitems + wpb - 1) / wpb;
+            u32 nitems = cols * ngroups * parts, grid = (nitems + wpb - 1) / wpb;
             hipLaunchKernelGGL(fn, dim3(grid), dim3(wg), (size_t)ctx->pipe_lds, ctx->stream,
-                               (const u64*)p->d_dmat, row_off, and_n, p->col_stride, p->ngroups, nb_from + c0, nitems, ctx->xcd_swz, (u64*)d_counts);
+                               (const u64*)p->d_dmat, row_off, and_n, p->col_stride, ngroups, nb_from + c0, nitems, ctx->xcd_swz, (u64*)d_counts);
             KCHK();
         }
         return BMX_OK;
@@ -1648,7 +1658,7 @@ static int pipeline_run_counts_impl(bmx_ctx* ctx, bmx_pipeline* p, uint32_t nb_f
     if (use_and_rows(ctx, p)) {
         // every operand block is GAP (or NULL / FULL): the union of the operands' 0-runs read straight from their slabs
         hipLaunchKernelGGL(and_rows_kernel<AR_COUNT>(ctx), dim3((u32)nitems64), dim3((u32)ctx->and_rows_wg), 0, ctx->stream,
-                           (const u64*)p->d_dmat, row_off, and_n, sub_n, p->col_stride, p->ngroups, nb_from, (u32)nitems64, ctx->xcd_swz, (u64*)d_counts,
+                           (const u64*)p->d_dmat, row_off, and_n, sub_n, p->col_stride, ngroups, nb_from, (u32)nitems64, ctx->xcd_swz, (u64*)d_counts,
                            (uint4*)nullptr, (u64*)nullptr, (BlockStat*)nullptr, 0u, 0xFFFFFFFFu, and_rows_diag_bits());
         KCHK();
         return BMX_OK;
@@ -1658,7 +1668,7 @@ static int pipeline_run_counts_impl(bmx_ctx* ctx, bmx_pipeline* p, uint32_t nb_f
         size_t lds = (size_t)(16384 * 2 + 2048) * 4;
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_pipe_counts_gapcount<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pipe_counts_gapcount<false>), dim3((u32)nitems64), dim3(1024), lds, ctx->stream,
-                           p->d_dmat, row_off, and_n, sub_n, p->col_stride, p->ngroups, nb_from, (u32)nitems64, (u64*)d_counts,
+                           p->d_dmat, row_off, and_n, sub_n, p->col_stride, ngroups, nb_from, (u32)nitems64, (u64*)d_counts,
                            (uint4*)nullptr, (u64*)nullptr, (BlockStat*)nullptr, 0u, 0xFFFFFFFFu);
         KCHK();
         return BMX_OK;
@@ -1673,10 +1683,10 @@ static int pipeline_run_counts_impl(bmx_ctx* ctx, bmx_pipeline* p, uint32_t nb_f
     u32 per = (ncols + nwin - 1u) / nwin;
     for (u32 c0 = 0; c0 < ncols; c0 += per) {
         u32 cols = std::min(per, ncols - c0);
-        u32 nitems = cols * p->ngroups;
+        u32 nitems = cols * ngroups;
         u32 grid = (nitems + 3) / 4;
 #define LAUNCH_PIPE(U) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_pipe_counts<U>), dim3(grid), dim3(256), lds, ctx->stream, \
-        p->d_dmat, row_off, and_n, sub_n, p->col_stride, p->ngroups, nb_from + c0, nitems, ctx->xcd_swz, (u64*)d_counts)
+        p->d_dmat, row_off, and_n, sub_n, p->col_stride, ngroups, nb_from + c0, nitems, ctx->xcd_swz, (u64*)d_counts)
         switch (ctx->pipe_unroll) {
         case 1: LAUNCH_PIPE(1); break;
         case 2: LAUNCH_PIPE(2); break;
@@ -1724,7 +1734,8 @@ int bmx_pipeline_describe(bmx_ctx* ctx, bmx_pipeline* p, uint32_t nb_from, uint3
 int bmx_pipeline_set_search_count_limit(bmx_ctx* ctx, bmx_pipeline* p, uint64_t limit)
 {
     ARGCHK(ctx && p && p->ctx == ctx);
-    p->search_limit = limit ? limit : ~0ull;
+    // 0, bm::id_max and the 48-bit id_max all mean "no limit" (the reference's default is id_max, src/bmaggregator.h:338)
+    p->search_limit = (limit == 0 || limit == 0xFFFFFFFFull || limit == 0xFFFFFFFFFFFFull) ? ~0ull : limit;
     return BMX_OK;
 }
 
@@ -1736,45 +1747,102 @@ int bmx_pipeline_last_windows(const bmx_pipeline* p, uint32_t* launched, uint32_
     return BMX_OK;
 }
 
+} // extern "C"
+
+// The counts run under pipeline::set_search_count_limit (src/bmaggregator.h:255, honoured PER ARG-GROUP at :1362-1367: a group
+// whose count has reached the limit is skipped on every following block -- "can find more, cannot find less").  Here: ascending
+// launch windows of block columns (each 4 x the one before, as find_first_and_sub walks them); the per-group totals stay on the
+// device; after a window k_limit_step (bmx_kernels9.h) drops the groups that have enough from the tables the next window is
+// launched over and writes the number of groups left into pinned memory -- the one word the host waits for.  A group returns
+// >= min(limit, its true count) and never more than its true count; h_stop[g] = the column at which it stopped.
+static int limit_counts_run(bmx_ctx* ctx, bmx_pipeline* p, uint32_t nb_from, uint32_t nb_to, uint64_t* counts_out)
+{
+    int rc;
+    uint32_t f = nb_from, t = nb_to;
+    if ((rc = pipe_range(p, f, t))) return rc;
+    const u32 ng = p->ngroups, ncols = t - f;
+    if (!p->h_win_groups) p->h_win_groups = new std::vector<uint32_t>();
+    if (!p->h_stop) p->h_stop = new std::vector<uint32_t>();
+    p->h_win_groups->clear(); p->h_stop->assign(ng, 0xFFFFFFFFu);
+    u32 w = std::max<u32>(ncols / 64u, 16u), planned = 0;
+    for (u32 c = 0, ww = w; c < ncols; c += ww, ww *= 4u) ++planned;
+    p->last_windows_planned = std::max(planned, 1u); p->last_windows = 0;
+    if (counts_out) for (u32 g = 0; g < ng; ++g) counts_out[g] = 0;
+    if (!ncols) return BMX_OK;
+    // collections / staged tables in force (resolved once, before the first window)
+    bmx_coll *ca = nullptr, *cs = nullptr;
+    if (p->h_uids && (rc = pipe_resolve_colls(ctx, p, true, &ca, &cs))) return rc;
+    const bool have_cg = ca && !p->cm_full && p->cm_buf;
+    const bool have_masks = p->staged_ok && p->d_gmask && p->d_gskip;
+    const size_t nch = std::max<u32>(p->nchunks, 1u);
+    // device state: totals, the window's compact counts, stop columns, two active lists, the compacted tables
+    const size_t words = (size_t)ng * (2 + 2 + 1 + 2 + 3 + (have_cg ? 4 : 0) + (have_masks ? nch + 1 : 0)) + 16;
+    u32* buf = nullptr;
+    if ((rc = dmalloc(ctx, (void**)&buf, words * 4))) return rc;
+    u64* d_tot = (u64*)buf; u64* d_cc = d_tot + ng;
+    u32* d_stop = (u32*)(d_cc + ng); u32* d_act[2] = {d_stop + ng, d_stop + 2 * (size_t)ng};
+    u32* d_ro = d_act[1] + ng; u32* d_an = d_ro + ng; u32* d_sn = d_an + ng;
+    u32* q = d_sn + ng;
+    q = (u32*)(((uintptr_t)q + 15u) & ~(uintptr_t)15u);
+    CollGroup* d_cg = nullptr; u32* d_gm = nullptr; u32* d_gs = nullptr;
+    if (have_cg) { d_cg = (CollGroup*)q; q += (size_t)ng * 4; }
+    if (have_masks) { d_gm = q; q += (size_t)ng * nch; d_gs = q; q += ng; }
+    u32* d_nact = q;
+    hipError_t e = hipMemsetAsync(d_tot, 0, (size_t)ng * 8, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(d_stop, 0xFF, (size_t)ng * 4, ctx->stream);
+    if (e != hipSuccess) { dfree(ctx, buf); return fail_hip(e, "limit_counts_run", __LINE__); }
+    LimitTables lt{p->d_meta, p->d_meta + ng, p->d_meta + 2 * (size_t)ng, d_ro, d_an, d_sn,
+                   have_cg ? (const CollGroup*)((const char*)p->cm_buf + p->cm_groups_off) : nullptr, d_cg,
+                   have_masks ? (const u32*)p->d_gmask : nullptr, have_masks ? (const u32*)p->d_gskip : nullptr, d_gm, d_gs, (u32)nch};
+    GroupView gv{d_ro, d_an, d_sn, ng, d_gm, d_gs, d_cg};
+    u32 n_active = ng; int cur = 0; bool first = true;
+    for (u32 c = 0; c < ncols && n_active && !rc; c += w, w *= 4u) {
+        const u32 c1 = (u32)std::min<u64>((u64)c + w, ncols);
+        gv.ngroups = n_active;
+        rc = pipeline_run_counts_impl(ctx, p, f + c, f + c1, d_cc, false, first ? nullptr : &gv);
+        if (rc) break;
+        hipLaunchKernelGGL(k_limit_step, dim3(1), dim3(1024), 0, ctx->stream, d_tot, (const u64*)d_cc, first ? (const u32*)nullptr : (const u32*)d_act[cur], n_active,
+                           p->search_limit, f + c1, d_stop, d_act[cur ^ 1], lt, d_nact, ctx->h_small + 60);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);        // (the word in pinned memory is all the host reads)
+        if (e != hipSuccess) { rc = fail_hip(e, "k_limit_step", __LINE__); break; }
+        p->h_win_groups->push_back(n_active);
+        ++p->last_windows;
+        n_active = (u32)ctx->h_small[60];
+        cur ^= 1; first = false;
+    }
+    if (!rc) {
+        e = hipMemcpyAsync(p->h_stop->data(), d_stop, (size_t)ng * 4, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess && counts_out) e = hipMemcpyAsync(counts_out, d_tot, (size_t)ng * 8, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) rc = fail_hip(e, "limit_counts_run readback", __LINE__);
+    } else (void)hipStreamSynchronize(ctx->stream);
+    dfree(ctx, buf);
+    return rc;
+}
+
+extern "C" {
+
+// groups every launched window of the last synchronous counts run under a limit ran over (out[0 .. min(cap, n))), n = windows launched
+int bmx_pipeline_last_window_groups(const bmx_pipeline* p, uint32_t* out, uint32_t cap, uint32_t* n)
+{
+    ARGCHK(p && (out || !cap));
+    const uint32_t have = p->h_win_groups ? (uint32_t)p->h_win_groups->size() : 0u;
+    for (uint32_t i = 0; i < have && i < cap; ++i) out[i] = (*p->h_win_groups)[i];
+    if (n) *n = have;
+    return BMX_OK;
+}
+
 int bmx_pipeline_run_counts(bmx_ctx* ctx, bmx_pipeline* p, uint32_t nb_from, uint32_t nb_to, uint64_t* counts_out)
 {
     ARGCHK(ctx && p && p->ctx == ctx && counts_out);
     int rc = set_dev(ctx); if (rc) return rc;
+    p->last_windows = p->last_windows_planned = 1;
+    if (p->search_limit != ~0ull) return limit_counts_run(ctx, p, nb_from, nb_to, counts_out);
     u64* d_counts = nullptr;
     size_t bytes = (size_t)p->ngroups * 8;
     if (p->ngroups <= 64) d_counts = ctx->d_small;
     else if ((rc = dmalloc(ctx, (void**)&d_counts, bytes))) return rc;
-    p->last_windows = p->last_windows_planned = 1;
-    if (p->search_limit != ~0ull) {
-        // set_search_count_limit (:255, honoured at :1365: a group whose count has reached the limit is not evaluated on the
-        // following blocks -- "can find more, cannot find less").  Here: ascending launch windows of block columns (as
-        // find_first_and_sub walks them), the counts read back after each; once EVERY group holds >= limit hits the remaining
-        // windows are not launched.  A group returns >= min(limit, its true count) and never more than its true count.
-        uint32_t f = nb_from, t = nb_to;
-        if ((rc = pipe_range(p, f, t))) { if (p->ngroups > 64) dfree(ctx, d_counts); return rc; }
-        std::vector<uint64_t> part(p->ngroups);
-        for (u32 g = 0; g < p->ngroups; ++g) counts_out[g] = 0;
-        const u32 ncols = t - f;
-        u32 w = std::max<u32>(ncols / 64u, 16u), planned = 0;
-        for (u32 c = 0, ww = w; c < ncols; c += ww, ww *= 4u) ++planned;
-        p->last_windows_planned = planned; p->last_windows = 0;
-        for (u32 c = 0; c < ncols && !rc; c += w, w *= 4u) {
-            const u32 c1 = (u32)std::min<u64>((u64)c + w, ncols);
-            rc = pipeline_run_counts_impl(ctx, p, f + c, f + c1, d_counts, p->last_windows == 0);
-            if (!rc) {
-                hipError_t e = hipMemcpyAsync(part.data(), d_counts, bytes, hipMemcpyDeviceToHost, ctx->stream);
-                if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-                if (e != hipSuccess) rc = fail_hip(e, "counts readback", __LINE__);
-            }
-            if (rc) break;
-            ++p->last_windows;
-            bool all = true;
-            for (u32 g = 0; g < p->ngroups; ++g) { counts_out[g] += part[g]; all = all && counts_out[g] >= p->search_limit; }
-            if (all) break;
-        }
-        if (p->ngroups > 64) dfree(ctx, d_counts);
-        return rc;
-    }
     rc = pipeline_run_counts_impl(ctx, p, nb_from, nb_to, d_counts, true);
     if (!rc) {
         hipError_t e = hipMemcpyAsync(counts_out, d_counts, bytes, hipMemcpyDeviceToHost, ctx->stream);
@@ -2727,9 +2795,16 @@ static int run_results_impl(bmx_ctx* ctx, bmx_pipeline* p, uint32_t nb_from, uin
     int rc = set_dev(ctx); if (rc) return rc;
     std::vector<bmx_vec*> res(p->ngroups, nullptr);
     auto cleanup = [&]() { for (bmx_vec* r : res) if (r) bmx_vec_free(ctx, r); };
+    // set_search_count_limit applies whenever counts are computed, result vectors included (the test at src/bmaggregator.h:1362
+    // sits in front of both branches): a counts run under the limit finds the column at which every group has enough, and the
+    // group's vector is produced up to there -- its count is >= min(limit, true count), bits beyond are not searched
+    const bool limited = counts_out && p->search_limit != ~0ull;
+    if (limited && (rc = limit_counts_run(ctx, p, nb_from, nb_to, nullptr))) return rc;
+    const uint32_t nb_to_all = nb_to;
     for (uint32_t g = 0; g < p->ngroups; ++g) {
         if (counts_out) counts_out[g] = 0;
         if (!(*p->h_and_n)[g] || !p->ncols) continue;                       // empty AND group: skipped (:1352)
+        nb_to = limited ? std::min(nb_to_all, (*p->h_stop)[g]) : nb_to_all;
         bmx_vec* v; BlockStat* st; u32* offs;
         if ((rc = result_begin(ctx, p->nbits, p->ncols, &v, &st, &offs))) { cleanup(); return rc; }
         bmx_coll *ca = nullptr, *cs = nullptr;

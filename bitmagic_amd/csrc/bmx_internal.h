@@ -132,8 +132,11 @@ struct bmx_pipeline {
     // vector freed before the pipeline is simply not found in any collection any more -- and what they resolved to
     uint64_t search_limit = ~0ull;       // pipeline::set_search_count_limit (src/bmaggregator.h:255): a group needs no more than this many hits
     uint32_t last_windows = 0, last_windows_planned = 0;   // launch windows of the last synchronous counts run under a limit
+    std::vector<uint32_t>* h_win_groups = nullptr;        // ... and the arg-groups every launched window ran over
+    std::vector<uint32_t>* h_stop = nullptr;              // ... and, per group, the block column at which it reached the limit (0xFFFFFFFF: never)
     std::vector<uint64_t>* h_uids = nullptr;
     uint64_t cm_gen = ~0ull;            // ctx->coll_gen at the last resolution
+    uint64_t cm_tried_gen = ~0ull - 1;  // ctx->coll_gen after the last attempt to build the group's collections (gap_pack 1): not retried until it changes
     uint64_t cm_a_id = 0, cm_s_id = 0;  // collections serving the AND lists / SUB lists (0 = none)
     bool cm_full = false;               // one group whose lists name their whole collections: the streaming kernel
     void* cm_buf = nullptr;             // device: member indices + CollGroup[ngroups]

@@ -244,3 +244,61 @@ void k_agg_and_rows(const u64* __restrict__ dmat, const u32* __restrict__ row_of
     __syncthreads();
     if (wave == 0) { Blk b; blk_from_lds(b, U, lane); store_result(b, col, 1, slab, desc, st, lane); }
 }
+
+// ---------------------------------------------------------------------------
+// pipeline::set_search_count_limit (src/bmaggregator.h:255, honoured per arg-group at :1362-1367: a group whose count has
+// reached the limit is not evaluated on the following blocks).  The counts run walks ascending windows of block columns; after
+// each window this one-workgroup kernel folds the window's compact counts into the per-group totals, notes the window at
+// whose end a group reached the limit (stop[]: a results run truncates the group's vector there) and COMPACTS the groups
+// that still need hits -- their ids and their rows of every per-group table the counts kernels read (row offsets, operand
+// counts, collection member ranges, plane masks) -- so that the next window is launched over those groups only.  The number
+// of groups left goes to pinned host memory: the host decides the next launch from that word, the counts stay on the device.
+// ---------------------------------------------------------------------------
+struct LimitTables {
+    const u32* row_off; const u32* and_n; const u32* sub_n;           // the pipeline's full tables (indexed by group)
+    u32* ro; u32* an; u32* sn;                                        // the compacted ones (indexed by position in `active`)
+    const CollGroup* cg_in; CollGroup* cg_out;                        // member ranges of groups served by packed collections (or null)
+    const u32* gmask_in; const u32* gskip_in; u32* gmask_out; u32* gskip_out; u32 nchunks;   // LDS-staged kernel: plane masks (or null)
+};
+
+__global__ __launch_bounds__(1024)
+void k_limit_step(u64* __restrict__ totals, const u64* __restrict__ cc, const u32* __restrict__ active_in /* null: every group */, u32 n_in,
+                  u64 limit, u32 win_end, u32* __restrict__ stop, u32* __restrict__ active_out, LimitTables t,
+                  u32* __restrict__ n_active_dev, u64* __restrict__ n_active_host)
+{
+    __shared__ u32 wsum[16];
+    __shared__ u32 base;
+    const u32 tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    if (tid == 0) base = 0u;
+    __syncthreads();
+    for (u32 i0 = 0; i0 < n_in; i0 += 1024u) {
+        const u32 i = i0 + tid;
+        bool keep = false; u32 g = 0u;
+        if (i < n_in) {
+            g = active_in ? active_in[i] : i;
+            const u64 c = totals[g] + cc[i];
+            totals[g] = c;
+            keep = c < limit;
+            if (!keep && stop[g] == 0xFFFFFFFFu) stop[g] = win_end;
+        }
+        const u64 m = __ballot(keep);
+        if (lane == 0) wsum[wave] = (u32)__popcll(m);
+        __syncthreads();
+        u32 off = base;
+        for (u32 w = 0; w < wave; ++w) off += wsum[w];
+        if (keep) {
+            const u32 pos = off + (u32)__builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u));
+            active_out[pos] = g;
+            t.ro[pos] = t.row_off[g]; t.an[pos] = t.and_n[g]; t.sn[pos] = t.sub_n[g];
+            if (t.cg_in) t.cg_out[pos] = t.cg_in[g];
+            if (t.gmask_in) {
+                for (u32 k = 0; k < t.nchunks; ++k) t.gmask_out[(size_t)pos * t.nchunks + k] = t.gmask_in[(size_t)g * t.nchunks + k];
+                t.gskip_out[pos] = t.gskip_in[g];
+            }
+        }
+        __syncthreads();
+        if (tid == 0) { u32 s = 0; for (u32 w = 0; w < 16u; ++w) s += wsum[w]; base += s; }
+        __syncthreads();
+    }
+    if (tid == 0) { *n_active_dev = base; *n_active_host = (u64)base; }
+}

@@ -287,14 +287,21 @@ int bmx_pipeline_destroy(bmx_ctx* ctx, bmx_pipeline* p);
  * to block columns [nb_from, nb_to) (nb_to = UINT32_MAX: all).  Synchronous. */
 int bmx_pipeline_run_counts(bmx_ctx* ctx, bmx_pipeline* p, uint32_t nb_from, uint32_t nb_to,
                             uint64_t* counts_out);
-/* pipeline::set_search_count_limit  src/bmaggregator.h:255, honoured at :1365: a group whose count has reached `limit` is not
- * evaluated on the blocks that follow ("can find more, cannot find less": top-k searches stop paying once they have enough).
- * bmx_pipeline_run_counts then walks the block columns in ascending launch windows (each 4 x the one before), reads the counts
- * back after every window and does not launch the remaining ones once EVERY group holds >= limit hits: counts_out[g] is
- * >= min(limit, the group's true count) and <= the true count.  limit 0 / UINT64_MAX = no limit (one run).
- * bmx_pipeline_last_windows: windows launched / planned by the last synchronous counts run. */
+/* pipeline::set_search_count_limit  src/bmaggregator.h:255, honoured PER ARG-GROUP at :1362-1367: a group whose count has
+ * reached `limit` is not evaluated on the blocks that follow ("can find more, cannot find less": top-k searches stop paying
+ * once they have enough).  bmx_pipeline_run_counts then walks the block columns in ascending launch windows (each 4 x the one
+ * before); the per-group totals stay on the device, and after every window the groups that have enough are DROPPED from the
+ * tables the next window is launched over (one word -- the number of groups left -- is what the host waits for): a later
+ * window runs over the groups that still need hits only, and no window is launched once none is left.  counts_out[g] is
+ * >= min(limit, the group's true count) and <= the true count.  limit 0 / bm::id_max (2^32 - 1, 2^48 - 1) / UINT64_MAX = no
+ * limit (one run).  As in the reference the limit applies whenever counts are computed: bmx_pipeline_run_results* with
+ * counts_out != NULL produces a group's vector up to the window at whose end the group had enough (its count is then
+ * >= min(limit, true count)); result-only runs ignore it.  bmx_pipeline_run_counts_dev (asynchronous) ignores it.
+ * bmx_pipeline_last_windows: windows launched / planned by the last synchronous counts run;
+ * bmx_pipeline_last_window_groups: out[w] = arg-groups window w of that run ran over (n = windows launched). */
 int bmx_pipeline_set_search_count_limit(bmx_ctx* ctx, bmx_pipeline* p, uint64_t limit);
 int bmx_pipeline_last_windows(const bmx_pipeline* p, uint32_t* launched, uint32_t* planned);
+int bmx_pipeline_last_window_groups(const bmx_pipeline* p, uint32_t* out, uint32_t cap, uint32_t* n);
 /* Same, asynchronous on the context's stream; d_counts is DEVICE memory
  * (ngroups x uint64) -- e.g. the buffer a following RCCL all-reduce sums. */
 int bmx_pipeline_run_counts_dev(bmx_ctx* ctx, bmx_pipeline* p, uint32_t nb_from, uint32_t nb_to,
@@ -305,7 +312,8 @@ int bmx_pipeline_run_counts_dev(bmx_ctx* ctx, bmx_pipeline* p, uint32_t nb_from,
  *   counts_out  != NULL  -> Opt::is_compute_counts()
  *   or_target_out != NULL -> pipeline::set_or_target (:245): OR of or_target_in (may be NULL) and every
  *                           group result, optimised (:1440-1447)
- * set_search_count_limit (:255): see bmx_pipeline_set_search_count_limit (it governs the counts-only runs). */
+ * set_search_count_limit (:255): with counts_out != NULL a group's vector is produced up to the window at whose end the group
+ *                           had enough hits (see bmx_pipeline_set_search_count_limit); without counts the limit does not apply. */
 int bmx_pipeline_run_results(bmx_ctx* ctx, bmx_pipeline* p, bmx_vec** results_out, uint64_t* counts_out,
                              const bmx_vec* or_target_in, bmx_vec** or_target_out);
 /* same for a pipeline whose options enable search masks (agg_run_options<.., .., true>::is_masks(), :65,78) under

@@ -2294,3 +2294,93 @@ def test_and_rows_kernel(ctx, port, nvec, nsub):
     finally:
         for k, v in (("and_rows", -1), ("and_rows_wg", 256), ("and_rows_depth", 3), ("and_rows_nt", 0), ("pipe_split", -1), ("direct_cols", 384)):
             ctx.set_tuning(k, v)
+
+
+def test_search_count_limit_drops_groups_per_group(ctx, port):
+    """pipeline::set_search_count_limit per ARG-GROUP (src/bmaggregator.h:1362-1367: a group at its limit is skipped on every
+    following block).  1,000 groups of which ONE has fewer hits than the limit: the first launch window runs over all of them,
+    every later window over that one group only (bmx_pipeline_last_window_groups); the satisfied groups return >= limit and
+    <= their true count, the short one its true count.  Same through the LDS-staged kernel and over GAP-only operands
+    (k_agg_and_rows).  Results + counts runs truncate a group's vector at the window where it had enough; result-only runs
+    ignore the limit; bm::id_max means no limit."""
+    ncols = 2000
+    nbits = ncols * 65536
+    dense = [bm.bvector.generate(ctx, SEED, 700 + i, 6554, nbits, with_common=True) for i in range(8)]
+    sparse = bm.bvector.generate(ctx, SEED, 790, 2, nbits)                 # ~2 bits per block
+    agg = bm.aggregator(ctx)
+    pairs = [(i, j) for i in range(8) for j in range(8) if i != j]
+    def mk(ngroups, limit, opt=bm.agg_opt_only_counts, short_at=None):
+        pipe = bm.aggregator.pipeline(ctx, opt)
+        for g in range(ngroups):
+            ag = pipe.add()
+            if g == short_at:
+                ag.add(dense[0], 0); ag.add(sparse, 0)
+            else:
+                i, j = pairs[g % len(pairs)]
+                ag.add(dense[i], 0); ag.add(dense[j], 0)
+                if g % 3 == 0: ag.add(dense[(i + j) % 8], 1 if (i + j) % 8 not in (i, j) else 0)
+        if limit is not None: pipe.set_search_count_limit(limit)
+        pipe.complete()
+        return pipe
+    ng, short = 1000, 617
+    full = [int(x) for x in agg.combine_and_sub(mk(ng, None, short_at=short))]
+    limit = 5000
+    assert full[short] < limit and min(c for g, c in enumerate(full) if g != short) > 100 * limit
+    try:
+        for staged in (-1, 0):
+            ctx.set_tuning("pipe_staged", staged)
+            p = mk(ng, limit, short_at=short)
+            got = [int(x) for x in agg.combine_and_sub(p)]
+            launched, planned = p.last_windows()
+            wg = p.last_window_groups()
+            assert launched == planned == len(wg) and planned >= 3, (staged, launched, planned, wg)
+            assert wg[0] == ng and all(x == 1 for x in wg[1:]), (staged, wg)
+            assert got[short] == full[short]
+            assert all(limit <= g <= t for k, (g, t) in enumerate(zip(got, full)) if k != short), staged
+            # the satisfied groups stopped after the first window: they hold what that window found, far below their true count
+            assert all(g < t // 8 for k, (g, t) in enumerate(zip(got, full)) if k != short)
+    finally:
+        ctx.set_tuning("pipe_staged", -1)
+    # every group satisfied in the first window: nothing else is launched
+    p = mk(64, limit); got = agg.combine_and_sub(p)
+    assert p.last_windows()[0] == 1 and p.last_window_groups() == [64] and all(int(g) >= limit for g in got)
+    # bm::id_max = no limit: one plain run
+    p = mk(64, None); p.set_search_count_limit(bm.ID_MAX)
+    assert [int(x) for x in agg.combine_and_sub(p)] == full[:64]
+    assert p.last_windows() == (1, 1)
+    # results + counts: a group's vector ends where its count passed the limit; result-only runs ignore the limit
+    pr = mk(40, limit, opt=bm.agg_opt_bvect_and_counts, short_at=7)
+    res = agg.combine_and_sub(pr)
+    cnt = [int(x) for x in pr.get_bv_count_vector()]
+    pf = mk(40, None, opt=bm.agg_opt_bvect_and_counts, short_at=7)
+    res_full = agg.combine_and_sub(pf)
+    cnt_full = [int(x) for x in pf.get_bv_count_vector()]
+    for g in range(40):
+        assert cnt[g] == res[g].count() and min(limit, cnt_full[g]) <= cnt[g] <= cnt_full[g], g
+        assert bm.count_and(res[g], res_full[g]) == cnt[g]                     # a subset of the unlimited result ...
+        if g != 7:
+            assert cnt[g] < cnt_full[g] // 8
+            last = int(res[g].to_indices()[-1]) >> 16                           # ... namely its leading block columns
+            assert bm.count_and(res[g], res_full[g]) == res_full[g].count_range(0, (last + 1) * 65536 - 1, res_full[g].build_rs_index())
+        else:
+            assert cnt[g] == cnt_full[g]
+    po = mk(12, limit, opt=bm.agg_run_options(True, False))                    # results only: the limit does not apply (:1362 is under is_compute_counts)
+    ro = agg.combine_and_sub(po)
+    assert [r.count() for r in ro] == [int(x) for x in agg.combine_and_sub(mk(12, None))]
+    # GAP-only operands (k_agg_and_rows) under a limit
+    gaps = [bm.bvector.generate(ctx, SEED, 900 + i, 120, nbits, with_common=True) for i in range(24)]
+    def mkg(limit):
+        pipe = bm.aggregator.pipeline(ctx)
+        for g in range(6):
+            ag = pipe.add()
+            for v in (gaps[g * 4:(g + 1) * 4] * 3 if g != 2 else gaps[8:12] * 2 + [sparse]): ag.add(v, 0)
+        if limit: pipe.set_search_count_limit(limit)
+        pipe.complete()
+        return pipe
+    pg = mkg(None)
+    assert "k_agg_and_rows" in pg.describe()
+    fg = [int(x) for x in agg.combine_and_sub(pg)]
+    lim = max(fg[2] + 1, 50)
+    pg2 = mkg(lim); gg = [int(x) for x in agg.combine_and_sub(pg2)]
+    wgs = pg2.last_window_groups()
+    assert gg[2] == fg[2] and all(min(lim, t) <= g <= t for g, t in zip(gg, fg)) and wgs[0] == 6 and wgs[-1] == 1, (gg, fg, wgs)
