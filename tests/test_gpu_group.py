@@ -210,6 +210,55 @@ def test_group_rccl_single_member(ctx, port):
     grp.close()
 
 
+def test_group_rccl_over_all_visible_devices(port):
+    """the first multi-GPU lease must not also be the first test.  When >= 2 devices are visible (skipped on the
+    one-GPU boxes of this pool) a BMX_GROUP_RCCL group over min(device_count, 8) DISTINCT devices must come up with that many
+    RCCL ranks, its pipeline counts (summed by the in-library ncclAllReduce) and its materialised results must equal the
+    single-device / oracle ones, shards must sit on their own devices, and the exchange time is reported per member."""
+    n = min(bm.device_count(), 8)
+    if n < 2:
+        pytest.skip(f"{bm.device_count()} device visible: the multi-device RCCL path needs >= 2")
+    nbits = 97 * 65536 + 4321
+    words, pv = _vectors(port, 6, nbits, [6554, 20000, 655])
+    grp = bm.group(list(range(n)), bm.GROUP_RCCL)
+    try:
+        assert grp.rccl_ranks() == n, (grp.rccl_ranks(), n)
+        gv = [bm.gbvector.from_block_table(grp, nbits, *p.flatten()) for p in pv]
+        agg = bm.gaggregator(grp)
+        groups = [([0, 1, 2], []), ([0], [3]), ([4, 5], [1]), ([0, 1, 2, 3, 4, 5], [])]
+        pipe = bm.gaggregator.pipeline(grp)
+        for a, s in groups:
+            ag = pipe.add()
+            for i in a: ag.add(gv[i], 0)
+            for i in s: ag.add(gv[i], 1)
+        pipe.complete()
+        exp = port.pipeline_counts([([pv[i] for i in a], [pv[i] for i in s]) for a, s in groups])
+        for _ in range(3):
+            got = agg.combine_and_sub(pipe)
+            assert (got == exp).all(), (got, exp)
+        xs = pipe.last_exchange_ms(); ks = pipe.last_ms()
+        assert len(xs) == n and len(ks) == n and all(x >= 0 for x in xs)
+        # the same counts from ONE device (a plain context on device 0) and through the host-sum exchange
+        c0 = bm.context(0)
+        sv = [bm.bvector.from_block_table(c0, nbits, *p.flatten()) for p in pv]
+        sp = bm.aggregator.pipeline(c0)
+        for a, s in groups:
+            ag = sp.add()
+            for i in a: ag.add(sv[i], 0)
+            for i in s: ag.add(sv[i], 1)
+        sp.complete()
+        assert (bm.aggregator(c0).combine_and_sub(sp) == got).all()
+        del sp, sv; c0.close()
+        # materialised results gathered from the shards; pairwise counts over shards
+        t, _any = agg.combine_and_sub([gv[0], gv[1]], [gv[3]])
+        e = port.agg_and_sub([pv[0], pv[1]], [pv[3]])
+        ge = bm.gbvector.from_block_table(grp, nbits, *e.flatten())
+        assert t.count() == e.count() and bm.gbvector.count_op2(bm.XOR, t, ge) == 0
+        assert bm.gbvector.count_op2(bm.AND, gv[0], gv[4]) == port.count_op2(0, pv[0], pv[4])
+    finally:
+        grp.close()
+
+
 def test_group_full_size_headline_shards(ctx):
     """BASELINE configs[2] shape through the group API at reduced width: 32 x 1e9-bit vectors, 8 members on one
     GPU; the sharded count equals the single-context count (size-independent property: shard sums = total)"""

@@ -316,3 +316,15 @@ def test_result_memory_is_what_the_result_holds(ctx, port):
     agg = bm.aggregator(ctx); agg.combine_and_sub(pipe)
     assert all(r.info()["bit_slab_blocks"] <= 3 for r in pipe.get_bv_res_vector())
     assert ctx.mem_used() - used < 24 * (3 * 8192 + (1 << 20)) + (8 << 20)   # 24 x 3 blocks, not 24 x 400
+
+
+def test_randomized_soak_slices():
+    """the randomized differential soaks (tools/soak_r04.py parts A-E: row kernel, collection members, long
+    mixed pairwise operations, search limits, asynchronous chains; tools/soak_r05.py parts F-G: the AND rows kernel, per-group
+    search limits) ran only under the builder's gpurun.  A bounded slice of each, fixed seeds, runs here: about a minute."""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for script, rounds in (("soak_r04.py", "4"), ("soak_r05.py", "14")):
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", script), rounds], capture_output=True, text=True, timeout=900, cwd=root)
+        tail = (r.stdout + r.stderr)[-2000:]
+        assert r.returncode == 0 and "done, failures: 0" in r.stdout, (script, tail)
