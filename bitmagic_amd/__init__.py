@@ -211,6 +211,13 @@ class bvector:
         return bvector(a.ctx, h)
 
     @staticmethod
+    def op2_count(op, a: "bvector", b: "bvector", opt_mode: int = opt_none, want_result: bool = True):
+        """bmx_op2_count: the three-operand operation and the count of its result in one call -> (vector | None, count)"""
+        h, c = C.c_void_p(), C.c_uint64()
+        check(lib().bmx_op2_count(a.ctx._h, op, a._h, b._h, int(opt_mode == opt_compress), C.byref(h) if want_result else None, C.byref(c)))
+        return (bvector(a.ctx, h) if want_result else None), c.value
+
+    @staticmethod
     def op2_async(op, a, b) -> "pending":
         """bmx_op2_dev: the three-operand operation (opt_none) enqueued on the context's stream; a / b are vectors (any block
         kinds) or unresolved results of earlier op2_async calls; -> pending (wait() gives the vector)"""

@@ -67,6 +67,7 @@ def lib() -> C.CDLL:
         "bmx_vec_to_words": (i32, [vp, vp, vp, u64]),
         "bmx_count": (i32, [vp, vp, P(u64)]),
         "bmx_op2": (i32, [vp, i32, vp, vp, i32, P(vp)]),
+        "bmx_op2_count": (i32, [vp, i32, vp, vp, i32, P(vp), P(u64)]),
         "bmx_op2_dev": (i32, [vp, i32, vp, vp, vp, vp, P(vp)]),
         "bmx_pending_wait": (i32, [vp, vp, P(vp)]),
         "bmx_pending_free": (i32, [vp, vp]),

@@ -2051,7 +2051,7 @@ int bmx_op2(bmx_ctx* ctx, int op, const bmx_vec* a, const bmx_vec* b, int opt_co
     // no GAP block can come out (neither operand holds one, no re-compression): the kernel folds the kind counts itself
     // and the layout scan is skipped -- k_op2, one synchronise, done -- unless result blocks vanished (then the scan /
     // compaction path below decides what to do with the slab)
-    bool no_gap = !opt_compress && a->counts[BMX_GAP] == 0 && b->counts[BMX_GAP] == 0, folded = false, emit = false;
+    bool no_gap = !opt_compress && a->counts[BMX_GAP] == 0 && b->counts[BMX_GAP] == 0, folded = false, emit = false, counted = false;
     if (nblocks) {
         // bit-blocks only on both sides: the streaming form (one machine-load of waves, each owning a stretch of columns)
         const bool stream = no_gap && ctx->pair_stream != 0 && a->nblocks == b->nblocks && a->counts[BMX_BIT] == nblocks &&
@@ -2080,11 +2080,16 @@ int bmx_op2(bmx_ctx* ctx, int op, const bmx_vec* a, const bmx_vec* b, int opt_co
                                v->d_bits, v->d_desc, st, (emit || no_gap || op == BMX_OR || op == BMX_XOR) ? FoldOut{ctx->d_slots, ctx->d_done, ctx->h_small + 2} : FoldOut{nullptr, nullptr, nullptr},
                                emit ? offs : nullptr, ctx->d_cursor, emit ? offs + nblocks : nullptr);
             folded = emit || op == BMX_OR || op == BMX_XOR;                 // (with re-compression AND / SUB go straight to the layout scan, no extra synchronise)
-        } else
+        } else {
+        // short vectors: a wave per column; the kernel also folds the popcount of its result (bvector::bit_and + count(), the
+        // plumbing case of BASELINE configs[0], is then ONE launch and one synchronise: bmx_count finds the count with the vector)
         hipLaunchKernelGGL(k_op2, dim3((nblocks + 3) / 4), dim3(256), 0, ctx->stream, op,
                            a->d_desc, a->nblocks, b->d_desc, b->nblocks, nblocks, opt_compress,
                            v->d_bits, v->d_desc, st,
-                           no_gap ? FoldOut{ctx->d_slots, ctx->d_done, ctx->h_small + 2} : FoldOut{nullptr, nullptr, nullptr});
+                           no_gap ? FoldOut{ctx->d_slots, ctx->d_done, ctx->h_small + 2} : FoldOut{nullptr, nullptr, nullptr},
+                           FoldOut{ctx->d_slots2, ctx->d_done2, ctx->h_small + 8});
+        counted = true;
+        }
         hipError_t e = hipGetLastError();
         if (e == hipSuccess && (no_gap || folded)) e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) { bmx_vec_free(ctx, v); return fail_hip(e, "k_op2", __LINE__); }
@@ -2096,13 +2101,29 @@ int bmx_op2(bmx_ctx* ctx, int op, const bmx_vec* a, const bmx_vec* b, int opt_co
         }
         if ((no_gap || folded) && ctx->h_small[2 + BMX_GAP] == 0 && ctx->h_small[2 + BMX_BIT] == nblocks) {
             for (int k = 0; k < 4; ++k) v->counts[k] = (uint32_t)ctx->h_small[2 + k];
+            if (counted) { v->count = ctx->h_small[8]; v->count_valid = true; }
             *result = v;
             return BMX_OK;
         }
     }
-    if ((rc = result_finish(ctx, v, st, offs))) { bmx_vec_free(ctx, v); return rc; }
+    if ((rc = result_finish(ctx, v, st, offs))) { bmx_vec_free(ctx, v); return rc; }       // (synchronises: the folded count has arrived too)
+    if (counted) { v->count = ctx->h_small[8]; v->count_valid = true; }
     *result = v;
     return BMX_OK;
+}
+
+// bit_and/or/xor/sub + count() in one call (bmx_op2(ctx, op, hA, hB, want_result, &hR, &count)): result
+// may be NULL (count only: bm::count_*, src/bmalgo.h:49-149).  Short vectors take one launch for both; long ones the
+// streaming kernels followed by the count pass.
+int bmx_op2_count(bmx_ctx* ctx, int op, const bmx_vec* a, const bmx_vec* b, int opt_compress, bmx_vec** result, uint64_t* count)
+{
+    ARGCHK(ctx && a && b && count);
+    if (!result) return bmx_count_op2(ctx, op, a, b, count);
+    int rc = bmx_op2(ctx, op, a, b, opt_compress, result);
+    if (rc) return rc;
+    rc = bmx_count(ctx, *result, count);
+    if (rc) { bmx_vec_free(ctx, *result); *result = nullptr; }
+    return rc;
 }
 
 // ---- asynchronous 3-operand operations (bmx_op2_dev / bmx_pending_wait / bmx_pending_free) ----
@@ -2207,7 +2228,7 @@ int bmx_op2_dev(bmx_ctx* ctx, int op, const bmx_vec* a, const bmx_pending* pa, c
                                v->d_bits, v->d_desc, st, fo, (u32*)nullptr, ctx->d_cursor, (u32*)nullptr);
         } else
             hipLaunchKernelGGL(k_op2, dim3((nblocks + 3) / 4), dim3(256), 0, ctx->stream, op, va->d_desc, va->nblocks, vb->d_desc, vb->nblocks, nblocks, 0,
-                               v->d_bits, v->d_desc, st, fo);
+                               v->d_bits, v->d_desc, st, fo, FoldOut{nullptr, nullptr, nullptr});
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipEventRecord(p->ev, ctx->stream);

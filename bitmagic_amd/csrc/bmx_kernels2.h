@@ -67,10 +67,11 @@ __device__ __forceinline__ u32 store_result_mode(const Blk& acc, u32 nb, u32 mod
                                                   uint4* __restrict__ slab, u64* __restrict__ desc,
                                                   BlockStat* __restrict__ st, u32 lane,
                                                   u32* __restrict__ gap_offs = nullptr, u64* __restrict__ gap_cursor = nullptr,
-                                                  u32* __restrict__ gap_list = nullptr)
+                                                  u32* __restrict__ gap_list = nullptr, u32* pop_out = nullptr)
 {
     Blk t;
     u32 pop = wave_sum(blk_lane_popcount(acc));
+    if (pop_out) *pop_out = pop;
     u32 runs = 1u + wave_sum(blk_transitions(acc, t, lane));
     u32 first = __shfl(acc.r[0].x, 0, 64) & 1u;
     u32 kind;
@@ -290,17 +291,17 @@ __device__ __forceinline__ u32 op2_store_mode(int op, u32 ka, u32 kb, int opt_co
 
 // one result block of a pairwise operation; returns its kind
 __device__ __forceinline__ u32 op2_block(int op, u64 a, u64 b, u32 nb, int opt_compress, u32* l,
-                                         uint4* __restrict__ slab, u64* __restrict__ desc, BlockStat* __restrict__ st, u32 lane)
+                                         uint4* __restrict__ slab, u64* __restrict__ desc, BlockStat* __restrict__ st, u32 lane, u32* pop_out = nullptr)
 {
     u32 ka = DESC_K(a), kb = DESC_K(b);
     // shortcuts that produce NULL / FULL without reading anything
     const u32 trivial = op2_trivial(op, ka, kb);
-    if (trivial != 4u) { store_trivial(trivial, nb, desc, st, lane); return trivial; }
+    if (trivial != 4u) { store_trivial(trivial, nb, desc, st, lane); if (pop_out) *pop_out = trivial == K_FULL ? 65536u : 0u; return trivial; }
     Blk x, y;
     blk_from_desc(a, x, l, lane);
     blk_from_desc(b, y, l, lane);
     blk_op(op, x, y);
-    return store_result_mode(x, nb, op2_store_mode(op, ka, kb, opt_compress), slab, desc, st, lane);
+    return store_result_mode(x, nb, op2_store_mode(op, ka, kb, opt_compress), slab, desc, st, lane, nullptr, nullptr, nullptr, pop_out);
 }
 
 // kinds.slots != null: the kind counts of the result are folded inside the kernel (kind_fanin_fold) -- used when no GAP
@@ -308,15 +309,16 @@ __device__ __forceinline__ u32 op2_block(int op, u64 a, u64 b, u32 nb, int opt_c
 __global__ __launch_bounds__(256)
 void k_op2(int op, const u64* __restrict__ da, u32 na, const u64* __restrict__ db, u32 nbk,
            u32 nblocks, int opt_compress, uint4* __restrict__ slab, u64* __restrict__ desc,
-           BlockStat* __restrict__ st, FoldOut kinds)
+           BlockStat* __restrict__ st, FoldOut kinds, FoldOut total /* slots != null: the popcount of the result is folded too (bit_and + count() in one launch) */)
 {
     __shared__ u32 lds[4 * 2048];
     u32 lane = lane_id(), wave = threadIdx.x >> 6;
     u32 nb = uniform32(blockIdx.x * 4u + wave);
-    u32 kind = 4u;
+    u32 kind = 4u, pop = 0u;
     if (nb < nblocks)
-        kind = op2_block(op, desc_at(da, na, nb), desc_at(db, nbk, nb), nb, opt_compress, lds + wave * 2048u, slab, desc, st, lane);
+        kind = op2_block(op, desc_at(da, na, nb), desc_at(db, nbk, nb), nb, opt_compress, lds + wave * 2048u, slab, desc, st, lane, &pop);
     if (kinds.slots) kind_fanin_fold(kind, kinds, lane, wave);
+    if (total.slots) count_fanin_fold(pop, total, lane, wave);
 }
 
 // bm::count_and/or/xor/sub  src/bmalgo.h:49,149,81,115 (distance_operation,

@@ -144,6 +144,13 @@ int bmx_count(bmx_ctx* ctx, const bmx_vec* a, uint64_t* count);
  * opt_compress != 0 re-compresses produced blocks (opt_compress, src/bm.h:6263). */
 int bmx_op2(bmx_ctx* ctx, int op, const bmx_vec* a, const bmx_vec* b, int opt_compress,
             bmx_vec** result);
+/* bit_and/or/xor/sub + count() of the result in ONE call (the reference's callers write
+ * bv.bit_and(a, b); bv.count();  src/bm.h:6185,2431 -- tests/perf and lang-maps/libbm BM_bvector_combine_AND + BM_bvector_count,
+ * libbm.h:439,314): *count = popcount of the result.  result may be NULL: count only (bm::count_*, src/bmalgo.h:49-149).
+ * Vectors of fewer than 2,048 blocks take one launch and one synchronise for both (the kernel folds the count; bmx_op2
+ * followed by bmx_count costs the same: the count travels with the result vector). */
+int bmx_op2_count(bmx_ctx* ctx, int op, const bmx_vec* a, const bmx_vec* b, int opt_compress,
+                  bmx_vec** result, uint64_t* count);
 /* The same three-operand operations (src/bm.h:6185,5973,6072,6403; opt_none), ASYNCHRONOUS on the context's stream: the call
  * enqueues the kernel and returns.  What bmx_op2 waits for is not the result -- it is complete on the stream when the kernel
  * ends -- but the counts of its block kinds, which the host needs to dispatch later operations over it; here they travel to

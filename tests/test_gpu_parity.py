@@ -2384,3 +2384,24 @@ def test_search_count_limit_drops_groups_per_group(ctx, port):
     pg2 = mkg(lim); gg = [int(x) for x in agg.combine_and_sub(pg2)]
     wgs = pg2.last_window_groups()
     assert gg[2] == fg[2] and all(min(lim, t) <= g <= t for g, t in zip(gg, fg)) and wgs[0] == 6 and wgs[-1] == 1, (gg, fg, wgs)
+
+
+def test_op2_count_in_one_call(ctx, port):
+    """bmx_op2_count (result + count from one call): for short vectors the pairwise kernel folds the popcount of
+    its result, so bit_and + count() is one launch (the count travels with the vector: bmx_count after bmx_op2 launches
+    nothing); long vectors, GAP operands, opt_compress, empty and full results, count-only form = the oracle"""
+    rng = np.random.default_rng(77)
+    for nbits, dqa, dqb in ((1_000_000, 6554, 6554), (40 * 65536 + 17, 655, 300), (2100 * 65536, 6554, 655), (3 * 65536, 65536, 40)):
+        wa, wb = port.gen_words(SEED, 11, dqa, nbits), port.gen_words(SEED, 12, dqb, nbits)
+        pa, pb = port.import_words(wa, True, nbits), port.import_words(wb, True, nbits)
+        ga, gb = bm.bvector.from_block_table(ctx, nbits, *pa.flatten()), bm.bvector.from_block_table(ctx, nbits, *pb.flatten())
+        for op in (bm.AND, bm.OR, bm.XOR, bm.SUB):
+            for opt in (bm.opt_none, bm.opt_compress):
+                e = port.op2(op, pa, pb, int(opt == bm.opt_compress))
+                t, c = bm.bvector.op2_count(op, ga, gb, opt)
+                assert c == e.count() and t.count() == c, (nbits, op, opt)
+                assert t.block_table()[0].tolist() == e.flatten()[0].tolist()
+                t2 = bm.bvector._op2(op, ga, gb, opt)
+                assert t2.count() == c
+            none, c = bm.bvector.op2_count(op, ga, gb, want_result=False)
+            assert none is None and c == port.count_op2(op, pa, pb)
