@@ -12,6 +12,7 @@
 #include "bmx_kernels7.h"
 #include "bmx_kernels8.h"
 #include "bmx_kernels9.h"
+#include "bmx_kernels10.h"
 
 #include <algorithm>
 #include <atomic>
@@ -42,6 +43,7 @@ void bmx_set_last_error(const char* msg) { g_last_error = msg ? msg : ""; }
 static int fail_hip(hipError_t e, const char* what, int line) { return bmx_fail_hip(e, what, "bmx.hip", line); }
 
 static void coll_free(bmx_ctx* ctx, size_t idx);
+static int vec_build_tdir(bmx_ctx* ctx, bmx_vec* v);
 static void coll_drop_vector(bmx_ctx* ctx, uint64_t uid);
 static bool coll_evict_one(bmx_ctx* ctx);
 static int set_dev(const bmx_ctx* ctx) { HIPCHK(hipSetDevice(ctx->device)); return BMX_OK; }
@@ -235,11 +237,22 @@ static int coll_build(bmx_ctx* ctx, const bmx_vec* const* v, size_t n, int polar
     for (size_t i = 0; i < n; ++i) { c->key[i] = v[i]->uid; c->index->emplace(v[i]->uid, (uint32_t)i); }      // (a repeated vector keeps its first index)
     struct BuildGuard { bmx_ctx* c; BuildGuard(bmx_ctx* x) : c(x) { ++c->coll_building; } ~BuildGuard() { --c->coll_building; } } guard(ctx);   // (no eviction from under a build)
     void* d_descs = nullptr; void* d_nblk = nullptr; u32* d_pre = nullptr; u32* d_sgl = nullptr; u32* d_words = nullptr;
+    void* d_optab = nullptr; u32* d_bt = nullptr;
     const bool split = polarity == 1 && ctx->coll_split != 0;
+    // sparse operands, OR / SUB role: the tile build (bmx_kernels10.h).  coll_build: -1 = where the operands average <= 4.1
+    // 16-byte chunks per GAP block (the rows of 14 columns fit one wave load nearly always), 0 = never, 1 = whenever possible
+    bool tiles = false;
+    if (split && ctx->coll_build != 0 && n <= C2_MAX_N) {
+        uint64_t gw = 0, gb = 0;
+        for (size_t i = 0; i < n; ++i) { gw += v[i]->gap_words; gb += v[i]->counts[BMX_GAP]; }
+        tiles = ctx->coll_build == 1 || (gb && gw * 10ull <= gb * 328ull);
+    }
+    u64 total = 0;
+    const size_t dir_bytes = ((size_t)n + 1) * ncols * 4;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     auto fail = [&](int code) {
         (void)hipStreamSynchronize(ctx->stream);
-        dfree(ctx, d_descs); dfree(ctx, d_nblk); dfree(ctx, d_pre); dfree(ctx, d_sgl); dfree(ctx, d_words);
+        dfree(ctx, d_descs); dfree(ctx, d_nblk); dfree(ctx, d_pre); dfree(ctx, d_sgl); dfree(ctx, d_words); dfree(ctx, d_optab); dfree(ctx, d_bt);
         dfree(ctx, c->d_runs); dfree(ctx, c->d_off); dfree(ctx, c->d_cnt); dfree(ctx, c->d_flags); dfree(ctx, c->d_cnt_s);
         dfree(ctx, c->d_dir); dfree(ctx, c->d_dir_s);
         if (e0) (void)hipEventDestroy(e0);
@@ -248,6 +261,47 @@ static int coll_build(bmx_ctx* ctx, const bmx_vec* const* v, size_t n, int polar
         delete c;
         return code;
     };
+    if (tiles) {
+        // ---- the tile build: two passes over the run lists, a workgroup per tile of 14 columns (bmx_kernels10.h) ----
+        const u32 ntiles = (ncols + ORR_TILE - 1u) / ORR_TILE, ngroups = ((u32)n + C2_GROUP - 1u) / C2_GROUP;
+        std::vector<u64> tab(n * 4, 0ull);
+        for (size_t i = 0; i < n; ++i) {
+            const bmx_vec* o = v[i];
+            if (!o->d_tdir && (rc = vec_build_tdir(ctx, const_cast<bmx_vec*>(o)))) return fail(rc);      // (a cache of the immutable vector's layout)
+            tab[i * 4] = (u64)(uintptr_t)o->d_tdir; tab[i * 4 + 1] = (u64)(uintptr_t)o->d_gaps;
+            tab[i * 4 + 2] = (u64)(uintptr_t)o->d_desc; tab[i * 4 + 3] = (u64)o->nblocks;
+        }
+        if ((rc = dmalloc(ctx, &d_optab, std::max<size_t>(tab.size() * 8, 64))) ||
+            (rc = dmalloc(ctx, (void**)&d_bt, (size_t)ntiles * ngroups * 16 * 4)) || (rc = dmalloc(ctx, (void**)&d_words, (size_t)ncols * 4)) ||
+            (rc = dmalloc(ctx, (void**)&c->d_off, ((size_t)ncols + 1) * 8)) || (rc = dmalloc(ctx, (void**)&c->d_cnt, (size_t)ncols * 4)) ||
+            (rc = dmalloc(ctx, (void**)&c->d_flags, (size_t)ncols * 4)) || (rc = dmalloc(ctx, (void**)&c->d_cnt_s, (size_t)ncols * 4))) return fail(rc);
+        hipError_t e = hipEventCreate(&e0);
+        if (e == hipSuccess) e = hipEventCreate(&e1);
+        if (e == hipSuccess) e = hipEventRecord(e0, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_optab, tab.data(), tab.size() * 8, hipMemcpyHostToDevice, ctx->stream);
+        if (e != hipSuccess) return fail(fail_hip(e, "coll_build (tiles)", __LINE__));
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_coll2_count<4>), dim3(ntiles), dim3(1024), 0, ctx->stream, (const u32x4*)d_optab, (u32)n, ncols, ngroups, ctx->xcd_swz,
+                           C2CountOut{c->d_cnt, c->d_cnt_s, c->d_flags, d_words, d_bt});
+        hipLaunchKernelGGL(k_coll_offsets, dim3(1), dim3(1024), 0, ctx->stream, (const u32*)d_words, ncols, c->d_off);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(&total, c->d_off + ncols, 8, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);          // (the operand table came from pageable memory: done too)
+        if (e != hipSuccess) return fail(fail_hip(e, "coll_build (tile count)", __LINE__));
+        c->entries = total;
+        if ((rc = dmalloc(ctx, (void**)&c->d_runs, std::max<size_t>((size_t)total * 4, 64))) ||
+            (rc = dmalloc(ctx, (void**)&c->d_dir, dir_bytes)) || (rc = dmalloc(ctx, (void**)&c->d_dir_s, dir_bytes))) return fail(rc);
+        const size_t lds = (size_t)ngroups * 16 * 4 * 2;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_coll2_scatter<8, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(k_coll2_scatter<8, 4>), dim3(ntiles), dim3(256), lds, ctx->stream, (const u32x4*)d_optab, (u32)n, ncols, ngroups, ctx->xcd_swz,
+                               (const u32*)d_bt, (const u64*)c->d_off, (const u32*)c->d_cnt, (const u32*)c->d_cnt_s, c->d_runs, c->d_dir, c->d_dir_s);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipEventRecord(e1, ctx->stream);
+        if (e == hipSuccess) e = hipEventSynchronize(e1);
+        if (e == hipSuccess) e = hipEventElapsedTime(&c->build_ms, e0, e1);
+        if (e != hipSuccess) return fail(fail_hip(e, "coll_build (tile scatter)", __LINE__));
+    } else {
     if ((rc = dmalloc(ctx, &d_descs, n * 8)) || (rc = dmalloc(ctx, &d_nblk, n * 4)) ||
         (rc = dmalloc(ctx, (void**)&d_pre, (size_t)n * ncols * 4)) ||
         (rc = dmalloc(ctx, (void**)&c->d_off, ((size_t)ncols + 1) * 8)) || (rc = dmalloc(ctx, (void**)&c->d_cnt, (size_t)ncols * 4)) ||
@@ -278,7 +332,6 @@ static int coll_build(bmx_ctx* ctx, const bmx_vec* const* v, size_t n, int polar
     } else
     hipLaunchKernelGGL(k_coll_offsets, dim3(1), dim3(1024), 0, ctx->stream, (const u32*)c->d_cnt, ncols, c->d_off);
     e = hipGetLastError();
-    u64 total = 0;
     if (e == hipSuccess) e = hipMemcpyAsync(&total, c->d_off + ncols, 8, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);          // (descs / nblk are read from pageable memory: they are done too)
     if (e != hipSuccess) return fail(fail_hip(e, "coll_build (count)", __LINE__));
@@ -300,7 +353,6 @@ static int coll_build(bmx_ctx* ctx, const bmx_vec* const* v, size_t n, int polar
         e = hipGetLastError();
     }
     // the member directory (bmx_kernels8.h): the prefixes of the passes above, column-major, with the members' block kinds
-    const size_t dir_bytes = ((size_t)n + 1) * ncols * 4;
     if (e == hipSuccess && ((rc = dmalloc(ctx, (void**)&c->d_dir, dir_bytes)) || (split && (rc = dmalloc(ctx, (void**)&c->d_dir_s, dir_bytes))))) return fail(rc);
     if (e == hipSuccess) {
         hipLaunchKernelGGL(k_coll_dir, dim3((ncols + 31) / 32, ((u32)n + 1 + 31) / 32), dim3(1024), 0, ctx->stream, (const u32*)d_pre, (const u32*)d_sgl,
@@ -311,8 +363,9 @@ static int coll_build(bmx_ctx* ctx, const bmx_vec* const* v, size_t n, int polar
     if (e == hipSuccess) e = hipEventSynchronize(e1);
     if (e == hipSuccess) e = hipEventElapsedTime(&c->build_ms, e0, e1);
     if (e != hipSuccess) return fail(fail_hip(e, "coll_build (scatter)", __LINE__));
+    }
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    dfree(ctx, d_descs); dfree(ctx, d_nblk); dfree(ctx, d_pre); dfree(ctx, d_sgl); dfree(ctx, d_words);
+    dfree(ctx, d_descs); dfree(ctx, d_nblk); dfree(ctx, d_pre); dfree(ctx, d_sgl); dfree(ctx, d_words); dfree(ctx, d_optab); dfree(ctx, d_bt);
     c->bytes = (uint64_t)total * 4 + (uint64_t)ncols * (split ? 20 : 16) + 8 + (uint64_t)dir_bytes * (split ? 2 : 1);
     c->run_bytes = (uint64_t)total * 4;
     c->id = ++ctx->coll_next_id;
@@ -650,7 +703,7 @@ int bmx_ctx_create(int device, void* stream, bmx_ctx** out)
     // an invalid value is ignored (the default stays)
     static const char* const env_keys[][2] = {
         {"BMX_PIPE_UNROLL", "pipe_unroll"}, {"BMX_PIPE_ROWS", "pipe_rows"}, {"BMX_PIPE_NT", "pipe_nt"},
-        {"BMX_PIPE_WG", "pipe_wg"}, {"BMX_PIPE_WINDOW", "pipe_window"}, {"BMX_PIPE_SPLIT", "pipe_split"}, {"BMX_OR_TILE", "or_tile"}, {"BMX_OR_ROWS", "or_rows"}, {"BMX_OR_DEPTH", "or_depth"}, {"BMX_OR_WINDOW", "or_window"}, {"BMX_DIRECT_COLS", "direct_cols"}, {"BMX_FF_WINDOW", "ff_window"}, {"BMX_GAP_COUNT", "gap_count"}, {"BMX_AND_ROWS", "and_rows"}, {"BMX_AGG_SHAPE", "agg_shape"}, {"BMX_AND_ROWS_WG", "and_rows_wg"}, {"BMX_AND_ROWS_DEPTH", "and_rows_depth"}, {"BMX_AND_ROWS_NT", "and_rows_nt"}, {"BMX_RANGE_HALVES", "range_halves"}, {"BMX_PAIR_STREAM", "pair_stream"}, {"BMX_PAIR_WGS", "pair_wgs"}, {"BMX_RS_LANES", "rs_lanes"}, {"BMX_RS_LINES", "rs_lines"}, {"BMX_RS_SELECT_LINES", "rs_select_lines"}, {"BMX_RS_SDIR_SHIFT", "rs_sdir_shift"}, {"BMX_COLL_SHAPE", "coll_shape"}, {"BMX_COLL_WINDOW", "coll_window"}, {"BMX_COLL_SPLIT", "coll_split"}, {"BMX_EQ_BIG", "eq_big"}, {"BMX_PAIR_LOOP", "pair_loop"}, {"BMX_PAIR_NT", "pair_nt"}, {"BMX_EQ_BIG_SHAPE", "eq_big_shape"}, {"BMX_OP2_WGS", "op2_wgs"}, {"BMX_OP2_LOOP", "op2_loop"}, {"BMX_OP2_NT", "op2_nt"}, {"BMX_GAP_PACK", "gap_pack"}, {"BMX_COLL_MEMBERS", "coll_members"}, {"BMX_XCD_SWIZZLE", "xcd_swizzle"}};
+        {"BMX_PIPE_WG", "pipe_wg"}, {"BMX_PIPE_WINDOW", "pipe_window"}, {"BMX_PIPE_SPLIT", "pipe_split"}, {"BMX_OR_TILE", "or_tile"}, {"BMX_OR_ROWS", "or_rows"}, {"BMX_OR_DEPTH", "or_depth"}, {"BMX_OR_WINDOW", "or_window"}, {"BMX_DIRECT_COLS", "direct_cols"}, {"BMX_FF_WINDOW", "ff_window"}, {"BMX_GAP_COUNT", "gap_count"}, {"BMX_AND_ROWS", "and_rows"}, {"BMX_AGG_SHAPE", "agg_shape"}, {"BMX_AND_ROWS_WG", "and_rows_wg"}, {"BMX_AND_ROWS_DEPTH", "and_rows_depth"}, {"BMX_AND_ROWS_NT", "and_rows_nt"}, {"BMX_RANGE_HALVES", "range_halves"}, {"BMX_PAIR_STREAM", "pair_stream"}, {"BMX_PAIR_WGS", "pair_wgs"}, {"BMX_RS_LANES", "rs_lanes"}, {"BMX_RS_LINES", "rs_lines"}, {"BMX_RS_SELECT_LINES", "rs_select_lines"}, {"BMX_RS_SDIR_SHIFT", "rs_sdir_shift"}, {"BMX_COLL_SHAPE", "coll_shape"}, {"BMX_COLL_WINDOW", "coll_window"}, {"BMX_COLL_SPLIT", "coll_split"}, {"BMX_COLL_BUILD", "coll_build"}, {"BMX_EQ_BIG", "eq_big"}, {"BMX_PAIR_LOOP", "pair_loop"}, {"BMX_PAIR_NT", "pair_nt"}, {"BMX_EQ_BIG_SHAPE", "eq_big_shape"}, {"BMX_OP2_WGS", "op2_wgs"}, {"BMX_OP2_LOOP", "op2_loop"}, {"BMX_OP2_NT", "op2_nt"}, {"BMX_GAP_PACK", "gap_pack"}, {"BMX_COLL_MEMBERS", "coll_members"}, {"BMX_XCD_SWIZZLE", "xcd_swizzle"}};
     for (auto& kv : env_keys)
         if (const char* e = getenv(kv[0])) (void)bmx_ctx_set_tuning(ctx, kv[1], atoi(e));
     g_last_error.clear();
@@ -726,6 +779,7 @@ int bmx_ctx_set_tuning(bmx_ctx* ctx, const char* key, int value)
     else if (k == "eq_big_shape") { ARGCHK(value >= 0 && value <= 2); ctx->eq_big_shape = value; }
     else if (k == "eq_big") { ARGCHK(value >= -1 && value <= 1); ctx->eq_big = value; }
     else if (k == "coll_split") { ARGCHK(value == 0 || value == 1); ctx->coll_split = value; }
+    else if (k == "coll_build") { ARGCHK(value >= -1 && value <= 1); ctx->coll_build = value; }
     else if (k == "coll_window") { ARGCHK(value >= 0); ctx->coll_window = value; }
     else if (k == "rs_select_lines") { ARGCHK(value >= 0 && value <= 2); ctx->rs_select_lines = value; }
     else if (k == "rs_sdir_shift") { ARGCHK(value == 0 || (value >= 6 && value <= 20)); ctx->rs_sdir_shift = value; }

@@ -82,6 +82,7 @@ struct bmx_ctx {
     float last_pack_ms = 0.f;
     uint32_t max_lds_bytes = 160u * 1024u;   // hipDeviceAttributeMaxSharedMemoryPerBlock of the device (queried at creation)
     int coll_split = 1;        // polarity-1 collections keep single-bit runs as 16-bit positions (half the bytes per isolated bit)
+    int coll_build = -1;       // how a polarity-1 split collection is built: -1 = through the tile directories where the operands are sparse (bmx_kernels10.h), 0 = the (operand, column tile) passes of bmx_kernels6.h, 1 = tiles whenever possible
     int coll_shape = 4;        // k_coll_apply shape: 0 = 256 threads, 1 = 256 + prefetch, 2 = 512 (configs[4] 2.50 vs 2.61 ms, the AND cases equal), 3 = 512 + prefetch, 4 = 512 with a wave's batch as ONE 4-KiB piece (default: -2.8 % / -1.7 %, profiles/r03ag), 5 = 4 + prefetch
     int pair_nt = 1;           // ... with non-temporal loads
     int pair_loop = -1;        // pairwise counts over mixed block kinds: -1 = persistent kernel (4 workgroups per CU), 0 = a wave per column, N = workgroups per CU

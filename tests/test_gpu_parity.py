@@ -2405,3 +2405,47 @@ def test_op2_count_in_one_call(ctx, port):
                 assert t2.count() == c
             none, c = bm.bvector.op2_count(op, ga, gb, want_result=False)
             assert none is None and c == port.count_op2(op, pa, pb)
+
+
+@pytest.mark.parametrize("dq,nvec,nblk,long_runs", [(13, 70, 30, False), (13, 333, 17, True), (40, 129, 45, True), (150, 64, 9, False), (5, 1100, 15, False)])
+def test_collection_tile_build_equals_column_build(port, dq, nvec, nblk, long_runs):
+    """Round 5: bmx_collection_prepare(ROLE_OR) through the tile directories (k_coll2_count / k_coll2_scatter, bmx_kernels10.h:
+    coll_build 1) builds the collection the (operand, column tile) passes of rounds 3 / 4 build (coll_build 0): the full union
+    (k_coll_apply streams the column regions), random subsets and SUB lists forced through the member directory
+    (k_coll_members reads dir / dir_s), a counts pipeline over it -- all equal to the oracle's bits, block kinds and counts
+    under both builds.  Rows the directory cannot describe (FULL blocks, blocks starting with a 1-run, tiles of more than 64
+    chunks: long_runs / specials), NULL-only operands, operands of different lengths, operand counts that are no multiple
+    of 64, more than 1,024 operands (17 groups)."""
+    rng = np.random.default_rng(dq * 131 + nvec)
+    nbits = nblk * 65536 - 777
+    words = _sparse_collection(port, rng, nvec, nbits, dq, long_runs=long_runs, ragged=True, specials=True)
+    for v in range(0, nvec, 9):                                            # blocks that start with a 1-run; an all-NULL operand
+        b = int(rng.integers(0, nblk))
+        if (b + 1) * 2048 <= words[v].size: words[v][b * 2048] |= np.uint32(1)
+    words[min(7, nvec - 1)][:] = 0
+    pv = [port.import_words(w, True, w.size * 32) for w in words]
+    assert all(p.flatten()[0].tolist().count(2) == 0 for p in pv), "operands must be free of bit-blocks"
+    nwb = (nblk + 1) * 2048
+    subsets = [rng.choice(nvec, size=int(rng.integers(16, nvec)), replace=False).tolist() for _ in range(6)]
+    e_all = port.agg_or(pv, False)
+    stats = {}
+    for build in (1, 0):
+        c = bm.context(0)
+        c.set_tuning("direct_cols", 0); c.set_tuning("pipe_split", 0); c.set_tuning("coll_build", build)
+        gv = [bm.bvector.from_block_table(c, w.size * 32, *p.flatten()) if i % 3 else bm.bit_import_u32(c, w, True) for i, (w, p) in enumerate(zip(words, pv))]
+        c.collection_prepare(gv, bm.ROLE_OR)
+        st = c.pack_stats(); assert st["collections"] == 1
+        stats[build] = (st["run_bytes"], st["bytes"])
+        agg = bm.aggregator(c)
+        o = agg.combine_or(gv)                                               # every member: the column regions as streams
+        assert (o.to_words(nwb) == e_all.to_words(nwb)).all(), build
+        assert o.block_table()[0].tolist() == (e_all.flatten()[0].tolist() + [0] * 8)[:o.info()["nblocks"]], build
+        c.set_tuning("coll_members", 1); c.set_tuning("or_rows", 0)          # subsets: the members' pieces through the directory
+        for k, sel in enumerate(subsets):
+            o = agg.combine_or([gv[i] for i in sel])
+            e = port.agg_or([pv[i] for i in sel], False)
+            assert (o.to_words(nwb) == e.to_words(nwb)).all(), (build, k)
+            assert o.block_table()[0].tolist() == (e.flatten()[0].tolist() + [0] * 8)[:o.info()["nblocks"]], (build, k)
+        assert c.pack_stats()["collections"] == 1
+        c.close()
+    assert stats[0] == stats[1], stats                                        # same run bytes, same total bytes
