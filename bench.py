@@ -1184,8 +1184,9 @@ def run_or_sharded(args, env, quick=False):
                           "break_even_calls": (round(pack["last_build_ms"] / (cold_ms - warm_ms), 1) if cold_ms > warm_ms else None),
                           "subset_of_the_collection": sub,
                           "packed_collection": {"bytes": pack["bytes"], "run_bytes": pack["run_bytes"],
-                                                "note": "bytes = run entries (4 B per multi-bit run, 2 B per single-bit run) + column tables + the "
-                                                        "member directory (8 B per member and column) that serves subsets and pipelines"}},
+                                                "note": "bytes = run entries (4 B per multi-bit run, 2 B per single-bit run) + column tables; the member "
+                                                        "directory (8 B per member and column) that serves subsets and pipelines is added by the first call "
+                                                        "that names only some of the members (tile build, bmx_kernels10.h)"}},
                "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": tsrc,
                             "kernel": kname, "algorithmic_bytes_per_launch": needed, "avg_launch_ms": round(cold_ms, 4),

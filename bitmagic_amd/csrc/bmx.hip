@@ -131,7 +131,7 @@ static void coll_free(bmx_ctx* ctx, size_t idx)
 {
     bmx_coll* c = ctx->colls[idx];
     dfree(ctx, c->d_runs); dfree(ctx, c->d_off); dfree(ctx, c->d_cnt); dfree(ctx, c->d_flags); dfree(ctx, c->d_cnt_s);
-    dfree(ctx, c->d_dir); dfree(ctx, c->d_dir_s);
+    dfree(ctx, c->d_dir); dfree(ctx, c->d_dir_s); dfree(ctx, c->d_bt);
     ctx->pack_bytes -= std::min<uint64_t>(ctx->pack_bytes, c->bytes);
     ctx->colls.erase(ctx->colls.begin() + (long)idx);
     ++ctx->coll_gen;                                       // pipelines that resolved their groups against a collection look again
@@ -275,32 +275,42 @@ static int coll_build(bmx_ctx* ctx, const bmx_vec* const* v, size_t n, int polar
             (rc = dmalloc(ctx, (void**)&d_bt, (size_t)ntiles * ngroups * 16 * 4)) || (rc = dmalloc(ctx, (void**)&d_words, (size_t)ncols * 4)) ||
             (rc = dmalloc(ctx, (void**)&c->d_off, ((size_t)ncols + 1) * 8)) || (rc = dmalloc(ctx, (void**)&c->d_cnt, (size_t)ncols * 4)) ||
             (rc = dmalloc(ctx, (void**)&c->d_flags, (size_t)ncols * 4)) || (rc = dmalloc(ctx, (void**)&c->d_cnt_s, (size_t)ncols * 4))) return fail(rc);
+        // (the member directory -- 8 B per member and column, 2 GB for configs[4] -- is built by coll_ensure_dir when a call that
+        // names only some of the members first needs it: a list of all members streams the column regions without it)
         hipError_t e = hipEventCreate(&e0);
         if (e == hipSuccess) e = hipEventCreate(&e1);
         if (e == hipSuccess) e = hipEventRecord(e0, ctx->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(d_optab, tab.data(), tab.size() * 8, hipMemcpyHostToDevice, ctx->stream);
         if (e != hipSuccess) return fail(fail_hip(e, "coll_build (tiles)", __LINE__));
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_coll2_count<4>), dim3(ntiles), dim3(1024), 0, ctx->stream, (const u32x4*)d_optab, (u32)n, ncols, ngroups, ctx->xcd_swz,
+        hipLaunchKernelGGL(k_coll2_count, dim3(ntiles), dim3(1024), 0, ctx->stream, (const u32x4*)d_optab, (u32)n, ncols, ngroups, ctx->xcd_swz,
                            C2CountOut{c->d_cnt, c->d_cnt_s, c->d_flags, d_words, d_bt});
         hipLaunchKernelGGL(k_coll_offsets, dim3(1), dim3(1024), 0, ctx->stream, (const u32*)d_words, ncols, c->d_off);
         e = hipGetLastError();
         if (e == hipSuccess) e = hipMemcpyAsync(&total, c->d_off + ncols, 8, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipEventRecord(e1, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);          // (the operand table came from pageable memory: done too)
+        float ms_count = 0.f;
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms_count, e0, e1);
         if (e != hipSuccess) return fail(fail_hip(e, "coll_build (tile count)", __LINE__));
         c->entries = total;
-        if ((rc = dmalloc(ctx, (void**)&c->d_runs, std::max<size_t>((size_t)total * 4, 64))) ||
-            (rc = dmalloc(ctx, (void**)&c->d_dir, dir_bytes)) || (rc = dmalloc(ctx, (void**)&c->d_dir_s, dir_bytes))) return fail(rc);
+        // (build_ms is the device time of the two passes: the allocation between them -- gigabytes the driver may have to map and
+        // clear, 0.1 to 120 ms on the boxes of this pool -- is host time the caller sees in the call's wall time)
+        if ((rc = dmalloc(ctx, (void**)&c->d_runs, std::max<size_t>((size_t)total * 4, 64)))) return fail(rc);
+        e = hipEventRecord(e0, ctx->stream);
+        if (e != hipSuccess) return fail(fail_hip(e, "coll_build (tile scatter)", __LINE__));
         const size_t lds = (size_t)ngroups * 16 * 4 * 2;
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_coll2_scatter<8, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e == hipSuccess) {
             hipLaunchKernelGGL(HIP_KERNEL_NAME(k_coll2_scatter<8, 4>), dim3(ntiles), dim3(256), lds, ctx->stream, (const u32x4*)d_optab, (u32)n, ncols, ngroups, ctx->xcd_swz,
-                               (const u32*)d_bt, (const u64*)c->d_off, (const u32*)c->d_cnt, (const u32*)c->d_cnt_s, c->d_runs, c->d_dir, c->d_dir_s);
+                               (const u32*)d_bt, (const u64*)c->d_off, (const u32*)c->d_cnt, (const u32*)c->d_cnt_s, c->d_runs, (u32*)nullptr, (u32*)nullptr, C2_SKIP_DIR);
             e = hipGetLastError();
         }
         if (e == hipSuccess) e = hipEventRecord(e1, ctx->stream);
         if (e == hipSuccess) e = hipEventSynchronize(e1);
         if (e == hipSuccess) e = hipEventElapsedTime(&c->build_ms, e0, e1);
         if (e != hipSuccess) return fail(fail_hip(e, "coll_build (tile scatter)", __LINE__));
+        c->build_ms += ms_count;
+        c->d_bt = d_bt; d_bt = nullptr; c->dir_pending = true;
     } else {
     if ((rc = dmalloc(ctx, &d_descs, n * 8)) || (rc = dmalloc(ctx, &d_nblk, n * 4)) ||
         (rc = dmalloc(ctx, (void**)&d_pre, (size_t)n * ncols * 4)) ||
@@ -366,7 +376,7 @@ static int coll_build(bmx_ctx* ctx, const bmx_vec* const* v, size_t n, int polar
     }
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     dfree(ctx, d_descs); dfree(ctx, d_nblk); dfree(ctx, d_pre); dfree(ctx, d_sgl); dfree(ctx, d_words); dfree(ctx, d_optab); dfree(ctx, d_bt);
-    c->bytes = (uint64_t)total * 4 + (uint64_t)ncols * (split ? 20 : 16) + 8 + (uint64_t)dir_bytes * (split ? 2 : 1);
+    c->bytes = (uint64_t)total * 4 + (uint64_t)ncols * (split ? 20 : 16) + 8 + (c->dir_pending ? (uint64_t)((ncols + ORR_TILE - 1u) / ORR_TILE) * ((n + C2_GROUP - 1) / C2_GROUP) * 64 : (uint64_t)dir_bytes * (split ? 2 : 1));
     c->run_bytes = (uint64_t)total * 4;
     c->id = ++ctx->coll_next_id;
     c->last_use = ++ctx->coll_tick;
@@ -478,6 +488,45 @@ static int coll_resolve_and_sub(bmx_ctx* ctx, const bmx_vec* const* va, size_t n
     return BMX_OK;
 }
 
+// The member directory of a collection built through the tile directories: one more pass over the members' rows (counts and
+// prefixes only: k_coll2_scatter without its run stores), the first time a call names only SOME of the members.
+static int coll_ensure_dir(bmx_ctx* ctx, bmx_coll* c)
+{
+    if (!c || !c->dir_pending) return BMX_OK;
+    int rc;
+    const size_t n = c->nvec;
+    const u32 ncols = c->ncols, ntiles = (ncols + ORR_TILE - 1u) / ORR_TILE, ngroups = ((u32)n + C2_GROUP - 1u) / C2_GROUP;
+    std::vector<u64> tab(n * 4, 0ull);
+    for (size_t i = 0; i < n; ++i) {
+        auto it = ctx->live_vecs.find(c->key[i]);
+        if (it == ctx->live_vecs.end()) { g_last_error = "a member of the collection is gone"; return BMX_ERR_BADARG; }
+        const bmx_vec* o = it->second;
+        tab[i * 4] = (u64)(uintptr_t)o->d_tdir; tab[i * 4 + 1] = (u64)(uintptr_t)o->d_gaps;
+        tab[i * 4 + 2] = (u64)(uintptr_t)o->d_desc; tab[i * 4 + 3] = (u64)o->nblocks;
+    }
+    const size_t dir_bytes = (n + 1) * (size_t)ncols * 4;
+    void* d_optab = nullptr;
+    CollPin pin; pin.pin(c);                                                  // (the allocations below must not evict it)
+    if ((rc = dmalloc(ctx, &d_optab, std::max<size_t>(tab.size() * 8, 64))) || (rc = dmalloc(ctx, (void**)&c->d_dir, dir_bytes)) ||
+        (rc = dmalloc(ctx, (void**)&c->d_dir_s, dir_bytes))) {
+        dfree(ctx, d_optab); dfree(ctx, c->d_dir); dfree(ctx, c->d_dir_s); c->d_dir = c->d_dir_s = nullptr; return rc;
+    }
+    hipError_t e = hipMemcpyAsync(d_optab, tab.data(), tab.size() * 8, hipMemcpyHostToDevice, ctx->stream);
+    const size_t lds = (size_t)ngroups * 16 * 4 * 2;
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_coll2_scatter<8, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_coll2_scatter<8, 4>), dim3(ntiles), dim3(256), lds, ctx->stream, (const u32x4*)d_optab, (u32)n, ncols, ngroups, ctx->xcd_swz,
+                           (const u32*)c->d_bt, (const u64*)c->d_off, (const u32*)c->d_cnt, (const u32*)c->d_cnt_s, c->d_runs, c->d_dir, c->d_dir_s, C2_SKIP_RUNS);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);                // (the table came from pageable memory)
+    dfree(ctx, d_optab);
+    if (e != hipSuccess) { dfree(ctx, c->d_dir); dfree(ctx, c->d_dir_s); c->d_dir = c->d_dir_s = nullptr; return fail_hip(e, "coll_ensure_dir", __LINE__); }
+    dfree(ctx, c->d_bt); c->d_bt = nullptr; c->dir_pending = false;
+    c->bytes += 2ull * dir_bytes; ctx->pack_bytes += 2ull * dir_bytes;
+    return BMX_OK;
+}
+
 static CollView coll_view(const bmx_coll* c)
 {
     if (!c) return CollView{nullptr, nullptr, nullptr, nullptr, 0u, 0u};
@@ -489,6 +538,7 @@ static int coll_members_launch(int mode, bmx_ctx* ctx, const bmx_coll* a, const 
                                u32 col_from, u32 col_to, int opt_compress, u64* d_counts, bmx_vec* v, BlockStat* st)
 {
     if (col_to <= col_from) return BMX_OK;
+    { int rce; if ((rce = coll_ensure_dir(ctx, const_cast<bmx_coll*>(a))) || (rce = coll_ensure_dir(ctx, const_cast<bmx_coll*>(s)))) return rce; }
     const u64 nitems = (u64)(col_to - col_from) * ngroups;
     if ((nitems + CM_WAVES - 1) / CM_WAVES > 0x7FFFFFFFull) { g_last_error = "too many (column, group) items in one run"; return BMX_ERR_RANGE; }
 #define CM_ARGS dim3((u32)((nitems + CM_WAVES - 1) / CM_WAVES)), dim3(CM_WAVES * 64), 0, ctx->stream, coll_view(a), coll_view(s), d_midx, d_groups, ngroups, col_from, col_to, opt_compress, \
@@ -996,12 +1046,14 @@ static int vec_build_tdir(bmx_ctx* ctx, bmx_vec* v)
 {
     if (v->d_tdir || !v->nblocks || !(v->counts[BMX_GAP] | v->counts[BMX_FULL])) return BMX_OK;
     const u32 ntiles = (v->nblocks + ORR_TILE - 1u) / ORR_TILE;
-    int rc = dmalloc(ctx, &v->d_tdir, (size_t)ntiles * 16);
+    // 16 B per tile + 4 B per block: behind the directory, the blocks' (multi-bit | single-bit << 16) 1-run counts
+    const size_t tbytes = (size_t)ntiles * 16 + (size_t)v->nblocks * 4;
+    int rc = dmalloc(ctx, &v->d_tdir, tbytes);
     if (rc) return rc;
     hipLaunchKernelGGL(k_build_tdir, dim3((ntiles + 255) / 256), dim3(256), 0, ctx->stream, (const u64*)v->d_desc, v->nblocks,
-                       (u64)(uintptr_t)v->d_gaps, (u32x4*)v->d_tdir, ntiles);
+                       (u64)(uintptr_t)v->d_gaps, (u32x4*)v->d_tdir, ntiles, (u32*)((char*)v->d_tdir + (size_t)ntiles * 16));
     KCHK();
-    v->bytes += (size_t)ntiles * 16;
+    v->bytes += tbytes;
     return BMX_OK;
 }
 

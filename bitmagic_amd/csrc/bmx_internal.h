@@ -153,6 +153,8 @@ struct bmx_coll {
     u32* d_runs; u64* d_off; u32* d_cnt; u32* d_flags;
     u32* d_cnt_s;                         // split bag (polarity 1): single-bit runs per column, kept as 16-bit positions behind the multi-bit runs; else null
     u32* d_dir; u32* d_dir_s;             // member directory [ncols][nvec + 1]: entries (split: multi-bit runs) before member i | kind << 30; singles before member i
+    u32* d_bt = nullptr;                  // tile build (bmx_kernels10.h): the (tile, group of 64 members, column) run counts, kept so that the
+    bool dir_pending = false;             // ... member directory can be built when a call first needs it (coll_ensure_dir)
     uint64_t entries, bytes, run_bytes, last_use, id;
     uint64_t alg_bytes;                   // algorithmic bytes of the GAP operands: sum of 2 x (len + 1)
     bool has_bit;                         // a bit-block was found while counting: unusable

@@ -97,8 +97,10 @@ __device__ __forceinline__ u32x4 c2_row_load(const OrRec& rec, u32 j, u32 lane16
     return *(gcptr4)(uintptr_t)(a + (lane16 < last16 ? lane16 : last16));
 }
 
-// pass 1.  grid = tiles of 14 columns; bt[(tile * ngroups + G) * 16 + col] = multis | singles << 16 of group G's operands
-template <int DEPTH>
+// pass 1.  grid = tiles of 14 columns; bt[(tile * ngroups + G) * 16 + col] = multis | singles << 16 of group G's operands.
+// The counts come from the per-block figures behind every vector's tile directory (k_build_tdir, bmx_kernels7.h): 4 B per
+// (operand, column) instead of the run lists themselves (the first version of this pass read all of them: 14 GB, 3.1 ms for
+// configs[4]).  Blocks of tiles the directory does not describe carry no figure and are walked from the descriptor table.
 __global__ __launch_bounds__(1024)
 void k_coll2_count(const u32x4* __restrict__ optab_, u32 n, u32 ncols, u32 ngroups, int xcd_swz, C2CountOut o)
 {
@@ -112,9 +114,6 @@ void k_coll2_count(const u32x4* __restrict__ optab_, u32 n, u32 ncols, u32 ngrou
     if (tid < 16u) { WM[tid] = 0u; WS[tid] = 0u; WF[tid] = 0u; WN[tid] = 0u; }
     if (lane < 16u) T[wave][lane] = 0u;
     __syncthreads();
-    const u32 le_lo = lane >= 31u ? ~0u : (2u << lane) - 1u;
-    const u32 le_hi = lane < 32u ? 0u : (lane == 63u ? ~0u : (2u << (lane - 32u)) - 1u);
-    const u32 lane16 = lane << 4;
     u32 fl = 0u, ngap = 0u;                                              // lanes 0 .. 13: flags / GAP operands of column c0 + lane
     for (u32 G = wave; G < ngroups; G += 16u) {
         const u32 op = G * C2_GROUP + lane;
@@ -126,6 +125,29 @@ void k_coll2_count(const u32x4* __restrict__ optab_, u32 n, u32 ncols, u32 ngrou
         const bool member = op < n;
         const bool fastrow = member && (rec.info & TREC_SLOW) == 0u;
         u64 slow_m = __ballot(member && (rec.info & TREC_SLOW) != 0u);
+        // the blocks' counts: behind the operand's directory of (nblocks + 13) / 14 tiles.  Lane k (< 14) reads column k of one
+        // operand after the other -- 56 contiguous bytes, one cache line per operand -- eight operands in flight
+        const u64 td = (u64)e0.x | ((u64)e0.y << 32);
+        const u32 nblk_l = e1.z;
+        const bool have = fastrow && td != 0ull && tile < (nblk_l + ORR_TILE - 1u) / ORR_TILE;
+        const u64 bc_l = have ? td + (u64)((nblk_l + ORR_TILE - 1u) / ORR_TILE) * 16u + (u64)c0 * 4u : 0ull;      // (0: nothing to read for this operand)
+        const u32 bclo = (u32)bc_l, bchi = (u32)(bc_l >> 32);
+        u32 acc_m = 0u, acc_s = 0u;
+        for (u32 j = 0; j < C2_GROUP; j += 8u) {
+            u32 v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const u32 jj = j + (u32)q;
+                const u64 a = (u64)(u32)__builtin_amdgcn_readlane((int)bclo, (int)jj) | ((u64)(u32)__builtin_amdgcn_readlane((int)bchi, (int)jj) << 32);
+                const u32 gm = TREC_GAPMASK((u32)__builtin_amdgcn_readlane((int)rec.info, (int)jj));
+                const bool rd = a != 0ull && lane < ORR_TILE && ((gm >> lane) & 1u) != 0u;
+                v[q] = *(const __attribute__((address_space(1))) u32*)(uintptr_t)(rd ? a + (u64)lane * 4u : dummy);
+                if (!rd) v[q] = 0u;
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { acc_m += v[q] & 0xFFFFu; acc_s += v[q] >> 16; }
+        }
+        if (lane < ORR_TILE) T[wave][lane] += acc_m | (acc_s << 16);
         // block kinds of the rows the directory describes: GAP where its mask says so, NULL elsewhere (a FULL block makes a
         // tile slow): a ballot per column over the 64 operands of the batch, lane k keeps column k
 #pragma unroll
@@ -133,28 +155,6 @@ void k_coll2_count(const u32x4* __restrict__ optab_, u32 n, u32 ncols, u32 ngrou
             const bool gbit = ((rec.info >> (8u + k)) & 1u) != 0u;
             const u64 g = __ballot(fastrow && gbit), z = __ballot(fastrow && !gbit);
             if (lane == k) { ngap += (u32)__popcll(g); fl |= z ? COLL_FLAG_NULL : 0u; }
-        }
-        u32x4 c[DEPTH];
-#pragma unroll
-        for (int k = 0; k < DEPTH; ++k) c[k] = c2_row_load(rec, (u32)k, lane16, dummy);
-        for (u32 j = 0; j < C2_GROUP; j += DEPTH) {
-#pragma unroll
-            for (int k = 0; k < DEPTH; ++k) {
-                const u32 jj = j + (u32)k;
-                const u32 ahi = (u32)__builtin_amdgcn_readlane((int)rec.ahi, (int)jj);
-                const u32 nch = OREC_NCH(ahi);
-                if (nch) {                                                 // (scalar) a row the directory describes
-                    const u32 mlo = (u32)__builtin_amdgcn_readlane((int)rec.mlo, (int)jj), mhi = (u32)__builtin_amdgcn_readlane((int)rec.mhi, (int)jj);
-                    const u32 info = (u32)__builtin_amdgcn_readlane((int)rec.info, (int)jj);
-                    const u32 nx = (u32)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)c[k].x, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
-                    const u32 col = c2_col_of_lane(mlo, mhi, le_lo, le_hi, ahi, info);
-                    u32 multi, single, y[4];
-                    c2_classify(c[k], nx, multi, single, y);
-                    const u32 v = lane < nch ? (u32)__popc(multi) | ((u32)__popc(single) << 16) : 0u;
-                    if (v) atomicAdd(&T[wave][col], v);
-                }
-                c[k] = c2_row_load(rec, jj + DEPTH, lane16, dummy);
-            }
         }
         // rows the directory handed back: a lane per column through the descriptor table
         while (slow_m) {
@@ -198,13 +198,17 @@ void k_coll2_count(const u32x4* __restrict__ optab_, u32 n, u32 ncols, u32 ngrou
 // the row lanes: every store instruction touched ~14 cache lines with a few bytes each -- 2 G partial-line writes for 51 M
 // lines of output, 14.1 ms.  Staged: lines are written whole.)  A sub-batch whose pieces do not fit the staging area -- dense
 // operands -- takes the direct stores.
-#define C2_CAPM 48u                  // staged multi-bit runs per column and sub-batch
-#define C2_CAPS 192u                 // staged single-bit positions per column and sub-batch
+#define C2_SKIP_DIR 1
+#define C2_SKIP_RUNS 6
+#define C2_CAPM 32u                  // staged multi-bit runs per column and sub-batch
+#define C2_CAPS 160u                 // staged single-bit positions per column and sub-batch
 template <int R, int NW>
 __global__ __launch_bounds__(NW * 64)
 void k_coll2_scatter(const u32x4* __restrict__ optab_, u32 n, u32 ncols, u32 ngroups, int xcd_swz, const u32* __restrict__ bt,
                      const u64* __restrict__ off, const u32* __restrict__ cnt, const u32* __restrict__ cnt_s,
-                     u32* __restrict__ runs, u32* __restrict__ dirm, u32* __restrict__ dirs)
+                     u32* __restrict__ runs, u32* __restrict__ dirm, u32* __restrict__ dirs,
+                     int skip /* C2_SKIP_DIR: the member directory is not written (bmx_collection_prepare: it is built when a call first needs it);
+                                 C2_SKIP_RUNS: only the directory is (that later pass) */)
 {
     extern __shared__ u32 lds_dyn[];
     u32* Pm = lds_dyn;                          // [ngroups][16]: multi-bit runs of the column before group G
@@ -225,7 +229,7 @@ void k_coll2_scatter(const u32x4* __restrict__ optab_, u32 n, u32 ncols, u32 ngr
         const u32 nall = in ? cnt[c] : 0u, ns = in ? cnt_s[c] : 0u;
         OC[tid] = in ? off[c] : 0ull;
         NM4[tid] = (nall - ns + 3u) & ~3u;
-        if (in) { dirm[(size_t)c * (n + 1u) + n] = nall - ns; dirs[(size_t)c * (n + 1u) + n] = ns; }
+        if (in && !(skip & C2_SKIP_DIR)) { dirm[(size_t)c * (n + 1u) + n] = nall - ns; dirs[(size_t)c * (n + 1u) + n] = ns; }
         u32 rm = 0u, rs = 0u;
         for (u32 G = 0; G < ngroups; ++G) {
             const u32 v = bt[((size_t)tile * ngroups + G) * 16u + tid];
@@ -307,7 +311,7 @@ void k_coll2_scatter(const u32x4* __restrict__ optab_, u32 n, u32 ncols, u32 ngr
                 const u32 info = (u32)__builtin_amdgcn_ds_bpermute((int)(jj << 2), (int)rec.info);
                 const u64 dt = (u64)(u32)__builtin_amdgcn_ds_bpermute((int)(jj << 2), (int)rec.dlo) | ((u64)(u32)__builtin_amdgcn_ds_bpermute((int)(jj << 2), (int)rec.dhi) << 32);
                 const u32 nblk = (u32)__builtin_amdgcn_ds_bpermute((int)(jj << 2), (int)rec.nblk);
-                if (zin && i < n && cc < ncols) {
+                if (zin && i < n && cc < ncols && !(skip & C2_SKIP_DIR)) {
                     u32 kind = ((info >> (8u + k)) & 1u) ? (u32)K_GAP : (u32)K_NULL;
                     if (info & TREC_SLOW) kind = DESC_K(c2_slow_desc(dt, nblk, c0, k));
                     dirm[(size_t)cc * (n + 1u) + i] = tm[r * 16u + k] | (kind << 30);
@@ -316,6 +320,7 @@ void k_coll2_scatter(const u32x4* __restrict__ optab_, u32 n, u32 ncols, u32 ngr
             }
             // (c) the runs into their places: the staging area (positions relative to the sub-batch's piece) or, when a piece does
             // not fit, global memory directly
+            if (!(skip & C2_SKIP_RUNS))
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const u32 jj = j0 + (u32)r;
@@ -377,15 +382,24 @@ void k_coll2_scatter(const u32x4* __restrict__ optab_, u32 n, u32 ncols, u32 ngr
                 }
             }
             // (d) every column's piece of the sub-batch, contiguous in the staging area, to its place in the column region
-            if (staged) {
+            if (staged && !(skip & C2_SKIP_RUNS)) {
                 wfence();
-#pragma unroll 1
+                // (all the staged values of a lane are read first, then stored: fourteen dependent LDS round trips otherwise)
+                u32 vm[ORR_TILE]; u16 vs[ORR_TILE][(C2_CAPS + 63u) / 64u];
+#pragma unroll
+                for (u32 k = 0; k < ORR_TILE; ++k) {
+                    vm[k] = SM[wave][k][lane < C2_CAPM ? lane : 0u];
+#pragma unroll
+                    for (u32 q = 0; q < (C2_CAPS + 63u) / 64u; ++q) vs[k][q] = SS[wave][k][q * 64u + lane < C2_CAPS ? q * 64u + lane : 0u];
+                }
+#pragma unroll
                 for (u32 k = 0; k < ORR_TILE; ++k) {
                     const u32 m0 = tm[k], m1 = tm[R * 16 + (int)k], s0 = ts[k], s1 = ts[R * 16 + (int)k];       // (uniform: every lane reads the same words)
                     u32* om = runs + OC[k] + m0;
                     u16* os = reinterpret_cast<u16*>(runs + OC[k] + NM4[k]) + s0;
-                    for (u32 z = lane; z < m1 - m0; z += 64u) om[z] = SM[wave][k][z];
-                    for (u32 z = lane; z < s1 - s0; z += 64u) os[z] = SS[wave][k][z];
+                    if (lane < m1 - m0) om[lane] = vm[k];
+#pragma unroll
+                    for (u32 q = 0; q < (C2_CAPS + 63u) / 64u; ++q) if (q * 64u + lane < s1 - s0) os[q * 64u + lane] = vs[k][q];
                 }
             }
         }

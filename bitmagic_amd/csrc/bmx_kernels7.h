@@ -49,18 +49,24 @@
 // tile directory of one vector: one thread per tile of ORR_TILE block columns; entry (16 B) =
 //   {first chunk of the tile in the slab, n chunks | TREC_SLOW | GAP columns << 8 | TREC_ALLGAP, M lo, M hi}
 // M = chunks that start a block
+// bcnt (round 5, may be null): per block, the 1-runs of the block as multi-bit | single-bit << 16 (what a split collection keeps
+// apart, bmx_kernels6.h) -- 0 for NULL / FULL blocks, 0xFFFFFFFF for the GAP blocks of a tile the directory does not describe.
+// The builder reads the run lists anyway (TREC_LONG): the counts let bmx_collection_prepare size the column regions of a
+// collection without a pass over the operands' run lists (bmx_kernels10.h).
 __global__ __launch_bounds__(256)
-void k_build_tdir(const u64* __restrict__ desc, u32 nblocks, u64 gaps_base, u32x4* __restrict__ tdir, u32 ntiles)
+void k_build_tdir(const u64* __restrict__ desc, u32 nblocks, u64 gaps_base, u32x4* __restrict__ tdir, u32 ntiles, u32* __restrict__ bcnt)
 {
     const u32 t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= ntiles) return;
     u64 next = 0, first = 0, M = 0;
     bool have = false, slow = false;
     u32 nch = 0, gapmask = 0;
+    u32 ch_of[ORR_TILE];
     for (u32 k = 0; k < ORR_TILE; ++k) {
         const u32 c = t * ORR_TILE + k;
         const u64 d = c < nblocks ? desc[c] : 0ull;
         const u32 kind = DESC_K(d);
+        ch_of[k] = 0u;
         if (kind == K_GAP) {
             const u64 a = DESC_P(d);
             const u32 meta = GMETA(d);
@@ -70,6 +76,7 @@ void k_build_tdir(const u64* __restrict__ desc, u32 nblocks, u64 gaps_base, u32x
             if (meta & 1u) slow = true;                           // starts with a 1-run: the row code pairs words as (0-run end, 1-run end)
             if (nch < 64u) M |= 1ull << nch;
             gapmask |= 1u << k;
+            ch_of[k] = ch;
             nch += ch; next = a + (u64)ch * 16u;
         } else if (kind != K_NULL) slow = true;                   // FULL (or a bit-block): the descriptor path takes the tile
     }
@@ -80,16 +87,26 @@ void k_build_tdir(const u64* __restrict__ desc, u32 nblocks, u64 gaps_base, u32x
     if (have && !slow) {
         gcptr4 g = (gcptr4)(uintptr_t)first;
         u32x4 cur = g[0];
-        for (u32 q = 0; q < nch; ++q) {
-            const u32x4 nxt = q + 1u < nch ? g[q + 1u] : (u32x4)(0xFFFFFFFFu);
-            const u32 x[5] = {cur.x, cur.y, cur.z, cur.w, nxt.x};
+        u32 q = 0u;
+        for (u32 k = 0; k < ORR_TILE; ++k) {
+            u32 m = 0u, sg = 0u;
+            for (u32 j = 0; j < ch_of[k]; ++j, ++q) {
+                const u32x4 nxt = q + 1u < nch ? g[q + 1u] : (u32x4)(0xFFFFFFFFu);
+                const u32 x[5] = {cur.x, cur.y, cur.z, cur.w, nxt.x};
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const u32 p = x[i] >> 16, e = x[i + 1] & 0xFFFFu;
-                any_long = any_long || (p != 0xFFFFu && e - p != 1u);
+                for (int i = 0; i < 4; ++i) {
+                    const u32 p = x[i] >> 16, e = x[i + 1] & 0xFFFFu;
+                    const bool run = p != 0xFFFFu, one = e - p == 1u;
+                    m += (run && !one) ? 1u : 0u; sg += (run && one) ? 1u : 0u;
+                }
+                cur = nxt;
             }
-            cur = nxt;
+            any_long = any_long || m != 0u;
+            if (bcnt && t * ORR_TILE + k < nblocks) bcnt[t * ORR_TILE + k] = m | (sg << 16);
         }
+    } else if (bcnt) {
+        for (u32 k = 0; k < ORR_TILE; ++k)
+            if (t * ORR_TILE + k < nblocks) bcnt[t * ORR_TILE + k] = ((gapmask >> k) & 1u) ? 0xFFFFFFFFu : 0u;
     }
     u32x4 r;
     r.x = (have && !slow) ? (u32)((first - gaps_base) >> 4) : 0u;
