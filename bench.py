@@ -948,6 +948,8 @@ def _select_kernel_name():
         return "k_select_l<4> (block index: running counts, cumulative row, bit line)"
     if sl == "1":
         return "k_select_lines<4> (block index + octant directory, then the rank line guessed by interpolation and verified by its header)"
+    if os.environ.get("BMX_RS_SELECT_TOP", "-1") != "0":
+        return "k_select_top<4> (the select directory's 65,536-entry summary in LDS -- one 1024-thread workgroup per CU -- then the rank line, interpolated guess verified by the line's header)"
     return "k_select_sdir<4> (select directory over the rank lines: the line of every 2^k-th one, interpolated guess verified by the line's header)"
 
 
@@ -997,6 +999,19 @@ def run_rank_select(args, env, quick=False, dq=None):
     qs, _ = torch.sort(qn)
     sorted_ms = event_avg_ms(lambda: _ffi.check(L.bmx_rank_batch_dev(ctx._h, v._h, rs._h, qs.data_ptr(), nq, out.data_ptr())), 5, ctx)
     sort_ms = event_avg_ms(lambda: torch.sort(qn), 3, ctx)
+    # select: the same batch with the ranks in ascending order ("every k-th element", cursor-style enumeration: neighbours in the
+    # batch share lines), and the round-4 kernel (global directory, two dependent reads) next to the LDS-directory one
+    qrs, _ = torch.sort(qr)
+    ctx.set_tuning("rs_sorted_hint", 1)
+    sel_sorted_ms = event_avg_ms(lambda: _ffi.check(L.bmx_select_batch_dev(ctx._h, v._h, rs._h, qrs.data_ptr(), nq, pos.data_ptr(), found.data_ptr())), 5, ctx)
+    ctx.set_tuning("rs_sorted_hint", 0)
+    ctx.set_tuning("rs_select_top", 0)
+    sel_sdir_ms = event_avg_ms(do_sel, 5, ctx)
+    ctx.set_tuning("rs_select_top", -1)
+    sel_by_batch = {}
+    for nqq in (100_000, 1_000_000, nq):
+        if nqq <= nq:
+            sel_by_batch[str(nqq)] = round(event_avg_ms(lambda: _ffi.check(L.bmx_select_batch_dev(ctx._h, v._h, rs._h, qr.data_ptr(), nqq, pos.data_ptr(), found.data_ptr())), 5, ctx), 4)
     # the bound: random 128-byte lines per second this box gathers from a buffer as large as the vector's bit slab
     info = v.info()
     slab_bytes = max(info["counts"][2] * 8192, 1 << 20)
@@ -1020,6 +1035,8 @@ def run_rank_select(args, env, quick=False, dq=None):
                       "rank_Mq_s": round(nq / rank_ms / 1e3, 1), "select_Mq_s": round(nq / sel_ms / 1e3, 1),
                       "rank_select_roundtrip_ok": ok,
                       "rank_ms_sorted_queries": round(sorted_ms, 4), "sort_ms_torch": round(sort_ms, 4),
+                      "select_ms_sorted_ranks": round(sel_sorted_ms, 4), "select_ms_global_directory_kernel": round(sel_sdir_ms, 4),
+                      "select_ms_by_batch": sel_by_batch,
                       "bucketing_note": "rank over the same queries pre-sorted by position vs the cost of sorting them (torch.sort): "
                                         "bucketing a batch by block pays only if sort + sorted run < the unsorted run"},
            "roofline": {"bound": "hbm", "achieved": round(rank_lines_s / 1e9, 3), "peak": round(ceil_lines_s / 1e9, 3),
@@ -1031,9 +1048,9 @@ def run_rank_select(args, env, quick=False, dq=None):
                                        f"a rank query's bit line) over a {slab_bytes / 1e6:.0f} MB buffer in {pm.value:.4f} ms",
                         "select": {"kernel": _select_kernel_name(), "achieved": round(sel_lines_s / 1e9, 3), "frac": round(sel_lines_s / ceil_lines_s, 4),
                                    "avg_launch_ms": round(sel_ms, 4),
-                                   "note": "queries per second against the same random-line rate: a select is at least TWO dependent reads "
-                                           "(a directory entry, L2-resident, then the line; a second line when the interpolated guess is off by one), "
-                                           "so 0.5 is the ceiling of this ratio"},
+                                   "note": "queries per second against the same random-line rate: with the directory summary in LDS a select is ONE "
+                                           "global read (the line) when the interpolated guess holds, a second line when it is off by one; the round-4 "
+                                           "kernel (directory in global memory: two dependent reads) is timed beside it (select_ms_global_directory_kernel)"},
                         "as_bandwidth_GBps": round(nq * 128 / rank_ms / 1e6, 1),
                         "frac_bytes": round(nq * 128 / rank_ms / 1e6 / HBM_PEAK_GBS, 4),
                         "select_frac_bytes": round(nq * 136 / sel_ms / 1e6 / HBM_PEAK_GBS, 4),
@@ -1431,7 +1448,7 @@ def summary_of(res):
     cpu = res.get("cpu_baseline")
     if cpu:
         out["cpu_baseline"] = {k: cpu.get(k) for k in ("value", "unit", "cores", "kind", "matches_gpu", "allcores_gbit_s", "cores_used", "matches_gpu_full", "matches_gpu_full_materialised", "matches_gpu_sample") if k in cpu}
-    for k in ("per_op", "rank_ms", "select_ms", "rank_Mq_s", "select_Mq_s", "rank_select_roundtrip_ok", "result_count", "cold_ms", "build_ms", "warm_ms",
+    for k in ("per_op", "rank_ms", "select_ms", "select_ms_sorted_ranks", "select_ms_global_directory_kernel", "rank_Mq_s", "select_Mq_s", "rank_select_roundtrip_ok", "result_count", "cold_ms", "build_ms", "warm_ms",
               "break_even_calls", "subset_of_the_collection", "own_read_write_probe"):
         if k in res["config"]:
             out[k] = res["config"][k]

@@ -753,7 +753,7 @@ int bmx_ctx_create(int device, void* stream, bmx_ctx** out)
     // an invalid value is ignored (the default stays)
     static const char* const env_keys[][2] = {
         {"BMX_PIPE_UNROLL", "pipe_unroll"}, {"BMX_PIPE_ROWS", "pipe_rows"}, {"BMX_PIPE_NT", "pipe_nt"},
-        {"BMX_PIPE_WG", "pipe_wg"}, {"BMX_PIPE_WINDOW", "pipe_window"}, {"BMX_PIPE_SPLIT", "pipe_split"}, {"BMX_OR_TILE", "or_tile"}, {"BMX_OR_ROWS", "or_rows"}, {"BMX_OR_DEPTH", "or_depth"}, {"BMX_OR_WINDOW", "or_window"}, {"BMX_DIRECT_COLS", "direct_cols"}, {"BMX_FF_WINDOW", "ff_window"}, {"BMX_GAP_COUNT", "gap_count"}, {"BMX_AND_ROWS", "and_rows"}, {"BMX_AGG_SHAPE", "agg_shape"}, {"BMX_AND_ROWS_WG", "and_rows_wg"}, {"BMX_AND_ROWS_DEPTH", "and_rows_depth"}, {"BMX_AND_ROWS_NT", "and_rows_nt"}, {"BMX_RANGE_HALVES", "range_halves"}, {"BMX_PAIR_STREAM", "pair_stream"}, {"BMX_PAIR_WGS", "pair_wgs"}, {"BMX_RS_LANES", "rs_lanes"}, {"BMX_RS_LINES", "rs_lines"}, {"BMX_RS_SELECT_LINES", "rs_select_lines"}, {"BMX_RS_SDIR_SHIFT", "rs_sdir_shift"}, {"BMX_COLL_SHAPE", "coll_shape"}, {"BMX_COLL_WINDOW", "coll_window"}, {"BMX_COLL_SPLIT", "coll_split"}, {"BMX_COLL_BUILD", "coll_build"}, {"BMX_EQ_BIG", "eq_big"}, {"BMX_PAIR_LOOP", "pair_loop"}, {"BMX_PAIR_NT", "pair_nt"}, {"BMX_EQ_BIG_SHAPE", "eq_big_shape"}, {"BMX_OP2_WGS", "op2_wgs"}, {"BMX_OP2_LOOP", "op2_loop"}, {"BMX_OP2_NT", "op2_nt"}, {"BMX_GAP_PACK", "gap_pack"}, {"BMX_COLL_MEMBERS", "coll_members"}, {"BMX_XCD_SWIZZLE", "xcd_swizzle"}};
+        {"BMX_PIPE_WG", "pipe_wg"}, {"BMX_PIPE_WINDOW", "pipe_window"}, {"BMX_PIPE_SPLIT", "pipe_split"}, {"BMX_OR_TILE", "or_tile"}, {"BMX_OR_ROWS", "or_rows"}, {"BMX_OR_DEPTH", "or_depth"}, {"BMX_OR_WINDOW", "or_window"}, {"BMX_DIRECT_COLS", "direct_cols"}, {"BMX_FF_WINDOW", "ff_window"}, {"BMX_GAP_COUNT", "gap_count"}, {"BMX_AND_ROWS", "and_rows"}, {"BMX_AGG_SHAPE", "agg_shape"}, {"BMX_AND_ROWS_WG", "and_rows_wg"}, {"BMX_AND_ROWS_DEPTH", "and_rows_depth"}, {"BMX_AND_ROWS_NT", "and_rows_nt"}, {"BMX_RANGE_HALVES", "range_halves"}, {"BMX_PAIR_STREAM", "pair_stream"}, {"BMX_PAIR_WGS", "pair_wgs"}, {"BMX_RS_LANES", "rs_lanes"}, {"BMX_RS_SELECT_TOP", "rs_select_top"}, {"BMX_RS_LINES", "rs_lines"}, {"BMX_RS_SELECT_LINES", "rs_select_lines"}, {"BMX_RS_SDIR_SHIFT", "rs_sdir_shift"}, {"BMX_COLL_SHAPE", "coll_shape"}, {"BMX_COLL_WINDOW", "coll_window"}, {"BMX_COLL_SPLIT", "coll_split"}, {"BMX_COLL_BUILD", "coll_build"}, {"BMX_EQ_BIG", "eq_big"}, {"BMX_PAIR_LOOP", "pair_loop"}, {"BMX_PAIR_NT", "pair_nt"}, {"BMX_EQ_BIG_SHAPE", "eq_big_shape"}, {"BMX_OP2_WGS", "op2_wgs"}, {"BMX_OP2_LOOP", "op2_loop"}, {"BMX_OP2_NT", "op2_nt"}, {"BMX_GAP_PACK", "gap_pack"}, {"BMX_COLL_MEMBERS", "coll_members"}, {"BMX_XCD_SWIZZLE", "xcd_swizzle"}};
     for (auto& kv : env_keys)
         if (const char* e = getenv(kv[0])) (void)bmx_ctx_set_tuning(ctx, kv[1], atoi(e));
     g_last_error.clear();
@@ -834,6 +834,8 @@ int bmx_ctx_set_tuning(bmx_ctx* ctx, const char* key, int value)
     else if (k == "rs_select_lines") { ARGCHK(value >= 0 && value <= 2); ctx->rs_select_lines = value; }
     else if (k == "rs_sdir_shift") { ARGCHK(value == 0 || (value >= 6 && value <= 20)); ctx->rs_sdir_shift = value; }
     else if (k == "rs_lines") { ARGCHK(value >= 0 && value <= 2); ctx->rs_lines = value; }
+    else if (k == "rs_sorted_hint") { ARGCHK(value == 0 || value == 1); ctx->rs_sorted_hint = value; }
+    else if (k == "rs_select_top") { ARGCHK(value >= -1 && value <= 1); ctx->rs_select_top = value; }
     else if (k == "rs_lanes") { ARGCHK(value == 0 || value == 2 || value == 4 || value == 8); ctx->rs_lanes = value; }
     else if (k == "pipe_wg") { ARGCHK(value == 0 || (value >= 64 && value <= 1024 && value % 64 == 0)); ctx->pipe_wg = value; }
     else if (k == "xcd_swizzle") ctx->xcd_swz = value != 0;
@@ -3558,7 +3560,21 @@ int bmx_rs_build(bmx_ctx* ctx, const bmx_vec* v, bmx_rs** out)
             hipLaunchKernelGGL(k_rs_sdir, dim3((u32)((nlines + 255u) / 256u)), dim3(256), 0, ctx->stream,
                                (const u32*)rs->d_lines, (u64)nlines, (u64)rs->count, sh, rs->d_sdir, (u64)rs->sdir_entries);
             RSCHK(hipGetLastError());
+            // the directory's summary for LDS (k_select_top): one entry per 2^stop_shift ones, at most 65,535 + the sentinel
+            uint32_t ssh = sh;
+            while (((rs->count + (1ull << ssh) - 1ull) >> ssh) + 1ull > STOP_ENTRIES && ssh < 40u) ++ssh;
+            const uint32_t n_top = (uint32_t)(((rs->count + (1ull << ssh) - 1ull) >> ssh) + 1ull);
+            if ((rc = dmalloc(ctx, (void**)&rs->d_stop, 256u * 4u + STOP_ENTRIES * 2u + 64u))) { bmx_rs_free(ctx, rs); return rc; }
+            RSCHK(hipMemsetAsync(rs->d_stop, 0, 256u * 4u + STOP_ENTRIES * 2u + 64u, ctx->stream));
+            RSCHK(hipMemsetAsync(ctx->d_small + 32, 0, 8, ctx->stream));
+            hipLaunchKernelGGL(k_rs_stop, dim3((n_top + 255u) / 256u), dim3(256), 0, ctx->stream, (const u32*)rs->d_sdir, (u64)rs->sdir_entries, ssh - sh, n_top,
+                               rs->d_stop, (u16*)(rs->d_stop + 256), (u32*)(ctx->d_small + 32));
+            RSCHK(hipGetLastError());
+            RSCHK(hipMemcpyAsync(ctx->h_small + 32, ctx->d_small + 32, 8, hipMemcpyDeviceToHost, ctx->stream));
             RSCHK(hipStreamSynchronize(ctx->stream));
+            rs->stop_shift = ssh;
+            if (ctx->h_small[32] != 0) { dfree(ctx, rs->d_stop); rs->d_stop = nullptr; }      // (256 entries spread over more than 65,535 lines somewhere: the global directory serves)
+            else rs->bytes += 256u * 4u + STOP_ENTRIES * 2u;
         }
 #undef RSCHK
     }
@@ -3580,7 +3596,7 @@ int bmx_rs_free(bmx_ctx* ctx, bmx_rs* rs)
     ARGCHK(ctx && rs->ctx == ctx);
     int rc = set_dev(ctx); if (rc) return rc;
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    dfree(ctx, rs->d_bcount); dfree(ctx, rs->d_sub); dfree(ctx, rs->d_rcount); dfree(ctx, rs->d_cum); dfree(ctx, rs->d_gidx); dfree(ctx, rs->d_sample); dfree(ctx, rs->d_lines); dfree(ctx, rs->d_dir8); dfree(ctx, rs->d_sdir);
+    dfree(ctx, rs->d_bcount); dfree(ctx, rs->d_sub); dfree(ctx, rs->d_rcount); dfree(ctx, rs->d_cum); dfree(ctx, rs->d_gidx); dfree(ctx, rs->d_sample); dfree(ctx, rs->d_lines); dfree(ctx, rs->d_dir8); dfree(ctx, rs->d_sdir); dfree(ctx, rs->d_stop);
     delete rs;
     return BMX_OK;
 }
@@ -3630,11 +3646,30 @@ int bmx_select_batch_dev(bmx_ctx* ctx, const bmx_vec* v, const bmx_rs* rs, const
     int rc = set_dev(ctx); if (rc) return rc;
     if (!q) return BMX_OK;
     int lpq = ctx->rs_lanes ? ctx->rs_lanes : (q >= (1u << 16) ? RS_SELECT_LANES_DEFAULT : 8);
+    // big batches over a vector whose directory summary fits LDS: k_select_top, two lanes per query (profiles/r05_select: 10 M random
+    // selects on configs[3] 0.377 ms against 0.416 / 0.436 for the global-directory kernel with four / two lanes, 100 M: 3.63 against
+    // 4.09; at 1 M the 129 KiB every workgroup copies first cost more than they save: 0.058 against 0.044 -- taken from 4 M queries)
+    const bool top_ok = rs->d_stop && rs->d_sdir && ctx->rs_select_lines == 2 && ctx->rs_select_top != 0 &&
+                        (ctx->rs_select_top == 1 || (q >= (1u << 22) && !ctx->rs_sorted_hint)) && q < (1ull << 32) && ctx->max_lds_bytes >= 256u * 4u + STOP_ENTRIES * 2u + 16384u;
+    if (top_ok && !ctx->rs_lanes) lpq = 2;
+    // ranks the caller says arrive in ascending order (cursor-style enumeration): neighbours share lines and directory entries;
+    // the global-directory kernel with two lanes per query is the fastest there (10 M: 0.25 ms against 0.38 random)
+    if (ctx->rs_sorted_hint && !ctx->rs_lanes && q >= (1u << 16)) lpq = 2;
     u32 grid = (u32)std::min<size_t>((q * (size_t)lpq + 255) / 256, 256u * 16u);
 #define SEL_ARGS dim3(grid), dim3(256), 0, ctx->stream, v->d_desc, v->nblocks, \
                  rs->d_rcount, rs->d_cum, rs->d_gidx, rs->d_sample, rs->nsamples, rs->sample_shift, rs->count, \
                  (const u64*)d_rank, (u64)q, (u64*)d_pos, (u8*)d_found
-    if (rs->d_sdir && lpq != 8 && ctx->rs_select_lines == 2) {
+    const bool top = top_ok && lpq != 8;
+    if (top) {
+        // the directory's summary in LDS: one 1024-thread workgroup per CU (129 KiB of LDS each), one global read per query
+        const size_t lds = 256u * 4u + STOP_ENTRIES * 2u + 16u * 64u * 16u;       // the summary + a queue of 64 parked queries per wave
+        auto fn = lpq == 2 ? k_select_top<2> : k_select_top<4>;
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        const u32 g = (u32)std::min<size_t>((q * (size_t)lpq + 1023) / 1024, 256u);
+        hipLaunchKernelGGL(fn, dim3(g), dim3(1024), lds, ctx->stream, (const u32*)rs->d_lines, (const u32*)rs->d_stop, rs->stop_shift, rs->count,
+                           (const u64*)d_rank, (u64)q, (u64*)d_pos, (u8*)d_found);
+    }
+    else if (rs->d_sdir && lpq != 8 && ctx->rs_select_lines == 2) {
         if (lpq == 2) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_select_sdir<2>), dim3(grid), dim3(256), 0, ctx->stream, (const u32*)rs->d_lines, (const u32*)rs->d_sdir,
                                          rs->sdir_shift, rs->count, (const u64*)d_rank, (u64)q, (u64*)d_pos, (u8*)d_found);
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_select_sdir<4>), dim3(grid), dim3(256), 0, ctx->stream, (const u32*)rs->d_lines, (const u32*)rs->d_sdir,

@@ -95,6 +95,8 @@ struct bmx_ctx {
     int rs_lines = 1;          // build_rs_index also lays the vector out as rank lines (one 128-B line per rank query; +108 % of the raw bits): 1 = where that is <= 1.2 x the vector's own device bytes (dense vectors), 2 = always, 0 = never
     int rs_sdir_shift = 0;     // ones per select-directory entry = 2^this; 0 = from the density (an entry per ~10 lines); grown when the directory would pass 8 MB
     int rs_select_lines = 2;   // select through the rank lines (octant directory + interpolated line guess verified by the line headers): 0 = k_select_l, 2 = select directory over the lines (k_select_sdir)
+    int rs_select_top = -1;    // select with the 65,536-entry directory summary in LDS (k_select_top): -1 = batches of >= 4 M queries, 0 = never, 1 = always (where the summary exists)
+    int rs_sorted_hint = 0;    // the caller's select batches arrive with ascending ranks (enumeration): the shape that is fastest for them
     int rs_lanes = 0;          // rank: lanes per query (k_rank_l): 0 = automatic, 8 = the original kernel, 2, 4
     int xcd_swz = 1;
 };
@@ -184,6 +186,7 @@ struct bmx_rs {
     u32* d_lines;                                         // rank lines: 69 x 128 B per block (count before the line + 960 bits), or null
     u32* d_sdir; uint32_t sdir_shift; uint64_t sdir_entries;  // with rank lines: select directory (line of every 2^shift-th one) + sentinel
     u16* d_dir8;                                          // with rank lines: ones of a block before each of its eight 8,192-bit octants
+    u32* d_stop = nullptr; uint32_t stop_shift = 0;       // with the select directory: its 65,536-entry summary for LDS (k_select_top): base[256] + 16-bit offsets, or null
     size_t bytes;
 };
 

@@ -1079,12 +1079,100 @@ void k_rs_sdir(const u32* __restrict__ lines, u64 nlines, u64 total, u32 shift, 
     if (j == nlines - 1u) sdir[nent - 1u] = (u32)j;
 }
 
+// the search the select kernels share: the target line lies in [lo, hi] (two adjacent directory entries 2^shift ones apart);
+// line j is read and its header decides -- found / earlier / later; a miss takes up to three secant steps (the header says how
+// many ones away the answer is; span = lines the entry's 2^shift ones are spread over), then bisects.  Iterations it0 ..
+// max_it - 1 are run; `searching` says whether the query is still open afterwards (lo / hi / j then hold its state).
+template <u32 LPQ>
+__device__ __forceinline__ void select_load(const u32* __restrict__ lines, u32 j, u32 sub, u32x4 (&v)[8u / LPQ])
+{
+    constexpr u32 NV = 8u / LPQ;
+    gcptr4 p = as_gc4(lines + (size_t)j * 32u) + sub * NV;
+#pragma unroll
+    for (u32 i = 0; i < NV; ++i) v[i] = p[i];
+}
+
+// one step of the search on the loaded line j: found (pos written, searching cleared) or the bounds and the next line updated
+template <u32 LPQ>
+__device__ __forceinline__ void select_eval(const u32x4 (&v)[8u / LPQ], u32& lo, u32& hi, u32& j, u64 span, u32 shift, u64 r,
+                                            bool& searching, bool& failed, u32 it, u64 qi, u32 lane, u32 sub, u64* __restrict__ pos)
+{
+    constexpr u32 NV = 8u / LPQ;
+    u32 wd[4 * NV];
+#pragma unroll
+    for (u32 i = 0; i < NV; ++i) { wd[4 * i] = v[i].x; wd[4 * i + 1] = v[i].y; wd[4 * i + 2] = v[i].z; wd[4 * i + 3] = v[i].w; }
+    u32 hlo = sub == 0 ? wd[0] : 0u, hhi = sub == 0 ? wd[1] : 0u;
+    hlo = group_first<LPQ>(hlo, lane); hhi = group_first<LPQ>(hhi, lane);
+    const u64 hdr = ((u64)hhi << 32) | hlo;                   // ones of the vector before this line
+    if (sub == 0) { wd[0] = 0u; wd[1] = 0u; }
+    u32 mine = 0;
+#pragma unroll
+    for (u32 t = 0; t < 4 * NV; ++t) mine += (u32)__popc(wd[t]);
+    u32 ltot;
+    const u32 excl = group_excl<LPQ>(mine, sub, lane, ltot);
+    const bool left = searching && r <= hdr;                  // the r-th one lies in an earlier line
+    const bool right = searching && r > hdr + ltot;           // ... in a later one
+    if (searching && !left && !right) {
+        const u32 need0 = (u32)(r - hdr);                     // 1..ltot inside this line
+        if (need0 > excl && need0 <= excl + mine) {
+            u32 need = need0 - excl, word = 0, wi = 0; bool got = false;
+#pragma unroll
+            for (u32 t = 0; t < 4 * NV; ++t) {
+                const u32 pc = (u32)__popc(wd[t]);
+                if (!got) { if (need <= pc) { word = wd[t]; wi = t; got = true; } else need -= pc; }
+            }
+            const u32 nb = j / RL_LINES, lj = j - nb * RL_LINES;
+            const u32 bit = lj * RL_BITS + ((sub * 4u * NV + wi) - 2u) * 32u + select_in_word(word, need);
+            pos[qi] = ((u64)nb << 16) + bit;
+        }
+        searching = false;
+    }
+    if (left) hi = j - 1u;
+    if (right) lo = j + 1u;
+    if (left || right) {
+        if (lo > hi) { searching = false; failed = true; }    // (cannot happen with consistent headers: reported as not found)
+        else if (it < 3u) {
+            const u64 away = left ? hdr - r : r - hdr - ltot - 1u;
+            u64 step = 1u + ((away * span) >> shift);                 // away / (S / span) lines, at least the neighbour
+            if (step > (u64)(hi - lo) + 1u) step = (u64)(hi - lo) + 1u;
+            u32 nj = left ? (j >= step ? j - (u32)step : 0u) : j + (u32)step;
+            j = nj < lo ? lo : (nj > hi ? hi : nj);
+        }
+        else j = lo + ((hi - lo) >> 1);
+    }
+}
+
+template <u32 LPQ>
+__device__ __forceinline__ void select_steps(const u32* __restrict__ lines, u32& lo, u32& hi, u32& j, u64 span, u32 shift, u64 r,
+                                             bool& searching, bool& failed, u32 it0, u32 max_it, u64 qi, u32 lane, u32 sub, u64* __restrict__ pos)
+{
+    for (u32 it = it0; __ballot(searching) != 0ull && it < max_it; ++it) {
+        u32x4 v[8u / LPQ];
+        select_load<LPQ>(lines, j, sub, v);
+        select_eval<LPQ>(v, lo, hi, j, span, shift, r, searching, failed, it, qi, lane, sub, pos);
+    }
+}
+
+template <u32 LPQ>
+__device__ __forceinline__ void select_walk(const u32* __restrict__ lines, u32 lo, u32 hi, u32 fr, u32 shift, u64 r, bool ok, bool live,
+                                            u64 qi, u32 lane, u32 sub, u64* __restrict__ pos, u8* __restrict__ found)
+{
+    u32 j = lo + (u32)(((u64)(hi - lo) * fr) >> shift);
+    const u64 span = (u64)(hi - lo) + 1u;
+    bool searching = ok, failed = false;
+    select_steps<LPQ>(lines, lo, hi, j, span, shift, r, searching, failed, 0u, 64u, qi, lane, sub, pos);
+    failed = failed || searching;                                    // (iteration cap reached: same)
+    if (live && sub == 0) {
+        found[qi] = (ok && !failed) ? 1 : 0;
+        if (!ok || failed) pos[qi] = 0;
+    }
+}
+
 template <u32 LPQ>
 __global__ __launch_bounds__(256)
 void k_select_sdir(const u32* __restrict__ lines, const u32* __restrict__ sdir, u32 shift, u64 total,
                    const u64* __restrict__ q, u64 nq, u64* __restrict__ pos, u8* __restrict__ found)
 {
-    constexpr u32 NV = 8u / LPQ;
     const u32 lane = lane_id();
     const u32 sub = lane & (LPQ - 1u);
     u64 qi = ((u64)blockIdx.x * blockDim.x + threadIdx.x) / LPQ;
@@ -1096,64 +1184,121 @@ void k_select_sdir(const u32* __restrict__ lines, const u32* __restrict__ sdir, 
         const bool ok = live && r != 0ull && r <= total;
         const u64 idx0 = ok ? r - 1u : 0ull;
         const u64 m = idx0 >> shift;
-        u32 lo = sdir[m], hi = sdir[m + 1u];
-        const u32 fr = (u32)(idx0 & ((1ull << shift) - 1u));
-        u32 j = lo + (u32)(((u64)(hi - lo) * fr) >> shift);
-        const u64 span = (u64)(hi - lo) + 1u;                        // lines the 2^shift ones of this entry are spread over
-        bool searching = ok, failed = false;
-        for (u32 it = 0; __ballot(searching) != 0ull && it < 64u; ++it) {
-            gcptr4 p = as_gc4(lines + (size_t)j * 32u) + sub * NV;
-            u32x4 v[NV];
+        const u32 lo = sdir[m], hi = sdir[m + 1u];
+        select_walk<LPQ>(lines, lo, hi, (u32)(idx0 & ((1ull << shift) - 1u)), shift, r, ok, live, qi, lane, sub, pos, found);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Round 5: select with the directory IN LDS.  k_select_sdir pays two dependent global reads per query -- the directory pair
+// (1.7 MB for configs[3]: it competes with the lines for the L2 and misses about once per query) and the line: 2.0 lines per
+// query, 0.45 ms for 10 M queries where rank takes 0.21.  A directory of 65,536 entries fits the 160 KiB of a CU: entry m = the
+// line of one number m 2^shift (shift chosen so that the vector's ones give <= 65,535 entries: ~64 lines per entry for
+// configs[3]) as a 16-bit offset from a 32-bit base per 256 entries -- 129 KiB, copied into LDS once per workgroup (one
+// workgroup per CU, 33 MB for the whole launch).  Both ends of the interpolation are exact, so the guess is off by a
+// Brownian-bridge error of ~0.3 lines: the headers send ~1 query in 8 to a second line.  One global read per query.
+// ---------------------------------------------------------------------------
+#define STOP_ENTRIES 65536u
+__global__ __launch_bounds__(256)
+void k_rs_stop(const u32* __restrict__ sdir, u64 nent, u32 d /* log2(entries of sdir per entry here) */, u32 n_top, u32* __restrict__ base, u16* __restrict__ t16, u32* __restrict__ bad)
+{
+    const u32 m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= n_top) return;
+    auto at = [&](u32 k) { const u64 i = (u64)k << d; return sdir[i < nent ? i : nent - 1u]; };
+    const u32 b = at(m & ~255u), v = at(m);
+    if ((m & 255u) == 0u) base[m >> 8] = b;
+    if (v - b > 65535u) atomicOr(bad, 1u);
+    t16[m] = (u16)(v - b);
+}
+
+template <u32 LPQ>
+__global__ __launch_bounds__(1024)
+void k_select_top(const u32* __restrict__ lines, const u32* __restrict__ stop /* base[256] then t16[65536] */, u32 shift, u64 total,
+                  const u64* __restrict__ q, u64 nq, u64* __restrict__ pos, u8* __restrict__ found)
+{
+    extern __shared__ u32 lds_dyn[];
+    {
+        const u32x4* src = reinterpret_cast<const u32x4*>(stop);
+        u32x4* dst = reinterpret_cast<u32x4*>(lds_dyn);
+        for (u32 i = threadIdx.x; i < (256u * 4u + STOP_ENTRIES * 2u) / 16u; i += 1024u) dst[i] = src[i];
+    }
+    __syncthreads();
+    const u32* base = lds_dyn;
+    const u16* t16 = reinterpret_cast<const u16*>(lds_dyn + 256);
+    const u32 lane = lane_id(), wave = uniform32(threadIdx.x >> 6);
+    const u32 sub = lane & (LPQ - 1u), grp = lane / LPQ;
+    constexpr u32 GPW = 64u / LPQ;                                    // queries a wave reads lines for at a time
+    // A query whose first line was not the right one does not hold its wave for a second round trip (with 16 .. 32 queries
+    // per wave nearly every wave would wait for somebody: the wave's rounds, not the queries' reads, would set the time): it
+    // is parked -- {query, lo, hi, next line} -- in the wave's queue and the wave reads on; whenever the queue holds a
+    // wave-load of them they take a round of their own.
+    u32x4* Q = reinterpret_cast<u32x4*>(lds_dyn + 256 + STOP_ENTRIES / 2u) + wave * 64u;
+    u32 qcount = 0u;
+    auto entry_of = [&](u64 r, u32& lo, u32& hi, u32& fr) {
+        const u64 idx0 = r - 1u;
+        const u32 m = (u32)(idx0 >> shift);
+        lo = base[m >> 8] + t16[m]; hi = base[(m + 1u) >> 8] + t16[m + 1u];
+        fr = (u32)(idx0 & ((1ull << shift) - 1u));
+    };
+    auto retry_round = [&](u32 first, u32 n) {                       // entries first .. first + n - 1 of the queue, to the end
+        const bool have = grp < n;
+        const u32x4 e = Q[first + (have ? grp : 0u)];
+        const u64 qi = e.x;
+        const u64 r = have ? q[qi] : 1ull;
+        u32 lo0, hi0, fr;
+        entry_of(r, lo0, hi0, fr);
+        u32 lo = e.y, hi = e.z, j = e.w;
+        bool searching = have, failed = false;
+        select_steps<LPQ>(lines, lo, hi, j, (u64)(hi0 - lo0) + 1u, shift, r, searching, failed, 1u, 64u, qi, lane, sub, pos);
+        failed = failed || searching;
+        if (have && sub == 0) { found[qi] = failed ? 0 : 1; if (failed) pos[qi] = 0; }
+    };
+    u64 qi0 = ((u64)blockIdx.x * blockDim.x + threadIdx.x) / LPQ;
+    const u64 stride = ((u64)gridDim.x * blockDim.x) / LPQ;
+    const u64 nq_round = (nq + GPW - 1ull) / GPW * GPW;
+    constexpr u32 UN = 2u;                                            // queries per lane group whose lines are in flight together
+    // the ranks are requested one iteration ahead: rank -> directory -> line is then ONE global round trip per iteration
+    u64 rn[UN];
 #pragma unroll
-            for (u32 i = 0; i < NV; ++i) v[i] = p[i];
-            u32 wd[4 * NV];
+    for (u32 u = 0; u < UN; ++u) { const u64 qq = qi0 + u * stride; rn[u] = qq < nq ? __builtin_nontemporal_load(&q[qq]) : 0ull; }
+    for (; qi0 < nq_round; qi0 += UN * stride) {
+        u64 qi[UN], r[UN]; bool live[UN], ok[UN], searching[UN], failed[UN];
+        u32 lo[UN], hi[UN], j[UN]; u64 span[UN];
+        u32x4 v[UN][8u / LPQ];
 #pragma unroll
-            for (u32 i = 0; i < NV; ++i) { wd[4 * i] = v[i].x; wd[4 * i + 1] = v[i].y; wd[4 * i + 2] = v[i].z; wd[4 * i + 3] = v[i].w; }
-            u32 hlo = sub == 0 ? wd[0] : 0u, hhi = sub == 0 ? wd[1] : 0u;
-            hlo = group_first<LPQ>(hlo, lane); hhi = group_first<LPQ>(hhi, lane);
-            const u64 hdr = ((u64)hhi << 32) | hlo;                   // ones of the vector before this line
-            if (sub == 0) { wd[0] = 0u; wd[1] = 0u; }
-            u32 mine = 0;
-#pragma unroll
-            for (u32 t = 0; t < 4 * NV; ++t) mine += (u32)__popc(wd[t]);
-            u32 ltot;
-            const u32 excl = group_excl<LPQ>(mine, sub, lane, ltot);
-            const bool left = searching && r <= hdr;                  // the r-th one lies in an earlier line
-            const bool right = searching && r > hdr + ltot;           // ... in a later one
-            if (searching && !left && !right) {
-                const u32 need0 = (u32)(r - hdr);                     // 1..ltot inside this line
-                if (need0 > excl && need0 <= excl + mine) {
-                    u32 need = need0 - excl, word = 0, wi = 0; bool got = false;
-#pragma unroll
-                    for (u32 t = 0; t < 4 * NV; ++t) {
-                        const u32 pc = (u32)__popc(wd[t]);
-                        if (!got) { if (need <= pc) { word = wd[t]; wi = t; got = true; } else need -= pc; }
-                    }
-                    const u32 nb = j / RL_LINES, lj = j - nb * RL_LINES;
-                    const u32 bit = lj * RL_BITS + ((sub * 4u * NV + wi) - 2u) * 32u + select_in_word(word, need);
-                    pos[qi] = ((u64)nb << 16) + bit;
-                }
-                searching = false;
-            }
-            if (left) hi = j - 1u;
-            if (right) lo = j + 1u;
-            if (left || right) {
-                if (lo > hi) { searching = false; failed = true; }    // (cannot happen with consistent headers: reported as not found)
-                else if (it < 3u) {
-                    // secant step: the header says how many ones away the answer is; opl = ones per line around here
-                    const u64 away = left ? hdr - r : r - hdr - ltot - 1u;
-                    u64 step = 1u + ((away * span) >> shift);                 // away / (S / span) lines, at least the neighbour
-                    if (step > (u64)(hi - lo) + 1u) step = (u64)(hi - lo) + 1u;
-                    u32 nj = left ? (j >= step ? j - (u32)step : 0u) : j + (u32)step;
-                    j = nj < lo ? lo : (nj > hi ? hi : nj);
-                }
-                else j = lo + ((hi - lo) >> 1);
-            }
+        for (u32 u = 0; u < UN; ++u) {
+            qi[u] = qi0 + u * stride;
+            live[u] = qi[u] < nq;
+            r[u] = rn[u];
+            ok[u] = live[u] && r[u] != 0ull && r[u] <= total;
+            u32 fr;
+            entry_of(ok[u] ? r[u] : 1ull, lo[u], hi[u], fr);
+            j[u] = lo[u] + (u32)(((u64)(hi[u] - lo[u]) * fr) >> shift);
+            span[u] = (u64)(hi[u] - lo[u]) + 1u;
+            searching[u] = ok[u]; failed[u] = false;
         }
-        failed = failed || searching;                                // (iteration cap reached: same)
-        if (live && sub == 0) {
-            found[qi] = (ok && !failed) ? 1 : 0;
-            if (!ok || failed) pos[qi] = 0;
+#pragma unroll
+        for (u32 u = 0; u < UN; ++u) { const u64 qq = qi0 + (UN + u) * stride; rn[u] = qq < nq ? __builtin_nontemporal_load(&q[qq]) : 0ull; }
+#pragma unroll
+        for (u32 u = 0; u < UN; ++u) select_load<LPQ>(lines, j[u], sub, v[u]);
+#pragma unroll
+        for (u32 u = 0; u < UN; ++u) {
+            if (qi[u] >= nq_round) continue;                          // (wave-uniform)
+            select_eval<LPQ>(v[u], lo[u], hi[u], j[u], span[u], shift, r[u], searching[u], failed[u], 0u, qi[u], lane, sub, pos);
+            if (live[u] && sub == 0 && !searching[u]) {
+                found[qi[u]] = (ok[u] && !failed[u]) ? 1 : 0;
+                if (!ok[u] || failed[u]) pos[qi[u]] = 0;
+            }
+            // park the open ones
+            const u64 open = __ballot(searching[u] && sub == 0);
+            if (searching[u] && sub == 0) {
+                const u32 at = qcount + (u32)__builtin_amdgcn_mbcnt_hi((u32)(open >> 32), __builtin_amdgcn_mbcnt_lo((u32)open, 0u));
+                u32x4 e; e.x = (u32)qi[u]; e.y = lo[u]; e.z = hi[u]; e.w = j[u];
+                Q[at] = e;
+            }
+            qcount += (u32)__popcll(open);
+            if (qcount >= GPW) { qcount -= GPW; retry_round(qcount, GPW); }
         }
     }
+    if (qcount) retry_round(0u, qcount);
 }

@@ -1420,7 +1420,8 @@ def test_range_hint(ctx, port, agg_path):
         agg.reset_range_hint()
 
 
-@pytest.mark.parametrize("unroll,lines,sel", [(8, 0, 0), (2, 0, 0), (4, 0, 0), (2, 1, 1), (4, 1, 1), (2, 1, 2), (4, 1, 2), (4, 1, (2, 6)), (4, 1, (2, 16))])
+@pytest.mark.parametrize("unroll,lines,sel", [(8, 0, 0), (2, 0, 0), (4, 0, 0), (2, 1, 1), (4, 1, 1), (2, 1, 2), (4, 1, 2), (4, 1, (2, 6)), (4, 1, (2, 16)),
+                                              (4, 1, (2, 0, 1)), (2, 1, (2, 6, 1)), (4, 1, (2, 16, 1))])
 def test_rank_select_queries_in_flight_forms(port, unroll, lines, sel):
     """k_rank_l<2|4> (fewer lanes per query = more queries in flight), k_rank_lines<2|4> (the vector laid out as rank
     lines: one 128-byte line per query) and the 8-lane kernels must give the oracle's answers on every block kind --
@@ -1431,7 +1432,11 @@ def test_rank_select_queries_in_flight_forms(port, unroll, lines, sel):
     c.set_tuning("rs_lines", 2 if lines else 0)                           # (2 = lines whatever the memory policy says: this vector is mostly NULL / FULL / GAP)
     # select over the lines: 1 = block index + octant directory (k_select_lines), 2 = select directory (k_select_sdir;
     # with 64 ones per entry -- several entries per line -- and with one entry for the whole vector: the bisection path)
-    if isinstance(sel, tuple): c.set_tuning("rs_sdir_shift", sel[1]); sel = sel[0]
+    # a third element 1: the directory's 65,536-entry summary in LDS (k_select_top, round 5) forced for every batch size
+    if isinstance(sel, tuple):
+        c.set_tuning("rs_sdir_shift", sel[1])
+        if len(sel) > 2: c.set_tuning("rs_select_top", sel[2])
+        sel = sel[0]
     c.set_tuning("rs_select_lines", sel)
     rng = np.random.default_rng(1234 + unroll)
     nblk = 23
