@@ -753,7 +753,7 @@ int bmx_ctx_create(int device, void* stream, bmx_ctx** out)
     // an invalid value is ignored (the default stays)
     static const char* const env_keys[][2] = {
         {"BMX_PIPE_UNROLL", "pipe_unroll"}, {"BMX_PIPE_ROWS", "pipe_rows"}, {"BMX_PIPE_NT", "pipe_nt"},
-        {"BMX_PIPE_WG", "pipe_wg"}, {"BMX_PIPE_WINDOW", "pipe_window"}, {"BMX_PIPE_SPLIT", "pipe_split"}, {"BMX_OR_TILE", "or_tile"}, {"BMX_OR_ROWS", "or_rows"}, {"BMX_OR_DEPTH", "or_depth"}, {"BMX_OR_WINDOW", "or_window"}, {"BMX_DIRECT_COLS", "direct_cols"}, {"BMX_FF_WINDOW", "ff_window"}, {"BMX_GAP_COUNT", "gap_count"}, {"BMX_AND_ROWS", "and_rows"}, {"BMX_AGG_SHAPE", "agg_shape"}, {"BMX_AND_ROWS_WG", "and_rows_wg"}, {"BMX_AND_ROWS_DEPTH", "and_rows_depth"}, {"BMX_AND_ROWS_NT", "and_rows_nt"}, {"BMX_RANGE_HALVES", "range_halves"}, {"BMX_PAIR_STREAM", "pair_stream"}, {"BMX_PAIR_WGS", "pair_wgs"}, {"BMX_RS_LANES", "rs_lanes"}, {"BMX_RS_SELECT_TOP", "rs_select_top"}, {"BMX_RS_LINES", "rs_lines"}, {"BMX_RS_SELECT_LINES", "rs_select_lines"}, {"BMX_RS_SDIR_SHIFT", "rs_sdir_shift"}, {"BMX_COLL_SHAPE", "coll_shape"}, {"BMX_COLL_WINDOW", "coll_window"}, {"BMX_COLL_SPLIT", "coll_split"}, {"BMX_COLL_BUILD", "coll_build"}, {"BMX_EQ_BIG", "eq_big"}, {"BMX_PAIR_LOOP", "pair_loop"}, {"BMX_PAIR_NT", "pair_nt"}, {"BMX_EQ_BIG_SHAPE", "eq_big_shape"}, {"BMX_OP2_WGS", "op2_wgs"}, {"BMX_OP2_LOOP", "op2_loop"}, {"BMX_OP2_NT", "op2_nt"}, {"BMX_GAP_PACK", "gap_pack"}, {"BMX_COLL_MEMBERS", "coll_members"}, {"BMX_XCD_SWIZZLE", "xcd_swizzle"}};
+        {"BMX_PIPE_WG", "pipe_wg"}, {"BMX_PIPE_WINDOW", "pipe_window"}, {"BMX_PIPE_SPLIT", "pipe_split"}, {"BMX_OR_TILE", "or_tile"}, {"BMX_OR_ROWS", "or_rows"}, {"BMX_OR_DEPTH", "or_depth"}, {"BMX_OR_WINDOW", "or_window"}, {"BMX_DIRECT_COLS", "direct_cols"}, {"BMX_FF_WINDOW", "ff_window"}, {"BMX_GAP_COUNT", "gap_count"}, {"BMX_AND_ROWS", "and_rows"}, {"BMX_AGG_SHAPE", "agg_shape"}, {"BMX_AND_ROWS_WG", "and_rows_wg"}, {"BMX_AND_ROWS_DEPTH", "and_rows_depth"}, {"BMX_AND_ROWS_NT", "and_rows_nt"}, {"BMX_AND_ROWS_IPW", "and_rows_ipw"}, {"BMX_RANGE_HALVES", "range_halves"}, {"BMX_PAIR_STREAM", "pair_stream"}, {"BMX_PAIR_WGS", "pair_wgs"}, {"BMX_RS_LANES", "rs_lanes"}, {"BMX_RS_SELECT_TOP", "rs_select_top"}, {"BMX_RS_LINES", "rs_lines"}, {"BMX_RS_SELECT_LINES", "rs_select_lines"}, {"BMX_RS_SDIR_SHIFT", "rs_sdir_shift"}, {"BMX_COLL_SHAPE", "coll_shape"}, {"BMX_COLL_WINDOW", "coll_window"}, {"BMX_COLL_SPLIT", "coll_split"}, {"BMX_COLL_BUILD", "coll_build"}, {"BMX_EQ_BIG", "eq_big"}, {"BMX_PAIR_LOOP", "pair_loop"}, {"BMX_PAIR_NT", "pair_nt"}, {"BMX_EQ_BIG_SHAPE", "eq_big_shape"}, {"BMX_OP2_WGS", "op2_wgs"}, {"BMX_OP2_LOOP", "op2_loop"}, {"BMX_OP2_NT", "op2_nt"}, {"BMX_GAP_PACK", "gap_pack"}, {"BMX_COLL_MEMBERS", "coll_members"}, {"BMX_XCD_SWIZZLE", "xcd_swizzle"}};
     for (auto& kv : env_keys)
         if (const char* e = getenv(kv[0])) (void)bmx_ctx_set_tuning(ctx, kv[1], atoi(e));
     g_last_error.clear();
@@ -816,6 +816,7 @@ int bmx_ctx_set_tuning(bmx_ctx* ctx, const char* key, int value)
     else if (k == "and_rows_wg") { ARGCHK(value == 128 || value == 256 || value == 512); ctx->and_rows_wg = value; }
     else if (k == "and_rows_depth") { ARGCHK(value == 2 || value == 3 || value == 4 || value == 8); ctx->and_rows_depth = value; }
     else if (k == "and_rows_nt") ctx->and_rows_nt = value != 0;
+    else if (k == "and_rows_ipw") { ARGCHK(value >= 0 && value <= 64); ctx->and_rows_ipw = value; }
     else if (k == "ff_window") { ARGCHK(value >= -1); ctx->ff_window = value; }
     else if (k == "or_window") { ARGCHK(value >= -9); ctx->or_window = value; }
     else if (k == "gap_pack") { ARGCHK(value >= -1 && value <= 1); ctx->gap_pack = value; }
@@ -1566,7 +1567,7 @@ static bool use_and_rows(const bmx_ctx* ctx, const bmx_pipeline* p, uint64_t ops
     if (ops_of_group) return ops_of_group >= 8u;
     return (uint64_t)p->n_ops >= 8ull * p->ngroups;
 }
-typedef void (*and_rows_fn)(const u64*, const u32*, const u32*, const u32*, u32, u32, u32, u32, int, u64*, uint4*, u64*, BlockStat*, u32, u32, int);
+typedef void (*and_rows_fn)(const u64*, const u32*, const u32*, const u32*, u32, u32, u32, u32, int, u64*, uint4*, u64*, BlockStat*, u32, u32, int, u32);
 // (tuning build only: BMX_DIAG_AROWS = 1 -> the row loads alone, 2 -> no fold / count; results are then meaningless)
 static int and_rows_diag_bits()
 {
@@ -1765,9 +1766,13 @@ static int pipeline_run_counts_impl(bmx_ctx* ctx, bmx_pipeline* p, uint32_t nb_f
     if (nitems64 > 0xFFFFFFF0ull) { g_last_error = "too many (column, group) items in one run"; return BMX_ERR_RANGE; }
     if (use_and_rows(ctx, p)) {
         // every operand block is GAP (or NULL / FULL): the union of the operands' 0-runs read straight from their slabs
-        hipLaunchKernelGGL(and_rows_kernel<AR_COUNT>(ctx), dim3((u32)nitems64), dim3((u32)ctx->and_rows_wg), 0, ctx->stream,
+        // (and_rows_ipw: several consecutive items -- arg-groups of one column -- per workgroup.  Measured on 16 groups x 2 .. 64 operands
+        // over 1e9-bit vectors: 1, 4 and 8 items per workgroup run within 2 % of each other -- such a run is bound by the chain of
+        // dependent round trips inside an item (row header, entries, pieces, fold), not by the dispatch rate -- so the default is 1)
+        const u32 ipw = ctx->and_rows_ipw > 0 ? (u32)ctx->and_rows_ipw : 1u;
+        hipLaunchKernelGGL(and_rows_kernel<AR_COUNT>(ctx), dim3((u32)((nitems64 + ipw - 1u) / ipw)), dim3((u32)ctx->and_rows_wg), 0, ctx->stream,
                            (const u64*)p->d_dmat, row_off, and_n, sub_n, p->col_stride, ngroups, nb_from, (u32)nitems64, ctx->xcd_swz, (u64*)d_counts,
-                           (uint4*)nullptr, (u64*)nullptr, (BlockStat*)nullptr, 0u, 0xFFFFFFFFu, and_rows_diag_bits());
+                           (uint4*)nullptr, (u64*)nullptr, (BlockStat*)nullptr, 0u, 0xFFFFFFFFu, and_rows_diag_bits(), ipw);
         KCHK();
         return BMX_OK;
     }
@@ -2761,7 +2766,7 @@ static int agg_and_sub_launch(bmx_ctx* ctx, const bmx_pipeline* p, uint32_t g, b
         // GAP-only operands: the union of 0-runs over the operands' own slabs, result block stored (bmx_kernels9.h)
         hipLaunchKernelGGL(and_rows_kernel<AR_STORE>(ctx), dim3(ncols), dim3((u32)ctx->and_rows_wg), 0, ctx->stream,
                            rows, p->d_meta /* row_off[0] = 0: rows already points at group g */, an, sn, p->col_stride, 1u, 0u, ncols, ctx->xcd_swz, (u64*)nullptr,
-                           v->d_bits, v->d_desc, st, nb_from, nb_to, 0);
+                           v->d_bits, v->d_desc, st, nb_from, nb_to, 0, 1u);
         e = hipGetLastError();
         return e == hipSuccess ? BMX_OK : fail_hip(e, "k_agg_and_rows", __LINE__);
     }

@@ -65,6 +65,7 @@ struct bmx_ctx {
     int agg_shape = 0;         // materialised combine_and / combine_and_sub over bit-block-only operands (k_agg_and_sub): 0 = 640 threads, three operand blocks in flight per wave, 1 = 512 threads, four in flight
     int and_rows = -1;         // AND / AND-SUB over GAP-only operands straight from their slabs (k_agg_and_rows, bmx_kernels9.h): -1 = automatic (>= 8 operands per group on average), 0 = never, 1 = whenever the pipeline holds no bit-block
     int and_rows_wg = 256;     // ... threads per workgroup (128 / 256 / 512)
+    int and_rows_ipw = 0;      // ... (column, group) items per workgroup: 0 = 1 (more measured no gain: profiles/r05_and_rows)
     int and_rows_nt = 0;       // ... non-temporal loads of the run lists
     int and_rows_depth = 3;    // ... 1-KiB pieces in flight per wave (2 / 3 / 4 / 8)
     int ff_window = 0;         // find_first_and_sub: block columns of the FIRST launch window (each next one is 4x larger): 0 = automatic, -1 = one launch

@@ -166,19 +166,12 @@ __device__ __forceinline__ void ar_union_list(const u64* __restrict__ list_back,
 //   AR_COUNT  counts[g] += popcount(AND of the AND list, minus the union of the SUB list)  (:1292-1399, counts only)
 //   AR_STORE  the same block stored as column `col` of a result vector with opt_compress (:1210); ngroups = 1
 template <int MODE, int WG, int DEPTH, bool NT>
-__global__ __launch_bounds__(WG)
-void k_agg_and_rows(const u64* __restrict__ dmat, const u32* __restrict__ row_off, const u32* __restrict__ and_n,
+__device__ __forceinline__ void ar_item(u32 item, u32* U, int* D, int* sm, u32* part, const u64* __restrict__ dmat, const u32* __restrict__ row_off, const u32* __restrict__ and_n,
                     const u32* __restrict__ sub_n, u32 col_stride, u32 ngroups, u32 col_from, u32 nitems, int xcd_swz,
                     u64* __restrict__ counts, uint4* __restrict__ slab, u64* __restrict__ desc, BlockStat* __restrict__ st,
                     u32 hint_from, u32 hint_to, int diag)
 {
-    __shared__ __attribute__((aligned(16))) u32 U[2048];
-    __shared__ __attribute__((aligned(16))) int D[2048];
-    __shared__ int sm[WG / 64];
-    __shared__ u32 part[WG / 64];
     const u32 tid = threadIdx.x, lane = tid & 63u, wave = uniform32(tid >> 6);       // (uniform: the piece bookkeeping of ar_union_list stays in SGPRs)
-    const u32 item = xcd_swz ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
-    if (item >= nitems) return;
     const u32 ci = item / ngroups, g = item - ci * ngroups;
     const u32 col = col_from + ci;
     if (MODE == AR_STORE && (col < hint_from || col >= hint_to)) { if (wave == 0) store_trivial(K_NULL, col, desc, st, lane); return; }
@@ -243,6 +236,29 @@ void k_agg_and_rows(const u64* __restrict__ dmat, const u32* __restrict__ row_of
     for (u32 k = 0; k < W; ++k) U[tid * W + k] = acc[k];
     __syncthreads();
     if (wave == 0) { Blk b; blk_from_lds(b, U, lane); store_result(b, col, 1, slab, desc, st, lane); }
+}
+
+// ipw (>= 1) consecutive items per workgroup (a knob: a counts pipeline of many arg-groups over short lists is hundreds of
+// thousands of items; measured, it is bound by the dependent round trips inside an item, not by the dispatch rate: default 1)
+template <int MODE, int WG, int DEPTH, bool NT>
+__global__ __launch_bounds__(WG)
+void k_agg_and_rows(const u64* __restrict__ dmat, const u32* __restrict__ row_off, const u32* __restrict__ and_n,
+                    const u32* __restrict__ sub_n, u32 col_stride, u32 ngroups, u32 col_from, u32 nitems, int xcd_swz,
+                    u64* __restrict__ counts, uint4* __restrict__ slab, u64* __restrict__ desc, BlockStat* __restrict__ st,
+                    u32 hint_from, u32 hint_to, int diag, u32 ipw)
+{
+    __shared__ __attribute__((aligned(16))) u32 U[2048];
+    __shared__ __attribute__((aligned(16))) int D[2048];
+    __shared__ int sm[WG / 64];
+    __shared__ u32 part[WG / 64];
+    const u32 b = xcd_swz ? xcd_remap(blockIdx.x, gridDim.x) : blockIdx.x;
+    for (u32 k = 0; k < ipw; ++k) {
+        const u32 item = b * ipw + k;
+        if (item >= nitems) return;
+        if (k) __syncthreads();                                   // (the item before has read U / D / part)
+        ar_item<MODE, WG, DEPTH, NT>(item, U, D, sm, part, dmat, row_off, and_n, sub_n, col_stride, ngroups, col_from, nitems, xcd_swz, counts, slab, desc, st,
+                                     hint_from, hint_to, diag);
+    }
 }
 
 // ---------------------------------------------------------------------------

@@ -2271,6 +2271,7 @@ def test_and_rows_kernel(ctx, port, nvec, nsub):
         ctx.set_tuning("pipe_split", 0); ctx.set_tuning("direct_cols", 0)     # (so few items / columns would take the one-workgroup-per-item kernels)
         for ar, wg, depth, nt in ((1, 256, 2, 0), (1, 512, 4, 1), (1, 512, 8, 0), (1, 256, 8, 1), (1, 128, 3, 0), (0, 512, 4, 0), (-1, 256, 3, 0)):
             ctx.set_tuning("and_rows", ar); ctx.set_tuning("and_rows_wg", wg); ctx.set_tuning("and_rows_depth", depth); ctx.set_tuning("and_rows_nt", nt)
+            ctx.set_tuning("and_rows_ipw", (1, 3, 8)[depth % 3])                  # (items per workgroup: several groups of a column share one)
             d = pipe.describe()
             assert ("k_agg_and_rows<COUNT,%d,%d>" % (wg, depth) in d) == (ar != 0), d
             got = agg.combine_and_sub(pipe)
@@ -2297,7 +2298,7 @@ def test_and_rows_kernel(ctx, port, nvec, nsub):
             assert (r is None) == (e.count() == 0)
             if r is not None: assert (r.to_words(nw) == e.to_words(nw)).all()
     finally:
-        for k, v in (("and_rows", -1), ("and_rows_wg", 256), ("and_rows_depth", 3), ("and_rows_nt", 0), ("pipe_split", -1), ("direct_cols", 384)):
+        for k, v in (("and_rows", -1), ("and_rows_wg", 256), ("and_rows_depth", 3), ("and_rows_nt", 0), ("and_rows_ipw", 0), ("pipe_split", -1), ("direct_cols", 384)):
             ctx.set_tuning(k, v)
 
 

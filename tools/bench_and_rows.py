@@ -70,8 +70,8 @@ if os.environ.get("CROSS"):
                 for v in vecs[gi * n:(gi + 1) * n]: g.add(v, 0)
             pipe.complete()
             out = {"dq": dq, "ops_per_group": n, "groups": ng, "alg_GB": round(pipe.operand_bytes() / 1e9, 3)}
-            for name, ar in (("rows", 1), ("older", 0)):
-                ctx.set_tuning("and_rows", ar)
+            for name, ar, wg, ipw in (("rows128", 1, 256, 4), ("rows", 1, 256, 1), ("rows512", 1, 256, 8), ("older", 0, 256, 0)):
+                ctx.set_tuning("and_rows", ar); ctx.set_tuning("and_rows_wg", wg); ctx.set_tuning("and_rows_ipw", ipw)
                 cnt = agg.combine_and_sub(pipe).copy()
                 for _ in range(2): agg.run_counts_dev(pipe, d_counts.value)
                 ctx.synchronize(); ts = []

@@ -7,5 +7,5 @@ CROSS=1 DQS=66,197 timeout 900 python tools/bench_and_rows.py 2> $O/err.txt | gr
 python - <<PY
 import json
 for l in open("$O/cross.jsonl"):
-    r = json.loads(l); print(r["dq"], r["ops_per_group"], r["groups"], r["alg_GB"], "rows", r["rows_ms"], "older", r["older_ms"], r["older_kernel"], r["rows_sum"] == r["older_sum"])
+    r = json.loads(l); print(r["dq"], r["ops_per_group"], r["groups"], r["alg_GB"], "ipw4", r["rows128_ms"], "ipw1", r["rows_ms"], "ipw8", r["rows512_ms"], "older", r["older_ms"], r["rows_sum"] == r["older_sum"])
 PY
