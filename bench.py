@@ -899,6 +899,8 @@ def run_pairwise(args, env, dq=None, quick=False):
         c1_traffic, c1_tsrc, _ = traffic_file("traffic_config1.json", kernel=L_pair_kernel_name(all_bit, va[0].info()["nblocks"]))
     elif nbits == NBITS_1G and dq == 655 and os.environ.get("BMX_PAIR_LOOP", "-1") == "-1":
         c1_traffic, c1_tsrc, _ = traffic_file("traffic_config1_1pct.json", kernel=L_pair_kernel_name(all_bit, va[0].info()["nblocks"]))
+    elif nbits == NBITS_1G and dq == 32768 and os.environ.get("BMX_PAIR_STREAM", "-1") == "-1":
+        c1_traffic, c1_tsrc, _ = traffic_file("traffic_config1_50pct.json", kernel=L_pair_kernel_name(all_bit, va[0].info()["nblocks"]))
     pct = dq / 65536 * 100
     res = {"metric": "Gbit/s of operand bits, pairwise count_and on 1e9-bit vectors (HBM-cold rotation)",
            "value": round(2 * nbits * npairs * steps / dt / 1e9, 2), "unit": "Gbit/s", "n_gpus": 1,
@@ -1022,7 +1024,8 @@ def run_rank_select(args, env, quick=False, dq=None):
     sel_lines_s = nq / (sel_ms * 1e-3)
     rank_kernel = ("k_rank_lines<2> (the vector laid out as rank lines by build_rs_index: count before the line + 960 bits per 128-B line)"
                    if rs.info()["has_lines"] and os.environ.get("BMX_RS_LANES", "0") != "8" else "k_rank_l / k_rank (descriptor + running count + cumulative row + bit line)")
-    traffic, tsrc, tj = traffic_file("traffic_config3.json", kernel=rank_kernel) if (nbits == NBITS_4G and dq == 6554 and nq == 10_000_000) else (None, None, {})
+    traffic, tsrc, tj = (traffic_file("traffic_config3.json" if dq == 6554 else "traffic_config3_1pct.json", kernel=rank_kernel)
+                         if (nbits == NBITS_4G and dq in (6554, 655) and nq == 10_000_000) else (None, None, {}))
     pct = dq / 65536 * 100
     res = {"metric": "M queries/s, rank + select (bmrs.h RS-index) on one 4e9-bit vector",
            "value": round(2 * nq * steps / dt / 1e6, 1), "unit": "Mqueries/s", "n_gpus": 1, "steps": steps,
@@ -1295,6 +1298,7 @@ def run_sparse_and(args, env, dq=197, quick=True):
         warm_count = int(counts.item()); warm_plan = pipe.describe()
     achieved = alg / cold_ms / 1e6
     pct = dq / 65536 * 100
+    sp_traffic, sp_tsrc, _ = (traffic_file("traffic_config2_dq%d.json" % dq, kernel=cold_plan) if (nvec == 256 and nbits == NBITS_1G and dq in (197, 66)) else (None, None, {}))
     res = {"metric": METRIC + f" -- at {pct:.1f} % (GAP-only operands), first call", "value": round(nvec * nbits * steps / dt / 1e9, 1), "unit": "Gbit/s",
            "n_gpus": 1, "steps": steps, "warmup": warmup, "ms_per_step": round(dt / steps * 1e3, 4), "higher_is_better": True, "scaling": "strong",
            "vs_baseline": None, "dtype": "u16", "data": "synthetic", "mode": env.mode,
@@ -1306,7 +1310,7 @@ def run_sparse_and(args, env, dq=197, quick=True):
                       "warm_count_equal": None if warm_count is None else bool(warm_count == cold_count),
                       "break_even_calls": (round(build_ms / (cold_ms - warm_ms), 1) if (warm_ms is not None and cold_ms > warm_ms) else None)},
            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                        "traffic": None, "kernel": cold_plan, "algorithmic_bytes_per_launch": alg, "avg_launch_ms": round(cold_ms, 4),
+                        "traffic": sp_traffic, "traffic_source": sp_tsrc, "kernel": cold_plan, "algorithmic_bytes_per_launch": alg, "avg_launch_ms": round(cold_ms, 4),
                         "note": "algorithmic bytes = 2 x (len + 1) B per GAP operand block (SURVEY section 8(d)); hipEvent pair around back-to-back runs"}}
     if warm_ms is not None:
         res["roofline"]["warm"] = {"kernel": warm_plan, "avg_launch_ms": round(warm_ms, 4), "achieved": round(alg / warm_ms / 1e6, 1),

@@ -26,6 +26,10 @@ TARGETS = [  # (json file, pmc file, kernel substring, workload label, kernel st
     ("traffic_config3.json", "pmc_config3.txt", "k_rank_lines", "rank_10M_on_4e9_bits_dq6554", "k_rank_lines"),
     ("traffic_config4.json", "pmc_config4.txt", "k_agg_or_rows", "combine_or_4096x4000000000_dq13_first_call", "k_agg_or_rows"),
     ("traffic_config4_warm.json", "pmc_config4.txt", "k_coll_apply", "combine_or_4096x4000000000_dq13_prepared_collection", "k_coll_apply<OR,512>"),
+    ("traffic_config1_50pct.json", "pmc_config1_50pct.txt", "k_count_op2_stream", "pairwise_count_2x1000000000_dq32768", "k_count_op2_stream"),
+    ("traffic_config3_1pct.json", "pmc_config3_1pct.txt", "k_rank_lines", "rank_10M_on_4e9_bits_dq655", "k_rank_lines"),
+    ("traffic_config2_dq197.json", "pmc_dq197.txt", "k_agg_and_rows", "agg_and_count_256x1000000000_dq197_first_call", "k_agg_and_rows"),
+    ("traffic_config2_dq66.json", "pmc_dq66.txt", "k_agg_and_rows", "agg_and_count_256x1000000000_dq66_first_call", "k_agg_and_rows"),
 ]
 for jname, pmc, ksub, workload, stamp in TARGETS:
     c = counters(pmc, ksub)
