@@ -343,10 +343,18 @@ static int coll_build(bmx_ctx* ctx, const bmx_vec* const* v, size_t n, int polar
     hipLaunchKernelGGL(k_coll_offsets, dim3(1), dim3(1024), 0, ctx->stream, (const u32*)c->d_cnt, ncols, c->d_off);
     e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(&total, c->d_off + ncols, 8, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipEventRecord(e1, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);          // (descs / nblk are read from pageable memory: they are done too)
+    float ms_count = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms_count, e0, e1);
     if (e != hipSuccess) return fail(fail_hip(e, "coll_build (count)", __LINE__));
     c->entries = total;
-    if ((rc = dmalloc(ctx, (void**)&c->d_runs, std::max<size_t>((size_t)total * 4, 64)))) return fail(rc);
+    // (build_ms = device time of the passes: the allocations between them are host time, see the tile build above)
+    const size_t dir_b = ((size_t)n + 1) * ncols * 4;
+    if ((rc = dmalloc(ctx, (void**)&c->d_runs, std::max<size_t>((size_t)total * 4, 64))) ||
+        (rc = dmalloc(ctx, (void**)&c->d_dir, dir_b)) || (split && (rc = dmalloc(ctx, (void**)&c->d_dir_s, dir_b)))) return fail(rc);
+    e = hipEventRecord(e0, ctx->stream);
+    if (e != hipSuccess) return fail(fail_hip(e, "coll_build (scatter)", __LINE__));
     if (total && split) {
         if (short_blocks) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_coll_scatter_split<8>), dim3((u32)n, ((ncols + 31) / 32 + COLL_YT - 1) / COLL_YT), dim3(256), 0, ctx->stream,
                                              (const u64* const*)d_descs, (const u32*)d_nblk, ncols, (const u32*)d_pre, (const u32*)d_sgl,
@@ -363,7 +371,6 @@ static int coll_build(bmx_ctx* ctx, const bmx_vec* const* v, size_t n, int polar
         e = hipGetLastError();
     }
     // the member directory (bmx_kernels8.h): the prefixes of the passes above, column-major, with the members' block kinds
-    if (e == hipSuccess && ((rc = dmalloc(ctx, (void**)&c->d_dir, dir_bytes)) || (split && (rc = dmalloc(ctx, (void**)&c->d_dir_s, dir_bytes))))) return fail(rc);
     if (e == hipSuccess) {
         hipLaunchKernelGGL(k_coll_dir, dim3((ncols + 31) / 32, ((u32)n + 1 + 31) / 32), dim3(1024), 0, ctx->stream, (const u32*)d_pre, (const u32*)d_sgl,
                            (const u32*)c->d_cnt, (const u32*)c->d_cnt_s, (u32)n, ncols, c->d_dir, c->d_dir_s);
@@ -373,6 +380,7 @@ static int coll_build(bmx_ctx* ctx, const bmx_vec* const* v, size_t n, int polar
     if (e == hipSuccess) e = hipEventSynchronize(e1);
     if (e == hipSuccess) e = hipEventElapsedTime(&c->build_ms, e0, e1);
     if (e != hipSuccess) return fail(fail_hip(e, "coll_build (scatter)", __LINE__));
+    c->build_ms += ms_count;
     }
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     dfree(ctx, d_descs); dfree(ctx, d_nblk); dfree(ctx, d_pre); dfree(ctx, d_sgl); dfree(ctx, d_words); dfree(ctx, d_optab); dfree(ctx, d_bt);
