@@ -2023,7 +2023,7 @@ static int result_begin(bmx_ctx* ctx, uint64_t nbits, uint32_t nblocks, bmx_vec*
 // it holds, not 125 MB, and bmx_pipeline_run_results over G groups needs (sum of the live blocks) + ONE transient
 // slab.  A nearly full slab is kept as it is (no second pass over the blocks); its ordinals are kept in d_ord so
 // that bmx_vec_download moves only live blocks.
-static int result_finish(bmx_ctx* ctx, bmx_vec* v, BlockStat* st, u32* offs)
+static int result_finish(bmx_ctx* ctx, bmx_vec* v, BlockStat* st, u32* offs, bool gaps_done = false /* the kernel wrote its GAP blocks itself: only the bit slab is laid out */)
 {
     int rc;
     uint32_t nblocks = v->nblocks;
@@ -2032,7 +2032,7 @@ static int result_finish(bmx_ctx* ctx, bmx_vec* v, BlockStat* st, u32* offs)
     KCHK();
     HIPCHK(hipMemcpyAsync(ctx->h_small, ctx->d_small, 6 * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    uint64_t gap_words = ctx->h_small[1];
+    uint64_t gap_words = gaps_done ? 0 : ctx->h_small[1];
     for (int k = 0; k < 4; ++k) v->counts[k] = (uint32_t)ctx->h_small[2 + k];
     bool pending = false;
     if (gap_words) {
@@ -2110,34 +2110,50 @@ static int vec_clone(bmx_ctx* ctx, const bmx_vec* a, bmx_vec** out)
 
 } // extern "C"
 
-// The tail of a pairwise operation whose kernel laid its GAP candidates out itself (k_op2_loop with a cursor; the stream has
-// been synchronised): kinds in h_small[2..5], GAP words in h_small[6], offsets in offs[].  k_emit_gaps is enqueued into a slab
-// of exactly those words and NOT waited for (st / offs live in the context's scratch, which the next operation touches only
-// behind it on the same stream).  A bit slab sparse enough to be compacted takes the scan path (result_finish) as before; a
-// nearly full one is kept, its ordinals left to the first download.
-static int op2_finish_laid_out(bmx_ctx* ctx, bmx_vec* v, BlockStat* st, u32* offs)
+// A GAP slab allocated at the operands' bound (the words a pairwise result can hold at most: a copied GAP block, a GAP x GAP
+// result of at most len(a) + len(b) runs) and filled by the kernel up to `used`: given back when nothing landed in it, moved
+// into a slab of its own size -- a copy and a descriptor rebase, enqueued -- when the slack is worth it (more than
+// `slack_ok` bytes), kept otherwise.  v->bytes does not hold the slab yet.
+static int gap_slab_trim(bmx_ctx* ctx, bmx_vec* v, uint64_t bound, uint64_t used, size_t slack_ok)
+{
+    int rc;
+    if (!used) { dfree(ctx, v->d_gaps); v->d_gaps = nullptr; v->gap_words = 0; return BMX_OK; }
+    if (bound > 2 * used + 4096 && (size_t)(bound - used) * 2 > slack_ok) {
+        u16* small_ = nullptr;
+        if ((rc = dmalloc(ctx, (void**)&small_, (size_t)used * 2 + 64))) return rc;
+        hipError_t e = hipMemcpyAsync(small_, v->d_gaps, (size_t)used * 2, hipMemcpyDeviceToDevice, ctx->stream);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_rebase_desc, dim3((v->nblocks + 255) / 256), dim3(256), 0, ctx->stream, (const u64*)v->d_desc, v->d_desc, v->nblocks,
+                               (u64)(uintptr_t)v->d_bits, (u64)(uintptr_t)v->d_bits, (u64)(uintptr_t)v->d_gaps, (u64)(uintptr_t)small_);
+            e = hipGetLastError();
+        }
+        if (e != hipSuccess) { (void)hipStreamSynchronize(ctx->stream); dfree(ctx, small_); return fail_hip(e, "gap_slab_trim", __LINE__); }
+        dfree(ctx, v->d_gaps);
+        v->d_gaps = small_; v->gap_words = used; v->bytes += (size_t)used * 2 + 64;
+    } else { v->gap_words = used; v->bytes += (size_t)bound * 2 + 64; }
+    return BMX_OK;
+}
+
+// The tail of a pairwise operation whose kernel wrote its GAP blocks itself (k_op2_loop with a cursor and a slab at the operands'
+// bound; the stream has been synchronised): kinds in h_small[2..5], the cursor in h_small[6].  A bit slab sparse enough to be
+// compacted takes the scan path (result_finish) as before; a nearly full one is kept, its ordinals left to the first download --
+// and with it a GAP slab whose slack stays under a quarter of the bytes the vector keeps in bit-blocks anyway.
+static int op2_finish_laid_out(bmx_ctx* ctx, bmx_vec* v, BlockStat* st, u32* offs, uint64_t bound)
 {
     const uint32_t nblocks = v->nblocks;
     uint32_t counts[4];
     for (int k = 0; k < 4; ++k) counts[k] = (uint32_t)ctx->h_small[2 + k];
-    const uint64_t used = ctx->h_small[6] & 0xFFFFFFFFFFull, ncand = ctx->h_small[6] >> 40;      // the cursor: words | candidates << 40
-    if ((uint64_t)counts[0] + counts[1] + counts[2] + counts[3] != nblocks || ncand != counts[BMX_GAP] || (used == 0) != (ncand == 0)) {
+    const uint64_t used = ctx->h_small[6] & 0xFFFFFFFFFFull, ncand = ctx->h_small[6] >> 40;      // the cursor: words | GAP blocks << 40
+    if ((uint64_t)counts[0] + counts[1] + counts[2] + counts[3] != nblocks || ncand != counts[BMX_GAP] || (used == 0) != (ncand == 0) || used > bound) {
         g_last_error = "bmx_op2: inconsistent fold of the result block kinds"; return BMX_ERR_DEVICE;
     }
     const uint32_t live = counts[BMX_BIT];
-    if (live && live < nblocks && (uint64_t)live * 8u < (uint64_t)nblocks * 7u) return result_finish(ctx, v, st, offs);
-    int rc;
+    const bool sparse = live && live < nblocks && (uint64_t)live * 8u < (uint64_t)nblocks * 7u;
+    int rc = gap_slab_trim(ctx, v, bound, used, sparse ? 0 : (size_t)live * 2048u);
+    if (rc) return rc;
+    if (sparse) return result_finish(ctx, v, st, offs, true);
     memcpy(v->counts, counts, sizeof(counts));
-    if (used) {
-        const size_t b_gaps = (size_t)used * 2 + 64;                  // + guard, see vec_alloc_device
-        if ((rc = dmalloc(ctx, (void**)&v->d_gaps, b_gaps))) return rc;
-        v->bytes += std::max<size_t>(b_gaps, 16);
-        v->gap_words = used;
-        hipLaunchKernelGGL(k_emit_gaps_list, dim3(((u32)ncand + 3) / 4), dim3(256), 0, ctx->stream,
-                           v->d_bits, (const u32*)(offs + nblocks), (u32)ncand, st, offs, v->d_gaps, v->d_desc);
-        KCHK();
-    }
-    if (live == 0) { dfree(ctx, v->d_bits); v->d_bits = nullptr; v->n_bit = 0; }     // (stream-ordered: whoever gets the slab next runs behind k_emit_gaps_list)
+    if (live == 0) { dfree(ctx, v->d_bits); v->d_bits = nullptr; v->n_bit = 0; }
     else if (live < nblocks) v->ord_lazy = true;
     return BMX_OK;
 }
@@ -2173,6 +2189,7 @@ int bmx_op2(bmx_ctx* ctx, int op, const bmx_vec* a, const bmx_vec* b, int opt_co
     // and the layout scan is skipped -- k_op2, one synchronise, done -- unless result blocks vanished (then the scan /
     // compaction path below decides what to do with the slab)
     bool no_gap = !opt_compress && a->counts[BMX_GAP] == 0 && b->counts[BMX_GAP] == 0, folded = false, emit = false, counted = false;
+    uint64_t gap_bound = 0;
     if (nblocks) {
         // bit-blocks only on both sides: the streaming form (one machine-load of waves, each owning a stretch of columns)
         const bool stream = no_gap && ctx->pair_stream != 0 && a->nblocks == b->nblocks && a->counts[BMX_BIT] == nblocks &&
@@ -2190,16 +2207,20 @@ int bmx_op2(bmx_ctx* ctx, int op, const bmx_vec* a, const bmx_vec* b, int opt_co
             const u32 wgs = (u32)(ctx->op2_loop > 0 ? ctx->op2_loop : 4);        // workgroups per CU = waves per SIMD
             const u32 grid = std::min<u32>((nblocks + 3u) / 4u, 256u * wgs);
             auto fn = (ctx->op2_nt & 1) ? k_op2_loop<4, true> : k_op2_loop<4, false>;
-            // Without re-compression the kernel also lays its GAP candidates out (a bump cursor instead of the layout scan) and folds
-            // the kinds: what is left after the one synchronise is an asynchronous k_emit_gaps into a slab of exactly the words the
-            // cursor counted -- unless the bit slab turns out sparse enough to be compacted, which takes the scan path as before.
+            // Without re-compression the kernel also lays its GAP candidates out (a bump cursor instead of the layout scan), converts
+            // them in its tail into a slab sized at the operands' bound, and folds the kinds: nothing is left after the one
+            // synchronise -- unless the bit slab turns out sparse enough to be compacted, which takes the scan path as before.
             // (The 16-bit kind counters of a fold slot hold 64 x 65,535 blocks.)
             emit = !opt_compress && !no_gap && nblocks <= 2000000u;
+            if (emit) {
+                gap_bound = (a->counts[BMX_GAP] ? a->gap_words : 0) + (b->counts[BMX_GAP] ? b->gap_words : 0) + 8u;
+                if ((rc = dmalloc(ctx, (void**)&v->d_gaps, (size_t)gap_bound * 2 + 64))) { bmx_vec_free(ctx, v); return rc; }
+            }
             // the kinds are folded whatever the operands hold: when every block came out as a bit-block (OR / XOR of two 1 % vectors:
             // their GAP x GAP results pass the 1,276-run limit) there is nothing for the layout scan to lay out
             hipLaunchKernelGGL(fn, dim3(grid), dim3(256), 0, ctx->stream, op, a->d_desc, a->nblocks, b->d_desc, b->nblocks, nblocks, opt_compress,
                                v->d_bits, v->d_desc, st, (emit || no_gap || op == BMX_OR || op == BMX_XOR) ? FoldOut{ctx->d_slots, ctx->d_done, ctx->h_small + 2} : FoldOut{nullptr, nullptr, nullptr},
-                               emit ? offs : nullptr, ctx->d_cursor, emit ? offs + nblocks : nullptr);
+                               emit ? offs : (u32*)nullptr, ctx->d_cursor, emit ? v->d_gaps : (u16*)nullptr);
             folded = emit || op == BMX_OR || op == BMX_XOR;                 // (with re-compression AND / SUB go straight to the layout scan, no extra synchronise)
         } else {
         // short vectors: a wave per column; the kernel also folds the popcount of its result (bvector::bit_and + count(), the
@@ -2215,7 +2236,7 @@ int bmx_op2(bmx_ctx* ctx, int op, const bmx_vec* a, const bmx_vec* b, int opt_co
         if (e == hipSuccess && (no_gap || folded)) e = hipStreamSynchronize(ctx->stream);
         if (e != hipSuccess) { bmx_vec_free(ctx, v); return fail_hip(e, "k_op2", __LINE__); }
         if (emit) {
-            rc = op2_finish_laid_out(ctx, v, st, offs);
+            rc = op2_finish_laid_out(ctx, v, st, offs, gap_bound);
             if (rc) { bmx_vec_free(ctx, v); return rc; }
             *result = v;
             return BMX_OK;
@@ -2259,9 +2280,9 @@ int bmx_op2_dev(bmx_ctx* ctx, int op, const bmx_vec* a, const bmx_pending* pa, c
     *out = nullptr;
     ARGCHK((!a || a->ctx == ctx) && (!b || b->ctx == ctx) && (!pa || pa->ctx == ctx) && (!pb || pb->ctx == ctx));
     // operands that may hold GAP blocks: the result may hold GAP blocks too -- at most the operands' GAP words together
-    // (a copied GAP block, a GAP x GAP result of at most len(a) + len(b) runs) -- so its GAP slab is allocated at that bound,
-    // the kernel lays the candidates out itself and k_emit_gaps converts them right behind it: the descriptors are complete
-    // on the stream and the result can be an operand at once; bmx_pending_wait trims the slab
+    // (a copied GAP block, a GAP x GAP result of at most len(a) + len(b) runs) -- so its GAP slab is allocated at that bound
+    // and the kernel converts its GAP candidates into it before it ends: the descriptors are complete on the stream and the
+    // result can be an operand at once; bmx_pending_wait trims the slab
     const uint64_t gap_bound = (a ? (a->counts[BMX_GAP] ? a->gap_words : 0) : pa->gap_bound) + (b ? (b->counts[BMX_GAP] ? b->gap_words : 0) : pb->gap_bound);
     int rc = set_dev(ctx); if (rc) return rc;
     const bmx_vec* va = a ? a : pa->v; const bmx_vec* vb = b ? b : pb->v;
@@ -2332,8 +2353,7 @@ int bmx_op2_dev(bmx_ctx* ctx, int op, const bmx_vec* a, const bmx_pending* pa, c
             const u32 grid = std::min<u32>((nblocks + 3u) / 4u, 256u * wgs);
             auto fn = (ctx->op2_nt & 1) ? k_op2_loop<4, true> : k_op2_loop<4, false>;
             hipLaunchKernelGGL(fn, dim3(grid), dim3(256), 0, ctx->stream, op, va->d_desc, va->nblocks, vb->d_desc, vb->nblocks, nblocks, 0,
-                               v->d_bits, v->d_desc, st, fo, offs, ctx->d_cursor, offs + nblocks);
-            hipLaunchKernelGGL(k_emit_gaps, dim3((nblocks + 3) / 4), dim3(256), 0, ctx->stream, v->d_bits, nblocks, st, offs, gap_slab, v->d_desc);
+                               v->d_bits, v->d_desc, st, fo, offs, ctx->d_cursor, gap_slab);
         } else if (stream) {
             const u32 waves = 4u, total = 256u * waves * (u32)std::max(ctx->op2_wgs, 1);
             const u32 per_wave = (nblocks + total - 1u) / total;
@@ -2346,7 +2366,7 @@ int bmx_op2_dev(bmx_ctx* ctx, int op, const bmx_vec* a, const bmx_pending* pa, c
             const u32 grid = std::min<u32>((nblocks + 3u) / 4u, 256u * wgs);
             auto fn = (ctx->op2_nt & 1) ? k_op2_loop<4, true> : k_op2_loop<4, false>;
             hipLaunchKernelGGL(fn, dim3(grid), dim3(256), 0, ctx->stream, op, va->d_desc, va->nblocks, vb->d_desc, vb->nblocks, nblocks, 0,
-                               v->d_bits, v->d_desc, st, fo, (u32*)nullptr, ctx->d_cursor, (u32*)nullptr);
+                               v->d_bits, v->d_desc, st, fo, (u32*)nullptr, ctx->d_cursor, (u16*)nullptr);
         } else
             hipLaunchKernelGGL(k_op2, dim3((nblocks + 3) / 4), dim3(256), 0, ctx->stream, op, va->d_desc, va->nblocks, vb->d_desc, vb->nblocks, nblocks, 0,
                                v->d_bits, v->d_desc, st, fo, FoldOut{nullptr, nullptr, nullptr});
@@ -2383,28 +2403,13 @@ int bmx_pending_wait(bmx_ctx* ctx, bmx_pending* p, bmx_vec** out)
                     used <= bound && (used == 0) == (ncand == 0);
     ctx->pend_used &= ~(1ull << p->slot);
     (void)hipEventDestroy(p->ev);
-    dfree(ctx, p->scratch);                                           // (k_emit_gaps, which read it, ran before the event)
+    dfree(ctx, p->scratch);                                           // (the kernel that wrote it ran before the event)
     p->v = nullptr;
     delete p;
     if (!ok) { (void)hipStreamSynchronize(ctx->stream); bmx_vec_free(ctx, v); g_last_error = "bmx_pending_wait: inconsistent fold of the result block kinds"; return BMX_ERR_DEVICE; }
     if (bound) {
-        // the GAP slab was allocated at the operands' bound: give it back when nothing landed in it, move the data into a slab of
-        // its own size when the bound is far off (a copy and a descriptor rebase, enqueued)
         v->bytes -= std::min<size_t>(v->bytes, (size_t)bound * 2 + 64);
-        if (!used) { dfree(ctx, v->d_gaps); v->d_gaps = nullptr; v->gap_words = 0; }
-        else if (bound > 2 * used + 4096) {
-            u16* small_ = nullptr;
-            if ((rc = dmalloc(ctx, (void**)&small_, (size_t)used * 2 + 64))) { bmx_vec_free(ctx, v); return rc; }
-            hipError_t e = hipMemcpyAsync(small_, v->d_gaps, (size_t)used * 2, hipMemcpyDeviceToDevice, ctx->stream);
-            if (e == hipSuccess) {
-                hipLaunchKernelGGL(k_rebase_desc, dim3((nblocks + 255) / 256), dim3(256), 0, ctx->stream, (const u64*)v->d_desc, v->d_desc, nblocks,
-                                   (u64)(uintptr_t)v->d_bits, (u64)(uintptr_t)v->d_bits, (u64)(uintptr_t)v->d_gaps, (u64)(uintptr_t)small_);
-                e = hipGetLastError();
-            }
-            if (e != hipSuccess) { (void)hipStreamSynchronize(ctx->stream); dfree(ctx, small_); bmx_vec_free(ctx, v); return fail_hip(e, "bmx_pending_wait (GAP slab)", __LINE__); }
-            dfree(ctx, v->d_gaps);
-            v->d_gaps = small_; v->gap_words = used; v->bytes += (size_t)used * 2 + 64;
-        } else { v->gap_words = used; v->bytes += (size_t)bound * 2 + 64; }
+        if ((rc = gap_slab_trim(ctx, v, bound, used, 0))) { bmx_vec_free(ctx, v); return rc; }
     }
     // the slab, as result_finish treats it: nothing alive -> back to the pool; sparse -> the survivors into a right-sized slab
     // (ordinals from the descriptor table; enqueued, not waited for); nearly full -> kept, ordinals at the first download

@@ -28,7 +28,10 @@ enum { ST_OPT = 1, ST_FORCE_BIT = 2, ST_TEST_ZERO = 4, ST_TEST_ONE = 8, ST_FORCE
 
 // bit_block_to_gap (src/bmfunc.h:5542) from the transition masks of a block (blk_transitions): run k ends just before the
 // k-th transition.  Writes the block's len + 1 words at g (16-byte aligned) and its 0xFFFF padding; all 64 lanes call.
-__device__ __forceinline__ void gap_emit_from_transitions(const Blk& t, u32 len, u32 first, u16* __restrict__ g, u32 lane)
+// The words are collected in `stage` (2,560 bytes of LDS private to the wave: 2-byte writes at the index a wave scan gives
+// every lane) and leave as whole 16-byte chunks -- written straight to memory, one 2-byte store per run end, a 1,270-run
+// block took ~12 us (round 5: measured behind k_op2_loop, profiles/r05_pair).
+__device__ __forceinline__ void gap_emit_from_transitions(const Blk& t, u32 len, u32 first, u16* __restrict__ g, u32 lane, u16* __restrict__ stage)
 {
     u32 idx_base = 1u;
 #pragma unroll
@@ -43,31 +46,38 @@ __device__ __forceinline__ void gap_emit_from_transitions(const Blk& t, u32 len,
             u32 m = tw[j];
             while (m) {
                 u32 k = __builtin_ctz(m); m &= m - 1u;
-                g[idx++] = (u16)((wbase + j) * 32u + k - 1u);
+                stage[idx++] = (u16)((wbase + j) * 32u + k - 1u);
             }
         }
         idx_base += __shfl(incl, 63, 64);
     }
     if (lane == 0) {
         u32 level = len <= 124u ? 0u : len <= 252u ? 1u : len <= 508u ? 2u : 3u;
-        g[0] = (u16)((len << 3) | (level << 1) | first);
-        g[len] = 65535u;
+        stage[0] = (u16)((len << 3) | (level << 1) | first);
+        stage[len] = 65535u;
     }
     // padding words up to the next 16-byte boundary read 0xFFFF: no run end but a block's last has that value, which is how
     // k_agg_or_rows (bmx_kernels7.h) tells a run from padding without the block's length
-    if (lane >= 1u && lane <= 7u && len + lane < ((len + 1u + 7u) & ~7u)) g[len + lane] = 0xFFFFu;
+    if (lane >= 1u && lane <= 7u && len + lane < ((len + 1u + 7u) & ~7u)) stage[len + lane] = 0xFFFFu;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const u32 nch = (len + 8u) >> 3;                              // 16-byte chunks holding words 0..len
+    const u32x4* s4 = reinterpret_cast<const u32x4*>(stage);
+    u32x4* g4 = reinterpret_cast<u32x4*>(g);
+    for (u32 ci = lane; ci < nch; ci += 64u) g4[ci] = s4[ci];
+    __builtin_amdgcn_wave_barrier();                              // (the stage is the wave's again)
 }
 
-// gap_offs != null: the producing kernel also lays the GAP candidates out -- a bump allocation of their 16-byte-padded
-// words from *gap_cursor, the offset left in gap_offs[nb] where k_emit_gaps looks for it, the block appended to gap_list[] --
-// so that no layout scan has to run between the kernel and k_emit_gaps (the order of the blocks in the GAP slab is then the
-// order of arrival) and k_emit_gaps_list launches over the candidates only.
+// gap_offs != null: the producing kernel also lays its GAP candidates out -- a bump allocation of their 16-byte-padded words
+// from *gap_cursor (low 40 bits: words, above: blocks), the offset left in gap_offs[nb] -- and converts them itself before it
+// ends (k_op2_loop's tail), into a slab the host sized at the operands' bound: neither a layout scan nor a conversion kernel runs
+// behind it (the order of the blocks in the GAP slab is then the order of arrival).
 template <bool SNT = false>
 __device__ __forceinline__ u32 store_result_mode(const Blk& acc, u32 nb, u32 mode,
                                                   uint4* __restrict__ slab, u64* __restrict__ desc,
                                                   BlockStat* __restrict__ st, u32 lane,
                                                   u32* __restrict__ gap_offs = nullptr, u64* __restrict__ gap_cursor = nullptr,
-                                                  u32* __restrict__ gap_list = nullptr, u32* pop_out = nullptr)
+                                                  u32* pop_out = nullptr, u32* gap_info = nullptr /* K_GAP with gap_offs: {offset, len << 1 | first} */)
 {
     Blk t;
     u32 pop = wave_sum(blk_lane_popcount(acc));
@@ -92,16 +102,17 @@ __device__ __forceinline__ u32 store_result_mode(const Blk& acc, u32 nb, u32 mod
             for (int i = 0; i < 8; ++i) __builtin_nontemporal_store(acc.r[i], &p[i * 64 + lane]);
         } else blk_store(acc, as_g4(slot), lane);
     }
+    u32 off = 0u;
     if (lane == 0) {
         st[nb] = BlockStat{pop, runs, first, kind};
         desc[nb] = (kind == K_BIT) ? DESC_MAKE(slot, K_BIT) : DESC_MAKE(0, kind == K_GAP ? K_NULL : kind);
         if (kind == K_GAP && gap_offs) {
             // one atomic for both: the low 40 bits of the cursor count padded words, the bits above count candidates
             const u64 cur = __hip_atomic_fetch_add(gap_cursor, (1ull << 40) | (u64)((runs + 1u + 7u) & ~7u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            gap_offs[nb] = (u32)(cur & 0xFFFFFFFFFFull);
-            gap_list[(u32)(cur >> 40)] = nb;
+            gap_offs[nb] = off = (u32)(cur & 0xFFFFFFFFFFull);
         }
     }
+    if (gap_info) { gap_info[0] = off; gap_info[1] = (runs << 1) | first; }     // (lane 0's values are the ones that count)
     return kind;
 }
 
@@ -135,30 +146,12 @@ __device__ __forceinline__ void store_trivial(u32 kind, u32 nb, u64* __restrict_
     }
 }
 
-// GAP conversion of the parked candidates named by a list (the kernel that produced them appended them: store_result_mode)
-__global__ __launch_bounds__(256)
-void k_emit_gaps_list(const uint4* __restrict__ slab, const u32* __restrict__ list, u32 n, const BlockStat* __restrict__ st,
-                      const u32* __restrict__ offs, u16* __restrict__ gap_slab, u64* __restrict__ desc)
-{
-    u32 lane = lane_id();
-    u32 i = uniform32(blockIdx.x * 4u + (threadIdx.x >> 6));
-    if (i >= n) return;
-    const u32 nb = uniform32(list[i]);
-    Blk b, t;
-    blk_load(b, as_gc4(slab + (size_t)nb * 512u), lane);
-    (void)blk_transitions(b, t, lane);
-    u16* g = gap_slab + offs[nb];
-    u32 len = uniform32(st[nb].runs);
-    u32 first = uniform32(st[nb].first);
-    gap_emit_from_transitions(t, len, first, g, lane);
-    if (lane == 0) desc[nb] = DESC_MAKE_GAP(g, len, first);
-}
-
 // GAP conversion of the parked candidates
 __global__ __launch_bounds__(256)
 void k_emit_gaps(const uint4* __restrict__ slab, u32 nblocks, const BlockStat* __restrict__ st,
                  const u32* __restrict__ offs, u16* __restrict__ gap_slab, u64* __restrict__ desc)
 {
+    __shared__ __attribute__((aligned(16))) u16 stage[4][1280];
     u32 lane = lane_id();
     u32 nb = uniform32(blockIdx.x * 4u + (threadIdx.x >> 6));
     if (nb >= nblocks) return;
@@ -169,7 +162,7 @@ void k_emit_gaps(const uint4* __restrict__ slab, u32 nblocks, const BlockStat* _
     u16* g = gap_slab + offs[nb];
     u32 len = uniform32(st[nb].runs);
     u32 first = uniform32(st[nb].first);
-    gap_emit_from_transitions(t, len, first, g, lane);
+    gap_emit_from_transitions(t, len, first, g, lane, stage[threadIdx.x >> 6]);
     if (lane == 0) desc[nb] = DESC_MAKE_GAP(g, len, first);
 }
 
@@ -301,7 +294,7 @@ __device__ __forceinline__ u32 op2_block(int op, u64 a, u64 b, u32 nb, int opt_c
     blk_from_desc(a, x, l, lane);
     blk_from_desc(b, y, l, lane);
     blk_op(op, x, y);
-    return store_result_mode(x, nb, op2_store_mode(op, ka, kb, opt_compress), slab, desc, st, lane, nullptr, nullptr, nullptr, pop_out);
+    return store_result_mode(x, nb, op2_store_mode(op, ka, kb, opt_compress), slab, desc, st, lane, nullptr, nullptr, pop_out);
 }
 
 // kinds.slots != null: the kind counts of the result are folded inside the kernel (kind_fanin_fold) -- used when no GAP
@@ -456,16 +449,24 @@ template <int WAVES, bool NT>
 __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(4)))
 void k_op2_loop(int op, const u64* __restrict__ da, u32 na, const u64* __restrict__ db, u32 nbk, u32 nblocks, int opt_compress,
                 uint4* __restrict__ slab, u64* __restrict__ desc, BlockStat* __restrict__ st, FoldOut kinds,
-                u32* __restrict__ gap_offs, u64* __restrict__ gap_cursor, u32* __restrict__ gap_list)
+                u32* __restrict__ gap_offs, u64* __restrict__ gap_cursor, u16* __restrict__ gap_slab)
 {
     // gap_offs != null: this kernel lays the GAP candidates out itself (bump allocation from *gap_cursor, offsets in gap_offs[];
-    // the last workgroup of the fold hands the cursor to kinds.out[4] and leaves it at zero): no layout scan before k_emit_gaps
+    // the last workgroup of the fold hands the cursor to kinds.out[4] and leaves it at zero) and converts them in its tail, into
+    // gap_slab (sized by the host at the operands' bound): no layout scan, no k_emit_gaps behind it
     __shared__ u32 lds[WAVES * 2048];
     const u32 lane = lane_id(), wave = threadIdx.x >> 6;
     u32* l = lds + wave * 2048u;
     const u32 total = gridDim.x * (u32)WAVES;
+    // the workgroup's GAP candidates, for its tail: {column, offset in the GAP slab, len << 1 | first} of the first PEND of them
+    constexpr u32 PEND = 20u * (u32)WAVES;
+    __shared__ u32 pend[PEND * 3u];
+    __shared__ u32 npend_wg;
+    if (threadIdx.x == 0) npend_wg = 0u;
+    __syncthreads();
     u64 kc = 0ull;
-    u32 c = uniform32(blockIdx.x * (u32)WAVES + wave);
+    const u32 c0 = uniform32(blockIdx.x * (u32)WAVES + wave);
+    u32 c = c0;
     auto raw = [&](const u64* __restrict__ d, u32 n, u32 col) -> u64 { return col < n ? d[col] : 0ull; };
     u64 ar = raw(da, na, c), br = raw(db, nbk, c);
     for (; c < nblocks; c += total) {
@@ -482,11 +483,57 @@ void k_op2_loop(int op, const u64* __restrict__ da, u32 na, const u64* __restric
             op2_finish(a, x, l, lane);
             op2_finish(b, y, l, lane);
             blk_op(op, x, y);
-            kind = store_result_mode<true>(x, c, op2_store_mode(op, ka, kb, opt_compress), slab, desc, st, lane, gap_offs, gap_cursor, gap_list);
+            u32 gi[2];
+            kind = store_result_mode<true>(x, c, op2_store_mode(op, ka, kb, opt_compress), slab, desc, st, lane, gap_offs, gap_cursor, nullptr, gi);
+            if (gap_offs && uniform32(kind) == K_GAP && lane == 0) {
+                const u32 at = atomicAdd(&npend_wg, 1u);
+                if (at < PEND) { pend[at * 3u] = c; pend[at * 3u + 1u] = gi[0]; pend[at * 3u + 2u] = gi[1]; }
+            }
         }
         kc += 1ull << (16u * kind);
     }
     if (kinds.slots) kind_fanin_fold_packed(kc, kinds, lane, wave, gap_offs ? gap_cursor : nullptr);
+    // Tail (round 5): the workgroup converts the GAP candidates its waves parked -- as bits in their slots of the result slab,
+    // which the loads of the same CU see (stores drained, then the workgroup barrier) -- into GAP blocks at the offsets they
+    // drew from the cursor.  Here and not where the block is classified: two block images are alive there at the kernel's
+    // 128-register cap, and every variant that converted in place spilled.  (This replaces a conversion kernel behind this
+    // one: 10-18 us and a launch gap behind a 60-us kernel.)  The candidates of the workgroup's list are dealt round the waves
+    // (a 1,270-run block takes ~5 us to convert: what ends the kernel is the wave with the most of them), the next one's
+    // block is requested before the current one is converted; a workgroup with more than PEND of them finds them again
+    // through st[] / gap_offs[].
+    if (gap_offs) {                                               // (kernel argument: the whole workgroup takes the branch)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const u32 npend = uniform32(npend_wg);
+        auto convert = [&](const Blk& b, u32 col, u32 off, u32 lf) {
+            Blk t;
+            (void)blk_transitions(b, t, lane);
+            u16* g = gap_slab + off;
+            gap_emit_from_transitions(t, lf >> 1, lf & 1u, g, lane, reinterpret_cast<u16*>(l));
+            if (lane == 0) desc[col] = DESC_MAKE_GAP(g, lf >> 1, lf & 1u);
+        };
+        if (npend <= PEND) {
+            if (wave < npend) {
+                Blk b0, b1;
+                blk_load(b0, as_gc4(slab + (size_t)uniform32(pend[wave * 3u]) * 512u), lane);
+                for (u32 i = wave; i < npend; i += (u32)WAVES) {
+                    const u32 nx = i + (u32)WAVES < npend ? i + (u32)WAVES : i;
+                    blk_load(b1, as_gc4(slab + (size_t)uniform32(pend[nx * 3u]) * 512u), lane);
+                    convert(b0, uniform32(pend[i * 3u]), uniform32(pend[i * 3u + 1u]), uniform32(pend[i * 3u + 2u]));
+                    b0 = b1;
+                }
+            }
+        } else {
+            for (c = c0; c < nblocks; c += total) {
+                if (uniform32(st[c].kind) != K_GAP) continue;
+                Blk b;
+                blk_load(b, as_gc4(slab + (size_t)c * 512u), lane);
+                convert(b, c, uniform32(gap_offs[c]), (uniform32(st[c].runs) << 1) | uniform32(st[c].first));
+            }
+        }
+    }
 }
 
 // bm::count_* when BOTH operands consist of bit-blocks only (the 10 % / 50 % cases of BASELINE configs[1]): the launch is
