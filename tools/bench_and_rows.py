@@ -17,6 +17,7 @@ for nt in (0, 1):
     for wg in (128, 256, 512):
         for dp in (2, 3, 4):
             variants.append(("rows_%d_%d_nt%d" % (wg, dp, nt), dict(and_rows=1, and_rows_wg=wg, and_rows_depth=dp, and_rows_nt=nt)))
+if os.environ.get("VARS"): variants = [v for v in variants if v[0] in os.environ["VARS"].split(",")]
 if DIAG:
     variants = [(n + "_diag%d" % d, dict(k, diag=d)) for d in (0, 1, 3, 4, 8) for n, k in variants if n in ("rows_256_2_nt0",)]
 import ctypes as C
@@ -26,7 +27,7 @@ d_counts = C.c_void_p()
 hip = C.CDLL("libamdhip64.so")
 hip.hipMalloc(C.byref(d_counts), 4096)
 for dq in dqs:
-    vecs = [bm.bvector.generate(ctx, SEED, v, dq, nbits, with_common=True) for v in range(nvec)]
+    vecs = [bm.bvector.generate(ctx, SEED, v, dq, nbits, with_common=os.environ.get("COMMON", "1") != "0") for v in range(nvec)]     # COMMON=0: independent operands (the AND is empty)
     st = vecs[0].calc_stat()
     agg = bm.aggregator(ctx)
     pipe = bm.aggregator.pipeline(ctx); g = pipe.add()
@@ -61,7 +62,7 @@ agg = bm.aggregator(ctx)
 if os.environ.get("CROSS"):
     for k, v in (("and_rows_wg", 256), ("and_rows_depth", 3), ("and_rows_nt", 0)): ctx.set_tuning(k, v)
     for dq in dqs:
-        vecs = [bm.bvector.generate(ctx, SEED, v, dq, nbits, with_common=True) for v in range(nvec)]
+        vecs = [bm.bvector.generate(ctx, SEED, v, dq, nbits, with_common=os.environ.get("COMMON", "1") != "0") for v in range(nvec)]     # COMMON=0: independent operands (the AND is empty)
         for n in (2, 4, 8, 12, 16, 24, 32, 64):
             ng = min(16, nvec // n)
             pipe = bm.aggregator.pipeline(ctx)
