@@ -2164,6 +2164,42 @@ def test_async_pairwise_chain(ctx, port, nblk):
     assert same(bm.bvector.bit_or(u1, u3), port.op2(bm.OR, f1, f3, False))
 
 
+def test_pairwise_gap_results_converted_by_the_kernel(ctx):
+    """Round 5: k_op2_loop converts its own GAP results in a tail phase (workgroup list of up to 80 candidates, dealt round the
+    waves; a workgroup with more finds them again through st[] / gap_offs[]).  Two sparse 1.7e9-bit vectors, every block a GAP
+    block, so EVERY result block of OR / XOR / SUB / AND is a GAP block: at one workgroup per CU (op2_loop 1) a workgroup parks
+    ~100 candidates (the overflow path), at the default ~25 (the list), and the wave-per-column kernel with the layout scan and
+    k_emit_gaps (op2_loop 0) is the older path: same bits, same block kinds, same counts as bm::count_*; the synchronous and
+    the asynchronous entry; results as operands and as host block tables."""
+    nbits = 1_700_000_000
+    a = bm.bvector.generate(ctx, 0xABCD, 1, 20, nbits)
+    b = bm.bvector.generate(ctx, 0xABCD, 2, 26, nbits)
+    nblk = a.info()["nblocks"]
+    assert a.calc_stat()["gap_blocks"] == nblk and b.calc_stat()["gap_blocks"] == nblk
+    counts = {op: f(a, b) for op, f in ((bm.AND, bm.count_and), (bm.OR, bm.count_or), (bm.XOR, bm.count_xor), (bm.SUB, bm.count_sub))}
+    try:
+        ref = {}
+        for loop in (0, -1, 1):
+            ctx.set_tuning("op2_loop", loop)
+            for op in (bm.OR, bm.XOR, bm.SUB, bm.AND):
+                t = bm.bvector._op2(op, a, b, bm.opt_none)
+                kinds = t.block_table()[0]
+                assert t.count() == counts[op], (loop, op)
+                if op != bm.AND: assert int((kinds == 3).sum()) == nblk, (loop, op)          # every block a GAP block
+                if loop == 0: ref[op] = (t, kinds)
+                else:
+                    assert bm.count_xor(t, ref[op][0]) == 0 and (kinds == ref[op][1]).all(), (loop, op)
+                    k, o, bb, g = t.block_table()
+                    back = bm.bvector.from_block_table(ctx, nbits, k, o, bb, g)
+                    assert bm.count_xor(back, ref[op][0]) == 0
+                    assert bm.count_and(t, a) == {bm.AND: counts[bm.AND], bm.SUB: counts[bm.SUB], bm.XOR: counts[bm.SUB], bm.OR: a.count()}[op]
+                    if loop == 1:
+                        u = bm.bvector.op2_async(op, a, b).wait()
+                        assert bm.count_xor(u, ref[op][0]) == 0 and (u.block_table()[0] == ref[op][1]).all()
+    finally:
+        ctx.set_tuning("op2_loop", -1)
+
+
 def test_full_size_pairwise_and_rank_select_vs_reference_on_all_cores(ctx):
     """BASELINE configs[1] and configs[3] at FULL size against the reference itself (oracle/_ref, the unmodified BitMagic;
     the C port where it is absent) fanned over the host cores by block range -- not only identities: the four counts of a
