@@ -1368,15 +1368,23 @@ def run_plumbing(args, env):
     dt, ev_ms = timed_region(step, steps, warmup, env)
     ob = ga.operand_bytes() + gb.operand_bytes()
     ms = dt / steps * 1e3
+    # the same as ONE host call (bmx_op2_count: result vector + its count), and the count alone (bm::count_and: no result)
+    def step1():
+        t, step1.c = bm.bvector.op2_count(bm.AND, ga, gb)
+    def step0():
+        step0.c = bm.count_and(ga, gb)
+    dt1, _ = timed_region(step1, steps, warmup, env)
+    dt0, _ = timed_region(step0, steps, warmup, env)
     res = {"metric": "Gbit/s of operand bits, bit_and + count on two 1M-bit vectors (plumbing case)", "value": round(2 * nbits * steps / dt / 1e9, 3),
            "unit": "Gbit/s", "n_gpus": 1, "steps": steps, "warmup": warmup, "ms_per_step": round(ms, 4), "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
            "config": {"workload": "two 1,000,000-bit vectors at 10 % (16 blocks each): bvector::bit_and (3-operand) + count()", "baseline_config": "configs[0]",
-                      "block_types_vec0": ga.calc_stat(), "gpu_count": int(step.c), "cpu_count": int(c_cpu), "counts_equal": bool(step.c == c_cpu == c2)},
+                      "block_types_vec0": ga.calc_stat(), "gpu_count": int(step.c), "cpu_count": int(c_cpu), "counts_equal": bool(step.c == c_cpu == c2 == step1.c == step0.c),
+                      "one_call_op2_count_ms": round(dt1 / steps * 1e3, 4), "count_and_only_ms": round(dt0 / steps * 1e3, 4)},
            "roofline": {"bound": "hbm", "achieved": round(ob / (ev_ms / steps) / 1e6, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(ob / (ev_ms / steps) / 1e6 / HBM_PEAK_GBS, 6), "traffic": None, "kernel": "k_op2 + k_vec_count (16 waves each)",
+                        "frac": round(ob / (ev_ms / steps) / 1e6 / HBM_PEAK_GBS, 6), "traffic": None, "kernel": "k_op2 (16 waves; folds the result's block kinds and its popcount: one launch, one synchronise; count() finds the count with the vector)",
                         "algorithmic_bytes_per_launch": int(ob), "avg_launch_ms": round(ev_ms / steps, 4),
-                        "note": "two host calls over 16 blocks: launch latency, not bandwidth; configs[0] is the CPU-runnable plumbing case"},
+                        "note": "two host calls (Python -> C-ABI) over 16 blocks: launch + synchronise latency, not bandwidth; configs[0] is the CPU-runnable plumbing case"},
            "cpu_baseline": {"value": round(2 * nbits / d_and / 1e9, 2), "unit": "Gbit/s", "cores": 1, "kind": "reference" if have_scalar else "port",
                             "impl": orc.name, "sample": f"bit_and (3-operand, new result vector) + count(), {reps} repetitions; AVX2 off (scalar build)",
                             "count_and_only_Gbit_s": round(2 * nbits / d_cnt / 1e9, 2), "us_per_bit_and_plus_count": round(d_and * 1e6, 2)}}

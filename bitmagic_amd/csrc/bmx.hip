@@ -2110,6 +2110,19 @@ static int vec_clone(bmx_ctx* ctx, const bmx_vec* a, bmx_vec** out)
 
 } // extern "C"
 
+// k_op2_loop's launch: op2_loop N > 0 = N workgroups of 4 waves per CU, -1 = 4 of them.  (Measured and dropped, profiles/r05_pair: ONE
+// 16-wave workgroup per CU when GAP results can come out, so that the conversions of its tail spread over 16 waves -- the tail
+// then starts when the slowest of 16 waves has left the column loop: AND 0.078 -> 0.082 ms, SUB 0.085 -> 0.086 ms.)
+static void op2_loop_launch(bmx_ctx* ctx, int op, const bmx_vec* va, const bmx_vec* vb, u32 nblocks, int opt_compress, bmx_vec* v, BlockStat* st,
+                            FoldOut fo, u32* offs, u16* gap_slab)
+{
+    const u32 wgs = (u32)(ctx->op2_loop > 0 ? ctx->op2_loop : 4);        // workgroups per CU = waves per SIMD
+    const u32 grid = std::min<u32>((nblocks + 3u) / 4u, 256u * wgs);
+    auto fn = (ctx->op2_nt & 1) ? k_op2_loop<4, true> : k_op2_loop<4, false>;
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(256), 0, ctx->stream, op, va->d_desc, va->nblocks, vb->d_desc, vb->nblocks, nblocks, opt_compress,
+                       v->d_bits, v->d_desc, st, fo, offs, ctx->d_cursor, gap_slab);
+}
+
 // A GAP slab allocated at the operands' bound (the words a pairwise result can hold at most: a copied GAP block, a GAP x GAP
 // result of at most len(a) + len(b) runs) and filled by the kernel up to `used`: given back when nothing landed in it, moved
 // into a slab of its own size -- a copy and a descriptor rebase, enqueued -- when the slack is worth it (more than
@@ -2204,9 +2217,6 @@ int bmx_op2(bmx_ctx* ctx, int op, const bmx_vec* a, const bmx_vec* b, int opt_co
                                v->d_bits, v->d_desc, st, FoldOut{ctx->d_slots, ctx->d_done, ctx->h_small + 2});
         } else if (ctx->op2_loop != 0 && nblocks >= 2048u) {
             // any block kinds, long vectors: the persistent form (one memory round trip per column, GAP blocks decoded from registers)
-            const u32 wgs = (u32)(ctx->op2_loop > 0 ? ctx->op2_loop : 4);        // workgroups per CU = waves per SIMD
-            const u32 grid = std::min<u32>((nblocks + 3u) / 4u, 256u * wgs);
-            auto fn = (ctx->op2_nt & 1) ? k_op2_loop<4, true> : k_op2_loop<4, false>;
             // Without re-compression the kernel also lays its GAP candidates out (a bump cursor instead of the layout scan), converts
             // them in its tail into a slab sized at the operands' bound, and folds the kinds: nothing is left after the one
             // synchronise -- unless the bit slab turns out sparse enough to be compacted, which takes the scan path as before.
@@ -2218,9 +2228,9 @@ int bmx_op2(bmx_ctx* ctx, int op, const bmx_vec* a, const bmx_vec* b, int opt_co
             }
             // the kinds are folded whatever the operands hold: when every block came out as a bit-block (OR / XOR of two 1 % vectors:
             // their GAP x GAP results pass the 1,276-run limit) there is nothing for the layout scan to lay out
-            hipLaunchKernelGGL(fn, dim3(grid), dim3(256), 0, ctx->stream, op, a->d_desc, a->nblocks, b->d_desc, b->nblocks, nblocks, opt_compress,
-                               v->d_bits, v->d_desc, st, (emit || no_gap || op == BMX_OR || op == BMX_XOR) ? FoldOut{ctx->d_slots, ctx->d_done, ctx->h_small + 2} : FoldOut{nullptr, nullptr, nullptr},
-                               emit ? offs : (u32*)nullptr, ctx->d_cursor, emit ? v->d_gaps : (u16*)nullptr);
+            op2_loop_launch(ctx, op, a, b, nblocks, opt_compress, v, st,
+                            (emit || no_gap || op == BMX_OR || op == BMX_XOR) ? FoldOut{ctx->d_slots, ctx->d_done, ctx->h_small + 2} : FoldOut{nullptr, nullptr, nullptr},
+                            emit ? offs : (u32*)nullptr, emit ? v->d_gaps : (u16*)nullptr);
             folded = emit || op == BMX_OR || op == BMX_XOR;                 // (with re-compression AND / SUB go straight to the layout scan, no extra synchronise)
         } else {
         // short vectors: a wave per column; the kernel also folds the popcount of its result (bvector::bit_and + count(), the
@@ -2349,11 +2359,7 @@ int bmx_op2_dev(bmx_ctx* ctx, int op, const bmx_vec* a, const bmx_pending* pa, c
         const bool stream = a && b && ctx->pair_stream != 0 && a->nblocks == b->nblocks && a->counts[BMX_BIT] == nblocks &&
                             b->counts[BMX_BIT] == nblocks && nblocks >= 2048u;
         if (gap_slab) {
-            const u32 wgs = (u32)(ctx->op2_loop > 0 ? ctx->op2_loop : 4);
-            const u32 grid = std::min<u32>((nblocks + 3u) / 4u, 256u * wgs);
-            auto fn = (ctx->op2_nt & 1) ? k_op2_loop<4, true> : k_op2_loop<4, false>;
-            hipLaunchKernelGGL(fn, dim3(grid), dim3(256), 0, ctx->stream, op, va->d_desc, va->nblocks, vb->d_desc, vb->nblocks, nblocks, 0,
-                               v->d_bits, v->d_desc, st, fo, offs, ctx->d_cursor, gap_slab);
+            op2_loop_launch(ctx, op, va, vb, nblocks, 0, v, st, fo, offs, gap_slab);
         } else if (stream) {
             const u32 waves = 4u, total = 256u * waves * (u32)std::max(ctx->op2_wgs, 1);
             const u32 per_wave = (nblocks + total - 1u) / total;
@@ -2362,11 +2368,7 @@ int bmx_op2_dev(bmx_ctx* ctx, int op, const bmx_vec* a, const bmx_pending* pa, c
                     : ctx->op2_nt == 1 ? k_op2_stream<4, true, false> : k_op2_stream<4, false, false>;
             hipLaunchKernelGGL(fn, dim3(grid), dim3(256), 0, ctx->stream, op, va->d_desc, vb->d_desc, nblocks, per_wave, v->d_bits, v->d_desc, st, fo);
         } else if (ctx->op2_loop != 0 && nblocks >= 2048u) {
-            const u32 wgs = (u32)(ctx->op2_loop > 0 ? ctx->op2_loop : 4);
-            const u32 grid = std::min<u32>((nblocks + 3u) / 4u, 256u * wgs);
-            auto fn = (ctx->op2_nt & 1) ? k_op2_loop<4, true> : k_op2_loop<4, false>;
-            hipLaunchKernelGGL(fn, dim3(grid), dim3(256), 0, ctx->stream, op, va->d_desc, va->nblocks, vb->d_desc, vb->nblocks, nblocks, 0,
-                               v->d_bits, v->d_desc, st, fo, (u32*)nullptr, ctx->d_cursor, (u16*)nullptr);
+            op2_loop_launch(ctx, op, va, vb, nblocks, 0, v, st, fo, nullptr, nullptr);
         } else
             hipLaunchKernelGGL(k_op2, dim3((nblocks + 3) / 4), dim3(256), 0, ctx->stream, op, va->d_desc, va->nblocks, vb->d_desc, vb->nblocks, nblocks, 0,
                                v->d_bits, v->d_desc, st, fo, FoldOut{nullptr, nullptr, nullptr});

@@ -2070,7 +2070,7 @@ def test_pairwise_materialised_long_mixed_vectors(ctx, port):
                 e = port.op2(op, x, y, opt)
                 exp[(opt, op, name)] = (e.flatten()[0].tolist(), e.to_words(nw), e.count())
     try:
-        for loop, nt in ((0, 3), (2, 3), (4, 2), (8, 3), (-1, 3)):
+        for loop, nt in ((0, 3), (2, 3), (4, 2), (8, 3), (-1, 3), (-1, 0)):
             ctx.set_tuning("op2_loop", loop); ctx.set_tuning("op2_nt", nt)
             for opt in (0, 1):
                 for op in range(4):
