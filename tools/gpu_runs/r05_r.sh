@@ -20,3 +20,4 @@ d=json.loads(open('gpurun_out/r05_r/bench_config0.json').read().strip().splitlin
 print(d['ms_per_step'], d['config'].get('one_call_op2_count_ms'), d['config'].get('count_and_only_ms'), d['config']['counts_equal'])
 PY
 cat $O/summary.txt
+# (the BMX_OP2_WAVES knob this script sets was removed after this run: the 16-wave shape lost, profiles/r05_pair/README.md)
