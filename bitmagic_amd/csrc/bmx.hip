@@ -2002,7 +2002,7 @@ int bmx_pipeline_operand_bytes(bmx_ctx* ctx, bmx_pipeline* p, uint32_t nb_from, 
 static int result_begin(bmx_ctx* ctx, uint64_t nbits, uint32_t nblocks, bmx_vec** out, BlockStat** st, u32** offs)
 {
     int rc;
-    // st[nblocks] + offs[nblocks] + the GAP candidate list k_op2_loop writes behind offs (offs + nblocks, up to nblocks entries)
+    // st[nblocks] + offs[nblocks] (+ nblocks words of slack behind them: round 4's candidate list lived there)
     size_t aux_need = (size_t)nblocks * (sizeof(BlockStat) + 4 + 4) + 64;
     if ((rc = ensure(ctx, &ctx->aux, &ctx->aux_bytes, aux_need))) return rc;
     *st = (BlockStat*)ctx->aux;
