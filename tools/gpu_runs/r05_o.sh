@@ -12,3 +12,4 @@ for l in open('gpurun_out/r05_o/and_rows.jsonl'):
     d=json.loads(l); print(d['dq'], d['variant'], d['ms'], d['frac'], d['count_ok'], d['kernel'][:40], d['materialised_host_ms'])
 PY
 cat $O/summary.txt
+# (record of the run behind profiles/r05_and_rows/filter_form: the filter_* variants exist only with that directory's patch applied)

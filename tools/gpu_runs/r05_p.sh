@@ -8,3 +8,4 @@ for l in open('gpurun_out/r05_p/and_rows_independent.jsonl'):
     d=json.loads(l); print(d['dq'], d['variant'], d['ms'], d['frac'], d['count'], d['count_ok'], d['alg_GB'])
 PY
 cat $O/summary.txt
+# (record of the run behind profiles/r05_and_rows/filter_form/and_rows_independent.jsonl: needs that directory's patch for the filter_* variants)
