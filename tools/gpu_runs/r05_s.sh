@@ -2,6 +2,10 @@
 # the slotted-slab variant of the first-call combine_or (profiles/r04_cold/slotted_slab_variant.patch, 9 % slower
 # in round 4 although it requests 13 % fewer lines) against the gather form, same code base (commit ee4b344, two worktrees under
 # _variants/, built here), same box, with counters: TCP / TA / TCC / SQ-LDS, one counter set per pass.
+# To recreate the two trees (they are not kept):
+#   git worktree add -f _variants/gather ee4b344; git worktree add -f _variants/slotted ee4b344
+#   (cd _variants/slotted && git apply profiles/r04_cold/slotted_slab_variant.patch)
+#   for v in gather slotted; do (cd _variants/$v && python -c 'import __graft_entry__ as g; g.build()'); done
 export TMPDIR=/tmp
 R=$PWD
 O=$R/gpurun_out/r05_s; rm -rf $O; mkdir -p $O
