@@ -347,7 +347,9 @@ class rs_index:
         """device bytes of the index and whether it holds rank lines (memory policy: tuning key rs_lines)"""
         b, h = C.c_uint64(), C.c_int32()
         check(lib().bmx_rs_info(self._h, C.byref(b), C.byref(h)))
-        return {"bytes": b.value, "has_lines": bool(h.value)}
+        sb, sbits = C.c_uint64(), C.c_int32()
+        check(lib().bmx_rs_select_format(self._h, C.byref(sbits), C.byref(sb)))
+        return {"bytes": b.value, "has_lines": bool(h.value), "select_offset_bits": sbits.value, "select_lines_bytes": sb.value}
 
     def export(self):
         """-> bcount[nb], sub_count[nb] (first | second<<16 | aux0<<32 | aux1<<48)"""

@@ -102,6 +102,7 @@ def lib() -> C.CDLL:
         "bmx_rs_build": (i32, [vp, vp, P(vp)]),
         "bmx_rs_free": (i32, [vp, vp]),
         "bmx_rs_info": (i32, [vp, P(u64), P(i32)]),
+        "bmx_rs_select_format": (i32, [vp, P(i32), P(u64)]),
         "bmx_rs_count": (i32, [vp, P(u64)]),
         "bmx_rs_export": (i32, [vp, vp, vp, vp]),
         "bmx_rank_batch": (i32, [vp, vp, vp, vp, C.c_size_t, vp]),

@@ -13,6 +13,7 @@
 #include "bmx_kernels8.h"
 #include "bmx_kernels9.h"
 #include "bmx_kernels10.h"
+#include "bmx_kernels11.h"
 
 #include <algorithm>
 #include <atomic>
@@ -761,7 +762,7 @@ int bmx_ctx_create(int device, void* stream, bmx_ctx** out)
     // an invalid value is ignored (the default stays)
     static const char* const env_keys[][2] = {
         {"BMX_PIPE_UNROLL", "pipe_unroll"}, {"BMX_PIPE_ROWS", "pipe_rows"}, {"BMX_PIPE_NT", "pipe_nt"},
-        {"BMX_PIPE_WG", "pipe_wg"}, {"BMX_PIPE_WINDOW", "pipe_window"}, {"BMX_PIPE_SPLIT", "pipe_split"}, {"BMX_OR_TILE", "or_tile"}, {"BMX_OR_ROWS", "or_rows"}, {"BMX_OR_DEPTH", "or_depth"}, {"BMX_OR_WINDOW", "or_window"}, {"BMX_DIRECT_COLS", "direct_cols"}, {"BMX_FF_WINDOW", "ff_window"}, {"BMX_GAP_COUNT", "gap_count"}, {"BMX_AND_ROWS", "and_rows"}, {"BMX_AGG_SHAPE", "agg_shape"}, {"BMX_AND_ROWS_WG", "and_rows_wg"}, {"BMX_AND_ROWS_DEPTH", "and_rows_depth"}, {"BMX_AND_ROWS_NT", "and_rows_nt"}, {"BMX_AND_ROWS_IPW", "and_rows_ipw"}, {"BMX_RANGE_HALVES", "range_halves"}, {"BMX_PAIR_STREAM", "pair_stream"}, {"BMX_PAIR_WGS", "pair_wgs"}, {"BMX_RS_LANES", "rs_lanes"}, {"BMX_RS_SELECT_TOP", "rs_select_top"}, {"BMX_RS_LINES", "rs_lines"}, {"BMX_RS_SELECT_LINES", "rs_select_lines"}, {"BMX_RS_SDIR_SHIFT", "rs_sdir_shift"}, {"BMX_COLL_SHAPE", "coll_shape"}, {"BMX_COLL_WINDOW", "coll_window"}, {"BMX_COLL_SPLIT", "coll_split"}, {"BMX_COLL_BUILD", "coll_build"}, {"BMX_EQ_BIG", "eq_big"}, {"BMX_PAIR_LOOP", "pair_loop"}, {"BMX_PAIR_NT", "pair_nt"}, {"BMX_EQ_BIG_SHAPE", "eq_big_shape"}, {"BMX_OP2_WGS", "op2_wgs"}, {"BMX_OP2_LOOP", "op2_loop"}, {"BMX_OP2_NT", "op2_nt"}, {"BMX_GAP_PACK", "gap_pack"}, {"BMX_COLL_MEMBERS", "coll_members"}, {"BMX_XCD_SWIZZLE", "xcd_swizzle"}};
+        {"BMX_PIPE_WG", "pipe_wg"}, {"BMX_PIPE_WINDOW", "pipe_window"}, {"BMX_PIPE_SPLIT", "pipe_split"}, {"BMX_OR_TILE", "or_tile"}, {"BMX_OR_ROWS", "or_rows"}, {"BMX_OR_DEPTH", "or_depth"}, {"BMX_OR_WINDOW", "or_window"}, {"BMX_DIRECT_COLS", "direct_cols"}, {"BMX_FF_WINDOW", "ff_window"}, {"BMX_GAP_COUNT", "gap_count"}, {"BMX_AND_ROWS", "and_rows"}, {"BMX_AGG_SHAPE", "agg_shape"}, {"BMX_AND_ROWS_WG", "and_rows_wg"}, {"BMX_AND_ROWS_DEPTH", "and_rows_depth"}, {"BMX_AND_ROWS_NT", "and_rows_nt"}, {"BMX_AND_ROWS_IPW", "and_rows_ipw"}, {"BMX_RANGE_HALVES", "range_halves"}, {"BMX_PAIR_STREAM", "pair_stream"}, {"BMX_PAIR_WGS", "pair_wgs"}, {"BMX_RS_LANES", "rs_lanes"}, {"BMX_RS_SELECT_TOP", "rs_select_top"}, {"BMX_RS_SELECT_SEL", "rs_select_sel"}, {"BMX_RS_LINES", "rs_lines"}, {"BMX_RS_SELECT_LINES", "rs_select_lines"}, {"BMX_RS_SDIR_SHIFT", "rs_sdir_shift"}, {"BMX_COLL_SHAPE", "coll_shape"}, {"BMX_COLL_WINDOW", "coll_window"}, {"BMX_COLL_SPLIT", "coll_split"}, {"BMX_COLL_BUILD", "coll_build"}, {"BMX_EQ_BIG", "eq_big"}, {"BMX_PAIR_LOOP", "pair_loop"}, {"BMX_PAIR_NT", "pair_nt"}, {"BMX_EQ_BIG_SHAPE", "eq_big_shape"}, {"BMX_OP2_WGS", "op2_wgs"}, {"BMX_OP2_LOOP", "op2_loop"}, {"BMX_OP2_NT", "op2_nt"}, {"BMX_GAP_PACK", "gap_pack"}, {"BMX_COLL_MEMBERS", "coll_members"}, {"BMX_XCD_SWIZZLE", "xcd_swizzle"}};
     for (auto& kv : env_keys)
         if (const char* e = getenv(kv[0])) (void)bmx_ctx_set_tuning(ctx, kv[1], atoi(e));
     g_last_error.clear();
@@ -844,6 +845,7 @@ int bmx_ctx_set_tuning(bmx_ctx* ctx, const char* key, int value)
     else if (k == "rs_sdir_shift") { ARGCHK(value == 0 || (value >= 6 && value <= 20)); ctx->rs_sdir_shift = value; }
     else if (k == "rs_lines") { ARGCHK(value >= 0 && value <= 2); ctx->rs_lines = value; }
     else if (k == "rs_sorted_hint") { ARGCHK(value == 0 || value == 1); ctx->rs_sorted_hint = value; }
+    else if (k == "rs_select_sel") { ARGCHK(value >= -1 && value <= 2); ctx->rs_select_sel = value; }
     else if (k == "rs_select_top") { ARGCHK(value >= -1 && value <= 1); ctx->rs_select_top = value; }
     else if (k == "rs_lanes") { ARGCHK(value == 0 || value == 2 || value == 4 || value == 8); ctx->rs_lanes = value; }
     else if (k == "pipe_wg") { ARGCHK(value == 0 || (value >= 64 && value <= 1024 && value % 64 == 0)); ctx->pipe_wg = value; }
@@ -3565,6 +3567,35 @@ int bmx_rs_build(bmx_ctx* ctx, const bmx_vec* v, bmx_rs** out)
         RSCHK(hipMemcpyAsync(ctx->h_small, ctx->d_small, 8, hipMemcpyDeviceToHost, ctx->stream));
         RSCHK(hipStreamSynchronize(ctx->stream));
         rs->count = ctx->h_small[0];
+        if (rs->count && ctx->rs_select_sel != 0) {
+            // select lines (bmx_kernels11.h): the ones' positions, 60 (16-bit offsets) or 30 (32-bit) per 128-byte line.  Memory
+            // policy (rs_select_sel -1): where they cost no more than 2 x what the vector and its rank lines hold on the device.
+            // The 16-bit form is tried unless the average spacing of the ones already says that 60 of them span half a block.
+            const double budget = 2.0 * ((double)v->bytes + (rs->d_lines ? (double)lines_bytes : 0.0));
+            const bool try16 = ctx->rs_select_sel != 2 && (double)v->nblocks * 65536.0 / (double)rs->count * 60.0 < 32768.0;
+            for (int bits = try16 ? 16 : 32; bits <= 32 && !rs->d_sel; bits += 16) {
+                const uint32_t K = bits == 16 ? 60u : 30u;
+                const uint64_t nsel = (rs->count + K - 1u) / K;
+                const size_t sb = (size_t)nsel * SL_BYTES;
+                if (ctx->rs_select_sel == -1 && (double)sb > budget) break;
+                u8* d = nullptr;
+                if (dmalloc(ctx, (void**)&d, sb) != BMX_OK) break;           // (an optional index: the directory kernels serve)
+                RSCHK(hipMemsetAsync(ctx->d_small + 32, 0, 8, ctx->stream));
+                if (bits == 16) {
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rs_sel_build<u16>), dim3((v->nblocks + 3) / 4), dim3(256), 0, ctx->stream, v->d_desc, v->nblocks, (const u64*)rs->d_rcount, d);
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rs_sel_check<u16>), dim3((u32)((nsel + 255u) / 256u)), dim3(256), 0, ctx->stream, (const u8*)d, (u64)nsel, (u64)rs->count, (const u64*)rs->d_rcount, v->nblocks, (u32*)(ctx->d_small + 32));
+                } else {
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rs_sel_build<u32>), dim3((v->nblocks + 3) / 4), dim3(256), 0, ctx->stream, v->d_desc, v->nblocks, (const u64*)rs->d_rcount, d);
+                    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rs_sel_check<u32>), dim3((u32)((nsel + 255u) / 256u)), dim3(256), 0, ctx->stream, (const u8*)d, (u64)nsel, (u64)rs->count, (const u64*)rs->d_rcount, v->nblocks, (u32*)(ctx->d_small + 32));
+                }
+                hipError_t e_ = hipGetLastError();
+                if (e_ == hipSuccess) e_ = hipMemcpyAsync(ctx->h_small + 32, ctx->d_small + 32, 8, hipMemcpyDeviceToHost, ctx->stream);
+                if (e_ == hipSuccess) e_ = hipStreamSynchronize(ctx->stream);
+                if (e_ != hipSuccess) { dfree(ctx, d); int r_ = fail_hip(e_, "select lines", __LINE__); bmx_rs_free(ctx, rs); return r_; }
+                if (ctx->h_small[32] != 0) { dfree(ctx, d); continue; }      // a line spans >= 2^bits bits: the wider form
+                rs->d_sel = d; rs->sel_bits = (uint32_t)bits; rs->sel_lines = nsel; rs->bytes += sb;
+            }
+        }
         if (rs->d_lines && rs->count) {
             // select directory over the lines: the line of every 2^shift-th one (+ sentinel); k_select_sdir
             const uint64_t nlines = (uint64_t)v->nblocks * RL_LINES;
@@ -3610,13 +3641,21 @@ int bmx_rs_info(const bmx_rs* rs, uint64_t* bytes, int* has_lines)
     return BMX_OK;
 }
 
+int bmx_rs_select_format(const bmx_rs* rs, int* offset_bits, uint64_t* bytes)
+{
+    ARGCHK(rs);
+    if (offset_bits) *offset_bits = rs->d_sel ? (int)rs->sel_bits : 0;
+    if (bytes) *bytes = rs->d_sel ? rs->sel_lines * SL_BYTES : 0;
+    return BMX_OK;
+}
+
 int bmx_rs_free(bmx_ctx* ctx, bmx_rs* rs)
 {
     if (!rs) return BMX_OK;
     ARGCHK(ctx && rs->ctx == ctx);
     int rc = set_dev(ctx); if (rc) return rc;
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    dfree(ctx, rs->d_bcount); dfree(ctx, rs->d_sub); dfree(ctx, rs->d_rcount); dfree(ctx, rs->d_cum); dfree(ctx, rs->d_gidx); dfree(ctx, rs->d_sample); dfree(ctx, rs->d_lines); dfree(ctx, rs->d_dir8); dfree(ctx, rs->d_sdir); dfree(ctx, rs->d_stop);
+    dfree(ctx, rs->d_bcount); dfree(ctx, rs->d_sub); dfree(ctx, rs->d_rcount); dfree(ctx, rs->d_cum); dfree(ctx, rs->d_gidx); dfree(ctx, rs->d_sample); dfree(ctx, rs->d_lines); dfree(ctx, rs->d_dir8); dfree(ctx, rs->d_sdir); dfree(ctx, rs->d_stop); dfree(ctx, rs->d_sel);
     delete rs;
     return BMX_OK;
 }
@@ -3665,6 +3704,14 @@ int bmx_select_batch_dev(bmx_ctx* ctx, const bmx_vec* v, const bmx_rs* rs, const
     ARGCHK(ctx && v && rs && v->ctx == ctx && rs->ctx == ctx && rs->nblocks == v->nblocks && (q == 0 || (d_rank && d_pos && d_found)));
     int rc = set_dev(ctx); if (rc) return rc;
     if (!q) return BMX_OK;
+    if (rs->d_sel && ctx->rs_select_sel != 0) {
+        // select lines: one lane and one 128-byte line per query, no search (bmx_kernels11.h); any batch size, any order
+        const u32 g = (u32)std::min<size_t>((q + 511) / 512, 256u * 8u);
+        if (rs->sel_bits == 16) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_select_sel<u16>), dim3(g), dim3(256), 0, ctx->stream, (const u8*)rs->d_sel, rs->count, (const u64*)d_rank, (u64)q, (u64*)d_pos, (u8*)d_found);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_select_sel<u32>), dim3(g), dim3(256), 0, ctx->stream, (const u8*)rs->d_sel, rs->count, (const u64*)d_rank, (u64)q, (u64*)d_pos, (u8*)d_found);
+        KCHK();
+        return BMX_OK;
+    }
     int lpq = ctx->rs_lanes ? ctx->rs_lanes : (q >= (1u << 16) ? RS_SELECT_LANES_DEFAULT : 8);
     // big batches over a vector whose directory summary fits LDS: k_select_top, two lanes per query (profiles/r05_select: 10 M random
     // selects on configs[3] 0.377 ms against 0.416 / 0.436 for the global-directory kernel with four / two lanes, 100 M: 3.63 against

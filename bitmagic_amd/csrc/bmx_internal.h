@@ -97,6 +97,7 @@ struct bmx_ctx {
     int rs_sdir_shift = 0;     // ones per select-directory entry = 2^this; 0 = from the density (an entry per ~10 lines); grown when the directory would pass 8 MB
     int rs_select_lines = 2;   // select through the rank lines (octant directory + interpolated line guess verified by the line headers): 0 = k_select_l, 2 = select directory over the lines (k_select_sdir)
     int rs_select_top = -1;    // select with the 65,536-entry directory summary in LDS (k_select_top): -1 = batches of >= 4 M queries, 0 = never, 1 = always (where the summary exists)
+    int rs_select_sel = -1;    // select lines (k_select_sel: the ones' positions laid out 60 / 30 per 128-byte line, one line per query, no search): -1 = built where they cost <= 2 x the vector + its rank lines, 0 = never built / never used, 1 = always (16-bit offsets, 32-bit if a line spans >= 2^16 bits), 2 = always with 32-bit offsets
     int rs_sorted_hint = 0;    // the caller's select batches arrive with ascending ranks (enumeration): the shape that is fastest for them
     int rs_lanes = 0;          // rank: lanes per query (k_rank_l): 0 = automatic, 8 = the original kernel, 2, 4
     int xcd_swz = 1;
@@ -187,6 +188,7 @@ struct bmx_rs {
     u32* d_lines;                                         // rank lines: 69 x 128 B per block (count before the line + 960 bits), or null
     u32* d_sdir; uint32_t sdir_shift; uint64_t sdir_entries;  // with rank lines: select directory (line of every 2^shift-th one) + sentinel
     u16* d_dir8;                                          // with rank lines: ones of a block before each of its eight 8,192-bit octants
+    u8* d_sel = nullptr; uint32_t sel_bits = 0; uint64_t sel_lines = 0;  // select lines (bmx_kernels11.h): the positions of the ones, K = 60 (16-bit offsets) / 30 (32-bit) per 128-byte line, or null
     u32* d_stop = nullptr; uint32_t stop_shift = 0;       // with the select directory: its 65,536-entry summary for LDS (k_select_top): base[256] + 16-bit offsets, or null
     size_t bytes;
 };

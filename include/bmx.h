@@ -352,6 +352,11 @@ int bmx_rs_free(bmx_ctx* ctx, bmx_rs* rs);
  * tuning key "rs_lines" 0 never | 1 this policy | 2 always) -- the rank lines:
  * the vector laid out once more with its running counts interleaved, +108 % of the raw bits) */
 int bmx_rs_info(const bmx_rs* rs, uint64_t* bytes, int* has_lines);
+/* the select lines of the index, if it has them (tuning key "rs_select_sel": -1 where they cost <= 2 x the vector and its rank
+ * lines | 0 never | 1 always | 2 always with 32-bit offsets): the positions of the ones laid out 60 (16-bit offsets) or 30 (32-bit)
+ * per 128-byte line, so that select(r) -- bvector::select src/bm.h:5350, rs_index::find src/bmrs.h:492 -- reads ONE line and
+ * searches nothing.  offset_bits = 16 | 32 | 0 (none: select runs through the rank lines' directory or the block tables) */
+int bmx_rs_select_format(const bmx_rs* rs, int* offset_bits, uint64_t* bytes);
 /* rs_index::count()  src/bmrs.h:340 */
 int bmx_rs_count(const bmx_rs* rs, uint64_t* count);
 /* reference-compatible per-block arrays so a host rs_index can be filled:

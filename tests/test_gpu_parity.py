@@ -1420,9 +1420,10 @@ def test_range_hint(ctx, port, agg_path):
         agg.reset_range_hint()
 
 
-@pytest.mark.parametrize("unroll,lines,sel", [(8, 0, 0), (2, 0, 0), (4, 0, 0), (2, 1, 1), (4, 1, 1), (2, 1, 2), (4, 1, 2), (4, 1, (2, 6)), (4, 1, (2, 16)),
-                                              (4, 1, (2, 0, 1)), (2, 1, (2, 6, 1)), (4, 1, (2, 16, 1))])
-def test_rank_select_queries_in_flight_forms(port, unroll, lines, sel):
+@pytest.mark.parametrize("unroll,lines,sel,selfmt", [(8, 0, 0, 0), (2, 0, 0, 0), (4, 0, 0, 0), (2, 1, 1, 0), (4, 1, 1, 0), (2, 1, 2, 0), (4, 1, 2, 0), (4, 1, (2, 6), 0), (4, 1, (2, 16), 0),
+                                                     (4, 1, (2, 0, 1), 0), (2, 1, (2, 6, 1), 0), (4, 1, (2, 16, 1), 0),
+                                                     (2, 1, 2, 1), (8, 0, 0, 1), (2, 1, 2, 2), (2, 0, 0, -1)])
+def test_rank_select_queries_in_flight_forms(port, unroll, lines, sel, selfmt):
     """k_rank_l<2|4> (fewer lanes per query = more queries in flight), k_rank_lines<2|4> (the vector laid out as rank
     lines: one 128-byte line per query) and the 8-lane kernels must give the oracle's answers on every block kind --
     NULL, FULL, bit, sparse and dense GAP -- incl. dead queries (rank 0, rank > count, position past the end) and
@@ -1438,6 +1439,10 @@ def test_rank_select_queries_in_flight_forms(port, unroll, lines, sel):
         if len(sel) > 2: c.set_tuning("rs_select_top", sel[2])
         sel = sel[0]
     c.set_tuning("rs_select_lines", sel)
+    # select lines (round 6, k_select_sel): 0 = not built, so that the forms above run the kernels they name; 1 = built with 16-bit
+    # offsets -- this vector has NULL blocks, a line of 60 ones spans more than a block somewhere, so the build must notice and
+    # take the 32-bit form; 2 = 32-bit offsets asked for; -1 = the memory policy decides
+    c.set_tuning("rs_select_sel", selfmt)
     rng = np.random.default_rng(1234 + unroll)
     nblk = 23
     nbits = nblk * 65536 - 777
@@ -1463,6 +1468,8 @@ def test_rank_select_queries_in_flight_forms(port, unroll, lines, sel):
     v = bm.bvector.from_block_table(c, nbits, *p.flatten())
     rs, prs = v.build_rs_index(), port.rs_build(p)
     cnt = p.count()
+    if selfmt == 0: assert rs.info()["select_offset_bits"] == 0
+    if selfmt > 0: assert rs.info()["select_offset_bits"] == 32 and rs.info()["select_lines_bytes"] == (cnt + 29) // 30 * 128
     for nq in (1, 7, 8, 9, 63, 1000, 4097):
         q = np.concatenate([rng.integers(0, nbits, size=nq).astype(np.uint64), np.array([0, nbits - 1, nbits, nbits + 70000, 65535, 65536], np.uint64)])
         assert (v.rank(q, rs) == prs.rank(q)).all(), (unroll, lines, nq)
@@ -1478,6 +1485,43 @@ def test_rank_select_queries_in_flight_forms(port, unroll, lines, sel):
     found, pos = v.select(allr, rs)
     ppos, pfound = prs.select(allr)
     assert found.all() and (pos == ppos).all()
+    del rs, v
+    c.close()
+
+
+@pytest.mark.parametrize("dq,nblk", [(6554, 40), (655, 40), (30000, 9), (200, 12)])
+def test_select_lines_16_bit_form(port, dq, nblk):
+    """select lines with 16-bit offsets (bmx_kernels11.h): a vector whose ones are spread evenly enough that 60 consecutive ones
+    never span a whole block keeps the 16-bit form -- lines that straddle one, two block borders (low bits wrap), bit and GAP
+    blocks, a FULL block in the middle; every one of the vector in order, random batches, dead queries.  At dq = 200
+    (0.3 %: 60 ones span ~20,000 bits on average, sometimes > 65,535) either form may result; the answers must not change"""
+    c = bm.context(0)
+    c.set_tuning("rs_select_sel", 1)
+    nbits = nblk * 65536 - 4321
+    words = port.gen_words(777 + dq, 3, dq, nbits)
+    words[5 * 2048:6 * 2048] = 0xFFFFFFFF                                 # one FULL block
+    p = port.import_words(words, True, nbits)
+    v = bm.bvector.from_block_table(c, nbits, *p.flatten())
+    rs, prs = v.build_rs_index(), port.rs_build(p)
+    cnt = p.count()
+    info = rs.info()
+    if dq >= 655: assert info["select_offset_bits"] == 16 and info["select_lines_bytes"] == (cnt + 59) // 60 * 128, info
+    else: assert info["select_offset_bits"] in (16, 32)
+    allr = np.arange(1, cnt + 1, dtype=np.uint64)
+    if cnt > 400000: allr = allr[:: cnt // 400000 + 1]
+    found, pos_all = v.select(allr, rs)
+    ppos, pfound = prs.select(allr)
+    assert found.all() and (pos_all == ppos).all()
+    rng = np.random.default_rng(dq)
+    for nq in (1, 63, 64, 65, 511, 512, 513, 100000):
+        r = np.concatenate([rng.integers(1, cnt + 1, size=nq).astype(np.uint64), np.array([1, cnt, 0, cnt + 1, 2 ** 40, 60, 61, 120, 121], np.uint64)])
+        found, pos = v.select(r, rs)
+        ppos, pfound = prs.select(r)
+        assert (found == pfound).all() and (pos[found] == ppos[pfound]).all() and (pos[~found] == 0).all(), (dq, nq)
+    # the policy form: the same answers whether or not the index took the lines
+    c.set_tuning("rs_select_sel", 0)
+    f0, p0 = v.select(allr[:5000], rs)
+    assert f0.all() and (p0 == pos_all[:5000]).all()
     del rs, v
     c.close()
 
