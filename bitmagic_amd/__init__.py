@@ -87,6 +87,19 @@ class context:
     def trim(self):
         check(lib().bmx_ctx_trim(self._h))
 
+    # -- debug aids (include/bmx.h "debug aids") --
+    def redzone_check(self) -> dict:
+        """verify the red zones of every live device allocation (contexts created under BMX_DEBUG_REDZONE=1)"""
+        en, hits = C.c_int32(), C.c_uint64()
+        buf = C.create_string_buffer(16384)
+        check(lib().bmx_debug_redzone_check(self._h, C.byref(en), C.byref(hits), buf, len(buf)))
+        return {"enabled": bool(en.value), "hits": hits.value, "report": buf.value.decode(errors="replace")}
+
+    def inject_failure(self, kind: int, after: int = 0) -> None:
+        """fault injection for tests: 1 / 2 / 3 = the library entry `after` calls from now throws bad_alloc / length_error / a non-std
+        exception, 4 = the device allocation `after` allocations from now fails, 5 = red-zone self-test, 0 = disarm"""
+        check(lib().bmx_debug_inject_failure(self._h, int(kind), int(after)))
+
     # -- packed collections (include/bmx.h "packed collections"): operand sets the engine keeps column-major --
     def collection_prepare(self, vecs, role: int = 1) -> None:
         """build the packed collection of an operand list now; role: ROLE_AND (0), ROLE_OR (1), ROLE_SUB (2)"""

@@ -148,6 +148,8 @@ def lib() -> C.CDLL:
         "bmx_gpipeline_describe": (i32, [vp, vp, i32, C.c_char_p, C.c_size_t, P(u32)]),
         "bmx_probe_random_lines": (i32, [vp, u64, u64, i32, P(C.c_float)]),
         "bmx_probe_stream_rw": (i32, [vp, u64, i32, i32, i32, P(C.c_float)]),
+        "bmx_debug_redzone_check": (i32, [vp, P(i32), P(u64), C.c_char_p, C.c_size_t]),
+        "bmx_debug_inject_failure": (i32, [vp, i32, C.c_longlong]),
         "bmx_timer_start": (i32, [vp]),
         "bmx_timer_stop_ms": (i32, [vp, P(C.c_float)]),
     }

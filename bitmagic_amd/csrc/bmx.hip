@@ -43,6 +43,28 @@ int bmx_fail_hip(hipError_t e, const char* what, const char* file, int line)
 void bmx_set_last_error(const char* msg) { g_last_error = msg ? msg : ""; }
 static int fail_hip(hipError_t e, const char* what, int line) { return bmx_fail_hip(e, what, "bmx.hip", line); }
 
+// The exception barrier of the C-ABI (ABI_TRY / ABI_END around every extern "C" body, bmx_internal.h): the reference's C
+// wrapper guarantees that no C++ exception reaches a C caller (lang-maps/libbm/src/libbm.cpp:28-35: every body is a
+// try / catch that turns std::bad_alloc into BM_ERR_BADALLOC); the host side here uses std::vector / std::map / std::string.
+int bmx_abi_caught(int kind, const char* what)
+{
+    if (kind == 0) { g_last_error = "out of host memory (std::bad_alloc)"; return BMX_ERR_BADALLOC; }
+    try { g_last_error = std::string("unexpected C++ exception inside the library: ") + (what ? what : "(not a std::exception)"); } catch (...) {}
+    return BMX_ERR_DEVICE;
+}
+// debug fault injection (bmx_debug_inject_failure): the ABI entry `after` calls from now on this thread throws
+static thread_local int g_inject_kind = 0;
+static thread_local long long g_inject_after = -1;
+void bmx_abi_enter()
+{
+    if (g_inject_after < 0) return;
+    if (g_inject_after-- > 0) return;
+    const int k = g_inject_kind; g_inject_kind = 0;
+    if (k == 1) throw std::bad_alloc();
+    if (k == 2) throw std::length_error("injected std::length_error");
+    if (k == 3) throw 42;
+}
+
 static void coll_free(bmx_ctx* ctx, size_t idx);
 static int vec_build_tdir(bmx_ctx* ctx, bmx_vec* v);
 static void coll_drop_vector(bmx_ctx* ctx, uint64_t uid);
@@ -56,22 +78,93 @@ static size_t pool_round(size_t bytes)
     return (bytes + g - 1) / g * g;
 }
 
-static int dmalloc_(bmx_ctx* ctx, void** p, size_t bytes);
-static int dmalloc(bmx_ctx* ctx, void** p, size_t bytes)
+// ---------------------------------------------------------------------------
+// red zones (debug, BMX_DEBUG_REDZONE=1): see bmx_ctx in bmx_internal.h
+// ---------------------------------------------------------------------------
+#define RZ_BYTES 4096u
+#define RZ_PATTERN 0xA5u
+struct RzSeg { const u8* p; u64 n; };
+__global__ __launch_bounds__(256)
+void k_rz_check(const RzSeg* __restrict__ seg, u32* __restrict__ bad /* per segment: damaged bytes; first damaged offset */)
+{
+    const RzSeg sg = seg[blockIdx.x];
+    u32 cnt = 0, first = 0xFFFFFFFFu;
+    for (u64 i = threadIdx.x; i < sg.n; i += 256u)
+        if (sg.p[i] != (u8)RZ_PATTERN) { ++cnt; if (first == 0xFFFFFFFFu) first = i < 0xFFFFFFFEull ? (u32)i : 0xFFFFFFFEu; }
+    if (cnt) { atomicAdd(&bad[2 * blockIdx.x], cnt); atomicMin(&bad[2 * blockIdx.x + 1], first); }
+}
+static size_t rz_user_end(size_t bytes) { return (bytes + 15u) & ~(size_t)15u; }
+// paint the zones around a block of `block` bytes at raw that serves a request of `bytes`; returns the user pointer
+static void* rz_arm(bmx_ctx* ctx, void* raw, size_t block, size_t bytes, int line)
+{
+    u8* user = (u8*)raw + RZ_BYTES;
+    const size_t end = rz_user_end(bytes);
+    (void)hipMemsetAsync(raw, RZ_PATTERN, RZ_BYTES, ctx->stream);
+    (void)hipMemsetAsync(user + end, RZ_PATTERN, block - RZ_BYTES - end, ctx->stream);
+    ctx->rz_live[user] = bmx_ctx::RzInfo{raw, block, bytes, line};
+    return user;
+}
+// verify the zones of one allocation (user != null) or of every live one; damaged allocations are counted, described in
+// ctx->rz_report (and on stderr) and repainted so that the same damage is reported once
+static void rz_verify(bmx_ctx* ctx, void* user_or_null)
+{
+    if (!ctx->redzone || ctx->rz_live.empty()) return;
+    std::vector<RzSeg> seg; std::vector<void*> who;
+    auto add = [&](void* user, const bmx_ctx::RzInfo& in) {
+        const size_t end = rz_user_end(in.bytes);
+        seg.push_back(RzSeg{(const u8*)in.raw, RZ_BYTES}); seg.push_back(RzSeg{(const u8*)user + end, in.block - RZ_BYTES - end});
+        who.push_back(user);
+    };
+    if (user_or_null) { auto it = ctx->rz_live.find(user_or_null); if (it == ctx->rz_live.end()) return; add(it->first, it->second); }
+    else for (auto& kv : ctx->rz_live) add(kv.first, kv.second);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    RzSeg* d_seg = nullptr; u32* d_bad = nullptr;
+    std::vector<u32> bad(seg.size() * 2);
+    for (size_t i = 0; i < seg.size(); ++i) { bad[2 * i] = 0; bad[2 * i + 1] = 0xFFFFFFFFu; }
+    if (hipMalloc((void**)&d_seg, seg.size() * sizeof(RzSeg)) != hipSuccess || hipMalloc((void**)&d_bad, bad.size() * 4) != hipSuccess) {
+        (void)hipGetLastError(); if (d_seg) (void)hipFree(d_seg); return;
+    }
+    (void)hipMemcpy(d_seg, seg.data(), seg.size() * sizeof(RzSeg), hipMemcpyHostToDevice);
+    (void)hipMemcpy(d_bad, bad.data(), bad.size() * 4, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(k_rz_check, dim3((u32)seg.size()), dim3(256), 0, ctx->stream, (const RzSeg*)d_seg, d_bad);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipMemcpy(bad.data(), d_bad, bad.size() * 4, hipMemcpyDeviceToHost);
+    (void)hipFree(d_seg); (void)hipFree(d_bad);
+    for (size_t a = 0; a < who.size(); ++a) {
+        const u32 front = bad[4 * a], rear = bad[4 * a + 2];
+        if (!front && !rear) continue;
+        const bmx_ctx::RzInfo& in = ctx->rz_live[who[a]];
+        char buf[320];
+        snprintf(buf, sizeof(buf), "[bmx redzone] allocation of %zu bytes made at bmx.hip:%d: %u byte(s) damaged in FRONT of it (first at -%u), %u byte(s) BEHIND it (first at +%zu past the requested size)\n",
+                 in.bytes, in.line, front, front ? RZ_BYTES - bad[4 * a + 1] : 0u, rear, rear ? (size_t)bad[4 * a + 3] + (rz_user_end(in.bytes) - in.bytes) : (size_t)0);
+        fputs(buf, stderr);
+        ++ctx->rz_hits;
+        if (ctx->rz_report.size() < 16384) ctx->rz_report += buf;
+        (void)rz_arm(ctx, in.raw, in.block, in.bytes, in.line);
+    }
+    (void)hipStreamSynchronize(ctx->stream);
+}
+
+static int dmalloc_(bmx_ctx* ctx, void** p, size_t bytes, int line);
+static int dmalloc_at(bmx_ctx* ctx, void** p, size_t bytes, int line)
 {
     static const bool trace = getenv("BMX_TRACE_ALLOC") != nullptr;
-    if (!trace || bytes < (64u << 20)) return dmalloc_(ctx, p, bytes);
+    if (!trace || bytes < (64u << 20)) return dmalloc_(ctx, p, bytes, line);
     const auto t0 = std::chrono::steady_clock::now();
     const size_t cached = ctx->pool_cached;
-    int rc = dmalloc_(ctx, p, bytes);
+    int rc = dmalloc_(ctx, p, bytes, line);
     fprintf(stderr, "[bmx] dmalloc %.1f MB: %.2f ms (%s)\n", bytes / 1048576.0,
             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), ctx->pool_cached < cached ? "pool" : "hipMalloc");
     return rc;
 }
-static int dmalloc_(bmx_ctx* ctx, void** p, size_t bytes)
+#define dmalloc(ctx, p, bytes) dmalloc_at((ctx), (p), (bytes), __LINE__)
+static int dmalloc_(bmx_ctx* ctx, void** p, size_t bytes, int line)
 {
     *p = nullptr;
-    size_t sz = pool_round(bytes);
+    if (ctx->fail_dmalloc_after >= 0 && ctx->fail_dmalloc_after-- == 0) {      // debug fault injection
+        g_last_error = "injected device allocation failure"; return BMX_ERR_BADALLOC;
+    }
+    size_t sz = pool_round(ctx->redzone ? rz_user_end(bytes) + 2u * RZ_BYTES : bytes);
     auto it = ctx->pool_free.lower_bound(sz);
     if (it != ctx->pool_free.end() && it->first <= sz + sz / 4) {          // best fit within 25 % slack
         *p = it->second; sz = it->first;
@@ -90,6 +183,7 @@ static int dmalloc_(bmx_ctx* ctx, void** p, size_t bytes)
         while (e == hipErrorOutOfMemory && coll_evict_one(ctx)) { (void)hipGetLastError(); e = hipMalloc(p, sz); }
         if (e != hipSuccess) return fail_hip(e, "hipMalloc", __LINE__);
     }
+    if (ctx->redzone) *p = rz_arm(ctx, *p, sz, bytes, line);
     ctx->pool_live[*p] = sz;
     ctx->mem_used += sz;
     return BMX_OK;
@@ -105,6 +199,10 @@ static void dfree(bmx_ctx* ctx, void* p)
     size_t sz = it->second;
     ctx->pool_live.erase(it);
     ctx->mem_used -= std::min<uint64_t>(ctx->mem_used, sz);
+    if (ctx->redzone) {
+        auto rz = ctx->rz_live.find(p);
+        if (rz != ctx->rz_live.end()) { rz_verify(ctx, p); p = rz->second.raw; ctx->rz_live.erase(rz); }
+    }
     if (ctx->pool_cached + sz <= ctx->pool_cap) { ctx->pool_free.emplace(sz, p); ctx->pool_cached += sz; }
     else { if (ctx->stream) (void)hipStreamSynchronize(ctx->stream); (void)hipFree(p); }
 }
@@ -116,14 +214,32 @@ static void pool_trim(bmx_ctx* ctx)
     ctx->pool_free.clear(); ctx->pool_cached = 0;
 }
 
-static int ensure(bmx_ctx* ctx, void** buf, size_t* cur, size_t need)
+// the grow-only buffers (scratch, aux)
+static void ensure_release(bmx_ctx* ctx, void** buf, size_t* cur)
+{
+    if (!*buf) return;
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    void* raw = *buf;
+    auto rz = ctx->rz_live.find(*buf);
+    if (rz != ctx->rz_live.end()) { rz_verify(ctx, *buf); raw = rz->second.raw; ctx->rz_live.erase(rz); }
+    (void)hipFree(raw); *buf = nullptr; *cur = 0;
+}
+static int ensure_at(bmx_ctx* ctx, void** buf, size_t* cur, size_t need, int line)
 {
     if (*cur >= need) return BMX_OK;
-    if (*buf) { HIPCHK(hipStreamSynchronize(ctx->stream)); (void)hipFree(*buf); *buf = nullptr; *cur = 0; }
-    HIPCHK(hipMalloc(buf, need));
+    ensure_release(ctx, buf, cur);
+    if (ctx->fail_dmalloc_after >= 0 && ctx->fail_dmalloc_after-- == 0) { g_last_error = "injected device allocation failure"; return BMX_ERR_BADALLOC; }
+    if (ctx->redzone) {
+        const size_t block = rz_user_end(need) + 2u * RZ_BYTES;
+        void* raw = nullptr;
+        HIPCHK(hipMalloc(&raw, block));
+        *buf = rz_arm(ctx, raw, block, need, line);
+    }
+    else HIPCHK(hipMalloc(buf, need));
     *cur = need;
     return BMX_OK;
 }
+#define ensure(ctx, buf, cur, need) ensure_at((ctx), (buf), (cur), (need), __LINE__)
 
 // ---------------------------------------------------------------------------
 // column-major packed GAP collections (bmx_kernels6.h, member directory bmx_kernels8.h)
@@ -516,6 +632,15 @@ static int coll_ensure_dir(bmx_ctx* ctx, bmx_coll* c)
     const size_t dir_bytes = (n + 1) * (size_t)ncols * 4;
     void* d_optab = nullptr;
     CollPin pin; pin.pin(c);                                                  // (the allocations below must not evict it)
+    // the directory counts against the packing budget like the runs do: least recently used, unpinned collections make room first
+    while (ctx->pack_bytes + 2ull * dir_bytes > ctx->pack_cap) {
+        size_t lru = ctx->colls.size();
+        for (size_t i = 0; i < ctx->colls.size(); ++i)
+            if (!ctx->colls[i]->pins && (lru == ctx->colls.size() || ctx->colls[i]->last_use < ctx->colls[lru]->last_use)) lru = i;
+        if (lru == ctx->colls.size()) break;
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess) break;              // (nothing may still read it)
+        coll_free(ctx, lru);
+    }
     if ((rc = dmalloc(ctx, &d_optab, std::max<size_t>(tab.size() * 8, 64))) || (rc = dmalloc(ctx, (void**)&c->d_dir, dir_bytes)) ||
         (rc = dmalloc(ctx, (void**)&c->d_dir_s, dir_bytes))) {
         dfree(ctx, d_optab); dfree(ctx, c->d_dir); dfree(ctx, c->d_dir_s); c->d_dir = c->d_dir_s = nullptr; return rc;
@@ -547,6 +672,10 @@ static int coll_members_launch(int mode, bmx_ctx* ctx, const bmx_coll* a, const 
                                u32 col_from, u32 col_to, int opt_compress, u64* d_counts, bmx_vec* v, BlockStat* st)
 {
     if (col_to <= col_from) return BMX_OK;
+    // both collections stay for the whole call: building the directory of one allocates GBs, and an allocation under memory
+    // pressure evicts the least recently used UNPINNED collection -- which must not be the other one (the pipeline callers hold
+    // a and s unpinned)
+    CollPin pin_both; pin_both.pin(const_cast<bmx_coll*>(a), const_cast<bmx_coll*>(s));
     { int rce; if ((rce = coll_ensure_dir(ctx, const_cast<bmx_coll*>(a))) || (rce = coll_ensure_dir(ctx, const_cast<bmx_coll*>(s)))) return rce; }
     const u64 nitems = (u64)(col_to - col_from) * ngroups;
     if ((nitems + CM_WAVES - 1) / CM_WAVES > 0x7FFFFFFFull) { g_last_error = "too many (column, group) items in one run"; return BMX_ERR_RANGE; }
@@ -713,15 +842,15 @@ const char* bmx_last_error(void) { return g_last_error.c_str(); }
 int bmx_simd_version(void) { return 950; }
 
 int bmx_device_count(int* n)
-{
+{ ABI_TRY
     ARGCHK(n);
     *n = 0;
     HIPCHK(hipGetDeviceCount(n));
     return BMX_OK;
-}
+ABI_END }
 
 int bmx_ctx_create(int device, void* stream, bmx_ctx** out)
-{
+{ ABI_TRY
     ARGCHK(out);
     *out = nullptr;
     int n = 0;
@@ -756,6 +885,7 @@ int bmx_ctx_create(int device, void* stream, bmx_ctx** out)
 #undef CTXCHK
     { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, device) == hipSuccess && v > 0) ctx->max_lds_bytes = (uint32_t)v; else (void)hipGetLastError(); }
     { size_t fr = 0, tot = 0; if (hipMemGetInfo(&fr, &tot) == hipSuccess && fr) ctx->pack_cap = (uint64_t)fr / 4; else (void)hipGetLastError(); }   // packed copies: at most a quarter of what is free now
+    if (const char* e = getenv("BMX_DEBUG_REDZONE")) ctx->redzone = atoi(e) != 0;
     if (const char* e = getenv("BMX_PACK_MAX_MB")) { long long mb = atoll(e); if (mb >= 0) ctx->pack_cap = (uint64_t)mb << 20; }
     if (const char* e = getenv("BMX_POOL_MAX_MB")) { long long mb = atoll(e); if (mb >= 0) ctx->pool_cap = (uint64_t)mb << 20; }
     // launch-shape knobs from the environment go through the same validation as bmx_ctx_set_tuning;
@@ -768,20 +898,22 @@ int bmx_ctx_create(int device, void* stream, bmx_ctx** out)
     g_last_error.clear();
     *out = ctx;
     return BMX_OK;
-}
+ABI_END }
 
 int bmx_ctx_destroy(bmx_ctx* ctx)
-{
+{ ABI_TRY
     if (!ctx) return BMX_OK;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     while (!ctx->colls.empty()) coll_free(ctx, ctx->colls.size() - 1);
     pool_trim(ctx);
     // vectors / pipelines the caller never freed: their handles die with the context, the device memory must not leak
-    for (auto& kv : ctx->pool_live) (void)hipFree(kv.first);
+    rz_verify(ctx, nullptr);
+    if (ctx->rz_hits) fprintf(stderr, "[bmx redzone] context destroyed with %llu damaged allocation(s) found during its life\n", (unsigned long long)ctx->rz_hits);
+    for (auto& kv : ctx->pool_live) { auto rz = ctx->rz_live.find(kv.first); (void)hipFree(rz != ctx->rz_live.end() ? rz->second.raw : kv.first); if (rz != ctx->rz_live.end()) ctx->rz_live.erase(rz); }
     ctx->pool_live.clear();
-    if (ctx->scratch) (void)hipFree(ctx->scratch);
-    if (ctx->aux) (void)hipFree(ctx->aux);
+    ensure_release(ctx, &ctx->scratch, &ctx->scratch_bytes);
+    ensure_release(ctx, &ctx->aux, &ctx->aux_bytes);
     if (ctx->d_small) (void)hipFree(ctx->d_small);
     if (ctx->d_slots) (void)hipFree(ctx->d_slots);
     if (ctx->d_done) (void)hipFree(ctx->d_done);
@@ -798,10 +930,10 @@ int bmx_ctx_destroy(bmx_ctx* ctx)
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return BMX_OK;
-}
+ABI_END }
 
 int bmx_ctx_set_tuning(bmx_ctx* ctx, const char* key, int value)
-{
+{ ABI_TRY
     ARGCHK(ctx && key);
     std::string k(key);
     if (k == "pipe_unroll") { ARGCHK(value == 0 || value == 1 || value == 2 || value == 4 || value == 8 || value == 16); ctx->pipe_unroll = value; }
@@ -852,14 +984,14 @@ int bmx_ctx_set_tuning(bmx_ctx* ctx, const char* key, int value)
     else if (k == "xcd_swizzle") ctx->xcd_swz = value != 0;
     else { g_last_error = "unknown tuning key"; return BMX_ERR_BADARG; }
     return BMX_OK;
-}
+ABI_END }
 
 // Measurement helper: ms of one pass of c = a & b over three buffers of `bytes` each, in the launch shape of k_op2_stream
 // (a wave per stretch of 8-KiB blocks, non-temporal 16-byte loads and stores): the yardstick bench.py --config 1 puts next
 // to the materialised pairwise operations.  The passes rotate over `sets` buffer triples so that nothing is served by the
 // Infinity Cache.
 int bmx_probe_stream_rw(bmx_ctx* ctx, uint64_t bytes, int sets, int wgs_per_cu, int iters, float* ms_per_pass)
-{
+{ ABI_TRY
     ARGCHK(ctx && ms_per_pass && bytes >= 8192 && sets >= 1 && sets <= 8 && wgs_per_cu >= 1 && wgs_per_cu <= 8 && iters >= 1);
     int rc = set_dev(ctx); if (rc) return rc;
     const u64 nblk = bytes / 8192;
@@ -884,7 +1016,7 @@ int bmx_probe_stream_rw(bmx_ctx* ctx, uint64_t bytes, int sets, int wgs_per_cu, 
     if (e != hipSuccess) return fail_hip(e, "bmx_probe_stream_rw", __LINE__);
     *ms_per_pass = ms / iters;
     return BMX_OK;
-}
+ABI_END }
 
 #ifdef BMX_DIAG
 int bmx_diag_stream_read(bmx_ctx* ctx, uint64_t bytes, int nt, uint32_t blocks_per_wave, int pattern, int iters, float* ms_per_pass)
@@ -920,30 +1052,65 @@ int bmx_diag_stream_read(bmx_ctx* ctx, uint64_t bytes, int nt, uint32_t blocks_p
 #endif  // BMX_DIAG
 
 int bmx_ctx_synchronize(bmx_ctx* ctx)
-{
+{ ABI_TRY
     ARGCHK(ctx);
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (ctx->redzone) {                                          // debug: every live allocation's red zones
+        int rc = set_dev(ctx); if (rc) return rc;
+        const uint64_t before = ctx->rz_hits;
+        rz_verify(ctx, nullptr);
+        if (ctx->rz_hits != before) { g_last_error = ctx->rz_report; return BMX_ERR_DEVICE; }
+    }
     return BMX_OK;
-}
+ABI_END }
+
+int bmx_debug_redzone_check(bmx_ctx* ctx, int* enabled, uint64_t* hits, char* report, size_t report_len)
+{ ABI_TRY
+    ARGCHK(ctx);
+    int rc = set_dev(ctx); if (rc) return rc;
+    rz_verify(ctx, nullptr);
+    if (enabled) *enabled = ctx->redzone ? 1 : 0;
+    if (hits) *hits = ctx->rz_hits;
+    if (report && report_len) { size_t n = std::min(report_len - 1, ctx->rz_report.size()); memcpy(report, ctx->rz_report.data(), n); report[n] = 0; }
+    return BMX_OK;
+ABI_END }
+
+int bmx_debug_inject_failure(bmx_ctx* ctx, int kind, long long after)
+{ ABI_TRY
+    ARGCHK(kind >= 0 && kind <= 5 && after >= 0);
+    if (kind == 4) { ARGCHK(ctx); ctx->fail_dmalloc_after = after; return BMX_OK; }
+    if (kind == 5) {                                             // red-zone self-test: one byte written just past the requested end of a fresh block
+        ARGCHK(ctx && ctx->redzone);
+        int rc = set_dev(ctx); if (rc) return rc;
+        void* d = nullptr;
+        if ((rc = dmalloc(ctx, &d, 1000 + (size_t)after))) return rc;
+        HIPCHK(hipMemsetAsync((u8*)d + rz_user_end(1000 + (size_t)after), 0, 1, ctx->stream));
+        dfree(ctx, d);
+        return BMX_OK;
+    }
+    if (kind == 0) { g_inject_after = -1; g_inject_kind = 0; if (ctx) ctx->fail_dmalloc_after = -1; return BMX_OK; }
+    g_inject_kind = kind; g_inject_after = after;
+    return BMX_OK;
+ABI_END }
 
 int bmx_ctx_trim(bmx_ctx* ctx)
-{
+{ ABI_TRY
     ARGCHK(ctx);
     int rc = set_dev(ctx); if (rc) return rc;
     HIPCHK(hipStreamSynchronize(ctx->stream));
     pool_trim(ctx);
     return BMX_OK;
-}
+ABI_END }
 
 int bmx_ctx_mem_used(const bmx_ctx* ctx, uint64_t* bytes)
-{
+{ ABI_TRY
     ARGCHK(ctx && bytes);
     *bytes = ctx->mem_used;
     return BMX_OK;
-}
+ABI_END }
 
 int bmx_collection_prepare(bmx_ctx* ctx, const bmx_vec* const* vecs, size_t n, int role)
-{
+{ ABI_TRY
     ARGCHK(ctx && n > 0 && vecs && (role == BMX_ROLE_OR || role == BMX_ROLE_AND || role == BMX_ROLE_SUB));
     int rc = set_dev(ctx); if (rc) return rc;
     for (size_t i = 0; i < n; ++i) if (!vecs[i] || vecs[i]->ctx != ctx) { g_last_error = "operand is null or belongs to another context"; return BMX_ERR_BADARG; }
@@ -966,40 +1133,40 @@ int bmx_collection_prepare(bmx_ctx* ctx, const bmx_vec* const* vecs, size_t n, i
     if (!rc && !c) { g_last_error = "vectors too long for a packed collection"; return BMX_ERR_RANGE; }
     if (!rc) c->prepared = true;
     return rc;
-}
+ABI_END }
 
 int bmx_ctx_pack_stats(const bmx_ctx* ctx, uint32_t* n_collections, uint64_t* bytes, float* last_build_ms)
-{
+{ ABI_TRY
     ARGCHK(ctx);
     if (n_collections) *n_collections = (uint32_t)ctx->colls.size();
     if (bytes) *bytes = ctx->pack_bytes;
     if (last_build_ms) *last_build_ms = ctx->last_pack_ms;
     return BMX_OK;
-}
+ABI_END }
 
 int bmx_ctx_pack_run_bytes(const bmx_ctx* ctx, uint64_t* bytes)
-{
+{ ABI_TRY
     ARGCHK(ctx && bytes);
     uint64_t b = 0;
     for (const bmx_coll* c : ctx->colls) b += c->run_bytes;
     *bytes = b;
     return BMX_OK;
-}
+ABI_END }
 
-int bmx_timer_start(bmx_ctx* ctx) { ARGCHK(ctx); HIPCHK(hipEventRecord(ctx->ev0, ctx->stream)); return BMX_OK; }
+int bmx_timer_start(bmx_ctx* ctx) { ABI_TRY ARGCHK(ctx); HIPCHK(hipEventRecord(ctx->ev0, ctx->stream)); return BMX_OK; ABI_END }
 int bmx_timer_stop_ms(bmx_ctx* ctx, float* ms)
-{
+{ ABI_TRY
     ARGCHK(ctx && ms);
     HIPCHK(hipEventRecord(ctx->ev1, ctx->stream));
     HIPCHK(hipEventSynchronize(ctx->ev1));
     HIPCHK(hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
     return BMX_OK;
-}
+ABI_END }
 
 // Measurement helper (like the timer): how many random 128-byte lines per second this box gathers from a buffer of
 // buf_bytes -- the bound of rank / select ("random access => bound by HBM transaction rate").
 int bmx_probe_random_lines(bmx_ctx* ctx, uint64_t buf_bytes, uint64_t nlines, int iters, float* ms_per_pass)
-{
+{ ABI_TRY
     ARGCHK(ctx && ms_per_pass && buf_bytes >= 128 && nlines >= 1 && iters >= 1);
     int rc = set_dev(ctx); if (rc) return rc;
     void* buf = nullptr;
@@ -1020,7 +1187,7 @@ int bmx_probe_random_lines(bmx_ctx* ctx, uint64_t buf_bytes, uint64_t nlines, in
     if (e != hipSuccess) return fail_hip(e, "bmx_probe_random_lines", __LINE__);
     *ms_per_pass = ms / iters;
     return BMX_OK;
-}
+ABI_END }
 
 // ---------------------------------------------------------------------------
 // vectors
@@ -1071,7 +1238,7 @@ static int vec_build_tdir(bmx_ctx* ctx, bmx_vec* v)
 }
 
 int bmx_vec_free(bmx_ctx* ctx, bmx_vec* v)
-{
+{ ABI_TRY
     if (!v) return BMX_OK;
     ARGCHK(ctx && v->ctx == ctx);
     int rc = set_dev(ctx); if (rc) return rc;
@@ -1081,13 +1248,13 @@ int bmx_vec_free(bmx_ctx* ctx, bmx_vec* v)
     dfree(ctx, v->d_desc); dfree(ctx, v->d_bits); dfree(ctx, v->d_gaps); dfree(ctx, v->d_ord); dfree(ctx, v->d_tdir);
     delete v;
     return BMX_OK;
-}
+ABI_END }
 
 int bmx_vec_upload(bmx_ctx* ctx, uint64_t nbits, uint32_t nblocks,
                    const uint8_t* kinds, const uint32_t* offs,
                    const uint32_t* bit_slab, uint32_t n_bit_blocks,
                    const uint16_t* gap_slab, uint64_t gap_words, bmx_vec** out)
-{
+{ ABI_TRY
     ARGCHK(ctx && out && (nblocks == 0 || (kinds && offs)));
     ARGCHK(n_bit_blocks == 0 || bit_slab);
     ARGCHK(gap_words == 0 || gap_slab);
@@ -1152,7 +1319,7 @@ int bmx_vec_upload(bmx_ctx* ctx, uint64_t nbits, uint32_t nblocks,
     }
     *out = v;
     return BMX_OK;
-}
+ABI_END }
 
 // raw block slab (in ctx->scratch, nblocks x 8 KiB) -> classified / compressed vector
 static int vec_from_raw(bmx_ctx* ctx, uint64_t nbits, uint32_t nblocks, int optimize, bmx_vec** out)
@@ -1190,7 +1357,7 @@ static int vec_from_raw(bmx_ctx* ctx, uint64_t nbits, uint32_t nblocks, int opti
 }
 
 int bmx_vec_import_bits(bmx_ctx* ctx, const uint32_t* words, uint64_t nwords, int optimize, bmx_vec** out)
-{
+{ ABI_TRY
     ARGCHK(ctx && out && (nwords == 0 || words));
     *out = nullptr;
     int rc = set_dev(ctx); if (rc) return rc;
@@ -1203,12 +1370,12 @@ int bmx_vec_import_bits(bmx_ctx* ctx, const uint32_t* words, uint64_t nwords, in
     if (raw_bytes > nwords * 4)
         HIPCHK(hipMemsetAsync((char*)ctx->scratch + nwords * 4, 0, raw_bytes - nwords * 4, ctx->stream));
     return vec_from_raw(ctx, nwords * 32ull, nblocks, optimize, out);
-}
+ABI_END }
 
 int bmx_vec_generate_shard(bmx_ctx* ctx, uint64_t seed, uint32_t vec_id, int with_common,
                            uint32_t density_q16, uint64_t nbits, uint32_t nb_from, uint32_t nb_to,
                            int optimize, bmx_vec** out)
-{
+{ ABI_TRY
     ARGCHK(ctx && out && density_q16 <= 65536u);
     *out = nullptr;
     int rc = set_dev(ctx); if (rc) return rc;
@@ -1229,13 +1396,13 @@ int bmx_vec_generate_shard(bmx_ctx* ctx, uint64_t seed, uint32_t vec_id, int wit
         KCHK();
     }
     return vec_from_raw(ctx, shard_bits, nblocks, optimize, out);
-}
+ABI_END }
 
 int bmx_vec_generate(bmx_ctx* ctx, uint64_t seed, uint32_t vec_id, int with_common,
                      uint32_t density_q16, uint64_t nbits, int optimize, bmx_vec** out)
-{
+{ ABI_TRY
     return bmx_vec_generate_shard(ctx, seed, vec_id, with_common, density_q16, nbits, 0u, 0xFFFFFFFFu, optimize, out);
-}
+ABI_END }
 
 } // extern "C"
 
@@ -1257,7 +1424,7 @@ extern "C" {
 
 int bmx_vec_info(const bmx_vec* v, uint64_t* nbits, uint32_t* nblocks, uint32_t counts[4],
                  uint32_t* bit_slab_blocks, uint64_t* gap_words)
-{
+{ ABI_TRY
     ARGCHK(v);
     if (nbits) *nbits = v->nbits;
     if (nblocks) *nblocks = v->nblocks;
@@ -1265,10 +1432,10 @@ int bmx_vec_info(const bmx_vec* v, uint64_t* nbits, uint32_t* nblocks, uint32_t 
     if (bit_slab_blocks) *bit_slab_blocks = (v->d_ord || v->ord_lazy) ? v->counts[BMX_BIT] : v->n_bit;   // a slab with unused slots is gathered on download
     if (gap_words) *gap_words = v->gap_words;
     return BMX_OK;
-}
+ABI_END }
 
 int bmx_vec_operand_bytes(bmx_ctx* ctx, const bmx_vec* v, uint64_t* bytes)
-{
+{ ABI_TRY
     ARGCHK(ctx && v && v->ctx == ctx && bytes);
     int rc = set_dev(ctx); if (rc) return rc;
     *bytes = 0;
@@ -1280,7 +1447,7 @@ int bmx_vec_operand_bytes(bmx_ctx* ctx, const bmx_vec* v, uint64_t* bytes)
     HIPCHK(hipStreamSynchronize(ctx->stream));
     *bytes = ctx->h_small[0];
     return BMX_OK;
-}
+ABI_END }
 
 // sorted positions of the set bits: device compaction (bmx_kernels6.h k_block_counts / k_rs_scan / k_expand_indices)
 static int vec_indices_impl(bmx_ctx* ctx, const bmx_vec* v, int width, void* out, bool out_is_host, uint64_t cap, uint64_t* n)
@@ -1323,18 +1490,18 @@ static int vec_indices_impl(bmx_ctx* ctx, const bmx_vec* v, int width, void* out
 }
 
 int bmx_vec_to_indices(bmx_ctx* ctx, const bmx_vec* v, int width, void* out, uint64_t cap, uint64_t* n)
-{
+{ ABI_TRY
     return vec_indices_impl(ctx, v, width, out, true, cap, n);
-}
+ABI_END }
 
 int bmx_vec_to_indices_dev(bmx_ctx* ctx, const bmx_vec* v, int width, void* d_out, uint64_t cap, uint64_t* n)
-{
+{ ABI_TRY
     return vec_indices_impl(ctx, v, width, d_out, false, cap, n);
-}
+ABI_END }
 
 int bmx_vec_download(bmx_ctx* ctx, const bmx_vec* v, uint8_t* kinds, uint32_t* offs,
                      uint32_t* bit_slab, uint16_t* gap_slab)
-{
+{ ABI_TRY
     ARGCHK(ctx && v && v->ctx == ctx);
     int rc = set_dev(ctx); if (rc) return rc;
     if (v->ord_lazy && !v->d_ord && (rc = vec_build_ord(ctx, const_cast<bmx_vec*>(v)))) return rc;   // (a cache of the immutable vector's layout: logically const)
@@ -1370,10 +1537,10 @@ int bmx_vec_download(bmx_ctx* ctx, const bmx_vec* v, uint8_t* kinds, uint32_t* o
     if (gap_slab && v->gap_words) HIPCHK(hipMemcpyAsync(gap_slab, v->d_gaps, (size_t)v->gap_words * 2, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return BMX_OK;
-}
+ABI_END }
 
 int bmx_vec_to_words(bmx_ctx* ctx, const bmx_vec* v, uint32_t* words, uint64_t nwords)
-{
+{ ABI_TRY
     ARGCHK(ctx && v && v->ctx == ctx && (nwords == 0 || words));
     int rc = set_dev(ctx); if (rc) return rc;
     if (!nwords) return BMX_OK;
@@ -1385,7 +1552,7 @@ int bmx_vec_to_words(bmx_ctx* ctx, const bmx_vec* v, uint32_t* words, uint64_t n
     HIPCHK(hipMemcpyAsync(words, ctx->scratch, nwords * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return BMX_OK;
-}
+ABI_END }
 
 } // extern "C"
 
@@ -1411,14 +1578,14 @@ int bmx_i_count_async(bmx_ctx* ctx, const bmx_vec* a, int slot)
 extern "C" {
 
 int bmx_count(bmx_ctx* ctx, const bmx_vec* a, uint64_t* count)
-{
+{ ABI_TRY
     ARGCHK(ctx && a && count && a->ctx == ctx);
     if (a->count_valid) { *count = a->count; return BMX_OK; }      // folded by the kernel that produced the vector
     int rc = bmx_i_count_async(ctx, a, 0); if (rc) return rc;
     HIPCHK(hipStreamSynchronize(ctx->stream));
     *count = ctx->h_small[0];
     return BMX_OK;
-}
+ABI_END }
 
 // ---------------------------------------------------------------------------
 // pipeline
@@ -1426,7 +1593,7 @@ int bmx_count(bmx_ctx* ctx, const bmx_vec* a, uint64_t* count)
 int bmx_pipeline_create(bmx_ctx* ctx, const bmx_vec* const* and_list, const uint32_t* and_n,
                         const bmx_vec* const* sub_list, const uint32_t* sub_n,
                         size_t ngroups, bmx_pipeline** out)
-{
+{ ABI_TRY
     ARGCHK(ctx && out && ngroups > 0 && ngroups < (1u << 20) && and_n && sub_n);
     *out = nullptr;
     int rc = set_dev(ctx); if (rc) return rc;
@@ -1540,10 +1707,10 @@ int bmx_pipeline_create(bmx_ctx* ctx, const bmx_vec* const* and_list, const uint
     *out = p;
     return BMX_OK;
 #undef PIPECHK
-}
+ABI_END }
 
 int bmx_pipeline_destroy(bmx_ctx* ctx, bmx_pipeline* p)
-{
+{ ABI_TRY
     if (!p) return BMX_OK;
     ARGCHK(ctx && p->ctx == ctx);
     int rc = set_dev(ctx); if (rc) return rc;
@@ -1554,7 +1721,7 @@ int bmx_pipeline_destroy(bmx_ctx* ctx, bmx_pipeline* p)
     delete p->h_row_off; delete p->h_and_n; delete p->h_sub_n; delete p->h_uids; delete p->h_win_groups; delete p->h_stop;
     delete p;
     return BMX_OK;
-}
+ABI_END }
 
 static int pipe_range(const bmx_pipeline* p, uint32_t& nb_from, uint32_t& nb_to)
 {
@@ -1694,9 +1861,9 @@ static int pipeline_run_counts_impl(bmx_ctx* ctx, bmx_pipeline* p, uint32_t nb_f
 extern "C" {
 
 int bmx_pipeline_run_counts_dev(bmx_ctx* ctx, bmx_pipeline* p, uint32_t nb_from, uint32_t nb_to, uint64_t* d_counts)
-{
+{ ABI_TRY
     return pipeline_run_counts_impl(ctx, p, nb_from, nb_to, d_counts, false);
-}
+ABI_END }
 
 static int pipeline_run_counts_impl(bmx_ctx* ctx, bmx_pipeline* p, uint32_t nb_from, uint32_t nb_to, uint64_t* d_counts, bool may_build, const GroupView* gv)
 {
@@ -1822,7 +1989,7 @@ static int pipeline_run_counts_impl(bmx_ctx* ctx, bmx_pipeline* p, uint32_t nb_f
 }
 
 int bmx_pipeline_describe(bmx_ctx* ctx, bmx_pipeline* p, uint32_t nb_from, uint32_t nb_to, char* buf, size_t buf_len, uint32_t* n_launches)
-{
+{ ABI_TRY
     ARGCHK(ctx && p && p->ctx == ctx && buf && buf_len > 0);
     if (n_launches) *n_launches = 1;
     int rc = pipe_range(p, nb_from, nb_to); if (rc) return rc;
@@ -1852,23 +2019,23 @@ int bmx_pipeline_describe(bmx_ctx* ctx, bmx_pipeline* p, uint32_t nb_from, uint3
         if (n_launches) *n_launches = nwin;
     }
     return BMX_OK;
-}
+ABI_END }
 
 int bmx_pipeline_set_search_count_limit(bmx_ctx* ctx, bmx_pipeline* p, uint64_t limit)
-{
+{ ABI_TRY
     ARGCHK(ctx && p && p->ctx == ctx);
     // 0, bm::id_max and the 48-bit id_max all mean "no limit" (the reference's default is id_max, src/bmaggregator.h:338)
     p->search_limit = (limit == 0 || limit == 0xFFFFFFFFull || limit == 0xFFFFFFFFFFFFull) ? ~0ull : limit;
     return BMX_OK;
-}
+ABI_END }
 
 int bmx_pipeline_last_windows(const bmx_pipeline* p, uint32_t* launched, uint32_t* planned)
-{
+{ ABI_TRY
     ARGCHK(p);
     if (launched) *launched = p->last_windows;
     if (planned) *planned = p->last_windows_planned;
     return BMX_OK;
-}
+ABI_END }
 
 } // extern "C"
 
@@ -1948,16 +2115,16 @@ extern "C" {
 
 // groups every launched window of the last synchronous counts run under a limit ran over (out[0 .. min(cap, n))), n = windows launched
 int bmx_pipeline_last_window_groups(const bmx_pipeline* p, uint32_t* out, uint32_t cap, uint32_t* n)
-{
+{ ABI_TRY
     ARGCHK(p && (out || !cap));
     const uint32_t have = p->h_win_groups ? (uint32_t)p->h_win_groups->size() : 0u;
     for (uint32_t i = 0; i < have && i < cap; ++i) out[i] = (*p->h_win_groups)[i];
     if (n) *n = have;
     return BMX_OK;
-}
+ABI_END }
 
 int bmx_pipeline_run_counts(bmx_ctx* ctx, bmx_pipeline* p, uint32_t nb_from, uint32_t nb_to, uint64_t* counts_out)
-{
+{ ABI_TRY
     ARGCHK(ctx && p && p->ctx == ctx && counts_out);
     int rc = set_dev(ctx); if (rc) return rc;
     p->last_windows = p->last_windows_planned = 1;
@@ -1974,10 +2141,10 @@ int bmx_pipeline_run_counts(bmx_ctx* ctx, bmx_pipeline* p, uint32_t nb_from, uin
     }
     if (p->ngroups > 64) dfree(ctx, d_counts);
     return rc;
-}
+ABI_END }
 
 int bmx_pipeline_operand_bytes(bmx_ctx* ctx, bmx_pipeline* p, uint32_t nb_from, uint32_t nb_to, uint64_t* bytes)
-{
+{ ABI_TRY
     ARGCHK(ctx && p && p->ctx == ctx && bytes);
     int rc = set_dev(ctx); if (rc) return rc;
     if ((rc = pipe_range(p, nb_from, nb_to))) return rc;
@@ -1993,7 +2160,7 @@ int bmx_pipeline_operand_bytes(bmx_ctx* ctx, bmx_pipeline* p, uint32_t nb_from, 
     HIPCHK(hipStreamSynchronize(ctx->stream));
     *bytes = ctx->h_small[0];
     return BMX_OK;
-}
+ABI_END }
 
 } // extern "C"
 
@@ -2176,7 +2343,7 @@ static int op2_finish_laid_out(bmx_ctx* ctx, bmx_vec* v, BlockStat* st, u32* off
 extern "C" {
 
 int bmx_op2(bmx_ctx* ctx, int op, const bmx_vec* a, const bmx_vec* b, int opt_compress, bmx_vec** result)
-{
+{ ABI_TRY
     ARGCHK(ctx && a && b && result && a->ctx == ctx && b->ctx == ctx && op >= BMX_AND && op <= BMX_SUB);
     *result = nullptr;
     int rc = set_dev(ctx); if (rc) return rc;
@@ -2264,13 +2431,13 @@ int bmx_op2(bmx_ctx* ctx, int op, const bmx_vec* a, const bmx_vec* b, int opt_co
     if (counted) { v->count = ctx->h_small[8]; v->count_valid = true; }
     *result = v;
     return BMX_OK;
-}
+ABI_END }
 
 // bit_and/or/xor/sub + count() in one call (bmx_op2(ctx, op, hA, hB, want_result, &hR, &count)): result
 // may be NULL (count only: bm::count_*, src/bmalgo.h:49-149).  Short vectors take one launch for both; long ones the
 // streaming kernels followed by the count pass.
 int bmx_op2_count(bmx_ctx* ctx, int op, const bmx_vec* a, const bmx_vec* b, int opt_compress, bmx_vec** result, uint64_t* count)
-{
+{ ABI_TRY
     ARGCHK(ctx && a && b && count);
     if (!result) return bmx_count_op2(ctx, op, a, b, count);
     int rc = bmx_op2(ctx, op, a, b, opt_compress, result);
@@ -2278,7 +2445,7 @@ int bmx_op2_count(bmx_ctx* ctx, int op, const bmx_vec* a, const bmx_vec* b, int 
     rc = bmx_count(ctx, *result, count);
     if (rc) { bmx_vec_free(ctx, *result); *result = nullptr; }
     return rc;
-}
+ABI_END }
 
 // ---- asynchronous 3-operand operations (bmx_op2_dev / bmx_pending_wait / bmx_pending_free) ----
 // What the synchronous bmx_op2 waits for is not the result -- that is complete on the stream when the kernel ends -- but the
@@ -2287,7 +2454,7 @@ int bmx_op2_count(bmx_ctx* ctx, int op, const bmx_vec* a, const bmx_vec* b, int 
 // counts into a pinned slot, the call returns at once, and a later operation that takes the unresolved result as an operand
 // simply runs the kernel that asks nothing of its operands' kinds (k_op2_loop / k_op2).  One synchronise resolves a whole chain.
 int bmx_op2_dev(bmx_ctx* ctx, int op, const bmx_vec* a, const bmx_pending* pa, const bmx_vec* b, const bmx_pending* pb, bmx_pending** out)
-{
+{ ABI_TRY
     ARGCHK(ctx && out && op >= BMX_AND && op <= BMX_SUB && ((a != nullptr) != (pa != nullptr)) && ((b != nullptr) != (pb != nullptr)));
     *out = nullptr;
     ARGCHK((!a || a->ctx == ctx) && (!b || b->ctx == ctx) && (!pa || pa->ctx == ctx) && (!pb || pb->ctx == ctx));
@@ -2382,10 +2549,10 @@ int bmx_op2_dev(bmx_ctx* ctx, int op, const bmx_vec* a, const bmx_pending* pa, c
     p->v = v;
     *out = p;
     return BMX_OK;
-}
+ABI_END }
 
 int bmx_pending_wait(bmx_ctx* ctx, bmx_pending* p, bmx_vec** out)
-{
+{ ABI_TRY
     ARGCHK(ctx && p && out && p->ctx == ctx && p->v);
     *out = nullptr;
     int rc = set_dev(ctx); if (rc) return rc;
@@ -2434,10 +2601,10 @@ int bmx_pending_wait(bmx_ctx* ctx, bmx_pending* p, bmx_vec** out)
     } else if (live < nblocks) v->ord_lazy = true;
     *out = v;
     return BMX_OK;
-}
+ABI_END }
 
 int bmx_pending_free(bmx_ctx* ctx, bmx_pending* p)
-{
+{ ABI_TRY
     if (!p) return BMX_OK;
     ARGCHK(ctx && p->ctx == ctx);
     (void)hipEventSynchronize(p->ev);
@@ -2447,7 +2614,7 @@ int bmx_pending_free(bmx_ctx* ctx, bmx_pending* p)
     int rc = p->v ? bmx_vec_free(ctx, p->v) : BMX_OK;
     delete p;
     return rc;
-}
+ABI_END }
 
 static int count_op2_launch(bmx_ctx* ctx, int op, const bmx_vec* a, const bmx_vec* b, u64* out, bool out_is_host)
 {
@@ -2494,9 +2661,9 @@ static int count_op2_launch(bmx_ctx* ctx, int op, const bmx_vec* a, const bmx_ve
 }
 
 int bmx_count_op2_dev(bmx_ctx* ctx, int op, const bmx_vec* a, const bmx_vec* b, uint64_t* d_count)
-{
+{ ABI_TRY
     return count_op2_launch(ctx, op, a, b, (u64*)d_count, false);
-}
+ABI_END }
 
 } // extern "C"
 
@@ -2509,14 +2676,14 @@ int bmx_i_count_op2_async(bmx_ctx* ctx, int op, const bmx_vec* a, const bmx_vec*
 extern "C" {
 
 int bmx_count_op2(bmx_ctx* ctx, int op, const bmx_vec* a, const bmx_vec* b, uint64_t* count)
-{
+{ ABI_TRY
     ARGCHK(ctx && count);
     int rc = bmx_i_count_op2_async(ctx, op, a, b, 0);
     if (rc) return rc;
     HIPCHK(hipStreamSynchronize(ctx->stream));
     *count = ctx->h_small[0];
     return BMX_OK;
-}
+ABI_END }
 
 // ---- small collections: aggregation in one launch straight from the descriptor tables (k_direct, bmx_kernels2.h) ----
 // waves per column of the one-launch path, 0 = take the row-table pipeline instead.  Long operand lists (24..1024) over few
@@ -2596,14 +2763,14 @@ static bool or_rows_wanted(const bmx_ctx* ctx, const bmx_vec* const* src, size_t
 }
 
 int bmx_agg_or(bmx_ctx* ctx, const bmx_vec* const* src, size_t n, bmx_vec** result)
-{
+{ ABI_TRY
     return agg_or_impl(ctx, src, n, 0 /* opt_mode_ = opt_none, src/bmaggregator.h:917 */, result);
-}
+ABI_END }
 
 int bmx_agg_or_opt(bmx_ctx* ctx, const bmx_vec* const* src, size_t n, int opt_compress, bmx_vec** result)
-{
+{ ABI_TRY
     return agg_or_impl(ctx, src, n, opt_compress ? 1 : 0, result);
-}
+ABI_END }
 
 static int agg_or_impl(bmx_ctx* ctx, const bmx_vec* const* src, size_t n, int opt_compress, bmx_vec** result)
 {
@@ -2832,7 +2999,7 @@ extern "C" {
 
 int bmx_agg_and_sub(bmx_ctx* ctx, const bmx_vec* const* src_and, size_t n_and,
                     const bmx_vec* const* src_sub, size_t n_sub, bmx_vec** result, int* any)
-{
+{ ABI_TRY
     ARGCHK(ctx && result && (n_and == 0 || src_and) && (n_sub == 0 || src_sub));
     *result = nullptr;
     if (any) *any = 0;
@@ -2919,7 +3086,7 @@ int bmx_agg_and_sub(bmx_ctx* ctx, const bmx_vec* const* src_and, size_t n_and,
     if (any) *any = (v->counts[BMX_FULL] + v->counts[BMX_BIT] + v->counts[BMX_GAP]) != 0;
     *result = v;
     return BMX_OK;
-}
+ABI_END }
 
 // combine_and_sub(pipe) with result vectors / counts / OR target (src/bmaggregator.h:1292-1449)
 static int run_results_impl(bmx_ctx* ctx, bmx_pipeline* p, uint32_t nb_from, uint32_t nb_to, bmx_vec** results_out, uint64_t* counts_out,
@@ -2927,15 +3094,15 @@ static int run_results_impl(bmx_ctx* ctx, bmx_pipeline* p, uint32_t nb_from, uin
 
 int bmx_pipeline_run_results(bmx_ctx* ctx, bmx_pipeline* p, bmx_vec** results_out, uint64_t* counts_out,
                              const bmx_vec* or_target_in, bmx_vec** or_target_out)
-{
+{ ABI_TRY
     return run_results_impl(ctx, p, 0u, 0xFFFFFFFFu, results_out, counts_out, or_target_in, or_target_out);
-}
+ABI_END }
 
 int bmx_pipeline_run_results_range(bmx_ctx* ctx, bmx_pipeline* p, uint32_t nb_from, uint32_t nb_to, bmx_vec** results_out,
                                    uint64_t* counts_out, const bmx_vec* or_target_in, bmx_vec** or_target_out)
-{
+{ ABI_TRY
     return run_results_impl(ctx, p, nb_from, nb_to, results_out, counts_out, or_target_in, or_target_out);
-}
+ABI_END }
 
 static int run_results_impl(bmx_ctx* ctx, bmx_pipeline* p, uint32_t nb_from, uint32_t nb_to, bmx_vec** results_out, uint64_t* counts_out,
                             const bmx_vec* or_target_in, bmx_vec** or_target_out)
@@ -3003,7 +3170,7 @@ static int hint_mask_vector(bmx_ctx* ctx, uint64_t nbits, uint32_t ncols, uint64
 
 int bmx_pipeline_run_results_hint(bmx_ctx* ctx, bmx_pipeline* p, uint64_t from, uint64_t to, bmx_vec** results_out,
                                   uint64_t* counts_out, const bmx_vec* or_target_in, bmx_vec** or_target_out)
-{
+{ ABI_TRY
     ARGCHK(ctx && p && p->ctx == ctx && (results_out || or_target_out || counts_out));
     if (from > to) { g_last_error = "range hint: from > to"; return BMX_ERR_RANGE; }
     const uint64_t nbf = from >> 16, nbt = to >> 16;
@@ -3043,7 +3210,7 @@ int bmx_pipeline_run_results_hint(bmx_ctx* ctx, bmx_pipeline* p, uint64_t from, 
     if (results_out) for (uint32_t g = 0; g < p->ngroups; ++g) results_out[g] = res[g];
     else cleanup();
     return BMX_OK;
-}
+ABI_END }
 
 static int find_first_impl(bmx_ctx* ctx, const bmx_vec* const* src_and, size_t n_and, const bmx_vec* const* src_sub, size_t n_sub,
                            bool ranged, uint64_t from, uint64_t to, int* found, uint64_t* idx)
@@ -3122,7 +3289,7 @@ static int find_first_impl(bmx_ctx* ctx, const bmx_vec* const* src_and, size_t n
 
 int bmx_agg_and_sub_indices(bmx_ctx* ctx, const bmx_vec* const* src_and, size_t n_and,
                             const bmx_vec* const* src_sub, size_t n_sub, int width, void* out, uint64_t cap, uint64_t* n)
-{
+{ ABI_TRY
     ARGCHK(n);
     *n = 0;
     bmx_vec* t = nullptr; int any = 0;
@@ -3131,20 +3298,20 @@ int bmx_agg_and_sub_indices(bmx_ctx* ctx, const bmx_vec* const* src_and, size_t 
     if (any) rc = bmx_vec_to_indices(ctx, t, width, out, cap, n);
     bmx_vec_free(ctx, t);
     return rc;
-}
+ABI_END }
 
 int bmx_find_first_and_sub(bmx_ctx* ctx, const bmx_vec* const* src_and, size_t n_and,
                            const bmx_vec* const* src_sub, size_t n_sub, int* found, uint64_t* idx)
-{
+{ ABI_TRY
     return find_first_impl(ctx, src_and, n_and, src_sub, n_sub, false, 0, 0, found, idx);
-}
+ABI_END }
 
 int bmx_find_first_and_sub_range(bmx_ctx* ctx, const bmx_vec* const* src_and, size_t n_and,
                                  const bmx_vec* const* src_sub, size_t n_sub, uint64_t from, uint64_t to,
                                  int* found, uint64_t* idx)
-{
+{ ABI_TRY
     return find_first_impl(ctx, src_and, n_and, src_sub, n_sub, true, from, to, found, idx);
-}
+ABI_END }
 
 // aggregator::combine_shift_right_and  src/bmaggregator.h:552,2494 (count form: set_compute_count, :363,2595)
 static int shift_right_and_impl(bmx_ctx* ctx, const bmx_vec* const* src, size_t n, int opt_compress, int any,
@@ -3213,16 +3380,16 @@ static int shift_right_and_impl(bmx_ctx* ctx, const bmx_vec* const* src, size_t 
 
 int bmx_agg_shift_right_and(bmx_ctx* ctx, const bmx_vec* const* src, size_t n, int opt_compress, int any,
                             bmx_vec** result, int* found)
-{
+{ ABI_TRY
     ARGCHK(result);
     return shift_right_and_impl(ctx, src, n, opt_compress, any, result, found, nullptr);
-}
+ABI_END }
 
 int bmx_agg_shift_right_and_count(bmx_ctx* ctx, const bmx_vec* const* src, size_t n, uint64_t* count)
-{
+{ ABI_TRY
     ARGCHK(count);
     return shift_right_and_impl(ctx, src, n, 0, 0, nullptr, nullptr, count);
-}
+ABI_END }
 
 // sparse_vector_scanner<SV>::find_gt/ge/lt/le/range/eq/zero/nonzero over resident slices (bmx_kernels4.h)
 // shared body of bmx_slice_compare / bmx_slice_compare_signed: `slices` are the planes the magnitude walk runs over;
@@ -3320,21 +3487,21 @@ static int slice_compare_unsigned(bmx_ctx* ctx, const bmx_vec* const* slices, si
 
 int bmx_slice_compare(bmx_ctx* ctx, const bmx_vec* const* slices, size_t nslices, int pred, uint64_t v0, uint64_t v1,
                       uint64_t size, const bmx_vec* not_null, bmx_vec** result, uint64_t* count)
-{
+{ ABI_TRY
     return slice_compare_unsigned(ctx, slices, nslices, pred, v0, v1, size, not_null, result, count, nullptr);
-}
+ABI_END }
 
 int bmx_slice_compare_stat(bmx_ctx* ctx, const bmx_vec* const* slices, size_t nslices, int pred, uint64_t v0, uint64_t v1,
                            uint64_t size, const bmx_vec* not_null, uint64_t* count, uint64_t* plane_bytes)
-{
+{ ABI_TRY
     ARGCHK(count && plane_bytes);
     return slice_compare_unsigned(ctx, slices, nslices, pred, v0, v1, size, not_null, nullptr, count, plane_bytes);
-}
+ABI_END }
 
 // signed containers: slices[0] = the sign plane, slices[1..] = magnitude planes (s2u encoding, src/bmbmatrix.h:2536-2548)
 int bmx_slice_compare_signed(bmx_ctx* ctx, const bmx_vec* const* slices, size_t nslices, int pred, int64_t v0, int64_t v1,
                              uint64_t size, const bmx_vec* not_null, bmx_vec** result, uint64_t* count)
-{
+{ ABI_TRY
     ARGCHK(ctx && (nslices == 0 || slices) && nslices <= 65 && pred >= BMX_CMP_GT && pred <= BMX_CMP_NONZERO && (result || count));
     ARGCHK(!not_null || not_null->ctx == ctx);
     const bmx_vec* sign = nslices ? slices[0] : nullptr;
@@ -3372,7 +3539,7 @@ int bmx_slice_compare_signed(bmx_ctx* ctx, const bmx_vec* const* slices, size_t 
     default: kp = CMP_NONZERO; mode = SIGN_NEG_ALL; break;                                          // any magnitude bit, or negative (-1 = sign only)
     }
     return slice_compare_impl(ctx, mag, nmag, kp, b0, b1, size, not_null, admits0 ? 1 : 0, sign, mode, result, count, nullptr);
-}
+ABI_END }
 
 // counts[q] = rows equal to values[q]: one pass over the planes whatever the number of queries (k_slice_eq_counts:
 // bit-matrix transposition + hash lookup); identical to the per-query AND-SUB groups of the reference
@@ -3380,7 +3547,7 @@ int bmx_slice_compare_signed(bmx_ctx* ctx, const bmx_vec* const* slices, size_t 
 // above the planes or in an absent plane matches nothing (:2621).
 int bmx_slice_eq_counts(bmx_ctx* ctx, const bmx_vec* const* slices, size_t nslices, const uint64_t* values, size_t n,
                         uint64_t size, const bmx_vec* not_null, uint64_t* counts)
-{
+{ ABI_TRY
     ARGCHK(ctx && (nslices == 0 || slices) && (n == 0 || (values && counts)));
     ARGCHK(!not_null || not_null->ctx == ctx);
     if (nslices > 32) { g_last_error = "more than 32 planes: use the pipeline form (bmx_pipeline_*)"; return BMX_ERR_RANGE; }
@@ -3513,13 +3680,13 @@ int bmx_slice_eq_counts(bmx_ctx* ctx, const bmx_vec* const* slices, size_t nslic
     if (rc) return rc;
     for (size_t q = 0; q < n; ++q) if (slot[q] >= 0) counts[q] = ucount[(size_t)slot[q]];
     return BMX_OK;
-}
+ABI_END }
 
 // ---------------------------------------------------------------------------
 // rank / select
 // ---------------------------------------------------------------------------
 int bmx_rs_build(bmx_ctx* ctx, const bmx_vec* v, bmx_rs** out)
-{
+{ ABI_TRY
     ARGCHK(ctx && v && out && v->ctx == ctx);
     *out = nullptr;
     int rc = set_dev(ctx); if (rc) return rc;
@@ -3631,26 +3798,26 @@ int bmx_rs_build(bmx_ctx* ctx, const bmx_vec* v, bmx_rs** out)
     }
     *out = rs;
     return BMX_OK;
-}
+ABI_END }
 
 int bmx_rs_info(const bmx_rs* rs, uint64_t* bytes, int* has_lines)
-{
+{ ABI_TRY
     ARGCHK(rs);
     if (bytes) *bytes = rs->bytes;
     if (has_lines) *has_lines = rs->d_lines ? 1 : 0;
     return BMX_OK;
-}
+ABI_END }
 
 int bmx_rs_select_format(const bmx_rs* rs, int* offset_bits, uint64_t* bytes)
-{
+{ ABI_TRY
     ARGCHK(rs);
     if (offset_bits) *offset_bits = rs->d_sel ? (int)rs->sel_bits : 0;
     if (bytes) *bytes = rs->d_sel ? rs->sel_lines * SL_BYTES : 0;
     return BMX_OK;
-}
+ABI_END }
 
 int bmx_rs_free(bmx_ctx* ctx, bmx_rs* rs)
-{
+{ ABI_TRY
     if (!rs) return BMX_OK;
     ARGCHK(ctx && rs->ctx == ctx);
     int rc = set_dev(ctx); if (rc) return rc;
@@ -3658,26 +3825,26 @@ int bmx_rs_free(bmx_ctx* ctx, bmx_rs* rs)
     dfree(ctx, rs->d_bcount); dfree(ctx, rs->d_sub); dfree(ctx, rs->d_rcount); dfree(ctx, rs->d_cum); dfree(ctx, rs->d_gidx); dfree(ctx, rs->d_sample); dfree(ctx, rs->d_lines); dfree(ctx, rs->d_dir8); dfree(ctx, rs->d_sdir); dfree(ctx, rs->d_stop); dfree(ctx, rs->d_sel);
     delete rs;
     return BMX_OK;
-}
+ABI_END }
 
-int bmx_rs_count(const bmx_rs* rs, uint64_t* count) { ARGCHK(rs && count); *count = rs->count; return BMX_OK; }
+int bmx_rs_count(const bmx_rs* rs, uint64_t* count) { ABI_TRY ARGCHK(rs && count); *count = rs->count; return BMX_OK; ABI_END }
 
 int bmx_rs_export(bmx_ctx* ctx, const bmx_rs* rs, uint32_t* bcount, uint64_t* sub_count)
-{
+{ ABI_TRY
     ARGCHK(ctx && rs && rs->ctx == ctx);
     int rc = set_dev(ctx); if (rc) return rc;
     if (bcount && rs->nblocks) HIPCHK(hipMemcpyAsync(bcount, rs->d_bcount, (size_t)rs->nblocks * 4, hipMemcpyDeviceToHost, ctx->stream));
     if (sub_count && rs->nblocks) HIPCHK(hipMemcpyAsync(sub_count, rs->d_sub, (size_t)rs->nblocks * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return BMX_OK;
-}
+ABI_END }
 
 #define RS_LANES_DEFAULT 2
 #define RS_SELECT_LANES_DEFAULT 4
 static u32 query_grid(size_t q) { return (u32)std::min<size_t>((q * 8 + 255) / 256, 256u * 16u); }
 
 int bmx_rank_batch_dev(bmx_ctx* ctx, const bmx_vec* v, const bmx_rs* rs, const uint64_t* d_n, size_t q, uint64_t* d_out)
-{
+{ ABI_TRY
     ARGCHK(ctx && v && rs && v->ctx == ctx && rs->ctx == ctx && rs->nblocks == v->nblocks && (q == 0 || (d_n && d_out)));
     int rc = set_dev(ctx); if (rc) return rc;
     if (!q) return BMX_OK;
@@ -3696,11 +3863,11 @@ int bmx_rank_batch_dev(bmx_ctx* ctx, const bmx_vec* v, const bmx_rs* rs, const u
 #undef RANK_ARGS
     KCHK();
     return BMX_OK;
-}
+ABI_END }
 
 int bmx_select_batch_dev(bmx_ctx* ctx, const bmx_vec* v, const bmx_rs* rs, const uint64_t* d_rank, size_t q,
                          uint64_t* d_pos, uint8_t* d_found)
-{
+{ ABI_TRY
     ARGCHK(ctx && v && rs && v->ctx == ctx && rs->ctx == ctx && rs->nblocks == v->nblocks && (q == 0 || (d_rank && d_pos && d_found)));
     int rc = set_dev(ctx); if (rc) return rc;
     if (!q) return BMX_OK;
@@ -3756,10 +3923,10 @@ int bmx_select_batch_dev(bmx_ctx* ctx, const bmx_vec* v, const bmx_rs* rs, const
 #undef SEL_ARGS
     KCHK();
     return BMX_OK;
-}
+ABI_END }
 
 int bmx_rank_batch(bmx_ctx* ctx, const bmx_vec* v, const bmx_rs* rs, const uint64_t* n, size_t q, uint64_t* out)
-{
+{ ABI_TRY
     ARGCHK(ctx && (q == 0 || (n && out)));
     int rc = set_dev(ctx); if (rc) return rc;
     if (!q) return BMX_OK;
@@ -3774,11 +3941,11 @@ int bmx_rank_batch(bmx_ctx* ctx, const bmx_vec* v, const bmx_rs* rs, const uint6
     dfree(ctx, d);
     if (e != hipSuccess) return fail_hip(e, "bmx_rank_batch", __LINE__);
     return rc;
-}
+ABI_END }
 
 int bmx_select_batch(bmx_ctx* ctx, const bmx_vec* v, const bmx_rs* rs, const uint64_t* rank, size_t q,
                      uint64_t* pos, uint8_t* found)
-{
+{ ABI_TRY
     ARGCHK(ctx && (q == 0 || (rank && pos && found)));
     int rc = set_dev(ctx); if (rc) return rc;
     if (!q) return BMX_OK;
@@ -3794,6 +3961,6 @@ int bmx_select_batch(bmx_ctx* ctx, const bmx_vec* v, const bmx_rs* rs, const uin
     dfree(ctx, d);
     if (e != hipSuccess) return fail_hip(e, "bmx_select_batch", __LINE__);
     return rc;
-}
+ABI_END }
 
 } // extern "C"

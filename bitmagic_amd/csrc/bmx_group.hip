@@ -250,7 +250,7 @@ static int load_rccl(bmx_group* g, const int* devices)
 extern "C" {
 
 int bmx_group_create(const int* devices, int n, int flags, bmx_group** out)
-{
+{ ABI_TRY
     ARGCHK(out && devices && n >= 1 && n <= 64 && (flags & ~BMX_GROUP_RCCL) == 0);
     *out = nullptr;
     if (flags & BMX_GROUP_RCCL)
@@ -269,10 +269,10 @@ int bmx_group_create(const int* devices, int n, int flags, bmx_group** out)
     { int rc = workers_start(g); if (rc) { bmx_group_destroy(g); return rc; } }
     *out = g;
     return BMX_OK;
-}
+ABI_END }
 
 int bmx_group_destroy(bmx_group* g)
-{
+{ ABI_TRY
     if (!g) return BMX_OK;
     workers_stop(g);
     for (size_t m = 0; m < g->comm.size(); ++m) if (g->comm[m] && g->p_comm_destroy) (void)g->p_comm_destroy(g->comm[m]);
@@ -280,26 +280,26 @@ int bmx_group_destroy(bmx_group* g)
     // librccl stays loaded: unloading a library that registered HIP fat binaries is not safe
     delete g;
     return BMX_OK;
-}
+ABI_END }
 
-int bmx_group_size(const bmx_group* g, int* n) { ARGCHK(g && n); *n = g->n; return BMX_OK; }
+int bmx_group_size(const bmx_group* g, int* n) { ABI_TRY ARGCHK(g && n); *n = g->n; return BMX_OK; ABI_END }
 
 int bmx_group_ctx(const bmx_group* g, int member, bmx_ctx** ctx)
-{
+{ ABI_TRY
     ARGCHK(g && ctx);
     if (member < 0 || member >= g->n) { bmx_set_last_error("member index out of range"); return BMX_ERR_RANGE; }
     *ctx = g->ctx[(size_t)member];
     return BMX_OK;
-}
+ABI_END }
 
 int bmx_group_shard_range(const bmx_group* g, uint32_t nblocks, int member, uint32_t* nb_from, uint32_t* nb_to)
-{
+{ ABI_TRY
     ARGCHK(g && nb_from && nb_to);
     if (member < 0 || member >= g->n) { bmx_set_last_error("member index out of range"); return BMX_ERR_RANGE; }
     part_ref p = part_for(const_cast<bmx_group*>(g), nblocks);
     *nb_from = p->bounds[(size_t)member]; *nb_to = p->bounds[(size_t)member + 1];
     return BMX_OK;
-}
+ABI_END }
 
 // ---- byte-weighted shard borders ("weighted by non-NULL operand bytes") ----
 static bool part_in_use(const bmx_group* g, uint32_t nblocks)
@@ -309,7 +309,7 @@ static bool part_in_use(const bmx_group* g, uint32_t nblocks)
 }
 
 int bmx_group_set_partition(bmx_group* g, uint32_t nblocks, const uint32_t* bounds)
-{
+{ ABI_TRY
     ARGCHK(g && bounds);
     if (bounds[0] != 0 || bounds[g->n] != nblocks) { bmx_set_last_error("partition must start at 0 and end at nblocks"); return BMX_ERR_RANGE; }
     for (int m = 0; m < g->n; ++m)
@@ -325,10 +325,10 @@ int bmx_group_set_partition(bmx_group* g, uint32_t nblocks, const uint32_t* boun
     p->bounds.assign(bounds, bounds + g->n + 1);
     g->parts[nblocks] = p;
     return BMX_OK;
-}
+ABI_END }
 
 int bmx_group_partition_by_weight(bmx_group* g, uint32_t nblocks, const uint64_t* weight, uint32_t* bounds_out)
-{
+{ ABI_TRY
     ARGCHK(g && (nblocks == 0 || weight));
     // border m = the first block at which the running weight reaches m/n of the total: every member gets the same
     // share of operand BYTES (not of block columns); empty stretches (NULL top-level ranges, src/bmblocks.h:556-564)
@@ -351,11 +351,11 @@ int bmx_group_partition_by_weight(bmx_group* g, uint32_t nblocks, const uint64_t
     if (rc) return rc;
     if (bounds_out) memcpy(bounds_out, b.data(), ((size_t)g->n + 1) * sizeof(uint32_t));
     return BMX_OK;
-}
+ABI_END }
 
 int bmx_block_table_weights(uint32_t nblocks, const uint8_t* kinds, const uint32_t* offs,
                             const uint16_t* gap_slab, uint64_t gap_words, uint64_t* weight)
-{
+{ ABI_TRY
     ARGCHK(weight && (nblocks == 0 || (kinds && offs)));
     for (uint32_t nb = 0; nb < nblocks; ++nb) {
         if (kinds[nb] == BMX_BIT) weight[nb] += 8192u;
@@ -365,10 +365,10 @@ int bmx_block_table_weights(uint32_t nblocks, const uint8_t* kinds, const uint32
         } else if (kinds[nb] > BMX_GAP) { bmx_set_last_error("bad block kind"); return BMX_ERR_BADARG; }
     }
     return BMX_OK;
-}
+ABI_END }
 
 int bmx_group_rccl_ranks(const bmx_group* g, int* n)
-{
+{ ABI_TRY
     ARGCHK(g && n);
     *n = 0;
     if (!(g->flags & BMX_GROUP_RCCL) || g->comm.empty() || !g->p_comm_count) return BMX_OK;
@@ -377,7 +377,7 @@ int bmx_group_rccl_ranks(const bmx_group* g, int* n)
     if (r != 0) { bmx_set_last_error("ncclCommCount failed"); return BMX_ERR_DEVICE; }
     *n = c;
     return BMX_OK;
-}
+ABI_END }
 
 static bmx_gvec* gvec_new(bmx_group* g, uint64_t nbits, uint32_t nblocks)
 {
@@ -390,14 +390,14 @@ static bmx_gvec* gvec_new(bmx_group* g, uint64_t nbits, uint32_t nblocks)
 }
 
 int bmx_gvec_free(bmx_group* g, bmx_gvec* v)
-{
+{ ABI_TRY
     if (!v) return BMX_OK;
     ARGCHK(g && v->g == g);
     int rc = BMX_OK;
     for (int m = 0; m < g->n; ++m) { int r = bmx_vec_free(g->ctx[(size_t)m], v->shard[(size_t)m]); if (r && !rc) rc = r; }
     delete v;
     return rc;
-}
+ABI_END }
 
 static uint64_t shard_bits(uint64_t nbits, uint32_t lo, uint32_t hi)
 {
@@ -408,7 +408,7 @@ static uint64_t shard_bits(uint64_t nbits, uint32_t lo, uint32_t hi)
 int bmx_gvec_upload(bmx_group* g, uint64_t nbits, uint32_t nblocks, const uint8_t* kinds, const uint32_t* offs,
                     const uint32_t* bit_slab, uint32_t n_bit_blocks, const uint16_t* gap_slab, uint64_t gap_words,
                     bmx_gvec** out)
-{
+{ ABI_TRY
     ARGCHK(g && out && (nblocks == 0 || (kinds && offs)));
     *out = nullptr;
     bmx_gvec* v = gvec_new(g, nbits, nblocks);
@@ -440,11 +440,11 @@ int bmx_gvec_upload(bmx_group* g, uint64_t nbits, uint32_t nblocks, const uint8_
     if (rc) { std::string keep = bmx_last_error(); bmx_gvec_free(g, v); bmx_set_last_error(keep.c_str()); return rc; }
     *out = v;
     return BMX_OK;
-}
+ABI_END }
 
 int bmx_gvec_generate(bmx_group* g, uint64_t seed, uint32_t vec_id, int with_common, uint32_t density_q16,
                       uint64_t nbits, int optimize, bmx_gvec** out)
-{
+{ ABI_TRY
     ARGCHK(g && out);
     *out = nullptr;
     uint64_t nblocks64 = (nbits + BMX_BLOCK_BITS - 1) / BMX_BLOCK_BITS;
@@ -459,11 +459,11 @@ int bmx_gvec_generate(bmx_group* g, uint64_t seed, uint32_t vec_id, int with_com
     if (rc) { std::string keep = bmx_last_error(); bmx_gvec_free(g, v); bmx_set_last_error(keep.c_str()); return rc; }
     *out = v;
     return BMX_OK;
-}
+ABI_END }
 
 int bmx_gvec_info(const bmx_gvec* v, uint64_t* nbits, uint32_t* nblocks, uint32_t counts[4],
                   uint32_t* bit_slab_blocks, uint64_t* gap_words)
-{
+{ ABI_TRY
     ARGCHK(v);
     uint32_t c[4] = {0, 0, 0, 0}; uint32_t slab = 0; uint64_t gw = 0;
     for (bmx_vec* s : v->shard) {
@@ -478,18 +478,18 @@ int bmx_gvec_info(const bmx_gvec* v, uint64_t* nbits, uint32_t* nblocks, uint32_
     if (bit_slab_blocks) *bit_slab_blocks = slab;
     if (gap_words) *gap_words = gw;
     return BMX_OK;
-}
+ABI_END }
 
 int bmx_gvec_shard(const bmx_gvec* v, int member, const bmx_vec** shard)
-{
+{ ABI_TRY
     ARGCHK(v && shard);
     if (member < 0 || member >= (int)v->shard.size()) { bmx_set_last_error("member index out of range"); return BMX_ERR_RANGE; }
     *shard = v->shard[(size_t)member];
     return BMX_OK;
-}
+ABI_END }
 
 int bmx_gvec_download(bmx_group* g, const bmx_gvec* v, uint8_t* kinds, uint32_t* offs, uint32_t* bit_slab, uint16_t* gap_slab)
-{
+{ ABI_TRY
     ARGCHK(g && v && v->g == g);
     uint32_t bbase = 0; uint64_t gbase = 0;
     for (int m = 0; m < g->n; ++m) {
@@ -514,10 +514,10 @@ int bmx_gvec_download(bmx_group* g, const bmx_gvec* v, uint8_t* kinds, uint32_t*
         bbase += sb; gbase += sg;
     }
     return BMX_OK;
-}
+ABI_END }
 
 int bmx_gvec_count(bmx_group* g, const bmx_gvec* a, uint64_t* count)
-{
+{ ABI_TRY
     ARGCHK(g && a && count && a->g == g);
     for (int m = 0; m < g->n; ++m) { int rc = bmx_i_count_async(g->ctx[(size_t)m], a->shard[(size_t)m], 0); if (rc) { (void)sync_all(g); return rc; } }
     int rc = sync_all(g); if (rc) return rc;
@@ -525,10 +525,10 @@ int bmx_gvec_count(bmx_group* g, const bmx_gvec* a, uint64_t* count)
     for (int m = 0; m < g->n; ++m) t += g->ctx[(size_t)m]->h_small[0];
     *count = t;
     return BMX_OK;
-}
+ABI_END }
 
 int bmx_gvec_count_op2(bmx_group* g, int op, const bmx_gvec* a, const bmx_gvec* b, uint64_t* count)
-{
+{ ABI_TRY
     ARGCHK(g && a && b && count && a->g == g && b->g == g);
     if (a->nblocks != b->nblocks || a->part != b->part) { bmx_set_last_error("sharded operands must cover the same block range (upload them with the same nblocks)"); return BMX_ERR_BADARG; }
     for (int m = 0; m < g->n; ++m) {
@@ -540,10 +540,10 @@ int bmx_gvec_count_op2(bmx_group* g, int op, const bmx_gvec* a, const bmx_gvec* 
     for (int m = 0; m < g->n; ++m) t += g->ctx[(size_t)m]->h_small[0];
     *count = t;
     return BMX_OK;
-}
+ABI_END }
 
 int bmx_gvec_op2(bmx_group* g, int op, const bmx_gvec* a, const bmx_gvec* b, int opt_compress, bmx_gvec** result)
-{
+{ ABI_TRY
     ARGCHK(g && a && b && result && a->g == g && b->g == g);
     *result = nullptr;
     if (a->nblocks != b->nblocks || a->part != b->part) { bmx_set_last_error("sharded operands must cover the same block range (upload them with the same nblocks)"); return BMX_ERR_BADARG; }
@@ -555,22 +555,22 @@ int bmx_gvec_op2(bmx_group* g, int op, const bmx_gvec* a, const bmx_gvec* b, int
     if (rc) { std::string keep = bmx_last_error(); bmx_gvec_free(g, v); bmx_set_last_error(keep.c_str()); return rc; }
     *result = v;
     return BMX_OK;
-}
+ABI_END }
 
 // ---- rank / select over a sharded vector (per-shard index, one exchange of the shard totals,
 // queries routed to the shard that owns the block) ----
 int bmx_grs_free(bmx_group* g, bmx_grs* rs)
-{
+{ ABI_TRY
     if (!rs) return BMX_OK;
     ARGCHK(g && rs->g == g);
     int rc = BMX_OK;
     for (int m = 0; m < g->n; ++m) { int r = bmx_rs_free(g->ctx[(size_t)m], rs->rs[(size_t)m]); if (r && !rc) rc = r; }
     delete rs;
     return rc;
-}
+ABI_END }
 
 int bmx_grs_build(bmx_group* g, const bmx_gvec* v, bmx_grs** out)
-{
+{ ABI_TRY
     ARGCHK(g && v && out && v->g == g);
     *out = nullptr;
     bmx_grs* rs = new (std::nothrow) bmx_grs();
@@ -587,19 +587,19 @@ int bmx_grs_build(bmx_group* g, const bmx_gvec* v, bmx_grs** out)
     if (rc) { std::string keep = bmx_last_error(); bmx_grs_free(g, rs); bmx_set_last_error(keep.c_str()); return rc; }
     *out = rs;
     return BMX_OK;
-}
+ABI_END }
 
 int bmx_grs_count(const bmx_grs* rs, uint64_t* count)
-{
+{ ABI_TRY
     ARGCHK(rs && count);
     *count = rs->before.back();
     return BMX_OK;
-}
+ABI_END }
 
 // queries are split by owner on the host, every member answers its share (one batch call per member, in parallel),
 // answers are put back in query order
 int bmx_grank_batch(bmx_group* g, const bmx_gvec* v, const bmx_grs* rs, const uint64_t* n, size_t q, uint64_t* out)
-{
+{ ABI_TRY
     ARGCHK(g && v && rs && v->g == g && rs->g == g && rs->v == v && (q == 0 || (n && out)));
     std::vector<uint32_t> lo((size_t)g->n + 1, 0);
     for (int m = 0; m < g->n; ++m) { uint32_t a, b; shard_of(v, m, &a, &b); lo[(size_t)m] = a; lo[(size_t)m + 1] = b; }
@@ -622,11 +622,11 @@ int bmx_grank_batch(bmx_group* g, const bmx_gvec* v, const bmx_grs* rs, const ui
     for (int m = 0; m < g->n; ++m)
         for (size_t k = 0; k < at[(size_t)m].size(); ++k) out[at[(size_t)m][k]] = rs->before[(size_t)m] + ans[(size_t)m][k];
     return BMX_OK;
-}
+ABI_END }
 
 int bmx_gselect_batch(bmx_group* g, const bmx_gvec* v, const bmx_grs* rs, const uint64_t* rank, size_t q,
                       uint64_t* pos, uint8_t* found)
-{
+{ ABI_TRY
     ARGCHK(g && v && rs && v->g == g && rs->g == g && rs->v == v && (q == 0 || (rank && pos && found)));
     std::vector<uint32_t> lo((size_t)g->n, 0);
     for (int m = 0; m < g->n; ++m) { uint32_t a, b; shard_of(v, m, &a, &b); lo[(size_t)m] = a; }
@@ -657,7 +657,7 @@ int bmx_gselect_batch(bmx_group* g, const bmx_gvec* v, const bmx_grs* rs, const 
             pos[i] = found[i] ? ans[(size_t)m][k] + (uint64_t)lo[(size_t)m] * BMX_BLOCK_BITS : 0;
         }
     return BMX_OK;
-}
+ABI_END }
 
 static int same_range(bmx_group* g, const bmx_gvec* const* src, size_t n, uint32_t* nblocks, uint64_t* nbits)
 {
@@ -673,7 +673,7 @@ static int same_range(bmx_group* g, const bmx_gvec* const* src, size_t n, uint32
 // bmx_collection_prepare over shards: every member transposes ITS block range of the vectors (the collection of member m
 // serves the aggregations member m runs: bmx_gagg_or / bmx_gagg_and_sub / bmx_gpipeline_* dispatch per member context)
 int bmx_gcollection_prepare(bmx_group* g, const bmx_gvec* const* vecs, size_t n, int role)
-{
+{ ABI_TRY
     ARGCHK(g && vecs && n >= 1);
     uint32_t nblocks = 0xFFFFFFFFu; uint64_t nbits = 0;
     int rc = same_range(g, vecs, n, &nblocks, &nbits); if (rc) return rc;
@@ -686,10 +686,10 @@ int bmx_gcollection_prepare(bmx_group* g, const bmx_gvec* const* vecs, size_t n,
         if (!any_gap) return BMX_OK;
         return bmx_collection_prepare(g->ctx[(size_t)m], h.data(), n, role);
     });
-}
+ABI_END }
 
 int bmx_gagg_or(bmx_group* g, const bmx_gvec* const* src, size_t n, int opt_compress, bmx_gvec** result)
-{
+{ ABI_TRY
     ARGCHK(g && result && (n == 0 || src));
     *result = nullptr;
     uint32_t nblocks = 0xFFFFFFFFu; uint64_t nbits = 0;
@@ -705,11 +705,11 @@ int bmx_gagg_or(bmx_group* g, const bmx_gvec* const* src, size_t n, int opt_comp
     if (rc) { std::string keep = bmx_last_error(); bmx_gvec_free(g, v); bmx_set_last_error(keep.c_str()); return rc; }
     *result = v;
     return BMX_OK;
-}
+ABI_END }
 
 int bmx_gagg_and_sub(bmx_group* g, const bmx_gvec* const* src_and, size_t n_and,
                      const bmx_gvec* const* src_sub, size_t n_sub, bmx_gvec** result, int* any)
-{
+{ ABI_TRY
     ARGCHK(g && result && (n_and == 0 || src_and) && (n_sub == 0 || src_sub));
     *result = nullptr;
     if (any) *any = 0;
@@ -730,13 +730,13 @@ int bmx_gagg_and_sub(bmx_group* g, const bmx_gvec* const* src_and, size_t n_and,
     if (any) for (int m = 0; m < g->n; ++m) *any |= many[(size_t)m];
     *result = v;
     return BMX_OK;
-}
+ABI_END }
 
 // aggregator::find_first_and_sub over sharded vectors (src/bmaggregator.h:1458): every member searches its own shard
 // (ascending launch windows inside), the answer is the hit of the LOWEST member that found one
 int bmx_gfind_first_and_sub(bmx_group* g, const bmx_gvec* const* src_and, size_t n_and,
                             const bmx_gvec* const* src_sub, size_t n_sub, int* found, uint64_t* idx)
-{
+{ ABI_TRY
     ARGCHK(g && found && idx && (n_and == 0 || src_and) && (n_sub == 0 || src_sub));
     *found = 0; *idx = 0;
     if (!n_and) return BMX_OK;
@@ -759,14 +759,14 @@ int bmx_gfind_first_and_sub(bmx_group* g, const bmx_gvec* const* src_and, size_t
             break;
         }
     return BMX_OK;
-}
+ABI_END }
 
 // sparse_vector_scanner range search over SHARDED bit-planes (bmx_slice_compare per member over its rows): the planes
 // (and the not-NULL vector) must cover the same block range and `size` must end in its last block; the result is sharded
 // like the planes, the count is the sum over the members
 int bmx_gslice_compare(bmx_group* g, const bmx_gvec* const* slices, size_t nslices, int pred, uint64_t v0, uint64_t v1,
                        uint64_t size, const bmx_gvec* not_null, bmx_gvec** result, uint64_t* count)
-{
+{ ABI_TRY
     ARGCHK(g && (nslices == 0 || slices) && nslices <= 64 && (result || count));
     if (result) *result = nullptr;
     if (count) *count = 0;
@@ -798,12 +798,12 @@ int bmx_gslice_compare(bmx_group* g, const bmx_gvec* const* slices, size_t nslic
     if (count) for (int m = 0; m < g->n; ++m) *count += cnt[(size_t)m];
     if (result) *result = v;
     return BMX_OK;
-}
+ABI_END }
 
 // bmx_slice_eq_counts over sharded bit-planes: every member counts over its own rows, the counts are summed
 int bmx_gslice_eq_counts(bmx_group* g, const bmx_gvec* const* slices, size_t nslices, const uint64_t* values, size_t n,
                          uint64_t size, const bmx_gvec* not_null, uint64_t* counts)
-{
+{ ABI_TRY
     ARGCHK(g && (nslices == 0 || slices) && (n == 0 || (values && counts)));
     uint32_t nblocks = 0xFFFFFFFFu;
     for (size_t i = 0; i < nslices; ++i) {
@@ -830,10 +830,10 @@ int bmx_gslice_eq_counts(bmx_group* g, const bmx_gvec* const* slices, size_t nsl
     if (rc) return rc;
     for (int m = 0; m < g->n; ++m) for (size_t q = 0; q < n; ++q) counts[q] += part[(size_t)m][q];
     return BMX_OK;
-}
+ABI_END }
 
 int bmx_gpipeline_destroy(bmx_group* g, bmx_gpipeline* p)
-{
+{ ABI_TRY
     if (!p) return BMX_OK;
     ARGCHK(g && p->g == g);
     for (int m = 0; m < g->n; ++m) {
@@ -849,11 +849,11 @@ int bmx_gpipeline_destroy(bmx_group* g, bmx_gpipeline* p)
     if (p->h_counts) (void)hipHostFree(p->h_counts);
     delete p;
     return BMX_OK;
-}
+ABI_END }
 
 int bmx_gpipeline_create(bmx_group* g, const bmx_gvec* const* and_list, const uint32_t* and_n,
                          const bmx_gvec* const* sub_list, const uint32_t* sub_n, size_t ngroups, bmx_gpipeline** out)
-{
+{ ABI_TRY
     ARGCHK(g && out && ngroups > 0 && ngroups < (1u << 20) && and_n && sub_n);
     *out = nullptr;
     size_t tot_and = 0, tot_sub = 0;
@@ -890,7 +890,7 @@ int bmx_gpipeline_create(bmx_group* g, const bmx_gvec* const* and_list, const ui
     if (rc) { std::string keep = bmx_last_error(); bmx_gpipeline_destroy(g, p); bmx_set_last_error(keep.c_str()); return rc; }
     *out = p;
     return BMX_OK;
-}
+ABI_END }
 
 // everything of one run that is enqueued: kernels on every member first, then the exchange.  A failure in the middle
 // must not leave the other members' work in flight when the caller sees the error: the wrapper below drains every
@@ -945,7 +945,7 @@ static int gpipeline_enqueue(bmx_group* g, bmx_gpipeline* p, bool rccl)
 // full shard count (then the sum is the true count) -- sum >= min(limit, true count) and <= true count, the reference's
 // contract ("can find more, cannot find less"), with no exchange between the windows.
 int bmx_gpipeline_set_search_count_limit(bmx_group* g, bmx_gpipeline* p, uint64_t limit)
-{
+{ ABI_TRY
     ARGCHK(g && p && p->g == g);
     for (int m = 0; m < g->n; ++m) {
         int rc = bmx_pipeline_set_search_count_limit(g->ctx[(size_t)m], p->pipe[(size_t)m], limit);
@@ -953,10 +953,10 @@ int bmx_gpipeline_set_search_count_limit(bmx_group* g, bmx_gpipeline* p, uint64_
     }
     p->search_limit = limit == 0 ? ~0ull : limit;
     return BMX_OK;
-}
+ABI_END }
 
 int bmx_gpipeline_run_counts(bmx_group* g, bmx_gpipeline* p, uint64_t* counts_out)
-{
+{ ABI_TRY
     ARGCHK(g && p && p->g == g && counts_out);
     const size_t ng = p->ngroups;
     if (p->search_limit != ~0ull) {
@@ -988,36 +988,36 @@ int bmx_gpipeline_run_counts(bmx_group* g, bmx_gpipeline* p, uint64_t* counts_ou
         p->last_ms[(size_t)m] = ms; p->last_xchg_ms[(size_t)m] = xs;
     }
     return BMX_OK;
-}
+ABI_END }
 
 int bmx_gpipeline_last_ms(bmx_group* g, const bmx_gpipeline* p, float* ms)
-{
+{ ABI_TRY
     ARGCHK(g && p && p->g == g && ms);
     for (int m = 0; m < g->n; ++m) ms[m] = p->last_ms[(size_t)m];
     return BMX_OK;
-}
+ABI_END }
 
 int bmx_gpipeline_last_exchange_ms(bmx_group* g, const bmx_gpipeline* p, float* ms)
-{
+{ ABI_TRY
     ARGCHK(g && p && p->g == g && ms);
     for (int m = 0; m < g->n; ++m) ms[m] = p->last_xchg_ms[(size_t)m];
     return BMX_OK;
-}
+ABI_END }
 
 int bmx_gpipeline_operand_bytes(bmx_group* g, bmx_gpipeline* p, uint64_t* bytes_per_member)
-{
+{ ABI_TRY
     ARGCHK(g && p && p->g == g && bytes_per_member);
     for (int m = 0; m < g->n; ++m) {
         int rc = bmx_pipeline_operand_bytes(g->ctx[(size_t)m], p->pipe[(size_t)m], 0u, 0xFFFFFFFFu, &bytes_per_member[m]);
         if (rc) return rc;
     }
     return BMX_OK;
-}
+ABI_END }
 
 int bmx_gpipeline_describe(bmx_group* g, bmx_gpipeline* p, int member, char* buf, size_t buf_len, uint32_t* n_launches)
-{
+{ ABI_TRY
     ARGCHK(g && p && p->g == g && member >= 0 && member < g->n);
     return bmx_pipeline_describe(g->ctx[(size_t)member], p->pipe[(size_t)member], 0u, 0xFFFFFFFFu, buf, buf_len, n_launches);
-}
+ABI_END }
 
 } // extern "C"

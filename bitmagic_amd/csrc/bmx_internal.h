@@ -22,6 +22,13 @@ void bmx_set_last_error(const char* msg);
 #define HIPCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return bmx_fail_hip(e_, #call, __FILE__, __LINE__); } while (0)
 #define ARGCHK(cond) do { if (!(cond)) { bmx_set_last_error("bad argument: " #cond); return BMX_ERR_BADARG; } } while (0)
 #define KCHK() HIPCHK(hipGetLastError())
+// the exception barrier around every extern "C" body: { ABI_TRY ... ABI_END }  (bmx.hip: bmx_abi_caught)
+#include <new>
+#include <stdexcept>
+int bmx_abi_caught(int kind, const char* what);
+void bmx_abi_enter();
+#define ABI_TRY try { bmx_abi_enter();
+#define ABI_END } catch (const std::bad_alloc&) { return bmx_abi_caught(0, nullptr); } catch (const std::exception& e_) { return bmx_abi_caught(1, e_.what()); } catch (...) { return bmx_abi_caught(2, nullptr); }
 
 struct bmx_ctx {
     int device = 0;
@@ -47,6 +54,15 @@ struct bmx_ctx {
     std::multimap<size_t, void*> pool_free;
     std::unordered_map<void*, size_t> pool_live;
     uint64_t pool_cached = 0, pool_cap = 16ull << 30;
+    // debug: red zones (BMX_DEBUG_REDZONE=1 when the context is created).  Every device allocation of the library -- pooled
+    // blocks (dmalloc: vectors' slabs, results, indexes, collections, tables) and the grow-only scratch / aux buffers -- gets
+    // RZ_BYTES of a canary pattern in front of it and from the end of the REQUESTED bytes (rounded to 16) to the end of the
+    // block behind it; verified when the block is freed, at bmx_ctx_synchronize, bmx_debug_redzone_check and context destroy.
+    struct RzInfo { void* raw; size_t block; size_t bytes; int line; };
+    bool redzone = false;
+    std::unordered_map<void*, RzInfo> rz_live;               // user pointer -> what lies around it
+    uint64_t rz_hits = 0; std::string rz_report;             // allocations found damaged so far, and where they came from
+    long long fail_dmalloc_after = -1;                        // debug fault injection: the allocation this many dmallocs from now fails (bmx_debug_inject_failure kind 4)
     int pipe_unroll = 0;       // operand slices per batch (two batches in flight); 0 = the measured best for the slice size
     int pipe_rows = 0;         // register rows (KiB of a block) per work item: 8 = whole block, 4/2/1 = slices, 0 = auto by item count
     int pipe_nt = 1;           // non-temporal operand loads (+4.5 % on the streamed-once headline case)

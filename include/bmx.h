@@ -485,6 +485,20 @@ int bmx_gpipeline_last_exchange_ms(bmx_group* g, const bmx_gpipeline* p, float* 
 int bmx_gpipeline_operand_bytes(bmx_group* g, bmx_gpipeline* p, uint64_t* bytes_per_member);
 int bmx_gpipeline_describe(bmx_group* g, bmx_gpipeline* p, int member, char* buf, size_t buf_len, uint32_t* n_launches);
 
+/* ---- debug aids (no reference twin) ----
+ * Red zones: a context created while BMX_DEBUG_REDZONE=1 is set surrounds every device allocation of the library (slabs, results,
+ * indexes, collections, tables, scratch) with 4 KiB of a canary pattern -- in front, and from the end of the requested bytes to
+ * the end of the block -- and verifies them when the block is freed, at bmx_ctx_synchronize (which then returns BMX_ERR_DEVICE
+ * with the report as bmx_last_error), here, and when the context is destroyed.  hits = damaged allocations found so far;
+ * report = one line per damaged allocation naming the line of bmx.hip that made it. */
+int bmx_debug_redzone_check(bmx_ctx* ctx, int* enabled, uint64_t* hits, char* report, size_t report_len);
+/* Fault injection for tests of the error paths.  kind 1 | 2 | 3: the library entry `after` calls from now on this thread throws
+ * std::bad_alloc | std::length_error | a non-standard exception at its first statement -- what must come back is a status
+ * (BMX_ERR_BADALLOC | BMX_ERR_DEVICE | BMX_ERR_DEVICE), never an exception (libbm.cpp:28-35); ctx may be NULL.  kind 4: the
+ * device allocation `after` allocations from now on ctx fails with BMX_ERR_BADALLOC.  kind 5 (red-zone contexts): writes one byte
+ * behind a fresh allocation -- the checker's self-test.  kind 0: disarm. */
+int bmx_debug_inject_failure(bmx_ctx* ctx, int kind, long long after);
+
 /* ---- timing helper: HIP events on the context's stream ---- */
 int bmx_timer_start(bmx_ctx* ctx);
 int bmx_timer_stop_ms(bmx_ctx* ctx, float* ms);   /* synchronises on the stop event */

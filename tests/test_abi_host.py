@@ -164,3 +164,43 @@ def test_no_kernel_of_the_default_build_touches_scratch():
     # (SGPR spills go to VGPR lanes, not to memory: they are not scratch)
     bad = {k: v for k, v in ks.items() if v["scratch"] or v["vgpr_spill"]}
     assert not bad, bad
+
+
+def test_no_exception_crosses_the_abi():
+    """lang-maps/libbm/src/libbm.cpp:28-35: every body of the reference's C wrapper is a try / catch that turns std::bad_alloc into
+    BM_ERR_BADALLOC -- a C caller never sees a C++ exception.  Every extern "C" body of libbmx.so sits in the same barrier
+    (ABI_TRY / ABI_END); bmx_debug_inject_failure makes the next entry throw at its first statement: what comes back must be a
+    status, and the library must work afterwards.  (No GPU needed: the throw precedes any device call.)"""
+    from bitmagic_amd import _ffi
+    L = _ffi.lib()
+    null = C.c_void_p()
+    out = C.c_void_p()
+    def upload():                                       # a call that is BADARG on any machine (null context)
+        return L.bmx_vec_upload(null, 0, 0, None, None, None, 0, None, 0, C.byref(out))
+    assert upload() == _ffi.ERR_BADARG
+    for kind, status, text in ((1, _ffi.ERR_BADALLOC, b"bad_alloc"), (2, _ffi.ERR_DEVICE, b"length_error"), (3, _ffi.ERR_DEVICE, b"not a std::exception")):
+        assert L.bmx_debug_inject_failure(null, kind, 0) == 0
+        assert upload() == status and text in L.bmx_last_error(), (kind, L.bmx_last_error())
+        assert upload() == _ffi.ERR_BADARG              # one shot: the library goes on
+    # `after` counts entries: two calls pass, the third throws -- through another entry point (the group layer's barrier)
+    assert L.bmx_debug_inject_failure(null, 1, 2) == 0
+    assert upload() == _ffi.ERR_BADARG and upload() == _ffi.ERR_BADARG
+    n = C.c_int32()
+    assert L.bmx_group_size(null, C.byref(n)) == _ffi.ERR_BADALLOC
+    assert L.bmx_group_size(null, C.byref(n)) == _ffi.ERR_BADARG
+    # disarm
+    assert L.bmx_debug_inject_failure(null, 1, 5) == 0 and L.bmx_debug_inject_failure(null, 0, 0) == 0
+    for _ in range(8): assert upload() == _ffi.ERR_BADARG
+
+
+def test_every_abi_body_sits_in_the_barrier():
+    """each `int bmx_*` that include/bmx.h declares is defined with ABI_TRY ... ABI_END in bmx.hip / bmx_group.hip"""
+    hdr = open(os.path.join(ROOT, "include", "bmx.h")).read()
+    names = set(re.findall(r"^int\s+(bmx_\w+)\s*\(", hdr, re.M))
+    src = "".join(open(os.path.join(ROOT, "bitmagic_amd", "csrc", f)).read() for f in ("bmx.hip", "bmx_group.hip"))
+    missing = []
+    for n in sorted(names):
+        m = re.search(r"^int\s+%s\s*\([^{;]*\)\s*\{([^\n]*)" % n, src, re.M | re.S)
+        assert m, n
+        if "ABI_TRY" not in m.group(1) and n != "bmx_simd_version": missing.append(n)
+    assert not missing, missing

@@ -328,3 +328,106 @@ def test_randomized_soak_slices():
         r = subprocess.run([sys.executable, os.path.join(root, "tools", script), rounds], capture_output=True, text=True, timeout=900, cwd=root)
         tail = (r.stdout + r.stderr)[-2000:]
         assert r.returncode == 0 and "done, failures: 0" in r.stdout, (script, tail)
+
+
+_REDZONE_SCRIPT = r'''
+import json, os, sys
+sys.path.insert(0, os.getcwd())
+import numpy as np
+import bitmagic_amd as bm
+import __graft_entry__ as g
+g.smoke()                                            # pipeline counts, combine_and_sub, count_and, rs index + rank on a red-zone context
+ctx = bm.context(0)
+out = {"enabled": ctx.redzone_check()["enabled"]}
+nbits = 40 * 65536 - 77
+vs = [bm.bvector.generate(ctx, 99, i, dq, nbits) for i, dq in enumerate((6554, 655, 66, 30000, 200, 66, 66, 200))]
+agg = bm.aggregator(ctx)
+for op in ("bit_and", "bit_or", "bit_xor", "bit_sub"):
+    r = getattr(bm.bvector, op)(vs[0], vs[1]); r.count(); r2 = getattr(bm.bvector, op)(vs[2], vs[4], bm.opt_compress); r2.count()
+agg.combine_or(vs[2:]); agg.combine_and_sub(vs[4:6], [vs[6]])
+ctx.collection_prepare(vs[4:], 1); agg.combine_or(vs[4:])
+for v in (vs[0], vs[1], vs[2]):
+    rs = v.build_rs_index(); n = rs.count()
+    if n: v.select(np.arange(1, min(n, 5000) + 1, dtype=np.uint64), rs); v.rank(np.arange(0, nbits, 997, dtype=np.uint64), rs)
+ctx.synchronize()
+out["hits_after_workload"] = ctx.redzone_check()["hits"]
+ctx.inject_failure(5, 0)                             # one byte written right behind a 1000-byte allocation
+rep = ctx.redzone_check()
+out["hits_after_self_test"] = rep["hits"]; out["report"] = rep["report"]
+ctx.inject_failure(5, 7)                             # ... and behind a 1007-byte one: the zone starts at the next multiple of 16
+out["hits_after_second"] = ctx.redzone_check()["hits"]
+try:
+    ctx.synchronize(); out["sync_after"] = "ok"
+except bm.BmxError as e:
+    out["sync_after"] = "error %d" % e.status
+print("REDZONE " + json.dumps(out))
+'''
+
+
+def test_red_zone_allocator_catches_overruns_and_the_suite_is_clean():
+    """VERDICT r5 #3: a context created under BMX_DEBUG_REDZONE=1 surrounds every device allocation with canaries (in front, and
+    from the end of the REQUESTED bytes to the end of the block) and verifies them at free / synchronize / destroy.  Here: the
+    smoke workload + pairwise ops, aggregations, a collection, rs indexes (rank lines, select lines) run clean; a deliberate
+    one-byte overrun IS caught and names the allocation; a slice of both soaks runs clean under the checker.  (The whole -m gpu
+    suite + both soaks under the checker: profiles/r06_redzone/.)"""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BMX_DEBUG_REDZONE="1")
+    r = subprocess.run([sys.executable, "-c", _REDZONE_SCRIPT], capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    line = [l for l in r.stdout.splitlines() if l.startswith("REDZONE ")]
+    assert r.returncode == 0 and line, (r.stdout + r.stderr)[-3000:]
+    out = json.loads(line[0][8:])
+    assert out["enabled"] and out["hits_after_workload"] == 0, out
+    assert out["hits_after_self_test"] == 1 and out["hits_after_second"] == 2, out
+    assert "BEHIND" in out["report"] and "1000 bytes" in out["report"] and "bmx.hip:" in out["report"], out
+    assert out["sync_after"] == "ok"                   # (a damage is reported once: the zones were repainted)
+    assert r.stderr.count("[bmx redzone] allocation") == 2, r.stderr[-2000:]
+    for script, rounds in (("soak_r04.py", "2"), ("soak_r05.py", "6")):
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", script), rounds], capture_output=True, text=True, timeout=900, cwd=root, env=env)
+        assert r.returncode == 0 and "done, failures: 0" in r.stdout and "[bmx redzone]" not in r.stderr, (script, (r.stdout + r.stderr)[-2000:])
+
+
+def test_device_allocation_failures_come_back_as_status(port):
+    """fault injection (bmx_debug_inject_failure kind 4): the k-th device allocation of a call fails.  Whatever k, the call
+    returns BMX_ERR_BADALLOC (or succeeds, if it allocates fewer than k + 1 times) -- never a crash, never a wrong answer -- the
+    context keeps working, and what the failed call had allocated is given back."""
+    c = bm.context(0)
+    nbits = 30 * 65536 - 5
+    vs = [bm.bvector.generate(c, 5, i, dq, nbits) for i, dq in enumerate((6554, 655, 66, 66, 200, 66))]
+    pv = [port.import_words(port.gen_words(5, i, dq, nbits), True, nbits) for i, dq in enumerate((6554, 655, 66, 66, 200, 66))]
+    agg = bm.aggregator(c)
+    exp_and = port.count_op2(0, pv[0], pv[1])
+    exp_or = port.agg_or(pv[2:]).count()
+    def pairwise(): return bm.bvector.bit_and(vs[0], vs[1]).count() == exp_and
+    def combine_or(): return agg.combine_or(vs[2:]).count() == exp_or
+    def rs_index():
+        rs = vs[0].build_rs_index()
+        return rs.count() == pv[0].count() and (vs[0].select(np.array([1, 77], np.uint64), rs)[1] == port.rs_build(pv[0]).select(np.array([1, 77], np.uint64))[0]).all()
+    def prepare(): c.collection_prepare(vs[2:], 1); return agg.combine_or(vs[2:]).count() == exp_or
+    def pipeline():
+        pipe = bm.aggregator.pipeline(c)
+        ag = pipe.add(); ag.add(vs[0], 0); ag.add(vs[1], 0); ag.add(vs[4], 1)
+        pipe.complete()
+        return int(agg.combine_and_sub(pipe)[0]) == int(port.pipeline_counts([([pv[0], pv[1]], [pv[4]])])[0])
+    for name, fn in (("pairwise", pairwise), ("combine_or", combine_or), ("rs_index", rs_index), ("prepare", prepare), ("pipeline", pipeline)):
+        assert fn(), name                                 # warm: pooled blocks, scratch sized
+        c.synchronize(); c.trim()
+        base = c.mem_used()
+        failed = 0
+        for k in range(0, 40):
+            c.inject_failure(4, k)
+            try:
+                ok = fn()
+                assert ok, (name, k)
+            except bm.BmxError as e:
+                assert e.status == 1, (name, k, str(e))
+                failed += 1
+            finally:
+                c.inject_failure(0, 0)
+            c.synchronize()
+        assert fn(), name
+        c.synchronize()
+        assert failed >= 1, name                          # (every one of these calls allocates at least once)
+        leaked = c.mem_used() - base
+        assert leaked <= (2 << 20), (name, leaked)        # (pool rounding of a fresh result may differ; a lost slab would be MBs per failure)
+    c.close()
