@@ -32,60 +32,86 @@ template <typename T> struct SelFmt;
 template <> struct SelFmt<u16> { static constexpr u32 K = 60u, UNIT = 16u; };
 template <> struct SelFmt<u32> { static constexpr u32 K = 30u, UNIT = 32u; };
 
+// Build: one wave per block (any kind).  The ones of a row of the block (256 words) get their global numbers from the wave's
+// popcount prefix; their low bits are staged in LDS in that order (the 8 KiB the GAP decoder used), and the wave writes the
+// staged run out front to back -- 16-bit offsets in aligned pairs: 256 contiguous bytes per store instruction instead of 64
+// two-byte stores strewn over a dozen lines (the first form of this kernel: 1.3 ms for configs[3], now the write of 853 MB
+// and the read of 500 MB at stream speed).  A line's base is written by whoever holds its slot 0.
 template <typename T>
-__device__ __forceinline__ void sel_put(u8* __restrict__ sel, u64& line, u32& slot, u64 pos)
+__device__ __forceinline__ void sel_stage_word(u32 w, u32 lowbase, u32& idx, u32 cb, T* __restrict__ stage, u32 cap)
 {
-    u8* L = sel + line * SL_BYTES;
-    reinterpret_cast<T*>(L + 8)[slot] = (T)pos;
-    if (slot == 0u) *reinterpret_cast<u64*>(L) = pos;
-    if (++slot == SelFmt<T>::K) { slot = 0u; ++line; }
+    while (w) {
+        const u32 b = (u32)__builtin_ctz(w);
+        const u32 at = idx - cb;
+        if (at < cap) stage[at] = (T)(lowbase + b);
+        ++idx; w &= w - 1u;
+    }
 }
 
-template <typename T>
-__device__ __forceinline__ void sel_emit_word(u32 w, u64 bitpos, u8* __restrict__ sel, u64& line, u32& slot)
-{
-    while (w) { const u32 b = (u32)__builtin_ctz(w); sel_put<T>(sel, line, slot, bitpos + b); w &= w - 1u; }
-}
-
-// one wave per block (any kind); rcount = inclusive running count per block
+// rcount = inclusive running count per block
 template <typename T>
 __global__ __launch_bounds__(256)
 void k_rs_sel_build(const u64* __restrict__ desc, u32 nblocks, const u64* __restrict__ rcount, u8* __restrict__ sel)
 {
     constexpr u32 K = SelFmt<T>::K;
+    constexpr u32 CAP = 8192u / (u32)sizeof(T);                           // staged ones per pass
     __shared__ u32 lds[4 * 2048];
     const u32 lane = lane_id(), wave = threadIdx.x >> 6;
     const u32 nb = uniform32(blockIdx.x * 4u + wave);
     if (nb >= nblocks) return;
     const u64 d = uniform64(desc[nb]);
-    const u32 k = DESC_K(d);
-    if (k == K_NULL) return;
+    if (DESC_K(d) == K_NULL) return;
     const u64 first = nb ? rcount[nb - 1u] : 0ull;
     const u64 bit0 = (u64)nb << 16;
-    if (k == K_FULL) {
-        // lane l takes ones first + 1024 l .. + 1023: 17 consecutive lines' worth apiece
-        u64 g = first + (u64)lane * 1024u;
-        u64 line = g / K; u32 slot = (u32)(g - line * K);
-        for (u32 i = 0; i < 1024u; ++i) sel_put<T>(sel, line, slot, bit0 + lane * 1024u + i);
-        return;
-    }
+    const u64 hi = sizeof(T) == 2 ? bit0 : (bit0 & 0xFFFFFFFF00000000ull);     // pos = hi + the stored low bits
     Blk b;
     blk_from_desc(d, b, lds + wave * 2048u, lane);
+    T* stage = reinterpret_cast<T*>(lds + wave * 2048u);
     u64 row_off = first;
-#pragma unroll
+#pragma unroll 1
     for (int i = 0; i < 8; ++i) {
         // row i = words i*256 .. i*256+255; lane l holds the four consecutive words i*256 + 4l .. + 3
         const u32 c = (u32)__popc(b.r[i].x) + (u32)__popc(b.r[i].y) + (u32)__popc(b.r[i].z) + (u32)__popc(b.r[i].w);
         const u32 incl = wave_scan_incl(c, lane);
         const u32 tot = uniform32(__shfl(incl, 63, 64));
-        if (c) {
-            const u64 g = row_off + (incl - c);
-            u64 line = g / K; u32 slot = (u32)(g - line * K);
-            const u64 wb = bit0 + ((u64)((u32)i * 256u + lane * 4u) << 5);
-            sel_emit_word<T>(b.r[i].x, wb, sel, line, slot);
-            sel_emit_word<T>(b.r[i].y, wb + 32u, sel, line, slot);
-            sel_emit_word<T>(b.r[i].z, wb + 64u, sel, line, slot);
-            sel_emit_word<T>(b.r[i].w, wb + 96u, sel, line, slot);
+        const u32 lowbase = (u32)(bit0 + ((u64)((u32)i * 256u + lane * 4u) << 5));   // low 32 bits of the position of the lane's first bit
+        for (u32 cb = 0; cb < tot; cb += CAP) {
+            u32 idx = incl - c;
+            if (c && idx < cb + CAP && idx + c > cb) {
+                sel_stage_word<T>(b.r[i].x, lowbase, idx, cb, stage, CAP);
+                sel_stage_word<T>(b.r[i].y, lowbase + 32u, idx, cb, stage, CAP);
+                sel_stage_word<T>(b.r[i].z, lowbase + 64u, idx, cb, stage, CAP);
+                sel_stage_word<T>(b.r[i].w, lowbase + 96u, idx, cb, stage, CAP);
+            }
+            const u32 n = tot - cb < CAP ? tot - cb : CAP;
+            const u64 g0 = row_off + cb;
+            if constexpr (sizeof(T) == 2) {
+                const u32 e0 = (u32)(g0 & 1u);                            // slot parity = one-number parity (K is even)
+                auto single = [&](u32 e) {
+                    const u64 g = g0 + e; const u64 line = g / K; const u32 slot = (u32)(g - line * K);
+                    u8* L = sel + line * SL_BYTES;
+                    reinterpret_cast<u16*>(L + 8)[slot] = stage[e];
+                    if (slot == 0u) *reinterpret_cast<u64*>(L) = hi + stage[e];
+                };
+                if (e0 && lane == 0u) single(0u);
+                const u32 np = (n - e0) >> 1;
+                for (u32 p = lane; p < np; p += 64u) {
+                    const u32 e = e0 + 2u * p;
+                    const u64 g = g0 + e; const u64 line = g / K; const u32 slot = (u32)(g - line * K);
+                    u8* L = sel + line * SL_BYTES;
+                    const u32 lo = stage[e], hi16 = stage[e + 1u];
+                    *reinterpret_cast<u32*>(L + 8 + slot * 2u) = lo | (hi16 << 16);
+                    if (slot == 0u) *reinterpret_cast<u64*>(L) = hi + lo;
+                }
+                if (((n - e0) & 1u) && lane == 63u) single(n - 1u);
+            } else {
+                for (u32 e = lane; e < n; e += 64u) {
+                    const u64 g = g0 + e; const u64 line = g / K; const u32 slot = (u32)(g - line * K);
+                    u8* L = sel + line * SL_BYTES;
+                    reinterpret_cast<u32*>(L + 8)[slot] = stage[e];
+                    if (slot == 0u) *reinterpret_cast<u64*>(L) = hi + stage[e];
+                }
+            }
         }
         row_off += tot;
     }

@@ -430,7 +430,11 @@ def test_rank_line_memory_policy(ctx, port):
     assert idn["has_lines"] and not isp["has_lines"]
     dev_bytes = lambda v: v.info()["gap_words"] * 2 + v.info()["nblocks"] * 8 + v.info()["counts"][bm.BIT] * 8192
     assert isp["bytes"] <= 1.2 * dev_bytes(sparse) + 600 * 300                # O(nblocks): running counts + two 128-byte rows per block
-    assert idn["bytes"] <= 1.2 * dev_bytes(dense) + 600 * 300 + 16 * 600
+    assert idn["bytes"] - idn["select_lines_bytes"] <= 1.2 * dev_bytes(dense) + 600 * 300 + 16 * 600
+    # select lines (round 6, rs_select_sel -1): 128 bytes per 60 (16-bit offsets) / 30 (32-bit) ones, where that is <= 2 x the vector
+    # and its rank lines -- this 10 % vector takes the 16-bit form; the sparse one (13 ones per block: 60 of them span blocks) the 32-bit
+    assert idn["select_offset_bits"] == 16 and idn["select_lines_bytes"] == (rd.count() + 59) // 60 * 128 <= 2 * 2.1 * dev_bytes(dense)
+    assert isp["select_offset_bits"] == 32 and isp["select_lines_bytes"] == (rsp.count() + 29) // 30 * 128
     ps = port.import_words(port.gen_words(5, 2, 13, nbits), True, nbits)
     prs = port.rs_build(ps)
     rng = np.random.default_rng(3)

@@ -75,6 +75,52 @@ __global__ void k_pieces(const u64* __restrict__ bases, u32 nstreams, u32 npiece
     if (x == 0x12345679u) { lds[threadIdx.x] = x; sink[0] = lds[(threadIdx.x + 1) % blockDim.x]; }
 }
 
+// Round 6: would GAP slabs on a 4-byte grid pay?  A configs[4] block is 2 (27 + 1) = 56 B; on the 16-byte grid of the
+// slabs it occupies 64 B, so a tile's row (14 blocks) is 896 B of which 112 B are padding.  This kernel reads rows of P bytes
+// packed back to back (P = 784: no padding; P = 896: today's bytes) that start on an arbitrary 4-byte boundary (jitter: the real
+// blocks have random lengths), either as 16-byte chunks from the aligned-down start (mode 0: what a kernel would do, shifting by
+// the row's phase afterwards) or as unaligned 16-byte loads from the row's own start (mode 1).  Same walk as k_pieces otherwise.
+template <int DEPTH>
+__global__ void k_rows_var(const u64* __restrict__ bases, u32 nstreams, u32 npieces, u32 P, u32 mode, u32 jitter, u32 S, u32* __restrict__ sink)
+{
+    extern __shared__ u32 lds[];
+    const u32 lane = threadIdx.x & 63u, wave = (u32)__builtin_amdgcn_readfirstlane(threadIdx.x >> 6), W = blockDim.x >> 6;     // (uniform: the bases come by scalar loads)
+    u32 piece = blockIdx.x;
+    if (mode & 256u) {                                   // xcd_remap of the library: every XCD takes one contiguous slice of the rows
+        const u32 q = npieces >> 3, rem = npieces & 7u, x = piece & 7u, i = piece >> 3;
+        piece = x * q + (x < rem ? x : rem) + i;
+        mode &= 255u;
+    }
+    if (piece >= npieces) return;
+    u32x4 acc = (u32x4)(0u);
+    u32 s = wave;
+    for (; s + (DEPTH - 1) * W < nstreams; s += DEPTH * W) {
+        u32x4 v[DEPTH]; u64 bvs[DEPTH];
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) bvs[d] = bases[s + d * W];            // (all bases first: one wait, then DEPTH rows in flight)
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            const u64 bv = bvs[d];
+            const u64 b = (u64)(u32)__builtin_amdgcn_readfirstlane((u32)bv) | ((u64)(u32)__builtin_amdgcn_readfirstlane((u32)(bv >> 32)) << 32);
+            const u32 h = ((s + d * W) * 2654435761u) ^ (piece * 40503u);
+            // byte offset of the row inside the stream.  jitter 1: a 4-byte phase (0 .. 12); 2: a 16-byte phase (0 .. 112: today's rows start
+            // on any 16-byte boundary); 3: 2 + the row's length varies by -32 .. +32 bytes (blocks of 48 / 64 / 80 bytes)
+            const u64 start = (u64)piece * S + (jitter == 1u ? ((h >> 7) & 3u) * 4u : jitter >= 2u ? ((h >> 7) & 7u) * 16u : 0u);
+            const u32 Pv = jitter == 3u ? P + ((h >> 12) % 5u) * 16u - 32u : P;
+            const u64 first = mode == 0 ? (start & ~15ull) : start;
+            const u64 end = start + Pv;
+            const u64 a = first + lane * 16u;
+            v[d] = (u32x4)(0u);
+            if (jitter == 4u) v[d] = __builtin_nontemporal_load((gptr)(b + (a < end ? a : end - 16u)));
+            else if (a < end) v[d] = __builtin_nontemporal_load((gptr)(b + a));
+        }
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) acc ^= v[d];
+    }
+    u32 x = acc.x ^ acc.y ^ acc.z ^ acc.w;
+    if (x == 0x12345679u) { lds[threadIdx.x] = x; sink[0] = lds[(threadIdx.x + 1) % blockDim.x]; }
+}
+
 typedef void (*kfn)(const u64*, u32, u32, u32*);
 static kfn pick(int depth, int lpp, int work)
 {
@@ -104,6 +150,48 @@ int main(int argc, char** argv)
     hipEvent_t e0, e1; CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
     u32* sink; CHK(hipMalloc(&sink, 64));
     u64* d_bases; CHK(hipMalloc(&d_bases, (size_t)nstreams * 8));
+    if (argc > 6) {                                      // argv[6] = "rows": the round-6 question (see k_rows_var)
+        std::vector<void*> owned; std::vector<u64> bases(nstreams);
+        const u64 alloc_bytes = ((stream_bytes / 784u + 2u) * 1024u + (2u << 20)) / (2u << 20) * (2u << 20);     // (rows of up to 1 KiB)
+        for (u32 s = 0; s < nstreams; ++s) { void* p; CHK(hipMalloc(&p, alloc_bytes)); owned.push_back(p); bases[s] = (u64)(uintptr_t)p;
+            hipLaunchKernelGGL(k_fill_random, dim3(256), dim3(256), 0, st, (u64*)p, alloc_bytes / 8, (u64)(uintptr_t)p); }
+        CHK(hipMemcpy(d_bases, bases.data(), (size_t)nstreams * 8, hipMemcpyHostToDevice));
+        CHK(hipStreamSynchronize(st));
+        const u32 nrows = (u32)(stream_bytes / 784u);                             // rows of 14 blocks: the same number either way
+        struct V { u32 P, mode, jitter; const char* what; u32 S = 0, load = 0; };
+        const V vs[] = {{896, 0, 0, "16-byte grid, every row 896 B and line-aligned"}, {896, 0, 2, "16-byte grid (today): rows of 896 B starting on any 16-byte boundary"},
+                        {896, 0, 3, "16-byte grid (today): rows of 864 .. 928 B starting on any 16-byte boundary"},
+                        {784, 0, 1, "4-byte grid: rows of 784 B, chunks from the aligned-down start"},
+                        {784, 1, 1, "4-byte grid: rows of 784 B, unaligned 16-byte loads"}, {784, 0, 0, "rows of 784 B that happen to start 16-byte aligned"},
+                        {800, 0, 2, "blocks packed on a 4-byte grid inside a tile, tiles on the 16-byte grid: rows of 800 B on any 16-byte boundary"},
+                        {896, 0, 0, "stride 896, 1024 B loaded (all 64 lanes: the row and 128 B of the next)", 896, 1024}, {896, 0, 0, "stride 896, 880 B loaded (55 lanes)", 896, 880},
+                        {896, 0, 0, "stride 896, 912 B loaded (57 lanes)", 896, 912}, {896, 0, 0, "stride 960, 896 B loaded (56 lanes)", 960, 896}, {896, 0, 0, "stride 1024, 896 B loaded (56 lanes)", 1024, 896},
+                        {896, 0, 0, "stride 832, 896 B loaded (56 lanes, rows overlap)", 832, 896}, {896, 0, 4, "stride 896, 896 B loaded by 64 lanes (lanes past the row repeat its last chunk: what k_agg_or_rows does)", 896, 896},
+                        {896, 256, 0, "XCD-contiguous rows (xcd_remap): stride 896, 896 B loaded", 896, 896}, {896, 256, 3, "XCD-contiguous rows: stride 896, 864 .. 928 B loaded on any 16-byte boundary", 896, 896},
+                        {896, 256, 0, "XCD-contiguous rows: stride 1024, 896 B loaded", 1024, 896}, {896, 256, 0, "XCD-contiguous rows: stride 960, 896 B loaded", 960, 896},
+                        {832, 256, 0, "XCD-contiguous rows: stride 832, 832 B loaded (13 columns)", 832, 832}, {960, 256, 0, "XCD-contiguous rows: stride 960, 960 B loaded (15 columns)", 960, 960},
+                        {1024, 256, 0, "XCD-contiguous rows: stride 1024, 1024 B loaded (16 columns)", 1024, 1024}, {784, 256, 1, "XCD-contiguous rows: 4-byte grid, rows of 784 B", 784, 784},
+                        {640, 0, 0, "sweep"}, {704, 0, 0, "sweep"}, {768, 0, 0, "sweep"}, {832, 0, 0, "sweep"}, {960, 0, 0, "sweep"},
+                        {1024, 0, 0, "1-KiB pieces (the round-4 probe's shape)"}};
+        for (int depth : {4}) for (const V& v : vs) for (int rep2 = 0; rep2 < 2; ++rep2) {
+            auto k = depth == 4 ? k_rows_var<4> : k_rows_var<8>;
+            CHK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            float best = 1e9f;
+            for (int rep = 0; rep < 4; ++rep) {
+                CHK(hipEventRecord(e0, st));
+                hipLaunchKernelGGL(k, dim3(nrows), dim3(1024), 131072, st, (const u64*)d_bases, nstreams, nrows, v.load ? v.load : v.P, v.mode, v.jitter, v.S ? v.S : v.P, sink);
+                CHK(hipEventRecord(e1, st));
+                CHK(hipEventSynchronize(e1));
+                float ms; CHK(hipEventElapsedTime(&ms, e0, e1));
+                if (rep && ms < best) best = ms;
+            }
+            const double bytes = (double)nrows * v.P * nstreams;
+            printf("{\"rows\": %u, \"row_bytes\": %u, \"mode\": %u, \"jitter\": %u, \"depth\": %d, \"ms\": %.4f, \"GBps\": %.1f, \"what\": \"%s\"}\n", nrows, v.P, v.mode, v.jitter, depth, best, bytes / best / 1e6, v.what);
+            fflush(stdout);
+        }
+        for (void* p : owned) CHK(hipFree(p));
+        return 0;
+    }
     const char* allocs[3] = {"sep", "arena", "pow2"};
     for (int am = 0; am < 3; ++am) {
         std::vector<void*> owned; std::vector<u64> bases(nstreams);
