@@ -103,7 +103,7 @@ def _cpu_worker_main(argv):
     """`bench.py --cpu-worker <kind> ...`: one independent replica (SURVEY section 8d "secondary = one replica per
     core") over block columns [lo, hi) of the workload -- block ranges are independent, so per-range results add up
     exactly.  Builds its inputs, prints READY, waits for a line on stdin, works, prints one JSON line.
-      and  lo hi nvec dq nbits reps      the headline: counts-only 256-way AND
+      and  lo hi nvec dq nbits reps [c]  the headline: counts-only 256-way AND (c = 0: data set B, no common part)
       pair lo hi ida idb dq nbits reps   configs[1]: count_and/or/xor/sub of one pair
       rank lo hi id dq nbits             configs[3]: count of the range, then (second stdin line = JSON {"n": [...],
                                          "r": [...]} in range-local coordinates) rank / select answers
@@ -126,8 +126,9 @@ def _cpu_worker_main(argv):
         sys.stdout.write(json.dumps(obj) + "\n"); sys.stdout.flush()
 
     if kind == "and":
-        lo, hi, nvec, dq, nbits, reps = (int(x) for x in rest)
-        vecs = [build(v, dq, nbits, lo, hi, True) for v in range(nvec)]
+        lo, hi, nvec, dq, nbits, reps = (int(x) for x in rest[:6])
+        with_common = (int(rest[6]) != 0) if len(rest) > 6 else True         # 0: data set B (independent operands)
+        vecs = [build(v, dq, nbits, lo, hi, with_common) for v in range(nvec)]
         groups = [(vecs, [])]
         ready()
         spans, cnt = [], 0
@@ -204,7 +205,7 @@ def _go(procs):
         p.stdin.write("go\n"); p.stdin.flush()
 
 
-def cpu_baseline_allcores(nvec: int, dq: int, nbits: int, cores: int, reps: int = 3):
+def cpu_baseline_allcores(nvec: int, dq: int, nbits: int, cores: int, reps: int = 3, with_common: bool = True):
     """the FULL workload on all host cores: every block column of all nvec vectors, block ranges fanned over
     `cores` worker processes (plain interpreters that never load HIP).  Returns the exact full-size count (pins
     the GPU's headline result against the reference) and the aggregate rate = all operand bits x reps /
@@ -213,7 +214,7 @@ def cpu_baseline_allcores(nvec: int, dq: int, nbits: int, cores: int, reps: int 
     nblocks = (nbits + 65535) // 65536
     cores = max(1, min(cores, nblocks))
     t0 = time.perf_counter()
-    procs = _spawn_workers([["and", *shard_range(nblocks, w, cores), nvec, dq, nbits, reps] for w in range(cores)])
+    procs = _spawn_workers([["and", *shard_range(nblocks, w, cores), nvec, dq, nbits, reps, int(with_common)] for w in range(cores)])
     try:
         _go(procs)
         t_ready = time.perf_counter() - t0
@@ -243,8 +244,12 @@ def cpu_pair_allcores(ida: int, idb: int, dq: int, nbits: int, cores: int, reps:
     finally:
         _finish_workers(procs)
     counts = [sum(r["counts"][op] for r in res) for op in range(4)]
-    first = min(r["spans"][0][0] for r in res); last = max(r["spans"][-1][1] for r in res)
-    return {"full_counts": counts, "allcores_gbit_s": round(2 * nblocks * 65536 * reps / (last - first) / 1e9, 1), "cores_used": cores}
+    # a worker's range of a 1e9-bit pair is ~60 blocks = microseconds of work: the span from the first start to the last end across
+    # 256 processes measures how fast this process can write 256 "go" lines, not the work (round 5 reported 12 Gbit/s for 256 cores
+    # that way).  Reported: the operand bits / the BUSIEST worker's own time per pass -- what the cores deliver when they run together.
+    busiest = max(sum(t1 - t0 for t0, t1 in r["spans"]) for r in res) / reps
+    return {"full_counts": counts, "allcores_gbit_s": round(2 * nblocks * 65536 / busiest / 1e9, 1), "cores_used": cores,
+            "allcores_timing": "operand bits / the busiest worker's own time per pass (input build and the release of the workers not timed)"}
 
 
 def cpu_rank_allcores(vid: int, dq: int, nbits: int, cores: int, sample_n, sample_r_fn):
@@ -849,7 +854,7 @@ def run_pairwise(args, env, dq=None, quick=False):
     # 125 MB tensors): the yardstick for the materialised ops above, whose kernel moves the same bytes
     rw_probe = None
     own_probe = None
-    if not quick:
+    if True:                                             # (cheap: also in the quick legs of the driver line)
         try:
             # the library's own yardstick: c = a & b in the launch shape of k_op2_stream (non-temporal 16-byte loads / stores),
             # no descriptors, no classification -- at 1, 2, 4, 8 workgroups per CU, rotating over 3 buffer triples
@@ -863,6 +868,7 @@ def run_pairwise(args, env, dq=None, quick=False):
                          "best_wgs_per_cu": best[0], "ms": round(best[1], 4), "GBps_read_plus_written": round(3 * nb_bytes / best[1] / 1e6, 1)}
         except Exception as e:
             own_probe = {"error": str(e)}
+    if not quick:
         try:
             nw = (nbits + 63) // 64
             xs = [torch.randint(0, 1 << 62, (nw,), dtype=torch.int64, device="cuda") for _ in range(3 * 3)]
@@ -933,8 +939,10 @@ def run_pairwise(args, env, dq=None, quick=False):
             if not args.no_allcores:
                 ncores = args.cpu_cores or len(os.sched_getaffinity(0))
                 full = cpu_pair_allcores(1, 2, dq, nbits, ncores)
-                cpu.update({"full_counts_and_or_xor_sub": full["full_counts"], "allcores_gbit_s": full["allcores_gbit_s"],
-                            "cores_used": full["cores_used"],
+                # (no all-cores RATE for a pairwise operation: a worker's share of a 1e9-bit pair is ~60 blocks = microseconds, and neither
+                # the span over 256 processes (round 5: it timed the release of the workers) nor the busiest worker's own time (one
+                # descheduled process sets it) measures the cores; the fan-out is the whole-pair CHECK of the four counts)
+                cpu.update({"full_counts_and_or_xor_sub": full["full_counts"], "cores_used": full["cores_used"],
                             "allcores_sample": "count_and/or/xor/sub of the WHOLE pair 0, block ranges fanned over the host cores",
                             "matches_gpu_full": bool(full["full_counts"] == pair0),
                             "matches_gpu_full_materialised": bool(full["full_counts"] == mat0)})
@@ -944,15 +952,22 @@ def run_pairwise(args, env, dq=None, quick=False):
     return res
 
 
-def _select_kernel_name():
+def _select_kernel_name(rs_info=None):
+    """the kernel bmx_select_batch_dev takes for a big batch, by the library's own rule (bmx.hip: select lines if the index holds them;
+    else the rank lines' directory with its summary in LDS -- two lanes per query unless BMX_RS_LANES says otherwise; else the tables)"""
+    if rs_info and rs_info.get("select_offset_bits") and os.environ.get("BMX_RS_SELECT_SEL", "-1") != "0":
+        return ("k_select_sel<u%d> (select lines: the ones' positions laid out %d per 128-byte line by build_rs_index -- one lane, one line per "
+                "query, no search)" % (rs_info["select_offset_bits"], 60 if rs_info["select_offset_bits"] == 16 else 30))
     sl = os.environ.get("BMX_RS_SELECT_LINES", "2")
-    if os.environ.get("BMX_RS_LINES", "1") == "0" or sl == "0":
-        return "k_select_l<4> (block index: running counts, cumulative row, bit line)"
+    lanes = os.environ.get("BMX_RS_LANES", "0")
+    if os.environ.get("BMX_RS_LINES", "1") == "0" or sl == "0" or (rs_info is not None and not rs_info.get("has_lines")):
+        return "k_select_l<%s> (block index: running counts, cumulative row, bit line)" % (lanes if lanes in ("2", "4") else "4")
     if sl == "1":
-        return "k_select_lines<4> (block index + octant directory, then the rank line guessed by interpolation and verified by its header)"
+        return "k_select_lines<%s> (block index + octant directory, then the rank line guessed by interpolation and verified by its header)" % (lanes if lanes in ("2", "4") else "4")
     if os.environ.get("BMX_RS_SELECT_TOP", "-1") != "0":
-        return "k_select_top<4> (the select directory's 65,536-entry summary in LDS -- one 1024-thread workgroup per CU -- then the rank line, interpolated guess verified by the line's header)"
-    return "k_select_sdir<4> (select directory over the rank lines: the line of every 2^k-th one, interpolated guess verified by the line's header)"
+        return ("k_select_top<%s> (the select directory's 65,536-entry summary in LDS -- one 1024-thread workgroup per CU -- then the rank line, "
+                "interpolated guess verified by the line's header)" % (lanes if lanes in ("2", "4") else "2"))
+    return "k_select_sdir<%s> (select directory over the rank lines: the line of every 2^k-th one, interpolated guess verified by the line's header)" % (lanes if lanes in ("2", "4") else "4")
 
 
 def L_pair_kernel_name(all_bit, nblocks):
@@ -1004,12 +1019,20 @@ def run_rank_select(args, env, quick=False, dq=None):
     # select: the same batch with the ranks in ascending order ("every k-th element", cursor-style enumeration: neighbours in the
     # batch share lines), and the round-4 kernel (global directory, two dependent reads) next to the LDS-directory one
     qrs, _ = torch.sort(qr)
-    ctx.set_tuning("rs_sorted_hint", 1)
-    sel_sorted_ms = event_avg_ms(lambda: _ffi.check(L.bmx_select_batch_dev(ctx._h, v._h, rs._h, qrs.data_ptr(), nq, pos.data_ptr(), found.data_ptr())), 5, ctx)
-    ctx.set_tuning("rs_sorted_hint", 0)
-    ctx.set_tuning("rs_select_top", 0)
-    sel_sdir_ms = event_avg_ms(do_sel, 5, ctx)
-    ctx.set_tuning("rs_select_top", -1)
+    env_int = lambda k, d: int(os.environ.get(k, d))
+    keep_tuning = {"rs_sorted_hint": 0, "rs_select_top": env_int("BMX_RS_SELECT_TOP", -1), "rs_select_sel": env_int("BMX_RS_SELECT_SEL", -1)}
+    try:
+        ctx.set_tuning("rs_sorted_hint", 1)
+        sel_sorted_ms = event_avg_ms(lambda: _ffi.check(L.bmx_select_batch_dev(ctx._h, v._h, rs._h, qrs.data_ptr(), nq, pos.data_ptr(), found.data_ptr())), 5, ctx)
+        ctx.set_tuning("rs_sorted_hint", 0)
+        # the kernels of the earlier rounds in the same run, through the same index: select lines off -> the rank lines' directory
+        # with its summary in LDS (round 5, k_select_top<2>); that off too -> the directory in global memory (round 4, k_select_sdir<4>)
+        ctx.set_tuning("rs_select_sel", 0)
+        sel_top_ms = event_avg_ms(do_sel, 5, ctx)
+        ctx.set_tuning("rs_select_top", 0)
+        sel_sdir_ms = event_avg_ms(do_sel, 5, ctx)
+    finally:
+        for k_, v_ in keep_tuning.items(): ctx.set_tuning(k_, v_)
     sel_by_batch = {}
     for nqq in (100_000, 1_000_000, nq):
         if nqq <= nq:
@@ -1026,6 +1049,10 @@ def run_rank_select(args, env, quick=False, dq=None):
                    if rs.info()["has_lines"] and os.environ.get("BMX_RS_LANES", "0") != "8" else "k_rank_l / k_rank (descriptor + running count + cumulative row + bit line)")
     traffic, tsrc, tj = (traffic_file("traffic_config3.json" if dq == 6554 else "traffic_config3_1pct.json", kernel=rank_kernel)
                          if (nbits == NBITS_4G and dq in (6554, 655) and nq == 10_000_000) else (None, None, {}))
+    rsi = rs.info()
+    sel_kernel = _select_kernel_name(rsi)
+    straffic, stsrc, stj = (traffic_file("traffic_config3_select.json" if dq == 6554 else "traffic_config3_1pct_select.json", kernel=sel_kernel)
+                            if (nbits == NBITS_4G and dq in (6554, 655) and nq == 10_000_000) else (None, None, {}))
     pct = dq / 65536 * 100
     res = {"metric": "M queries/s, rank + select (bmrs.h RS-index) on one 4e9-bit vector",
            "value": round(2 * nq * steps / dt / 1e6, 1), "unit": "Mqueries/s", "n_gpus": 1, "steps": steps,
@@ -1038,7 +1065,10 @@ def run_rank_select(args, env, quick=False, dq=None):
                       "rank_Mq_s": round(nq / rank_ms / 1e3, 1), "select_Mq_s": round(nq / sel_ms / 1e3, 1),
                       "rank_select_roundtrip_ok": ok,
                       "rank_ms_sorted_queries": round(sorted_ms, 4), "sort_ms_torch": round(sort_ms, 4),
-                      "select_ms_sorted_ranks": round(sel_sorted_ms, 4), "select_ms_global_directory_kernel": round(sel_sdir_ms, 4),
+                      "select_ms_sorted_ranks": round(sel_sorted_ms, 4), "select_ms_lds_directory_kernel": round(sel_top_ms, 4),
+                      "select_ms_global_directory_kernel": round(sel_sdir_ms, 4),
+                      "rs_index": {"bytes": rsi["bytes"], "rank_lines": rsi["has_lines"], "select_offset_bits": rsi["select_offset_bits"],
+                                   "select_lines_bytes": rsi["select_lines_bytes"]},
                       "select_ms_by_batch": sel_by_batch,
                       "bucketing_note": "rank over the same queries pre-sorted by position vs the cost of sorting them (torch.sort): "
                                         "bucketing a batch by block pays only if sort + sorted run < the unsorted run"},
@@ -1049,11 +1079,16 @@ def run_rank_select(args, env, quick=False, dq=None):
                         "algorithmic_bytes_per_launch": nq * 128, "avg_launch_ms": round(rank_ms, 4),
                         "peak_source": f"bmx_probe_random_lines in this run: {nq} random 128-B lines (8 lanes x 16 B, the access shape of "
                                        f"a rank query's bit line) over a {slab_bytes / 1e6:.0f} MB buffer in {pm.value:.4f} ms",
-                        "select": {"kernel": _select_kernel_name(), "achieved": round(sel_lines_s / 1e9, 3), "frac": round(sel_lines_s / ceil_lines_s, 4),
+                        "select": {"kernel": sel_kernel, "achieved": round(sel_lines_s / 1e9, 3), "frac": round(sel_lines_s / ceil_lines_s, 4),
                                    "avg_launch_ms": round(sel_ms, 4),
-                                   "note": "queries per second against the same random-line rate: with the directory summary in LDS a select is ONE "
-                                           "global read (the line) when the interpolated guess holds, a second line when it is off by one; the round-4 "
-                                           "kernel (directory in global memory: two dependent reads) is timed beside it (select_ms_global_directory_kernel)"},
+                                   "note": "queries per second against the same random-line rate.  With select lines (round 6) a select reads ONE "
+                                           "128-byte line that holds the answer -- no guess, no retry; the round-5 kernel (rank lines + directory "
+                                           "summary in LDS: a second line whenever the interpolated guess is off, 1.8 missed lines per query by PMC) "
+                                           "and the round-4 kernel (directory in global memory) are timed beside it through the same index "
+                                           "(select_ms_lds_directory_kernel, select_ms_global_directory_kernel)"},
+                        "select_traffic": straffic, "select_traffic_source": stsrc,
+                        "select_lines_per_query": (round(stj["tcc_miss_per_launch"] / nq, 3) if straffic and stj.get("tcc_miss_per_launch") else None),
+                        "rank_lines_per_query": (round(tj["tcc_miss_per_launch"] / nq, 3) if traffic and tj.get("tcc_miss_per_launch") else None),
                         "as_bandwidth_GBps": round(nq * 128 / rank_ms / 1e6, 1),
                         "frac_bytes": round(nq * 128 / rank_ms / 1e6 / HBM_PEAK_GBS, 4),
                         "select_frac_bytes": round(nq * 136 / sel_ms / 1e6 / HBM_PEAK_GBS, 4),
@@ -1234,7 +1269,7 @@ def run_or_sharded(args, env, quick=False):
                     # bounded full-width check: ALL nvec vectors, a spread sample of block columns, against the GPU result's
                     # count over exactly those columns
                     ncores = args.cpu_cores or len(os.sched_getaffinity(0))
-                    nsample = min(nblocks, max(8, min(ncores, 64)))
+                    nsample = min(nblocks, max(8, min(8 * ncores, 2048)))     # (0.25 s per column and core: 8 columns per worker)
                     blocks = sorted(set(int(x) for x in np.linspace(0, nblocks - 1, nsample)))
                     ref, secs, _k, _i, used = cpu_or_sample(nvec, dq, nbits, blocks, ncores)
                     t = last[0]
@@ -1244,7 +1279,7 @@ def run_or_sharded(args, env, quick=False):
                     got = t.count_range(l, r_, trs)
                     cpu.update({"sampled_block_columns": len(blocks), "cores_used": used,
                                 "allcores_sample": f"combine_or over ALL {nvec} vectors on {len(blocks)} block columns spread over the range "
-                                                   f"(one column per worker process, {secs:.1f} s), compared with count_range of the GPU result",
+                                                   f"({(len(blocks) + used - 1) // used} column(s) per worker process, {secs:.1f} s), compared with count_range of the GPU result",
                                 "matches_gpu_sample": bool([int(x) for x in got] == [ref[b] for b in blocks])})
                 res["cpu_baseline"] = cpu
             except Exception as e:
@@ -1334,6 +1369,48 @@ def run_sparse_and(args, env, dq=197, quick=True):
             res["cpu_baseline"] = cpu
         except Exception as e:
             res["cpu_baseline"] = {"value": None, "unit": "Gbit/s", "cores": 1, "kind": "reference", "sample": f"failed: {e}"}
+    del pipe, vecs
+    ctx.trim()
+    return res
+
+
+def run_dataset_b(args, env):
+    """SURVEY section 8(d) config 3, data set B: 256 INDEPENDENT 10 % vectors -- the AND of every block column is empty after ~8 operands
+    and the reference leaves the column there (digest -> 0, src/bmaggregator.h:1994-2120, :2052); the kernel tests its running
+    result after every batch of operands and stops the column the same way.  Reported as time and Gbit/s of LOGICAL operand bits
+    (what the call covers); there is no bandwidth figure -- almost none of the bytes are read, that is the point."""
+    import bitmagic_amd as bm
+    torch, ctx = env.torch, env.ctx
+    nvec, nbits, dq = 256, NBITS_1G, 6554
+    vecs = [bm.bvector.generate(ctx, SEED, v, dq, nbits, with_common=False) for v in range(nvec)]
+    pipe = bm.aggregator.pipeline(ctx)
+    ag = pipe.add()
+    for v in vecs: ag.add(v, 0)
+    pipe.complete(); ctx.synchronize()
+    agg = bm.aggregator(ctx)
+    counts = torch.zeros(1, dtype=torch.int64, device="cuda")
+    kernel = lambda: agg.run_counts_dev(pipe, counts.data_ptr())
+    dt, ev_ms = timed_region(kernel, 20, 3, env)
+    total = int(counts.item())
+    ms = ev_ms / 20
+    res = {"metric": "Gbit/s of logical operand bits, 256-way fused AND+COUNT on 1e9-bit vectors, data set B (independent operands: early exit)",
+           "value": round(nvec * nbits / ms / 1e6, 1), "unit": "Gbit/s", "n_gpus": 1, "steps": 20, "warmup": 3, "ms_per_step": round(dt / 20 * 1e3, 4),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+           "config": {"workload": f"aggregator::combine_and + count over {nvec} x {nbits}-bit INDEPENDENT vectors at 10 % (data set B): every column's AND is empty after a few operands",
+                      "baseline_config": "configs[2], data set B", "result_count": total, "kernel_plan": pipe.describe(),
+                      "operand_bytes_if_nothing_exited": pipe.operand_bytes()},
+           "roofline": {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None, "kernel": pipe.describe()[:80],
+                        "avg_launch_ms": round(ms, 4),
+                        "note": "no bandwidth figure: the call reads a few operands per column and leaves; `value` counts the logical bits the call covers"}}
+    if not args.no_cpu:
+        try:
+            ncores = args.cpu_cores or len(os.sched_getaffinity(0))
+            full = cpu_baseline_allcores(nvec, dq, nbits, ncores, reps=3, with_common=False)
+            res["cpu_baseline"] = {"value": full["allcores_gbit_s"], "unit": "Gbit/s", "cores": full["cores_used"], "kind": full["allcores_kind"], "impl": full["allcores_impl"],
+                                   "sample": full["allcores_sample"], "full_count": full["full_count"], "matches_gpu_full": bool(full["full_count"] == total),
+                                   "allcores_gbit_s": full["allcores_gbit_s"], "cores_used": full["cores_used"]}
+        except Exception as e:
+            res["cpu_baseline"] = {"value": None, "unit": "Gbit/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
     del pipe, vecs
     ctx.trim()
     return res
@@ -1456,16 +1533,17 @@ def summary_of(res):
         return None
     out = {"metric": res["metric"], "value": res["value"], "unit": res["unit"], "ms_per_step": res["ms_per_step"],
            "steps": res["steps"], "workload": res["config"]["workload"],
-           "roofline": {k: res["roofline"].get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "kernel", "avg_launch_ms", "traffic", "frac_bytes", "select_frac_bytes") if k in res["roofline"] or k in ("bound", "achieved", "peak", "unit", "frac", "kernel", "avg_launch_ms", "traffic")}}
+           "roofline": {k: res["roofline"].get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "kernel", "avg_launch_ms", "traffic", "frac_bytes", "select_frac_bytes", "select_traffic", "select_lines_per_query", "rank_lines_per_query") if k in res["roofline"] or k in ("bound", "achieved", "peak", "unit", "frac", "kernel", "avg_launch_ms", "traffic")}}
     cpu = res.get("cpu_baseline")
     if cpu:
         out["cpu_baseline"] = {k: cpu.get(k) for k in ("value", "unit", "cores", "kind", "matches_gpu", "allcores_gbit_s", "cores_used", "matches_gpu_full", "matches_gpu_full_materialised", "matches_gpu_sample") if k in cpu}
-    for k in ("per_op", "rank_ms", "select_ms", "select_ms_sorted_ranks", "select_ms_global_directory_kernel", "rank_Mq_s", "select_Mq_s", "rank_select_roundtrip_ok", "result_count", "cold_ms", "build_ms", "warm_ms",
+    for k in ("per_op", "rank_ms", "select_ms", "select_ms_sorted_ranks", "select_ms_lds_directory_kernel", "select_ms_global_directory_kernel", "rs_build_ms", "rs_index", "rank_Mq_s", "select_Mq_s", "rank_select_roundtrip_ok", "result_count", "cold_ms", "build_ms", "warm_ms",
               "break_even_calls", "subset_of_the_collection", "own_read_write_probe"):
         if k in res["config"]:
             out[k] = res["config"][k]
     if "select" in res["roofline"]:
         out["roofline"]["select_frac"] = res["roofline"]["select"]["frac"]
+        out["roofline"]["select_kernel"] = res["roofline"]["select"]["kernel"][:24]
     if "warm" in res["roofline"]:
         out["roofline"]["warm"] = {k: res["roofline"]["warm"].get(k) for k in ("kernel", "avg_launch_ms", "achieved", "frac", "reference_format_GBps")}
     return out
@@ -1551,6 +1629,7 @@ def main():
                              ("configs[3]", lambda: run_rank_select(args, env, quick=True)),
                              ("configs[3] at 1 %", lambda: run_rank_select(args, env, quick=True, dq=655)),
                              ("configs[4]", lambda: run_or_sharded(args, env, quick=True)),
+                             ("configs[2] data set B", lambda: run_dataset_b(args, env)),
                              ("configs[2] at 0.3 %", lambda: run_sparse_and(args, env, dq=197)),
                              ("configs[2] at 0.1 %", lambda: run_sparse_and(args, env, dq=66))):
                 try:

@@ -28,6 +28,8 @@ TARGETS = [  # (json file, pmc file, kernel substring, workload label, kernel st
     ("traffic_config4_warm.json", "pmc_config4.txt", "k_coll_apply", "combine_or_4096x4000000000_dq13_prepared_collection", "k_coll_apply<OR,512>"),
     ("traffic_config1_50pct.json", "pmc_config1_50pct.txt", "k_count_op2_stream", "pairwise_count_2x1000000000_dq32768", "k_count_op2_stream"),
     ("traffic_config3_1pct.json", "pmc_config3_1pct.txt", "k_rank_lines", "rank_10M_on_4e9_bits_dq655", "k_rank_lines"),
+    ("traffic_config3_select.json", "pmc_config3.txt", "k_select_sel", "select_10M_on_4e9_bits_dq6554", "k_select_sel"),
+    ("traffic_config3_1pct_select.json", "pmc_config3_1pct.txt", "k_select_sel", "select_10M_on_4e9_bits_dq655", "k_select_sel"),
     ("traffic_config2_dq197.json", "pmc_dq197.txt", "k_agg_and_rows", "agg_and_count_256x1000000000_dq197_first_call", "k_agg_and_rows"),
     ("traffic_config2_dq66.json", "pmc_dq66.txt", "k_agg_and_rows", "agg_and_count_256x1000000000_dq66_first_call", "k_agg_and_rows"),
 ]
@@ -48,6 +50,8 @@ for jname, pmc, ksub, workload, stamp in TARGETS:
         src += f"; cross-check TCC_MISS_sum {c['TCC_MISS_sum'][0]:,.0f} x 128 B = {c['TCC_MISS_sum'][0] * 128 / 1e9:.3f} GB"
     j = {"workload": workload, "kernel": stamp, "commit": commit, "hbm_bytes_per_launch": hbm}
     if "algorithmic_bytes_per_launch" in old: j["algorithmic_bytes_per_launch"] = old["algorithmic_bytes_per_launch"]
+    if "TCC_MISS_sum" in c: j["tcc_miss_per_launch"] = c["TCC_MISS_sum"][0]              # 128-byte lines that left the L2
+    if "TCP_TCC_READ_REQ_sum" in c: j["tcp_tcc_read_req_per_launch"] = c["TCP_TCC_READ_REQ_sum"][0]
     j["source"] = src
     json.dump(j, open(path, "w"), indent=1); open(path, "a").write("\n")
     print(jname, stamp, commit, hbm, ("= %.3f x algorithmic" % (hbm / j["algorithmic_bytes_per_launch"])) if "algorithmic_bytes_per_launch" in j else "")
