@@ -1614,6 +1614,7 @@ int bmx_pipeline_create(bmx_ctx* ctx, const bmx_vec* const* and_list, const uint
     uint32_t ncols = 0, col_stride = 0; bool has_gap = false, has_bit = false; uint64_t max_bits = 0;
     uint64_t gap_words_sum = 0, gap_blocks_sum = 0;
     size_t ia = 0, is = 0;
+    uint32_t null_row_off = 0;
     for (size_t g = 0; g < ngroups; ++g) {
         row_off[g] = col_stride; col_stride += 2 + and_n[g] + sub_n[g];
         m_and_n[g] = and_n[g]; m_sub_n[g] = sub_n[g];
@@ -1631,12 +1632,13 @@ int bmx_pipeline_create(bmx_ctx* ctx, const bmx_vec* const* and_list, const uint
             max_bits = std::max(max_bits, v->nbits);
         }
     }
+    null_row_off = col_stride; col_stride += 2;               // the always-empty row behind the groups' rows (k_limit_null)
 #define PIPECHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { int r_ = fail_hip(e_, #call, __LINE__); bmx_pipeline_destroy(ctx, p); return r_; } } while (0)
     bmx_pipeline* p = new (std::nothrow) bmx_pipeline();
     if (!p) return BMX_ERR_BADALLOC;
     memset(p, 0, sizeof(*p));
     p->search_limit = ~0ull; p->cm_gen = ~0ull; p->cm_tried_gen = ~0ull - 1;     // (the memset above wiped the member initialisers)
-    p->ctx = ctx; p->ngroups = (uint32_t)ngroups; p->ncols = ncols; p->col_stride = col_stride; p->n_ops = (uint32_t)n_ops; p->has_gap = has_gap; p->has_bit = has_bit; p->gap_avg_words = gap_blocks_sum ? (uint32_t)(gap_words_sum / gap_blocks_sum) : 0u;
+    p->ctx = ctx; p->ngroups = (uint32_t)ngroups; p->ncols = ncols; p->col_stride = col_stride; p->null_row_off = null_row_off; p->n_ops = (uint32_t)n_ops; p->has_gap = has_gap; p->has_bit = has_bit; p->gap_avg_words = gap_blocks_sum ? (uint32_t)(gap_words_sum / gap_blocks_sum) : 0u;
     p->nbits = max_bits;
     p->h_row_off = new std::vector<u32>(row_off, row_off + ngroups);
     p->h_and_n = new std::vector<u32>(m_and_n, m_and_n + ngroups);
@@ -1700,6 +1702,8 @@ int bmx_pipeline_create(bmx_ctx* ctx, const bmx_vec* const* and_list, const uint
         u64 nrows = (u64)ncols * ngroups;                  // one wave per (column, group) row
         hipLaunchKernelGGL(k_pipe_sort, dim3((u32)((nrows + 3) / 4)), dim3(256), 0, ctx->stream,
                            po, (u32)ngroups, ncols, col_stride, p->d_dmat);
+        PIPECHK(hipGetLastError());
+        hipLaunchKernelGGL(k_pipe_null_rows, dim3((ncols + 255u) / 256u), dim3(256), 0, ctx->stream, p->d_dmat, ncols, col_stride, null_row_off);
         PIPECHK(hipGetLastError());
     }
     // no synchronise: the tables went through the pinned ring and everything that uses the rows is ordered behind
@@ -1857,11 +1861,14 @@ static int pipe_resolve_colls(bmx_ctx* ctx, bmx_pipeline* p, bool may_build, bmx
 // a subset of a pipeline's arg-groups for one counts launch: the compacted per-group tables k_limit_step wrote
 struct GroupView { const u32* row_off; const u32* and_n; const u32* sub_n; u32 ngroups; const u32* gmask; const u32* gskip; const CollGroup* cgroups; };
 static int pipeline_run_counts_impl(bmx_ctx* ctx, bmx_pipeline* p, uint32_t nb_from, uint32_t nb_to, uint64_t* d_counts, bool may_build, const GroupView* gv = nullptr);
+static int limit_counts_run_dev(bmx_ctx* ctx, bmx_pipeline* p, uint32_t nb_from, uint32_t nb_to, uint64_t* d_counts);
 
 extern "C" {
 
 int bmx_pipeline_run_counts_dev(bmx_ctx* ctx, bmx_pipeline* p, uint32_t nb_from, uint32_t nb_to, uint64_t* d_counts)
 { ABI_TRY
+    ARGCHK(ctx && p && p->ctx == ctx && d_counts);
+    if (p->search_limit != ~0ull) return limit_counts_run_dev(ctx, p, nb_from, nb_to, d_counts);
     return pipeline_run_counts_impl(ctx, p, nb_from, nb_to, d_counts, false);
 ABI_END }
 
@@ -2062,6 +2069,7 @@ static int limit_counts_run(bmx_ctx* ctx, bmx_pipeline* p, uint32_t nb_from, uin
     // collections / staged tables in force (resolved once, before the first window)
     bmx_coll *ca = nullptr, *cs = nullptr;
     if (p->h_uids && (rc = pipe_resolve_colls(ctx, p, true, &ca, &cs))) return rc;
+    CollPin pin; pin.pin(ca, cs);                              // (the member table captured below must stay what the windows resolve: no eviction mid-run)
     const bool have_cg = ca && !p->cm_full && p->cm_buf;
     const bool have_masks = p->staged_ok && p->d_gmask && p->d_gskip;
     const size_t nch = std::max<u32>(p->nchunks, 1u);
@@ -2108,6 +2116,54 @@ static int limit_counts_run(bmx_ctx* ctx, bmx_pipeline* p, uint32_t nb_from, uin
         if (e != hipSuccess) rc = fail_hip(e, "limit_counts_run readback", __LINE__);
     } else (void)hipStreamSynchronize(ctx->stream);
     dfree(ctx, buf);
+    return rc;
+}
+
+// The asynchronous entry under a limit: the same ascending windows, ALL enqueued, nothing read back.  Every window runs over all
+// arg-groups through private copies of the group tables; k_limit_null (bmx_kernels9.h) points the groups that have enough at null
+// entries after each window, so their items of the later windows end at a header.  (A pipeline served as ONE whole packed
+// collection -- cm_full -- has a single fused group with no table entry to null: it runs to the end and returns its true count.)
+static int limit_counts_run_dev(bmx_ctx* ctx, bmx_pipeline* p, uint32_t nb_from, uint32_t nb_to, uint64_t* d_counts)
+{
+    int rc = set_dev(ctx); if (rc) return rc;
+    uint32_t f = nb_from, t = nb_to;
+    if ((rc = pipe_range(p, f, t))) return rc;
+    const u32 ng = p->ngroups, ncols = t - f;
+    HIPCHK(hipMemsetAsync(d_counts, 0, (size_t)std::max(ng, 1u) * 8, ctx->stream));
+    if (!ncols || !ng) return BMX_OK;
+    bmx_coll *ca = nullptr, *cs = nullptr;
+    if (p->h_uids && (rc = pipe_resolve_colls(ctx, p, false, &ca, &cs))) return rc;
+    CollPin pin; pin.pin(ca, cs);
+    const bool have_cg = ca && !p->cm_full && p->cm_buf;
+    const bool have_masks = p->staged_ok && p->d_gmask && p->d_gskip;
+    // totals, the window's counts, row offsets, (member ranges), (gskip)
+    const size_t words = (size_t)ng * (2 + 2 + 1 + (have_cg ? 4 : 0) + (have_masks ? 1 : 0)) + 16;
+    u32* buf = nullptr;
+    if ((rc = dmalloc(ctx, (void**)&buf, words * 4))) return rc;
+    u64* d_tot = (u64*)buf; u64* d_cc = d_tot + ng;
+    u32* d_ro = (u32*)(d_cc + ng);
+    u32* q = d_ro + ng;
+    q = (u32*)(((uintptr_t)q + 15u) & ~(uintptr_t)15u);
+    CollGroup* d_cg = nullptr; u32* d_gs = nullptr;
+    if (have_cg) { d_cg = (CollGroup*)q; q += (size_t)ng * 4; }
+    if (have_masks) { d_gs = q; q += ng; }
+    hipError_t e = hipMemsetAsync(d_tot, 0, (size_t)ng * 8, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_ro, p->d_meta, (size_t)ng * 4, hipMemcpyDeviceToDevice, ctx->stream);
+    if (e == hipSuccess && have_cg) e = hipMemcpyAsync(d_cg, (const char*)p->cm_buf + p->cm_groups_off, (size_t)ng * sizeof(CollGroup), hipMemcpyDeviceToDevice, ctx->stream);
+    if (e == hipSuccess && have_masks) e = hipMemcpyAsync(d_gs, p->d_gskip, (size_t)ng * 4, hipMemcpyDeviceToDevice, ctx->stream);
+    if (e != hipSuccess) { dfree(ctx, buf); return fail_hip(e, "limit_counts_run_dev", __LINE__); }
+    GroupView gv{d_ro, p->d_meta + ng, p->d_meta + 2 * (size_t)ng, ng, have_masks ? (const u32*)p->d_gmask : nullptr, d_gs, d_cg};
+    u32 w = std::max<u32>(ncols / 64u, 16u);
+    for (u32 c = 0; c < ncols && !rc; c += w, w *= 4u) {
+        const u32 c1 = (u32)std::min<u64>((u64)c + w, ncols);
+        rc = pipeline_run_counts_impl(ctx, p, f + c, f + c1, d_cc, false, &gv);
+        if (rc) break;
+        hipLaunchKernelGGL(k_limit_null, dim3((ng + 255u) / 256u), dim3(256), 0, ctx->stream, d_tot, (const u64*)d_cc, ng, p->search_limit, p->null_row_off,
+                           d_ro, d_cg, d_gs, c1 >= ncols ? (u64*)d_counts : (u64*)nullptr);
+        e = hipGetLastError();
+        if (e != hipSuccess) { rc = fail_hip(e, "k_limit_null", __LINE__); break; }
+    }
+    dfree(ctx, buf);                                               // (pooled: handed only to work enqueued behind this run)
     return rc;
 }
 

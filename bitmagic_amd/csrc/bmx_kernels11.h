@@ -68,7 +68,7 @@ void k_rs_sel_build(const u64* __restrict__ desc, u32 nblocks, const u64* __rest
     blk_from_desc(d, b, lds + wave * 2048u, lane);
     T* stage = reinterpret_cast<T*>(lds + wave * 2048u);
     u64 row_off = first;
-#pragma unroll 1
+#pragma unroll                                                           // (a row index known at compile time: the block image stays in registers)
     for (int i = 0; i < 8; ++i) {
         // row i = words i*256 .. i*256+255; lane l holds the four consecutive words i*256 + 4l .. + 3
         const u32 c = (u32)__popc(b.r[i].x) + (u32)__popc(b.r[i].y) + (u32)__popc(b.r[i].z) + (u32)__popc(b.r[i].w);

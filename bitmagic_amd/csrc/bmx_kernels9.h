@@ -318,3 +318,37 @@ void k_limit_step(u64* __restrict__ totals, const u64* __restrict__ cc, const u3
     }
     if (tid == 0) { *n_active_dev = base; *n_active_host = (u64)base; }
 }
+
+// ---------------------------------------------------------------------------
+// The same limit on the ASYNCHRONOUS counts entry (round 6, bmx_pipeline_run_counts_dev): no host decision between windows, so
+// nothing is compacted -- every window is enqueued over ALL arg-groups, and after a window this kernel (a thread per group) folds
+// the window's counts into the totals and points a group that has enough at a NULL entry of every table the counts kernels
+// read: the always-ROW_EMPTY row that ends each column record (row kernels return at its header), an empty member range
+// (k_coll_members: an empty AND list ends the column), gskip = 1 (the LDS-staged kernel).  A finished group then costs one
+// header read per (column, group) item instead of its operands -- "can find more, cannot find less" (src/bmaggregator.h:1362).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256)
+void k_pipe_null_rows(u64* __restrict__ dmat, u32 ncols, u32 col_stride, u32 null_off)
+{
+    const u32 c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ncols) return;
+    u64* row = dmat + (size_t)c * col_stride + null_off;
+    row[0] = 0ull; row[1] = ROW_EMPTY;
+}
+
+__global__ __launch_bounds__(256)
+void k_limit_null(u64* __restrict__ totals, const u64* __restrict__ cc, u32 ng, u64 limit, u32 null_off,
+                  u32* __restrict__ ro, CollGroup* __restrict__ cg, u32* __restrict__ gskip, u64* __restrict__ out /* non-null on the last window: the totals */)
+{
+    const u32 g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= ng) return;
+    const u64 c = totals[g] + cc[g];
+    totals[g] = c;
+    if (c >= limit) {
+        ro[g] = null_off;
+        if (cg) cg[g] = CollGroup{0u, 0u, 0u, 0u};
+        if (gskip) gskip[g] = 1u;
+    }
+    if (out) out[g] = c;
+}
+

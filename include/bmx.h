@@ -303,7 +303,10 @@ int bmx_pipeline_run_counts(bmx_ctx* ctx, bmx_pipeline* p, uint32_t nb_from, uin
  * >= min(limit, the group's true count) and <= the true count.  limit 0 / bm::id_max (2^32 - 1, 2^48 - 1) / UINT64_MAX = no
  * limit (one run).  As in the reference the limit applies whenever counts are computed: bmx_pipeline_run_results* with
  * counts_out != NULL produces a group's vector up to the window at whose end the group had enough (its count is then
- * >= min(limit, true count)); result-only runs ignore it.  bmx_pipeline_run_counts_dev (asynchronous) ignores it.
+ * >= min(limit, true count)); result-only runs ignore it.  bmx_pipeline_run_counts_dev (asynchronous) honours it without a host
+ * decision: the same windows are all enqueued over all groups, and after each one the groups that have enough are pointed at null
+ * table entries on the device, so their items of the later windows end at a header read (same totals as the synchronous run; a
+ * pipeline that is served as ONE whole packed collection runs to the end and returns its true count).
  * bmx_pipeline_last_windows: windows launched / planned by the last synchronous counts run;
  * bmx_pipeline_last_window_groups: out[w] = arg-groups window w of that run ran over (n = windows launched). */
 int bmx_pipeline_set_search_count_limit(bmx_ctx* ctx, bmx_pipeline* p, uint64_t limit);

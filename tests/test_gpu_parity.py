@@ -2429,6 +2429,10 @@ def test_search_count_limit_drops_groups_per_group(ctx, port):
             assert all(limit <= g <= t for k, (g, t) in enumerate(zip(got, full)) if k != short), staged
             # the satisfied groups stopped after the first window: they hold what that window found, far below their true count
             assert all(g < t // 8 for k, (g, t) in enumerate(zip(got, full)) if k != short)
+            # round 6: the ASYNCHRONOUS entry honours the limit too -- every window enqueued over all groups, a finished group
+            # pointed at null table entries on the device (k_limit_null): same windows, same totals, no host decision in between
+            dev = _dev_counts(ctx, agg, p, ng)
+            assert dev == got, (staged, [(k, a, b) for k, (a, b) in enumerate(zip(dev, got)) if a != b][:5])
     finally:
         ctx.set_tuning("pipe_staged", -1)
     # every group satisfied in the first window: nothing else is launched
@@ -2474,6 +2478,26 @@ def test_search_count_limit_drops_groups_per_group(ctx, port):
     pg2 = mkg(lim); gg = [int(x) for x in agg.combine_and_sub(pg2)]
     wgs = pg2.last_window_groups()
     assert gg[2] == fg[2] and all(min(lim, t) <= g <= t for g, t in zip(gg, fg)) and wgs[0] == 6 and wgs[-1] == 1, (gg, fg, wgs)
+    assert _dev_counts(ctx, agg, pg2, 6) == gg                                 # the asynchronous entry over GAP-only operands
+    assert _dev_counts(ctx, agg, pg, 6) == fg                                  # ... and without a limit
+    # ... and over the members of a packed collection (k_coll_members: a finished group gets an empty member range)
+    ctx.collection_prepare(gaps, bm.ROLE_AND)
+    try:
+        ctx.set_tuning("coll_members", 1)
+        pg3 = mkg(lim); g3 = [int(x) for x in agg.combine_and_sub(pg3)]
+        assert g3[2] == fg[2] and all(min(lim, t) <= g <= t for g, t in zip(g3, fg)), (g3, fg)
+        assert _dev_counts(ctx, agg, pg3, 6) == g3
+    finally:
+        ctx.set_tuning("coll_members", -1)
+
+
+def _dev_counts(ctx, agg, pipe, ng):
+    import torch
+    d = torch.full((ng,), -1, dtype=torch.int64, device="cuda")
+    torch.cuda.synchronize()
+    agg.run_counts_dev(pipe, d.data_ptr())
+    ctx.synchronize()
+    return [int(x) for x in d.cpu().tolist()]
 
 
 def test_op2_count_in_one_call(ctx, port):
