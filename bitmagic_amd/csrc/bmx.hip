@@ -1638,7 +1638,7 @@ int bmx_pipeline_create(bmx_ctx* ctx, const bmx_vec* const* and_list, const uint
     if (!p) return BMX_ERR_BADALLOC;
     memset(p, 0, sizeof(*p));
     p->search_limit = ~0ull; p->cm_gen = ~0ull; p->cm_tried_gen = ~0ull - 1;     // (the memset above wiped the member initialisers)
-    p->ctx = ctx; p->ngroups = (uint32_t)ngroups; p->ncols = ncols; p->col_stride = col_stride; p->null_row_off = null_row_off; p->n_ops = (uint32_t)n_ops; p->has_gap = has_gap; p->has_bit = has_bit; p->gap_avg_words = gap_blocks_sum ? (uint32_t)(gap_words_sum / gap_blocks_sum) : 0u;
+    p->ctx = ctx; p->ngroups = (uint32_t)ngroups; p->ncols = ncols; p->col_stride = col_stride; p->null_row_off = null_row_off; { uint32_t ml_ = 0; for (size_t g = 0; g < ngroups; ++g) ml_ = std::max(ml_, std::max(and_n[g], sub_n[g])); p->max_list = ml_; } p->n_ops = (uint32_t)n_ops; p->has_gap = has_gap; p->has_bit = has_bit; p->gap_avg_words = gap_blocks_sum ? (uint32_t)(gap_words_sum / gap_blocks_sum) : 0u;
     p->nbits = max_bits;
     p->h_row_off = new std::vector<u32>(row_off, row_off + ngroups);
     p->h_and_n = new std::vector<u32>(m_and_n, m_and_n + ngroups);
@@ -1743,7 +1743,7 @@ static int pipe_range(const bmx_pipeline* p, uint32_t& nb_from, uint32_t& nb_to)
 // 0.51 / 1.35 against 1.56 / 2.10 -- a tie up to 4 operands, a win from 8 on: and_rows -1 takes it from 8 operands per group.
 static bool use_and_rows(const bmx_ctx* ctx, const bmx_pipeline* p, uint64_t ops_of_group = 0)
 {
-    if (ctx->and_rows == 0 || ctx->gap_count == 1 || !p->has_gap || p->has_bit) return false;
+    if (ctx->and_rows == 0 || ctx->gap_count == 1 || !p->has_gap || p->has_bit || p->max_list > 32767u) return false;
     if (ctx->and_rows > 0) return true;
     if (ops_of_group) return ops_of_group >= 8u;
     return (uint64_t)p->n_ops >= 8ull * p->ngroups;

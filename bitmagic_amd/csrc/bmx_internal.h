@@ -135,6 +135,7 @@ struct bmx_vec {
 struct bmx_pipeline {
     bmx_ctx* ctx;
     uint32_t ngroups, ncols, col_stride, n_ops;
+    uint32_t max_list;                    // the longest AND / SUB list of an arg-group (k_agg_and_rows keeps per-word operand counts in 16 bits: <= 32,767)
     uint32_t null_row_off;                // every column record ends with a row that is always ROW_EMPTY: what the asynchronous counts run under a search limit points a finished group at
     bool has_gap;
     bool has_bit = false;      // any operand vector holds a bit-block
