@@ -1195,8 +1195,14 @@ void k_select_sdir(const u32* __restrict__ lines, const u32* __restrict__ sdir, 
 // query, 0.45 ms for 10 M queries where rank takes 0.21.  A directory of 65,536 entries fits the 160 KiB of a CU: entry m = the
 // line of one number m 2^shift (shift chosen so that the vector's ones give <= 65,535 entries: ~64 lines per entry for
 // configs[3]) as a 16-bit offset from a 32-bit base per 256 entries -- 129 KiB, copied into LDS once per workgroup (one
-// workgroup per CU, 33 MB for the whole launch).  Both ends of the interpolation are exact, so the guess is off by a
-// Brownian-bridge error of ~0.3 lines: the headers send ~1 query in 8 to a second line.  One global read per query.
+// workgroup per CU, 33 MB for the whole launch).  How often the guess is a line off -- corrected in round 6 against the PMC of
+// profiles/r05final (TCC_MISS 18.0 M per 10 M queries = 1.8 lines per query where rank misses 0.96) and a replay of the search on
+// Bernoulli data (profiles/r06_select/README.md: 1.55 line reads per query at 10 %, 1.86 at 1 %): about every SECOND query, not one
+// in eight.  An entry knows the LINE of its sampled one, not where in the line it sits (half a line of bias between the two ends of
+// the interpolation), and between two samples ~85 lines apart the ones wander by ~0.35 lines at 10 % density, ~1.2 lines at 1 %.
+// The kernel is bound by those second lines (it costs per missed line what rank costs), not by its instructions.  Vectors whose
+// index holds select lines (bmx_kernels11.h: <= ~12 % ones) do not come here any more; this kernel serves the denser ones, where the
+// wander is small (0.15 lines at 50 %).
 // ---------------------------------------------------------------------------
 #define STOP_ENTRIES 65536u
 __global__ __launch_bounds__(256)
