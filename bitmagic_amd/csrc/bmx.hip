@@ -1638,7 +1638,7 @@ int bmx_pipeline_create(bmx_ctx* ctx, const bmx_vec* const* and_list, const uint
     if (!p) return BMX_ERR_BADALLOC;
     memset(p, 0, sizeof(*p));
     p->search_limit = ~0ull; p->cm_gen = ~0ull; p->cm_tried_gen = ~0ull - 1;     // (the memset above wiped the member initialisers)
-    p->ctx = ctx; p->ngroups = (uint32_t)ngroups; p->ncols = ncols; p->col_stride = col_stride; p->null_row_off = null_row_off; { uint32_t ml_ = 0; for (size_t g = 0; g < ngroups; ++g) ml_ = std::max(ml_, std::max(and_n[g], sub_n[g])); p->max_list = ml_; } p->n_ops = (uint32_t)n_ops; p->has_gap = has_gap; p->has_bit = has_bit; p->gap_avg_words = gap_blocks_sum ? (uint32_t)(gap_words_sum / gap_blocks_sum) : 0u;
+    p->ctx = ctx; p->ngroups = (uint32_t)ngroups; p->ncols = ncols; p->col_stride = col_stride; p->null_row_off = null_row_off; p->n_ops = (uint32_t)n_ops; p->has_gap = has_gap; p->has_bit = has_bit; p->gap_avg_words = gap_blocks_sum ? (uint32_t)(gap_words_sum / gap_blocks_sum) : 0u;
     p->nbits = max_bits;
     p->h_row_off = new std::vector<u32>(row_off, row_off + ngroups);
     p->h_and_n = new std::vector<u32>(m_and_n, m_and_n + ngroups);
@@ -1743,7 +1743,7 @@ static int pipe_range(const bmx_pipeline* p, uint32_t& nb_from, uint32_t& nb_to)
 // 0.51 / 1.35 against 1.56 / 2.10 -- a tie up to 4 operands, a win from 8 on: and_rows -1 takes it from 8 operands per group.
 static bool use_and_rows(const bmx_ctx* ctx, const bmx_pipeline* p, uint64_t ops_of_group = 0)
 {
-    if (ctx->and_rows == 0 || ctx->gap_count == 1 || !p->has_gap || p->has_bit || p->max_list > 32767u) return false;
+    if (ctx->and_rows == 0 || ctx->gap_count == 1 || !p->has_gap || p->has_bit) return false;
     if (ctx->and_rows > 0) return true;
     if (ops_of_group) return ops_of_group >= 8u;
     return (uint64_t)p->n_ops >= 8ull * p->ngroups;
@@ -3834,21 +3834,37 @@ int bmx_rs_build(bmx_ctx* ctx, const bmx_vec* v, bmx_rs** out)
             hipLaunchKernelGGL(k_rs_sdir, dim3((u32)((nlines + 255u) / 256u)), dim3(256), 0, ctx->stream,
                                (const u32*)rs->d_lines, (u64)nlines, (u64)rs->count, sh, rs->d_sdir, (u64)rs->sdir_entries);
             RSCHK(hipGetLastError());
-            // the directory's summary for LDS (k_select_top): one entry per 2^stop_shift ones, at most 65,535 + the sentinel
+            // the directory's summary for LDS (k_select_top): one entry per 2^stop_shift ones, at most 65,535 + the sentinel; an entry
+            // is the position of its one to 1 / 2^fb of a line (fb <= 3: as fine as the 16-bit offsets of a group of 64 entries allow)
             uint32_t ssh = sh;
             while (((rs->count + (1ull << ssh) - 1ull) >> ssh) + 1ull > STOP_ENTRIES && ssh < 40u) ++ssh;
             const uint32_t n_top = (uint32_t)(((rs->count + (1ull << ssh) - 1ull) >> ssh) + 1ull);
-            if ((rc = dmalloc(ctx, (void**)&rs->d_stop, 256u * 4u + STOP_ENTRIES * 2u + 64u))) { bmx_rs_free(ctx, rs); return rc; }
-            RSCHK(hipMemsetAsync(rs->d_stop, 0, 256u * 4u + STOP_ENTRIES * 2u + 64u, ctx->stream));
-            RSCHK(hipMemsetAsync(ctx->d_small + 32, 0, 8, ctx->stream));
-            hipLaunchKernelGGL(k_rs_stop, dim3((n_top + 255u) / 256u), dim3(256), 0, ctx->stream, (const u32*)rs->d_sdir, (u64)rs->sdir_entries, ssh - sh, n_top,
-                               rs->d_stop, (u16*)(rs->d_stop + 256), (u32*)(ctx->d_small + 32));
-            RSCHK(hipGetLastError());
-            RSCHK(hipMemcpyAsync(ctx->h_small + 32, ctx->d_small + 32, 8, hipMemcpyDeviceToHost, ctx->stream));
-            RSCHK(hipStreamSynchronize(ctx->stream));
-            rs->stop_shift = ssh;
-            if (ctx->h_small[32] != 0) { dfree(ctx, rs->d_stop); rs->d_stop = nullptr; }      // (256 entries spread over more than 65,535 lines somewhere: the global directory serves)
-            else rs->bytes += 256u * 4u + STOP_ENTRIES * 2u;
+            u32* d_p8 = nullptr;
+            if (nlines < (1ull << 28) && dmalloc(ctx, (void**)&d_p8, (size_t)n_top * 4u + 64u) == BMX_OK) {
+                if ((rc = dmalloc(ctx, (void**)&rs->d_stop, STOP_BYTES + 64u))) { dfree(ctx, d_p8); bmx_rs_free(ctx, rs); return rc; }
+                hipError_t e_ = hipMemsetAsync(rs->d_stop, 0, STOP_BYTES + 64u, ctx->stream);
+                if (e_ == hipSuccess) e_ = hipMemsetAsync(ctx->d_small + 32, 0, 8, ctx->stream);
+                if (e_ == hipSuccess) {
+                    hipLaunchKernelGGL(k_rs_stop_pos, dim3((n_top + 255u) / 256u), dim3(256), 0, ctx->stream, (const u32*)rs->d_lines, (const u32*)rs->d_sdir, (u64)rs->sdir_entries,
+                                       sh, ssh, n_top, (u64)rs->count, d_p8);
+                    hipLaunchKernelGGL(k_rs_stop_range, dim3((n_top / STOP_GROUP + 256u) / 256u), dim3(256), 0, ctx->stream, (const u32*)d_p8, n_top, (u32*)(ctx->d_small + 32));
+                    e_ = hipGetLastError();
+                }
+                if (e_ == hipSuccess) e_ = hipMemcpyAsync(ctx->h_small + 32, ctx->d_small + 32, 8, hipMemcpyDeviceToHost, ctx->stream);
+                if (e_ == hipSuccess) e_ = hipStreamSynchronize(ctx->stream);
+                if (e_ != hipSuccess) { dfree(ctx, d_p8); int r_ = fail_hip(e_, "select summary", __LINE__); bmx_rs_free(ctx, rs); return r_; }
+                const uint32_t spread = (uint32_t)ctx->h_small[32];          // in eighths of a line
+                uint32_t fb = 3u;
+                while (fb > 0u && (spread >> (3u - fb)) > 65000u) --fb;
+                if ((spread >> (3u - fb)) > 65000u) { dfree(ctx, rs->d_stop); rs->d_stop = nullptr; }   // (64 entries spread over more than 65,000 lines somewhere: the global directory serves)
+                else {
+                    hipLaunchKernelGGL(k_rs_stop_pack, dim3((n_top + 255u) / 256u), dim3(256), 0, ctx->stream, (const u32*)d_p8, n_top, 3u - fb, rs->d_stop, (u16*)(rs->d_stop + STOP_BASES));
+                    e_ = hipGetLastError();
+                    if (e_ != hipSuccess) { dfree(ctx, d_p8); int r_ = fail_hip(e_, "k_rs_stop_pack", __LINE__); bmx_rs_free(ctx, rs); return r_; }
+                    rs->stop_shift = ssh; rs->stop_fb = fb; rs->bytes += STOP_BYTES;
+                }
+                dfree(ctx, d_p8);
+            }
         }
 #undef RSCHK
     }
@@ -3940,7 +3956,7 @@ int bmx_select_batch_dev(bmx_ctx* ctx, const bmx_vec* v, const bmx_rs* rs, const
     // selects on configs[3] 0.377 ms against 0.416 / 0.436 for the global-directory kernel with four / two lanes, 100 M: 3.63 against
     // 4.09; at 1 M the 129 KiB every workgroup copies first cost more than they save: 0.058 against 0.044 -- taken from 4 M queries)
     const bool top_ok = rs->d_stop && rs->d_sdir && ctx->rs_select_lines == 2 && ctx->rs_select_top != 0 &&
-                        (ctx->rs_select_top == 1 || (q >= (1u << 22) && !ctx->rs_sorted_hint)) && q < (1ull << 32) && ctx->max_lds_bytes >= 256u * 4u + STOP_ENTRIES * 2u + 16384u;
+                        (ctx->rs_select_top == 1 || (q >= (1u << 22) && !ctx->rs_sorted_hint)) && q < (1ull << 32) && ctx->max_lds_bytes >= STOP_BYTES + 16384u;
     if (top_ok && !ctx->rs_lanes) lpq = 2;
     // ranks the caller says arrive in ascending order (cursor-style enumeration): neighbours share lines and directory entries;
     // the global-directory kernel with two lanes per query is the fastest there (10 M: 0.25 ms against 0.38 random)
@@ -3952,11 +3968,11 @@ int bmx_select_batch_dev(bmx_ctx* ctx, const bmx_vec* v, const bmx_rs* rs, const
     const bool top = top_ok && lpq != 8;
     if (top) {
         // the directory's summary in LDS: one 1024-thread workgroup per CU (129 KiB of LDS each), one global read per query
-        const size_t lds = 256u * 4u + STOP_ENTRIES * 2u + 16u * 64u * 16u;       // the summary + a queue of 64 parked queries per wave
+        const size_t lds = STOP_BYTES + 16u * 64u * 16u;                          // the summary + a queue of 64 parked queries per wave
         auto fn = lpq == 2 ? k_select_top<2> : k_select_top<4>;
         HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         const u32 g = (u32)std::min<size_t>((q * (size_t)lpq + 1023) / 1024, 256u);
-        hipLaunchKernelGGL(fn, dim3(g), dim3(1024), lds, ctx->stream, (const u32*)rs->d_lines, (const u32*)rs->d_stop, rs->stop_shift, rs->count,
+        hipLaunchKernelGGL(fn, dim3(g), dim3(1024), lds, ctx->stream, (const u32*)rs->d_lines, (const u32*)rs->d_stop, rs->stop_shift, rs->stop_fb, rs->count,
                            (const u64*)d_rank, (u64)q, (u64*)d_pos, (u8*)d_found);
     }
     else if (rs->d_sdir && lpq != 8 && ctx->rs_select_lines == 2) {

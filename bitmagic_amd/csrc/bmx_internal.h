@@ -135,7 +135,6 @@ struct bmx_vec {
 struct bmx_pipeline {
     bmx_ctx* ctx;
     uint32_t ngroups, ncols, col_stride, n_ops;
-    uint32_t max_list;                    // the longest AND / SUB list of an arg-group (k_agg_and_rows keeps per-word operand counts in 16 bits: <= 32,767)
     uint32_t null_row_off;                // every column record ends with a row that is always ROW_EMPTY: what the asynchronous counts run under a search limit points a finished group at
     bool has_gap;
     bool has_bit = false;      // any operand vector holds a bit-block
@@ -207,7 +206,7 @@ struct bmx_rs {
     u32* d_sdir; uint32_t sdir_shift; uint64_t sdir_entries;  // with rank lines: select directory (line of every 2^shift-th one) + sentinel
     u16* d_dir8;                                          // with rank lines: ones of a block before each of its eight 8,192-bit octants
     u8* d_sel = nullptr; uint32_t sel_bits = 0; uint64_t sel_lines = 0;  // select lines (bmx_kernels11.h): the positions of the ones, K = 60 (16-bit offsets) / 30 (32-bit) per 128-byte line, or null
-    u32* d_stop = nullptr; uint32_t stop_shift = 0;       // with the select directory: its 65,536-entry summary for LDS (k_select_top): base[256] + 16-bit offsets, or null
+    u32* d_stop = nullptr; uint32_t stop_shift = 0, stop_fb = 0;       // with the select directory: its 65,536-entry summary for LDS (k_select_top): positions to 1 / 2^stop_fb of a line as base[1024] + 16-bit offsets, or null
     size_t bytes;
 };
 

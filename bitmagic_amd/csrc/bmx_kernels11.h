@@ -67,7 +67,11 @@ void k_rs_sel_build(const u64* __restrict__ desc, u32 nblocks, const u64* __rest
     Blk b;
     blk_from_desc(d, b, lds + wave * 2048u, lane);
     T* stage = reinterpret_cast<T*>(lds + wave * 2048u);
-    u64 row_off = first;
+    // (one 64-bit division per block: the ones of the block are numbered from the block's first line in 32 bits)
+    const u64 line0 = first / K;
+    const u32 rem0 = (u32)(first - line0 * K);
+    u8* const sel0 = sel + line0 * SL_BYTES;
+    u32 row_off = rem0;                                                   // number of the row's first one, counted from line0's slot 0
 #pragma unroll                                                           // (a row index known at compile time: the block image stays in registers)
     for (int i = 0; i < 8; ++i) {
         // row i = words i*256 .. i*256+255; lane l holds the four consecutive words i*256 + 4l .. + 3
@@ -84,12 +88,12 @@ void k_rs_sel_build(const u64* __restrict__ desc, u32 nblocks, const u64* __rest
                 sel_stage_word<T>(b.r[i].w, lowbase + 96u, idx, cb, stage, CAP);
             }
             const u32 n = tot - cb < CAP ? tot - cb : CAP;
-            const u64 g0 = row_off + cb;
+            const u32 g0 = row_off + cb;
             if constexpr (sizeof(T) == 2) {
-                const u32 e0 = (u32)(g0 & 1u);                            // slot parity = one-number parity (K is even)
+                const u32 e0 = g0 & 1u;                                   // slot parity = one-number parity (K is even, and so is line0 K)
                 auto single = [&](u32 e) {
-                    const u64 g = g0 + e; const u64 line = g / K; const u32 slot = (u32)(g - line * K);
-                    u8* L = sel + line * SL_BYTES;
+                    const u32 g = g0 + e; const u32 line = g / K; const u32 slot = g - line * K;
+                    u8* L = sel0 + (size_t)line * SL_BYTES;
                     reinterpret_cast<u16*>(L + 8)[slot] = stage[e];
                     if (slot == 0u) *reinterpret_cast<u64*>(L) = hi + stage[e];
                 };
@@ -97,8 +101,8 @@ void k_rs_sel_build(const u64* __restrict__ desc, u32 nblocks, const u64* __rest
                 const u32 np = (n - e0) >> 1;
                 for (u32 p = lane; p < np; p += 64u) {
                     const u32 e = e0 + 2u * p;
-                    const u64 g = g0 + e; const u64 line = g / K; const u32 slot = (u32)(g - line * K);
-                    u8* L = sel + line * SL_BYTES;
+                    const u32 g = g0 + e; const u32 line = g / K; const u32 slot = g - line * K;
+                    u8* L = sel0 + (size_t)line * SL_BYTES;
                     const u32 lo = stage[e], hi16 = stage[e + 1u];
                     *reinterpret_cast<u32*>(L + 8 + slot * 2u) = lo | (hi16 << 16);
                     if (slot == 0u) *reinterpret_cast<u64*>(L) = hi + lo;
@@ -106,8 +110,8 @@ void k_rs_sel_build(const u64* __restrict__ desc, u32 nblocks, const u64* __rest
                 if (((n - e0) & 1u) && lane == 63u) single(n - 1u);
             } else {
                 for (u32 e = lane; e < n; e += 64u) {
-                    const u64 g = g0 + e; const u64 line = g / K; const u32 slot = (u32)(g - line * K);
-                    u8* L = sel + line * SL_BYTES;
+                    const u32 g = g0 + e; const u32 line = g / K; const u32 slot = g - line * K;
+                    u8* L = sel0 + (size_t)line * SL_BYTES;
                     reinterpret_cast<u32*>(L + 8)[slot] = stage[e];
                     if (slot == 0u) *reinterpret_cast<u64*>(L) = hi + stage[e];
                 }

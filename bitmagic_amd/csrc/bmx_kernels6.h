@@ -1205,32 +1205,66 @@ void k_select_sdir(const u32* __restrict__ lines, const u32* __restrict__ sdir, 
 // wander is small (0.15 lines at 50 %).
 // ---------------------------------------------------------------------------
 #define STOP_ENTRIES 65536u
+#define STOP_GROUP 64u                  // entries per 32-bit base
+#define STOP_BASES (STOP_ENTRIES / STOP_GROUP)
+#define STOP_BYTES (STOP_BASES * 4u + STOP_ENTRIES * 2u)
+// Round 6: an entry is the POSITION of its sampled one to 1 / 2^fb of a line (fb <= 3), not just its line: with line-granular
+// entries the two ends of the interpolation are half a line off on average and every second guess lands a line away
+// (tools/sim_select_guess.py: 1.55 line reads per query at 10 % density, 1.50 at 50 %; with the position: 1.28 / 1.10).
+// k_rs_stop_pos: P8[m] = 8 x line + (bit of the one inside the line's 960) / 120 for one number m << d_ones (0-based), found in the
+// line the directory names; the sentinel entry: the end of the directory's last line.  k_rs_stop_range: the largest spread of a
+// group of 64 entries (the host picks fb so that it fits 16 bits).  k_rs_stop_pack: base[g] + 16-bit offsets at that fb.
 __global__ __launch_bounds__(256)
-void k_rs_stop(const u32* __restrict__ sdir, u64 nent, u32 d /* log2(entries of sdir per entry here) */, u32 n_top, u32* __restrict__ base, u16* __restrict__ t16, u32* __restrict__ bad)
+void k_rs_stop_pos(const u32* __restrict__ lines, const u32* __restrict__ sdir, u64 nent, u32 sh, u32 ssh, u32 n_top, u64 total, u32* __restrict__ P8)
 {
     const u32 m = blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= n_top) return;
-    auto at = [&](u32 k) { const u64 i = (u64)k << d; return sdir[i < nent ? i : nent - 1u]; };
-    const u32 b = at(m & ~255u), v = at(m);
-    if ((m & 255u) == 0u) base[m >> 8] = b;
-    if (v - b > 65535u) atomicOr(bad, 1u);
+    const u64 k = (u64)m << ssh;                                   // the one (0-based) this entry samples
+    if (k >= total) { P8[m] = sdir[nent - 1u] * 8u + 7u; return; } // the sentinel
+    const u32 j = sdir[k >> sh];
+    const u32* L = lines + (size_t)j * 32u;
+    const u64 h = *reinterpret_cast<const u64*>(L);
+    u32 need = (u32)(k - h) + 1u, bit = 0u;                        // the need-th one of the line's 30 data words
+    for (u32 w = 2u; w < 32u; ++w) {
+        const u32 x = L[w], pc = (u32)__popc(x);
+        if (need <= pc) { bit = (w - 2u) * 32u + select_in_word(x, need); break; }
+        need -= pc;
+    }
+    P8[m] = j * 8u + bit / 120u;
+}
+__global__ __launch_bounds__(256)
+void k_rs_stop_range(const u32* __restrict__ P8, u32 n_top, u32* __restrict__ max_range)
+{
+    const u32 g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g * STOP_GROUP >= n_top) return;
+    // (entry (g + 1) x 64 reads its offset against group g + 1's base, but hi of entry g x 64 + 63 needs nothing of group g)
+    const u32 last = g * STOP_GROUP + STOP_GROUP - 1u < n_top ? g * STOP_GROUP + STOP_GROUP - 1u : n_top - 1u;
+    atomicMax(max_range, P8[last] - P8[g * STOP_GROUP]);
+}
+__global__ __launch_bounds__(256)
+void k_rs_stop_pack(const u32* __restrict__ P8, u32 n_top, u32 down /* 3 - fb */, u32* __restrict__ base, u16* __restrict__ t16)
+{
+    const u32 m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= n_top) return;
+    const u32 b = P8[m & ~(STOP_GROUP - 1u)] >> down, v = P8[m] >> down;
+    if ((m & (STOP_GROUP - 1u)) == 0u) base[m / STOP_GROUP] = b;
     t16[m] = (u16)(v - b);
 }
 
 template <u32 LPQ>
 __global__ __launch_bounds__(1024)
-void k_select_top(const u32* __restrict__ lines, const u32* __restrict__ stop /* base[256] then t16[65536] */, u32 shift, u64 total,
+void k_select_top(const u32* __restrict__ lines, const u32* __restrict__ stop /* base[1024] then t16[65536] */, u32 shift, u32 fb, u64 total,
                   const u64* __restrict__ q, u64 nq, u64* __restrict__ pos, u8* __restrict__ found)
 {
     extern __shared__ u32 lds_dyn[];
     {
         const u32x4* src = reinterpret_cast<const u32x4*>(stop);
         u32x4* dst = reinterpret_cast<u32x4*>(lds_dyn);
-        for (u32 i = threadIdx.x; i < (256u * 4u + STOP_ENTRIES * 2u) / 16u; i += 1024u) dst[i] = src[i];
+        for (u32 i = threadIdx.x; i < STOP_BYTES / 16u; i += 1024u) dst[i] = src[i];
     }
     __syncthreads();
     const u32* base = lds_dyn;
-    const u16* t16 = reinterpret_cast<const u16*>(lds_dyn + 256);
+    const u16* t16 = reinterpret_cast<const u16*>(lds_dyn + STOP_BASES);
     const u32 lane = lane_id(), wave = uniform32(threadIdx.x >> 6);
     const u32 sub = lane & (LPQ - 1u), grp = lane / LPQ;
     constexpr u32 GPW = 64u / LPQ;                                    // queries a wave reads lines for at a time
@@ -1238,21 +1272,27 @@ void k_select_top(const u32* __restrict__ lines, const u32* __restrict__ stop /*
     // per wave nearly every wave would wait for somebody: the wave's rounds, not the queries' reads, would set the time): it
     // is parked -- {query, lo, hi, next line} -- in the wave's queue and the wave reads on; whenever the queue holds a
     // wave-load of them they take a round of their own.
-    u32x4* Q = reinterpret_cast<u32x4*>(lds_dyn + 256 + STOP_ENTRIES / 2u) + wave * 64u;
+    u32x4* Q = reinterpret_cast<u32x4*>(lds_dyn + STOP_BASES + STOP_ENTRIES / 2u) + wave * 64u;
     u32 qcount = 0u;
-    auto entry_of = [&](u64 r, u32& lo, u32& hi, u32& fr) {
+    // the two entries around one number r: their lines (lo, hi: the bounds of the search) and the interpolated first guess g
+    auto entry_of = [&](u64 r, u32& lo, u32& hi, u32& g) {
         const u64 idx0 = r - 1u;
         const u32 m = (u32)(idx0 >> shift);
-        lo = base[m >> 8] + t16[m]; hi = base[(m + 1u) >> 8] + t16[m + 1u];
-        fr = (u32)(idx0 & ((1ull << shift) - 1u));
+        const u32 plo = base[m / STOP_GROUP] + t16[m], phi = base[(m + 1u) / STOP_GROUP] + t16[m + 1u];
+        lo = plo >> fb; hi = phi >> fb;
+        const u64 fr = idx0 & ((1ull << shift) - 1u);
+        // positions in half units: 2 plo + 1 (the middle of the entry's own unit) + the share of the distance
+        const u64 p2 = 2ull * plo + 1ull + ((2ull * (u64)(phi - plo) * fr) >> shift);
+        const u32 j = (u32)(p2 >> (fb + 1u));
+        g = j < lo ? lo : (j > hi ? hi : j);
     };
     auto retry_round = [&](u32 first, u32 n) {                       // entries first .. first + n - 1 of the queue, to the end
         const bool have = grp < n;
         const u32x4 e = Q[first + (have ? grp : 0u)];
         const u64 qi = e.x;
         const u64 r = have ? q[qi] : 1ull;
-        u32 lo0, hi0, fr;
-        entry_of(r, lo0, hi0, fr);
+        u32 lo0, hi0, g0;
+        entry_of(r, lo0, hi0, g0);
         u32 lo = e.y, hi = e.z, j = e.w;
         bool searching = have, failed = false;
         select_steps<LPQ>(lines, lo, hi, j, (u64)(hi0 - lo0) + 1u, shift, r, searching, failed, 1u, 64u, qi, lane, sub, pos);
@@ -1277,9 +1317,7 @@ void k_select_top(const u32* __restrict__ lines, const u32* __restrict__ stop /*
             live[u] = qi[u] < nq;
             r[u] = rn[u];
             ok[u] = live[u] && r[u] != 0ull && r[u] <= total;
-            u32 fr;
-            entry_of(ok[u] ? r[u] : 1ull, lo[u], hi[u], fr);
-            j[u] = lo[u] + (u32)(((u64)(hi[u] - lo[u]) * fr) >> shift);
+            entry_of(ok[u] ? r[u] : 1ull, lo[u], hi[u], j[u]);
             span[u] = (u64)(hi[u] - lo[u]) + 1u;
             searching[u] = ok[u]; failed[u] = false;
         }

@@ -32,64 +32,34 @@
 
 enum { AR_COUNT = 0, AR_STORE = 1 };
 
-// Round 6: the runs of a block are applied as a CHAIN.  One run [s, e] of a union used to cost four LDS atomics: its two edge words
-// into U, +1 behind the first and -1 at the last word in the difference array D.  The diagnostic build (profiles/r05_and_rows) put 23 %
-// of the kernel at 0.1 % on the bank conflicts of those atomics -- a CU's LDS serves ~16 M of them per launch at ~6 cycles each, about
-// as long as the kernel runs -- so the count is the lever.  In sparse data the 1-bit between two 0-runs sits INSIDE a word: the word in
-// which run t ends is the word in which run t + 1 starts.  Run t + 1 therefore applies run t's end edge together with its own start edge
-// (one atomicOr of the two masks), and the pair "-1 at this word, +1 at the next" of the difference array collapses into one BREAK: the
-// coverage of the chain dips at exactly this word.  X[w] = (D[w] << 16) + breaks[w] keeps both in the 8 KiB that D had (operand counts
-// <= 32,767 per list: the host checks); ar_fold: covered(w) = prefix(D)(w) - breaks[w] > 0.  Two atomics per run in the common case
-// instead of four; every other case -- the previous run ended in another word, one of the two lies inside one word, the first and the
-// last run of a block -- applies its edges and differences separately, as before.
-// r = lo16: the position BEFORE the run (0xFFFF for a run that starts the block: the 16-bit add wraps to 0) | hi16: its last position
-struct ArRun { u32 ws, we, ml, mh; };
-__device__ __forceinline__ ArRun ar_decode(u32 r)
+// one run [s, e] of a union: its edge words into U; the words between them through the difference array D (+1 behind the first,
+// -1 at the last: an adjacent pair of words nets to nothing, so no test for "longer than two words").  r = lo16: the position
+// BEFORE the run (0xFFFF for a run that starts the block: the 16-bit add wraps to 0) | hi16: its last position
+#ifdef BMX_DIAG
+// timing probes: 4 = the vector work without the LDS atomics (folded into a register), 8 = the atomics at conflict-free addresses
+__device__ __forceinline__ void ar_apply_run_diag(u32 r, bool valid, u32* U, int* D, int diag, u32 lane, u32& sink)
 {
     const u32 s = (u32)(u16)((u16)r + (u16)1u), e = r >> 16;
-    return ArRun{s >> 5, r >> 21, ~0u << (s & 31u), ~(~1u << (e & 31u))};
-}
-// the run `c` of a chain whose predecessor in the same block is `p` (has_p); last: no wanted run follows it in its block
-__device__ __forceinline__ void ar_apply_chain(const ArRun& c, bool valid, bool last, const ArRun& p, bool has_p, u32* U, int* X)
-{
-    const bool multi = c.ws != c.we;
-    const bool pm = valid && has_p && p.ws != p.we;                  // the run before spans words: its end edge is still open
-    const bool joined = pm && p.we == c.ws;
-    if (valid) atomicOr(&U[c.ws], (multi ? c.ml : (c.ml & c.mh)) | (joined ? p.mh : 0u));
-    if (pm && !joined) atomicOr(&U[p.we], p.mh);
-    if (joined && multi) atomicAdd(&X[c.ws], 1);                     // a break
-    else {
-        if (pm) atomicSub(&X[p.we], 65536);
-        if (valid && multi) atomicAdd(&X[c.ws + 1u], 65536);
+    u32 ws = s >> 5, we = r >> 21;
+    const u32 ml = ~0u << (s & 31u), mh = ~(~1u << (e & 31u));
+    const bool same = ws == we;
+    if (diag & 4) { if (valid) { sink ^= (same ? (ml & mh) : ml) + ws; if (!same) sink ^= mh + we; } return; }
+    if (valid) {
+        atomicOr(&U[lane], same ? (ml & mh) : ml);
+        if (!same) { atomicOr(&U[lane + 64u], mh); atomicAdd(&D[lane + 128u], 1); atomicSub(&D[lane + 192u], 1); }
     }
-    if (valid && last && multi) { atomicOr(&U[c.we], c.mh); atomicSub(&X[c.we], 65536); }
 }
-
-// interior words covered by a long run: prefix sum of the difference halves of X over the 2048 words, minus the word's breaks;
-// covered words become all ones.  X is left zeroed.  Called by the whole workgroup between barriers; sm: WG / 64 ints.
-template <int WG>
-__device__ __forceinline__ void ar_fold(u32* U, int* X, int* sm, u32 tid)
+#endif
+__device__ __forceinline__ void ar_apply_run(u32 r, bool valid, u32* U, int* D)
 {
-    constexpr u32 W = 2048u / WG;
-    const u32 lane = tid & 63u, wave = tid >> 6;
-    int d[W]; int sum = 0;
-#pragma unroll
-    for (u32 k = 0; k < W; k += 4u) {
-        u32x4 t = *reinterpret_cast<u32x4*>(&X[tid * W + k]);
-        d[k] = (int)t.x; d[k + 1] = (int)t.y; d[k + 2] = (int)t.z; d[k + 3] = (int)t.w;
-        *reinterpret_cast<u32x4*>(&X[tid * W + k]) = (u32x4)(0u);
+    const u32 s = (u32)(u16)((u16)r + (u16)1u), e = r >> 16;
+    const u32 ws = s >> 5, we = r >> 21;
+    const u32 ml = ~0u << (s & 31u), mh = ~(~1u << (e & 31u));
+    const bool same = ws == we;
+    if (valid) {
+        atomicOr(&U[ws], same ? (ml & mh) : ml);
+        if (!same) { atomicOr(&U[we], mh); atomicAdd(&D[ws + 1u], 1); atomicSub(&D[we], 1); }
     }
-#pragma unroll
-    for (u32 k = 0; k < W; ++k) sum += d[k] >> 16;                   // (arithmetic: the low half is a non-negative count, it never borrows)
-    int incl = (int)wave_scan_incl((u32)sum, lane);
-    if (lane == 63) sm[wave] = incl;
-    __syncthreads();
-    int running = incl - sum;
-#pragma unroll
-    for (u32 i = 0; i < WG / 64u; ++i) if (i < wave) running += sm[i];
-#pragma unroll
-    for (u32 k = 0; k < W; ++k) { running += d[k] >> 16; if (running - (d[k] & 0xFFFF) > 0) U[tid * W + k] = ~0u; }
-    __syncthreads();
 }
 
 // union of the runs of value `want` of the n GAP operands whose row entries sit at list_back[0], list_back[-1], ...
@@ -150,7 +120,7 @@ __device__ __forceinline__ void ar_union_list(const u64* __restrict__ list_back,
         };
 #pragma unroll
         for (int k = 0; k < DEPTH; ++k) issue(k);
-        u32 carry = 0u, carry_r = 0u;
+        u32 carry = 0u;
         for (u32 q0 = 0; q0 < npieces; q0 += (u32)DEPTH) {
 #pragma unroll
             for (int k = 0; k < DEPTH; ++k) {
@@ -170,20 +140,20 @@ __device__ __forceinline__ void ar_union_list(const u64* __restrict__ list_back,
                     const int lim0 = (ci == 0u && !odd) ? -1 : lim;
 #ifdef BMX_DIAG
                     if (diag & 1) { if ((d[0] ^ d[1] ^ d[2] ^ d[3] ^ d[4] ^ sel ^ (u32)lim0) == 0x12345679u) U[lane] = 1u; }    // timing probe: the loads alone
-                    else
+                    else if (diag & 12) {
+                        u32 sink = 0u;
+                        ar_apply_run_diag(__builtin_amdgcn_perm(d[1], d[0], sel), lim0 >= 0, U, D, diag, lane, sink);
+                        ar_apply_run_diag(__builtin_amdgcn_perm(d[2], d[1], sel), lim >= 2, U, D, diag, lane, sink);
+                        ar_apply_run_diag(__builtin_amdgcn_perm(d[3], d[2], sel), lim >= 4, U, D, diag, lane, sink);
+                        ar_apply_run_diag(__builtin_amdgcn_perm(d[4], d[3], sel), lim >= 6, U, D, diag, lane, sink);
+                        if (sink == 0x12345679u) U[lane] = 1u;
+                    } else
 #endif
                     {
-                        const u32 r0 = __builtin_amdgcn_perm(d[1], d[0], sel), r1 = __builtin_amdgcn_perm(d[2], d[1], sel);
-                        const u32 r2 = __builtin_amdgcn_perm(d[3], d[2], sel), r3 = __builtin_amdgcn_perm(d[4], d[3], sel);
-                        // the run before this lane's first: the last run of the lane before (chunk ci - 1 of the same block when ci >= 1)
-                        const u32 rp = (u32)__builtin_amdgcn_update_dpp((int)carry_r, (int)r3, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
-                        carry_r = (u32)__builtin_amdgcn_readlane((int)r3, 63);
-                        const ArRun a0 = ar_decode(r0), a1 = ar_decode(r1), a2 = ar_decode(r2), a3 = ar_decode(r3), ap = ar_decode(rp);
-                        const bool in = ci != 0u;                          // (a block's first wanted run -- kk = 1 or 2 -- has no predecessor)
-                        ar_apply_chain(a0, lim0 >= 0, lim0 >= 0 && lim <= 1, ap, in, U, D);
-                        ar_apply_chain(a1, lim >= 2, lim >= 2 && lim <= 3, a0, in || odd, U, D);
-                        ar_apply_chain(a2, lim >= 4, lim >= 4 && lim <= 5, a1, true, U, D);
-                        ar_apply_chain(a3, lim >= 6, lim >= 6 && lim <= 7, a2, true, U, D);
+                        ar_apply_run(__builtin_amdgcn_perm(d[1], d[0], sel), lim0 >= 0, U, D);
+                        ar_apply_run(__builtin_amdgcn_perm(d[2], d[1], sel), lim >= 2, U, D);
+                        ar_apply_run(__builtin_amdgcn_perm(d[3], d[2], sel), lim >= 4, U, D);
+                        ar_apply_run(__builtin_amdgcn_perm(d[4], d[3], sel), lim >= 6, U, D);
                     }
                 }
                 issue(k);
@@ -229,7 +199,7 @@ __device__ __forceinline__ void ar_item(u32 item, u32* U, int* D, int* sm, u32* 
     if (diag & 2) return;                                      // timing probe: no fold, no count
 #endif
     __syncthreads();
-    if (nga) ar_fold<WG>(U, D, sm, tid);                       // (block-uniform; the barriers inside are reached by every thread)
+    if (nga) coll_fold<WG>(U, D, sm, tid);                     // (block-uniform; the barriers inside are reached by every thread)
     // ... complemented: the accumulator
     u32 acc[W];
 #pragma unroll
@@ -242,7 +212,7 @@ __device__ __forceinline__ void ar_item(u32 item, u32* U, int* D, int* sm, u32* 
         __syncthreads();
         ar_union_list<WG, DEPTH, NT>(row + 2 + na + ns - 1u, ngs, 1u, U, D, lane, wave, dummy, diag);
         __syncthreads();
-        ar_fold<WG>(U, D, sm, tid);
+        coll_fold<WG>(U, D, sm, tid);
 #pragma unroll
         for (u32 k = 0; k < W; ++k) acc[k] &= ~U[tid * W + k];
     }

@@ -1530,6 +1530,33 @@ def test_select_lines_16_bit_form(port, dq, nblk):
     c.close()
 
 
+@pytest.mark.parametrize("dq,nblk,uneven", [(32768, 300, False), (20000, 150, True), (6554, 400, False)])
+def test_select_top_position_exact_summary(port, dq, nblk, uneven):
+    """k_select_top with the round-6 summary (an entry = the position of its sampled one to 1 / 2^fb of a line, bases per 64 entries):
+    dense vectors, which the select lines do not cover; an uneven vector (a stretch of empty blocks in the middle: the groups' spread
+    decides fb); every answer against the oracle -- the headers decide, the summary only guesses"""
+    c = bm.context(0)
+    c.set_tuning("rs_select_sel", 0); c.set_tuning("rs_lines", 2); c.set_tuning("rs_select_top", 1)
+    nbits = nblk * 65536 - 1234
+    words = port.gen_words(4321 + dq, 9, dq, nbits)
+    if uneven: words[40 * 2048:110 * 2048] = 0
+    p = port.import_words(words, True, nbits)
+    v = bm.bvector.from_block_table(c, nbits, *p.flatten())
+    rs, prs = v.build_rs_index(), port.rs_build(p)
+    cnt = p.count()
+    rng = np.random.default_rng(dq)
+    for nq in (1, 63, 5000, 300000):
+        r = np.concatenate([rng.integers(1, cnt + 1, size=nq).astype(np.uint64), np.array([1, cnt, 0, cnt + 1], np.uint64)])
+        found, pos = v.select(r, rs)
+        ppos, pfound = prs.select(r)
+        assert (found == pfound).all() and (pos[found] == ppos[pfound]).all() and (pos[~found] == 0).all(), (dq, nq)
+    allr = np.arange(1, cnt + 1, dtype=np.uint64)[:: max(1, cnt // 250000)]
+    found, pos = v.select(allr, rs)
+    assert found.all() and (pos == prs.select(allr)[0]).all()
+    del rs, v
+    c.close()
+
+
 def _sparse_collection(port, rng, nvec, nbits, dq, long_runs=False, ragged=False, specials=True):
     """GAP-only operands (no bit-blocks): sparse noise OR a shared component (so that ANDs survive), optionally wide
     1-runs (multi-word intervals), NULL / FULL blocks and operands shorter than the others"""

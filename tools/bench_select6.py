@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Round 6: select through the select lines (k_select_sel, bmx_kernels11.h: one 128-byte line per query, no search) next to the
 round-5 kernel (k_select_top: directory summary in LDS, interpolated guess verified by the line header) and rank, on the configs[3]
-vector (4e9 bits) at 10 % / 1 % / 0.1 % -- one JSON line per (density, batch).  Also what build_rs_index costs with and without the
+vector (4e9 bits) at 10 % / 1 % / 0.1 % and at 50 % (too dense for select lines under the memory policy: the `select_lines` column is then
+k_select_top with its round-6 position-exact summary) -- one JSON line per (density, batch).  Also what build_rs_index costs with and without the
 select lines and what the index holds."""
 import json, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -11,7 +12,7 @@ from bitmagic_amd import _ffi
 L = _ffi.lib()
 s = torch.cuda.Stream(); torch.cuda.set_stream(s)
 ctx = bm.context(0, s.cuda_stream)
-dens = [int(x) for x in (sys.argv[1].split(",") if len(sys.argv) > 1 else ("6554", "655", "66"))]
+dens = [int(x) for x in (sys.argv[1].split(",") if len(sys.argv) > 1 else ("6554", "655", "66", "32768"))]
 batches = [int(x) for x in (sys.argv[2].split(",") if len(sys.argv) > 2 else ("100000", "1000000", "10000000", "100000000"))]
 def avg(fn, n=5):
     fn(); ctx.synchronize(); ctx.timer_start()
