@@ -64,6 +64,7 @@ timeout 600 python tools/bench_and_rows.py > $O/and_rows_shapes.jsonl 2>> $O/err
 timeout 900 python tools/soak_r05.py 200 > $O/soak_r05.txt 2>&1
 ( export BMX_DEBUG_REDZONE=1; timeout 1200 python -m pytest tests -q -m gpu > $O/pytest_redzone.txt 2>&1; timeout 900 python tools/soak_r05.py 120 > $O/soak_r05_redzone.txt 2>&1; timeout 900 python tools/soak_r04.py 40 > $O/soak_r04_redzone.txt 2>&1 )
 timeout 900 python tools/soak_r04.py 40 > $O/soak_r04.txt 2>&1
+timeout 900 python tools/soak_r06.py 60 > $O/soak_r06.txt 2>&1
 # rocprofv3 --stats of the bench commands
 stats_of bench $B --no-cpu --no-others --no-shard-probe
 stats_of config1 $B --config 1 --no-cpu
@@ -86,7 +87,7 @@ pmc_of $O/pmc_dq66.txt "k_agg_and_rows" -- $B --density-q16 66 --no-prepare --no
 # summary LAST, from this pass's files only
 cat $O/rc.txt > $O/summary.txt
 grep -E "passed|failed" $O/pytest.txt >> $O/summary.txt; cat $O/pytest_time.txt $O/bench_time.txt | grep real >> $O/summary.txt
-tail -2 $O/soak_r05.txt >> $O/summary.txt; tail -1 $O/soak_r04.txt >> $O/summary.txt
+tail -2 $O/soak_r05.txt >> $O/summary.txt; tail -1 $O/soak_r04.txt >> $O/summary.txt; tail -2 $O/soak_r06.txt >> $O/summary.txt
 echo "red zones (BMX_DEBUG_REDZONE=1): $(grep -E "passed|failed" $O/pytest_redzone.txt | tail -1); reports: $(cat $O/pytest_redzone.txt $O/soak_r05_redzone.txt $O/soak_r04_redzone.txt | grep -c "bmx redzone"); $(tail -1 $O/soak_r05_redzone.txt); $(tail -1 $O/soak_r04_redzone.txt)" >> $O/summary.txt
 python - <<PY >> $O/summary.txt
 import json, glob, os
