@@ -17,10 +17,17 @@ import csv, sys, collections
 acc = collections.defaultdict(list)
 try:
     for r in csv.DictReader(open(sys.argv[1])):
-        if any(k in r["Kernel_Name"] for k in sys.argv[2].split("|")): acc[(r["Kernel_Name"][:48], r["Counter_Name"])].append(float(r["Counter_Value"]))
+        if any(k in r["Kernel_Name"] for k in sys.argv[2].split("|")): acc[(r["Kernel_Name"][:48], r["Counter_Name"], int(r.get("Grid_Size", 0) or 0))].append(float(r["Counter_Value"]))
 except Exception as e:
     print("pmc pass failed:", e)
-for k, v in sorted(acc.items()): print(k[0], k[1], "per launch avg", sum(v) / len(v), "launches", len(v))
+# one line per (kernel, counter) over the launches of its LARGEST grid (the full-size calls: a run also launches a kernel on small
+# batches / subsets, which must not dilute the per-launch figure); the other launch shapes follow as "# shape" lines
+big = {}
+for (k, c, g), v in acc.items():
+    if (k, c) not in big or g > big[(k, c)][0]: big[(k, c)] = (g, v)
+for (k, c), (g, v) in sorted(big.items()): print(k, c, "per launch avg", sum(v) / len(v), "launches", len(v))
+for (k, c, g), v in sorted(acc.items()):
+    if big[(k, c)][0] != g: print("# shape", k, c, "grid", g, "avg", sum(v) / len(v), "launches", len(v))
 PY
   done
 }
