@@ -105,8 +105,11 @@ __global__ void k_rows_var(const u64* __restrict__ bases, u32 nstreams, u32 npie
             const u32 h = ((s + d * W) * 2654435761u) ^ (piece * 40503u);
             // byte offset of the row inside the stream.  jitter 1: a 4-byte phase (0 .. 12); 2: a 16-byte phase (0 .. 112: today's rows start
             // on any 16-byte boundary); 3: 2 + the row's length varies by -32 .. +32 bytes (blocks of 48 / 64 / 80 bytes)
-            const u64 start = (u64)piece * S + (jitter == 1u ? ((h >> 7) & 3u) * 4u : jitter >= 2u ? ((h >> 7) & 7u) * 16u : 0u);
-            const u32 Pv = jitter == 3u ? P + ((h >> 12) % 5u) * 16u - 32u : P;
+            // jitter 5: TILE-ALIGNED rows -- every row starts on a 128-byte line, its length varies by -32 .. +32 bytes and two rows in five
+            // take another line (strides of 896 and 1024 bytes alternate): what padding the slab at tile boundaries would give
+            const u64 start = jitter == 5u ? (u64)piece * S + 128ull * ((2u * piece) / 5u)
+                                           : (u64)piece * S + (jitter == 1u ? ((h >> 7) & 3u) * 4u : jitter >= 2u ? ((h >> 7) & 7u) * 16u : 0u);
+            const u32 Pv = (jitter == 3u || jitter == 5u) ? P + ((h >> 12) % 5u) * 16u - 32u : P;
             const u64 first = mode == 0 ? (start & ~15ull) : start;
             const u64 end = start + Pv;
             const u64 a = first + lane * 16u;
@@ -152,7 +155,7 @@ int main(int argc, char** argv)
     u64* d_bases; CHK(hipMalloc(&d_bases, (size_t)nstreams * 8));
     if (argc > 6) {                                      // argv[6] = "rows": the round-6 question (see k_rows_var)
         std::vector<void*> owned; std::vector<u64> bases(nstreams);
-        const u64 alloc_bytes = ((stream_bytes / 784u + 2u) * 1024u + (2u << 20)) / (2u << 20) * (2u << 20);     // (rows of up to 1 KiB)
+        const u64 alloc_bytes = ((stream_bytes / 784u + 2u) * 1100u + (2u << 20)) / (2u << 20) * (2u << 20);     // (rows of up to 1 KiB)
         for (u32 s = 0; s < nstreams; ++s) { void* p; CHK(hipMalloc(&p, alloc_bytes)); owned.push_back(p); bases[s] = (u64)(uintptr_t)p;
             hipLaunchKernelGGL(k_fill_random, dim3(256), dim3(256), 0, st, (u64*)p, alloc_bytes / 8, (u64)(uintptr_t)p); }
         CHK(hipMemcpy(d_bases, bases.data(), (size_t)nstreams * 8, hipMemcpyHostToDevice));
@@ -171,6 +174,9 @@ int main(int argc, char** argv)
                         {896, 256, 0, "XCD-contiguous rows: stride 1024, 896 B loaded", 1024, 896}, {896, 256, 0, "XCD-contiguous rows: stride 960, 896 B loaded", 960, 896},
                         {832, 256, 0, "XCD-contiguous rows: stride 832, 832 B loaded (13 columns)", 832, 832}, {960, 256, 0, "XCD-contiguous rows: stride 960, 960 B loaded (15 columns)", 960, 960},
                         {1024, 256, 0, "XCD-contiguous rows: stride 1024, 1024 B loaded (16 columns)", 1024, 1024}, {784, 256, 1, "XCD-contiguous rows: 4-byte grid, rows of 784 B", 784, 784},
+                        {896, 256, 5, "XCD-contiguous rows: TILE-ALIGNED slab -- rows of 864 .. 928 B, each starting on a 128-byte line (strides 896 / 1024)", 896, 896},
+                        {896, 256, 3, "XCD-contiguous rows: today (again, next to the line above)", 896, 896},
+                        {896, 256, 5, "XCD-contiguous rows: TILE-ALIGNED slab (again)", 896, 896},
                         {640, 0, 0, "sweep"}, {704, 0, 0, "sweep"}, {768, 0, 0, "sweep"}, {832, 0, 0, "sweep"}, {960, 0, 0, "sweep"},
                         {1024, 0, 0, "1-KiB pieces (the round-4 probe's shape)"}};
         for (int depth : {4}) for (const V& v : vs) for (int rep2 = 0; rep2 < 2; ++rep2) {
