@@ -75,6 +75,18 @@ public:
     rs_index(const rs_index&) = delete;
     rs_index& operator=(const rs_index&) = delete;
     size_type count() const { uint64_t c = 0; if (h_) check(bmx_rs_count(h_, &c)); return c; }
+    /// what the index holds on the device: total bytes, whether the vector was laid out as rank lines (one line per rank query) and
+    /// as select lines (offset width 16 | 32, 0 = none: select then searches the rank lines' directory or the block tables)
+    struct device_layout { uint64_t bytes = 0; bool rank_lines = false; int select_offset_bits = 0; uint64_t select_lines_bytes = 0; };
+    device_layout layout() const
+    {
+        device_layout l;
+        if (!h_) return l;
+        int has = 0;
+        check(bmx_rs_info(h_, &l.bytes, &has)); l.rank_lines = has != 0;
+        check(bmx_rs_select_format(h_, &l.select_offset_bits, &l.select_lines_bytes));
+        return l;
+    }
     /// bcount[nb] and sub_count[nb] = first | second<<16 | aux0<<32 | aux1<<48 (src/bm.h:2646-2656)
     void export_blocks(std::vector<uint32_t>& bcount, std::vector<uint64_t>& sub_count, uint32_t nblocks) const
     {

@@ -152,6 +152,12 @@ int main()
     }
     uint64_t dummy;
     REQUIRE(!gv[5].select(0, dummy, rs) && !gv[5].select(rs.count() + 1, dummy, rs));
+    {   // round 6: what the index holds on the device (bmx_rs_info + bmx_rs_select_format through the facade)
+        const bmx::rs_index::device_layout l = rs.layout();
+        REQUIRE(l.bytes > 0 && (l.select_offset_bits == 0 || l.select_offset_bits == 16 || l.select_offset_bits == 32));
+        REQUIRE((l.select_offset_bits == 0) == (l.select_lines_bytes == 0));
+        if (l.select_offset_bits) REQUIRE(l.select_lines_bytes == (rs.count() + (l.select_offset_bits == 16 ? 59 : 29)) / (l.select_offset_bits == 16 ? 60 : 30) * 128);
+    }
     bmo_rs_free(prs);
     for (unsigned v = 0; v < NV; ++v) bmo_vec_free(pv[v]);
     std::printf("test_facade ok\n");
