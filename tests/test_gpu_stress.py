@@ -321,10 +321,10 @@ def test_result_memory_is_what_the_result_holds(ctx, port):
 def test_randomized_soak_slices():
     """the randomized differential soaks (tools/soak_r04.py parts A-E: row kernel, collection members, long
     mixed pairwise operations, search limits, asynchronous chains; tools/soak_r05.py parts F-G: the AND rows kernel, per-group
-    search limits) ran only under the builder's gpurun.  A bounded slice of each, fixed seeds, runs here: about a minute."""
+    search limits; round 6: tools/soak_r06.py parts H-I: select lines, the search limit on the asynchronous counts entry) ran only under the builder's gpurun.  A bounded slice of each, fixed seeds, runs here: about a minute."""
     import subprocess, sys, os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for script, rounds in (("soak_r04.py", "4"), ("soak_r05.py", "14")):
+    for script, rounds in (("soak_r04.py", "4"), ("soak_r05.py", "14"), ("soak_r06.py", "8")):
         r = subprocess.run([sys.executable, os.path.join(root, "tools", script), rounds], capture_output=True, text=True, timeout=900, cwd=root)
         tail = (r.stdout + r.stderr)[-2000:]
         assert r.returncode == 0 and "done, failures: 0" in r.stdout, (script, tail)
