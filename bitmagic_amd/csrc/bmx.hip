@@ -879,7 +879,7 @@ int bmx_ctx_create(int device, void* stream, bmx_ctx** out)
     CTXCHK(hipMemsetAsync(ctx->d_slots2, 0, COUNT_SLOTS * COUNT_SLOT_STRIDE * sizeof(u64), ctx->stream));
     CTXCHK(hipMalloc((void**)&ctx->d_done2, FOLD_DONE_WORDS * 4));
     CTXCHK(hipMemsetAsync(ctx->d_done2, 0, FOLD_DONE_WORDS * 4, ctx->stream));
-    CTXCHK(hipHostMalloc((void**)&ctx->h_pend, 64 * 8 * sizeof(u64)));
+    CTXCHK(hipHostMalloc((void**)&ctx->h_pend, PEND_SLOTS * 8 * sizeof(u64)));
     CTXCHK(hipMalloc((void**)&ctx->d_cursor, 64));
     CTXCHK(hipMemsetAsync(ctx->d_cursor, 0, 64, ctx->stream));
 #undef CTXCHK
@@ -2525,8 +2525,8 @@ int bmx_op2_dev(bmx_ctx* ctx, int op, const bmx_vec* a, const bmx_pending* pa, c
     const uint64_t nbits = std::max(va->nbits, vb->nbits);
     if (nblocks > 2000000u) { g_last_error = "bmx_op2_dev: more than 2,000,000 blocks (the in-kernel fold of the kind counts holds 64 x 65,535): use bmx_op2"; return BMX_ERR_RANGE; }
     int slot = -1;
-    for (int i = 0; i < 64; ++i) if (!(ctx->pend_used >> i & 1ull)) { slot = i; break; }
-    if (slot < 0) { g_last_error = "bmx_op2_dev: 64 unresolved results are outstanding (bmx_pending_wait / bmx_pending_free them)"; return BMX_ERR_RANGE; }
+    for (int i = 0; i < PEND_SLOTS; ++i) if (!(ctx->pend_used[i >> 6] >> (i & 63) & 1ull)) { slot = i; break; }
+    if (slot < 0) { g_last_error = "bmx_op2_dev: 1,024 unresolved results are outstanding (bmx_pending_wait / bmx_pending_free them)"; return BMX_ERR_RANGE; }
     bmx_pending* p = new (std::nothrow) bmx_pending();
     if (!p) return BMX_ERR_BADALLOC;
     p->ctx = ctx; p->v = nullptr; p->slot = slot; p->ev = nullptr; p->gap_bound = 0; p->scratch = nullptr; p->resolved = false;
@@ -2553,7 +2553,7 @@ int bmx_op2_dev(bmx_ctx* ctx, int op, const bmx_vec* a, const bmx_pending* pa, c
         if (ee == hipSuccess) ee = hipEventRecord(p->ev, ctx->stream);
         if (ee != hipSuccess) { bmx_vec_free(ctx, c); delete p; return fail_hip(ee, "bmx_op2_dev (alias)", __LINE__); }
         p->v = c; p->resolved = true; p->gap_bound = c->d_gaps ? c->gap_words : 0;
-        ctx->pend_used |= 1ull << slot;
+        ctx->pend_used[slot >> 6] |= 1ull << (slot & 63);
         *out = p;
         return BMX_OK;
     }
@@ -2601,7 +2601,7 @@ int bmx_op2_dev(bmx_ctx* ctx, int op, const bmx_vec* a, const bmx_pending* pa, c
     }
     if (e == hipSuccess) e = hipEventRecord(p->ev, ctx->stream);
     if (e != hipSuccess) { (void)hipStreamSynchronize(ctx->stream); (void)hipEventDestroy(p->ev); dfree(ctx, p->scratch); bmx_vec_free(ctx, v); delete p; return fail_hip(e, "bmx_op2_dev", __LINE__); }
-    ctx->pend_used |= 1ull << slot;
+    ctx->pend_used[slot >> 6] |= 1ull << (slot & 63);
     p->v = v;
     *out = p;
     return BMX_OK;
@@ -2615,7 +2615,7 @@ int bmx_pending_wait(bmx_ctx* ctx, bmx_pending* p, bmx_vec** out)
     HIPCHK(hipEventSynchronize(p->ev));
     bmx_vec* v = p->v;
     if (p->resolved) {
-        ctx->pend_used &= ~(1ull << p->slot);
+        ctx->pend_used[p->slot >> 6] &= ~(1ull << (p->slot & 63));
         (void)hipEventDestroy(p->ev);
         p->v = nullptr;
         delete p;
@@ -2628,7 +2628,7 @@ int bmx_pending_wait(bmx_ctx* ctx, bmx_pending* p, bmx_vec** out)
     const uint64_t used = hs[4] & 0xFFFFFFFFFFull, ncand = hs[4] >> 40, bound = p->gap_bound;
     const bool ok = (uint64_t)v->counts[0] + v->counts[1] + v->counts[2] + v->counts[3] == nblocks && ncand == v->counts[BMX_GAP] &&
                     used <= bound && (used == 0) == (ncand == 0);
-    ctx->pend_used &= ~(1ull << p->slot);
+    ctx->pend_used[p->slot >> 6] &= ~(1ull << (p->slot & 63));
     (void)hipEventDestroy(p->ev);
     dfree(ctx, p->scratch);                                           // (the kernel that wrote it ran before the event)
     p->v = nullptr;
@@ -2665,7 +2665,7 @@ int bmx_pending_free(bmx_ctx* ctx, bmx_pending* p)
     ARGCHK(ctx && p->ctx == ctx);
     (void)hipEventSynchronize(p->ev);
     (void)hipEventDestroy(p->ev);
-    ctx->pend_used &= ~(1ull << p->slot);
+    ctx->pend_used[p->slot >> 6] &= ~(1ull << (p->slot & 63));
     dfree(ctx, p->scratch);
     int rc = p->v ? bmx_vec_free(ctx, p->v) : BMX_OK;
     delete p;

@@ -22,6 +22,7 @@ void bmx_set_last_error(const char* msg);
 #define HIPCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return bmx_fail_hip(e_, #call, __FILE__, __LINE__); } while (0)
 #define ARGCHK(cond) do { if (!(cond)) { bmx_set_last_error("bad argument: " #cond); return BMX_ERR_BADARG; } } while (0)
 #define KCHK() HIPCHK(hipGetLastError())
+#define PEND_SLOTS 1024
 // the exception barrier around every extern "C" body: { ABI_TRY ... ABI_END }  (bmx.hip: bmx_abi_caught)
 #include <new>
 #include <stdexcept>
@@ -42,7 +43,7 @@ struct bmx_ctx {
     u64* d_small = nullptr;                                 // 64 x u64 result words
     u64* d_slots = nullptr;                                 // COUNT_SLOTS striped count accumulators (kept zero between launches)
     u64* d_slots2 = nullptr; u32* d_done2 = nullptr;        // a second fold (slots + tickets) for kernels that fold block kinds AND a count
-    u64* h_pend = nullptr; uint64_t pend_used = 0;         // 64 pinned slots (8 x u64) for the kind counts of unresolved asynchronous results
+    u64* h_pend = nullptr; uint64_t pend_used[16] = {};    // PEND_SLOTS = 1,024 pinned slots (8 x u64) for the kind counts of unresolved asynchronous results (round 6: 64 before)
     u64* d_cursor = nullptr;                                // bump cursor of kernels that write GAP results themselves (k_op2_loop); zero between launches
     u64* d_zero = nullptr;                                  // 256 bytes of zeros: what an invalid slot of an unconditional load reads
     u32* d_done = nullptr;                                  // workgroup ticket of the in-kernel folds (kept zero between launches)

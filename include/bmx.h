@@ -164,7 +164,7 @@ int bmx_op2_count(bmx_ctx* ctx, int op, const bmx_vec* a, const bmx_vec* b, int 
  * (an unresolved x is waited for), x ^ x and x - x are empty.
  *   bmx_pending_wait   waits for THIS result only, turns it into an ordinary vector (*out; the handle is consumed)
  *   bmx_pending_free   drops an unresolved result (it may still be an operand of operations enqueued earlier)
- * At most 64 unresolved results per context and 2,000,000 blocks (1.3e11 bits) per operand (BMX_ERR_RANGE).  bmx_pending is a handle type of its own: no other entry point
+ * At most 1,024 unresolved results per context (round 6; 64 before) and 2,000,000 blocks (1.3e11 bits) per operand (BMX_ERR_RANGE).  bmx_pending is a handle type of its own: no other entry point
  * accepts one, so a vector whose kind counts are not known yet can never reach a dispatch decision. */
 int bmx_op2_dev(bmx_ctx* ctx, int op, const bmx_vec* a, const bmx_pending* pa, const bmx_vec* b, const bmx_pending* pb,
                 bmx_pending** out);
